@@ -1,0 +1,202 @@
+/* mmf_amd.h — C ABI of libmmf_amd.so: the MI355X (gfx950 / CDNA4) kernels behind MMF's cross-modal
+ * transformer fusion hot path (VisualBERT first).
+ *
+ * The reference (facebookresearch/mmf) has no FFI on this path: every operation below is, there, a
+ * stock ATen call issued from Python (`nn.Linear`, `torch.matmul`, `softmax`, `nn.LayerNorm`,
+ * `nn.Dropout`, `nn.Embedding`, autograd).  Each entry point cites the reference call site it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding and the
+ * `torch.autograd.Function` / `nn.Module` mirror that a reference maintainer would register through
+ * `mmf.common.registry`.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless the name ends in `_host`;
+ *   - `stream` is a `hipStream_t` passed as `void*`; every call only ENQUEUES work on it (no host
+ *     sync, no allocation) so the whole step can be captured in a hipGraph;
+ *   - "bf16" buffers are IEEE bfloat16 (upper 16 bits of fp32, round-to-nearest-even);
+ *   - return 0 on success, non-zero on error; `mmf_amd_last_error()` returns the message;
+ *   - matrices are row-major with an explicit leading dimension (`ld*`, in elements).
+ */
+#ifndef MMF_AMD_H
+#define MMF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMF_AMD_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------------ */
+int mmf_amd_abi_version(void);
+const char* mmf_amd_last_error(void);
+/* Name of the gfx target the device code was compiled for ("gfx950"). */
+const char* mmf_amd_target(void);
+
+/* ---- GEMM with fused epilogue ----------------------------------------------------------------
+ * C[m][n] = epilogue( sum_k A(m,k) * B(n,k) ), bf16 MFMA, fp32 accumulate.
+ *   a_kmajor = 0: A(m,k) = A[m*lda + k]      a_kmajor = 1: A(m,k) = A[k*lda + m]
+ *   b_kmajor = 0: B(n,k) = B[n*ldb + k]      b_kmajor = 1: B(n,k) = B[k*ldb + n]
+ * Replaces: nn.Linear forward  (mmf/modules/hf_layers.py:169,179-180; HF BertSelfOutput /
+ * BertIntermediate / BertOutput at hf_layers.py:248,289,290; mmf/modules/embeddings.py:352;
+ * mmf/models/visual_bert.py:401), and its autograd dgrad (a=0,b=1) / wgrad (a=1,b=1)
+ * (mmf/trainers/core/training_loop.py:211).
+ * Epilogue, in this order, on v = acc:
+ *   v += bias[n]; v += coladd[n]; v += rowtab[rowidx[m]*rowtab_ld + n];
+ *   act==1: U[m][n] = v (if U), v = gelu_erf(v)        (HF BertIntermediate)
+ *   act==2: v *= gelu_erf'(aux[m][n])                  (backward of the above)
+ *   dropout(v) with (drop_key, drop_thr16, drop_scale), element index m*N+n
+ *   v += resid[m][n]                                   (HF BertSelfOutput / BertOutput residual)
+ *   out_f32 ? C = v + beta*C (float) : C = bf16(v)
+ * Output rows can be remapped: row = m + (m / grp_in) * grp_pad + grp_off when grp_in > 0
+ * (writes the visual rows of the joint [B, T+R, H] sequence, embeddings.py:447-451).
+ * Constraints: lda, ldb multiples of 8; a row operand is read in 8-element chunks along K, so its
+ * leading dimension must cover round_up(K, 8) and the padding must be finite (zeros); a k-major
+ * operand must be readable up to round_up(rows, 8) columns; fp32 operands
+ * (a_f32 / b_f32) are converted to bf16 on the fly (at most one of the two).
+ */
+typedef struct mmf_gemm_desc {
+    const void* A;
+    const void* B;
+    void* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int a_kmajor, b_kmajor;
+    int a_f32, b_f32, out_f32;
+    float beta;
+    const float* bias;
+    const float* coladd;
+    const float* rowtab;
+    const int64_t* rowidx;
+    int rowtab_ld;
+    int act;
+    void* U;
+    const void* aux;
+    const void* resid;
+    int ldr;
+    uint32_t drop_key;
+    uint32_t drop_thr16;
+    float drop_scale;
+    int grp_in, grp_pad, grp_off;
+} mmf_gemm_desc;
+int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
+
+/* ---- fused multi-head attention -------------------------------------------------------------
+ * Replaces BertSelfAttentionJit.forward, mmf/modules/hf_layers.py:161-213 (scores = QK^T /
+ * sqrt(d) + mask; softmax; dropout; PV; head merge) without materialising the [B,A,S,S] tensors,
+ * and its autograd backward.  head_dim is 64.  q/k/v/ctx are token-major: element (b, s, head, e)
+ * at ptr[(b*S + s)*ld + head*64 + e]  (for the packed QKV projection output: q = qkv, k = qkv+H,
+ * v = qkv+2H, ld = 3H).  `mask` is the ADDITIVE key mask of visual_bert.py:94-106, shape [B, Sk]
+ * fp32 (0 or -10000), or NULL.  lse[b][head][s] = log-sum-exp of the masked, scaled scores row.
+ * Dropout element index: ((b*heads + head)*Sq + q)*Sk_pad + key with Sk_pad = round_up(Sk, 32).
+ */
+typedef struct mmf_attn_desc {
+    const void* q;
+    const void* k;
+    const void* v;
+    int ldq, ldk, ldv;
+    const float* mask;
+    void* ctx;
+    int ldo;
+    float* lse;
+    int B, heads, Sq, Sk;
+    float scale;
+    uint32_t drop_key;
+    uint32_t drop_thr16;
+    float drop_scale;
+} mmf_attn_desc;
+int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
+
+typedef struct mmf_attn_bwd_desc {
+    mmf_attn_desc f;   /* forward operands (ctx = forward output O, lse = saved) */
+    const void* dctx;  /* bf16, same layout as ctx (ldo) */
+    void* dq;
+    void* dk;
+    void* dv;          /* bf16, layouts ldq / ldk / ldv like q / k / v */
+    float* delta;      /* workspace [B, heads, Sq] fp32 */
+} mmf_attn_bwd_desc;
+int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream);
+
+/* ---- LayerNorm ------------------------------------------------------------------------------
+ * y = (x - mean) * rstd * gamma + beta over the last dim H (eps inside the sqrt), fp32 statistics.
+ * Replaces nn.LayerNorm(H, eps=1e-12) in HF BertSelfOutput / BertOutput / BertEmbeddings
+ * (call sites hf_layers.py:248,290; embeddings.py:456) and BertPredictionHeadTransform
+ * (visual_bert.py:328).  x, y bf16 [rows, H]; mean, rstd fp32 [rows] (saved for backward).
+ * H % 4 == 0, H <= 2048.
+ */
+int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int rows, int H, float eps, void* stream);
+/* Backward.  dy, x bf16 [rows,H] -> dx bf16 (grad w.r.t. the pre-LN sum; this is also the gradient
+ * of the residual branch).  If dlin != NULL it receives dropout_backward(dx) with the forward's
+ * dropout config, element index row*H + col (the gradient of the Linear output that fed the
+ * residual add); with thr16 == 0 pass dlin = NULL and use dx.  dgamma/dbeta/dbias (fp32 [H], any
+ * may be NULL) get the column sums of dy*xhat, dy and dlin; `accumulate` != 0 adds to them.
+ * partials: fp32 workspace of mmf_layernorm_bwd_ws_floats(H) floats.
+ */
+int mmf_layernorm_bwd_ws_floats(int H);
+int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      void* dx, void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
+                      float* dgamma, float* dbeta, float* dbias, int accumulate, float* partials,
+                      int rows, int H, void* stream);
+
+/* ---- embeddings (BertVisioLinguisticEmbeddings, mmf/modules/embeddings.py:329-345) ------------
+ * Text rows of the joint pre-LayerNorm sequence: y[b*S + t] = word[ids[b,t]] + pos[t] + type[seg[b,t]].
+ * Tables are fp32 [*, H]; y is bf16 [B*S, H]; ids/seg int64 [B, T].
+ */
+int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
+                       const float* type, void* y, int B, int T, int S, int H, void* stream);
+/* out[idx[r]] += x[row r] for r in [0, nb*rpb): row r = (b, i) lives at x + (b*bstride + i)*ld.
+ * idx == NULL means bucket (i + idx_base) (position ids) when per_pos != 0, else bucket idx_base.
+ * fp32 atomics into `out` [nbuckets, H] (caller zero-fills when not accumulating).
+ * few_buckets != 0 pre-reduces inside the workgroup for <= 2 distinct buckets (type tables).
+ */
+int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, const int64_t* idx, int idx_ld,
+                         int per_pos, int idx_base, float* out, int H, int few_buckets, void* stream);
+
+/* ---- small row utilities ----------------------------------------------------------------------
+ * gather: out[b] = dropout(x[b*S + index[b]]), bf16 rows of H (visual_bert.py:389-400, the
+ * `pooler_strategy: vqa` token pick + dropout).  scatter: dx[b*S + index[b]] = dropout_bwd(dout[b]).
+ */
+int mmf_gather_rows(const void* x, const int64_t* index, void* out, int B, int S, int H,
+                    uint32_t drop_key, uint32_t drop_thr16, float drop_scale, void* stream);
+int mmf_scatter_rows(const void* dout, const int64_t* index, void* dx, int B, int S, int H,
+                     uint32_t drop_key, uint32_t drop_thr16, float drop_scale, void* stream);
+/* out[n] = beta*out[n] + sum over rows of x (bf16); rows = nb groups of rpb rows, group stride
+ * bstride rows, row stride ld.  Bias gradients. */
+int mmf_colsum_bf16(const void* x, int ld, int nb, int rpb, int bstride, int N, float* out, float beta,
+                    float* partials, void* stream);
+int mmf_colsum_ws_floats(int N);
+int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* mask_add[b][s] = (1 - mask[b][s]) * -10000  (visual_bert.py:94-106); mask int64 [B,S]. */
+int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream);
+
+/* ---- loss: LogitBinaryCrossEntropy, mmf/modules/losses.py:225-251 ---------------------------
+ * loss = mean(BCEWithLogits(scores, targets)) * N.  scores/targets fp32 [B, N] (row stride N).
+ * fwd writes the scalar to loss[0].  bwd writes dscores (bf16, row stride ldd >= N, pad columns
+ * zeroed) = gscale * (sigmoid(x) - t) / B, gscale read from the device scalar gloss (or 1 if NULL).
+ */
+int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, int B, int N, void* stream);
+int mmf_bce_logits_bwd(const float* scores, const float* targets, const float* gloss, void* dscores, int ldd,
+                       int B, int N, void* stream);
+
+/* ---- optimizer: AdamW (mmf/modules/optimizers.py:8-17; transformers.AdamW semantics) ----------
+ * One fused pass over a flat fp32 parameter arena: p, g, m, v [n].  Weight decay is
+ * given per SEGMENT: seg_end[i] (exclusive prefix ends, int64 [nseg]) and seg_wd[i] (weight decay of
+ * segment i; segment starts must be multiples of 4 elements).  Also refreshes the bf16 shadow `p16`
+ * (may be NULL).  mode 0 = transformers.AdamW update rule, mode 1 = torch.optim.AdamW.  g is
+ * multiplied by grad_scale first (loss-scale / world-size folding).
+ */
+int mmf_adamw_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const int64_t* seg_end,
+                   const float* seg_wd, int nseg, float lr, float beta1, float beta2, float eps, int step,
+                   int correct_bias, int mode, float grad_scale, void* stream);
+
+/* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
+int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */
+int mmf_probe_mfma32(const void* a, const void* b, float* d, void* stream);   /* out 64x16 */
+int mmf_probe_tr16(const void* lds_image_2048_bf16, const int* byte_addr_per_lane, void* out_64x4_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMF_AMD_H */

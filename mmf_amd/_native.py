@@ -1,0 +1,294 @@
+"""ctypes binding of libmmf_amd.so (the gfx950 kernels + C ABI declared in include/mmf_amd.h).
+
+This is the only place Python touches the native library.  There is NO fallback: if the shared
+library is missing or a call fails, an exception is raised — the product path never silently
+degrades to eager PyTorch or to the CPU oracle.
+
+PyTorch is used here purely as plumbing: device memory (`tensor.data_ptr()`), the current HIP
+stream, and dtype bookkeeping.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmf_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmf_amd.h")
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+        ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
+        ("a_f32", C.c_int), ("b_f32", C.c_int), ("out_f32", C.c_int),
+        ("beta", C.c_float),
+        ("bias", C.c_void_p), ("coladd", C.c_void_p),
+        ("rowtab", C.c_void_p), ("rowidx", C.c_void_p), ("rowtab_ld", C.c_int),
+        ("act", C.c_int), ("U", C.c_void_p), ("aux", C.c_void_p),
+        ("resid", C.c_void_p), ("ldr", C.c_int),
+        ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float),
+        ("grp_in", C.c_int), ("grp_pad", C.c_int), ("grp_off", C.c_int),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int),
+        ("mask", C.c_void_p), ("ctx", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
+        ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int),
+        ("scale", C.c_float),
+        ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float),
+    ]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ("f", AttnDesc), ("dctx", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+        ("delta", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the native library; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "mmf_amd native library not found at %s. Build it with `python -m mmf_amd.csrc.build` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path." % LIB_PATH
+        )
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - environment specific
+        raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e))
+    L.mmf_amd_last_error.restype = C.c_char_p
+    L.mmf_amd_target.restype = C.c_char_p
+    L.mmf_amd_abi_version.restype = C.c_int
+    if L.mmf_amd_abi_version() != 1:
+        raise NativeLibraryError("ABI version mismatch: library %d, binding 1" % L.mmf_amd_abi_version())
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise NativeLibraryError("%s failed (rc=%d): %s" % (what, rc, lib().mmf_amd_last_error().decode()))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise NativeLibraryError("%s must live in HBM (cuda/hip tensor), got %s" % (name, t.device))
+    if t.dtype != dtype:
+        raise NativeLibraryError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+def drop_cfg(p, key):
+    """(key, thr16, scale) for dropout probability p; thr16 == 0 disables dropout."""
+    if p is None or p <= 0.0:
+        return 0, 0, 1.0
+    thr = int(round(p * 65536.0))
+    thr = max(1, min(thr, 65535))
+    return int(key) & 0xFFFFFFFF, thr, 1.0 / (1.0 - thr / 65536.0)
+
+
+# --------------------------------------------------------------------------------------------
+# GEMM
+# --------------------------------------------------------------------------------------------
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
+         rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=(0, 0, 1.0),
+         grp=(0, 0, 0)):
+    d = GemmDesc()
+    d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.a_f32 = int(A.dtype == torch.float32)
+    d.b_f32 = int(B.dtype == torch.float32)
+    d.out_f32 = int(C_out.dtype == torch.float32)
+    for t, n in ((A, "A"), (B, "B")):
+        if t.dtype not in (torch.bfloat16, torch.float32):
+            raise NativeLibraryError("gemm operand %s must be bf16 or fp32" % n)
+    if C_out.dtype not in (torch.bfloat16, torch.float32):
+        raise NativeLibraryError("gemm output must be bf16 or fp32")
+    _req(bias, torch.float32, "bias"); _req(coladd, torch.float32, "coladd"); _req(rowtab, torch.float32, "rowtab")
+    _req(rowidx, torch.int64, "rowidx"); _req(U, torch.bfloat16, "U"); _req(aux, torch.bfloat16, "aux")
+    _req(resid, torch.bfloat16, "resid")
+    d.beta = beta
+    d.bias, d.coladd, d.rowtab, d.rowidx, d.rowtab_ld = _p(bias), _p(coladd), _p(rowtab), _p(rowidx), rowtab_ld
+    d.act, d.U, d.aux = act, _p(U), _p(aux)
+    d.resid, d.ldr = _p(resid), ldr
+    d.drop_key, d.drop_thr16, d.drop_scale = drop
+    d.grp_in, d.grp_pad, d.grp_off = grp
+    _check(lib().mmf_gemm_bf16(C.byref(d), _stream()), "mmf_gemm_bf16")
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop):
+    d = AttnDesc()
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):
+        _req(t, torch.bfloat16, n)
+    _req(mask, torch.float32, "mask"); _req(lse, torch.float32, "lse")
+    d.q, d.k, d.v = _p(q), _p(k), _p(v)
+    d.ldq, d.ldk, d.ldv = ldq, ldk, ldv
+    d.mask, d.ctx, d.ldo, d.lse = _p(mask), _p(ctx), ldo, _p(lse)
+    d.B, d.heads, d.Sq, d.Sk = B, heads, Sq, Sk
+    d.scale = scale
+    d.drop_key, d.drop_thr16, d.drop_scale = drop
+    return d
+
+
+def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=(0, 0, 1.0)):
+    d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop)
+    _check(lib().mmf_attention_fwd(C.byref(d), _stream()), "mmf_attention_fwd")
+
+
+def attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta,
+                  drop=(0, 0, 1.0)):
+    d = AttnBwdDesc()
+    d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop)
+    for t, n in ((dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _req(t, torch.bfloat16, n)
+    _req(delta, torch.float32, "delta")
+    d.dctx, d.dq, d.dk, d.dv, d.delta = _p(dctx), _p(dq), _p(dk), _p(dv), _p(delta)
+    _check(lib().mmf_attention_bwd(C.byref(d), _stream()), "mmf_attention_bwd")
+
+
+# --------------------------------------------------------------------------------------------
+# row kernels
+# --------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, H, eps):
+    _req(x, torch.bfloat16, "x"); _req(y, torch.bfloat16, "y")
+    _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    _req(mean, torch.float32, "mean"); _req(rstd, torch.float32, "rstd")
+    _check(lib().mmf_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, H, C.c_float(eps), _stream()),
+           "mmf_layernorm_fwd")
+
+
+def layernorm_bwd_ws_floats(H):
+    return lib().mmf_layernorm_bwd_ws_floats(H)
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, dgamma, dbeta, dbias, accumulate, partials, rows, H):
+    for t, n in ((dy, "dy"), (x, "x"), (dx, "dx"), (dlin, "dlin")):
+        _req(t, torch.bfloat16, n)
+    for t, n in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta"), (dbias, "dbias"),
+                 (partials, "partials")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dlin), C.c_uint32(drop[0]),
+                                   C.c_uint32(drop[1]), C.c_float(drop[2]), _p(dgamma), _p(dbeta), _p(dbias),
+                                   int(accumulate), _p(partials), rows, H, _stream()), "mmf_layernorm_bwd")
+
+
+def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H):
+    _req(ids, torch.int64, "ids"); _req(seg, torch.int64, "seg"); _req(y, torch.bfloat16, "y")
+    for t, n in ((word, "word"), (pos, "pos"), (typ, "type")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_embed_text_fwd(_p(ids), _p(seg), _p(word), _p(pos), _p(typ), _p(y), B, T, S, H, _stream()),
+           "mmf_embed_text_fwd")
+
+
+def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, few_buckets):
+    _req(x, torch.bfloat16, "x"); _req(idx, torch.int64, "idx"); _req(out, torch.float32, "out")
+    _check(lib().mmf_rows_scatter_add(_p(x), ld, nb, rpb, bstride, _p(idx), idx_ld, int(per_pos), idx_base, _p(out), H,
+                                      int(few_buckets), _stream()), "mmf_rows_scatter_add")
+
+
+def gather_rows(x, index, out, B, S, H, drop=(0, 0, 1.0)):
+    _req(x, torch.bfloat16, "x"); _req(index, torch.int64, "index"); _req(out, torch.bfloat16, "out")
+    _check(lib().mmf_gather_rows(_p(x), _p(index), _p(out), B, S, H, C.c_uint32(drop[0]), C.c_uint32(drop[1]),
+                                 C.c_float(drop[2]), _stream()), "mmf_gather_rows")
+
+
+def scatter_rows(dout, index, dx, B, S, H, drop=(0, 0, 1.0)):
+    _req(dout, torch.bfloat16, "dout"); _req(index, torch.int64, "index"); _req(dx, torch.bfloat16, "dx")
+    _check(lib().mmf_scatter_rows(_p(dout), _p(index), _p(dx), B, S, H, C.c_uint32(drop[0]), C.c_uint32(drop[1]),
+                                  C.c_float(drop[2]), _stream()), "mmf_scatter_rows")
+
+
+def colsum_ws_floats(N):
+    return lib().mmf_colsum_ws_floats(N)
+
+
+def colsum(x, ld, nb, rpb, bstride, N, out, beta, partials):
+    _req(x, torch.bfloat16, "x"); _req(out, torch.float32, "out"); _req(partials, torch.float32, "partials")
+    _check(lib().mmf_colsum_bf16(_p(x), ld, nb, rpb, bstride, N, _p(out), C.c_float(beta), _p(partials), _stream()),
+           "mmf_colsum_bf16")
+
+
+def cast_f32_to_bf16(src, dst, n=None):
+    _req(src, torch.float32, "src"); _req(dst, torch.bfloat16, "dst")
+    n = src.numel() if n is None else n
+    _check(lib().mmf_cast_f32_to_bf16(_p(src), _p(dst), C.c_int64(n), _stream()), "mmf_cast_f32_to_bf16")
+
+
+def cast_bf16_to_f32(src, dst, n=None):
+    _req(src, torch.bfloat16, "src"); _req(dst, torch.float32, "dst")
+    n = src.numel() if n is None else n
+    _check(lib().mmf_cast_bf16_to_f32(_p(src), _p(dst), C.c_int64(n), _stream()), "mmf_cast_bf16_to_f32")
+
+
+def make_additive_mask(mask, out):
+    _req(mask, torch.int64, "mask"); _req(out, torch.float32, "out")
+    _check(lib().mmf_make_additive_mask(_p(mask), _p(out), C.c_int64(mask.numel()), _stream()), "mmf_make_additive_mask")
+
+
+def bce_logits_fwd(scores, targets, loss, B, N):
+    for t, n in ((scores, "scores"), (targets, "targets"), (loss, "loss")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_bce_logits_fwd(_p(scores), _p(targets), _p(loss), B, N, _stream()), "mmf_bce_logits_fwd")
+
+
+def bce_logits_bwd(scores, targets, gloss, dscores, ldd, B, N):
+    for t, n in ((scores, "scores"), (targets, "targets"), (gloss, "gloss")):
+        _req(t, torch.float32, n)
+    _req(dscores, torch.bfloat16, "dscores")
+    _check(lib().mmf_bce_logits_bwd(_p(scores), _p(targets), _p(gloss), _p(dscores), ldd, B, N, _stream()),
+           "mmf_bce_logits_bwd")
+
+
+def adamw_step(p, g, m, v, p16, n, seg_end, seg_wd, nseg, lr, beta1, beta2, eps, step, correct_bias, mode, grad_scale):
+    for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (seg_wd, "seg_wd")):
+        _req(t, torch.float32, nme)
+    _req(p16, torch.bfloat16, "p16"); _req(seg_end, torch.int64, "seg_end")
+    _check(lib().mmf_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), C.c_int64(n), _p(seg_end), _p(seg_wd), nseg,
+                                C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), int(step),
+                                int(correct_bias), int(mode), C.c_float(grad_scale), _stream()), "mmf_adamw_step")
+
+
+def probe_mfma16(a, b, d):
+    _check(lib().mmf_probe_mfma16(_p(a), _p(b), _p(d), _stream()), "mmf_probe_mfma16")
+
+
+def probe_mfma32(a, b, d):
+    _check(lib().mmf_probe_mfma32(_p(a), _p(b), _p(d), _stream()), "mmf_probe_mfma32")
+
+
+def probe_tr16(img, addr, out):
+    _check(lib().mmf_probe_tr16(_p(img), _p(addr), _p(out), _stream()), "mmf_probe_tr16")

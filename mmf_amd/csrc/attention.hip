@@ -1,0 +1,487 @@
+// mmf_amd :: fused multi-head attention forward / backward for gfx950 (head_dim 64, Sk <= 256).
+//
+// Replaces BertSelfAttentionJit.forward (mmf/modules/hf_layers.py:161-213):
+//     scores = Q K^T / sqrt(d) + mask ; probs = softmax(scores) ; probs = dropout(probs) ;
+//     ctx = probs V ; permute + view to [B, S, H]
+// and its autograd backward, WITHOUT materialising the [B, A, S, S] scores / probs tensors
+// (80 MB fp32 each per layer at the VisualBERT VQA2 shape).
+//
+// Work decomposition: a 256-thread workgroup owns one (batch, head) and 128 query rows; each of
+// its 4 waves owns 32 query rows and ALL keys (Sk <= 256 -> <= 8 key tiles of 32), so the softmax
+// is the exact two-pass formulation of the reference (no online rescaling) held entirely in
+// registers.  A whole head's K and V (29 KB each at S = 228) are staged once in LDS.
+//
+// MFMA: v_mfma_f32_32x32x16_bf16, D[i][j] (+)= sum_k A[i][k] B[k][j]; lane l supplies row/col
+// x = l & 31 and the 8 reduction slots (h = l >> 5, e = 0..7); it receives D[(r&3)+8(r>>2)+4h][x],
+// r = 0..15.  The hardware pairs slot (h, e) of A with slot (h, e) of B, so any assignment of
+// reduction indices to slots is valid as long as both operands use the same one; the kernels use
+//   feature reductions  (over d)   : slot (h, e) of step s  <->  d = 16 s + 8 h + e
+//   key / query reductions         : slot (h, e) of step u  <->  index 16 u + 4 h + (e&3) + 8 (e>>2)
+// The second assignment is exactly the register order in which a lane holds a score tile, so the
+// probabilities feed the next MFMA straight from registers (no LDS round trip, no permutes).
+#include "common.h"
+#include "mmf_amd.h"
+
+namespace {
+
+constexpr int HD = 64;            // head dim
+constexpr int TSTRIDE = 520;      // bytes per row of a transposed [64 d][<=256 idx] LDS image (+8 pad:
+                                  // ds_read_b64 of 32 consecutive d rows hits 32 distinct 8-byte slots)
+constexpr int RM_BYTES = 256 * 128;
+constexpr int TR_BYTES = HD * TSTRIDE;
+
+DEVI int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+DEVI int tr_off(int d, int idx) { return d * TSTRIDE + idx * 2; }
+
+// Stage rows [0, npad) of a token-major [rows][64] bf16 matrix (row stride ld) into LDS, row-major
+// swizzled image and/or transposed image.  Rows >= nvalid are zero-filled.
+template <bool RM, bool TR>
+DEVI void stage_rows(const bf16* g, int ld, int nvalid, int npad, unsigned char* lds_rm, unsigned char* lds_tr,
+                     int tid) {
+    for (int c = tid; c < npad * 8; c += 256) {
+        const int row = c >> 3, ch = c & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < nvalid) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + ch * 8);
+        if (RM) *reinterpret_cast<uint4*>(lds_rm + rm_off(row, ch)) = v;
+        if (TR) {
+            const bf16x8 e = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<bf16*>(lds_tr + tr_off(ch * 8 + i, row)) = e[i];
+        }
+    }
+}
+
+// feature-reduction operand from a row-major LDS image: tile row x (absolute row = row0 + x), step s
+DEVI bf16x8 frag_rm(const unsigned char* lds_rm, int row0, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(lds_rm + rm_off(row0 + (lane & 31), 2 * s + (lane >> 5)));
+}
+// feature-reduction operand straight from global memory (one row per lane, clamped by caller)
+DEVI bf16x8 frag_global(const bf16* rowptr, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(rowptr + 16 * s + 8 * (lane >> 5));
+}
+// index-reduction operand from a transposed LDS image: row d = d0 + x, indices idx0 + 16u + ...
+DEVI bf16x8 frag_tr(const unsigned char* lds_tr, int d0, int idx0, int u, int lane) {
+    const unsigned char* p = lds_tr + tr_off(d0 + (lane & 31), idx0 + 16 * u + 4 * (lane >> 5));
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 16);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+// index-reduction operand from a score tile held in registers (regs 8u .. 8u+7)
+DEVI bf16x8 frag_regs(const f32x16& p, int u) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16)p[8 * u + e];
+    return r;
+}
+
+struct AttnArgs {
+    const bf16* q; const bf16* k; const bf16* v;
+    int ldq, ldk, ldv;
+    const float* mask;
+    bf16* ctx; int ldo;
+    float* lse;
+    int B, heads, Sq, Sk, skp;
+    float scale;
+    DropoutCfg drop;
+    // backward only
+    const bf16* dctx; bf16* dq; bf16* dk; bf16* dv; float* delta;
+};
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_k = smem;                         // row-major K  [NKT*32][64]
+    unsigned char* lds_vt = smem + NKT * 32 * 128;       // transposed V [64][NKT*32]
+    float* lds_mask = reinterpret_cast<float*>(lds_vt + TR_BYTES);  // [NKT*32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
+    const int q0 = blockIdx.y * 128 + wave * 32;
+    constexpr int SKP = NKT * 32;
+
+    const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
+    const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
+    stage_rows<true, false>(kbase, a.ldk, a.Sk, SKP, lds_k, nullptr, tid);
+    stage_rows<false, true>(vbase, a.ldv, a.Sk, SKP, nullptr, lds_vt, tid);
+    for (int i = tid; i < SKP; i += 256)
+        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] : 0.f) : -INFINITY;
+    __syncthreads();
+    if (q0 >= a.Sq) return;
+
+    // Q fragments (B operand: column = query row)
+    const int qrow = min(q0 + x, a.Sq - 1);
+    const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = frag_global(qptr, s, lane);
+
+    // scores^T tiles: sc[t][r] = S[q = q0+x][key = 32t + (r&3) + 8(r>>2) + 4h]
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        f32x16 acc = {};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_k, 32 * t, s, lane), qf[s], acc, 0, 0, 0);
+        sc[t] = acc;
+    }
+
+    // softmax over keys (exact two-pass, fp32), as nn.functional.softmax(scores/sqrt(d) + mask)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+            sc[t][4 * c + 0] = sc[t][4 * c + 0] * a.scale + mk.x;
+            sc[t][4 * c + 1] = sc[t][4 * c + 1] * a.scale + mk.y;
+            sc[t][4 * c + 2] = sc[t][4 * c + 2] * a.scale + mk.z;
+            sc[t][4 * c + 3] = sc[t][4 * c + 3] * a.scale + mk.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[t][4 * c + i]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(sc[t][r] - mx);
+            sc[t][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (h == 0 && q0 + x < a.Sq) a.lse[((size_t)bh) * a.Sq + q0 + x] = mx + __logf(sum);
+
+    // dropout on the probabilities (hf_layers.py:201), index ((bh*Sq + q)*SKP + key)
+    if (a.drop.thr16) {
+        const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)SKP;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 ds = drop_scale4(a.drop.key, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[t][4 * c + i] *= ds[i];
+            }
+    }
+
+    // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+    f32x16 o[2] = {};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 pf = frag_regs(sc[t], u);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_vt, 32 * dt, 32 * t, u, lane), pf, o[dt], 0, 0, 0);
+        }
+
+    if (q0 + x < a.Sq) {
+        bf16* optr = a.ctx + ((size_t)b * a.Sq + q0 + x) * a.ldo + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<bf16x4*>(optr + 32 * dt + 8 * c + 4 * h) =
+                    pack4(o[dt][4 * c + 0] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv);
+    }
+}
+
+// =================================================================================================
+// backward
+//   P = softmax row (recomputed from the saved log-sum-exp), Pd = dropout(P)
+//   dV = Pd^T dO ; dPd = dO V^T ; dS = P o (dropscale o dPd - delta), delta = rowsum(dO o O)
+//   dQ = dS K * scale ; dK = dS^T Q * scale
+// =================================================================================================
+// delta[b][head][q] = sum_d dO[b,q,head,d] * O[b,q,head,d].  One wave per token row, 16 lanes per head.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ dO, int ldo,
+                                                          float* __restrict__ delta, int B, int Sq, int heads) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * Sq) return;
+    const int b = row / Sq, q = row - b * Sq;
+    const int H = heads * HD;
+    for (int c0 = 0; c0 < H; c0 += 256) {
+        const int col = c0 + lane * 4;
+        float acc = 0.f;
+        if (col < H) {
+            const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(o + (size_t)row * ldo + col);
+            const bf16x4 x2 = *reinterpret_cast<const bf16x4*>(dO + (size_t)row * ldo + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc += (float)x1[i] * (float)x2[i];
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((lane & 15) == 0 && col < H) {
+            const int head = col / HD;
+            delta[((size_t)b * heads + head) * Sq + q] = acc;
+        }
+    }
+}
+
+// dQ kernel: same decomposition as the forward (wave = 32 query rows, all keys).
+template <int NKT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SKP = NKT * 32;
+    unsigned char* lds_k = smem;                               // row-major K
+    unsigned char* lds_v = lds_k + SKP * 128;                  // row-major V
+    unsigned char* lds_kt = lds_v + SKP * 128;                 // transposed K
+    float* lds_mask = reinterpret_cast<float*>(lds_kt + TR_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
+    const int q0 = blockIdx.y * 128 + wave * 32;
+
+    const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
+    const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
+    stage_rows<true, true>(kbase, a.ldk, a.Sk, SKP, lds_k, lds_kt, tid);
+    stage_rows<true, false>(vbase, a.ldv, a.Sk, SKP, lds_v, nullptr, tid);
+    for (int i = tid; i < SKP; i += 256)
+        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] : 0.f) : -INFINITY;
+    __syncthreads();
+    if (q0 >= a.Sq) return;
+
+    const int qrow = min(q0 + x, a.Sq - 1);
+    const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
+    const bf16* doptr = a.dctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { qf[s] = frag_global(qptr, s, lane); dof[s] = frag_global(doptr, s, lane); }
+    const float L = a.lse[(size_t)bh * a.Sq + qrow];
+    const float dl = a.delta[(size_t)bh * a.Sq + qrow];
+    const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)SKP;
+
+    f32x16 dqo[2] = {};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        f32x16 s_acc = {}, dp_acc = {};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_k, 32 * t, s, lane), qf[s], s_acc, 0, 0, 0);
+            dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_v, 32 * t, s, lane), dof[s], dp_acc, 0, 0, 0);
+        }
+        // dS^T[key][q] (scaled by `scale` for the dQ product)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+            const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            f32x4 ds = {1.f, 1.f, 1.f, 1.f};
+            if (a.drop.thr16) ds = drop_scale4(a.drop.key, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = __expf(s_acc[4 * c + i] * a.scale + mkv[i] - L);
+                s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * ds[i] - dl) * a.scale;
+            }
+        }
+        // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 df = frag_regs(s_acc, u);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                dqo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_kt, 32 * dt, 32 * t, u, lane), df, dqo[dt], 0, 0, 0);
+        }
+    }
+    if (q0 + x < a.Sq) {
+        bf16* optr = a.dq + ((size_t)b * a.Sq + q0 + x) * a.ldq + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<bf16x4*>(optr + 32 * dt + 8 * c + 4 * h) =
+                    pack4(dqo[dt][4 * c + 0], dqo[dt][4 * c + 1], dqo[dt][4 * c + 2], dqo[dt][4 * c + 3]);
+    }
+}
+
+// dK/dV kernel: wave = 32 key rows, loops over all query tiles.
+template <int NQT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SQP = NQT * 32;
+    unsigned char* lds_q = smem;                               // row-major Q
+    unsigned char* lds_do = lds_q + SQP * 128;                 // row-major dO
+    unsigned char* lds_qt = lds_do + SQP * 128;                // transposed Q
+    unsigned char* lds_dot = lds_qt + TR_BYTES;                // transposed dO
+    float* lds_lse = reinterpret_cast<float*>(lds_dot + TR_BYTES);   // [SQP]
+    float* lds_delta = lds_lse + SQP;                                 // [SQP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
+    const int k0 = blockIdx.y * 128 + wave * 32;
+    const int SKP = a.skp;
+
+    const bf16* qbase = a.q + (size_t)b * a.Sq * a.ldq + head * HD;
+    const bf16* dobase = a.dctx + (size_t)b * a.Sq * a.ldo + head * HD;
+    stage_rows<true, true>(qbase, a.ldq, a.Sq, SQP, lds_q, lds_qt, tid);
+    stage_rows<true, true>(dobase, a.ldo, a.Sq, SQP, lds_do, lds_dot, tid);
+    for (int i = tid; i < SQP; i += 256) {
+        // padded query rows: lse = +inf -> p = exp(-inf) = 0, so they contribute nothing
+        lds_lse[i] = (i < a.Sq) ? a.lse[(size_t)bh * a.Sq + i] : INFINITY;
+        lds_delta[i] = (i < a.Sq) ? a.delta[(size_t)bh * a.Sq + i] : 0.f;
+    }
+    __syncthreads();
+    if (k0 >= a.Sk) return;
+
+    const int krow = min(k0 + x, a.Sk - 1);
+    const bool kvalid = (k0 + x) < a.Sk;
+    const bf16* kptr = a.k + ((size_t)b * a.Sk + krow) * a.ldk + head * HD;
+    const bf16* vptr = a.v + ((size_t)b * a.Sk + krow) * a.ldv + head * HD;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
+    const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] : 0.f) : -INFINITY;
+
+    f32x16 dko[2] = {}, dvo[2] = {};
+#pragma unroll 1
+    for (int t = 0; t < NQT; ++t) {
+        // S[q][key], dPd[q][key]: rows q = 32t + (r&3)+8(r>>2)+4h, column key = k0 + x
+        f32x16 s_acc = {}, dp_acc = {};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_q, 32 * t, s, lane), kf[s], s_acc, 0, 0, 0);
+            dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_do, 32 * t, s, lane), vf[s], dp_acc, 0, 0, 0);
+        }
+        f32x16 pd;  // dropout(P) for dV
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 L4 = *reinterpret_cast<const float4*>(lds_lse + 32 * t + 8 * c + 4 * h);
+            const float4 D4 = *reinterpret_cast<const float4*>(lds_delta + 32 * t + 8 * c + 4 * h);
+            const float Lv[4] = {L4.x, L4.y, L4.z, L4.w};
+            const float Dv[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 32 * t + 8 * c + 4 * h + i;
+                float dsc = 1.f;
+                if (a.drop.thr16)
+                    dsc = drop_scale1(a.drop.key, ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)SKP + (uint32_t)(k0 + x),
+                                      a.drop.thr16, a.drop.scale);
+                const float p = __expf(s_acc[4 * c + i] * a.scale + mk - Lv[i]);
+                pd[4 * c + i] = p * dsc;
+                s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * dsc - Dv[i]) * a.scale;
+            }
+        }
+        // dV^T[d][key] += sum_q dO^T[d][q] Pd[q][key] ; dK^T[d][key] += sum_q Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 pf = frag_regs(pd, u);
+            const bf16x8 df = frag_regs(s_acc, u);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_dot, 32 * dt, 32 * t, u, lane), pf, dvo[dt], 0, 0, 0);
+                dko[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_qt, 32 * dt, 32 * t, u, lane), df, dko[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (kvalid) {
+        bf16* dkptr = a.dk + ((size_t)b * a.Sk + k0 + x) * a.ldk + head * HD;
+        bf16* dvptr = a.dv + ((size_t)b * a.Sk + k0 + x) * a.ldv + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                *reinterpret_cast<bf16x4*>(dkptr + 32 * dt + 8 * c + 4 * h) =
+                    pack4(dko[dt][4 * c + 0], dko[dt][4 * c + 1], dko[dt][4 * c + 2], dko[dt][4 * c + 3]);
+                *reinterpret_cast<bf16x4*>(dvptr + 32 * dt + 8 * c + 4 * h) =
+                    pack4(dvo[dt][4 * c + 0], dvo[dt][4 * c + 1], dvo[dt][4 * c + 2], dvo[dt][4 * c + 3]);
+            }
+    }
+}
+
+int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
+    MMF_CHECK_ARG(d && d->q && d->k && d->v, "attention: null operand");
+    MMF_CHECK_ARG(d->B > 0 && d->heads > 0 && d->Sq > 0 && d->Sk > 0, "attention: empty shape");
+    MMF_CHECK_ARG(d->Sk <= 256 && d->Sq <= 256, "attention: Sq and Sk must be <= 256 in this build");
+    MMF_CHECK_ARG((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0 && (d->ldo % 8) == 0,
+                  "attention: leading dimensions must be multiples of 8 elements");
+    a.q = (const bf16*)d->q; a.k = (const bf16*)d->k; a.v = (const bf16*)d->v;
+    a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv;
+    a.mask = d->mask; a.ctx = (bf16*)d->ctx; a.ldo = d->ldo; a.lse = d->lse;
+    a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk;
+    a.skp = (d->Sk + 31) / 32 * 32;
+    a.scale = d->scale;
+    a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale;
+    a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
+    return 0;
+}
+
+template <typename K>
+int set_lds(K kern, int bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { mmf_amd_set_error(hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
+    AttnArgs a;
+    if (int rc = fill_args(d, a)) return rc;
+    MMF_CHECK_ARG(d->ctx && d->lse, "attention_fwd: null output");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nkt = a.skp / 32;
+    const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
+#define LAUNCH_FWD(N)                                                                            \
+    {                                                                                            \
+        const int lds = N * 32 * 128 + TR_BYTES + N * 32 * 4;                                    \
+        if (int rc = set_lds(attn_fwd_kernel<N>, lds)) return rc;                                \
+        hipLaunchKernelGGL(attn_fwd_kernel<N>, grid, dim3(256), lds, s, a);                      \
+    }
+    if (nkt <= 4) LAUNCH_FWD(4) else LAUNCH_FWD(8)
+#undef LAUNCH_FWD
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
+    AttnArgs a;
+    MMF_CHECK_ARG(d, "attention_bwd: null desc");
+    if (int rc = fill_args(&d->f, a)) return rc;
+    MMF_CHECK_ARG(d->f.ctx && d->f.lse && d->dctx && d->dq && d->dk && d->dv && d->delta, "attention_bwd: null operand");
+    a.dctx = (const bf16*)d->dctx; a.dq = (bf16*)d->dq; a.dk = (bf16*)d->dk; a.dv = (bf16*)d->dv; a.delta = d->delta;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((a.B * a.Sq + 3) / 4), dim3(256), 0, s, a.ctx, a.dctx, a.ldo, a.delta,
+                       a.B, a.Sq, a.heads);
+    MMF_CHECK_LAUNCH();
+
+    const int nkt = a.skp / 32;
+    const int nqt = (a.Sq + 31) / 32;
+    {
+        const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
+#define LAUNCH_DQ(N)                                                                             \
+    {                                                                                            \
+        const int lds = 2 * N * 32 * 128 + TR_BYTES + N * 32 * 4;                                \
+        if (int rc = set_lds(attn_bwd_dq_kernel<N>, lds)) return rc;                             \
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<N>, grid, dim3(256), lds, s, a);                   \
+    }
+        if (nkt <= 4) LAUNCH_DQ(4) else LAUNCH_DQ(8)
+#undef LAUNCH_DQ
+        MMF_CHECK_LAUNCH();
+    }
+    {
+        const dim3 grid(a.B * a.heads, (a.Sk + 127) / 128);
+#define LAUNCH_DKV(N)                                                                            \
+    {                                                                                            \
+        const int lds = 2 * N * 32 * 128 + 2 * TR_BYTES + 2 * N * 32 * 4;                        \
+        if (int rc = set_lds(attn_bwd_dkv_kernel<N>, lds)) return rc;                            \
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<N>, grid, dim3(256), lds, s, a);                  \
+    }
+        if (nqt <= 4) LAUNCH_DKV(4) else LAUNCH_DKV(8)
+#undef LAUNCH_DKV
+        MMF_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,116 @@
+// mmf_amd :: device-side helpers shared by every gfx950 kernel in this library.
+// MI355X / CDNA4 only: wave = 64 lanes, MFMA bf16, 160 KiB LDS. No CUDA/portability paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define MMF_WAVE 64
+#define DEVI __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing for the C ABI (host side)
+// ---------------------------------------------------------------------------------------------
+#ifdef __cplusplus
+extern "C" {
+#endif
+void mmf_amd_set_error(const char* msg);
+#ifdef __cplusplus
+}
+#endif
+
+#define MMF_CHECK_ARG(cond, msg)                                                        \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            mmf_amd_set_error(msg " [" #cond "]");                                      \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+
+#define MMF_CHECK_LAUNCH()                                                              \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) {                                                        \
+            mmf_amd_set_error(hipGetErrorString(e__));                                  \
+            return 2;                                                                   \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// numeric helpers
+// ---------------------------------------------------------------------------------------------
+DEVI float bf2f(bf16 x) { return (float)x; }
+DEVI bf16 f2bf(float x) { return (bf16)x; }  // lowers to v_cvt_pk_bf16_f32 (RNE) on gfx950
+
+DEVI bf16x4 pack4(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d;
+    return r;
+}
+
+// exact-erf GELU, as HF `gelu` (transformers ACT2FN["gelu"]): x * 0.5 * (1 + erf(x / sqrt(2)))
+DEVI float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu(x) = Phi(x) + x * phi(x)
+DEVI float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// wave-wide (64 lane) reductions
+DEVI float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based dropout RNG.  One 32-bit hash per PAIR of elements; element e of a dropout site
+// keeps iff its 16-bit half >= thr16 (thr16 = round(p * 65536)).  The same (key, linear index)
+// reproduces the same decision in backward, whatever the thread mapping.
+// ---------------------------------------------------------------------------------------------
+DEVI uint32_t mix32(uint32_t x) {  // "lowbias32" integer finalizer
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+DEVI uint32_t drop_hash(uint32_t key, uint32_t pair_idx) { return mix32(mix32(pair_idx) ^ key); }
+// keep-scale factors (0 or scale) for the 4 consecutive elements starting at linear index idx4
+// (idx4 % 4 == 0).
+DEVI f32x4 drop_scale4(uint32_t key, uint32_t idx4, uint32_t thr16, float scale) {
+    const uint32_t h0 = drop_hash(key, idx4 >> 1);
+    const uint32_t h1 = drop_hash(key, (idx4 >> 1) + 1);
+    f32x4 r;
+    r[0] = ((h0 & 0xffffu) >= thr16) ? scale : 0.f;
+    r[1] = ((h0 >> 16) >= thr16) ? scale : 0.f;
+    r[2] = ((h1 & 0xffffu) >= thr16) ? scale : 0.f;
+    r[3] = ((h1 >> 16) >= thr16) ? scale : 0.f;
+    return r;
+}
+DEVI float drop_scale1(uint32_t key, uint32_t idx, uint32_t thr16, float scale) {
+    const uint32_t h = drop_hash(key, idx >> 1);
+    const uint32_t half = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
+    return (half >= thr16) ? scale : 0.f;
+}
+
+struct DropoutCfg {
+    uint32_t key;    // per-site key (host mixes the step seed with the site id)
+    uint32_t thr16;  // 0 => dropout disabled
+    float scale;     // 1 / (1 - thr16/65536)
+};

@@ -1,0 +1,374 @@
+// mmf_amd :: bf16 MFMA GEMM for gfx950 with fused epilogues.
+//
+// Replaces the stock ATen `nn.Linear` / `torch.matmul` calls on the reference hot path:
+//   Q/K/V projections        mmf/modules/hf_layers.py:169,179-180
+//   attention output dense   HF BertSelfOutput   (call site hf_layers.py:248)
+//   FFN up + GELU            HF BertIntermediate (call site hf_layers.py:289)
+//   FFN down                 HF BertOutput       (call site hf_layers.py:290)
+//   visual projection        mmf/modules/embeddings.py:319,352
+//   classifier head          mmf/models/visual_bert.py:327-330
+// and their autograd backward (dgrad / wgrad), mmf/trainers/core/training_loop.py:211.
+//
+// C[m][n] = sum_k A(m,k) * B(n,k)          (fp32 accumulate on v_mfma_f32_16x16x32_bf16)
+//   A "row"    : A(m,k) = A[m*lda + k]        A "k-major": A(m,k) = A[k*lda + m]
+//   B "row"    : B(n,k) = B[n*ldb + k]        B "k-major": B(n,k) = B[k*ldb + n]
+//   forward  Y = X W^T      : A row,     B row      (W is [out,in] like nn.Linear)
+//   dgrad    dX = dY W      : A row,     B k-major  (reduction index = out = row index of W)
+//   wgrad    dW = dY^T X    : A k-major, B k-major  (reduction index = token = row index of both)
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), wave tile 64x64 = 4x4 MFMA 16x16 fragments.
+// Register-staged double-buffered LDS (global -> VGPR -> LDS), one barrier per K-tile.
+// LDS images (16 KiB per operand per stage, 64 KiB per workgroup -> 2 workgroups / CU):
+//   row operand     : [128 rows][8 chunks of 16 B], chunk ^= (row & 7)   -> conflict-free ds_read_b128
+//   k-major operand : [64 k-rows][256 B], bytes rotated by 32*((k&3) + 4*((k>>3)&1)) within the row
+//                     -> conflict-free ds_read_b64_tr_b16 (hardware 4x16 transpose read)
+// The MFMA is issued with operands swapped (A-operand = B tile fragment) so each lane ends up
+// holding 4 CONSECUTIVE n for one m: epilogue loads/stores are 8-byte (bf16) / 16-byte (fp32).
+#include "common.h"
+#include "mmf_amd.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int OPER_BYTES = 16384;  // one operand tile in LDS
+
+struct EpiArgs {
+    void* C;            // output
+    int ldc;
+    int out_f32;        // 1: C is float, else bf16
+    float beta;         // C = acc + beta*C   (fp32 output only; gradient accumulation)
+    const float* bias;  // [N] or null
+    const float* coladd;  // [N] extra per-column addend or null
+    const float* rowtab;  // optional table gathered per output row: rowtab[rowidx[m]*rowtab_ld + n]
+    const int64_t* rowidx;
+    int rowtab_ld;
+    int act;            // 0 none | 1 gelu(acc) (U := pre-activation if U != null) | 2 acc * gelu'(aux)
+    bf16* U;
+    const bf16* aux;    // same indexing as C (ldc)
+    const bf16* resid;  // added after activation/dropout, ldr
+    int ldr;
+    DropoutCfg drop;    // applied to (acc + bias) before the residual add; index = m*N + n
+    int grp_in, grp_pad, grp_off;  // output row remap: row = m + (m / grp_in) * grp_pad + grp_off
+    int M, N;
+};
+
+DEVI int rot_kmajor(int krow) { return 32 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
+
+// ---- global -> register staging -------------------------------------------------------------
+template <typename T>
+struct Stage;  // 4 chunks of 8 elements per thread per operand tile
+
+template <>
+struct Stage<bf16> {
+    uint4 v[4];
+    template <bool RAGGED>
+    DEVI void load(int i, const bf16* p, bool ok) {
+        if (RAGGED && !ok) v[i] = make_uint4(0, 0, 0, 0);
+        else v[i] = *reinterpret_cast<const uint4*>(p);
+    }
+};
+template <>
+struct Stage<float> {
+    uint4 v[4];
+    template <bool RAGGED>
+    DEVI void load(int i, const float* p, bool ok) {
+        if (RAGGED && !ok) { v[i] = make_uint4(0, 0, 0, 0); return; }
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        bf16x8 r;
+        r[0] = (bf16)a.x; r[1] = (bf16)a.y; r[2] = (bf16)a.z; r[3] = (bf16)a.w;
+        r[4] = (bf16)b.x; r[5] = (bf16)b.y; r[6] = (bf16)b.z; r[7] = (bf16)b.w;
+        v[i] = __builtin_bit_cast(uint4, r);
+    }
+};
+
+// Issue the global loads of one operand tile (rows [r0, r0+128) x k [k0, k0+64)).
+template <typename T, bool KMAJOR, bool RAGGED>
+DEVI void stage_load(Stage<T>& st, const T* base, int ld, int r0, int k0, int R, int K, int tid) {
+    if (!KMAJOR) {
+        const int kc = tid & 7;
+        const int k = k0 + kc * 8;
+        const bool kok = k < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = r0 + (tid >> 3) + 32 * i;
+            if (RAGGED) row = row < R ? row : R - 1;
+            st.template load<RAGGED>(i, base + (size_t)row * ld + k, kok);
+        }
+    } else {
+        const int nc = tid & 15;
+        const int col = r0 + nc * 8;
+        const bool cok = col < R;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int krow = k0 + (tid >> 4) + 16 * i;
+            const bool ok = cok && (krow < K);
+            st.template load<RAGGED>(i, base + (size_t)(RAGGED ? (ok ? krow : 0) : krow) * ld + (RAGGED ? (ok ? col : 0) : col), ok);
+        }
+    }
+}
+
+template <typename T, bool KMAJOR>
+DEVI void stage_store(const Stage<T>& st, unsigned char* lds, int tid) {
+    if (!KMAJOR) {
+        const int kc = tid & 7;
+        const int sw = (tid >> 3) & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(lds + row * 128 + ((kc ^ sw) << 4)) = st.v[i];
+        }
+    } else {
+        const int nc = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int krow = (tid >> 4) + 16 * i;
+            *reinterpret_cast<uint4*>(lds + krow * 256 + ((nc * 16 + rot_kmajor(krow)) & 255)) = st.v[i];
+        }
+    }
+}
+
+// ---- LDS -> MFMA fragment ---------------------------------------------------------------------
+// Fragment f (16 rows starting at wrow0 + 16 f), k sub-step kk (32 k each). Lane l holds tile row
+// (l & 15) and the 8 reduction slots of lane group g = l >> 4; both layouts use reduction rows
+// kk*32 + 8g + [0,8) for group g, so a row operand and a k-major operand pair up correctly.
+template <bool KMAJOR>
+DEVI bf16x8 read_frag(const unsigned char* lds, int wrow0, int f, int kk, int lane) {
+    if (!KMAJOR) {
+        const int row = wrow0 + f * 16 + (lane & 15);
+        const int chunk = kk * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    } else {
+        const int g = lane >> 4, p = lane & 15;
+        const int col = wrow0 + f * 16 + (p & 3) * 4;
+        const int rot = 32 * ((p >> 2) + 4 * (g & 1));
+        const int krow0 = kk * 32 + 8 * g + (p >> 2);
+        const int cb = (col * 2 + rot) & 255;
+        typedef s16x4 __attribute__((address_space(3))) * lds_p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + krow0 * 256 + cb));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + (krow0 + 4) * 256 + cb));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+// ---- epilogue -----------------------------------------------------------------------------------
+DEVI f32x4 load_f4(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return f32x4{t.x, t.y, t.z, t.w};
+}
+DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc) {
+    if (m >= e.M || n >= e.N) return;
+    const bool full = (n + 4 <= e.N);
+    f32x4 v = acc;
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ok[r] = (n + r) < e.N;
+    if (e.bias) {
+        if (full) v += load_f4(e.bias + n);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += e.bias[n + r];
+        }
+    }
+    if (e.coladd) {
+        if (full) v += load_f4(e.coladd + n);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += e.coladd[n + r];
+        }
+    }
+    if (e.rowtab) {
+        const float* t = e.rowtab + (size_t)e.rowidx[m] * e.rowtab_ld + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += t[r];
+    }
+    int orow = m;
+    if (e.grp_in > 0) orow = m + (m / e.grp_in) * e.grp_pad + e.grp_off;
+    const size_t off = (size_t)orow * e.ldc + n;
+    const bool vec = full && ((e.ldc & 3) == 0);
+    if (e.act == 1) {
+        if (e.U) {
+            if (vec) *reinterpret_cast<bf16x4*>(e.U + off) = pack4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (ok[r]) e.U[off + r] = (bf16)v[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    } else if (e.act == 2) {
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            const bf16x4 ub = *reinterpret_cast<const bf16x4*>(e.aux + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = (float)ub[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) u[r] = (float)e.aux[off + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(u[r]);
+    }
+    if (e.drop.thr16)
+        v *= drop_scale4(e.drop.key, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop.thr16, e.drop.scale);
+    if (e.resid) {
+        const size_t roff = (size_t)orow * e.ldr + n;
+        if (full && ((e.ldr & 3) == 0)) {
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(e.resid + roff);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += (float)e.resid[roff + r];
+        }
+    }
+    if (e.out_f32) {
+        float* C = reinterpret_cast<float*>(e.C) + off;
+        if (vec) {
+            if (e.beta != 0.f) v += e.beta * load_f4(C);
+            *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) C[r] = v[r] + (e.beta != 0.f ? e.beta * C[r] : 0.f);
+        }
+    } else {
+        bf16* C = reinterpret_cast<bf16*>(e.C) + off;
+        if (vec) *reinterpret_cast<bf16x4*>(C) = pack4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) C[r] = (bf16)v[r];
+        }
+    }
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------
+template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
+                                                             int M, int N, int K, int lda, int ldb,
+                                                             int tiles_m, int tiles_n, EpiArgs epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of the
+    // (m-major, n-fastest) tile list so the A row panel and the weight panel stay in its L2.
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage<AT> sa;
+    Stage<BT> sb;
+    const int nk = (K + BK - 1) / BK;
+
+    stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, 0, M, K, tid);
+    stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, 0, N, K, tid);
+    stage_store<AT, A_KMAJOR>(sa, smem, tid);
+    stage_store<BT, B_KMAJOR>(sb, smem + OPER_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const unsigned char* la = smem + cur * 2 * OPER_BYTES;
+        const unsigned char* lb = la + OPER_BYTES;
+        // Prefetch the next K-tile into registers while this one is multiplied.  The last iteration
+        // re-fetches its own tile (into the idle buffer) so the loop body stays branch-free and the
+        // staging registers never become a loop-carried aggregate (which hipcc would put in scratch).
+        const int kn = (kt + 1 < nk) ? kt + 1 : kt;
+        stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, kn * BK, M, K, tid);
+        stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, kn * BK, N, K, tid);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fa[f] = read_frag<A_KMAJOR>(la, wm * 64, f, kk, lane);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fb[f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        unsigned char* na = smem + (cur ^ 1) * 2 * OPER_BYTES;
+        stage_store<AT, A_KMAJOR>(sa, na, tid);
+        stage_store<BT, B_KMAJOR>(sb, na + OPER_BYTES, tid);
+        __syncthreads();
+    }
+
+    // D = (C tile)^T fragment: lane holds n = 4*(lane>>4) + [0,4), m = lane & 15.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            epilogue4(epi, m, n, acc[i][j]);
+        }
+    }
+}
+
+template <typename AT, typename BT, bool AK, bool BK_, bool RG>
+int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG>), dim3(tm * tn), dim3(256), 4 * OPER_BYTES, s,
+                       reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
+                       d->lda, d->ldb, tm, tn, e);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
+    MMF_CHECK_ARG(d && d->A && d->B && d->C, "mmf_gemm_bf16: null operand");
+    MMF_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "mmf_gemm_bf16: empty shape");
+    MMF_CHECK_ARG((d->lda % 8) == 0 && (d->ldb % 8) == 0, "mmf_gemm_bf16: lda/ldb must be multiples of 8 elements");
+    // row operands are fetched in 8-element chunks along K: the last chunk may run into the row padding
+    // (which must hold finite values, normally zeros), so the leading dimension has to cover it.
+    const int k8 = (d->K + 7) / 8 * 8;
+    MMF_CHECK_ARG(d->a_kmajor || d->lda >= k8, "mmf_gemm_bf16: lda must cover round_up(K, 8) for a row operand");
+    MMF_CHECK_ARG(d->b_kmajor || d->ldb >= k8, "mmf_gemm_bf16: ldb must cover round_up(K, 8) for a row operand");
+    MMF_CHECK_ARG(!(d->a_f32 && d->b_f32), "mmf_gemm_bf16: at most one fp32 operand");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    EpiArgs e;
+    e.C = d->C; e.ldc = d->ldc; e.out_f32 = d->out_f32; e.beta = d->beta;
+    e.bias = d->bias; e.coladd = d->coladd; e.rowtab = d->rowtab; e.rowidx = d->rowidx; e.rowtab_ld = d->rowtab_ld;
+    e.act = d->act; e.U = reinterpret_cast<bf16*>(d->U); e.aux = reinterpret_cast<const bf16*>(d->aux);
+    e.resid = reinterpret_cast<const bf16*>(d->resid); e.ldr = d->ldr;
+    e.drop.key = d->drop_key; e.drop.thr16 = d->drop_thr16; e.drop.scale = d->drop_scale;
+    e.grp_in = d->grp_in; e.grp_pad = d->grp_pad; e.grp_off = d->grp_off;
+    e.M = d->M; e.N = d->N;
+    MMF_CHECK_ARG(d->act != 2 || d->aux, "mmf_gemm_bf16: act=2 needs aux");
+    MMF_CHECK_ARG(!d->rowtab || d->rowidx, "mmf_gemm_bf16: rowtab needs rowidx");
+
+    // ragged unless every tile is full and every chunk in range
+    const bool ragged = (d->M % BM) || (d->N % BN) || (d->K % BK);
+    const int key = (d->a_kmajor ? 1 : 0) | (d->b_kmajor ? 2 : 0) | (d->a_f32 ? 4 : 0) | (d->b_f32 ? 8 : 0);
+    switch (key) {
+        case 0: return ragged ? launch<bf16, bf16, false, false, true>(d, e, s) : launch<bf16, bf16, false, false, false>(d, e, s);
+        case 4: return ragged ? launch<float, bf16, false, false, true>(d, e, s) : launch<float, bf16, false, false, false>(d, e, s);
+        case 2: return ragged ? launch<bf16, bf16, false, true, true>(d, e, s) : launch<bf16, bf16, false, true, false>(d, e, s);
+        case 3: return ragged ? launch<bf16, bf16, true, true, true>(d, e, s) : launch<bf16, bf16, true, true, false>(d, e, s);
+        case 11: return ragged ? launch<bf16, float, true, true, true>(d, e, s) : launch<bf16, float, true, true, false>(d, e, s);
+        default: break;
+    }
+    mmf_amd_set_error("mmf_gemm_bf16: unsupported operand layout combination");
+    return 1;
+}

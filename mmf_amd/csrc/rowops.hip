@@ -1,0 +1,602 @@
+// mmf_amd :: HBM-bound row kernels for gfx950: LayerNorm fwd/bwd, embedding gather / scatter-add,
+// gather/scatter of pooled rows, column sums (bias grads), dtype casts, additive mask, BCE-with-logits
+// loss, fused AdamW.  One wave (64 lanes) per row, 8-byte (bf16x4) / 16-byte (fp32x4) accesses per
+// lane, fp32 arithmetic, wave-shuffle reductions.  Reference call sites are cited at each C entry
+// point in include/mmf_amd.h.
+#include "common.h"
+#include "mmf_amd.h"
+
+namespace {
+
+// lane `lane` of a wave owns columns (lane + 64*c)*4 .. +3, c = 0..NCH-1 (NCH = ceil(H / 256))
+#define COL_OF(c) (((lane) + 64 * (c)) * 4)
+
+DEVI f32x4 load4(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+DEVI f32x4 load4(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+DEVI void store4(bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = pack4(v[0], v[1], v[2], v[3]); }
+DEVI void store4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int H,
+                                                      float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* xr = x + (size_t)row * H;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (COL_OF(c) < H) { v[c] = load4(xr + COL_OF(c)); s += v[c][0] + v[c][1] + v[c][2] + v[c][3]; }
+    }
+    const float mu = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (COL_OF(c) < H) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[c][i] - mu; q += d * d; }
+        }
+    const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
+    bf16* yr = y + (size_t)row * H;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (COL_OF(c) < H) {
+            const f32x4 g = load4(gamma + COL_OF(c)), b = load4(beta + COL_OF(c));
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mu) * rs * g[i] + b[i];
+            store4(yr + COL_OF(c), o);
+        }
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (+ dropout backward of the producing Linear, + column-sum partials)
+// partials layout: [gridDim.x][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias
+// ------------------------------------------------------------------------------------------------
+constexpr int LNB_GRID = 512;
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, bf16* __restrict__ dx,
+                                                      bf16* __restrict__ dlin, DropoutCfg drop, float* __restrict__ partials,
+                                                      int rows, int H) {
+    __shared__ float red[4][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 ag[NCH], ab[NCH], al[NCH], gm[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        ag[c] = ab[c] = al[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gm[c] = (COL_OF(c) < H) ? load4(gamma + COL_OF(c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NCH], g[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            xh[c] = g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (COL_OF(c) < H) {
+                const f32x4 xv = load4(x + (size_t)row * H + COL_OF(c));
+                const f32x4 dv = load4(dy + (size_t)row * H + COL_OF(c));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[c][i] = (xv[i] - mu) * rs;
+                    g[c][i] = dv[i] * gm[c][i];
+                    s1 += g[c][i];
+                    s2 += g[c][i] * xh[c][i];
+                    ag[c][i] += dv[i] * xh[c][i];
+                    ab[c][i] += dv[i];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (COL_OF(c) < H) {
+                f32x4 d;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = rs * (g[c][i] - c1 - xh[c][i] * c2);
+                store4(dx + (size_t)row * H + COL_OF(c), d);
+                if (dlin) {
+                    const f32x4 sc = drop_scale4(drop.key, (uint32_t)row * (uint32_t)H + (uint32_t)COL_OF(c), drop.thr16, drop.scale);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[i] *= sc[i];
+                    store4(dlin + (size_t)row * H + COL_OF(c), d);
+                }
+                // bias gradient uses the same rounding the wgrad GEMM will see
+                const bf16x4 dr = pack4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) al[c][i] += (float)dr[i];
+            }
+    }
+    // combine the 4 waves of the workgroup, one quantity at a time
+#pragma unroll 1
+    for (int qn = 0; qn < 3; ++qn) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f32x4 v = (qn == 0) ? ag[c] : (qn == 1) ? ab[c] : al[c];
+            *reinterpret_cast<float4*>(&red[wave][COL_OF(c)]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < H; col += 256)
+            partials[((size_t)blockIdx.x * 3 + qn) * H + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+    }
+}
+
+// out_q[col] (+)= sum_blk partials[blk][q][col]
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblk, int H, float* o0, float* o1, float* o2,
+                                     int accumulate) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int qn = blockIdx.y;
+    float* out = (qn == 0) ? o0 : (qn == 1) ? o1 : o2;
+    if (col >= H || out == nullptr) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partials[((size_t)b * 3 + qn) * H + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeddings
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+                                                          const float* __restrict__ word, const float* __restrict__ pos,
+                                                          const float* __restrict__ type, bf16* __restrict__ y, int B, int T,
+                                                          int S, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * T) return;
+    const int b = r / T, t = r - b * T;
+    const int64_t id = ids[r];
+    const int64_t sg = seg ? seg[r] : 0;
+    const float* w = word + (size_t)id * H;
+    const float* p = pos + (size_t)t * H;
+    const float* ty = type + (size_t)sg * H;
+    bf16* yr = y + ((size_t)b * S + t) * H;
+    for (int col = lane * 4; col < H; col += 256) {
+        const f32x4 a = load4(w + col), c = load4(p + col), d = load4(ty + col);
+        // same association order as embeddings.py:344 (words + position) + token_type
+        store4(yr + col, f32x4{(a[0] + c[0]) + d[0], (a[1] + c[1]) + d[1], (a[2] + c[2]) + d[2], (a[3] + c[3]) + d[3]});
+    }
+}
+
+DEVI int bucket_of(const int64_t* idx, int idx_ld, int per_pos, int idx_base, int b, int i) {
+    if (idx) return (int)idx[(size_t)b * idx_ld + i];
+    return per_pos ? i + idx_base : idx_base;
+}
+
+__global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
+                                                                  const int64_t* __restrict__ idx, int idx_ld, int per_pos,
+                                                                  int idx_base, float* __restrict__ out, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nb * rpb) return;
+    const int b = r / rpb, i = r - b * rpb;
+    const int bk = bucket_of(idx, idx_ld, per_pos, idx_base, b, i);
+    const bf16* xr = x + ((size_t)b * bstride + i) * ld;
+    float* o = out + (size_t)bk * H;
+    for (int col = lane * 4; col < H; col += 256) {
+        const f32x4 v = load4(xr + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(o + col + j, v[j]);
+    }
+}
+
+// <= 2 buckets: accumulate 64 rows per workgroup in registers, then one atomic per column per bucket.
+__global__ __launch_bounds__(256) void scatter_add_few_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
+                                                               const int64_t* __restrict__ idx, int idx_ld, int per_pos,
+                                                               int idx_base, float* __restrict__ out, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = nb * rpb;
+    const int r0 = blockIdx.x * 64;
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k = wave; k < 64; k += 4) {
+            const int r = r0 + k;
+            if (r >= total) break;
+            const int b = r / rpb, i = r - b * rpb;
+            const int bk = bucket_of(idx, idx_ld, per_pos, idx_base, b, i);
+            const f32x4 v = load4(x + ((size_t)b * bstride + i) * ld + col);
+            if (bk == 0) a0 += v;
+            else if (bk == 1) a1 += v;
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(out + (size_t)bk * H + col + j, v[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (a0[j] != 0.f) atomicAdd(out + col + j, a0[j]);
+            if (a1[j] != 0.f) atomicAdd(out + H + col + j, a1[j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ x, const int64_t* __restrict__ index,
+                                                           bf16* __restrict__ out, int B, int S, int H, DropoutCfg drop,
+                                                           int scatter) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int64_t ix = index[b];
+    ix = ix < 0 ? 0 : (ix >= S ? S - 1 : ix);
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+        if (drop.thr16) sc = drop_scale4(drop.key, (uint32_t)b * (uint32_t)H + (uint32_t)col, drop.thr16, drop.scale);
+        if (!scatter) {
+            const f32x4 v = load4(x + ((size_t)b * S + ix) * H + col);
+            store4(out + (size_t)b * H + col, v * sc);
+        } else {
+            const f32x4 v = load4(x + (size_t)b * H + col);
+            store4(out + ((size_t)b * S + ix) * H + col, v * sc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: grid (CS_GROUPS, ceil(N/256)); partials [CS_GROUPS][N]
+// ------------------------------------------------------------------------------------------------
+constexpr int CS_GROUPS = 64;
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride, int N,
+                                                      float* __restrict__ partials) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y * 256 + lane * 4;
+    const int total = nb * rpb;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        for (int r = blockIdx.x * 4 + wave; r < total; r += gridDim.x * 4) {
+            const int b = r / rpb, i = r - b * rpb;
+            const bf16* p = x + ((size_t)b * bstride + i) * ld + col;
+            if (col + 4 <= N) acc += load4(p);
+            else for (int j = 0; j < 4; ++j) if (col + j < N) acc[j] += (float)p[j];
+        }
+    }
+    *reinterpret_cast<float4*>(&red[wave][lane * 4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c < N) partials[(size_t)blockIdx.x * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ partials, int ngroups, int N, float* __restrict__ out, float beta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int g = 0; g < ngroups; ++g) s += partials[(size_t)g * N + c];
+    out[c] = (beta != 0.f) ? beta * out[c] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// casts / mask
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+            bf16x8 r;
+            r[0] = (bf16)a.x; r[1] = (bf16)a.y; r[2] = (bf16)a.z; r[3] = (bf16)a.w;
+            r[4] = (bf16)b.x; r[5] = (bf16)b.y; r[6] = (bf16)b.z; r[7] = (bf16)b.w;
+            *reinterpret_cast<bf16x8*>(dst + i) = r;
+        } else {
+            for (int64_t j = i; j < n; ++j) dst[j] = (bf16)src[j];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) store4(dst + i, load4(src + i));
+        else for (int64_t j = i; j < n; ++j) dst[j] = (float)src[j];
+    }
+}
+__global__ void additive_mask_kernel(const int64_t* __restrict__ m, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (1.0f - (float)m[i]) * -10000.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BCE with logits (losses.py:246-251)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ loss,
+                                                        int B, int N) {
+    __shared__ float red[16];
+    const int64_t n = (int64_t)B * N;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float xv = x[i], tv = t[i];
+        // numerically stable form used by ATen: max(x,0) - x*t + log1p(exp(-|x|))
+        s += fmaxf(xv, 0.f) - xv * tv + log1pf(__expf(-fabsf(xv)));
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 16; ++i) tot += red[i];
+        // mean over B*N, times N  ==  sum / B
+        loss[0] = tot / (float)B;
+    }
+}
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                       const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int B, int N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * ldd) return;
+    const int b = (int)(i / ldd), n = (int)(i - (int64_t)b * ldd);
+    float v = 0.f;
+    if (n < N) {
+        const float g = gloss ? gloss[0] : 1.f;
+        const float xv = x[(size_t)b * N + n];
+        v = g * (1.f / (1.f + __expf(-xv)) - t[(size_t)b * N + n]) / (float)B;
+    }
+    d[i] = (bf16)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused AdamW over a flat arena
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, bf16* __restrict__ p16, int64_t n,
+                                                     const int64_t* __restrict__ seg_end, const float* __restrict__ seg_wd, int nseg,
+                                                     float lr, float beta1, float beta2, float eps, float bc1, float bc2,
+                                                     int mode, float grad_scale) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        // segment lookup (binary search over exclusive ends); 4-element groups never straddle a segment
+        // boundary because every segment start is 4-aligned in the arena.
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (i < seg_end[mid]) hi = mid; else lo = mid + 1; }
+        const float wd = seg_wd[lo];
+        const int cnt = (i + 4 <= n) ? 4 : (int)(n - i);
+        for (int j = 0; j < cnt; ++j) {
+            const float gj = g[i + j] * grad_scale;
+            float pj = p[i + j];
+            const float mj = beta1 * m[i + j] + (1.f - beta1) * gj;
+            const float vj = beta2 * v[i + j] + (1.f - beta2) * gj * gj;
+            m[i + j] = mj; v[i + j] = vj;
+            if (mode == 0) {
+                // transformers.AdamW (optimizers.py:8-17 imports it): step_size = lr*sqrt(bc2)/bc1, denom = sqrt(v)+eps,
+                // decoupled decay applied AFTER the update with plain lr.
+                const float denom = sqrtf(vj) + eps;
+                pj -= (lr * sqrtf(bc2) / bc1) * (mj / denom);
+                if (wd > 0.f) pj -= lr * wd * pj;
+            } else {
+                // torch.optim.AdamW: decay first, denom = sqrt(v)/sqrt(bc2) + eps
+                pj *= (1.f - lr * wd);
+                const float denom = sqrtf(vj) / sqrtf(bc2) + eps;
+                pj -= (lr / bc1) * (mj / denom);
+            }
+            p[i + j] = pj;
+            if (p16) p16[i + j] = (bf16)pj;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout probes
+// ------------------------------------------------------------------------------------------------
+__global__ void probe_mfma16_kernel(const bf16x8* a, const bf16x8* b, f32x4* d) {
+    const int l = threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[l], b[l], acc, 0, 0, 0);
+    d[l] = acc;
+}
+__global__ void probe_mfma32_kernel(const bf16x8* a, const bf16x8* b, f32x16* d) {
+    const int l = threadIdx.x;
+    f32x16 acc = {};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[l], b[l], acc, 0, 0, 0);
+    d[l] = acc;
+}
+__global__ void probe_tr16_kernel(const uint4* img, const int* addr, s16x4* out) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4096];
+    const int l = threadIdx.x;
+    for (int i = l; i < 256; i += 64) reinterpret_cast<uint4*>(lds)[i] = img[i];
+    __syncthreads();
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    out[l] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + addr[l]));
+}
+
+template <int NCH, typename... A>
+void launch_ln_fwd(int rows, hipStream_t s, A... a) {
+    hipLaunchKernelGGL(ln_fwd_kernel<NCH>, dim3((rows + 3) / 4), dim3(256), 0, s, a...);
+}
+template <int NCH, typename... A>
+void launch_ln_bwd(int grid, hipStream_t s, A... a) {
+    hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(256), 0, s, a...);
+}
+
+inline int grid_for(int64_t n, int per_block, int cap) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
+                      int H, float eps, void* stream) {
+    MMF_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null operand");
+    MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 2048, "layernorm_fwd: need H % 4 == 0 and H <= 2048");
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (H + 255) / 256;
+    const bf16* xp = (const bf16*)x; bf16* yp = (bf16*)y;
+    switch (nch) {
+        case 1: launch_ln_fwd<1>(rows, s, xp, gamma, beta, yp, mean, rstd, rows, H, eps); break;
+        case 2: launch_ln_fwd<2>(rows, s, xp, gamma, beta, yp, mean, rstd, rows, H, eps); break;
+        case 3: launch_ln_fwd<3>(rows, s, xp, gamma, beta, yp, mean, rstd, rows, H, eps); break;
+        case 4: launch_ln_fwd<4>(rows, s, xp, gamma, beta, yp, mean, rstd, rows, H, eps); break;
+        default: launch_ln_fwd<8>(rows, s, xp, gamma, beta, yp, mean, rstd, rows, H, eps); break;
+    }
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_layernorm_bwd_ws_floats(int H) { return LNB_GRID * 3 * H; }
+
+int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                      void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, float* dgamma, float* dbeta,
+                      float* dbias, int accumulate, float* partials, int rows, int H, void* stream) {
+    MMF_CHECK_ARG(dy && x && mean && rstd && gamma && dx && partials, "layernorm_bwd: null operand");
+    MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 1024, "layernorm_bwd: need H % 4 == 0 and H <= 1024");
+    MMF_CHECK_ARG(drop_thr16 == 0 || dlin, "layernorm_bwd: dropout needs dlin");
+    hipStream_t s = (hipStream_t)stream;
+    DropoutCfg dc{drop_key, drop_thr16, drop_scale};
+    const int grid = grid_for(rows, 4, LNB_GRID);
+    const int nch = (H + 255) / 256;
+    const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
+    switch (nch) {
+        case 1: launch_ln_bwd<1>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
+        case 2: launch_ln_bwd<2>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
+        case 3: launch_ln_bwd<3>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
+        default: launch_ln_bwd<4>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
+    }
+    MMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((H + 255) / 256, 3), dim3(256), 0, s, partials, grid, H, dgamma, dbeta, dbias,
+                       accumulate);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, void* y,
+                       int B, int T, int S, int H, void* stream) {
+    MMF_CHECK_ARG(ids && word && pos && type && y, "embed_text_fwd: null operand");
+    MMF_CHECK_ARG(B > 0 && T > 0 && S >= T && (H % 4) == 0, "embed_text_fwd: bad shape");
+    hipLaunchKernelGGL(embed_text_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
+                       (bf16*)y, B, T, S, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, const int64_t* idx, int idx_ld, int per_pos,
+                         int idx_base, float* out, int H, int few_buckets, void* stream) {
+    MMF_CHECK_ARG(x && out, "rows_scatter_add: null operand");
+    MMF_CHECK_ARG(nb > 0 && rpb > 0 && (H % 4) == 0 && (ld % 4) == 0, "rows_scatter_add: bad shape");
+    const int total = nb * rpb;
+    if (few_buckets)
+        hipLaunchKernelGGL(scatter_add_few_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld,
+                           nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H);
+    else
+        hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_gather_rows(const void* x, const int64_t* index, void* out, int B, int S, int H, uint32_t drop_key,
+                    uint32_t drop_thr16, float drop_scale, void* stream) {
+    MMF_CHECK_ARG(x && index && out && (H % 4) == 0, "gather_rows: bad operand");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, index, (bf16*)out,
+                       B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale}, 0);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_scatter_rows(const void* dout, const int64_t* index, void* dx, int B, int S, int H, uint32_t drop_key,
+                     uint32_t drop_thr16, float drop_scale, void* stream) {
+    MMF_CHECK_ARG(dout && index && dx && (H % 4) == 0, "scatter_rows: bad operand");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, index,
+                       (bf16*)dx, B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale}, 1);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_colsum_ws_floats(int N) { return CS_GROUPS * N; }
+int mmf_colsum_bf16(const void* x, int ld, int nb, int rpb, int bstride, int N, float* out, float beta, float* partials,
+                    void* stream) {
+    MMF_CHECK_ARG(x && out && partials, "colsum: null operand");
+    MMF_CHECK_ARG(nb > 0 && rpb > 0 && N > 0 && (ld % 4) == 0, "colsum: bad shape");
+    const int groups = grid_for((int64_t)nb * rpb, 4, CS_GROUPS);
+    hipLaunchKernelGGL(colsum_kernel, dim3(groups, (N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb,
+                       bstride, N, partials);
+    MMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, groups, N, out, beta);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    MMF_CHECK_ARG(src && dst && n >= 0, "cast: null operand");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 2048, 4096)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+    MMF_CHECK_ARG(src && dst && n >= 0, "cast: null operand");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, dst, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream) {
+    MMF_CHECK_ARG(mask && out && n > 0, "additive_mask: bad operand");
+    hipLaunchKernelGGL(additive_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, out, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, int B, int N, void* stream) {
+    MMF_CHECK_ARG(scores && targets && loss && B > 0 && N > 0, "bce_fwd: bad operand");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, targets, loss, B, N);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_bce_logits_bwd(const float* scores, const float* targets, const float* gloss, void* dscores, int ldd, int B, int N,
+                       void* stream) {
+    MMF_CHECK_ARG(scores && targets && dscores && B > 0 && N > 0 && ldd >= N, "bce_bwd: bad operand");
+    const int64_t n = (int64_t)B * ldd;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, targets, gloss,
+                       (bf16*)dscores, ldd, B, N);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_adamw_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const int64_t* seg_end,
+                   const float* seg_wd, int nseg, float lr, float beta1, float beta2, float eps, int step, int correct_bias,
+                   int mode, float grad_scale, void* stream) {
+    MMF_CHECK_ARG(p && g && m && v && seg_end && seg_wd && nseg > 0 && n > 0 && step >= 1, "adamw: bad operand");
+    float bc1 = 1.f, bc2 = 1.f;
+    if (correct_bias) {
+        bc1 = 1.f - powf(beta1, (float)step);
+        bc2 = 1.f - powf(beta2, (float)step);
+    }
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p16, n,
+                       seg_end, seg_wd, nseg, lr, beta1, beta2, eps, bc1, bc2, mode, grad_scale);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream) {
+    hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16x8*)a, (const bf16x8*)b, (f32x4*)d);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_probe_mfma32(const void* a, const void* b, float* d, void* stream) {
+    hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16x8*)a, (const bf16x8*)b, (f32x16*)d);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_probe_tr16(const void* img, const int* addr, void* out, void* stream) {
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint4*)img, addr, (s16x4*)out);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

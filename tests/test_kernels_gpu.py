@@ -1,0 +1,378 @@
+"""Per-kernel parity tests (GPU): every HIP kernel, called through the C ABI, against a plain PyTorch
+fp32 reference of the same op evaluated on the SAME bf16-rounded inputs.  Tolerances: bf16 outputs
+carry one rounding (2^-9 relative) plus fp32 accumulation-order noise; fp32 outputs only the latter.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def nat():
+    from mmf_amd import _native
+    return _native
+
+
+def rnd(*shape, scale=1.0, dtype=torch.bfloat16, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xFFFF) + 17)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.float(); ref = ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError("%s: %d/%d elements off, max err %.4g (ref scale %.4g), first bad %s got %.5g ref %.5g" % (
+            what, int(bad.sum()), bad.numel(), float(err.max()), float(ref.abs().max()), idx,
+            float(got[tuple(idx)]), float(ref[tuple(idx)])))
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (384, 768, 768), (100, 200, 72), (32, 3129, 768), (7296, 768, 768)])
+def test_gemm_forward_bias(M, N, K):
+    A = rnd(M, K); B = rnd(N, K); bias = rnd(N, dtype=torch.float32)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(A, B, C, M, N, K, K, K, N, bias=bias)
+    ref = A.float() @ B.float().t() + bias
+    close(C, ref, 1e-2, 2e-2 * math.sqrt(K) / 8, "fwd bf16")
+    # fp32 output (scores head), ragged ldc
+    C32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    nat().gemm(A, B, C32, M, N, K, K, K, N, bias=bias)
+    close(C32, ref, 1e-4, 1e-3 * math.sqrt(K) / 8, "fwd f32")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (384, 768, 3072), (100, 72, 200), (32, 768, 3129)])
+def test_gemm_dgrad_b_kmajor(M, N, K):
+    # dX[M,N] = dY[M,K] W[K,N]  (W row index is the reduction index)
+    ldk = (K + 7) // 8 * 8
+    dY = torch.zeros(M, ldk, dtype=torch.bfloat16, device=DEV)
+    dY[:, :K] = rnd(M, K)
+    W = rnd(K, N) if N % 8 == 0 else None
+    if W is None:
+        pytest.skip("ldb must be a multiple of 8")
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(dY, W, out, M, N, K, ldk, N, N, b_kmajor=True)
+    ref = dY[:, :K].float() @ W.float()
+    close(out, ref, 1e-2, 2e-2 * math.sqrt(K) / 8, "dgrad")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (768, 3072, 7296), (768, 768, 320), (3129, 768, 32), (200, 136, 100)])
+def test_gemm_wgrad_both_kmajor(M, N, K):
+    # dW[M,N] = dY^T X : A = dY [K, M] k-major, B = X [K, N] k-major
+    ldm = (M + 7) // 8 * 8
+    dY = torch.zeros(K, ldm, dtype=torch.bfloat16, device=DEV); dY[:, :M] = rnd(K, M)
+    X = rnd(K, N)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    nat().gemm(dY, X, out, M, N, K, ldm, N, N, a_kmajor=True, b_kmajor=True)
+    ref = dY[:, :M].float().t() @ X.float()
+    close(out, ref, 1e-4, 2e-3 * math.sqrt(K) / 8, "wgrad")
+    # accumulate (beta = 1)
+    nat().gemm(dY, X, out, M, N, K, ldm, N, N, a_kmajor=True, b_kmajor=True, beta=1.0)
+    close(out, 2 * ref, 1e-4, 4e-3 * math.sqrt(K) / 8, "wgrad accumulate")
+
+
+def test_gemm_visual_projection_epilogue():
+    # embeddings.py:352-367: projection(feat) + position_embeddings_visual[0] + token_type_embeddings_visual[type]
+    B, R, T, H, D = 3, 100, 28, 768, 2048
+    S = T + R
+    feat = rnd(B * R, D, dtype=torch.float32).abs()
+    W = rnd(H, D, scale=0.02); bias = rnd(H, dtype=torch.float32)
+    typ = rnd(2, H, dtype=torch.float32); pos0 = rnd(H, dtype=torch.float32)
+    vt = torch.randint(0, 2, (B * R,), device=DEV)
+    y = torch.zeros(B * S, H, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(feat, W, y, B * R, H, D, D, D, H, bias=bias, coladd=pos0, rowtab=typ, rowidx=vt, rowtab_ld=H, grp=(R, T, T))
+    ref = feat.to(torch.bfloat16).float() @ W.float().t() + bias + pos0 + typ[vt]
+    got = y.view(B, S, H)[:, T:, :].reshape(B * R, H)
+    close(got, ref, 1e-2, 3e-2, "visual projection")
+    assert float(y.view(B, S, H)[:, :T].abs().max()) == 0.0
+    # wgrad with fp32 k-major B: dW[H, D] = dV^T feat
+    dV = rnd(B * R, H)
+    dW = torch.empty(H, D, dtype=torch.float32, device=DEV)
+    nat().gemm(dV, feat, dW, H, D, B * R, H, D, D, a_kmajor=True, b_kmajor=True)
+    close(dW, dV.float().t() @ feat.to(torch.bfloat16).float(), 1e-4, 2e-2, "visual wgrad")
+
+
+def test_gemm_gelu_and_dgelu_epilogues():
+    M, N, K = 256, 512, 256
+    A = rnd(M, K); W = rnd(N, K, scale=0.05); bias = rnd(N, dtype=torch.float32)
+    U = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); Hh = torch.empty_like(U)
+    nat().gemm(A, W, Hh, M, N, K, K, K, N, bias=bias, act=1, U=U)
+    u_ref = A.float() @ W.float().t() + bias
+    close(U, u_ref, 1e-2, 2e-2, "pre-activation")
+    close(Hh, torch.nn.functional.gelu(u_ref), 1e-2, 2e-2, "gelu")
+    # dgelu: out = (dY Wd) * gelu'(U)
+    dY = rnd(M, 128); Wd = rnd(128, N, scale=0.1)
+    dU = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(dY, Wd, dU, M, N, 128, 128, N, N, b_kmajor=True, act=2, aux=U)
+    u = U.float().requires_grad_(True)
+    torch.nn.functional.gelu(u).backward(dY.float() @ Wd.float())
+    close(dU, u.grad, 1e-2, 2e-2, "dgelu")
+
+
+def test_gemm_residual_and_dropout_epilogue():
+    M, N, K = 384, 768, 256
+    A = rnd(M, K); W = rnd(N, K, scale=0.05); bias = rnd(N, dtype=torch.float32); R = rnd(M, N)
+    Y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(A, W, Y, M, N, K, K, K, N, bias=bias, resid=R, ldr=N)
+    lin = A.float() @ W.float().t() + bias
+    close(Y, lin + R.float(), 1e-2, 2e-2, "residual")
+    drop = nat().drop_cfg(0.1, 12345)
+    Yd = torch.empty_like(Y)
+    nat().gemm(A, W, Yd, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, drop=drop)
+    d = Yd.float() - R.float()
+    kept = (d - lin * drop[2]).abs() <= 2e-2 + 2e-2 * lin.abs()
+    dropped = d.abs() <= 2e-2
+    assert bool((kept | dropped).all())
+    frac = float((~kept & dropped).float().mean())
+    assert 0.08 < frac < 0.12, frac
+    # LayerNorm-backward's dropout mask must be the same mask (same key / index convention)
+    mean = torch.zeros(M, device=DEV); rstd = torch.ones(M, device=DEV); gamma = torch.ones(N, device=DEV)
+    dy = rnd(M, N); x = rnd(M, N)
+    dx = torch.empty_like(dy); dlin = torch.empty_like(dy)
+    ws = torch.empty(nat().layernorm_bwd_ws_floats(N), device=DEV)
+    nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, None, None, None, 0, ws, M, N)
+    mask_ln = (dlin.float().abs() > 0) | (dx.float().abs() == 0)
+    mask_gemm = ~(~kept & dropped)
+    agree = float((mask_ln == mask_gemm).float().mean())
+    assert agree > 0.999, agree
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def attn_ref(q, k, v, mask, scale, pmask=None, pscale=1.0):
+    # q,k,v [B, heads, S, 64] fp32; mask [B, Sk] additive
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s + mask[:, None, None, :]
+    p = torch.softmax(s, dim=-1)
+    lse = torch.logsumexp(s, dim=-1)
+    if pmask is not None:
+        p = p * pmask * pscale
+    return torch.matmul(p, v), lse
+
+
+def split_heads(x, B, S, heads):
+    return x.view(B, S, heads, 64).permute(0, 2, 1, 3).float()
+
+
+@pytest.mark.parametrize("B,heads,S", [(2, 3, 228), (1, 2, 100), (1, 1, 256), (2, 2, 33), (1, 12, 128)])
+def test_attention_forward_backward(B, heads, S):
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, scale=1.0)
+    mbin = (torch.rand(B, S, device=DEV) > 0.2).long()
+    mbin[:, 0] = 1
+    mask = torch.empty(B, S, device=DEV)
+    nat().make_additive_mask(mbin, mask)
+    assert torch.equal(mask, (1.0 - mbin.float()) * -10000.0)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, S, device=DEV)
+    scale = 1.0 / math.sqrt(64)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    nat().attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, scale)
+    qf = split_heads(qkv[:, :H].contiguous(), B, S, heads).requires_grad_(True)
+    kf = split_heads(qkv[:, H:2 * H].contiguous(), B, S, heads).requires_grad_(True)
+    vf = split_heads(qkv[:, 2 * H:].contiguous(), B, S, heads).requires_grad_(True)
+    o_ref, lse_ref = attn_ref(qf, kf, vf, mask, scale)
+    got = split_heads(ctx, B, S, heads)
+    close(got, o_ref, 2e-2, 2e-2, "attention ctx")
+    close(lse, lse_ref, 1e-4, 2e-3, "lse")
+    # backward
+    dctx = rnd(B * S, H)
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B, heads, S, device=DEV)
+    nat().attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, scale, dctx,
+                        dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta)
+    o_ref.backward(split_heads(dctx, B, S, heads))
+    for name, got_, ref_ in (("dq", dqkv[:, :H], qf.grad), ("dk", dqkv[:, H:2 * H], kf.grad), ("dv", dqkv[:, 2 * H:], vf.grad)):
+        g = split_heads(got_.contiguous(), B, S, heads)
+        close(g, ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name)
+
+
+def test_attention_fully_masked_rows_are_uniform():
+    # additive -10000 (not -inf): a row whose keys are all masked attends uniformly
+    B, heads, S = 1, 1, 64
+    H = 64
+    qkv = rnd(B * S, 3 * H)
+    mask = torch.full((B, S), -10000.0, device=DEV)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, S, device=DEV)
+    nat().attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, 0.125)
+    qf, kf, vf = (split_heads(qkv[:, i * H:(i + 1) * H].contiguous(), B, S, heads) for i in range(3))
+    o_ref, _ = attn_ref(qf, kf, vf, mask, 0.125)
+    close(split_heads(ctx, B, S, heads), o_ref, 2e-2, 2e-2, "masked rows")
+    assert torch.isfinite(ctx.float()).all()
+
+
+def test_attention_dropout_consistent_between_forward_and_backward():
+    # With Sk = 64 and V = I the context IS the dropped probability matrix, which exposes the mask.
+    B, heads, S = 2, 2, 64
+    H = heads * 64
+    qk = rnd(B * S, 2 * H)
+    eye = torch.eye(64, device=DEV, dtype=torch.bfloat16)
+    v = eye.repeat(B, heads).contiguous()  # [B*S, H]: row s of every head = e_s
+    qkv = torch.cat([qk, v], dim=1).contiguous()
+    drop = nat().drop_cfg(0.1, 777)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, S, device=DEV)
+    scale = 0.125
+    nat().attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, ctx, H, lse, B, heads, S, S, scale, drop)
+    qf, kf, vf = (split_heads(qkv[:, i * H:(i + 1) * H].contiguous(), B, S, heads).requires_grad_(True) for i in range(3))
+    p_ref = torch.softmax(torch.matmul(qf, kf.transpose(-1, -2)) * scale, dim=-1)
+    pd = split_heads(ctx, B, S, heads)  # [B, heads, q, key]
+    pmask = (pd > 0.5 * p_ref * drop[2]).float()
+    frac = 1.0 - float(pmask.mean())
+    assert 0.07 < frac < 0.13, frac
+    close(pd, p_ref * pmask * drop[2], 2e-2, 2e-3, "dropped probabilities")
+    # backward with the same mask
+    dctx = rnd(B * S, H)
+    dqkv = torch.zeros_like(qkv); delta = torch.empty(B, heads, S, device=DEV)
+    nat().attention_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, ctx, H, lse, B, heads, S, S, scale,
+                        dctx, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta, drop)
+    o_ref, _ = attn_ref(qf, kf, vf, None, scale, pmask, drop[2])
+    o_ref.backward(split_heads(dctx, B, S, heads))
+    for name, i, ref_ in (("dq", 0, qf.grad), ("dk", 1, kf.grad), ("dv", 2, vf.grad)):
+        g = split_heads(dqkv[:, i * H:(i + 1) * H].contiguous(), B, S, heads)
+        close(g, ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name + " (dropout)")
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,H", [(7296, 768), (33, 768), (64, 1024), (5, 64), (12, 256)])
+def test_layernorm_forward_backward(rows, H):
+    x = rnd(rows, H, scale=2.0); gamma = rnd(H, dtype=torch.float32) + 1.0; beta = rnd(H, dtype=torch.float32)
+    y = torch.empty_like(x); mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    nat().layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, H, 1e-12)
+    xf = x.float().requires_grad_(True); g = gamma.clone().requires_grad_(True); b = beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (H,), g, b, 1e-12)
+    close(y, ref, 1e-2, 1e-2, "ln fwd")
+    close(mean, xf.mean(-1), 1e-4, 1e-5, "mean")
+    dy = rnd(rows, H)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(H, device=DEV); dbeta = torch.empty(H, device=DEV); dbias = torch.empty(H, device=DEV)
+    ws = torch.empty(nat().layernorm_bwd_ws_floats(H), device=DEV)
+    nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, (0, 0, 1.0), dgamma, dbeta, dbias, 0, ws, rows, H)
+    ref.backward(dy.float())
+    close(dx, xf.grad, 1e-2, 1e-2 * float(xf.grad.abs().max()), "ln dx")
+    close(dgamma, g.grad, 1e-3, 1e-3 * float(g.grad.abs().max()) + 1e-4, "dgamma")
+    close(dbeta, b.grad, 1e-3, 1e-3 * float(b.grad.abs().max()) + 1e-4, "dbeta")
+    close(dbias, dx.float().sum(0), 1e-3, 1e-3 * float(dx.float().sum(0).abs().max()) + 1e-4, "dbias")
+    # accumulate flag
+    nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, (0, 0, 1.0), dgamma, dbeta, None, 1, ws, rows, H)
+    close(dgamma, 2 * g.grad, 1e-3, 2e-3 * float(g.grad.abs().max()) + 1e-4, "dgamma accumulate")
+
+
+# ---------------------------------------------------------------------------------------------
+# embeddings / row utilities / loss / optimizer
+# ---------------------------------------------------------------------------------------------
+def test_embed_text_and_scatter_add():
+    B, T, S, H, V = 4, 16, 24, 768, 1000
+    ids = torch.randint(0, V, (B, T), device=DEV); seg = torch.randint(0, 2, (B, T), device=DEV)
+    word = rnd(V, H, dtype=torch.float32); pos = rnd(64, H, dtype=torch.float32); typ = rnd(2, H, dtype=torch.float32)
+    y = torch.zeros(B * S, H, dtype=torch.bfloat16, device=DEV)
+    nat().embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H)
+    ref = word[ids] + pos[torch.arange(T, device=DEV)][None] + typ[seg]
+    close(y.view(B, S, H)[:, :T], ref, 1e-2, 1e-2, "embed text")
+    # backward scatters
+    d = rnd(B * S, H)
+    d3 = d.view(B, S, H).float()
+    dword = torch.zeros(V, H, device=DEV)
+    nat().rows_scatter_add(d, H, B, T, S, ids, T, 0, 0, dword, H, 0)
+    close(dword, torch.zeros(V, H, device=DEV).index_add_(0, ids.view(-1), d3[:, :T].reshape(-1, H)), 1e-4, 1e-4, "dword")
+    dpos = torch.zeros(64, H, device=DEV)
+    nat().rows_scatter_add(d, H, B, T, S, None, 0, 1, 0, dpos, H, 0)
+    close(dpos[:T], d3[:, :T].sum(0), 1e-4, 1e-4, "dpos")
+    dtyp = torch.zeros(2, H, device=DEV)
+    nat().rows_scatter_add(d, H, B, T, S, seg, T, 0, 0, dtyp, H, 1)
+    close(dtyp, torch.zeros(2, H, device=DEV).index_add_(0, seg.view(-1), d3[:, :T].reshape(-1, H)), 1e-4, 1e-3, "dtype")
+    # visual rows: bucket 0 for every row (position_ids_visual = 0, embeddings.py:411-419)
+    dpv = torch.zeros(4, H, device=DEV)
+    nat().rows_scatter_add(d[T:], H, B, S - T, S, None, 0, 0, 0, dpv, H, 1)
+    close(dpv[0], d3[:, T:].sum((0, 1)), 1e-4, 1e-3, "dpos_visual")
+
+
+def test_gather_scatter_colsum_cast():
+    B, S, H = 8, 20, 768
+    x = rnd(B * S, H); idx = torch.randint(0, S, (B,), device=DEV)
+    out = torch.empty(B, H, dtype=torch.bfloat16, device=DEV)
+    nat().gather_rows(x, idx, out, B, S, H)
+    assert torch.equal(out, x.view(B, S, H)[torch.arange(B), idx])
+    dx = torch.zeros_like(x)
+    nat().scatter_rows(out, idx, dx, B, S, H)
+    ref = torch.zeros_like(x).view(B, S, H); ref[torch.arange(B), idx] = out
+    assert torch.equal(dx.view(B, S, H), ref)
+    drop = nat().drop_cfg(0.1, 9)
+    o2 = torch.empty_like(out); nat().gather_rows(x, idx, o2, B, S, H, drop)
+    d2 = torch.zeros_like(x); nat().scatter_rows(out, idx, d2, B, S, H, drop)
+    assert torch.equal(o2 == 0, d2.view(B, S, H)[torch.arange(B), idx] == 0)
+    # colsum
+    for N in (768, 3072, 2304, 100):
+        m = rnd(300, N)
+        o = torch.empty(N, device=DEV); ws = torch.empty(nat().colsum_ws_floats(N), device=DEV)
+        nat().colsum(m, N, 1, 300, 0, N, o, 0.0, ws)
+        close(o, m.float().sum(0), 1e-4, 1e-3, "colsum")
+    m = rnd(4 * 10, 768)
+    o = torch.empty(768, device=DEV); ws = torch.empty(nat().colsum_ws_floats(768), device=DEV)
+    nat().colsum(m[3:], 768, 4, 5, 10, 768, o, 0.0, ws)   # rows 3..7 of each group of 10
+    close(o, m.view(4, 10, 768)[:, 3:8].float().sum((0, 1)), 1e-4, 1e-3, "colsum groups")
+    # casts
+    f = rnd(100003, dtype=torch.float32)
+    h = torch.empty(100003, dtype=torch.bfloat16, device=DEV)
+    nat().cast_f32_to_bf16(f, h)
+    assert torch.equal(h, f.to(torch.bfloat16))
+    f2 = torch.empty_like(f); nat().cast_bf16_to_f32(h, f2)
+    assert torch.equal(f2, h.float())
+
+
+def test_bce_logits_loss():
+    B, N = 32, 3129
+    x = rnd(B, N, dtype=torch.float32, scale=3.0).contiguous()
+    t = (torch.rand(B, N, device=DEV) > 0.99).float() * 0.6
+    loss = torch.empty(1, device=DEV)
+    nat().bce_logits_fwd(x, t, loss, B, N)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, t, reduction="mean") * N
+    close(loss[0], ref.detach(), 1e-5, 1e-5, "bce loss")
+    ref.backward()
+    ldd = 3136
+    d = torch.full((B, ldd), 7.0, dtype=torch.bfloat16, device=DEV)
+    nat().bce_logits_bwd(x, t, None, d, ldd, B, N)
+    close(d[:, :N], xr.grad, 1e-2, 1e-5, "bce grad")
+    assert float(d[:, N:].abs().max()) == 0.0
+
+
+def test_adamw_matches_reference_rules():
+    n = 5000
+    p0 = rnd(n, dtype=torch.float32); g = rnd(n, dtype=torch.float32)
+    seg_end = torch.tensor([2000, 5000], device=DEV); seg_wd = torch.tensor([0.01, 0.0], device=DEV)
+    lr, b1, b2, eps = 5e-3, 0.9, 0.999, 1e-8
+    # torch.optim.AdamW (mode 1)
+    params = [p0[:2000].clone().requires_grad_(True), p0[2000:].clone().requires_grad_(True)]
+    opt = torch.optim.AdamW([{"params": [params[0]], "weight_decay": 0.01}, {"params": [params[1]], "weight_decay": 0.0}], lr=lr, betas=(b1, b2), eps=eps)
+    p = p0.clone(); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV); p16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in (1, 2, 3):
+        params[0].grad = g[:2000].clone(); params[1].grad = g[2000:].clone()
+        opt.step()
+        nat().adamw_step(p, g, m, v, p16, n, seg_end, seg_wd, 2, lr, b1, b2, eps, step, 1, 1, 1.0)
+    close(p, torch.cat([params[0].detach(), params[1].detach()]), 1e-5, 1e-6, "adamw torch mode")
+    assert torch.equal(p16, p.to(torch.bfloat16))
+    # transformers.AdamW rule (mode 0), restated
+    p = p0.clone(); m.zero_(); v.zero_()
+    pr = p0.clone(); mr = torch.zeros(n, device=DEV); vr = torch.zeros(n, device=DEV)
+    wd = torch.cat([torch.full((2000,), 0.01, device=DEV), torch.zeros(3000, device=DEV)])
+    for step in (1, 2):
+        nat().adamw_step(p, g, m, v, None, n, seg_end, seg_wd, 2, lr, b1, b2, eps, step, 1, 0, 1.0)
+        mr = b1 * mr + (1 - b1) * g; vr = b2 * vr + (1 - b2) * g * g
+        ss = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        pr = pr - ss * mr / (vr.sqrt() + eps)
+        pr = pr - lr * wd * pr
+    close(p, pr, 1e-5, 1e-6, "adamw hf mode")

@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads and exports every symbol that
+include/mmf_amd.h declares (no compute calls here: there is no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mmf_amd import _native
+
+
+def _declared_functions():
+    src = open(_native.HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(mmf_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    if not os.path.exists(_native.LIB_PATH):
+        from mmf_amd.csrc.build import build
+        build(verbose=False)
+    return ctypes.CDLL(_native.LIB_PATH)
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared_functions()
+    for required in ("mmf_gemm_bf16", "mmf_attention_fwd", "mmf_attention_bwd", "mmf_layernorm_fwd",
+                     "mmf_layernorm_bwd", "mmf_embed_text_fwd", "mmf_bce_logits_fwd", "mmf_adamw_step"):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    missing = [n for n in _declared_functions() if not hasattr(built_lib, n)]
+    assert not missing, "declared in include/mmf_amd.h but not exported: %s" % missing
+
+
+def test_abi_version_and_target(built_lib):
+    built_lib.mmf_amd_target.restype = ctypes.c_char_p
+    assert built_lib.mmf_amd_abi_version() == 1
+    assert built_lib.mmf_amd_target() == b"gfx950"
+
+
+def test_binding_structs_match_header_field_order():
+    src = open(_native.HEADER_PATH).read()
+    body = re.search(r"typedef struct mmf_gemm_desc \{(.*?)\} mmf_gemm_desc;", src, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = names[0].split()[-1].lstrip("*")
+        fields.append(first)
+        fields.extend(n.strip().lstrip("*") for n in names[1:])
+    assert fields == [f[0] for f in _native.GemmDesc._fields_]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeLibraryError):
+        _native.lib()
+
+
+def test_argument_errors_are_reported_not_swallowed(built_lib):
+    built_lib.mmf_amd_last_error.restype = ctypes.c_char_p
+    d = _native.GemmDesc()
+    rc = built_lib.mmf_gemm_bf16(ctypes.byref(d), None)
+    assert rc != 0
+    assert b"null operand" in built_lib.mmf_amd_last_error()

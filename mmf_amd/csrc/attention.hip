@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     // dropout on the probabilities (hf_layers.py:201), index ((bh*Sq + q)*SKP + key)
     if (a.drop.thr16) {
-        const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)SKP;
+        const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int s = 0; s < 4; ++s) { qf[s] = frag_global(qptr, s, lane); dof[s] = frag_global(doptr, s, lane); }
     const float L = a.lse[(size_t)bh * a.Sq + qrow];
     const float dl = a.delta[(size_t)bh * a.Sq + qrow];
-    const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)SKP;
+    const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
 
     f32x16 dqo[2] = {};
 #pragma unroll

@@ -141,10 +141,11 @@ def test_gemm_residual_and_dropout_epilogue():
     dx = torch.empty_like(dy); dlin = torch.empty_like(dy)
     ws = torch.empty(nat().layernorm_bwd_ws_floats(N), device=DEV)
     nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, None, None, None, 0, ws, M, N)
-    mask_ln = (dlin.float().abs() > 0) | (dx.float().abs() == 0)
-    mask_gemm = ~(~kept & dropped)
-    agree = float((mask_ln == mask_gemm).float().mean())
-    assert agree > 0.999, agree
+    sel = (lin.abs() > 0.1) & (dx.float().abs() > 0)     # elements where both masks are observable
+    mask_ln = dlin.float().abs() > 0
+    mask_gemm = d.abs() > 0.05
+    assert int(sel.sum()) > 0.5 * sel.numel()
+    assert torch.equal(mask_ln[sel], mask_gemm[sel])
 
 
 # ---------------------------------------------------------------------------------------------

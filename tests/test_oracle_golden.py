@@ -1,0 +1,65 @@
+"""Pins the CPU oracle (oracle/visual_bert_oracle.py) against fixtures produced by the REAL reference
+implementation (tests/golden/make_golden.py ran /root/reference's VisualBERT + LogitBinaryCrossEntropy).
+fp32 vs fp32 on CPU: tolerances are accumulation-order noise only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import visual_bert_oracle as O
+from tests.golden_utils import load_case
+
+
+@pytest.mark.parametrize("name", ["tiny", "small64"])
+def test_oracle_matches_reference_forward_loss_and_gradients(name):
+    z, case, cfg, sd, sample = load_case(name)
+    # the oracle's parameter inventory is the reference's state dict, name for name and shape for shape
+    shapes = O.parameter_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in shapes.items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.visual_bert_forward(sd, cfg, sample, train=False, return_hidden=True)
+    np.testing.assert_allclose(out["scores"].detach().numpy(), z["scores"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out["sequence_output"].detach().numpy(), z["sequence_output"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(out["pooled_output"].detach().numpy(), z["pooled_output"], rtol=1e-5, atol=5e-6)
+    loss = O.logit_bce(out["scores"], sample["targets"])
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    for gname, norm, gsum in zip(z["grad_names"], z["grad_norms"], z["grad_sums"]):
+        key = str(gname)[len("model."):]
+        g = sd[key].grad
+        if norm == 0.0:
+            # the pooler is computed and discarded under pooler_strategy == "vqa": no gradient
+            assert g is None or float(g.abs().max()) == 0.0, key
+            continue
+        assert g is not None, key
+        assert abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+        assert abs(float(g.double().sum()) - gsum) <= 1e-4 * norm + 1e-7, key
+        full = "grad::model." + key
+        if full in z.files:
+            np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
+
+
+def test_pooler_has_no_gradient_under_vqa_pooling():
+    z, case, cfg, sd, sample = load_case("tiny")
+    names = [str(n) for n in z["grad_names"]]
+    norms = dict(zip(names, z["grad_norms"]))
+    assert norms["model.bert.pooler.dense.weight"] == 0.0 and norms["model.bert.pooler.dense.bias"] == 0.0
+
+
+def test_attention_mask_is_additive_minus_10000():
+    """A fully masked key set still yields finite, uniform attention (mask is -10000, not -inf;
+    visual_bert.py:106) -- every query row then averages the values."""
+    z, case, cfg, sd, sample = load_case("tiny")
+    ids, input_mask, attn, tt, feats, vtype = O.prepare_inputs(sample)
+    seq, pooled, hidden = O.visual_bert_base(sd, cfg, ids, torch.zeros_like(attn), tt, feats, vtype)
+    assert torch.isfinite(seq).all()
+    ref, _, _ = O.visual_bert_base(sd, cfg, ids, torch.ones_like(attn), tt, feats, vtype)
+    # all-masked == all-visible: a constant shift of every score leaves the softmax unchanged
+    assert torch.allclose(seq, ref, atol=1e-4)
+
+
+def test_synthetic_batch_contract():
+    cfg = dict(O.DEFAULT_CONFIG)
+    b = O.synthetic_batch(cfg, 4, seed=3)
+    assert b["input_ids"].shape == (4, 128) and b["image_feature_0"].shape == (4, 100, 2048)
+    assert b["targets"].shape == (4, 3129) and float(b["targets"].sum()) == pytest.approx(4 * 1.9)
+    assert int(b["input_mask"].sum()) == 4 * 128

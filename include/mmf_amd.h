@@ -167,6 +167,15 @@ int mmf_colsum_bf16(const void* x, int ld, int nb, int rpb, int bstride, int N, 
                     float* partials, void* stream);
 int mmf_colsum_ws_floats(int N);
 int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* 2-D casts with leading dimensions (elements); f32->bf16 zero-fills the pad columns [cols, ldd). */
+int mmf_cast2d_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int rows, int cols, void* stream);
+int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int rows, int cols, void* stream);
+/* y[i] = x[i] * keep_scale(i): nn.Dropout forward AND backward (embeddings.py:458), bf16, n < 2^32. */
+int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
+                     void* stream);
+/* du = dh * gelu_erf'(u): backward of HF BertIntermediate's activation when it is not fused into
+ * the producing GEMM's epilogue (mmf_gemm_desc.act == 2). */
+int mmf_gelu_bwd_bf16(const void* dh, const void* u, void* du, int64_t n, void* stream);
 int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* mask_add[b][s] = (1 - mask[b][s]) * -10000  (visual_bert.py:94-106); mask int64 [B,S]. */
 int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream);

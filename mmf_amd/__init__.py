@@ -1,0 +1,12 @@
+"""mmf_amd — MI355X (gfx950 / CDNA4) native implementation of MMF's cross-modal transformer fusion
+hot path (VisualBERT first), behind MMF's registry / BaseModel / SampleList API.
+
+Importing the package registers the HIP-backed components in `mmf_amd.common.registry.registry`
+the same way `mmf.utils.env.setup_imports` fills MMF's registry.
+"""
+from mmf_amd.common.registry import registry  # noqa: F401
+from mmf_amd.common.sample import Sample, SampleList  # noqa: F401
+from mmf_amd.modules import losses as _losses  # noqa: F401
+from mmf_amd.models import visual_bert as _visual_bert  # noqa: F401
+
+__version__ = "0.1.0"

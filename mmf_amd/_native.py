@@ -254,6 +254,28 @@ def cast_bf16_to_f32(src, dst, n=None):
     _check(lib().mmf_cast_bf16_to_f32(_p(src), _p(dst), C.c_int64(n), _stream()), "mmf_cast_bf16_to_f32")
 
 
+def cast2d_f32_to_bf16(src, lds, dst, ldd, rows, cols):
+    _req(src, torch.float32, "src"); _req(dst, torch.bfloat16, "dst")
+    _check(lib().mmf_cast2d_f32_to_bf16(_p(src), lds, _p(dst), ldd, rows, cols, _stream()), "mmf_cast2d_f32_to_bf16")
+
+
+def cast2d_bf16_to_f32(src, lds, dst, ldd, rows, cols):
+    _req(src, torch.bfloat16, "src"); _req(dst, torch.float32, "dst")
+    _check(lib().mmf_cast2d_bf16_to_f32(_p(src), lds, _p(dst), ldd, rows, cols, _stream()), "mmf_cast2d_bf16_to_f32")
+
+
+def dropout(x, y, drop):
+    _req(x, torch.bfloat16, "x"); _req(y, torch.bfloat16, "y")
+    _check(lib().mmf_dropout_bf16(_p(x), _p(y), C.c_int64(x.numel()), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
+                                  C.c_float(drop[2]), _stream()), "mmf_dropout_bf16")
+
+
+def gelu_bwd(dh, u, du):
+    for t, nme in ((dh, "dh"), (u, "u"), (du, "du")):
+        _req(t, torch.bfloat16, nme)
+    _check(lib().mmf_gelu_bwd_bf16(_p(dh), _p(u), _p(du), C.c_int64(dh.numel()), _stream()), "mmf_gelu_bwd_bf16")
+
+
 def make_additive_mask(mask, out):
     _req(mask, torch.int64, "mask"); _req(out, torch.float32, "out")
     _check(lib().mmf_make_additive_mask(_p(mask), _p(out), C.c_int64(mask.numel()), _stream()), "mmf_make_additive_mask")

@@ -312,6 +312,38 @@ __global__ void additive_mask_kernel(const int64_t* __restrict__ m, float* __res
     if (i < n) out[i] = (1.0f - (float)m[i]) * -10000.0f;
 }
 
+// y = x * keep_scale(index)  (forward and backward of nn.Dropout are the same map)
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n, DropoutCfg d) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) store4(y + i, load4(x + i) * drop_scale4(d.key, (uint32_t)i, d.thr16, d.scale));
+        else for (int64_t j = i; j < n; ++j) y[j] = (bf16)((float)x[j] * drop_scale1(d.key, (uint32_t)j, d.thr16, d.scale));
+    }
+}
+// du = dh * gelu'(u)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ u, bf16* __restrict__ du, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const f32x4 a = load4(dh + i), b = load4(u + i);
+            store4(du + i, f32x4{a[0] * gelu_erf_grad(b[0]), a[1] * gelu_erf_grad(b[1]), a[2] * gelu_erf_grad(b[2]), a[3] * gelu_erf_grad(b[3])});
+        } else for (int64_t j = i; j < n; ++j) du[j] = (bf16)((float)dh[j] * gelu_erf_grad((float)u[j]));
+    }
+}
+// 2-D casts with leading dimensions; destination pad columns [cols, ldd) are zero-filled
+__global__ __launch_bounds__(256) void cast2d_f32_bf16_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, int rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * ldd) return;
+    const int r = (int)(i / ldd), c = (int)(i - (int64_t)r * ldd);
+    dst[i] = (c < cols) ? (bf16)src[(size_t)r * lds_ + c] : (bf16)0.f;
+}
+__global__ __launch_bounds__(256) void cast2d_bf16_f32_kernel(const bf16* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    dst[(size_t)r * ldd + c] = (float)src[(size_t)r * lds_ + c];
+}
+
 // ------------------------------------------------------------------------------------------------
 // BCE with logits (losses.py:246-251)
 // ------------------------------------------------------------------------------------------------
@@ -548,6 +580,37 @@ int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
 int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream) {
     MMF_CHECK_ARG(mask && out && n > 0, "additive_mask: bad operand");
     hipLaunchKernelGGL(additive_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, out, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, void* stream) {
+    MMF_CHECK_ARG(x && y && n > 0 && n < ((int64_t)1 << 32), "dropout: bad operand");
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n,
+                       DropoutCfg{drop_key, drop_thr16, drop_scale});
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_gelu_bwd_bf16(const void* dh, const void* u, void* du, int64_t n, void* stream) {
+    MMF_CHECK_ARG(dh && u && du && n > 0, "gelu_bwd: bad operand");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh, (const bf16*)u,
+                       (bf16*)du, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_cast2d_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int rows, int cols, void* stream) {
+    MMF_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "cast2d: bad operand");
+    const int64_t n = (int64_t)rows * ldd;
+    hipLaunchKernelGGL(cast2d_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, lds, (bf16*)dst,
+                       ldd, rows, cols);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int rows, int cols, void* stream) {
+    MMF_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "cast2d: bad operand");
+    const int64_t n = (int64_t)rows * cols;
+    hipLaunchKernelGGL(cast2d_bf16_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, lds,
+                       dst, ldd, rows, cols);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,524 @@
+"""Autograd surface of the MI355X kernels: `torch.autograd.Function`s whose forward AND backward
+are hand-written HIP kernels called through the C ABI (mmf_amd/_native.py -> libmmf_amd.so).
+
+Activations travel in bf16 (HBM-resident, token-major `[B*S, H]`), parameters stay fp32 masters
+with the reference's names and shapes; each Function takes the bf16 *shadow* of its weights (see
+`ShadowCache`) next to the fp32 parameter so that autograd still delivers fp32 parameter gradients.
+Nothing here falls back to eager PyTorch math: torch is used for allocation, views and autograd
+bookkeeping only.
+
+Reference ops replaced (paths relative to the reference root):
+  LinearFn                  nn.Linear                                      (hf_layers.py:169-180, visual_bert.py:330)
+  SelfAttentionFn           BertSelfAttentionJit.forward                   (hf_layers.py:161-213)
+  DenseDropoutResidualLNFn  HF BertSelfOutput / BertOutput                 (call sites hf_layers.py:248,290)
+  DenseGeluFn               HF BertIntermediate                            (call site hf_layers.py:289)
+  FeedForwardFn             BertIntermediate + BertOutput fused            (hf_layers.py:289-290)
+  LayerNormFn               nn.LayerNorm                                   (visual_bert.py:328)
+  VisioLinguisticEmbeddingsFn  BertVisioLinguisticEmbeddings.forward       (embeddings.py:423-459)
+  GatherRowsFn              torch.gather + Dropout of the `vqa` pooler     (visual_bert.py:389-400)
+  LogitBCEFn                LogitBinaryCrossEntropy                        (losses.py:246-251)
+"""
+import math
+import weakref
+
+import torch
+
+from mmf_amd import _native as nat
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# dropout keys
+# ---------------------------------------------------------------------------------------------
+class _DropoutKeys:
+    """Per-site dropout keys: mix(torch seed, running counter).  `torch.manual_seed(s)` therefore
+    reproduces the masks; backward re-uses the key saved by forward."""
+
+    def __init__(self):
+        self.seed = None
+        self.counter = 0
+
+    def next(self):
+        seed = torch.initial_seed()
+        if seed != self.seed:
+            self.seed, self.counter = seed, 0
+        self.counter += 1
+        x = (seed * 0x9E3779B97F4A7C15 + self.counter * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        return (x * 0x94D049BB133111EB >> 16) & 0xFFFFFFFF
+
+
+dropout_keys = _DropoutKeys()
+
+
+def make_drop(p, training):
+    if not training or p is None or p <= 0.0:
+        return (0, 0, 1.0)
+    return nat.drop_cfg(p, dropout_keys.next())
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 shadows of fp32 master parameters
+# ---------------------------------------------------------------------------------------------
+class ShadowCache:
+    """bf16 copies of fp32 parameters, refreshed (one cast kernel) whenever the parameter's version
+    counter or storage changes.  Several parameters can share one contiguous shadow (Q|K|V)."""
+
+    def __init__(self):
+        self._store = weakref.WeakKeyDictionary()
+
+    def get(self, *params, dtype=BF16):
+        head = params[0]
+        ent = self._store.get(head)
+        sig = tuple((p._version, p.data_ptr()) for p in params)
+        if ent is not None and ent[0] == sig and ent[2] == dtype:
+            return ent[1]
+        rows = sum(p.shape[0] for p in params)
+        shape = (rows,) + tuple(head.shape[1:])
+        buf = ent[1] if ent is not None and ent[1].shape == shape and ent[2] == dtype else torch.empty(
+            shape, dtype=dtype, device=head.device)
+        r = 0
+        for p in params:
+            n = p.shape[0]
+            src = p.detach()
+            if not src.is_contiguous():
+                src = src.contiguous()
+            if dtype == BF16:
+                nat.cast_f32_to_bf16(src, buf[r:r + n])
+            else:
+                buf[r:r + n].copy_(src)
+            r += n
+        self._store[head] = (sig, buf, dtype)
+        return buf
+
+
+shadows = ShadowCache()
+
+
+def _as_bf16_2d(x):
+    """Token-major bf16 view [rows, features] of an activation (casts fp32 inputs once)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype != BF16:
+        if x2.dtype != F32:
+            x2 = x2.float()
+        out = torch.empty(x2.shape, dtype=BF16, device=x2.device)
+        nat.cast_f32_to_bf16(x2.contiguous(), out)
+        return out
+    return x2 if x2.is_contiguous() else x2.contiguous()
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _grad_bf16(g, cols):
+    """bf16, contiguous, ld == cols (cols % 8 == 0) version of an incoming gradient."""
+    g2 = g.reshape(-1, g.shape[-1])
+    if g2.dtype == BF16 and g2.is_contiguous():
+        return g2
+    return _as_bf16_2d(g2)
+
+
+# ---------------------------------------------------------------------------------------------
+# shared forward/backward pieces
+# ---------------------------------------------------------------------------------------------
+def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=None):
+    """dy [M,N] bf16 (row stride ldy, pad columns zero), x [M,K] bf16, w16 [N,K].
+    Returns (dx [M,K] bf16 or None, dW [N,K] fp32)."""
+    dev = dy.device
+    dx = None
+    if need_dx:
+        dx = torch.empty(M, K, dtype=BF16, device=dev)
+        nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
+                 act=2 if act_aux is not None else 0, aux=act_aux)
+    dw = torch.empty(N, K, dtype=F32, device=dev)
+    nat.gemm(dy, x, dw, N, K, M, ldy, x.stride(0), K, a_kmajor=True, b_kmajor=True)
+    return dx, dw
+
+
+def _colsum(x, ld, rows, N):
+    out = torch.empty(N, dtype=F32, device=x.device)
+    ws = torch.empty(nat.colsum_ws_floats(N), dtype=F32, device=x.device)
+    nat.colsum(x, ld, 1, rows, 0, N, out, 0.0, ws)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear
+# ---------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b.  x [*, K] (bf16 or fp32), weight [N, K] fp32 master + bf16 shadow, y bf16 or fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, out_f32):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        N = weight.shape[0]
+        y = torch.empty(M, N, dtype=F32 if out_f32 else BF16, device=x2.device)
+        nat.gemm(x2, w16, y, M, N, K, K, K, N, bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(x2, w16)
+        ctx.dims = (M, N, K, x.shape, bias is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w16 = ctx.saved_tensors
+        M, N, K, xshape, has_bias = ctx.dims
+        ldy = _pad8(N)
+        g2 = gy.reshape(M, N)
+        if g2.dtype == BF16 and N == ldy and g2.is_contiguous():
+            dy = g2
+        else:
+            dy = torch.empty(M, ldy, dtype=BF16, device=gy.device)
+            if g2.dtype == BF16:
+                g2 = g2.float()
+            nat.cast2d_f32_to_bf16(g2.contiguous(), N, dy, ldy, M, N)
+        dx, dw = _linear_bwd(dy, ldy, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
+        db = _colsum(dy, ldy, M, N) if has_bias else None
+        return (dx.view(xshape) if dx is not None else None), dw, db, None, None
+
+
+def linear(x, weight, bias, out_f32=False):
+    return LinearFn.apply(x, weight, bias, shadows.get(weight), out_f32)
+
+
+# ---------------------------------------------------------------------------------------------
+# self attention (QKV projection + fused attention)
+# ---------------------------------------------------------------------------------------------
+def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop):
+    M, H = x2.shape
+    dev = x2.device
+    qkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
+    nat.gemm(x2, wqkv16, qkv, M, 3 * H, H, H, H, 3 * H, bias=bqkv)
+    ctxt = torch.empty(M, H, dtype=BF16, device=dev)
+    lse = torch.empty(B, heads, S, dtype=F32, device=dev)
+    scale = 1.0 / math.sqrt(H // heads)
+    nat.attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale, drop)
+    return qkv, ctxt, lse
+
+
+def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True):
+    M, H = x2.shape
+    dev = x2.device
+    dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
+    delta = torch.empty(B, heads, S, dtype=F32, device=dev)
+    scale = 1.0 / math.sqrt(H // heads)
+    nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
+                      dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop)
+    dx, dw = _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid)
+    db = _colsum(dqkv, 3 * H, M, 3 * H)
+    return dx, dw, db
+
+
+class SelfAttentionFn(torch.autograd.Function):
+    """BertSelfAttentionJit.forward: returns the context layer [B, S, H] (bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wqkv16, bqkv, mask_add, heads, drop):
+        B, S, H = x.shape
+        x2 = _as_bf16_2d(x)
+        qkv, ctxt, lse = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, wqkv16, mask_add)
+        ctx.meta = (B, S, H, heads, drop)
+        return ctxt.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, qkv, ctxt, lse, wqkv16, mask_add = ctx.saved_tensors
+        B, S, H, heads, drop = ctx.meta
+        dx, dw, db = _attn_bwd(_grad_bf16(g, H), x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop,
+                               need_dx=ctx.needs_input_grad[0])
+        return ((dx.view(B, S, H) if dx is not None else None), dw[:H], db[:H], dw[H:2 * H], db[H:2 * H], dw[2 * H:], db[2 * H:],
+                None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense -> dropout -> (+ residual) -> LayerNorm      (BertSelfOutput / BertOutput)
+# ---------------------------------------------------------------------------------------------
+def _ddrln_fwd(h2, resid2, w16, bias, gamma, beta, eps, drop):
+    M, K = h2.shape
+    N = w16.shape[0]
+    dev = h2.device
+    y = torch.empty(M, N, dtype=BF16, device=dev)
+    nat.gemm(h2, w16, y, M, N, K, K, K, N, bias=bias, resid=resid2, ldr=N, drop=drop)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    mean = torch.empty(M, dtype=F32, device=dev)
+    rstd = torch.empty(M, dtype=F32, device=dev)
+    nat.layernorm_fwd(y, gamma, beta, out, mean, rstd, M, N, eps)
+    return out, y, mean, rstd
+
+
+def _ln_bwd(dy, y, mean, rstd, gamma, drop, want_dbias):
+    M, N = y.shape
+    dev = y.device
+    dx = torch.empty(M, N, dtype=BF16, device=dev)
+    dlin = torch.empty(M, N, dtype=BF16, device=dev) if drop[1] else None
+    dgamma = torch.empty(N, dtype=F32, device=dev)
+    dbeta = torch.empty(N, dtype=F32, device=dev)
+    dbias = torch.empty(N, dtype=F32, device=dev) if want_dbias else None
+    ws = torch.empty(nat.layernorm_bwd_ws_floats(N), dtype=F32, device=dev)
+    nat.layernorm_bwd(dy, y, mean, rstd, gamma, dx, dlin, drop, dgamma, dbeta, dbias, 0, ws, M, N)
+    return dx, (dlin if dlin is not None else dx), dgamma, dbeta, dbias
+
+
+class DenseDropoutResidualLNFn(torch.autograd.Function):
+    """LayerNorm(dropout(h W^T + b) + residual)."""
+
+    @staticmethod
+    def forward(ctx, h, resid, weight, bias, gamma, beta, w16, eps, drop):
+        h2 = _as_bf16_2d(h)
+        r2 = _as_bf16_2d(resid)
+        out, y, mean, rstd = _ddrln_fwd(h2, r2, w16, bias.detach(), gamma.detach(), beta.detach(), eps, drop)
+        ctx.save_for_backward(h2, y, mean, rstd, w16, gamma.detach())
+        ctx.meta = (h.shape, resid.shape, drop)
+        return out.view(resid.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        h2, y, mean, rstd, w16, gamma = ctx.saved_tensors
+        hshape, rshape, drop = ctx.meta
+        M, N = y.shape
+        K = h2.shape[1]
+        dx, dlin, dgamma, dbeta, dbias = _ln_bwd(_grad_bf16(g, N), y, mean, rstd, gamma, drop, True)
+        dh, dw = _linear_bwd(dlin, N, h2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
+        return ((dh.view(hshape) if dh is not None else None), dx.view(rshape), dw, dbias, dgamma, dbeta, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense -> GELU      (BertIntermediate)
+# ---------------------------------------------------------------------------------------------
+class DenseGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        N = w16.shape[0]
+        u = torch.empty(M, N, dtype=BF16, device=x2.device)
+        hh = torch.empty(M, N, dtype=BF16, device=x2.device)
+        nat.gemm(x2, w16, hh, M, N, K, K, K, N, bias=bias.detach(), act=1, U=u)
+        ctx.save_for_backward(x2, u, w16)
+        ctx.xshape = x.shape
+        return hh.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, u, w16 = ctx.saved_tensors
+        M, K = x2.shape
+        N = w16.shape[0]
+        du = torch.empty(M, N, dtype=BF16, device=x2.device)
+        nat.gelu_bwd(_grad_bf16(g, N), u, du)
+        dx, dw = _linear_bwd(du, N, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
+        db = _colsum(du, N, M, N)
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None
+
+
+# ---------------------------------------------------------------------------------------------
+# fused transformer sub-blocks (what BertLayerJit.forward actually runs)
+# ---------------------------------------------------------------------------------------------
+class AttentionBlockFn(torch.autograd.Function):
+    """BertAttentionJit.forward (hf_layers.py:233-252): self-attention + BertSelfOutput, with the
+    residual-gradient add fused into the QKV dgrad epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, wqkv16, bqkv, wo16, mask_add, heads, eps, drop_attn, drop_hid):
+        B, S, H = x.shape
+        x2 = _as_bf16_2d(x)
+        qkv, ctxt, lse = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn)
+        out, y, mean, rstd = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), gamma.detach(), beta.detach(), eps, drop_hid)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add)
+        ctx.meta = (B, S, H, heads, drop_attn, drop_hid)
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add = ctx.saved_tensors
+        B, S, H, heads, drop_attn, drop_hid = ctx.meta
+        M = B * S
+        dres, dlin, dgamma, dbeta, dbo = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
+        dctx, dwo = _linear_bwd(dlin, H, ctxt, wo16, M, H, H)
+        dx, dwqkv, dbqkv = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres)
+        return (dx.view(B, S, H), dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
+                dwo, dbo, dgamma, dbeta, None, None, None, None, None, None, None, None)
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """BertIntermediate + BertOutput (hf_layers.py:289-290): GELU in the up-projection epilogue,
+    dropout + residual in the down-projection epilogue, GELU' in the down-projection dgrad epilogue,
+    residual-gradient add in the up-projection dgrad epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, w1_16, w2_16, eps, drop_hid):
+        shape = x.shape
+        x2 = _as_bf16_2d(x)
+        M, H = x2.shape
+        I = w1_16.shape[0]
+        dev = x2.device
+        u = torch.empty(M, I, dtype=BF16, device=dev)
+        hh = torch.empty(M, I, dtype=BF16, device=dev)
+        nat.gemm(x2, w1_16, hh, M, I, H, H, H, I, bias=b1.detach(), act=1, U=u)
+        out, y, mean, rstd = _ddrln_fwd(hh, x2, w2_16, b2.detach(), gamma.detach(), beta.detach(), eps, drop_hid)
+        ctx.save_for_backward(x2, u, hh, y, mean, rstd, w1_16, w2_16, gamma.detach())
+        ctx.meta = (shape, drop_hid)
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, u, hh, y, mean, rstd, w1_16, w2_16, gamma = ctx.saved_tensors
+        shape, drop_hid = ctx.meta
+        M, H = x2.shape
+        I = w1_16.shape[0]
+        dres, dlin, dgamma, dbeta, db2 = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
+        du, dw2 = _linear_bwd(dlin, H, hh, w2_16, M, H, I, act_aux=u)        # du = (dlin W2) * gelu'(u)
+        dx, dw1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres)     # dx = du W1 + dres
+        db1 = _colsum(du, I, M, I)
+        return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = _as_bf16_2d(x)
+        M, N = x2.shape
+        out = torch.empty(M, N, dtype=BF16, device=x2.device)
+        mean = torch.empty(M, dtype=F32, device=x2.device)
+        rstd = torch.empty(M, dtype=F32, device=x2.device)
+        nat.layernorm_fwd(x2, gamma.detach(), beta.detach(), out, mean, rstd, M, N, eps)
+        ctx.save_for_backward(x2, mean, rstd, gamma.detach())
+        ctx.xshape = x.shape
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        dx, _, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, x2.shape[1]), x2, mean, rstd, gamma, (0, 0, 1.0), False)
+        return dx.view(ctx.xshape), dgamma, dbeta, None
+
+
+# ---------------------------------------------------------------------------------------------
+# embeddings
+# ---------------------------------------------------------------------------------------------
+class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
+    """BertVisioLinguisticEmbeddings.forward (embeddings.py:423-459, image_text_alignment=None)."""
+
+    @staticmethod
+    def forward(ctx, input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b,
+                proj_w16, eps, drop):
+        B, T = input_ids.shape
+        H = word.shape[1]
+        R = 0 if feats is None else feats.shape[1]
+        S = T + R
+        dev = word.device
+        y = torch.empty(B * S, H, dtype=BF16, device=dev)
+        ids = input_ids.contiguous()
+        seg = token_type_ids.contiguous()
+        nat.embed_text_fwd(ids, seg, word.detach(), pos.detach(), typ.detach(), y, B, T, S, H)
+        f2 = None
+        if R:
+            D = feats.shape[2]
+            f2 = feats.reshape(B * R, D)
+            if f2.dtype not in (F32, BF16):
+                f2 = f2.float()
+            f2 = f2.contiguous()
+            vt = vtype.reshape(B * R).contiguous()
+            nat.gemm(f2, proj_w16, y, B * R, H, D, D, D, H, bias=proj_b.detach(), coladd=pos_vis.detach()[0],
+                     rowtab=typ_vis.detach(), rowidx=vt, rowtab_ld=H, grp=(R, T, T))
+        else:
+            vt = None
+        out = torch.empty(B * S, H, dtype=BF16, device=dev)
+        mean = torch.empty(B * S, dtype=F32, device=dev)
+        rstd = torch.empty(B * S, dtype=F32, device=dev)
+        nat.layernorm_fwd(y, ln_w.detach(), ln_b.detach(), out, mean, rstd, B * S, H, eps)
+        if drop[1]:
+            out2 = torch.empty_like(out)
+            nat.dropout(out, out2, drop)
+            out = out2
+        ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16)
+        ctx.meta = (B, T, R, S, H, drop, word.shape[0], pos.shape[0], typ.shape[0], typ_vis.shape[0], pos_vis.shape[0])
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, seg, f2, vt, y, mean, rstd, ln_w, proj_w16 = ctx.saved_tensors
+        B, T, R, S, H, drop, V, P, NT, NTV, PV = ctx.meta
+        dev = y.device
+        dy = _grad_bf16(g, H)
+        if drop[1]:
+            d2 = torch.empty_like(dy)
+            nat.dropout(dy, d2, drop)
+            dy = d2
+        dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, (0, 0, 1.0), False)
+        dword = torch.zeros(V, H, dtype=F32, device=dev)
+        nat.rows_scatter_add(dpre, H, B, T, S, ids, T, 0, 0, dword, H, 0)
+        dpos = torch.zeros(P, H, dtype=F32, device=dev)
+        nat.rows_scatter_add(dpre, H, B, T, S, None, 0, 1, 0, dpos, H, 0)
+        dtyp = torch.zeros(NT, H, dtype=F32, device=dev)
+        nat.rows_scatter_add(dpre, H, B, T, S, seg, T, 0, 0, dtyp, H, 1)
+        dtyp_vis = dpos_vis = dproj_w = dproj_b = None
+        if R:
+            vis = dpre[T:]  # row (b, r) of the visual block lives at dpre[b*S + T + r]
+            dtyp_vis = torch.zeros(NTV, H, dtype=F32, device=dev)
+            nat.rows_scatter_add(vis, H, B, R, S, vt, R, 0, 0, dtyp_vis, H, 1)
+            dpos_vis = torch.zeros(PV, H, dtype=F32, device=dev)
+            nat.rows_scatter_add(vis, H, B, R, S, None, 0, 0, 0, dpos_vis, H, 1)
+            dvis = dpre.view(B, S, H)[:, T:, :].contiguous().view(B * R, H)
+            D = f2.shape[1]
+            dproj_w = torch.empty(H, D, dtype=F32, device=dev)
+            nat.gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D, a_kmajor=True, b_kmajor=True)
+            dproj_b = _colsum(dvis, H, B * R, H)
+        return (None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# pooled-token gather (+ dropout) and the loss
+# ---------------------------------------------------------------------------------------------
+class GatherRowsFn(torch.autograd.Function):
+    """out[b] = dropout(x[b, index[b]]): torch.gather + nn.Dropout of visual_bert.py:389-400."""
+
+    @staticmethod
+    def forward(ctx, x, index, drop):
+        B, S, H = x.shape
+        x2 = _as_bf16_2d(x)
+        out = torch.empty(B, H, dtype=BF16, device=x2.device)
+        idx = index.contiguous()
+        nat.gather_rows(x2, idx, out, B, S, H, drop)
+        ctx.save_for_backward(idx)
+        ctx.meta = (B, S, H, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, S, H, drop = ctx.meta
+        dx = torch.zeros(B * S, H, dtype=BF16, device=g.device)
+        nat.scatter_rows(_grad_bf16(g, H), idx, dx, B, S, H, drop)
+        return dx.view(B, S, H), None, None
+
+
+class LogitBCEFn(torch.autograd.Function):
+    """mean(BCEWithLogits(scores, targets)) * num_labels   (losses.py:246-251)."""
+
+    @staticmethod
+    def forward(ctx, scores, targets):
+        B, N = scores.shape
+        s = scores.float().contiguous()
+        t = targets.float().contiguous()
+        loss = torch.empty(1, dtype=F32, device=s.device)
+        nat.bce_logits_fwd(s, t, loss, B, N)
+        ctx.save_for_backward(s, t)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t = ctx.saved_tensors
+        B, N = s.shape
+        ldd = _pad8(N)
+        d16 = torch.empty(B, ldd, dtype=BF16, device=s.device)
+        nat.bce_logits_bwd(s, t, g.float().reshape(1).contiguous(), d16, ldd, B, N)
+        d = torch.empty(B, N, dtype=F32, device=s.device)
+        nat.cast2d_bf16_to_f32(d16, ldd, d, N, B, N)
+        return d, None

@@ -1,0 +1,80 @@
+"""`BaseModel` with the reference's contract (mmf/models/base_model.py:66-410) minus the
+PyTorch-Lightning plumbing: `__init__(config)`, `build()`, `init_losses()`, `forward(sample_list) ->
+dict`, `__call__` moves the batch to the model's device, checks the output is a Mapping and attaches
+`losses` via `self.losses(sample_list, output)`; `load_state_dict` applies `format_state_key`."""
+import collections
+import warnings
+from copy import deepcopy
+
+import torch
+from torch import nn
+
+from mmf_amd.common.sample import SampleList, to_device
+from mmf_amd.modules.losses import Losses
+
+
+class BaseModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self._logged_warning = {"losses_present": False}
+        self._is_pretrained = False
+
+    @property
+    def is_pretrained(self):
+        return self._is_pretrained
+
+    @is_pretrained.setter
+    def is_pretrained(self, x):
+        self._is_pretrained = x
+
+    @classmethod
+    def config_path(cls):
+        return None
+
+    @classmethod
+    def format_state_key(cls, key):
+        return key
+
+    def build(self):
+        raise NotImplementedError("Build method not implemented in the child model class.")
+
+    def init_losses(self):
+        """base_model.py:157-184."""
+        losses = self.config.get("losses", [])
+        if len(losses) == 0 and not self.is_pretrained:
+            warnings.warn("No losses are defined in model configuration. You are expected to return loss in your "
+                          "return dict from forward.")
+        self.losses = Losses(losses)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        copied = deepcopy(state_dict)
+        for key in list(copied.keys()):
+            copied[self.format_state_key(key)] = copied.pop(key)
+        return super().load_state_dict(copied, *args, **kwargs)
+
+    def forward(self, sample_list, *args, **kwargs):
+        raise NotImplementedError("Forward of the child model class needs to be implemented.")
+
+    def _device(self):
+        try:
+            return next(self.parameters()).device
+        except StopIteration:
+            return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+    def __call__(self, sample_list, *args, **kwargs):
+        sample_list = to_device(sample_list, self._device())
+        model_output = super().__call__(sample_list, *args, **kwargs)
+        if self.is_pretrained:
+            return model_output
+        assert isinstance(model_output, collections.abc.Mapping), "A dict must be returned from the forward of the model."
+        if "losses" in model_output:
+            if not self._logged_warning["losses_present"]:
+                warnings.warn("'losses' already present in model output. No calculation will be done in base model.")
+                self._logged_warning["losses_present"] = True
+            assert isinstance(model_output["losses"], collections.abc.Mapping), "'losses' must be a dict."
+        elif hasattr(self, "losses"):
+            model_output["losses"] = self.losses(sample_list, model_output)
+        else:
+            model_output["losses"] = {}
+        return model_output

@@ -1,0 +1,215 @@
+"""VisualBERT behind MMF's model API, running on the gfx950 kernels.
+
+Mirrors mmf/models/visual_bert.py: `VisualBERTBase` (:43-157), `VisualBERTForClassification`
+(:284-404) and the registered `VisualBERT(BaseModel)` (:407-601) — same constructor arguments, same
+`forward(sample_list) -> {"scores": [B, num_labels]}` contract, same parameter names/shapes (MMF zoo
+checkpoints load unmodified: `model.bert.encoder.layer.3.attention.self.query.weight` ...).
+
+MI355X-first differences, all internal:
+  * activations are bf16 token-major tensors in HBM, statistics / softmax / accumulators fp32;
+  * the whole embedding stage, each attention block and each feed-forward block is ONE autograd node
+    made of hand-written HIP kernels (mmf_amd/functional.py);
+  * the BertPooler is skipped when `pooler_strategy == "vqa"` (the reference computes it at :146 and
+    discards it at :389-398); its parameters still exist and simply receive no gradient, exactly as
+    in the reference.
+"""
+import torch
+from torch import nn
+
+from mmf_amd import functional as Fn
+from mmf_amd.common.registry import registry
+from mmf_amd.models.base_model import BaseModel
+from mmf_amd.modules.embeddings import BertVisioLinguisticEmbeddings
+from mmf_amd.modules.hf_layers import (
+    BertConfig, BertEncoderJit, BertLayerJit, BertPooler, BertPredictionHeadTransform, Linear, init_bert_weights)
+from mmf_amd.utils.configuration import to_container
+from mmf_amd.utils.modeling import get_optimizer_parameters_for_bert
+
+
+class VisualBERTBase(nn.Module):
+    """visual_bert.py:43-157."""
+
+    def __init__(self, config, visual_embedding_dim=512, embedding_strategy="plain", bypass_transformer=False,
+                 output_attentions=False, output_hidden_states=False, skip_pooler=False):
+        super().__init__()
+        self.config = config
+        config.visual_embedding_dim = visual_embedding_dim
+        config.embedding_strategy = embedding_strategy
+        config.bypass_transformer = bypass_transformer
+        config.output_attentions = output_attentions
+        config.output_hidden_states = output_hidden_states
+        if output_attentions:
+            raise NotImplementedError("output_attentions: the fused attention kernel never materialises the probabilities")
+        self.embeddings = BertVisioLinguisticEmbeddings(config)
+        self.encoder = BertEncoderJit(config)
+        self.pooler = BertPooler(config)
+        self.bypass_transformer = bypass_transformer
+        if self.bypass_transformer:
+            self.additional_layer = BertLayerJit(config)
+        self.output_attentions = output_attentions
+        self.output_hidden_states = output_hidden_states
+        self.skip_pooler = skip_pooler
+        self.init_weights()
+
+    def _init_weights(self, module):
+        init_bert_weights(module, self.config.initializer_range)
+
+    def init_weights(self):
+        self.apply(self._init_weights)
+
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, visual_embeddings=None,
+                visual_embeddings_type=None, image_text_alignment=None):
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        # additive mask (1 - m) * -10000, visual_bert.py:94-106, built by a HIP kernel as fp32 [B, S]
+        am = attention_mask.contiguous()
+        if am.dtype != torch.int64:
+            am = am.long()
+        mask_add = torch.empty(am.shape, dtype=torch.float32, device=am.device)
+        Fn.nat.make_additive_mask(am, mask_add)
+        extended_attention_mask = mask_add.view(am.shape[0], 1, 1, am.shape[1])
+
+        embedding_output = self.embeddings(input_ids, token_type_ids, visual_embeddings=visual_embeddings,
+                                           visual_embeddings_type=visual_embeddings_type,
+                                           image_text_alignment=image_text_alignment)
+        if self.bypass_transformer and visual_embeddings is not None:
+            raise NotImplementedError("bypass_transformer (visual_bert.py:116-141) needs a [B,1,S,S] mask; not built yet")
+        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
+                                      output_hidden_states=self.output_hidden_states)
+        sequence_output = encoded_layers[0]
+        pooled_output = None if self.skip_pooler else self.pooler(sequence_output)
+        return sequence_output, pooled_output, []
+
+
+class VisualBERTForClassification(nn.Module):
+    """visual_bert.py:284-404."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.output_attentions = self.config.output_attentions
+        self.output_hidden_states = self.config.output_hidden_states
+        self.pooler_strategy = self.config.get("pooler_strategy", "default")
+        self.bert_model_name = getattr(self.config, "bert_model_name", None)
+        self.bert_config = BertConfig.from_dict(to_container(self.config))
+        # The reference downloads `bert-base-uncased` when bert_model_name is set (visual_bert.py:309-320).
+        # Offline we build the same architecture (BertConfig defaults == bert-base-uncased, overridden by any
+        # BERT key present in the model config); real weights arrive via load_state_dict / an MMF checkpoint.
+        self.bert = VisualBERTBase(
+            self.bert_config, visual_embedding_dim=self.config.visual_embedding_dim,
+            embedding_strategy=self.config.embedding_strategy, bypass_transformer=self.config.bypass_transformer,
+            output_attentions=self.config.output_attentions, output_hidden_states=self.config.output_hidden_states,
+            skip_pooler=(self.pooler_strategy == "vqa"))
+        self.training_head_type = self.config.training_head_type
+        self.num_labels = self.config.num_labels
+        self.dropout_prob = self.bert.config.hidden_dropout_prob
+        if self.training_head_type == "nlvr2":
+            raise NotImplementedError("the nlvr2 head (visual_bert.py:324-325,364-370) is not built yet")
+        self.classifier = nn.Sequential(
+            BertPredictionHeadTransform(self.bert.config),
+            Linear(self.bert.config.hidden_size, self.config.num_labels),
+        )
+        self.init_weights()
+
+    def init_weights(self):
+        if self.config.get("random_initialize", False) is False:
+            self.classifier.apply(self.bert._init_weights)
+        if "losses" in self.config and self.config.get("zerobias", False):
+            for loss in self.config.losses:
+                if "bce" in loss["type"]:
+                    self.classifier[1].bias.data.fill_(self.config.biasfill)
+
+    def forward(self, input_ids, input_mask, attention_mask=None, token_type_ids=None, visual_embeddings=None,
+                visual_embeddings_type=None, image_text_alignment=None, masked_lm_labels=None):
+        sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
+                                                      visual_embeddings_type, image_text_alignment)
+        output_dict = {}
+        if self.output_hidden_states:
+            output_dict["sequence_output"] = sequence_output
+            output_dict["pooled_output"] = pooled_output
+        drop = Fn.make_drop(self.dropout_prob, self.training)
+        if self.pooler_strategy == "vqa":
+            # representation of the second-to-last text token (visual_bert.py:389-398) + dropout (:400)
+            index_to_gather = input_mask.sum(1) - 2
+            pooled = Fn.GatherRowsFn.apply(sequence_output, index_to_gather, drop)
+        else:
+            pooled = pooled_output.to(torch.bfloat16)
+            if drop[1]:
+                d = torch.empty_like(pooled)
+                Fn.nat.dropout(pooled.contiguous(), d, drop)
+                pooled = d
+        hidden = self.classifier[0](pooled)
+        logits = self.classifier[1](hidden, out_f32=True)
+        output_dict["scores"] = logits.contiguous().view(-1, self.num_labels)
+        return output_dict
+
+
+@registry.register_model("visual_bert")
+class VisualBERT(BaseModel):
+    """visual_bert.py:407-601."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.config = config
+        self.training_head_type = self.config.training_head_type
+
+    @classmethod
+    def config_path(cls):
+        return "configs/models/visual_bert/pretrain.yaml"
+
+    def build(self):
+        if self.training_head_type == "pretraining":
+            raise NotImplementedError("VisualBERTForPretraining (visual_bert.py:160-281) is a later milestone")
+        self.model = VisualBERTForClassification(self.config)
+        if self.config.get("special_visual_initialize", False):
+            self.model.bert.embeddings.initialize_visual_from_pretrained()
+        if getattr(self.config, "freeze_base", False):
+            for p in self.model.bert.parameters():
+                p.requires_grad = False
+
+    def get_optimizer_parameters(self, config):
+        return get_optimizer_parameters_for_bert(self.model, config)
+
+    @classmethod
+    def format_state_key(cls, key):
+        return (key.replace("bert.bert", "model.bert").replace("bert.cls", "model.cls")
+                .replace("bert.classifier", "model.classifier"))
+
+    # ---- input massaging, visual_bert.py:444-556 ------------------------------------------------
+    def update_sample_list_based_on_head(self, sample_list):
+        image_info = sample_list.get("image_info_0", None) or {}
+        image_dim_variable = image_info.get("max_features", None)
+        image_feat_variable = sample_list.get("image_feature_0", None)
+        if image_dim_variable is None:
+            image_dim_variable = sample_list["image_feature_0"].new_full(
+                size=(image_feat_variable.size(0), 1), fill_value=image_feat_variable.size(1))
+        sample_list["visual_embeddings"] = image_feat_variable
+        sample_list["image_dim"] = image_dim_variable
+        sample_list["token_type_ids"] = sample_list["segment_ids"]
+        return sample_list
+
+    def add_custom_params(self, sample_list):
+        visual_embeddings = sample_list["visual_embeddings"]
+        image_dim = sample_list["image_dim"]
+        image_mask = torch.arange(visual_embeddings.size(-2), device=visual_embeddings.device).expand(
+            visual_embeddings.size()[:-1])
+        if image_dim.dim() < image_mask.dim():
+            image_dim = image_dim.unsqueeze(-1)
+        sample_list["image_mask"] = (image_mask < image_dim).long()
+        return sample_list
+
+    def add_post_flatten_params(self, sample_list):
+        sample_list["visual_embeddings_type"] = torch.zeros_like(sample_list["image_mask"])
+        sample_list["attention_mask"] = torch.cat((sample_list["input_mask"], sample_list["image_mask"]), dim=-1)
+        return sample_list
+
+    def forward(self, sample_list):
+        sample_list = self.update_sample_list_based_on_head(sample_list)
+        sample_list = self.add_custom_params(sample_list)
+        sample_list = self.add_post_flatten_params(sample_list)
+        return self.model(
+            sample_list["input_ids"], sample_list["input_mask"], sample_list["attention_mask"],
+            sample_list["token_type_ids"], sample_list["visual_embeddings"], sample_list["visual_embeddings_type"],
+            sample_list.get("image_text_alignment", None), sample_list.get("masked_lm_labels", None))

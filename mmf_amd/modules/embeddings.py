@@ -1,0 +1,49 @@
+"""BertVisioLinguisticEmbeddings with the reference's parameters (mmf/modules/embeddings.py:309-459)
+and a single fused forward: text rows (gather + sum), visual rows (fp32 features -> bf16 MFMA GEMM
+with bias / type / position added in the epilogue) written into one `[B, T+R, H]` buffer, LayerNorm,
+dropout — all gfx950 kernels (mmf_amd.functional.VisioLinguisticEmbeddingsFn)."""
+from copy import deepcopy
+
+import torch
+from torch import nn
+
+from mmf_amd import functional as Fn
+from mmf_amd.modules.hf_layers import LayerNorm, Linear
+
+
+class BertVisioLinguisticEmbeddings(nn.Module):
+    def __init__(self, config, *args, **kwargs):
+        super().__init__()
+        H = config.hidden_size
+        # HF BertEmbeddings members (embeddings.py:309-311 -> super().__init__)
+        self.word_embeddings = nn.Embedding(config.vocab_size, H)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, H)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, H)
+        self.LayerNorm = LayerNorm(H, eps=config.layer_norm_eps)
+        self.dropout_prob = config.hidden_dropout_prob
+        # visual members (:312-319)
+        self.token_type_embeddings_visual = nn.Embedding(config.type_vocab_size, H)
+        self.position_embeddings_visual = nn.Embedding(config.max_position_embeddings, H)
+        self.projection = Linear(config.visual_embedding_dim, H)
+
+    def initialize_visual_from_pretrained(self):
+        """embeddings.py:321-327."""
+        self.token_type_embeddings_visual.weight = nn.Parameter(
+            deepcopy(self.token_type_embeddings.weight.data), requires_grad=True)
+        self.position_embeddings_visual.weight = nn.Parameter(
+            deepcopy(self.position_embeddings.weight.data), requires_grad=True)
+
+    def forward(self, input_ids, token_type_ids=None, visual_embeddings=None, visual_embeddings_type=None,
+                image_text_alignment=None):
+        if image_text_alignment is not None:
+            raise NotImplementedError("image_text_alignment (embeddings.py:376-410) is not on the VQA2 path")
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        if visual_embeddings is None or visual_embeddings_type is None:
+            visual_embeddings = visual_embeddings_type = None
+        return Fn.VisioLinguisticEmbeddingsFn.apply(
+            input_ids, token_type_ids, visual_embeddings, visual_embeddings_type,
+            self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
+            self.LayerNorm.weight, self.LayerNorm.bias, self.token_type_embeddings_visual.weight,
+            self.position_embeddings_visual.weight, self.projection.weight, self.projection.bias,
+            Fn.shadows.get(self.projection.weight), self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training))

@@ -1,0 +1,263 @@
+"""HIP-backed transformer encoder modules with the reference's class names, parameter names and
+shapes (mmf/modules/hf_layers.py:138-355 plus the HF blocks it instantiates: BertSelfOutput,
+BertIntermediate, BertOutput, BertPooler, BertPredictionHeadTransform).
+
+`state_dict()` keys are identical to the reference's (`attention.self.query.weight`,
+`attention.output.LayerNorm.bias`, `intermediate.dense.weight`, ...), so MMF / HF checkpoints load
+unmodified.  Activations are bf16 `[B, S, H]` tensors in HBM; every forward and backward is a
+hand-written gfx950 kernel (mmf_amd/functional.py).  There is no eager fallback.
+"""
+import torch
+from torch import nn
+
+from mmf_amd import functional as Fn
+
+
+class BertConfig:
+    """The subset of HF `BertConfig` the encoder reads (defaults = bert-base-uncased)."""
+
+    def __init__(self, **kw):
+        d = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                 hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=512,
+                 type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12, output_attentions=False,
+                 output_hidden_states=False, is_decoder=False)
+        d.update(kw)
+        for k, v in d.items():
+            setattr(self, k, v)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**{k: v for k, v in dict(d).items() if not isinstance(v, (dict, list))})
+
+    def get(self, k, default=None):
+        return getattr(self, k, default)
+
+
+class Linear(nn.Module):
+    """nn.Linear parameter container (weight [out, in], bias [out]) whose forward is the MFMA GEMM."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+
+    def forward(self, x, out_f32=False):
+        return Fn.linear(x, self.weight, self.bias, out_f32)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-12):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.bias = nn.Parameter(torch.zeros(hidden_size))
+        self.eps = eps
+
+    def forward(self, x):
+        return Fn.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
+def init_bert_weights(module, std=0.02):
+    """HF `BertPreTrainedModel._init_weights`: normal(0, initializer_range) for Linear / Embedding
+    weights, zero biases, LayerNorm = (1, 0)."""
+    if isinstance(module, (Linear, nn.Linear)):
+        module.weight.data.normal_(mean=0.0, std=std)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    elif isinstance(module, nn.Embedding):
+        module.weight.data.normal_(mean=0.0, std=std)
+    elif isinstance(module, (LayerNorm, nn.LayerNorm)):
+        module.weight.data.fill_(1.0)
+        module.bias.data.zero_()
+
+
+def additive_key_mask(attention_mask, batch, seq):
+    """The reference hands the encoder the broadcastable additive mask `[B, 1, 1, S]`
+    (visual_bert.py:94-106).  The fused kernel wants it as fp32 `[B, S]`."""
+    if attention_mask is None:
+        return None
+    m = attention_mask
+    if m.dim() == 4:
+        if m.shape[1] != 1 or m.shape[2] != 1:
+            raise NotImplementedError("per-query attention masks [B,1,S,S] are not supported by the fused kernel yet")
+        m = m.reshape(batch, seq)
+    if m.dtype != torch.float32:
+        m = m.float()
+    return m.contiguous()
+
+
+class BertSelfAttentionJit(nn.Module):
+    """hf_layers.py:138-213.  Returns `(context_layer, attention_probs)`; the probabilities are never
+    materialised by the fused kernel, so the second element is an empty placeholder."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)" % (
+                config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        if self.attention_head_size != 64:
+            raise ValueError("the gfx950 fused attention kernel is built for head_dim 64, got %d" % self.attention_head_size)
+        self.query = Linear(config.hidden_size, self.all_head_size)
+        self.key = Linear(config.hidden_size, self.all_head_size)
+        self.value = Linear(config.hidden_size, self.all_head_size)
+        self.dropout_prob = config.attention_probs_dropout_prob
+
+    def packed_qkv(self):
+        w16 = Fn.shadows.get(self.query.weight, self.key.weight, self.value.weight)
+        b32 = Fn.shadows.get(self.query.bias, self.key.bias, self.value.bias, dtype=torch.float32)
+        return w16, b32
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None):
+        if head_mask is not None or encoder_hidden_states is not None:
+            raise NotImplementedError("head_mask / cross-attention are not on the VisualBERT path")
+        B, S, _ = hidden_states.shape
+        w16, b32 = self.packed_qkv()
+        drop = Fn.make_drop(self.dropout_prob, self.training)
+        ctx = Fn.SelfAttentionFn.apply(hidden_states, self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                                       self.value.weight, self.value.bias, w16, b32,
+                                       additive_key_mask(attention_mask, B, S), self.num_attention_heads, drop)
+        return ctx, hidden_states.new_empty(0)
+
+
+class BertSelfOutput(nn.Module):
+    """HF BertSelfOutput: LayerNorm(dropout(dense(h)) + input)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout_prob = config.hidden_dropout_prob
+
+    def forward(self, hidden_states, input_tensor):
+        drop = Fn.make_drop(self.dropout_prob, self.training)
+        return Fn.DenseDropoutResidualLNFn.apply(hidden_states, input_tensor, self.dense.weight, self.dense.bias,
+                                                 self.LayerNorm.weight, self.LayerNorm.bias, Fn.shadows.get(self.dense.weight),
+                                                 self.LayerNorm.eps, drop)
+
+
+class BertIntermediate(nn.Module):
+    """HF BertIntermediate: gelu(dense(x)) with the exact-erf GELU."""
+
+    def __init__(self, config):
+        super().__init__()
+        if getattr(config, "hidden_act", "gelu") != "gelu":
+            raise ValueError("only hidden_act == 'gelu' is implemented")
+        self.dense = Linear(config.hidden_size, config.intermediate_size)
+
+    def forward(self, hidden_states):
+        return Fn.DenseGeluFn.apply(hidden_states, self.dense.weight, self.dense.bias, Fn.shadows.get(self.dense.weight))
+
+
+class BertOutput(nn.Module):
+    """HF BertOutput: LayerNorm(dropout(dense(h)) + input)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout_prob = config.hidden_dropout_prob
+
+    def forward(self, hidden_states, input_tensor):
+        drop = Fn.make_drop(self.dropout_prob, self.training)
+        return Fn.DenseDropoutResidualLNFn.apply(hidden_states, input_tensor, self.dense.weight, self.dense.bias,
+                                                 self.LayerNorm.weight, self.LayerNorm.bias, Fn.shadows.get(self.dense.weight),
+                                                 self.LayerNorm.eps, drop)
+
+
+class BertAttentionJit(nn.Module):
+    """hf_layers.py:216-252."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttentionJit(config)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None):
+        if head_mask is not None or encoder_hidden_states is not None:
+            raise NotImplementedError("head_mask / cross-attention are not on the VisualBERT path")
+        B, S, _ = hidden_states.shape
+        sa, so = self.self, self.output
+        w16, b32 = sa.packed_qkv()
+        out = Fn.AttentionBlockFn.apply(
+            hidden_states, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
+            so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, w16, b32, Fn.shadows.get(so.dense.weight),
+            additive_key_mask(attention_mask, B, S), sa.num_attention_heads, so.LayerNorm.eps,
+            Fn.make_drop(sa.dropout_prob, self.training), Fn.make_drop(so.dropout_prob, self.training))
+        return (out,)
+
+
+class BertLayerJit(nn.Module):
+    """hf_layers.py:255-292: attention sub-layer then feed-forward sub-layer, two fused autograd nodes."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.attention = BertAttentionJit(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None):
+        attention_output = self.attention(hidden_states, attention_mask, head_mask)[0]
+        it, ot = self.intermediate, self.output
+        layer_output = Fn.FeedForwardFn.apply(
+            attention_output, it.dense.weight, it.dense.bias, ot.dense.weight, ot.dense.bias, ot.LayerNorm.weight,
+            ot.LayerNorm.bias, Fn.shadows.get(it.dense.weight), Fn.shadows.get(ot.dense.weight), ot.LayerNorm.eps,
+            Fn.make_drop(ot.dropout_prob, self.training))
+        return (layer_output,)
+
+
+class BertEncoderJit(nn.Module):
+    """hf_layers.py:295-355."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.output_attentions = getattr(config, "output_attentions", False)
+        self.output_hidden_states = getattr(config, "output_hidden_states", False)
+        self.layer = nn.ModuleList([BertLayerJit(config) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                output_attentions=False, output_hidden_states=False, return_dict=False, head_mask=None):
+        if output_attentions:
+            raise NotImplementedError("attention probabilities are not materialised by the fused kernel")
+        all_hidden_states = ()
+        for layer_module in self.layer:
+            if output_hidden_states:
+                all_hidden_states = all_hidden_states + (hidden_states,)
+            hidden_states = layer_module(hidden_states, attention_mask, None, encoder_hidden_states, encoder_attention_mask)[0]
+        if output_hidden_states:
+            all_hidden_states = all_hidden_states + (hidden_states,)
+        outputs = (hidden_states,)
+        if output_hidden_states:
+            outputs = outputs + (all_hidden_states,)
+        return outputs
+
+
+class BertPooler(nn.Module):
+    """HF BertPooler: tanh(dense(h[:, 0])).  Dead work under `pooler_strategy: vqa` (visual_bert.py:146
+    vs :389-398); kept for the `default` strategy and for checkpoint compatibility."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+
+    def forward(self, hidden_states):
+        first = hidden_states[:, 0]
+        return torch.tanh(self.dense(first, out_f32=True))
+
+
+class BertPredictionHeadTransform(nn.Module):
+    """HF BertPredictionHeadTransform: LayerNorm(gelu(dense(x)))."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+    def forward(self, hidden_states):
+        h = Fn.DenseGeluFn.apply(hidden_states, self.dense.weight, self.dense.bias, Fn.shadows.get(self.dense.weight))
+        return self.LayerNorm(h)

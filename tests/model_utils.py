@@ -1,0 +1,42 @@
+"""Builders shared by the model-level tests."""
+import torch
+
+from mmf_amd.utils.build import build_model
+from mmf_amd.utils.configuration import Config
+
+
+def model_config(cfg, **over):
+    """MMF model_config.visual_bert (configs/models/visual_bert/defaults.yaml + vqa2 project config)
+    for an oracle-style BERT config dict."""
+    d = dict(
+        model="visual_bert", bert_model_name=None, training_head_type="classification",
+        visual_embedding_dim=cfg["visual_embedding_dim"], special_visual_initialize=True, embedding_strategy="plain",
+        bypass_transformer=False, output_attentions=False, output_hidden_states=False, random_initialize=False,
+        freeze_base=False, finetune_lr_multiplier=1, pooler_strategy=cfg.get("pooler_strategy", "vqa"), zerobias=False,
+        hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
+        num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
+        vocab_size=cfg["vocab_size"], max_position_embeddings=cfg["max_position_embeddings"],
+        type_vocab_size=cfg.get("type_vocab_size", 2), hidden_dropout_prob=cfg.get("hidden_dropout_prob", 0.1),
+        attention_probs_dropout_prob=cfg.get("attention_probs_dropout_prob", 0.1), layer_norm_eps=cfg["layer_norm_eps"],
+        num_labels=cfg["num_labels"], losses=[dict(type="logit_bce")])
+    d.update(over)
+    return Config(d)
+
+
+def build_visual_bert(cfg, sd=None, device="cuda", **over):
+    model = build_model(model_config(cfg, **over))
+    if sd is not None:
+        model.load_state_dict({"model." + k: v for k, v in sd.items()}, strict=True)
+    return model.to(device)
+
+
+def sample_to(sample, device):
+    out = {}
+    for k, v in sample.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.to(device)
+        elif isinstance(v, dict):
+            out[k] = sample_to(v, device)
+        else:
+            out[k] = v
+    return out

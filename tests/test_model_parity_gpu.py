@@ -1,0 +1,109 @@
+"""Model-level parity (GPU): the HIP-backed VisualBERT, built through the registry like MMF builds
+it, against (1) the golden vectors produced by the real reference and (2) the CPU oracle at the
+full VQA2 configuration.  Tolerance: BASELINE.json north_star, 5e-2 for the bf16 path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import visual_bert_oracle as O
+from tests.golden_utils import load_case
+from tests.model_utils import build_visual_bert, sample_to
+from mmf_amd.common.sample import SampleList
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-2
+
+
+def rel_err(a, b):
+    a = a.double().flatten().cpu(); b = b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_golden_small64_forward_loss_and_gradients():
+    z, case, cfg, sd, sample = load_case("small64")
+    model = build_visual_bert(cfg, sd, output_hidden_states=True)
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    scores = out["scores"].float().cpu().numpy()
+    assert scores.shape == z["scores"].shape
+    np.testing.assert_allclose(scores, z["scores"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(out["sequence_output"].float().cpu().numpy(), z["sequence_output"], rtol=TOL, atol=TOL)
+    (key, loss), = out["losses"].items()
+    assert key == "train/vqa2/logit_bce"
+    assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    loss.sum().backward()
+    params = dict(model.named_parameters())
+    worst = {}
+    for gname, norm, gsum in zip(z["grad_names"], z["grad_norms"], z["grad_sums"]):
+        p = params[str(gname)]
+        if norm == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, gname  # pooler: no gradient under `vqa`
+            continue
+        assert p.grad is not None, gname
+        gn = float(p.grad.double().norm())
+        worst[str(gname)] = abs(gn - norm) / norm
+        full = "grad::" + str(gname)
+        if full in z.files:
+            assert rel_err(p.grad, torch.from_numpy(z[full])) <= TOL, gname
+    bad = {k: v for k, v in worst.items() if v > TOL}
+    assert not bad, bad
+
+
+def test_full_config_forward_backward_matches_oracle():
+    cfg = dict(O.DEFAULT_CONFIG)
+    cfg["num_hidden_layers"] = 12
+    sd = O.init_state_dict(cfg, seed=7)
+    # give biases / LayerNorms non-trivial values so a dropped or swapped parameter cannot hide
+    g = torch.Generator().manual_seed(8)
+    for k in sd:
+        if k.endswith(".bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+        elif k.endswith("LayerNorm.weight"):
+            sd[k] = 1.0 + torch.randn(sd[k].shape, generator=g) * 0.05
+    B = 2
+    sample = O.synthetic_batch(cfg, B, seed=99)
+    sample["input_mask"][1, 90:] = 0
+    sample["image_info_0"]["max_features"][0] = 73
+    model = build_visual_bert(cfg, sd, output_hidden_states=True)
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.visual_bert_forward(sdr, cfg, sample, train=False, return_hidden=True)
+    assert rel_err(out["sequence_output"], ref["sequence_output"]) <= TOL
+    d = (out["scores"].float().cpu() - ref["scores"]).abs().max().item()
+    assert d <= TOL, d
+    (key, loss), = out["losses"].items()
+    ref_loss = O.logit_bce(ref["scores"], sample["targets"])
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    loss.sum().backward()
+    ref_loss.backward()
+    params = dict(model.named_parameters())
+    errs = {}
+    for k, v in sdr.items():
+        p = params["model." + k]
+        if v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, k
+        errs[k] = rel_err(p.grad, v.grad)
+    bad = {k: round(e, 4) for k, e in errs.items() if e > TOL}
+    assert not bad, bad
+
+
+def test_training_mode_runs_and_is_seed_reproducible():
+    z, case, cfg, sd, sample = load_case("small64")
+    model = build_visual_bert(cfg, sd)
+    model.train()
+    batch = SampleList(sample_to(sample, "cuda"))
+    torch.manual_seed(5)
+    a = model(batch)["scores"].float().clone()
+    torch.manual_seed(5)
+    b = model(batch)["scores"].float().clone()
+    torch.manual_seed(6)
+    c = model(batch)["scores"].float().clone()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c)
+    model.eval()
+    e = model(batch)["scores"].float()
+    assert float((a - e).abs().max()) > 0
+    # dropout noise is zero-mean: the train-mode scores stay near the eval-mode ones
+    assert float((a - e).abs().mean()) < 0.5

@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""VisualBERT VQA2 training-step benchmark on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic VQA2 batch that is already resident in HBM
+(32 samples / GPU, 128 text tokens + 100 regions x 2048 fp32): zero grads, forward (train mode, dropout
+on), logit_bce, backward through every hand-written kernel, and for N > 1 the bucketed RCCL gradient
+all-reduce overlapped with backward.  `value` = samples/s over all ranks (weak scaling).
+
+Besides the contract fields the JSON line carries
+  roofline     : the dominant kernel (bf16 MFMA GEMM), algorithmic FLOPs per launch / average launch
+                 duration measured live with HIP events on the launch stream during one instrumented step
+  cpu_baseline : the CPU oracle (oracle/visual_bert_oracle.py, a port of the reference algorithm) timed
+                 on the host cores of the same box, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+FWD_BWD_GFLOP_PER_SAMPLE = 122.9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE: 32)")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (not the headline)")
+    ap.add_argument("--optimizer", action="store_true", help="also run AdamW inside the step (reported separately)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def build(device, rank):
+    import mmf_amd  # noqa: F401
+    from mmf_amd.utils.build import build_model
+    from mmf_amd.utils.configuration import Config
+    cfg = Config(
+        model="visual_bert", bert_model_name="bert-base-uncased", training_head_type="classification",
+        visual_embedding_dim=2048, special_visual_initialize=True, embedding_strategy="plain", bypass_transformer=False,
+        output_attentions=False, output_hidden_states=False, random_initialize=False, freeze_base=False,
+        finetune_lr_multiplier=1, pooler_strategy="vqa", zerobias=False, hidden_size=768, hidden_dropout_prob=0.1,
+        num_labels=3129, losses=[dict(type="logit_bce")])
+    torch.manual_seed(1234)  # identical replicas on every rank, like DDP's broadcast of rank 0's weights
+    model = build_model(cfg).to(device)
+    return model
+
+
+def synthetic_batch(batch, rank, device):
+    from mmf_amd.common.sample import SampleList
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(0, 30522, (batch, 128), generator=g)
+    ids[:, 0] = 101
+    targets = torch.zeros(batch, 3129)
+    for b in range(batch):
+        cols = torch.randperm(3129, generator=g)[:3]
+        targets[b, cols] = torch.tensor([1.0, 0.6, 0.3])
+    sl = SampleList({
+        "input_ids": ids, "input_mask": torch.ones(batch, 128, dtype=torch.long),
+        "segment_ids": torch.zeros(batch, 128, dtype=torch.long),
+        "image_feature_0": torch.rand(batch, 100, 2048, generator=g),
+        "image_info_0": {"max_features": torch.full((batch,), 100, dtype=torch.long)},
+        "targets": targets, "dataset_name": "vqa2", "dataset_type": "train"})
+    return sl.to(device)
+
+
+class GemmProbe:
+    """Times every mmf_gemm_bf16 launch of ONE step with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.rec = []
+
+    def __enter__(self):
+        from mmf_amd import _native as nat
+        self.nat, self.orig = nat, nat.gemm
+
+        def timed(A, B, C_out, M, N, K, *a, **kw):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(A, B, C_out, M, N, K, *a, **kw)
+            e1.record()
+            variant = "%s%s%s" % ("T" if kw.get("a_kmajor") else "N", "N" if kw.get("b_kmajor") else "T",
+                                  "_ragged" if (M % 128 or N % 128 or K % 64) else "")
+            self.rec.append((variant, (M, N, K), 2.0 * M * N * K, e0, e1))
+
+        nat.gemm = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.nat.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        by = {}
+        for variant, shape, flops, e0, e1 in self.rec:
+            d = by.setdefault(variant, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1; d["ms"] += e0.elapsed_time(e1); d["flops"] += flops
+        return by
+
+
+def cpu_baseline(batch, steps):
+    from oracle import visual_bert_oracle as O
+    cfg = dict(O.DEFAULT_CONFIG)
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: v.requires_grad_(True) for k, v in O.init_state_dict(cfg, seed=1234).items()}
+    sample = O.synthetic_batch(cfg, batch, seed=1234)
+    times = []
+    for i in range(steps + 1):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = O.train_step_loss(sd, cfg, sample, train=True)
+        list(out["losses"].values())[0].backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(batch / t, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (fp32 PyTorch port of the reference path) fwd+bwd, train mode, B=%d, median of %d steps after 1 warm-up"
+                      % (batch, steps)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from mmf_amd.utils import distributed as D
+    rank, world = D.distributed_init_from_env()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    model = build(device, rank)
+    model.train(not args.eval_mode)
+    batch = synthetic_batch(args.batch, rank, device)
+    from mmf_amd.trainers.core.device import parallelize_model
+    reducer = parallelize_model(model)
+    opt = None
+    if args.optimizer:
+        from mmf_amd.utils.configuration import Config
+        full = Config(model="visual_bert", optimizer=dict(params=dict(lr=5e-5)), model_config=dict(visual_bert=model.config))
+        opt = torch.optim.AdamW(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(batch)
+        loss = sum(v.sum() for v in out["losses"].values())
+        loss.backward()
+        reducer.finish()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+
+    # one instrumented step for the roofline of the dominant kernel
+    with GemmProbe() as probe:
+        step()
+    by = probe.summary()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        dom = max(by, key=lambda k: by[k]["ms"])
+        tot_ms = sum(v["ms"] for v in by.values()); tot_fl = sum(v["flops"] for v in by.values())
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom, None)
+            except Exception:
+                traffic = None
+        roof = {
+            "bound": "mfma", "kernel": "gemm_bf16_kernel[%s]" % dom,
+            "achieved": round(by[dom]["flops"] / by[dom]["ms"] / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(by[dom]["flops"] / by[dom]["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "avg_launch_ms": round(by[dom]["ms"] / by[dom]["launches"], 4), "launches_per_step": by[dom]["launches"],
+            "traffic": traffic,
+            "all_gemm": {"tflops": round(tot_fl / tot_ms / 1e9, 2), "ms_per_step": round(tot_ms, 3),
+                         "variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / v["ms"] / 1e9, 1)}
+                                      for k, v in sorted(by.items())}},
+            "step_frac_of_mfma_peak": round(value / world * FWD_BWD_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
+        }
+        line = {
+            "metric": "samples/sec/node VisualBERT VQA2 fwd+bwd, 100 regions x 2048 + 128 tok, bs=32/GPU",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "VisualBERT-base single-stream (100 regions + 128 tok) VQA2 bf16, fwd+logit_bce+bwd%s%s"
+                                   % ("+AdamW" if opt is not None else "", "" if not args.eval_mode else " (eval mode)"),
+                       "global_batch": args.batch * world, "seq_len": 228, "parallelism": "dp%d" % world,
+                       "dropout": not args.eval_mode, "loss": round(loss_val, 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,19 +33,16 @@ F32 = torch.float32
 # dropout keys
 # ---------------------------------------------------------------------------------------------
 class _DropoutKeys:
-    """Per-site dropout keys: mix(torch seed, running counter).  `torch.manual_seed(s)` therefore
-    reproduces the masks; backward re-uses the key saved by forward."""
-
-    def __init__(self):
-        self.seed = None
-        self.counter = 0
+    """Per-site dropout keys drawn from the device's default torch generator: key = mix(seed, Philox
+    offset), and the offset is advanced like any torch random op would.  `torch.manual_seed(s)`
+    therefore reproduces the masks and `torch.cuda.get_rng_state()` checkpoints them; backward
+    re-uses the key saved by forward."""
 
     def next(self):
-        seed = torch.initial_seed()
-        if seed != self.seed:
-            self.seed, self.counter = seed, 0
-        self.counter += 1
-        x = (seed * 0x9E3779B97F4A7C15 + self.counter * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        gen = torch.cuda.default_generators[torch.cuda.current_device()]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4)
+        x = (seed * 0x9E3779B97F4A7C15 + (off + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
         x ^= x >> 31
         return (x * 0x94D049BB133111EB >> 16) & 0xFFFFFFFF
 
@@ -67,14 +64,17 @@ class ShadowCache:
     counter or storage changes.  Several parameters can share one contiguous shadow (Q|K|V)."""
 
     def __init__(self):
-        self._store = weakref.WeakKeyDictionary()
+        self._store = {}  # id(head parameter) -> (signature, buffer, dtype); entry dies with the parameter
 
     def get(self, *params, dtype=BF16):
         head = params[0]
-        ent = self._store.get(head)
-        sig = tuple((p._version, p.data_ptr()) for p in params)
+        key = id(head)
+        ent = self._store.get(key)
+        sig = tuple((id(p), p._version, p.data_ptr()) for p in params)
         if ent is not None and ent[0] == sig and ent[2] == dtype:
             return ent[1]
+        if ent is None:
+            weakref.finalize(head, self._store.pop, key, None)
         rows = sum(p.shape[0] for p in params)
         shape = (rows,) + tuple(head.shape[1:])
         buf = ent[1] if ent is not None and ent[1].shape == shape and ent[2] == dtype else torch.empty(
@@ -90,7 +90,7 @@ class ShadowCache:
             else:
                 buf[r:r + n].copy_(src)
             r += n
-        self._store[head] = (sig, buf, dtype)
+        self._store[key] = (sig, buf, dtype)
         return buf
 
 

@@ -1,0 +1,111 @@
+"""Data-parallel gradient synchronisation for one node of MI355Xs.
+
+Replaces the `DistributedDataParallel` wrap at mmf/trainers/core/device.py:104-110 (collective C1 of
+SURVEY.md §2.3: a mean all-reduce of all 114 M gradients every step).  Same semantics — every rank
+ends `backward()` with the average gradient in `param.grad`, parameters that received no gradient
+(the BertPooler under `pooler_strategy: vqa`; the reference needs `find_unused_parameters=True` for
+it, tools/sweeps/sweep_visual_bert.py:41) are simply skipped — but shaped for xGMI:
+
+  * gradients are packed into a few LARGE flat buckets (default 64 MiB) in the order backward produces
+    them (head -> layer 11 ... 0 -> embeddings), because an xGMI ring all-reduce is bound by one
+    153 GB/s link and per-collective latency, not by switch bandwidth;
+  * a bucket is all-reduced (RCCL, `backend="nccl"`) on the communicator's own stream as soon as its
+    last gradient has been accumulated (`register_post_accumulate_grad_hook`), overlapping the
+    remaining backward kernels;
+  * `finish()` waits for the in-flight buckets, scales by 1/world and scatters the result back into
+    `param.grad`.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradientReducer:
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, comm_dtype=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm_dtype = comm_dtype
+        # reverse registration order ~ order in which backward produces gradients
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()
+        self.buckets = []
+        cur, size = [], 0
+        for p in params:
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._bucket_of[id(p)] = bi
+        self._skip = set()   # parameters that produced no gradient in earlier steps (e.g. the pooler)
+        self._ready = [set() for _ in self.buckets]
+        self._inflight = []
+        self._handles = []
+        if self.world > 1:
+            for p in params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def reset(self):
+        self._ready = [set() for _ in self.buckets]
+        self._inflight = []
+        self._launched = [False] * len(self.buckets)
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[id(p)]
+        self._ready[bi].add(id(p))
+        if not self._launched[bi] and len(self._ready[bi]) >= self._expected(bi):
+            self._launch(bi)
+
+    def _expected(self, bi):
+        return sum(1 for p in self.buckets[bi] if id(p) not in self._skip)
+
+    def _launch(self, bi):
+        self._launched[bi] = True
+        plist = [p for p in self.buckets[bi] if p.grad is not None]
+        if not plist:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in plist])
+        if self.comm_dtype is not None and flat.dtype != self.comm_dtype:
+            flat = flat.to(self.comm_dtype)
+        work = dist.all_reduce(flat, group=self.group, async_op=True)
+        self._inflight.append((work, flat, plist))
+
+    def finish(self):
+        """Call after `loss.backward()`: flush partially filled buckets (parameters without a gradient
+        never report), wait, average, scatter back."""
+        if self.world <= 1:
+            return
+        for bi in range(len(self.buckets)):
+            for p in self.buckets[bi]:
+                if p.grad is None:
+                    self._skip.add(id(p))   # do not wait for it next step
+                else:
+                    self._skip.discard(id(p))
+            if not self._launched[bi]:
+                self._launch(bi)
+        inv = 1.0 / self.world
+        for work, flat, plist in self._inflight:
+            work.wait()
+            off = 0
+            for p in plist:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad).to(p.grad.dtype)).mul_(inv)
+                off += n
+        self.reset()
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def parallelize_model(model, **kw):
+    """TrainerDeviceMixin.parallelize_model (device.py:75-113), MI355X flavour: returns the reducer to
+    call `finish()` on after backward (a no-op at world size 1)."""
+    return GradientReducer(model, **kw)

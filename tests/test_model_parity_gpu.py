@@ -15,7 +15,7 @@ TOL = 5e-2
 
 
 def rel_err(a, b):
-    a = a.double().flatten().cpu(); b = b.double().flatten().cpu()
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
@@ -24,10 +24,10 @@ def test_golden_small64_forward_loss_and_gradients():
     model = build_visual_bert(cfg, sd, output_hidden_states=True)
     model.eval()
     out = model(SampleList(sample_to(sample, "cuda")))
-    scores = out["scores"].float().cpu().numpy()
+    scores = out["scores"].detach().float().cpu().numpy()
     assert scores.shape == z["scores"].shape
     np.testing.assert_allclose(scores, z["scores"], rtol=TOL, atol=TOL)
-    np.testing.assert_allclose(out["sequence_output"].float().cpu().numpy(), z["sequence_output"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(out["sequence_output"].detach().float().cpu().numpy(), z["sequence_output"], rtol=TOL, atol=TOL)
     (key, loss), = out["losses"].items()
     assert key == "train/vqa2/logit_bce"
     assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
@@ -41,6 +41,12 @@ def test_golden_small64_forward_loss_and_gradients():
             continue
         assert p.grad is not None, gname
         gn = float(p.grad.double().norm())
+        if str(gname).endswith("self.key.bias"):
+            # d/d(key bias) is identically zero in exact arithmetic (a per-query constant shift of the scores
+            # cancels in the softmax): both sides hold rounding noise only.  Check it is small, not equal.
+            qn = float(params[str(gname).replace("key.bias", "query.bias")].grad.double().norm())
+            assert gn <= TOL * qn + 1e-6, (gname, gn, qn)
+            continue
         worst[str(gname)] = abs(gn - norm) / norm
         full = "grad::" + str(gname)
         if full in z.files:
@@ -84,7 +90,14 @@ def test_full_config_forward_backward_matches_oracle():
         if v.grad is None or float(v.grad.abs().max()) == 0.0:
             continue
         assert p.grad is not None, k
+        if k.endswith("self.key.bias"):  # exactly zero in exact arithmetic (see the golden test): noise vs noise
+            qn = float(params["model." + k.replace("key.bias", "query.bias")].grad.double().norm())
+            assert float(p.grad.double().norm()) <= TOL * qn + 1e-6, k
+            continue
         errs[k] = rel_err(p.grad, v.grad)
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({k: float(e) for k, e in errs.items()}, open("gpurun_out/full_config_grad_rel_err.json", "w"), indent=1)
     bad = {k: round(e, 4) for k, e in errs.items() if e > TOL}
     assert not bad, bad
 

@@ -78,8 +78,12 @@ typedef struct mmf_gemm_desc {
     uint32_t drop_thr16;
     float drop_scale;
     int grp_in, grp_pad, grp_off;
+    void* splitk_ws;          /* optional fp32 workspace enabling deterministic split-K (fp32 output, no epilogue) */
+    int64_t splitk_ws_bytes;  /* >= mmf_gemm_splitk_splits(M,N,K) * M * N * 4 to take effect */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
+/* Number of K splits mmf_gemm_bf16 will use for this shape when given a workspace (1 = no split). */
+int mmf_gemm_splitk_splits(int M, int N, int K);
 
 /* ---- fused multi-head attention -------------------------------------------------------------
  * Replaces BertSelfAttentionJit.forward, mmf/modules/hf_layers.py:161-213 (scores = QK^T /
@@ -182,10 +186,12 @@ int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* str
 
 /* ---- loss: LogitBinaryCrossEntropy, mmf/modules/losses.py:225-251 ---------------------------
  * loss = mean(BCEWithLogits(scores, targets)) * N.  scores/targets fp32 [B, N] (row stride N).
- * fwd writes the scalar to loss[0].  bwd writes dscores (bf16, row stride ldd >= N, pad columns
+ * fwd writes the scalar to loss[0] (ws: fp32 workspace of mmf_bce_logits_ws_floats() floats; the
+ * two-stage reduction is deterministic).  bwd writes dscores (bf16, row stride ldd >= N, pad columns
  * zeroed) = gscale * (sigmoid(x) - t) / B, gscale read from the device scalar gloss (or 1 if NULL).
  */
-int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, int B, int N, void* stream);
+int mmf_bce_logits_ws_floats(void);
+int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, float* ws, int B, int N, void* stream);
 int mmf_bce_logits_bwd(const float* scores, const float* targets, const float* gloss, void* dscores, int ldd,
                        int B, int N, void* stream);
 

@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("resid", C.c_void_p), ("ldr", C.c_int),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float),
         ("grp_in", C.c_int), ("grp_pad", C.c_int), ("grp_off", C.c_int),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -144,6 +145,11 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
     d.resid, d.ldr = _p(resid), ldr
     d.drop_key, d.drop_thr16, d.drop_scale = drop
     d.grp_in, d.grp_pad, d.grp_off = grp
+    if d.out_f32 and a_kmajor and b_kmajor and bias is None and resid is None and act == 0:
+        sp = lib().mmf_gemm_splitk_splits(M, N, K)
+        if sp > 1:
+            ws = torch.empty(sp * M * N, dtype=torch.float32, device=C_out.device)
+            d.splitk_ws, d.splitk_ws_bytes = _p(ws), ws.numel() * 4
     _check(lib().mmf_gemm_bf16(C.byref(d), _stream()), "mmf_gemm_bf16")
 
 
@@ -284,7 +290,8 @@ def make_additive_mask(mask, out):
 def bce_logits_fwd(scores, targets, loss, B, N):
     for t, n in ((scores, "scores"), (targets, "targets"), (loss, "loss")):
         _req(t, torch.float32, n)
-    _check(lib().mmf_bce_logits_fwd(_p(scores), _p(targets), _p(loss), B, N, _stream()), "mmf_bce_logits_fwd")
+    ws = torch.empty(lib().mmf_bce_logits_ws_floats(), dtype=torch.float32, device=scores.device)
+    _check(lib().mmf_bce_logits_fwd(_p(scores), _p(targets), _p(loss), _p(ws), B, N, _stream()), "mmf_bce_logits_fwd")
 
 
 def bce_logits_bwd(scores, targets, gloss, dscores, ldd, B, N):

@@ -50,6 +50,8 @@ struct EpiArgs {
     DropoutCfg drop;    // applied to (acc + bias) before the residual add; index = m*N + n
     int grp_in, grp_pad, grp_off;  // output row remap: row = m + (m / grp_in) * grp_pad + grp_off
     int M, N;
+    long slab_stride;   // split-K: split s writes its partial tile to C + s * slab_stride (fp32 slabs)
+    int splits;
 };
 
 DEVI int rot_kmajor(int krow) { return 32 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
@@ -128,6 +130,46 @@ DEVI void stage_store(const Stage<T>& st, unsigned char* lds, int tid) {
     }
 }
 
+// ---- global -> LDS direct (LDS-DMA, global_load_lds_dwordx4) -------------------------------------
+// One wave-instruction moves 64 x 16 B = 1 KiB to LDS at (wave-uniform base) + lane * 16, so the LDS
+// image is lane-linear and the swizzle / rotation is applied to each lane's SOURCE address instead
+// (the same involution the fragment reads apply).  Out-of-range chunks read a 16-byte zero buffer.
+__device__ uint4 g_zero16;
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+template <bool KMAJOR, bool RAGGED>
+DEVI void stage_dma(const bf16* base, int ld, int r0, int k0, int R, int K, unsigned char* lds, int tid) {
+    const int wave = tid >> 6;
+    if (!KMAJOR) {
+        const int sw = (tid >> 3) & 7;
+        const int k = k0 + ((tid & 7) ^ sw) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = r0 + (tid >> 3) + 32 * i;
+            if (RAGGED) row = row < R ? row : R - 1;
+            const bf16* src = base + (size_t)row * ld + k;
+            if (RAGGED && k >= K) src = reinterpret_cast<const bf16*>(&g_zero16);
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * 4096 + wave * 1024), 16, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = (tid >> 4) + 16 * i;
+            const int logical = ((tid & 15) - (rot_kmajor(kr) >> 4)) & 15;
+            const int col = r0 + logical * 8;
+            const int krow = k0 + kr;
+            const bf16* src = base + (size_t)krow * ld + col;
+            if (RAGGED && (col >= R || krow >= K)) src = reinterpret_cast<const bf16*>(&g_zero16);
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * 4096 + wave * 1024), 16, 0, 0);
+        }
+    }
+}
+
+template <typename T> struct is_bf16 { static constexpr bool value = false; };
+template <> struct is_bf16<bf16> { static constexpr bool value = true; };
+
 // ---- LDS -> MFMA fragment ---------------------------------------------------------------------
 // Fragment f (16 rows starting at wrow0 + 16 f), k sub-step kk (32 k each). Lane l holds tile row
 // (l & 15) and the 8 reduction slots of lane group g = l >> 4; both layouts use reduction rows
@@ -160,7 +202,7 @@ DEVI f32x4 load_f4(const float* p) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     return f32x4{t.x, t.y, t.z, t.w};
 }
-DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc) {
+DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc, int split) {
     if (m >= e.M || n >= e.N) return;
     const bool full = (n + 4 <= e.N);
     f32x4 v = acc;
@@ -188,7 +230,7 @@ DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc) {
     }
     int orow = m;
     if (e.grp_in > 0) orow = m + (m / e.grp_in) * e.grp_pad + e.grp_off;
-    const size_t off = (size_t)orow * e.ldc + n;
+    const size_t off = (size_t)orow * e.ldc + n + (size_t)split * e.slab_stride;
     const bool vec = full && ((e.ldc & 3) == 0);
     if (e.act == 1) {
         if (e.U) {
@@ -249,8 +291,9 @@ DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc) {
 template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
                                                              int M, int N, int K, int lda, int ldb,
-                                                             int tiles_m, int tiles_n, EpiArgs epi) {
+                                                             int tiles_m, int tiles_n, int splits, EpiArgs epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool A_DMA = is_bf16<AT>::value, B_DMA = is_bf16<BT>::value;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -258,12 +301,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict_
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of the
     // (m-major, n-fastest) tile list so the A row panel and the weight panel stay in its L2.
-    const int nblk = tiles_m * tiles_n;
+    const int ntile = tiles_m * tiles_n;
+    const int nblk = ntile * splits;
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
+    const int split = bid / ntile;
+    bid -= split * ntile;
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -275,24 +321,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict_
 
     Stage<AT> sa;
     Stage<BT> sb;
-    const int nk = (K + BK - 1) / BK;
+    const int nk_all = (K + BK - 1) / BK;
+    const int kt0 = (int)((long)nk_all * split / splits), kt1 = (int)((long)nk_all * (split + 1) / splits);
+    const int nk = kt1 - kt0;
 
-    stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, 0, M, K, tid);
-    stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, 0, N, K, tid);
-    stage_store<AT, A_KMAJOR>(sa, smem, tid);
-    stage_store<BT, B_KMAJOR>(sb, smem + OPER_BYTES, tid);
+    // prologue: tile kt0 -> stage 0
+    if (A_DMA) stage_dma<A_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(A), lda, m0, kt0 * BK, M, K, smem, tid);
+    else { stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, kt0 * BK, M, K, tid); stage_store<AT, A_KMAJOR>(sa, smem, tid); }
+    if (B_DMA) stage_dma<B_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(B), ldb, n0, kt0 * BK, N, K, smem + OPER_BYTES, tid);
+    else { stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, kt0 * BK, N, K, tid); stage_store<BT, B_KMAJOR>(sb, smem + OPER_BYTES, tid); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const unsigned char* la = smem + cur * 2 * OPER_BYTES;
         const unsigned char* lb = la + OPER_BYTES;
-        // Prefetch the next K-tile into registers while this one is multiplied.  The last iteration
-        // re-fetches its own tile (into the idle buffer) so the loop body stays branch-free and the
-        // staging registers never become a loop-carried aggregate (which hipcc would put in scratch).
-        const int kn = (kt + 1 < nk) ? kt + 1 : kt;
-        stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, kn * BK, M, K, tid);
-        stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, kn * BK, N, K, tid);
+        unsigned char* na = smem + (cur ^ 1) * 2 * OPER_BYTES;
+        // Prefetch the next K-tile while this one is multiplied (the last iteration re-fetches its own
+        // tile into the idle buffer so the loop body stays branch-free).  bf16 operands go straight to
+        // LDS by DMA; fp32 operands are converted in registers and written after the MFMAs.
+        const int kn = kt0 + ((kt + 1 < nk) ? kt + 1 : kt);
+        if (A_DMA) stage_dma<A_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(A), lda, m0, kn * BK, M, K, na, tid);
+        else stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, kn * BK, M, K, tid);
+        if (B_DMA) stage_dma<B_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(B), ldb, n0, kn * BK, N, K, na + OPER_BYTES, tid);
+        else stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, kn * BK, N, K, tid);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue ahead of the MFMAs
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[4], fb[4];
@@ -306,9 +360,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict_
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        unsigned char* na = smem + (cur ^ 1) * 2 * OPER_BYTES;
-        stage_store<AT, A_KMAJOR>(sa, na, tid);
-        stage_store<BT, B_KMAJOR>(sb, na + OPER_BYTES, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!A_DMA) stage_store<AT, A_KMAJOR>(sa, na, tid);
+        if (!B_DMA) stage_store<BT, B_KMAJOR>(sb, na + OPER_BYTES, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -319,17 +374,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            epilogue4(epi, m, n, acc[i][j]);
+            epilogue4(epi, m, n, acc[i][j], split);
         }
     }
+}
+
+// C[m][n] = beta * C[m][n] + sum_s slab[s][m][n]   (N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long n, int N, float* __restrict__ C,
+                                                             int ldc, float beta) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 acc = load_f4(ws + i);
+    for (int s = 1; s < splits; ++s) acc += load_f4(ws + (long)s * n + i);
+    const long m = i / N;
+    float* c = C + m * ldc + (i - m * N);
+    if (beta != 0.f) acc += beta * load_f4(c);
+    *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG>), dim3(tm * tn), dim3(256), 4 * OPER_BYTES, s,
+    const int splits = e.splits > 1 ? e.splits : 1;
+    const EpiArgs& e2 = e;
+    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG>), dim3(tm * tn * splits), dim3(256), 4 * OPER_BYTES, s,
                        reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
-                       d->lda, d->ldb, tm, tn, e);
+                       d->lda, d->ldb, tm, tn, splits, e2);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -355,20 +425,55 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     e.drop.key = d->drop_key; e.drop.thr16 = d->drop_thr16; e.drop.scale = d->drop_scale;
     e.grp_in = d->grp_in; e.grp_pad = d->grp_pad; e.grp_off = d->grp_off;
     e.M = d->M; e.N = d->N;
+    // Split-K: a weight-gradient GEMM has few output tiles (768x768 -> 36) and a long reduction (K = tokens).
+    // With a workspace, the K range is spread over `splits` workgroups per tile; each writes an fp32 partial slab
+    // and a second kernel sums the slabs in a fixed order (deterministic, no atomics).
+    e.slab_stride = 0; e.splits = 1;
+    float* final_c = nullptr; int final_ldc = 0; float final_beta = 0.f;
+    {
+        const int sp = mmf_gemm_splitk_splits(d->M, d->N, d->K);
+        const bool plain = d->out_f32 && !d->bias && !d->coladd && !d->rowtab && d->act == 0 && !d->resid && !d->drop_thr16 &&
+                           d->grp_in == 0;
+        if (plain && sp > 1 && d->splitk_ws && d->splitk_ws_bytes >= (long)sp * d->M * d->N * (long)sizeof(float)) {
+            e.splits = sp;
+            e.slab_stride = (long)d->M * d->N;
+            final_c = reinterpret_cast<float*>(d->C); final_ldc = d->ldc; final_beta = d->beta;
+            e.C = d->splitk_ws; e.ldc = d->N; e.beta = 0.f;
+        }
+    }
     MMF_CHECK_ARG(d->act != 2 || d->aux, "mmf_gemm_bf16: act=2 needs aux");
     MMF_CHECK_ARG(!d->rowtab || d->rowidx, "mmf_gemm_bf16: rowtab needs rowidx");
 
     // ragged unless every tile is full and every chunk in range
     const bool ragged = (d->M % BM) || (d->N % BN) || (d->K % BK);
     const int key = (d->a_kmajor ? 1 : 0) | (d->b_kmajor ? 2 : 0) | (d->a_f32 ? 4 : 0) | (d->b_f32 ? 8 : 0);
+    int rc = -1;
     switch (key) {
-        case 0: return ragged ? launch<bf16, bf16, false, false, true>(d, e, s) : launch<bf16, bf16, false, false, false>(d, e, s);
-        case 4: return ragged ? launch<float, bf16, false, false, true>(d, e, s) : launch<float, bf16, false, false, false>(d, e, s);
-        case 2: return ragged ? launch<bf16, bf16, false, true, true>(d, e, s) : launch<bf16, bf16, false, true, false>(d, e, s);
-        case 3: return ragged ? launch<bf16, bf16, true, true, true>(d, e, s) : launch<bf16, bf16, true, true, false>(d, e, s);
-        case 11: return ragged ? launch<bf16, float, true, true, true>(d, e, s) : launch<bf16, float, true, true, false>(d, e, s);
-        default: break;
+        case 0: rc = ragged ? launch<bf16, bf16, false, false, true>(d, e, s) : launch<bf16, bf16, false, false, false>(d, e, s); break;
+        case 4: rc = ragged ? launch<float, bf16, false, false, true>(d, e, s) : launch<float, bf16, false, false, false>(d, e, s); break;
+        case 2: rc = ragged ? launch<bf16, bf16, false, true, true>(d, e, s) : launch<bf16, bf16, false, true, false>(d, e, s); break;
+        case 3: rc = ragged ? launch<bf16, bf16, true, true, true>(d, e, s) : launch<bf16, bf16, true, true, false>(d, e, s); break;
+        case 11: rc = ragged ? launch<bf16, float, true, true, true>(d, e, s) : launch<bf16, float, true, true, false>(d, e, s); break;
+        default:
+            mmf_amd_set_error("mmf_gemm_bf16: unsupported operand layout combination");
+            return 1;
     }
-    mmf_amd_set_error("mmf_gemm_bf16: unsupported operand layout combination");
-    return 1;
+    if (rc != 0) return rc;
+    if (final_c) {
+        const long n = (long)d->M * d->N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(d->splitk_ws), e.splits, n, d->N, final_c, final_ldc, final_beta);
+        MMF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int mmf_gemm_splitk_splits(int M, int N, int K) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int nk_all = (K + BK - 1) / BK;
+    if (tiles >= 384 || nk_all < 8 || (N % 4) != 0) return 1;
+    int sp = (512 + tiles - 1) / tiles;
+    if (sp > nk_all / 4) sp = nk_all / 4;
+    if (sp > 16) sp = 16;
+    return sp < 1 ? 1 : sp;
 }

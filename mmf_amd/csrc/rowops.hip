@@ -142,16 +142,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     }
 }
 
-// out_q[col] (+)= sum_blk partials[blk][q][col]
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblk, int H, float* o0, float* o1, float* o2,
-                                     int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+// out_q[col] (+)= sum_blk partials[blk][q][col].  Workgroup = 8 row-groups x 32 columns.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblk, int H, float* o0, float* o1,
+                                                             float* o2, int accumulate) {
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
     const int qn = blockIdx.y;
     float* out = (qn == 0) ? o0 : (qn == 1) ? o1 : o2;
-    if (col >= H || out == nullptr) return;
+    if (out == nullptr) return;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partials[((size_t)b * 3 + qn) * H + col];
-    out[col] = accumulate ? out[col] + s : s;
+    if (col < H)
+        for (int b = rg; b < nblk; b += 8) s += partials[((size_t)b * 3 + qn) * H + col];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && col < H) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][c];
+        out[col] = accumulate ? out[col] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,16 +210,16 @@ __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __r
     }
 }
 
-// <= 2 buckets: accumulate 64 rows per workgroup in registers, then one atomic per column per bucket.
+// <= 2 buckets: accumulate 16 rows per workgroup in registers, then one atomic per column per bucket.
 __global__ __launch_bounds__(256) void scatter_add_few_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                const int64_t* __restrict__ idx, int idx_ld, int per_pos,
                                                                int idx_base, float* __restrict__ out, int H) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nb * rpb;
-    const int r0 = blockIdx.x * 64;
+    const int r0 = blockIdx.x * 16;
     for (int col = lane * 4; col < H; col += 256) {
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        for (int k = wave; k < 64; k += 4) {
+        for (int k = wave; k < 16; k += 4) {
             const int r = r0 + k;
             if (r >= total) break;
             const int b = r / rpb, i = r - b * rpb;
@@ -275,12 +285,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c < N) partials[(size_t)blockIdx.x * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void colsum_reduce_kernel(const float* __restrict__ partials, int ngroups, int N, float* __restrict__ out, float beta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partials, int ngroups, int N, float* __restrict__ out,
+                                                             float beta) {
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int g = 0; g < ngroups; ++g) s += partials[(size_t)g * N + c];
-    out[c] = (beta != 0.f) ? beta * out[c] + s : s;
+    if (col < N)
+        for (int g = rg; g < ngroups; g += 8) s += partials[(size_t)g * N + col];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && col < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][c];
+        out[col] = (beta != 0.f) ? beta * out[col] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,12 +367,12 @@ __global__ __launch_bounds__(256) void cast2d_bf16_f32_kernel(const bf16* __rest
 // ------------------------------------------------------------------------------------------------
 // BCE with logits (losses.py:246-251)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ loss,
-                                                        int B, int N) {
-    __shared__ float red[16];
-    const int64_t n = (int64_t)B * N;
+constexpr int BCE_BLOCKS = 128;
+__global__ __launch_bounds__(256) void bce_fwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                               float* __restrict__ partial, int64_t n) {
+    __shared__ float red[4];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float xv = x[i], tv = t[i];
         // numerically stable form used by ATen: max(x,0) - x*t + log1p(exp(-|x|))
         s += fmaxf(xv, 0.f) - xv * tv + log1pf(__expf(-fabsf(xv)));
@@ -360,12 +380,14 @@ __global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* __restrict__
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < 16; ++i) tot += red[i];
-        // mean over B*N, times N  ==  sum / B
-        loss[0] = tot / (float)B;
-    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void bce_fwd_final_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ loss, int B) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += partial[i];
+    s = wave_sum(s);
+    // mean over B*N, times N  ==  sum / B
+    if (threadIdx.x == 0) loss[0] = s / (float)B;
 }
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
                                                        const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int B, int N) {
@@ -501,7 +523,7 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
         default: launch_ln_bwd<4>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
     }
     MMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((H + 255) / 256, 3), dim3(256), 0, s, partials, grid, H, dgamma, dbeta, dbias,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((H + 31) / 32, 3), dim3(256), 0, s, partials, grid, H, dgamma, dbeta, dbias,
                        accumulate);
     MMF_CHECK_LAUNCH();
     return 0;
@@ -523,7 +545,7 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
     MMF_CHECK_ARG(nb > 0 && rpb > 0 && (H % 4) == 0 && (ld % 4) == 0, "rows_scatter_add: bad shape");
     const int total = nb * rpb;
     if (few_buckets)
-        hipLaunchKernelGGL(scatter_add_few_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld,
+        hipLaunchKernelGGL(scatter_add_few_kernel, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld,
                            nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H);
     else
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
@@ -558,7 +580,7 @@ int mmf_colsum_bf16(const void* x, int ld, int nb, int rpb, int bstride, int N, 
     hipLaunchKernelGGL(colsum_kernel, dim3(groups, (N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb,
                        bstride, N, partials);
     MMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, groups, N, out, beta);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, groups, N, out, beta);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -615,9 +637,12 @@ int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int ro
     return 0;
 }
 
-int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, int B, int N, void* stream) {
-    MMF_CHECK_ARG(scores && targets && loss && B > 0 && N > 0, "bce_fwd: bad operand");
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, targets, loss, B, N);
+int mmf_bce_logits_ws_floats(void) { return BCE_BLOCKS; }
+int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, float* ws, int B, int N, void* stream) {
+    MMF_CHECK_ARG(scores && targets && loss && ws && B > 0 && N > 0, "bce_fwd: bad operand");
+    hipLaunchKernelGGL(bce_fwd_partial_kernel, dim3(BCE_BLOCKS), dim3(256), 0, (hipStream_t)stream, scores, targets, ws, (int64_t)B * N);
+    MMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bce_fwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, BCE_BLOCKS, loss, B);
     MMF_CHECK_LAUNCH();
     return 0;
 }

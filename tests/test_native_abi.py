@@ -43,7 +43,7 @@ def test_abi_version_and_target(built_lib):
 
 
 def test_binding_structs_match_header_field_order():
-    src = open(_native.HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", open(_native.HEADER_PATH).read(), flags=re.S)
     body = re.search(r"typedef struct mmf_gemm_desc \{(.*?)\} mmf_gemm_desc;", src, flags=re.S).group(1)
     fields = []
     for decl in body.split(";"):

@@ -1,0 +1,269 @@
+// mmf_amd :: device code shared by the GEMM kernels (LDS images, LDS-DMA staging, MFMA fragment reads,
+// fused epilogue).  See gemm.hip for the layout description.
+#pragma once
+#include "common.h"
+#include "mmf_amd.h"
+
+namespace gemm {
+
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int OPER_BYTES = 16384;  // one operand tile in LDS
+
+struct EpiArgs {
+    void* C;            // output
+    int ldc;
+    int out_f32;        // 1: C is float, else bf16
+    float beta;         // C = acc + beta*C   (fp32 output only; gradient accumulation)
+    const float* bias;  // [N] or null
+    const float* coladd;  // [N] extra per-column addend or null
+    const float* rowtab;  // optional table gathered per output row: rowtab[rowidx[m]*rowtab_ld + n]
+    const int64_t* rowidx;
+    int rowtab_ld;
+    int act;            // 0 none | 1 gelu(acc) (U := pre-activation if U != null) | 2 acc * gelu'(aux)
+    bf16* U;
+    const bf16* aux;    // same indexing as C (ldc)
+    const bf16* resid;  // added after activation/dropout, ldr
+    int ldr;
+    DropoutCfg drop;    // applied to (acc + bias) before the residual add; index = m*N + n
+    int grp_in, grp_pad, grp_off;  // output row remap: row = m + (m / grp_in) * grp_pad + grp_off
+    int M, N;
+    long slab_stride;   // split-K: split s writes its partial tile to C + s * slab_stride (fp32 slabs)
+    int splits;
+};
+
+DEVI int rot_kmajor(int krow) { return 32 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
+
+// ---- global -> register staging -------------------------------------------------------------
+template <typename T>
+struct Stage;  // 4 chunks of 8 elements per thread per operand tile
+
+template <>
+struct Stage<bf16> {
+    uint4 v[4];
+    template <bool RAGGED>
+    DEVI void load(int i, const bf16* p, bool ok) {
+        if (RAGGED && !ok) v[i] = make_uint4(0, 0, 0, 0);
+        else v[i] = *reinterpret_cast<const uint4*>(p);
+    }
+};
+template <>
+struct Stage<float> {
+    uint4 v[4];
+    template <bool RAGGED>
+    DEVI void load(int i, const float* p, bool ok) {
+        if (RAGGED && !ok) { v[i] = make_uint4(0, 0, 0, 0); return; }
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        bf16x8 r;
+        r[0] = (bf16)a.x; r[1] = (bf16)a.y; r[2] = (bf16)a.z; r[3] = (bf16)a.w;
+        r[4] = (bf16)b.x; r[5] = (bf16)b.y; r[6] = (bf16)b.z; r[7] = (bf16)b.w;
+        v[i] = __builtin_bit_cast(uint4, r);
+    }
+};
+
+// Issue the global loads of one operand tile (rows [r0, r0+128) x k [k0, k0+64)).
+template <typename T, bool KMAJOR, bool RAGGED>
+DEVI void stage_load(Stage<T>& st, const T* base, int ld, int r0, int k0, int R, int K, int tid) {
+    if (!KMAJOR) {
+        const int kc = tid & 7;
+        const int k = k0 + kc * 8;
+        const bool kok = k < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = r0 + (tid >> 3) + 32 * i;
+            if (RAGGED) row = row < R ? row : R - 1;
+            st.template load<RAGGED>(i, base + (size_t)row * ld + k, kok);
+        }
+    } else {
+        const int nc = tid & 15;
+        const int col = r0 + nc * 8;
+        const bool cok = col < R;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int krow = k0 + (tid >> 4) + 16 * i;
+            const bool ok = cok && (krow < K);
+            st.template load<RAGGED>(i, base + (size_t)(RAGGED ? (ok ? krow : 0) : krow) * ld + (RAGGED ? (ok ? col : 0) : col), ok);
+        }
+    }
+}
+
+template <typename T, bool KMAJOR>
+DEVI void stage_store(const Stage<T>& st, unsigned char* lds, int tid) {
+    if (!KMAJOR) {
+        const int kc = tid & 7;
+        const int sw = (tid >> 3) & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(lds + row * 128 + ((kc ^ sw) << 4)) = st.v[i];
+        }
+    } else {
+        const int nc = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int krow = (tid >> 4) + 16 * i;
+            *reinterpret_cast<uint4*>(lds + krow * 256 + ((nc * 16 + rot_kmajor(krow)) & 255)) = st.v[i];
+        }
+    }
+}
+
+// ---- global -> LDS direct (LDS-DMA, global_load_lds_dwordx4) -------------------------------------
+// One wave-instruction moves 64 x 16 B = 1 KiB to LDS at (wave-uniform base) + lane * 16, so the LDS
+// image is lane-linear and the swizzle / rotation is applied to each lane's SOURCE address instead
+// (the same involution the fragment reads apply).  Out-of-range chunks read a 16-byte zero buffer.
+static __device__ uint4 g_zero16;
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+template <bool KMAJOR, bool RAGGED>
+DEVI void stage_dma(const bf16* base, int ld, int r0, int k0, int R, int K, unsigned char* lds, int tid) {
+    const int wave = tid >> 6;
+    if (!KMAJOR) {
+        const int sw = (tid >> 3) & 7;
+        const int k = k0 + ((tid & 7) ^ sw) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = r0 + (tid >> 3) + 32 * i;
+            if (RAGGED) row = row < R ? row : R - 1;
+            const bf16* src = base + (size_t)row * ld + k;
+            if (RAGGED && k >= K) src = reinterpret_cast<const bf16*>(&g_zero16);
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * 4096 + wave * 1024), 16, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = (tid >> 4) + 16 * i;
+            const int logical = ((tid & 15) - (rot_kmajor(kr) >> 4)) & 15;
+            const int col = r0 + logical * 8;
+            const int krow = k0 + kr;
+            const bf16* src = base + (size_t)krow * ld + col;
+            if (RAGGED && (col >= R || krow >= K)) src = reinterpret_cast<const bf16*>(&g_zero16);
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * 4096 + wave * 1024), 16, 0, 0);
+        }
+    }
+}
+
+template <typename T> struct is_bf16 { static constexpr bool value = false; };
+template <> struct is_bf16<bf16> { static constexpr bool value = true; };
+
+// ---- LDS -> MFMA fragment ---------------------------------------------------------------------
+// Fragment f (16 rows starting at wrow0 + 16 f), k sub-step kk (32 k each). Lane l holds tile row
+// (l & 15) and the 8 reduction slots of lane group g = l >> 4; both layouts use reduction rows
+// kk*32 + 8g + [0,8) for group g, so a row operand and a k-major operand pair up correctly.
+template <bool KMAJOR>
+DEVI bf16x8 read_frag(const unsigned char* lds, int wrow0, int f, int kk, int lane) {
+    if (!KMAJOR) {
+        const int row = wrow0 + f * 16 + (lane & 15);
+        const int chunk = kk * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    } else {
+        const int g = lane >> 4, p = lane & 15;
+        const int col = wrow0 + f * 16 + (p & 3) * 4;
+        const int rot = 32 * ((p >> 2) + 4 * (g & 1));
+        const int krow0 = kk * 32 + 8 * g + (p >> 2);
+        const int cb = (col * 2 + rot) & 255;
+        typedef s16x4 __attribute__((address_space(3))) * lds_p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + krow0 * 256 + cb));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + (krow0 + 4) * 256 + cb));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+// ---- epilogue -----------------------------------------------------------------------------------
+DEVI f32x4 load_f4(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return f32x4{t.x, t.y, t.z, t.w};
+}
+DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc, int split) {
+    if (m >= e.M || n >= e.N) return;
+    const bool full = (n + 4 <= e.N);
+    f32x4 v = acc;
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ok[r] = (n + r) < e.N;
+    if (e.bias) {
+        if (full) v += load_f4(e.bias + n);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += e.bias[n + r];
+        }
+    }
+    if (e.coladd) {
+        if (full) v += load_f4(e.coladd + n);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += e.coladd[n + r];
+        }
+    }
+    if (e.rowtab) {
+        const float* t = e.rowtab + (size_t)e.rowidx[m] * e.rowtab_ld + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += t[r];
+    }
+    int orow = m;
+    if (e.grp_in > 0) orow = m + (m / e.grp_in) * e.grp_pad + e.grp_off;
+    const size_t off = (size_t)orow * e.ldc + n + (size_t)split * e.slab_stride;
+    const bool vec = full && ((e.ldc & 3) == 0);
+    if (e.act == 1) {
+        if (e.U) {
+            if (vec) *reinterpret_cast<bf16x4*>(e.U + off) = pack4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (ok[r]) e.U[off + r] = (bf16)v[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    } else if (e.act == 2) {
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            const bf16x4 ub = *reinterpret_cast<const bf16x4*>(e.aux + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = (float)ub[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) u[r] = (float)e.aux[off + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(u[r]);
+    }
+    if (e.drop.thr16)
+        v *= drop_scale4(e.drop.key, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop.thr16, e.drop.scale);
+    if (e.resid) {
+        const size_t roff = (size_t)orow * e.ldr + n;
+        if (full && ((e.ldr & 3) == 0)) {
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(e.resid + roff);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += (float)e.resid[roff + r];
+        }
+    }
+    if (e.out_f32) {
+        float* C = reinterpret_cast<float*>(e.C) + off;
+        if (vec) {
+            if (e.beta != 0.f) v += e.beta * load_f4(C);
+            *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) C[r] = v[r] + (e.beta != 0.f ? e.beta * C[r] : 0.f);
+        }
+    } else {
+        bf16* C = reinterpret_cast<bf16*>(e.C) + off;
+        if (vec) *reinterpret_cast<bf16x4*>(C) = pack4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[r]) C[r] = (bf16)v[r];
+        }
+    }
+}
+
+
+}  // namespace gemm

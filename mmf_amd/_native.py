@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("resid", C.c_void_p), ("ldr", C.c_int),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float),
         ("grp_in", C.c_int), ("grp_pad", C.c_int), ("grp_off", C.c_int),
-        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("no_ring", C.c_int),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("debug_flags", C.c_int),
     ]
 
 
@@ -58,6 +58,9 @@ class AttnBwdDesc(C.Structure):
 
 
 _lib = None
+# kernel-development switches (see mmf_gemm_desc.debug_flags); all zero in production
+_GEMM_DEBUG = ((int(os.environ.get("MMF_AMD_GEMM_DBG", "0")) << 4) | (int(os.environ.get("MMF_AMD_GEMM_4WAVE", "0")) << 8)
+               | (int(os.environ.get("MMF_AMD_GEMM_NO96", "0")) << 9))
 
 
 def lib():
@@ -122,9 +125,9 @@ def drop_cfg(p, key):
 # --------------------------------------------------------------------------------------------
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
          rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=(0, 0, 1.0),
-         grp=(0, 0, 0), no_ring=False):
+         grp=(0, 0, 0), debug_flags=0):
     d = GemmDesc()
-    d.no_ring = int(no_ring)
+    d.debug_flags = int(debug_flags) | _GEMM_DEBUG
     d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, ldc

@@ -28,21 +28,24 @@
 
 using namespace gemm;
 
-int mmf_gemm_ring_dispatch(const mmf_gemm_desc* d, const gemm::EpiArgs& e, hipStream_t s);
-
 namespace {
 
 // ---- the kernel ---------------------------------------------------------------------------------
-template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
+template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_>
+__global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
                                                              int M, int N, int K, int lda, int ldb,
-                                                             int tiles_m, int tiles_n, int splits, EpiArgs epi) {
+                                                             int tiles_m, int tiles_n, int splits, int dbg, EpiArgs epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool A_DMA = is_bf16<AT>::value, B_DMA = is_bf16<BT>::value;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    // Wave grid over the 128 x BN_ tile.  BN_ = 128: 2 x NWN waves of 64 x (128/NWN).  BN_ = 96 (8 waves only): 4 x 2 waves of 32 x 48,
+    // used where 128-wide tiles would leave a third of the CUs idle in the last round (N = 768 / 2304 at M = 7296).
+    constexpr int NTH = 128 * NWN;
+    constexpr int WGN = (BN_ == 96) ? 2 : NWN, WGM = (2 * NWN) / WGN;
+    constexpr int WTM = 128 / WGM, WTN = BN_ / WGN, NFM = WTM / 16, NFN = WTN / 16;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of the
     // (m-major, n-fastest) tile list so the A row panel and the weight panel stay in its L2.
@@ -55,26 +58,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict_
     }
     const int split = bid / ntile;
     bid -= split * ntile;
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // 8-row super-rows, column-major inside: the ~64 tiles resident on one XCD share 8 A row-panels and a few B
+    // panels that fit its 4 MiB L2 (the weight panel is then re-read once per super-row, not once per row).
+    int tile_m, tile_n;
+    {
+        const int per_sr = 8 * tiles_n;
+        const int sr = bid / per_sr, rem = bid - sr * per_sr;
+        const int h = min(8, tiles_m - sr * 8);
+        tile_n = rem / h;
+        tile_m = sr * 8 + (rem - tile_n * h);
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN_;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NFM][NFN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NFM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NFN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Stage<AT> sa;
-    Stage<BT> sb;
+    const int NB = (BN_ == 128) ? N : min(N, n0 + BN_);   // B rows / columns beyond the tile are never fetched
+    Stage<AT, 1024 / NTH> sa;
+    Stage<BT, 1024 / NTH> sb;
     const int nk_all = (K + BK - 1) / BK;
     const int kt0 = (int)((long)nk_all * split / splits), kt1 = (int)((long)nk_all * (split + 1) / splits);
     const int nk = kt1 - kt0;
 
     // prologue: tile kt0 -> stage 0
-    if (A_DMA) stage_dma<A_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(A), lda, m0, kt0 * BK, M, K, smem, tid);
-    else { stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, kt0 * BK, M, K, tid); stage_store<AT, A_KMAJOR>(sa, smem, tid); }
-    if (B_DMA) stage_dma<B_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(B), ldb, n0, kt0 * BK, N, K, smem + OPER_BYTES, tid);
-    else { stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, kt0 * BK, N, K, tid); stage_store<BT, B_KMAJOR>(sb, smem + OPER_BYTES, tid); }
+    if (A_DMA) stage_dma<A_KMAJOR, RAGGED, NTH>(reinterpret_cast<const bf16*>(A), lda, m0, kt0 * BK, M, K, smem, tid);
+    else { stage_load<AT, A_KMAJOR, RAGGED, NTH>(sa, A, lda, m0, kt0 * BK, M, K, tid); stage_store<AT, A_KMAJOR, NTH>(sa, smem, tid); }
+    if (B_DMA) stage_dma<B_KMAJOR, RAGGED || BN_ != 128, NTH>(reinterpret_cast<const bf16*>(B), ldb, n0, kt0 * BK, NB, K, smem + OPER_BYTES, tid);
+    else { stage_load<BT, B_KMAJOR, RAGGED, NTH>(sb, B, ldb, n0, kt0 * BK, N, K, tid); stage_store<BT, B_KMAJOR, NTH>(sb, smem + OPER_BYTES, tid); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -87,38 +100,48 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const AT* __restrict_
         // tile into the idle buffer so the loop body stays branch-free).  bf16 operands go straight to
         // LDS by DMA; fp32 operands are converted in registers and written after the MFMAs.
         const int kn = kt0 + ((kt + 1 < nk) ? kt + 1 : kt);
-        if (A_DMA) stage_dma<A_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(A), lda, m0, kn * BK, M, K, na, tid);
-        else stage_load<AT, A_KMAJOR, RAGGED>(sa, A, lda, m0, kn * BK, M, K, tid);
-        if (B_DMA) stage_dma<B_KMAJOR, RAGGED>(reinterpret_cast<const bf16*>(B), ldb, n0, kn * BK, N, K, na + OPER_BYTES, tid);
-        else stage_load<BT, B_KMAJOR, RAGGED>(sb, B, ldb, n0, kn * BK, N, K, tid);
+        if (!(dbg & 1)) {
+        if (A_DMA) stage_dma<A_KMAJOR, RAGGED, NTH>(reinterpret_cast<const bf16*>(A), lda, m0, kn * BK, M, K, na, tid);
+        else stage_load<AT, A_KMAJOR, RAGGED, NTH>(sa, A, lda, m0, kn * BK, M, K, tid);
+        if (B_DMA) stage_dma<B_KMAJOR, RAGGED || BN_ != 128, NTH>(reinterpret_cast<const bf16*>(B), ldb, n0, kn * BK, NB, K, na + OPER_BYTES, tid);
+        else stage_load<BT, B_KMAJOR, RAGGED, NTH>(sb, B, ldb, n0, kn * BK, N, K, tid);
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue ahead of the MFMAs
+        if (!(dbg & 2))
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[NFM], fb[NFN];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) fa[f] = read_frag<A_KMAJOR>(la, wm * 64, f, kk, lane);
+            for (int f = 0; f < NFM; ++f) fa[f] = read_frag<A_KMAJOR>(la, wm * WTM, f, kk, lane);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) fb[f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
+            for (int f = 0; f < NFN; ++f) fb[f] = read_frag<B_KMAJOR>(lb, wn * WTN, f, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NFM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NFN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!A_DMA) stage_store<AT, A_KMAJOR>(sa, na, tid);
-        if (!B_DMA) stage_store<BT, B_KMAJOR>(sb, na + OPER_BYTES, tid);
+        if (!A_DMA) stage_store<AT, A_KMAJOR, NTH>(sa, na, tid);
+        if (!B_DMA) stage_store<BT, B_KMAJOR, NTH>(sb, na + OPER_BYTES, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(dbg & 4)) __syncthreads();
     }
 
+    if (dbg & 8) {   // debugging: keep the accumulators alive but skip the epilogue
+#pragma unroll
+        for (int i = 0; i < NFM; ++i)
+#pragma unroll
+            for (int j = 0; j < NFN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     // D = (C tile)^T fragment: lane holds n = 4*(lane>>4) + [0,4), m = lane & 15.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < NFM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        for (int j = 0; j < NFN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
             epilogue4(epi, m, n, acc[i][j], split);
         }
     }
@@ -137,16 +160,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-template <typename AT, typename BT, bool AK, bool BK_, bool RG>
-int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
-    const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN - 1) / BN;
+template <typename AT, typename BT, bool AK, bool BK_, bool RG, int NWN, int BN_>
+int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN_ - 1) / BN_;
     const int splits = e.splits > 1 ? e.splits : 1;
     const EpiArgs& e2 = e;
-    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG>), dim3(tm * tn * splits), dim3(256), 4 * OPER_BYTES, s,
+    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_>), dim3(tm * tn * splits), dim3(128 * NWN), 4 * OPER_BYTES, s,
                        reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
-                       d->lda, d->ldb, tm, tn, splits, e2);
+                       d->lda, d->ldb, tm, tn, splits, (d->debug_flags >> 4) & 15, e2);
     MMF_CHECK_LAUNCH();
     return 0;
+}
+
+template <typename AT, typename BT, bool AK, bool BK_, bool RG>
+int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    // 8 waves (64x32 per wave, 4 waves per SIMD with two workgroups per CU) hide LDS / MFMA-issue latency
+    // better than 4 waves (64x64 per wave); bit 8 of no_ring selects the 4-wave form for A/B measurements.
+    if (d->debug_flags & 256) return launch_n<AT, BT, AK, BK_, RG, 2, 128>(d, e, s);
+    // 96-wide tiles when they need fewer rounds of the 512 workgroup slots (256 CUs x 2) than 128-wide ones
+    if (!RG && !AK && is_bf16<AT>::value && is_bf16<BT>::value && (d->N % 96) == 0 && !(d->debug_flags & 512)) {
+        const long tm = d->M / BM;
+        const long r128 = (tm * ((d->N + 127) / 128) + 511) / 512, r96 = (tm * (d->N / 96) + 511) / 512;
+        if (r96 * 96 < r128 * 128) return launch_n<AT, BT, AK, BK_, false, 4, 96>(d, e, s);
+    }
+    return launch_n<AT, BT, AK, BK_, RG, 4, 128>(d, e, s);
 }
 
 }  // namespace
@@ -192,8 +229,8 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     // ragged unless every tile is full and every chunk in range
     const bool ragged = (d->M % BM) || (d->N % BN) || (d->K % BK);
     const int key = (d->a_kmajor ? 1 : 0) | (d->b_kmajor ? 2 : 0) | (d->a_f32 ? 4 : 0) | (d->b_f32 ? 8 : 0);
-    int rc = (d->no_ring ? -1 : mmf_gemm_ring_dispatch(d, e, s));
-    if (rc < 0) switch (key) {
+    int rc = -1;
+    switch (key) {
         case 0: rc = ragged ? launch<bf16, bf16, false, false, true>(d, e, s) : launch<bf16, bf16, false, false, false>(d, e, s); break;
         case 4: rc = ragged ? launch<float, bf16, false, false, true>(d, e, s) : launch<float, bf16, false, false, false>(d, e, s); break;
         case 2: rc = ragged ? launch<bf16, bf16, false, true, true>(d, e, s) : launch<bf16, bf16, false, true, false>(d, e, s); break;

@@ -35,21 +35,21 @@ struct EpiArgs {
 DEVI int rot_kmajor(int krow) { return 32 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
 
 // ---- global -> register staging -------------------------------------------------------------
-template <typename T>
-struct Stage;  // 4 chunks of 8 elements per thread per operand tile
+template <typename T, int NP = 4>
+struct Stage;  // NP = 1024 / threads chunks of 8 elements per thread per operand tile
 
-template <>
-struct Stage<bf16> {
-    uint4 v[4];
+template <int NP>
+struct Stage<bf16, NP> {
+    uint4 v[NP];
     template <bool RAGGED>
     DEVI void load(int i, const bf16* p, bool ok) {
         if (RAGGED && !ok) v[i] = make_uint4(0, 0, 0, 0);
         else v[i] = *reinterpret_cast<const uint4*>(p);
     }
 };
-template <>
-struct Stage<float> {
-    uint4 v[4];
+template <int NP>
+struct Stage<float, NP> {
+    uint4 v[NP];
     template <bool RAGGED>
     DEVI void load(int i, const float* p, bool ok) {
         if (RAGGED && !ok) { v[i] = make_uint4(0, 0, 0, 0); return; }
@@ -63,15 +63,15 @@ struct Stage<float> {
 };
 
 // Issue the global loads of one operand tile (rows [r0, r0+128) x k [k0, k0+64)).
-template <typename T, bool KMAJOR, bool RAGGED>
-DEVI void stage_load(Stage<T>& st, const T* base, int ld, int r0, int k0, int R, int K, int tid) {
+template <typename T, bool KMAJOR, bool RAGGED, int NTH = 256>
+DEVI void stage_load(Stage<T, 1024 / NTH>& st, const T* base, int ld, int r0, int k0, int R, int K, int tid) {
     if (!KMAJOR) {
         const int kc = tid & 7;
         const int k = k0 + kc * 8;
         const bool kok = k < K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = r0 + (tid >> 3) + 32 * i;
+        for (int i = 0; i < 1024 / NTH; ++i) {
+            int row = r0 + (tid >> 3) + (NTH / 8) * i;
             if (RAGGED) row = row < R ? row : R - 1;
             st.template load<RAGGED>(i, base + (size_t)row * ld + k, kok);
         }
@@ -80,29 +80,29 @@ DEVI void stage_load(Stage<T>& st, const T* base, int ld, int r0, int k0, int R,
         const int col = r0 + nc * 8;
         const bool cok = col < R;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int krow = k0 + (tid >> 4) + 16 * i;
+        for (int i = 0; i < 1024 / NTH; ++i) {
+            const int krow = k0 + (tid >> 4) + (NTH / 16) * i;
             const bool ok = cok && (krow < K);
             st.template load<RAGGED>(i, base + (size_t)(RAGGED ? (ok ? krow : 0) : krow) * ld + (RAGGED ? (ok ? col : 0) : col), ok);
         }
     }
 }
 
-template <typename T, bool KMAJOR>
-DEVI void stage_store(const Stage<T>& st, unsigned char* lds, int tid) {
+template <typename T, bool KMAJOR, int NTH = 256>
+DEVI void stage_store(const Stage<T, 1024 / NTH>& st, unsigned char* lds, int tid) {
     if (!KMAJOR) {
         const int kc = tid & 7;
         const int sw = (tid >> 3) & 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (tid >> 3) + 32 * i;
+        for (int i = 0; i < 1024 / NTH; ++i) {
+            const int row = (tid >> 3) + (NTH / 8) * i;
             *reinterpret_cast<uint4*>(lds + row * 128 + ((kc ^ sw) << 4)) = st.v[i];
         }
     } else {
         const int nc = tid & 15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int krow = (tid >> 4) + 16 * i;
+        for (int i = 0; i < 1024 / NTH; ++i) {
+            const int krow = (tid >> 4) + (NTH / 16) * i;
             *reinterpret_cast<uint4*>(lds + krow * 256 + ((nc * 16 + rot_kmajor(krow)) & 255)) = st.v[i];
         }
     }
@@ -117,30 +117,30 @@ static __device__ uint4 g_zero16;
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
-template <bool KMAJOR, bool RAGGED>
+template <bool KMAJOR, bool RAGGED, int NTH = 256>
 DEVI void stage_dma(const bf16* base, int ld, int r0, int k0, int R, int K, unsigned char* lds, int tid) {
     const int wave = tid >> 6;
     if (!KMAJOR) {
         const int sw = (tid >> 3) & 7;
         const int k = k0 + ((tid & 7) ^ sw) * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = r0 + (tid >> 3) + 32 * i;
+        for (int i = 0; i < 1024 / NTH; ++i) {
+            int row = r0 + (tid >> 3) + (NTH / 8) * i;
             if (RAGGED) row = row < R ? row : R - 1;
             const bf16* src = base + (size_t)row * ld + k;
             if (RAGGED && k >= K) src = reinterpret_cast<const bf16*>(&g_zero16);
-            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * 4096 + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * (NTH * 16) + wave * 1024), 16, 0, 0);
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kr = (tid >> 4) + 16 * i;
+        for (int i = 0; i < 1024 / NTH; ++i) {
+            const int kr = (tid >> 4) + (NTH / 16) * i;
             const int logical = ((tid & 15) - (rot_kmajor(kr) >> 4)) & 15;
             const int col = r0 + logical * 8;
             const int krow = k0 + kr;
             const bf16* src = base + (size_t)krow * ld + col;
             if (RAGGED && (col >= R || krow >= K)) src = reinterpret_cast<const bf16*>(&g_zero16);
-            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * 4096 + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + i * (NTH * 16) + wave * 1024), 16, 0, 0);
         }
     }
 }

@@ -103,22 +103,22 @@ def test_gemm_visual_projection_epilogue():
 
 
 @pytest.mark.parametrize("N", [768, 2304, 3072, 384])
-def test_gemm_ring_and_generic_kernels_agree(N):
-    """The LDS-DMA ring kernel (fast path) and the generic 2-stage kernel compute the same thing."""
+def test_gemm_tile_variants_agree(N):
+    """8-wave 128x128 / 128x96 tiles (production) and the 4-wave 128x128 form compute the same thing."""
     M, K = 1024, 768
     A = rnd(M, K); B = rnd(N, K); bias = rnd(N, dtype=torch.float32); R = rnd(M, N)
     C1 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); C2 = torch.empty_like(C1)
     nat().gemm(A, B, C1, M, N, K, K, K, N, bias=bias, resid=R, ldr=N)
-    nat().gemm(A, B, C2, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, no_ring=True)
+    nat().gemm(A, B, C2, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, debug_flags=256)
     assert torch.equal(C1, C2)
     Bk = rnd(K, N)
     nat().gemm(A, Bk, C1, M, N, K, K, N, N, b_kmajor=True)
-    nat().gemm(A, Bk, C2, M, N, K, K, N, N, b_kmajor=True, no_ring=True)
+    nat().gemm(A, Bk, C2, M, N, K, K, N, N, b_kmajor=True, debug_flags=256)
     assert torch.equal(C1, C2)
     Ak = rnd(K, M)
     W1 = torch.empty(M, N, dtype=torch.float32, device=DEV); W2 = torch.empty_like(W1)
     nat().gemm(Ak, Bk, W1, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True)
-    nat().gemm(Ak, Bk, W2, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True, no_ring=True)
+    nat().gemm(Ak, Bk, W2, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True, debug_flags=256)
     close(W1, W2, 1e-5, 1e-4, "wgrad ring vs generic")
 
 

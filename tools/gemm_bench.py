@@ -39,7 +39,10 @@ def run(kind, m, n, k, iters=20):
 
 if __name__ == "__main__":
     tot_ms = tot_fl = 0
+    only = sys.argv[1:]
     for name, kind, m, n, k in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
         ms, tf = run(kind, m, n, k)
         tot_ms += ms; tot_fl += 2.0 * m * n * k
         print("%-12s %s M=%5d N=%5d K=%5d  %8.1f us  %7.1f TFLOP/s" % (name, kind, m, n, k, ms * 1e3, tf))

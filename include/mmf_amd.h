@@ -153,10 +153,14 @@ int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word
 /* out[idx[r]] += x[row r] for r in [0, nb*rpb): row r = (b, i) lives at x + (b*bstride + i)*ld.
  * idx == NULL means bucket (i + idx_base) (position ids) when per_pos != 0, else bucket idx_base.
  * fp32 atomics into `out` [nbuckets, H] (caller zero-fills when not accumulating).
- * few_buckets != 0 pre-reduces inside the workgroup for <= 2 distinct buckets (type tables).
+ * few_buckets != 0: the table has `nbuckets` rows and (almost) every index is 0 or 1 (token-type tables,
+ * position_ids_visual == 0): deterministic two-stage column sums through `ws`
+ * (mmf_rows_scatter_add_ws_floats(H) floats) instead of atomics.
  */
+int mmf_rows_scatter_add_ws_floats(int H);
 int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, const int64_t* idx, int idx_ld,
-                         int per_pos, int idx_base, float* out, int H, int few_buckets, void* stream);
+                         int per_pos, int idx_base, float* out, int H, int few_buckets, int nbuckets, float* ws,
+                         void* stream);
 
 /* ---- small row utilities ----------------------------------------------------------------------
  * gather: out[b] = dropout(x[b*S + index[b]]), bf16 rows of H (visual_bert.py:389-400, the

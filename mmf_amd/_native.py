@@ -226,8 +226,11 @@ def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H):
 
 def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, few_buckets):
     _req(x, torch.bfloat16, "x"); _req(idx, torch.int64, "idx"); _req(out, torch.float32, "out")
+    ws = None
+    if few_buckets:
+        ws = torch.empty(lib().mmf_rows_scatter_add_ws_floats(H), dtype=torch.float32, device=out.device)
     _check(lib().mmf_rows_scatter_add(_p(x), ld, nb, rpb, bstride, _p(idx), idx_ld, int(per_pos), idx_base, _p(out), H,
-                                      int(few_buckets), _stream()), "mmf_rows_scatter_add")
+                                      int(few_buckets), int(out.shape[0]), _p(ws), _stream()), "mmf_rows_scatter_add")
 
 
 def gather_rows(x, index, out, B, S, H, drop=(0, 0, 1.0)):

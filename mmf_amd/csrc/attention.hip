@@ -9,7 +9,9 @@
 // Work decomposition: a 256-thread workgroup owns one (batch, head) and 128 query rows; each of
 // its 4 waves owns 32 query rows and ALL keys (Sk <= 256 -> <= 8 key tiles of 32), so the softmax
 // is the exact two-pass formulation of the reference (no online rescaling) held entirely in
-// registers.  A whole head's K and V (29 KB each at S = 228) are staged once in LDS.
+// registers.  A whole head's K and V (29 KB each at S = 228) are staged once in LDS, row-major; the
+// operands that need the transposed view (V in P V, K in dS K, Q / dO in the dK / dV products) are read with the
+// gfx950 hardware transpose read ds_read_b64_tr_b16, so no transposed copy is ever built.
 //
 // MFMA: v_mfma_f32_32x32x16_bf16, D[i][j] (+)= sum_k A[i][k] B[k][j]; lane l supplies row/col
 // x = l & 31 and the 8 reduction slots (h = l >> 5, e = 0..7); it receives D[(r&3)+8(r>>2)+4h][x],
@@ -25,29 +27,17 @@
 namespace {
 
 constexpr int HD = 64;            // head dim
-constexpr int TSTRIDE = 520;      // bytes per row of a transposed [64 d][<=256 idx] LDS image (+8 pad:
-                                  // ds_read_b64 of 32 consecutive d rows hits 32 distinct 8-byte slots)
-constexpr int RM_BYTES = 256 * 128;
-constexpr int TR_BYTES = HD * TSTRIDE;
 
 DEVI int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-DEVI int tr_off(int d, int idx) { return d * TSTRIDE + idx * 2; }
 
-// Stage rows [0, npad) of a token-major [rows][64] bf16 matrix (row stride ld) into LDS, row-major
-// swizzled image and/or transposed image.  Rows >= nvalid are zero-filled.
-template <bool RM, bool TR>
-DEVI void stage_rows(const bf16* g, int ld, int nvalid, int npad, unsigned char* lds_rm, unsigned char* lds_tr,
-                     int tid) {
+// Stage rows [0, npad) of a token-major [rows][64] bf16 matrix (row stride ld) into a row-major swizzled LDS image.
+// Rows >= nvalid are zero-filled.
+DEVI void stage_rows(const bf16* g, int ld, int nvalid, int npad, unsigned char* lds_rm, int tid) {
     for (int c = tid; c < npad * 8; c += 256) {
         const int row = c >> 3, ch = c & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < nvalid) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + ch * 8);
-        if (RM) *reinterpret_cast<uint4*>(lds_rm + rm_off(row, ch)) = v;
-        if (TR) {
-            const bf16x8 e = __builtin_bit_cast(bf16x8, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<bf16*>(lds_tr + tr_off(ch * 8 + i, row)) = e[i];
-        }
+        *reinterpret_cast<uint4*>(lds_rm + rm_off(row, ch)) = v;
     }
 }
 
@@ -59,15 +49,21 @@ DEVI bf16x8 frag_rm(const unsigned char* lds_rm, int row0, int s, int lane) {
 DEVI bf16x8 frag_global(const bf16* rowptr, int s, int lane) {
     return *reinterpret_cast<const bf16x8*>(rowptr + 16 * s + 8 * (lane >> 5));
 }
-// index-reduction operand from a transposed LDS image: row d = d0 + x, indices idx0 + 16u + ...
-DEVI bf16x8 frag_tr(const unsigned char* lds_tr, int d0, int idx0, int u, int lane) {
-    const unsigned char* p = lds_tr + tr_off(d0 + (lane & 31), idx0 + 16 * u + 4 * (lane >> 5));
-    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
-    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 16);
-    bf16x8 r;
+// index-reduction operand by hardware transpose read (ds_read_b64_tr_b16) from a ROW-MAJOR image: slot (h, e) of
+// lane x receives M[idx0 + 16u + 4h + (e&3) + 8(e>>2)][d0 + x].  A 16-lane group reads a 4-row x 16-column block
+// (lane p addresses row p>>2, 8 bytes at column 4(p&3)) and lane i of the group gets column i of the 4 rows.
+DEVI bf16x8 frag_tr(const unsigned char* lds_rm, int d0, int idx0, int u, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int row = idx0 + 16 * u + 4 * (g >> 1) + (p >> 2);
+    const int c = d0 + 16 * (g & 1) + (p & 3) * 4;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_rm + rm_off(row, c >> 3) + (c & 7) * 2));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_rm + rm_off(row + 8, c >> 3) + (c & 7) * 2));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+    return __builtin_bit_cast(bf16x8, r);
 }
 // index-reduction operand from a score tile held in registers (regs 8u .. 8u+7)
 DEVI bf16x8 frag_regs(const f32x16& p, int u) {
@@ -97,8 +93,8 @@ template <int NKT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_k = smem;                         // row-major K  [NKT*32][64]
-    unsigned char* lds_vt = smem + NKT * 32 * 128;       // transposed V [64][NKT*32]
-    float* lds_mask = reinterpret_cast<float*>(lds_vt + TR_BYTES);  // [NKT*32]
+    unsigned char* lds_v = smem + NKT * 32 * 128;        // row-major V  [NKT*32][64]
+    float* lds_mask = reinterpret_cast<float*>(lds_v + NKT * 32 * 128);  // [NKT*32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 31, h = lane >> 5;
@@ -108,8 +104,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
-    stage_rows<true, false>(kbase, a.ldk, a.Sk, SKP, lds_k, nullptr, tid);
-    stage_rows<false, true>(vbase, a.ldv, a.Sk, SKP, nullptr, lds_vt, tid);
+    stage_rows(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
+    stage_rows(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
     for (int i = tid; i < SKP; i += 256)
         lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] : 0.f) : -INFINITY;
     __syncthreads();
@@ -183,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             const bf16x8 pf = frag_regs(sc[t], u);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_vt, 32 * dt, 32 * t, u, lane), pf, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_v, 32 * dt, 32 * t, u, lane), pf, o[dt], 0, 0, 0);
         }
 
     if (q0 + x < a.Sq) {
@@ -231,13 +227,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 
 // dQ kernel: same decomposition as the forward (wave = 32 query rows, all keys).
 template <int NKT>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SKP = NKT * 32;
     unsigned char* lds_k = smem;                               // row-major K
     unsigned char* lds_v = lds_k + SKP * 128;                  // row-major V
-    unsigned char* lds_kt = lds_v + SKP * 128;                 // transposed K
-    float* lds_mask = reinterpret_cast<float*>(lds_kt + TR_BYTES);
+    float* lds_mask = reinterpret_cast<float*>(lds_v + SKP * 128);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 31, h = lane >> 5;
@@ -246,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
 
     const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
-    stage_rows<true, true>(kbase, a.ldk, a.Sk, SKP, lds_k, lds_kt, tid);
-    stage_rows<true, false>(vbase, a.ldv, a.Sk, SKP, lds_v, nullptr, tid);
+    stage_rows(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
+    stage_rows(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
     for (int i = tid; i < SKP; i += 256)
         lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] : 0.f) : -INFINITY;
     __syncthreads();
@@ -291,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
             const bf16x8 df = frag_regs(s_acc, u);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                dqo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_kt, 32 * dt, 32 * t, u, lane), df, dqo[dt], 0, 0, 0);
+                dqo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_k, 32 * dt, 32 * t, u, lane), df, dqo[dt], 0, 0, 0);
         }
     }
     if (q0 + x < a.Sq) {
@@ -307,14 +302,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // dK/dV kernel: wave = 32 key rows, loops over all query tiles.
 template <int NQT>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SQP = NQT * 32;
     unsigned char* lds_q = smem;                               // row-major Q
     unsigned char* lds_do = lds_q + SQP * 128;                 // row-major dO
-    unsigned char* lds_qt = lds_do + SQP * 128;                // transposed Q
-    unsigned char* lds_dot = lds_qt + TR_BYTES;                // transposed dO
-    float* lds_lse = reinterpret_cast<float*>(lds_dot + TR_BYTES);   // [SQP]
+    float* lds_lse = reinterpret_cast<float*>(lds_do + SQP * 128);   // [SQP]
     float* lds_delta = lds_lse + SQP;                                 // [SQP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -325,8 +318,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     const bf16* qbase = a.q + (size_t)b * a.Sq * a.ldq + head * HD;
     const bf16* dobase = a.dctx + (size_t)b * a.Sq * a.ldo + head * HD;
-    stage_rows<true, true>(qbase, a.ldq, a.Sq, SQP, lds_q, lds_qt, tid);
-    stage_rows<true, true>(dobase, a.ldo, a.Sq, SQP, lds_do, lds_dot, tid);
+    stage_rows(qbase, a.ldq, a.Sq, SQP, lds_q, tid);
+    stage_rows(dobase, a.ldo, a.Sq, SQP, lds_do, tid);
     for (int i = tid; i < SQP; i += 256) {
         // padded query rows: lse = +inf -> p = exp(-inf) = 0, so they contribute nothing
         lds_lse[i] = (i < a.Sq) ? a.lse[(size_t)bh * a.Sq + i] : INFINITY;
@@ -380,8 +373,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
             const bf16x8 df = frag_regs(s_acc, u);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dvo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_dot, 32 * dt, 32 * t, u, lane), pf, dvo[dt], 0, 0, 0);
-                dko[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_qt, 32 * dt, 32 * t, u, lane), df, dko[dt], 0, 0, 0);
+                dvo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_do, 32 * dt, 32 * t, u, lane), pf, dvo[dt], 0, 0, 0);
+                dko[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_q, 32 * dt, 32 * t, u, lane), df, dko[dt], 0, 0, 0);
             }
         }
     }
@@ -435,7 +428,7 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
 #define LAUNCH_FWD(N)                                                                            \
     {                                                                                            \
-        const int lds = N * 32 * 128 + TR_BYTES + N * 32 * 4;                                    \
+        const int lds = 2 * N * 32 * 128 + N * 32 * 4;                                           \
         if (int rc = set_lds(attn_fwd_kernel<N>, lds)) return rc;                                \
         hipLaunchKernelGGL(attn_fwd_kernel<N>, grid, dim3(256), lds, s, a);                      \
     }
@@ -463,7 +456,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
 #define LAUNCH_DQ(N)                                                                             \
     {                                                                                            \
-        const int lds = 2 * N * 32 * 128 + TR_BYTES + N * 32 * 4;                                \
+        const int lds = 2 * N * 32 * 128 + N * 32 * 4;                                           \
         if (int rc = set_lds(attn_bwd_dq_kernel<N>, lds)) return rc;                             \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<N>, grid, dim3(256), lds, s, a);                   \
     }
@@ -475,7 +468,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         const dim3 grid(a.B * a.heads, (a.Sk + 127) / 128);
 #define LAUNCH_DKV(N)                                                                            \
     {                                                                                            \
-        const int lds = 2 * N * 32 * 128 + 2 * TR_BYTES + 2 * N * 32 * 4;                        \
+        const int lds = 2 * N * 32 * 128 + 2 * N * 32 * 4;                                       \
         if (int rc = set_lds(attn_bwd_dkv_kernel<N>, lds)) return rc;                            \
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<N>, grid, dim3(256), lds, s, a);                  \
     }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // LayerNorm backward (+ dropout backward of the producing Linear, + column-sum partials)
 // partials layout: [gridDim.x][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias
 // ------------------------------------------------------------------------------------------------
-constexpr int LNB_GRID = 512;
+constexpr int LNB_GRID = 256;
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
@@ -210,18 +210,19 @@ __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __r
     }
 }
 
-// <= 2 buckets: accumulate 16 rows per workgroup in registers, then one atomic per column per bucket.
+// <= 2 buckets (token-type tables, the single visual position row): deterministic two-stage column sums per bucket.
+// stage 1: grid (FEW_GROUPS, ceil(H/256)); partials [FEW_GROUPS][2][H].  Rows whose bucket is >= 2 fall back to atomics.
+constexpr int FEW_GROUPS = 32;
 __global__ __launch_bounds__(256) void scatter_add_few_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                const int64_t* __restrict__ idx, int idx_ld, int per_pos,
-                                                               int idx_base, float* __restrict__ out, int H) {
+                                                               int idx_base, float* __restrict__ out, int H, float* __restrict__ partials) {
+    __shared__ float red[4][2][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nb * rpb;
-    const int r0 = blockIdx.x * 16;
-    for (int col = lane * 4; col < H; col += 256) {
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        for (int k = wave; k < 16; k += 4) {
-            const int r = r0 + k;
-            if (r >= total) break;
+    const int col = blockIdx.y * 256 + lane * 4;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (col < H) {
+        for (int r = blockIdx.x * 4 + wave; r < total; r += gridDim.x * 4) {
             const int b = r / rpb, i = r - b * rpb;
             const int bk = bucket_of(idx, idx_ld, per_pos, idx_base, b, i);
             const f32x4 v = load4(x + ((size_t)b * bstride + i) * ld + col);
@@ -232,12 +233,25 @@ __global__ __launch_bounds__(256) void scatter_add_few_kernel(const bf16* __rest
                 for (int j = 0; j < 4; ++j) atomicAdd(out + (size_t)bk * H + col + j, v[j]);
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (a0[j] != 0.f) atomicAdd(out + col + j, a0[j]);
-            if (a1[j] != 0.f) atomicAdd(out + H + col + j, a1[j]);
-        }
     }
+    *reinterpret_cast<float4*>(&red[wave][0][lane * 4]) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    *reinterpret_cast<float4*>(&red[wave][1][lane * 4]) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    __syncthreads();
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c < H) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            partials[((size_t)blockIdx.x * 2 + k) * H + c] = red[0][k][threadIdx.x] + red[1][k][threadIdx.x] + red[2][k][threadIdx.x] + red[3][k][threadIdx.x];
+    }
+}
+__global__ __launch_bounds__(256) void scatter_add_few_reduce_kernel(const float* __restrict__ partials, int ngroups, int H, int nbuckets,
+                                                                      float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (c >= H || k >= nbuckets) return;
+    float s = 0.f;
+    for (int g = 0; g < ngroups; ++g) s += partials[((size_t)g * 2 + k) * H + c];
+    out[(size_t)k * H + c] += s;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ x, const int64_t* __restrict__ index,
@@ -539,17 +553,24 @@ int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word
     return 0;
 }
 
+int mmf_rows_scatter_add_ws_floats(int H) { return FEW_GROUPS * 2 * H; }
 int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, const int64_t* idx, int idx_ld, int per_pos,
-                         int idx_base, float* out, int H, int few_buckets, void* stream) {
+                         int idx_base, float* out, int H, int few_buckets, int nbuckets, float* ws, void* stream) {
     MMF_CHECK_ARG(x && out, "rows_scatter_add: null operand");
     MMF_CHECK_ARG(nb > 0 && rpb > 0 && (H % 4) == 0 && (ld % 4) == 0, "rows_scatter_add: bad shape");
     const int total = nb * rpb;
-    if (few_buckets)
-        hipLaunchKernelGGL(scatter_add_few_kernel, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld,
-                           nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H);
-    else
+    if (few_buckets) {
+        MMF_CHECK_ARG(ws && nbuckets >= 1, "rows_scatter_add: few_buckets needs a workspace and the bucket count");
+        const int groups = grid_for(total, 4, FEW_GROUPS);
+        hipLaunchKernelGGL(scatter_add_few_kernel, dim3(groups, (H + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld,
+                           nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, ws);
+        MMF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(scatter_add_few_reduce_kernel, dim3((H + 255) / 256, nbuckets < 2 ? nbuckets : 2), dim3(256), 0,
+                           (hipStream_t)stream, ws, groups, H, nbuckets, out);
+    } else {
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
                            ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H);
+    }
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -40,8 +40,8 @@ def parse():
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (not the headline)")
     ap.add_argument("--optimizer", action="store_true", help="also run AdamW inside the step (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
 
 
@@ -127,7 +127,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(batch, steps, budget_s=25.0):
+def cpu_baseline(batch, steps, budget_s=20.0):
     """The oracle (fp32 PyTorch port of the reference path) on the host cores: forward + logit_bce + backward in
     train mode.  Bounded: one warm-up step, then timed steps until `steps` are done or `budget_s` is spent."""
     from oracle import visual_bert_oracle as O

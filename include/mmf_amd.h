@@ -43,8 +43,8 @@ const char* mmf_amd_target(void);
  * (mmf/trainers/core/training_loop.py:211).
  * Epilogue, in this order, on v = acc:
  *   v += bias[n]; v += coladd[n]; v += rowtab[rowidx[m]*rowtab_ld + n];
- *   act==1: U[m][n] = v (if U), v = gelu_erf(v)        (HF BertIntermediate)
- *   act==2: v *= gelu_erf'(aux[m][n])                  (backward of the above)
+ *   act==1: U[m][n] = gelu_erf'(v) (if U), v = gelu_erf(v)   (HF BertIntermediate; exact-erf GELU)
+ *   act==2: v *= aux[m][n]                                   (backward of the above: aux = the saved U)
  *   dropout(v) with (drop_key, drop_thr16, drop_scale), element index m*N+n
  *   v += resid[m][n]                                   (HF BertSelfOutput / BertOutput residual)
  *   out_f32 ? C = v + beta*C (float) : C = bf16(v)
@@ -182,9 +182,9 @@ int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int ro
 /* y[i] = x[i] * keep_scale(i): nn.Dropout forward AND backward (embeddings.py:458), bf16, n < 2^32. */
 int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
                      void* stream);
-/* du = dh * gelu_erf'(u): backward of HF BertIntermediate's activation when it is not fused into
- * the producing GEMM's epilogue (mmf_gemm_desc.act == 2). */
-int mmf_gelu_bwd_bf16(const void* dh, const void* u, void* du, int64_t n, void* stream);
+/* du = dh * g with g = gelu_erf'(u) as saved by the forward epilogue (act == 1): backward of HF
+ * BertIntermediate's activation when it is not fused into a dgrad GEMM epilogue (act == 2). */
+int mmf_gelu_bwd_bf16(const void* dh, const void* g, void* du, int64_t n, void* stream);
 int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* mask_add[b][s] = (1 - mask[b][s]) * -10000  (visual_bert.py:94-106); mask int64 [B,S]. */
 int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream);

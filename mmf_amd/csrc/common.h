@@ -58,14 +58,22 @@ DEVI bf16x4 pack4(float a, float b, float c, float d) {
     return r;
 }
 
-// exact-erf GELU, as HF `gelu` (transformers ACT2FN["gelu"]): x * 0.5 * (1 + erf(x / sqrt(2)))
-DEVI float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// d/dx gelu(x) = Phi(x) + x * phi(x)
-DEVI float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+// exact-erf GELU, as HF `gelu` (transformers ACT2FN["gelu"]): x * 0.5 * (1 + erf(x / sqrt(2))), and its derivative
+// Phi(x) + x * phi(x).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 round-off of the product
+// and far below the bf16 output rounding); exp(-x^2/2) is shared by erf's tail and by phi.  ~20 VALU ops per
+// element instead of the ~70 of libm erff + expf, which made the FFN epilogues VALU-bound.
+DEVI void gelu_erf_both(float x, float& h, float& g) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float e = __expf(-ax * ax);  // exp(-x^2 / 2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    h = x * cdf;
+    g = cdf + x * 0.39894228040143267794f * e;
 }
+DEVI float gelu_erf(float x) { float h, g; gelu_erf_both(x, h, g); return h; }
+DEVI float gelu_erf_grad(float x) { float h, g; gelu_erf_both(x, h, g); return g; }
 
 // wave-wide (64 lane) reductions
 DEVI float wave_sum(float v) {

@@ -20,7 +20,7 @@ struct EpiArgs {
     const float* rowtab;  // optional table gathered per output row: rowtab[rowidx[m]*rowtab_ld + n]
     const int64_t* rowidx;
     int rowtab_ld;
-    int act;            // 0 none | 1 gelu(acc) (U := pre-activation if U != null) | 2 acc * gelu'(aux)
+    int act;            // 0 none | 1 gelu(acc) (U := gelu'(acc) if U != null) | 2 acc * aux
     bf16* U;
     const bf16* aux;    // same indexing as C (ldc)
     const bf16* resid;  // added after activation/dropout, ldr
@@ -211,15 +211,18 @@ DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc, int split) {
     const size_t off = (size_t)orow * e.ldc + n + (size_t)split * e.slab_stride;
     const bool vec = full && ((e.ldc & 3) == 0);
     if (e.act == 1) {
+        // HF BertIntermediate: h = gelu(v).  U receives gelu'(v) (NOT v): the backward epilogue (act == 2) then
+        // only multiplies, and the pre-activation itself is never needed again.
+        f32x4 gd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float hh, gg; gelu_erf_both(v[r], hh, gg); v[r] = hh; gd[r] = gg; }
         if (e.U) {
-            if (vec) *reinterpret_cast<bf16x4*>(e.U + off) = pack4(v[0], v[1], v[2], v[3]);
+            if (vec) *reinterpret_cast<bf16x4*>(e.U + off) = pack4(gd[0], gd[1], gd[2], gd[3]);
             else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (ok[r]) e.U[off + r] = (bf16)v[r];
+                for (int r = 0; r < 4; ++r) if (ok[r]) e.U[off + r] = (bf16)gd[r];
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     } else if (e.act == 2) {
         f32x4 u = {0.f, 0.f, 0.f, 0.f};
         if (vec) {
@@ -230,8 +233,7 @@ DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc, int split) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (ok[r]) u[r] = (float)e.aux[off + r];
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(u[r]);
+        v *= u;
     }
     if (e.drop.thr16)
         v *= drop_scale4(e.drop.key, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop.thr16, e.drop.scale);

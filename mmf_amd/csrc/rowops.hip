@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // LayerNorm backward (+ dropout backward of the producing Linear, + column-sum partials)
 // partials layout: [gridDim.x][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias
 // ------------------------------------------------------------------------------------------------
-constexpr int LNB_GRID = 256;
+constexpr int LNB_GRID = 512;
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     float* out = (qn == 0) ? o0 : (qn == 1) ? o1 : o2;
     if (out == nullptr) return;
     float s = 0.f;
-    if (col < H)
+    if (col < H) {
+#pragma unroll 16
         for (int b = rg; b < nblk; b += 8) s += partials[((size_t)b * 3 + qn) * H + col];
+    }
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && col < H) {
@@ -305,8 +307,10 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + c;
     float s = 0.f;
-    if (col < N)
+    if (col < N) {
+#pragma unroll 8
         for (int g = rg; g < ngroups; g += 8) s += partials[(size_t)g * N + col];
+    }
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && col < N) {
@@ -354,14 +358,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x
         else for (int64_t j = i; j < n; ++j) y[j] = (bf16)((float)x[j] * drop_scale1(d.key, (uint32_t)j, d.thr16, d.scale));
     }
 }
-// du = dh * gelu'(u)
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ u, bf16* __restrict__ du, int64_t n) {
+// du = dh * g, g = gelu'(u) as saved by the forward GEMM epilogue (act == 1)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ g, bf16* __restrict__ du, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-        if (i + 4 <= n) {
-            const f32x4 a = load4(dh + i), b = load4(u + i);
-            store4(du + i, f32x4{a[0] * gelu_erf_grad(b[0]), a[1] * gelu_erf_grad(b[1]), a[2] * gelu_erf_grad(b[2]), a[3] * gelu_erf_grad(b[3])});
-        } else for (int64_t j = i; j < n; ++j) du[j] = (bf16)((float)dh[j] * gelu_erf_grad((float)u[j]));
+        if (i + 4 <= n) store4(du + i, load4(dh + i) * load4(g + i));
+        else for (int64_t j = i; j < n; ++j) du[j] = (bf16)((float)dh[j] * (float)g[j]);
     }
 }
 // 2-D casts with leading dimensions; destination pad columns [cols, ldd) are zero-filled

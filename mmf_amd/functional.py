@@ -370,7 +370,7 @@ class FeedForwardFn(torch.autograd.Function):
         M, H = x2.shape
         I = w1_16.shape[0]
         dres, dlin, dgamma, dbeta, db2 = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
-        du, dw2 = _linear_bwd(dlin, H, hh, w2_16, M, H, I, act_aux=u)        # du = (dlin W2) * gelu'(u)
+        du, dw2 = _linear_bwd(dlin, H, hh, w2_16, M, H, I, act_aux=u)        # du = (dlin W2) * gelu'(u), gelu' saved by the forward
         dx, dw1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres)     # dx = du W1 + dres
         db1 = _colsum(du, I, M, I)
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None

@@ -125,18 +125,38 @@ def test_gemm_tile_variants_agree(N):
 def test_gemm_gelu_and_dgelu_epilogues():
     M, N, K = 256, 512, 256
     A = rnd(M, K); W = rnd(N, K, scale=0.05); bias = rnd(N, dtype=torch.float32)
-    U = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); Hh = torch.empty_like(U)
-    nat().gemm(A, W, Hh, M, N, K, K, K, N, bias=bias, act=1, U=U)
-    u_ref = A.float() @ W.float().t() + bias
-    close(U, u_ref, 1e-2, 2e-2, "pre-activation")
-    close(Hh, torch.nn.functional.gelu(u_ref), 1e-2, 2e-2, "gelu")
-    # dgelu: out = (dY Wd) * gelu'(U)
+    G = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); Hh = torch.empty_like(G)
+    nat().gemm(A, W, Hh, M, N, K, K, K, N, bias=bias, act=1, U=G)
+    u_ref = (A.float() @ W.float().t() + bias).requires_grad_(True)
+    h_ref = torch.nn.functional.gelu(u_ref)
+    h_ref.sum().backward()
+    close(Hh, h_ref.detach(), 1e-2, 2e-2, "gelu")
+    close(G, u_ref.grad, 1e-2, 1e-2, "gelu' saved by the forward epilogue")
+    # dgelu: out = (dY Wd) * G
     dY = rnd(M, 128); Wd = rnd(128, N, scale=0.1)
     dU = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    nat().gemm(dY, Wd, dU, M, N, 128, 128, N, N, b_kmajor=True, act=2, aux=U)
-    u = U.float().requires_grad_(True)
-    torch.nn.functional.gelu(u).backward(dY.float() @ Wd.float())
-    close(dU, u.grad, 1e-2, 2e-2, "dgelu")
+    nat().gemm(dY, Wd, dU, M, N, 128, 128, N, N, b_kmajor=True, act=2, aux=G)
+    close(dU, (dY.float() @ Wd.float()) * G.float(), 1e-2, 2e-2, "dgelu")
+    dU2 = torch.empty_like(dU)
+    dH = rnd(M, N)
+    nat().gelu_bwd(dH, G, dU2)
+    close(dU2, dH.float() * G.float(), 1e-2, 1e-3, "standalone gelu backward")
+
+
+def test_fast_erf_gelu_is_accurate_in_fp32():
+    """gelu / gelu' (Abramowitz-Stegun erf) against torch's exact-erf GELU through an fp32-output GEMM with K padding."""
+    M, N, K = 128, 128, 64
+    x = torch.linspace(-9.0, 9.0, M * N, device=DEV).view(M, N)
+    eye = torch.zeros(N, K, dtype=torch.bfloat16, device=DEV)
+    A = torch.zeros(M, K, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    G = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(A, eye, out, M, N, K, K, K, N, rowtab=x.contiguous(), rowidx=torch.arange(M, device=DEV), rowtab_ld=N, act=1, U=G)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.gelu(xr)
+    ref.sum().backward()
+    assert float((out - ref.detach()).abs().max()) < 2e-6
+    assert float((G.float() - xr.grad).abs().max()) < 6e-3   # bf16 storage of values in [-0.13, 1.13]
 
 
 def test_gemm_residual_and_dropout_epilogue():

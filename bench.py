@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (not the headline)")
     ap.add_argument("--optimizer", action="store_true", help="also run AdamW inside the step (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one hipGraph")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
@@ -188,6 +189,13 @@ def main():
             opt.step()
         return loss
 
+    eager_step = step
+    use_graph = (world == 1) and not args.no_graph and opt is None
+    if use_graph:
+        # one hipGraph for forward + loss + backward (mmf_amd/utils/graph.py): removes the per-kernel launch cost
+        from mmf_amd.utils.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, batch, warmup=2)
+        step = lambda: graphed()  # noqa: E731
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -208,7 +216,7 @@ def main():
 
     # one instrumented step for the roofline of the dominant kernel
     with GemmProbe() as probe:
-        step()
+        eager_step()
     by = probe.summary()
 
     if rank == 0:
@@ -242,7 +250,7 @@ def main():
             "config": {"workload": "VisualBERT-base single-stream (100 regions + 128 tok) VQA2 bf16, fwd+logit_bce+bwd%s%s"
                                    % ("+AdamW" if opt is not None else "", "" if not args.eval_mode else " (eval mode)"),
                        "global_batch": args.batch * world, "seq_len": 228, "parallelism": "dp%d" % world,
-                       "dropout": not args.eval_mode, "loss": round(loss_val, 4)},
+                       "dropout": not args.eval_mode, "loss": round(loss_val, 4), "launch": "hipGraph" if use_graph else "eager"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

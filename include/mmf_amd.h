@@ -77,6 +77,7 @@ typedef struct mmf_gemm_desc {
     uint32_t drop_key;
     uint32_t drop_thr16;
     float drop_scale;
+    const uint32_t* drop_seed; /* optional device word mixed into drop_key at run time (hipGraph replays) */
     int grp_in, grp_pad, grp_off;
     void* splitk_ws;          /* optional fp32 workspace enabling deterministic split-K (fp32 output, no epilogue) */
     int64_t splitk_ws_bytes;  /* >= mmf_gemm_splitk_splits(M,N,K) * M * N * 4 to take effect */
@@ -109,6 +110,7 @@ typedef struct mmf_attn_desc {
     uint32_t drop_key;
     uint32_t drop_thr16;
     float drop_scale;
+    const uint32_t* drop_seed;
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
 
@@ -141,8 +143,8 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
 int mmf_layernorm_bwd_ws_floats(int H);
 int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       void* dx, void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
-                      float* dgamma, float* dbeta, float* dbias, int accumulate, float* partials,
-                      int rows, int H, void* stream);
+                      const uint32_t* drop_seed, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                      float* partials, int rows, int H, void* stream);
 
 /* ---- embeddings (BertVisioLinguisticEmbeddings, mmf/modules/embeddings.py:329-345) ------------
  * Text rows of the joint pre-LayerNorm sequence: y[b*S + t] = word[ids[b,t]] + pos[t] + type[seg[b,t]].
@@ -167,9 +169,11 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
  * `pooler_strategy: vqa` token pick + dropout).  scatter: dx[b*S + index[b]] = dropout_bwd(dout[b]).
  */
 int mmf_gather_rows(const void* x, const int64_t* index, void* out, int B, int S, int H,
-                    uint32_t drop_key, uint32_t drop_thr16, float drop_scale, void* stream);
+                    uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed,
+                    void* stream);
 int mmf_scatter_rows(const void* dout, const int64_t* index, void* dx, int B, int S, int H,
-                     uint32_t drop_key, uint32_t drop_thr16, float drop_scale, void* stream);
+                     uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed,
+                     void* stream);
 /* out[n] = beta*out[n] + sum over rows of x (bf16); rows = nb groups of rpb rows, group stride
  * bstride rows, row stride ld.  Bias gradients. */
 int mmf_colsum_bf16(const void* x, int ld, int nb, int rpb, int bstride, int N, float* out, float beta,
@@ -181,7 +185,11 @@ int mmf_cast2d_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int ro
 int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int rows, int cols, void* stream);
 /* y[i] = x[i] * keep_scale(i): nn.Dropout forward AND backward (embeddings.py:458), bf16, n < 2^32. */
 int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
-                     void* stream);
+                     const uint32_t* drop_seed, void* stream);
+/* Dropout everywhere: keep(i) = hash(key', i) >= thr16 with key' = drop_key + drop_seed[0] * 0x9E3779B1 when a
+ * drop_seed pointer is given (else key' = drop_key).  mmf_seed_advance increments that device word; put it at the
+ * head of a captured step so every hipGraph replay draws fresh masks while forward and backward still agree. */
+int mmf_seed_advance(uint32_t* seed, void* stream);
 /* du = dh * g with g = gelu_erf'(u) as saved by the forward epilogue (act == 1): backward of HF
  * BertIntermediate's activation when it is not fused into a dgrad GEMM epilogue (act == 2). */
 int mmf_gelu_bwd_bf16(const void* dh, const void* g, void* du, int64_t n, void* stream);

@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("rowtab", C.c_void_p), ("rowidx", C.c_void_p), ("rowtab_ld", C.c_int),
         ("act", C.c_int), ("U", C.c_void_p), ("aux", C.c_void_p),
         ("resid", C.c_void_p), ("ldr", C.c_int),
-        ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float),
+        ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("grp_in", C.c_int), ("grp_pad", C.c_int), ("grp_off", C.c_int),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("debug_flags", C.c_int),
     ]
@@ -46,7 +46,7 @@ class AttnDesc(C.Structure):
         ("mask", C.c_void_p), ("ctx", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
         ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int),
         ("scale", C.c_float),
-        ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float),
+        ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
     ]
 
 
@@ -111,20 +111,30 @@ def _req(t, dtype, name):
         raise NativeLibraryError("%s must be %s, got %s" % (name, dtype, t.dtype))
 
 
-def drop_cfg(p, key):
-    """(key, thr16, scale) for dropout probability p; thr16 == 0 disables dropout."""
+NO_DROP = (0, 0, 1.0, None)
+
+
+def drop_cfg(p, key, seed=None):
+    """(key, thr16, scale, seed_tensor) for dropout probability p; thr16 == 0 disables dropout.  `seed` is an
+    optional 1-element int32 device tensor mixed into the key at run time (hipGraph replays)."""
     if p is None or p <= 0.0:
-        return 0, 0, 1.0
+        return NO_DROP
     thr = int(round(p * 65536.0))
     thr = max(1, min(thr, 65535))
-    return int(key) & 0xFFFFFFFF, thr, 1.0 / (1.0 - thr / 65536.0)
+    return int(key) & 0xFFFFFFFF, thr, 1.0 / (1.0 - thr / 65536.0), seed
+
+
+def _drop4(drop):
+    if len(drop) == 3:
+        return drop[0], drop[1], drop[2], None
+    return drop[0], drop[1], drop[2], _p(drop[3])
 
 
 # --------------------------------------------------------------------------------------------
 # GEMM
 # --------------------------------------------------------------------------------------------
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
-         rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=(0, 0, 1.0),
+         rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
          grp=(0, 0, 0), debug_flags=0):
     d = GemmDesc()
     d.debug_flags = int(debug_flags) | _GEMM_DEBUG
@@ -147,7 +157,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
     d.bias, d.coladd, d.rowtab, d.rowidx, d.rowtab_ld = _p(bias), _p(coladd), _p(rowtab), _p(rowidx), rowtab_ld
     d.act, d.U, d.aux = act, _p(U), _p(aux)
     d.resid, d.ldr = _p(resid), ldr
-    d.drop_key, d.drop_thr16, d.drop_scale = drop
+    d.drop_key, d.drop_thr16, d.drop_scale, d.drop_seed = _drop4(drop)
     d.grp_in, d.grp_pad, d.grp_off = grp
     if d.out_f32 and a_kmajor and b_kmajor and bias is None and resid is None and act == 0:
         sp = lib().mmf_gemm_splitk_splits(M, N, K)
@@ -170,17 +180,17 @@ def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, sc
     d.mask, d.ctx, d.ldo, d.lse = _p(mask), _p(ctx), ldo, _p(lse)
     d.B, d.heads, d.Sq, d.Sk = B, heads, Sq, Sk
     d.scale = scale
-    d.drop_key, d.drop_thr16, d.drop_scale = drop
+    d.drop_key, d.drop_thr16, d.drop_scale, d.drop_seed = _drop4(drop)
     return d
 
 
-def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=(0, 0, 1.0)):
+def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP):
     d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop)
     _check(lib().mmf_attention_fwd(C.byref(d), _stream()), "mmf_attention_fwd")
 
 
 def attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta,
-                  drop=(0, 0, 1.0)):
+                  drop=NO_DROP):
     d = AttnBwdDesc()
     d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop)
     for t, n in ((dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
@@ -211,8 +221,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, dgamma, dbeta, dbias
     for t, n in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta"), (dbias, "dbias"),
                  (partials, "partials")):
         _req(t, torch.float32, n)
-    _check(lib().mmf_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dlin), C.c_uint32(drop[0]),
-                                   C.c_uint32(drop[1]), C.c_float(drop[2]), _p(dgamma), _p(dbeta), _p(dbias),
+    k, t, sc, sd = _drop4(drop)
+    _check(lib().mmf_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dlin), C.c_uint32(k),
+                                   C.c_uint32(t), C.c_float(sc), sd, _p(dgamma), _p(dbeta), _p(dbias),
                                    int(accumulate), _p(partials), rows, H, _stream()), "mmf_layernorm_bwd")
 
 
@@ -233,16 +244,18 @@ def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, ou
                                       int(few_buckets), int(out.shape[0]), _p(ws), _stream()), "mmf_rows_scatter_add")
 
 
-def gather_rows(x, index, out, B, S, H, drop=(0, 0, 1.0)):
+def gather_rows(x, index, out, B, S, H, drop=NO_DROP):
     _req(x, torch.bfloat16, "x"); _req(index, torch.int64, "index"); _req(out, torch.bfloat16, "out")
-    _check(lib().mmf_gather_rows(_p(x), _p(index), _p(out), B, S, H, C.c_uint32(drop[0]), C.c_uint32(drop[1]),
-                                 C.c_float(drop[2]), _stream()), "mmf_gather_rows")
+    k, t, sc, sd = _drop4(drop)
+    _check(lib().mmf_gather_rows(_p(x), _p(index), _p(out), B, S, H, C.c_uint32(k), C.c_uint32(t), C.c_float(sc), sd, _stream()),
+           "mmf_gather_rows")
 
 
-def scatter_rows(dout, index, dx, B, S, H, drop=(0, 0, 1.0)):
+def scatter_rows(dout, index, dx, B, S, H, drop=NO_DROP):
     _req(dout, torch.bfloat16, "dout"); _req(index, torch.int64, "index"); _req(dx, torch.bfloat16, "dx")
-    _check(lib().mmf_scatter_rows(_p(dout), _p(index), _p(dx), B, S, H, C.c_uint32(drop[0]), C.c_uint32(drop[1]),
-                                  C.c_float(drop[2]), _stream()), "mmf_scatter_rows")
+    k, t, sc, sd = _drop4(drop)
+    _check(lib().mmf_scatter_rows(_p(dout), _p(index), _p(dx), B, S, H, C.c_uint32(k), C.c_uint32(t), C.c_float(sc), sd, _stream()),
+           "mmf_scatter_rows")
 
 
 def colsum_ws_floats(N):
@@ -279,8 +292,14 @@ def cast2d_bf16_to_f32(src, lds, dst, ldd, rows, cols):
 
 def dropout(x, y, drop):
     _req(x, torch.bfloat16, "x"); _req(y, torch.bfloat16, "y")
-    _check(lib().mmf_dropout_bf16(_p(x), _p(y), C.c_int64(x.numel()), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
-                                  C.c_float(drop[2]), _stream()), "mmf_dropout_bf16")
+    k, t, sc, sd = _drop4(drop)
+    _check(lib().mmf_dropout_bf16(_p(x), _p(y), C.c_int64(x.numel()), C.c_uint32(k), C.c_uint32(t), C.c_float(sc), sd, _stream()),
+           "mmf_dropout_bf16")
+
+
+def seed_advance(seed):
+    _req(seed, torch.int32, "seed")
+    _check(lib().mmf_seed_advance(_p(seed), _stream()), "mmf_seed_advance")
 
 
 def gelu_bwd(dh, u, du):

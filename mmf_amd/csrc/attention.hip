@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 ds = drop_scale4(a.drop.key, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
+                const f32x4 ds = drop_scale4(drop_key(a.drop), rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[t][4 * c + i] *= ds[i];
             }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
             const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
             f32x4 ds = {1.f, 1.f, 1.f, 1.f};
-            if (a.drop.thr16) ds = drop_scale4(a.drop.key, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
+            if (a.drop.thr16) ds = drop_scale4(drop_key(a.drop), rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float p = __expf(s_acc[4 * c + i] * a.scale + mkv[i] - L);
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 const int q = 32 * t + 8 * c + 4 * h + i;
                 float dsc = 1.f;
                 if (a.drop.thr16)
-                    dsc = drop_scale1(a.drop.key, ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)SKP + (uint32_t)(k0 + x),
+                    dsc = drop_scale1(drop_key(a.drop), ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)SKP + (uint32_t)(k0 + x),
                                       a.drop.thr16, a.drop.scale);
                 const float p = __expf(s_acc[4 * c + i] * a.scale + mk - Lv[i]);
                 pd[4 * c + i] = p * dsc;
@@ -405,7 +405,7 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk;
     a.skp = (d->Sk + 31) / 32 * 32;
     a.scale = d->scale;
-    a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale;
+    a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
     return 0;
 }

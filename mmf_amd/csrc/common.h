@@ -118,7 +118,11 @@ DEVI float drop_scale1(uint32_t key, uint32_t idx, uint32_t thr16, float scale) 
 }
 
 struct DropoutCfg {
-    uint32_t key;    // per-site key (host mixes the step seed with the site id)
-    uint32_t thr16;  // 0 => dropout disabled
-    float scale;     // 1 / (1 - thr16/65536)
+    uint32_t key;          // per-site key (host mixes the step seed with the site id)
+    uint32_t thr16;        // 0 => dropout disabled
+    float scale;           // 1 / (1 - thr16/65536)
+    const uint32_t* seed;  // optional device word mixed into the key at run time: lets a captured hipGraph draw
+                           // fresh masks on every replay (mmf_seed_advance bumps it inside the graph)
 };
+// effective key of a site for this launch (wave-uniform)
+DEVI uint32_t drop_key(const DropoutCfg& d) { return d.seed ? d.key + d.seed[0] * 0x9E3779B1u : d.key; }

@@ -22,8 +22,8 @@
 //   row operand     : [128 rows][8 chunks of 16 B], chunk ^= (row & 7)   -> conflict-free ds_read_b128
 //   k-major operand : [64 k-rows][256 B], bytes rotated by 32*((k&3) + 4*((k>>3)&1)) within the row
 //                     -> conflict-free ds_read_b64_tr_b16 (hardware 4x16 transpose read)
-// The MFMA is issued with operands swapped (A-operand = B tile fragment) so each lane ends up
-// holding 4 CONSECUTIVE n for one m: epilogue loads/stores are 8-byte (bf16) / 16-byte (fp32).
+// The MFMA is issued with operands swapped (A-operand = B tile fragment) so each lane ends up holding 4 CONSECUTIVE n
+// for one m; the fp32 tile is then staged through LDS and written row-wise (16 bytes per lane, full cache lines).
 #include "gemm_common.h"
 
 using namespace gemm;
@@ -135,15 +135,24 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
             for (int j = 0; j < NFN; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // D = (C tile)^T fragment: lane holds n = 4*(lane>>4) + [0,4), m = lane & 15.
+    // Epilogue.  The MFMA D fragment gives a lane 4 consecutive n of one m; dumped as-is the global accesses would be
+    // 32-byte segments scattered over 16 rows.  Stage the fp32 tile through the (now idle) LDS stages instead and walk
+    // it row-wise: every thread then owns 8 consecutive columns of one row, so bias / residual / saved-gelu' loads and
+    // the output stores are full-line, 16-byte-per-lane transactions.
+    constexpr int CLD = BN_ + 4;   // +4 floats: 16 rows of a fragment column land on distinct banks
+    float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < NFM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+    for (int i = 0; i < NFM; ++i)
 #pragma unroll
         for (int j = 0; j < NFN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
-            epilogue4(epi, m, n, acc[i][j], split);
+            const int row = wm * WTM + i * 16 + (lane & 15), col = wn * WTN + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<float4*>(cs + row * CLD + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
+    __syncthreads();
+    constexpr int SEG = BN_ / 8;
+    for (int idx = tid; idx < BM * SEG; idx += NTH) {
+        const int row = idx / SEG, seg = idx - row * SEG;
+        epilogue8(epi, m0 + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), split);
     }
 }
 
@@ -165,7 +174,16 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN_ - 1) / BN_;
     const int splits = e.splits > 1 ? e.splits : 1;
     const EpiArgs& e2 = e;
-    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_>), dim3(tm * tn * splits), dim3(128 * NWN), 4 * OPER_BYTES, s,
+    constexpr int cstage = BM * (BN_ + 4) * (int)sizeof(float);
+    constexpr int lds_bytes = cstage > 4 * OPER_BYTES ? cstage : 4 * OPER_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_>), dim3(tm * tn * splits), dim3(128 * NWN), lds_bytes, s,
                        reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
                        d->lda, d->ldb, tm, tn, splits, (d->debug_flags >> 4) & 15, e2);
     MMF_CHECK_LAUNCH();
@@ -204,7 +222,7 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     e.bias = d->bias; e.coladd = d->coladd; e.rowtab = d->rowtab; e.rowidx = d->rowidx; e.rowtab_ld = d->rowtab_ld;
     e.act = d->act; e.U = reinterpret_cast<bf16*>(d->U); e.aux = reinterpret_cast<const bf16*>(d->aux);
     e.resid = reinterpret_cast<const bf16*>(d->resid); e.ldr = d->ldr;
-    e.drop.key = d->drop_key; e.drop.thr16 = d->drop_thr16; e.drop.scale = d->drop_scale;
+    e.drop.key = d->drop_key; e.drop.thr16 = d->drop_thr16; e.drop.scale = d->drop_scale; e.drop.seed = d->drop_seed;
     e.grp_in = d->grp_in; e.grp_pad = d->grp_pad; e.grp_off = d->grp_off;
     e.M = d->M; e.N = d->N;
     // Split-K: a weight-gradient GEMM has few output tiles (768x768 -> 36) and a long reduction (K = tokens).

@@ -180,92 +180,119 @@ DEVI f32x4 load_f4(const float* p) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     return f32x4{t.x, t.y, t.z, t.w};
 }
-DEVI void epilogue4(const EpiArgs& e, int m, int n, f32x4 acc, int split) {
-    if (m >= e.M || n >= e.N) return;
-    const bool full = (n + 4 <= e.N);
-    f32x4 v = acc;
-    bool ok[4];
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+DEVI f32x8 load_f8(const float* p) {
+    const f32x4 a = load_f4(p), b = load_f4(p + 4);
+    return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+DEVI f32x8 load_bf8(const bf16* p) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+    f32x8 r;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ok[r] = (n + r) < e.N;
+    for (int i = 0; i < 8; ++i) r[i] = (float)t[i];
+    return r;
+}
+DEVI void store_bf8(bf16* p, f32x8 v) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+// Epilogue of one output row segment: 8 consecutive columns n..n+7 of row m (fp32 accumulators staged through LDS
+// so that every global access of the epilogue is a full 16/32-byte-per-lane, row-contiguous transaction).
+DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
+    if (m >= e.M || n >= e.N) return;
+    const bool full = (n + 8 <= e.N);
+    bool ok[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ok[r] = (n + r) < e.N;
     if (e.bias) {
-        if (full) v += load_f4(e.bias + n);
+        if (full) v += load_f8(e.bias + n);
         else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += e.bias[n + r];
+            for (int r = 0; r < 8; ++r) if (ok[r]) v[r] += e.bias[n + r];
         }
     }
     if (e.coladd) {
-        if (full) v += load_f4(e.coladd + n);
+        if (full) v += load_f8(e.coladd + n);
         else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += e.coladd[n + r];
+            for (int r = 0; r < 8; ++r) if (ok[r]) v[r] += e.coladd[n + r];
         }
     }
     if (e.rowtab) {
         const float* t = e.rowtab + (size_t)e.rowidx[m] * e.rowtab_ld + n;
+        if (full && ((e.rowtab_ld & 3) == 0)) v += load_f8(t);
+        else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += t[r];
+            for (int r = 0; r < 8; ++r) if (ok[r]) v[r] += t[r];
+        }
     }
     int orow = m;
     if (e.grp_in > 0) orow = m + (m / e.grp_in) * e.grp_pad + e.grp_off;
     const size_t off = (size_t)orow * e.ldc + n + (size_t)split * e.slab_stride;
-    const bool vec = full && ((e.ldc & 3) == 0);
+    const bool vec = full && ((e.ldc & 7) == 0);
     if (e.act == 1) {
         // HF BertIntermediate: h = gelu(v).  U receives gelu'(v) (NOT v): the backward epilogue (act == 2) then
         // only multiplies, and the pre-activation itself is never needed again.
-        f32x4 gd;
+        f32x8 gd;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float hh, gg; gelu_erf_both(v[r], hh, gg); v[r] = hh; gd[r] = gg; }
+        for (int r = 0; r < 8; ++r) { float hh, gg; gelu_erf_both(v[r], hh, gg); v[r] = hh; gd[r] = gg; }
         if (e.U) {
-            if (vec) *reinterpret_cast<bf16x4*>(e.U + off) = pack4(gd[0], gd[1], gd[2], gd[3]);
+            if (vec) store_bf8(e.U + off, gd);
             else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (ok[r]) e.U[off + r] = (bf16)gd[r];
+                for (int r = 0; r < 8; ++r) if (ok[r]) e.U[off + r] = (bf16)gd[r];
             }
         }
     } else if (e.act == 2) {
-        f32x4 u = {0.f, 0.f, 0.f, 0.f};
-        if (vec) {
-            const bf16x4 ub = *reinterpret_cast<const bf16x4*>(e.aux + off);
+        if (vec) v *= load_bf8(e.aux + off);
+        else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u[r] = (float)ub[r];
+            for (int r = 0; r < 8; ++r) if (ok[r]) v[r] *= (float)e.aux[off + r];
+        }
+    }
+    if (e.drop.thr16) {
+        const uint32_t idx = (uint32_t)m * (uint32_t)e.N + (uint32_t)n;
+        const uint32_t dkey = drop_key(e.drop);
+        if ((idx & 3u) == 0) {
+            const f32x4 s0 = drop_scale4(dkey, idx, e.drop.thr16, e.drop.scale);
+            const f32x4 s1 = drop_scale4(dkey, idx + 4, e.drop.thr16, e.drop.scale);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] *= s0[r]; v[r + 4] *= s1[r]; }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (ok[r]) u[r] = (float)e.aux[off + r];
+            for (int r = 0; r < 8; ++r) v[r] *= drop_scale1(dkey, idx + r, e.drop.thr16, e.drop.scale);
         }
-        v *= u;
     }
-    if (e.drop.thr16)
-        v *= drop_scale4(e.drop.key, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop.thr16, e.drop.scale);
     if (e.resid) {
         const size_t roff = (size_t)orow * e.ldr + n;
-        if (full && ((e.ldr & 3) == 0)) {
-            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(e.resid + roff);
+        if (full && ((e.ldr & 7) == 0)) v += load_bf8(e.resid + roff);
+        else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (ok[r]) v[r] += (float)e.resid[roff + r];
+            for (int r = 0; r < 8; ++r) if (ok[r]) v[r] += (float)e.resid[roff + r];
         }
     }
     if (e.out_f32) {
         float* C = reinterpret_cast<float*>(e.C) + off;
-        if (vec) {
-            if (e.beta != 0.f) v += e.beta * load_f4(C);
+        if (full && ((e.ldc & 3) == 0)) {
+            if (e.beta != 0.f) v += e.beta * load_f8(C);
             *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (ok[r]) C[r] = v[r] + (e.beta != 0.f ? e.beta * C[r] : 0.f);
+            for (int r = 0; r < 8; ++r) if (ok[r]) C[r] = v[r] + (e.beta != 0.f ? e.beta * C[r] : 0.f);
         }
     } else {
         bf16* C = reinterpret_cast<bf16*>(e.C) + off;
-        if (vec) *reinterpret_cast<bf16x4*>(C) = pack4(v[0], v[1], v[2], v[3]);
+        if (vec) store_bf8(C, v);
         else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (ok[r]) C[r] = (bf16)v[r];
+            for (int r = 0; r < 8; ++r) if (ok[r]) C[r] = (bf16)v[r];
         }
     }
 }
-
 
 }  // namespace gemm

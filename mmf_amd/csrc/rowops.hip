@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                 for (int i = 0; i < 4; ++i) d[i] = rs * (g[c][i] - c1 - xh[c][i] * c2);
                 store4(dx + (size_t)row * H + COL_OF(c), d);
                 if (dlin) {
-                    const f32x4 sc = drop_scale4(drop.key, (uint32_t)row * (uint32_t)H + (uint32_t)COL_OF(c), drop.thr16, drop.scale);
+                    const f32x4 sc = drop_scale4(drop_key(drop), (uint32_t)row * (uint32_t)H + (uint32_t)COL_OF(c), drop.thr16, drop.scale);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d[i] *= sc[i];
                     store4(dlin + (size_t)row * H + COL_OF(c), d);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict
     ix = ix < 0 ? 0 : (ix >= S ? S - 1 : ix);
     for (int col = lane * 4; col < H; col += 256) {
         f32x4 sc = {1.f, 1.f, 1.f, 1.f};
-        if (drop.thr16) sc = drop_scale4(drop.key, (uint32_t)b * (uint32_t)H + (uint32_t)col, drop.thr16, drop.scale);
+        if (drop.thr16) sc = drop_scale4(drop_key(drop), (uint32_t)b * (uint32_t)H + (uint32_t)col, drop.thr16, drop.scale);
         if (!scatter) {
             const f32x4 v = load4(x + ((size_t)b * S + ix) * H + col);
             store4(out + (size_t)b * H + col, v * sc);
@@ -354,8 +354,8 @@ __global__ void additive_mask_kernel(const int64_t* __restrict__ m, float* __res
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n, DropoutCfg d) {
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-        if (i + 4 <= n) store4(y + i, load4(x + i) * drop_scale4(d.key, (uint32_t)i, d.thr16, d.scale));
-        else for (int64_t j = i; j < n; ++j) y[j] = (bf16)((float)x[j] * drop_scale1(d.key, (uint32_t)j, d.thr16, d.scale));
+        if (i + 4 <= n) store4(y + i, load4(x + i) * drop_scale4(drop_key(d), (uint32_t)i, d.thr16, d.scale));
+        else for (int64_t j = i; j < n; ++j) y[j] = (bf16)((float)x[j] * drop_scale1(drop_key(d), (uint32_t)j, d.thr16, d.scale));
     }
 }
 // du = dh * g, g = gelu'(u) as saved by the forward GEMM epilogue (act == 1)
@@ -522,13 +522,13 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
 int mmf_layernorm_bwd_ws_floats(int H) { return LNB_GRID * 3 * H; }
 
 int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
-                      void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, float* dgamma, float* dbeta,
-                      float* dbias, int accumulate, float* partials, int rows, int H, void* stream) {
+                      void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, float* dgamma,
+                      float* dbeta, float* dbias, int accumulate, float* partials, int rows, int H, void* stream) {
     MMF_CHECK_ARG(dy && x && mean && rstd && gamma && dx && partials, "layernorm_bwd: null operand");
     MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 1024, "layernorm_bwd: need H % 4 == 0 and H <= 1024");
     MMF_CHECK_ARG(drop_thr16 == 0 || dlin, "layernorm_bwd: dropout needs dlin");
     hipStream_t s = (hipStream_t)stream;
-    DropoutCfg dc{drop_key, drop_thr16, drop_scale};
+    DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
     const int grid = grid_for(rows, 4, LNB_GRID);
     const int nch = (H + 255) / 256;
     const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
@@ -578,18 +578,18 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
 }
 
 int mmf_gather_rows(const void* x, const int64_t* index, void* out, int B, int S, int H, uint32_t drop_key,
-                    uint32_t drop_thr16, float drop_scale, void* stream) {
+                    uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream) {
     MMF_CHECK_ARG(x && index && out && (H % 4) == 0, "gather_rows: bad operand");
     hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, index, (bf16*)out,
-                       B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale}, 0);
+                       B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed}, 0);
     MMF_CHECK_LAUNCH();
     return 0;
 }
 int mmf_scatter_rows(const void* dout, const int64_t* index, void* dx, int B, int S, int H, uint32_t drop_key,
-                     uint32_t drop_thr16, float drop_scale, void* stream) {
+                     uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream) {
     MMF_CHECK_ARG(dout && index && dx && (H % 4) == 0, "scatter_rows: bad operand");
     hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, index,
-                       (bf16*)dx, B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale}, 1);
+                       (bf16*)dx, B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed}, 1);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -629,10 +629,11 @@ int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* str
     return 0;
 }
 
-int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, void* stream) {
+int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
+                     const uint32_t* drop_seed, void* stream) {
     MMF_CHECK_ARG(x && y && n > 0 && n < ((int64_t)1 << 32), "dropout: bad operand");
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n,
-                       DropoutCfg{drop_key, drop_thr16, drop_scale});
+                       DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed});
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -660,6 +661,15 @@ int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int ro
     return 0;
 }
 
+__global__ void seed_advance_kernel(uint32_t* seed) { seed[0] += 1u; }
+}  // extern "C" (kernel must not have C linkage)
+extern "C" {
+int mmf_seed_advance(uint32_t* seed, void* stream) {
+    MMF_CHECK_ARG(seed, "seed_advance: null");
+    hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
 int mmf_bce_logits_ws_floats(void) { return BCE_BLOCKS; }
 int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, float* ws, int B, int N, void* stream) {
     MMF_CHECK_ARG(scores && targets && loss && ws && B > 0 && N > 0, "bce_fwd: bad operand");

@@ -33,18 +33,46 @@ F32 = torch.float32
 # dropout keys
 # ---------------------------------------------------------------------------------------------
 class _DropoutKeys:
-    """Per-site dropout keys drawn from the device's default torch generator: key = mix(seed, Philox
-    offset), and the offset is advanced like any torch random op would.  `torch.manual_seed(s)`
-    therefore reproduces the masks and `torch.cuda.get_rng_state()` checkpoints them; backward
-    re-uses the key saved by forward."""
+    """Per-site dropout keys.
+
+    Eager mode: key = mix(seed, Philox offset) of the device's default torch generator, and the offset is advanced
+    like any torch random op would: `torch.manual_seed(s)` reproduces the masks, `torch.cuda.get_rng_state()`
+    checkpoints them; backward re-uses the key saved by forward.
+
+    Graph mode (`with dropout_keys.graph_mode(seed_tensor)` around capture): site keys are a fixed sequence baked
+    into the captured kernels and a device word (`seed_tensor`, int32[1]) is mixed in at run time;
+    `nat.seed_advance(seed_tensor)` captured at the head of the step makes every replay draw fresh masks."""
+
+    def __init__(self):
+        self.seed_tensor = None
+        self.counter = 0
+
+    @staticmethod
+    def _mix(a, b):
+        x = (a * 0x9E3779B97F4A7C15 + (b + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        return (x * 0x94D049BB133111EB >> 16) & 0xFFFFFFFF
 
     def next(self):
+        if self.seed_tensor is not None:
+            self.counter += 1
+            return self._mix(0x5EED, self.counter), self.seed_tensor
         gen = torch.cuda.default_generators[torch.cuda.current_device()]
         seed, off = gen.initial_seed(), gen.get_offset()
         gen.set_offset(off + 4)
-        x = (seed * 0x9E3779B97F4A7C15 + (off + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-        x ^= x >> 31
-        return (x * 0x94D049BB133111EB >> 16) & 0xFFFFFFFF
+        return self._mix(seed, off), None
+
+    def graph_mode(self, seed_tensor):
+        keys = self
+
+        class _Ctx:
+            def __enter__(self_):
+                keys.seed_tensor, keys.counter = seed_tensor, 0
+
+            def __exit__(self_, *exc):
+                keys.seed_tensor = None
+
+        return _Ctx()
 
 
 dropout_keys = _DropoutKeys()
@@ -52,8 +80,9 @@ dropout_keys = _DropoutKeys()
 
 def make_drop(p, training):
     if not training or p is None or p <= 0.0:
-        return (0, 0, 1.0)
-    return nat.drop_cfg(p, dropout_keys.next())
+        return nat.NO_DROP
+    key, seed = dropout_keys.next()
+    return nat.drop_cfg(p, key, seed)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -65,6 +94,10 @@ class ShadowCache:
 
     def __init__(self):
         self._store = {}  # id(head parameter) -> (signature, buffer, dtype); entry dies with the parameter
+
+    def clear(self):
+        """Forget every shadow: the next use re-casts (used before hipGraph capture)."""
+        self._store.clear()
 
     def get(self, *params, dtype=BF16):
         head = params[0]
@@ -395,7 +428,7 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x2, mean, rstd, gamma = ctx.saved_tensors
-        dx, _, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, x2.shape[1]), x2, mean, rstd, gamma, (0, 0, 1.0), False)
+        dx, _, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, x2.shape[1]), x2, mean, rstd, gamma, nat.NO_DROP, False)
         return dx.view(ctx.xshape), dgamma, dbeta, None
 
 
@@ -451,7 +484,7 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             d2 = torch.empty_like(dy)
             nat.dropout(dy, d2, drop)
             dy = d2
-        dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, (0, 0, 1.0), False)
+        dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, nat.NO_DROP, False)
         dword = torch.zeros(V, H, dtype=F32, device=dev)
         nat.rows_scatter_add(dpre, H, B, T, S, ids, T, 0, 0, dword, H, 0)
         dpos = torch.zeros(P, H, dtype=F32, device=dev)

@@ -1,0 +1,75 @@
+"""hipGraph capture of the training step.
+
+The step is ~450 short kernels; launched one by one from Python the host (ctypes + autograd bookkeeping)
+becomes the bottleneck once the kernels are fast.  `GraphedTrainStep` runs a few eager warm-up steps,
+then captures zero-grad-free forward + loss + backward into ONE hipGraph and replays it: no Python, no
+per-kernel launch cost.  Everything the path launches is capture-safe by construction (only stream-ordered
+work, no host sync, no allocation outside torch's caching allocator).
+
+Dropout under replay: site keys are baked into the captured kernels, so a device word (`self.seed`) is mixed
+into every key at run time and `mmf_seed_advance` — the first node of the graph — bumps it, i.e. each replay
+draws fresh masks while forward and backward of the same replay agree (mmf_amd.functional._DropoutKeys).
+The fp32 -> bf16 weight-shadow casts are captured too, so replays see parameter updates made between them.
+"""
+import torch
+
+from mmf_amd import functional as Fn
+from mmf_amd.common.sample import SampleList
+
+
+def _clone_batch(batch):
+    out = SampleList()
+    for k in batch.fields():
+        v = batch[k]
+        if isinstance(v, torch.Tensor):
+            out[k] = v.clone()
+        elif isinstance(v, SampleList):
+            out[k] = _clone_batch(v)
+        else:
+            out[k] = v
+    return out
+
+
+def _copy_batch(dst, src):
+    for k in dst.fields():
+        v = dst[k]
+        if isinstance(v, torch.Tensor):
+            v.copy_(src[k], non_blocking=True)
+        elif isinstance(v, SampleList):
+            _copy_batch(v, src[k])
+
+
+class GraphedTrainStep:
+    def __init__(self, model, batch, warmup=3, loss_of=None):
+        self.model = model
+        self.loss_of = loss_of or (lambda out: sum(v.sum() for v in out["losses"].values()))
+        self.static_batch = _clone_batch(batch)
+        dev = next(model.parameters()).device
+        self.seed = torch.zeros(1, dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), Fn.dropout_keys.graph_mode(self.seed):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        model.zero_grad(set_to_none=True)
+        Fn.shadows.clear()   # so the weight-shadow casts are part of the captured step
+        with Fn.dropout_keys.graph_mode(self.seed):
+            with torch.cuda.graph(self.graph):
+                self.out, self.loss = self._eager()
+
+    def _eager(self):
+        Fn.nat.seed_advance(self.seed)
+        self.model.zero_grad(set_to_none=True)
+        out = self.model(self.static_batch)
+        loss = self.loss_of(out)
+        loss.backward()
+        return out, loss
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            _copy_batch(self.static_batch, batch)
+        self.graph.replay()
+        return self.loss

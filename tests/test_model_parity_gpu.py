@@ -120,3 +120,33 @@ def test_training_mode_runs_and_is_seed_reproducible():
     assert float((a - e).abs().max()) > 0
     # dropout noise is zero-mean: the train-mode scores stay near the eval-mode ones
     assert float((a - e).abs().mean()) < 0.5
+
+
+def test_graph_replay_matches_eager_and_redraws_dropout():
+    """One hipGraph for forward + loss + backward: same numbers as the eager step in eval mode; in train mode every
+    replay draws fresh dropout masks (device-side seed) and gradients stay finite."""
+    from mmf_amd.utils.graph import GraphedTrainStep
+    z, case, cfg, sd, sample = load_case("small64")
+    model = build_visual_bert(cfg, sd)
+    batch = SampleList(sample_to(sample, "cuda"))
+    model.eval()
+    out = model(batch)
+    loss = sum(v.sum() for v in out["losses"].values())
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    ref_loss = float(loss)
+    ref_grad = model.model.classifier[1].weight.grad.clone()
+    g = GraphedTrainStep(model, batch, warmup=2)
+    l1 = float(g())
+    assert abs(l1 - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert torch.allclose(model.model.classifier[1].weight.grad, ref_grad, rtol=1e-4, atol=1e-6)
+    # parameters changed between replays are seen (the shadow casts are inside the graph)
+    with torch.no_grad():
+        model.model.classifier[1].bias.add_(0.5)
+    l2 = float(g())
+    assert abs(l2 - l1) > 1e-3
+    model.train()
+    gt = GraphedTrainStep(model, batch, warmup=2)
+    a, b = float(gt()), float(gt())
+    assert a != b                       # fresh masks per replay
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

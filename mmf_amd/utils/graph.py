@@ -11,10 +11,26 @@ into every key at run time and `mmf_seed_advance` — the first node of the grap
 draws fresh masks while forward and backward of the same replay agree (mmf_amd.functional._DropoutKeys).
 The fp32 -> bf16 weight-shadow casts are captured too, so replays see parameter updates made between them.
 """
+import gc
+
 import torch
 
 from mmf_amd import functional as Fn
+from mmf_amd.common.registry import registry
 from mmf_amd.common.sample import SampleList
+
+
+def release_autograd_state():
+    """Drop what keeps an earlier eager step's autograd graph alive on our side (the losses `Losses.forward`
+    registers, losses.py:127-131) and collect garbage.
+
+    Why it matters: a parameter's AccumulateGrad node is bound to the stream it was first created on and lives as
+    long as any graph references it.  If an eager forward ran on the legacy default stream and its outputs are still
+    alive, the captured backward hands gradients to those nodes, the default stream is dragged into the capture and
+    `hipStreamEndCapture` crashes.  Callers must also drop their own references (`del out, loss`) — or simply run
+    eager steps under `torch.cuda.stream(...)`."""
+    registry.unregister("losses")
+    gc.collect()
 
 
 def _clone_batch(batch):
@@ -43,7 +59,9 @@ class GraphedTrainStep:
     def __init__(self, model, batch, warmup=3, loss_of=None):
         self.model = model
         self.loss_of = loss_of or (lambda out: sum(v.sum() for v in out["losses"].values()))
+        release_autograd_state()
         self.static_batch = _clone_batch(batch)
+        self.params = [p for p in model.parameters() if p.requires_grad]
         dev = next(model.parameters()).device
         self.seed = torch.zeros(1, dtype=torch.int32, device=dev)
         side = torch.cuda.Stream(device=dev)
@@ -62,10 +80,15 @@ class GraphedTrainStep:
 
     def _eager(self):
         Fn.nat.seed_advance(self.seed)
-        self.model.zero_grad(set_to_none=True)
         out = self.model(self.static_batch)
         loss = self.loss_of(out)
-        loss.backward()
+        # torch.autograd.grad instead of loss.backward(): AccumulateGrad nodes are bound to the stream they were first
+        # created on; if an earlier eager step created them on the legacy default stream, running them inside the
+        # capture drags that stream into it and hipStreamEndCapture crashes.  Capturing the gradients directly keeps
+        # every captured node on the capture stream.
+        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        for p, g in zip(self.params, grads):
+            p.grad = g
         return out, loss
 
     def __call__(self, batch=None):

@@ -177,7 +177,8 @@ def main():
     if args.optimizer:
         from mmf_amd.utils.configuration import Config
         full = Config(model="visual_bert", optimizer=dict(params=dict(lr=5e-5)), model_config=dict(visual_bert=model.config))
-        opt = torch.optim.AdamW(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
+        from mmf_amd.common.registry import registry
+        opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)   # fused multi-tensor HIP AdamW
 
     def step():
         model.zero_grad(set_to_none=True)

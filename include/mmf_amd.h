@@ -219,6 +219,38 @@ int mmf_adamw_step(float* p, const float* g, float* m, float* v, void* p16, int6
                    const float* seg_wd, int nseg, float lr, float beta1, float beta2, float eps, int step,
                    int correct_bias, int mode, float grad_scale, void* stream);
 
+/* Multi-tensor form: up to MMF_MT_MAX separately allocated parameter tensors per launch (fp32 p/g/m/v, optional bf16
+ * shadow p16 refreshed in the same pass), per-tensor lr and weight decay (the two BERT groups of
+ * mmf/utils/modeling.py:18-46 and the finetune LR multiplier).  If norm_sq != NULL the gradients are scaled by
+ * min(1, max_norm / (sqrt(norm_sq[0]) + 1e-6)) on the fly: clip_gradients (mmf/utils/general.py:33-50) folded
+ * into the update.  mmf_l2norm_sq_multi computes (or accumulates) sum(g^2) over a tensor list deterministically;
+ * ws: mmf_l2norm_sq_ws_floats(list) floats. */
+#define MMF_MT_MAX 40
+typedef struct mmf_adamw_multi_desc {
+    int n;
+    void* p[MMF_MT_MAX];
+    const void* g[MMF_MT_MAX];
+    void* m[MMF_MT_MAX];
+    void* v[MMF_MT_MAX];
+    void* p16[MMF_MT_MAX];
+    int64_t numel[MMF_MT_MAX];
+    float lr[MMF_MT_MAX];
+    float wd[MMF_MT_MAX];
+    float beta1, beta2, eps;
+    int step, correct_bias, mode;
+    float grad_scale;
+    const float* norm_sq;
+    float max_norm;
+} mmf_adamw_multi_desc;
+int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream);
+typedef struct mmf_tensor_list {
+    int n;
+    const void* ptr[MMF_MT_MAX];
+    int64_t numel[MMF_MT_MAX];
+} mmf_tensor_list;
+int mmf_l2norm_sq_ws_floats(const mmf_tensor_list* d);
+int mmf_l2norm_sq_multi(const mmf_tensor_list* d, float* out, int accumulate, float* ws, void* stream);
+
 /* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
 int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */
 int mmf_probe_mfma32(const void* a, const void* b, float* d, void* stream);   /* out 64x16 */

@@ -50,6 +50,24 @@ class AttnDesc(C.Structure):
     ]
 
 
+MT_MAX = 40
+
+
+class AdamWMultiDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int),
+        ("p", C.c_void_p * MT_MAX), ("g", C.c_void_p * MT_MAX), ("m", C.c_void_p * MT_MAX), ("v", C.c_void_p * MT_MAX),
+        ("p16", C.c_void_p * MT_MAX), ("numel", C.c_int64 * MT_MAX), ("lr", C.c_float * MT_MAX), ("wd", C.c_float * MT_MAX),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("step", C.c_int), ("correct_bias", C.c_int), ("mode", C.c_int),
+        ("grad_scale", C.c_float), ("norm_sq", C.c_void_p), ("max_norm", C.c_float),
+    ]
+
+
+class TensorList(C.Structure):
+    _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * MT_MAX), ("numel", C.c_int64 * MT_MAX)]
+
+
 class AttnBwdDesc(C.Structure):
     _fields_ = [
         ("f", AttnDesc), ("dctx", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
@@ -335,6 +353,38 @@ def adamw_step(p, g, m, v, p16, n, seg_end, seg_wd, nseg, lr, beta1, beta2, eps,
     _check(lib().mmf_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p16), C.c_int64(n), _p(seg_end), _p(seg_wd), nseg,
                                 C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), int(step),
                                 int(correct_bias), int(mode), C.c_float(grad_scale), _stream()), "mmf_adamw_step")
+
+
+def adamw_multi(items, beta1, beta2, eps, step, correct_bias, mode, grad_scale=1.0, norm_sq=None, max_norm=0.0):
+    """items: list of (p, g, m, v, p16 or None, lr, wd); fp32 contiguous tensors, any number (launched MT_MAX at a time)."""
+    for i0 in range(0, len(items), MT_MAX):
+        chunk = items[i0:i0 + MT_MAX]
+        d = AdamWMultiDesc()
+        d.n = len(chunk)
+        for i, (p, g, m, v, p16, lr, wd) in enumerate(chunk):
+            d.p[i], d.g[i], d.m[i], d.v[i] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            d.p16[i] = p16.data_ptr() if p16 is not None else None
+            d.numel[i], d.lr[i], d.wd[i] = p.numel(), lr, wd
+        d.beta1, d.beta2, d.eps = beta1, beta2, eps
+        d.step, d.correct_bias, d.mode = int(step), int(correct_bias), int(mode)
+        d.grad_scale = grad_scale
+        d.norm_sq = norm_sq.data_ptr() if norm_sq is not None else None
+        d.max_norm = max_norm
+        _check(lib().mmf_adamw_multi(C.byref(d), _stream()), "mmf_adamw_multi")
+
+
+def l2norm_sq_multi(tensors, out):
+    """out[0] = sum over all tensors of sum(x^2) (fp32 tensors), deterministic."""
+    _req(out, torch.float32, "out")
+    for i0 in range(0, len(tensors), MT_MAX):
+        chunk = tensors[i0:i0 + MT_MAX]
+        d = TensorList()
+        d.n = len(chunk)
+        for i, t in enumerate(chunk):
+            _req(t, torch.float32, "tensor")
+            d.ptr[i], d.numel[i] = t.data_ptr(), t.numel()
+        ws = torch.empty(lib().mmf_l2norm_sq_ws_floats(C.byref(d)), dtype=torch.float32, device=out.device)
+        _check(lib().mmf_l2norm_sq_multi(C.byref(d), _p(out), int(i0 > 0), _p(ws), _stream()), "mmf_l2norm_sq_multi")
 
 
 def probe_mfma16(a, b, d):

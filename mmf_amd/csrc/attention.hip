@@ -30,15 +30,26 @@ constexpr int HD = 64;            // head dim
 
 DEVI int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// Stage rows [0, npad) of a token-major [rows][64] bf16 matrix (row stride ld) into a row-major swizzled LDS image.
-// Rows >= nvalid are zero-filled.
+// Stage rows [0, npad) of a token-major [rows][64] bf16 matrix (row stride ld) into a row-major swizzled LDS image by
+// LDS-DMA (global_load_lds_dwordx4): one wave-instruction fills 8 rows (1 KiB, lane-linear), so the chunk swizzle is
+// applied to each lane's SOURCE address.  Rows >= nvalid read a 16-byte zero buffer.  All DMAs of a tile are issued
+// back to back; the caller waits once (s_waitcnt vmcnt(0) + barrier).  npad is a multiple of 32.
+static __device__ uint4 g_zero16;
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
 DEVI void stage_rows(const bf16* g, int ld, int nvalid, int npad, unsigned char* lds_rm, int tid) {
-    for (int c = tid; c < npad * 8; c += 256) {
-        const int row = c >> 3, ch = c & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < nvalid) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + ch * 8);
-        *reinterpret_cast<uint4*>(lds_rm + rm_off(row, ch)) = v;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r0 = wave * 8; r0 < npad; r0 += 32) {
+        const int row = r0 + (lane >> 3);
+        const int logical = (lane & 7) ^ ((row >> 1) & 7);
+        const bf16* src = (row < nvalid) ? g + (size_t)row * ld + logical * 8 : reinterpret_cast<const bf16*>(&g_zero16);
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds_rm + r0 * 128), 16, 0, 0);
     }
+}
+DEVI void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // feature-reduction operand from a row-major LDS image: tile row x (absolute row = row0 + x), step s
@@ -106,9 +117,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
     stage_rows(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
     stage_rows(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
-    for (int i = tid; i < SKP; i += 256)
-        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] : 0.f) : -INFINITY;
-    __syncthreads();
+    for (int i = tid; i < SKP; i += 256)   // additive mask, already in the log2 domain
+        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    stage_wait();
     if (q0 >= a.Sq) return;
 
     // Q fragments (B operand: column = query row)
@@ -129,17 +140,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         sc[t] = acc;
     }
 
-    // softmax over keys (exact two-pass, fp32), as nn.functional.softmax(scores/sqrt(d) + mask)
+    // softmax over keys (exact two-pass, fp32), as nn.functional.softmax(scores/sqrt(d) + mask); evaluated in the
+    // log2 domain (t = s * log2e) so each probability costs one subtract and one v_exp_f32.
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = a.scale * LOG2E;
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
-            sc[t][4 * c + 0] = sc[t][4 * c + 0] * a.scale + mk.x;
-            sc[t][4 * c + 1] = sc[t][4 * c + 1] * a.scale + mk.y;
-            sc[t][4 * c + 2] = sc[t][4 * c + 2] * a.scale + mk.z;
-            sc[t][4 * c + 3] = sc[t][4 * c + 3] * a.scale + mk.w;
+            sc[t][4 * c + 0] = sc[t][4 * c + 0] * sc2 + mk.x;
+            sc[t][4 * c + 1] = sc[t][4 * c + 1] * sc2 + mk.y;
+            sc[t][4 * c + 2] = sc[t][4 * c + 2] * sc2 + mk.z;
+            sc[t][4 * c + 3] = sc[t][4 * c + 3] * sc2 + mk.w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[t][4 * c + i]);
         }
@@ -149,13 +163,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = __expf(sc[t][r] - mx);
+            const float p = exp2f(sc[t][r] - mx);
             sc[t][r] = p;
             sum += p;
         }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
-    if (h == 0 && q0 + x < a.Sq) a.lse[((size_t)bh) * a.Sq + q0 + x] = mx + __logf(sum);
+    if (h == 0 && q0 + x < a.Sq) a.lse[((size_t)bh) * a.Sq + q0 + x] = (mx + log2f(sum)) * 0.6931471805599453f;
 
     // dropout on the probabilities (hf_layers.py:201), index ((bh*Sq + q)*SKP + key)
     if (a.drop.thr16) {
@@ -243,9 +257,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
     stage_rows(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
     stage_rows(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
-    for (int i = tid; i < SKP; i += 256)
-        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] : 0.f) : -INFINITY;
-    __syncthreads();
+    for (int i = tid; i < SKP; i += 256)   // additive mask in the log2 domain
+        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    stage_wait();
     if (q0 >= a.Sq) return;
 
     const int qrow = min(q0 + x, a.Sq - 1);
@@ -254,7 +268,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) { qf[s] = frag_global(qptr, s, lane); dof[s] = frag_global(doptr, s, lane); }
-    const float L = a.lse[(size_t)bh * a.Sq + qrow];
+    const float L = a.lse[(size_t)bh * a.Sq + qrow] * 1.4426950408889634f;   // log2 domain
+    const float sc2 = a.scale * 1.4426950408889634f;
     const float dl = a.delta[(size_t)bh * a.Sq + qrow];
     const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
 
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             if (a.drop.thr16) ds = drop_scale4(drop_key(a.drop), rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float p = __expf(s_acc[4 * c + i] * a.scale + mkv[i] - L);
+                const float p = exp2f(s_acc[4 * c + i] * sc2 + mkv[i] - L);
                 s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * ds[i] - dl) * a.scale;
             }
         }
@@ -322,10 +337,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     stage_rows(dobase, a.ldo, a.Sq, SQP, lds_do, tid);
     for (int i = tid; i < SQP; i += 256) {
         // padded query rows: lse = +inf -> p = exp(-inf) = 0, so they contribute nothing
-        lds_lse[i] = (i < a.Sq) ? a.lse[(size_t)bh * a.Sq + i] : INFINITY;
+        lds_lse[i] = (i < a.Sq) ? a.lse[(size_t)bh * a.Sq + i] * 1.4426950408889634f : INFINITY;   // log2 domain
         lds_delta[i] = (i < a.Sq) ? a.delta[(size_t)bh * a.Sq + i] : 0.f;
     }
-    __syncthreads();
+    stage_wait();
     if (k0 >= a.Sk) return;
 
     const int krow = min(k0 + x, a.Sk - 1);
@@ -335,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
-    const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] : 0.f) : -INFINITY;
+    const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    const float sc2 = a.scale * 1.4426950408889634f;
 
     f32x16 dko[2] = {}, dvo[2] = {};
 #pragma unroll 1
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 if (a.drop.thr16)
                     dsc = drop_scale1(drop_key(a.drop), ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)SKP + (uint32_t)(k0 + x),
                                       a.drop.thr16, a.drop.scale);
-                const float p = __expf(s_acc[4 * c + i] * a.scale + mk - Lv[i]);
+                const float p = exp2f(s_acc[4 * c + i] * sc2 + mk - Lv[i]);
                 pd[4 * c + i] = p * dsc;
                 s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * dsc - Dv[i]) * a.scale;
             }

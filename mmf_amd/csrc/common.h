@@ -98,7 +98,7 @@ DEVI uint32_t mix32(uint32_t x) {  // "lowbias32" integer finalizer
     x ^= x >> 16;
     return x;
 }
-DEVI uint32_t drop_hash(uint32_t key, uint32_t pair_idx) { return mix32(mix32(pair_idx) ^ key); }
+DEVI uint32_t drop_hash(uint32_t key, uint32_t pair_idx) { return mix32(pair_idx * 0x9E3779B1u + key); }
 // keep-scale factors (0 or scale) for the 4 consecutive elements starting at linear index idx4
 // (idx4 % 4 == 0).
 DEVI f32x4 drop_scale4(uint32_t key, uint32_t idx4, uint32_t thr16, float scale) {

@@ -70,15 +70,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // LayerNorm backward (+ dropout backward of the producing Linear, + column-sum partials)
 // partials layout: [gridDim.x][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias
 // ------------------------------------------------------------------------------------------------
-constexpr int LNB_GRID = 512;
+constexpr int LNB_GRID = 128;   // workgroups of 16 waves (2048 waves in flight); one partial row per workgroup
+constexpr int LNB_WAVES = 16;
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, bf16* __restrict__ dx,
                                                       bf16* __restrict__ dlin, DropoutCfg drop, float* __restrict__ partials,
                                                       int rows, int H) {
-    __shared__ float red[4][NCH * 256];
+    __shared__ float red[LNB_WAVES][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 ag[NCH], ab[NCH], al[NCH], gm[NCH];
 #pragma unroll
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         ag[c] = ab[c] = al[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         gm[c] = (COL_OF(c) < H) ? load4(gamma + COL_OF(c)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[NCH], g[NCH];
         float s1 = 0.f, s2 = 0.f;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                 for (int i = 0; i < 4; ++i) al[c][i] += (float)dr[i];
             }
     }
-    // combine the 4 waves of the workgroup, one quantity at a time
+    // combine the waves of the workgroup, one quantity at a time
 #pragma unroll 1
     for (int qn = 0; qn < 3; ++qn) {
         __syncthreads();
@@ -137,8 +138,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             *reinterpret_cast<float4*>(&red[wave][COL_OF(c)]) = make_float4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
-        for (int col = threadIdx.x; col < H; col += 256)
-            partials[((size_t)blockIdx.x * 3 + qn) * H + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+        for (int col = threadIdx.x; col < H; col += 64 * LNB_WAVES) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < LNB_WAVES; ++w) t += red[w][col];
+            partials[((size_t)blockIdx.x * 3 + qn) * H + col] = t;
+        }
     }
 }
 
@@ -460,6 +465,81 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// multi-tensor AdamW / gradient L2 norm: one launch covers up to MMF_MT_MAX tensors (grid.y = tensor, grid.x = chunk)
+// ------------------------------------------------------------------------------------------------
+constexpr int MT_CHUNK = 16384;   // elements per workgroup
+__global__ __launch_bounds__(256) void adamw_multi_kernel(mmf_adamw_multi_desc d, float bc1, float bc2) {
+    const int t = blockIdx.y;
+    const int64_t n = d.numel[t];
+    const int64_t base = (int64_t)blockIdx.x * MT_CHUNK;
+    if (base >= n) return;
+    float* __restrict__ p = reinterpret_cast<float*>(d.p[t]);
+    const float* __restrict__ g = reinterpret_cast<const float*>(d.g[t]);
+    float* __restrict__ m = reinterpret_cast<float*>(d.m[t]);
+    float* __restrict__ v = reinterpret_cast<float*>(d.v[t]);
+    bf16* __restrict__ p16 = reinterpret_cast<bf16*>(d.p16[t]);
+    const float lr = d.lr[t], wd = d.wd[t], b1 = d.beta1, b2 = d.beta2, eps = d.eps;
+    float gs = d.grad_scale;
+    if (d.norm_sq) {   // gradient clipping folded into the update: coef = min(1, max_norm / (||g|| + 1e-6))
+        const float coef = d.max_norm / (sqrtf(d.norm_sq[0]) + 1e-6f);
+        gs *= coef < 1.f ? coef : 1.f;
+    }
+    const int64_t end = (base + MT_CHUNK < n) ? base + MT_CHUNK : n;
+    for (int64_t i = base + threadIdx.x * 4; i < end; i += 1024) {
+        const int cnt = (i + 4 <= end) ? 4 : (int)(end - i);
+        const bool vec = (cnt == 4) && ((i & 3) == 0);
+        f32x4 pv, gv, mv, vv;
+        if (vec) { pv = load4(p + i); gv = load4(g + i); mv = load4(m + i); vv = load4(v + i); }
+        else for (int j = 0; j < 4; ++j) { const bool ok = j < cnt; pv[j] = ok ? p[i + j] : 0.f; gv[j] = ok ? g[i + j] : 0.f; mv[j] = ok ? m[i + j] : 0.f; vv[j] = ok ? v[i + j] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = gv[j] * gs;
+            mv[j] = b1 * mv[j] + (1.f - b1) * gj;
+            vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+            if (d.mode == 0) {   // transformers.AdamW
+                pv[j] -= (lr * sqrtf(bc2) / bc1) * (mv[j] / (sqrtf(vv[j]) + eps));
+                if (wd > 0.f) pv[j] -= lr * wd * pv[j];
+            } else {             // torch.optim.AdamW
+                pv[j] *= (1.f - lr * wd);
+                pv[j] -= (lr / bc1) * (mv[j] / (sqrtf(vv[j]) / sqrtf(bc2) + eps));
+            }
+        }
+        if (vec) {
+            store4(p + i, pv); store4(m + i, mv); store4(v + i, vv);
+            if (p16) store4(p16 + i, pv);
+        } else for (int j = 0; j < cnt; ++j) { p[i + j] = pv[j]; m[i + j] = mv[j]; v[i + j] = vv[j]; if (p16) p16[i + j] = (bf16)pv[j]; }
+    }
+}
+__global__ __launch_bounds__(256) void l2norm_multi_kernel(mmf_tensor_list d, float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int t = blockIdx.y;
+    const int64_t n = d.numel[t];
+    const int64_t base = (int64_t)blockIdx.x * MT_CHUNK;
+    float s = 0.f;
+    if (base < n) {
+        const float* __restrict__ g = reinterpret_cast<const float*>(d.ptr[t]);
+        const int64_t end = (base + MT_CHUNK < n) ? base + MT_CHUNK : n;
+        for (int64_t i = base + threadIdx.x * 4; i < end; i += 1024) {
+            if (i + 4 <= end && (i & 3) == 0) { const f32x4 x = load4(g + i); s += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]; }
+            else for (int64_t j = i; j < end && j < i + 4; ++j) s += g[j] * g[j];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int n, float* __restrict__ out, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout probes
 // ------------------------------------------------------------------------------------------------
 __global__ void probe_mfma16_kernel(const bf16x8* a, const bf16x8* b, f32x4* d) {
@@ -489,7 +569,7 @@ void launch_ln_fwd(int rows, hipStream_t s, A... a) {
 }
 template <int NCH, typename... A>
 void launch_ln_bwd(int grid, hipStream_t s, A... a) {
-    hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(256), 0, s, a...);
+    hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(64 * LNB_WAVES), 0, s, a...);
 }
 
 inline int grid_for(int64_t n, int per_block, int cap) {
@@ -529,7 +609,7 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     MMF_CHECK_ARG(drop_thr16 == 0 || dlin, "layernorm_bwd: dropout needs dlin");
     hipStream_t s = (hipStream_t)stream;
     DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
-    const int grid = grid_for(rows, 4, LNB_GRID);
+    const int grid = grid_for(rows, LNB_WAVES, LNB_GRID);
     const int nch = (H + 255) / 256;
     const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
     switch (nch) {
@@ -700,6 +780,36 @@ int mmf_adamw_step(float* p, const float* g, float* m, float* v, void* p16, int6
     }
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p16, n,
                        seg_end, seg_wd, nseg, lr, beta1, beta2, eps, bc1, bc2, mode, grad_scale);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream) {
+    MMF_CHECK_ARG(d && d->n > 0 && d->n <= MMF_MT_MAX && d->step >= 1, "adamw_multi: bad descriptor");
+    int64_t mx = 0;
+    for (int i = 0; i < d->n; ++i) {
+        MMF_CHECK_ARG(d->p[i] && d->g[i] && d->m[i] && d->v[i] && d->numel[i] > 0, "adamw_multi: null tensor");
+        mx = d->numel[i] > mx ? d->numel[i] : mx;
+    }
+    float bc1 = 1.f, bc2 = 1.f;
+    if (d->correct_bias) { bc1 = 1.f - powf(d->beta1, (float)d->step); bc2 = 1.f - powf(d->beta2, (float)d->step); }
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)((mx + MT_CHUNK - 1) / MT_CHUNK), d->n), dim3(256), 0, (hipStream_t)stream, *d, bc1, bc2);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_l2norm_sq_ws_floats(const mmf_tensor_list* d) {
+    int64_t mx = 0;
+    for (int i = 0; i < d->n; ++i) mx = d->numel[i] > mx ? d->numel[i] : mx;
+    return (int)((mx + MT_CHUNK - 1) / MT_CHUNK) * d->n;
+}
+int mmf_l2norm_sq_multi(const mmf_tensor_list* d, float* out, int accumulate, float* ws, void* stream) {
+    MMF_CHECK_ARG(d && d->n > 0 && d->n <= MMF_MT_MAX && out && ws, "l2norm_sq_multi: bad descriptor");
+    int64_t mx = 0;
+    for (int i = 0; i < d->n; ++i) { MMF_CHECK_ARG(d->ptr[i] && d->numel[i] > 0, "l2norm_sq_multi: null tensor"); mx = d->numel[i] > mx ? d->numel[i] : mx; }
+    const unsigned gx = (unsigned)((mx + MT_CHUNK - 1) / MT_CHUNK);
+    hipLaunchKernelGGL(l2norm_multi_kernel, dim3(gx, d->n), dim3(256), 0, (hipStream_t)stream, *d, ws);
+    MMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, (int)(gx * d->n), out, accumulate);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -94,10 +94,27 @@ class ShadowCache:
 
     def __init__(self):
         self._store = {}  # id(head parameter) -> (signature, buffer, dtype); entry dies with the parameter
+        self._slot = {}   # id(parameter) -> (head key, first row) for bf16 shadows
 
     def clear(self):
         """Forget every shadow: the next use re-casts (used before hipGraph capture)."""
         self._store.clear()
+        self._slot.clear()
+
+    def slot(self, p):
+        """The bf16 shadow rows of parameter `p` if it has an up-to-date shadow, else None.  The fused optimizer
+        writes the new bf16 value there in the same pass that updates the fp32 master (no re-cast next step)."""
+        ent = self._slot.get(id(p))
+        if ent is None:
+            return None
+        key, r0 = ent
+        st = self._store.get(key)
+        if st is None or st[2] != BF16:
+            return None
+        for q, ver, ptr in st[0]:
+            if q == id(p) and (ver != p._version or ptr != p.data_ptr()):
+                return None
+        return st[1][r0:r0 + p.shape[0]]
 
     def get(self, *params, dtype=BF16):
         head = params[0]
@@ -122,6 +139,8 @@ class ShadowCache:
                 nat.cast_f32_to_bf16(src, buf[r:r + n])
             else:
                 buf[r:r + n].copy_(src)
+            if dtype == BF16:
+                self._slot[id(p)] = (key, r)
             r += n
         self._store[key] = (sig, buf, dtype)
         return buf

@@ -1,0 +1,71 @@
+"""`adam_w` for the MI355X path: the reference registers `transformers.AdamW` under that key
+(mmf/modules/optimizers.py:8-17); this is the same update rule as ONE multi-tensor HIP kernel per 40
+parameters (`mmf_adamw_multi`), which also refreshes the bf16 weight shadows in the same pass and can fold
+gradient clipping (`clip_gradients`, mmf/utils/general.py:33-50) into the update.
+
+    optimizer = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(config), lr=5e-5, eps=1e-8)
+"""
+import torch
+
+from mmf_amd import _native as nat
+from mmf_amd import functional as Fn
+from mmf_amd.common.registry import registry
+
+
+@registry.register_optimizer("adam_w")
+class AdamW(torch.optim.Optimizer):
+    """transformers.AdamW signature and semantics (`correct_bias`, decoupled decay applied after the Adam step).
+    `torch_mode=True` switches to torch.optim.AdamW's rule (decay first, eps outside the bias-corrected sqrt)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, torch_mode=False):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameters: {} - should be in [0.0, 1.0[".format(betas))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+        self.torch_mode = torch_mode
+        self._clip = None
+
+    @torch.no_grad()
+    def clip_grad_norm(self, max_norm):
+        """Total gradient L2 norm (one deterministic multi-tensor reduction); the clipping itself is folded into the
+        next `step()`.  `clip_gradients` (general.py:39-40) calls this when the optimizer provides it."""
+        grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not grads:
+            return torch.zeros(())
+        norm_sq = torch.empty(1, dtype=torch.float32, device=grads[0].device)
+        nat.l2norm_sq_multi([g if g.is_contiguous() else g.contiguous() for g in grads], norm_sq)
+        self._clip = (norm_sq, float(max_norm))
+        return norm_sq.sqrt()[0]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            items = []
+            step = group.get("step", 0) + 1
+            group["step"] = step
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                items.append((p, g, st["exp_avg"], st["exp_avg_sq"], Fn.shadows.slot(p), group["lr"], group["weight_decay"]))
+            if not items:
+                continue
+            b1, b2 = group["betas"]
+            norm_sq, max_norm = self._clip if self._clip is not None else (None, 0.0)
+            nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
+                            1.0, norm_sq, max_norm)
+        self._clip = None
+        return loss

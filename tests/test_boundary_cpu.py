@@ -90,3 +90,20 @@ def test_model_refuses_to_run_without_hbm_tensors():
     from mmf_amd._native import NativeLibraryError
     with pytest.raises((NativeLibraryError, RuntimeError)):
         model(SampleList(sample))
+
+
+def test_warmup_linear_schedule_matches_transformers():
+    import transformers
+    from mmf_amd.common.registry import registry as reg
+    w = torch.nn.Parameter(torch.zeros(1))
+    o1 = torch.optim.SGD([w], lr=5e-5); o2 = torch.optim.SGD([w], lr=5e-5)
+    s1 = reg.get_scheduler_class("warmup_linear")(o1, num_warmup_steps=6, num_training_steps=60)
+    s2 = transformers.get_linear_schedule_with_warmup(o2, num_warmup_steps=6, num_training_steps=60)
+    for _ in range(70):
+        assert abs(o1.param_groups[0]["lr"] - o2.param_groups[0]["lr"]) < 1e-12
+        o1.step(); o2.step(); s1.step(); s2.step()
+
+
+def test_adam_w_is_registered():
+    from mmf_amd.common.registry import registry as reg
+    assert reg.get_optimizer_class("adam_w").__name__ == "AdamW"

@@ -417,3 +417,60 @@ def test_adamw_matches_reference_rules():
         pr = pr - ss * mr / (vr.sqrt() + eps)
         pr = pr - lr * wd * pr
     close(p, pr, 1e-5, 1e-6, "adamw hf mode")
+
+
+def test_multi_tensor_adamw_optimizer_matches_reference_rules():
+    """mmf_amd.modules.optimizers.AdamW (registered "adam_w") vs torch.optim.AdamW (torch_mode) and vs the restated
+    transformers.AdamW rule, over 60 tensors of ragged sizes in two weight-decay groups, with gradient clipping."""
+    import mmf_amd
+    from mmf_amd.common.registry import registry
+    cls = registry.get_optimizer_class("adam_w")
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(int(torch.randint(1, 300, (1,), generator=gen)), int(torch.randint(1, 70, (1,), generator=gen))) for _ in range(59)] + [(30000, 64)]
+    base = [torch.randn(s, generator=gen).to(DEV) for s in shapes]
+    grads = [torch.randn(s, generator=gen).to(DEV) * 3 for s in shapes]
+    def groups(ps):
+        return [{"params": ps[0::2], "weight_decay": 0.01}, {"params": ps[1::2], "weight_decay": 0.0}]
+    # torch rule
+    ours = [b.clone().requires_grad_(True) for b in base]; ref = [b.clone().requires_grad_(True) for b in base]
+    o1 = cls(groups(ours), lr=3e-3, eps=1e-8, torch_mode=True); o2 = torch.optim.AdamW(groups(ref), lr=3e-3, eps=1e-8)
+    for _ in range(3):
+        for p, q, g in zip(ours, ref, grads):
+            p.grad = g.clone(); q.grad = g.clone()
+        n1 = o1.clip_grad_norm(5.0); n2 = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        close(n1, n2, 1e-5, 1e-5, "grad norm")
+        o1.step(); o2.step()
+    for p, q in zip(ours, ref):
+        close(p.detach(), q.detach(), 2e-5, 2e-6, "adamw multi (torch rule + clip)")
+    # transformers rule (restated), no clipping
+    ours = [b.clone().requires_grad_(True) for b in base]
+    o1 = cls(groups(ours), lr=3e-3, eps=1e-8, correct_bias=True)
+    pr = [b.clone() for b in base]; mr = [torch.zeros_like(b) for b in base]; vr = [torch.zeros_like(b) for b in base]
+    for step in (1, 2):
+        for p, g in zip(ours, grads):
+            p.grad = g.clone()
+        o1.step()
+        for i, g in enumerate(grads):
+            wd = 0.01 if i % 2 == 0 else 0.0
+            mr[i] = 0.9 * mr[i] + 0.1 * g; vr[i] = 0.999 * vr[i] + 0.001 * g * g
+            ss = 3e-3 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+            pr[i] = pr[i] - ss * mr[i] / (vr[i].sqrt() + 1e-8)
+            pr[i] = pr[i] - 3e-3 * wd * pr[i]
+    for p, q in zip(ours, pr):
+        close(p.detach(), q, 2e-5, 2e-6, "adamw multi (transformers rule)")
+
+
+def test_optimizer_refreshes_bf16_shadows_in_place():
+    """After a fused step the cached bf16 weight shadow equals bf16(new fp32 master) without a re-cast."""
+    from mmf_amd import functional as Fn
+    from mmf_amd.modules.hf_layers import Linear
+    from mmf_amd.modules.optimizers import AdamW
+    lin = Linear(64, 128).to(DEV)
+    torch.nn.init.normal_(lin.weight); torch.nn.init.normal_(lin.bias)
+    x = rnd(8, 64)
+    y = lin(x); y.float().sum().backward()
+    sh = Fn.shadows.get(lin.weight)
+    opt = AdamW(lin.parameters(), lr=1e-2)
+    opt.step()
+    assert Fn.shadows.get(lin.weight) is sh              # still considered fresh (no new cast)
+    assert torch.equal(sh, lin.weight.detach().to(torch.bfloat16))

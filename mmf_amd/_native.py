@@ -78,7 +78,7 @@ class AttnBwdDesc(C.Structure):
 _lib = None
 # kernel-development switches (see mmf_gemm_desc.debug_flags); all zero in production
 _GEMM_DEBUG = ((int(os.environ.get("MMF_AMD_GEMM_DBG", "0")) << 4) | (int(os.environ.get("MMF_AMD_GEMM_4WAVE", "0")) << 8)
-               | (int(os.environ.get("MMF_AMD_GEMM_NO96", "0")) << 9))
+               | (int(os.environ.get("MMF_AMD_GEMM_NO96", "0")) << 9) | (int(os.environ.get("MMF_AMD_GEMM_K32", "0")) << 10))
 
 
 def lib():

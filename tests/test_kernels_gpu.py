@@ -119,7 +119,18 @@ def test_gemm_tile_variants_agree(N):
     W1 = torch.empty(M, N, dtype=torch.float32, device=DEV); W2 = torch.empty_like(W1)
     nat().gemm(Ak, Bk, W1, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True)
     nat().gemm(Ak, Bk, W2, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True, debug_flags=256)
-    close(W1, W2, 1e-5, 1e-4, "wgrad ring vs generic")
+    close(W1, W2, 1e-5, 1e-4, "wgrad 8-wave vs 4-wave")
+    # BK = 32 / four-workgroups-per-CU form (gemm32.hip)
+    C3 = torch.empty_like(C1)
+    nat().gemm(A, B, C3, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, debug_flags=1024)
+    nat().gemm(A, B, C2, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, debug_flags=256)
+    assert torch.equal(C3, C2)
+    nat().gemm(A, Bk, C3, M, N, K, K, N, N, b_kmajor=True, debug_flags=1024)
+    nat().gemm(A, Bk, C2, M, N, K, K, N, N, b_kmajor=True, debug_flags=256)
+    assert torch.equal(C3, C2)
+    W3 = torch.empty_like(W1)
+    nat().gemm(Ak, Bk, W3, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True, debug_flags=1024)
+    close(W3, W2, 1e-5, 1e-4, "wgrad BK=32 form")
 
 
 def test_gemm_gelu_and_dgelu_epilogues():

@@ -45,6 +45,8 @@ const char* mmf_amd_target(void);
  *   v += bias[n]; v += coladd[n]; v += rowtab[rowidx[m]*rowtab_ld + n];
  *   act==1: U[m][n] = gelu_erf'(v) (if U), v = gelu_erf(v)   (HF BertIntermediate; exact-erf GELU)
  *   act==2: v *= aux[m][n]                                   (backward of the above: aux = the saved U)
+ *   act==3: v = tanh(v)                                      (HF BertPooler, mmf/models/mmbt.py:311)
+ *   act==4: v *= 1 - aux[m][n]^2                             (backward of tanh: aux = the saved output)
  *   dropout(v) with (drop_key, drop_thr16, drop_scale), element index m*N+n
  *   v += resid[m][n]                                   (HF BertSelfOutput / BertOutput residual)
  *   out_f32 ? C = v + beta*C (float) : C = bf16(v)
@@ -148,10 +150,11 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
 
 /* ---- embeddings (BertVisioLinguisticEmbeddings, mmf/modules/embeddings.py:329-345) ------------
  * Text rows of the joint pre-LayerNorm sequence: y[b*S + t] = word[ids[b,t]] + pos[t] + type[seg[b,t]].
- * Tables are fp32 [*, H]; y is bf16 [B*S, H]; ids/seg int64 [B, T].
+ * Tables are fp32 [*, H]; y is bf16 [B*S, H]; ids/seg int64 [B, T].  General form (MMBT, mmf/models/mmbt.py:84-129,
+ * 245-250): y[b*S + row0 + t] = word[ids[b,t]] + pos[pos0 + t] + type[seg[b,t]].
  */
 int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
-                       const float* type, void* y, int B, int T, int S, int H, void* stream);
+                       const float* type, void* y, int B, int T, int S, int H, int row0, int pos0, void* stream);
 /* out[idx[r]] += x[row r] for r in [0, nb*rpb): row r = (b, i) lives at x + (b*bstride + i)*ld.
  * idx == NULL means bucket (i + idx_base) (position ids) when per_pos != 0, else bucket idx_base.
  * fp32 atomics into `out` [nbuckets, H] (caller zero-fills when not accumulating).
@@ -207,6 +210,14 @@ int mmf_bce_logits_ws_floats(void);
 int mmf_bce_logits_fwd(const float* scores, const float* targets, float* loss, float* ws, int B, int N, void* stream);
 int mmf_bce_logits_bwd(const float* scores, const float* targets, const float* gloss, void* dscores, int ldd,
                        int B, int N, void* stream);
+
+/* ---- loss: nn.CrossEntropyLoss(ignore_index) as used by MMF's `cross_entropy` loss (mmf/modules/losses.py) ---------
+ * logits fp32 [B, C] (C <= a few dozen classes), labels int64 [B]; mean over the non-ignored rows.  fwd writes
+ * loss[0] and count[0] (number of contributing rows, reused by bwd).  bwd: dlogits fp32 [B, C]. */
+int mmf_cross_entropy_fwd(const float* logits, const int64_t* labels, float* loss, float* count, int B, int C,
+                          int ignore_index, void* stream);
+int mmf_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* count, const float* gloss,
+                          float* dlogits, int B, int C, int ignore_index, void* stream);
 
 /* ---- optimizer: AdamW (mmf/modules/optimizers.py:8-17; transformers.AdamW semantics) ----------
  * One fused pass over a flat fp32 parameter arena: p, g, m, v [n].  Weight decay is

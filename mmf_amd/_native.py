@@ -245,11 +245,11 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, dgamma, dbeta, dbias
                                    int(accumulate), _p(partials), rows, H, _stream()), "mmf_layernorm_bwd")
 
 
-def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H):
+def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
     _req(ids, torch.int64, "ids"); _req(seg, torch.int64, "seg"); _req(y, torch.bfloat16, "y")
     for t, n in ((word, "word"), (pos, "pos"), (typ, "type")):
         _req(t, torch.float32, n)
-    _check(lib().mmf_embed_text_fwd(_p(ids), _p(seg), _p(word), _p(pos), _p(typ), _p(y), B, T, S, H, _stream()),
+    _check(lib().mmf_embed_text_fwd(_p(ids), _p(seg), _p(word), _p(pos), _p(typ), _p(y), B, T, S, H, row0, pos0, _stream()),
            "mmf_embed_text_fwd")
 
 
@@ -344,6 +344,17 @@ def bce_logits_bwd(scores, targets, gloss, dscores, ldd, B, N):
     _req(dscores, torch.bfloat16, "dscores")
     _check(lib().mmf_bce_logits_bwd(_p(scores), _p(targets), _p(gloss), _p(dscores), ldd, B, N, _stream()),
            "mmf_bce_logits_bwd")
+
+
+def cross_entropy_fwd(logits, labels, loss, count, B, Cn, ignore_index=-100):
+    _req(logits, torch.float32, "logits"); _req(labels, torch.int64, "labels"); _req(loss, torch.float32, "loss"); _req(count, torch.float32, "count")
+    _check(lib().mmf_cross_entropy_fwd(_p(logits), _p(labels), _p(loss), _p(count), B, Cn, ignore_index, _stream()), "mmf_cross_entropy_fwd")
+
+
+def cross_entropy_bwd(logits, labels, count, gloss, dlogits, B, Cn, ignore_index=-100):
+    _req(logits, torch.float32, "logits"); _req(labels, torch.int64, "labels"); _req(dlogits, torch.float32, "dlogits")
+    _check(lib().mmf_cross_entropy_bwd(_p(logits), _p(labels), _p(count), _p(gloss), _p(dlogits), B, Cn, ignore_index, _stream()),
+           "mmf_cross_entropy_bwd")
 
 
 def adamw_step(p, g, m, v, p16, n, seg_end, seg_wd, nseg, lr, beta1, beta2, eps, step, correct_bias, mode, grad_scale):

@@ -243,7 +243,8 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
             e.C = d->splitk_ws; e.ldc = d->N; e.beta = 0.f;
         }
     }
-    MMF_CHECK_ARG(d->act != 2 || d->aux, "mmf_gemm_bf16: act=2 needs aux");
+    MMF_CHECK_ARG((d->act != 2 && d->act != 4) || d->aux, "mmf_gemm_bf16: act=2/4 needs aux");
+    MMF_CHECK_ARG(d->act >= 0 && d->act <= 4, "mmf_gemm_bf16: unknown act");
     MMF_CHECK_ARG(!d->rowtab || d->rowidx, "mmf_gemm_bf16: rowtab needs rowidx");
 
     // ragged unless every tile is full and every chunk in range

@@ -20,7 +20,7 @@ struct EpiArgs {
     const float* rowtab;  // optional table gathered per output row: rowtab[rowidx[m]*rowtab_ld + n]
     const int64_t* rowidx;
     int rowtab_ld;
-    int act;            // 0 none | 1 gelu(acc) (U := gelu'(acc) if U != null) | 2 acc * aux
+    int act;            // 0 none | 1 gelu(acc) (U := gelu'(acc) if U != null) | 2 acc * aux | 3 tanh(acc) | 4 acc * (1 - aux^2)
     bf16* U;
     const bf16* aux;    // same indexing as C (ldc)
     const bf16* resid;  // added after activation/dropout, ldr
@@ -253,6 +253,18 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (ok[r]) v[r] *= (float)e.aux[off + r];
         }
+    } else if (e.act == 3) {   // HF BertPooler: tanh
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
+    } else if (e.act == 4) {   // backward of tanh: v *= 1 - y^2, y = saved output (aux)
+        f32x8 y = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (vec) y = load_bf8(e.aux + off);
+        else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ok[r]) y[r] = (float)e.aux[off + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= 1.f - y[r] * y[r];
     }
     if (e.drop.thr16) {
         const uint32_t idx = (uint32_t)m * (uint32_t)e.N + (uint32_t)n;

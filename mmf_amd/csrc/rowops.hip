@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                           const float* __restrict__ word, const float* __restrict__ pos,
                                                           const float* __restrict__ type, bf16* __restrict__ y, int B, int T,
-                                                          int S, int H) {
+                                                          int S, int H, int row0, int pos0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= B * T) return;
@@ -185,9 +185,9 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     const int64_t id = ids[r];
     const int64_t sg = seg ? seg[r] : 0;
     const float* w = word + (size_t)id * H;
-    const float* p = pos + (size_t)t * H;
+    const float* p = pos + (size_t)(t + pos0) * H;
     const float* ty = type + (size_t)sg * H;
-    bf16* yr = y + ((size_t)b * S + t) * H;
+    bf16* yr = y + ((size_t)b * S + row0 + t) * H;
     for (int col = lane * 4; col < H; col += 256) {
         const f32x4 a = load4(w + col), c = load4(p + col), d = load4(ty + col);
         // same association order as embeddings.py:344 (words + position) + token_type
@@ -425,6 +425,42 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// softmax cross-entropy (nn.CrossEntropyLoss, mean over the rows whose label != ignore_index): C <= 64 classes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ce_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab, float* __restrict__ loss,
+                                                    float* __restrict__ count, int B, int C, int ignore_index) {
+    float s = 0.f, n = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        const int64_t y = lab[b];
+        if (y == ignore_index || y < 0 || y >= C) continue;
+        const float* r = x + (size_t)b * C;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, r[c]);
+        float z = 0.f;
+        for (int c = 0; c < C; ++c) z += __expf(r[c] - mx);
+        s += mx + __logf(z) - r[y];
+        n += 1.f;
+    }
+    s = wave_sum(s); n = wave_sum(n);
+    if (threadIdx.x == 0) { loss[0] = s / n; count[0] = n; }   // 0/0 = NaN when every label is ignored, like torch
+}
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab, const float* __restrict__ count,
+                                                     const float* __restrict__ gloss, float* __restrict__ dx, int B, int C, int ignore_index) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int64_t y = lab[b];
+    float* d = dx + (size_t)b * C;
+    if (y == ignore_index || y < 0 || y >= C) { for (int c = 0; c < C; ++c) d[c] = 0.f; return; }
+    const float* r = x + (size_t)b * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, r[c]);
+    float z = 0.f;
+    for (int c = 0; c < C; ++c) z += __expf(r[c] - mx);
+    const float g = (gloss ? gloss[0] : 1.f) / count[0];
+    for (int c = 0; c < C; ++c) d[c] = g * (__expf(r[c] - mx) / z - (c == y ? 1.f : 0.f));
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused AdamW over a flat arena
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -626,11 +662,11 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
 }
 
 int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, void* y,
-                       int B, int T, int S, int H, void* stream) {
+                       int B, int T, int S, int H, int row0, int pos0, void* stream) {
     MMF_CHECK_ARG(ids && word && pos && type && y, "embed_text_fwd: null operand");
-    MMF_CHECK_ARG(B > 0 && T > 0 && S >= T && (H % 4) == 0, "embed_text_fwd: bad shape");
+    MMF_CHECK_ARG(B > 0 && T > 0 && row0 >= 0 && S >= row0 + T && pos0 >= 0 && (H % 4) == 0, "embed_text_fwd: bad shape");
     hipLaunchKernelGGL(embed_text_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
-                       (bf16*)y, B, T, S, H);
+                       (bf16*)y, B, T, S, H, row0, pos0);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -765,6 +801,21 @@ int mmf_bce_logits_bwd(const float* scores, const float* targets, const float* g
     const int64_t n = (int64_t)B * ldd;
     hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, targets, gloss,
                        (bf16*)dscores, ldd, B, N);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_cross_entropy_fwd(const float* logits, const int64_t* labels, float* loss, float* count, int B, int C, int ignore_index, void* stream) {
+    MMF_CHECK_ARG(logits && labels && loss && count && B > 0 && C > 0, "cross_entropy_fwd: bad operand");
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logits, labels, loss, count, B, C, ignore_index);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* count, const float* gloss, float* dlogits, int B, int C,
+                          int ignore_index, void* stream) {
+    MMF_CHECK_ARG(logits && labels && count && dlogits && B > 0 && C > 0, "cross_entropy_bwd: bad operand");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, labels, count, gloss, dlogits, B, C,
+                       ignore_index);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -112,5 +112,119 @@ def main():
         print(name, "loss", loss.item(), "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
 
 
+MMBT_CASES = {
+    "mmbt_small64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
+                         max_position_embeddings=40, modal_hidden_size=72, num_labels=2, B=4, T=12, N=7, seed=21),
+}
+
+
+def make_mmbt():
+    """MMBT (BASELINE configs[0]) through the reference's own MMBTBase.forward / MMBTModel / ModalEmbeddings /
+    BertModelJit and MMBTForClassification.forward, direct-feature input (identity modal encoder)."""
+    from torch import nn
+    from transformers import BertConfig
+    M = refshim.ref_import("mmf.models.mmbt")
+    from mmf.modules.hf_layers import BertModelJit
+    from mmf.modules.losses import CrossEntropyLoss
+    from transformers.models.bert.modeling_bert import BertPredictionHeadTransform
+
+    for name, c in MMBT_CASES.items():
+        bcfg = BertConfig(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+                          num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                          vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"], type_vocab_size=2,
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12)
+        mcfg = M.MMBTConfig(bcfg, num_labels=c["num_labels"], modal_hidden_size=c["modal_hidden_size"])
+
+        class Holder(nn.Module):
+            pass
+
+        class RefMMBT(nn.Module):   # module tree of MMBTForClassification: bert.mmbt.*, classifier.*
+            def __init__(self):
+                super().__init__()
+                self.bert = Holder()
+                self.bert.mmbt = M.MMBTModel(mcfg, BertModelJit(bcfg), nn.Identity())
+                self.classifier = nn.Sequential(BertPredictionHeadTransform(bcfg), nn.Linear(c["hidden_size"], c["num_labels"]))
+
+        ref = RefMMBT().eval()
+        uniq = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+                if not k.endswith("position_ids") and not k.endswith("token_type_ids") and "modal_encoder.position_embeddings" not in k
+                and "modal_encoder.token_type_embeddings" not in k and "modal_encoder.word_embeddings" not in k
+                and "modal_encoder.LayerNorm" not in k}
+        sd = detweights.state_dict(uniq, c["seed"])
+        missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected, unexpected
+        # MMBTBase.forward needs only these attributes of `self`
+        base = Holder()
+        base._is_direct_features_input = True
+        base.use_modal_start_token = True
+        base.use_modal_end_token = True
+        base.num_max_segment = 2
+        base.mmbt = ref.bert.mmbt
+        base.extract_modal_end_token = lambda sl: M.MMBTBase.extract_modal_end_token(base, sl)
+        head = Holder()
+        head.bert = lambda sl: M.MMBTBase.forward(base, sl)
+        head.output_hidden_states = False
+        head.output_attentions = False
+        head.fused_feature_only = False
+        head.dropout = nn.Dropout(0.1).eval()
+        head.classifier = ref.classifier
+        head.num_labels = c["num_labels"]
+
+        B, T, N, seed = c["B"], c["T"], c["N"], c["seed"]
+        ids = (detweights.uniform(B * T, seed + 100) * c["vocab_size"]).astype(np.int64).reshape(B, T)
+        mask = np.ones((B, T), dtype=np.int64)
+        mask[1, T // 2:] = 0
+        mask[2, T - 3:] = 0
+        seg = np.zeros((B, T), dtype=np.int64)
+        feats = detweights.uniform(B * N * c["modal_hidden_size"], seed + 102).astype(np.float32).reshape(B, N, -1)
+        targets = (detweights.uniform(B, seed + 103) > 0.5).astype(np.int64)
+        sl = SampleList(input_ids=torch.from_numpy(ids.copy()), input_mask=torch.from_numpy(mask.copy()),
+                        segment_ids=torch.from_numpy(seg), image_feature_0=torch.from_numpy(feats),
+                        targets=torch.from_numpy(targets), dataset_name="hateful_memes", dataset_type="train")
+        seq_holder = {}
+        orig_forward = ref.bert.mmbt.forward
+
+        def spy(*a, **k):
+            out = orig_forward(*a, **k)
+            seq_holder["seq"], seq_holder["pooled"] = out[0], out[1]
+            return out
+
+        ref.bert.mmbt.forward = spy
+        out = M.MMBTForClassification.forward(head, sl)
+        loss = CrossEntropyLoss()(sl, out)
+        loss.backward()
+        rec = {"in_input_ids": ids, "in_input_mask": mask, "in_segment_ids": seg, "in_image_feature_0": feats, "in_targets": targets}
+        rec["scores"] = out["scores"].detach().numpy()
+        rec["sequence_output"] = seq_holder["seq"].detach().numpy()
+        rec["pooled_output"] = seq_holder["pooled"].detach().numpy()
+        rec["loss"] = np.array(loss.item(), dtype=np.float64)
+        names, norms, sums = [], [], []
+        seen = set()
+        for k, p in ref.named_parameters():   # named_parameters lists shared parameters once
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            g = p.grad
+            names.append("model." + k)
+            norms.append(0.0 if g is None else float(g.double().norm()))
+            sums.append(0.0 if g is None else float(g.double().sum()))
+            if g is not None and g.numel() <= 4096:
+                rec["grad::model." + k] = g.numpy()
+        rec["grad_names"] = np.array(names)
+        rec["grad_norms"] = np.array(norms)
+        rec["grad_sums"] = np.array(sums)
+        rec["param_names"] = np.array(["model." + k for k in uniq.keys()])
+        rec["param_shapes"] = np.array([",".join(map(str, s)) for s in uniq.values()])
+        rec["state_dict_keys"] = np.array(["model." + k for k in ref.state_dict().keys()])
+        rec["case"] = np.array(repr(c))
+        path = os.path.join(HERE, "%s.npz" % name)
+        np.savez_compressed(path, **rec)
+        print(name, "loss", loss.item(), "scores", rec["scores"][0], "->", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1:] or ["visual_bert", "mmbt"]
+    if "visual_bert" in which:
+        main()
+    if "mmbt" in which:
+        make_mmbt()

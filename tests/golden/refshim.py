@@ -105,3 +105,16 @@ def install():
         except ModuleNotFoundError as e:
             _stub(e.name)
     raise RuntimeError("could not import reference")
+
+
+def ref_import(name, tries=200):
+    """Import a reference module, stubbing whatever third-party package is missing on the way."""
+    import importlib
+    for _ in range(tries):
+        try:
+            return importlib.import_module(name)
+        except ModuleNotFoundError as e:
+            if e.name and e.name.startswith("mmf."):
+                raise
+            _stub(e.name)
+    raise RuntimeError("could not import " + name)

@@ -31,3 +31,23 @@ def load_case(name):
     # the reference model prefixes its parameters with "model." (visual_bert.py:420-422)
     sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}
     return z, case, cfg, sd, sample
+
+
+def load_mmbt_case(name="mmbt_small64"):
+    z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n)[len("model."):]: tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {k: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    cfg = dict(
+        vocab_size=case["vocab_size"], hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"],
+        num_attention_heads=case["num_attention_heads"], intermediate_size=case["intermediate_size"],
+        max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2, layer_norm_eps=1e-12,
+        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, modal_hidden_size=case["modal_hidden_size"],
+        num_labels=case["num_labels"], use_modal_start_token=True, use_modal_end_token=True, num_segments=2,
+        initializer_range=0.02)
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),
+        "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "hateful_memes", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample

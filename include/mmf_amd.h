@@ -196,6 +196,8 @@ int mmf_seed_advance(uint32_t* seed, void* stream);
 /* du = dh * g with g = gelu_erf'(u) as saved by the forward epilogue (act == 1): backward of HF
  * BertIntermediate's activation when it is not fused into a dgrad GEMM epilogue (act == 2). */
 int mmf_gelu_bwd_bf16(const void* dh, const void* g, void* du, int64_t n, void* stream);
+/* dx = dy * (1 - y^2): backward of the tanh in HF BertPooler (mmf/models/mmbt.py:311), y = saved output. */
+int mmf_tanh_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
 int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* mask_add[b][s] = (1 - mask[b][s]) * -10000  (visual_bert.py:94-106); mask int64 [B,S]. */
 int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream);

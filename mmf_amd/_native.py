@@ -326,6 +326,12 @@ def gelu_bwd(dh, u, du):
     _check(lib().mmf_gelu_bwd_bf16(_p(dh), _p(u), _p(du), C.c_int64(dh.numel()), _stream()), "mmf_gelu_bwd_bf16")
 
 
+def tanh_bwd(dy, y, dx):
+    for t, nme in ((dy, "dy"), (y, "y"), (dx, "dx")):
+        _req(t, torch.bfloat16, nme)
+    _check(lib().mmf_tanh_bwd_bf16(_p(dy), _p(y), _p(dx), C.c_int64(dy.numel()), _stream()), "mmf_tanh_bwd_bf16")
+
+
 def make_additive_mask(mask, out):
     _req(mask, torch.int64, "mask"); _req(out, torch.float32, "out")
     _check(lib().mmf_make_additive_mask(_p(mask), _p(out), C.c_int64(mask.numel()), _stream()), "mmf_make_additive_mask")

@@ -371,6 +371,11 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ 
         else for (int64_t j = i; j < n; ++j) du[j] = (bf16)((float)dh[j] * (float)g[j]);
     }
 }
+// dx = dy * (1 - y^2): backward of tanh (HF BertPooler)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float yy = (float)y[i]; dx[i] = (bf16)((float)dy[i] * (1.f - yy * yy)); }
+}
 // 2-D casts with leading dimensions; destination pad columns [cols, ldd) are zero-filled
 __global__ __launch_bounds__(256) void cast2d_f32_bf16_kernel(const float* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd, int rows, int cols) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -757,6 +762,12 @@ int mmf_gelu_bwd_bf16(const void* dh, const void* u, void* du, int64_t n, void* 
     MMF_CHECK_ARG(dh && u && du && n > 0, "gelu_bwd: bad operand");
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh, (const bf16*)u,
                        (bf16*)du, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_tanh_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream) {
+    MMF_CHECK_ARG(dy && y && dx && n > 0, "tanh_bwd: bad operand");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n);
     MMF_CHECK_LAUNCH();
     return 0;
 }

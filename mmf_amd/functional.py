@@ -574,3 +574,152 @@ class LogitBCEFn(torch.autograd.Function):
         d = torch.empty(B, N, dtype=F32, device=s.device)
         nat.cast2d_bf16_to_f32(d16, ldd, d, N, B, N)
         return d, None
+
+
+# ---------------------------------------------------------------------------------------------
+# MMBT pieces (mmf/models/mmbt.py)
+# ---------------------------------------------------------------------------------------------
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout on a bf16 activation with the counter-hash mask (same mask regenerated in backward)."""
+
+    @staticmethod
+    def forward(ctx, x, drop):
+        x2 = _as_bf16_2d(x)
+        y = torch.empty_like(x2)
+        nat.dropout(x2, y, drop)
+        ctx.drop = drop
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = _grad_bf16(g, g.shape[-1])
+        d = torch.empty_like(g2)
+        nat.dropout(g2, d, ctx.drop)
+        return d.view(g.shape), None
+
+
+class LinearTanhFn(torch.autograd.Function):
+    """HF BertPooler body: tanh(x W^T + b), tanh fused in the GEMM epilogue (act = 3)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        N = w16.shape[0]
+        y = torch.empty(M, N, dtype=BF16, device=x2.device)
+        nat.gemm(x2, w16, y, M, N, K, K, K, N, bias=bias.detach(), act=3)
+        ctx.save_for_backward(x2, y, w16)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, y, w16 = ctx.saved_tensors
+        M, K = x2.shape
+        N = w16.shape[0]
+        dpre = torch.empty(M, N, dtype=BF16, device=x2.device)
+        nat.tanh_bwd(_grad_bf16(g, N), y, dpre)
+        dx, dw = _linear_bwd(dpre, N, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, _colsum(dpre, N, M, N), None
+
+
+class MMBTEmbeddingsFn(torch.autograd.Function):
+    """ModalEmbeddings.forward (mmbt.py:84-129) and BertEmbeddingsJit.forward for the text (hf_layers.py:108-135),
+    concatenated modal-first (mmbt.py:225), in one buffer: [start token | N projected features | end token | T text].
+    The two LayerNorm + dropout passes of the reference share their parameters, so one pass over all rows is the
+    same computation."""
+
+    @staticmethod
+    def forward(ctx, feats, input_ids, start_tok, end_tok, text_type_ids, modal_type, word, pos, typ, ln_w, ln_b, proj_w, proj_b,
+                proj_w16, eps, drop):
+        B, N, D = feats.shape
+        T = input_ids.shape[1]
+        H = word.shape[1]
+        s0 = 1 if start_tok is not None else 0
+        L = N + s0 + (1 if end_tok is not None else 0)
+        S = L + T
+        dev = word.device
+        y = torch.empty(B * S, H, dtype=BF16, device=dev)
+        wd, pd, td = word.detach(), pos.detach(), typ.detach()
+        mtype = torch.full((B, 1), int(modal_type), dtype=torch.int64, device=dev)
+        ids = input_ids.contiguous()
+        seg = text_type_ids.contiguous()
+        st = start_tok.reshape(B, 1).contiguous() if start_tok is not None else None
+        en = end_tok.reshape(B, 1).contiguous() if end_tok is not None else None
+        if st is not None:
+            nat.embed_text_fwd(st, mtype, wd, pd, td, y, B, 1, S, H, 0, 0)
+        if en is not None:
+            nat.embed_text_fwd(en, mtype, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
+        nat.embed_text_fwd(ids, seg, wd, pd, td, y, B, T, S, H, L, 0)
+        f2 = feats.reshape(B * N, D)
+        if f2.dtype not in (F32, BF16):
+            f2 = f2.float()
+        f2 = f2.contiguous()
+        posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
+        nat.gemm(f2, proj_w16, y, B * N, H, D, D, D, H, bias=proj_b.detach(), coladd=td[int(modal_type)], rowtab=pd, rowidx=posidx,
+                 rowtab_ld=H, grp=(N, S - N, s0))
+        out = torch.empty(B * S, H, dtype=BF16, device=dev)
+        mean = torch.empty(B * S, dtype=F32, device=dev)
+        rstd = torch.empty(B * S, dtype=F32, device=dev)
+        nat.layernorm_fwd(y, ln_w.detach(), ln_b.detach(), out, mean, rstd, B * S, H, eps)
+        if drop[1]:
+            out2 = torch.empty_like(out)
+            nat.dropout(out, out2, drop)
+            out = out2
+        ctx.save_for_backward(ids, seg, st, en, f2, y, mean, rstd, ln_w.detach(), proj_w16)
+        ctx.meta = (B, N, T, S, L, s0, H, drop, int(modal_type), word.shape[0], pos.shape[0], typ.shape[0])
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, seg, st, en, f2, y, mean, rstd, ln_w, proj_w16 = ctx.saved_tensors
+        B, N, T, S, L, s0, H, drop, modal_type, V, P, NT = ctx.meta
+        dev = y.device
+        dy = _grad_bf16(g, H)
+        if drop[1]:
+            d2 = torch.empty_like(dy)
+            nat.dropout(dy, d2, drop)
+            dy = d2
+        dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, nat.NO_DROP, False)
+        dword = torch.zeros(V, H, dtype=F32, device=dev)
+        nat.rows_scatter_add(dpre[L:], H, B, T, S, ids, T, 0, 0, dword, H, 0)
+        if st is not None:
+            nat.rows_scatter_add(dpre, H, B, 1, S, st, 1, 0, 0, dword, H, 0)
+        if en is not None:
+            nat.rows_scatter_add(dpre[s0 + N:], H, B, 1, S, en, 1, 0, 0, dword, H, 0)
+        dpos = torch.zeros(P, H, dtype=F32, device=dev)
+        nat.rows_scatter_add(dpre, H, B, L, S, None, 0, 1, 0, dpos, H, 0)        # modal block: position = row index
+        nat.rows_scatter_add(dpre[L:], H, B, T, S, None, 0, 1, 0, dpos, H, 0)    # text: positions restart at 0
+        dtyp = torch.zeros(NT, H, dtype=F32, device=dev)
+        nat.rows_scatter_add(dpre[L:], H, B, T, S, seg, T, 0, 0, dtyp, H, 1)
+        nat.rows_scatter_add(dpre, H, B, L, S, None, 0, 0, modal_type, dtyp, H, 1)
+        dvis = dpre.view(B, S, H)[:, s0:s0 + N, :].contiguous().view(B * N, H)
+        D = f2.shape[1]
+        dproj_w = torch.empty(H, D, dtype=F32, device=dev)
+        nat.gemm(dvis, f2, dproj_w, H, D, B * N, H, D, D, a_kmajor=True, b_kmajor=True)
+        dproj_b = _colsum(dvis, H, B * N, H)
+        return (None, None, None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dproj_w, dproj_b, None, None, None)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index) over [B, C] fp32 logits (MMF `cross_entropy`, losses.py:595-602)."""
+
+    @staticmethod
+    def forward(ctx, scores, targets, ignore_index):
+        B, Cn = scores.shape
+        s = scores.float().contiguous()
+        t = targets.contiguous()
+        loss = torch.empty(1, dtype=F32, device=s.device)
+        count = torch.empty(1, dtype=F32, device=s.device)
+        nat.cross_entropy_fwd(s, t, loss, count, B, Cn, ignore_index)
+        ctx.save_for_backward(s, t, count)
+        ctx.ignore_index = ignore_index
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t, count = ctx.saved_tensors
+        B, Cn = s.shape
+        d = torch.empty(B, Cn, dtype=F32, device=s.device)
+        nat.cross_entropy_bwd(s, t, count, g.float().reshape(1).contiguous(), d, B, Cn, ctx.ignore_index)
+        return d, None, None

@@ -1,0 +1,268 @@
+"""MMBT behind MMF's model API, on the gfx950 kernels (BASELINE.json configs[0]; SURVEY.md §8 "next" row).
+
+Mirrors mmf/models/mmbt.py: `MMBTConfig` (:42-64), `ModalEmbeddings` (:67-129), `MMBTModel` (:132-324),
+`MMBTBase` (:327-444), `MMBTForClassification` (:526-563) and the registered `MMBT(BaseModel)` (:566-658):
+same constructor arguments, same `forward(sample_list) -> {"scores": [B, num_labels]}`, same parameter tree
+(`model.bert.mmbt.transformer.*`, `model.bert.mmbt.modal_encoder.*`, `model.classifier.*`), including the
+modal encoder's ALIASES of the text embedding tables and LayerNorm (:78-82), so MMF checkpoints load unmodified.
+
+Scope: `direct_features_input: true` — the modality arrives as pre-extracted `[B, N, modal_hidden_size]`
+features and the modal encoder is the identity.  The CNN / detectron encoders that produce such features in the
+reference (mmf/modules/encoders.py) sit upstream of the hot path and are out of scope; asking
+for one raises.  The pretraining head (:447-523) is not built.
+
+MI355X-first internals: the modal block (start token, projected features, end token) and the text block are
+written into ONE `[B, L+T, H]` bf16 buffer and normalised by one LayerNorm kernel (`functional.MMBTEmbeddingsFn`)
+instead of two embedding modules + `torch.cat`; the pooler's tanh lives in the GEMM epilogue.
+"""
+import torch
+from torch import nn
+
+from mmf_amd import functional as Fn
+from mmf_amd.common.registry import registry
+from mmf_amd.models.base_model import BaseModel
+from mmf_amd.modules.hf_layers import BertConfig, BertModelJit, BertPredictionHeadTransform, Linear, init_bert_weights
+from mmf_amd.utils.configuration import to_container
+from mmf_amd.utils.modeling import get_optimizer_parameters_for_bert
+
+
+class MMBTConfig:
+    """mmbt.py:42-64 — a view of the transformer config plus the modal width."""
+
+    def __init__(self, config, num_labels=None, modal_hidden_size=2048):
+        self.__dict__ = config.__dict__
+        self.modal_hidden_size = modal_hidden_size
+        if num_labels:
+            self.num_labels = num_labels
+
+
+class ModalEmbeddings(nn.Module):
+    """mmbt.py:67-129.  Holds `proj_embeddings` and aliases of the transformer's embedding tables."""
+
+    def __init__(self, config, encoder, embeddings):
+        super().__init__()
+        self.config = config
+        self.encoder = encoder
+        self.proj_embeddings = Linear(config.modal_hidden_size, config.hidden_size)
+        self.position_embeddings = embeddings.position_embeddings
+        self.token_type_embeddings = embeddings.token_type_embeddings
+        self.word_embeddings = embeddings.word_embeddings
+        self.LayerNorm = embeddings.LayerNorm
+        self.dropout_prob = config.hidden_dropout_prob
+
+
+class MMBTModel(nn.Module):
+    """mmbt.py:132-324 (encoder mode)."""
+
+    def __init__(self, config, transformer, encoder):
+        super().__init__()
+        self.is_decoder = getattr(config, "is_decoder", False)
+        if self.is_decoder:
+            raise NotImplementedError("MMBT as a decoder (mmbt.py:244-266) is not built")
+        self.num_hidden_layers = config.num_hidden_layers
+        self.transformer = transformer
+        self.modal_encoder = ModalEmbeddings(config, encoder, transformer.embeddings)
+
+    def forward(self, input_modal, input_ids, modal_start_tokens=None, modal_end_tokens=None, attention_mask=None,
+                token_type_ids=None, modal_token_type_ids=None, position_ids=None, modal_position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None):
+        if position_ids is not None or modal_position_ids is not None or inputs_embeds is not None or head_mask is not None:
+            raise NotImplementedError("explicit position ids / inputs_embeds / head_mask are not on the built MMBT path")
+        input_modal = self.modal_encoder.encoder(input_modal)
+        if input_modal.dim() == 2:
+            input_modal = input_modal.unsqueeze(1)
+        B, N = input_modal.shape[0], input_modal.shape[1]
+        L = N + (modal_start_tokens is not None) + (modal_end_tokens is not None)
+        if token_type_ids is None:
+            token_type_ids = torch.ones_like(input_ids)                                     # :213-216
+        if modal_token_type_ids is None:
+            modal_type = 0                                                                  # :117-122
+        elif isinstance(modal_token_type_ids, int):
+            modal_type = modal_token_type_ids
+        else:
+            lo, hi = int(modal_token_type_ids.min()), int(modal_token_type_ids.max())
+            if lo != hi:
+                raise NotImplementedError("per-position modal_token_type_ids: the fused modal block adds ONE type row")
+            modal_type = lo
+        emb, me = self.transformer.embeddings, self.modal_encoder
+        hidden = Fn.MMBTEmbeddingsFn.apply(
+            input_modal, input_ids, modal_start_tokens, modal_end_tokens, token_type_ids, modal_type,
+            emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+            emb.LayerNorm.weight, emb.LayerNorm.bias, me.proj_embeddings.weight, me.proj_embeddings.bias,
+            Fn.shadows.get(me.proj_embeddings.weight), emb.LayerNorm.eps, Fn.make_drop(emb.dropout_prob, self.training))
+        S = hidden.shape[1]
+        dev = hidden.device
+        if attention_mask is None:
+            am = torch.ones(B, S, dtype=torch.int64, device=dev)                            # :228-229
+        else:
+            am = torch.cat([torch.ones(B, L, dtype=torch.int64, device=dev), attention_mask.long()], dim=1)  # :232-238
+        mask_add = torch.empty(B, S, dtype=torch.float32, device=dev)
+        Fn.nat.make_additive_mask(am.contiguous(), mask_add)                                # (1 - m) * -10000, :283
+        sequence_output = self.transformer.encoder(hidden, mask_add.view(B, 1, 1, S))[0]
+        pooled_output = self.transformer.pooler(sequence_output)
+        return sequence_output, pooled_output
+
+    def get_input_embeddings(self):
+        return self.transformer.embeddings.word_embeddings
+
+
+def _build_text_config(config):
+    """TransformerEncoder's config: bert-base-uncased defaults overridden by `text_encoder.params`
+    (mmf/modules/encoders.py TransformerEncoder / mmf/utils/modeling... `build_config`)."""
+    te = to_container(config.get("text_encoder", {}) or {})
+    if te and te.get("type", "transformer") != "transformer":
+        raise NotImplementedError("text_encoder.type=%r: only the BERT transformer encoder is built" % te.get("type"))
+    params = dict(te.get("params", {}) or {})
+    params.pop("bert_model_name", None)
+    num_segments = params.pop("num_segments", 2)
+    params.pop("random_init", None)
+    return BertConfig.from_dict(params), num_segments
+
+
+def _build_modal_encoder(config):
+    me = to_container(config.get("modal_encoder", {}) or {})
+    kind = me.get("type", "identity") if me else "identity"
+    if not config.get("direct_features_input", False) or kind not in ("identity", None):
+        raise NotImplementedError(
+            "MMBT modal_encoder type=%r with direct_features_input=%r: only pre-extracted features through the identity "
+            "encoder are on the built path (the CNN / detectron feature extractors are out of scope, SURVEY.md §8)"
+            % (kind, config.get("direct_features_input", False)))
+    return nn.Identity()
+
+
+class MMBTBase(nn.Module):
+    """mmbt.py:327-444 (+ MultiModalEncoderBase, mmf/modules/encoders.py)."""
+
+    def __init__(self, config, *args, **kwargs):
+        super().__init__()
+        self.config = config
+        self._is_direct_features_input = config.get("direct_features_input", False)
+        self.build()
+
+    def build(self):
+        self._encoder_config, self.num_max_segment = _build_text_config(self.config)
+        modal_encoder = _build_modal_encoder(self.config)
+        self._mmbt_config = MMBTConfig(self._encoder_config, num_labels=self.config.num_labels,
+                                       modal_hidden_size=self.config.modal_hidden_size)
+        self.use_modal_start_token = self.config.use_modal_start_token
+        self.use_modal_end_token = self.config.use_modal_end_token
+        self.mmbt = MMBTModel(self._mmbt_config, BertModelJit(self._encoder_config), modal_encoder)
+
+    @property
+    def encoder_config(self):
+        return self._encoder_config
+
+    def extract_modal_end_token(self, sample_list):
+        """mmbt.py:346-363: the last real text token becomes the modal end token; text shifts left by one."""
+        gather_index = sample_list["input_mask"].sum(1, keepdim=True) - 1
+        modal_end_token = torch.gather(sample_list["input_ids"], 1, gather_index).squeeze(1).clone().detach()
+        batch_size = sample_list["input_ids"].size(0)
+        device = sample_list["input_ids"].device
+        sample_list["input_ids"] = torch.cat([sample_list["input_ids"][:, 1:], sample_list["input_ids"][:, -1:]], dim=1)
+        sample_list["input_mask"] = torch.cat(
+            [sample_list["input_mask"][:, 1:], torch.zeros([batch_size, 1], dtype=torch.long, device=device)], dim=1)
+        return modal_end_token
+
+    def forward(self, sample_list):
+        if self._is_direct_features_input:
+            input_modal = sample_list["input_modal"] if "input_modal" in sample_list else sample_list["image_feature_0"]
+        else:
+            input_modal = sample_list["image"]
+        modal_start_token = None
+        if self.use_modal_start_token:
+            modal_start_token = sample_list["input_ids"][:, 0].clone().detach()
+        modal_end_token = None
+        if self.use_modal_end_token:
+            modal_end_token = self.extract_modal_end_token(sample_list)
+        if "modal_token_type_ids" in sample_list:
+            modal_token_type_ids = sample_list["modal_token_type_ids"]
+        else:
+            # mmbt.py:385-410 — the reference compares device tensors in Python (`if max_id == min_id`), i.e. it also
+            # reads the segment range back to the host here.
+            token_value = 0
+            segment_ids = sample_list["segment_ids"]
+            max_id, min_id = int(segment_ids.max()), int(segment_ids.min())
+            if max_id == min_id:
+                if max_id == 0:
+                    token_value = 1
+            else:
+                max_segment = self.num_max_segment - 1
+                if max_id != max_segment:
+                    token_value = max_segment
+            modal_token_type_ids = token_value
+        if input_modal.dim() == 2:
+            input_modal = input_modal.unsqueeze(dim=1)
+        return self.mmbt(input_modal, input_ids=sample_list["input_ids"], modal_start_tokens=modal_start_token,
+                         modal_end_tokens=modal_end_token, attention_mask=sample_list["input_mask"],
+                         token_type_ids=sample_list["segment_ids"], modal_token_type_ids=modal_token_type_ids)
+
+
+class MMBTForClassification(nn.Module):
+    """mmbt.py:526-563."""
+
+    def __init__(self, config, *args, **kwargs):
+        super().__init__()
+        self.config = config
+        self.bert = MMBTBase(config, *args, **kwargs)
+        self.encoder_config = self.bert.encoder_config
+        self.num_labels = self.config.num_labels
+        self.output_hidden_states = self.encoder_config.output_hidden_states
+        self.output_attentions = self.encoder_config.output_attentions
+        if self.output_attentions:
+            raise NotImplementedError("output_attentions: the fused attention kernel never materialises the probabilities")
+        self.fused_feature_only = self.config.get("fused_feature_only", False)
+        self.dropout_prob = self.encoder_config.hidden_dropout_prob
+        self.classifier = nn.Sequential(
+            BertPredictionHeadTransform(self.encoder_config),
+            Linear(self.encoder_config.hidden_size, self.config.num_labels),
+        )
+        self.classifier.apply(lambda m: init_bert_weights(m, self.encoder_config.initializer_range))
+
+    def forward(self, sample_list):
+        module_output = self.bert(sample_list)
+        pooled_output = module_output[1]
+        output = {}
+        drop = Fn.make_drop(self.dropout_prob, self.training)
+        if drop[1]:
+            pooled_output = Fn.DropoutFn.apply(pooled_output, drop)
+        if self.fused_feature_only:
+            output["fused_feature"] = self.classifier[0](pooled_output)
+            return output
+        hidden = self.classifier[0](pooled_output)
+        logits = self.classifier[1](hidden, out_f32=True)
+        output["scores"] = logits.contiguous().view(-1, self.num_labels)
+        return output
+
+
+@registry.register_model("mmbt")
+class MMBT(BaseModel):
+    """mmbt.py:566-658."""
+
+    def __init__(self, config, *args, **kwargs):
+        super().__init__(config)
+
+    @classmethod
+    def config_path(cls):
+        return "configs/models/mmbt/pretrain.yaml"
+
+    def build(self):
+        if self.config.get("training_head_type", "pretraining") == "pretraining":
+            raise NotImplementedError("MMBTForPreTraining (mmbt.py:447-523) is a later milestone")
+        self.model = MMBTForClassification(self.config)
+        if self.config.get("freeze_complete_base", False) or self.config.get("freeze_text", False):
+            for p in self.model.bert.mmbt.transformer.parameters():
+                p.requires_grad = False
+        if self.config.get("freeze_complete_base", False) or self.config.get("freeze_modal", False):
+            for p in self.model.bert.mmbt.modal_encoder.parameters():
+                p.requires_grad = False
+
+    @classmethod
+    def format_state_key(cls, key):
+        return (key.replace("base.bert", "model.bert").replace("base.cls", "model.cls")
+                .replace("base.classifier", "model.classifier"))
+
+    def forward(self, sample_list):
+        return self.model(sample_list)
+
+    def get_optimizer_parameters(self, config):
+        return get_optimizer_parameters_for_bert(self.model, config)

@@ -135,11 +135,7 @@ class VisualBERTForClassification(nn.Module):
             index_to_gather = input_mask.sum(1) - 2
             pooled = Fn.GatherRowsFn.apply(sequence_output, index_to_gather, drop)
         else:
-            pooled = pooled_output.to(torch.bfloat16)
-            if drop[1]:
-                d = torch.empty_like(pooled)
-                Fn.nat.dropout(pooled.contiguous(), d, drop)
-                pooled = d
+            pooled = Fn.DropoutFn.apply(pooled_output, drop) if drop[1] else pooled_output
         hidden = self.classifier[0](pooled)
         logits = self.classifier[1](hidden, out_f32=True)
         output_dict["scores"] = logits.contiguous().view(-1, self.num_labels)

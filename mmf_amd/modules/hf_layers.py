@@ -246,8 +246,60 @@ class BertPooler(nn.Module):
         self.dense = Linear(config.hidden_size, config.hidden_size)
 
     def forward(self, hidden_states):
-        first = hidden_states[:, 0]
-        return torch.tanh(self.dense(first, out_f32=True))
+        # row 0 of every sample (gather kernel), then dense + tanh in one GEMM epilogue
+        B = hidden_states.shape[0]
+        index = torch.zeros(B, dtype=torch.int64, device=hidden_states.device)
+        first = Fn.GatherRowsFn.apply(hidden_states, index, Fn.nat.NO_DROP)
+        return Fn.LinearTanhFn.apply(first, self.dense.weight, self.dense.bias, Fn.shadows.get(self.dense.weight))
+
+
+class BertEmbeddingsJit(nn.Module):
+    """HF BertEmbeddings parameters (hf_layers.py:98-135).  `forward` is the text-only embedding stage."""
+
+    def __init__(self, config):
+        super().__init__()
+        H = config.hidden_size
+        self.word_embeddings = nn.Embedding(config.vocab_size, H)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, H)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, H)
+        self.LayerNorm = LayerNorm(H, eps=config.layer_norm_eps)
+        self.dropout_prob = config.hidden_dropout_prob
+
+    def forward(self, input_ids, token_type_ids=None, position_ids=None, inputs_embeds=None):
+        if position_ids is not None or inputs_embeds is not None:
+            raise NotImplementedError("explicit position_ids / inputs_embeds are not on the built paths")
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        z = self.word_embeddings.weight.new_zeros(1, self.word_embeddings.weight.shape[1])
+        return Fn.VisioLinguisticEmbeddingsFn.apply(
+            input_ids, token_type_ids, None, None, self.word_embeddings.weight, self.position_embeddings.weight,
+            self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias, z, z, z, z, None,
+            self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training))
+
+
+class BertModelJit(nn.Module):
+    """Parameter tree of the reference's BertModelJit (hf_layers.py:358-452): embeddings / encoder / pooler."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embeddings = BertEmbeddingsJit(config)
+        self.encoder = BertEncoderJit(config)
+        self.pooler = BertPooler(config)
+        self.apply(lambda m: init_bert_weights(m, config.initializer_range))
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None):
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        am = attention_mask.contiguous().long()
+        mask_add = torch.empty(am.shape, dtype=torch.float32, device=am.device)
+        Fn.nat.make_additive_mask(am, mask_add)
+        h = self.embeddings(input_ids, token_type_ids)
+        seq = self.encoder(h, mask_add.view(am.shape[0], 1, 1, am.shape[1]))[0]
+        return seq, self.pooler(seq)
 
 
 class BertPredictionHeadTransform(nn.Module):

@@ -84,3 +84,19 @@ class LogitBinaryCrossEntropy(nn.Module):
 
     def forward(self, sample_list, model_output):
         return Fn.LogitBCEFn.apply(model_output["scores"], sample_list["targets"])
+
+
+@registry.register_loss("cross_entropy")
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss(**params)(scores, targets)   (losses.py:595-602).  HIP kernels; supports
+    `ignore_index` and mean reduction (the reference's defaults)."""
+
+    def __init__(self, **params):
+        super().__init__()
+        extra = set(params) - {"ignore_index", "reduction"}
+        if extra or params.get("reduction", "mean") != "mean":
+            raise NotImplementedError("cross_entropy: only ignore_index / reduction='mean' are built (got %s)" % sorted(params))
+        self.ignore_index = int(params.get("ignore_index", -100))
+
+    def forward(self, sample_list, model_output):
+        return Fn.CrossEntropyFn.apply(model_output["scores"], sample_list["targets"], self.ignore_index)

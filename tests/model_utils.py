@@ -40,3 +40,34 @@ def sample_to(sample, device):
         else:
             out[k] = v
     return out
+
+
+def mmbt_model_config(cfg, **over):
+    """MMF model_config.mmbt (configs/models/mmbt/defaults.yaml + classification / direct features)."""
+    d = dict(
+        model="mmbt", training_head_type="classification", bert_model_name=None, direct_features_input=True,
+        freeze_text=False, freeze_modal=False, freeze_complete_base=False, finetune_lr_multiplier=1, fused_feature_only=False,
+        modal_hidden_size=cfg["modal_hidden_size"], text_hidden_size=cfg["hidden_size"], num_labels=cfg["num_labels"],
+        modal_encoder=dict(type="identity", params={}), use_modal_start_token=cfg.get("use_modal_start_token", True),
+        use_modal_end_token=cfg.get("use_modal_end_token", True),
+        text_encoder=dict(type="transformer", params=dict(
+            num_segments=cfg.get("num_segments", 2), bert_model_name=None, hidden_size=cfg["hidden_size"],
+            num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+            intermediate_size=cfg["intermediate_size"], vocab_size=cfg["vocab_size"],
+            max_position_embeddings=cfg["max_position_embeddings"], type_vocab_size=cfg.get("type_vocab_size", 2),
+            hidden_dropout_prob=cfg.get("hidden_dropout_prob", 0.1),
+            attention_probs_dropout_prob=cfg.get("attention_probs_dropout_prob", 0.1), layer_norm_eps=cfg["layer_norm_eps"],
+            output_attentions=False, output_hidden_states=False)),
+        losses=[dict(type="cross_entropy")])
+    d.update(over)
+    return Config(d)
+
+
+def build_mmbt(cfg, sd=None, shared=None, device="cuda", **over):
+    model = build_model(mmbt_model_config(cfg, **over))
+    if sd is not None:
+        full = {"model." + k: v for k, v in sd.items()}
+        for alias, src in (shared or {}).items():
+            full["model." + alias] = sd[src]
+        model.load_state_dict(full, strict=True)
+    return model.to(device)

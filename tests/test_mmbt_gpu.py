@@ -1,0 +1,170 @@
+"""MMBT on the HIP path (GPU): the kernels MMBT adds (tanh GEMM epilogue, tanh backward, the generalized
+text-embedding kernel, cross-entropy) against plain PyTorch fp32, and the registered `mmbt` model against the
+fixture recorded from the real reference (tests/golden/mmbt_small64.npz) and the CPU oracle.
+Tolerance: BASELINE.json north_star, 5e-2 for the bf16 path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmbt_oracle as O
+from tests.golden_utils import load_mmbt_case
+from tests.model_utils import build_mmbt, sample_to
+from tests.test_kernels_gpu import close, nat, rnd, DEV
+from mmf_amd.common.sample import SampleList
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-2
+
+
+def rel_err(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_gemm_tanh_epilogue_and_tanh_backward():
+    M, N, K = 96, 768, 768
+    A = rnd(M, K, scale=0.5); W = rnd(N, K, scale=0.05); bias = rnd(N, dtype=torch.float32)
+    Y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(A, W, Y, M, N, K, K, K, N, bias=bias, act=3)
+    ref = torch.tanh(A.float() @ W.float().t() + bias)
+    close(Y, ref, 1e-2, 1e-2, "tanh epilogue")
+    dy = rnd(M, N); dx = torch.empty_like(dy)
+    nat().tanh_bwd(dy, Y, dx)
+    close(dx, dy.float() * (1 - Y.float() ** 2), 1e-2, 1e-3, "tanh bwd")
+    # act = 4: GEMM output times (1 - aux^2)
+    Z = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(A, W, Z, M, N, K, K, K, N, act=4, aux=Y)
+    close(Z, (A.float() @ W.float().t()) * (1 - Y.float() ** 2), 1e-2, 2e-2, "(1-aux^2) epilogue")
+
+
+def test_embed_text_row_and_position_offsets():
+    B, T, S, H, V = 3, 5, 16, 256, 500
+    ids = torch.randint(0, V, (B, T), device=DEV); seg = torch.randint(0, 2, (B, T), device=DEV)
+    word = rnd(V, H, dtype=torch.float32); pos = rnd(32, H, dtype=torch.float32); typ = rnd(2, H, dtype=torch.float32)
+    y = torch.zeros(B * S, H, dtype=torch.bfloat16, device=DEV)
+    nat().embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H, 7, 3)
+    ref = word[ids] + pos[torch.arange(T, device=DEV) + 3][None] + typ[seg]
+    y3 = y.view(B, S, H)
+    close(y3[:, 7:7 + T], ref, 1e-2, 1e-2, "embed rows 7.., positions 3..")
+    assert float(y3[:, :7].abs().max()) == 0 and float(y3[:, 7 + T:].abs().max()) == 0
+    # single-token form used for the modal start / end tokens
+    tok = torch.randint(0, V, (B, 1), device=DEV); mt = torch.ones(B, 1, dtype=torch.int64, device=DEV)
+    nat().embed_text_fwd(tok, mt, word, pos, typ, y, B, 1, S, H, 15, 15)
+    close(y3[:, 15], word[tok[:, 0]] + pos[15] + typ[1], 1e-2, 1e-2, "end token row")
+
+
+@pytest.mark.parametrize("B,C", [(16, 2), (64, 3129), (5, 7)])
+def test_cross_entropy_forward_backward(B, C):
+    import mmf_amd.functional as Fn
+    s = rnd(B, C, dtype=torch.float32, scale=3.0).requires_grad_(True)
+    t = torch.randint(0, C, (B,), device=DEV)
+    t[B // 2] = -100
+    loss = Fn.CrossEntropyFn.apply(s, t, -100)
+    sr = s.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(sr, t, ignore_index=-100)
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    (loss * 1.7).backward(); (ref * 1.7).backward()
+    close(s.grad, sr.grad, 1e-4, 1e-6, "dlogits")
+    assert float(s.grad[B // 2].abs().max()) == 0
+
+
+def test_dropout_fn_is_differentiable_with_the_same_mask():
+    import mmf_amd.functional as Fn
+    x = rnd(64, 768).requires_grad_(True)
+    drop = nat().drop_cfg(0.1, 1234)
+    y = Fn.DropoutFn.apply(x, drop)
+    y.float().sum().backward()
+    kept = y != 0
+    assert 0.85 < kept.float().mean().item() < 0.95
+    assert torch.equal(x.grad != 0, kept | ((x.detach() == 0) & (x.grad != 0)))
+    close(x.grad[kept], torch.full_like(x.grad[kept], 1 / 0.9), 1e-2, 1e-3, "dropout grad scale")
+
+
+def test_mmbt_golden_forward_loss_and_gradients():
+    z, case, cfg, sd, sample = load_mmbt_case()
+    model = build_mmbt(cfg, sd, O.SHARED)
+    model.eval()
+    seq = {}
+    mm = model.model.bert.mmbt
+    hook = mm.register_forward_hook(lambda m, i, o: seq.update(seq=o[0], pooled=o[1]))
+    out = model(SampleList(sample_to(sample, "cuda")))
+    hook.remove()
+    np.testing.assert_allclose(out["scores"].detach().float().cpu().numpy(), z["scores"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(seq["seq"].detach().float().cpu().numpy(), z["sequence_output"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(seq["pooled"].detach().float().cpu().numpy(), z["pooled_output"], rtol=TOL, atol=TOL)
+    (key, loss), = out["losses"].items()
+    assert key == "train/hateful_memes/cross_entropy"
+    assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    loss.sum().backward()
+    params = dict(model.named_parameters())
+    worst = {}
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        gname = str(gname)
+        p = params[gname]
+        assert p.grad is not None, gname
+        gn = float(p.grad.double().norm())
+        if gname.endswith("self.key.bias"):   # identically zero in exact arithmetic: noise on both sides
+            qn = float(params[gname.replace("key.bias", "query.bias")].grad.double().norm())
+            assert gn <= TOL * qn + 1e-6, (gname, gn, qn)
+            continue
+        worst[gname] = abs(gn - norm) / norm
+        full = "grad::" + gname
+        if full in z.files:
+            assert rel_err(p.grad, torch.from_numpy(z[full])) <= TOL, gname
+    bad = {k: round(v, 4) for k, v in worst.items() if v > TOL}
+    assert not bad, bad
+
+
+def test_mmbt_all_gradients_match_oracle_without_modal_tokens():
+    """Second layout (no start / end token, ragged masks, all-ones segments) against the pinned CPU oracle,
+    every parameter's full gradient."""
+    z, case, cfg, sd, sample = load_mmbt_case()
+    cfg = dict(cfg, use_modal_start_token=False, use_modal_end_token=False)
+    sample = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items()}
+    sample["segment_ids"] = torch.ones_like(sample["segment_ids"])   # -> modal token type 0 (mmbt.py:398-404)
+    model = build_mmbt(cfg, sd, O.SHARED)
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mmbt_forward(sdr, cfg, {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items()})
+    assert float((out["scores"].float().cpu() - ref["scores"]).abs().max()) <= TOL
+    (key, loss), = out["losses"].items()
+    ref_loss = O.cross_entropy(ref["scores"], sample["targets"])
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    loss.sum().backward(); ref_loss.backward()
+    params = dict(model.named_parameters())
+    errs = {}
+    for k, v in sdr.items():
+        p = params["model." + k]
+        assert p.grad is not None and v.grad is not None, k
+        if k.endswith("self.key.bias"):
+            continue
+        errs[k] = rel_err(p.grad, v.grad)
+    bad = {k: round(e, 4) for k, e in errs.items() if e > TOL}
+    assert not bad, bad
+
+
+def test_mmbt_training_step_is_seed_reproducible_and_updates():
+    import mmf_amd
+    from mmf_amd.modules.optimizers import AdamW
+    z, case, cfg, sd, sample = load_mmbt_case()
+    model = build_mmbt(cfg, sd, O.SHARED)
+    model.train()
+    batch = sample_to(sample, "cuda")
+    torch.manual_seed(3)
+    a = model(SampleList(dict(batch)))["scores"].float().clone()
+    torch.manual_seed(3)
+    b = model(SampleList(dict(batch)))["scores"].float().clone()
+    assert torch.equal(a, b)
+    from mmf_amd.utils.configuration import Config
+    full = Config(model="mmbt", optimizer=dict(params=dict(lr=1e-3)), model_config=dict(mmbt=model.config))
+    opt = AdamW(model.get_optimizer_parameters(full), lr=1e-3)
+    losses = []
+    for _ in range(8):
+        out = model(SampleList(dict(batch)))
+        loss = sum(v.sum() for v in out["losses"].values())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses

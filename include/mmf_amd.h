@@ -29,6 +29,12 @@ extern "C" {
 
 /* ---- library ------------------------------------------------------------------------------ */
 int mmf_amd_abi_version(void);
+/* Integer tuning knobs for on-hardware sweeps (0 = built-in heuristic).  Not part of the reference's interface. */
+enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
+       MMF_TUN_LN_BWD_GRID = 1,    /* workgroups of mmf_layernorm_bwd (<= MMF_LN_BWD_MAX_GRID) */
+       MMF_TUN_COUNT = 8 };
+int mmf_amd_set_tunable(int which, int value);
+int mmf_amd_get_tunable(int which);
 const char* mmf_amd_last_error(void);
 /* Name of the gfx target the device code was compiled for ("gfx950"). */
 const char* mmf_amd_target(void);
@@ -161,11 +167,13 @@ int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word
  * few_buckets != 0: the table has `nbuckets` rows and (almost) every index is 0 or 1 (token-type tables,
  * position_ids_visual == 0): deterministic two-stage column sums through `ws`
  * (mmf_rows_scatter_add_ws_floats(H) floats) instead of atomics.
+ * skip_bucket >= 0: rows that map to that bucket are dropped — nn.Embedding(padding_idx=pad_token_id) keeps the
+ * [PAD] row's gradient at zero (HF BertEmbeddings word_embeddings; reached from embeddings.py:309).
  */
 int mmf_rows_scatter_add_ws_floats(int H);
 int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, const int64_t* idx, int idx_ld,
                          int per_pos, int idx_base, float* out, int H, int few_buckets, int nbuckets, float* ws,
-                         void* stream);
+                         int skip_bucket, void* stream);
 
 /* ---- small row utilities ----------------------------------------------------------------------
  * gather: out[b] = dropout(x[b*S + index[b]]), bf16 rows of H (visual_bert.py:389-400, the

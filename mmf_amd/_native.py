@@ -253,13 +253,14 @@ def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
            "mmf_embed_text_fwd")
 
 
-def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, few_buckets):
+def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, few_buckets, skip_bucket=-1):
     _req(x, torch.bfloat16, "x"); _req(idx, torch.int64, "idx"); _req(out, torch.float32, "out")
     ws = None
     if few_buckets:
         ws = torch.empty(lib().mmf_rows_scatter_add_ws_floats(H), dtype=torch.float32, device=out.device)
     _check(lib().mmf_rows_scatter_add(_p(x), ld, nb, rpb, bstride, _p(idx), idx_ld, int(per_pos), idx_base, _p(out), H,
-                                      int(few_buckets), int(out.shape[0]), _p(ws), _stream()), "mmf_rows_scatter_add")
+                                      int(few_buckets), int(out.shape[0]), _p(ws), int(-1 if skip_bucket is None else skip_bucket), _stream()),
+           "mmf_rows_scatter_add")
 
 
 def gather_rows(x, index, out, B, S, H, drop=NO_DROP):
@@ -330,6 +331,13 @@ def tanh_bwd(dy, y, dx):
     for t, nme in ((dy, "dy"), (y, "y"), (dx, "dx")):
         _req(t, torch.bfloat16, nme)
     _check(lib().mmf_tanh_bwd_bf16(_p(dy), _p(y), _p(dx), C.c_int64(dy.numel()), _stream()), "mmf_tanh_bwd_bf16")
+
+
+TUN_SPLITK_FORCE, TUN_LN_BWD_GRID = 0, 1
+
+
+def set_tunable(which, value):
+    _check(lib().mmf_amd_set_tunable(int(which), int(value)), "mmf_amd_set_tunable")
 
 
 def make_additive_mask(mask, out):

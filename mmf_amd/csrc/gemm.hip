@@ -278,11 +278,14 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
 extern "C" int mmf_gemm_splitk_splits(int M, int N, int K) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int nk_all = (K + BK - 1) / BK;
-    if (tiles >= 256 || nk_all < 16 || (N % 4) != 0) return 1;
-    // minimise (rounds of 256 CUs) / splits plus a slab-traffic penalty per split
+    if (tiles >= 512 || nk_all < 16 || (N % 4) != 0) return 1;
+    if (const int f = mmf_amd_get_tunable(MMF_TUN_SPLITK_FORCE)) return f < 1 ? 1 : (f > nk_all / 2 ? nk_all / 2 : f);
+    // Two workgroups are resident per CU (512 slots).  Cost in k-tile units: rounds x k-tiles per workgroup, plus ~1.5
+    // k-tiles per split for writing and re-reading one more fp32 slab (fitted to tools/micro_sweep.py on MI355X:
+    // qkv 2304x768 -> 4, out 768x768 -> 8, ffn 3072x768 -> 3).
     int best = 1; double bc = 1e30;
     for (int sp = 1; sp <= 16 && sp * 8 <= nk_all; ++sp) {
-        const double c = (double)((tiles * sp + 255) / 256) / sp + 0.03 * sp;
+        const double c = (double)((tiles * sp + 511) / 512) * ((nk_all + sp - 1) / sp) + 1.5 * sp;
         if (c < bc - 1e-9) { bc = c; best = sp; }
     }
     return best;

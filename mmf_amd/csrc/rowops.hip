@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // LayerNorm backward (+ dropout backward of the producing Linear, + column-sum partials)
 // partials layout: [gridDim.x][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias
 // ------------------------------------------------------------------------------------------------
-constexpr int LNB_GRID = 128;   // workgroups of 16 waves (2048 waves in flight); one partial row per workgroup
+constexpr int LNB_GRID = 128;       // default workgroups (16 waves each); one partial row per workgroup
+constexpr int LNB_MAX_GRID = 512;   // the workspace is sized for this many (MMF_TUN_LN_BWD_GRID may raise the grid)
 constexpr int LNB_WAVES = 16;
 
 template <int NCH>
@@ -87,34 +88,51 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const bf16* __re
         ag[c] = ab[c] = al[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         gm[c] = (COL_OF(c) < H) ? load4(gamma + COL_OF(c)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
-        const float mu = mean[row], rs = rstd[row];
+    // software-pipelined over this wave's rows: the next row's loads are in flight during the reductions of the current one
+    const int rstep = gridDim.x * LNB_WAVES;
+    int row = blockIdx.x * LNB_WAVES + wave;
+    bf16x4 xr[NCH], dr_[NCH];
+    float mu = 0.f, rs = 0.f;
+    auto fetch = [&](int r) {
+        if (r < rows) {
+            mu = mean[r]; rs = rstd[r];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (COL_OF(c) < H) {
+                    xr[c] = *reinterpret_cast<const bf16x4*>(x + (size_t)r * H + COL_OF(c));
+                    dr_[c] = *reinterpret_cast<const bf16x4*>(dy + (size_t)r * H + COL_OF(c));
+                }
+        }
+    };
+    fetch(row);
+    for (; row < rows; row += rstep) {
         f32x4 xh[NCH], g[NCH];
         float s1 = 0.f, s2 = 0.f;
+        const float rs_c = rs;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             xh[c] = g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (COL_OF(c) < H) {
-                const f32x4 xv = load4(x + (size_t)row * H + COL_OF(c));
-                const f32x4 dv = load4(dy + (size_t)row * H + COL_OF(c));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    xh[c][i] = (xv[i] - mu) * rs;
-                    g[c][i] = dv[i] * gm[c][i];
+                    const float xv = (float)xr[c][i], dv = (float)dr_[c][i];
+                    xh[c][i] = (xv - mu) * rs_c;
+                    g[c][i] = dv * gm[c][i];
                     s1 += g[c][i];
                     s2 += g[c][i] * xh[c][i];
-                    ag[c][i] += dv[i] * xh[c][i];
-                    ab[c][i] += dv[i];
+                    ag[c][i] += dv * xh[c][i];
+                    ab[c][i] += dv;
                 }
             }
         }
+        fetch(row + rstep);
         const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
             if (COL_OF(c) < H) {
                 f32x4 d;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i] = rs * (g[c][i] - c1 - xh[c][i] * c2);
+                for (int i = 0; i < 4; ++i) d[i] = rs_c * (g[c][i] - c1 - xh[c][i] * c2);
                 store4(dx + (size_t)row * H + COL_OF(c), d);
                 if (dlin) {
                     const f32x4 sc = drop_scale4(drop_key(drop), (uint32_t)row * (uint32_t)H + (uint32_t)COL_OF(c), drop.thr16, drop.scale);
@@ -202,12 +220,13 @@ DEVI int bucket_of(const int64_t* idx, int idx_ld, int per_pos, int idx_base, in
 
 __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                   const int64_t* __restrict__ idx, int idx_ld, int per_pos,
-                                                                  int idx_base, float* __restrict__ out, int H) {
+                                                                  int idx_base, float* __restrict__ out, int H, int skip) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= nb * rpb) return;
     const int b = r / rpb, i = r - b * rpb;
     const int bk = bucket_of(idx, idx_ld, per_pos, idx_base, b, i);
+    if (bk == skip) return;
     const bf16* xr = x + ((size_t)b * bstride + i) * ld;
     float* o = out + (size_t)bk * H;
     for (int col = lane * 4; col < H; col += 256) {
@@ -640,7 +659,7 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
     return 0;
 }
 
-int mmf_layernorm_bwd_ws_floats(int H) { return LNB_GRID * 3 * H; }
+int mmf_layernorm_bwd_ws_floats(int H) { return LNB_MAX_GRID * 3 * H; }
 
 int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                       void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, float* dgamma,
@@ -650,7 +669,8 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     MMF_CHECK_ARG(drop_thr16 == 0 || dlin, "layernorm_bwd: dropout needs dlin");
     hipStream_t s = (hipStream_t)stream;
     DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
-    const int grid = grid_for(rows, LNB_WAVES, LNB_GRID);
+    const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
+    const int grid = grid_for(rows, LNB_WAVES, tg > 0 ? (tg > LNB_MAX_GRID ? LNB_MAX_GRID : tg) : LNB_GRID);
     const int nch = (H + 255) / 256;
     const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
     switch (nch) {
@@ -678,8 +698,10 @@ int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word
 
 int mmf_rows_scatter_add_ws_floats(int H) { return FEW_GROUPS * 2 * H; }
 int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, const int64_t* idx, int idx_ld, int per_pos,
-                         int idx_base, float* out, int H, int few_buckets, int nbuckets, float* ws, void* stream) {
+                         int idx_base, float* out, int H, int few_buckets, int nbuckets, float* ws, int skip_bucket,
+                         void* stream) {
     MMF_CHECK_ARG(x && out, "rows_scatter_add: null operand");
+    MMF_CHECK_ARG(!(few_buckets && skip_bucket >= 0), "rows_scatter_add: skip_bucket is for the atomic (large-table) form");
     MMF_CHECK_ARG(nb > 0 && rpb > 0 && (H % 4) == 0 && (ld % 4) == 0, "rows_scatter_add: bad shape");
     const int total = nb * rpb;
     if (few_buckets) {
@@ -692,7 +714,7 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
                            (hipStream_t)stream, ws, groups, H, nbuckets, out);
     } else {
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                           ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H);
+                           ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, skip_bucket);
     }
     MMF_CHECK_LAUNCH();
     return 0;

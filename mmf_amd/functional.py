@@ -459,7 +459,7 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b,
-                proj_w16, eps, drop):
+                proj_w16, eps, drop, pad_idx=None):
         B, T = input_ids.shape
         H = word.shape[1]
         R = 0 if feats is None else feats.shape[1]
@@ -491,6 +491,7 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             out = out2
         ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16)
         ctx.meta = (B, T, R, S, H, drop, word.shape[0], pos.shape[0], typ.shape[0], typ_vis.shape[0], pos_vis.shape[0])
+        ctx.pad_idx = -1 if pad_idx is None else int(pad_idx)
         return out.view(B, S, H)
 
     @staticmethod
@@ -505,7 +506,7 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             dy = d2
         dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, nat.NO_DROP, False)
         dword = torch.zeros(V, H, dtype=F32, device=dev)
-        nat.rows_scatter_add(dpre, H, B, T, S, ids, T, 0, 0, dword, H, 0)
+        nat.rows_scatter_add(dpre, H, B, T, S, ids, T, 0, 0, dword, H, 0, ctx.pad_idx)   # padding_idx rows get no gradient
         dpos = torch.zeros(P, H, dtype=F32, device=dev)
         nat.rows_scatter_add(dpre, H, B, T, S, None, 0, 1, 0, dpos, H, 0)
         dtyp = torch.zeros(NT, H, dtype=F32, device=dev)
@@ -522,7 +523,7 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             dproj_w = torch.empty(H, D, dtype=F32, device=dev)
             nat.gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D, a_kmajor=True, b_kmajor=True)
             dproj_b = _colsum(dvis, H, B * R, H)
-        return (None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, None, None, None)
+        return (None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -631,7 +632,7 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, input_ids, start_tok, end_tok, text_type_ids, modal_type, word, pos, typ, ln_w, ln_b, proj_w, proj_b,
-                proj_w16, eps, drop):
+                proj_w16, eps, drop, pad_idx=None):
         B, N, D = feats.shape
         T = input_ids.shape[1]
         H = word.shape[1]
@@ -668,6 +669,7 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
             out = out2
         ctx.save_for_backward(ids, seg, st, en, f2, y, mean, rstd, ln_w.detach(), proj_w16)
         ctx.meta = (B, N, T, S, L, s0, H, drop, int(modal_type), word.shape[0], pos.shape[0], typ.shape[0])
+        ctx.pad_idx = -1 if pad_idx is None else int(pad_idx)
         return out.view(B, S, H)
 
     @staticmethod
@@ -682,11 +684,11 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
             dy = d2
         dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, nat.NO_DROP, False)
         dword = torch.zeros(V, H, dtype=F32, device=dev)
-        nat.rows_scatter_add(dpre[L:], H, B, T, S, ids, T, 0, 0, dword, H, 0)
+        nat.rows_scatter_add(dpre[L:], H, B, T, S, ids, T, 0, 0, dword, H, 0, ctx.pad_idx)
         if st is not None:
-            nat.rows_scatter_add(dpre, H, B, 1, S, st, 1, 0, 0, dword, H, 0)
+            nat.rows_scatter_add(dpre, H, B, 1, S, st, 1, 0, 0, dword, H, 0, ctx.pad_idx)
         if en is not None:
-            nat.rows_scatter_add(dpre[s0 + N:], H, B, 1, S, en, 1, 0, 0, dword, H, 0)
+            nat.rows_scatter_add(dpre[s0 + N:], H, B, 1, S, en, 1, 0, 0, dword, H, 0, ctx.pad_idx)
         dpos = torch.zeros(P, H, dtype=F32, device=dev)
         nat.rows_scatter_add(dpre, H, B, L, S, None, 0, 1, 0, dpos, H, 0)        # modal block: position = row index
         nat.rows_scatter_add(dpre[L:], H, B, T, S, None, 0, 1, 0, dpos, H, 0)    # text: positions restart at 0
@@ -698,7 +700,7 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
         dproj_w = torch.empty(H, D, dtype=F32, device=dev)
         nat.gemm(dvis, f2, dproj_w, H, D, B * N, H, D, D, a_kmajor=True, b_kmajor=True)
         dproj_b = _colsum(dvis, H, B * N, H)
-        return (None, None, None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dproj_w, dproj_b, None, None, None)
+        return (None, None, None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dproj_w, dproj_b, None, None, None, None)
 
 
 class CrossEntropyFn(torch.autograd.Function):

@@ -89,7 +89,8 @@ class MMBTModel(nn.Module):
             input_modal, input_ids, modal_start_tokens, modal_end_tokens, token_type_ids, modal_type,
             emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
             emb.LayerNorm.weight, emb.LayerNorm.bias, me.proj_embeddings.weight, me.proj_embeddings.bias,
-            Fn.shadows.get(me.proj_embeddings.weight), emb.LayerNorm.eps, Fn.make_drop(emb.dropout_prob, self.training))
+            Fn.shadows.get(me.proj_embeddings.weight), emb.LayerNorm.eps, Fn.make_drop(emb.dropout_prob, self.training),
+            emb.word_embeddings.padding_idx)
         S = hidden.shape[1]
         dev = hidden.device
         if attention_mask is None:

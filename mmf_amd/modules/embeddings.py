@@ -16,7 +16,7 @@ class BertVisioLinguisticEmbeddings(nn.Module):
         super().__init__()
         H = config.hidden_size
         # HF BertEmbeddings members (embeddings.py:309-311 -> super().__init__)
-        self.word_embeddings = nn.Embedding(config.vocab_size, H)
+        self.word_embeddings = nn.Embedding(config.vocab_size, H, padding_idx=getattr(config, "pad_token_id", 0))
         self.position_embeddings = nn.Embedding(config.max_position_embeddings, H)
         self.token_type_embeddings = nn.Embedding(config.type_vocab_size, H)
         self.LayerNorm = LayerNorm(H, eps=config.layer_norm_eps)
@@ -46,4 +46,5 @@ class BertVisioLinguisticEmbeddings(nn.Module):
             self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
             self.LayerNorm.weight, self.LayerNorm.bias, self.token_type_embeddings_visual.weight,
             self.position_embeddings_visual.weight, self.projection.weight, self.projection.bias,
-            Fn.shadows.get(self.projection.weight), self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training))
+            Fn.shadows.get(self.projection.weight), self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training),
+            self.word_embeddings.padding_idx)

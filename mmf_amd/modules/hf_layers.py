@@ -19,7 +19,7 @@ class BertConfig:
     def __init__(self, **kw):
         d = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                  hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=512,
-                 type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12, output_attentions=False,
+                 type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12, pad_token_id=0, output_attentions=False,
                  output_hidden_states=False, is_decoder=False)
         d.update(kw)
         for k, v in d.items():
@@ -66,6 +66,8 @@ def init_bert_weights(module, std=0.02):
             module.bias.data.zero_()
     elif isinstance(module, nn.Embedding):
         module.weight.data.normal_(mean=0.0, std=std)
+        if module.padding_idx is not None:
+            module.weight.data[module.padding_idx].zero_()
     elif isinstance(module, (LayerNorm, nn.LayerNorm)):
         module.weight.data.fill_(1.0)
         module.bias.data.zero_()
@@ -259,7 +261,7 @@ class BertEmbeddingsJit(nn.Module):
     def __init__(self, config):
         super().__init__()
         H = config.hidden_size
-        self.word_embeddings = nn.Embedding(config.vocab_size, H)
+        self.word_embeddings = nn.Embedding(config.vocab_size, H, padding_idx=getattr(config, "pad_token_id", 0))
         self.position_embeddings = nn.Embedding(config.max_position_embeddings, H)
         self.token_type_embeddings = nn.Embedding(config.type_vocab_size, H)
         self.LayerNorm = LayerNorm(H, eps=config.layer_norm_eps)
@@ -274,7 +276,7 @@ class BertEmbeddingsJit(nn.Module):
         return Fn.VisioLinguisticEmbeddingsFn.apply(
             input_ids, token_type_ids, None, None, self.word_embeddings.weight, self.position_embeddings.weight,
             self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias, z, z, z, z, None,
-            self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training))
+            self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training), self.word_embeddings.padding_idx)
 
 
 class BertModelJit(nn.Module):

@@ -86,9 +86,9 @@ def modal_embeddings(sd, cfg, input_modal, start_token, end_token, token_type_id
     e = T_ + "embeddings."
     tok = F.linear(input_modal, sd[M_ + "proj_embeddings.weight"], sd[M_ + "proj_embeddings.bias"])  # :92
     if start_token is not None:
-        tok = torch.cat([F.embedding(start_token, sd[e + "word_embeddings.weight"]).unsqueeze(1), tok], dim=1)  # :95-100
+        tok = torch.cat([F.embedding(start_token, sd[e + "word_embeddings.weight"], padding_idx=cfg.get("pad_token_id", 0)).unsqueeze(1), tok], dim=1)  # :95-100
     if end_token is not None:
-        tok = torch.cat([tok, F.embedding(end_token, sd[e + "word_embeddings.weight"]).unsqueeze(1)], dim=1)  # :102-107
+        tok = torch.cat([tok, F.embedding(end_token, sd[e + "word_embeddings.weight"], padding_idx=cfg.get("pad_token_id", 0)).unsqueeze(1)], dim=1)  # :102-107
     L = tok.size(1)
     position_ids = torch.arange(L, device=tok.device).unsqueeze(0).expand(tok.size(0), L)  # :109-115
     if token_type_ids is None:
@@ -104,7 +104,7 @@ def text_embeddings(sd, cfg, input_ids, token_type_ids, dropout_p=0.0):
     e = T_ + "embeddings."
     T = input_ids.size(1)
     position_ids = torch.arange(T, device=input_ids.device).unsqueeze(0).expand(input_ids.shape)
-    emb = (F.embedding(input_ids, sd[e + "word_embeddings.weight"]) + F.embedding(position_ids, sd[e + "position_embeddings.weight"])
+    emb = (F.embedding(input_ids, sd[e + "word_embeddings.weight"], padding_idx=cfg.get("pad_token_id", 0)) + F.embedding(position_ids, sd[e + "position_embeddings.weight"])
            + F.embedding(token_type_ids, sd[e + "token_type_embeddings.weight"]))
     emb = layer_norm(emb, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], cfg["layer_norm_eps"])
     return F.dropout(emb, dropout_p, training=dropout_p > 0)

@@ -110,7 +110,7 @@ def embeddings(sd, cfg, input_ids, token_type_ids, visual_embeddings, visual_emb
     e = "bert.embeddings."
     T = input_ids.size(1)
     position_ids = torch.arange(T, device=input_ids.device).unsqueeze(0).expand_as(input_ids)  # :332-335
-    words = F.embedding(input_ids, sd[e + "word_embeddings.weight"])  # :339
+    words = F.embedding(input_ids, sd[e + "word_embeddings.weight"], padding_idx=cfg.get("pad_token_id", 0))  # :339
     pos = F.embedding(position_ids, sd[e + "position_embeddings.weight"])  # :341
     typ = F.embedding(token_type_ids, sd[e + "token_type_embeddings.weight"])  # :342
     text = words + pos + typ  # :343

@@ -57,6 +57,7 @@ def make_inputs(c):
     mask = np.ones((B, T), dtype=np.int64)
     mask[1, T // 2:] = 0           # a padded question
     mask[2, T - 2:] = 0
+    ids[mask == 0] = 0             # [PAD] = pad_token_id: HF's word_embeddings has padding_idx=0 (no gradient for that row)
     seg = (detweights.uniform(B * T, seed + 101) > 0.7).astype(np.int64).reshape(B, T)
     feats = detweights.uniform(B * R * c["visual_embedding_dim"], seed + 102).astype(np.float32).reshape(B, R, -1)
     max_features = np.array([R, R - 2, R - 1], dtype=np.int64)[:B]
@@ -175,6 +176,7 @@ def make_mmbt():
         mask = np.ones((B, T), dtype=np.int64)
         mask[1, T // 2:] = 0
         mask[2, T - 3:] = 0
+        ids[mask == 0] = 0   # [PAD]
         seg = np.zeros((B, T), dtype=np.int64)
         feats = detweights.uniform(B * N * c["modal_hidden_size"], seed + 102).astype(np.float32).reshape(B, N, -1)
         targets = (detweights.uniform(B, seed + 103) > 0.5).astype(np.int64)
@@ -221,10 +223,143 @@ def make_mmbt():
         np.savez_compressed(path, **rec)
         print(name, "loss", loss.item(), "scores", rec["scores"][0], "->", path, os.path.getsize(path), "bytes")
 
+MMFT_CASES = {
+    "mmft_small64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
+                         max_position_embeddings=40, embedding_dim=72, num_labels=5, B=3, T=12, R=7, seed=31),
+}
+
+
+def make_mmft():
+    """MMF Transformer (mmft) through the reference's own MMFTransformer.forward / preprocess_sample,
+    BaseTransformerBackend.forward + HuggingfaceBackend.generate_* , HuggingfaceEmbeddings, BertModelJit encoder and the
+    MLP head.  The pieces that need the network in the reference (`AutoConfig/BertModelJit.from_pretrained`) are replaced by
+    a randomly-initialised BertModelJit of the same class; the encoder is called the way the reference's scripted branch
+    calls it (huggingface.py:227) — its eager branch (:229-231) passes `[None]*L` in the `encoder_hidden_states` slot of
+    this tree's BertEncoderJit and cannot run."""
+    import types
+    from torch import nn
+    from transformers import BertConfig
+    M = refshim.ref_import("mmf.models.mmf_transformer")
+    HB = refshim.ref_import("mmf.models.transformers.backends.huggingface")
+    TB = refshim.ref_import("mmf.models.transformers.base")
+    from mmf.models.transformers.heads.mlp import MLP
+    from mmf.modules.hf_layers import BertModelJit
+    from mmf.modules.losses import CrossEntropyLoss
+
+    for name, c in MMFT_CASES.items():
+        torch.manual_seed(c["seed"])
+        bcfg = BertConfig(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+                          num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                          vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"], type_vocab_size=2,
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12, pad_token_id=0)
+        mcfg = OmegaConf.create(dict(
+            model="mmft", transformer_base="bert-base-uncased", num_labels=c["num_labels"], initializer_range=0.02,
+            initializer_mean=0.0, token_noise_std=0.01, token_noise_mean=0.0, layer_norm_weight_fill=1.0, random_initialize=False,
+            heads=[dict(type="mlp", hidden_size=c["hidden_size"], num_labels=c["num_labels"])],
+            modalities=[
+                dict(type="text", key="text", position_dim=c["max_position_embeddings"], segment_id=0,
+                     embedding_dim=c["hidden_size"], layer_norm_eps=1e-12, hidden_dropout_prob=0.1),
+                dict(type="image", key="image", embedding_dim=c["embedding_dim"], position_dim=c["max_position_embeddings"],
+                     segment_id=1, layer_norm_eps=1e-12, hidden_dropout_prob=0.1),
+            ]))
+
+        class RefBackend(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.config = mcfg
+                self.transformer_config = bcfg
+                self.transformer = BertModelJit(bcfg)
+                self.embeddings = HB.HuggingfaceEmbeddings(mcfg, bcfg, self.transformer)
+
+            generate_embeddings = HB.HuggingfaceBackend.generate_embeddings
+            generate_attention_mask = HB.HuggingfaceBackend.generate_attention_mask
+            forward = TB.BaseTransformerBackend.forward
+
+            def generate_encoded_layers(self, embedding, attention_mask):
+                encoded_layers = self.transformer.encoder(embedding, attention_mask)   # huggingface.py:227
+                return encoded_layers[-1], encoded_layers[0]                            # :232
+
+        class RefMMFT(nn.Module):   # module tree of MMFTransformer: backend.*, encoders.*, heads.*
+            def __init__(self):
+                super().__init__()
+                self.config = mcfg
+                self.backend = RefBackend()
+                self.encoders = nn.ModuleDict({"text": nn.Identity(), "image": nn.Identity()})
+                self.heads = nn.ModuleList([MLP(mcfg.heads[0])])
+                self.modality_keys = ["text", "image"]
+                self.modality_type = ["text", "image"]
+                self.modality_segments = [0, 1]
+
+        for fn in ("forward", "preprocess_sample", "_infer_input_ids", "_check_keys_for_modality", "_infer_position_ids",
+                   "_infer_masks", "_infer_segment_ids", "_infer_itm_labels", "_infer_mlm_labels", "postprocess_output"):
+            setattr(RefMMFT, fn, getattr(M.MMFTransformer, fn))
+        ref = RefMMFT().eval()
+        full = {k: tuple(v.shape) for k, v in ref.state_dict().items() if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")}
+        alias = {"backend.embeddings.token_embeddings.0.weight": "backend.transformer.embeddings.word_embeddings.weight",
+                 "backend.embeddings.layer_norms.0.weight": "backend.transformer.embeddings.LayerNorm.weight",
+                 "backend.embeddings.layer_norms.0.bias": "backend.transformer.embeddings.LayerNorm.bias"}
+        uniq = {k: v for k, v in full.items() if k not in alias}
+        sd = detweights.state_dict(uniq, c["seed"])
+        missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected, unexpected
+        assert ref.backend.embeddings.token_embeddings[0].weight is ref.backend.transformer.embeddings.word_embeddings.weight
+
+        B, T, R, seed = c["B"], c["T"], c["R"], c["seed"]
+        ids = (detweights.uniform(B * T, seed + 100) * c["vocab_size"]).astype(np.int64).reshape(B, T)
+        mask = np.ones((B, T), dtype=np.int64)
+        mask[1, T // 2:] = 0
+        mask[2, T - 3:] = 0
+        ids[mask == 0] = 0   # [PAD]
+        seg = np.zeros((B, T), dtype=np.int64)
+        feats = detweights.uniform(B * R * c["embedding_dim"], seed + 102).astype(np.float32).reshape(B, R, -1)
+        image_mask = np.ones((B, R), dtype=np.int64)
+        image_mask[1, R - 2:] = 0
+        targets = (detweights.uniform(B, seed + 103) * c["num_labels"]).astype(np.int64)
+        sl = SampleList(input_ids=torch.from_numpy(ids), input_mask=torch.from_numpy(mask), segment_ids=torch.from_numpy(seg),
+                        image=torch.from_numpy(feats), image_mask=torch.from_numpy(image_mask), targets=torch.from_numpy(targets),
+                        dataset_name="hateful_memes", dataset_type="train")
+        holder = {}
+        orig = ref.backend.forward
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            holder["seq"] = out[0]
+            return out
+
+        ref.backend.forward = spy
+        out = ref(sl)
+        loss = CrossEntropyLoss()(sl, out)
+        loss.backward()
+        rec = {"in_input_ids": ids, "in_input_mask": mask, "in_segment_ids": seg, "in_image": feats, "in_image_mask": image_mask,
+               "in_targets": targets}
+        rec["scores"] = out["scores"].detach().numpy()
+        rec["sequence_output"] = holder["seq"].detach().numpy()
+        rec["loss"] = np.array(loss.item(), dtype=np.float64)
+        names, norms, sums = [], [], []
+        for k, p in ref.named_parameters():
+            g = p.grad
+            names.append(k)
+            norms.append(0.0 if g is None else float(g.double().norm()))
+            sums.append(0.0 if g is None else float(g.double().sum()))
+            if g is not None and g.numel() <= 4096:
+                rec["grad::" + k] = g.numpy()
+        rec["grad_names"] = np.array(names)
+        rec["grad_norms"] = np.array(norms)
+        rec["grad_sums"] = np.array(sums)
+        rec["param_names"] = np.array(list(uniq.keys()))
+        rec["param_shapes"] = np.array([",".join(map(str, s)) for s in uniq.values()])
+        rec["state_dict_keys"] = np.array(list(ref.state_dict().keys()))
+        rec["case"] = np.array(repr(c))
+        path = os.path.join(HERE, "%s.npz" % name)
+        np.savez_compressed(path, **rec)
+        print(name, "loss", loss.item(), "scores", rec["scores"][0], "->", path, os.path.getsize(path), "bytes")
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "mmbt"]
+    which = sys.argv[1:] or ["visual_bert", "mmbt", "mmft"]
     if "visual_bert" in which:
         main()
     if "mmbt" in which:
         make_mmbt()
+    if "mmft" in which:
+        make_mmft()

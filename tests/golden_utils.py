@@ -51,3 +51,29 @@ def load_mmbt_case(name="mmbt_small64"):
         "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "hateful_memes", "dataset_type": "train",
     }
     return z, case, cfg, sd, sample
+
+
+def load_mmft_case(name="mmft_small64"):
+    z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {k: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    cfg = dict(
+        vocab_size=case["vocab_size"], hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"],
+        num_attention_heads=case["num_attention_heads"], intermediate_size=case["intermediate_size"],
+        max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2, layer_norm_eps=1e-12,
+        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, pad_token_id=0, num_labels=case["num_labels"],
+        head_layer_norm_eps=1e-6, head_dropout_prob=0.1, initializer_range=0.02,
+        modalities=[
+            dict(type="text", key="text", position_dim=case["max_position_embeddings"], segment_id=0,
+                 embedding_dim=case["hidden_size"], layer_norm_eps=1e-12, hidden_dropout_prob=0.1),
+            dict(type="image", key="image", embedding_dim=case["embedding_dim"], position_dim=case["max_position_embeddings"],
+                 segment_id=1, layer_norm_eps=1e-12, hidden_dropout_prob=0.1),
+        ])
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image": torch.from_numpy(z["in_image"]),
+        "image_mask": torch.from_numpy(z["in_image_mask"]), "targets": torch.from_numpy(z["in_targets"]),
+        "dataset_name": "hateful_memes", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample

@@ -1,0 +1,46 @@
+"""Pins oracle/mmft_oracle.py against the fixture produced by the REAL reference MMF Transformer path
+(MMFTransformer.forward/preprocess_sample + BaseTransformerBackend.forward + HuggingfaceEmbeddings + BertModelJit
+encoder + MLP head + cross_entropy); see tests/golden/make_golden.py::make_mmft."""
+import numpy as np
+import torch
+
+from oracle import mmft_oracle as O
+from tests.golden_utils import load_mmft_case
+
+
+def test_mmft_oracle_matches_reference_forward_loss_and_gradients():
+    z, case, cfg, sd, sample = load_mmft_case()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.mmft_forward(sd, cfg, dict(sample), train=False)
+    np.testing.assert_allclose(out["scores"].detach().numpy(), z["scores"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out["sequence_output"].detach().numpy(), z["sequence_output"], rtol=1e-5, atol=5e-6)
+    loss = torch.nn.functional.cross_entropy(out["scores"], sample["targets"])
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    alias = O.shared(cfg)
+    seen = 0
+    for gname, norm, gsum in zip(z["grad_names"], z["grad_norms"], z["grad_sums"]):
+        key = alias.get(str(gname), str(gname))
+        g = sd[key].grad
+        if norm == 0.0:   # the transformer's own position/type tables and pooler are not on MMFT's forward path
+            assert g is None or float(g.abs().max()) == 0.0, key
+            continue
+        seen += 1
+        assert g is not None, key
+        assert abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+        assert abs(float(g.double().sum()) - gsum) <= 1e-4 * norm + 1e-7, key
+        full = "grad::" + str(gname)
+        if full in z.files:
+            np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
+    assert seen >= 40
+    # [PAD] rows of the word table receive no gradient (padding_idx) although pad ids occur in the batch
+    assert (sample["input_ids"] == 0).any()
+    assert float(sd["backend.transformer.embeddings.word_embeddings.weight"].grad[0].abs().max()) == 0.0
+
+
+def test_reference_state_dict_aliases():
+    z, case, cfg, sd, sample = load_mmft_case()
+    keys = set(str(k) for k in z["state_dict_keys"])
+    for alias, owner in O.shared(cfg).items():
+        assert alias in keys and owner in keys

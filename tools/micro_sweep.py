@@ -1,0 +1,60 @@
+"""On-hardware sweeps of the tuning knobs (include/mmf_amd.h MMF_TUN_*): LayerNorm-backward grid, split-K count of the
+weight-gradient GEMMs (both GEMM forms).  python tools/micro_sweep.py [ln] [wgrad]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mmf_amd import _native as nat
+
+
+def timeit(f, iters=30):
+    for _ in range(3):
+        f()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters):
+        f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def ln_sweep():
+    rows, H = 7296, 768
+    dev = "cuda"
+    dy = torch.randn(rows, H, device=dev).bfloat16(); x = torch.randn(rows, H, device=dev).bfloat16()
+    mean = torch.randn(rows, device=dev); rstd = torch.rand(rows, device=dev) + 0.5; gamma = torch.randn(H, device=dev)
+    dx = torch.empty_like(dy); dlin = torch.empty_like(dy)
+    dg = torch.empty(H, device=dev); db = torch.empty(H, device=dev); dbias = torch.empty(H, device=dev)
+    ws = torch.empty(nat.layernorm_bwd_ws_floats(H), device=dev)
+    for grid in (128, 192, 256, 384, 512):
+        nat.set_tunable(nat.TUN_LN_BWD_GRID, grid)
+        t0 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat.NO_DROP, dg, db, None, False, ws, rows, H))
+        t1 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, dbias, False, ws, rows, H))
+        print("ln_bwd grid %3d: plain %6.1f us   dropout+dbias %6.1f us (incl. reduce kernel)" % (grid, t0, t1), flush=True)
+    nat.set_tunable(nat.TUN_LN_BWD_GRID, 0)
+
+
+def wgrad_sweep():
+    Mtok = 7296
+    dev = "cuda"
+    for name, m, n in (("qkv", 2304, 768), ("out", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)):
+        A = torch.randn(Mtok, m, device=dev).bfloat16(); B = torch.randn(Mtok, n, device=dev).bfloat16()
+        C = torch.empty(m, n, device=dev, dtype=torch.float32)
+        fl = 2.0 * m * n * Mtok
+        for form, flag in (("k64", 2048), ("k32", 1024)):
+            line = []
+            for sp in (0, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14):
+                nat.set_tunable(nat.TUN_SPLITK_FORCE, sp)
+                us = timeit(lambda: nat.gemm(A, B, C, m, n, Mtok, m, n, n, a_kmajor=True, b_kmajor=True, debug_flags=flag))
+                line.append("%d:%.0f(%.0f)" % (sp, us, fl / us / 1e6))
+            print("wgrad %-4s %s  sp:us(TF) " % (name, form) + " ".join(line), flush=True)
+    nat.set_tunable(nat.TUN_SPLITK_FORCE, 0)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ln", "wgrad"]
+    if "ln" in which:
+        ln_sweep()
+    if "wgrad" in which:
+        wgrad_sweep()

@@ -161,6 +161,15 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
  */
 int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
                        const float* type, void* y, int B, int T, int S, int H, int row0, int pos0, void* stream);
+/* MMF Transformer per-modality embedding sum (mmf/models/transformers/backends/huggingface.py:145-155):
+ * y[b*S + row0 + i] = x[b*L + i] + pos[pos0 + i] + type[seg[b,i]]; x, y bf16 rows of H, tables fp32; pos and
+ * (seg, type) may be NULL (the reference adds them only when the modality has position / segment ids). */
+int mmf_rows_add_embed(const void* x, const int64_t* seg, const float* pos, const float* type, void* y, int B, int L,
+                       int S, int H, int row0, int pos0, void* stream);
+/* The `torch.cat(list_embeddings, dim=1)` of huggingface.py:159 and its backward split, one modality block per
+ * call: dst[(b*dst_bstride + i), :] = src[(b*src_bstride + i), :], b < nb, i < rpb; strides in rows; H % 8 == 0. */
+int mmf_copy_rows_bf16(const void* src, int src_bstride, void* dst, int dst_bstride, int nb, int rpb, int H,
+                       void* stream);
 /* out[idx[r]] += x[row r] for r in [0, nb*rpb): row r = (b, i) lives at x + (b*bstride + i)*ld.
  * idx == NULL means bucket (i + idx_base) (position ids) when per_pos != 0, else bucket idx_base.
  * fp32 atomics into `out` [nbuckets, H] (caller zero-fills when not accumulating).

@@ -253,6 +253,17 @@ def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
            "mmf_embed_text_fwd")
 
 
+def rows_add_embed(x, seg, pos, typ, y, B, L, S, H, row0=0, pos0=0):
+    _req(x, torch.bfloat16, "x"); _req(y, torch.bfloat16, "y"); _req(seg, torch.int64, "seg")
+    _req(pos, torch.float32, "pos"); _req(typ, torch.float32, "type")
+    _check(lib().mmf_rows_add_embed(_p(x), _p(seg), _p(pos), _p(typ), _p(y), B, L, S, H, row0, pos0, _stream()), "mmf_rows_add_embed")
+
+
+def copy_rows(src, src_bstride, dst, dst_bstride, nb, rpb, H):
+    _req(src, torch.bfloat16, "src"); _req(dst, torch.bfloat16, "dst")
+    _check(lib().mmf_copy_rows_bf16(_p(src), src_bstride, _p(dst), dst_bstride, nb, rpb, H, _stream()), "mmf_copy_rows_bf16")
+
+
 def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, few_buckets, skip_bucket=-1):
     _req(x, torch.bfloat16, "x"); _req(idx, torch.int64, "idx"); _req(out, torch.float32, "out")
     ws = None

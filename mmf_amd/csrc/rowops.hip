@@ -213,6 +213,38 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     }
 }
 
+// y[b*S + row0 + i] = x[b*L + i] + pos[pos0 + i] + type[seg[b,i]]   (pos / seg may be null)
+__global__ __launch_bounds__(256) void rows_add_embed_kernel(const bf16* __restrict__ x, const int64_t* __restrict__ seg,
+                                                              const float* __restrict__ pos, const float* __restrict__ type,
+                                                              bf16* __restrict__ y, int B, int L, int S, int H, int row0, int pos0) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * L) return;
+    const int b = r / L, i = r - b * L;
+    const bf16* xr = x + (size_t)r * H;
+    const float* p = pos ? pos + (size_t)(i + pos0) * H : nullptr;
+    const float* ty = (type && seg) ? type + (size_t)seg[r] * H : nullptr;
+    bf16* yr = y + ((size_t)b * S + row0 + i) * H;
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 v = load4(xr + col);
+        if (p) { const f32x4 c = load4(p + col); v += c; }
+        if (ty) { const f32x4 d = load4(ty + col); v += d; }
+        store4(yr + col, v);
+    }
+}
+
+// dst[(b*dst_bs + i), :] = src[(b*src_bs + i), :]  for b < nb, i < rpb: one modality's block of a [B, S, H] sequence
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__ src, int src_bs, bf16* __restrict__ dst, int dst_bs,
+                                                         int nb, int rpb, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nb * rpb) return;
+    const int b = r / rpb, i = r - b * rpb;
+    const bf16* s = src + ((size_t)b * src_bs + i) * H;
+    bf16* d = dst + ((size_t)b * dst_bs + i) * H;
+    for (int col = lane * 8; col < H; col += 512) *reinterpret_cast<uint4*>(d + col) = *reinterpret_cast<const uint4*>(s + col);
+}
+
 DEVI int bucket_of(const int64_t* idx, int idx_ld, int per_pos, int idx_base, int b, int i) {
     if (idx) return (int)idx[(size_t)b * idx_ld + i];
     return per_pos ? i + idx_base : idx_base;
@@ -692,6 +724,25 @@ int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word
     MMF_CHECK_ARG(B > 0 && T > 0 && row0 >= 0 && S >= row0 + T && pos0 >= 0 && (H % 4) == 0, "embed_text_fwd: bad shape");
     hipLaunchKernelGGL(embed_text_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
                        (bf16*)y, B, T, S, H, row0, pos0);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_rows_add_embed(const void* x, const int64_t* seg, const float* pos, const float* type, void* y, int B, int L, int S, int H,
+                       int row0, int pos0, void* stream) {
+    MMF_CHECK_ARG(x && y, "rows_add_embed: null operand");
+    MMF_CHECK_ARG(B > 0 && L > 0 && row0 >= 0 && S >= row0 + L && pos0 >= 0 && (H % 4) == 0, "rows_add_embed: bad shape");
+    hipLaunchKernelGGL(rows_add_embed_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, seg, pos, type,
+                       (bf16*)y, B, L, S, H, row0, pos0);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_copy_rows_bf16(const void* src, int src_bstride, void* dst, int dst_bstride, int nb, int rpb, int H, void* stream) {
+    MMF_CHECK_ARG(src && dst, "copy_rows: null operand");
+    MMF_CHECK_ARG(nb > 0 && rpb > 0 && src_bstride >= rpb && dst_bstride >= rpb && (H % 8) == 0, "copy_rows: bad shape");
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((nb * rpb + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, src_bstride,
+                       (bf16*)dst, dst_bstride, nb, rpb, H);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -205,7 +205,10 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, w16, out_f32):
-        x2 = _as_bf16_2d(x)
+        if x.dtype == F32 and not x.requires_grad:
+            x2 = x.reshape(-1, x.shape[-1]).contiguous()   # raw fp32 features: converted while staged by the GEMM
+        else:
+            x2 = _as_bf16_2d(x)
         M, K = x2.shape
         N = weight.shape[0]
         y = torch.empty(M, N, dtype=F32 if out_f32 else BF16, device=x2.device)
@@ -725,3 +728,65 @@ class CrossEntropyFn(torch.autograd.Function):
         d = torch.empty(B, Cn, dtype=F32, device=s.device)
         nat.cross_entropy_bwd(s, t, count, g.float().reshape(1).contiguous(), d, B, Cn, ctx.ignore_index)
         return d, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# MMF Transformer pieces (mmf/models/transformers/backends/huggingface.py)
+# ---------------------------------------------------------------------------------------------
+class AddPosTypeFn(torch.autograd.Function):
+    """total = tok + pos_emb(arange(L)) + token_type_embeddings(segment_ids)   (huggingface.py:147-155) for a modality
+    whose token embedding is a projection (`x` [B, L, H] bf16).  Either table may be None."""
+
+    @staticmethod
+    def forward(ctx, x, seg, pos, typ):
+        B, L, H = x.shape
+        x2 = _as_bf16_2d(x)
+        y = torch.empty(B * L, H, dtype=BF16, device=x2.device)
+        sg = seg.contiguous() if (seg is not None and typ is not None) else None
+        nat.rows_add_embed(x2, sg, pos.detach() if pos is not None else None, typ.detach() if sg is not None else None, y, B, L, L, H)
+        ctx.save_for_backward(sg)
+        ctx.meta = (B, L, H, None if pos is None else pos.shape[0], None if typ is None else typ.shape[0])
+        return y.view(B, L, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        (sg,) = ctx.saved_tensors
+        B, L, H, P, NT = ctx.meta
+        g2 = _grad_bf16(g, H)
+        dpos = dtyp = None
+        if P is not None:
+            dpos = torch.zeros(P, H, dtype=F32, device=g2.device)
+            nat.rows_scatter_add(g2, H, B, L, L, None, 0, 1, 0, dpos, H, 0)
+        if NT is not None and sg is not None:
+            dtyp = torch.zeros(NT, H, dtype=F32, device=g2.device)
+            nat.rows_scatter_add(g2, H, B, L, L, sg, L, 0, 0, dtyp, H, 1)
+        return g2.view(B, L, H), None, dpos, dtyp
+
+
+class ConcatRowsFn(torch.autograd.Function):
+    """torch.cat(list_embeddings, dim=1) (huggingface.py:159) of [B, L_m, H] bf16 blocks as strided HIP copies."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, _, H = xs[0].shape
+        lens = [int(x.shape[1]) for x in xs]
+        S = sum(lens)
+        out = torch.empty(B, S, H, dtype=BF16, device=xs[0].device)
+        off = 0
+        for x, L in zip(xs, lens):
+            nat.copy_rows(_as_bf16_2d(x), L, out.view(B * S, H)[off:], S, B, L, H)
+            off += L
+        ctx.meta = (B, S, H, lens)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, H, lens = ctx.meta
+        g2 = _grad_bf16(g, H)
+        outs, off = [], 0
+        for L in lens:
+            d = torch.empty(B * L, H, dtype=BF16, device=g2.device)
+            nat.copy_rows(g2[off:], S, d, L, B, L, H)
+            outs.append(d.view(B, L, H))
+            off += L
+        return tuple(outs)

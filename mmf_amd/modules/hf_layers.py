@@ -46,6 +46,18 @@ class Linear(nn.Module):
         return Fn.linear(x, self.weight, self.bias, out_f32)
 
 
+class Dropout(nn.Module):
+    """nn.Dropout on a bf16 activation with the counter-hash mask of the fused kernels."""
+
+    def __init__(self, p=0.1):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        drop = Fn.make_drop(self.p, self.training)
+        return Fn.DropoutFn.apply(x, drop) if drop[1] else x
+
+
 class LayerNorm(nn.Module):
     def __init__(self, hidden_size, eps=1e-12):
         super().__init__()
@@ -305,11 +317,12 @@ class BertModelJit(nn.Module):
 
 
 class BertPredictionHeadTransform(nn.Module):
-    """HF BertPredictionHeadTransform: LayerNorm(gelu(dense(x)))."""
+    """HF BertPredictionHeadTransform: LayerNorm(gelu(dense(x))); `in_dim` as in MMF's PredictionHeadTransformWithInDim
+    (mmf/models/transformers/heads/mlp.py:90-94)."""
 
-    def __init__(self, config):
+    def __init__(self, config, in_dim=None):
         super().__init__()
-        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.dense = Linear(config.hidden_size if in_dim is None else in_dim, config.hidden_size)
         self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
 
     def forward(self, hidden_states):

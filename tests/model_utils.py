@@ -71,3 +71,32 @@ def build_mmbt(cfg, sd=None, shared=None, device="cuda", **over):
             full["model." + alias] = sd[src]
         model.load_state_dict(full, strict=True)
     return model.to(device)
+
+
+def mmft_model_config(cfg, **over):
+    """MMF model_config.mmf_transformer (configs/models/mmf_transformer/defaults.yaml) with identity encoders."""
+    d = dict(
+        model="mmft", transformer_base=None, backend=dict(type="huggingface", freeze=False, params={}),
+        heads=[dict(type="mlp", freeze=False, lr_multiplier=1.0, hidden_size=cfg["hidden_size"], num_labels=cfg["num_labels"],
+                    layer_norm_eps=cfg.get("head_layer_norm_eps", 1e-6), hidden_dropout_prob=cfg.get("head_dropout_prob", 0.1))],
+        modalities=[dict(m) for m in cfg["modalities"]], initializer_range=0.02, initializer_mean=0.0, token_noise_std=0.01,
+        token_noise_mean=0.0, layer_norm_weight_fill=1.0, random_initialize=False, freeze_image_encoder=False,
+        tie_weight_to_encoder=None, num_labels=cfg["num_labels"],
+        hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+        intermediate_size=cfg["intermediate_size"], vocab_size=cfg["vocab_size"],
+        max_position_embeddings=cfg["max_position_embeddings"], type_vocab_size=cfg.get("type_vocab_size", 2),
+        hidden_dropout_prob=cfg.get("hidden_dropout_prob", 0.1),
+        attention_probs_dropout_prob=cfg.get("attention_probs_dropout_prob", 0.1), layer_norm_eps=cfg["layer_norm_eps"],
+        losses=[dict(type="cross_entropy")])
+    d.update(over)
+    return Config(d)
+
+
+def build_mmft(cfg, sd=None, shared=None, device="cuda", **over):
+    model = build_model(mmft_model_config(cfg, **over))
+    if sd is not None:
+        full = dict(sd)
+        for alias, src in (shared or {}).items():
+            full[alias] = sd[src]
+        model.load_state_dict(full, strict=True)
+    return model.to(device)

@@ -1,0 +1,160 @@
+"""MMF Transformer on the HIP path (GPU): the two kernels it adds (per-modality embedding sum, concat/split copies),
+the fp32-feature Linear, and the registered `mmft` model against the fixture recorded from the real reference
+(tests/golden/mmft_small64.npz) and the CPU oracle.  Tolerance: BASELINE.json north_star, 5e-2 for the bf16 path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmft_oracle as O
+from tests.golden_utils import load_mmft_case
+from tests.model_utils import build_mmft, sample_to
+from tests.test_kernels_gpu import close, nat, rnd, DEV
+from mmf_amd.common.sample import SampleList
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-2
+
+
+def rel_err(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_rows_add_embed_and_its_backward():
+    import mmf_amd.functional as Fn
+    B, L, H = 3, 7, 256
+    x = rnd(B, L, H).requires_grad_(True)
+    seg = torch.randint(0, 3, (B, L), device=DEV)
+    pos = rnd(16, H, dtype=torch.float32).requires_grad_(True); typ = rnd(3, H, dtype=torch.float32).requires_grad_(True)
+    y = Fn.AddPosTypeFn.apply(x, seg, pos, typ)
+    ref = x.detach().float() + pos.detach()[:L][None] + typ.detach()[seg]
+    close(y, ref, 1e-2, 1e-2, "add pos/type")
+    g = rnd(B, L, H, seed=5)
+    y.backward(g)
+    assert torch.equal(x.grad, g)
+    close(pos.grad[:L], g.float().sum(0), 1e-4, 1e-3, "dpos")
+    assert float(pos.grad[L:].abs().max()) == 0
+    close(typ.grad, torch.zeros(3, H, device=DEV).index_add_(0, seg.view(-1), g.float().view(-1, H)), 1e-4, 1e-3, "dtype")
+    # no segment ids / no positions
+    y2 = Fn.AddPosTypeFn.apply(x.detach(), None, pos.detach(), None)
+    close(y2, x.detach().float() + pos.detach()[:L][None], 1e-2, 1e-2, "add pos only")
+
+
+def test_concat_rows_forward_and_split_backward():
+    import mmf_amd.functional as Fn
+    B, H = 4, 128
+    a = rnd(B, 5, H).requires_grad_(True); b = rnd(B, 1, H).requires_grad_(True); c = rnd(B, 9, H).requires_grad_(True)
+    out = Fn.ConcatRowsFn.apply(a, b, c)
+    assert torch.equal(out, torch.cat([a, b, c], dim=1).detach())
+    g = rnd(B, 15, H, seed=3)
+    out.backward(g)
+    assert torch.equal(a.grad, g[:, :5]) and torch.equal(b.grad, g[:, 5:6]) and torch.equal(c.grad, g[:, 6:])
+
+
+def test_linear_takes_raw_fp32_features():
+    import mmf_amd.functional as Fn
+    M, K, N = 300, 72, 128
+    x = rnd(M, K, dtype=torch.float32)
+    w = rnd(N, K, dtype=torch.float32, scale=0.1).requires_grad_(True); bias = rnd(N, dtype=torch.float32).requires_grad_(True)
+    y = Fn.linear(x, w, bias)
+    ref = x.bfloat16().float() @ w.detach().bfloat16().float().t() + bias.detach()
+    close(y, ref, 1e-2, 2e-2, "fp32-input linear")
+    g = rnd(M, N, seed=9)
+    y.backward(g)
+    close(w.grad, g.float().t() @ x.bfloat16().float(), 1e-2, 5e-2, "wgrad with fp32 activations")
+    close(bias.grad, g.float().sum(0), 1e-3, 1e-2, "bias grad")
+
+
+def test_mmft_golden_forward_loss_and_gradients():
+    z, case, cfg, sd, sample = load_mmft_case()
+    model = build_mmft(cfg, sd, O.shared(cfg))
+    model.eval()
+    seq = {}
+    hook = model.backend.register_forward_hook(lambda m, i, o: seq.update(seq=o[0]))
+    out = model(SampleList(sample_to(sample, "cuda")))
+    hook.remove()
+    np.testing.assert_allclose(out["scores"].detach().float().cpu().numpy(), z["scores"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(seq["seq"].detach().float().cpu().numpy(), z["sequence_output"], rtol=TOL, atol=TOL)
+    (key, loss), = out["losses"].items()
+    assert key == "train/hateful_memes/cross_entropy"
+    assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    loss.sum().backward()
+    params = dict(model.named_parameters())
+    alias = O.shared(cfg)
+    worst = {}
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        gname = str(gname)
+        p = params[alias.get(gname, gname)]
+        if norm == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, gname
+            continue
+        assert p.grad is not None, gname
+        gn = float(p.grad.double().norm())
+        if gname.endswith("self.key.bias"):
+            qn = float(params[gname.replace("key.bias", "query.bias")].grad.double().norm())
+            assert gn <= TOL * qn + 1e-6, (gname, gn, qn)
+            continue
+        worst[gname] = abs(gn - norm) / norm
+        full = "grad::" + gname
+        if full in z.files:
+            assert rel_err(p.grad, torch.from_numpy(z[full])) <= TOL, gname
+    bad = {k: round(v, 4) for k, v in worst.items() if v > TOL}
+    assert not bad, bad
+    # padding_idx: the [PAD] row of the word table gets no gradient
+    assert float(params["backend.transformer.embeddings.word_embeddings.weight"].grad[0].abs().max()) == 0.0
+
+
+def test_mmft_all_gradients_match_oracle_three_modalities():
+    """Three modalities (text + two feature streams, one without segment ids), every parameter's full gradient
+    against the pinned CPU oracle."""
+    z, case, cfg, sd, sample = load_mmft_case()
+    H = cfg["hidden_size"]
+    cfg = dict(cfg)
+    cfg["modalities"] = [dict(m) for m in cfg["modalities"]] + [
+        dict(type="audio", key="audio", embedding_dim=40, position_dim=cfg["max_position_embeddings"], layer_norm_eps=1e-12,
+             hidden_dropout_prob=0.1)]
+    g = torch.Generator().manual_seed(77)
+    sd = dict(sd)
+    for k, shp in O.parameter_shapes(cfg).items():
+        if k not in sd or tuple(sd[k].shape) != tuple(shp):
+            sd[k] = (1.0 + 0.05 * torch.randn(shp, generator=g)) if k.endswith("1.weight") or "layer_norms" in k and k.endswith("weight") \
+                else 0.05 * torch.randn(shp, generator=g)
+    sample = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items()}
+    sample["audio"] = torch.randn(sample["input_ids"].shape[0], 5, 40, generator=g)
+    model = build_mmft(cfg, sd, O.shared(cfg))
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mmft_forward(sdr, cfg, dict(sample))
+    assert float((out["scores"].detach().float().cpu() - ref["scores"].detach()).abs().max()) <= TOL
+    (key, loss), = out["losses"].items()
+    ref_loss = torch.nn.functional.cross_entropy(ref["scores"], sample["targets"])
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    loss.sum().backward(); ref_loss.backward()
+    params = dict(model.named_parameters())
+    errs = {}
+    for k, v in sdr.items():
+        p = params[k]
+        if v.grad is None or float(v.grad.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        if k.endswith("self.key.bias"):
+            continue
+        errs[k] = rel_err(p.grad, v.grad)
+    bad = {k: round(e, 4) for k, e in errs.items() if e > TOL}
+    assert not bad, bad
+
+
+def test_mmft_training_mode_is_seed_reproducible():
+    z, case, cfg, sd, sample = load_mmft_case()
+    model = build_mmft(cfg, sd, O.shared(cfg))
+    model.train()
+    batch = sample_to(sample, "cuda")
+    torch.manual_seed(3)
+    a = model(SampleList(dict(batch)))["scores"].float().clone()
+    torch.manual_seed(3)
+    b = model(SampleList(dict(batch)))["scores"].float().clone()
+    torch.manual_seed(4)
+    c = model(SampleList(dict(batch)))["scores"].float().clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)

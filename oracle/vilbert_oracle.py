@@ -1,0 +1,242 @@
+"""CPU oracle for ViLBERT (BASELINE.json configs[2]) — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+fp32 PyTorch restatement of mmf/models/vilbert.py: `BertSelfAttention` :46-114 / `BertImageSelfAttention` :153-247
+(dynamic_attention=False), `BertLayer` :131-146 / `BertImageLayer` :313-332, `BertBiAttention` :347-475, `BertBiOutput`
+:478-512, `BertConnectionLayer` :515-556, `BertEncoder.forward` :590-796 (fixed_*_layer=0, no in_batch_pairs / fast mode),
+`BertTextPooler` / `BertImagePooler` :799-826, `BertImageFeatureEmbeddings` :891-913, `ViLBERTBase.forward` :936-1051,
+`ViLBERTForClassification.forward` :1281-1333 and `ViLBERT.forward` :1364-1446 (input massaging).
+
+Parity status: PINNED against tests/golden/vilbert_small.npz, produced by running those reference classes
+(tests/golden/make_golden.py::make_vilbert; text heads d=64, visual and co-attention heads d=128 as in the real config).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from oracle.visual_bert_oracle import layer_norm
+
+DEFAULT_CONFIG = dict(
+    vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+    max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
+    attention_probs_dropout_prob=0.1, pad_token_id=0, v_feature_size=2048, v_hidden_size=1024, v_num_hidden_layers=6,
+    v_num_attention_heads=8, v_intermediate_size=1024, bi_hidden_size=1024, bi_num_attention_heads=8,
+    v_attention_probs_dropout_prob=0.1, v_hidden_dropout_prob=0.1, v_biattention_id=[0, 1, 2, 3, 4, 5],
+    t_biattention_id=[6, 7, 8, 9, 10, 11], fusion_method="mul", num_labels=3129,
+)
+
+
+def _layer_shapes(s, p, H, I):
+    for n in ("query", "key", "value"):
+        s[p + "attention.self.%s.weight" % n] = (H, H)
+        s[p + "attention.self.%s.bias" % n] = (H,)
+    s[p + "attention.output.dense.weight"] = (H, H)
+    s[p + "attention.output.dense.bias"] = (H,)
+    s[p + "attention.output.LayerNorm.weight"] = (H,)
+    s[p + "attention.output.LayerNorm.bias"] = (H,)
+    s[p + "intermediate.dense.weight"] = (I, H)
+    s[p + "intermediate.dense.bias"] = (I,)
+    s[p + "output.dense.weight"] = (H, I)
+    s[p + "output.dense.bias"] = (H,)
+    s[p + "output.LayerNorm.weight"] = (H,)
+    s[p + "output.LayerNorm.bias"] = (H,)
+
+
+def parameter_shapes(cfg):
+    H, I, VH, VI, BH = (cfg["hidden_size"], cfg["intermediate_size"], cfg["v_hidden_size"], cfg["v_intermediate_size"],
+                        cfg["bi_hidden_size"])
+    s = OrderedDict()
+    e = "bert.embeddings."
+    s[e + "word_embeddings.weight"] = (cfg["vocab_size"], H)
+    s[e + "position_embeddings.weight"] = (cfg["max_position_embeddings"], H)
+    s[e + "token_type_embeddings.weight"] = (cfg["type_vocab_size"], H)
+    s[e + "LayerNorm.weight"] = (H,)
+    s[e + "LayerNorm.bias"] = (H,)
+    v = "bert.v_embeddings."
+    s[v + "image_embeddings.weight"] = (VH, cfg["v_feature_size"])
+    s[v + "image_embeddings.bias"] = (VH,)
+    s[v + "image_location_embeddings.weight"] = (VH, 5)
+    s[v + "image_location_embeddings.bias"] = (VH,)
+    s[v + "LayerNorm.weight"] = (VH,)
+    s[v + "LayerNorm.bias"] = (VH,)
+    for i in range(cfg["num_hidden_layers"]):
+        _layer_shapes(s, "bert.encoder.layer.%d." % i, H, I)
+    for i in range(cfg["v_num_hidden_layers"]):
+        _layer_shapes(s, "bert.encoder.v_layer.%d." % i, VH, VI)
+    for i in range(len(cfg["v_biattention_id"])):
+        p = "bert.encoder.c_layer.%d." % i
+        for n, din in (("query1", VH), ("key1", VH), ("value1", VH), ("query2", H), ("key2", H), ("value2", H)):
+            s[p + "biattention.%s.weight" % n] = (BH, din)
+            s[p + "biattention.%s.bias" % n] = (BH,)
+        for n, dout in (("1", VH), ("2", H)):
+            if n == "2":
+                pass
+            s[p + "biOutput.dense%s.weight" % n] = (dout, BH)
+            s[p + "biOutput.dense%s.bias" % n] = (dout,)
+            s[p + "biOutput.LayerNorm%s.weight" % n] = (dout,)
+            s[p + "biOutput.LayerNorm%s.bias" % n] = (dout,)
+            s[p + "biOutput.q_dense%s.weight" % n] = (dout, BH)      # declared, never used (vilbert.py:486,493)
+            s[p + "biOutput.q_dense%s.bias" % n] = (dout,)
+        s[p + "v_intermediate.dense.weight"] = (VI, VH)
+        s[p + "v_intermediate.dense.bias"] = (VI,)
+        s[p + "v_output.dense.weight"] = (VH, VI)
+        s[p + "v_output.dense.bias"] = (VH,)
+        s[p + "v_output.LayerNorm.weight"] = (VH,)
+        s[p + "v_output.LayerNorm.bias"] = (VH,)
+        s[p + "t_intermediate.dense.weight"] = (I, H)
+        s[p + "t_intermediate.dense.bias"] = (I,)
+        s[p + "t_output.dense.weight"] = (H, I)
+        s[p + "t_output.dense.bias"] = (H,)
+        s[p + "t_output.LayerNorm.weight"] = (H,)
+        s[p + "t_output.LayerNorm.bias"] = (H,)
+    s["bert.t_pooler.dense.weight"] = (BH, H)
+    s["bert.t_pooler.dense.bias"] = (BH,)
+    s["bert.v_pooler.dense.weight"] = (BH, VH)
+    s["bert.v_pooler.dense.bias"] = (BH,)
+    s["classifier.0.dense.weight"] = (BH, BH)
+    s["classifier.0.dense.bias"] = (BH,)
+    s["classifier.0.LayerNorm.weight"] = (BH,)
+    s["classifier.0.LayerNorm.bias"] = (BH,)
+    s["classifier.1.weight"] = (cfg["num_labels"], BH)
+    s["classifier.1.bias"] = (cfg["num_labels"],)
+    return s
+
+
+def _heads(x, n):
+    B, S, Hd = x.shape
+    return x.view(B, S, n, Hd // n).permute(0, 2, 1, 3)   # transpose_for_scores, :66-72
+
+
+def attention(q, k, v, n_heads, ext_mask, dropout_p):
+    """scores = Q K^T / sqrt(d) + mask ; softmax ; dropout ; P V ; merge heads   (:89-104, :217-236, :418-452)."""
+    ql, kl, vl = _heads(q, n_heads), _heads(k, n_heads), _heads(v, n_heads)
+    scores = torch.matmul(ql, kl.transpose(-1, -2)) / math.sqrt(ql.shape[-1])
+    scores = scores + ext_mask
+    probs = F.dropout(F.softmax(scores, dim=-1), dropout_p, training=dropout_p > 0)
+    ctx = torch.matmul(probs, vl).permute(0, 2, 1, 3).contiguous()
+    return ctx.view(ctx.shape[0], ctx.shape[1], -1)
+
+
+def stream_layer(sd, p, n_heads, hidden, ext_mask, hidden_dropout, attn_dropout, eps=1e-12):
+    """BertLayer.forward :138-146 (text) and BertImageLayer.forward :320-332 (visual, dynamic_attention off): the HF
+    BertSelfOutput / BertIntermediate / BertOutput blocks and their Image twins (:250-310) are the same arithmetic."""
+    lin = lambda x, n: F.linear(x, sd[p + n + ".weight"], sd[p + n + ".bias"])
+    ctx = attention(lin(hidden, "attention.self.query"), lin(hidden, "attention.self.key"), lin(hidden, "attention.self.value"),
+                    n_heads, ext_mask, attn_dropout)
+    a = F.dropout(lin(ctx, "attention.output.dense"), hidden_dropout, training=hidden_dropout > 0)
+    a = layer_norm(a + hidden, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], eps)
+    h = F.gelu(lin(a, "intermediate.dense"))
+    o = F.dropout(lin(h, "output.dense"), hidden_dropout, training=hidden_dropout > 0)
+    return layer_norm(o + a, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
+
+
+def connection_layer(sd, cfg, i, img, img_mask, txt, txt_mask, train):
+    """BertConnectionLayer.forward :528-556 = BertBiAttention :388-475 + BertBiOutput :496-512 + the two FFNs."""
+    p = "bert.encoder.c_layer.%d." % i
+    lin = lambda x, n: F.linear(x, sd[p + n + ".weight"], sd[p + n + ".bias"])
+    nh = cfg["bi_num_attention_heads"]
+    vd = cfg["v_hidden_dropout_prob"] if train else 0.0
+    td = cfg["hidden_dropout_prob"] if train else 0.0
+    vad = cfg["v_attention_probs_dropout_prob"] if train else 0.0
+    tad = cfg["attention_probs_dropout_prob"] if train else 0.0
+    # text queries over image keys/values -> context_layer1 (goes to the TEXT stream); mask = image mask (:418-436)
+    ctx1 = attention(lin(txt, "biattention.query2"), lin(img, "biattention.key1"), lin(img, "biattention.value1"), nh, img_mask, vad)
+    # image queries over text keys/values -> context_layer2 (goes to the IMAGE stream); mask = text mask (:438-457)
+    ctx2 = attention(lin(img, "biattention.query1"), lin(txt, "biattention.key2"), lin(txt, "biattention.value2"), nh, txt_mask, tad)
+    # biOutput(bi_output2, input_tensor1, bi_output1, input_tensor2), :538-540
+    a1 = F.dropout(lin(ctx2, "biOutput.dense1"), vd, training=vd > 0)
+    a2 = F.dropout(lin(ctx1, "biOutput.dense2"), td, training=td > 0)
+    a1 = layer_norm(a1 + img, sd[p + "biOutput.LayerNorm1.weight"], sd[p + "biOutput.LayerNorm1.bias"], 1e-12)
+    a2 = layer_norm(a2 + txt, sd[p + "biOutput.LayerNorm2.weight"], sd[p + "biOutput.LayerNorm2.bias"], 1e-12)
+    h1 = F.gelu(lin(a1, "v_intermediate.dense"))
+    o1 = F.dropout(lin(h1, "v_output.dense"), vd, training=vd > 0)
+    o1 = layer_norm(o1 + a1, sd[p + "v_output.LayerNorm.weight"], sd[p + "v_output.LayerNorm.bias"], 1e-12)
+    h2 = F.gelu(lin(a2, "t_intermediate.dense"))
+    o2 = F.dropout(lin(h2, "t_output.dense"), td, training=td > 0)
+    o2 = layer_norm(o2 + a2, sd[p + "t_output.LayerNorm.weight"], sd[p + "t_output.LayerNorm.bias"], cfg["layer_norm_eps"])
+    return o1, o2
+
+
+def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False):
+    """BertEncoder.forward :590-796 with fixed_t_layer = fixed_v_layer = 0, with_coattention, no batch expansion."""
+    td = cfg["hidden_dropout_prob"] if train else 0.0
+    tad = cfg["attention_probs_dropout_prob"] if train else 0.0
+    vd = cfg["v_hidden_dropout_prob"] if train else 0.0
+    vad = cfg["v_attention_probs_dropout_prob"] if train else 0.0
+    t_layer = lambda i, x: stream_layer(sd, "bert.encoder.layer.%d." % i, cfg["num_attention_heads"], x, txt_mask, td, tad,
+                                        cfg["layer_norm_eps"])
+    v_layer = lambda i, x: stream_layer(sd, "bert.encoder.v_layer.%d." % i, cfg["v_num_attention_heads"], x, img_mask, vd, vad)
+    v_start = t_start = 0
+    for count, (v_end, t_end) in enumerate(zip(cfg["v_biattention_id"], cfg["t_biattention_id"])):
+        for i in range(t_start, t_end):
+            txt = t_layer(i, txt)
+        for i in range(v_start, v_end):
+            img = v_layer(i, img)
+        img, txt = connection_layer(sd, cfg, count, img, img_mask, txt, txt_mask, train)
+        v_start, t_start = v_end, t_end
+    for i in range(v_start, cfg["v_num_hidden_layers"]):
+        img = v_layer(i, img)
+    for i in range(t_start, cfg["num_hidden_layers"]):
+        txt = t_layer(i, txt)
+    return txt, img
+
+
+def vilbert_base(sd, cfg, input_txt, image_feature, image_location, token_type_ids, attention_mask, image_attention_mask,
+                 train=False):
+    """ViLBERTBase.forward :936-1051."""
+    if attention_mask is None:
+        attention_mask = torch.ones_like(input_txt)
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(input_txt)
+    if image_attention_mask is None:
+        image_attention_mask = torch.ones(image_feature.size(0), image_feature.size(1)).type_as(input_txt)
+    ext_t = (1.0 - attention_mask[:, None, None, :].to(torch.float32)) * -10000.0            # :988-1000
+    ext_v = (1.0 - image_attention_mask[:, None, None, :].to(torch.float32)) * -10000.0      # :1009
+    hd = cfg["hidden_dropout_prob"] if train else 0.0
+    e = "bert.embeddings."
+    T = input_txt.size(1)
+    pos = torch.arange(T, device=input_txt.device).unsqueeze(0).expand(input_txt.shape)
+    txt = (F.embedding(input_txt, sd[e + "word_embeddings.weight"], padding_idx=cfg.get("pad_token_id", 0))
+           + F.embedding(token_type_ids, sd[e + "token_type_embeddings.weight"])
+           + F.embedding(pos, sd[e + "position_embeddings.weight"]))                          # HF BertEmbeddings
+    txt = F.dropout(layer_norm(txt, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], cfg["layer_norm_eps"]), hd, training=hd > 0)
+    v = "bert.v_embeddings."
+    img = (F.linear(image_feature, sd[v + "image_embeddings.weight"], sd[v + "image_embeddings.bias"])
+           + F.linear(image_location, sd[v + "image_location_embeddings.weight"], sd[v + "image_location_embeddings.bias"]))  # :905-910
+    img = F.dropout(layer_norm(img, sd[v + "LayerNorm.weight"], sd[v + "LayerNorm.bias"], 1e-12), hd, training=hd > 0)     # :911
+    seq_t, seq_v = encoder(sd, cfg, txt, img, ext_t, ext_v, train)
+    pooled_t = F.relu(F.linear(seq_t[:, 0], sd["bert.t_pooler.dense.weight"], sd["bert.t_pooler.dense.bias"]))   # :805-811
+    pooled_v = F.relu(F.linear(seq_v[:, 0], sd["bert.v_pooler.dense.weight"], sd["bert.v_pooler.dense.bias"]))   # :820-826
+    return seq_t, seq_v, pooled_t, pooled_v
+
+
+def prepare_inputs(sample_list):
+    """ViLBERT.get_image_and_text_features :1364-1418 (non-nlvr2) + the mask of :1431-1443."""
+    info = sample_list.get("image_info_0", None) or {}
+    feats = sample_list["image_feature_0"]
+    image_dim = info.get("max_features", None)
+    image_mask = None
+    if feats is not None and image_dim is not None:
+        image_mask = torch.arange(feats.size(-2), device=feats.device).expand(*feats.size()[:-1])
+        if image_dim.dim() < image_mask.dim():
+            image_dim = image_dim.unsqueeze(-1)
+        image_mask = (image_mask < image_dim).long()
+    return dict(input_ids=sample_list["input_ids"], attention_mask=sample_list["input_mask"],
+                token_type_ids=sample_list["segment_ids"], image_feature=feats, image_location=info.get("bbox", None),
+                image_attention_mask=image_mask)
+
+
+def vilbert_forward(sd, cfg, sample_list, train=False):
+    """ViLBERT.forward :1423-1446 -> ViLBERTForClassification.forward :1281-1333."""
+    p = prepare_inputs(sample_list)
+    seq_t, seq_v, pooled_t, pooled_v = vilbert_base(sd, cfg, p["input_ids"], p["image_feature"], p["image_location"],
+                                                    p["token_type_ids"], p["attention_mask"], p["image_attention_mask"], train)
+    fused = pooled_t * pooled_v if cfg.get("fusion_method", "mul") == "mul" else pooled_t + pooled_v   # :1315-1320
+    hd = cfg["hidden_dropout_prob"] if train else 0.0
+    x = F.dropout(fused, hd, training=hd > 0)
+    x = F.gelu(F.linear(x, sd["classifier.0.dense.weight"], sd["classifier.0.dense.bias"]))
+    x = layer_norm(x, sd["classifier.0.LayerNorm.weight"], sd["classifier.0.LayerNorm.bias"], cfg["layer_norm_eps"])
+    logits = F.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])
+    return {"scores": logits.contiguous().view(-1, cfg["num_labels"]), "sequence_output_t": seq_t, "sequence_output_v": seq_v,
+            "pooled_output_t": pooled_t, "pooled_output_v": pooled_v}

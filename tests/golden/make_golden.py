@@ -355,11 +355,150 @@ def make_mmft():
         print(name, "loss", loss.item(), "scores", rec["scores"][0], "->", path, os.path.getsize(path), "bytes")
 
 
+VILBERT_CASES = {
+    # text stream d=64, visual + co-attention streams d=128 (as in the real config: 768/12, 1024/8, 1024/8)
+    "vilbert_small": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=4,
+                          v_hidden_size=256, v_num_attention_heads=2, v_intermediate_size=192, v_num_hidden_layers=3,
+                          bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
+                          v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=211, max_position_embeddings=40,
+                          v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=41),
+}
+
+
+def vilbert_reference_config(c):
+    return OmegaConf.create(dict(
+        bert_model_name=None, training_head_type="classification", visual_embedding_dim=c["v_feature_size"],
+        special_visual_initialize=True, hard_cap_seq_len=None, cut_first="text", embedding_strategy="plain",
+        bypass_transformer=False, output_attentions=False, output_hidden_states=False, text_only=False, random_initialize=False,
+        freeze_base=False, finetune_lr_multiplier=1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12, hidden_act="gelu",
+        hidden_dropout_prob=0.1, hidden_size=c["hidden_size"], initializer_range=0.02, intermediate_size=c["intermediate_size"],
+        max_position_embeddings=c["max_position_embeddings"], num_attention_heads=c["num_attention_heads"],
+        num_hidden_layers=c["num_hidden_layers"], type_vocab_size=2, vocab_size=c["vocab_size"],
+        v_feature_size=c["v_feature_size"], v_target_size=1601, v_hidden_size=c["v_hidden_size"],
+        v_num_hidden_layers=c["v_num_hidden_layers"], v_num_attention_heads=c["v_num_attention_heads"],
+        v_intermediate_size=c["v_intermediate_size"], bi_hidden_size=c["bi_hidden_size"],
+        bi_num_attention_heads=c["bi_num_attention_heads"], bi_intermediate_size=c["bi_intermediate_size"], bi_attention_type=1,
+        v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.1, v_initializer_range=0.02,
+        v_biattention_id=c["v_biattention_id"], t_biattention_id=c["t_biattention_id"], pooling_method="mul", fusion_method="mul",
+        fast_mode=False, with_coattention=True, dynamic_attention=False, in_batch_pairs=False, task_specific_tokens=False,
+        fixed_v_layer=0, fixed_t_layer=0, visualization=False, visual_target=0, objective=0, num_negative=128, model="vilbert",
+        num_labels=c["num_labels"], losses=[dict(type="logit_bce")]))
+
+
+def make_vilbert():
+    """ViLBERT (two streams + co-attention, classification head) through the reference's own ViLBERT.forward /
+    get_image_and_text_features, ViLBERTForClassification.forward, ViLBERTBase, BertEncoder, BertConnectionLayer,
+    BertBiAttention, BertImageLayer, ... (mmf/models/vilbert.py).  Only `ViLBERTBase.from_pretrained` (network) is replaced
+    by constructing `ViLBERTBase(config)` directly."""
+    from copy import deepcopy
+    from torch import nn
+    from transformers import BertConfig
+    M = refshim.ref_import("mmf.models.vilbert")
+    from transformers.models.bert.modeling_bert import BertPredictionHeadTransform
+    # replace_with_jit() (vilbert.py:920) monkey-patches HF's own BertSelfAttention / BertLayer / BertEncoder for
+    # TorchScript; ViLBERT never calls those classes (it defines its own attention) and the patch targets methods that the
+    # installed transformers no longer has.
+    M.replace_with_jit = lambda: None
+
+    for name, c in VILBERT_CASES.items():
+        torch.manual_seed(c["seed"])
+        cfg = vilbert_reference_config(c)
+        bcfg = BertConfig.from_dict(OmegaConf.to_container(cfg))
+
+        class RefCls(nn.Module):   # module tree of ViLBERTForClassification (vilbert.py:1243-1270)
+            def __init__(self):
+                super().__init__()
+                self.config = cfg
+                self.bert = M.ViLBERTBase(bcfg)
+                self.training_head_type = "classification"
+                self.num_labels = c["num_labels"]
+                self.fusion_method = "mul"
+                self.dropout = nn.Dropout(0.1)
+                ccfg = deepcopy(bcfg)
+                ccfg.hidden_size = c["bi_hidden_size"]
+                self.classifier = nn.Sequential(BertPredictionHeadTransform(ccfg), nn.Linear(ccfg.hidden_size, c["num_labels"]))
+
+            forward = M.ViLBERTForClassification.forward
+
+        class RefViLBERT(nn.Module):   # the registered BaseModel: `model.*`
+            def __init__(self):
+                super().__init__()
+                self.config = cfg
+                self.model = RefCls()
+
+            get_image_and_text_features = M.ViLBERT.get_image_and_text_features
+            forward = M.ViLBERT.forward
+
+        ref = RefViLBERT().eval()
+        shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+                  if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")}
+        sd = detweights.state_dict(shapes, c["seed"])
+        missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected, unexpected
+        B, T, R, seed = c["B"], c["T"], c["R"], c["seed"]
+        ids = (detweights.uniform(B * T, seed + 100) * c["vocab_size"]).astype(np.int64).reshape(B, T)
+        mask = np.ones((B, T), dtype=np.int64)
+        mask[1, T // 2:] = 0
+        mask[2, T - 3:] = 0
+        ids[mask == 0] = 0   # [PAD]
+        seg = np.zeros((B, T), dtype=np.int64)
+        feats = detweights.uniform(B * R * c["v_feature_size"], seed + 102).astype(np.float32).reshape(B, R, -1)
+        bbox = detweights.uniform(B * R * 5, seed + 104).astype(np.float32).reshape(B, R, 5)
+        max_features = np.array([R, R - 2, R - 1], dtype=np.int64)[:B]
+        targets = np.zeros((B, c["num_labels"]), dtype=np.float32)
+        for b in range(B):
+            targets[b, (3 * b + 1) % c["num_labels"]] = 1.0
+            targets[b, (5 * b + 2) % c["num_labels"]] = 0.6
+        sl = SampleList(input_ids=torch.from_numpy(ids), input_mask=torch.from_numpy(mask), segment_ids=torch.from_numpy(seg),
+                        image_feature_0=torch.from_numpy(feats),
+                        image_info_0=SampleList(max_features=torch.from_numpy(max_features), bbox=torch.from_numpy(bbox)),
+                        targets=torch.from_numpy(targets), dataset_name="vqa2", dataset_type="train")
+        holder = {}
+        orig = ref.model.bert.forward
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            holder["t"], holder["v"], holder["pt"], holder["pv"] = out[0], out[1], out[2], out[3]
+            return out
+
+        ref.model.bert.forward = spy
+        out = ref(sl)
+        loss = LogitBinaryCrossEntropy()(sl, out)
+        loss.backward()
+        rec = {"in_input_ids": ids, "in_input_mask": mask, "in_segment_ids": seg, "in_image_feature_0": feats, "in_bbox": bbox,
+               "in_max_features": max_features, "in_targets": targets}
+        rec["scores"] = out["scores"].detach().numpy()
+        rec["sequence_output_t"] = holder["t"].detach().numpy()
+        rec["sequence_output_v"] = holder["v"].detach().numpy()
+        rec["pooled_output_t"] = holder["pt"].detach().numpy()
+        rec["pooled_output_v"] = holder["pv"].detach().numpy()
+        rec["loss"] = np.array(loss.item(), dtype=np.float64)
+        names, norms, sums = [], [], []
+        for k, p in ref.named_parameters():
+            g = p.grad
+            names.append(k)
+            norms.append(0.0 if g is None else float(g.double().norm()))
+            sums.append(0.0 if g is None else float(g.double().sum()))
+            if g is not None and g.numel() <= 4096:
+                rec["grad::" + k] = g.numpy()
+        rec["grad_names"] = np.array(names)
+        rec["grad_norms"] = np.array(norms)
+        rec["grad_sums"] = np.array(sums)
+        rec["param_names"] = np.array(list(shapes.keys()))
+        rec["param_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
+        rec["case"] = np.array(repr(c))
+        path = os.path.join(HERE, "%s.npz" % name)
+        np.savez_compressed(path, **rec)
+        print(name, "loss", loss.item(), "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "mmbt", "mmft"]
+    which = sys.argv[1:] or ["visual_bert", "mmbt", "mmft", "vilbert"]
     if "visual_bert" in which:
         main()
     if "mmbt" in which:
         make_mmbt()
     if "mmft" in which:
         make_mmft()
+    if "vilbert" in which:
+        make_vilbert()

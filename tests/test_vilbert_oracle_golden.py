@@ -1,0 +1,37 @@
+"""Pins oracle/vilbert_oracle.py against the fixture produced by the REAL reference ViLBERT path (ViLBERT.forward ->
+ViLBERTForClassification.forward -> ViLBERTBase -> BertEncoder / BertConnectionLayer / BertBiAttention ... + logit_bce);
+see tests/golden/make_golden.py::make_vilbert."""
+import numpy as np
+import torch
+
+from oracle import vilbert_oracle as O
+from oracle.visual_bert_oracle import logit_bce
+from tests.golden_utils import load_vilbert_case
+
+
+def test_vilbert_oracle_matches_reference_forward_loss_and_gradients():
+    z, case, cfg, sd, sample = load_vilbert_case()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.vilbert_forward(sd, cfg, dict(sample), train=False)
+    np.testing.assert_allclose(out["scores"].detach().numpy(), z["scores"], rtol=1e-5, atol=5e-6)
+    for k in ("sequence_output_t", "sequence_output_v", "pooled_output_t", "pooled_output_v"):
+        np.testing.assert_allclose(out[k].detach().numpy(), z[k], rtol=1e-5, atol=1e-5, err_msg=k)
+    loss = logit_bce(out["scores"], sample["targets"])
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    checked = 0
+    for gname, norm, gsum in zip(z["grad_names"], z["grad_norms"], z["grad_sums"]):
+        key = str(gname)[len("model."):]
+        g = sd[key].grad
+        if norm == 0.0:   # biOutput.q_dense1/2 are declared but never used (vilbert.py:486,493)
+            assert "q_dense" in key and (g is None or float(g.abs().max()) == 0.0), key
+            continue
+        checked += 1
+        assert g is not None, key
+        assert abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+        assert abs(float(g.double().sum()) - gsum) <= 1e-4 * norm + 1e-7, key
+        full = "grad::" + str(gname)
+        if full in z.files:
+            np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
+    assert checked == len(sd) - 8

@@ -98,8 +98,9 @@ int mmf_gemm_splitk_splits(int M, int N, int K);
 /* ---- fused multi-head attention -------------------------------------------------------------
  * Replaces BertSelfAttentionJit.forward, mmf/modules/hf_layers.py:161-213 (scores = QK^T /
  * sqrt(d) + mask; softmax; dropout; PV; head merge) without materialising the [B,A,S,S] tensors,
- * and its autograd backward.  head_dim is 64.  q/k/v/ctx are token-major: element (b, s, head, e)
- * at ptr[(b*S + s)*ld + head*64 + e]  (for the packed QKV projection output: q = qkv, k = qkv+H,
+ * and its autograd backward.  head_dim is 64 (Sq, Sk <= 256) or 128 (Sq, Sk <= 128: the visual and co-attention
+ * streams of mmf/models/vilbert.py:153-247,347-475; q and k/v may come from different sequences, Sq != Sk).
+ * q/k/v/ctx are token-major: element (b, s, head, e) at ptr[(b*S + s)*ld + head*head_dim + e]  (for the packed QKV projection output: q = qkv, k = qkv+H,
  * v = qkv+2H, ld = 3H).  `mask` is the ADDITIVE key mask of visual_bert.py:94-106, shape [B, Sk]
  * fp32 (0 or -10000), or NULL.  lse[b][head][s] = log-sum-exp of the masked, scaled scores row.
  * Dropout element index: ((b*heads + head)*Sq + q)*Sk_pad + key with Sk_pad = round_up(Sk, 32).
@@ -119,6 +120,9 @@ typedef struct mmf_attn_desc {
     uint32_t drop_thr16;
     float drop_scale;
     const uint32_t* drop_seed;
+    int head_dim;   /* 0 = 64 */
+    float* ctx_f32; /* optional fp32 copy of ctx (layout of ctx, ldo): forward writes it, backward then forms
+                       delta = rowsum(dO o O) from the unrounded O, which keeps sum_key dS = 0 to fp32 accuracy */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
 
@@ -213,6 +217,9 @@ int mmf_seed_advance(uint32_t* seed, void* stream);
 /* du = dh * g with g = gelu_erf'(u) as saved by the forward epilogue (act == 1): backward of HF
  * BertIntermediate's activation when it is not fused into a dgrad GEMM epilogue (act == 2). */
 int mmf_gelu_bwd_bf16(const void* dh, const void* g, void* du, int64_t n, void* stream);
+/* Pointwise bf16 ops of ViLBERT's poolers and stream fusion (mmf/models/vilbert.py:799-826, 1315-1320):
+ * op 0: out = a * b; op 1: out = relu(a); op 2: out = a * (b > 0) (ReLU backward, b = forward output). */
+int mmf_eltwise_bf16(int op, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* dx = dy * (1 - y^2): backward of the tanh in HF BertPooler (mmf/models/mmbt.py:311), y = saved output. */
 int mmf_tanh_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
 int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -47,6 +47,7 @@ class AttnDesc(C.Structure):
         ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int),
         ("scale", C.c_float),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
+        ("head_dim", C.c_int), ("ctx_f32", C.c_void_p),
     ]
 
 
@@ -188,7 +189,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
 # --------------------------------------------------------------------------------------------
 # attention
 # --------------------------------------------------------------------------------------------
-def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop):
+def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim=64, ctx_f32=None):
     d = AttnDesc()
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):
         _req(t, torch.bfloat16, n)
@@ -199,18 +200,21 @@ def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, sc
     d.B, d.heads, d.Sq, d.Sk = B, heads, Sq, Sk
     d.scale = scale
     d.drop_key, d.drop_thr16, d.drop_scale, d.drop_seed = _drop4(drop)
+    d.head_dim = head_dim
+    _req(ctx_f32, torch.float32, "ctx_f32")
+    d.ctx_f32 = _p(ctx_f32)
     return d
 
 
-def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP):
-    d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop)
+def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP, head_dim=64, ctx_f32=None):
+    d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32)
     _check(lib().mmf_attention_fwd(C.byref(d), _stream()), "mmf_attention_fwd")
 
 
 def attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta,
-                  drop=NO_DROP):
+                  drop=NO_DROP, head_dim=64, ctx_f32=None):
     d = AttnBwdDesc()
-    d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop)
+    d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32)
     for t, n in ((dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, torch.bfloat16, n)
     _req(delta, torch.float32, "delta")
@@ -336,6 +340,11 @@ def gelu_bwd(dh, u, du):
     for t, nme in ((dh, "dh"), (u, "u"), (du, "du")):
         _req(t, torch.bfloat16, nme)
     _check(lib().mmf_gelu_bwd_bf16(_p(dh), _p(u), _p(du), C.c_int64(dh.numel()), _stream()), "mmf_gelu_bwd_bf16")
+
+
+def eltwise(op, a, b, out):
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(out, torch.bfloat16, "out")
+    _check(lib().mmf_eltwise_bf16(int(op), _p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "mmf_eltwise_bf16")
 
 
 def tanh_bwd(dy, y, dx):

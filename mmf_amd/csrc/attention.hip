@@ -1,4 +1,5 @@
-// mmf_amd :: fused multi-head attention forward / backward for gfx950 (head_dim 64, Sk <= 256).
+// mmf_amd :: fused multi-head attention forward / backward for gfx950 (head_dim 64 with Sk <= 256, or head_dim 128 —
+// ViLBERT's visual and co-attention streams, mmf/models/vilbert.py:153-247,347-475 — with Sq, Sk <= 128).
 //
 // Replaces BertSelfAttentionJit.forward (mmf/modules/hf_layers.py:161-213):
 //     scores = Q K^T / sqrt(d) + mask ; probs = softmax(scores) ; probs = dropout(probs) ;
@@ -26,25 +27,34 @@
 
 namespace {
 
-constexpr int HD = 64;            // head dim
+// Row-major LDS image of a [rows][D] bf16 matrix: 2D bytes per row, 16-byte chunks XOR-swizzled so that both access
+// patterns are bank-conflict free: 16 lanes reading the same logical chunk of 16 different rows (frag_rm), and 32 lanes
+// reading a 4-row x 4-chunk block (the transpose read in frag_tr).  With 128-byte rows (D = 64) two consecutive rows
+// cover all 64 banks, so the swizzle advances every second row; with 256-byte rows (D = 128) every row starts on bank
+// 0: rows differ in the 64-byte window ((row & 3) << 2) and, across groups of four rows, in the chunk within it.
+template <int D> DEVI int swz(int row);
+template <> DEVI int swz<64>(int row) { return (row >> 1) & 7; }
+template <> DEVI int swz<128>(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+template <int D> DEVI int rm_off(int row, int chunk) { return row * (2 * D) + ((chunk ^ swz<D>(row)) << 4); }
 
-DEVI int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// Stage rows [0, npad) of a token-major [rows][64] bf16 matrix (row stride ld) into a row-major swizzled LDS image by
-// LDS-DMA (global_load_lds_dwordx4): one wave-instruction fills 8 rows (1 KiB, lane-linear), so the chunk swizzle is
-// applied to each lane's SOURCE address.  Rows >= nvalid read a 16-byte zero buffer.  All DMAs of a tile are issued
-// back to back; the caller waits once (s_waitcnt vmcnt(0) + barrier).  npad is a multiple of 32.
+// Stage rows [0, npad) of a token-major [rows][D] bf16 matrix (row stride ld) into the swizzled LDS image by LDS-DMA
+// (global_load_lds_dwordx4): one wave-instruction fills 1 KiB lane-linear (8 rows at D = 64, 4 rows at D = 128), so
+// the chunk swizzle is applied to each lane's SOURCE address.  Rows >= nvalid read a 16-byte zero buffer.  All DMAs
+// of a tile are issued back to back; the caller waits once (s_waitcnt vmcnt(0) + barrier).  npad is a multiple of 32.
 static __device__ uint4 g_zero16;
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
+template <int D>
 DEVI void stage_rows(const bf16* g, int ld, int nvalid, int npad, unsigned char* lds_rm, int tid) {
+    constexpr int CPR = D / 8;          // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;       // rows per wave-instruction
     const int wave = tid >> 6, lane = tid & 63;
-    for (int r0 = wave * 8; r0 < npad; r0 += 32) {
-        const int row = r0 + (lane >> 3);
-        const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    for (int r0 = wave * RPI; r0 < npad; r0 += 4 * RPI) {
+        const int row = r0 + lane / CPR;
+        const int logical = (lane % CPR) ^ swz<D>(row);
         const bf16* src = (row < nvalid) ? g + (size_t)row * ld + logical * 8 : reinterpret_cast<const bf16*>(&g_zero16);
-        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds_rm + r0 * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds_rm + r0 * (2 * D)), 16, 0, 0);
     }
 }
 DEVI void stage_wait() {
@@ -53,8 +63,9 @@ DEVI void stage_wait() {
 }
 
 // feature-reduction operand from a row-major LDS image: tile row x (absolute row = row0 + x), step s
+template <int D>
 DEVI bf16x8 frag_rm(const unsigned char* lds_rm, int row0, int s, int lane) {
-    return *reinterpret_cast<const bf16x8*>(lds_rm + rm_off(row0 + (lane & 31), 2 * s + (lane >> 5)));
+    return *reinterpret_cast<const bf16x8*>(lds_rm + rm_off<D>(row0 + (lane & 31), 2 * s + (lane >> 5)));
 }
 // feature-reduction operand straight from global memory (one row per lane, clamped by caller)
 DEVI bf16x8 frag_global(const bf16* rowptr, int s, int lane) {
@@ -63,13 +74,14 @@ DEVI bf16x8 frag_global(const bf16* rowptr, int s, int lane) {
 // index-reduction operand by hardware transpose read (ds_read_b64_tr_b16) from a ROW-MAJOR image: slot (h, e) of
 // lane x receives M[idx0 + 16u + 4h + (e&3) + 8(e>>2)][d0 + x].  A 16-lane group reads a 4-row x 16-column block
 // (lane p addresses row p>>2, 8 bytes at column 4(p&3)) and lane i of the group gets column i of the 4 rows.
+template <int D>
 DEVI bf16x8 frag_tr(const unsigned char* lds_rm, int d0, int idx0, int u, int lane) {
     const int g = lane >> 4, p = lane & 15;
     const int row = idx0 + 16 * u + 4 * (g >> 1) + (p >> 2);
     const int c = d0 + 16 * (g & 1) + (p & 3) * 4;
     typedef s16x4 __attribute__((address_space(3))) * lds_p;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_rm + rm_off(row, c >> 3) + (c & 7) * 2));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_rm + rm_off(row + 8, c >> 3) + (c & 7) * 2));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_rm + rm_off<D>(row, c >> 3) + (c & 7) * 2));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_rm + rm_off<D>(row + 8, c >> 3) + (c & 7) * 2));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     s16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
@@ -89,8 +101,9 @@ struct AttnArgs {
     int ldq, ldk, ldv;
     const float* mask;
     bf16* ctx; int ldo;
+    float* ctx32;        // optional fp32 copy of ctx (same ldo): makes delta = rowsum(dO o O) exact in backward
     float* lse;
-    int B, heads, Sq, Sk, skp;
+    int B, heads, Sq, Sk, skp, hd;
     float scale;
     DropoutCfg drop;
     // backward only
@@ -100,12 +113,13 @@ struct AttnArgs {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+template <int NKT, int D>
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* lds_k = smem;                         // row-major K  [NKT*32][64]
-    unsigned char* lds_v = smem + NKT * 32 * 128;        // row-major V  [NKT*32][64]
-    float* lds_mask = reinterpret_cast<float*>(lds_v + NKT * 32 * 128);  // [NKT*32]
+    unsigned char* lds_k = smem;                         // row-major K  [NKT*32][D]
+    unsigned char* lds_v = smem + NKT * 32 * ROWB;       // row-major V  [NKT*32][D]
+    float* lds_mask = reinterpret_cast<float*>(lds_v + NKT * 32 * ROWB);  // [NKT*32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 31, h = lane >> 5;
@@ -115,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
-    stage_rows(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
-    stage_rows(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
+    stage_rows<D>(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
+    stage_rows<D>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
     for (int i = tid; i < SKP; i += 256)   // additive mask, already in the log2 domain
         lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
     stage_wait();
@@ -125,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // Q fragments (B operand: column = query row)
     const int qrow = min(q0 + x, a.Sq - 1);
     const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
-    bf16x8 qf[4];
+    bf16x8 qf[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = frag_global(qptr, s, lane);
+    for (int s = 0; s < NS; ++s) qf[s] = frag_global(qptr, s, lane);
 
     // scores^T tiles: sc[t][r] = S[q = q0+x][key = 32t + (r&3) + 8(r>>2) + 4h]
     f32x16 sc[NKT];
@@ -135,8 +149,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int t = 0; t < NKT; ++t) {
         f32x16 acc = {};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_k, 32 * t, s, lane), qf[s], acc, 0, 0, 0);
+        for (int s = 0; s < NS; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_k, 32 * t, s, lane), qf[s], acc, 0, 0, 0);
         sc[t] = acc;
     }
 
@@ -185,25 +199,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 
     // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
-    f32x16 o[2] = {};
+    f32x16 o[NDT] = {};
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bf16x8 pf = frag_regs(sc[t], u);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_v, 32 * dt, 32 * t, u, lane), pf, o[dt], 0, 0, 0);
+            for (int dt = 0; dt < NDT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_v, 32 * dt, 32 * t, u, lane), pf, o[dt], 0, 0, 0);
         }
 
     if (q0 + x < a.Sq) {
         bf16* optr = a.ctx + ((size_t)b * a.Sq + q0 + x) * a.ldo + head * HD;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 *reinterpret_cast<bf16x4*>(optr + 32 * dt + 8 * c + 4 * h) =
                     pack4(o[dt][4 * c + 0] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv);
+        if (a.ctx32) {
+            float* o32 = a.ctx32 + ((size_t)b * a.Sq + q0 + x) * a.ldo + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<float4*>(o32 + 32 * dt + 8 * c + 4 * h) =
+                        make_float4(o[dt][4 * c + 0] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv);
+        }
     }
 }
 
@@ -213,9 +236,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 //   dV = Pd^T dO ; dPd = dO V^T ; dS = P o (dropscale o dPd - delta), delta = rowsum(dO o O)
 //   dQ = dS K * scale ; dK = dS^T Q * scale
 // =================================================================================================
-// delta[b][head][q] = sum_d dO[b,q,head,d] * O[b,q,head,d].  One wave per token row, 16 lanes per head.
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ dO, int ldo,
-                                                          float* __restrict__ delta, int B, int Sq, int heads) {
+// delta[b][head][q] = sum_d dO[b,q,head,d] * O[b,q,head,d].  One wave per token row, head_dim/4 lanes per head.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const float* __restrict__ o32,
+                                                          const bf16* __restrict__ dO, int ldo, float* __restrict__ delta, int B, int Sq,
+                                                          int heads, int HD) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B * Sq) return;
@@ -225,14 +249,21 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
         const int col = c0 + lane * 4;
         float acc = 0.f;
         if (col < H) {
-            const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(o + (size_t)row * ldo + col);
             const bf16x4 x2 = *reinterpret_cast<const bf16x4*>(dO + (size_t)row * ldo + col);
+            if (o32) {
+                // exact O: sum_key dS[q][key] = 0 then holds to fp32 rounding, so the common component of K (e.g. the key
+                // bias) cannot leak into dQ -- with a bf16 O it does, at 2^-9 |dO||O| per row
+                const float4 x1 = *reinterpret_cast<const float4*>(o32 + (size_t)row * ldo + col);
+                acc = x1.x * (float)x2[0] + x1.y * (float)x2[1] + x1.z * (float)x2[2] + x1.w * (float)x2[3];
+            } else {
+                const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(o + (size_t)row * ldo + col);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc += (float)x1[i] * (float)x2[i];
+                for (int i = 0; i < 4; ++i) acc += (float)x1[i] * (float)x2[i];
+            }
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if ((lane & 15) == 0 && col < H) {
+        const int lph = HD / 4;   // lanes per head: 16 (d = 64) or 32 (d = 128)
+        for (int off = lph / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((lane & (lph - 1)) == 0 && col < H) {
             const int head = col / HD;
             delta[((size_t)b * heads + head) * Sq + q] = acc;
         }
@@ -240,13 +271,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 // dQ kernel: same decomposition as the forward (wave = 32 query rows, all keys).
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int NKT, int D>
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SKP = NKT * 32;
     unsigned char* lds_k = smem;                               // row-major K
-    unsigned char* lds_v = lds_k + SKP * 128;                  // row-major V
-    float* lds_mask = reinterpret_cast<float*>(lds_v + SKP * 128);
+    unsigned char* lds_v = lds_k + SKP * ROWB;                 // row-major V
+    float* lds_mask = reinterpret_cast<float*>(lds_v + SKP * ROWB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 31, h = lane >> 5;
@@ -255,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
     const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
-    stage_rows(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
-    stage_rows(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
+    stage_rows<D>(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
+    stage_rows<D>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
     for (int i = tid; i < SKP; i += 256)   // additive mask in the log2 domain
         lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
     stage_wait();
@@ -265,22 +297,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int qrow = min(q0 + x, a.Sq - 1);
     const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
     const bf16* doptr = a.dctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
-    bf16x8 qf[4], dof[4];
+    bf16x8 qf[NS], dof[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { qf[s] = frag_global(qptr, s, lane); dof[s] = frag_global(doptr, s, lane); }
+    for (int s = 0; s < NS; ++s) { qf[s] = frag_global(qptr, s, lane); dof[s] = frag_global(doptr, s, lane); }
     const float L = a.lse[(size_t)bh * a.Sq + qrow] * 1.4426950408889634f;   // log2 domain
     const float sc2 = a.scale * 1.4426950408889634f;
     const float dl = a.delta[(size_t)bh * a.Sq + qrow];
     const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
 
-    f32x16 dqo[2] = {};
+    f32x16 dqo[NDT] = {};
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         f32x16 s_acc = {}, dp_acc = {};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_k, 32 * t, s, lane), qf[s], s_acc, 0, 0, 0);
-            dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_v, 32 * t, s, lane), dof[s], dp_acc, 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_k, 32 * t, s, lane), qf[s], s_acc, 0, 0, 0);
+            dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_v, 32 * t, s, lane), dof[s], dp_acc, 0, 0, 0);
         }
         // dS^T[key][q] (scaled by `scale` for the dQ product)
 #pragma unroll
@@ -300,14 +332,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int u = 0; u < 2; ++u) {
             const bf16x8 df = frag_regs(s_acc, u);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                dqo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_k, 32 * dt, 32 * t, u, lane), df, dqo[dt], 0, 0, 0);
+            for (int dt = 0; dt < NDT; ++dt)
+                dqo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_k, 32 * dt, 32 * t, u, lane), df, dqo[dt], 0, 0, 0);
         }
     }
     if (q0 + x < a.Sq) {
         bf16* optr = a.dq + ((size_t)b * a.Sq + q0 + x) * a.ldq + head * HD;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 *reinterpret_cast<bf16x4*>(optr + 32 * dt + 8 * c + 4 * h) =
@@ -316,13 +348,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // dK/dV kernel: wave = 32 key rows, loops over all query tiles.
-template <int NQT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int NQT, int D>
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SQP = NQT * 32;
     unsigned char* lds_q = smem;                               // row-major Q
-    unsigned char* lds_do = lds_q + SQP * 128;                 // row-major dO
-    float* lds_lse = reinterpret_cast<float*>(lds_do + SQP * 128);   // [SQP]
+    unsigned char* lds_do = lds_q + SQP * ROWB;                // row-major dO
+    float* lds_lse = reinterpret_cast<float*>(lds_do + SQP * ROWB);  // [SQP]
     float* lds_delta = lds_lse + SQP;                                 // [SQP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -333,8 +366,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     const bf16* qbase = a.q + (size_t)b * a.Sq * a.ldq + head * HD;
     const bf16* dobase = a.dctx + (size_t)b * a.Sq * a.ldo + head * HD;
-    stage_rows(qbase, a.ldq, a.Sq, SQP, lds_q, tid);
-    stage_rows(dobase, a.ldo, a.Sq, SQP, lds_do, tid);
+    stage_rows<D>(qbase, a.ldq, a.Sq, SQP, lds_q, tid);
+    stage_rows<D>(dobase, a.ldo, a.Sq, SQP, lds_do, tid);
     for (int i = tid; i < SQP; i += 256) {
         // padded query rows: lse = +inf -> p = exp(-inf) = 0, so they contribute nothing
         lds_lse[i] = (i < a.Sq) ? a.lse[(size_t)bh * a.Sq + i] * 1.4426950408889634f : INFINITY;   // log2 domain
@@ -347,21 +380,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bool kvalid = (k0 + x) < a.Sk;
     const bf16* kptr = a.k + ((size_t)b * a.Sk + krow) * a.ldk + head * HD;
     const bf16* vptr = a.v + ((size_t)b * a.Sk + krow) * a.ldv + head * HD;
-    bf16x8 kf[4], vf[4];
+    bf16x8 kf[NS], vf[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
+    for (int s = 0; s < NS; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
     const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
     const float sc2 = a.scale * 1.4426950408889634f;
 
-    f32x16 dko[2] = {}, dvo[2] = {};
+    f32x16 dko[NDT] = {}, dvo[NDT] = {};
 #pragma unroll 1
     for (int t = 0; t < NQT; ++t) {
         // S[q][key], dPd[q][key]: rows q = 32t + (r&3)+8(r>>2)+4h, column key = k0 + x
         f32x16 s_acc = {}, dp_acc = {};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_q, 32 * t, s, lane), kf[s], s_acc, 0, 0, 0);
-            dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(lds_do, 32 * t, s, lane), vf[s], dp_acc, 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_q, 32 * t, s, lane), kf[s], s_acc, 0, 0, 0);
+            dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_do, 32 * t, s, lane), vf[s], dp_acc, 0, 0, 0);
         }
         f32x16 pd;  // dropout(P) for dV
 #pragma unroll
@@ -388,9 +421,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             const bf16x8 pf = frag_regs(pd, u);
             const bf16x8 df = frag_regs(s_acc, u);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dvo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_do, 32 * dt, 32 * t, u, lane), pf, dvo[dt], 0, 0, 0);
-                dko[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(lds_q, 32 * dt, 32 * t, u, lane), df, dko[dt], 0, 0, 0);
+            for (int dt = 0; dt < NDT; ++dt) {
+                dvo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_do, 32 * dt, 32 * t, u, lane), pf, dvo[dt], 0, 0, 0);
+                dko[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_q, 32 * dt, 32 * t, u, lane), df, dko[dt], 0, 0, 0);
             }
         }
     }
@@ -398,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         bf16* dkptr = a.dk + ((size_t)b * a.Sk + k0 + x) * a.ldk + head * HD;
         bf16* dvptr = a.dv + ((size_t)b * a.Sk + k0 + x) * a.ldv + head * HD;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 *reinterpret_cast<bf16x4*>(dkptr + 32 * dt + 8 * c + 4 * h) =
@@ -412,13 +445,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     MMF_CHECK_ARG(d && d->q && d->k && d->v, "attention: null operand");
     MMF_CHECK_ARG(d->B > 0 && d->heads > 0 && d->Sq > 0 && d->Sk > 0, "attention: empty shape");
+    const int hd = d->head_dim ? d->head_dim : 64;
+    MMF_CHECK_ARG(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
     MMF_CHECK_ARG(d->Sk <= 256 && d->Sq <= 256, "attention: Sq and Sk must be <= 256 in this build");
+    MMF_CHECK_ARG(hd == 64 || (d->Sk <= 128 && d->Sq <= 128), "attention: head_dim 128 is built for Sq, Sk <= 128");
     MMF_CHECK_ARG((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0 && (d->ldo % 8) == 0,
                   "attention: leading dimensions must be multiples of 8 elements");
     a.q = (const bf16*)d->q; a.k = (const bf16*)d->k; a.v = (const bf16*)d->v;
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv;
-    a.mask = d->mask; a.ctx = (bf16*)d->ctx; a.ldo = d->ldo; a.lse = d->lse;
-    a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk;
+    a.mask = d->mask; a.ctx = (bf16*)d->ctx; a.ldo = d->ldo; a.lse = d->lse; a.ctx32 = d->ctx_f32;
+    a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk; a.hd = hd;
     a.skp = (d->Sk + 31) / 32 * 32;
     a.scale = d->scale;
     a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
@@ -442,13 +478,13 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nkt = a.skp / 32;
     const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
-#define LAUNCH_FWD(N)                                                                            \
+#define LAUNCH_FWD(N, DD)                                                                        \
     {                                                                                            \
-        const int lds = 2 * N * 32 * 128 + N * 32 * 4;                                           \
-        if (int rc = set_lds(attn_fwd_kernel<N>, lds)) return rc;                                \
-        hipLaunchKernelGGL(attn_fwd_kernel<N>, grid, dim3(256), lds, s, a);                      \
+        const int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4;                                      \
+        if (int rc = set_lds(attn_fwd_kernel<N, DD>, lds)) return rc;                            \
+        hipLaunchKernelGGL((attn_fwd_kernel<N, DD>), grid, dim3(256), lds, s, a);                \
     }
-    if (nkt <= 4) LAUNCH_FWD(4) else LAUNCH_FWD(8)
+    if (a.hd == 128) LAUNCH_FWD(4, 128) else if (nkt <= 4) LAUNCH_FWD(4, 64) else LAUNCH_FWD(8, 64)
 #undef LAUNCH_FWD
     MMF_CHECK_LAUNCH();
     return 0;
@@ -462,33 +498,33 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     a.dctx = (const bf16*)d->dctx; a.dq = (bf16*)d->dq; a.dk = (bf16*)d->dk; a.dv = (bf16*)d->dv; a.delta = d->delta;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((a.B * a.Sq + 3) / 4), dim3(256), 0, s, a.ctx, a.dctx, a.ldo, a.delta,
-                       a.B, a.Sq, a.heads);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((a.B * a.Sq + 3) / 4), dim3(256), 0, s, a.ctx, a.ctx32, a.dctx, a.ldo, a.delta,
+                       a.B, a.Sq, a.heads, a.hd);
     MMF_CHECK_LAUNCH();
 
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;
     {
         const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
-#define LAUNCH_DQ(N)                                                                             \
+#define LAUNCH_DQ(N, DD)                                                                         \
     {                                                                                            \
-        const int lds = 2 * N * 32 * 128 + N * 32 * 4;                                           \
-        if (int rc = set_lds(attn_bwd_dq_kernel<N>, lds)) return rc;                             \
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<N>, grid, dim3(256), lds, s, a);                   \
+        const int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4;                                      \
+        if (int rc = set_lds(attn_bwd_dq_kernel<N, DD>, lds)) return rc;                         \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<N, DD>), grid, dim3(256), lds, s, a);             \
     }
-        if (nkt <= 4) LAUNCH_DQ(4) else LAUNCH_DQ(8)
+        if (a.hd == 128) LAUNCH_DQ(4, 128) else if (nkt <= 4) LAUNCH_DQ(4, 64) else LAUNCH_DQ(8, 64)
 #undef LAUNCH_DQ
         MMF_CHECK_LAUNCH();
     }
     {
         const dim3 grid(a.B * a.heads, (a.Sk + 127) / 128);
-#define LAUNCH_DKV(N)                                                                            \
+#define LAUNCH_DKV(N, DD)                                                                        \
     {                                                                                            \
-        const int lds = 2 * N * 32 * 128 + 2 * N * 32 * 4;                                       \
-        if (int rc = set_lds(attn_bwd_dkv_kernel<N>, lds)) return rc;                            \
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<N>, grid, dim3(256), lds, s, a);                  \
+        const int lds = 2 * N * 32 * (2 * DD) + 2 * N * 32 * 4;                                  \
+        if (int rc = set_lds(attn_bwd_dkv_kernel<N, DD>, lds)) return rc;                        \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, DD>), grid, dim3(256), lds, s, a);            \
     }
-        if (nqt <= 4) LAUNCH_DKV(4) else LAUNCH_DKV(8)
+        if (a.hd == 128) LAUNCH_DKV(4, 128) else if (nqt <= 4) LAUNCH_DKV(4, 64) else LAUNCH_DKV(8, 64)
 #undef LAUNCH_DKV
         MMF_CHECK_LAUNCH();
     }

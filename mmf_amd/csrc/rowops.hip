@@ -422,6 +422,18 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ 
         else for (int64_t j = i; j < n; ++j) du[j] = (bf16)((float)dh[j] * (float)g[j]);
     }
 }
+// small pointwise ops on bf16 vectors: 0: a*b   1: relu(a)   2: a * (b > 0)   (ViLBERT poolers / fusion, vilbert.py:799-826,1315-1320)
+__global__ __launch_bounds__(256) void eltwise_kernel(int op, const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out,
+                                                       int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = (float)a[i];
+    float r;
+    if (op == 0) r = x * (float)b[i];
+    else if (op == 1) r = x > 0.f ? x : 0.f;
+    else r = ((float)b[i] > 0.f) ? x : 0.f;
+    out[i] = (bf16)r;
+}
 // dx = dy * (1 - y^2): backward of tanh (HF BertPooler)
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dx, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -835,6 +847,13 @@ int mmf_gelu_bwd_bf16(const void* dh, const void* u, void* du, int64_t n, void* 
     MMF_CHECK_ARG(dh && u && du && n > 0, "gelu_bwd: bad operand");
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh, (const bf16*)u,
                        (bf16*)du, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_eltwise_bf16(int op, const void* a, const void* b, void* out, int64_t n, void* stream) {
+    MMF_CHECK_ARG(a && out && n > 0 && op >= 0 && op <= 2 && (op == 1 || b), "eltwise: bad operand");
+    hipLaunchKernelGGL(eltwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, (const bf16*)a,
+                       (const bf16*)b, (bf16*)out, n);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -242,7 +242,17 @@ def linear(x, weight, bias, out_f32=False):
 # ---------------------------------------------------------------------------------------------
 # self attention (QKV projection + fused attention)
 # ---------------------------------------------------------------------------------------------
-def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop):
+# Keep an fp32 copy of the attention output for the backward's delta = rowsum(dO o O): with the bf16 O the rows of dS sum
+# to ~2^-9 |dO||O| instead of 0 and the common component of K / Q (their biases) leaks into dQ / dK.  Costs one extra
+# [tokens, H] fp32 write in forward and read in backward per layer (~0.7 % of a VisualBERT step).
+EXACT_ATTENTION_DELTA = True
+
+
+def _o32(M, H, dev, need):
+    return torch.empty(M, H, dtype=F32, device=dev) if (need and EXACT_ATTENTION_DELTA) else None
+
+
+def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True):
     M, H = x2.shape
     dev = x2.device
     qkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
@@ -250,18 +260,20 @@ def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop):
     ctxt = torch.empty(M, H, dtype=BF16, device=dev)
     lse = torch.empty(B, heads, S, dtype=F32, device=dev)
     scale = 1.0 / math.sqrt(H // heads)
-    nat.attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale, drop)
-    return qkv, ctxt, lse
+    o32 = _o32(M, H, dev, need_bwd)
+    nat.attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale, drop,
+                      head_dim=H // heads, ctx_f32=o32)
+    return qkv, ctxt, lse, o32
 
 
-def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True):
+def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True, o32=None):
     M, H = x2.shape
     dev = x2.device
     dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
     delta = torch.empty(B, heads, S, dtype=F32, device=dev)
     scale = 1.0 / math.sqrt(H // heads)
     nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
-                      dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop)
+                      dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32)
     dx, dw = _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid)
     db = _colsum(dqkv, 3 * H, M, 3 * H)
     return dx, dw, db
@@ -274,17 +286,17 @@ class SelfAttentionFn(torch.autograd.Function):
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, wqkv16, bqkv, mask_add, heads, drop):
         B, S, H = x.shape
         x2 = _as_bf16_2d(x)
-        qkv, ctxt, lse = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop)
-        ctx.save_for_backward(x2, qkv, ctxt, lse, wqkv16, mask_add)
+        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, any(ctx.needs_input_grad))
+        ctx.save_for_backward(x2, qkv, ctxt, lse, wqkv16, mask_add, o32)
         ctx.meta = (B, S, H, heads, drop)
         return ctxt.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        x2, qkv, ctxt, lse, wqkv16, mask_add = ctx.saved_tensors
+        x2, qkv, ctxt, lse, wqkv16, mask_add, o32 = ctx.saved_tensors
         B, S, H, heads, drop = ctx.meta
         dx, dw, db = _attn_bwd(_grad_bf16(g, H), x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop,
-                               need_dx=ctx.needs_input_grad[0])
+                               need_dx=ctx.needs_input_grad[0], o32=o32)
         return ((dx.view(B, S, H) if dx is not None else None), dw[:H], db[:H], dw[H:2 * H], db[H:2 * H], dw[2 * H:], db[2 * H:],
                 None, None, None, None, None)
 
@@ -380,20 +392,20 @@ class AttentionBlockFn(torch.autograd.Function):
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, wqkv16, bqkv, wo16, mask_add, heads, eps, drop_attn, drop_hid):
         B, S, H = x.shape
         x2 = _as_bf16_2d(x)
-        qkv, ctxt, lse = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn)
+        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad))
         out, y, mean, rstd = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), gamma.detach(), beta.detach(), eps, drop_hid)
-        ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add, o32)
         ctx.meta = (B, S, H, heads, drop_attn, drop_hid)
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add = ctx.saved_tensors
+        x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add, o32 = ctx.saved_tensors
         B, S, H, heads, drop_attn, drop_hid = ctx.meta
         M = B * S
         dres, dlin, dgamma, dbeta, dbo = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
         dctx, dwo = _linear_bwd(dlin, H, ctxt, wo16, M, H, H)
-        dx, dwqkv, dbqkv = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres)
+        dx, dwqkv, dbqkv = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32)
         return (dx.view(B, S, H), dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
                 dwo, dbo, dgamma, dbeta, None, None, None, None, None, None, None, None)
 
@@ -790,3 +802,163 @@ class ConcatRowsFn(torch.autograd.Function):
             outs.append(d.view(B, L, H))
             off += L
         return tuple(outs)
+
+
+# ---------------------------------------------------------------------------------------------
+# ViLBERT pieces (mmf/models/vilbert.py)
+# ---------------------------------------------------------------------------------------------
+class BiAttentionFn(torch.autograd.Function):
+    """BertBiAttention.forward (vilbert.py:388-475): text queries over image keys/values (context_layer1, image mask,
+    dropout1) and image queries over text keys/values (context_layer2, text mask, dropout2).  Each stream's Q|K|V is one
+    packed GEMM; the two cross attentions read the other stream's K and V straight out of its packed buffer."""
+
+    @staticmethod
+    def forward(ctx, img, txt, q1w, q1b, k1w, k1b, v1w, v1b, q2w, q2b, k2w, k2b, v2w, v2b, w1_16, b1, w2_16, b2,
+                img_mask_add, txt_mask_add, heads, drop1, drop2):
+        """q1w .. v2b are the reference's six separate projections (autograd leaves); w*_16 / b* their packed shadows."""
+        B, R, VH = img.shape
+        T, H = txt.shape[1], txt.shape[2]
+        BH = w1_16.shape[0] // 3
+        hd = BH // heads
+        i2, t2 = _as_bf16_2d(img), _as_bf16_2d(txt)
+        dev = i2.device
+        qkv1 = torch.empty(B * R, 3 * BH, dtype=BF16, device=dev)
+        qkv2 = torch.empty(B * T, 3 * BH, dtype=BF16, device=dev)
+        nat.gemm(i2, w1_16, qkv1, B * R, 3 * BH, VH, VH, VH, 3 * BH, bias=b1)
+        nat.gemm(t2, w2_16, qkv2, B * T, 3 * BH, H, H, H, 3 * BH, bias=b2)
+        scale = 1.0 / math.sqrt(hd)
+        ctx1 = torch.empty(B * T, BH, dtype=BF16, device=dev)
+        lse1 = torch.empty(B, heads, T, dtype=F32, device=dev)
+        need = any(ctx.needs_input_grad)
+        o1, o2 = _o32(B * T, BH, dev, need), _o32(B * R, BH, dev, need)
+        nat.attention_fwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, img_mask_add, ctx1, BH, lse1, B, heads, T, R,
+                          scale, drop1, head_dim=hd, ctx_f32=o1)
+        ctx2 = torch.empty(B * R, BH, dtype=BF16, device=dev)
+        lse2 = torch.empty(B, heads, R, dtype=F32, device=dev)
+        nat.attention_fwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add, ctx2, BH, lse2, B, heads, R, T,
+                          scale, drop2, head_dim=hd, ctx_f32=o2)
+        ctx.save_for_backward(i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1_16, w2_16, img_mask_add, txt_mask_add, o1, o2)
+        ctx.meta = (B, R, T, VH, H, BH, heads, drop1, drop2)
+        return ctx1.view(B, T, BH), ctx2.view(B, R, BH)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1_16, w2_16, img_mask_add, txt_mask_add, o1, o2 = ctx.saved_tensors
+        B, R, T, VH, H, BH, heads, drop1, drop2 = ctx.meta
+        hd = BH // heads
+        dev = i2.device
+        scale = 1.0 / math.sqrt(hd)
+        dqkv1 = torch.empty(B * R, 3 * BH, dtype=BF16, device=dev)
+        dqkv2 = torch.empty(B * T, 3 * BH, dtype=BF16, device=dev)
+        delta1 = torch.empty(B, heads, T, dtype=F32, device=dev)
+        delta2 = torch.empty(B, heads, R, dtype=F32, device=dev)
+        nat.attention_bwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, img_mask_add, ctx1, BH, lse1, B, heads, T, R,
+                          scale, _grad_bf16(g1, BH), dqkv2, dqkv1[:, BH:], dqkv1[:, 2 * BH:], delta1, drop1, head_dim=hd, ctx_f32=o1)
+        nat.attention_bwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add, ctx2, BH, lse2, B, heads, R, T,
+                          scale, _grad_bf16(g2, BH), dqkv1, dqkv2[:, BH:], dqkv2[:, 2 * BH:], delta2, drop2, head_dim=hd, ctx_f32=o2)
+        dimg, dw1 = _linear_bwd(dqkv1, 3 * BH, i2, w1_16, B * R, 3 * BH, VH)
+        dtxt, dw2 = _linear_bwd(dqkv2, 3 * BH, t2, w2_16, B * T, 3 * BH, H)
+        db1 = _colsum(dqkv1, 3 * BH, B * R, 3 * BH)
+        db2 = _colsum(dqkv2, 3 * BH, B * T, 3 * BH)
+        return (dimg.view(B, R, VH), dtxt.view(B, T, H),
+                dw1[:BH], db1[:BH], dw1[BH:2 * BH], db1[BH:2 * BH], dw1[2 * BH:], db1[2 * BH:],
+                dw2[:BH], db2[:BH], dw2[BH:2 * BH], db2[BH:2 * BH], dw2[2 * BH:], db2[2 * BH:],
+                None, None, None, None, None, None, None, None, None)
+
+
+class ImageFeatureEmbeddingsFn(torch.autograd.Function):
+    """BertImageFeatureEmbeddings.forward (vilbert.py:904-913): LayerNorm(Linear(features) + Linear(5-d location)),
+    dropout.  The 5-wide location operand is zero-padded to 8 columns (16-byte rows for the GEMM loader) and its GEMM
+    adds the feature projection in the epilogue."""
+
+    @staticmethod
+    def forward(ctx, feats, loc, w_img, b_img, w_loc, b_loc, ln_w, ln_b, w_img16, eps, drop):
+        B, R, D = feats.shape
+        VH = w_img16.shape[0]
+        M = B * R
+        dev = w_img.device
+        f2 = feats.reshape(M, D)
+        if f2.dtype not in (F32, BF16):
+            f2 = f2.float()
+        f2 = f2.contiguous()
+        KL = loc.shape[-1]
+        KP = _pad8(KL)
+        l8 = torch.empty(M, KP, dtype=BF16, device=dev)
+        nat.cast2d_f32_to_bf16(loc.reshape(M, KL).float().contiguous(), KL, l8, KP, M, KL)
+        wl8 = torch.empty(VH, KP, dtype=BF16, device=dev)
+        nat.cast2d_f32_to_bf16(w_loc.detach().contiguous(), KL, wl8, KP, VH, KL)
+        y0 = torch.empty(M, VH, dtype=BF16, device=dev)
+        nat.gemm(f2, w_img16, y0, M, VH, D, D, D, VH, bias=b_img.detach())
+        y = torch.empty(M, VH, dtype=BF16, device=dev)
+        nat.gemm(l8, wl8, y, M, VH, KP, KP, KP, VH, bias=b_loc.detach(), resid=y0, ldr=VH)
+        out = torch.empty(M, VH, dtype=BF16, device=dev)
+        mean = torch.empty(M, dtype=F32, device=dev)
+        rstd = torch.empty(M, dtype=F32, device=dev)
+        nat.layernorm_fwd(y, ln_w.detach(), ln_b.detach(), out, mean, rstd, M, VH, eps)
+        if drop[1]:
+            o2 = torch.empty_like(out)
+            nat.dropout(out, o2, drop)
+            out = o2
+        ctx.save_for_backward(f2, l8, y, mean, rstd, ln_w.detach())
+        ctx.meta = (B, R, D, VH, KL, KP, drop)
+        return out.view(B, R, VH)
+
+    @staticmethod
+    def backward(ctx, g):
+        f2, l8, y, mean, rstd, ln_w = ctx.saved_tensors
+        B, R, D, VH, KL, KP, drop = ctx.meta
+        M = B * R
+        dev = y.device
+        dy = _grad_bf16(g, VH)
+        if drop[1]:
+            d2 = torch.empty_like(dy)
+            nat.dropout(dy, d2, drop)
+            dy = d2
+        dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, nat.NO_DROP, False)
+        dw_img = torch.empty(VH, D, dtype=F32, device=dev)
+        nat.gemm(dpre, f2, dw_img, VH, D, M, VH, D, D, a_kmajor=True, b_kmajor=True)
+        dwl8 = torch.empty(VH, KP, dtype=F32, device=dev)
+        nat.gemm(dpre, l8, dwl8, VH, KP, M, VH, KP, KP, a_kmajor=True, b_kmajor=True)
+        db = _colsum(dpre, VH, M, VH)
+        return (None, None, dw_img, db, dwl8[:, :KL].contiguous(), db.clone(), dgamma, dbeta, None, None, None)
+
+
+class EltwiseMulFn(torch.autograd.Function):
+    """pooled_output_t * pooled_output_v (vilbert.py:1318)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a2, b2 = _as_bf16_2d(a), _as_bf16_2d(b)
+        out = torch.empty_like(a2)
+        nat.eltwise(0, a2, b2, out)
+        ctx.save_for_backward(a2, b2)
+        return out.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        g2 = _grad_bf16(g, g.shape[-1])
+        da, db = torch.empty_like(a2), torch.empty_like(b2)
+        nat.eltwise(0, g2, b2, da)
+        nat.eltwise(0, g2, a2, db)
+        return da.view(g.shape), db.view(g.shape)
+
+
+class ReluFn(torch.autograd.Function):
+    """nn.ReLU of the ViLBERT poolers (vilbert.py:803,818)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x2 = _as_bf16_2d(x)
+        y = torch.empty_like(x2)
+        nat.eltwise(1, x2, None, y)
+        ctx.save_for_backward(y)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g2 = _grad_bf16(g, g.shape[-1])
+        d = torch.empty_like(y)
+        nat.eltwise(2, g2, y, d)
+        return d.view(g.shape)

@@ -1,0 +1,379 @@
+"""ViLBERT behind MMF's model API on the gfx950 kernels (BASELINE.json configs[2]).
+
+Mirrors mmf/models/vilbert.py: `BertImageFeatureEmbeddings` (:891-913), `BertBiAttention` (:347-475), `BertBiOutput`
+(:478-512), `BertConnectionLayer` (:515-556), `BertEncoder` (:559-796), `BertTextPooler` / `BertImagePooler` (:799-826),
+`ViLBERTBase` (:916-1051), `ViLBERTForClassification` (:1243-1333) and the registered `ViLBERT(BaseModel)` (:1336-1472):
+same config keys, same `forward(sample_list) -> {"scores": [B, num_labels]}`, and the reference's parameter tree
+(`model.bert.embeddings.*`, `.v_embeddings.*`, `.encoder.{layer,v_layer,c_layer}.*`, `.t_pooler`, `.v_pooler`,
+`model.classifier.*`, including the never-used `biOutput.q_dense{1,2}`), so MMF checkpoints load unmodified.
+
+MI355X-first internals: the text / visual stream layers are the same two fused autograd nodes as VisualBERT's layers
+(the visual stream and the co-attention run the head_dim-128 build of the attention kernel); a connection layer is one
+bi-attention node (two packed Q|K|V GEMMs + two cross attentions that read the other stream's K, V in place), two
+dense+dropout+residual+LayerNorm nodes and two feed-forward nodes.
+
+Not built (raise): the pretraining heads (:1054-1240), `nlvr2` pairing, `dynamic_attention` gates (:204-216),
+`in_batch_pairs` / `fast_mode` batch expansion (:684-735), `task_specific_tokens`, `fixed_{t,v}_layer` > 0 and
+attention-map outputs (`visualization`, `output_all_attention_masks`: the fused kernel never materialises them).
+"""
+import torch
+from torch import nn
+
+from mmf_amd import functional as Fn
+from mmf_amd.common.registry import registry
+from mmf_amd.models.base_model import BaseModel
+from mmf_amd.modules.hf_layers import (
+    BertConfig, BertEmbeddingsJit, BertIntermediate, BertLayerJit, BertOutput, BertPredictionHeadTransform, LayerNorm, Linear,
+    init_bert_weights)
+from mmf_amd.utils.configuration import to_container
+from mmf_amd.utils.modeling import get_optimizer_parameters_for_bert
+
+
+def _stream_config(config, prefix):
+    """BertConfig view of one stream: '' = text (hidden_size, ...), 'v_' = visual (v_hidden_size, ...)."""
+    g = lambda k, d=None: getattr(config, prefix + k, getattr(config, k, d))
+    return BertConfig(hidden_size=g("hidden_size"), num_attention_heads=g("num_attention_heads"),
+                      intermediate_size=g("intermediate_size"), hidden_dropout_prob=g("hidden_dropout_prob"),
+                      attention_probs_dropout_prob=g("attention_probs_dropout_prob"), hidden_act=g("hidden_act", "gelu"),
+                      layer_norm_eps=1e-12 if prefix else getattr(config, "layer_norm_eps", 1e-12))
+
+
+def _additive_mask(mask):
+    m = mask.contiguous().long()
+    out = torch.empty(m.shape, dtype=torch.float32, device=m.device)
+    Fn.nat.make_additive_mask(m, out)      # (1 - m) * -10000, vilbert.py:1000,1009
+    return out
+
+
+class BertImageFeatureEmbeddings(nn.Module):
+    """vilbert.py:891-913."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.image_embeddings = Linear(config.v_feature_size, config.v_hidden_size)
+        self.image_location_embeddings = Linear(5, config.v_hidden_size)
+        self.LayerNorm = LayerNorm(config.v_hidden_size, eps=1e-12)
+        self.dropout_prob = config.hidden_dropout_prob
+
+    def forward(self, image_feature, image_location):
+        ie, le = self.image_embeddings, self.image_location_embeddings
+        return Fn.ImageFeatureEmbeddingsFn.apply(image_feature, image_location, ie.weight, ie.bias, le.weight, le.bias,
+                                                 self.LayerNorm.weight, self.LayerNorm.bias, Fn.shadows.get(ie.weight),
+                                                 self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training))
+
+
+class BertBiAttention(nn.Module):
+    """vilbert.py:347-475."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.bi_hidden_size % config.bi_num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)" % (
+                config.bi_hidden_size, config.bi_num_attention_heads))
+        self.num_attention_heads = config.bi_num_attention_heads
+        self.attention_head_size = config.bi_hidden_size // config.bi_num_attention_heads
+        if self.attention_head_size not in (64, 128):
+            raise ValueError("the gfx950 fused attention kernel is built for head_dim 64 or 128, got %d" % self.attention_head_size)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query1 = Linear(config.v_hidden_size, self.all_head_size)
+        self.key1 = Linear(config.v_hidden_size, self.all_head_size)
+        self.value1 = Linear(config.v_hidden_size, self.all_head_size)
+        self.dropout1_prob = config.v_attention_probs_dropout_prob
+        self.query2 = Linear(config.hidden_size, self.all_head_size)
+        self.key2 = Linear(config.hidden_size, self.all_head_size)
+        self.value2 = Linear(config.hidden_size, self.all_head_size)
+        self.dropout2_prob = config.attention_probs_dropout_prob
+
+    def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
+                use_co_attention_mask=False):
+        """(image, image additive mask [B, R], text, text additive mask [B, T]) -> (context_layer1 [B, T, bi],
+        context_layer2 [B, R, bi], {})."""
+        if use_co_attention_mask:
+            raise NotImplementedError("use_co_attention_mask is dead code in the reference (vilbert.py:421,448) and is not built")
+        s = Fn.shadows
+        w1 = s.get(self.query1.weight, self.key1.weight, self.value1.weight)
+        b1 = s.get(self.query1.bias, self.key1.bias, self.value1.bias, dtype=torch.float32)
+        w2 = s.get(self.query2.weight, self.key2.weight, self.value2.weight)
+        b2 = s.get(self.query2.bias, self.key2.bias, self.value2.bias, dtype=torch.float32)
+        c1, c2 = Fn.BiAttentionFn.apply(
+            input_tensor1, input_tensor2, self.query1.weight, self.query1.bias, self.key1.weight, self.key1.bias,
+            self.value1.weight, self.value1.bias, self.query2.weight, self.query2.bias, self.key2.weight, self.key2.bias,
+            self.value2.weight, self.value2.bias, w1, b1, w2, b2, attention_mask1, attention_mask2, self.num_attention_heads,
+            Fn.make_drop(self.dropout1_prob, self.training), Fn.make_drop(self.dropout2_prob, self.training))
+        return c1, c2, {}
+
+
+class BertBiOutput(nn.Module):
+    """vilbert.py:478-512 (q_dense1 / q_dense2 exist in the reference's parameter tree and are never called)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense1 = Linear(config.bi_hidden_size, config.v_hidden_size)
+        self.LayerNorm1 = LayerNorm(config.v_hidden_size, eps=1e-12)
+        self.dropout1_prob = config.v_hidden_dropout_prob
+        self.q_dense1 = Linear(config.bi_hidden_size, config.v_hidden_size)
+        self.dense2 = Linear(config.bi_hidden_size, config.hidden_size)
+        self.LayerNorm2 = LayerNorm(config.hidden_size, eps=1e-12)
+        self.dropout2_prob = config.hidden_dropout_prob
+        self.q_dense2 = Linear(config.bi_hidden_size, config.hidden_size)
+
+    def forward(self, hidden_states1, input_tensor1, hidden_states2, input_tensor2):
+        out1 = Fn.DenseDropoutResidualLNFn.apply(
+            hidden_states1, input_tensor1, self.dense1.weight, self.dense1.bias, self.LayerNorm1.weight, self.LayerNorm1.bias,
+            Fn.shadows.get(self.dense1.weight), self.LayerNorm1.eps, Fn.make_drop(self.dropout1_prob, self.training))
+        out2 = Fn.DenseDropoutResidualLNFn.apply(
+            hidden_states2, input_tensor2, self.dense2.weight, self.dense2.bias, self.LayerNorm2.weight, self.LayerNorm2.bias,
+            Fn.shadows.get(self.dense2.weight), self.LayerNorm2.eps, Fn.make_drop(self.dropout2_prob, self.training))
+        return out1, out2
+
+
+def _feed_forward(it, ot, x, training):
+    return Fn.FeedForwardFn.apply(x, it.dense.weight, it.dense.bias, ot.dense.weight, ot.dense.bias, ot.LayerNorm.weight,
+                                  ot.LayerNorm.bias, Fn.shadows.get(it.dense.weight), Fn.shadows.get(ot.dense.weight),
+                                  ot.LayerNorm.eps, Fn.make_drop(ot.dropout_prob, training))
+
+
+class BertConnectionLayer(nn.Module):
+    """vilbert.py:515-556."""
+
+    def __init__(self, config):
+        super().__init__()
+        vcfg, tcfg = _stream_config(config, "v_"), _stream_config(config, "")
+        self.biattention = BertBiAttention(config)
+        self.biOutput = BertBiOutput(config)
+        self.v_intermediate = BertIntermediate(vcfg)
+        self.v_output = BertOutput(vcfg)
+        self.t_intermediate = BertIntermediate(tcfg)
+        self.t_output = BertOutput(tcfg)
+
+    def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
+                use_co_attention_mask=False):
+        bi_output1, bi_output2, co_attention_probs = self.biattention(
+            input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask, use_co_attention_mask)
+        attention_output1, attention_output2 = self.biOutput(bi_output2, input_tensor1, bi_output1, input_tensor2)
+        layer_output1 = _feed_forward(self.v_intermediate, self.v_output, attention_output1, self.training)
+        layer_output2 = _feed_forward(self.t_intermediate, self.t_output, attention_output2, self.training)
+        return layer_output1, layer_output2, co_attention_probs
+
+
+class BertEncoder(nn.Module):
+    """vilbert.py:559-796."""
+
+    def __init__(self, config):
+        super().__init__()
+        for flag in ("fast_mode", "in_batch_pairs"):
+            if getattr(config, flag, False):
+                raise NotImplementedError("ViLBERT %s (vilbert.py:684-735) is not built" % flag)
+        if getattr(config, "fixed_t_layer", 0) or getattr(config, "fixed_v_layer", 0):
+            raise NotImplementedError("fixed_t_layer / fixed_v_layer > 0 (no-grad prefix layers, vilbert.py:625-666) are not built")
+        if getattr(config, "dynamic_attention", False):
+            raise NotImplementedError("dynamic_attention gates (vilbert.py:204-216) are not built")
+        self.with_coattention = config.with_coattention
+        self.v_biattention_id = list(config.v_biattention_id)
+        self.t_biattention_id = list(config.t_biattention_id)
+        self.layer = nn.ModuleList([BertLayerJit(_stream_config(config, "")) for _ in range(config.num_hidden_layers)])
+        self.v_layer = nn.ModuleList([BertLayerJit(_stream_config(config, "v_")) for _ in range(config.v_num_hidden_layers)])
+        self.c_layer = nn.ModuleList([BertConnectionLayer(config) for _ in range(len(self.v_biattention_id))])
+
+    def forward(self, txt_embedding, image_embedding, txt_attention_mask, txt_attention_mask2, image_attention_mask,
+                co_attention_mask=None, output_all_encoded_layers=True, output_all_attention_masks=False):
+        """Masks are the additive fp32 key masks [B, T] / [B, R]."""
+        if output_all_attention_masks:
+            raise NotImplementedError("attention maps are never materialised by the fused kernel")
+        v_start = t_start = 0
+        all_t, all_v = [], []
+        for count, (v_end, t_end) in enumerate(zip(self.v_biattention_id, self.t_biattention_id)):
+            for idx in range(t_start, t_end):
+                txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
+            for idx in range(v_start, v_end):
+                image_embedding = self.v_layer[idx](image_embedding, image_attention_mask)[0]
+            if self.with_coattention:
+                image_embedding, txt_embedding, _ = self.c_layer[count](image_embedding, image_attention_mask, txt_embedding,
+                                                                        txt_attention_mask)
+            v_start, t_start = v_end, t_end
+            if output_all_encoded_layers:
+                all_t.append(txt_embedding)
+                all_v.append(image_embedding)
+        for idx in range(v_start, len(self.v_layer)):
+            image_embedding = self.v_layer[idx](image_embedding, image_attention_mask)[0]
+        for idx in range(t_start, len(self.layer)):
+            txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
+        if not output_all_encoded_layers:
+            all_t.append(txt_embedding)
+            all_v.append(image_embedding)
+        return all_t, all_v, ([], [], [])
+
+
+class _ReluPooler(nn.Module):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.dense = Linear(in_dim, out_dim)
+
+    def forward(self, hidden_states):
+        B = hidden_states.shape[0]
+        index = torch.zeros(B, dtype=torch.int64, device=hidden_states.device)
+        first = Fn.GatherRowsFn.apply(hidden_states, index, Fn.nat.NO_DROP)
+        return Fn.ReluFn.apply(self.dense(first))
+
+
+class BertTextPooler(_ReluPooler):
+    """vilbert.py:799-811."""
+
+    def __init__(self, config):
+        super().__init__(config.hidden_size, config.bi_hidden_size)
+
+
+class BertImagePooler(_ReluPooler):
+    """vilbert.py:814-826."""
+
+    def __init__(self, config):
+        super().__init__(config.v_hidden_size, config.bi_hidden_size)
+
+
+class ViLBERTBase(nn.Module):
+    """vilbert.py:916-1051."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if getattr(config, "task_specific_tokens", False):
+            raise NotImplementedError("task_specific_tokens (vilbert.py:977-980) is not built")
+        if getattr(config, "visualization", False):
+            raise NotImplementedError("visualization: the fused attention kernel never materialises the probabilities")
+        self.embeddings = BertEmbeddingsJit(config)
+        self.v_embeddings = BertImageFeatureEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.t_pooler = BertTextPooler(config)
+        self.v_pooler = BertImagePooler(config)
+        self.init_weights()
+
+    def _init_weights(self, module):
+        init_bert_weights(module, self.config.initializer_range)
+
+    def init_weights(self):
+        self.apply(self._init_weights)
+
+    def forward(self, input_txt, image_feature, image_location, token_type_ids=None, attention_mask=None,
+                image_attention_mask=None, co_attention_mask=None, task_ids=None, output_all_encoded_layers=False,
+                output_all_attention_masks=False):
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_txt)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_txt)
+        if image_attention_mask is None:
+            image_attention_mask = torch.ones(image_feature.size(0), image_feature.size(1)).type_as(input_txt)
+        txt_mask_add = _additive_mask(attention_mask)
+        img_mask_add = _additive_mask(image_attention_mask)
+        embedding_output = self.embeddings(input_txt, token_type_ids)
+        v_embedding_output = self.v_embeddings(image_feature, image_location)
+        encoded_layers_t, encoded_layers_v, all_attention_mask = self.encoder(
+            embedding_output, v_embedding_output, txt_mask_add, None, img_mask_add, None,
+            output_all_encoded_layers=output_all_encoded_layers, output_all_attention_masks=output_all_attention_masks)
+        sequence_output_t = encoded_layers_t[-1]
+        sequence_output_v = encoded_layers_v[-1]
+        pooled_output_t = self.t_pooler(sequence_output_t)
+        pooled_output_v = self.v_pooler(sequence_output_v)
+        return (sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v, None,
+                encoded_layers_t if output_all_encoded_layers else None, encoded_layers_v if output_all_encoded_layers else None)
+
+
+class ViLBERTForClassification(nn.Module):
+    """vilbert.py:1243-1333."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bert_config = BertConfig.from_dict({k: v for k, v in to_container(config).items()})
+        for k in ("v_biattention_id", "t_biattention_id"):
+            setattr(self.bert_config, k, list(config[k]))
+        self.bert = ViLBERTBase(self.bert_config)
+        self.training_head_type = self.config.training_head_type
+        if self.training_head_type == "nlvr2":
+            raise NotImplementedError("the nlvr2 pairing head (vilbert.py:1264-1265,1322-1323) is not built")
+        self.num_labels = self.config.num_labels
+        self.fusion_method = config.fusion_method
+        if self.fusion_method not in ("sum", "mul"):
+            raise AssertionError
+        self.dropout_prob = self.config.hidden_dropout_prob
+        ccfg = BertConfig(hidden_size=config.bi_hidden_size, layer_norm_eps=self.bert_config.layer_norm_eps)
+        self.classifier = nn.Sequential(BertPredictionHeadTransform(ccfg), Linear(config.bi_hidden_size, self.num_labels))
+        self.init_weights()
+
+    def init_weights(self):
+        if self.config.get("random_initialize", False) is False:
+            self.classifier.apply(self.bert._init_weights)
+
+    def forward(self, input_ids, image_feature, image_location, token_type_ids=None, attention_mask=None,
+                image_attention_mask=None, masked_lm_labels=None, image_label=None, image_target=None,
+                next_sentence_label=None, output_all_attention_masks=False):
+        (sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v, _, _, _) = self.bert(
+            input_ids, image_feature, image_location, token_type_ids, attention_mask, image_attention_mask,
+            output_all_encoded_layers=False, output_all_attention_masks=output_all_attention_masks)
+        output = {}
+        if self.fusion_method == "mul":
+            fused = Fn.EltwiseMulFn.apply(pooled_output_t, pooled_output_v)
+        else:
+            fused = pooled_output_t + pooled_output_v
+        drop = Fn.make_drop(self.dropout_prob, self.training)
+        pooled_output = Fn.DropoutFn.apply(fused, drop) if drop[1] else fused
+        hidden = self.classifier[0](pooled_output)
+        logits = self.classifier[1](hidden, out_f32=True)
+        output["scores"] = logits.contiguous().view(-1, self.num_labels)
+        return output
+
+
+@registry.register_model("vilbert")
+class ViLBERT(BaseModel):
+    """vilbert.py:1336-1472."""
+
+    def __init__(self, config):
+        super().__init__(config)
+
+    @classmethod
+    def config_path(cls):
+        return "configs/models/vilbert/pretrain.yaml"
+
+    @classmethod
+    def format_state_key(cls, key):
+        return (key.replace("bert.bert", "model.bert").replace("bert.cls", "model.cls")
+                .replace("bert.classifier", "model.classifier"))
+
+    def build(self):
+        if self.config.training_head_type == "pretraining":
+            raise NotImplementedError("ViLBERTForPretraining (vilbert.py:1054-1240) is a later milestone")
+        self.model = ViLBERTForClassification(self.config)
+        if self.config.get("freeze_base", False):
+            for p in self.model.bert.parameters():
+                p.requires_grad = False
+
+    def get_image_and_text_features(self, sample_list):
+        """vilbert.py:1364-1418 (single-image datasets)."""
+        if sample_list.get("dataset_name", None) == "nlvr2":
+            raise NotImplementedError("nlvr2 image pairs (vilbert.py:1369-1394) are not built")
+        image_info = sample_list.get("image_info_0", None) or {}
+        return {
+            "input_ids": sample_list["input_ids"], "attention_mask": sample_list["input_mask"],
+            "token_type_ids": sample_list["segment_ids"], "image_dim": image_info.get("max_features", None),
+            "image_feature": sample_list.get("image_feature_0", None), "image_location": image_info.get("bbox", None),
+            "image_target": None, "image_label": sample_list.get("image_labels", None),
+        }
+
+    def get_optimizer_parameters(self, config):
+        return get_optimizer_parameters_for_bert(self.model, config)
+
+    def forward(self, sample_list):
+        params = self.get_image_and_text_features(sample_list)
+        params["masked_lm_labels"] = sample_list.get("lm_label_ids", None)
+        if params["image_feature"] is not None and params["image_dim"] is not None:
+            image_mask = torch.arange(params["image_feature"].size(-2), device=params["image_feature"].device).expand(
+                *params["image_feature"].size()[:-1])
+            if len(params["image_dim"].size()) < len(image_mask.size()):
+                params["image_dim"] = params["image_dim"].unsqueeze(-1)
+                assert len(params["image_dim"].size()) == len(image_mask.size())
+            params["image_attention_mask"] = (image_mask < params["image_dim"]).long()
+        else:
+            params["image_attention_mask"] = None
+        params.pop("image_dim")
+        return self.model(params["input_ids"], params["image_feature"], params["image_location"], params["token_type_ids"],
+                          params["attention_mask"], params["image_attention_mask"], params["masked_lm_labels"],
+                          params["image_label"], params["image_target"])

@@ -112,8 +112,8 @@ class BertSelfAttentionJit(nn.Module):
         self.num_attention_heads = config.num_attention_heads
         self.attention_head_size = config.hidden_size // config.num_attention_heads
         self.all_head_size = self.num_attention_heads * self.attention_head_size
-        if self.attention_head_size != 64:
-            raise ValueError("the gfx950 fused attention kernel is built for head_dim 64, got %d" % self.attention_head_size)
+        if self.attention_head_size not in (64, 128):
+            raise ValueError("the gfx950 fused attention kernel is built for head_dim 64 or 128, got %d" % self.attention_head_size)
         self.query = Linear(config.hidden_size, self.all_head_size)
         self.key = Linear(config.hidden_size, self.all_head_size)
         self.value = Linear(config.hidden_size, self.all_head_size)

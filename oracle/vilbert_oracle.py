@@ -183,8 +183,12 @@ def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False):
 
 
 def vilbert_base(sd, cfg, input_txt, image_feature, image_location, token_type_ids, attention_mask, image_attention_mask,
-                 train=False):
-    """ViLBERTBase.forward :936-1051."""
+                 train=False, pooler_masks=None):
+    """ViLBERTBase.forward :936-1051.
+
+    `pooler_masks=(mask_t, mask_v)` (test aid) evaluates the two ReLU poolers on a GIVEN branch (`pre * mask` instead of
+    `relu(pre)`): a pre-activation within bf16 noise of zero can land on either side of the kink in a reduced-precision
+    run, and the gradient of a piecewise-linear map is only comparable on the same piece."""
     if attention_mask is None:
         attention_mask = torch.ones_like(input_txt)
     if token_type_ids is None:
@@ -206,8 +210,10 @@ def vilbert_base(sd, cfg, input_txt, image_feature, image_location, token_type_i
            + F.linear(image_location, sd[v + "image_location_embeddings.weight"], sd[v + "image_location_embeddings.bias"]))  # :905-910
     img = F.dropout(layer_norm(img, sd[v + "LayerNorm.weight"], sd[v + "LayerNorm.bias"], 1e-12), hd, training=hd > 0)     # :911
     seq_t, seq_v = encoder(sd, cfg, txt, img, ext_t, ext_v, train)
-    pooled_t = F.relu(F.linear(seq_t[:, 0], sd["bert.t_pooler.dense.weight"], sd["bert.t_pooler.dense.bias"]))   # :805-811
-    pooled_v = F.relu(F.linear(seq_v[:, 0], sd["bert.v_pooler.dense.weight"], sd["bert.v_pooler.dense.bias"]))   # :820-826
+    pre_t = F.linear(seq_t[:, 0], sd["bert.t_pooler.dense.weight"], sd["bert.t_pooler.dense.bias"])   # :805-811
+    pre_v = F.linear(seq_v[:, 0], sd["bert.v_pooler.dense.weight"], sd["bert.v_pooler.dense.bias"])   # :820-826
+    pooled_t = F.relu(pre_t) if pooler_masks is None else pre_t * pooler_masks[0]
+    pooled_v = F.relu(pre_v) if pooler_masks is None else pre_v * pooler_masks[1]
     return seq_t, seq_v, pooled_t, pooled_v
 
 
@@ -227,11 +233,12 @@ def prepare_inputs(sample_list):
                 image_attention_mask=image_mask)
 
 
-def vilbert_forward(sd, cfg, sample_list, train=False):
+def vilbert_forward(sd, cfg, sample_list, train=False, pooler_masks=None):
     """ViLBERT.forward :1423-1446 -> ViLBERTForClassification.forward :1281-1333."""
     p = prepare_inputs(sample_list)
     seq_t, seq_v, pooled_t, pooled_v = vilbert_base(sd, cfg, p["input_ids"], p["image_feature"], p["image_location"],
-                                                    p["token_type_ids"], p["attention_mask"], p["image_attention_mask"], train)
+                                                    p["token_type_ids"], p["attention_mask"], p["image_attention_mask"], train,
+                                                    pooler_masks)
     fused = pooled_t * pooled_v if cfg.get("fusion_method", "mul") == "mul" else pooled_t + pooled_v   # :1315-1320
     hd = cfg["hidden_dropout_prob"] if train else 0.0
     x = F.dropout(fused, hd, training=hd > 0)

@@ -100,3 +100,35 @@ def build_mmft(cfg, sd=None, shared=None, device="cuda", **over):
             full[alias] = sd[src]
         model.load_state_dict(full, strict=True)
     return model.to(device)
+
+
+def vilbert_model_config(cfg, **over):
+    """MMF model_config.vilbert (configs/models/vilbert/defaults.yaml), classification head."""
+    d = dict(
+        model="vilbert", bert_model_name=None, training_head_type="classification", visual_embedding_dim=cfg["v_feature_size"],
+        special_visual_initialize=True, hard_cap_seq_len=None, cut_first="text", embedding_strategy="plain", bypass_transformer=False,
+        output_attentions=False, output_hidden_states=False, text_only=False, random_initialize=False, freeze_base=False,
+        finetune_lr_multiplier=1, attention_probs_dropout_prob=cfg.get("attention_probs_dropout_prob", 0.1),
+        layer_norm_eps=cfg["layer_norm_eps"], hidden_act="gelu", hidden_dropout_prob=cfg.get("hidden_dropout_prob", 0.1),
+        hidden_size=cfg["hidden_size"], initializer_range=0.02, intermediate_size=cfg["intermediate_size"],
+        max_position_embeddings=cfg["max_position_embeddings"], num_attention_heads=cfg["num_attention_heads"],
+        num_hidden_layers=cfg["num_hidden_layers"], type_vocab_size=2, vocab_size=cfg["vocab_size"],
+        v_feature_size=cfg["v_feature_size"], v_target_size=1601, v_hidden_size=cfg["v_hidden_size"],
+        v_num_hidden_layers=cfg["v_num_hidden_layers"], v_num_attention_heads=cfg["v_num_attention_heads"],
+        v_intermediate_size=cfg["v_intermediate_size"], bi_hidden_size=cfg["bi_hidden_size"],
+        bi_num_attention_heads=cfg["bi_num_attention_heads"], bi_intermediate_size=cfg.get("bi_intermediate_size", 1024),
+        bi_attention_type=1, v_attention_probs_dropout_prob=cfg.get("v_attention_probs_dropout_prob", 0.1), v_hidden_act="gelu",
+        v_hidden_dropout_prob=cfg.get("v_hidden_dropout_prob", 0.1), v_initializer_range=0.02,
+        v_biattention_id=list(cfg["v_biattention_id"]), t_biattention_id=list(cfg["t_biattention_id"]), pooling_method="mul",
+        fusion_method=cfg.get("fusion_method", "mul"), fast_mode=False, with_coattention=True, dynamic_attention=False,
+        in_batch_pairs=False, task_specific_tokens=False, fixed_v_layer=0, fixed_t_layer=0, visualization=False, visual_target=0,
+        objective=0, num_negative=128, num_labels=cfg["num_labels"], losses=[dict(type="logit_bce")])
+    d.update(over)
+    return Config(d)
+
+
+def build_vilbert(cfg, sd=None, device="cuda", **over):
+    model = build_model(vilbert_model_config(cfg, **over))
+    if sd is not None:
+        model.load_state_dict({"model." + k: v for k, v in sd.items()}, strict=True)
+    return model.to(device)

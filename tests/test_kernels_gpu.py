@@ -251,6 +251,38 @@ def test_attention_forward_backward(B, heads, S):
         close(g, ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name)
 
 
+def test_attention_exact_delta_reduces_common_mode_leak():
+    """A common component in K (e.g. the key bias) must not reach dQ: sum_key dS = 0.  With delta formed from the bf16 O the
+    rows of dS sum to ~2^-9 |dO||O| and that times mean(K) lands in dQ; the fp32 copy of O removes that term (what is
+    left is the bf16 rounding of dS itself ahead of the dS K product)."""
+    B, heads, S, d = 2, 2, 100, 64
+    H = heads * d
+    qkv = rnd(B * S, 3 * H, scale=0.3)
+    qkv[:, H:2 * H] += 6.0            # large common component in every key
+    scale = 1.0 / math.sqrt(d)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    qf = split_heads(q.contiguous(), B, S, heads).requires_grad_(True)
+    kf = split_heads(k.contiguous(), B, S, heads).requires_grad_(True)
+    vf = split_heads(v.contiguous(), B, S, heads).requires_grad_(True)
+    o_ref, _ = attn_ref(qf, kf, vf, None, scale)
+    dctx = rnd(B * S, H)
+    o_ref.backward(split_heads(dctx, B, S, heads))
+    errs = {}
+    for exact in (False, True):
+        ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, S, device=DEV)
+        o32 = torch.empty(B * S, H, device=DEV) if exact else None
+        nat().attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, None, ctx, H, lse, B, heads, S, S, scale, ctx_f32=o32)
+        if exact:
+            assert torch.equal(o32.bfloat16(), ctx)
+        dqkv = torch.zeros_like(qkv); delta = torch.empty(B, heads, S, device=DEV)
+        nat().attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, None, ctx, H, lse, B, heads, S, S, scale, dctx,
+                            dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta, ctx_f32=o32)
+        g = split_heads(dqkv[:, :H].contiguous(), B, S, heads)
+        errs[exact] = float((g - qf.grad).norm() / qf.grad.norm())
+    assert errs[True] <= 5e-2, errs
+    assert errs[True] < 0.9 * errs[False], errs
+
+
 def test_attention_fully_masked_rows_are_uniform():
     # additive -10000 (not -inf): a row whose keys are all masked attends uniformly (SURVEY §7)
     B, heads, S = 1, 1, 64

@@ -1,0 +1,31 @@
+"""ViLBERT host mirror, CPU side: registered model builds with the reference's parameter tree (names and shapes
+recorded from the real reference) and the unbuilt variants raise."""
+import pytest
+
+from oracle import vilbert_oracle as O
+from tests.golden_utils import load_vilbert_case
+from tests.model_utils import build_vilbert, vilbert_model_config
+from mmf_amd.common.registry import registry
+from mmf_amd.utils.build import build_model
+
+
+def test_registered_and_state_dict_matches_reference_tree():
+    z, case, cfg, sd, sample = load_vilbert_case()
+    assert registry.get_model_class("vilbert") is not None
+    model = build_vilbert(cfg, sd, device="cpu")
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    assert ours == ref
+    assert len(list(model.named_parameters())) == len(O.parameter_shapes(cfg))
+    enc = model.model.bert.encoder
+    assert (len(enc.layer), len(enc.v_layer), len(enc.c_layer)) == (cfg["num_hidden_layers"], cfg["v_num_hidden_layers"], 2)
+    assert enc.v_layer[0].attention.self.attention_head_size == 128 and enc.layer[0].attention.self.attention_head_size == 64
+
+
+def test_unbuilt_variants_raise():
+    z, case, cfg, sd, sample = load_vilbert_case()
+    for over in (dict(training_head_type="pretraining"), dict(training_head_type="nlvr2"), dict(dynamic_attention=True),
+                 dict(in_batch_pairs=True), dict(fast_mode=True), dict(task_specific_tokens=True), dict(fixed_t_layer=1),
+                 dict(visualization=True)):
+        with pytest.raises(NotImplementedError):
+            build_model(vilbert_model_config(cfg, **over))

@@ -29,6 +29,10 @@ def test_vilbert_oracle_matches_reference_forward_loss_and_gradients():
             continue
         checked += 1
         assert g is not None, key
+        if key.endswith(".key.bias") or key.endswith("key1.bias") or key.endswith("key2.bias"):
+            # identically zero in exact arithmetic (a per-query constant shift cancels in the softmax): fp32 noise on both sides
+            assert norm < 1e-6 and float(g.double().norm()) < 1e-6, key
+            continue
         assert abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
         assert abs(float(g.double().sum()) - gsum) <= 1e-4 * norm + 1e-7, key
         full = "grad::" + str(gname)

@@ -5,10 +5,50 @@
 
 MMF imports `env.user_dir` before it builds the config (mmf_cli/run.py:25, mmf/utils/env.py:32-93;
 fixture tests/data/user_dir/).  A two-line user dir (`from mmf_amd import plugin; plugin.install()`)
-re-registers "visual_bert" and "logit_bce" in MMF's own registry with the HIP-backed classes: a later
-`register_model` simply overwrites the dict entry (mmf/common/registry.py:319), and the adapter class
-created here derives from MMF's `BaseModel` so the `issubclass` assertion at registry.py:316 holds.
+re-registers the HIP-backed components in MMF's own registry: a later `register_*` simply overwrites the dict
+entry (mmf/common/registry.py:319), and the model adapters created here derive from MMF's `BaseModel`, so the
+`issubclass` assertion at registry.py:316 holds and MMF's `build_model` (mmf/utils/build.py:116-151), `Losses`,
+checkpointing and trainer loop run unchanged around the HIP-backed networks.
+
+Registered: models `visual_bert`, `mmbt`, `vilbert`, `mmft` / `mmf_transformer`; losses `logit_bce`,
+`cross_entropy`; optimizer `adam_w`; scheduler `warmup_linear`; transformer backend `huggingface`; transformer heads
+`mlp` / `multilayer_mlp`.
 """
+
+
+def _adapter(mmf_base_model, hip_cls, children):
+    """MMF-facing adapter: MMF's BaseModel plumbing (device move, Losses, checkpoints) around the HIP-backed network.
+    `children` are the sub-module names the reference model owns directly (`model` for VisualBERT / MMBT / ViLBERT,
+    `backend` / `encoders` / `heads` for MMF Transformer), so the parameter tree keeps the reference's names."""
+
+    class Adapter(mmf_base_model):
+        def __init__(self, config, *args, **kwargs):
+            super().__init__(config)
+            self.config = config
+
+        @classmethod
+        def config_path(cls):
+            return hip_cls.config_path()
+
+        @classmethod
+        def format_state_key(cls, key):
+            return hip_cls.format_state_key(key)
+
+        def build(self):
+            inner = hip_cls(self.config)
+            inner.build()
+            for name in children:
+                setattr(self, name, getattr(inner, name))
+            self._inner = [inner]  # not a sub-module: the parameters live under `children`, as in the reference
+
+        def get_optimizer_parameters(self, config):
+            return self._inner[0].get_optimizer_parameters(config)
+
+        def forward(self, sample_list):
+            return hip_cls.forward(self._inner[0], sample_list)
+
+    Adapter.__name__ = Adapter.__qualname__ = hip_cls.__name__
+    return Adapter
 
 
 def install():
@@ -16,37 +56,23 @@ def install():
     from mmf.models.base_model import BaseModel as MMFBaseModel
 
     import mmf_amd  # noqa: F401  (fills mmf_amd's registry)
-    from mmf_amd.models.visual_bert import VisualBERT as HipVisualBERT
-    from mmf_amd.modules.losses import LogitBinaryCrossEntropy as HipLogitBCE
+    from mmf_amd.common.registry import registry as hip_registry
+    from mmf_amd.models.mmbt import MMBT
+    from mmf_amd.models.mmf_transformer import MMFTransformer
+    from mmf_amd.models.vilbert import ViLBERT
+    from mmf_amd.models.visual_bert import VisualBERT
 
-    class VisualBERT(MMFBaseModel):
-        """MMF-facing adapter: MMF's BaseModel plumbing (device move, Losses, checkpoints) around the
-        HIP-backed network."""
-
-        def __init__(self, config):
-            super().__init__(config)
-            self.config = config
-
-        @classmethod
-        def config_path(cls):
-            return HipVisualBERT.config_path()
-
-        @classmethod
-        def format_state_key(cls, key):
-            return HipVisualBERT.format_state_key(key)
-
-        def build(self):
-            inner = HipVisualBERT(self.config)
-            inner.build()
-            self.model = inner.model
-            self._inner = [inner]  # not a sub-module: parameters live under self.model as in the reference
-
-        def get_optimizer_parameters(self, config):
-            return self._inner[0].get_optimizer_parameters(config)
-
-        def forward(self, sample_list):
-            return HipVisualBERT.forward(self._inner[0], sample_list)
-
-    mmf_registry.register_model("visual_bert")(VisualBERT)
-    mmf_registry.register_loss("logit_bce")(HipLogitBCE)
-    return VisualBERT
+    adapters = {}
+    for names, cls, children in ((("visual_bert",), VisualBERT, ("model",)), (("mmbt",), MMBT, ("model",)),
+                                 (("vilbert",), ViLBERT, ("model",)),
+                                 (("mmft", "mmf_transformer"), MMFTransformer, ("backend", "encoders", "heads"))):
+        adapter = _adapter(MMFBaseModel, cls, children)
+        for name in names:
+            mmf_registry.register_model(name)(adapter)
+            adapters[name] = adapter
+    for kind, names in (("loss", ("logit_bce", "cross_entropy")), ("optimizer", ("adam_w",)), ("scheduler", ("warmup_linear",)),
+                        ("transformer_backend", ("huggingface",)), ("transformer_head", ("mlp", "multilayer_mlp"))):
+        for name in names:
+            obj = getattr(hip_registry, "get_%s_class" % kind)(name)
+            getattr(mmf_registry, "register_%s" % kind)(name)(obj)
+    return adapters

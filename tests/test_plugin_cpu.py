@@ -1,0 +1,73 @@
+"""`mmf_amd.plugin.install()` against a stand-in for the MMF package (the real one is not installed here and does not
+exist on the GPU box): every HIP-backed component lands in MMF's registry, the model adapters derive from MMF's own
+BaseModel (mmf/common/registry.py:316) and keep the reference's parameter tree."""
+import sys
+import types
+
+import pytest
+from torch import nn
+
+from tests.golden_utils import load_mmft_case, load_vilbert_case
+from tests.model_utils import mmft_model_config, vilbert_model_config
+
+
+@pytest.fixture
+def fake_mmf():
+    class Registry:
+        store = {}
+
+        def __getattr__(self, name):
+            if name.startswith("register_"):
+                kind = name[len("register_"):]
+
+                def reg(key):
+                    def wrap(obj):
+                        if kind == "model":
+                            assert issubclass(obj, BaseModel), "All models must inherit BaseModel class"
+                        self.store[(kind, key)] = obj
+                        return obj
+                    return wrap
+                return reg
+            raise AttributeError(name)
+
+    class BaseModel(nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+
+    mods = {"mmf": types.ModuleType("mmf"), "mmf.common": types.ModuleType("mmf.common"),
+            "mmf.common.registry": types.ModuleType("mmf.common.registry"), "mmf.models": types.ModuleType("mmf.models"),
+            "mmf.models.base_model": types.ModuleType("mmf.models.base_model")}
+    mods["mmf.common.registry"].registry = Registry()
+    mods["mmf.models.base_model"].BaseModel = BaseModel
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    yield mods["mmf.common.registry"].registry, BaseModel
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def test_install_registers_everything_and_keeps_the_parameter_tree(fake_mmf):
+    registry, BaseModel = fake_mmf
+    from mmf_amd import plugin
+    from mmf_amd.utils.build import build_model
+    adapters = plugin.install()
+    assert set(adapters) == {"visual_bert", "mmbt", "vilbert", "mmft", "mmf_transformer"}
+    for key in (("loss", "logit_bce"), ("loss", "cross_entropy"), ("optimizer", "adam_w"), ("scheduler", "warmup_linear"),
+                ("transformer_backend", "huggingface"), ("transformer_head", "mlp"), ("model", "vilbert")):
+        assert key in registry.store, key
+    z, case, cfg, sd, sample = load_vilbert_case()
+    mc = vilbert_model_config(cfg)
+    m = registry.store[("model", "vilbert")](mc)
+    assert isinstance(m, BaseModel)
+    m.build()
+    assert set(m.state_dict().keys()) == set(build_model(mc).state_dict().keys())
+    z, case, cfg, sd, sample = load_mmft_case()
+    mc = mmft_model_config(cfg)
+    m = registry.store[("model", "mmft")](mc)
+    m.build()
+    assert set(m.state_dict().keys()) == set(build_model(mc).state_dict().keys())
+    assert type(m).format_state_key("classifier.2.weight") == "heads.0.classifier.2.weight"

@@ -269,7 +269,8 @@ typedef struct mmf_adamw_multi_desc {
     const void* g[MMF_MT_MAX];
     void* m[MMF_MT_MAX];
     void* v[MMF_MT_MAX];
-    void* p16[MMF_MT_MAX];
+    void* p16[MMF_MT_MAX];    /* optional bf16 mirror (GEMM weight shadow), refreshed in the same pass */
+    void* p32[MMF_MT_MAX];    /* optional fp32 mirror (slice of a packed Q|K|V bias), refreshed in the same pass */
     int64_t numel[MMF_MT_MAX];
     float lr[MMF_MT_MAX];
     float wd[MMF_MT_MAX];
@@ -278,8 +279,16 @@ typedef struct mmf_adamw_multi_desc {
     float grad_scale;
     const float* norm_sq;
     float max_norm;
+    const float* dev_state;   /* optional device words {step, lr multiplier}: the update reads the step count (bias
+                                 correction) and the schedule factor from HBM, so the launch can be replayed from a
+                                 hipGraph; `step` above is then ignored.  Advanced by mmf_optim_state_advance. */
 } mmf_adamw_multi_desc;
 int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream);
+/* state[0] += 1 (optimizer step count t); state[1] = LR multiplier for step t: schedule 0 -> 1, schedule 1 ->
+ * MMF's `warmup_linear` (mmf/modules/schedulers.py:34-37 = transformers.get_linear_schedule_with_warmup) evaluated
+ * at t - 1 (the scheduler is stepped after the optimizer): (t-1)/warmup while t-1 < warmup, else
+ * max(0, (total - (t-1)) / max(1, total - warmup)). */
+int mmf_optim_state_advance(float* state, int schedule, float warmup_steps, float total_steps, void* stream);
 typedef struct mmf_tensor_list {
     int n;
     const void* ptr[MMF_MT_MAX];

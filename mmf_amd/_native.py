@@ -58,10 +58,10 @@ class AdamWMultiDesc(C.Structure):
     _fields_ = [
         ("n", C.c_int),
         ("p", C.c_void_p * MT_MAX), ("g", C.c_void_p * MT_MAX), ("m", C.c_void_p * MT_MAX), ("v", C.c_void_p * MT_MAX),
-        ("p16", C.c_void_p * MT_MAX), ("numel", C.c_int64 * MT_MAX), ("lr", C.c_float * MT_MAX), ("wd", C.c_float * MT_MAX),
+        ("p16", C.c_void_p * MT_MAX), ("p32", C.c_void_p * MT_MAX), ("numel", C.c_int64 * MT_MAX), ("lr", C.c_float * MT_MAX), ("wd", C.c_float * MT_MAX),
         ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("step", C.c_int), ("correct_bias", C.c_int), ("mode", C.c_int),
-        ("grad_scale", C.c_float), ("norm_sq", C.c_void_p), ("max_norm", C.c_float),
+        ("grad_scale", C.c_float), ("norm_sq", C.c_void_p), ("max_norm", C.c_float), ("dev_state", C.c_void_p),
     ]
 
 
@@ -400,22 +400,31 @@ def adamw_step(p, g, m, v, p16, n, seg_end, seg_wd, nseg, lr, beta1, beta2, eps,
                                 int(correct_bias), int(mode), C.c_float(grad_scale), _stream()), "mmf_adamw_step")
 
 
-def adamw_multi(items, beta1, beta2, eps, step, correct_bias, mode, grad_scale=1.0, norm_sq=None, max_norm=0.0):
-    """items: list of (p, g, m, v, p16 or None, lr, wd); fp32 contiguous tensors, any number (launched MT_MAX at a time)."""
+def adamw_multi(items, beta1, beta2, eps, step, correct_bias, mode, grad_scale=1.0, norm_sq=None, max_norm=0.0, dev_state=None):
+    """items: list of (p, g, m, v, mirror or None, lr, wd); fp32 contiguous tensors, any number (launched MT_MAX at a time).
+    `mirror` is the bf16 weight shadow or the fp32 packed-bias slice that must follow the parameter."""
     for i0 in range(0, len(items), MT_MAX):
         chunk = items[i0:i0 + MT_MAX]
         d = AdamWMultiDesc()
         d.n = len(chunk)
         for i, (p, g, m, v, p16, lr, wd) in enumerate(chunk):
             d.p[i], d.g[i], d.m[i], d.v[i] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
-            d.p16[i] = p16.data_ptr() if p16 is not None else None
+            d.p16[i] = p16.data_ptr() if (p16 is not None and p16.dtype == torch.bfloat16) else None
+            d.p32[i] = p16.data_ptr() if (p16 is not None and p16.dtype == torch.float32) else None
             d.numel[i], d.lr[i], d.wd[i] = p.numel(), lr, wd
         d.beta1, d.beta2, d.eps = beta1, beta2, eps
         d.step, d.correct_bias, d.mode = int(step), int(correct_bias), int(mode)
         d.grad_scale = grad_scale
         d.norm_sq = norm_sq.data_ptr() if norm_sq is not None else None
         d.max_norm = max_norm
+        d.dev_state = dev_state.data_ptr() if dev_state is not None else None
         _check(lib().mmf_adamw_multi(C.byref(d), _stream()), "mmf_adamw_multi")
+
+
+def optim_state_advance(state, schedule=0, warmup_steps=0.0, total_steps=0.0):
+    _req(state, torch.float32, "state")
+    _check(lib().mmf_optim_state_advance(_p(state), int(schedule), C.c_float(warmup_steps), C.c_float(total_steps), _stream()),
+           "mmf_optim_state_advance")
 
 
 def l2norm_sq_multi(tensors, out):

@@ -572,6 +572,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // multi-tensor AdamW / gradient L2 norm: one launch covers up to MMF_MT_MAX tensors (grid.y = tensor, grid.x = chunk)
 // ------------------------------------------------------------------------------------------------
 constexpr int MT_CHUNK = 16384;   // elements per workgroup
+__global__ void optim_state_advance_kernel(float* state, int schedule, float warmup, float total) {
+    const float t = state[0] + 1.f;
+    state[0] = t;
+    float f = 1.f;
+    if (schedule == 1) {
+        const float s = t - 1.f;
+        f = (s < warmup) ? s / fmaxf(1.f, warmup) : fmaxf(0.f, (total - s) / fmaxf(1.f, total - warmup));
+    }
+    state[1] = f;
+}
+
 __global__ __launch_bounds__(256) void adamw_multi_kernel(mmf_adamw_multi_desc d, float bc1, float bc2) {
     const int t = blockIdx.y;
     const int64_t n = d.numel[t];
@@ -582,7 +593,14 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(mmf_adamw_multi_desc d
     float* __restrict__ m = reinterpret_cast<float*>(d.m[t]);
     float* __restrict__ v = reinterpret_cast<float*>(d.v[t]);
     bf16* __restrict__ p16 = reinterpret_cast<bf16*>(d.p16[t]);
-    const float lr = d.lr[t], wd = d.wd[t], b1 = d.beta1, b2 = d.beta2, eps = d.eps;
+    float* __restrict__ p32 = reinterpret_cast<float*>(d.p32[t]);
+    float lr = d.lr[t];
+    const float wd = d.wd[t], b1 = d.beta1, b2 = d.beta2, eps = d.eps;
+    if (d.dev_state) {   // step count and schedule factor live in HBM (hipGraph replay)
+        const float step = d.dev_state[0];
+        lr *= d.dev_state[1];
+        if (d.correct_bias) { bc1 = 1.f - powf(b1, step); bc2 = 1.f - powf(b2, step); }
+    }
     float gs = d.grad_scale;
     if (d.norm_sq) {   // gradient clipping folded into the update: coef = min(1, max_norm / (||g|| + 1e-6))
         const float coef = d.max_norm / (sqrtf(d.norm_sq[0]) + 1e-6f);
@@ -611,7 +629,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(mmf_adamw_multi_desc d
         if (vec) {
             store4(p + i, pv); store4(m + i, mv); store4(v + i, vv);
             if (p16) store4(p16 + i, pv);
-        } else for (int j = 0; j < cnt; ++j) { p[i + j] = pv[j]; m[i + j] = mv[j]; v[i + j] = vv[j]; if (p16) p16[i + j] = (bf16)pv[j]; }
+            if (p32) store4(p32 + i, pv);
+        } else for (int j = 0; j < cnt; ++j) { p[i + j] = pv[j]; m[i + j] = mv[j]; v[i + j] = vv[j]; if (p16) p16[i + j] = (bf16)pv[j]; if (p32) p32[i + j] = pv[j]; }
     }
 }
 __global__ __launch_bounds__(256) void l2norm_multi_kernel(mmf_tensor_list d, float* __restrict__ partials) {
@@ -939,15 +958,21 @@ int mmf_adamw_step(float* p, const float* g, float* m, float* v, void* p16, int6
 }
 
 int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream) {
-    MMF_CHECK_ARG(d && d->n > 0 && d->n <= MMF_MT_MAX && d->step >= 1, "adamw_multi: bad descriptor");
+    MMF_CHECK_ARG(d && d->n > 0 && d->n <= MMF_MT_MAX && (d->step >= 1 || d->dev_state), "adamw_multi: bad descriptor");
     int64_t mx = 0;
     for (int i = 0; i < d->n; ++i) {
         MMF_CHECK_ARG(d->p[i] && d->g[i] && d->m[i] && d->v[i] && d->numel[i] > 0, "adamw_multi: null tensor");
         mx = d->numel[i] > mx ? d->numel[i] : mx;
     }
     float bc1 = 1.f, bc2 = 1.f;
-    if (d->correct_bias) { bc1 = 1.f - powf(d->beta1, (float)d->step); bc2 = 1.f - powf(d->beta2, (float)d->step); }
+    if (d->correct_bias && !d->dev_state) { bc1 = 1.f - powf(d->beta1, (float)d->step); bc2 = 1.f - powf(d->beta2, (float)d->step); }
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)((mx + MT_CHUNK - 1) / MT_CHUNK), d->n), dim3(256), 0, (hipStream_t)stream, *d, bc1, bc2);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_optim_state_advance(float* state, int schedule, float warmup_steps, float total_steps, void* stream) {
+    MMF_CHECK_ARG(state && (schedule == 0 || schedule == 1), "optim_state_advance: bad argument");
+    hipLaunchKernelGGL(optim_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, schedule, warmup_steps, total_steps);
     MMF_CHECK_LAUNCH();
     return 0;
 }

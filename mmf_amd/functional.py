@@ -102,14 +102,15 @@ class ShadowCache:
         self._slot.clear()
 
     def slot(self, p):
-        """The bf16 shadow rows of parameter `p` if it has an up-to-date shadow, else None.  The fused optimizer
-        writes the new bf16 value there in the same pass that updates the fp32 master (no re-cast next step)."""
+        """The mirror rows of parameter `p` (bf16 weight shadow, or its slice of a packed fp32 Q|K|V bias) if it has an
+        up-to-date one, else None.  The fused optimizer writes the new value there in the same pass that updates the
+        fp32 master: no re-cast / re-pack next step, and the update stays visible to a replayed hipGraph."""
         ent = self._slot.get(id(p))
         if ent is None:
             return None
         key, r0 = ent
         st = self._store.get(key)
-        if st is None or st[2] != BF16:
+        if st is None:
             return None
         for q, ver, ptr in st[0]:
             if q == id(p) and (ver != p._version or ptr != p.data_ptr()):
@@ -139,7 +140,7 @@ class ShadowCache:
                 nat.cast_f32_to_bf16(src, buf[r:r + n])
             else:
                 buf[r:r + n].copy_(src)
-            if dtype == BF16:
+            if dtype == BF16 or len(params) > 1:   # a lone fp32 "shadow" would just be the parameter itself
                 self._slot[id(p)] = (key, r)
             r += n
         self._store[key] = (sig, buf, dtype)

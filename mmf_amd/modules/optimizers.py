@@ -17,7 +17,12 @@ class AdamW(torch.optim.Optimizer):
     """transformers.AdamW signature and semantics (`correct_bias`, decoupled decay applied after the Adam step).
     `torch_mode=True` switches to torch.optim.AdamW's rule (decay first, eps outside the bias-corrected sqrt)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, torch_mode=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, torch_mode=False,
+                 capturable=False, schedule=None):
+        """`capturable=True` keeps the step count (bias correction) and the LR-schedule factor in device memory, advanced
+        by a one-thread kernel at the start of every `step()`, so the whole update can be replayed from a hipGraph
+        (`mmf_amd.utils.graph.GraphedTrainStep(optimizer=...)`).  `schedule=("warmup_linear", warmup_steps, total_steps)`
+        evaluates MMF's `warmup_linear` scheduler on the device as well (do not also attach a host-side scheduler)."""
         if lr < 0.0:
             raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
@@ -27,6 +32,11 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
         self.torch_mode = torch_mode
         self._clip = None
+        self.capturable = capturable
+        if schedule is not None and (not capturable or schedule[0] != "warmup_linear"):
+            raise ValueError("schedule=('warmup_linear', warmup_steps, total_steps) needs capturable=True")
+        self._schedule = (0, 0.0, 0.0) if schedule is None else (1, float(schedule[1]), float(schedule[2]))
+        self._dev_state = None
 
     @torch.no_grad()
     def clip_grad_norm(self, max_norm):
@@ -46,6 +56,13 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        dev_state = None
+        if self.capturable:
+            if self._dev_state is None:
+                dev = self.param_groups[0]["params"][0].device
+                self._dev_state = torch.zeros(2, dtype=torch.float32, device=dev)
+            nat.optim_state_advance(self._dev_state, *self._schedule)
+            dev_state = self._dev_state
         for group in self.param_groups:
             items = []
             step = group.get("step", 0) + 1
@@ -66,6 +83,6 @@ class AdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             norm_sq, max_norm = self._clip if self._clip is not None else (None, 0.0)
             nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
-                            1.0, norm_sq, max_norm)
+                            1.0, norm_sq, max_norm, dev_state)
         self._clip = None
         return loss

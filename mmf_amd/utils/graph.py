@@ -56,8 +56,15 @@ def _copy_batch(dst, src):
 
 
 class GraphedTrainStep:
-    def __init__(self, model, batch, warmup=3, loss_of=None):
+    """`optimizer` (an `adam_w` built with `capturable=True`) puts the parameter update into the graph as well: one
+    replay = one full training step.  The optimizer then also keeps the bf16 weight shadows current, so no cast kernel
+    is captured; without it the casts are captured so that replays see updates made between them."""
+
+    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None):
         self.model = model
+        self.optimizer = optimizer
+        if optimizer is not None and not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedTrainStep needs an optimizer whose step reads its counters from device memory (capturable=True)")
         self.loss_of = loss_of or (lambda out: sum(v.sum() for v in out["losses"].values()))
         release_autograd_state()
         self.static_batch = _clone_batch(batch)
@@ -73,7 +80,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
-        Fn.shadows.clear()   # so the weight-shadow casts are part of the captured step
+        if optimizer is None:
+            Fn.shadows.clear()   # so the weight-shadow casts are part of the captured step
         with Fn.dropout_keys.graph_mode(self.seed):
             with torch.cuda.graph(self.graph):
                 self.out, self.loss = self._eager()
@@ -89,6 +97,8 @@ class GraphedTrainStep:
         grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g
+        if self.optimizer is not None:
+            self.optimizer.step()
         return out, loss
 
     def __call__(self, batch=None):

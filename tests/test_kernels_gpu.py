@@ -517,3 +517,56 @@ def test_optimizer_refreshes_bf16_shadows_in_place():
     opt.step()
     assert Fn.shadows.get(lin.weight) is sh              # still considered fresh (no new cast)
     assert torch.equal(sh, lin.weight.detach().to(torch.bfloat16))
+
+
+def test_optimizer_keeps_packed_qkv_biases_current():
+    """Q|K|V biases are consumed from one packed fp32 copy; the fused step must write it too, or the forward would keep
+    using the biases of step 0."""
+    from mmf_amd import functional as Fn
+    from mmf_amd.modules.hf_layers import BertConfig, BertSelfAttentionJit
+    from mmf_amd.modules.optimizers import AdamW
+    att = BertSelfAttentionJit(BertConfig(hidden_size=128, num_attention_heads=2)).to(DEV)
+    for p in att.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    x = rnd(2, 16, 128)
+    ctx, _ = att(x)
+    ctx.float().sum().backward()
+    w16, b32 = att.packed_qkv()
+    before = b32.clone()
+    AdamW(att.parameters(), lr=1e-2).step()
+    w16b, b32b = att.packed_qkv()
+    assert b32b is b32 and w16b is w16                    # no re-pack
+    expect = torch.cat([att.query.bias, att.key.bias, att.value.bias]).detach()
+    assert torch.equal(b32, expect) and not torch.equal(b32[256:], before[256:])
+    assert torch.equal(w16, torch.cat([att.query.weight, att.key.weight, att.value.weight]).detach().bfloat16())
+
+
+def test_capturable_adamw_matches_host_counters_and_warmup_linear():
+    from mmf_amd.modules.optimizers import AdamW
+    torch.manual_seed(0)
+    ps = [torch.randn(300, 7, device=DEV), torch.randn(64, device=DEV)]
+    pa = [torch.nn.Parameter(p.clone()) for p in ps]; pb = [torch.nn.Parameter(p.clone()) for p in ps]
+    oa = AdamW(pa, lr=1e-2, weight_decay=0.01)
+    ob = AdamW(pb, lr=1e-2, weight_decay=0.01, capturable=True)
+    for it in range(4):
+        gs = [torch.randn_like(p) for p in ps]
+        for q, r, g in zip(pa, pb, gs):
+            q.grad = g.clone(); r.grad = g.clone()
+        oa.step(); ob.step()
+    for q, r in zip(pa, pb):
+        assert torch.allclose(q, r, rtol=1e-6, atol=1e-7)
+    assert float(ob._dev_state[0]) == 4.0
+    # device-side warmup_linear == lr * lambda(t - 1) applied by hand
+    pc = [torch.nn.Parameter(p.clone()) for p in ps]; pd = [torch.nn.Parameter(p.clone()) for p in ps]
+    oc = AdamW(pc, lr=1e-2, capturable=True, schedule=("warmup_linear", 2, 6))
+    od = AdamW(pd, lr=1e-2)
+    lam = lambda s: s / 2 if s < 2 else max(0.0, (6 - s) / 4)
+    for it in range(5):
+        gs = [torch.randn_like(p) for p in ps]
+        for q, r, g in zip(pc, pd, gs):
+            q.grad = g.clone(); r.grad = g.clone()
+        for grp in od.param_groups:
+            grp["lr"] = 1e-2 * lam(it)
+        oc.step(); od.step()
+    for q, r in zip(pc, pd):
+        assert torch.allclose(q, r, rtol=1e-5, atol=1e-7)

@@ -154,3 +154,39 @@ def test_graph_replay_matches_eager_and_redraws_dropout():
     a, b = float(gt()), float(gt())
     assert a != b                       # fresh masks per replay
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_graph_with_optimizer_is_one_full_training_step():
+    """Forward + loss + backward + fused AdamW replayed as ONE hipGraph: same parameters after 3 updates as 3 eager
+    steps (eval mode: no dropout), and the step counter / shadows / packed biases all advance inside the graph."""
+    from mmf_amd.modules.optimizers import AdamW
+    from mmf_amd.utils.graph import GraphedTrainStep
+    z, case, cfg, sd, sample = load_case("small64")
+    batch = SampleList(sample_to(sample, "cuda"))
+
+    def fresh():
+        m = build_visual_bert(cfg, sd)
+        m.eval()
+        return m, AdamW(m.parameters(), lr=1e-3, weight_decay=0.01, capturable=True)
+
+    m1, o1 = fresh()
+    g = GraphedTrainStep(m1, batch, warmup=1, optimizer=o1)      # 1 eager warm-up update (the capture itself runs nothing)
+    g(); g()
+    assert float(o1._dev_state[0]) == 3.0
+    m2, o2 = fresh()
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        for _ in range(3):
+            out = m2(batch)
+            loss = sum(v.sum() for v in out["losses"].values())
+            m2.zero_grad(set_to_none=True)
+            loss.backward()
+            o2.step()
+            del out, loss
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        worst = max(worst, float((p - q).abs().max()))
+    assert worst <= 2e-4, worst     # 3 Adam steps of 1e-3: any skipped / doubled update would show at 1e-3
+    att = m1.model.bert.encoder.layer[0].attention.self
+    assert torch.equal(att.packed_qkv()[1], torch.cat([att.query.bias, att.key.bias, att.value.bias]).detach())

@@ -70,3 +70,16 @@ def test_argument_errors_are_reported_not_swallowed(built_lib):
     rc = built_lib.mmf_gemm_bf16(ctypes.byref(d), None)
     assert rc != 0
     assert b"null operand" in built_lib.mmf_amd_last_error()
+
+
+def test_library_is_not_older_than_its_sources():
+    """The in-tree .so travels to the GPU box as built: a stale build (header / kernel edited, library not rebuilt)
+    shows up there as struct-layout garbage.  __graft_entry__.build() rebuilds; this catches forgetting to."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "mmf_amd", "libmmf_amd.so")
+    srcs = glob.glob(os.path.join(root, "mmf_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "mmf_amd", "csrc", "*.h")) + \
+        [os.path.join(root, "include", "mmf_amd.h")]
+    newest = max(srcs, key=os.path.getmtime)
+    assert os.path.getmtime(so) >= os.path.getmtime(newest), "rebuild: %s is newer than libmmf_amd.so" % os.path.relpath(newest, root)

@@ -33,7 +33,7 @@ int mmf_gemm_k32_dispatch(const mmf_gemm_desc* d, const gemm::EpiArgs& e, hipStr
 namespace {
 
 // ---- the kernel ---------------------------------------------------------------------------------
-template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_>
+template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_, int KS = 1>
 __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
                                                              int M, int N, int K, int lda, int ldb,
                                                              int tiles_m, int tiles_n, int splits, int dbg, EpiArgs epi) {
@@ -44,10 +44,14 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
     const int wave = tid >> 6;
     // Wave grid over the 128 x BN_ tile.  BN_ = 128: 2 x NWN waves of 64 x (128/NWN).  BN_ = 96 (8 waves only): 4 x 2 waves of 32 x 48,
     // used where 128-wide tiles would leave a third of the CUs idle in the last round (N = 768 / 2304 at M = 7296).
+    // KS = 2 (8 waves): 2 x 2 waves of 64 x (BN_/2), times two K-halves — each wave multiplies ONE of the two 32-deep
+    // halves of a stage.  Same MFMA count per wave and step, a third fewer LDS operand reads (a 64x64 wave tile reuses
+    // each fragment twice as often as a 64x32 one); the two halves are summed once, in the epilogue's LDS stage.
     constexpr int NTH = 128 * NWN;
-    constexpr int WGN = (BN_ == 96) ? 2 : NWN, WGM = (2 * NWN) / WGN;
+    constexpr int WGN = (KS == 2) ? 2 : ((BN_ == 96) ? 2 : NWN), WGM = (2 * NWN / KS) / WGN;
     constexpr int WTM = 128 / WGM, WTN = BN_ / WGN, NFM = WTM / 16, NFN = WTN / 16;
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int wk = (KS == 2) ? wave / (WGM * WGN) : 0;
+    const int wm = (wave % (WGM * WGN)) / WGN, wn = wave % WGN;
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of the
     // (m-major, n-fastest) tile list so the A row panel and the weight panel stay in its L2.
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue ahead of the MFMAs
         if (!(dbg & 2))
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int k2 = 0; k2 < 2 / KS; ++k2) {
+            const int kk = (KS == 2) ? wk : k2;
             bf16x8 fa[NFM], fb[NFN];
 #pragma unroll
             for (int f = 0; f < NFM; ++f) fa[f] = read_frag<A_KMAJOR>(la, wm * WTM, f, kk, lane);
@@ -143,14 +148,30 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
     // the output stores are full-line, 16-byte-per-lane transactions.
     constexpr int CLD = BN_ + 4;   // +4 floats: 16 rows of a fragment column land on distinct banks
     float* cs = reinterpret_cast<float*>(smem);
+    if (wk == 0) {
 #pragma unroll
-    for (int i = 0; i < NFM; ++i)
+        for (int i = 0; i < NFM; ++i)
 #pragma unroll
-        for (int j = 0; j < NFN; ++j) {
-            const int row = wm * WTM + i * 16 + (lane & 15), col = wn * WTN + j * 16 + (lane >> 4) * 4;
-            *reinterpret_cast<float4*>(cs + row * CLD + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        }
+            for (int j = 0; j < NFN; ++j) {
+                const int row = wm * WTM + i * 16 + (lane & 15), col = wn * WTN + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<float4*>(cs + row * CLD + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+    }
     __syncthreads();
+    if (KS == 2) {
+        if (wk == 1) {   // add the second K-half in place (each (wm, wn) region has exactly one writer per phase)
+#pragma unroll
+            for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                for (int j = 0; j < NFN; ++j) {
+                    const int row = wm * WTM + i * 16 + (lane & 15), col = wn * WTN + j * 16 + (lane >> 4) * 4;
+                    float4* pc = reinterpret_cast<float4*>(cs + row * CLD + col);
+                    const float4 v = *pc;
+                    *pc = make_float4(v.x + acc[i][j][0], v.y + acc[i][j][1], v.z + acc[i][j][2], v.w + acc[i][j][3]);
+                }
+        }
+        __syncthreads();
+    }
     constexpr int SEG = BN_ / 8;
     for (int idx = tid; idx < BM * SEG; idx += NTH) {
         const int row = idx / SEG, seg = idx - row * SEG;
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-template <typename AT, typename BT, bool AK, bool BK_, bool RG, int NWN, int BN_>
+template <typename AT, typename BT, bool AK, bool BK_, bool RG, int NWN, int BN_, int KS = 1>
 int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN_ - 1) / BN_;
     const int splits = e.splits > 1 ? e.splits : 1;
@@ -180,12 +201,12 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     constexpr int lds_bytes = cstage > 4 * OPER_BYTES ? cstage : 4 * OPER_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_>),
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_>), dim3(tm * tn * splits), dim3(128 * NWN), lds_bytes, s,
+    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS>), dim3(tm * tn * splits), dim3(128 * NWN), lds_bytes, s,
                        reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
                        d->lda, d->ldb, tm, tn, splits, (d->debug_flags >> 4) & 15, e2);
     MMF_CHECK_LAUNCH();
@@ -194,16 +215,24 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
 
 template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
-    // 8 waves (64x32 per wave, 4 waves per SIMD with two workgroups per CU) hide LDS / MFMA-issue latency
-    // better than 4 waves (64x64 per wave); bit 8 of no_ring selects the 4-wave form for A/B measurements.
+    // 8 waves (4 per SIMD with two workgroups per CU) hide LDS / MFMA-issue latency better than 4 waves of 64x64;
+    // bit 8 of debug_flags selects the 4-wave form for A/B measurements.
     if (d->debug_flags & 256) return launch_n<AT, BT, AK, BK_, RG, 2, 128>(d, e, s);
+    // Wave layout: 2x4 waves of 64x32 over both K-halves of a stage (KS = 1), or 2x2 waves of 64x64 times the two
+    // K-halves (KS = 2: a third fewer LDS operand reads, one extra pass over the LDS C stage at the end).  Measured
+    // (tools/micro_sweep.py gemm): KS = 2 wins 1-5 % once a workgroup runs >= 24 K-steps (FFN-down forward, the long
+    // dgrads, the split weight gradients) and loses 3-14 % on the 12-step K = 768 GEMMs.  Bit 12 forces it, bit 13 forbids.
+    const int splits = e.splits > 1 ? e.splits : 1;
+    const int ksteps = (d->K + BK - 1) / BK / splits;
+    const bool ks2 = (d->debug_flags & 4096) || (ksteps >= 24 && !(d->debug_flags & 8192));
     // 96-wide tiles when they need fewer rounds of the 512 workgroup slots (256 CUs x 2) than 128-wide ones
     if (!RG && !AK && is_bf16<AT>::value && is_bf16<BT>::value && (d->N % 96) == 0 && !(d->debug_flags & 512)) {
         const long tm = d->M / BM;
         const long r128 = (tm * ((d->N + 127) / 128) + 511) / 512, r96 = (tm * (d->N / 96) + 511) / 512;
-        if (r96 * 96 < r128 * 128) return launch_n<AT, BT, AK, BK_, false, 4, 96>(d, e, s);
+        if (r96 * 96 < r128 * 128)
+            return ks2 ? launch_n<AT, BT, AK, BK_, false, 4, 96, 2>(d, e, s) : launch_n<AT, BT, AK, BK_, false, 4, 96>(d, e, s);
     }
-    return launch_n<AT, BT, AK, BK_, RG, 4, 128>(d, e, s);
+    return ks2 ? launch_n<AT, BT, AK, BK_, RG, 4, 128, 2>(d, e, s) : launch_n<AT, BT, AK, BK_, RG, 4, 128>(d, e, s);
 }
 
 }  // namespace

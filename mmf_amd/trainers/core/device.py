@@ -12,8 +12,9 @@ it, tools/sweeps/sweep_visual_bert.py:41) are simply skipped — but shaped for 
   * a bucket is all-reduced (RCCL, `backend="nccl"`) on the communicator's own stream as soon as its
     last gradient has been accumulated (`register_post_accumulate_grad_hook`), overlapping the
     remaining backward kernels;
-  * `finish()` waits for the in-flight buckets, scales by 1/world and scatters the result back into
-    `param.grad`.
+  * `finish()` waits for the in-flight buckets and REBINDS every `param.grad` to its slice of the averaged flat
+    bucket — no per-parameter copy or scale kernels (416 launches per step for this model otherwise); the mean is
+    one multiply per bucket.
 """
 import torch
 import torch.distributed as dist
@@ -70,11 +71,19 @@ class GradientReducer:
         plist = [p for p in self.buckets[bi] if p.grad is not None]
         if not plist:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in plist])
+        # one flat fp32 buffer per bucket, every slot starting on a 256-byte boundary (the fused optimizer reads the
+        # slices with 16-byte vector loads); filled by ONE multi-tensor copy
+        offs, total = [], 0
+        for p in plist:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=torch.float32, device=plist[0].grad.device) if any(p.numel() % 64 for p in plist) else \
+            torch.empty(total, dtype=torch.float32, device=plist[0].grad.device)
+        torch._foreach_copy_([flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, plist)], [p.grad for p in plist])
         if self.comm_dtype is not None and flat.dtype != self.comm_dtype:
             flat = flat.to(self.comm_dtype)
-        work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self._inflight.append((work, flat, plist))
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((work, flat, plist, offs))
 
     def finish(self):
         """Call after `loss.backward()`: flush partially filled buckets (parameters without a gradient
@@ -90,13 +99,13 @@ class GradientReducer:
             if not self._launched[bi]:
                 self._launch(bi)
         inv = 1.0 / self.world
-        for work, flat, plist in self._inflight:
+        for work, flat, plist, offs in self._inflight:
             work.wait()
-            off = 0
-            for p in plist:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad).to(p.grad.dtype)).mul_(inv)
-                off += n
+            if flat.dtype != torch.float32:
+                flat = flat.float()
+            flat.mul_(inv)   # one multiply per 64 MiB bucket
+            for off, p in zip(offs, plist):
+                p.grad = flat[off:off + p.numel()].view_as(p)   # rebind, no copy: the optimizer reads the bucket slice
         self.reset()
 
     def remove(self):

@@ -131,6 +131,16 @@ def test_gemm_tile_variants_agree(N):
     W3 = torch.empty_like(W1)
     nat().gemm(Ak, Bk, W3, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True, debug_flags=1024)
     close(W3, W2, 1e-5, 1e-4, "wgrad BK=32 form")
+    # K-split wave layout (bit 12 forces it, bit 13 forbids it): same sums in a different order
+    nat().gemm(A, B, C3, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, debug_flags=4096)
+    nat().gemm(A, B, C2, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, debug_flags=8192)
+    close(C3, C2, 1e-2, 1e-2, "fwd K-split layout")
+    nat().gemm(A, Bk, C3, M, N, K, K, N, N, b_kmajor=True, debug_flags=4096)
+    nat().gemm(A, Bk, C2, M, N, K, K, N, N, b_kmajor=True, debug_flags=8192)
+    close(C3, C2, 1e-2, 1e-2, "dgrad K-split layout")
+    nat().gemm(Ak, Bk, W3, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True, debug_flags=4096)
+    nat().gemm(Ak, Bk, W2, M, N, K, M, N, N, a_kmajor=True, b_kmajor=True, debug_flags=8192)
+    close(W3, W2, 1e-5, 1e-4, "wgrad K-split layout")
 
 
 def test_gemm_gelu_and_dgelu_epilogues():

@@ -52,9 +52,40 @@ def wgrad_sweep():
     nat.set_tunable(nat.TUN_SPLITK_FORCE, 0)
 
 
+def gemm_variants():
+    """All twelve per-layer GEMMs with the default wave layout and with the K-split wave layout (debug flag 4096)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from gemm_bench import SHAPES
+    dev = "cuda"
+    tot = {0: 0.0, 4096: 0.0}
+    for name, kind, m, n, k in SHAPES:
+        if kind == "NT":
+            A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(n, k, device=dev).bfloat16()
+            C = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+            f = lambda fl: nat.gemm(A, B, C, m, n, k, k, k, n, debug_flags=fl)
+        elif kind == "NN":
+            A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(k, n, device=dev).bfloat16()
+            C = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+            f = lambda fl: nat.gemm(A, B, C, m, n, k, k, n, n, b_kmajor=True, debug_flags=fl)
+        else:
+            A = torch.randn(k, m, device=dev).bfloat16(); B = torch.randn(k, n, device=dev).bfloat16()
+            C = torch.empty(m, n, device=dev, dtype=torch.float32)
+            f = lambda fl: nat.gemm(A, B, C, m, n, k, m, n, n, a_kmajor=True, b_kmajor=True, debug_flags=fl | 2048)
+        res = {}
+        for fl in (0, 4096, 0, 4096):
+            res.setdefault(fl, []).append(timeit(lambda: f(fl)))
+        a, b = min(res[0]), min(res[4096])
+        tot[0] += a; tot[4096] += b
+        print("%-12s %s M=%5d N=%5d K=%5d   default %6.1f us (%5.0f TF)   ksplit %6.1f us (%5.0f TF)  %+5.1f%%" % (
+            name, kind, m, n, k, a, 2.0 * m * n * k / a / 1e6, b, 2.0 * m * n * k / b / 1e6, 100 * (a - b) / a), flush=True)
+    print("layer total: default %.1f us, ksplit %.1f us" % (tot[0], tot[4096]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ln", "wgrad"]
     if "ln" in which:
         ln_sweep()
     if "wgrad" in which:
         wgrad_sweep()
+    if "gemm" in which:
+        gemm_variants()

@@ -89,7 +89,7 @@ typedef struct mmf_gemm_desc {
     int grp_in, grp_pad, grp_off;
     void* splitk_ws;          /* optional fp32 workspace enabling deterministic split-K (fp32 output, no epilogue) */
     int64_t splitk_ws_bytes;  /* >= mmf_gemm_splitk_splits(M,N,K) * M * N * 4 to take effect */
-    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 10 / 11: force / forbid the BK=32 form, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches */
+    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
 /* Number of K splits mmf_gemm_bf16 will use for this shape when given a workspace (1 = no split). */

@@ -79,7 +79,7 @@ class AttnBwdDesc(C.Structure):
 _lib = None
 # kernel-development switches (see mmf_gemm_desc.debug_flags); all zero in production
 _GEMM_DEBUG = ((int(os.environ.get("MMF_AMD_GEMM_DBG", "0")) << 4) | (int(os.environ.get("MMF_AMD_GEMM_4WAVE", "0")) << 8)
-               | (int(os.environ.get("MMF_AMD_GEMM_NO96", "0")) << 9) | (int(os.environ.get("MMF_AMD_GEMM_K32", "0")) << 10))
+               | (int(os.environ.get("MMF_AMD_GEMM_NO96", "0")) << 9))
 
 
 def lib():

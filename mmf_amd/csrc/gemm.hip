@@ -28,7 +28,6 @@
 
 using namespace gemm;
 
-int mmf_gemm_k32_dispatch(const mmf_gemm_desc* d, const gemm::EpiArgs& e, hipStream_t s);
 
 namespace {
 
@@ -279,11 +278,7 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     // ragged unless every tile is full and every chunk in range
     const bool ragged = (d->M % BM) || (d->N % BN) || (d->K % BK);
     const int key = (d->a_kmajor ? 1 : 0) | (d->b_kmajor ? 2 : 0) | (d->a_f32 ? 4 : 0) | (d->b_f32 ? 8 : 0);
-    // BK = 32 / four-workgroups-per-CU form (gemm32.hip): measured faster only for weight gradients with enough work
-    // to fill its 1024 workgroup slots (both operands k-major: full 256-byte DMA rows); bit 10 forces it, bit 11 forbids it.
-    const long wg_count = (long)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN) * (e.splits > 1 ? e.splits : 1);
-    const bool want32 = (d->debug_flags & 1024) || (d->a_kmajor && d->b_kmajor && wg_count >= 600 && !(d->debug_flags & 2048));
-    int rc = want32 ? mmf_gemm_k32_dispatch(d, e, s) : -1;
+    int rc = -1;
     if (rc < 0) switch (key) {
         case 0: rc = ragged ? launch<bf16, bf16, false, false, true>(d, e, s) : launch<bf16, bf16, false, false, false>(d, e, s); break;
         case 4: rc = ragged ? launch<float, bf16, false, false, true>(d, e, s) : launch<float, bf16, false, false, false>(d, e, s); break;

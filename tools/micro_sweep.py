@@ -42,7 +42,7 @@ def wgrad_sweep():
         A = torch.randn(Mtok, m, device=dev).bfloat16(); B = torch.randn(Mtok, n, device=dev).bfloat16()
         C = torch.empty(m, n, device=dev, dtype=torch.float32)
         fl = 2.0 * m * n * Mtok
-        for form, flag in (("k64", 2048), ("k32", 1024)):
+        for form, flag in (("k64", 0),):
             line = []
             for sp in (0, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14):
                 nat.set_tunable(nat.TUN_SPLITK_FORCE, sp)
@@ -53,11 +53,12 @@ def wgrad_sweep():
 
 
 def gemm_variants():
-    """All twelve per-layer GEMMs with the default wave layout and with the K-split wave layout (debug flag 4096)."""
+    """All twelve per-layer GEMMs: default dispatch, K-split wave layout forced (bit 12) and forbidden (bit 13)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     from gemm_bench import SHAPES
     dev = "cuda"
-    tot = {0: 0.0, 4096: 0.0}
+    variants = (("default", 0), ("ksplit", 4096), ("no-ksplit", 8192))
+    tot = {n: 0.0 for n, _ in variants}
     for name, kind, m, n, k in SHAPES:
         if kind == "NT":
             A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(n, k, device=dev).bfloat16()
@@ -70,15 +71,17 @@ def gemm_variants():
         else:
             A = torch.randn(k, m, device=dev).bfloat16(); B = torch.randn(k, n, device=dev).bfloat16()
             C = torch.empty(m, n, device=dev, dtype=torch.float32)
-            f = lambda fl: nat.gemm(A, B, C, m, n, k, m, n, n, a_kmajor=True, b_kmajor=True, debug_flags=fl | 2048)
+            f = lambda fl: nat.gemm(A, B, C, m, n, k, m, n, n, a_kmajor=True, b_kmajor=True, debug_flags=fl)
         res = {}
-        for fl in (0, 4096, 0, 4096):
-            res.setdefault(fl, []).append(timeit(lambda: f(fl)))
-        a, b = min(res[0]), min(res[4096])
-        tot[0] += a; tot[4096] += b
-        print("%-12s %s M=%5d N=%5d K=%5d   default %6.1f us (%5.0f TF)   ksplit %6.1f us (%5.0f TF)  %+5.1f%%" % (
-            name, kind, m, n, k, a, 2.0 * m * n * k / a / 1e6, b, 2.0 * m * n * k / b / 1e6, 100 * (a - b) / a), flush=True)
-    print("layer total: default %.1f us, ksplit %.1f us" % (tot[0], tot[4096]))
+        for rep in range(2):
+            for vn, fl in variants:
+                res.setdefault(vn, []).append(timeit(lambda: f(fl)))
+        line = "%-11s %s N=%5d K=%5d " % (name, kind, n, k)
+        for vn, _ in variants:
+            t = min(res[vn]); tot[vn] += t
+            line += " %s %5.1f us (%4.0f TF)" % (vn, t, 2.0 * m * n * k / t / 1e6)
+        print(line, flush=True)
+    print("layer totals: " + "  ".join("%s %.1f us" % (vn, tot[vn]) for vn, _ in variants))
 
 
 if __name__ == "__main__":

@@ -72,15 +72,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // ------------------------------------------------------------------------------------------------
 constexpr int LNB_GRID = 128;       // default workgroups (16 waves each); one partial row per workgroup
 constexpr int LNB_MAX_GRID = 512;   // the workspace is sized for this many (MMF_TUN_LN_BWD_GRID may raise the grid)
-constexpr int LNB_WAVES = 16;
+constexpr int LNB_WAVES = 16;      // waves per workgroup for H <= 768; H = 1024 (four column chunks per lane) runs 8 waves so that
+                                   // its register budget doubles and nothing spills
+template <int NCH> struct LnbWaves { static constexpr int value = (NCH >= 4) ? 8 : LNB_WAVES; };
 
 template <int NCH>
-__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+__global__ __launch_bounds__(64 * LnbWaves<NCH>::value) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, bf16* __restrict__ dx,
                                                       bf16* __restrict__ dlin, DropoutCfg drop, float* __restrict__ partials,
                                                       int rows, int H) {
-    __shared__ float red[LNB_WAVES][NCH * 256];
+    constexpr int NWV = LnbWaves<NCH>::value;
+    __shared__ float red[NWV][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 ag[NCH], ab[NCH], al[NCH], gm[NCH];
 #pragma unroll
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const bf16* __re
         gm[c] = (COL_OF(c) < H) ? load4(gamma + COL_OF(c)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // software-pipelined over this wave's rows: the next row's loads are in flight during the reductions of the current one
-    const int rstep = gridDim.x * LNB_WAVES;
-    int row = blockIdx.x * LNB_WAVES + wave;
+    const int rstep = gridDim.x * NWV;
+    int row = blockIdx.x * NWV + wave;
     bf16x4 xr[NCH], dr_[NCH];
     float mu = 0.f, rs = 0.f;
     auto fetch = [&](int r) {
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const bf16* __re
             *reinterpret_cast<float4*>(&red[wave][COL_OF(c)]) = make_float4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
-        for (int col = threadIdx.x; col < H; col += 64 * LNB_WAVES) {
+        for (int col = threadIdx.x; col < H; col += 64 * NWV) {
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < LNB_WAVES; ++w) t += red[w][col];
+            for (int w = 0; w < NWV; ++w) t += red[w][col];
             partials[((size_t)blockIdx.x * 3 + qn) * H + col] = t;
         }
     }
@@ -692,7 +695,7 @@ void launch_ln_fwd(int rows, hipStream_t s, A... a) {
 }
 template <int NCH, typename... A>
 void launch_ln_bwd(int grid, hipStream_t s, A... a) {
-    hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(64 * LNB_WAVES), 0, s, a...);
+    hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(64 * LnbWaves<NCH>::value), 0, s, a...);
 }
 
 inline int grid_for(int64_t n, int per_block, int cap) {
@@ -733,7 +736,8 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     hipStream_t s = (hipStream_t)stream;
     DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
     const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
-    const int grid = grid_for(rows, LNB_WAVES, tg > 0 ? (tg > LNB_MAX_GRID ? LNB_MAX_GRID : tg) : LNB_GRID);
+    const int nch_ = (H + 255) / 256;
+    const int grid = grid_for(rows, nch_ >= 4 ? 8 : LNB_WAVES, tg > 0 ? (tg > LNB_MAX_GRID ? LNB_MAX_GRID : tg) : (nch_ >= 4 ? 2 * LNB_GRID : LNB_GRID));
     const int nch = (H + 255) / 256;
     const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
     switch (nch) {

@@ -146,6 +146,52 @@ def test_mmft_all_gradients_match_oracle_three_modalities():
     assert not bad, bad
 
 
+def test_mmft_bert_large_widths_match_oracle():
+    """BASELINE.json configs[3] shape class (MMFT / UNITER at BERT-large widths: H = 1024, 16 heads, I = 4096, joint sequence
+    128 tokens + 100 regions x 2048) with two layers: every parameter's full gradient against the pinned CPU oracle."""
+    H = 1024
+    cfg = dict(O.DEFAULT_CONFIG)
+    cfg.update(hidden_size=H, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096, vocab_size=2000,
+               max_position_embeddings=128, num_labels=3, initializer_range=0.02)
+    cfg["modalities"] = [dict(type="text", key="text", position_dim=128, segment_id=0, embedding_dim=H, layer_norm_eps=1e-12, hidden_dropout_prob=0.1),
+                         dict(type="image", key="image", embedding_dim=2048, position_dim=128, segment_id=1, layer_norm_eps=1e-12,
+                              hidden_dropout_prob=0.1)]
+    g = torch.Generator().manual_seed(11)
+    sd = {}
+    for k, shp in O.parameter_shapes(cfg).items():
+        ln = k.endswith("LayerNorm.weight") or (("layer_norms" in k or k.endswith(".1.weight")) and len(shp) == 1 and k.endswith("weight"))
+        sd[k] = (1.0 + 0.05 * torch.randn(shp, generator=g)) if ln else 0.02 * torch.randn(shp, generator=g)
+    B, T, R = 2, 128, 100
+    ids = torch.randint(1, cfg["vocab_size"], (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.long); mask[1, 77:] = 0; ids[mask == 0] = 0
+    image_mask = torch.ones(B, R, dtype=torch.long); image_mask[0, 90:] = 0
+    sample = {"input_ids": ids, "input_mask": mask, "segment_ids": torch.zeros(B, T, dtype=torch.long),
+              "image": torch.randn(B, R, 2048, generator=g), "image_mask": image_mask, "targets": torch.tensor([2, 0]),
+              "dataset_name": "hateful_memes", "dataset_type": "train"}
+    model = build_mmft(cfg, sd, O.shared(cfg))
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mmft_forward(sdr, cfg, dict(sample))
+    assert rel_err(out["scores"], ref["scores"]) <= TOL
+    (key, loss), = out["losses"].items()
+    ref_loss = torch.nn.functional.cross_entropy(ref["scores"], sample["targets"])
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    loss.sum().backward(); ref_loss.backward()
+    params = dict(model.named_parameters())
+    errs = {}
+    for k, v in sdr.items():
+        p = params[k]
+        if v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, k
+        if k.endswith("self.key.bias"):
+            continue
+        errs[k] = rel_err(p.grad, v.grad)
+    bad = {k: round(e, 4) for k, e in errs.items() if e > TOL}
+    assert not bad, bad
+
+
 def test_mmft_training_mode_is_seed_reproducible():
     z, case, cfg, sd, sample = load_mmft_case()
     model = build_mmft(cfg, sd, O.shared(cfg))

@@ -133,15 +133,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     stage_rows<D>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
     for (int i = tid; i < SKP; i += 256)   // additive mask, already in the log2 domain
         lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
-    stage_wait();
-    if (q0 >= a.Sq) return;
-
-    // Q fragments (B operand: column = query row)
+    // Q fragments (B operand: column = query row), fetched while the K / V DMA is still in flight
     const int qrow = min(q0 + x, a.Sq - 1);
     const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = frag_global(qptr, s, lane);
+    stage_wait();
+    if (q0 >= a.Sq) return;
 
     // scores^T tiles: sc[t][r] = S[q = q0+x][key = 32t + (r&3) + 8(r>>2) + 4h]
     f32x16 sc[NKT];
@@ -291,9 +290,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     stage_rows<D>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
     for (int i = tid; i < SKP; i += 256)   // additive mask in the log2 domain
         lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
-    stage_wait();
-    if (q0 >= a.Sq) return;
-
+    // per-query operands straight from global memory, fetched while the K / V DMA is still in flight
     const int qrow = min(q0 + x, a.Sq - 1);
     const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
     const bf16* doptr = a.dctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
@@ -303,6 +300,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     const float L = a.lse[(size_t)bh * a.Sq + qrow] * 1.4426950408889634f;   // log2 domain
     const float sc2 = a.scale * 1.4426950408889634f;
     const float dl = a.delta[(size_t)bh * a.Sq + qrow];
+    stage_wait();
+    if (q0 >= a.Sq) return;
     const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
 
     f32x16 dqo[NDT] = {};
@@ -373,9 +372,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
         lds_lse[i] = (i < a.Sq) ? a.lse[(size_t)bh * a.Sq + i] * 1.4426950408889634f : INFINITY;   // log2 domain
         lds_delta[i] = (i < a.Sq) ? a.delta[(size_t)bh * a.Sq + i] : 0.f;
     }
-    stage_wait();
-    if (k0 >= a.Sk) return;
-
+    // per-key operands straight from global memory, fetched while the Q / dO DMA is still in flight
     const int krow = min(k0 + x, a.Sk - 1);
     const bool kvalid = (k0 + x) < a.Sk;
     const bf16* kptr = a.k + ((size_t)b * a.Sk + krow) * a.ldk + head * HD;
@@ -384,6 +381,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
 #pragma unroll
     for (int s = 0; s < NS; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
     const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    stage_wait();
+    if (k0 >= a.Sk) return;
     const float sc2 = a.scale * 1.4426950408889634f;
 
     f32x16 dko[NDT] = {}, dvo[NDT] = {};

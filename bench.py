@@ -170,6 +170,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback for the product path")
+    local_rank %= torch.cuda.device_count()     # (several ranks may share a device under MMF_AMD_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

@@ -39,9 +39,11 @@ def distributed_init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     use_gpu = torch.cuda.is_available()
     if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
+        # MMF_AMD_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses duplicate devices): used to exercise
+        # the multi-rank code path on a single-GPU box
+        backend = os.environ.get("MMF_AMD_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
     if use_gpu:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
     t = torch.zeros(1, device="cuda" if use_gpu else "cpu")

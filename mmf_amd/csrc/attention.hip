@@ -235,40 +235,6 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
 //   dV = Pd^T dO ; dPd = dO V^T ; dS = P o (dropscale o dPd - delta), delta = rowsum(dO o O)
 //   dQ = dS K * scale ; dK = dS^T Q * scale
 // =================================================================================================
-// delta[b][head][q] = sum_d dO[b,q,head,d] * O[b,q,head,d].  One wave per token row, head_dim/4 lanes per head.
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const float* __restrict__ o32,
-                                                          const bf16* __restrict__ dO, int ldo, float* __restrict__ delta, int B, int Sq,
-                                                          int heads, int HD) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= B * Sq) return;
-    const int b = row / Sq, q = row - b * Sq;
-    const int H = heads * HD;
-    for (int c0 = 0; c0 < H; c0 += 256) {
-        const int col = c0 + lane * 4;
-        float acc = 0.f;
-        if (col < H) {
-            const bf16x4 x2 = *reinterpret_cast<const bf16x4*>(dO + (size_t)row * ldo + col);
-            if (o32) {
-                // exact O: sum_key dS[q][key] = 0 then holds to fp32 rounding, so the common component of K (e.g. the key
-                // bias) cannot leak into dQ -- with a bf16 O it does, at 2^-9 |dO||O| per row
-                const float4 x1 = *reinterpret_cast<const float4*>(o32 + (size_t)row * ldo + col);
-                acc = x1.x * (float)x2[0] + x1.y * (float)x2[1] + x1.z * (float)x2[2] + x1.w * (float)x2[3];
-            } else {
-                const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(o + (size_t)row * ldo + col);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc += (float)x1[i] * (float)x2[i];
-            }
-        }
-        const int lph = HD / 4;   // lanes per head: 16 (d = 64) or 32 (d = 128)
-        for (int off = lph / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if ((lane & (lph - 1)) == 0 && col < H) {
-            const int head = col / HD;
-            delta[((size_t)b * heads + head) * Sq + q] = acc;
-        }
-    }
-}
-
 // dQ kernel: same decomposition as the forward (wave = 32 query rows, all keys).
 template <int NKT, int D>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -299,7 +265,31 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     for (int s = 0; s < NS; ++s) { qf[s] = frag_global(qptr, s, lane); dof[s] = frag_global(doptr, s, lane); }
     const float L = a.lse[(size_t)bh * a.Sq + qrow] * 1.4426950408889634f;   // log2 domain
     const float sc2 = a.scale * 1.4426950408889634f;
-    const float dl = a.delta[(size_t)bh * a.Sq + qrow];
+    // delta[q] = sum_d dO[q][d] * O[q][d], formed here (one launch less): this lane holds half of the row's dO already
+    // (slots 16s + 8h + e); O comes from the fp32 copy when the forward kept one (exact row sums of dS), else from ctx
+    float dl = 0.f;
+    {
+        if (a.ctx32) {
+            const float* orow = a.ctx32 + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float4 o0 = *reinterpret_cast<const float4*>(orow + 16 * s + 8 * h);
+                const float4 o1 = *reinterpret_cast<const float4*>(orow + 16 * s + 8 * h + 4);
+                dl += o0.x * (float)dof[s][0] + o0.y * (float)dof[s][1] + o0.z * (float)dof[s][2] + o0.w * (float)dof[s][3] +
+                      o1.x * (float)dof[s][4] + o1.y * (float)dof[s][5] + o1.z * (float)dof[s][6] + o1.w * (float)dof[s][7];
+            }
+        } else {
+            const bf16* orow = a.ctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bf16x8 ov = frag_global(orow, s, lane);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (float)ov[e] * (float)dof[s][e];
+            }
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (h == 0 && q0 + x < a.Sq) a.delta[(size_t)bh * a.Sq + q0 + x] = dl;   // the dK/dV kernel (next launch) reads it
+    }
     stage_wait();
     if (q0 >= a.Sq) return;
     const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
@@ -497,9 +487,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     a.dctx = (const bf16*)d->dctx; a.dq = (bf16*)d->dq; a.dk = (bf16*)d->dk; a.dv = (bf16*)d->dv; a.delta = d->delta;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((a.B * a.Sq + 3) / 4), dim3(256), 0, s, a.ctx, a.ctx32, a.dctx, a.ldo, a.delta,
-                       a.B, a.Sq, a.heads, a.hd);
-    MMF_CHECK_LAUNCH();
+    // delta = rowsum(dO o O) is formed inside the dQ kernel and handed to the dK/dV kernel through d->delta
 
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;

@@ -88,7 +88,11 @@ typedef struct mmf_gemm_desc {
     const uint32_t* drop_seed; /* optional device word mixed into drop_key at run time (hipGraph replays) */
     int grp_in, grp_pad, grp_off;
     void* splitk_ws;          /* optional fp32 workspace enabling deterministic split-K (fp32 output, no epilogue) */
-    int64_t splitk_ws_bytes;  /* >= mmf_gemm_splitk_splits(M,N,K) * M * N * 4 to take effect */
+    int64_t splitk_ws_bytes;  /* >= mmf_gemm_splitk_splits(M,N,K) * M * (N + 1) * 4 to take effect */
+    float* rowsum_out;        /* optional fp32 [M], weight-gradient form only (a_kmajor && b_kmajor with split-K active):
+                                 rowsum_out[m] = sum_k A[k][m] — the bias gradient (column sums of dY) computed by the
+                                 same launch with one extra MFMA per A fragment against a ones operand, carried through
+                                 the split-K workspace (behind the slabs) and summed by the slab reduction */
     int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);

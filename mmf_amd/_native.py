@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("resid", C.c_void_p), ("ldr", C.c_int),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("grp_in", C.c_int), ("grp_pad", C.c_int), ("grp_off", C.c_int),
-        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("debug_flags", C.c_int),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("rowsum_out", C.c_void_p), ("debug_flags", C.c_int),
     ]
 
 
@@ -154,7 +154,9 @@ def _drop4(drop):
 # --------------------------------------------------------------------------------------------
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
          rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
-         grp=(0, 0, 0), debug_flags=0):
+         grp=(0, 0, 0), debug_flags=0, rowsum_out=None):
+    """`rowsum_out` (fp32 [M], weight-gradient form): also returns sum_k A[k][m], the bias gradient; only honoured when the
+    split-K path is active — check `gemm_rowsum_supported(M, N, K)` first."""
     d = GemmDesc()
     d.debug_flags = int(debug_flags) | _GEMM_DEBUG
     d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
@@ -181,9 +183,17 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
     if d.out_f32 and a_kmajor and b_kmajor and bias is None and resid is None and act == 0:
         sp = lib().mmf_gemm_splitk_splits(M, N, K)
         if sp > 1:
-            ws = torch.empty(sp * M * N, dtype=torch.float32, device=C_out.device)
+            ws = torch.empty(sp * M * (N + 1), dtype=torch.float32, device=C_out.device)
             d.splitk_ws, d.splitk_ws_bytes = _p(ws), ws.numel() * 4
+    if rowsum_out is not None:
+        _req(rowsum_out, torch.float32, "rowsum_out")
+        d.rowsum_out = _p(rowsum_out)
     _check(lib().mmf_gemm_bf16(C.byref(d), _stream()), "mmf_gemm_bf16")
+
+
+def gemm_rowsum_supported(M, N, K):
+    """True when a weight-gradient GEMM of this shape runs split-K, i.e. can carry the bias gradient (`rowsum_out`)."""
+    return lib().mmf_gemm_splitk_splits(M, N, K) > 1
 
 
 # --------------------------------------------------------------------------------------------

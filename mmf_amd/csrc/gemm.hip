@@ -32,7 +32,7 @@ using namespace gemm;
 namespace {
 
 // ---- the kernel ---------------------------------------------------------------------------------
-template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_, int KS = 1>
+template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_, int KS = 1, bool RS = false>
 __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
                                                              int M, int N, int K, int lda, int ldb,
                                                              int tiles_m, int tiles_n, int splits, int dbg, EpiArgs epi) {
@@ -80,6 +80,17 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
     for (int i = 0; i < NFM; ++i)
 #pragma unroll
         for (int j = 0; j < NFN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Bias gradient riding on the weight-gradient GEMM: rowsum[m] = sum_k A[k][m] = (A^T . 1)[m].  The first column of
+    // workgroups multiplies every A fragment once more, against an all-ones operand; every column of that 16x16 result
+    // holds the row sums.  (Only the wn == 0 waves do it, so each row is produced once per K-half.)
+    // (RS is a compile-time switch: the extra accumulators would push the K-split layout over its register budget.)
+    const bool do_rowsum = RS && epi.rowsum_col >= 0 && tile_n == 0 && wn == 0;
+    f32x4 accr[RS ? NFM : 1];
+#pragma unroll
+    for (int i = 0; i < (RS ? NFM : 1); ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 
     const int NB = (BN_ == 128) ? N : min(N, n0 + BN_);   // B rows / columns beyond the tile are never fetched
     Stage<AT, 1024 / NTH> sa;
@@ -126,6 +137,10 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
 #pragma unroll
                 for (int j = 0; j < NFN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if (RS && do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < NFM; ++i) accr[RS ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accr[RS ? i : 0], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!A_DMA) stage_store<AT, A_KMAJOR, NTH>(sa, na, tid);
@@ -147,6 +162,11 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
     // the output stores are full-line, 16-byte-per-lane transactions.
     constexpr int CLD = BN_ + 4;   // +4 floats: 16 rows of a fragment column land on distinct banks
     float* cs = reinterpret_cast<float*>(smem);
+    float* rs = cs + BM * CLD;     // [BM] row sums (bias-gradient partials), behind the C stage
+    if (RS && do_rowsum && wk == 0 && lane < 16) {
+#pragma unroll
+        for (int i = 0; i < NFM; ++i) rs[wm * WTM + i * 16 + lane] = accr[RS ? i : 0][0];
+    }
     if (wk == 0) {
 #pragma unroll
         for (int i = 0; i < NFM; ++i)
@@ -158,6 +178,10 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
     }
     __syncthreads();
     if (KS == 2) {
+        if (RS && do_rowsum && wk == 1 && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < NFM; ++i) rs[wm * WTM + i * 16 + lane] += accr[RS ? i : 0][0];
+        }
         if (wk == 1) {   // add the second K-half in place (each (wm, wn) region has exactly one writer per phase)
 #pragma unroll
             for (int i = 0; i < NFM; ++i)
@@ -176,13 +200,26 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
         const int row = idx / SEG, seg = idx - row * SEG;
         epilogue8(epi, m0 + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), split);
     }
+    if (RS && epi.rowsum_col >= 0 && tile_n == 0 && tid < BM && m0 + tid < M)
+        reinterpret_cast<float*>(epi.C)[(size_t)splits * epi.slab_stride + (size_t)split * M + m0 + tid] = rs[tid];
 }
 
-// C[m][n] = beta * C[m][n] + sum_s slab[s][m][n]   (N % 4 == 0)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long n, int N, float* __restrict__ C,
-                                                             int ldc, float beta) {
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
+// C[m][n] = beta * C[m][n] + sum_s slab[s][m][n]   (N % 4 == 0).  Behind the `splits` slabs the workspace holds
+// [splits][M] row-sum partials (bias gradient); the threads past the last float4 group sum those into rowsum[m].
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long n, int N, int M,
+                                                             float* __restrict__ C, int ldc, float beta, float* __restrict__ rowsum) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = t * 4;
+    if (i >= n) {
+        const long m = t - n / 4;
+        if (rowsum != nullptr && m < M) {
+            const float* rp = ws + (long)splits * n;
+            float a = rp[m];
+            for (int s = 1; s < splits; ++s) a += rp[(long)s * M + m];
+            rowsum[m] = a;
+        }
+        return;
+    }
     f32x4 acc = load_f4(ws + i);
     for (int s = 1; s < splits; ++s) acc += load_f4(ws + (long)s * n + i);
     const long m = i / N;
@@ -191,21 +228,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-template <typename AT, typename BT, bool AK, bool BK_, bool RG, int NWN, int BN_, int KS = 1>
+template <typename AT, typename BT, bool AK, bool BK_, bool RG, int NWN, int BN_, int KS = 1, bool RS = false>
 int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN_ - 1) / BN_;
     const int splits = e.splits > 1 ? e.splits : 1;
     const EpiArgs& e2 = e;
-    constexpr int cstage = BM * (BN_ + 4) * (int)sizeof(float);
+    constexpr int cstage = BM * (BN_ + 4) * (int)sizeof(float) + BM * (int)sizeof(float);   // C stage + row sums
     constexpr int lds_bytes = cstage > 4 * OPER_BYTES ? cstage : 4 * OPER_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS>),
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS, RS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS>), dim3(tm * tn * splits), dim3(128 * NWN), lds_bytes, s,
+    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS, RS>), dim3(tm * tn * splits), dim3(128 * NWN), lds_bytes, s,
                        reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
                        d->lda, d->ldb, tm, tn, splits, (d->debug_flags >> 4) & 15, e2);
     MMF_CHECK_LAUNCH();
@@ -216,6 +253,8 @@ template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     // 8 waves (4 per SIMD with two workgroups per CU) hide LDS / MFMA-issue latency better than 4 waves of 64x64;
     // bit 8 of debug_flags selects the 4-wave form for A/B measurements.
+    if (AK && BK_ && is_bf16<AT>::value && is_bf16<BT>::value && e.rowsum_col >= 0)   // weight gradient carrying the bias gradient
+        return launch_n<AT, BT, AK, BK_, RG, 4, 128, 1, AK && BK_>(d, e, s);
     if (d->debug_flags & 256) return launch_n<AT, BT, AK, BK_, RG, 2, 128>(d, e, s);
     // Wave layout: 2x4 waves of 64x32 over both K-halves of a stage (KS = 1), or 2x2 waves of 64x64 times the two
     // K-halves (KS = 2: a third fewer LDS operand reads, one extra pass over the LDS C stage at the end).  Measured
@@ -258,18 +297,23 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     // Split-K: a weight-gradient GEMM has few output tiles (768x768 -> 36) and a long reduction (K = tokens).
     // With a workspace, the K range is spread over `splits` workgroups per tile; each writes an fp32 partial slab
     // and a second kernel sums the slabs in a fixed order (deterministic, no atomics).
-    e.slab_stride = 0; e.splits = 1;
+    e.slab_stride = 0; e.splits = 1; e.rowsum_col = -1;
     float* final_c = nullptr; int final_ldc = 0; float final_beta = 0.f;
     {
         const int sp = mmf_gemm_splitk_splits(d->M, d->N, d->K);
         const bool plain = d->out_f32 && !d->bias && !d->coladd && !d->rowtab && d->act == 0 && !d->resid && !d->drop_thr16 &&
                            d->grp_in == 0;
-        if (plain && sp > 1 && d->splitk_ws && d->splitk_ws_bytes >= (long)sp * d->M * d->N * (long)sizeof(float)) {
+        if (plain && sp > 1 && d->splitk_ws && d->splitk_ws_bytes >= (long)sp * d->M * (d->N + 1) * (long)sizeof(float)) {
             e.splits = sp;
             e.slab_stride = (long)d->M * d->N;
             final_c = reinterpret_cast<float*>(d->C); final_ldc = d->ldc; final_beta = d->beta;
             e.C = d->splitk_ws; e.ldc = d->N; e.beta = 0.f;
         }
+    }
+    if (d->rowsum_out) {
+        MMF_CHECK_ARG(d->a_kmajor && d->b_kmajor && !d->a_f32 && !d->b_f32 && final_c,
+                      "mmf_gemm_bf16: rowsum_out needs the weight-gradient form (both operands k-major, bf16 A) with split-K active");
+        e.rowsum_col = 1;   // on; the partials live behind the slabs: ws[splits * M * N + split * M + m]
     }
     MMF_CHECK_ARG((d->act != 2 && d->act != 4) || d->aux, "mmf_gemm_bf16: act=2/4 needs aux");
     MMF_CHECK_ARG(d->act >= 0 && d->act <= 4, "mmf_gemm_bf16: unknown act");
@@ -292,8 +336,10 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     if (rc != 0) return rc;
     if (final_c) {
         const long n = (long)d->M * d->N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<const float*>(d->splitk_ws), e.splits, n, d->N, final_c, final_ldc, final_beta);
+        const long threads = n / 4 + (d->rowsum_out ? d->M : 0);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(d->splitk_ws), e.splits, n, d->N, d->M, final_c, final_ldc, final_beta,
+                           d->rowsum_out);
         MMF_CHECK_LAUNCH();
     }
     return 0;

@@ -177,9 +177,11 @@ def _grad_bf16(g, cols):
 # ---------------------------------------------------------------------------------------------
 # shared forward/backward pieces
 # ---------------------------------------------------------------------------------------------
-def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=None):
+def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=None, want_db=False):
     """dy [M,N] bf16 (row stride ldy, pad columns zero), x [M,K] bf16, w16 [N,K].
-    Returns (dx [M,K] bf16 or None, dW [N,K] fp32)."""
+    Returns (dx [M,K] bf16 or None, dW [N,K] fp32) and, with `want_db`, the bias gradient [N] fp32 as a third value —
+    carried by the weight-gradient GEMM itself when that runs split-K (one extra MFMA per A fragment against a ones
+    operand, no separate pass over dy), else by the column-sum kernels."""
     dev = dy.device
     dx = None
     if need_dx:
@@ -187,8 +189,14 @@ def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=N
         nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
                  act=2 if act_aux is not None else 0, aux=act_aux)
     dw = torch.empty(N, K, dtype=F32, device=dev)
-    nat.gemm(dy, x, dw, N, K, M, ldy, x.stride(0), K, a_kmajor=True, b_kmajor=True)
-    return dx, dw
+    fused = want_db and x.dtype == BF16 and nat.gemm_rowsum_supported(N, K, M)
+    db = torch.empty(N, dtype=F32, device=dev) if fused else None
+    nat.gemm(dy, x, dw, N, K, M, ldy, x.stride(0), K, a_kmajor=True, b_kmajor=True, rowsum_out=db)
+    if not want_db:
+        return dx, dw
+    if db is None:
+        db = _colsum(dy, ldy, M, N)
+    return dx, dw, db
 
 
 def _colsum(x, ld, rows, N):
@@ -231,8 +239,10 @@ class LinearFn(torch.autograd.Function):
             if g2.dtype == BF16:
                 g2 = g2.float()
             nat.cast2d_f32_to_bf16(g2.contiguous(), N, dy, ldy, M, N)
-        dx, dw = _linear_bwd(dy, ldy, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
-        db = _colsum(dy, ldy, M, N) if has_bias else None
+        if has_bias:
+            dx, dw, db = _linear_bwd(dy, ldy, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
+        else:
+            (dx, dw), db = _linear_bwd(dy, ldy, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0]), None
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None
 
 
@@ -275,9 +285,7 @@ def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_
     scale = 1.0 / math.sqrt(H // heads)
     nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
                       dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32)
-    dx, dw = _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid)
-    db = _colsum(dqkv, 3 * H, M, 3 * H)
-    return dx, dw, db
+    return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True)
 
 
 class SelfAttentionFn(torch.autograd.Function):
@@ -377,8 +385,7 @@ class DenseGeluFn(torch.autograd.Function):
         N = w16.shape[0]
         du = torch.empty(M, N, dtype=BF16, device=x2.device)
         nat.gelu_bwd(_grad_bf16(g, N), u, du)
-        dx, dw = _linear_bwd(du, N, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
-        db = _colsum(du, N, M, N)
+        dx, dw, db = _linear_bwd(du, N, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
         return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None
 
 
@@ -439,8 +446,7 @@ class FeedForwardFn(torch.autograd.Function):
         I = w1_16.shape[0]
         dres, dlin, dgamma, dbeta, db2 = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
         du, dw2 = _linear_bwd(dlin, H, hh, w2_16, M, H, I, act_aux=u)        # du = (dlin W2) * gelu'(u), gelu' saved by the forward
-        dx, dw1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres)     # dx = du W1 + dres
-        db1 = _colsum(du, I, M, I)
+        dx, dw1, db1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres, want_db=True)     # dx = du W1 + dres
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
 
 
@@ -636,8 +642,8 @@ class LinearTanhFn(torch.autograd.Function):
         N = w16.shape[0]
         dpre = torch.empty(M, N, dtype=BF16, device=x2.device)
         nat.tanh_bwd(_grad_bf16(g, N), y, dpre)
-        dx, dw = _linear_bwd(dpre, N, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
-        return (dx.view(ctx.xshape) if dx is not None else None), dw, _colsum(dpre, N, M, N), None
+        dx, dw, db = _linear_bwd(dpre, N, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None
 
 
 class MMBTEmbeddingsFn(torch.autograd.Function):
@@ -857,10 +863,8 @@ class BiAttentionFn(torch.autograd.Function):
                           scale, _grad_bf16(g1, BH), dqkv2, dqkv1[:, BH:], dqkv1[:, 2 * BH:], delta1, drop1, head_dim=hd, ctx_f32=o1)
         nat.attention_bwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add, ctx2, BH, lse2, B, heads, R, T,
                           scale, _grad_bf16(g2, BH), dqkv1, dqkv2[:, BH:], dqkv2[:, 2 * BH:], delta2, drop2, head_dim=hd, ctx_f32=o2)
-        dimg, dw1 = _linear_bwd(dqkv1, 3 * BH, i2, w1_16, B * R, 3 * BH, VH)
-        dtxt, dw2 = _linear_bwd(dqkv2, 3 * BH, t2, w2_16, B * T, 3 * BH, H)
-        db1 = _colsum(dqkv1, 3 * BH, B * R, 3 * BH)
-        db2 = _colsum(dqkv2, 3 * BH, B * T, 3 * BH)
+        dimg, dw1, db1 = _linear_bwd(dqkv1, 3 * BH, i2, w1_16, B * R, 3 * BH, VH, want_db=True)
+        dtxt, dw2, db2 = _linear_bwd(dqkv2, 3 * BH, t2, w2_16, B * T, 3 * BH, H, want_db=True)
         return (dimg.view(B, R, VH), dtxt.view(B, T, H),
                 dw1[:BH], db1[:BH], dw1[BH:2 * BH], db1[BH:2 * BH], dw1[2 * BH:], db1[2 * BH:],
                 dw2[:BH], db2[:BH], dw2[BH:2 * BH], db2[BH:2 * BH], dw2[2 * BH:], db2[2 * BH:],

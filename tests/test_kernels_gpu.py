@@ -102,6 +102,26 @@ def test_gemm_visual_projection_epilogue():
     close(dW, dV.float().t() @ feat.to(torch.bfloat16).float(), 1e-4, 2e-2, "visual wgrad")
 
 
+@pytest.mark.parametrize("Nout,Kin,T", [(768, 768, 7296), (2304, 768, 7296), (3072, 768, 2048), (200, 136, 4096), (768, 3072, 7296)])
+def test_gemm_wgrad_carries_the_bias_gradient(Nout, Kin, T):
+    """Weight-gradient form with `rowsum_out`: the same launch returns dW = dY^T X and db = column sums of dY (ones-operand
+    MFMA in the first column of workgroups, extra slab column, summed by the slab reduction)."""
+    assert nat().gemm_rowsum_supported(Nout, Kin, T)
+    dY = rnd(T, Nout); X = rnd(T, Kin)
+    dW = torch.empty(Nout, Kin, dtype=torch.float32, device=DEV); db = torch.full((Nout,), float("nan"), device=DEV)
+    nat().gemm(dY, X, dW, Nout, Kin, T, Nout, Kin, Kin, a_kmajor=True, b_kmajor=True, rowsum_out=db)
+    close(dW, dY.float().t() @ X.float(), 1e-4, 2e-3 * math.sqrt(T) / 8, "dW with fused bias gradient")
+    close(db, dY.float().sum(0), 1e-5, 1e-3, "fused bias gradient")
+    # and dW is what the plain weight-gradient launch gives
+    dW2 = torch.empty_like(dW)
+    nat().gemm(dY, X, dW2, Nout, Kin, T, Nout, Kin, Kin, a_kmajor=True, b_kmajor=True, debug_flags=8192)
+    close(dW, dW2, 1e-6, 1e-5, "dW with / without the fused bias gradient")
+    # shapes that do not split fall back (the Python layer checks first); asking anyway is an error, not a silent skip
+    if not nat().gemm_rowsum_supported(Nout, Kin, 64):
+        with pytest.raises(Exception):
+            nat().gemm(dY[:64], X[:64], dW, Nout, Kin, 64, Nout, Kin, Kin, a_kmajor=True, b_kmajor=True, rowsum_out=db)
+
+
 @pytest.mark.parametrize("N", [768, 2304, 3072, 384])
 def test_gemm_tile_variants_agree(N):
     """8-wave 128x128 / 128x96 tiles (production), the 4-wave 128x128 form and the K-split wave layout compute the same thing."""

@@ -19,6 +19,7 @@ Reference ops replaced (paths relative to the reference root):
   LogitBCEFn                LogitBinaryCrossEntropy                        (losses.py:246-251)
 """
 import math
+import os
 import weakref
 
 import torch
@@ -177,6 +178,9 @@ def _grad_bf16(g, cols):
 # ---------------------------------------------------------------------------------------------
 # shared forward/backward pieces
 # ---------------------------------------------------------------------------------------------
+_FUSED_DB = os.environ.get("MMF_AMD_NO_FUSED_DB", "0") != "1"   # A/B switch for measurements
+
+
 def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=None, want_db=False):
     """dy [M,N] bf16 (row stride ldy, pad columns zero), x [M,K] bf16, w16 [N,K].
     Returns (dx [M,K] bf16 or None, dW [N,K] fp32) and, with `want_db`, the bias gradient [N] fp32 as a third value —
@@ -189,7 +193,7 @@ def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=N
         nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
                  act=2 if act_aux is not None else 0, aux=act_aux)
     dw = torch.empty(N, K, dtype=F32, device=dev)
-    fused = want_db and x.dtype == BF16 and nat.gemm_rowsum_supported(N, K, M)
+    fused = want_db and x.dtype == BF16 and _FUSED_DB and nat.gemm_rowsum_supported(N, K, M)
     db = torch.empty(N, dtype=F32, device=dev) if fused else None
     nat.gemm(dy, x, dw, N, K, M, ldy, x.stride(0), K, a_kmajor=True, b_kmajor=True, rowsum_out=db)
     if not want_db:

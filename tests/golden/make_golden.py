@@ -494,8 +494,154 @@ def make_vilbert():
         print(name, "loss", loss.item(), "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
 
 
+UNITER_CASES = {
+    "uniter_small64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
+                           max_position_embeddings=40, img_dim=72, head_hidden_size=256, num_labels=13, B=3, T=12, R=7, seed=51),
+}
+
+
+def make_uniter():
+    """UNITER (classification, task vqa2) through the reference's own UNITER.forward / add_custom_params / add_pos_feat,
+    UNITERForClassification.forward -> _infer_with_heads, UNITERModelBase.forward + _compute_*_embeddings,
+    UNITERImageEmbeddings, HF BertEmbeddings / BertEncoder and the MLP head (mmf/models/uniter.py).  Only the
+    `from_pretrained` calls of UNITERModelBase.__init__ (network) are replaced by constructing the same HF classes from a
+    small config."""
+    from torch import nn
+    from transformers import BertConfig
+    from transformers.models.bert.modeling_bert import BertEmbeddings, BertModel
+    MLP = refshim.ref_import("mmf.models.transformers.heads.mlp").MLP
+    U = refshim.ref_import("mmf.models.uniter")
+    from mmf.modules.losses import MMFLoss
+
+    for name, c in UNITER_CASES.items():
+        torch.manual_seed(c["seed"])
+        bcfg = BertConfig(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+                          num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                          vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"], type_vocab_size=2,
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12, pad_token_id=0)
+        bcfg._attn_implementation = "eager"
+
+        class EncoderCompat(nn.Module):
+            """HF BertEncoder called the transformers<=4.10 way (the reference's pin): positional tuple output
+            (last_hidden_state, all_hidden_states).  The installed transformers 5 no longer returns the hidden states from
+            the encoder call, so the layer loop of BertEncoder.forward is spelled out over the very same BertLayer modules."""
+
+            def __init__(self, enc):
+                super().__init__()
+                self.layer = enc.layer
+
+            def forward(self, hidden_states, attention_mask=None, output_hidden_states=False):
+                all_hidden = ()
+                for layer in self.layer:
+                    all_hidden = all_hidden + (hidden_states,)
+                    out = layer(hidden_states, attention_mask=attention_mask)
+                    hidden_states = out[0] if isinstance(out, (tuple, list)) else out
+                all_hidden = all_hidden + (hidden_states,)
+                return (hidden_states, all_hidden)
+
+        class RefBase(nn.Module):   # module tree of UNITERModelBase (uniter.py:117-150)
+            def __init__(self):
+                super().__init__()
+                self.text_embeddings = BertEmbeddings(bcfg)
+                self.img_embeddings = U.UNITERImageEmbeddings(img_dim=c["img_dim"], hidden_size=c["hidden_size"], hidden_dropout_prob=0.1)
+                bm = BertModel(bcfg)
+                self.encoder = EncoderCompat(bm.encoder)
+                self.pooler = bm.pooler
+
+        for fn in ("_compute_txt_embeddings", "_compute_img_embeddings", "_compute_img_txt_embeddings", "forward"):
+            setattr(RefBase, fn, getattr(U.UNITERModelBase, fn))
+
+        head_cfg = OmegaConf.create(dict(type="mlp", freeze=False, lr_multiplier=1.0, in_dim=c["hidden_size"],
+                                         hidden_size=c["head_hidden_size"], num_labels=c["num_labels"], pooler_name="bert_pooler"))
+
+        class RefCls(nn.Module):    # UNITERForClassification (uniter.py:286-347)
+            def __init__(self):
+                super().__init__()
+                self.uniter = RefBase()
+                self.heads = nn.ModuleDict({"vqa2": MLP(head_cfg)})
+                self.tasks = ["vqa2"]
+                self.losses = nn.ModuleDict({"vqa2": MMFLoss("logit_bce")})
+
+            forward = U.UNITERForClassification.forward
+
+        class RefUNITER(nn.Module):  # the registered BaseModel (uniter.py:621-773)
+            def __init__(self):
+                super().__init__()
+                self.uniter = RefCls()
+                self.tasks = ["vqa2"]
+
+            add_pos_feat = U.UNITER.add_pos_feat
+            add_custom_params = U.UNITER.add_custom_params
+            forward = U.UNITER.forward
+
+        ref = RefUNITER().eval()
+        shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+                  if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")}
+        sd = detweights.state_dict(shapes, c["seed"])
+        missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected, unexpected
+        B, T, R, seed = c["B"], c["T"], c["R"], c["seed"]
+        ids = (detweights.uniform(B * T, seed + 100) * c["vocab_size"]).astype(np.int64).reshape(B, T)
+        mask = np.ones((B, T), dtype=np.int64)
+        mask[1, T // 2:] = 0
+        mask[2, T - 3:] = 0
+        ids[mask == 0] = 0   # [PAD]
+        feats = (2.0 * detweights.uniform(B * R * c["img_dim"], seed + 102) - 1.0).astype(np.float32).reshape(B, R, -1)
+        xy = detweights.uniform(B * R * 4, seed + 104).astype(np.float32).reshape(B, R, 4)
+        x1 = np.minimum(xy[..., 0], xy[..., 2]) * 600 + 2; x2 = np.maximum(xy[..., 0], xy[..., 2]) * 600 + 4
+        y1 = np.minimum(xy[..., 1], xy[..., 3]) * 400 + 2; y2 = np.maximum(xy[..., 1], xy[..., 3]) * 400 + 4
+        bbox = np.stack([x1, y1, x2, y2], axis=-1).astype(np.float32)      # pixel boxes -> normalised by (w, h) in add_pos_feat
+        img_w = np.full((B,), 640, dtype=np.int64); img_h = np.full((B,), 480, dtype=np.int64)
+        max_features = np.array([R, R - 2, R - 1], dtype=np.int64)[:B]
+        targets = np.zeros((B, c["num_labels"]), dtype=np.float32)
+        for b in range(B):
+            targets[b, (3 * b + 1) % c["num_labels"]] = 1.0
+            targets[b, (5 * b + 2) % c["num_labels"]] = 0.6
+        sl = SampleList(input_ids=torch.from_numpy(ids), input_mask=torch.from_numpy(mask), segment_ids=torch.zeros(B, T, dtype=torch.long),
+                        image_feature_0=torch.from_numpy(feats),
+                        image_info_0=SampleList(max_features=torch.from_numpy(max_features), bbox=bbox, image_width=img_w, image_height=img_h),
+                        targets=torch.from_numpy(targets), dataset_name="vqa2", dataset_type="train")
+        holder = {}
+        orig = ref.uniter.uniter.forward
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            holder["seq"] = out.final_layer
+            return out
+
+        ref.uniter.uniter.forward = spy
+        out = ref(sl)
+        (lkey, loss), = out["losses"].items()
+        loss = loss.sum()
+        loss.backward()
+        rec = {"in_input_ids": ids, "in_input_mask": mask, "in_image_feature_0": feats, "in_bbox": bbox, "in_image_width": img_w,
+               "in_image_height": img_h, "in_max_features": max_features, "in_targets": targets}
+        rec["scores"] = out["scores"].detach().numpy()
+        rec["sequence_output"] = holder["seq"].detach().numpy()
+        rec["img_pos_feat"] = sl["img_pos_feat"].detach().numpy()
+        rec["loss"] = np.array(loss.item(), dtype=np.float64)
+        rec["loss_key"] = np.array(lkey)
+        names, norms, sums = [], [], []
+        for k, p in ref.named_parameters():
+            g = p.grad
+            names.append(k)
+            norms.append(0.0 if g is None else float(g.double().norm()))
+            sums.append(0.0 if g is None else float(g.double().sum()))
+            if g is not None and g.numel() <= 4096:
+                rec["grad::" + k] = g.numpy()
+        rec["grad_names"] = np.array(names)
+        rec["grad_norms"] = np.array(norms)
+        rec["grad_sums"] = np.array(sums)
+        rec["param_names"] = np.array(list(shapes.keys()))
+        rec["param_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
+        rec["case"] = np.array(repr(c))
+        path = os.path.join(HERE, "%s.npz" % name)
+        np.savez_compressed(path, **rec)
+        print(name, "loss", loss.item(), lkey, "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "mmbt", "mmft", "vilbert"]
+    which = sys.argv[1:] or ["visual_bert", "mmbt", "mmft", "vilbert", "uniter"]
     if "visual_bert" in which:
         main()
     if "mmbt" in which:
@@ -504,3 +650,5 @@ if __name__ == "__main__":
         make_mmft()
     if "vilbert" in which:
         make_vilbert()
+    if "uniter" in which:
+        make_uniter()

@@ -103,3 +103,26 @@ def load_vilbert_case(name="vilbert_small"):
         "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "vqa2", "dataset_type": "train",
     }
     return z, case, cfg, sd, sample
+
+
+def load_uniter_case(name="uniter_small64"):
+    z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {k: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    cfg = dict(
+        vocab_size=case["vocab_size"], hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"],
+        num_attention_heads=case["num_attention_heads"], intermediate_size=case["intermediate_size"],
+        max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2, layer_norm_eps=1e-12,
+        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, pad_token_id=0, img_dim=case["img_dim"], pos_dim=7,
+        img_hidden_dropout_prob=0.1, task="vqa2", head_hidden_size=case["head_hidden_size"], head_layer_norm_eps=1e-6,
+        head_dropout_prob=0.1, num_labels=case["num_labels"], initializer_range=0.02)
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "segment_ids": torch.zeros_like(torch.from_numpy(z["in_input_ids"])),
+        "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),
+        "image_info_0": {"max_features": torch.from_numpy(z["in_max_features"]), "bbox": torch.from_numpy(z["in_bbox"]),
+                         "image_width": torch.from_numpy(z["in_image_width"]), "image_height": torch.from_numpy(z["in_image_height"])},
+        "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "vqa2", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample

@@ -174,6 +174,9 @@ int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word
  * (seg, type) may be NULL (the reference adds them only when the modality has position / segment ids). */
 int mmf_rows_add_embed(const void* x, const int64_t* seg, const float* pos, const float* type, void* y, int B, int L,
                        int S, int H, int row0, int pos0, void* stream);
+/* UNITER (mmf/models/uniter.py:74-78): y[r, :] = bf16(x[r, :] + table[idx[r], :]) — region features (fp32 [rows, D]) plus the
+ * mask embedding row selected by the image mask; idx / table NULL: plain conversion.  D % 4 == 0. */
+int mmf_rows_add_table_f32(const float* x, const int64_t* idx, const float* table, void* y, int rows, int D, void* stream);
 /* The `torch.cat(list_embeddings, dim=1)` of huggingface.py:159 and its backward split, one modality block per
  * call: dst[(b*dst_bstride + i), :] = src[(b*src_bstride + i), :], b < nb, i < rpb; strides in rows; H % 8 == 0. */
 int mmf_copy_rows_bf16(const void* src, int src_bstride, void* dst, int dst_bstride, int nb, int rpb, int H,
@@ -222,7 +225,8 @@ int mmf_seed_advance(uint32_t* seed, void* stream);
  * BertIntermediate's activation when it is not fused into a dgrad GEMM epilogue (act == 2). */
 int mmf_gelu_bwd_bf16(const void* dh, const void* g, void* du, int64_t n, void* stream);
 /* Pointwise bf16 ops of ViLBERT's poolers and stream fusion (mmf/models/vilbert.py:799-826, 1315-1320):
- * op 0: out = a * b; op 1: out = relu(a); op 2: out = a * (b > 0) (ReLU backward, b = forward output). */
+ * op 0: out = a * b; op 1: out = relu(a); op 2: out = a * (b > 0) (ReLU backward, b = forward output); op 3: out = a + b
+ * (UNITER's image + position embedding sum, mmf/models/uniter.py:82). */
 int mmf_eltwise_bf16(int op, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* dx = dy * (1 - y^2): backward of the tanh in HF BertPooler (mmf/models/mmbt.py:311), y = saved output. */
 int mmf_tanh_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);

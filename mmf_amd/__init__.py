@@ -13,5 +13,6 @@ from mmf_amd.models import visual_bert as _visual_bert  # noqa: F401
 from mmf_amd.models import mmbt as _mmbt  # noqa: F401
 from mmf_amd.models import mmf_transformer as _mmft  # noqa: F401
 from mmf_amd.models import vilbert as _vilbert  # noqa: F401
+from mmf_amd.models import uniter as _uniter  # noqa: F401
 
 __version__ = "0.1.0"

@@ -273,6 +273,11 @@ def rows_add_embed(x, seg, pos, typ, y, B, L, S, H, row0=0, pos0=0):
     _check(lib().mmf_rows_add_embed(_p(x), _p(seg), _p(pos), _p(typ), _p(y), B, L, S, H, row0, pos0, _stream()), "mmf_rows_add_embed")
 
 
+def rows_add_table_f32(x, idx, table, y, rows, D):
+    _req(x, torch.float32, "x"); _req(idx, torch.int64, "idx"); _req(table, torch.float32, "table"); _req(y, torch.bfloat16, "y")
+    _check(lib().mmf_rows_add_table_f32(_p(x), _p(idx), _p(table), _p(y), rows, D, _stream()), "mmf_rows_add_table_f32")
+
+
 def copy_rows(src, src_bstride, dst, dst_bstride, nb, rpb, H):
     _req(src, torch.bfloat16, "src"); _req(dst, torch.bfloat16, "dst")
     _check(lib().mmf_copy_rows_bf16(_p(src), src_bstride, _p(dst), dst_bstride, nb, rpb, H, _stream()), "mmf_copy_rows_bf16")

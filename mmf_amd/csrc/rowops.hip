@@ -74,7 +74,7 @@ constexpr int LNB_GRID = 128;       // default workgroups (16 waves each); one p
 constexpr int LNB_MAX_GRID = 512;   // the workspace is sized for this many (MMF_TUN_LN_BWD_GRID may raise the grid)
 constexpr int LNB_WAVES = 16;      // waves per workgroup for H <= 768; H = 1024 (four column chunks per lane) runs 8 waves so that
                                    // its register budget doubles and nothing spills
-template <int NCH> struct LnbWaves { static constexpr int value = (NCH >= 4) ? 8 : LNB_WAVES; };
+template <int NCH> struct LnbWaves { static constexpr int value = (NCH >= 5) ? 4 : (NCH >= 4) ? 8 : LNB_WAVES; };   // 5..8 chunks (H <= 2048): 4 waves
 
 template <int NCH>
 __global__ __launch_bounds__(64 * LnbWaves<NCH>::value) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
@@ -232,6 +232,22 @@ __global__ __launch_bounds__(256) void rows_add_embed_kernel(const bf16* __restr
         f32x4 v = load4(xr + col);
         if (p) { const f32x4 c = load4(p + col); v += c; }
         if (ty) { const f32x4 d = load4(ty + col); v += d; }
+        store4(yr + col, v);
+    }
+}
+
+// y[r, :] = bf16(x[r, :] + table[idx[r], :])   (x fp32 region features, table fp32 [*, D]; idx may be null: plain cast)
+__global__ __launch_bounds__(256) void rows_add_table_f32_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                                  const float* __restrict__ table, bf16* __restrict__ y, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * D;
+    const float* t = (idx && table) ? table + (size_t)idx[r] * D : nullptr;
+    bf16* yr = y + (size_t)r * D;
+    for (int col = lane * 4; col < D; col += 256) {
+        f32x4 v = load4(xr + col);
+        if (t) { const f32x4 c = load4(t + col); v += c; }
         store4(yr + col, v);
     }
 }
@@ -425,7 +441,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ 
         else for (int64_t j = i; j < n; ++j) du[j] = (bf16)((float)dh[j] * (float)g[j]);
     }
 }
-// small pointwise ops on bf16 vectors: 0: a*b   1: relu(a)   2: a * (b > 0)   (ViLBERT poolers / fusion, vilbert.py:799-826,1315-1320)
+// small pointwise ops on bf16 vectors: 0: a*b   1: relu(a)   2: a * (b > 0)   3: a + b   (ViLBERT poolers / fusion,
+// vilbert.py:799-826,1315-1320; UNITER image + position embedding sum, uniter.py:82)
 __global__ __launch_bounds__(256) void eltwise_kernel(int op, const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out,
                                                        int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -434,6 +451,7 @@ __global__ __launch_bounds__(256) void eltwise_kernel(int op, const bf16* __rest
     float r;
     if (op == 0) r = x * (float)b[i];
     else if (op == 1) r = x > 0.f ? x : 0.f;
+    else if (op == 3) r = x + (float)b[i];
     else r = ((float)b[i] > 0.f) ? x : 0.f;
     out[i] = (bf16)r;
 }
@@ -731,20 +749,22 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
                       void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, float* dgamma,
                       float* dbeta, float* dbias, int accumulate, float* partials, int rows, int H, void* stream) {
     MMF_CHECK_ARG(dy && x && mean && rstd && gamma && dx && partials, "layernorm_bwd: null operand");
-    MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 1024, "layernorm_bwd: need H % 4 == 0 and H <= 1024");
+    MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 2048, "layernorm_bwd: need H % 4 == 0 and H <= 2048");
     MMF_CHECK_ARG(drop_thr16 == 0 || dlin, "layernorm_bwd: dropout needs dlin");
     hipStream_t s = (hipStream_t)stream;
     DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
     const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
     const int nch_ = (H + 255) / 256;
-    const int grid = grid_for(rows, nch_ >= 4 ? 8 : LNB_WAVES, tg > 0 ? (tg > LNB_MAX_GRID ? LNB_MAX_GRID : tg) : (nch_ >= 4 ? 2 * LNB_GRID : LNB_GRID));
+    const int grid = grid_for(rows, nch_ >= 5 ? 4 : nch_ >= 4 ? 8 : LNB_WAVES, tg > 0 ? (tg > LNB_MAX_GRID ? LNB_MAX_GRID : tg) : (nch_ >= 4 ? 2 * LNB_GRID : LNB_GRID));
     const int nch = (H + 255) / 256;
     const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
     switch (nch) {
         case 1: launch_ln_bwd<1>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
         case 2: launch_ln_bwd<2>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
         case 3: launch_ln_bwd<3>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
-        default: launch_ln_bwd<4>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
+        case 4: launch_ln_bwd<4>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
+        case 5: case 6: launch_ln_bwd<6>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
+        default: launch_ln_bwd<8>(grid, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, H); break;
     }
     MMF_CHECK_LAUNCH();
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((H + 31) / 32, 3), dim3(256), 0, s, partials, grid, H, dgamma, dbeta, dbias,
@@ -769,6 +789,13 @@ int mmf_rows_add_embed(const void* x, const int64_t* seg, const float* pos, cons
     MMF_CHECK_ARG(B > 0 && L > 0 && row0 >= 0 && S >= row0 + L && pos0 >= 0 && (H % 4) == 0, "rows_add_embed: bad shape");
     hipLaunchKernelGGL(rows_add_embed_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, seg, pos, type,
                        (bf16*)y, B, L, S, H, row0, pos0);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_rows_add_table_f32(const float* x, const int64_t* idx, const float* table, void* y, int rows, int D, void* stream) {
+    MMF_CHECK_ARG(x && y && rows > 0 && D > 0 && (D % 4) == 0, "rows_add_table_f32: bad operand");
+    hipLaunchKernelGGL(rows_add_table_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, idx, table, (bf16*)y, rows, D);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -874,7 +901,7 @@ int mmf_gelu_bwd_bf16(const void* dh, const void* u, void* du, int64_t n, void* 
     return 0;
 }
 int mmf_eltwise_bf16(int op, const void* a, const void* b, void* out, int64_t n, void* stream) {
-    MMF_CHECK_ARG(a && out && n > 0 && op >= 0 && op <= 2 && (op == 1 || b), "eltwise: bad operand");
+    MMF_CHECK_ARG(a && out && n > 0 && op >= 0 && op <= 3 && (op == 1 || b), "eltwise: bad operand");
     hipLaunchKernelGGL(eltwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, (const bf16*)a,
                        (const bf16*)b, (bf16*)out, n);
     MMF_CHECK_LAUNCH();

@@ -971,3 +971,82 @@ class ReluFn(torch.autograd.Function):
         d = torch.empty_like(y)
         nat.eltwise(2, g2, y, d)
         return d.view(g.shape)
+
+
+# ---------------------------------------------------------------------------------------------
+# UNITER pieces (mmf/models/uniter.py)
+# ---------------------------------------------------------------------------------------------
+class FeatureTableAddFn(torch.autograd.Function):
+    """img_feat + mask_embedding(img_masks) (uniter.py:74-78): fp32 region features plus a table row picked per region, written
+    once as bf16 (the conversion the feature GEMM would do anyway).  `padding_idx` rows of the table receive no gradient."""
+
+    @staticmethod
+    def forward(ctx, feats, idx, table, padding_idx):
+        B, R, D = feats.shape
+        f2 = feats.reshape(B * R, D).float().contiguous()
+        ix = idx.reshape(B * R).contiguous() if idx is not None else None
+        y = torch.empty(B * R, D, dtype=BF16, device=table.device)
+        nat.rows_add_table_f32(f2, ix, table.detach() if ix is not None else None, y, B * R, D)
+        ctx.save_for_backward(ix)
+        ctx.meta = (B, R, D, table.shape[0], padding_idx)
+        return y.view(B, R, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ix,) = ctx.saved_tensors
+        B, R, D, NT, pad = ctx.meta
+        if ix is None:
+            return None, None, None, None
+        g2 = _grad_bf16(g, D)
+        dt = torch.zeros(NT, D, dtype=F32, device=g2.device)
+        nat.rows_scatter_add(g2, D, B, R, R, ix.view(B, R), R, 0, 0, dt, D, 1)     # deterministic two-bucket column sums
+        if pad is not None:
+            dt[pad].zero_()
+        return None, None, dt, None
+
+
+class AddFn(torch.autograd.Function):
+    """a + b on bf16 activations (transformed_im + transformed_pos, uniter.py:82)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a2, b2 = _as_bf16_2d(a), _as_bf16_2d(b)
+        out = torch.empty_like(a2)
+        nat.eltwise(3, a2, b2, out)
+        return out.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class SmallKLinearFn(torch.autograd.Function):
+    """nn.Linear over a handful of input features (UNITER's 7-d box geometry, uniter.py:64,81): the operand is zero-padded to a
+    multiple of 8 columns so that its rows are 16-byte aligned for the GEMM loader.  The input gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K = x.shape[-1]
+        KP = _pad8(K)
+        N = weight.shape[0]
+        x2 = x.reshape(-1, K).float().contiguous()
+        M = x2.shape[0]
+        dev = weight.device
+        x8 = torch.empty(M, KP, dtype=BF16, device=dev)
+        nat.cast2d_f32_to_bf16(x2, K, x8, KP, M, K)
+        w8 = torch.empty(N, KP, dtype=BF16, device=dev)
+        nat.cast2d_f32_to_bf16(weight.detach().contiguous(), K, w8, KP, N, K)
+        y = torch.empty(M, N, dtype=BF16, device=dev)
+        nat.gemm(x8, w8, y, M, N, KP, KP, KP, N, bias=bias.detach())
+        ctx.save_for_backward(x8)
+        ctx.meta = (x.shape, M, N, K, KP)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x8,) = ctx.saved_tensors
+        xshape, M, N, K, KP = ctx.meta
+        dy = _grad_bf16(g, N)
+        dw8 = torch.empty(N, KP, dtype=F32, device=dy.device)
+        nat.gemm(dy, x8, dw8, N, KP, M, N, KP, KP, a_kmajor=True, b_kmajor=True)
+        return None, dw8[:, :K].contiguous(), _colsum(dy, N, M, N)

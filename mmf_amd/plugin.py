@@ -10,7 +10,7 @@ entry (mmf/common/registry.py:319), and the model adapters created here derive f
 `issubclass` assertion at registry.py:316 holds and MMF's `build_model` (mmf/utils/build.py:116-151), `Losses`,
 checkpointing and trainer loop run unchanged around the HIP-backed networks.
 
-Registered: models `visual_bert`, `mmbt`, `vilbert`, `mmft` / `mmf_transformer`; losses `logit_bce`,
+Registered: models `visual_bert`, `mmbt`, `vilbert`, `uniter`, `mmft` / `mmf_transformer`; losses `logit_bce`,
 `cross_entropy`; optimizer `adam_w`; scheduler `warmup_linear`; transformer backend `huggingface`; transformer heads
 `mlp` / `multilayer_mlp`.
 """
@@ -41,6 +41,12 @@ def _adapter(mmf_base_model, hip_cls, children):
                 setattr(self, name, getattr(inner, name))
             self._inner = [inner]  # not a sub-module: the parameters live under `children`, as in the reference
 
+        def init_losses(self):
+            from mmf_amd.models.base_model import BaseModel as HipBaseModel
+            if hip_cls.init_losses is not HipBaseModel.init_losses:      # e.g. UNITER defers losses to its sub-model
+                return hip_cls.init_losses(self._inner[0])
+            return super().init_losses()
+
         def get_optimizer_parameters(self, config):
             return self._inner[0].get_optimizer_parameters(config)
 
@@ -59,12 +65,13 @@ def install():
     from mmf_amd.common.registry import registry as hip_registry
     from mmf_amd.models.mmbt import MMBT
     from mmf_amd.models.mmf_transformer import MMFTransformer
+    from mmf_amd.models.uniter import UNITER
     from mmf_amd.models.vilbert import ViLBERT
     from mmf_amd.models.visual_bert import VisualBERT
 
     adapters = {}
     for names, cls, children in ((("visual_bert",), VisualBERT, ("model",)), (("mmbt",), MMBT, ("model",)),
-                                 (("vilbert",), ViLBERT, ("model",)),
+                                 (("vilbert",), ViLBERT, ("model",)), (("uniter",), UNITER, ("uniter",)),
                                  (("mmft", "mmf_transformer"), MMFTransformer, ("backend", "encoders", "heads"))):
         adapter = _adapter(MMFBaseModel, cls, children)
         for name in names:

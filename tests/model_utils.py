@@ -132,3 +132,28 @@ def build_vilbert(cfg, sd=None, device="cuda", **over):
     if sd is not None:
         model.load_state_dict({"model." + k: v for k, v in sd.items()}, strict=True)
     return model.to(device)
+
+
+def uniter_model_config(cfg, **over):
+    """MMF model_config.uniter (configs/models/uniter/defaults.yaml), classification on task vqa2."""
+    bert = dict(hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                intermediate_size=cfg["intermediate_size"], vocab_size=cfg["vocab_size"],
+                max_position_embeddings=cfg["max_position_embeddings"], type_vocab_size=2,
+                hidden_dropout_prob=cfg.get("hidden_dropout_prob", 0.1),
+                attention_probs_dropout_prob=cfg.get("attention_probs_dropout_prob", 0.1), layer_norm_eps=cfg["layer_norm_eps"])
+    d = dict(
+        model="uniter", random_init=True, bert_model_name=None, img_dim=cfg["img_dim"], hidden_size=cfg["hidden_size"],
+        hidden_dropout_prob=cfg.get("img_hidden_dropout_prob", 0.1), text_embeddings=dict(type="bert_embeddings", params=dict(bert)),
+        encoder=dict(type="transformer", params=dict(bert)),
+        heads=dict(vqa2=dict(type="mlp", freeze=False, lr_multiplier=1.0, in_dim=cfg["hidden_size"], hidden_size=cfg["head_hidden_size"],
+                             num_labels=cfg["num_labels"], pooler_name="bert_pooler")),
+        losses=dict(vqa2="logit_bce"), tasks=["vqa2"], do_pretraining=False)
+    d.update(over)
+    return Config(d)
+
+
+def build_uniter(cfg, sd=None, device="cuda", **over):
+    model = build_model(uniter_model_config(cfg, **over))
+    if sd is not None:
+        model.load_state_dict(sd, strict=True)
+    return model.to(device)

@@ -55,7 +55,7 @@ def test_install_registers_everything_and_keeps_the_parameter_tree(fake_mmf):
     from mmf_amd import plugin
     from mmf_amd.utils.build import build_model
     adapters = plugin.install()
-    assert set(adapters) == {"visual_bert", "mmbt", "vilbert", "mmft", "mmf_transformer"}
+    assert set(adapters) == {"visual_bert", "mmbt", "vilbert", "uniter", "mmft", "mmf_transformer"}
     for key in (("loss", "logit_bce"), ("loss", "cross_entropy"), ("optimizer", "adam_w"), ("scheduler", "warmup_linear"),
                 ("transformer_backend", "huggingface"), ("transformer_head", "mlp"), ("model", "vilbert")):
         assert key in registry.store, key

@@ -1050,3 +1050,29 @@ class SmallKLinearFn(torch.autograd.Function):
         dw8 = torch.empty(N, KP, dtype=F32, device=dy.device)
         nat.gemm(dy, x8, dw8, N, KP, M, N, KP, KP, a_kmajor=True, b_kmajor=True)
         return None, dw8[:, :K].contiguous(), _colsum(dy, N, M, N)
+
+
+class PairHalvesFn(torch.autograd.Function):
+    """nlvr2: pooled outputs of the two images of a sample side by side, [2B, H] -> [B, 2H] =
+    cat(x[:B], x[B:], dim=1) (visual_bert.py:369-374, vilbert.py:1322-1323 equivalent), as two strided row copies."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x2 = _as_bf16_2d(x)
+        B2, H = x2.shape
+        B = B2 // 2
+        out = torch.empty(B, 2 * H, dtype=BF16, device=x2.device)
+        o2 = out.view(2 * B, H)
+        nat.copy_rows(x2, 1, o2, 2, B, 1, H)              # first image  -> columns [0, H)
+        nat.copy_rows(x2[B:], 1, o2[1:], 2, B, 1, H)      # second image -> columns [H, 2H)
+        ctx.meta = (B, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H = ctx.meta
+        g2 = _grad_bf16(g, 2 * H).view(2 * B, H)
+        dx = torch.empty(2 * B, H, dtype=BF16, device=g2.device)
+        nat.copy_rows(g2, 2, dx, 1, B, 1, H)
+        nat.copy_rows(g2[1:], 2, dx[B:], 1, B, 1, H)
+        return dx

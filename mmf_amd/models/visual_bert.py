@@ -106,7 +106,9 @@ class VisualBERTForClassification(nn.Module):
         self.num_labels = self.config.num_labels
         self.dropout_prob = self.bert.config.hidden_dropout_prob
         if self.training_head_type == "nlvr2":
-            raise NotImplementedError("the nlvr2 head (visual_bert.py:324-325,364-370) is not built yet")
+            if self.pooler_strategy == "vqa":
+                raise ValueError("training_head_type nlvr2 pairs the BertPooler outputs; pooler_strategy must not be 'vqa'")
+            self.bert.config.hidden_size *= 2          # visual_bert.py:324-325
         self.classifier = nn.Sequential(
             BertPredictionHeadTransform(self.bert.config),
             Linear(self.bert.config.hidden_size, self.config.num_labels),
@@ -125,6 +127,8 @@ class VisualBERTForClassification(nn.Module):
                 visual_embeddings_type=None, image_text_alignment=None, masked_lm_labels=None):
         sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
                                                       visual_embeddings_type, image_text_alignment)
+        if self.training_head_type == "nlvr2":
+            pooled_output = Fn.PairHalvesFn.apply(pooled_output)       # 2B x H -> B x 2H, visual_bert.py:369-374
         output_dict = {}
         if self.output_hidden_states:
             output_dict["sequence_output"] = sequence_output
@@ -175,9 +179,23 @@ class VisualBERT(BaseModel):
 
     # ---- input massaging, visual_bert.py:444-556 ------------------------------------------------
     def update_sample_list_based_on_head(self, sample_list):
-        image_info = sample_list.get("image_info_0", None) or {}
-        image_dim_variable = image_info.get("max_features", None)
-        image_feat_variable = sample_list.get("image_feature_0", None)
+        bert_input_ids, bert_input_mask = sample_list["input_ids"], sample_list["input_mask"]
+        bert_input_type_ids = sample_list["segment_ids"]
+        if self.training_head_type == "nlvr2":          # visual_bert.py:490-514: text repeated, the two images stacked
+            bert_input_ids = torch.cat([bert_input_ids, bert_input_ids])
+            bert_input_mask = torch.cat([bert_input_mask, bert_input_mask])
+            bert_input_type_ids = torch.cat([bert_input_type_ids, bert_input_type_ids])
+            img0, img1 = sample_list.get("img0", None) or {}, sample_list.get("img1", None) or {}
+            image_feat_variable = torch.cat([img0["image_feature_0"], img1["image_feature_0"]])
+            d0 = (img0.get("image_info_0", None) or {}).get("max_features", None)
+            d1 = (img1.get("image_info_0", None) or {}).get("max_features", None)
+            image_dim_variable = torch.cat([d0, d1]) if d0 is not None and d1 is not None else None
+        else:
+            image_info = sample_list.get("image_info_0", None) or {}
+            image_dim_variable = image_info.get("max_features", None)
+            image_feat_variable = sample_list.get("image_feature_0", None)
+        sample_list["input_ids"], sample_list["input_mask"] = bert_input_ids, bert_input_mask
+        sample_list["segment_ids"] = bert_input_type_ids
         if image_dim_variable is None:
             image_dim_variable = sample_list["image_feature_0"].new_full(
                 size=(image_feat_variable.size(0), 1), fill_value=image_feat_variable.size(1))

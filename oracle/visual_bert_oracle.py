@@ -67,6 +67,8 @@ def parameter_shapes(cfg):
         s[p + "output.LayerNorm.bias"] = (H,)
     s["bert.pooler.dense.weight"] = (H, H)
     s["bert.pooler.dense.bias"] = (H,)
+    if cfg.get("training_head_type", "classification") == "nlvr2":
+        H = 2 * H   # visual_bert.py:324-325: the head sees the two images' pooled outputs side by side
     s["classifier.0.dense.weight"] = (H, H)
     s["classifier.0.dense.bias"] = (H,)
     s["classifier.0.LayerNorm.weight"] = (H,)
@@ -187,7 +189,10 @@ def visual_bert_base(sd, cfg, input_ids, attention_mask, token_type_ids, visual_
 
 
 def classification_head(sd, cfg, sequence_output, pooled_output, input_mask, train=False):
-    """VisualBERTForClassification.forward, visual_bert.py:389-403."""
+    """VisualBERTForClassification.forward, visual_bert.py:369-403."""
+    if cfg.get("training_head_type", "classification") == "nlvr2":
+        b = pooled_output.size(0)
+        pooled_output = torch.cat([pooled_output[: b // 2], pooled_output[b // 2:]], dim=1)  # :369-374, 2B x H -> B x 2H
     if cfg.get("pooler_strategy", "default") == "vqa":
         index = input_mask.sum(1) - 2  # :391
         pooled_output = torch.gather(
@@ -209,9 +214,20 @@ def prepare_inputs(sample_list):
     input_ids = sample_list["input_ids"]
     input_mask = sample_list["input_mask"]
     token_type_ids = sample_list["segment_ids"]
-    feats = sample_list["image_feature_0"]
-    image_dim = None
-    info = sample_list.get("image_info_0", None)
+    if "img0" in sample_list and "img1" in sample_list:   # training_head_type == "nlvr2", :490-514: both images, text repeated
+        input_ids = torch.cat([input_ids, input_ids])
+        input_mask = torch.cat([input_mask, input_mask])
+        token_type_ids = torch.cat([token_type_ids, token_type_ids])
+        i0, i1 = sample_list["img0"], sample_list["img1"]
+        feats = torch.cat([i0["image_feature_0"], i1["image_feature_0"]])
+        d0 = (i0.get("image_info_0", None) or {}).get("max_features", None)
+        d1 = (i1.get("image_info_0", None) or {}).get("max_features", None)
+        image_dim = torch.cat([d0, d1]) if d0 is not None and d1 is not None else None
+        info = None
+    else:
+        feats = sample_list["image_feature_0"]
+        image_dim = None
+        info = sample_list.get("image_info_0", None)
     if info is not None:
         image_dim = info.get("max_features", None)  # :518-520
     if image_dim is None:

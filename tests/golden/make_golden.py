@@ -640,10 +640,68 @@ def make_uniter():
         print(name, "loss", loss.item(), lkey, "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
 
 
+def make_visual_bert_nlvr2():
+    """VisualBERT with `training_head_type: nlvr2` (two images per sample, default BertPooler strategy) through the
+    reference's own VisualBERT.forward (visual_bert.py:483-601) and VisualBERTForClassification (:284-404)."""
+    from mmf.modules.losses import CrossEntropyLoss
+    c = dict(CASES["small64"], num_labels=2, seed=61)
+    cfg = reference_config(c)
+    cfg["training_head_type"] = "nlvr2"
+    cfg["pooler_strategy"] = "default"
+    cfg["losses"] = [dict(type="cross_entropy")]
+    model = ref_vb.VisualBERT(cfg)
+    model.build()
+    model.eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith("position_ids")}
+    sd = detweights.state_dict(shapes, c["seed"])
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("position_ids") for k in missing), (missing, unexpected)
+    inp = make_inputs(c)
+    B, R = c["B"], c["R"]
+    feats1 = (detweights.uniform(B * R * c["visual_embedding_dim"], c["seed"] + 202)).astype(np.float32).reshape(B, R, -1)
+    mf1 = np.array([R - 1, R, R - 3], dtype=np.int64)[:B]
+    targets = (detweights.uniform(B, c["seed"] + 203) > 0.5).astype(np.int64)
+    sl = SampleList(
+        input_ids=torch.from_numpy(inp["input_ids"]), input_mask=torch.from_numpy(inp["input_mask"]),
+        segment_ids=torch.from_numpy(inp["segment_ids"]),
+        img0=SampleList(image_feature_0=torch.from_numpy(inp["image_feature_0"]),
+                        image_info_0=SampleList(max_features=torch.from_numpy(inp["max_features"]))),
+        img1=SampleList(image_feature_0=torch.from_numpy(feats1), image_info_0=SampleList(max_features=torch.from_numpy(mf1))),
+        image_feature_0=torch.from_numpy(inp["image_feature_0"]),
+        targets=torch.from_numpy(targets), dataset_name="nlvr2", dataset_type="train")
+    out = model.forward(sl)
+    loss = CrossEntropyLoss()(sl, out)
+    loss.backward()
+    rec = {"in_input_ids": inp["input_ids"], "in_input_mask": inp["input_mask"], "in_segment_ids": inp["segment_ids"],
+           "in_feats0": inp["image_feature_0"], "in_feats1": feats1, "in_max_features0": inp["max_features"], "in_max_features1": mf1,
+           "in_targets": targets}
+    rec["scores"] = out["scores"].detach().numpy()
+    rec["loss"] = np.array(loss.item(), dtype=np.float64)
+    names, norms, sums = [], [], []
+    for k, p in model.named_parameters():
+        g = p.grad
+        names.append(k)
+        norms.append(0.0 if g is None else float(g.double().norm()))
+        sums.append(0.0 if g is None else float(g.double().sum()))
+        if g is not None and g.numel() <= 4096:
+            rec["grad::" + k] = g.numpy()
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms)
+    rec["grad_sums"] = np.array(sums)
+    rec["param_names"] = np.array(list(shapes.keys()))
+    rec["param_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
+    rec["case"] = np.array(repr(c))
+    path = os.path.join(HERE, "visual_bert_nlvr2.npz")
+    np.savez_compressed(path, **rec)
+    print("visual_bert_nlvr2 loss", loss.item(), "scores", rec["scores"], "->", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "mmbt", "mmft", "vilbert", "uniter"]
+    which = sys.argv[1:] or ["visual_bert", "nlvr2", "mmbt", "mmft", "vilbert", "uniter"]
     if "visual_bert" in which:
         main()
+    if "nlvr2" in which:
+        make_visual_bert_nlvr2()
     if "mmbt" in which:
         make_mmbt()
     if "mmft" in which:

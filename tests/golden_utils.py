@@ -126,3 +126,26 @@ def load_uniter_case(name="uniter_small64"):
         "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "vqa2", "dataset_type": "train",
     }
     return z, case, cfg, sd, sample
+
+
+def load_nlvr2_case():
+    z = np.load(os.path.join(GOLDEN_DIR, "visual_bert_nlvr2.npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {k: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}
+    cfg = dict(
+        vocab_size=case["vocab_size"], hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"],
+        num_attention_heads=case["num_attention_heads"], intermediate_size=case["intermediate_size"],
+        max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2, layer_norm_eps=1e-12,
+        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, visual_embedding_dim=case["visual_embedding_dim"],
+        num_labels=case["num_labels"], pooler_strategy="default", training_head_type="nlvr2", initializer_range=0.02)
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "segment_ids": torch.from_numpy(z["in_segment_ids"]),
+        "img0": {"image_feature_0": torch.from_numpy(z["in_feats0"]), "image_info_0": {"max_features": torch.from_numpy(z["in_max_features0"])}},
+        "img1": {"image_feature_0": torch.from_numpy(z["in_feats1"]), "image_info_0": {"max_features": torch.from_numpy(z["in_max_features1"])}},
+        "image_feature_0": torch.from_numpy(z["in_feats0"]),
+        "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "nlvr2", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample

@@ -107,3 +107,14 @@ def test_warmup_linear_schedule_matches_transformers():
 def test_adam_w_is_registered():
     from mmf_amd.common.registry import registry as reg
     assert reg.get_optimizer_class("adam_w").__name__ == "AdamW"
+
+
+def test_nlvr2_head_parameter_tree_matches_the_reference():
+    from tests.golden_utils import load_nlvr2_case
+    from tests.model_utils import build_visual_bert
+    z, case, cfg, sd, sample = load_nlvr2_case()
+    model = build_visual_bert(cfg, sd, device="cpu", training_head_type="nlvr2", losses=[dict(type="cross_entropy")])
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    assert ours == ref
+    assert ours["model.classifier.0.dense.weight"] == (2 * cfg["hidden_size"], 2 * cfg["hidden_size"])

@@ -190,3 +190,33 @@ def test_graph_with_optimizer_is_one_full_training_step():
     assert worst <= 2e-4, worst     # 3 Adam steps of 1e-3: any skipped / doubled update would show at 1e-3
     att = m1.model.bert.encoder.layer[0].attention.self
     assert torch.equal(att.packed_qkv()[1], torch.cat([att.query.bias, att.key.bias, att.value.bias]).detach())
+
+
+def test_nlvr2_head_golden_forward_loss_and_gradients():
+    """`training_head_type: nlvr2` (two images per sample; pooled outputs paired into [B, 2H]) against the fixture recorded
+    from the real reference."""
+    from tests.golden_utils import load_nlvr2_case
+    z, case, cfg, sd, sample = load_nlvr2_case()
+    model = build_visual_bert(cfg, sd, training_head_type="nlvr2", losses=[dict(type="cross_entropy")])
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    assert out["scores"].shape == (case["B"], 2)
+    np.testing.assert_allclose(out["scores"].detach().float().cpu().numpy(), z["scores"], rtol=TOL, atol=TOL)
+    (key, loss), = out["losses"].items()
+    assert key == "train/nlvr2/cross_entropy"
+    assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    loss.sum().backward()
+    params = dict(model.named_parameters())
+    worst = {}
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        gname = str(gname)
+        p = params[gname]
+        assert p.grad is not None, gname
+        if gname.endswith("self.key.bias"):
+            continue
+        worst[gname] = abs(float(p.grad.double().norm()) - norm) / norm
+        full = "grad::" + gname
+        if full in z.files:
+            assert rel_err(p.grad, torch.from_numpy(z[full])) <= TOL, gname
+    bad = {k: round(v, 4) for k, v in worst.items() if v > TOL}
+    assert not bad, bad

@@ -63,3 +63,23 @@ def test_synthetic_batch_contract():
     assert b["input_ids"].shape == (4, 128) and b["image_feature_0"].shape == (4, 100, 2048)
     assert b["targets"].shape == (4, 3129) and float(b["targets"].sum()) == pytest.approx(4 * 1.9)
     assert int(b["input_mask"].sum()) == 4 * 128
+
+
+def test_oracle_nlvr2_head_matches_reference():
+    """`training_head_type: nlvr2` (two images per sample, pooled outputs side by side, visual_bert.py:369-374, 490-514)."""
+    import torch.nn.functional as F
+    from tests.golden_utils import load_nlvr2_case
+    z, case, cfg, sd, sample = load_nlvr2_case()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.visual_bert_forward(sd, cfg, sample, train=False)
+    np.testing.assert_allclose(out["scores"].detach().numpy(), z["scores"], rtol=1e-5, atol=2e-6)
+    loss = F.cross_entropy(out["scores"], sample["targets"])
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        key = str(gname)[len("model."):]
+        g = sd[key].grad
+        if key.endswith("self.key.bias"):
+            continue
+        assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key

@@ -12,7 +12,8 @@ MI355X-first internals: the text / visual stream layers are the same two fused a
 bi-attention node (two packed Q|K|V GEMMs + two cross attentions that read the other stream's K, V in place), two
 dense+dropout+residual+LayerNorm nodes and two feed-forward nodes.
 
-Not built (raise): the pretraining heads (:1054-1240), `nlvr2` pairing, `dynamic_attention` gates (:204-216),
+The `nlvr2` head (two images per sample, :1262-1265, 1322-1323, 1369-1394) is built.
+Not built (raise): the pretraining heads (:1054-1240), `dynamic_attention` gates (:204-216),
 `in_batch_pairs` / `fast_mode` batch expansion (:684-735), `task_specific_tokens`, `fixed_{t,v}_layer` > 0 and
 attention-map outputs (`visualization`, `output_all_attention_masks`: the fused kernel never materialises them).
 """
@@ -288,15 +289,14 @@ class ViLBERTForClassification(nn.Module):
             setattr(self.bert_config, k, list(config[k]))
         self.bert = ViLBERTBase(self.bert_config)
         self.training_head_type = self.config.training_head_type
-        if self.training_head_type == "nlvr2":
-            raise NotImplementedError("the nlvr2 pairing head (vilbert.py:1264-1265,1322-1323) is not built")
         self.num_labels = self.config.num_labels
         self.fusion_method = config.fusion_method
         if self.fusion_method not in ("sum", "mul"):
             raise AssertionError
         self.dropout_prob = self.config.hidden_dropout_prob
-        ccfg = BertConfig(hidden_size=config.bi_hidden_size, layer_norm_eps=self.bert_config.layer_norm_eps)
-        self.classifier = nn.Sequential(BertPredictionHeadTransform(ccfg), Linear(config.bi_hidden_size, self.num_labels))
+        head_width = config.bi_hidden_size * (2 if self.training_head_type == "nlvr2" else 1)      # vilbert.py:1262-1265
+        ccfg = BertConfig(hidden_size=head_width, layer_norm_eps=self.bert_config.layer_norm_eps)
+        self.classifier = nn.Sequential(BertPredictionHeadTransform(ccfg), Linear(head_width, self.num_labels))
         self.init_weights()
 
     def init_weights(self):
@@ -316,6 +316,9 @@ class ViLBERTForClassification(nn.Module):
             fused = pooled_output_t + pooled_output_v
         drop = Fn.make_drop(self.dropout_prob, self.training)
         pooled_output = Fn.DropoutFn.apply(fused, drop) if drop[1] else fused
+        if self.training_head_type == "nlvr2":
+            # pairs CONSECUTIVE rows of the stacked [img0 batch; img1 batch] exactly as the reference's view does (:1322-1323)
+            pooled_output = pooled_output.reshape(-1, pooled_output.size(1) * 2)
         hidden = self.classifier[0](pooled_output)
         logits = self.classifier[1](hidden, out_f32=True)
         output["scores"] = logits.contiguous().view(-1, self.num_labels)
@@ -348,12 +351,20 @@ class ViLBERT(BaseModel):
 
     def get_image_and_text_features(self, sample_list):
         """vilbert.py:1364-1418 (single-image datasets)."""
-        if sample_list.get("dataset_name", None) == "nlvr2":
-            raise NotImplementedError("nlvr2 image pairs (vilbert.py:1369-1394) are not built")
+        ids, mask, tt = sample_list["input_ids"], sample_list["input_mask"], sample_list["segment_ids"]
+        if sample_list.get("dataset_name", None) == "nlvr2":          # vilbert.py:1369-1394
+            ids, mask, tt = torch.cat([ids, ids]), torch.cat([mask, mask]), torch.cat([tt, tt])
+            i0, i1 = sample_list["img0"], sample_list["img1"]
+            info0, info1 = i0.get("image_info_0", None) or {}, i1.get("image_info_0", None) or {}
+            return {
+                "input_ids": ids, "attention_mask": mask, "token_type_ids": tt,
+                "image_dim": torch.cat([info0["max_features"], info1["max_features"]]),
+                "image_feature": torch.cat([i0["image_feature_0"], i1["image_feature_0"]]),
+                "image_location": torch.cat([info0["bbox"], info1["bbox"]]), "image_target": None, "image_label": None,
+            }
         image_info = sample_list.get("image_info_0", None) or {}
         return {
-            "input_ids": sample_list["input_ids"], "attention_mask": sample_list["input_mask"],
-            "token_type_ids": sample_list["segment_ids"], "image_dim": image_info.get("max_features", None),
+            "input_ids": ids, "attention_mask": mask, "token_type_ids": tt, "image_dim": image_info.get("max_features", None),
             "image_feature": sample_list.get("image_feature_0", None), "image_location": image_info.get("bbox", None),
             "image_target": None, "image_label": sample_list.get("image_labels", None),
         }

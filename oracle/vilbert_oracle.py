@@ -94,6 +94,8 @@ def parameter_shapes(cfg):
     s["bert.t_pooler.dense.bias"] = (BH,)
     s["bert.v_pooler.dense.weight"] = (BH, VH)
     s["bert.v_pooler.dense.bias"] = (BH,)
+    if cfg.get("training_head_type", "classification") == "nlvr2":
+        BH = 2 * BH        # vilbert.py:1262-1265: the head runs on pairs of pooled vectors
     s["classifier.0.dense.weight"] = (BH, BH)
     s["classifier.0.dense.bias"] = (BH,)
     s["classifier.0.LayerNorm.weight"] = (BH,)
@@ -219,8 +221,16 @@ def vilbert_base(sd, cfg, input_txt, image_feature, image_location, token_type_i
 
 def prepare_inputs(sample_list):
     """ViLBERT.get_image_and_text_features :1364-1418 (non-nlvr2) + the mask of :1431-1443."""
-    info = sample_list.get("image_info_0", None) or {}
-    feats = sample_list["image_feature_0"]
+    ids, amask, tt = sample_list["input_ids"], sample_list["input_mask"], sample_list["segment_ids"]
+    if sample_list.get("dataset_name", None) == "nlvr2":      # :1369-1394: text repeated, the two images stacked
+        ids, amask, tt = torch.cat([ids, ids]), torch.cat([amask, amask]), torch.cat([tt, tt])
+        i0, i1 = sample_list["img0"], sample_list["img1"]
+        feats = torch.cat([i0["image_feature_0"], i1["image_feature_0"]])
+        info = {"max_features": torch.cat([i0["image_info_0"]["max_features"], i1["image_info_0"]["max_features"]]),
+                "bbox": torch.cat([i0["image_info_0"]["bbox"], i1["image_info_0"]["bbox"]])}
+    else:
+        info = sample_list.get("image_info_0", None) or {}
+        feats = sample_list["image_feature_0"]
     image_dim = info.get("max_features", None)
     image_mask = None
     if feats is not None and image_dim is not None:
@@ -228,8 +238,7 @@ def prepare_inputs(sample_list):
         if image_dim.dim() < image_mask.dim():
             image_dim = image_dim.unsqueeze(-1)
         image_mask = (image_mask < image_dim).long()
-    return dict(input_ids=sample_list["input_ids"], attention_mask=sample_list["input_mask"],
-                token_type_ids=sample_list["segment_ids"], image_feature=feats, image_location=info.get("bbox", None),
+    return dict(input_ids=ids, attention_mask=amask, token_type_ids=tt, image_feature=feats, image_location=info.get("bbox", None),
                 image_attention_mask=image_mask)
 
 
@@ -242,6 +251,8 @@ def vilbert_forward(sd, cfg, sample_list, train=False, pooler_masks=None):
     fused = pooled_t * pooled_v if cfg.get("fusion_method", "mul") == "mul" else pooled_t + pooled_v   # :1315-1320
     hd = cfg["hidden_dropout_prob"] if train else 0.0
     x = F.dropout(fused, hd, training=hd > 0)
+    if cfg.get("training_head_type", "classification") == "nlvr2":
+        x = x.view(-1, x.size(1) * 2)        # :1322-1323 (pairs CONSECUTIVE rows of the stacked batch, as the reference does)
     x = F.gelu(F.linear(x, sd["classifier.0.dense.weight"], sd["classifier.0.dense.bias"]))
     x = layer_norm(x, sd["classifier.0.LayerNorm.weight"], sd["classifier.0.LayerNorm.bias"], cfg["layer_norm_eps"])
     logits = F.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])

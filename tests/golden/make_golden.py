@@ -355,6 +355,12 @@ def make_mmft():
         print(name, "loss", loss.item(), "scores", rec["scores"][0], "->", path, os.path.getsize(path), "bytes")
 
 
+VILBERT_NLVR2 = dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2,
+                     v_hidden_size=256, v_num_attention_heads=2, v_intermediate_size=192, v_num_hidden_layers=2,
+                     bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
+                     v_biattention_id=[0], t_biattention_id=[1], vocab_size=211, max_position_embeddings=40,
+                     v_feature_size=72, num_labels=2, B=3, T=12, R=7, seed=47, nlvr2=True)
+
 VILBERT_CASES = {
     # text stream d=64, visual + co-attention streams d=128 (as in the real config: 768/12, 1024/8, 1024/8)
     "vilbert_small": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=4,
@@ -400,9 +406,14 @@ def make_vilbert():
     # installed transformers no longer has.
     M.replace_with_jit = lambda: None
 
-    for name, c in VILBERT_CASES.items():
+    cases = dict(VILBERT_CASES)
+    cases["vilbert_nlvr2"] = VILBERT_NLVR2
+    for name, c in cases.items():
+        nlvr2 = bool(c.get("nlvr2", False))
         torch.manual_seed(c["seed"])
         cfg = vilbert_reference_config(c)
+        if nlvr2:
+            cfg["training_head_type"] = "nlvr2"
         bcfg = BertConfig.from_dict(OmegaConf.to_container(cfg))
 
         class RefCls(nn.Module):   # module tree of ViLBERTForClassification (vilbert.py:1243-1270)
@@ -410,12 +421,12 @@ def make_vilbert():
                 super().__init__()
                 self.config = cfg
                 self.bert = M.ViLBERTBase(bcfg)
-                self.training_head_type = "classification"
+                self.training_head_type = "nlvr2" if nlvr2 else "classification"
                 self.num_labels = c["num_labels"]
                 self.fusion_method = "mul"
                 self.dropout = nn.Dropout(0.1)
                 ccfg = deepcopy(bcfg)
-                ccfg.hidden_size = c["bi_hidden_size"]
+                ccfg.hidden_size = c["bi_hidden_size"] * (2 if nlvr2 else 1)      # vilbert.py:1262-1265
                 self.classifier = nn.Sequential(BertPredictionHeadTransform(ccfg), nn.Linear(ccfg.hidden_size, c["num_labels"]))
 
             forward = M.ViLBERTForClassification.forward
@@ -455,6 +466,19 @@ def make_vilbert():
                         image_feature_0=torch.from_numpy(feats),
                         image_info_0=SampleList(max_features=torch.from_numpy(max_features), bbox=torch.from_numpy(bbox)),
                         targets=torch.from_numpy(targets), dataset_name="vqa2", dataset_type="train")
+        extra = {}
+        if nlvr2:      # two images per sample (vilbert.py:1369-1394); labels are class indices
+            feats1 = (2.0 * detweights.uniform(B * R * c["v_feature_size"], seed + 202) - 1.0).astype(np.float32).reshape(B, R, -1)
+            bbox1 = detweights.uniform(B * R * 5, seed + 204).astype(np.float32).reshape(B, R, 5)
+            mf1 = np.array([R - 1, R, R - 3], dtype=np.int64)[:B]
+            labels = (detweights.uniform(B, seed + 203) > 0.5).astype(np.int64)
+            sl = SampleList(input_ids=torch.from_numpy(ids), input_mask=torch.from_numpy(mask), segment_ids=torch.from_numpy(seg),
+                            img0=SampleList(image_feature_0=torch.from_numpy(feats),
+                                            image_info_0=SampleList(max_features=torch.from_numpy(max_features), bbox=torch.from_numpy(bbox))),
+                            img1=SampleList(image_feature_0=torch.from_numpy(feats1),
+                                            image_info_0=SampleList(max_features=torch.from_numpy(mf1), bbox=torch.from_numpy(bbox1))),
+                            targets=torch.from_numpy(labels), dataset_name="nlvr2", dataset_type="train")
+            extra = {"in_feats1": feats1, "in_bbox1": bbox1, "in_max_features1": mf1, "in_labels": labels}
         holder = {}
         orig = ref.model.bert.forward
 
@@ -465,10 +489,15 @@ def make_vilbert():
 
         ref.model.bert.forward = spy
         out = ref(sl)
-        loss = LogitBinaryCrossEntropy()(sl, out)
+        if nlvr2:
+            from mmf.modules.losses import CrossEntropyLoss
+            loss = CrossEntropyLoss()(sl, out)
+        else:
+            loss = LogitBinaryCrossEntropy()(sl, out)
         loss.backward()
         rec = {"in_input_ids": ids, "in_input_mask": mask, "in_segment_ids": seg, "in_image_feature_0": feats, "in_bbox": bbox,
                "in_max_features": max_features, "in_targets": targets}
+        rec.update(extra)
         rec["scores"] = out["scores"].detach().numpy()
         rec["sequence_output_t"] = holder["t"].detach().numpy()
         rec["sequence_output_v"] = holder["v"].detach().numpy()

@@ -80,6 +80,7 @@ def load_mmft_case(name="mmft_small64"):
 
 
 def load_vilbert_case(name="vilbert_small"):
+    """`vilbert_small`: classification head; `vilbert_nlvr2`: two images per sample (img0 / img1), paired head."""
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))
     shapes = {str(n)[len("model."):]: tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
@@ -102,6 +103,15 @@ def load_vilbert_case(name="vilbert_small"):
         "image_info_0": {"max_features": torch.from_numpy(z["in_max_features"]), "bbox": torch.from_numpy(z["in_bbox"])},
         "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "vqa2", "dataset_type": "train",
     }
+    if case.get("nlvr2", False):
+        cfg["training_head_type"] = "nlvr2"
+        sample = {
+            "input_ids": sample["input_ids"], "input_mask": sample["input_mask"], "segment_ids": sample["segment_ids"],
+            "img0": {"image_feature_0": sample["image_feature_0"], "image_info_0": sample["image_info_0"]},
+            "img1": {"image_feature_0": torch.from_numpy(z["in_feats1"]),
+                     "image_info_0": {"max_features": torch.from_numpy(z["in_max_features1"]), "bbox": torch.from_numpy(z["in_bbox1"])}},
+            "targets": torch.from_numpy(z["in_labels"]), "dataset_name": "nlvr2", "dataset_type": "train",
+        }
     return z, case, cfg, sd, sample
 
 

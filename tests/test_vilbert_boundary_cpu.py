@@ -24,7 +24,7 @@ def test_registered_and_state_dict_matches_reference_tree():
 
 def test_unbuilt_variants_raise():
     z, case, cfg, sd, sample = load_vilbert_case()
-    for over in (dict(training_head_type="pretraining"), dict(training_head_type="nlvr2"), dict(dynamic_attention=True),
+    for over in (dict(training_head_type="pretraining"), dict(dynamic_attention=True),
                  dict(in_batch_pairs=True), dict(fast_mode=True), dict(task_specific_tokens=True), dict(fixed_t_layer=1),
                  dict(visualization=True)):
         with pytest.raises(NotImplementedError):

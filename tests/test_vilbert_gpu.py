@@ -117,12 +117,12 @@ def test_image_feature_embeddings_five_wide_location_operand():
         assert rel_err(p.grad, q.grad) <= TOL, (name, rel_err(p.grad, q.grad))
 
 
-def _bf16_weight_sensitivity(sd, cfg, sample, targets, masks):
+def _bf16_weight_sensitivity(sd, cfg, sample, targets, masks, loss_fn=logit_bce):
     """How far each gradient moves when the weights are merely rounded to bf16 (something every bf16 implementation
     does) — a per-parameter measure of conditioning, evaluated with the CPU oracle."""
     def run(weights):
         s = {k: v.clone().requires_grad_(True) for k, v in weights.items()}
-        logit_bce(O.vilbert_forward(s, cfg, dict(sample), pooler_masks=masks)["scores"], targets).backward()
+        loss_fn(O.vilbert_forward(s, cfg, dict(sample), pooler_masks=masks)["scores"], targets).backward()
         return {k: v.grad for k, v in s.items()}
     g0, g1 = run(sd), run({k: v.bfloat16().float() for k, v in sd.items()})
     return {k: rel_err(g1[k], g0[k]) for k in g0 if g0[k] is not None and float(g0[k].abs().max()) > 0}
@@ -227,6 +227,37 @@ def test_vilbert_real_stream_widths_match_oracle():
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump({"flips": flips, "bad": bad}, open("gpurun_out/vilbert_real_widths.json", "w"))
     assert not bad, bad
+
+
+def test_vilbert_nlvr2_golden_forward_loss_and_gradients():
+    z, case, cfg, sd, sample = load_vilbert_case("vilbert_nlvr2")
+    model = build_vilbert(cfg, sd, training_head_type="nlvr2", losses=[dict(type="cross_entropy")])
+    model.eval()
+    got = {}
+    hook = model.model.bert.register_forward_hook(lambda m, i, o: got.update(pt=o[2], pv=o[3]))
+    out = model(SampleList(sample_to(sample, "cuda")))
+    hook.remove()
+    assert out["scores"].shape == (case["B"], 2)
+    np.testing.assert_allclose(out["scores"].detach().float().cpu().numpy(), z["scores"], rtol=TOL, atol=TOL)
+    (key, loss), = out["losses"].items()
+    assert key == "train/nlvr2/cross_entropy" and abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    masks = ((got["pt"].detach().float().cpu() > 0).float(), (got["pv"].detach().float().cpu() > 0).float())
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.vilbert_forward(sdr, cfg, dict(sample), pooler_masks=masks)
+    ref_loss = torch.nn.functional.cross_entropy(ref["scores"], sample["targets"])
+    ref_loss.backward()
+    loss.sum().backward()
+    params = dict(model.named_parameters())
+    sens = _bf16_weight_sensitivity(sd, cfg, sample, sample["targets"], masks, torch.nn.functional.cross_entropy)
+    errs = {}
+    for k, v in sdr.items():
+        p = params["model." + k]
+        if v.grad is None or float(v.grad.abs().max()) == 0.0 or k.endswith(".key.bias") or k.endswith("key1.bias") or k.endswith("key2.bias"):
+            continue
+        assert p.grad is not None, k
+        errs[k] = rel_err(p.grad, v.grad)
+    bad = {k: round(e, 4) for k, e in errs.items() if e > max(TOL, 6.0 * sens.get(k, 0.0))}     # see _check_against
+    assert not bad, (bad, {k: round(sens[k], 4) for k in bad})
 
 
 def test_vilbert_training_mode_is_seed_reproducible():

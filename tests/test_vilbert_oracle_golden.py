@@ -39,3 +39,22 @@ def test_vilbert_oracle_matches_reference_forward_loss_and_gradients():
         if full in z.files:
             np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
     assert checked == len(sd) - 8
+
+
+def test_vilbert_oracle_nlvr2_matches_reference():
+    """Two images per sample (vilbert.py:1369-1394) and the paired head (:1262-1265, 1322-1323)."""
+    import torch.nn.functional as F
+    z, case, cfg, sd, sample = load_vilbert_case("vilbert_nlvr2")
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.vilbert_forward(sd, cfg, dict(sample), train=False)
+    np.testing.assert_allclose(out["scores"].detach().numpy(), z["scores"], rtol=1e-5, atol=5e-6)
+    loss = F.cross_entropy(out["scores"], sample["targets"])
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        key = str(gname)[len("model."):]
+        g = sd[key].grad
+        if norm == 0.0 or key.endswith(".key.bias") or key.endswith("key1.bias") or key.endswith("key2.bias"):
+            continue
+        assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key

@@ -37,6 +37,9 @@ def main(tag):
         lines.append("%-8d %-12.1f %-10.2f %-10.2f %-10.2f %-7.2f %s" % (len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot, k))
     lines.append("TOTAL kernel time %.1f us over %d dispatches (%.2f ms per step)" % (tot, len(rows), tot / 8e3))
     open("profiles/%s_kernel_stats.txt" % tag, "w").write("\n".join(lines) + "\n")
+    raw = glob.glob(src + "/trace/*kernel_stats.csv")       # rocprofv3's own --stats table, verbatim
+    if raw:
+        open("profiles/%s_rocprofv3_kernel_stats.csv" % tag, "w").write(open(raw[0]).read())
     # ---- traffic
     traffic = {}
     per = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -265,32 +265,44 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     for (int s = 0; s < NS; ++s) { qf[s] = frag_global(qptr, s, lane); dof[s] = frag_global(doptr, s, lane); }
     const float L = a.lse[(size_t)bh * a.Sq + qrow] * 1.4426950408889634f;   // log2 domain
     const float sc2 = a.scale * 1.4426950408889634f;
-    // delta[q] = sum_d dO[q][d] * O[q][d], formed here (one launch less): this lane holds half of the row's dO already
-    // (slots 16s + 8h + e); O comes from the fp32 copy when the forward kept one (exact row sums of dS), else from ctx
+    // delta[q] = sum_d dO[q][d] * O[q][d], formed here (one launch less).  With the fp32 copy of O (exact row sums of dS) the
+    // workgroup's 128 rows are read cooperatively — two threads per row, each a contiguous half of the head slice — so the
+    // cold fp32 rows come in as full cache lines; the result goes through LDS to the lane that owns the query and out to
+    // a.delta for the dK/dV kernel (next launch).
     float dl = 0.f;
-    {
-        if (a.ctx32) {
-            const float* orow = a.ctx32 + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
+    float* lds_delta = lds_mask + SKP;      // [128]
+    if (a.ctx32) {
+        const int r = tid >> 1, hh = tid & 1;
+        const int qr = min((int)blockIdx.y * 128 + r, a.Sq - 1);
+        const float* orow = a.ctx32 + ((size_t)b * a.Sq + qr) * a.ldo + head * HD + hh * (HD / 2);
+        const bf16* drow = a.dctx + ((size_t)b * a.Sq + qr) * a.ldo + head * HD + hh * (HD / 2);
+        float part = 0.f;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const float4 o0 = *reinterpret_cast<const float4*>(orow + 16 * s + 8 * h);
-                const float4 o1 = *reinterpret_cast<const float4*>(orow + 16 * s + 8 * h + 4);
-                dl += o0.x * (float)dof[s][0] + o0.y * (float)dof[s][1] + o0.z * (float)dof[s][2] + o0.w * (float)dof[s][3] +
-                      o1.x * (float)dof[s][4] + o1.y * (float)dof[s][5] + o1.z * (float)dof[s][6] + o1.w * (float)dof[s][7];
-            }
-        } else {
-            const bf16* orow = a.ctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
+        for (int i = 0; i < HD / 16; ++i) {
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + 8 * i);
+            const float4 o0 = *reinterpret_cast<const float4*>(orow + 8 * i);
+            const float4 o1 = *reinterpret_cast<const float4*>(orow + 8 * i + 4);
+            part += o0.x * (float)dv[0] + o0.y * (float)dv[1] + o0.z * (float)dv[2] + o0.w * (float)dv[3] +
+                    o1.x * (float)dv[4] + o1.y * (float)dv[5] + o1.z * (float)dv[6] + o1.w * (float)dv[7];
+        }
+        part += __shfl_xor(part, 1, 64);
+        if (hh == 0) {
+            lds_delta[r] = part;
+            if ((int)blockIdx.y * 128 + r < a.Sq) a.delta[(size_t)bh * a.Sq + blockIdx.y * 128 + r] = part;
+        }
+    } else {
+        const bf16* orow = a.ctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const bf16x8 ov = frag_global(orow, s, lane);
+        for (int s = 0; s < NS; ++s) {
+            const bf16x8 ov = frag_global(orow, s, lane);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dl += (float)ov[e] * (float)dof[s][e];
-            }
+            for (int e = 0; e < 8; ++e) dl += (float)ov[e] * (float)dof[s][e];
         }
         dl += __shfl_xor(dl, 32, 64);
-        if (h == 0 && q0 + x < a.Sq) a.delta[(size_t)bh * a.Sq + q0 + x] = dl;   // the dK/dV kernel (next launch) reads it
+        if (h == 0 && q0 + x < a.Sq) a.delta[(size_t)bh * a.Sq + q0 + x] = dl;
     }
     stage_wait();
+    if (a.ctx32) dl = lds_delta[wave * 32 + x];
     if (q0 >= a.Sq) return;
     const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
 
@@ -495,7 +507,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
 #define LAUNCH_DQ(N, DD)                                                                         \
     {                                                                                            \
-        const int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4;                                      \
+        const int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4 + 128 * 4;                            \
         if (int rc = set_lds(attn_bwd_dq_kernel<N, DD>, lds)) return rc;                         \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<N, DD>), grid, dim3(256), lds, s, a);             \
     }

@@ -127,6 +127,10 @@ typedef struct mmf_attn_desc {
     int head_dim;   /* 0 = 64 */
     float* ctx_f32; /* optional fp32 copy of ctx (layout of ctx, ldo): forward writes it, backward then forms
                        delta = rowsum(dO o O) from the unrounded O, which keeps sum_key dS = 0 to fp32 accuracy */
+    int causal_tail; /* 0 = none.  n > 0: the prefix-LM mask of M4C's multimodal transformer, MMT.forward,
+                        mmf/models/m4c.py:424-440 (a [B,1,L,L] mask there), without materialising it: the last n
+                        positions (decoding steps) are visible only to each other, causally (key <= query); all
+                        other pairs use `mask`.  Needs Sq == Sk and head_dim 64. */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
 
@@ -252,6 +256,37 @@ int mmf_cross_entropy_fwd(const float* logits, const int64_t* labels, float* los
                           int ignore_index, void* stream);
 int mmf_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* count, const float* gloss,
                           float* dlogits, int B, int C, int ignore_index, void* stream);
+
+/* ---- M4C (mmf/models/m4c.py) -------------------------------------------------------------------
+ * F.normalize(x, dim=-1) of the appearance / FastText / PHOC features (m4c.py:195,212,217,223): y[r, :D] = x[r, :D] /
+ * max(||x[r, :D]||_2, eps), written as bf16 at row stride ldy — `y` may point at a column offset inside the wider
+ * concatenated OCR feature row of m4c.py:235-237, any element alignment.  x is fp32 (x_f32 != 0) or bf16, row stride ldx.
+ * inv_norm[r] = 1 / max(||x||, eps) is saved for the backward: dx = (g - y <g, y>) * inv_norm. */
+int mmf_l2norm_rows_fwd(const void* x, int x_f32, int ldx, void* y, int ldy, float* inv_norm, int rows, int D, float eps, void* stream);
+int mmf_l2norm_rows_bwd(const void* g, int ldg, const void* y, int ldy, const float* inv_norm, void* dx, int lddx, int rows, int D,
+                        void* stream);
+/* `_batch_gather(cat([ans_emb, ocr_emb]), prev_inds)` of PrevPredEmbeddings.forward (m4c.py:526-528, 566-578) without
+ * building the concatenation: out[r] = idx[r] < rows_a ? a[idx[r]] : b[idx[r] - rows_a]; bf16 rows of H (H % 8 == 0); the
+ * caller folds the batch offset of the OCR rows into idx.  Backward is mmf_rows_scatter_add into an fp32 [rows_a + rows_b, H]. */
+int mmf_gather_rows2(const void* a, int64_t rows_a, const void* b, int64_t rows_b, const int64_t* idx, void* out, int n, int H,
+                     void* stream);
+/* OcrPtrNet.forward (m4c.py:474-493): out[b, t, n] = scale * <q[b, t, :], k[b, n, :]> + mask_add[b, n]; q bf16 [B*T, HQ],
+ * k bf16 [B*N, HQ], mask_add fp32 [B, N] (0 / -10000) or NULL, out fp32 with row stride ldo — pointed at column
+ * `num_choices` of the [B*T, num_choices + N] score matrix it realises the torch.cat of m4c.py:282.  Backward: dscores
+ * fp32 (row stride ldd, same column offset) -> dq, dk bf16. */
+int mmf_ptr_scores_fwd(const void* q, const void* k, const float* mask_add, float* out, int ldo, int B, int T, int N, int HQ,
+                       float scale, void* stream);
+int mmf_ptr_scores_bwd(const float* dscores, int ldd, const void* q, const void* k, void* dq, void* dk, int B, int T, int N, int HQ,
+                       float scale, void* stream);
+/* M4CDecodingBCEWithMaskLoss.forward (mmf/modules/losses.py:581-592): loss = sum_r w[r] sum_n BCEWithLogits(x[r,n], t[r,n])
+ * / max(sum_r w[r], 1); scores / targets fp32 [rows, N], row_weight = train_loss_mask flattened to [rows].  fwd writes
+ * loss[0] and count[0] (the denominator, reused by bwd); deterministic two-stage reduction through ws
+ * (mmf_bce_rowmask_ws_floats() floats).  bwd: dscores fp32 [rows, N] = gloss[0] * w[r] * (sigmoid(x) - t) / count. */
+int mmf_bce_rowmask_ws_floats(void);
+int mmf_bce_rowmask_fwd(const float* scores, const float* targets, const float* row_weight, float* loss, float* count, float* ws,
+                        int rows, int N, void* stream);
+int mmf_bce_rowmask_bwd(const float* scores, const float* targets, const float* row_weight, const float* count, const float* gloss,
+                        float* dscores, int rows, int N, void* stream);
 
 /* ---- optimizer: AdamW (mmf/modules/optimizers.py:8-17; transformers.AdamW semantics) ----------
  * One fused pass over a flat fp32 parameter arena: p, g, m, v [n].  Weight decay is

@@ -14,5 +14,6 @@ from mmf_amd.models import mmbt as _mmbt  # noqa: F401
 from mmf_amd.models import mmf_transformer as _mmft  # noqa: F401
 from mmf_amd.models import vilbert as _vilbert  # noqa: F401
 from mmf_amd.models import uniter as _uniter  # noqa: F401
+from mmf_amd.models import m4c as _m4c  # noqa: F401
 
 __version__ = "0.1.0"

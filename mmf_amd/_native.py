@@ -47,7 +47,7 @@ class AttnDesc(C.Structure):
         ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int),
         ("scale", C.c_float),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
-        ("head_dim", C.c_int), ("ctx_f32", C.c_void_p),
+        ("head_dim", C.c_int), ("ctx_f32", C.c_void_p), ("causal_tail", C.c_int),
     ]
 
 
@@ -199,8 +199,10 @@ def gemm_rowsum_supported(M, N, K):
 # --------------------------------------------------------------------------------------------
 # attention
 # --------------------------------------------------------------------------------------------
-def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim=64, ctx_f32=None):
+def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim=64, ctx_f32=None,
+               causal_tail=0):
     d = AttnDesc()
+    d.causal_tail = int(causal_tail)
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):
         _req(t, torch.bfloat16, n)
     _req(mask, torch.float32, "mask"); _req(lse, torch.float32, "lse")
@@ -216,15 +218,16 @@ def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, sc
     return d
 
 
-def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP, head_dim=64, ctx_f32=None):
-    d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32)
+def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP, head_dim=64, ctx_f32=None,
+                  causal_tail=0):
+    d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail)
     _check(lib().mmf_attention_fwd(C.byref(d), _stream()), "mmf_attention_fwd")
 
 
 def attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta,
-                  drop=NO_DROP, head_dim=64, ctx_f32=None):
+                  drop=NO_DROP, head_dim=64, ctx_f32=None, causal_tail=0):
     d = AttnBwdDesc()
-    d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32)
+    d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail)
     for t, n in ((dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, torch.bfloat16, n)
     _req(delta, torch.float32, "delta")
@@ -404,6 +407,59 @@ def cross_entropy_bwd(logits, labels, count, gloss, dlogits, B, Cn, ignore_index
     _req(logits, torch.float32, "logits"); _req(labels, torch.int64, "labels"); _req(dlogits, torch.float32, "dlogits")
     _check(lib().mmf_cross_entropy_bwd(_p(logits), _p(labels), _p(count), _p(gloss), _p(dlogits), B, Cn, ignore_index, _stream()),
            "mmf_cross_entropy_bwd")
+
+
+# --------------------------------------------------------------------------------------------
+# M4C kernels (mmf_amd/csrc/m4c_ops.hip)
+# --------------------------------------------------------------------------------------------
+def l2norm_rows_fwd(x, ldx, y, ldy, inv_norm, rows, D, eps=1e-12):
+    """y[r, :D] = x[r, :D] / max(||x[r, :D]||, eps); x fp32 or bf16; y bf16 (may be a column slice of a wider row)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise NativeLibraryError("l2norm_rows_fwd: x must be fp32 or bf16")
+    _req(x, x.dtype, "x"); _req(y, torch.bfloat16, "y"); _req(inv_norm, torch.float32, "inv_norm")
+    _check(lib().mmf_l2norm_rows_fwd(_p(x), int(x.dtype == torch.float32), ldx, _p(y), ldy, _p(inv_norm), rows, D, C.c_float(eps),
+                                     _stream()), "mmf_l2norm_rows_fwd")
+
+
+def l2norm_rows_bwd(g, ldg, y, ldy, inv_norm, dx, lddx, rows, D):
+    _req(g, torch.bfloat16, "g"); _req(y, torch.bfloat16, "y"); _req(dx, torch.bfloat16, "dx"); _req(inv_norm, torch.float32, "inv_norm")
+    _check(lib().mmf_l2norm_rows_bwd(_p(g), ldg, _p(y), ldy, _p(inv_norm), _p(dx), lddx, rows, D, _stream()), "mmf_l2norm_rows_bwd")
+
+
+def gather_rows2(a, b, idx, out, n, H):
+    """out[r] = idx[r] < len(a) ? a[idx[r]] : b[idx[r] - len(a)]; a, b bf16 [*, H]."""
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(idx, torch.int64, "idx"); _req(out, torch.bfloat16, "out")
+    _check(lib().mmf_gather_rows2(_p(a), C.c_int64(a.shape[0]), _p(b), C.c_int64(0 if b is None else b.shape[0]), _p(idx), _p(out), n, H,
+                                  _stream()), "mmf_gather_rows2")
+
+
+def ptr_scores_fwd(q, k, mask_add, out, ldo, B, T, N, HQ, scale):
+    _req(q, torch.bfloat16, "q"); _req(k, torch.bfloat16, "k"); _req(mask_add, torch.float32, "mask_add"); _req(out, torch.float32, "out")
+    _check(lib().mmf_ptr_scores_fwd(_p(q), _p(k), _p(mask_add), _p(out), ldo, B, T, N, HQ, C.c_float(scale), _stream()), "mmf_ptr_scores_fwd")
+
+
+def ptr_scores_bwd(dscores, ldd, q, k, dq, dk, B, T, N, HQ, scale):
+    _req(dscores, torch.float32, "dscores")
+    for t, nme in ((q, "q"), (k, "k"), (dq, "dq"), (dk, "dk")):
+        _req(t, torch.bfloat16, nme)
+    _check(lib().mmf_ptr_scores_bwd(_p(dscores), ldd, _p(q), _p(k), _p(dq), _p(dk), B, T, N, HQ, C.c_float(scale), _stream()),
+           "mmf_ptr_scores_bwd")
+
+
+def bce_rowmask_fwd(scores, targets, row_weight, loss, count, rows, N):
+    for t, nme in ((scores, "scores"), (targets, "targets"), (row_weight, "row_weight"), (loss, "loss"), (count, "count")):
+        _req(t, torch.float32, nme)
+    ws = torch.empty(lib().mmf_bce_rowmask_ws_floats(), dtype=torch.float32, device=scores.device)
+    _check(lib().mmf_bce_rowmask_fwd(_p(scores), _p(targets), _p(row_weight), _p(loss), _p(count), _p(ws), rows, N, _stream()),
+           "mmf_bce_rowmask_fwd")
+
+
+def bce_rowmask_bwd(scores, targets, row_weight, count, gloss, dscores, rows, N):
+    for t, nme in ((scores, "scores"), (targets, "targets"), (row_weight, "row_weight"), (count, "count"), (gloss, "gloss"),
+                   (dscores, "dscores")):
+        _req(t, torch.float32, nme)
+    _check(lib().mmf_bce_rowmask_bwd(_p(scores), _p(targets), _p(row_weight), _p(count), _p(gloss), _p(dscores), rows, N, _stream()),
+           "mmf_bce_rowmask_bwd")
 
 
 def adamw_step(p, g, m, v, p16, n, seg_end, seg_wd, nseg, lr, beta1, beta2, eps, step, correct_bias, mode, grad_scale):

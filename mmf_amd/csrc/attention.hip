@@ -96,6 +96,17 @@ DEVI bf16x8 frag_regs(const f32x16& p, int u) {
     return r;
 }
 
+// Prefix-LM mask of M4C's multimodal transformer (mmf/models/m4c.py:424-440), folded into the key mask: keys at or after
+// `cfrom` (the decoding steps) are visible only to queries q >= cfrom with key <= q, whatever the key mask says; every
+// other (query, key) pair keeps the additive key mask.  Values are in the log2 domain like lds_mask.
+DEVI void tail_mask(float (&mkv)[4], int key0, int q, int cfrom, int Sk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = key0 + i;
+        if (key >= cfrom && key < Sk) mkv[i] = (q >= cfrom && key <= q) ? 0.f : -10000.f * 1.4426950408889634f;
+    }
+}
+
 struct AttnArgs {
     const bf16* q; const bf16* k; const bf16* v;
     int ldq, ldk, ldv;
@@ -104,6 +115,7 @@ struct AttnArgs {
     float* ctx32;        // optional fp32 copy of ctx (same ldo): makes delta = rowsum(dO o O) exact in backward
     float* lse;
     int B, heads, Sq, Sk, skp, hd;
+    int cfrom;           // first key of the causal tail (== Sk when there is none), see mmf_attn_desc.causal_tail
     float scale;
     DropoutCfg drop;
     // backward only
@@ -113,7 +125,7 @@ struct AttnArgs {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int NKT, int D>
+template <int NKT, int D, bool CZ>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs a) {
     constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -163,12 +175,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
-            sc[t][4 * c + 0] = sc[t][4 * c + 0] * sc2 + mk.x;
-            sc[t][4 * c + 1] = sc[t][4 * c + 1] * sc2 + mk.y;
-            sc[t][4 * c + 2] = sc[t][4 * c + 2] * sc2 + mk.z;
-            sc[t][4 * c + 3] = sc[t][4 * c + 3] * sc2 + mk.w;
+            float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[t][4 * c + i]);
+            for (int i = 0; i < 4; ++i) {
+                sc[t][4 * c + i] = sc[t][4 * c + i] * sc2 + mkv[i];
+                mx = fmaxf(mx, sc[t][4 * c + i]);
+            }
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
 //   dQ = dS K * scale ; dK = dS^T Q * scale
 // =================================================================================================
 // dQ kernel: same decomposition as the forward (wave = 32 query rows, all keys).
-template <int NKT, int D>
+template <int NKT, int D, bool CZ>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -319,7 +332,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
-            const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
             f32x4 ds = {1.f, 1.f, 1.f, 1.f};
             if (a.drop.thr16) ds = drop_scale4(drop_key(a.drop), rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
 #pragma unroll
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
 }
 
 // dK/dV kernel: wave = 32 key rows, loops over all query tiles.
-template <int NQT, int D>
+template <int NQT, int D, bool CZ>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -411,7 +425,11 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
                 if (a.drop.thr16)
                     dsc = drop_scale1(drop_key(a.drop), ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)SKP + (uint32_t)(k0 + x),
                                       a.drop.thr16, a.drop.scale);
-                const float p = exp2f(s_acc[4 * c + i] * sc2 + mk - Lv[i]);
+                float mkq = mk;
+                if constexpr (CZ) {   // causal tail (see tail_mask): this lane's key against query q
+                    if (kvalid && k0 + x >= a.cfrom) mkq = (q >= a.cfrom && k0 + x <= q) ? 0.f : -10000.f * 1.4426950408889634f;
+                }
+                const float p = exp2f(s_acc[4 * c + i] * sc2 + mkq - Lv[i]);
                 pd[4 * c + i] = p * dsc;
                 s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * dsc - Dv[i]) * a.scale;
             }
@@ -457,6 +475,9 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.mask = d->mask; a.ctx = (bf16*)d->ctx; a.ldo = d->ldo; a.lse = d->lse; a.ctx32 = d->ctx_f32;
     a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk; a.hd = hd;
     a.skp = (d->Sk + 31) / 32 * 32;
+    MMF_CHECK_ARG(d->causal_tail >= 0 && d->causal_tail <= d->Sk, "attention: causal_tail out of range");
+    MMF_CHECK_ARG(d->causal_tail == 0 || (d->Sq == d->Sk && hd == 64), "attention: a causal tail needs self-attention (Sq == Sk) with head_dim 64");
+    a.cfrom = d->Sk - d->causal_tail;
     a.scale = d->scale;
     a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
@@ -479,13 +500,16 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nkt = a.skp / 32;
     const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
-#define LAUNCH_FWD(N, DD)                                                                        \
+#define LAUNCH_FWD(N, DD, CZ)                                                                    \
     {                                                                                            \
         const int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4;                                      \
-        if (int rc = set_lds(attn_fwd_kernel<N, DD>, lds)) return rc;                            \
-        hipLaunchKernelGGL((attn_fwd_kernel<N, DD>), grid, dim3(256), lds, s, a);                \
+        if (int rc = set_lds(attn_fwd_kernel<N, DD, CZ>, lds)) return rc;                        \
+        hipLaunchKernelGGL((attn_fwd_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);            \
     }
-    if (a.hd == 128) LAUNCH_FWD(4, 128) else if (nkt <= 4) LAUNCH_FWD(4, 64) else LAUNCH_FWD(8, 64)
+    const bool cz = a.cfrom < a.Sk;
+    if (a.hd == 128) LAUNCH_FWD(4, 128, false)
+    else if (nkt <= 4) { if (cz) LAUNCH_FWD(4, 64, true) else LAUNCH_FWD(4, 64, false) }
+    else { if (cz) LAUNCH_FWD(8, 64, true) else LAUNCH_FWD(8, 64, false) }
 #undef LAUNCH_FWD
     MMF_CHECK_LAUNCH();
     return 0;
@@ -503,27 +527,32 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
 
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;
+    const bool cz = a.cfrom < a.Sk;
     {
         const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
-#define LAUNCH_DQ(N, DD)                                                                         \
+#define LAUNCH_DQ(N, DD, CZ)                                                                     \
     {                                                                                            \
         const int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4 + 128 * 4;                            \
-        if (int rc = set_lds(attn_bwd_dq_kernel<N, DD>, lds)) return rc;                         \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<N, DD>), grid, dim3(256), lds, s, a);             \
+        if (int rc = set_lds(attn_bwd_dq_kernel<N, DD, CZ>, lds)) return rc;                     \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);         \
     }
-        if (a.hd == 128) LAUNCH_DQ(4, 128) else if (nkt <= 4) LAUNCH_DQ(4, 64) else LAUNCH_DQ(8, 64)
+        if (a.hd == 128) LAUNCH_DQ(4, 128, false)
+        else if (nkt <= 4) { if (cz) LAUNCH_DQ(4, 64, true) else LAUNCH_DQ(4, 64, false) }
+        else { if (cz) LAUNCH_DQ(8, 64, true) else LAUNCH_DQ(8, 64, false) }
 #undef LAUNCH_DQ
         MMF_CHECK_LAUNCH();
     }
     {
         const dim3 grid(a.B * a.heads, (a.Sk + 127) / 128);
-#define LAUNCH_DKV(N, DD)                                                                        \
+#define LAUNCH_DKV(N, DD, CZ)                                                                    \
     {                                                                                            \
         const int lds = 2 * N * 32 * (2 * DD) + 2 * N * 32 * 4;                                  \
-        if (int rc = set_lds(attn_bwd_dkv_kernel<N, DD>, lds)) return rc;                        \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, DD>), grid, dim3(256), lds, s, a);            \
+        if (int rc = set_lds(attn_bwd_dkv_kernel<N, DD, CZ>, lds)) return rc;                    \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);        \
     }
-        if (a.hd == 128) LAUNCH_DKV(4, 128) else if (nqt <= 4) LAUNCH_DKV(4, 64) else LAUNCH_DKV(8, 64)
+        if (a.hd == 128) LAUNCH_DKV(4, 128, false)
+        else if (nqt <= 4) { if (cz) LAUNCH_DKV(4, 64, true) else LAUNCH_DKV(4, 64, false) }
+        else { if (cz) LAUNCH_DKV(8, 64, true) else LAUNCH_DKV(8, 64, false) }
 #undef LAUNCH_DKV
         MMF_CHECK_LAUNCH();
     }

@@ -267,7 +267,24 @@ def _o32(M, H, dev, need):
     return torch.empty(M, H, dtype=F32, device=dev) if (need and EXACT_ATTENTION_DELTA) else None
 
 
-def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True):
+class PrefixLMMask:
+    """What M4C's multimodal transformer hands its encoder as a [B, 1, L, L] tensor (MMT.forward, mmf/models/m4c.py:424-440),
+    in the form the fused attention kernel takes it: the additive key mask [B, L] fp32 plus the number of trailing
+    decoding positions that see each other causally (`mmf_attn_desc.causal_tail`).  Pass it wherever an encoder accepts
+    `attention_mask`."""
+    __slots__ = ("key_mask", "causal_tail")
+
+    def __init__(self, key_mask, causal_tail):
+        self.key_mask, self.causal_tail = key_mask, int(causal_tail)
+
+
+def _split_mask(mask):
+    if isinstance(mask, PrefixLMMask):
+        return mask.key_mask, mask.causal_tail
+    return mask, 0
+
+
+def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail=0):
     M, H = x2.shape
     dev = x2.device
     qkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
@@ -277,18 +294,18 @@ def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True):
     scale = 1.0 / math.sqrt(H // heads)
     o32 = _o32(M, H, dev, need_bwd)
     nat.attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale, drop,
-                      head_dim=H // heads, ctx_f32=o32)
+                      head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
     return qkv, ctxt, lse, o32
 
 
-def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True, o32=None):
+def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True, o32=None, tail=0):
     M, H = x2.shape
     dev = x2.device
     dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
     delta = torch.empty(B, heads, S, dtype=F32, device=dev)
     scale = 1.0 / math.sqrt(H // heads)
     nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
-                      dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32)
+                      dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
     return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True)
 
 
@@ -299,17 +316,18 @@ class SelfAttentionFn(torch.autograd.Function):
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, wqkv16, bqkv, mask_add, heads, drop):
         B, S, H = x.shape
         x2 = _as_bf16_2d(x)
-        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, any(ctx.needs_input_grad))
+        mask_add, tail = _split_mask(mask_add)
+        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, any(ctx.needs_input_grad), tail)
         ctx.save_for_backward(x2, qkv, ctxt, lse, wqkv16, mask_add, o32)
-        ctx.meta = (B, S, H, heads, drop)
+        ctx.meta = (B, S, H, heads, drop, tail)
         return ctxt.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
         x2, qkv, ctxt, lse, wqkv16, mask_add, o32 = ctx.saved_tensors
-        B, S, H, heads, drop = ctx.meta
+        B, S, H, heads, drop, tail = ctx.meta
         dx, dw, db = _attn_bwd(_grad_bf16(g, H), x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop,
-                               need_dx=ctx.needs_input_grad[0], o32=o32)
+                               need_dx=ctx.needs_input_grad[0], o32=o32, tail=tail)
         return ((dx.view(B, S, H) if dx is not None else None), dw[:H], db[:H], dw[H:2 * H], db[H:2 * H], dw[2 * H:], db[2 * H:],
                 None, None, None, None, None)
 
@@ -404,20 +422,22 @@ class AttentionBlockFn(torch.autograd.Function):
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, wqkv16, bqkv, wo16, mask_add, heads, eps, drop_attn, drop_hid):
         B, S, H = x.shape
         x2 = _as_bf16_2d(x)
-        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad))
+        mask_add, tail = _split_mask(mask_add)
+        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail)
         out, y, mean, rstd = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), gamma.detach(), beta.detach(), eps, drop_hid)
         ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add, o32)
-        ctx.meta = (B, S, H, heads, drop_attn, drop_hid)
+        ctx.meta = (B, S, H, heads, drop_attn, drop_hid, tail)
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
         x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add, o32 = ctx.saved_tensors
-        B, S, H, heads, drop_attn, drop_hid = ctx.meta
+        B, S, H, heads, drop_attn, drop_hid, tail = ctx.meta
         M = B * S
         dres, dlin, dgamma, dbeta, dbo = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
         dctx, dwo = _linear_bwd(dlin, H, ctxt, wo16, M, H, H)
-        dx, dwqkv, dbqkv = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32)
+        dx, dwqkv, dbqkv = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32,
+                                     tail=tail)
         return (dx.view(B, S, H), dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
                 dwo, dbo, dgamma, dbeta, None, None, None, None, None, None, None, None)
 
@@ -1076,3 +1096,255 @@ class PairHalvesFn(torch.autograd.Function):
         nat.copy_rows(g2, 2, dx, 1, B, 1, H)
         nat.copy_rows(g2[1:], 2, dx[B:], 1, B, 1, H)
         return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# M4C pieces (mmf/models/m4c.py)
+# ---------------------------------------------------------------------------------------------
+class L2NormRowsFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) (m4c.py:195) -> bf16.  x: fp32 input features or a bf16 activation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D)
+        if x2.dtype not in (F32, BF16):
+            x2 = x2.float()
+        x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty(rows, D, dtype=BF16, device=x2.device)
+        inv = torch.empty(rows, dtype=F32, device=x2.device)
+        nat.l2norm_rows_fwd(x2, D, y, D, inv, rows, D)
+        ctx.save_for_backward(y, inv)
+        ctx.xshape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, inv = ctx.saved_tensors
+        rows, D = y.shape
+        g2 = _grad_bf16(g, D)
+        dx = torch.empty(rows, D, dtype=BF16, device=y.device)
+        nat.l2norm_rows_bwd(g2, D, y, D, inv, dx, D, rows, D)
+        return dx.view(ctx.xshape)
+
+
+class OcrFeatureConcatFn(torch.autograd.Function):
+    """cat([normalize(fasttext), normalize(phoc), normalize(fc7), zeros(order vectors)], -1) of m4c.py:211-237 written once
+    as bf16 rows padded to a multiple of 8 columns (16-byte rows for the GEMM loader).  Only the appearance feature
+    (`fc7`, bf16 activation) carries a gradient; the two text features are inputs."""
+
+    @staticmethod
+    def forward(ctx, fasttext, phoc, fc7, order_dim):
+        B, N, _ = fasttext.shape
+        rows = B * N
+        d0, d1, d2 = fasttext.shape[-1], phoc.shape[-1], fc7.shape[-1]
+        K = d0 + d1 + d2 + int(order_dim)
+        KP = _pad8(K)
+        dev = fc7.device
+        out = torch.zeros(rows, KP, dtype=BF16, device=dev)
+        inv = torch.empty(3, rows, dtype=F32, device=dev)
+        f0 = fasttext.reshape(rows, d0).float().contiguous()
+        f1 = phoc.reshape(rows, d1).float().contiguous()
+        f2 = _as_bf16_2d(fc7)
+        nat.l2norm_rows_fwd(f0, d0, out, KP, inv[0], rows, d0)
+        nat.l2norm_rows_fwd(f1, d1, out[:, d0:], KP, inv[1], rows, d1)
+        nat.l2norm_rows_fwd(f2, d2, out[:, d0 + d1:], KP, inv[2], rows, d2)
+        ctx.save_for_backward(out, inv)
+        ctx.meta = (B, N, d0 + d1, d2, KP)
+        return out.view(B, N, KP)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, inv = ctx.saved_tensors
+        B, N, off, d2, KP = ctx.meta
+        rows = B * N
+        g2 = _grad_bf16(g, KP)
+        dx = torch.empty(rows, d2, dtype=BF16, device=out.device)
+        nat.l2norm_rows_bwd(g2[:, off:], KP, out[:, off:], KP, inv[2], dx, d2, rows, d2)
+        return None, None, dx.view(B, N, d2), None
+
+
+class PaddedLinearFn(torch.autograd.Function):
+    """nn.Linear whose input width K is not a multiple of 8 (M4C's 3002-wide OCR feature, m4c.py:243): `x` arrives as bf16
+    rows already zero-padded to KP = round_up(K, 8) columns (OcrFeatureConcatFn); the weight is padded the same way while
+    it is converted to bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, K = weight.shape
+        KP = x.shape[-1]
+        if KP != _pad8(K):
+            raise ValueError("PaddedLinearFn: input has %d columns, expected round_up(%d, 8)" % (KP, K))
+        x2 = _as_bf16_2d(x)
+        M = x2.shape[0]
+        dev = weight.device
+        w8 = torch.empty(N, KP, dtype=BF16, device=dev)
+        nat.cast2d_f32_to_bf16(weight.detach().contiguous(), K, w8, KP, N, K)
+        y = torch.empty(M, N, dtype=BF16, device=dev)
+        nat.gemm(x2, w8, y, M, N, KP, KP, KP, N, bias=bias.detach())
+        ctx.save_for_backward(x2, w8)
+        ctx.meta = (x.shape, M, N, K, KP)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w8 = ctx.saved_tensors
+        xshape, M, N, K, KP = ctx.meta
+        dy = _grad_bf16(g, N)
+        dx, dw8, db = _linear_bwd(dy, N, x2, w8, M, N, KP, need_dx=ctx.needs_input_grad[0], want_db=True)
+        return (dx.view(xshape) if dx is not None else None), dw8[:, :K].contiguous(), db
+
+
+class ParamRowsFn(torch.autograd.Function):
+    """A weight matrix used as an activation: `fixed_ans_emb = self.classifier.module.weight` (m4c.py:268).  Forward hands
+    out the bf16 shadow the GEMMs already keep; backward converts the row gradients to the parameter's fp32."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        w16 = shadows.get(weight)
+        return w16.view(w16.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = _grad_bf16(g, g.shape[-1])
+        d = torch.empty(g2.shape, dtype=F32, device=g2.device)
+        nat.cast_bf16_to_f32(g2, d)
+        return d
+
+
+class PrevPredGatherFn(torch.autograd.Function):
+    """_batch_gather(cat([ans_emb.expand(B), ocr_emb], 1), prev_inds) of PrevPredEmbeddings.forward (m4c.py:526-528) without
+    the [B, V + N, H] concatenation: one two-source row gather; backward scatter-adds (repeated indices, e.g. <pad>,
+    collide) into an fp32 [V + B*N, H] buffer that splits into the two gradients."""
+
+    @staticmethod
+    def forward(ctx, ans, ocr, prev_inds):
+        V, H = ans.shape
+        B, N, _ = ocr.shape
+        T = prev_inds.shape[1]
+        a2, o2 = _as_bf16_2d(ans), _as_bf16_2d(ocr)
+        batch = torch.arange(B, device=prev_inds.device, dtype=torch.int64).unsqueeze(1) * N
+        flat = torch.where(prev_inds < V, prev_inds, prev_inds + batch).contiguous()     # OCR row (b, i) -> V + b*N + i
+        out = torch.empty(B * T, H, dtype=BF16, device=a2.device)
+        nat.gather_rows2(a2, o2, flat, out, B * T, H)
+        ctx.save_for_backward(flat)
+        ctx.meta = (V, B, N, T, H)
+        return out.view(B, T, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        V, B, N, T, H = ctx.meta
+        g2 = _grad_bf16(g, H)
+        d = torch.zeros(V + B * N, H, dtype=F32, device=g2.device)
+        nat.rows_scatter_add(g2, H, B, T, T, flat, T, 0, 0, d, H, 0)
+        d16 = torch.empty(V + B * N, H, dtype=BF16, device=g2.device)
+        nat.cast_f32_to_bf16(d, d16)
+        return d16[:V], d16[V:].view(B, N, H), None
+
+
+class M4CScoresFn(torch.autograd.Function):
+    """M4C._forward_output (m4c.py:275-283): fixed-vocabulary scores `classifier(dec)`, the OCR pointer scores
+    `OcrPtrNet(dec, ocr, ocr_mask)` (:474-493) and their concatenation, written by the two producers straight into one
+    fp32 [B, T, V + N] buffer (the classifier GEMM with ldc = V + N, the pointer kernel at column V)."""
+
+    @staticmethod
+    def forward(ctx, dec, ocr, cls_w, cls_b, q_w, q_b, k_w, k_b, ocr_mask_add, cls_w16, q_w16, k_w16):
+        B, T, H = dec.shape
+        N = ocr.shape[1]
+        V, HQ = cls_w.shape[0], q_w.shape[0]
+        dec2, ocr2 = _as_bf16_2d(dec), _as_bf16_2d(ocr)
+        dev = dec2.device
+        out = torch.empty(B * T, V + N, dtype=F32, device=dev)
+        nat.gemm(dec2, cls_w16, out, B * T, V, H, H, H, V + N, bias=cls_b.detach())
+        q = torch.empty(B * T, HQ, dtype=BF16, device=dev)
+        k = torch.empty(B * N, HQ, dtype=BF16, device=dev)
+        nat.gemm(dec2, q_w16, q, B * T, HQ, H, H, H, HQ, bias=q_b.detach())
+        nat.gemm(ocr2, k_w16, k, B * N, HQ, H, H, H, HQ, bias=k_b.detach())
+        scale = 1.0 / math.sqrt(HQ)
+        nat.ptr_scores_fwd(q, k, ocr_mask_add, out[:, V:], V + N, B, T, N, HQ, scale)
+        ctx.save_for_backward(dec2, ocr2, q, k, cls_w16, q_w16, k_w16)
+        ctx.meta = (B, T, N, H, V, HQ, scale)
+        return out.view(B, T, V + N)
+
+    @staticmethod
+    def backward(ctx, g):
+        dec2, ocr2, q, k, cls_w16, q_w16, k_w16 = ctx.saved_tensors
+        B, T, N, H, V, HQ, scale = ctx.meta
+        M = B * T
+        dev = dec2.device
+        g2 = g.reshape(M, V + N)
+        if g2.dtype != F32:
+            g2 = g2.float()
+        g2 = g2.contiguous()
+        ldv = _pad8(V)
+        dfix = torch.empty(M, ldv, dtype=BF16, device=dev)
+        nat.cast2d_f32_to_bf16(g2, V + N, dfix, ldv, M, V)
+        ddec, dcw, dcb = _linear_bwd(dfix, ldv, dec2, cls_w16, M, V, H, want_db=True)
+        dq = torch.empty(M, HQ, dtype=BF16, device=dev)
+        dk = torch.empty(B * N, HQ, dtype=BF16, device=dev)
+        nat.ptr_scores_bwd(g2[:, V:], V + N, q, k, dq, dk, B, T, N, HQ, scale)
+        ddec, dqw, dqb = _linear_bwd(dq, HQ, dec2, q_w16, M, HQ, H, dx_resid=ddec, want_db=True)
+        docr, dkw, dkb = _linear_bwd(dk, HQ, ocr2, k_w16, B * N, HQ, H, want_db=True)
+        return ddec.view(B, T, H), docr.view(B, N, H), dcw, dcb, dqw, dqb, dkw, dkb, None, None, None, None
+
+
+class DecodingBCEWithMaskFn(torch.autograd.Function):
+    """M4CDecodingBCEWithMaskLoss.forward (mmf/modules/losses.py:581-592): sum(BCEWithLogits(scores, targets) * loss_mask) /
+    max(sum(loss_mask), 1).  Returns a 1-element tensor like the reference."""
+
+    @staticmethod
+    def forward(ctx, scores, targets, loss_mask):
+        assert scores.dim() == 3 and loss_mask.dim() == 2
+        B, T, Cn = scores.shape
+        s = scores.float().contiguous()
+        t = targets.float().contiguous()
+        w = loss_mask.float().contiguous()
+        loss = torch.empty(1, dtype=F32, device=s.device)
+        count = torch.empty(1, dtype=F32, device=s.device)
+        nat.bce_rowmask_fwd(s, t, w, loss, count, B * T, Cn)
+        ctx.save_for_backward(s, t, w, count)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t, w, count = ctx.saved_tensors
+        B, T, Cn = s.shape
+        d = torch.empty(B, T, Cn, dtype=F32, device=s.device)
+        nat.bce_rowmask_bwd(s, t, w, count, g.float().reshape(1).contiguous(), d, B * T, Cn)
+        return d, None, None
+
+
+class SplitRowsFn(torch.autograd.Function):
+    """The slices `mmt_seq_output[:, a:b]` of MMT.forward (m4c.py:446-449) as strided HIP copies: [B, S, H] -> one
+    contiguous [B, L_i, H] block per entry of `lens` (sum(lens) == S).  Backward writes the block gradients back into
+    one [B, S, H] buffer; blocks nobody used stay zero."""
+
+    @staticmethod
+    def forward(ctx, x, lens):
+        B, S, H = x.shape
+        lens = [int(l) for l in lens]
+        assert sum(lens) == S
+        x2 = _as_bf16_2d(x)
+        outs, off = [], 0
+        for L in lens:
+            d = torch.empty(B * L, H, dtype=BF16, device=x2.device)
+            nat.copy_rows(x2[off:], S, d, L, B, L, H)
+            outs.append(d.view(B, L, H))
+            off += L
+        ctx.meta = (B, S, H, lens)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, S, H, lens = ctx.meta
+        dev = next(g.device for g in gs if g is not None)
+        dx = torch.zeros(B * S, H, dtype=BF16, device=dev)
+        off = 0
+        for g, L in zip(gs, lens):
+            if g is not None:
+                nat.copy_rows(_grad_bf16(g, H), L, dx[off:], S, B, L, H)
+            off += L
+        return dx.view(B, S, H), None

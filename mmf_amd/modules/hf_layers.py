@@ -90,10 +90,13 @@ def additive_key_mask(attention_mask, batch, seq):
     (visual_bert.py:94-106).  The fused kernel wants it as fp32 `[B, S]`."""
     if attention_mask is None:
         return None
+    if isinstance(attention_mask, Fn.PrefixLMMask):   # M4C's prefix-LM mask (m4c.py:424-440): key mask + causal tail
+        return Fn.PrefixLMMask(additive_key_mask(attention_mask.key_mask, batch, seq), attention_mask.causal_tail)
     m = attention_mask
     if m.dim() == 4:
         if m.shape[1] != 1 or m.shape[2] != 1:
-            raise NotImplementedError("per-query attention masks [B,1,S,S] are not supported by the fused kernel yet")
+            raise NotImplementedError("a materialised per-query mask [B,1,S,S] is not read by the fused kernel; for M4C's "
+                                      "prefix-LM mask pass mmf_amd.functional.PrefixLMMask(key_mask, dec_steps)")
         m = m.reshape(batch, seq)
     if m.dtype != torch.float32:
         m = m.float()

@@ -100,3 +100,15 @@ class CrossEntropyLoss(nn.Module):
 
     def forward(self, sample_list, model_output):
         return Fn.CrossEntropyFn.apply(model_output["scores"], sample_list["targets"], self.ignore_index)
+
+
+@registry.register_loss("m4c_decoding_bce_with_mask")
+class M4CDecodingBCEWithMaskLoss(nn.Module):
+    """losses.py:575-592: BCE over the decoding steps, weighted by `train_loss_mask`, normalised by max(sum(mask), 1)."""
+
+    def forward(self, sample_list, model_output):
+        scores = model_output["scores"]
+        targets = sample_list["targets"]
+        loss_mask = sample_list["train_loss_mask"]
+        assert scores.dim() == 3 and loss_mask.dim() == 2
+        return Fn.DecodingBCEWithMaskFn.apply(scores, targets, loss_mask)

@@ -669,6 +669,187 @@ def make_uniter():
         print(name, "loss", loss.item(), lkey, "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
 
 
+M4C_CASES = {
+    # text_bert 128-wide (2 heads) projected to a 192-wide (3 heads) MMT; ragged text / objects / OCR; 5 decoding steps
+    "m4c_small64": dict(text_hidden_size=128, text_num_hidden_layers=2, text_num_attention_heads=2, text_intermediate_size=256,
+                        vocab_size=211, max_position_embeddings=40, hidden_size=192, num_hidden_layers=2, num_attention_heads=3,
+                        intermediate_size=384, obj_in_dim=72, obj_fc7_dim=80, ocr_in_dim=72, ocr_fc7_dim=88, num_choices=37,
+                        query_key_size=128, B=3, T=8, O=7, N=6, D=5, seed=71),
+}
+
+
+def m4c_inputs(c):
+    """Deterministic M4C batch (numpy): the keys M4C.forward reads from the sample list (m4c.py:183-253,285-294) plus
+    the loss inputs (losses.py:581-592)."""
+    B, T, O, N, D, seed = c["B"], c["T"], c["O"], c["N"], c["D"], c["seed"]
+    V = c["num_choices"]
+    u = detweights.uniform
+    text = (u(B * T, seed + 100) * c["vocab_size"]).astype(np.int64).reshape(B, T)
+    text_len = np.array([T, T // 2, T - 2], dtype=np.int64)[:B]
+    for b in range(B):
+        text[b, text_len[b]:] = 0     # [PAD]
+    rec = dict(
+        text=text, text_len=text_len,
+        image_feature_0=(2.0 * u(B * O * c["obj_in_dim"], seed + 101) - 1.0).astype(np.float32).reshape(B, O, -1),
+        obj_bbox_coordinates=u(B * O * 4, seed + 102).astype(np.float32).reshape(B, O, 4),
+        obj_max_features=np.array([O, O - 2, O - 1], dtype=np.int64)[:B],
+        context_feature_0=(2.0 * u(B * N * 300, seed + 103) - 1.0).astype(np.float32).reshape(B, N, 300),
+        context_feature_1=u(B * N * 604, seed + 104).astype(np.float32).reshape(B, N, 604),
+        image_feature_1=(2.0 * u(B * (N + 3) * c["ocr_in_dim"], seed + 105) - 1.0).astype(np.float32).reshape(B, N + 3, -1),
+        ocr_bbox_coordinates=u(B * N * 4, seed + 106).astype(np.float32).reshape(B, N, 4),
+        ocr_max_features=np.array([N, N - 3, N - 2], dtype=np.int64)[:B],
+        order_vectors=u(B * N * N, seed + 107).astype(np.float32).reshape(B, N, N),   # zeroed by the model (m4c.py:227)
+    )
+    prev = (u(B * D, seed + 108) * (V + N)).astype(np.int64).reshape(B, D)
+    prev[:, 0] = 1            # BOS
+    prev[1, 3:] = 0           # <pad> repeated: colliding rows in the gather's backward
+    prev[2, 2] = V + 1        # an OCR copy
+    prev[0, 4] = V + N - 1
+    rec["train_prev_inds"] = prev
+    tg = np.zeros((B, D, V + N), dtype=np.float32)
+    pick = (u(B * D * 2, seed + 109) * (V + N)).astype(np.int64).reshape(B, D, 2)
+    for b in range(B):
+        for t in range(D):
+            tg[b, t, pick[b, t, 0]] = 1.0
+            tg[b, t, pick[b, t, 1]] = 0.6
+    rec["targets"] = tg
+    lm = np.ones((B, D), dtype=np.float32)
+    lm[1, 3:] = 0.0
+    lm[2, 4:] = 0.0
+    rec["train_loss_mask"] = lm
+    return rec
+
+
+def m4c_sample_list(rec):
+    t = torch.from_numpy
+    return SampleList(
+        text=t(rec["text"]), text_len=t(rec["text_len"]), image_feature_0=t(rec["image_feature_0"]),
+        obj_bbox_coordinates=t(rec["obj_bbox_coordinates"]), image_info_0=SampleList(max_features=t(rec["obj_max_features"])),
+        context_feature_0=t(rec["context_feature_0"]), context_feature_1=t(rec["context_feature_1"]),
+        image_feature_1=t(rec["image_feature_1"]), ocr_bbox_coordinates=t(rec["ocr_bbox_coordinates"]),
+        context_info_0=SampleList(max_features=t(rec["ocr_max_features"])), order_vectors=t(rec["order_vectors"]),
+        train_prev_inds=t(rec["train_prev_inds"]), targets=t(rec["targets"]), train_loss_mask=t(rec["train_loss_mask"]),
+        dataset_name="textvqa", dataset_type="train")
+
+
+def make_m4c():
+    """M4C (BASELINE configs[4]) through the reference's own `M4C._forward_*` methods over its `TextBert`, `MMT`,
+    `OcrPtrNet`, `PrevPredEmbeddings`, `ClassifierLayer("linear")` and the `FinetuneFasterRcnnFpnFc7.forward` body, plus
+    `M4CDecodingBCEWithMaskLoss`.  The registered class itself needs the dataset registry and the detectron fc7 pickles
+    (m4c.py:36-44,56-68), so the module tree of M4C.build() is assembled here and the reference's methods are bound to it."""
+    from torch import nn
+    from transformers import BertConfig
+    M = refshim.ref_import("mmf.models.m4c")
+    E = refshim.ref_import("mmf.modules.encoders")
+    from mmf.modules.layers import ClassifierLayer
+    from mmf.modules.losses import M4CDecodingBCEWithMaskLoss
+
+    for name, c in M4C_CASES.items():
+        tcfg = BertConfig(hidden_size=c["text_hidden_size"], num_hidden_layers=c["text_num_hidden_layers"],
+                          num_attention_heads=c["text_num_attention_heads"], intermediate_size=c["text_intermediate_size"],
+                          vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"], type_vocab_size=2,
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12, pad_token_id=0)
+        mcfg = BertConfig(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+                          num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12)
+        tcfg._attn_implementation = "eager"
+        mcfg._attn_implementation = "eager"
+        H, N = c["hidden_size"], c["N"]
+
+        class Fc7(nn.Module):       # FinetuneFasterRcnnFpnFc7 minus the pickle loading of its constructor
+            def __init__(self, in_dim, out_dim):
+                super().__init__()
+                self.lc = nn.Linear(in_dim, out_dim)
+
+            forward = E.FinetuneFasterRcnnFpnFc7.forward
+
+        class RefM4C(nn.Module):    # module tree of M4C.build(), m4c.py:46-170
+            def __init__(self):
+                super().__init__()
+                self.mmt_config = mcfg
+                self.text_bert = M.TextBert(tcfg)
+                self.text_bert_out_linear = nn.Linear(c["text_hidden_size"], H)
+                self.obj_faster_rcnn_fc7 = Fc7(c["obj_in_dim"], c["obj_fc7_dim"])
+                self.linear_obj_feat_to_mmt_in = nn.Linear(c["obj_fc7_dim"], H)
+                self.linear_obj_bbox_to_mmt_in = nn.Linear(4, H)
+                self.obj_feat_layer_norm = nn.LayerNorm(H)
+                self.obj_bbox_layer_norm = nn.LayerNorm(H)
+                self.obj_drop = nn.Dropout(0.1)
+                self.remove_ocr_fasttext = self.remove_ocr_phoc = self.remove_ocr_frcn = False
+                self.remove_ocr_semantics = self.remove_ocr_bbox = False
+                self.ocr_faster_rcnn_fc7 = Fc7(c["ocr_in_dim"], c["ocr_fc7_dim"])
+                self.linear_ocr_feat_to_mmt_in = nn.Linear(300 + 604 + c["ocr_fc7_dim"] + N, H)
+                self.linear_ocr_bbox_to_mmt_in = nn.Linear(4, H)
+                self.ocr_feat_layer_norm = nn.LayerNorm(H)
+                self.ocr_bbox_layer_norm = nn.LayerNorm(H)
+                self.ocr_drop = nn.Dropout(0.1)
+                self.mmt = M.MMT(mcfg)
+                self.ocr_ptr_net = M.OcrPtrNet(hidden_size=H, query_key_size=c["query_key_size"])
+                self.classifier = ClassifierLayer("linear", in_dim=H, out_dim=c["num_choices"])
+                self.answer_processor = SampleList(BOS_IDX=1)
+
+        for fn in ("forward", "_forward_txt_encoding", "_forward_obj_encoding", "_forward_ocr_encoding", "_forward_mmt",
+                   "_forward_output", "_forward_mmt_and_output"):
+            setattr(RefM4C, fn, getattr(M.M4C, fn))
+
+        ref = RefM4C().eval()
+        shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+                  if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")}
+        sd = detweights.state_dict(shapes, c["seed"])
+        for k in sd:               # nn.LayerNorm gains that are not called "LayerNorm.weight"
+            if k.endswith("layer_norm.weight"):
+                sd[k] = sd[k] + 1.0
+        missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected, unexpected
+        rec_in = m4c_inputs(c)
+        sl = m4c_sample_list(rec_in)
+
+        # teacher forcing (self.training, m4c.py:286-289) with every dropout off: only the top-level flag is set, the
+        # sub-modules stay in eval mode
+        ref.training = True
+        fwd = {}
+        ref._forward_txt_encoding(sl, fwd)
+        ref._forward_obj_encoding(sl, fwd)
+        ref._forward_ocr_encoding(sl, fwd)
+        ref._forward_mmt_and_output(sl, fwd)
+        out = {"scores": fwd["scores"]}
+        loss = M4CDecodingBCEWithMaskLoss()(sl, out).sum()
+        loss.backward()
+        rec = {"in_" + k: v for k, v in rec_in.items()}
+        rec["scores"] = out["scores"].detach().numpy()
+        for k in ("obj_mmt_in", "ocr_mmt_in", "txt_emb", "mmt_seq_output"):
+            rec[k] = fwd[k].detach().numpy()
+        rec["loss"] = np.array(loss.item(), dtype=np.float64)
+        names, norms, sums = [], [], []
+        for k, p in ref.named_parameters():
+            g = p.grad
+            names.append(k)
+            norms.append(0.0 if g is None else float(g.double().norm()))
+            sums.append(0.0 if g is None else float(g.double().sum()))
+            if g is not None and g.numel() <= 4096:
+                rec["grad::" + k] = g.numpy()
+        rec["grad_names"] = np.array(names)
+        rec["grad_norms"] = np.array(norms)
+        rec["grad_sums"] = np.array(sums)
+
+        # greedy decoding (not self.training, m4c.py:290-305) through M4C.forward itself
+        ref.training = False
+        with torch.no_grad():
+            dec = ref.forward(m4c_sample_list(rec_in))
+        rec["decode_scores"] = dec["scores"].numpy()
+        rec["decode_argmax"] = dec["scores"].argmax(dim=-1).numpy()
+        top2 = dec["scores"].topk(2, dim=-1).values
+        rec["decode_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+
+        rec["param_names"] = np.array(list(shapes.keys()))
+        rec["param_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
+        rec["case"] = np.array(repr(c))
+        path = os.path.join(HERE, "%s.npz" % name)
+        np.savez_compressed(path, **rec)
+        print(name, "loss", loss.item(), "scores[0,0,:4]", rec["scores"][0, 0, :4], "decode", rec["decode_argmax"].tolist(),
+              "->", path, os.path.getsize(path), "bytes")
+
+
 def make_visual_bert_nlvr2():
     """VisualBERT with `training_head_type: nlvr2` (two images per sample, default BertPooler strategy) through the
     reference's own VisualBERT.forward (visual_bert.py:483-601) and VisualBERTForClassification (:284-404)."""
@@ -726,7 +907,7 @@ def make_visual_bert_nlvr2():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "nlvr2", "mmbt", "mmft", "vilbert", "uniter"]
+    which = sys.argv[1:] or ["visual_bert", "nlvr2", "mmbt", "mmft", "vilbert", "uniter", "m4c"]
     if "visual_bert" in which:
         main()
     if "nlvr2" in which:
@@ -739,3 +920,5 @@ if __name__ == "__main__":
         make_vilbert()
     if "uniter" in which:
         make_uniter()
+    if "m4c" in which:
+        make_m4c()

@@ -159,3 +159,35 @@ def load_nlvr2_case():
         "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "nlvr2", "dataset_type": "train",
     }
     return z, case, cfg, sd, sample
+
+
+def load_m4c_case(name="m4c_small64"):
+    z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    w = detweights.state_dict(shapes, case["seed"])
+    for k in w:                    # nn.LayerNorm gains not named "LayerNorm.weight" (make_golden.py::make_m4c)
+        if k.endswith("layer_norm.weight"):
+            w[k] = w[k] + 1.0
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    cfg = dict(
+        text_hidden_size=case["text_hidden_size"], text_num_hidden_layers=case["text_num_hidden_layers"],
+        text_num_attention_heads=case["text_num_attention_heads"], text_intermediate_size=case["text_intermediate_size"],
+        vocab_size=case["vocab_size"], max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2,
+        hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"], num_attention_heads=case["num_attention_heads"],
+        intermediate_size=case["intermediate_size"], layer_norm_eps=1e-12, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+        obj_in_dim=case["obj_in_dim"], obj_fc7_dim=case["obj_fc7_dim"], ocr_in_dim=case["ocr_in_dim"], ocr_fc7_dim=case["ocr_fc7_dim"],
+        fasttext_dim=300, phoc_dim=604, ocr_max_num=case["N"], obj_dropout_prob=0.1, ocr_dropout_prob=0.1,
+        num_choices=case["num_choices"], query_key_size=case["query_key_size"], max_dec_length=100, max_type_num=5, bos_idx=1,
+        pad_token_id=0)
+    t = lambda k: torch.from_numpy(z["in_" + k])
+    sample = {
+        "text": t("text"), "text_len": t("text_len"), "image_feature_0": t("image_feature_0"),
+        "obj_bbox_coordinates": t("obj_bbox_coordinates"), "image_info_0": {"max_features": t("obj_max_features")},
+        "context_feature_0": t("context_feature_0"), "context_feature_1": t("context_feature_1"),
+        "image_feature_1": t("image_feature_1"), "ocr_bbox_coordinates": t("ocr_bbox_coordinates"),
+        "context_info_0": {"max_features": t("ocr_max_features")}, "order_vectors": t("order_vectors"),
+        "train_prev_inds": t("train_prev_inds"), "targets": t("targets"), "train_loss_mask": t("train_loss_mask"),
+        "dataset_name": "textvqa", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample

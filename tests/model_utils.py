@@ -157,3 +157,38 @@ def build_uniter(cfg, sd=None, device="cuda", **over):
     if sd is not None:
         model.load_state_dict(sd, strict=True)
     return model.to(device)
+
+
+def m4c_model_config(cfg, **over):
+    """MMF model_config.m4c (configs/models/m4c/defaults.yaml) for an oracle-style config dict."""
+    d = dict(
+        model="m4c", lr_scale_frcn=0.1, lr_scale_text_bert=0.1, lr_scale_mmt=1.0, text_bert_init_from_bert_base=False,
+        text_bert=dict(hidden_size=cfg["text_hidden_size"], num_hidden_layers=cfg["text_num_hidden_layers"],
+                       num_attention_heads=cfg["text_num_attention_heads"], intermediate_size=cfg["text_intermediate_size"],
+                       vocab_size=cfg["vocab_size"], max_position_embeddings=cfg["max_position_embeddings"]),
+        obj=dict(mmt_in_dim=cfg["obj_fc7_dim"], dropout_prob=cfg.get("obj_dropout_prob", 0.1), in_dim=cfg["obj_in_dim"],
+                 fc7_dim=cfg["obj_fc7_dim"]),
+        ocr=dict(mmt_in_dim=cfg["fasttext_dim"] + cfg["phoc_dim"] + cfg["ocr_fc7_dim"] + cfg["ocr_max_num"],
+                 dropout_prob=cfg.get("ocr_dropout_prob", 0.1), in_dim=cfg["ocr_in_dim"], fc7_dim=cfg["ocr_fc7_dim"]),
+        mmt=dict(hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                 num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"]),
+        classifier=dict(type="linear", ocr_max_num=cfg["ocr_max_num"],
+                        ocr_ptr_net=dict(hidden_size=cfg["hidden_size"], query_key_size=cfg["query_key_size"]), params={}),
+        model_data_dir="", losses=[dict(type="m4c_decoding_bce_with_mask")])
+    d.update(over)
+    return Config(d)
+
+
+def build_m4c(cfg, sd=None, device="cuda", dataset="textvqa", **over):
+    """The registry entries M4C reads at construction (m4c.py:39, 158, 172), then build_model."""
+    import warnings
+    from mmf_amd.common.registry import registry
+    registry.register("config", Config({"datasets": dataset}))
+    registry.register(dataset + "_num_final_outputs", cfg["num_choices"] + cfg["ocr_max_num"])
+    registry.register(dataset + "_answer_processor", Config({"BOS_IDX": cfg.get("bos_idx", 1)}))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # the fc7 pickles are absent by design here
+        model = build_model(m4c_model_config(cfg, **over))
+    if sd is not None:
+        model.load_state_dict(sd, strict=True)
+    return model.to(device)

@@ -1,0 +1,162 @@
+"""CPU stand-in for mmf_amd._native used by the host-logic ("dry run") tests: every kernel entry point becomes a
+shape / dtype / extent CHECK with no arithmetic, so the Python side of a model — autograd Functions, buffer sizes,
+leading dimensions, argument order, the number of gradients each backward returns — can be exercised here, where there
+is no GPU.  It computes nothing: outputs keep whatever torch.empty gave them.  Numerical parity is the `-m gpu` tests' job."""
+import contextlib
+
+import torch
+
+from mmf_amd import _native as N
+
+_INT_RETURNS = {
+    "layernorm_bwd_ws_floats": lambda H: 64 * 3 * H, "colsum_ws_floats": lambda n: 64 * n,
+    "gemm_rowsum_supported": lambda M, Nn, K: False,
+}
+_KEEP = {"drop_cfg", "_drop4", "lib", "_check", "_stream", "_p", "_req"}
+calls = []
+
+
+def _room(t):
+    """elements addressable from t's first element to the end of its storage"""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
+def _need(t, rows, ld, cols, what):
+    if t is None:
+        return
+    need = (rows - 1) * ld + cols
+    assert _room(t) >= need, "%s: needs %d elements from its base pointer, buffer has %d" % (what, need, _room(t))
+
+
+def _gemm(A, B, C_out, M, Nn, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None, rowtab=None,
+          rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=N.NO_DROP, grp=(0, 0, 0), debug_flags=0,
+          rowsum_out=None):
+    assert A.dtype in (torch.bfloat16, torch.float32) and B.dtype in (torch.bfloat16, torch.float32)
+    assert lda % 8 == 0 and ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 (%d, %d)" % (lda, ldb)
+    k8 = (K + 7) // 8 * 8
+    if a_kmajor:
+        _need(A, K, lda, (M + 7) // 8 * 8 if lda >= (M + 7) // 8 * 8 else M, "gemm A (k-major)")
+    else:
+        assert lda >= k8, "gemm: lda %d does not cover round_up(K=%d, 8)" % (lda, K)
+        _need(A, M, lda, K, "gemm A")
+    if b_kmajor:
+        _need(B, K, ldb, Nn, "gemm B (k-major)")
+    else:
+        assert ldb >= k8, "gemm: ldb %d does not cover round_up(K=%d, 8)" % (ldb, K)
+        _need(B, Nn, ldb, K, "gemm B")
+    rows_out = M if grp[0] == 0 else M + (M // grp[0]) * grp[1] + grp[2]
+    _need(C_out, rows_out, ldc, Nn, "gemm C")
+    for v, n in ((bias, Nn), (coladd, Nn)):
+        if v is not None:
+            assert v.dtype == torch.float32 and v.numel() >= n
+    if resid is not None:
+        _need(resid, M, ldr, Nn, "gemm resid")
+    if rowsum_out is not None:
+        assert rowsum_out.numel() >= M
+    calls.append(("gemm", M, Nn, K))
+
+
+def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=N.NO_DROP, head_dim=64, ctx_f32=None,
+                   causal_tail=0):
+    assert head_dim in (64, 128) and 0 <= causal_tail <= Sk and (causal_tail == 0 or (Sq == Sk and head_dim == 64))
+    assert Sq <= 256 and Sk <= 256
+    _need(q, B * Sq, ldq, heads * head_dim, "attention q"); _need(k, B * Sk, ldk, heads * head_dim, "attention k")
+    _need(v, B * Sk, ldv, heads * head_dim, "attention v"); _need(ctx, B * Sq, ldo, heads * head_dim, "attention ctx")
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.numel() >= B * Sk
+    assert lse.numel() >= B * heads * Sq
+    calls.append(("attention_fwd", B, heads, Sq, Sk, causal_tail))
+
+
+def _attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta, drop=N.NO_DROP,
+                   head_dim=64, ctx_f32=None, causal_tail=0):
+    _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail)
+    _need(dctx, B * Sq, ldo, heads * head_dim, "attention dctx"); _need(dq, B * Sq, ldq, heads * head_dim, "attention dq")
+    _need(dk, B * Sk, ldk, heads * head_dim, "attention dk"); _need(dv, B * Sk, ldv, heads * head_dim, "attention dv")
+    calls[-1] = ("attention_bwd", B, heads, Sq, Sk, causal_tail)
+
+
+def _copy_rows(src, src_bstride, dst, dst_bstride, nb, rpb, H):
+    assert H % 8 == 0
+    _need(src, (nb - 1) * src_bstride + rpb, H, H, "copy_rows src"); _need(dst, (nb - 1) * dst_bstride + rpb, H, H, "copy_rows dst")
+
+
+def _l2norm_fwd(x, ldx, y, ldy, inv, rows, D, eps=1e-12):
+    assert x.dtype in (torch.float32, torch.bfloat16) and y.dtype == torch.bfloat16 and inv.dtype == torch.float32
+    _need(x, rows, ldx, D, "l2norm x"); _need(y, rows, ldy, D, "l2norm y"); assert inv.numel() >= rows and inv.is_contiguous()
+
+
+def _l2norm_bwd(g, ldg, y, ldy, inv, dx, lddx, rows, D):
+    _need(g, rows, ldg, D, "l2norm g"); _need(y, rows, ldy, D, "l2norm y"); _need(dx, rows, lddx, D, "l2norm dx")
+
+
+def _gather_rows2(a, b, idx, out, n, H):
+    assert H % 8 == 0 and a.shape[1] == H and b.shape[1] == H and idx.dtype == torch.int64 and idx.numel() == n
+    assert int(idx.min()) >= 0 and int(idx.max()) < a.shape[0] + b.shape[0]
+    _need(out, n, H, H, "gather2 out")
+
+
+def _ptr_fwd(q, k, mask_add, out, ldo, B, T, Nn, HQ, scale):
+    assert HQ % 8 == 0
+    _need(q, B * T, HQ, HQ, "ptr q"); _need(k, B * Nn, HQ, HQ, "ptr k"); _need(out, B * T, ldo, Nn, "ptr out")
+    assert mask_add is None or (mask_add.dtype == torch.float32 and mask_add.numel() == B * Nn)
+
+
+def _ptr_bwd(ds, ldd, q, k, dq, dk, B, T, Nn, HQ, scale):
+    assert ds.dtype == torch.float32
+    _need(ds, B * T, ldd, Nn, "ptr ds"); _need(dq, B * T, HQ, HQ, "ptr dq"); _need(dk, B * Nn, HQ, HQ, "ptr dk")
+
+
+def _scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, few_buckets, skip_bucket=-1):
+    _need(x, (nb - 1) * bstride + rpb, ld, H, "scatter_add x")
+    if idx is not None:
+        assert idx.dtype == torch.int64 and _room(idx) >= (nb - 1) * idx_ld + rpb
+        assert int(idx.max()) < out.shape[0], "scatter_add: index %d outside the %d-row table" % (int(idx.max()), out.shape[0])
+    assert out.dtype == torch.float32 and out.shape[1] == H
+
+
+def _cast2d_f32(src, lds, dst, ldd, rows, cols):
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16
+    _need(src, rows, lds, cols, "cast2d src"); _need(dst, rows, ldd, ldd, "cast2d dst")
+
+
+def _bce_rowmask_fwd(scores, targets, w, loss, count, rows, Nn):
+    assert scores.numel() == rows * Nn == targets.numel() and w.numel() == rows and loss.numel() == 1 and count.numel() == 1
+
+
+def _bce_rowmask_bwd(scores, targets, w, count, gloss, d, rows, Nn):
+    assert d.numel() == rows * Nn and gloss.numel() == 1
+
+
+_CHECKED = {"gemm": _gemm, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
+            "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
+            "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,
+            "bce_rowmask_fwd": _bce_rowmask_fwd, "bce_rowmask_bwd": _bce_rowmask_bwd}
+
+
+@contextlib.contextmanager
+def installed():
+    """Replace every kernel wrapper of mmf_amd._native by its checker (or a no-op) for the duration of the block."""
+    saved = {}
+    for name, obj in list(vars(N).items()):
+        if name.startswith("__") or name in _KEEP or not callable(obj) or isinstance(obj, type):
+            continue
+        if getattr(obj, "__module__", None) != N.__name__:
+            continue
+        saved[name] = obj
+        if name in _CHECKED:
+            setattr(N, name, _CHECKED[name])
+        elif name in _INT_RETURNS:
+            setattr(N, name, _INT_RETURNS[name])
+        else:
+            setattr(N, name, (lambda nm: (lambda *a, **k: calls.append((nm,))))(name))
+    del calls[:]
+    from mmf_amd import functional as Fn
+    try:
+        # dropout keys normally come from the device's Philox state: use the graph-mode key sequence instead
+        with Fn.dropout_keys.graph_mode(torch.zeros(1, dtype=torch.int32)):
+            yield calls
+    finally:
+        Fn.shadows.clear()
+        for name, obj in saved.items():
+            setattr(N, name, obj)

@@ -1,0 +1,359 @@
+"""M4C on the HIP path (GPU): the kernels it adds — the causal-tail (prefix-LM) attention mask, L2 row normalisation, the
+two-source previous-prediction gather, the OCR pointer scores, the masked decoding BCE — against plain PyTorch fp32 on
+the same inputs, then the registered `m4c` model against the fixture recorded from the real reference
+(tests/golden/m4c_small64.npz) and the pinned CPU oracle: teacher-forced scores, loss and every parameter gradient, and
+the greedy decoding loop.  Tolerance 5e-2 (bf16 path)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import m4c_oracle as O
+from tests.golden_utils import load_m4c_case
+from tests.model_utils import build_m4c, sample_to
+from tests.test_kernels_gpu import DEV, close, nat, rnd, split_heads
+from mmf_amd.common.sample import SampleList
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-2
+
+
+def rel_err(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+# ---------------------------------------------------------------------------------------------
+# attention with the prefix-LM mask of MMT.forward (m4c.py:424-440)
+# ---------------------------------------------------------------------------------------------
+def prefix_lm_ref_mask(mbin, tail):
+    """[B, 1, S, S] additive mask built the way the reference does."""
+    B, S = mbin.shape
+    ext = mbin.float()[:, None, None, :].repeat(1, 1, S, 1)
+    ext[:, :, S - tail:, S - tail:] = torch.tril(torch.ones(tail, tail, device=mbin.device))
+    return (1.0 - ext) * -10000.0
+
+
+@pytest.mark.parametrize("B,heads,S,tail", [(2, 3, 26, 5), (2, 12, 182, 12), (1, 2, 100, 100), (1, 1, 256, 31), (3, 2, 33, 1)])
+def test_attention_causal_tail_forward_backward(B, heads, S, tail):
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, scale=1.0, seed=S + tail)
+    mbin = (torch.rand(B, S, device=DEV) > 0.2).long()
+    mbin[:, 0] = 1
+    mbin[:, S - tail:] = 0                      # dec_mask = 0 (m4c.py:405-407): only the causal block opens these keys
+    mask = torch.empty(B, S, device=DEV)
+    nat().make_additive_mask(mbin, mask)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, S, device=DEV)
+    o32 = torch.empty(B * S, H, device=DEV)
+    scale = 1.0 / math.sqrt(64)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    nat().attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, scale, ctx_f32=o32, causal_tail=tail)
+    qf, kf, vf = (split_heads(t.contiguous(), B, S, heads).requires_grad_(True) for t in (q, k, v))
+    full = prefix_lm_ref_mask(mbin, tail)       # [B, 1, S, S]
+    s = torch.matmul(qf, kf.transpose(-1, -2)) * scale + full
+    p = torch.softmax(s, dim=-1)
+    o_ref = torch.matmul(p, vf)
+    close(split_heads(ctx, B, S, heads), o_ref, 2e-2, 2e-2, "causal-tail ctx")
+    close(lse, torch.logsumexp(s, dim=-1), 1e-4, 2e-3, "causal-tail lse")
+    # structure: an encoding query puts (numerically) nothing on decoding keys; decoding query i nothing on keys > i
+    assert float(p[:, :, : S - tail, S - tail:].max()) < 1e-30 if tail < S else True
+    dctx = rnd(B * S, H, seed=7)
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B, heads, S, device=DEV)
+    nat().attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, scale, dctx,
+                        dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta, ctx_f32=o32, causal_tail=tail)
+    o_ref.backward(split_heads(dctx, B, S, heads))
+    for name, got_, ref_ in (("dq", dqkv[:, :H], qf.grad), ("dk", dqkv[:, H:2 * H], kf.grad), ("dv", dqkv[:, 2 * H:], vf.grad)):
+        g = split_heads(got_.contiguous(), B, S, heads)
+        close(g, ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name + " (causal tail)")
+
+
+def test_attention_without_tail_is_unchanged_by_the_new_field():
+    B, heads, S = 2, 2, 70
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, seed=5)
+    outs = []
+    for tail in (0, 0):
+        ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, S, device=DEV)
+        nat().attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, ctx, H, lse, B, heads, S, S, 0.125,
+                            causal_tail=tail)
+        outs.append(ctx)
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(nat().NativeLibraryError):      # a causal tail needs Sq == Sk
+        ctx = torch.empty(B * 10, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, 10, device=DEV)
+        nat().attention_fwd(qkv[: B * 10, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, ctx, H, lse, B, heads, 10, S,
+                            0.125, causal_tail=3)
+
+
+# ---------------------------------------------------------------------------------------------
+# row kernels
+# ---------------------------------------------------------------------------------------------
+def test_l2norm_rows_and_ocr_feature_concat():
+    import mmf_amd.functional as Fn
+    B, N = 3, 6
+    x32 = torch.randn(B, N, 300, device=DEV)
+    y = Fn.L2NormRowsFn.apply(x32)
+    close(y, torch.nn.functional.normalize(x32, dim=-1), 1e-2, 1e-3, "normalize fp32 input")
+    xb = rnd(B, N, 88, seed=3).requires_grad_(True)
+    yb = Fn.L2NormRowsFn.apply(xb)
+    xr = xb.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xr, dim=-1)
+    close(yb, ref, 1e-2, 1e-3, "normalize bf16 input")
+    g = rnd(B, N, 88, seed=4)
+    yb.backward(g); ref.backward(g.float())
+    close(xb.grad, xr.grad, 2e-2, 2e-2 * float(xr.grad.abs().max()), "normalize backward")
+    # zero rows stay zero (eps clamp), no NaN
+    z = Fn.L2NormRowsFn.apply(torch.zeros(2, 3, 16, device=DEV))
+    assert float(z.float().abs().max()) == 0.0
+    # the concatenated OCR feature: [fasttext 300 | phoc 604 | fc7 88 | 6 zeros | pad] -> 1000 columns
+    ft = torch.randn(B, N, 300, device=DEV); ph = torch.rand(B, N, 604, device=DEV)
+    f7 = rnd(B, N, 88, seed=5).requires_grad_(True)
+    cat = Fn.OcrFeatureConcatFn.apply(ft, ph, f7, 6)
+    assert tuple(cat.shape) == (B, N, 1000)
+    f7r = f7.detach().float().requires_grad_(True)
+    nrm = torch.nn.functional.normalize
+    ref = torch.cat([nrm(ft, dim=-1), nrm(ph, dim=-1), nrm(f7r, dim=-1), torch.zeros(B, N, 8, device=DEV)], dim=-1)
+    close(cat, ref, 1e-2, 1e-3, "ocr feature concat")
+    g = rnd(B, N, 1000, seed=6)
+    cat.backward(g); ref.backward(g.float())
+    close(f7.grad, f7r.grad, 2e-2, 2e-2 * float(f7r.grad.abs().max()), "ocr feature concat backward")
+    # 998-wide linear over it
+    w = (torch.randn(192, 998, device=DEV) * 0.05).requires_grad_(True); b = torch.randn(192, device=DEV).requires_grad_(True)
+    cat2 = cat.detach().clone().requires_grad_(True)
+    out = Fn.PaddedLinearFn.apply(cat2, w, b)
+    wr = w.detach().bfloat16().float().requires_grad_(True)
+    cr = cat2.detach().float().requires_grad_(True)
+    ref = cr[..., :998] @ wr.t() + b.detach()
+    close(out, ref, 1e-2, 2e-2, "998-wide linear")
+    go = rnd(B, N, 192, seed=8)
+    out.backward(go); ref.backward(go.float())
+    close(w.grad, wr.grad, 2e-2, 2e-2 * float(wr.grad.abs().max()), "998-wide wgrad")
+    close(b.grad, go.float().sum((0, 1)), 1e-3, 1e-2, "998-wide bias grad")
+    close(cat2.grad[..., :998], cr.grad[..., :998], 2e-2, 2e-2 * float(cr.grad.abs().max()), "998-wide dgrad")
+
+
+def test_prev_pred_gather_and_param_rows():
+    import mmf_amd.functional as Fn
+    V, B, N, T, H = 37, 3, 6, 5, 192
+    ans = rnd(V, H, seed=1).requires_grad_(True)
+    ocr = rnd(B, N, H, seed=2).requires_grad_(True)
+    prev = torch.randint(0, V + N, (B, T), device=DEV)
+    prev[:, 0] = 1; prev[1, 2:] = 0; prev[2, 3] = V + N - 1; prev[0, 1] = V
+    out = Fn.PrevPredGatherFn.apply(ans, ocr, prev)
+    cat = torch.cat([ans.detach().float().unsqueeze(0).expand(B, -1, -1), ocr.detach().float()], dim=1)
+    ref = torch.gather(cat, 1, prev.unsqueeze(-1).expand(B, T, H))
+    assert torch.equal(out.float(), ref)
+    g = rnd(B, T, H, seed=3)
+    out.backward(g)
+    cat_g = torch.zeros(B, V + N, H, device=DEV)
+    cat_g.scatter_add_(1, prev.unsqueeze(-1).expand(B, T, H), g.float())
+    close(ans.grad, cat_g[:, :V].sum(0), 1e-2, 2e-2, "answer-table gradient (colliding <pad> rows)")
+    close(ocr.grad, cat_g[:, V:], 1e-2, 2e-2, "ocr-row gradient")
+    w = torch.randn(V, H, device=DEV).requires_grad_(True)
+    a = Fn.ParamRowsFn.apply(w)
+    assert a.dtype == torch.bfloat16 and torch.equal(a, w.detach().bfloat16())
+    a.backward(g.new_ones(V, H))
+    assert w.grad.dtype == torch.float32 and float((w.grad - 1).abs().max()) == 0.0
+
+
+def test_ptr_scores_and_scores_concat():
+    import mmf_amd.functional as Fn
+    B, T, N, H, HQ, V = 3, 5, 6, 192, 128, 37
+    dec = rnd(B, T, H, seed=1).requires_grad_(True); ocr = rnd(B, N, H, seed=2).requires_grad_(True)
+    P = lambda *s, sc=0.05: (torch.randn(*s, device=DEV) * sc).requires_grad_(True)
+    cw, cb, qw, qb, kw, kb = P(V, H), P(V), P(HQ, H), P(HQ), P(HQ, H), P(HQ)
+    mbin = torch.ones(B, N, dtype=torch.long, device=DEV); mbin[1, 3:] = 0; mbin[2, 4:] = 0
+    madd = torch.empty(B, N, device=DEV); nat().make_additive_mask(mbin, madd)
+    scores = Fn.M4CScoresFn.apply(dec, ocr, cw, cb, qw, qb, kw, kb, madd, Fn.shadows.get(cw), Fn.shadows.get(qw), Fn.shadows.get(kw))
+    assert tuple(scores.shape) == (B, T, V + N) and scores.dtype == torch.float32
+    r = lambda t: t.detach().bfloat16().float().requires_grad_(True)
+    decr, ocrr, cwr, qwr, kwr = r(dec), r(ocr), r(cw), r(qw), r(kw)
+    cbr, qbr, kbr = (t.detach().clone().requires_grad_(True) for t in (cb, qb, kb))
+    fixed = decr @ cwr.t() + cbr
+    q = (decr @ qwr.t() + qbr).bfloat16().float(); k = (ocrr @ kwr.t() + kbr).bfloat16().float()
+    qf = decr @ qwr.t() + qbr; kf = ocrr @ kwr.t() + kbr
+    dyn = torch.matmul(qf, kf.transpose(-1, -2)) / math.sqrt(HQ) + madd[:, None, :]
+    ref = torch.cat([fixed, dyn], dim=-1)
+    close(scores, ref, 2e-2, 3e-2, "scores = [classifier | pointer]")
+    g = torch.randn(B, T, V + N, device=DEV)
+    scores.backward(g); ref.backward(g)
+    for name, a, b_ in (("d dec", dec.grad, decr.grad), ("d ocr", ocr.grad, ocrr.grad), ("d cls w", cw.grad, cwr.grad), ("d cls b", cb.grad, cbr.grad),
+                        ("d q w", qw.grad, qwr.grad), ("d q b", qb.grad, qbr.grad), ("d k w", kw.grad, kwr.grad), ("d k b", kb.grad, kbr.grad)):
+        assert rel_err(a, b_) <= 3e-2, (name, rel_err(a, b_))
+
+
+def test_decoding_bce_with_mask():
+    import mmf_amd.functional as Fn
+    B, T, Cn = 3, 5, 43
+    x = torch.randn(B, T, Cn, device=DEV).requires_grad_(True)
+    t = (torch.rand(B, T, Cn, device=DEV) > 0.9).float() * 0.6
+    for w in (torch.tensor([[1., 1, 1, 0, 0], [1, 0, 0, 0, 0], [1, 1, 1, 1, 1]], device=DEV), torch.zeros(B, T, device=DEV)):
+        x.grad = None
+        loss = Fn.DecodingBCEWithMaskFn.apply(x, t, w)
+        xr = x.detach().clone().requires_grad_(True)
+        ref = O.decoding_bce_with_mask(xr, t, w)
+        assert tuple(loss.shape) == (1,)
+        assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+        (loss * 1.7).sum().backward(); (ref * 1.7).sum().backward()
+        close(x.grad, xr.grad, 1e-4, 1e-6, "masked BCE gradient")
+
+
+# ---------------------------------------------------------------------------------------------
+# the registered model
+# ---------------------------------------------------------------------------------------------
+def _teacher_forcing(model):
+    """Teacher forcing (m4c.py:286-289) with every dropout off: only the top-level flag is set, exactly what the fixture's
+    generator does with the reference (tests/golden/make_golden.py::make_m4c)."""
+    model.eval()
+    model.training = True
+    return model
+
+
+def _oracle_grads(sd, cfg, sample, gates=None):
+    s = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    r = O.m4c_forward(s, cfg, dict(sample), training_mode=True, return_all=True, relu_gates=gates)
+    O.decoding_bce_with_mask(r["scores"], sample["targets"], sample["train_loss_mask"]).sum().backward()
+    return {k: v.grad for k, v in s.items()}, r
+
+
+def _bf16_weight_sensitivity(sd, cfg, sample, gates=None):
+    """How far each gradient moves when weights and input features are merely rounded to bf16 (something every bf16
+    implementation does) - a per-parameter measure of conditioning, evaluated with the CPU oracle.  Largest on this
+    fixture: the fc7 layers (ReLU gates of pre-activations within rounding noise of zero: 2-3 %) and the query / key
+    projections (softmax Jacobians: ~1 %)."""
+    g0, _ = _oracle_grads(sd, cfg, sample, gates)
+    sb = dict(sample)
+    for k in ("image_feature_0", "image_feature_1", "context_feature_0", "context_feature_1", "obj_bbox_coordinates", "ocr_bbox_coordinates"):
+        sb[k] = sample[k].bfloat16().float()
+    g1, _ = _oracle_grads({k: v.bfloat16().float() for k, v in sd.items()}, cfg, sb, gates)
+    return {k: rel_err(g1[k], g0[k]) for k in g0}
+
+
+def _skip(name):
+    # attention key biases: identically zero in exact arithmetic (a per-query constant cancels in the softmax); the
+    # pointer network's key bias is a real gradient (no softmax there)
+    return name.endswith(".key.bias") and "ocr_ptr_net" not in name
+
+
+def test_m4c_golden_forward_loss_and_gradients():
+    z, case, cfg, sd, sample = load_m4c_case()
+    model = _teacher_forcing(build_m4c(cfg, sd))
+    got = {}
+    hooks = [model.mmt.register_forward_hook(lambda m, i, o: got.update(seq=o["mmt_seq_output"]))]
+    out = model(SampleList(sample_to(sample, "cuda")))
+    for h in hooks:
+        h.remove()
+    np.testing.assert_allclose(got["seq"].detach().float().cpu().numpy(), z["mmt_seq_output"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(out["scores"].detach().float().cpu().numpy(), z["scores"], rtol=TOL, atol=TOL)
+    (key, loss), = out["losses"].items()
+    assert key == "train/textvqa/m4c_decoding_bce_with_mask"
+    assert abs(loss.sum().item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    loss.sum().backward()
+    sens = _bf16_weight_sensitivity(sd, cfg, sample)
+    params = dict(model.named_parameters())
+    bad = {}
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        gname = str(gname)
+        p = params[gname]
+        assert p.grad is not None, gname
+        if _skip(gname):
+            continue
+        tol = max(TOL, 6.0 * sens[gname])      # 5e-2, or 6x the movement caused by bf16-rounding weights and inputs alone
+        e = abs(float(p.grad.double().norm()) - norm) / norm
+        full = "grad::" + gname
+        if full in z.files:
+            e = max(e, rel_err(p.grad, torch.from_numpy(z[full])))
+        if e > tol:
+            bad[gname] = (round(e, 4), round(sens[gname], 4))
+    assert not bad, bad
+    assert float(params["text_bert.embeddings.word_embeddings.weight"].grad[0].abs().max()) == 0.0     # [PAD]
+
+
+def test_m4c_every_gradient_matches_the_oracle():
+    """Full gradients of every parameter against the pinned oracle, with the oracle's two fc7 ReLUs gated by the signs the
+    HIP path saw (a handful of pre-activations sit within bf16 noise of zero; the flip count is asserted to be tiny)."""
+    z, case, cfg, sd, sample = load_m4c_case()
+    model = _teacher_forcing(build_m4c(cfg, sd))
+    gates = {}
+    hooks = [model.obj_faster_rcnn_fc7.register_forward_hook(lambda m, i, o: gates.update(obj=(o.detach().float() > 0).cpu())),
+             model.ocr_faster_rcnn_fc7.register_forward_hook(lambda m, i, o: gates.update(ocr=(o.detach().float() > 0).cpu()))]
+    out = model(SampleList(sample_to(sample, "cuda")))
+    for h in hooks:
+        h.remove()
+    (key, loss), = out["losses"].items()
+    loss.sum().backward()
+    own = {"obj": O.fc7(sd, "obj_faster_rcnn_fc7.", sample["image_feature_0"]) > 0,
+           "ocr": O.fc7(sd, "ocr_faster_rcnn_fc7.", sample["image_feature_1"][:, : case["N"]]) > 0}
+    flips = {k: int((own[k] != gates[k]).sum()) for k in own}
+    assert all(flips[k] <= 0.01 * own[k].numel() for k in own), flips
+    ref_grads, ref = _oracle_grads(sd, cfg, sample, gates)
+    assert rel_err(out["scores"], ref["scores"]) <= TOL
+    sens = _bf16_weight_sensitivity(sd, cfg, sample, gates)
+    params = dict(model.named_parameters())
+    bad = {}
+    for k, g in ref_grads.items():
+        if _skip(k):
+            continue
+        e = rel_err(params[k].grad, g)
+        if e > max(TOL, 6.0 * sens[k]):
+            bad[k] = (round(e, 4), round(sens[k], 4))
+    assert not bad, (flips, bad)
+
+
+def test_m4c_greedy_decoding_matches_reference():
+    z, case, cfg, sd, sample = load_m4c_case()
+    model = build_m4c(cfg, sd).eval()
+    with torch.no_grad():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    scores = out["scores"].float().cpu()
+    am = scores.argmax(-1).numpy()
+    # the fixture's decoding margins (top-1 minus top-2) are ~4: bf16 noise cannot flip them
+    assert float(z["decode_margin"].min()) > 1.0
+    np.testing.assert_array_equal(am, z["decode_argmax"])
+    np.testing.assert_allclose(scores.numpy(), z["decode_scores"], rtol=TOL, atol=TOL)
+    # training-mode call with the decoded sequence as previous predictions reproduces the decoded scores (self-consistency
+    # of the loop: step t only ever saw predictions < t)
+    prev = torch.zeros_like(sample["train_prev_inds"]); prev[:, 0] = 1; prev[:, 1:] = torch.from_numpy(am)[:, :-1]
+    s2 = dict(sample); s2["train_prev_inds"] = prev
+    model2 = _teacher_forcing(model)
+    with torch.no_grad():
+        again = model2(SampleList(sample_to(s2, "cuda")))["scores"].float().cpu()
+    np.testing.assert_allclose(again.numpy(), scores.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_m4c_textvqa_shape_trains_with_dropout_and_stays_finite():
+    """The configured shape (BASELINE.json configs[4]): 20 + 100 + 50 + 12 positions, 768 wide, 5000 + 50 scores."""
+    cfg = dict(O.DEFAULT_CONFIG)
+    from mmf_amd.common.registry import registry
+    from mmf_amd.utils.configuration import Config
+    import warnings
+    registry.register("config", Config({"datasets": "textvqa"}))
+    registry.register("textvqa_num_final_outputs", 5050)
+    registry.register("textvqa_answer_processor", Config({"BOS_IDX": 1}))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = registry.get_model_class("m4c")(Config({"model": "m4c", "text_bert_init_from_bert_base": False}))
+        model.build(); model.init_losses()
+    model = model.to("cuda").train()
+    B = 4
+    g = torch.Generator().manual_seed(3)
+    sample = {
+        "text": torch.randint(1, 30522, (B, 20), generator=g), "text_len": torch.tensor([20, 9, 14, 5]),
+        "image_feature_0": torch.rand(B, 100, 2048, generator=g), "obj_bbox_coordinates": torch.rand(B, 100, 4, generator=g),
+        "image_info_0": {"max_features": torch.tensor([100, 37, 64, 100])},
+        "context_feature_0": torch.randn(B, 50, 300, generator=g), "context_feature_1": torch.rand(B, 50, 604, generator=g),
+        "image_feature_1": torch.rand(B, 100, 2048, generator=g), "ocr_bbox_coordinates": torch.rand(B, 50, 4, generator=g),
+        "context_info_0": {"max_features": torch.tensor([50, 0, 13, 31])}, "order_vectors": torch.zeros(B, 50, 50),
+        "train_prev_inds": torch.randint(0, 5050, (B, 12), generator=g), "targets": (torch.rand(B, 12, 5050, generator=g) > 0.999).float(),
+        "train_loss_mask": (torch.rand(B, 12, generator=g) > 0.3).float(), "dataset_name": "textvqa", "dataset_type": "train"}
+    out = model(SampleList(sample_to(sample, "cuda")))
+    assert tuple(out["scores"].shape) == (B, 12, 5050)
+    (key, loss), = out["losses"].items()
+    loss.sum().backward()
+    assert torch.isfinite(loss).all()
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    # sample 1 has no OCR token at all: its pointer scores are all -10000 + noise, and nothing blows up
+    assert float(out["scores"][1, :, 5000:].max()) < -9000

@@ -52,15 +52,23 @@ class Registry:
             cur = cur.setdefault(part, {})
         cur[path[-1]] = obj
 
+    # another registry consulted for key/value state this one does not hold: `mmf_amd.plugin.install()` points it at
+    # MMF's own registry, where MMF's dataset builders put e.g. `<dataset>_num_final_outputs` and the answer processor
+    # that M4C reads at build time (mmf/models/m4c.py:39,158,172)
+    fallback = None
+
     @classmethod
     def get(cls, name, default=None, no_warning=False):
         value = cls.mapping["state"]
         for part in name.split("."):
             if not isinstance(value, dict):
-                return default
+                value = default
+                break
             value = value.get(part, default)
             if value is default:
                 break
+        if value is default and cls.fallback is not None:
+            return cls.fallback.get(name, default, no_warning=True)
         return value
 
     @classmethod

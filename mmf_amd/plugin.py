@@ -10,8 +10,8 @@ entry (mmf/common/registry.py:319), and the model adapters created here derive f
 `issubclass` assertion at registry.py:316 holds and MMF's `build_model` (mmf/utils/build.py:116-151), `Losses`,
 checkpointing and trainer loop run unchanged around the HIP-backed networks.
 
-Registered: models `visual_bert`, `mmbt`, `vilbert`, `uniter`, `mmft` / `mmf_transformer`; losses `logit_bce`,
-`cross_entropy`; optimizer `adam_w`; scheduler `warmup_linear`; transformer backend `huggingface`; transformer heads
+Registered: models `visual_bert`, `mmbt`, `vilbert`, `uniter`, `m4c`, `mmft` / `mmf_transformer`; losses `logit_bce`,
+`cross_entropy`, `m4c_decoding_bce_with_mask`; encoder `finetune_faster_rcnn_fpn_fc7`; optimizer `adam_w`; scheduler `warmup_linear`; transformer backend `huggingface`; transformer heads
 `mlp` / `multilayer_mlp`.
 """
 
@@ -57,27 +57,36 @@ def _adapter(mmf_base_model, hip_cls, children):
     return Adapter
 
 
+# the sub-modules M4C.build() creates directly on the model (mmf/models/m4c.py:46-170)
+M4C_CHILDREN = ("text_bert", "text_bert_out_linear", "obj_faster_rcnn_fc7", "linear_obj_feat_to_mmt_in", "linear_obj_bbox_to_mmt_in",
+                "obj_feat_layer_norm", "obj_bbox_layer_norm", "obj_drop", "ocr_faster_rcnn_fc7", "linear_ocr_feat_to_mmt_in",
+                "linear_ocr_bbox_to_mmt_in", "ocr_feat_layer_norm", "ocr_bbox_layer_norm", "ocr_drop", "mmt", "ocr_ptr_net", "classifier")
+
+
 def install():
     from mmf.common.registry import registry as mmf_registry  # noqa: the reference package
     from mmf.models.base_model import BaseModel as MMFBaseModel
 
     import mmf_amd  # noqa: F401  (fills mmf_amd's registry)
     from mmf_amd.common.registry import registry as hip_registry
+    from mmf_amd.models.m4c import M4C
     from mmf_amd.models.mmbt import MMBT
     from mmf_amd.models.mmf_transformer import MMFTransformer
     from mmf_amd.models.uniter import UNITER
     from mmf_amd.models.vilbert import ViLBERT
     from mmf_amd.models.visual_bert import VisualBERT
 
+    type(hip_registry).fallback = mmf_registry      # key/value state (dataset sizes, processors) lives in MMF's registry
     adapters = {}
     for names, cls, children in ((("visual_bert",), VisualBERT, ("model",)), (("mmbt",), MMBT, ("model",)),
                                  (("vilbert",), ViLBERT, ("model",)), (("uniter",), UNITER, ("uniter",)),
+                                 (("m4c",), M4C, M4C_CHILDREN),
                                  (("mmft", "mmf_transformer"), MMFTransformer, ("backend", "encoders", "heads"))):
         adapter = _adapter(MMFBaseModel, cls, children)
         for name in names:
             mmf_registry.register_model(name)(adapter)
             adapters[name] = adapter
-    for kind, names in (("loss", ("logit_bce", "cross_entropy")), ("optimizer", ("adam_w",)), ("scheduler", ("warmup_linear",)),
+    for kind, names in (("loss", ("logit_bce", "cross_entropy", "m4c_decoding_bce_with_mask")), ("encoder", ("finetune_faster_rcnn_fpn_fc7",)), ("optimizer", ("adam_w",)), ("scheduler", ("warmup_linear",)),
                         ("transformer_backend", ("huggingface",)), ("transformer_head", ("mlp", "multilayer_mlp"))):
         for name in names:
             obj = getattr(hip_registry, "get_%s_class" % kind)(name)

@@ -7,14 +7,18 @@ import types
 import pytest
 from torch import nn
 
-from tests.golden_utils import load_mmft_case, load_vilbert_case
-from tests.model_utils import mmft_model_config, vilbert_model_config
+from tests.golden_utils import load_m4c_case, load_mmft_case, load_vilbert_case
+from tests.model_utils import build_m4c, m4c_model_config, mmft_model_config, vilbert_model_config
 
 
 @pytest.fixture
 def fake_mmf():
     class Registry:
         store = {}
+        state = {}
+
+        def get(self, name, default=None, no_warning=False):
+            return self.state.get(name, default)
 
         def __getattr__(self, name):
             if name.startswith("register_"):
@@ -43,6 +47,8 @@ def fake_mmf():
     saved = {k: sys.modules.get(k) for k in mods}
     sys.modules.update(mods)
     yield mods["mmf.common.registry"].registry, BaseModel
+    from mmf_amd.common.registry import registry as hip_registry
+    type(hip_registry).fallback = None
     for k, v in saved.items():
         if v is None:
             sys.modules.pop(k, None)
@@ -55,9 +61,10 @@ def test_install_registers_everything_and_keeps_the_parameter_tree(fake_mmf):
     from mmf_amd import plugin
     from mmf_amd.utils.build import build_model
     adapters = plugin.install()
-    assert set(adapters) == {"visual_bert", "mmbt", "vilbert", "uniter", "mmft", "mmf_transformer"}
+    assert set(adapters) == {"visual_bert", "mmbt", "vilbert", "uniter", "m4c", "mmft", "mmf_transformer"}
     for key in (("loss", "logit_bce"), ("loss", "cross_entropy"), ("optimizer", "adam_w"), ("scheduler", "warmup_linear"),
-                ("transformer_backend", "huggingface"), ("transformer_head", "mlp"), ("model", "vilbert")):
+                ("transformer_backend", "huggingface"), ("transformer_head", "mlp"), ("model", "vilbert"),
+                ("loss", "m4c_decoding_bce_with_mask"), ("encoder", "finetune_faster_rcnn_fpn_fc7"), ("model", "m4c")):
         assert key in registry.store, key
     z, case, cfg, sd, sample = load_vilbert_case()
     mc = vilbert_model_config(cfg)
@@ -71,3 +78,16 @@ def test_install_registers_everything_and_keeps_the_parameter_tree(fake_mmf):
     m.build()
     assert set(m.state_dict().keys()) == set(build_model(mc).state_dict().keys())
     assert type(m).format_state_key("classifier.2.weight") == "heads.0.classifier.2.weight"
+    # M4C: the adapter exposes the sub-modules M4C.build() creates, under the reference's names
+    z, case, cfg, sd, sample = load_m4c_case()
+    ref_keys = set(build_m4c(cfg, None, device="cpu").state_dict().keys())
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = registry.store[("model", "m4c")](m4c_model_config(cfg))
+        m.build()
+    assert isinstance(m, BaseModel) and set(m.state_dict().keys()) == ref_keys == {str(n) for n in z["param_names"]}
+    # key/value state M4C reads at build time is found in MMF's registry when mmf_amd's own does not hold it
+    from mmf_amd.common.registry import registry as hip_registry
+    registry.state["someset_num_final_outputs"] = 4242
+    assert hip_registry.get("someset_num_final_outputs") == 4242 and hip_registry.get("absent_key", "dflt") == "dflt"

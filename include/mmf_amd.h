@@ -340,6 +340,20 @@ typedef struct mmf_tensor_list {
 int mmf_l2norm_sq_ws_floats(const mmf_tensor_list* d);
 int mmf_l2norm_sq_multi(const mmf_tensor_list* d, float* out, int accumulate, float* ws, void* stream);
 
+/* ---- transposed weight shadows -------------------------------------------------------------------------------------
+ * dst[i] (bf16 [cols, rows]) = transpose of src[i] (bf16 [rows, cols], row-major), for up to MMF_MT_MAX matrices per
+ * launch; rows and cols multiples of 64.  Keeps W^T twins of the bf16 weight shadows current so that the input-gradient
+ * GEMM of nn.Linear (dX = dY W; autograd of mmf/modules/hf_layers.py:169-180,248,289-290) runs with two row operands
+ * instead of a k-major W.  Not a reference operation: an internal layout choice. */
+typedef struct mmf_transpose_list {
+    int n;
+    const void* src[MMF_MT_MAX];
+    void* dst[MMF_MT_MAX];
+    int rows[MMF_MT_MAX];
+    int cols[MMF_MT_MAX];
+} mmf_transpose_list;
+int mmf_transpose_bf16_multi(const mmf_transpose_list* d, void* stream);
+
 /* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
 int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */
 int mmf_probe_mfma32(const void* a, const void* b, float* d, void* stream);   /* out 64x16 */

@@ -69,6 +69,11 @@ class TensorList(C.Structure):
     _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * MT_MAX), ("numel", C.c_int64 * MT_MAX)]
 
 
+class TransposeList(C.Structure):
+    _fields_ = [("n", C.c_int), ("src", C.c_void_p * MT_MAX), ("dst", C.c_void_p * MT_MAX), ("rows", C.c_int * MT_MAX),
+                ("cols", C.c_int * MT_MAX)]
+
+
 class AttnBwdDesc(C.Structure):
     _fields_ = [
         ("f", AttnDesc), ("dctx", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
@@ -510,6 +515,20 @@ def l2norm_sq_multi(tensors, out):
             d.ptr[i], d.numel[i] = t.data_ptr(), t.numel()
         ws = torch.empty(lib().mmf_l2norm_sq_ws_floats(C.byref(d)), dtype=torch.float32, device=out.device)
         _check(lib().mmf_l2norm_sq_multi(C.byref(d), _p(out), int(i0 > 0), _p(ws), _stream()), "mmf_l2norm_sq_multi")
+
+
+def transpose_multi(pairs):
+    """dst = src^T for every (src bf16 [R, C], dst bf16 [C, R]) pair; R, C multiples of 64; MT_MAX matrices per launch."""
+    for i0 in range(0, len(pairs), MT_MAX):
+        chunk = pairs[i0:i0 + MT_MAX]
+        d = TransposeList()
+        d.n = len(chunk)
+        for i, (src, dst) in enumerate(chunk):
+            _req(src, torch.bfloat16, "src"); _req(dst, torch.bfloat16, "dst")
+            if not (src.is_contiguous() and dst.is_contiguous()) or tuple(dst.shape) != (src.shape[1], src.shape[0]):
+                raise NativeLibraryError("transpose_multi: contiguous [R, C] -> [C, R] pairs expected")
+            d.src[i], d.dst[i], d.rows[i], d.cols[i] = src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1]
+        _check(lib().mmf_transpose_bf16_multi(C.byref(d), _stream()), "mmf_transpose_bf16_multi")
 
 
 def probe_mfma16(a, b, d):

@@ -89,6 +89,13 @@ def make_drop(p, training):
 # ---------------------------------------------------------------------------------------------
 # bf16 shadows of fp32 master parameters
 # ---------------------------------------------------------------------------------------------
+# Transposed weight twins for the input-gradient GEMMs (opt-in experiment, MMF_AMD_DGRAD_NT=1).  In the isolated microbenchmark
+# a GEMM with two row operands is ~18 % faster than the same shape with a k-major W (tools/gemm_vs_library.py); inside the
+# training step the same-box A/B shows no gain (11.62 vs 11.53-11.62 ms per full update, 11.09 vs 10.96-11.04 ms forward +
+# backward), so the k-major form - no extra 170 MB, no transpose per update - stays the default.
+DGRAD_NT = os.environ.get("MMF_AMD_DGRAD_NT", "0") == "1"
+
+
 class ShadowCache:
     """bf16 copies of fp32 parameters, refreshed (one cast kernel) whenever the parameter's version
     counter or storage changes.  Several parameters can share one contiguous shadow (Q|K|V)."""
@@ -96,11 +103,43 @@ class ShadowCache:
     def __init__(self):
         self._store = {}  # id(head parameter) -> (signature, buffer, dtype); entry dies with the parameter
         self._slot = {}   # id(parameter) -> (head key, first row) for bf16 shadows
+        self._t = {}      # head key -> (signature at transposition, W^T buffer): transposed twins for the dgrad GEMMs
+        self._by_ptr = {}  # data_ptr of a bf16 shadow buffer -> head key
 
     def clear(self):
         """Forget every shadow: the next use re-casts (used before hipGraph capture)."""
         self._store.clear()
         self._slot.clear()
+        self._t.clear()
+        self._by_ptr.clear()
+
+    def transposed(self, w16):
+        """W^T [in, out] (bf16) of the weight shadow `w16` [out, in], or None when `w16` is not a whole tracked shadow (or
+        its dimensions are not multiples of 64, or MMF_AMD_DGRAD_NT=0).  Built on first use, re-built when the shadow's
+        signature changed (a re-cast after `load_state_dict` / a torch optimizer), and kept current by
+        `refresh_transposed()` when the fused optimizer updates parameters and shadows in place."""
+        if not DGRAD_NT or w16.dim() != 2:
+            return None
+        key = self._by_ptr.get(w16.data_ptr())
+        ent = self._store.get(key) if key is not None else None
+        if ent is None or ent[2] != BF16 or ent[1].data_ptr() != w16.data_ptr() or ent[1].shape != w16.shape:
+            return None
+        R, Cn = ent[1].shape
+        if R % 64 or Cn % 64:
+            return None
+        t = self._t.get(key)
+        if t is not None and t[0] == ent[0]:
+            return t[1]
+        tbuf = t[1] if (t is not None and tuple(t[1].shape) == (Cn, R)) else torch.empty(Cn, R, dtype=BF16, device=w16.device)
+        nat.transpose_multi([(ent[1], tbuf)])
+        self._t[key] = (ent[0], tbuf)
+        return tbuf
+
+    def refresh_transposed(self):
+        """Re-transpose every live twin from its (already updated) shadow: called by the fused optimizer's step."""
+        pairs = [(self._store[k][1], t[1]) for k, t in self._t.items() if k in self._store and self._store[k][0] == t[0]]
+        if pairs:
+            nat.transpose_multi(pairs)
 
     def slot(self, p):
         """The mirror rows of parameter `p` (bf16 weight shadow, or its slice of a packed fp32 Q|K|V bias) if it has an
@@ -127,6 +166,7 @@ class ShadowCache:
             return ent[1]
         if ent is None:
             weakref.finalize(head, self._store.pop, key, None)
+            weakref.finalize(head, self._t.pop, key, None)
         rows = sum(p.shape[0] for p in params)
         shape = (rows,) + tuple(head.shape[1:])
         buf = ent[1] if ent is not None and ent[1].shape == shape and ent[2] == dtype else torch.empty(
@@ -145,6 +185,8 @@ class ShadowCache:
                 self._slot[id(p)] = (key, r)
             r += n
         self._store[key] = (sig, buf, dtype)
+        if dtype == BF16:
+            self._by_ptr[buf.data_ptr()] = key
         return buf
 
 
@@ -190,8 +232,12 @@ def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=N
     dx = None
     if need_dx:
         dx = torch.empty(M, K, dtype=BF16, device=dev)
-        nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
-                 act=2 if act_aux is not None else 0, aux=act_aux)
+        wt = shadows.transposed(w16) if N % 8 == 0 else None
+        if wt is not None:     # dX = dY (W^T)^T with two row operands (experiment, see DGRAD_NT)
+            nat.gemm(dy, wt, dx, M, K, N, ldy, N, K, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
+        else:
+            nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
+                     act=2 if act_aux is not None else 0, aux=act_aux)
     dw = torch.empty(N, K, dtype=F32, device=dev)
     fused = want_db and x.dtype == BF16 and _FUSED_DB and nat.gemm_rowsum_supported(N, K, M)
     db = torch.empty(N, dtype=F32, device=dev) if fused else None

@@ -85,4 +85,5 @@ class AdamW(torch.optim.Optimizer):
             nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
                             1.0, norm_sq, max_norm, dev_state)
         self._clip = None
+        Fn.shadows.refresh_transposed()     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
         return loss

@@ -44,7 +44,7 @@ def _gemm(A, B, C_out, M, Nn, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, 
     else:
         assert ldb >= k8, "gemm: ldb %d does not cover round_up(K=%d, 8)" % (ldb, K)
         _need(B, Nn, ldb, K, "gemm B")
-    rows_out = M if grp[0] == 0 else M + (M // grp[0]) * grp[1] + grp[2]
+    rows_out = M if grp[0] == 0 else (M - 1) + ((M - 1) // grp[0]) * grp[1] + grp[2] + 1
     _need(C_out, rows_out, ldc, Nn, "gemm C")
     for v, n in ((bias, Nn), (coladd, Nn)):
         if v is not None:

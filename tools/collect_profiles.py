@@ -5,11 +5,12 @@ import collections, csv, glob, json, os, re, sys
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "")
-    m = re.search(r"gemm_bf16_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d+)E", name)
+    m = re.search(r"gemm_bf16_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d+)E(?:Li(\d)ELb(\d)E)?", name)
     if m:
-        a, b, ak, bk, rg, nwn, bn = m.groups()
-        return "gemm_bf16_kernel<A=%s,B=%s,%s%s,%s,%dwaves,BN=%s>" % ("bf16" if a != "f" else "f32", "bf16" if b != "f" else "f32",
-            "T" if ak == "1" else "N", "N" if bk == "1" else "T", "ragged" if rg == "1" else "full", 2 * int(nwn), bn)
+        a, b, ak, bk, rg, nwn, bn, ks, rs = m.groups()
+        extra = ("" if ks in (None, "1") else ",Ksplit") + ("" if rs in (None, "0") else ",+bias-grad")
+        return "gemm_bf16_kernel<A=%s,B=%s,%s%s,%s,%dwaves,BN=%s%s>" % ("bf16" if a != "f" else "f32", "bf16" if b != "f" else "f32",
+            "T" if ak == "1" else "N", "N" if bk == "1" else "T", "ragged" if rg == "1" else "full", 2 * int(nwn), bn, extra)
     m = re.search(r"gemm_bf16_kernel<([^>]*)>", name)
     if m:
         return "gemm_bf16_kernel<%s>" % m.group(1)
@@ -57,8 +58,9 @@ def main(tag):
         traffic[v] = {"bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024), "fetch_size_kb_raw": round(fetch_kb, 1),
                       "write_size_kb_raw": round(write_kb, 1), "launches": len(d.get("FETCH_SIZE", [])),
                       "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B for wide coalesced reads)"}
-    json.dump({k: v["bytes_per_launch"] for k, v in traffic.items()}, open("profiles/pmc_traffic.json", "w"), indent=1)
-    json.dump(traffic, open("profiles/%s_pmc_traffic_detail.json" % tag, "w"), indent=1)
+    if traffic:      # a trace-only refresh keeps the PMC summaries of the last full run
+        json.dump({k: v["bytes_per_launch"] for k, v in traffic.items()}, open("profiles/pmc_traffic.json", "w"), indent=1)
+        json.dump(traffic, open("profiles/%s_pmc_traffic_detail.json" % tag, "w"), indent=1)
     # ---- SQ counters
     f = glob.glob(src + "/pmc_sq/*counter_collection.csv")
     if f:

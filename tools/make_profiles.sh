@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 mkdir -p $out
 CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $CMD > $out/trace.log 2>&1
+[ "$2" = "trace-only" ] && { grep -h metric $out/trace.log | cut -c1-300; exit 0; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- $CMD > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- $CMD > $out/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq -o p -- $CMD > $out/pmc_sq.log 2>&1

@@ -52,12 +52,17 @@ def wgrad_sweep():
     nat.set_tunable(nat.TUN_SPLITK_FORCE, 0)
 
 
-def gemm_variants():
-    """All twelve per-layer GEMMs: default dispatch, K-split wave layout forced (bit 12) and forbidden (bit 13)."""
+ABLATIONS = (("default", 0), ("no-dma", 1 << 4), ("no-mfma", 2 << 4), ("no-epilogue", 8 << 4), ("dma-only", (2 | 8) << 4),
+             ("mfma+lds-only", (1 | 8) << 4), ("epilogue-only", (1 | 2) << 4), ("skeleton", (1 | 2 | 8) << 4))
+
+
+def gemm_variants(variants=(("default", 0), ("ksplit", 4096), ("no-ksplit", 8192))):
+    """All twelve per-layer GEMMs: default dispatch, K-split wave layout forced (bit 12) and forbidden (bit 13); or, with
+    ABLATIONS, the kernel with parts switched off (debug_flags bits 4-7: bit 4 no operand prefetch after the first stage,
+    bit 5 no LDS reads / MFMAs, bit 7 no epilogue) - results are garbage, only the timings mean something."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     from gemm_bench import SHAPES
     dev = "cuda"
-    variants = (("default", 0), ("ksplit", 4096), ("no-ksplit", 8192))
     tot = {n: 0.0 for n, _ in variants}
     for name, kind, m, n, k in SHAPES:
         if kind == "NT":
@@ -92,3 +97,5 @@ if __name__ == "__main__":
         wgrad_sweep()
     if "gemm" in which:
         gemm_variants()
+    if "ablate" in which:
+        gemm_variants(ABLATIONS)

@@ -249,12 +249,130 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     return 0;
 }
 
+
+// ---- 256 x 128 tile, three-stage LDS-DMA ring (EXPERIMENTAL, debug_flags bit 14; not used by default) -----------------
+// Status: correct (tests/test_gemm256_gpu.py, incl. a 30-launch race screen) and 20-40 % SLOWER than the 128-row kernel on every
+// forward / dgrad shape of the VisualBERT layer (574.6 against 477.1 us per layer, tools/micro_sweep.py tile256): with one
+// workgroup of 8 waves per CU (2 waves per SIMD) the compiler-scheduled read-wait-MFMA sequence of a step leaves the MFMA pipe
+// idle while fragments are in flight, and the deeper ring does not buy that back.  Kept as the tested skeleton (ring, counted
+// waits, masked ragged-M epilogue) for the phase-interleaved schedule of cdna_hip_programming.md section 5.
+// One workgroup per CU (144 KiB of LDS), 8 waves as 4 x 2 wave tiles of 64 x 64 (8 fragment reads per 16 MFMAs), K-step 64.
+// Per step a CU stages 48 KiB for 4.2 MFLOP (85 FLOP per staged byte against 64 for two 128 x 128 workgroups), and the ring
+// keeps TWO stages in flight: iteration kt waits with a counted `s_waitcnt vmcnt(6)` (the six LDS-DMA instructions of stage
+// kt + 1 may still be outstanding), crosses one raw `s_barrier`, issues stage kt + 2 into the buffer everybody finished
+// reading in iteration kt - 1, and multiplies stage kt.  A is a row operand (two 128-row images per stage), B a row or a
+// k-major operand (the same LDS images and fragment reads as the 128 x 128 kernel); M may be ragged (row clamp + masked
+// epilogue), N % 128 == 0 and K % 64 == 0.  The fp32 tile is staged through the idle ring for the row-wise epilogue.
+constexpr int BM2 = 256, NSTAGE2 = 3, STAGE2_BYTES = 3 * OPER_BYTES;
+
+template <bool B_KMAJOR, bool RAGGED>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
+                                                          int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntile = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware order, as in gemm_bf16_kernel
+        const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    int tile_m, tile_n;
+    {
+        const int per_sr = 4 * tiles_n;          // 4-row super-rows (1024 rows of A), column-major inside
+        const int sr = bid / per_sr, rem = bid - sr * per_sr;
+        const int h = min(4, tiles_m - sr * 4);
+        tile_n = rem / h;
+        tile_m = sr * 4 + (rem - tile_n * h);
+    }
+    const int m0 = tile_m * BM2, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    auto issue = [&](int kt, int buf) {
+        unsigned char* st = smem + buf * STAGE2_BYTES;
+        stage_dma<false, RAGGED, 512>(A, lda, m0, kt * BK, M, K, st, tid);
+        stage_dma<false, RAGGED, 512>(A, lda, m0 + 128, kt * BK, M, K, st + OPER_BYTES, tid);
+        stage_dma<B_KMAJOR, false, 512>(B, ldb, n0, kt * BK, N, K, st + 2 * OPER_BYTES, tid);
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(kt + 2, buf >= 1 ? buf - 1 : 2);      // (kt + 2) % 3 == (buf + 2) % 3
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* la = smem + buf * STAGE2_BYTES + (wm >> 1) * OPER_BYTES;
+        const unsigned char* lb = smem + buf * STAGE2_BYTES + 2 * OPER_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fa[f] = read_frag<false>(la, (wm & 1) * 64, f, kk, lane);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fb[f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    __syncthreads();       // every wave is done with the ring: it becomes the fp32 C stage
+    constexpr int CLD = BN + 4;
+    float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wm * 64 + i * 16 + (lane & 15), col = wn * 64 + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<float4*>(cs + row * CLD + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    __syncthreads();
+    constexpr int SEG = BN / 8;
+    for (int idx = tid; idx < BM2 * SEG; idx += 512) {
+        const int row = idx / SEG, seg = idx - row * SEG;
+        epilogue8(epi, m0 + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), 0);
+    }
+}
+
+template <bool BK_, bool RG>
+int launch256(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    const int tm = (d->M + BM2 - 1) / BM2, tn = d->N / BN;
+    constexpr int cstage = BM2 * (BN + 4) * (int)sizeof(float);
+    constexpr int lds_bytes = cstage > NSTAGE2 * STAGE2_BYTES ? cstage : NSTAGE2 * STAGE2_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<BK_, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<BK_, RG>), dim3(tm * tn), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
+                       reinterpret_cast<const bf16*>(d->B), d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     // 8 waves (4 per SIMD with two workgroups per CU) hide LDS / MFMA-issue latency better than 4 waves of 64x64;
     // bit 8 of debug_flags selects the 4-wave form for A/B measurements.
     if (AK && BK_ && is_bf16<AT>::value && is_bf16<BT>::value && e.rowsum_col >= 0)   // weight gradient carrying the bias gradient
         return launch_n<AT, BT, AK, BK_, RG, 4, 128, 1, AK && BK_>(d, e, s);
+    // 256 x 128 tiles with the three-stage ring (experimental: debug_flags bit 14 selects it)
+    if constexpr (!AK && is_bf16<AT>::value && is_bf16<BT>::value) {
+        if ((d->debug_flags & 16384) && e.splits <= 1 && (d->N % BN) == 0 && (d->K % BK) == 0 && d->M >= BM2)
+            return (d->M % BM2) ? launch256<BK_, true>(d, e, s) : launch256<BK_, false>(d, e, s);
+    }
     if (d->debug_flags & 256) return launch_n<AT, BT, AK, BK_, RG, 2, 128>(d, e, s);
     // Wave layout: 2x4 waves of 64x32 over both K-halves of a stage (KS = 1), or 2x2 waves of 64x64 times the two
     // K-halves (KS = 2: a third fewer LDS operand reads, one extra pass over the LDS C stage at the end).  Measured

@@ -99,3 +99,5 @@ if __name__ == "__main__":
         gemm_variants()
     if "ablate" in which:
         gemm_variants(ABLATIONS)
+    if "tile256" in which:      # the 256 x 128 three-stage-ring kernel (debug_flags bit 14; the weight gradients ignore it)
+        gemm_variants((("default", 0), ("tile256", 16384)))

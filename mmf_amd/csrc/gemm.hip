@@ -252,7 +252,8 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
 
 // ---- 256 x 128 tile, three-stage LDS-DMA ring (EXPERIMENTAL, debug_flags bit 14; not used by default) -----------------
 // Status: correct (tests/test_gemm256_gpu.py, incl. a 30-launch race screen) and 20-40 % SLOWER than the 128-row kernel on every
-// forward / dgrad shape of the VisualBERT layer (574.6 against 477.1 us per layer, tools/micro_sweep.py tile256): with one
+// forward / dgrad shape of the VisualBERT layer (572 us per layer, 549 with all fragment reads of a step issued first - bit 15 -
+// against 477; tools/micro_sweep.py tile256, profiles/r01_gemm256_experiment.txt): with one
 // workgroup of 8 waves per CU (2 waves per SIMD) the compiler-scheduled read-wait-MFMA sequence of a step leaves the MFMA pipe
 // idle while fragments are in flight, and the deeper ring does not buy that back.  Kept as the tested skeleton (ring, counted
 // waits, masked ragged-M epilogue) for the phase-interleaved schedule of cdna_hip_programming.md section 5.
@@ -265,7 +266,7 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
 // epilogue), N % 128 == 0 and K % 64 == 0.  The fp32 tile is staged through the idle ring for the row-wise epilogue.
 constexpr int BM2 = 256, NSTAGE2 = 3, STAGE2_BYTES = 3 * OPER_BYTES;
 
-template <bool B_KMAJOR, bool RAGGED>
+template <bool B_KMAJOR, bool RAGGED, bool PRE>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
                                                           int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -312,6 +313,24 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* la = smem + buf * STAGE2_BYTES + (wm >> 1) * OPER_BYTES;
         const unsigned char* lb = smem + buf * STAGE2_BYTES + 2 * OPER_BYTES;
+        if constexpr (PRE) {     // bit 15: all 16 fragment reads of the step first, so the second half's land behind the first half's MFMAs
+            bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) fa[kk][f] = read_frag<false>(la, (wm & 1) * 64, f, kk, lane);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) fb[kk][f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // without it the scheduler sinks the reads back between the MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[4], fb[4];
@@ -324,6 +343,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
         }
         buf = buf == 2 ? 0 : buf + 1;
     }
@@ -345,18 +365,18 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict_
     }
 }
 
-template <bool BK_, bool RG>
+template <bool BK_, bool RG, bool PRE>
 int launch256(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM2 - 1) / BM2, tn = d->N / BN;
     constexpr int cstage = BM2 * (BN + 4) * (int)sizeof(float);
     constexpr int lds_bytes = cstage > NSTAGE2 * STAGE2_BYTES ? cstage : NSTAGE2 * STAGE2_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<BK_, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<BK_, RG, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<BK_, RG>), dim3(tm * tn), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
+    hipLaunchKernelGGL((gemm256_kernel<BK_, RG, PRE>), dim3(tm * tn), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
                        reinterpret_cast<const bf16*>(d->B), d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e);
     MMF_CHECK_LAUNCH();
     return 0;
@@ -371,7 +391,11 @@ int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     // 256 x 128 tiles with the three-stage ring (experimental: debug_flags bit 14 selects it)
     if constexpr (!AK && is_bf16<AT>::value && is_bf16<BT>::value) {
         if ((d->debug_flags & 16384) && e.splits <= 1 && (d->N % BN) == 0 && (d->K % BK) == 0 && d->M >= BM2)
-            return (d->M % BM2) ? launch256<BK_, true>(d, e, s) : launch256<BK_, false>(d, e, s);
+        {
+            const bool pre = d->debug_flags & 32768;
+            if (d->M % BM2) return pre ? launch256<BK_, true, true>(d, e, s) : launch256<BK_, true, false>(d, e, s);
+            return pre ? launch256<BK_, false, true>(d, e, s) : launch256<BK_, false, false>(d, e, s);
+        }
     }
     if (d->debug_flags & 256) return launch_n<AT, BT, AK, BK_, RG, 2, 128>(d, e, s);
     // Wave layout: 2x4 waves of 64x32 over both K-halves of a stage (KS = 1), or 2x2 waves of 64x64 times the two

@@ -18,11 +18,12 @@ def _same(C, C0, K):
         close(C, C0.float(), 1e-2, 2e-2, "256-row vs 128-row kernel")
 
 
+@pytest.mark.parametrize("flags", [T256, T256 | 32768])
 @pytest.mark.parametrize("M,N,K", [(7296, 768, 768), (7296, 3072, 768), (1024, 768, 3072), (456, 2304, 768), (256, 128, 64), (300, 128, 128)])
-def test_gemm256_forward_bias_matches_torch_and_the_default_kernel(M, N, K):
+def test_gemm256_forward_bias_matches_torch_and_the_default_kernel(M, N, K, flags):
     A = rnd(M, K, seed=1); B = rnd(N, K, seed=2, scale=0.05); bias = torch.randn(N, device=DEV)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); C0 = torch.empty_like(C)
-    nat().gemm(A, B, C, M, N, K, K, K, N, bias=bias, debug_flags=T256)
+    nat().gemm(A, B, C, M, N, K, K, K, N, bias=bias, debug_flags=flags)
     nat().gemm(A, B, C0, M, N, K, K, K, N, bias=bias)
     ref = A.float() @ B.float().t() + bias
     close(C, ref, 1e-2, 2e-2, "256-row tile forward")
@@ -47,13 +48,14 @@ def test_gemm256_gelu_residual_dropout_and_fp32_output():
     close(Cf, A.float() @ B.float().t(), 1e-4, 1e-3, "fp32 output")
 
 
+@pytest.mark.parametrize("flags", [T256, T256 | 32768])
 @pytest.mark.parametrize("M,N,K", [(7296, 768, 2304), (7296, 3072, 768), (520, 768, 768)])
-def test_gemm256_dgrad_k_major_weight(M, N, K):
+def test_gemm256_dgrad_k_major_weight(M, N, K, flags):
     # dX [M, N] = dY [M, K] W [K, N]  (W k-major), with the gelu' multiply and the residual-gradient add of the FFN backward
     dY = rnd(M, K, seed=6); W = rnd(K, N, seed=7, scale=0.05)
     aux = rnd(M, N, seed=8); resid = rnd(M, N, seed=9)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); C0 = torch.empty_like(C)
-    nat().gemm(dY, W, C, M, N, K, K, N, N, b_kmajor=True, act=2, aux=aux, resid=resid, ldr=N, debug_flags=T256)
+    nat().gemm(dY, W, C, M, N, K, K, N, N, b_kmajor=True, act=2, aux=aux, resid=resid, ldr=N, debug_flags=flags)
     nat().gemm(dY, W, C0, M, N, K, K, N, N, b_kmajor=True, act=2, aux=aux, resid=resid, ldr=N)
     ref = (dY.float() @ W.float()) * aux.float() + resid.float()
     close(C, ref, 1e-2, 3e-2, "256-row tile dgrad")

@@ -93,7 +93,7 @@ typedef struct mmf_gemm_desc {
                                  rowsum_out[m] = sum_k A[k][m] — the bias gradient (column sums of dY) computed by the
                                  same launch with one extra MFMA per A fragment against a ones operand, carried through
                                  the split-K workspace (behind the slabs) and summed by the slab reduction */
-    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bit 14: experimental 256x128 three-stage-ring kernel (forward / dgrad forms; bit 15: its reads-first schedule), bits 4-7: ablation switches */
+    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bit 14: experimental 256x128 three-stage-ring kernel (forward / dgrad forms; bit 15: its reads-first schedule, bit 16: its ping-pong schedule - not yet run on hardware), bits 4-7: ablation switches */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
 /* Number of K splits mmf_gemm_bf16 will use for this shape when given a workspace (1 = no split). */

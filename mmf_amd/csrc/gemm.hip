@@ -266,7 +266,7 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
 // epilogue), N % 128 == 0 and K % 64 == 0.  The fp32 tile is staged through the idle ring for the row-wise epilogue.
 constexpr int BM2 = 256, NSTAGE2 = 3, STAGE2_BYTES = 3 * OPER_BYTES;
 
-template <bool B_KMAJOR, bool RAGGED, bool PRE>
+template <bool B_KMAJOR, bool RAGGED, int SCHED>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
                                                           int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -304,6 +304,71 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict_
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     int buf = 0;
+    if constexpr (SCHED == 2) {
+        // Ping-pong schedule (bit 16; UNTESTED ON HARDWARE as of round 1 - written against the ISA, to be race-screened with
+        // tests/test_gemm256_gpu.py before any use).  The 8 waves form two groups of four, one wave of each group per SIMD; the
+        // second group runs ONE barrier interval behind the first, so on every SIMD one wave issues its 16 MFMAs (COMP) while
+        // the other fetches its next 8 fragments and issues its share of the LDS-DMA for the stage two K-tiles ahead (LOAD).
+        // A K-tile is LOAD0 | COMP0 | LOAD1 | COMP1 with a raw s_barrier after each; global barrier numbering below counts from
+        // the first barrier after the prologue, interval I(n) lies between barriers n and n + 1:
+        //   group 0:  LOAD0[t] in I(4t), COMP0[t] in I(4t+1), LOAD1[t] in I(4t+2), COMP1[t] in I(4t+3)
+        //   group 1:  the same, one interval later.
+        // RAW (stage t+1 is first read in I(4t+4)): every wave retires its own stage-(t+1) pieces with the counted vmcnt at the
+        //   end of LOAD1[t] (I(4t+2) / I(4t+3)), i.e. before barrier 4t+4.
+        // WAR (stage t+2 overwrites the buffer of stage t-1, whose last reads are group 1's LOAD1[t-1] in I(4t-1)): every LOAD
+        //   ends with lgkmcnt(0) before its barrier, and the earliest re-staging is group 0's LOAD0[t] in I(4t), after barrier 4t.
+        const int grp = wave >> 2;
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char* la = smem + buf * STAGE2_BYTES + (wm >> 1) * OPER_BYTES;
+            const unsigned char* lb = smem + buf * STAGE2_BYTES + 2 * OPER_BYTES;
+            unsigned char* nst = smem + (buf >= 1 ? buf - 1 : 2) * STAGE2_BYTES;
+            const bool more = kt + 2 < nk;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // ---- LOAD kk
+#pragma unroll
+                for (int f = 0; f < 4; ++f) fa[f] = read_frag<false>(la, (wm & 1) * 64, f, kk, lane);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) fb[f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
+                if (more) {
+                    if (kk == 0) {
+                        stage_dma<false, RAGGED, 512, 0, 2>(A, lda, m0, (kt + 2) * BK, M, K, nst, tid);
+                        stage_dma<false, RAGGED, 512, 0, 1>(A, lda, m0 + 128, (kt + 2) * BK, M, K, nst + OPER_BYTES, tid);
+                    } else {
+                        stage_dma<false, RAGGED, 512, 1, 2>(A, lda, m0 + 128, (kt + 2) * BK, M, K, nst + OPER_BYTES, tid);
+                        stage_dma<B_KMAJOR, false, 512, 0, 2>(B, ldb, n0, (kt + 2) * BK, N, K, nst + 2 * OPER_BYTES, tid);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kk == 1) {
+                    if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- COMP kk
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -313,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* la = smem + buf * STAGE2_BYTES + (wm >> 1) * OPER_BYTES;
         const unsigned char* lb = smem + buf * STAGE2_BYTES + 2 * OPER_BYTES;
-        if constexpr (PRE) {     // bit 15: all 16 fragment reads of the step first, so the second half's land behind the first half's MFMAs
+        if constexpr (SCHED == 1) {     // bit 15: all 16 fragment reads of the step first, so the second half's land behind the first half's MFMAs
             bf16x8 fa[2][4], fb[2][4];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -365,18 +430,18 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict_
     }
 }
 
-template <bool BK_, bool RG, bool PRE>
+template <bool BK_, bool RG, int SCHED>
 int launch256(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM2 - 1) / BM2, tn = d->N / BN;
     constexpr int cstage = BM2 * (BN + 4) * (int)sizeof(float);
     constexpr int lds_bytes = cstage > NSTAGE2 * STAGE2_BYTES ? cstage : NSTAGE2 * STAGE2_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<BK_, RG, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<BK_, RG, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<BK_, RG, PRE>), dim3(tm * tn), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
+    hipLaunchKernelGGL((gemm256_kernel<BK_, RG, SCHED>), dim3(tm * tn), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
                        reinterpret_cast<const bf16*>(d->B), d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e);
     MMF_CHECK_LAUNCH();
     return 0;
@@ -392,9 +457,9 @@ int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     if constexpr (!AK && is_bf16<AT>::value && is_bf16<BT>::value) {
         if ((d->debug_flags & 16384) && e.splits <= 1 && (d->N % BN) == 0 && (d->K % BK) == 0 && d->M >= BM2)
         {
-            const bool pre = d->debug_flags & 32768;
-            if (d->M % BM2) return pre ? launch256<BK_, true, true>(d, e, s) : launch256<BK_, true, false>(d, e, s);
-            return pre ? launch256<BK_, false, true>(d, e, s) : launch256<BK_, false, false>(d, e, s);
+            const int sched = (d->debug_flags & 65536) ? 2 : ((d->debug_flags & 32768) ? 1 : 0);   // bit 16 ping-pong, bit 15 reads-first
+            if (d->M % BM2) return sched == 2 ? launch256<BK_, true, 2>(d, e, s) : sched == 1 ? launch256<BK_, true, 1>(d, e, s) : launch256<BK_, true, 0>(d, e, s);
+            return sched == 2 ? launch256<BK_, false, 2>(d, e, s) : sched == 1 ? launch256<BK_, false, 1>(d, e, s) : launch256<BK_, false, 0>(d, e, s);
         }
     }
     if (d->debug_flags & 256) return launch_n<AT, BT, AK, BK_, RG, 2, 128>(d, e, s);

@@ -118,14 +118,15 @@ static __device__ uint4 g_zero16;
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
-template <bool KMAJOR, bool RAGGED, int NTH = 256>
+// I0 / I1 select a sub-range of the 1024 / NTH wave-instructions of a tile (a schedule may spread them over several phases).
+template <bool KMAJOR, bool RAGGED, int NTH = 256, int I0 = 0, int I1 = 1024 / NTH>
 DEVI void stage_dma(const bf16* base, int ld, int r0, int k0, int R, int K, unsigned char* lds, int tid) {
     const int wave = tid >> 6;
     if (!KMAJOR) {
         const int sw = (tid >> 3) & 7;
         const int k = k0 + ((tid & 7) ^ sw) * 8;
 #pragma unroll
-        for (int i = 0; i < 1024 / NTH; ++i) {
+        for (int i = I0; i < I1; ++i) {
             int row = r0 + (tid >> 3) + (NTH / 8) * i;
             if (RAGGED) row = row < R ? row : R - 1;
             const bf16* src = base + (size_t)row * ld + k;
@@ -134,7 +135,7 @@ DEVI void stage_dma(const bf16* base, int ld, int r0, int k0, int R, int K, unsi
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 1024 / NTH; ++i) {
+        for (int i = I0; i < I1; ++i) {
             const int kr = (tid >> 4) + (NTH / 16) * i;
             const int logical = ((tid & 15) - (rot_kmajor(kr) >> 4)) & 15;
             const int col = r0 + logical * 8;

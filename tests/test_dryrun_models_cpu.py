@@ -1,0 +1,89 @@
+"""Host-side dry run of one training step (train mode, dropout on, fused AdamW) of every registered model on CPU.  The kernel
+wrappers are replaced by extent / dtype / leading-dimension checkers (tests/native_stub.py), so this exercises the Python half
+of each path — every autograd Function's forward and backward, buffer sizes, argument order, the optimizer's parameter
+groups — and compares WHICH parameters receive a gradient with the reference (the fixtures record the reference's gradient
+norms: a parameter the reference leaves without gradient must stay without one here, and vice versa).  The numbers are the
+`-m gpu` tests' job."""
+import pytest
+import torch
+
+from mmf_amd.common.registry import registry
+from mmf_amd.common.sample import SampleList
+from mmf_amd.utils.configuration import Config
+from tests import golden_utils as G
+from tests import model_utils as MU
+from tests import native_stub
+
+
+def _visual_bert():
+    z, case, cfg, sd, sample = G.load_case("small64")
+    return z, MU.build_visual_bert(cfg, sd, device="cpu"), sample, "model."
+
+
+def _nlvr2():
+    z, case, cfg, sd, sample = G.load_nlvr2_case()
+    return z, MU.build_visual_bert(cfg, sd, device="cpu", training_head_type="nlvr2", pooler_strategy="default",
+                                   losses=[dict(type="cross_entropy")]), sample, "model."
+
+
+def _mmbt():
+    z, case, cfg, sd, sample = G.load_mmbt_case()
+    from oracle.mmbt_oracle import SHARED
+    return z, MU.build_mmbt(cfg, sd, SHARED, device="cpu"), sample, "model."
+
+
+def _mmft():
+    z, case, cfg, sd, sample = G.load_mmft_case()
+    from oracle.mmft_oracle import shared
+    return z, MU.build_mmft(cfg, sd, shared(cfg), device="cpu"), sample, ""
+
+
+def _vilbert():
+    z, case, cfg, sd, sample = G.load_vilbert_case()
+    return z, MU.build_vilbert(cfg, sd, device="cpu"), sample, "model."
+
+
+def _uniter():
+    z, case, cfg, sd, sample = G.load_uniter_case()
+    return z, MU.build_uniter(cfg, sd, device="cpu"), sample, ""
+
+
+def _m4c():
+    z, case, cfg, sd, sample = G.load_m4c_case()
+    return z, MU.build_m4c(cfg, sd, device="cpu"), sample, ""
+
+
+CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "mmbt": _mmbt, "mmft": _mmft, "vilbert": _vilbert, "uniter": _uniter,
+         "m4c": _m4c}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_training_step_plumbing(name):
+    z, model, sample, prefix = CASES[name]()
+    model.train()
+    key = name.split("_nlvr2")[0]
+    full = Config(model=key, optimizer=dict(params=dict(lr=5e-5)), model_config={key: model.config})
+    opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
+    with native_stub.installed() as calls:
+        out = model(SampleList(sample))
+        assert out["scores"].dtype == torch.float32 and out["scores"].shape[0] > 0
+        assert len(out["losses"]) == 1
+        (lkey, loss), = out["losses"].items()
+        assert lkey.startswith("train/") and loss.numel() == 1
+        loss.sum().backward()
+        opt.step()
+    assert any(c[0] == "gemm" for c in calls) and any(c[0] == "attention_bwd" for c in calls) and any(c[0] == "adamw_multi" for c in calls)
+    params = dict(model.named_parameters())
+    # every parameter in exactly one optimizer group
+    seen = [id(p) for g in opt.param_groups for p in g["params"]]
+    assert len(seen) == len(set(seen)) and set(seen) == {id(p) for p in params.values()}
+    ref = {str(n): float(v) for n, v in zip(z["grad_names"], z["grad_norms"])}
+    assert ref, "fixture without gradient records"
+    for n, norm in ref.items():
+        n = n if n in params else (n[len("model."):] if n.startswith("model.") and n[len("model."):] in params else n)
+        assert n in params, n
+        p = params[n]
+        if norm == 0.0:
+            assert p.grad is None, "%s: the reference leaves this parameter without a gradient" % n
+        else:
+            assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == torch.float32, n

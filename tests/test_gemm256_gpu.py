@@ -5,8 +5,13 @@ import torch
 
 from tests.test_kernels_gpu import DEV, close, nat, rnd
 
+import os
+
 pytestmark = pytest.mark.gpu
 T256 = 16384
+# schedules of the 256-row kernel: plain ring, reads-first (bit 15), and - only on request, it has not run on hardware yet -
+# the ping-pong schedule (bit 16): MMF_AMD_TEST_PINGPONG=1 python -m pytest tests/test_gemm256_gpu.py
+SCHEDULES = [T256, T256 | 32768] + ([T256 | 65536] if os.environ.get("MMF_AMD_TEST_PINGPONG") == "1" else [])
 
 
 def _same(C, C0, K):
@@ -18,7 +23,7 @@ def _same(C, C0, K):
         close(C, C0.float(), 1e-2, 2e-2, "256-row vs 128-row kernel")
 
 
-@pytest.mark.parametrize("flags", [T256, T256 | 32768])
+@pytest.mark.parametrize("flags", SCHEDULES)
 @pytest.mark.parametrize("M,N,K", [(7296, 768, 768), (7296, 3072, 768), (1024, 768, 3072), (456, 2304, 768), (256, 128, 64), (300, 128, 128)])
 def test_gemm256_forward_bias_matches_torch_and_the_default_kernel(M, N, K, flags):
     A = rnd(M, K, seed=1); B = rnd(N, K, seed=2, scale=0.05); bias = torch.randn(N, device=DEV)
@@ -48,7 +53,7 @@ def test_gemm256_gelu_residual_dropout_and_fp32_output():
     close(Cf, A.float() @ B.float().t(), 1e-4, 1e-3, "fp32 output")
 
 
-@pytest.mark.parametrize("flags", [T256, T256 | 32768])
+@pytest.mark.parametrize("flags", SCHEDULES)
 @pytest.mark.parametrize("M,N,K", [(7296, 768, 2304), (7296, 3072, 768), (520, 768, 768)])
 def test_gemm256_dgrad_k_major_weight(M, N, K, flags):
     # dX [M, N] = dY [M, K] W [K, N]  (W k-major), with the gelu' multiply and the residual-gradient add of the FFN backward
@@ -66,14 +71,10 @@ def test_gemm256_repeated_launches_are_stable():
     """Race screen: the ring's RAW / WAR ordering must not depend on timing - 30 launches, identical results."""
     M, N, K = 7296, 2304, 768
     A = rnd(M, K, seed=11); B = rnd(N, K, seed=12, scale=0.05)
-    first = None
-    for _ in range(30):
-        C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        nat().gemm(A, B, C, M, N, K, K, K, N, debug_flags=T256)
-        if first is None:
-            first = C
-        else:
-            assert torch.equal(C, first)
-    C0 = torch.empty_like(first)
+    C0 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     nat().gemm(A, B, C0, M, N, K, K, K, N)
-    assert torch.equal(first, C0)
+    for flags in SCHEDULES:
+        for _ in range(30):
+            C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            nat().gemm(A, B, C, M, N, K, K, K, N, debug_flags=flags)
+            assert torch.equal(C, C0), flags

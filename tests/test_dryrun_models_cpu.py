@@ -87,3 +87,50 @@ def test_training_step_plumbing(name):
             assert p.grad is None, "%s: the reference leaves this parameter without a gradient" % n
         else:
             assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == torch.float32, n
+
+
+def _step(model, sample):
+    model.train()
+    with native_stub.installed():
+        out = model(SampleList(sample))
+        loss = sum(v.sum() for v in out["losses"].values())
+        loss.backward()
+    return out
+
+
+def test_visual_bert_config_branches_plumbing():
+    """`pooler_strategy: default` (BertPooler on token 0), `zerobias`, `freeze_base` (visual_bert.py:121-131,168-170,389-398)."""
+    z, case, cfg, sd, sample = G.load_case("small64")
+    m = MU.build_visual_bert(cfg, sd, device="cpu", pooler_strategy="default")
+    _step(m, sample)
+    assert m.model.bert.pooler.dense.weight.grad is not None          # the pooler is on the path now
+    m = MU.build_visual_bert(cfg, None, device="cpu", zerobias=True, biasfill=-2.0)      # the reference reads config.biasfill too (:347)
+    assert bool((m.model.classifier[1].bias == -2.0).all())
+    m = MU.build_visual_bert(cfg, sd, device="cpu", freeze_base=True)
+    _step(m, sample)
+    assert all(p.grad is None for n, p in m.named_parameters() if n.startswith("model.bert."))
+    assert m.model.classifier[1].weight.grad is not None
+
+
+def test_mmbt_config_branches_plumbing():
+    """No modal start / end tokens, `fused_feature_only`, frozen text / modal halves (mmbt.py:173-178,229-231,253-259)."""
+    from oracle.mmbt_oracle import SHARED
+    z, case, cfg, sd, sample = G.load_mmbt_case()
+    for kw in (dict(use_modal_start_token=False, use_modal_end_token=False), dict(use_modal_start_token=True, use_modal_end_token=False)):
+        m = MU.build_mmbt(dict(cfg, **kw), sd, SHARED, device="cpu")
+        out = _step(m, sample)
+        assert out["scores"].shape == (case["B"], cfg["num_labels"])
+    m = MU.build_mmbt(cfg, sd, SHARED, device="cpu", freeze_text=True)
+    _step(m, sample)
+    assert m.model.bert.mmbt.transformer.encoder.layer[0].attention.self.query.weight.grad is None
+    assert m.model.classifier[1].weight.grad is not None
+
+
+def test_vilbert_sum_fusion_and_frozen_base_plumbing():
+    """`fusion_method: sum` (vilbert.py:1315-1320) and `freeze_base` (:1429-1431)."""
+    z, case, cfg, sd, sample = G.load_vilbert_case()
+    m = MU.build_vilbert(dict(cfg, fusion_method="sum"), sd, device="cpu")
+    _step(m, sample)
+    m = MU.build_vilbert(cfg, sd, device="cpu", freeze_base=True)
+    _step(m, sample)
+    assert all(p.grad is None for n, p in m.named_parameters() if n.startswith("model.bert."))

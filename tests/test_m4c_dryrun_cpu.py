@@ -46,3 +46,42 @@ def test_m4c_greedy_decoding_plumbing():
     fwd = [c for c in calls if c[0] == "attention_fwd"]
     # text_bert once (deterministic in eval mode), the multimodal transformer once per decoding step (m4c.py:297-305)
     assert len(fwd) == cfg["text_num_hidden_layers"] + D * cfg["num_hidden_layers"]
+
+
+import pytest
+
+
+@pytest.mark.parametrize("switch", ["remove_ocr_fasttext", "remove_ocr_phoc", "remove_ocr_frcn", "remove_ocr_semantics", "remove_ocr_bbox"])
+def test_m4c_ocr_ablation_switches_plumbing(switch):
+    """The `remove_ocr_*` switches of m4c.py:121-125,229-241: the step still runs end to end and the parameters upstream of a
+    removed input get no (or an all-zero-input) gradient path without breaking the others."""
+    z, case, cfg, sd, sample = load_m4c_case()
+    from tests.model_utils import m4c_model_config
+    base = m4c_model_config(cfg)
+    ocr = dict(base["ocr"]); ocr[switch] = True
+    model = build_m4c(cfg, sd, device="cpu", ocr=ocr)
+    assert getattr(model, switch) is True
+    model.train()
+    with native_stub.installed():
+        out = model(SampleList(sample))
+        (key, loss), = out["losses"].items()
+        loss.sum().backward()
+    for n, p in model.named_parameters():
+        if n.startswith("ocr_faster_rcnn_fc7.") and switch in ("remove_ocr_frcn", "remove_ocr_semantics"):
+            continue                                    # the appearance feature is cut off: no gradient reaches fc7
+        assert p.grad is not None, n
+
+
+def test_m4c_identity_text_projection_plumbing():
+    """text_bert as wide as the MMT (the real configuration): `text_bert_out_linear` is nn.Identity (m4c.py:88-98)."""
+    z, case, cfg, sd, sample = load_m4c_case()
+    cfg = dict(cfg, text_hidden_size=cfg["hidden_size"], text_num_attention_heads=cfg["num_attention_heads"],
+               text_intermediate_size=cfg["intermediate_size"])
+    model = build_m4c(cfg, None, device="cpu")
+    assert isinstance(model.text_bert_out_linear, torch.nn.Identity)
+    model.train()
+    with native_stub.installed():
+        out = model(SampleList(sample))
+        (key, loss), = out["losses"].items()
+        loss.sum().backward()
+    assert all(p.grad is not None for p in model.parameters())

@@ -34,6 +34,14 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROAR
 FWD_BWD_GFLOP_PER_SAMPLE = 122.9
 
 
+def baseline_metric():
+    """The metric string exactly as BASELINE.json spells it (fallback: the same text in ASCII)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "samples/sec/node VisualBERT VQA2 fwd+bwd, 100 regions x 2048 + 128 tok, bs=32/GPU"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,7 +283,7 @@ def main():
             "step_frac_of_mfma_peak": round(value / world * FWD_BWD_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
         }
         line = {
-            "metric": "samples/sec/node VisualBERT VQA2 fwd+bwd, 100 regions x 2048 + 128 tok, bs=32/GPU",
+            "metric": baseline_metric(),
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

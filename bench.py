@@ -93,14 +93,14 @@ def synthetic_batch(batch, rank, device):
 
 
 class GemmProbe:
-    """Times every mmf_gemm_bf16 launch of ONE step with HIP events on the launch stream."""
+    """Times every mmf_gemm_bf16 / mmf_gemm_bf16_grouped launch of ONE step with HIP events on the launch stream."""
 
     def __init__(self):
         self.rec = []
 
     def __enter__(self):
         from mmf_amd import _native as nat
-        self.nat, self.orig = nat, nat.gemm
+        self.nat, self.orig, self.orig_grouped = nat, nat.gemm, nat.gemm_grouped
 
         def timed(A, B, C_out, M, N, K, *a, **kw):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -111,11 +111,22 @@ class GemmProbe:
                                   "_ragged" if (M % 128 or N % 128 or K % 64) else "")
             self.rec.append((variant, (M, N, K), 2.0 * M * N * K, e0, e1))
 
+        def timed_grouped(problems):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_grouped(problems)
+            e1.record()
+            p0 = problems[0]
+            variant = "%s%s_grouped" % ("T" if p0.get("a_kmajor") else "N", "N" if p0.get("b_kmajor") else "T")
+            self.rec.append((variant, None, sum(2.0 * p["M"] * p["N"] * p["K"] for p in problems), e0, e1))
+
         nat.gemm = timed
+        nat.gemm_grouped = timed_grouped
         return self
 
     def __exit__(self, *exc):
         self.nat.gemm = self.orig
+        self.nat.gemm_grouped = self.orig_grouped
 
     def summary(self):
         torch.cuda.synchronize()

@@ -89,13 +89,25 @@ typedef struct mmf_gemm_desc {
     int grp_in, grp_pad, grp_off;
     void* splitk_ws;          /* optional fp32 workspace enabling deterministic split-K (fp32 output, no epilogue) */
     int64_t splitk_ws_bytes;  /* >= mmf_gemm_splitk_splits(M,N,K) * M * (N + 1) * 4 to take effect */
-    float* rowsum_out;        /* optional fp32 [M], weight-gradient form only (a_kmajor && b_kmajor with split-K active):
-                                 rowsum_out[m] = sum_k A[k][m] — the bias gradient (column sums of dY) computed by the
-                                 same launch with one extra MFMA per A fragment against a ones operand, carried through
-                                 the split-K workspace (behind the slabs) and summed by the slab reduction */
-    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bit 14: experimental 256x128 three-stage-ring kernel (forward / dgrad forms; bit 15: its reads-first schedule, bit 16: its ping-pong schedule - not yet run on hardware), bits 4-7: ablation switches */
+    float* rowsum_out;        /* optional fp32 [M], weight-gradient form only (a_kmajor && b_kmajor, bf16 operands):
+                                 rowsum_out[m] = sum_k A[k][m] — the bias gradient (column sums of dY; autograd of the `+ bias`
+                                 of nn.Linear, hf_layers.py:169-180) computed by the same launch with one extra MFMA per A
+                                 fragment against a ones operand; with split-K it travels through the workspace (behind the
+                                 slabs) and is summed by the slab reduction, else it is written directly */
+    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
+/* `count` (1..8) independent GEMMs of ONE operand layout (a_kmajor, b_kmajor, a_f32, b_f32 equal) in one launch: the tile
+ * lists are concatenated, so small problems fill the chip together.  No split-K (splitk_ws ignored); each problem keeps its
+ * own epilogue and rowsum_out.  Replaces the four weight-gradient GEMMs autograd issues per transformer layer
+ * (dW = dY^T X of the Linear layers at hf_layers.py:169-180 and of HF BertSelfOutput / BertIntermediate / BertOutput,
+ * call sites hf_layers.py:248,289,290; mmf/trainers/core/training_loop.py:211). */
+int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream);
+/* Development aid (profiling, not a reference operation): while `buf` (device memory, (1 + capacity_records) * 64 bytes,
+ * zeroed) is set, every workgroup of every GEMM launch appends one 64-byte timeline record of s_memrealtime (100 MHz) stamps
+ * {launch << 32 | block, HW_ID | XCC_ID << 32, entry, first stage landed, K loop done, tile staged, stores drained, tile};
+ * word 0 of the buffer counts the records.  NULL switches it off. */
+int mmf_gemm_set_probe(void* buf, int64_t capacity_records);
 /* Number of K splits mmf_gemm_bf16 will use for this shape when given a workspace (1 = no split). */
 int mmf_gemm_splitk_splits(int M, int N, int K);
 

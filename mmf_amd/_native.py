@@ -157,12 +157,10 @@ def _drop4(drop):
 # --------------------------------------------------------------------------------------------
 # GEMM
 # --------------------------------------------------------------------------------------------
-def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
-         rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
-         grp=(0, 0, 0), debug_flags=0, rowsum_out=None):
-    """`rowsum_out` (fp32 [M], weight-gradient form): also returns sum_k A[k][m], the bias gradient; only honoured when the
-    split-K path is active — check `gemm_rowsum_supported(M, N, K)` first."""
-    d = GemmDesc()
+def _gemm_desc(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
+               rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
+               grp=(0, 0, 0), debug_flags=0, rowsum_out=None, d=None):
+    d = GemmDesc() if d is None else d
     d.debug_flags = int(debug_flags) | _GEMM_DEBUG
     d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
     d.M, d.N, d.K = M, N, K
@@ -174,6 +172,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
     for t, n in ((A, "A"), (B, "B")):
         if t.dtype not in (torch.bfloat16, torch.float32):
             raise NativeLibraryError("gemm operand %s must be bf16 or fp32" % n)
+        if not t.is_cuda:
+            raise NativeLibraryError("gemm operand %s must live in HBM (cuda/hip tensor), got %s" % (n, t.device))
     if C_out.dtype not in (torch.bfloat16, torch.float32):
         raise NativeLibraryError("gemm output must be bf16 or fp32")
     _req(bias, torch.float32, "bias"); _req(coladd, torch.float32, "coladd"); _req(rowtab, torch.float32, "rowtab")
@@ -185,20 +185,56 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
     d.resid, d.ldr = _p(resid), ldr
     d.drop_key, d.drop_thr16, d.drop_scale, d.drop_seed = _drop4(drop)
     d.grp_in, d.grp_pad, d.grp_off = grp
+    if rowsum_out is not None:
+        _req(rowsum_out, torch.float32, "rowsum_out")
+        d.rowsum_out = _p(rowsum_out)
+    return d
+
+
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
+         rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
+         grp=(0, 0, 0), debug_flags=0, rowsum_out=None):
+    """`rowsum_out` (fp32 [M], weight-gradient form): also returns sum_k A[k][m], the bias gradient (with or without split-K)."""
+    d = _gemm_desc(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, beta, bias, coladd, rowtab, rowidx, rowtab_ld, act, U,
+                   aux, resid, ldr, drop, grp, debug_flags, rowsum_out)
     if d.out_f32 and a_kmajor and b_kmajor and bias is None and resid is None and act == 0:
         sp = lib().mmf_gemm_splitk_splits(M, N, K)
         if sp > 1:
             ws = torch.empty(sp * M * (N + 1), dtype=torch.float32, device=C_out.device)
             d.splitk_ws, d.splitk_ws_bytes = _p(ws), ws.numel() * 4
-    if rowsum_out is not None:
-        _req(rowsum_out, torch.float32, "rowsum_out")
-        d.rowsum_out = _p(rowsum_out)
     _check(lib().mmf_gemm_bf16(C.byref(d), _stream()), "mmf_gemm_bf16")
 
 
+GEMM_GROUP_MAX = 8
+
+
+def gemm_grouped(problems):
+    """Several GEMMs of one operand layout in ONE launch (mmf_gemm_bf16_grouped): `problems` is a list of dicts holding the
+    arguments of `gemm` (positional ones under their names A, B, C_out, M, N, K, lda, ldb, ldc).  No split-K; every problem
+    keeps its own epilogue and `rowsum_out`."""
+    n = len(problems)
+    if not 1 <= n <= GEMM_GROUP_MAX:
+        raise NativeLibraryError("gemm_grouped takes 1..%d problems, got %d" % (GEMM_GROUP_MAX, n))
+    arr = (GemmDesc * n)()
+    for i, kw in enumerate(problems):
+        _gemm_desc(d=arr[i], **kw)
+    _check(lib().mmf_gemm_bf16_grouped(arr, n, _stream()), "mmf_gemm_bf16_grouped")
+
+
+def gemm_set_probe(buf):
+    """Development aid: `buf` = zeroed int64 device tensor of 8 * (1 + capacity) words (or None to switch the probe off);
+    while set, every GEMM workgroup appends a timeline record (see gemm.hip Probe)."""
+    if buf is None:
+        _check(lib().mmf_gemm_set_probe(None, C.c_int64(0)), "mmf_gemm_set_probe")
+    else:
+        _req(buf, torch.int64, "probe buffer")
+        _check(lib().mmf_gemm_set_probe(_p(buf), C.c_int64(buf.numel() // 8 - 1)), "mmf_gemm_set_probe")
+
+
 def gemm_rowsum_supported(M, N, K):
-    """True when a weight-gradient GEMM of this shape runs split-K, i.e. can carry the bias gradient (`rowsum_out`)."""
-    return lib().mmf_gemm_splitk_splits(M, N, K) > 1
+    """True when a weight-gradient GEMM of this shape can carry the bias gradient (`rowsum_out`): always, since the row sums
+    are written directly when the launch does not split K."""
+    return True
 
 
 # --------------------------------------------------------------------------------------------

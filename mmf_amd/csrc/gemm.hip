@@ -31,16 +31,23 @@ using namespace gemm;
 
 namespace {
 
-// ---- the kernel ---------------------------------------------------------------------------------
-template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_, int KS = 1, bool RS = false>
-__global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
-                                                             int M, int N, int K, int lda, int ldb,
-                                                             int tiles_m, int tiles_n, int splits, int dbg, EpiArgs epi) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// ---- timeline probe (development aid; off unless mmf_gemm_set_probe was called) ---------------------------------
+// One record of 8 u64 per workgroup: {launch id << 32 | block id, HW_ID | XCC_ID << 32, t_entry, t_first_stage_landed, t_kloop_done,
+// t_staged, t_stores_done, tile}.  Slot 0 of the buffer is the allocation counter.  Timestamps are s_memrealtime ticks (10 ns).
+struct Probe { unsigned long long* buf; unsigned cap; unsigned launch; };
+DEVI unsigned long long probe_now() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, one counter for the whole device
+
+// ---- one output tile --------------------------------------------------------------------------------
+template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_, int KS, bool RS>
+DEVI void gemm_tile(const AT* __restrict__ A, const BT* __restrict__ B, int M, int N, int K, int lda, int ldb,
+                    int tile_m, int tile_n, int split, int splits, int dbg, const EpiArgs& epi, unsigned char* smem, const Probe& pr) {
     constexpr bool A_DMA = is_bf16<AT>::value, B_DMA = is_bf16<BT>::value;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    unsigned long long pt[5] = {0, 0, 0, 0, 0};
+    const bool probing = pr.buf != nullptr;
+    if (probing) pt[0] = probe_now();
     // Wave grid over the 128 x BN_ tile.  BN_ = 128: 2 x NWN waves of 64 x (128/NWN).  BN_ = 96 (8 waves only): 4 x 2 waves of 32 x 48,
     // used where 128-wide tiles would leave a third of the CUs idle in the last round (N = 768 / 2304 at M = 7296).
     // KS = 2 (8 waves): 2 x 2 waves of 64 x (BN_/2), times two K-halves — each wave multiplies ONE of the two 32-deep
@@ -51,28 +58,6 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
     constexpr int WTM = 128 / WGM, WTN = BN_ / WGN, NFM = WTM / 16, NFN = WTN / 16;
     const int wk = (KS == 2) ? wave / (WGM * WGN) : 0;
     const int wm = (wave % (WGM * WGN)) / WGN, wn = wave % WGN;
-
-    // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of the
-    // (m-major, n-fastest) tile list so the A row panel and the weight panel stay in its L2.
-    const int ntile = tiles_m * tiles_n;
-    const int nblk = ntile * splits;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int split = bid / ntile;
-    bid -= split * ntile;
-    // 8-row super-rows, column-major inside: the ~64 tiles resident on one XCD share 8 A row-panels and a few B
-    // panels that fit its 4 MiB L2 (the weight panel is then re-read once per super-row, not once per row).
-    int tile_m, tile_n;
-    {
-        const int per_sr = 8 * tiles_n;
-        const int sr = bid / per_sr, rem = bid - sr * per_sr;
-        const int h = min(8, tiles_m - sr * 8);
-        tile_n = rem / h;
-        tile_m = sr * 8 + (rem - tile_n * h);
-    }
     const int m0 = tile_m * BM, n0 = tile_n * BN_;
 
     f32x4 acc[NFM][NFN];
@@ -106,6 +91,7 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
     else { stage_load<BT, B_KMAJOR, RAGGED, NTH>(sb, B, ldb, n0, kt0 * BK, N, K, tid); stage_store<BT, B_KMAJOR, NTH>(sb, smem + OPER_BYTES, tid); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (probing) pt[1] = probe_now();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -149,6 +135,7 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
         if (!(dbg & 4)) __syncthreads();
     }
 
+    if (probing) pt[2] = probe_now();
     if (dbg & 8) {   // debugging: keep the accumulators alive but skip the epilogue
 #pragma unroll
         for (int i = 0; i < NFM; ++i)
@@ -195,13 +182,92 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __r
         }
         __syncthreads();
     }
+    if (probing) pt[3] = probe_now();
     constexpr int SEG = BN_ / 8;
     for (int idx = tid; idx < BM * SEG; idx += NTH) {
         const int row = idx / SEG, seg = idx - row * SEG;
         epilogue8(epi, m0 + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), split);
     }
-    if (RS && epi.rowsum_col >= 0 && tile_n == 0 && tid < BM && m0 + tid < M)
-        reinterpret_cast<float*>(epi.C)[(size_t)splits * epi.slab_stride + (size_t)split * M + m0 + tid] = rs[tid];
+    if (RS && epi.rowsum_col >= 0 && tile_n == 0 && tid < BM && m0 + tid < M) {
+        if (epi.rowsum_direct) epi.rowsum_direct[m0 + tid] = rs[tid];     // no split-K: this tile saw the whole reduction
+        else reinterpret_cast<float*>(epi.C)[(size_t)splits * epi.slab_stride + (size_t)split * M + m0 + tid] = rs[tid];
+    }
+    if (probing) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the record's last stamp includes the drain of this wave's stores
+        pt[4] = probe_now();
+        if (tid == 0) {
+            const unsigned slot = atomicAdd(reinterpret_cast<unsigned*>(pr.buf), 1u);
+            if (slot < pr.cap) {
+                unsigned long long* r = pr.buf + 8 * (size_t)(slot + 1);
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                r[0] = ((unsigned long long)pr.launch << 32) | blockIdx.x;
+                r[1] = ((unsigned long long)xcc << 32) | hw;
+                r[2] = pt[0]; r[3] = pt[1]; r[4] = pt[2]; r[5] = pt[3]; r[6] = pt[4];
+                r[7] = ((unsigned long long)(unsigned)tile_m << 32) | (unsigned)tile_n | ((unsigned long long)(unsigned)split << 56);
+            }
+        }
+    }
+}
+
+// XCD-aware tile order shared by both entry points: block b runs on XCD b % 8; every XCD gets a contiguous run of the tile list.
+DEVI int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+// 8-row super-rows, column-major inside: the ~64 tiles resident on one XCD share 8 A row-panels and a few B
+// panels that fit its 4 MiB L2 (the weight panel is then re-read once per super-row, not once per row).
+DEVI void super_row_tile(int bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    const int per_sr = 8 * tiles_n;
+    const int sr = bid / per_sr, rem = bid - sr * per_sr;
+    const int h = min(8, tiles_m - sr * 8);
+    tile_n = rem / h;
+    tile_m = sr * 8 + (rem - tile_n * h);
+}
+
+template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_, int KS = 1, bool RS = false>
+__global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_kernel(const AT* __restrict__ A, const BT* __restrict__ B,
+                                                             int M, int N, int K, int lda, int ldb,
+                                                             int tiles_m, int tiles_n, int splits, int dbg, EpiArgs epi, Probe pr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ntile = tiles_m * tiles_n;
+    int bid = xcd_remap(blockIdx.x, ntile * splits);
+    const int split = bid / ntile;
+    bid -= split * ntile;
+    int tile_m, tile_n;
+    super_row_tile(bid, tiles_m, tiles_n, tile_m, tile_n);
+    gemm_tile<AT, BT, A_KMAJOR, B_KMAJOR, RAGGED, NWN, BN_, KS, RS>(A, B, M, N, K, lda, ldb, tile_m, tile_n, split, splits, dbg, epi, smem, pr);
+}
+
+// ---- grouped launch: several independent problems of one operand layout in ONE grid --------------------------------------
+// The tile lists of the problems are concatenated (each in its own super-row order) and the XCD remap runs over the whole
+// list.  Used for the weight gradients of a transformer layer (four GEMMs with 36 - 144 output tiles each and a 7296-long
+// reduction): together they fill the 512 workgroup slots of the chip in one round WITHOUT split-K, so the fp32 slabs, their
+// reduction kernels and three launch boundaries per layer disappear.
+constexpr int MAXG = 8;
+struct GroupProblem {
+    const void* A; const void* B;
+    int M, N, K, lda, ldb, tiles_m, tiles_n;
+    EpiArgs epi;
+};
+struct GroupArgs {
+    int count, total;
+    int start[MAXG + 1];
+    GroupProblem p[MAXG];
+};
+
+template <typename AT, typename BT, bool A_KMAJOR, bool B_KMAJOR, bool RAGGED, int NWN, int BN_, int KS = 1, bool RS = false>
+__global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_grouped_kernel(GroupArgs g, Probe pr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int bid = xcd_remap(blockIdx.x, g.total);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXG; ++i) gi += (i < g.count && bid >= g.start[i]) ? 1 : 0;
+    const GroupProblem& P = g.p[gi];
+    bid -= g.start[gi];
+    int tile_m, tile_n;
+    super_row_tile(bid, P.tiles_m, P.tiles_n, tile_m, tile_n);
+    gemm_tile<AT, BT, A_KMAJOR, B_KMAJOR, RAGGED, NWN, BN_, KS, RS>(reinterpret_cast<const AT*>(P.A), reinterpret_cast<const BT*>(P.B), P.M, P.N, P.K,
+                                                                  P.lda, P.ldb, tile_m, tile_n, 0, 1, 0, P.epi, smem, pr);
 }
 
 // C[m][n] = beta * C[m][n] + sum_s slab[s][m][n]   (N % 4 == 0).  Behind the `splits` slabs the workspace holds
@@ -228,6 +294,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// timeline probe state (host): set by mmf_gemm_set_probe, consumed by every GEMM launch while set
+static Probe g_probe = {nullptr, 0u, 0u};
+static Probe next_probe() {
+    Probe p = g_probe;
+    if (p.buf) g_probe.launch++;
+    return p;
+}
+
 template <typename AT, typename BT, bool AK, bool BK_, bool RG, int NWN, int BN_, int KS = 1, bool RS = false>
 int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN_ - 1) / BN_;
@@ -244,208 +318,27 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS, RS>), dim3(tm * tn * splits), dim3(128 * NWN), lds_bytes, s,
                        reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
-                       d->lda, d->ldb, tm, tn, splits, (d->debug_flags >> 4) & 15, e2);
+                       d->lda, d->ldb, tm, tn, splits, (d->debug_flags >> 4) & 15, e2, next_probe());
     MMF_CHECK_LAUNCH();
     return 0;
 }
 
-
-// ---- 256 x 128 tile, three-stage LDS-DMA ring (EXPERIMENTAL, debug_flags bit 14; not used by default) -----------------
-// Status: correct (tests/test_gemm256_gpu.py, incl. a 30-launch race screen) and 20-40 % SLOWER than the 128-row kernel on every
-// forward / dgrad shape of the VisualBERT layer (572 us per layer, 549 with all fragment reads of a step issued first - bit 15 -
-// against 477; tools/micro_sweep.py tile256, profiles/r01_gemm256_experiment.txt): with one
-// workgroup of 8 waves per CU (2 waves per SIMD) the compiler-scheduled read-wait-MFMA sequence of a step leaves the MFMA pipe
-// idle while fragments are in flight, and the deeper ring does not buy that back.  Kept as the tested skeleton (ring, counted
-// waits, masked ragged-M epilogue) for the phase-interleaved schedule of cdna_hip_programming.md section 5.
-// One workgroup per CU (144 KiB of LDS), 8 waves as 4 x 2 wave tiles of 64 x 64 (8 fragment reads per 16 MFMAs), K-step 64.
-// Per step a CU stages 48 KiB for 4.2 MFLOP (85 FLOP per staged byte against 64 for two 128 x 128 workgroups), and the ring
-// keeps TWO stages in flight: iteration kt waits with a counted `s_waitcnt vmcnt(6)` (the six LDS-DMA instructions of stage
-// kt + 1 may still be outstanding), crosses one raw `s_barrier`, issues stage kt + 2 into the buffer everybody finished
-// reading in iteration kt - 1, and multiplies stage kt.  A is a row operand (two 128-row images per stage), B a row or a
-// k-major operand (the same LDS images and fragment reads as the 128 x 128 kernel); M may be ragged (row clamp + masked
-// epilogue), N % 128 == 0 and K % 64 == 0.  The fp32 tile is staged through the idle ring for the row-wise epilogue.
-constexpr int BM2 = 256, NSTAGE2 = 3, STAGE2_BYTES = 3 * OPER_BYTES;
-
-template <bool B_KMAJOR, bool RAGGED, int SCHED>
-__global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
-                                                          int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntile = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {   // XCD-aware order, as in gemm_bf16_kernel
-        const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    int tile_m, tile_n;
-    {
-        const int per_sr = 4 * tiles_n;          // 4-row super-rows (1024 rows of A), column-major inside
-        const int sr = bid / per_sr, rem = bid - sr * per_sr;
-        const int h = min(4, tiles_m - sr * 4);
-        tile_n = rem / h;
-        tile_m = sr * 4 + (rem - tile_n * h);
-    }
-    const int m0 = tile_m * BM2, n0 = tile_n * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BK;
-    auto issue = [&](int kt, int buf) {
-        unsigned char* st = smem + buf * STAGE2_BYTES;
-        stage_dma<false, RAGGED, 512>(A, lda, m0, kt * BK, M, K, st, tid);
-        stage_dma<false, RAGGED, 512>(A, lda, m0 + 128, kt * BK, M, K, st + OPER_BYTES, tid);
-        stage_dma<B_KMAJOR, false, 512>(B, ldb, n0, kt * BK, N, K, st + 2 * OPER_BYTES, tid);
-    };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int buf = 0;
-    if constexpr (SCHED == 2) {
-        // Ping-pong schedule (bit 16; UNTESTED ON HARDWARE as of round 1 - written against the ISA, to be race-screened with
-        // tests/test_gemm256_gpu.py before any use).  The 8 waves form two groups of four, one wave of each group per SIMD; the
-        // second group runs ONE barrier interval behind the first, so on every SIMD one wave issues its 16 MFMAs (COMP) while
-        // the other fetches its next 8 fragments and issues its share of the LDS-DMA for the stage two K-tiles ahead (LOAD).
-        // A K-tile is LOAD0 | COMP0 | LOAD1 | COMP1 with a raw s_barrier after each; global barrier numbering below counts from
-        // the first barrier after the prologue, interval I(n) lies between barriers n and n + 1:
-        //   group 0:  LOAD0[t] in I(4t), COMP0[t] in I(4t+1), LOAD1[t] in I(4t+2), COMP1[t] in I(4t+3)
-        //   group 1:  the same, one interval later.
-        // RAW (stage t+1 is first read in I(4t+4)): every wave retires its own stage-(t+1) pieces with the counted vmcnt at the
-        //   end of LOAD1[t] (I(4t+2) / I(4t+3)), i.e. before barrier 4t+4.
-        // WAR (stage t+2 overwrites the buffer of stage t-1, whose last reads are group 1's LOAD1[t-1] in I(4t-1)): every LOAD
-        //   ends with lgkmcnt(0) before its barrier, and the earliest re-staging is group 0's LOAD0[t] in I(4t), after barrier 4t.
-        const int grp = wave >> 2;
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const unsigned char* la = smem + buf * STAGE2_BYTES + (wm >> 1) * OPER_BYTES;
-            const unsigned char* lb = smem + buf * STAGE2_BYTES + 2 * OPER_BYTES;
-            unsigned char* nst = smem + (buf >= 1 ? buf - 1 : 2) * STAGE2_BYTES;
-            const bool more = kt + 2 < nk;
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                // ---- LOAD kk
-#pragma unroll
-                for (int f = 0; f < 4; ++f) fa[f] = read_frag<false>(la, (wm & 1) * 64, f, kk, lane);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) fb[f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
-                if (more) {
-                    if (kk == 0) {
-                        stage_dma<false, RAGGED, 512, 0, 2>(A, lda, m0, (kt + 2) * BK, M, K, nst, tid);
-                        stage_dma<false, RAGGED, 512, 0, 1>(A, lda, m0 + 128, (kt + 2) * BK, M, K, nst + OPER_BYTES, tid);
-                    } else {
-                        stage_dma<false, RAGGED, 512, 1, 2>(A, lda, m0 + 128, (kt + 2) * BK, M, K, nst + OPER_BYTES, tid);
-                        stage_dma<B_KMAJOR, false, 512, 0, 2>(B, ldb, n0, (kt + 2) * BK, N, K, nst + 2 * OPER_BYTES, tid);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (kk == 1) {
-                    if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- COMP kk
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-        if (grp == 0) __builtin_amdgcn_s_barrier();
-    } else
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) issue(kt + 2, buf >= 1 ? buf - 1 : 2);      // (kt + 2) % 3 == (buf + 2) % 3
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* la = smem + buf * STAGE2_BYTES + (wm >> 1) * OPER_BYTES;
-        const unsigned char* lb = smem + buf * STAGE2_BYTES + 2 * OPER_BYTES;
-        if constexpr (SCHED == 1) {     // bit 15: all 16 fragment reads of the step first, so the second half's land behind the first half's MFMAs
-            bf16x8 fa[2][4], fb[2][4];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int f = 0; f < 4; ++f) fa[kk][f] = read_frag<false>(la, (wm & 1) * 64, f, kk, lane);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) fb[kk][f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);     // without it the scheduler sinks the reads back between the MFMAs
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) fa[f] = read_frag<false>(la, (wm & 1) * 64, f, kk, lane);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) fb[f] = read_frag<B_KMAJOR>(lb, wn * 64, f, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    __syncthreads();       // every wave is done with the ring: it becomes the fp32 C stage
-    constexpr int CLD = BN + 4;
-    float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = wm * 64 + i * 16 + (lane & 15), col = wn * 64 + j * 16 + (lane >> 4) * 4;
-            *reinterpret_cast<float4*>(cs + row * CLD + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        }
-    __syncthreads();
-    constexpr int SEG = BN / 8;
-    for (int idx = tid; idx < BM2 * SEG; idx += 512) {
-        const int row = idx / SEG, seg = idx - row * SEG;
-        epilogue8(epi, m0 + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), 0);
-    }
-}
-
-template <bool BK_, bool RG, int SCHED>
-int launch256(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
-    const int tm = (d->M + BM2 - 1) / BM2, tn = d->N / BN;
-    constexpr int cstage = BM2 * (BN + 4) * (int)sizeof(float);
-    constexpr int lds_bytes = cstage > NSTAGE2 * STAGE2_BYTES ? cstage : NSTAGE2 * STAGE2_BYTES;
+template <typename AT, typename BT, bool AK, bool BK_, bool RG, int NWN, int BN_, int KS = 1, bool RS = false>
+int launch_grouped_n(const GroupArgs& g, hipStream_t s) {
+    constexpr int cstage = BM * (BN_ + 4) * (int)sizeof(float) + BM * (int)sizeof(float);
+    constexpr int lds_bytes = cstage > 4 * OPER_BYTES ? cstage : 4 * OPER_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<BK_, RG, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_grouped_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS, RS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<BK_, RG, SCHED>), dim3(tm * tn), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
-                       reinterpret_cast<const bf16*>(d->B), d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e);
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS, RS>), dim3(g.total), dim3(128 * NWN), lds_bytes, s, g, next_probe());
     MMF_CHECK_LAUNCH();
     return 0;
 }
+
 
 template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
@@ -453,15 +346,6 @@ int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     // bit 8 of debug_flags selects the 4-wave form for A/B measurements.
     if (AK && BK_ && is_bf16<AT>::value && is_bf16<BT>::value && e.rowsum_col >= 0)   // weight gradient carrying the bias gradient
         return launch_n<AT, BT, AK, BK_, RG, 4, 128, 1, AK && BK_>(d, e, s);
-    // 256 x 128 tiles with the three-stage ring (experimental: debug_flags bit 14 selects it)
-    if constexpr (!AK && is_bf16<AT>::value && is_bf16<BT>::value) {
-        if ((d->debug_flags & 16384) && e.splits <= 1 && (d->N % BN) == 0 && (d->K % BK) == 0 && d->M >= BM2)
-        {
-            const int sched = (d->debug_flags & 65536) ? 2 : ((d->debug_flags & 32768) ? 1 : 0);   // bit 16 ping-pong, bit 15 reads-first
-            if (d->M % BM2) return sched == 2 ? launch256<BK_, true, 2>(d, e, s) : sched == 1 ? launch256<BK_, true, 1>(d, e, s) : launch256<BK_, true, 0>(d, e, s);
-            return sched == 2 ? launch256<BK_, false, 2>(d, e, s) : sched == 1 ? launch256<BK_, false, 1>(d, e, s) : launch256<BK_, false, 0>(d, e, s);
-        }
-    }
     if (d->debug_flags & 256) return launch_n<AT, BT, AK, BK_, RG, 2, 128>(d, e, s);
     // Wave layout: 2x4 waves of 64x32 over both K-halves of a stage (KS = 1), or 2x2 waves of 64x64 times the two
     // K-halves (KS = 2: a third fewer LDS operand reads, one extra pass over the LDS C stage at the end).  Measured
@@ -482,7 +366,7 @@ int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
+static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     MMF_CHECK_ARG(d && d->A && d->B && d->C, "mmf_gemm_bf16: null operand");
     MMF_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "mmf_gemm_bf16: empty shape");
     MMF_CHECK_ARG((d->lda % 8) == 0 && (d->ldb % 8) == 0, "mmf_gemm_bf16: lda/ldb must be multiples of 8 elements");
@@ -492,8 +376,9 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     MMF_CHECK_ARG(d->a_kmajor || d->lda >= k8, "mmf_gemm_bf16: lda must cover round_up(K, 8) for a row operand");
     MMF_CHECK_ARG(d->b_kmajor || d->ldb >= k8, "mmf_gemm_bf16: ldb must cover round_up(K, 8) for a row operand");
     MMF_CHECK_ARG(!(d->a_f32 && d->b_f32), "mmf_gemm_bf16: at most one fp32 operand");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    EpiArgs e;
+    MMF_CHECK_ARG((d->act != 2 && d->act != 4) || d->aux, "mmf_gemm_bf16: act=2/4 needs aux");
+    MMF_CHECK_ARG(d->act >= 0 && d->act <= 4, "mmf_gemm_bf16: unknown act");
+    MMF_CHECK_ARG(!d->rowtab || d->rowidx, "mmf_gemm_bf16: rowtab needs rowidx");
     e.C = d->C; e.ldc = d->ldc; e.out_f32 = d->out_f32; e.beta = d->beta;
     e.bias = d->bias; e.coladd = d->coladd; e.rowtab = d->rowtab; e.rowidx = d->rowidx; e.rowtab_ld = d->rowtab_ld;
     e.act = d->act; e.U = reinterpret_cast<bf16*>(d->U); e.aux = reinterpret_cast<const bf16*>(d->aux);
@@ -501,10 +386,17 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     e.drop.key = d->drop_key; e.drop.thr16 = d->drop_thr16; e.drop.scale = d->drop_scale; e.drop.seed = d->drop_seed;
     e.grp_in = d->grp_in; e.grp_pad = d->grp_pad; e.grp_off = d->grp_off;
     e.M = d->M; e.N = d->N;
+    e.slab_stride = 0; e.splits = 1; e.rowsum_col = -1; e.rowsum_direct = nullptr;
+    return 0;
+}
+
+extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
+    EpiArgs e;
+    if (int rc = check_and_fill(d, e)) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // Split-K: a weight-gradient GEMM has few output tiles (768x768 -> 36) and a long reduction (K = tokens).
     // With a workspace, the K range is spread over `splits` workgroups per tile; each writes an fp32 partial slab
     // and a second kernel sums the slabs in a fixed order (deterministic, no atomics).
-    e.slab_stride = 0; e.splits = 1; e.rowsum_col = -1;
     float* final_c = nullptr; int final_ldc = 0; float final_beta = 0.f;
     {
         const int sp = mmf_gemm_splitk_splits(d->M, d->N, d->K);
@@ -518,13 +410,11 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
         }
     }
     if (d->rowsum_out) {
-        MMF_CHECK_ARG(d->a_kmajor && d->b_kmajor && !d->a_f32 && !d->b_f32 && final_c,
-                      "mmf_gemm_bf16: rowsum_out needs the weight-gradient form (both operands k-major, bf16 A) with split-K active");
-        e.rowsum_col = 1;   // on; the partials live behind the slabs: ws[splits * M * N + split * M + m]
+        MMF_CHECK_ARG(d->a_kmajor && d->b_kmajor && !d->a_f32 && !d->b_f32,
+                      "mmf_gemm_bf16: rowsum_out needs the weight-gradient form (both operands k-major, bf16)");
+        e.rowsum_col = 1;   // on; with split-K the partials live behind the slabs: ws[splits * M * N + split * M + m]
+        if (!final_c) e.rowsum_direct = d->rowsum_out;   // one workgroup per tile sees the whole reduction: written directly
     }
-    MMF_CHECK_ARG((d->act != 2 && d->act != 4) || d->aux, "mmf_gemm_bf16: act=2/4 needs aux");
-    MMF_CHECK_ARG(d->act >= 0 && d->act <= 4, "mmf_gemm_bf16: unknown act");
-    MMF_CHECK_ARG(!d->rowtab || d->rowidx, "mmf_gemm_bf16: rowtab needs rowidx");
 
     // ragged unless every tile is full and every chunk in range
     const bool ragged = (d->M % BM) || (d->N % BN) || (d->K % BK);
@@ -566,4 +456,53 @@ extern "C" int mmf_gemm_splitk_splits(int M, int N, int K) {
         if (c < bc - 1e-9) { bc = c; best = sp; }
     }
     return best;
+}
+
+// Several GEMMs of ONE operand layout in one grid (see gemm_bf16_grouped_kernel).  Every problem runs without split-K and with its
+// own epilogue; `rowsum_out` is honoured (written directly).  debug_flags, splitk_ws are ignored.
+extern "C" int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream) {
+    MMF_CHECK_ARG(descs && count >= 1 && count <= MAXG, "mmf_gemm_bf16_grouped: 1 .. 8 problems");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GroupArgs g;
+    g.count = count;
+    int total = 0;
+    bool ragged = false, rowsum = false;
+    const int key = (descs[0].a_kmajor ? 1 : 0) | (descs[0].b_kmajor ? 2 : 0) | (descs[0].a_f32 ? 4 : 0) | (descs[0].b_f32 ? 8 : 0);
+    for (int i = 0; i < count; ++i) {
+        const mmf_gemm_desc* d = descs + i;
+        GroupProblem& P = g.p[i];
+        if (int rc = check_and_fill(d, P.epi)) return rc;
+        const int k = (d->a_kmajor ? 1 : 0) | (d->b_kmajor ? 2 : 0) | (d->a_f32 ? 4 : 0) | (d->b_f32 ? 8 : 0);
+        MMF_CHECK_ARG(k == key, "mmf_gemm_bf16_grouped: all problems must share the operand layout and dtypes");
+        if (d->rowsum_out) {
+            MMF_CHECK_ARG(key == 3, "mmf_gemm_bf16_grouped: rowsum_out needs the weight-gradient form (both operands k-major, bf16)");
+            P.epi.rowsum_col = 1; P.epi.rowsum_direct = d->rowsum_out; rowsum = true;
+        }
+        P.A = d->A; P.B = d->B; P.M = d->M; P.N = d->N; P.K = d->K; P.lda = d->lda; P.ldb = d->ldb;
+        P.tiles_m = (d->M + BM - 1) / BM; P.tiles_n = (d->N + BN - 1) / BN;
+        g.start[i] = total;
+        total += P.tiles_m * P.tiles_n;
+        ragged = ragged || (d->M % BM) || (d->N % BN) || (d->K % BK);
+    }
+    for (int i = count; i <= MAXG; ++i) g.start[i] = total;
+    g.total = total;
+    switch (key) {
+        case 0: return ragged ? launch_grouped_n<bf16, bf16, false, false, true, 4, 128>(g, s) : launch_grouped_n<bf16, bf16, false, false, false, 4, 128>(g, s);
+        case 2: return ragged ? launch_grouped_n<bf16, bf16, false, true, true, 4, 128>(g, s) : launch_grouped_n<bf16, bf16, false, true, false, 4, 128>(g, s);
+        case 3:
+            if (rowsum) return ragged ? launch_grouped_n<bf16, bf16, true, true, true, 4, 128, 1, true>(g, s) : launch_grouped_n<bf16, bf16, true, true, false, 4, 128, 1, true>(g, s);
+            return ragged ? launch_grouped_n<bf16, bf16, true, true, true, 4, 128, 2>(g, s) : launch_grouped_n<bf16, bf16, true, true, false, 4, 128, 2>(g, s);
+        default:
+            mmf_amd_set_error("mmf_gemm_bf16_grouped: unsupported operand layout combination");
+            return 1;
+    }
+}
+
+// Development aid: while a probe buffer is set, every workgroup of every GEMM launch appends one 64-byte timeline record (see Probe).
+// buf: device memory, (1 + capacity) * 64 bytes, zeroed by the caller; NULL switches the probe off.
+extern "C" int mmf_gemm_set_probe(void* buf, int64_t capacity_records) {
+    g_probe.buf = reinterpret_cast<unsigned long long*>(buf);
+    g_probe.cap = (unsigned)(capacity_records > 0 ? capacity_records : 0);
+    g_probe.launch = 0;
+    return 0;
 }

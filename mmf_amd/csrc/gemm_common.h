@@ -31,6 +31,7 @@ struct EpiArgs {
     long slab_stride;   // split-K: split s writes its partial tile to C + s * slab_stride (fp32 slabs)
     int splits;
     int rowsum_col;     // >= 0: also write per-row sums of A (bias-gradient partials) behind the split-K slabs; -1: off
+    float* rowsum_direct;  // no split-K: the row sums go straight here ([M] fp32) instead of behind the slabs
 };
 
 DEVI int rot_kmajor(int krow) { return 32 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }

@@ -13,6 +13,7 @@ Reference ops replaced (paths relative to the reference root):
   DenseDropoutResidualLNFn  HF BertSelfOutput / BertOutput                 (call sites hf_layers.py:248,290)
   DenseGeluFn               HF BertIntermediate                            (call site hf_layers.py:289)
   FeedForwardFn             BertIntermediate + BertOutput fused            (hf_layers.py:289-290)
+  TransformerLayerFn        BertLayerJit.forward, one autograd node        (hf_layers.py:255-292)
   LayerNormFn               nn.LayerNorm                                   (visual_bert.py:328)
   VisioLinguisticEmbeddingsFn  BertVisioLinguisticEmbeddings.forward       (embeddings.py:423-459)
   GatherRowsFn              torch.gather + Dropout of the `vqa` pooler     (visual_bert.py:389-400)
@@ -518,6 +519,80 @@ class FeedForwardFn(torch.autograd.Function):
         du, dw2 = _linear_bwd(dlin, H, hh, w2_16, M, H, I, act_aux=u)        # du = (dlin W2) * gelu'(u), gelu' saved by the forward
         dx, dw1, db1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres, want_db=True)     # dx = du W1 + dres
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
+
+
+def _dgrad(dy, ldy, w16, M, N, K, dx_resid=None, act_aux=None):
+    """dX [M, K] = dY [M, N] W [N, K] (W k-major: no transposed copy), residual-gradient add / saved-GELU' multiply fused."""
+    dx = torch.empty(M, K, dtype=BF16, device=dy.device)
+    nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
+    return dx
+
+
+def _wgrad_problem(dy, ldy, x, M, N, K, want_db):
+    """Deferred weight gradient dW [N, K] = dY^T X (+ bias gradient = column sums of dY) as a `nat.gemm_grouped` problem."""
+    dw = torch.empty(N, K, dtype=F32, device=dy.device)
+    db = torch.empty(N, dtype=F32, device=dy.device) if want_db else None
+    prob = dict(A=dy, B=x, C_out=dw, M=N, N=K, K=M, lda=ldy, ldb=x.stride(0), ldc=K, a_kmajor=True, b_kmajor=True, rowsum_out=db)
+    return prob, dw, db
+
+
+class TransformerLayerFn(torch.autograd.Function):
+    """BertLayerJit.forward (hf_layers.py:255-292) as ONE autograd node: the attention sub-layer (AttentionBlockFn) followed by
+    the feed-forward sub-layer (FeedForwardFn), same kernels and same saved tensors.  What the fusion buys is in backward:
+    the four weight gradients of the layer (dW_qkv, dW_o, dW_1, dW_2, with the two bias gradients that are column sums of
+    GEMM operands) leave the dgrad chain and run at its end as ONE grouped launch (`nat.gemm_grouped`): 432 output tiles at
+    the VisualBERT VQA2 shape = one round of the chip's 512 workgroup slots, each tile reducing over all 7296 tokens itself —
+    no split-K slabs, no slab-reduction kernels."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2,
+                wqkv16, bqkv, wo16, w1_16, w2_16, mask_add, heads, eps1, eps2, drop_attn, drop_hid1, drop_hid2):
+        B, S, H = x.shape
+        x2 = _as_bf16_2d(x)
+        M = B * S
+        I = w1_16.shape[0]
+        dev = x2.device
+        mask_add, tail = _split_mask(mask_add)
+        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail)
+        a_out, y1, mean1, rstd1 = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), g1.detach(), be1.detach(), eps1, drop_hid1)
+        u = torch.empty(M, I, dtype=BF16, device=dev)
+        hh = torch.empty(M, I, dtype=BF16, device=dev)
+        nat.gemm(a_out, w1_16, hh, M, I, H, H, H, I, bias=b1.detach(), act=1, U=u)
+        out, y2, mean2, rstd2 = _ddrln_fwd(hh, a_out, w2_16, b2.detach(), g2.detach(), be2.detach(), eps2, drop_hid2)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean1, rstd1, a_out, u, hh, y2, mean2, rstd2, wqkv16, wo16, w1_16, w2_16,
+                              g1.detach(), g2.detach(), mask_add, o32)
+        ctx.meta = (B, S, H, I, heads, drop_attn, drop_hid1, drop_hid2, tail)
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2, qkv, ctxt, lse, y1, mean1, rstd1, a_out, u, hh, y2, mean2, rstd2, wqkv16, wo16, w1_16, w2_16, g1, g2, mask_add,
+         o32) = ctx.saved_tensors
+        B, S, H, I, heads, drop_attn, drop_hid1, drop_hid2, tail = ctx.meta
+        M = B * S
+        dev = x2.device
+        # feed-forward sub-layer
+        dres2, dlin2, dg2, dbe2, db2 = _ln_bwd(_grad_bf16(g, H), y2, mean2, rstd2, g2, drop_hid2, True)
+        du = _dgrad(dlin2, H, w2_16, M, H, I, act_aux=u)                  # (dlin2 W2) * gelu'(u)
+        da = _dgrad(du, I, w1_16, M, I, H, dx_resid=dres2)                # du W1 + dres2  = gradient of the attention block's output
+        # attention sub-layer
+        dres1, dlin1, dg1, dbe1, dbo = _ln_bwd(da, y1, mean1, rstd1, g1, drop_hid1, True)
+        dctx = _dgrad(dlin1, H, wo16, M, H, H)
+        dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
+        delta = torch.empty(B, heads, S, dtype=F32, device=dev)
+        scale = 1.0 / math.sqrt(H // heads)
+        nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
+                          dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
+        dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1) if ctx.needs_input_grad[0] else None
+        # the four weight gradients, one launch
+        p_1, dw1, db1 = _wgrad_problem(du, I, a_out, M, I, H, True)
+        p_2, dw2, _ = _wgrad_problem(dlin2, H, hh, M, H, I, False)
+        p_q, dwqkv, dbqkv = _wgrad_problem(dqkv, 3 * H, x2, M, 3 * H, H, True)
+        p_o, dwo, _ = _wgrad_problem(dlin1, H, ctxt, M, H, H, False)
+        nat.gemm_grouped([p_1, p_2, p_q, p_o])
+        return ((dx.view(B, S, H) if dx is not None else None),
+                dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, dbe1,
+                dw1, db1, dw2, db2, dg2, dbe2) + (None,) * 13
 
 
 # ---------------------------------------------------------------------------------------------

@@ -209,7 +209,8 @@ class BertAttentionJit(nn.Module):
 
 
 class BertLayerJit(nn.Module):
-    """hf_layers.py:255-292: attention sub-layer then feed-forward sub-layer, two fused autograd nodes."""
+    """hf_layers.py:255-292: attention sub-layer then feed-forward sub-layer as ONE autograd node (Fn.TransformerLayerFn),
+    so that backward can run the layer's four weight gradients as one grouped launch."""
 
     def __init__(self, config):
         super().__init__()
@@ -219,11 +220,19 @@ class BertLayerJit(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None):
-        attention_output = self.attention(hidden_states, attention_mask, head_mask)[0]
-        it, ot = self.intermediate, self.output
-        layer_output = Fn.FeedForwardFn.apply(
-            attention_output, it.dense.weight, it.dense.bias, ot.dense.weight, ot.dense.bias, ot.LayerNorm.weight,
-            ot.LayerNorm.bias, Fn.shadows.get(it.dense.weight), Fn.shadows.get(ot.dense.weight), ot.LayerNorm.eps,
+        if head_mask is not None or encoder_hidden_states is not None:
+            raise NotImplementedError("head_mask / cross-attention are not on the VisualBERT path")
+        B, S, _ = hidden_states.shape
+        at, it, ot = self.attention, self.intermediate, self.output
+        sa, so = at.self, at.output
+        w16, b32 = sa.packed_qkv()
+        layer_output = Fn.TransformerLayerFn.apply(
+            hidden_states, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
+            so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias,
+            it.dense.weight, it.dense.bias, ot.dense.weight, ot.dense.bias, ot.LayerNorm.weight, ot.LayerNorm.bias,
+            w16, b32, Fn.shadows.get(so.dense.weight), Fn.shadows.get(it.dense.weight), Fn.shadows.get(ot.dense.weight),
+            additive_key_mask(attention_mask, B, S), sa.num_attention_heads, so.LayerNorm.eps, ot.LayerNorm.eps,
+            Fn.make_drop(sa.dropout_prob, self.training), Fn.make_drop(so.dropout_prob, self.training),
             Fn.make_drop(ot.dropout_prob, self.training))
         return (layer_output,)
 

@@ -10,7 +10,7 @@ from mmf_amd import _native as N
 
 _INT_RETURNS = {
     "layernorm_bwd_ws_floats": lambda H: 64 * 3 * H, "colsum_ws_floats": lambda n: 64 * n,
-    "gemm_rowsum_supported": lambda M, Nn, K: False,
+    "gemm_rowsum_supported": lambda M, Nn, K: True,
 }
 _KEEP = {"drop_cfg", "_drop4", "lib", "_check", "_stream", "_p", "_req"}
 calls = []
@@ -54,6 +54,18 @@ def _gemm(A, B, C_out, M, Nn, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, 
     if rowsum_out is not None:
         assert rowsum_out.numel() >= M
     calls.append(("gemm", M, Nn, K))
+
+
+def _gemm_grouped(problems):
+    assert 1 <= len(problems) <= N.GEMM_GROUP_MAX
+    key = None
+    for kw in problems:
+        kw = dict(kw)
+        k = (bool(kw.get("a_kmajor")), bool(kw.get("b_kmajor")), kw["A"].dtype, kw["B"].dtype)
+        assert key is None or key == k, "gemm_grouped: mixed operand layouts"
+        key = k
+        _gemm(kw.pop("A"), kw.pop("B"), kw.pop("C_out"), kw.pop("M"), kw.pop("N"), kw.pop("K"), kw.pop("lda"), kw.pop("ldb"),
+              kw.pop("ldc"), **kw)
 
 
 def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=N.NO_DROP, head_dim=64, ctx_f32=None,
@@ -128,7 +140,7 @@ def _bce_rowmask_bwd(scores, targets, w, count, gloss, d, rows, Nn):
     assert d.numel() == rows * Nn and gloss.numel() == 1
 
 
-_CHECKED = {"gemm": _gemm, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
+_CHECKED = {"gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,
             "bce_rowmask_fwd": _bce_rowmask_fwd, "bce_rowmask_bwd": _bce_rowmask_bwd}

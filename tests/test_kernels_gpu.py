@@ -116,10 +116,69 @@ def test_gemm_wgrad_carries_the_bias_gradient(Nout, Kin, T):
     dW2 = torch.empty_like(dW)
     nat().gemm(dY, X, dW2, Nout, Kin, T, Nout, Kin, Kin, a_kmajor=True, b_kmajor=True, debug_flags=8192)
     close(dW, dW2, 1e-6, 1e-5, "dW with / without the fused bias gradient")
-    # shapes that do not split fall back (the Python layer checks first); asking anyway is an error, not a silent skip
-    if not nat().gemm_rowsum_supported(Nout, Kin, 64):
-        with pytest.raises(Exception):
-            nat().gemm(dY[:64], X[:64], dW, Nout, Kin, 64, Nout, Kin, Kin, a_kmajor=True, b_kmajor=True, rowsum_out=db)
+    # a reduction too short to split K: the row sums are written directly by the one workgroup per tile
+    db2 = torch.full((Nout,), float("nan"), device=DEV)
+    nat().gemm(dY[:64], X[:64], dW, Nout, Kin, 64, Nout, Kin, Kin, a_kmajor=True, b_kmajor=True, rowsum_out=db2)
+    close(dW, dY[:64].float().t() @ X[:64].float(), 1e-4, 1e-3, "dW, unsplit")
+    close(db2, dY[:64].float().sum(0), 1e-5, 1e-3, "bias gradient, unsplit")
+
+
+@pytest.mark.parametrize("T", [7296, 456, 64])
+def test_gemm_grouped_layer_weight_gradients(T):
+    """The four weight gradients of a transformer layer (+ two bias gradients) as ONE grouped launch, no split-K: each against
+    fp32 torch and against its own separate launch (split-K there, so equal up to fp32 summation order)."""
+    H, I = 768, 3072
+    du = rnd(T, I, seed=1); a_out = rnd(T, H, seed=2); dlin2 = rnd(T, H, seed=3); hh = rnd(T, I, seed=4)
+    dqkv = rnd(T, 3 * H, seed=5); x = rnd(T, H, seed=6); dlin1 = rnd(T, H, seed=7); ctxt = rnd(T, H, seed=8)
+    specs = [(du, a_out, I, H, True), (dlin2, hh, H, I, False), (dqkv, x, 3 * H, H, True), (dlin1, ctxt, H, H, False)]
+    probs, outs = [], []
+    for dy, xx, N, K, want_db in specs:
+        dw = torch.full((N, K), float("nan"), device=DEV); db = torch.full((N,), float("nan"), device=DEV) if want_db else None
+        probs.append(dict(A=dy, B=xx, C_out=dw, M=N, N=K, K=T, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True, rowsum_out=db))
+        outs.append((dw, db))
+    nat().gemm_grouped(probs)
+    for (dy, xx, N, K, want_db), (dw, db) in zip(specs, outs):
+        ref = dy.float().t() @ xx.float()
+        close(dw, ref, 1e-4, 2e-3 * math.sqrt(T) / 8, "grouped dW %dx%d" % (N, K))
+        sep = torch.empty_like(dw)
+        nat().gemm(dy, xx, sep, N, K, T, N, K, K, a_kmajor=True, b_kmajor=True)
+        close(dw, sep, 1e-5, 2e-4 * math.sqrt(T) / 8, "grouped vs separate launch")
+        if want_db:
+            close(db, dy.float().sum(0), 1e-5, 1e-3 * math.sqrt(T) / 8, "grouped bias gradient")
+
+
+def test_gemm_grouped_forward_problems_keep_their_epilogues():
+    """Grouping is layout-generic: two forward GEMMs of different shapes, each with its own bias / residual, in one launch;
+    results are bit-identical to the separate launches (same tiles, same K order)."""
+    A1 = rnd(300, 768, seed=1); W1 = rnd(384, 768, seed=2, scale=0.05); b1 = rnd(384, dtype=torch.float32, seed=3)
+    A2 = rnd(1024, 256, seed=4); W2 = rnd(768, 256, seed=5, scale=0.05); b2 = rnd(768, dtype=torch.float32, seed=6); R2 = rnd(1024, 768, seed=7)
+    C1 = torch.empty(300, 384, dtype=torch.bfloat16, device=DEV); C2 = torch.empty(1024, 768, dtype=torch.bfloat16, device=DEV)
+    nat().gemm_grouped([dict(A=A1, B=W1, C_out=C1, M=300, N=384, K=768, lda=768, ldb=768, ldc=384, bias=b1),
+                        dict(A=A2, B=W2, C_out=C2, M=1024, N=768, K=256, lda=256, ldb=256, ldc=768, bias=b2, resid=R2, ldr=768)])
+    S1 = torch.empty_like(C1); S2 = torch.empty_like(C2)
+    nat().gemm(A1, W1, S1, 300, 384, 768, 768, 768, 384, bias=b1, debug_flags=512 | 8192)
+    nat().gemm(A2, W2, S2, 1024, 768, 256, 256, 256, 768, bias=b2, resid=R2, ldr=768, debug_flags=512 | 8192)
+    assert torch.equal(C1, S1) and torch.equal(C2, S2)
+    with pytest.raises(Exception):      # mixed operand layouts are refused
+        nat().gemm_grouped([dict(A=A1, B=W1, C_out=C1, M=300, N=384, K=768, lda=768, ldb=768, ldc=384),
+                            dict(A=A2, B=rnd(256, 768, seed=9), C_out=C2, M=1024, N=768, K=256, lda=256, ldb=768, ldc=768, b_kmajor=True)])
+
+
+def test_gemm_timeline_probe_records_every_workgroup():
+    M, N, K = 1024, 768, 768
+    A = rnd(M, K); B = rnd(N, K); C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    buf = torch.zeros(8 * (1 + 256), dtype=torch.int64, device=DEV)
+    nat().gemm_set_probe(buf)
+    try:
+        nat().gemm(A, B, C, M, N, K, K, K, N, debug_flags=512)
+        torch.cuda.synchronize()
+    finally:
+        nat().gemm_set_probe(None)
+    n = int(buf[0].item())
+    assert n == (M // 128) * (N // 128)
+    rec = buf[8:8 * (1 + n)].view(n, 8)
+    assert bool((rec[:, 3] >= rec[:, 2]).all()) and bool((rec[:, 6] >= rec[:, 4]).all())
+    close(C, A.float() @ B.float().t(), 1e-2, 5e-2, "probed launch still computes")
 
 
 @pytest.mark.parametrize("N", [768, 2304, 3072, 384])

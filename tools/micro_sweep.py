@@ -99,6 +99,3 @@ if __name__ == "__main__":
         gemm_variants()
     if "ablate" in which:
         gemm_variants(ABLATIONS)
-    if "tile256" in which:      # the 256 x 128 three-stage-ring kernel (debug_flags bit 14; the weight gradients ignore it)
-        gemm_variants((("default", 0), ("tile256", 16384), ("tile256-reads-first", 16384 | 32768)) +
-                      ((("tile256-ping-pong", 16384 | 65536),) if os.environ.get("MMF_AMD_TEST_PINGPONG") == "1" else ()))

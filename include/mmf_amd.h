@@ -32,6 +32,7 @@ int mmf_amd_abi_version(void);
 /* Integer tuning knobs for on-hardware sweeps (0 = built-in heuristic).  Not part of the reference's interface. */
 enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_LN_BWD_GRID = 1,    /* workgroups of mmf_layernorm_bwd (<= MMF_LN_BWD_MAX_GRID) */
+       MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 */
        MMF_TUN_COUNT = 8 };
 int mmf_amd_set_tunable(int which, int value);
 int mmf_amd_get_tunable(int which);
@@ -94,7 +95,7 @@ typedef struct mmf_gemm_desc {
                                  of nn.Linear, hf_layers.py:169-180) computed by the same launch with one extra MFMA per A
                                  fragment against a ones operand; with split-K it travels through the workspace (behind the
                                  slabs) and is summed by the slab reduction, else it is written directly */
-    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches */
+    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches, bit 17: never a wide (one workgroup per CU) tile */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
 /* `count` (1..8) independent GEMMs of ONE operand layout (a_kmajor, b_kmajor, a_f32, b_f32 equal) in one launch: the tile

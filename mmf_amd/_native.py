@@ -107,6 +107,8 @@ def lib():
     if L.mmf_amd_abi_version() != 1:
         raise NativeLibraryError("ABI version mismatch: library %d, binding 1" % L.mmf_amd_abi_version())
     _lib = L
+    if os.environ.get("MMF_AMD_GEMM_WIDE"):      # A/B switch for measurements: -1 never a wide tile, 1..3 force one (see MMF_TUN_GEMM_WIDE)
+        L.mmf_amd_set_tunable(2, int(os.environ["MMF_AMD_GEMM_WIDE"]))
     return L
 
 
@@ -412,7 +414,7 @@ def tanh_bwd(dy, y, dx):
     _check(lib().mmf_tanh_bwd_bf16(_p(dy), _p(y), _p(dx), C.c_int64(dy.numel()), _stream()), "mmf_tanh_bwd_bf16")
 
 
-TUN_SPLITK_FORCE, TUN_LN_BWD_GRID = 0, 1
+TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE = 0, 1, 2
 
 
 def set_tunable(which, value):

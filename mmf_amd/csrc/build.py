@@ -20,14 +20,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
     "-Wno-unused-result", "-I", INCLUDE, "-I", HERE,
-]
+] + os.environ.get("MMF_AMD_EXTRA_HIPCC_FLAGS", "").split()     # e.g. -DMMF_WIDE_ABLATE for tools/wide_ablate.py
 
 
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    deps = [src, os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_common.h"), os.path.join(INCLUDE, "mmf_amd.h"), __file__]
+    deps = [src, os.path.join(INCLUDE, "mmf_amd.h"), __file__] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

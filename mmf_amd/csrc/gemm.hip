@@ -25,16 +25,13 @@
 // The MFMA is issued with operands swapped (A-operand = B tile fragment) so each lane ends up holding 4 CONSECUTIVE n
 // for one m; the fp32 tile is then staged through LDS and written row-wise (16 bytes per lane, full cache lines).
 #include "gemm_common.h"
+#include "gemm_wide.h"
 
 using namespace gemm;
 
 
 namespace {
 
-// ---- timeline probe (development aid; off unless mmf_gemm_set_probe was called) ---------------------------------
-// One record of 8 u64 per workgroup: {launch id << 32 | block id, HW_ID | XCC_ID << 32, t_entry, t_first_stage_landed, t_kloop_done,
-// t_staged, t_stores_done, tile}.  Slot 0 of the buffer is the allocation counter.  Timestamps are s_memrealtime ticks (10 ns).
-struct Probe { unsigned long long* buf; unsigned cap; unsigned launch; };
 DEVI unsigned long long probe_now() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, one counter for the whole device
 
 // ---- one output tile --------------------------------------------------------------------------------
@@ -340,8 +337,81 @@ int launch_grouped_n(const GroupArgs& g, hipStream_t s) {
 }
 
 
+// ---- wide tiles (gemm_wide.h): one workgroup per CU ---------------------------------------------------------------------
+template <int BM_, int BN_, int WGM, int WGN, int NS>
+int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    const int tm = (d->M + BM_ - 1) / BM_, tn = d->N / BN_;
+    constexpr int lds_bytes = NS * (BM_ + BN_) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (a0 != hipSuccess || a1 != hipSuccess) { mmf_amd_set_error(hipGetErrorString(a0 != hipSuccess ? a0 : a1)); return 2; }
+        attr_set = true;
+    }
+    const bf16* A = reinterpret_cast<const bf16*>(d->A);
+    const bf16* B = reinterpret_cast<const bf16*>(d->B);
+#ifdef MMF_WIDE_ABLATE
+    const int abl = (d->debug_flags >> 4) & 7;
+#define MMF_WIDE_ABL_CASE(V)                                                                                                          \
+    if (abl == V) {                                                                                                                   \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, V>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe()); \
+        MMF_CHECK_LAUNCH();                                                                                                           \
+        return 0;                                                                                                                     \
+    }
+    MMF_WIDE_ABL_CASE(1) MMF_WIDE_ABL_CASE(2) MMF_WIDE_ABL_CASE(3) MMF_WIDE_ABL_CASE(4) MMF_WIDE_ABL_CASE(5) MMF_WIDE_ABL_CASE(6) MMF_WIDE_ABL_CASE(7)
+#undef MMF_WIDE_ABL_CASE
+#endif
+    if (d->M % BM_)
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
+    else
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Modelled launch time (us) of a tile shape: rounds x (K-steps x max(staging, MFMA) + fixed), with the measured per-CU staging rate
+// (85 GB/s, profiles/r02_lds_dma_ceiling.txt) and 90 % of the per-CU MFMA peak; `slots` = workgroups resident per CU.
+static double tile_cost(long M, long N, long K, int bm, int bn, int slots) {
+    const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const double rounds = (double)((tiles + 256L * slots - 1) / (256L * slots));
+    const double stage_us = (double)(bm + bn) * 128.0 * slots / 85e3;
+    const double mfma_us = 2.0 * bm * bn * 64.0 * slots / (9.77e6 * 0.9);
+    return rounds * ((double)((K + 63) / 64) * (stage_us > mfma_us ? stage_us : mfma_us) + 5.0);
+}
+// 0: keep the 128-row kernel; 1: 256 x 96, 2: 192 x 192, 3: 256 x 128.
+static int wide_choice(const mmf_gemm_desc* d) {
+    const int force = mmf_amd_get_tunable(MMF_TUN_GEMM_WIDE);
+    if (force < 0 || (d->debug_flags & 131072) || d->M < 512 || (d->K % 64) != 0 || d->K < 128) return 0;
+    static const int BMs[4] = {0, 256, 192, 256}, BNs[4] = {0, 96, 192, 128};
+    if (force >= 1 && force <= 3) return (d->N % BNs[force]) == 0 ? force : 0;
+    // One workgroup per CU cannot hide a heavy epilogue behind a co-resident workgroup's K loop: the GELU up-projection (two
+    // bf16 outputs, erf + exp per element) measured 70.7 us with wide tiles against 60.5 us inside the training step.
+    if (d->act == 1) return 0;
+    double best = tile_cost(d->M, d->N, d->K, 128, 128, 2);
+    if ((d->N % 96) == 0) { const double c = tile_cost(d->M, d->N, d->K, 128, 96, 2); if (c < best) best = c; }
+    int pick = 0;
+    for (int c = 1; c <= 3; ++c) {
+        if (d->N % BNs[c]) continue;
+        const double t = tile_cost(d->M, d->N, d->K, BMs[c], BNs[c], 1);
+        if (t < best * 0.97) { best = t; pick = c; }
+    }
+    return pick;
+}
+
 template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    if constexpr (!AK && !BK_ && is_bf16<AT>::value && is_bf16<BT>::value) {
+        if (e.splits <= 1) {
+            switch (wide_choice(d)) {
+                case 1: return launch_wide<256, 96, 4, 2, 3>(d, e, s);
+                case 2: return launch_wide<192, 192, 2, 4, 3>(d, e, s);
+                case 3: return launch_wide<256, 128, 4, 2, 3>(d, e, s);
+                default: break;
+            }
+        }
+    }
     // 8 waves (4 per SIMD with two workgroups per CU) hide LDS / MFMA-issue latency better than 4 waves of 64x64;
     // bit 8 of debug_flags selects the 4-wave form for A/B measurements.
     if (AK && BK_ && is_bf16<AT>::value && is_bf16<BT>::value && e.rowsum_col >= 0)   // weight gradient carrying the bias gradient

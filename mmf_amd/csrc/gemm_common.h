@@ -34,6 +34,11 @@ struct EpiArgs {
     float* rowsum_direct;  // no split-K: the row sums go straight here ([M] fp32) instead of behind the slabs
 };
 
+// Timeline probe (development aid; off unless mmf_gemm_set_probe was called).  One record of 8 u64 per workgroup:
+// {launch id << 32 | block id, HW_ID | XCC_ID << 32, t_entry, t_first_stage_landed, t_kloop_done, t_staged, t_stores_done, tile}.
+// Slot 0 of the buffer is the allocation counter.  Timestamps are s_memrealtime ticks (100 MHz, one counter per device).
+struct Probe { unsigned long long* buf; unsigned cap; unsigned launch; };
+
 DEVI int rot_kmajor(int krow) { return 32 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
 
 // ---- global -> register staging -------------------------------------------------------------

@@ -170,7 +170,7 @@ def test_gemm_timeline_probe_records_every_workgroup():
     buf = torch.zeros(8 * (1 + 256), dtype=torch.int64, device=DEV)
     nat().gemm_set_probe(buf)
     try:
-        nat().gemm(A, B, C, M, N, K, K, K, N, debug_flags=512)
+        nat().gemm(A, B, C, M, N, K, K, K, N, debug_flags=512 | (1 << 17))      # 128 x 128 tiles of the 128-row kernel
         torch.cuda.synchronize()
     finally:
         nat().gemm_set_probe(None)

@@ -99,3 +99,5 @@ if __name__ == "__main__":
         gemm_variants()
     if "ablate" in which:
         gemm_variants(ABLATIONS)
+    if "wide" in which:       # forward shapes: dispatcher's choice (wide tiles where the model says so) against the 128-row kernel
+        gemm_variants((("auto", 0), ("128-row", 1 << 17)))

@@ -33,6 +33,7 @@ int mmf_amd_abi_version(void);
 enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_LN_BWD_GRID = 1,    /* workgroups of mmf_layernorm_bwd (<= MMF_LN_BWD_MAX_GRID) */
        MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 */
+       MMF_TUN_LN_OLD = 3,         /* 1: LayerNorm with the one-wave-per-row, 8-byte-per-lane kernels even when H % 256 == 0 (A/B measurements) */
        MMF_TUN_COUNT = 8 };
 int mmf_amd_set_tunable(int which, int value);
 int mmf_amd_get_tunable(int which);

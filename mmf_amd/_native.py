@@ -109,6 +109,8 @@ def lib():
     _lib = L
     if os.environ.get("MMF_AMD_GEMM_WIDE"):      # A/B switch for measurements: -1 never a wide tile, 1..3 force one (see MMF_TUN_GEMM_WIDE)
         L.mmf_amd_set_tunable(2, int(os.environ["MMF_AMD_GEMM_WIDE"]))
+    if os.environ.get("MMF_AMD_LN_OLD"):
+        L.mmf_amd_set_tunable(3, int(os.environ["MMF_AMD_LN_OLD"]))
     return L
 
 
@@ -414,7 +416,7 @@ def tanh_bwd(dy, y, dx):
     _check(lib().mmf_tanh_bwd_bf16(_p(dy), _p(y), _p(dx), C.c_int64(dy.numel()), _stream()), "mmf_tanh_bwd_bf16")
 
 
-TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE = 0, 1, 2
+TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE, TUN_LN_OLD = 0, 1, 2, 3
 
 
 def set_tunable(which, value):

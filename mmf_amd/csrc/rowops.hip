@@ -193,6 +193,182 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm, H a multiple of 256 (768 / 1024 / 512 ...): HALF a wave per row.  Lane (l & 31) owns the 8 consecutive columns
+// (l & 31) * 8 + 256 * c .. + 7 of its row, c = 0 .. H/256 - 1, so every access is a 16-byte-per-lane, 512-byte-per-half-wave
+// contiguous transaction (the 8-byte form above reaches 2.4 - 2.9 TB/s, a third of HBM bandwidth), two rows are in flight per
+// wave, and the row reductions are 5 cross-lane steps inside the half.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x8r __attribute__((ext_vector_type(8)));
+DEVI f32x8r load8(const bf16* p) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+    f32x8r r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+    return r;
+}
+DEVI f32x8r load8(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    return f32x8r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+DEVI void store8(bf16* p, f32x8r v) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+DEVI float half_sum(float v) {      // sum over the 32 lanes of this half-wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NC>   // NC = H / 256
+__global__ __launch_bounds__(256) void ln_fwd_h_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps) {
+    constexpr int H = NC * 256;
+    const int hl = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const bf16* xr = x + (size_t)row * H + hl * 8;
+    f32x8r v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        v[c] = load8(xr + 256 * c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[c][i];
+    }
+    const float mu = half_sum(s) * (1.f / (float)H);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mu; q += d * d; }
+    const float rs = rsqrtf(half_sum(q) * (1.f / (float)H) + eps);
+    bf16* yr = y + (size_t)row * H + hl * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x8r g = load8(gamma + hl * 8 + 256 * c), b = load8(beta + hl * 8 + 256 * c);
+        f32x8r o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * g[i] + b[i];
+        store8(yr + 256 * c, o);
+    }
+    if (hl == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
+// Backward: a workgroup of 4 waves = 8 half-waves; half-wave h owns rows blockIdx * 8 + h + 8 * gridDim * i (two rows each at the
+// VQA2 shape: 456 workgroups, two co-resident per CU so that one streams while the other reduces); all loads of a row are issued before anything is reduced.  Column-sum partials (dgamma, dbeta, optionally dbias) are combined across the
+// workgroup's 32 half-waves in LDS and written once per workgroup: partials[blk][q][H], q < NQ.
+template <int NC, bool DBIAS>
+__global__ __launch_bounds__(256) void ln_bwd_h_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, bf16* __restrict__ dx,
+                                                         bf16* __restrict__ dlin, DropoutCfg drop, float* __restrict__ partials, int rows) {
+    constexpr int H = NC * 256, NQ = DBIAS ? 3 : 2;
+    __shared__ float red[8][H / 8 + 1][8];        // one quantity at a time: [half-wave][lane chunk][8]   (+1: bank spread)
+    const int hl = threadIdx.x & 31, half = threadIdx.x >> 5;
+    f32x8r ag[NC], ab[NC], al[DBIAS ? NC : 1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        ag[c] = ab[c] = f32x8r{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (DBIAS) al[c] = ag[c];
+    }
+    // (gamma is re-read per chunk from L1 / L2 in both passes instead of being held: the register budget is what decides how
+    // many workgroups - rows in flight - a CU holds)
+    for (int row = blockIdx.x * 8 + half; row < rows; row += 8 * gridDim.x) {
+        const size_t off = (size_t)row * H + hl * 8;
+        f32x8r xv[NC], dv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { xv[c] = load8(x + off + 256 * c); dv[c] = load8(dy + off + 256 * c); }
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x8r gm = load8(gamma + hl * 8 + 256 * c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xv[c][i] = (xv[c][i] - mu) * rs;                  // xhat
+                const float g = dv[c][i] * gm[i];
+                s1 += g;
+                s2 += g * xv[c][i];
+            }
+        }
+        const float c1 = half_sum(s1) * (1.f / (float)H), c2 = half_sum(s2) * (1.f / (float)H);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x8r gm = load8(gamma + hl * 8 + 256 * c);
+            f32x8r d;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                d[i] = rs * (dv[c][i] * gm[i] - c1 - xv[c][i] * c2);
+                ag[c][i] += dv[c][i] * xv[c][i];
+                ab[c][i] += dv[c][i];
+            }
+            store8(dx + off + 256 * c, d);
+            if (dlin) {
+                const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
+                const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale);
+                const f32x4 s1_ = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { d[i] *= s0[i]; d[i + 4] *= s1_[i]; }
+                store8(dlin + off + 256 * c, d);
+            }
+            if (DBIAS) {     // the bias gradient uses the same rounding the weight-gradient GEMM will see
+#pragma unroll
+                for (int i = 0; i < 8; ++i) al[c][i] += (float)(bf16)d[i];
+            }
+        }
+    }
+#pragma unroll 1
+    for (int qn = 0; qn < NQ; ++qn) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x8r v = (qn == 0) ? ag[c] : (qn == 1) ? ab[c] : al[DBIAS ? c : 0];
+            float* dst = &red[half][hl + 32 * c][0];
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < H; col += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += red[w][col >> 3][col & 7];
+            partials[((size_t)blockIdx.x * 3 + qn) * H + col] = t;
+        }
+    }
+}
+
+// out_q[col] (+)= sum_blk partials[blk][q][col]: 64 columns x 16 block-groups per workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_h_kernel(const float* __restrict__ partials, int nblk, int H, float* o0, float* o1,
+                                                                float* o2, int accumulate) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int qn = blockIdx.y;
+    float* out = (qn == 0) ? o0 : (qn == 1) ? o1 : o2;
+    if (out == nullptr) return;
+    float s = 0.f;
+    if (col < H) {
+#pragma unroll 4
+        for (int b = rg; b < nblk; b += 16) s += partials[((size_t)b * 3 + qn) * H + col];
+    }
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && col < H) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][c];
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // embeddings
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
@@ -732,6 +908,17 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
     hipStream_t s = (hipStream_t)stream;
     const int nch = (H + 255) / 256;
     const bf16* xp = (const bf16*)x; bf16* yp = (bf16*)y;
+    if ((H % 256) == 0 && H <= 1024 && !mmf_amd_get_tunable(MMF_TUN_LN_OLD)) {     // half a wave per row, 16-byte accesses
+        const dim3 grid((rows + 7) / 8);
+        switch (H / 256) {
+            case 1: hipLaunchKernelGGL(ln_fwd_h_kernel<1>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
+            case 2: hipLaunchKernelGGL(ln_fwd_h_kernel<2>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
+            case 3: hipLaunchKernelGGL(ln_fwd_h_kernel<3>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
+            default: hipLaunchKernelGGL(ln_fwd_h_kernel<4>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
+        }
+        MMF_CHECK_LAUNCH();
+        return 0;
+    }
     switch (nch) {
         case 1: launch_ln_fwd<1>(rows, s, xp, gamma, beta, yp, mean, rstd, rows, H, eps); break;
         case 2: launch_ln_fwd<2>(rows, s, xp, gamma, beta, yp, mean, rstd, rows, H, eps); break;
@@ -754,6 +941,26 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     hipStream_t s = (hipStream_t)stream;
     DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
     const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
+    if ((H % 256) == 0 && H <= 1024 && !(H == 1024 && dbias) && !mmf_amd_get_tunable(MMF_TUN_LN_OLD)) {     // half a wave per row, 16-byte accesses
+        int grid = (rows + 15) / 16;
+        if (grid > LNB_MAX_GRID) grid = LNB_MAX_GRID;
+        if (tg > 0 && tg < grid) grid = tg;
+        const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
+#define MMF_LNB_H(NC)                                                                                                              \
+        if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows); \
+        else hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows);
+        switch (H / 256) {
+            case 1: MMF_LNB_H(1) break;
+            case 2: MMF_LNB_H(2) break;
+            case 3: MMF_LNB_H(3) break;
+            default: MMF_LNB_H(4) break;
+        }
+#undef MMF_LNB_H
+        MMF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ln_bwd_reduce_h_kernel, dim3((H + 63) / 64, dbias ? 3 : 2), dim3(1024), 0, s, partials, grid, H, dgamma, dbeta, dbias, accumulate);
+        MMF_CHECK_LAUNCH();
+        return 0;
+    }
     const int nch_ = (H + 255) / 256;
     const int grid = grid_for(rows, nch_ >= 5 ? 4 : nch_ >= 4 ? 8 : LNB_WAVES, tg > 0 ? (tg > LNB_MAX_GRID ? LNB_MAX_GRID : tg) : (nch_ >= 4 ? 2 * LNB_GRID : LNB_GRID));
     const int nch = (H + 255) / 256;

@@ -572,11 +572,13 @@ class TransformerLayerFn(torch.autograd.Function):
         M = B * S
         dev = x2.device
         # feed-forward sub-layer
-        dres2, dlin2, dg2, dbe2, db2 = _ln_bwd(_grad_bf16(g, H), y2, mean2, rstd2, g2, drop_hid2, True)
+        # (the bias gradients of the two output projections are column sums of dlin2 / dlin1, i.e. of the A operands of their
+        # weight-gradient GEMMs: the grouped launch below delivers them, the LayerNorm backward does not have to)
+        dres2, dlin2, dg2, dbe2, _ = _ln_bwd(_grad_bf16(g, H), y2, mean2, rstd2, g2, drop_hid2, False)
         du = _dgrad(dlin2, H, w2_16, M, H, I, act_aux=u)                  # (dlin2 W2) * gelu'(u)
         da = _dgrad(du, I, w1_16, M, I, H, dx_resid=dres2)                # du W1 + dres2  = gradient of the attention block's output
         # attention sub-layer
-        dres1, dlin1, dg1, dbe1, dbo = _ln_bwd(da, y1, mean1, rstd1, g1, drop_hid1, True)
+        dres1, dlin1, dg1, dbe1, _ = _ln_bwd(da, y1, mean1, rstd1, g1, drop_hid1, False)
         dctx = _dgrad(dlin1, H, wo16, M, H, H)
         dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, S, dtype=F32, device=dev)
@@ -586,9 +588,9 @@ class TransformerLayerFn(torch.autograd.Function):
         dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1) if ctx.needs_input_grad[0] else None
         # the four weight gradients, one launch
         p_1, dw1, db1 = _wgrad_problem(du, I, a_out, M, I, H, True)
-        p_2, dw2, _ = _wgrad_problem(dlin2, H, hh, M, H, I, False)
+        p_2, dw2, db2 = _wgrad_problem(dlin2, H, hh, M, H, I, True)
         p_q, dwqkv, dbqkv = _wgrad_problem(dqkv, 3 * H, x2, M, 3 * H, H, True)
-        p_o, dwo, _ = _wgrad_problem(dlin1, H, ctxt, M, H, H, False)
+        p_o, dwo, dbo = _wgrad_problem(dlin1, H, ctxt, M, H, H, True)
         nat.gemm_grouped([p_1, p_2, p_q, p_o])
         return ((dx.view(B, S, H) if dx is not None else None),
                 dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, dbe1,

@@ -410,7 +410,7 @@ def test_attention_dropout_consistent_between_forward_and_backward():
 # ---------------------------------------------------------------------------------------------
 # LayerNorm
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rows,H", [(7296, 768), (33, 768), (64, 1024), (5, 64), (12, 256)])
+@pytest.mark.parametrize("rows,H", [(7296, 768), (33, 768), (64, 1024), (5, 64), (12, 256), (20011, 768), (100, 512), (14592, 1024)])
 def test_layernorm_forward_backward(rows, H):
     x = rnd(rows, H, scale=2.0); gamma = rnd(H, dtype=torch.float32) + 1.0; beta = rnd(H, dtype=torch.float32)
     y = torch.empty_like(x); mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
@@ -432,6 +432,32 @@ def test_layernorm_forward_backward(rows, H):
     # accumulate flag
     nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, (0, 0, 1.0), dgamma, dbeta, None, 1, ws, rows, H)
     close(dgamma, 2 * g.grad, 1e-3, 2e-3 * float(g.grad.abs().max()) + 1e-4, "dgamma accumulate")
+
+
+@pytest.mark.parametrize("H", [768, 1024])
+def test_layernorm_half_wave_kernels_agree_with_the_one_wave_per_row_kernels(H):
+    """H % 256 == 0 runs the half-wave-per-row, 16-byte kernels; MMF_TUN_LN_OLD selects the one-wave-per-row form.  Same maths:
+    outputs equal up to fp32 summation order (bf16 outputs almost always identical), dropout masks identical."""
+    rows = 3000
+    x = rnd(rows, H, scale=2.0, seed=1); gamma = rnd(H, dtype=torch.float32, seed=2) + 1.0; beta = rnd(H, dtype=torch.float32, seed=3)
+    dy = rnd(rows, H, seed=4)
+    drop = nat().drop_cfg(0.1, 77)
+    res = []
+    for old in (0, 1):
+        nat().set_tunable(nat().TUN_LN_OLD, old)
+        try:
+            y = torch.empty_like(x); mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+            nat().layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, H, 1e-12)
+            dx = torch.empty_like(x); dlin = torch.empty_like(x)
+            dg = torch.empty(H, device=DEV); db = torch.empty(H, device=DEV)
+            ws = torch.empty(nat().layernorm_bwd_ws_floats(H), device=DEV)
+            nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, dg, db, None, 0, ws, rows, H)
+            res.append((y, mean, rstd, dx, dlin, dg, db))
+        finally:
+            nat().set_tunable(nat().TUN_LN_OLD, 0)
+    for a, b, name in zip(res[0], res[1], ("y", "mean", "rstd", "dx", "dlin", "dgamma", "dbeta")):
+        close(a, b, 1e-2 if a.dtype == torch.bfloat16 else 1e-5, 1e-2 if a.dtype == torch.bfloat16 else 1e-4 * float(b.abs().max()), name)
+    assert torch.equal(res[0][4] == 0, res[1][4] == 0)      # same dropout mask
 
 
 # ---------------------------------------------------------------------------------------------

@@ -9,14 +9,26 @@ from mmf_amd import _native as nat
 
 
 def timeit(f, iters=30):
+    """us per call of `f`, measured on a hipGraph of `iters` back-to-back calls (no host launch floor)."""
     for _ in range(3):
         f()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        f()
+        st.synchronize()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(iters):
+                f()
+    torch.cuda.synchronize()
+    g.replay()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    for _ in range(iters):
-        f()
+    for _ in range(3):
+        g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    return e0.elapsed_time(e1) / (3 * iters) * 1e3
 
 
 def ln_sweep():
@@ -27,12 +39,23 @@ def ln_sweep():
     dx = torch.empty_like(dy); dlin = torch.empty_like(dy)
     dg = torch.empty(H, device=dev); db = torch.empty(H, device=dev); dbias = torch.empty(H, device=dev)
     ws = torch.empty(nat.layernorm_bwd_ws_floats(H), device=dev)
+    y = torch.empty_like(x)
+    for old in (0, 1):
+        nat.set_tunable(nat.TUN_LN_OLD, old)
+        tf = timeit(lambda: nat.layernorm_fwd(x, gamma, gamma, y, mean, rstd, rows, H, 1e-12))
+        t0 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat.NO_DROP, dg, db, None, False, ws, rows, H))
+        t1 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, None, False, ws, rows, H))
+        t2 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, dbias, False, ws, rows, H))
+        print("%s kernels: fwd %5.1f us (%.2f TB/s)  bwd plain %5.1f  bwd+dropout %5.1f (%.2f TB/s incl. reduce)  +dbias %5.1f" % (
+            "one-wave-per-row" if old else "half-wave-per-row", tf, 22.4e6 / tf / 1e6, t0, t1, 44.8e6 / t1 / 1e6, t2), flush=True)
+    nat.set_tunable(nat.TUN_LN_OLD, 1)
     for grid in (128, 192, 256, 384, 512):
         nat.set_tunable(nat.TUN_LN_BWD_GRID, grid)
         t0 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat.NO_DROP, dg, db, None, False, ws, rows, H))
         t1 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, dbias, False, ws, rows, H))
         print("ln_bwd grid %3d: plain %6.1f us   dropout+dbias %6.1f us (incl. reduce kernel)" % (grid, t0, t1), flush=True)
     nat.set_tunable(nat.TUN_LN_BWD_GRID, 0)
+    nat.set_tunable(nat.TUN_LN_OLD, 0)
 
 
 def wgrad_sweep():

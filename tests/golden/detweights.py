@@ -39,3 +39,18 @@ def state_dict(shapes, seed, std=0.05):
             w = w + 1.0
         out[name] = w
     return out
+
+
+def sharpen_m4c_decoder(sd, cls_scale=12.0, ptr_scale=24.0):
+    """M4C output layers rescaled (no new randomness) for the second greedy-decoding fixture: with the plain deterministic
+    weights every decoding step picks BOS, so previous predictions never select an OCR row.  The classifier bias is dropped and
+    its weight scaled up, the pointer network's query / key projections are scaled up and lose their biases: the per-step
+    scores then spread over fixed-vocabulary and OCR-copy indices with top-1 / top-2 margins far above bf16 noise."""
+    out = {k: v.copy() for k, v in sd.items()}
+    out["classifier.module.bias"] = np.zeros_like(out["classifier.module.bias"])
+    out["classifier.module.weight"] = out["classifier.module.weight"] * np.float32(cls_scale)
+    for k in ("ocr_ptr_net.query.weight", "ocr_ptr_net.key.weight"):
+        out[k] = out[k] * np.float32(ptr_scale)
+    for k in ("ocr_ptr_net.query.bias", "ocr_ptr_net.key.bias"):
+        out[k] = np.zeros_like(out[k])
+    return out

@@ -744,7 +744,7 @@ def make_m4c():
     from mmf.modules.layers import ClassifierLayer
     from mmf.modules.losses import M4CDecodingBCEWithMaskLoss
 
-    for name, c in M4C_CASES.items():
+    def build_ref(c):
         tcfg = BertConfig(hidden_size=c["text_hidden_size"], num_hidden_layers=c["text_num_hidden_layers"],
                           num_attention_heads=c["text_num_attention_heads"], intermediate_size=c["text_intermediate_size"],
                           vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"], type_vocab_size=2,
@@ -801,6 +801,12 @@ def make_m4c():
                 sd[k] = sd[k] + 1.0
         missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         assert not unexpected, unexpected
+
+        return ref, sd, shapes
+
+    for name, c in M4C_CASES.items():
+        ref, sd, shapes = build_ref(c)
+        H, N = c["hidden_size"], c["N"]
         rec_in = m4c_inputs(c)
         sl = m4c_sample_list(rec_in)
 
@@ -841,12 +847,25 @@ def make_m4c():
         top2 = dec["scores"].topk(2, dim=-1).values
         rec["decode_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
 
+        # second decoding fixture: with the deterministic weights above every step decodes BOS, so the loop's feedback path
+        # (previous predictions >= num_choices select OCR rows in the two-source gather, m4c.py:526-528) is never taken.
+        # detweights.sharpen_m4c_decoder rescales the output layers (no new randomness) so that the greedy sequence mixes
+        # fixed-vocabulary and OCR-copy indices with margins far above bf16 noise.
+        sd2 = detweights.sharpen_m4c_decoder(sd)
+        ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()}, strict=False)
+        with torch.no_grad():
+            dec2 = ref.forward(m4c_sample_list(rec_in))
+        rec["decode2_scores"] = dec2["scores"].numpy()
+        rec["decode2_argmax"] = dec2["scores"].argmax(dim=-1).numpy()
+        top2 = dec2["scores"].topk(2, dim=-1).values
+        rec["decode2_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+
         rec["param_names"] = np.array(list(shapes.keys()))
         rec["param_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
         rec["case"] = np.array(repr(c))
         path = os.path.join(HERE, "%s.npz" % name)
         np.savez_compressed(path, **rec)
-        print(name, "loss", loss.item(), "scores[0,0,:4]", rec["scores"][0, 0, :4], "decode", rec["decode_argmax"].tolist(),
+        print(name, "loss", loss.item(), "scores[0,0,:4]", rec["scores"][0, 0, :4], "decode", rec["decode_argmax"].tolist(), "decode2", rec["decode2_argmax"].tolist(), "min margin", float(rec["decode2_margin"].min()),
               "->", path, os.path.getsize(path), "bytes")
 
 

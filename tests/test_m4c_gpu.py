@@ -324,6 +324,26 @@ def test_m4c_greedy_decoding_matches_reference():
     np.testing.assert_allclose(again.numpy(), scores.numpy(), rtol=1e-3, atol=1e-3)
 
 
+def test_m4c_greedy_decoding_with_ocr_feedback_matches_reference():
+    """The second decoding fixture: sharpened output layers make the reference's greedy sequence mix fixed-vocabulary and
+    OCR-copy indices (margins >= 1.6 logits), so the loop's feedback through the two-source gather is what is compared."""
+    from tests.golden import detweights
+    z, case, cfg, sd, sample = load_m4c_case()
+    am_ref = z["decode2_argmax"]
+    assert (am_ref >= case["num_choices"]).any() and (am_ref < case["num_choices"]).any()
+    assert float(z["decode2_margin"].min()) > 1.0
+    sd2 = {k: torch.from_numpy(v) for k, v in detweights.sharpen_m4c_decoder({k: v.numpy() for k, v in sd.items()}).items()}
+    model = build_m4c(cfg, sd2).eval()
+    with torch.no_grad():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    scores = out["scores"].float().cpu()
+    np.testing.assert_array_equal(scores.argmax(-1).numpy(), am_ref)
+    ref = torch.from_numpy(z["decode2_scores"])
+    valid = ref > -5000            # masked OCR slots hold -10000 + noise on both sides
+    # (the sharpened layers blow the logits up to hundreds: the bf16 error is judged against that scale)
+    assert float((scores - ref).abs()[valid].max()) <= TOL * float(ref[valid].abs().max())
+
+
 def test_m4c_textvqa_shape_trains_with_dropout_and_stays_finite():
     """The configured shape (BASELINE.json configs[4]): 20 + 100 + 50 + 12 positions, 768 wide, 5000 + 50 scores."""
     cfg = dict(O.DEFAULT_CONFIG)
@@ -358,3 +378,55 @@ def test_m4c_textvqa_shape_trains_with_dropout_and_stays_finite():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
     # sample 1 has no OCR token at all: its pointer scores are all -10000 + noise, and nothing blows up
     assert float(out["scores"][1, :, 5000:].max()) < -9000
+
+
+def test_m4c_textvqa_shape_matches_the_oracle():
+    """Parity (not just finiteness) at the configured TextVQA shape — 20 + 100 + 50 + 12 positions, 768 wide, 5000 + 50 scores:
+    teacher-forced scores, loss and the gradients of the large tensors against the pinned CPU oracle on the same weights."""
+    cfg = dict(O.DEFAULT_CONFIG)
+    from mmf_amd.common.registry import registry
+    from mmf_amd.utils.configuration import Config
+    import warnings
+    registry.register("config", Config({"datasets": "textvqa"}))
+    registry.register("textvqa_num_final_outputs", 5050)
+    registry.register("textvqa_answer_processor", Config({"BOS_IDX": 1}))
+    torch.manual_seed(17)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = registry.get_model_class("m4c")(Config({"model": "m4c", "text_bert_init_from_bert_base": False}))
+        model.build(); model.init_losses()
+    model = _teacher_forcing(model.to("cuda"))
+    B = 3
+    g = torch.Generator().manual_seed(4)
+    prev = torch.randint(0, 5050, (B, 12), generator=g); prev[:, 0] = 1; prev[0, 5] = 5000 + 7; prev[2, 3] = 5000 + 1
+    sample = {
+        "text": torch.randint(1, 30522, (B, 20), generator=g), "text_len": torch.tensor([20, 9, 14]),
+        "image_feature_0": torch.rand(B, 100, 2048, generator=g), "obj_bbox_coordinates": torch.rand(B, 100, 4, generator=g),
+        "image_info_0": {"max_features": torch.tensor([100, 37, 64])},
+        "context_feature_0": torch.randn(B, 50, 300, generator=g), "context_feature_1": torch.rand(B, 50, 604, generator=g),
+        "image_feature_1": torch.rand(B, 100, 2048, generator=g), "ocr_bbox_coordinates": torch.rand(B, 50, 4, generator=g),
+        "context_info_0": {"max_features": torch.tensor([50, 13, 31])}, "order_vectors": torch.zeros(B, 50, 50),
+        "train_prev_inds": prev, "targets": (torch.rand(B, 12, 5050, generator=g) > 0.999).float(),
+        "train_loss_mask": (torch.rand(B, 12, generator=g) > 0.3).float(), "dataset_name": "textvqa", "dataset_type": "train"}
+    out = model(SampleList(sample_to(sample, "cuda")))
+    (key, loss), = out["losses"].items()
+    loss.sum().backward()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    s = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    s.update({k: v for k, v in sd.items() if not v.is_floating_point()})
+    ref = O.m4c_forward(s, cfg, dict(sample), training_mode=True, return_all=True)
+    ref_loss = O.decoding_bce_with_mask(ref["scores"], sample["targets"], sample["train_loss_mask"]).sum()
+    ref_loss.backward()
+    got = out["scores"].detach().float().cpu()
+    valid = ref["scores"].detach() > -5000
+    assert float(((got - ref["scores"].detach()).abs() / (1.0 + ref["scores"].detach().abs()))[valid].max()) <= TOL
+    assert abs(loss.sum().item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    params = dict(model.named_parameters())
+    checked = 0
+    for k, v in s.items():
+        if not v.is_floating_point() or v.grad is None or v.numel() < 100000 or "fc7" in k or _skip(k):
+            continue          # (the fc7 ReLU gates sit on bf16-noise-sized pre-activations: covered with gating by the fixture tests)
+        e = rel_err(params[k].grad, v.grad)
+        assert e <= 2 * TOL, (k, e)
+        checked += 1
+    assert checked >= 20

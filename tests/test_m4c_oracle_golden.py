@@ -54,3 +54,18 @@ def test_m4c_oracle_greedy_decoding_matches_reference():
         out = O.m4c_forward(sd, cfg, dict(sample), training_mode=False, return_all=True)
     np.testing.assert_array_equal(out["scores"].argmax(-1).numpy(), z["decode_argmax"])
     np.testing.assert_allclose(out["scores"].numpy(), z["decode_scores"], rtol=1e-5, atol=2e-5)
+
+
+def test_m4c_oracle_greedy_decoding_feeds_back_ocr_copies():
+    """Second decoding fixture (sharpened output layers, tests/golden/detweights.py): the reference's greedy sequence mixes
+    fixed-vocabulary and OCR-copy indices, so previous predictions >= num_choices go through the OCR half of the gather."""
+    from tests.golden import detweights
+    z, case, cfg, sd, sample = load_m4c_case()
+    am = z["decode2_argmax"]
+    V = case["num_choices"]
+    assert (am >= V).any() and (am < V).any() and len(np.unique(am)) >= 4      # the fixture really is mixed
+    sd2 = {k: torch.from_numpy(v) for k, v in detweights.sharpen_m4c_decoder({k: v.numpy() for k, v in sd.items()}).items()}
+    with torch.no_grad():
+        out = O.m4c_forward(sd2, cfg, dict(sample), training_mode=False, return_all=True)
+    np.testing.assert_array_equal(out["scores"].argmax(-1).numpy(), am)
+    np.testing.assert_allclose(out["scores"].numpy(), z["decode2_scores"], rtol=1e-5, atol=1e-4)

@@ -50,7 +50,18 @@ def _adapter(mmf_base_model, hip_cls, children):
         def get_optimizer_parameters(self, config):
             return self._inner[0].get_optimizer_parameters(config)
 
+        def train(self, mode=True):
+            # the HIP-backed network is deliberately NOT a registered sub-module (its parameters live under `children`), so
+            # nn.Module.train() does not reach it: forward it by hand — M4C.forward branches on `self.training` (teacher
+            # forcing against greedy decoding, mmf/models/m4c.py:286-305)
+            super().train(mode)
+            inner = self.__dict__.get("_inner")
+            if inner:
+                inner[0].train(mode)
+            return self
+
         def forward(self, sample_list):
+            self._inner[0].training = self.training
             return hip_cls.forward(self._inner[0], sample_list)
 
     Adapter.__name__ = Adapter.__qualname__ = hip_cls.__name__
@@ -90,5 +101,13 @@ def install():
                         ("transformer_backend", ("huggingface",)), ("transformer_head", ("mlp", "multilayer_mlp"))):
         for name in names:
             obj = getattr(hip_registry, "get_%s_class" % kind)(name)
+            if kind == "encoder":
+                # MMF's registry asserts issubclass(encoder, mmf.modules.encoders.Encoder) (registry.py:443-447)
+                try:
+                    from mmf.modules.encoders import Encoder as MMFEncoder
+                except ImportError:       # a stripped-down MMF without the encoders module
+                    MMFEncoder = None
+                if MMFEncoder is not None and not issubclass(obj, MMFEncoder):
+                    obj = type(obj.__name__, (obj, MMFEncoder), {"__doc__": obj.__doc__})
             getattr(mmf_registry, "register_%s" % kind)(name)(obj)
     return adapters

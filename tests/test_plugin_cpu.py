@@ -91,3 +91,46 @@ def test_install_registers_everything_and_keeps_the_parameter_tree(fake_mmf):
     from mmf_amd.common.registry import registry as hip_registry
     registry.state["someset_num_final_outputs"] = 4242
     assert hip_registry.get("someset_num_final_outputs") == 4242 and hip_registry.get("absent_key", "dflt") == "dflt"
+
+
+def test_adapter_train_eval_reach_the_hip_network(fake_mmf):
+    """The HIP-backed network sits behind the adapter outside the module tree (its parameters are exposed through the
+    reference's child names), so train() / eval() are forwarded by hand: M4C picks greedy decoding from `self.training`."""
+    registry, BaseModel = fake_mmf
+    from mmf_amd import plugin
+    plugin.install()
+    z, case, cfg, sd, sample = load_m4c_case()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = registry.store[("model", "m4c")](m4c_model_config(cfg))
+        m.build()
+    inner = m._inner[0]
+    m.eval()
+    assert not m.training and not inner.training and not inner.mmt.training
+    m.train()
+    assert m.training and inner.training
+    # the branch M4C.forward takes follows the adapter's mode: count multimodal-transformer passes on a dry run
+    from tests import native_stub
+    from mmf_amd.common.sample import SampleList
+    calls = {"n": 0}
+    orig = type(inner.mmt).forward
+
+    def counting(self_, *a, **k):
+        calls["n"] += 1
+        return orig(self_, *a, **k)
+
+    type(inner.mmt).forward = counting
+    try:
+        with native_stub.installed():
+            m.train(); calls["n"] = 0
+            m(SampleList(sample))
+            teacher_forced = calls["n"]
+            m.eval(); calls["n"] = 0
+            import torch
+            with torch.no_grad():
+                m(SampleList(sample))
+            greedy = calls["n"]
+    finally:
+        type(inner.mmt).forward = orig
+    assert teacher_forced == 1 and greedy == case["D"]

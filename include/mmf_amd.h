@@ -185,8 +185,15 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
  * Tables are fp32 [*, H]; y is bf16 [B*S, H]; ids/seg int64 [B, T].  General form (MMBT, mmf/models/mmbt.py:84-129,
  * 245-250): y[b*S + row0 + t] = word[ids[b,t]] + pos[pos0 + t] + type[seg[b,t]].
  */
+/* Table sizes V (word rows), P (position rows), NT (type rows) bound the indices like nn.Embedding does: pos0 + T > P is an
+ * argument error; an id outside [0, V) or a segment id outside [0, NT) cannot be seen by the host without a sync, so the kernel
+ * writes a zero row for it and raises the device-side index-error flag (mmf_amd_take_index_error).  0 = unchecked. */
 int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
-                       const float* type, void* y, int B, int T, int S, int H, int row0, int pos0, void* stream);
+                       const float* type, void* y, int B, int T, int S, int H, int row0, int pos0, int V, int P, int NT,
+                       void* stream);
+/* 1 if any index-consuming kernel (embedding gathers, scatter-adds) met an out-of-table index since the last call, else 0;
+ * clears the flag.  Synchronises with the device: call it between steps, not inside a captured region. */
+int mmf_amd_take_index_error(void);
 /* MMF Transformer per-modality embedding sum (mmf/models/transformers/backends/huggingface.py:145-155):
  * y[b*S + row0 + i] = x[b*L + i] + pos[pos0 + i] + type[seg[b,i]]; x, y bf16 rows of H, tables fp32; pos and
  * (seg, type) may be NULL (the reference adds them only when the modality has position / segment ids). */
@@ -205,6 +212,7 @@ int mmf_copy_rows_bf16(const void* src, int src_bstride, void* dst, int dst_bstr
  * few_buckets != 0: the table has `nbuckets` rows and (almost) every index is 0 or 1 (token-type tables,
  * position_ids_visual == 0): deterministic two-stage column sums through `ws`
  * (mmf_rows_scatter_add_ws_floats(H) floats) instead of atomics.
+ * Indices outside [0, nbuckets) (nbuckets > 0) are skipped and raise the index-error flag instead of writing out of bounds.
  * skip_bucket >= 0: rows that map to that bucket are dropped — nn.Embedding(padding_idx=pad_token_id) keeps the
  * [PAD] row's gradient at zero (HF BertEmbeddings word_embeddings; reached from embeddings.py:309).
  */

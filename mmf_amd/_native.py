@@ -311,8 +311,17 @@ def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
     _req(ids, torch.int64, "ids"); _req(seg, torch.int64, "seg"); _req(y, torch.bfloat16, "y")
     for t, n in ((word, "word"), (pos, "pos"), (typ, "type")):
         _req(t, torch.float32, n)
-    _check(lib().mmf_embed_text_fwd(_p(ids), _p(seg), _p(word), _p(pos), _p(typ), _p(y), B, T, S, H, row0, pos0, _stream()),
-           "mmf_embed_text_fwd")
+    _check(lib().mmf_embed_text_fwd(_p(ids), _p(seg), _p(word), _p(pos), _p(typ), _p(y), B, T, S, H, row0, pos0,
+                                    int(word.shape[0]), int(pos.shape[0]), int(typ.shape[0]), _stream()), "mmf_embed_text_fwd")
+
+
+def take_index_error():
+    """True if an embedding gather / scatter-add met an index outside its table since the last call (the offending rows
+    were skipped, nothing was read or written out of bounds); clears the flag.  Synchronises: call between steps."""
+    rc = lib().mmf_amd_take_index_error()
+    if rc < 0:
+        _check(1, "mmf_amd_take_index_error")
+    return bool(rc)
 
 
 def rows_add_embed(x, seg, pos, typ, y, B, L, S, H, row0=0, pos0=0):

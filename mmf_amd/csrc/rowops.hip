@@ -371,16 +371,23 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_h_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------
 // embeddings
 // ------------------------------------------------------------------------------------------------
+extern __device__ int g_index_error;
 __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                           const float* __restrict__ word, const float* __restrict__ pos,
                                                           const float* __restrict__ type, bf16* __restrict__ y, int B, int T,
-                                                          int S, int H, int row0, int pos0) {
+                                                          int S, int H, int row0, int pos0, int V, int NT) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= B * T) return;
     const int b = r / T, t = r - b * T;
     const int64_t id = ids[r];
     const int64_t sg = seg ? seg[r] : 0;
+    bf16* yr0 = y + ((size_t)b * S + row0 + t) * H;
+    if ((V > 0 && (id < 0 || id >= V)) || (NT > 0 && (sg < 0 || sg >= NT))) {      // out of the table: zero row + error flag
+        if (lane == 0) atomicOr(&g_index_error, 1);
+        for (int col = lane * 4; col < H; col += 256) store4(yr0 + col, f32x4{0.f, 0.f, 0.f, 0.f});
+        return;
+    }
     const float* w = word + (size_t)id * H;
     const float* p = pos + (size_t)(t + pos0) * H;
     const float* ty = type + (size_t)sg * H;
@@ -440,6 +447,12 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__
     for (int col = lane * 8; col < H; col += 512) *reinterpret_cast<uint4*>(d + col) = *reinterpret_cast<const uint4*>(s + col);
 }
 
+// Set by the index-consuming kernels when they meet an id outside its table (nn.Embedding raises IndexError there,
+// mmf/modules/embeddings.py:329-345): the offending row is skipped (forward: written as zeros) instead of reading or, in the
+// backward, atomically WRITING out of bounds; mmf_amd_take_index_error() reports and clears the flag.
+__device__ int g_index_error = 0;
+DEVI void flag_index_error() { atomicOr(&g_index_error, 1); }
+
 DEVI int bucket_of(const int64_t* idx, int idx_ld, int per_pos, int idx_base, int b, int i) {
     if (idx) return (int)idx[(size_t)b * idx_ld + i];
     return per_pos ? i + idx_base : idx_base;
@@ -447,13 +460,14 @@ DEVI int bucket_of(const int64_t* idx, int idx_ld, int per_pos, int idx_base, in
 
 __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                   const int64_t* __restrict__ idx, int idx_ld, int per_pos,
-                                                                  int idx_base, float* __restrict__ out, int H, int skip) {
+                                                                  int idx_base, float* __restrict__ out, int H, int skip, int nbuckets) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= nb * rpb) return;
     const int b = r / rpb, i = r - b * rpb;
     const int bk = bucket_of(idx, idx_ld, per_pos, idx_base, b, i);
     if (bk == skip) return;
+    if (nbuckets > 0 && (bk < 0 || bk >= nbuckets)) { if (lane == 0) flag_index_error(); return; }
     const bf16* xr = x + ((size_t)b * bstride + i) * ld;
     float* o = out + (size_t)bk * H;
     for (int col = lane * 4; col < H; col += 256) {
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __r
 constexpr int FEW_GROUPS = 32;
 __global__ __launch_bounds__(256) void scatter_add_few_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                const int64_t* __restrict__ idx, int idx_ld, int per_pos,
-                                                               int idx_base, float* __restrict__ out, int H, float* __restrict__ partials) {
+                                                               int idx_base, float* __restrict__ out, int H, float* __restrict__ partials, int nbuckets) {
     __shared__ float red[4][2][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nb * rpb;
@@ -481,6 +495,7 @@ __global__ __launch_bounds__(256) void scatter_add_few_kernel(const bf16* __rest
             const f32x4 v = load4(x + ((size_t)b * bstride + i) * ld + col);
             if (bk == 0) a0 += v;
             else if (bk == 1) a1 += v;
+            else if (bk < 0 || bk >= nbuckets) { if (lane == 0) flag_index_error(); }
             else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(out + (size_t)bk * H + col + j, v[j]);
@@ -980,12 +995,20 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     return 0;
 }
 
+int mmf_amd_take_index_error(void) {
+    int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_index_error), sizeof(int)) != hipSuccess) { mmf_amd_set_error("take_index_error: copy failed"); return -1; }
+    if (v) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_index_error), &z, sizeof(int)); }
+    return v;
+}
+
 int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, void* y,
-                       int B, int T, int S, int H, int row0, int pos0, void* stream) {
+                       int B, int T, int S, int H, int row0, int pos0, int V, int P, int NT, void* stream) {
     MMF_CHECK_ARG(ids && word && pos && type && y, "embed_text_fwd: null operand");
     MMF_CHECK_ARG(B > 0 && T > 0 && row0 >= 0 && S >= row0 + T && pos0 >= 0 && (H % 4) == 0, "embed_text_fwd: bad shape");
+    MMF_CHECK_ARG(P <= 0 || pos0 + T <= P, "embed_text_fwd: sequence longer than the position table (max_position_embeddings)");
     hipLaunchKernelGGL(embed_text_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
-                       (bf16*)y, B, T, S, H, row0, pos0);
+                       (bf16*)y, B, T, S, H, row0, pos0, V, NT);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -1023,18 +1046,19 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
     MMF_CHECK_ARG(x && out, "rows_scatter_add: null operand");
     MMF_CHECK_ARG(!(few_buckets && skip_bucket >= 0), "rows_scatter_add: skip_bucket is for the atomic (large-table) form");
     MMF_CHECK_ARG(nb > 0 && rpb > 0 && (H % 4) == 0 && (ld % 4) == 0, "rows_scatter_add: bad shape");
+    MMF_CHECK_ARG(idx || nbuckets <= 0 || (per_pos ? idx_base + rpb <= nbuckets : idx_base < nbuckets), "rows_scatter_add: bucket outside the table");
     const int total = nb * rpb;
     if (few_buckets) {
         MMF_CHECK_ARG(ws && nbuckets >= 1, "rows_scatter_add: few_buckets needs a workspace and the bucket count");
         const int groups = grid_for(total, 4, FEW_GROUPS);
         hipLaunchKernelGGL(scatter_add_few_kernel, dim3(groups, (H + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld,
-                           nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, ws);
+                           nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, ws, nbuckets);
         MMF_CHECK_LAUNCH();
         hipLaunchKernelGGL(scatter_add_few_reduce_kernel, dim3((H + 255) / 256, nbuckets < 2 ? nbuckets : 2), dim3(256), 0,
                            (hipStream_t)stream, ws, groups, H, nbuckets, out);
     } else {
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                           ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, skip_bucket);
+                           ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, skip_bucket, nbuckets);
     }
     MMF_CHECK_LAUNCH();
     return 0;

@@ -489,6 +489,38 @@ def test_embed_text_and_scatter_add():
     close(dpv[0], d3[:, T:].sum((0, 1)), 1e-4, 1e-3, "dpos_visual")
 
 
+def test_embedding_indices_are_bounded_like_nn_embedding():
+    """nn.Embedding raises IndexError for an id outside its table; here the host cannot see device ids without a sync, so the
+    kernels skip the offending rows (forward: zero row; backward: no atomic write out of bounds) and raise a device flag that
+    `take_index_error()` reports.  A sequence longer than the position table is refused on the host."""
+    B, T, S, H, V = 2, 8, 8, 256, 50
+    word = rnd(V, H, dtype=torch.float32); pos = rnd(16, H, dtype=torch.float32); typ = rnd(2, H, dtype=torch.float32)
+    ids = torch.randint(0, V, (B, T), device=DEV); seg = torch.zeros(B, T, dtype=torch.int64, device=DEV)
+    y = torch.full((B * S, H), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert nat().take_index_error() is False
+    nat().embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H)
+    assert nat().take_index_error() is False
+    bad = ids.clone(); bad[1, 3] = V + 5; bad[0, 0] = -1
+    seg2 = seg.clone(); seg2[1, 6] = 2
+    nat().embed_text_fwd(bad, seg2, word, pos, typ, y, B, T, S, H)
+    assert nat().take_index_error() is True and nat().take_index_error() is False        # reported once, then cleared
+    yv = y.view(B, S, H).float()
+    assert float(yv[1, 3].abs().max()) == 0.0 and float(yv[0, 0].abs().max()) == 0.0 and float(yv[1, 6].abs().max()) == 0.0
+    close(yv[0, 1], word[ids[0, 1]] + pos[1] + typ[0], 1e-2, 1e-2, "in-range rows unaffected")
+    with pytest.raises(nat().NativeLibraryError):          # 8 positions starting at 12 overrun the 16-row position table
+        nat().embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H, 0, 12)
+    # backward: an index past the table must not be written anywhere
+    d = rnd(B * S, H)
+    guard = torch.zeros(V + 64, H, device=DEV)             # rows [V, V + 64) play the memory behind the table
+    nat().rows_scatter_add(d, H, B, T, S, bad, T, 0, 0, guard[:V], H, 0)
+    assert nat().take_index_error() is True
+    assert float(guard[V:].abs().max()) == 0.0
+    ok = torch.zeros(V, H, device=DEV)
+    keep = (bad >= 0) & (bad < V)
+    ok.index_add_(0, bad[keep], d.view(B, S, H)[:, :T][keep].float())
+    close(guard[:V], ok, 1e-4, 1e-4, "in-range rows still accumulate")
+
+
 def test_gather_scatter_colsum_cast():
     B, S, H = 8, 20, 768
     x = rnd(B * S, H); idx = torch.randint(0, S, (B,), device=DEV)

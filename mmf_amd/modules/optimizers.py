@@ -64,9 +64,7 @@ class AdamW(torch.optim.Optimizer):
             nat.optim_state_advance(self._dev_state, *self._schedule)
             dev_state = self._dev_state
         for group in self.param_groups:
-            items = []
-            step = group.get("step", 0) + 1
-            group["step"] = step
+            by_step = {}
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -74,16 +72,55 @@ class AdamW(torch.optim.Optimizer):
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
                 st = self.state[p]
                 if len(st) == 0:
+                    st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                # per-parameter step count, as transformers.AdamW keeps it (state["step"]): the bias correction of a parameter
+                # that first receives a gradient late starts at 1, and checkpoints exchange with the reference optimizer
+                st["step"] = int(st.get("step", 0)) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                items.append((p, g, st["exp_avg"], st["exp_avg_sq"], Fn.shadows.slot(p), group["lr"], group["weight_decay"]))
-            if not items:
-                continue
+                by_step.setdefault(st["step"], []).append(
+                    (p, g, st["exp_avg"], st["exp_avg_sq"], Fn.shadows.slot(p), group["lr"], group["weight_decay"]))
             b1, b2 = group["betas"]
             norm_sq, max_norm = self._clip if self._clip is not None else (None, 0.0)
-            nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
-                            1.0, norm_sq, max_norm, dev_state)
+            for step, items in sorted(by_step.items()):       # one launch per distinct step count (normally exactly one)
+                nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
+                                1.0, norm_sq, max_norm, dev_state)
         self._clip = None
         Fn.shadows.refresh_transposed()     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
         return loss
+
+    # ---- checkpoints ---------------------------------------------------------------------------------------------------
+    # `capturable=True` keeps the live step count and schedule factor on the device (they advance inside replayed hipGraphs,
+    # where this Python never runs): state_dict() reads them back so that a resumed run continues the bias correction and the
+    # warm-up where it stopped, and load_state_dict() seeds them — from this optimizer's own checkpoints or from a
+    # transformers.AdamW / reference checkpoint (per-parameter state["step"]).
+    def _device_step(self):
+        if self.capturable and self._dev_state is not None:
+            return int(round(float(self._dev_state[0].item())))
+        return None
+
+    def state_dict(self):
+        dstep = self._device_step()
+        if dstep is not None:
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = dstep
+        sd = super().state_dict()
+        if self.capturable and self._dev_state is not None:
+            sd["mmf_amd_dev_state"] = self._dev_state.detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        dev = state_dict.pop("mmf_amd_dev_state", None)
+        super().load_state_dict(state_dict)
+        steps = [int(st["step"]) for st in self.state.values() if "step" in st]
+        if self.capturable:
+            device = self.param_groups[0]["params"][0].device
+            if dev is not None:
+                self._dev_state = dev.to(device=device, dtype=torch.float32).clone()
+            elif steps:
+                # a checkpoint written by the reference optimizer: the device counter continues from its step count; the
+                # schedule factor is re-derived by the next optimizer_state_advance
+                self._dev_state = torch.tensor([float(max(steps)), 1.0], dtype=torch.float32, device=device)

@@ -640,6 +640,69 @@ def test_multi_tensor_adamw_optimizer_matches_reference_rules():
         close(p.detach(), q, 2e-5, 2e-6, "adamw multi (transformers rule)")
 
 
+@pytest.mark.parametrize("capturable", [False, True])
+def test_optimizer_checkpoint_resumes_step_count_and_schedule(capturable):
+    """state_dict() carries a per-parameter `step` (the transformers.AdamW format) and, for the capturable form, the device
+    words that hold the live step count / warm-up factor: 2 updates + checkpoint + 2 updates in a NEW optimizer equal 4
+    uninterrupted updates; a reference-format checkpoint (no device words) resumes at its step count; a parameter that
+    gets its first gradient late starts its own bias correction at step 1."""
+    from mmf_amd.modules.optimizers import AdamW
+    gen = torch.Generator().manual_seed(9)
+    base = [torch.randn(40, 33, generator=gen).to(DEV), torch.randn(257, generator=gen).to(DEV), torch.randn(8, 8, generator=gen).to(DEV)]
+    grads = [[torch.randn(b.shape, generator=gen).to(DEV) for b in base] for _ in range(4)]
+    kw = dict(lr=2e-3, weight_decay=0.01, capturable=capturable)
+    if capturable:
+        kw["schedule"] = ("warmup_linear", 3.0, 10.0)
+
+    def run(opt, ps, steps):
+        for gs in steps:
+            for p, g in zip(ps, gs):
+                p.grad = g.clone()
+            opt.step()
+
+    a = [b.clone().requires_grad_(True) for b in base]
+    oa = AdamW(a, **kw)
+    run(oa, a, grads)
+    b = [x.clone().requires_grad_(True) for x in base]
+    ob = AdamW(b, **kw)
+    run(ob, b, grads[:2])
+    ck = ob.state_dict()
+    assert all(int(st["step"]) == 2 for st in ck["state"].values())
+    assert ("mmf_amd_dev_state" in ck) == capturable
+    # a checkpoint in the reference optimizer's format (per-parameter step, no device words); cloned now: torch's
+    # load_state_dict keeps tensors that already have the right dtype / device, so `oc` below shares `ck`'s moments
+    ref_ck = {"state": {i: {"step": 2, "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()} for i, st in ck["state"].items()},
+              "param_groups": ck["param_groups"]}
+    import copy
+    c = [x.detach().clone().requires_grad_(True) for x in b]
+    oc = AdamW(c, **kw)
+    oc.load_state_dict(copy.deepcopy(ck))
+    run(oc, c, grads[2:])
+    for p, q in zip(a, c):
+        close(q.detach(), p.detach(), 1e-6, 1e-7, "resumed == uninterrupted")
+    d = [x.detach().clone().requires_grad_(True) for x in b]
+    od = AdamW(d, **kw)
+    od.load_state_dict(ref_ck)
+    run(od, d, grads[2:])
+    for p, q in zip(a, d):
+        close(q.detach(), p.detach(), 1e-6, 1e-7, "resumed from a reference-format checkpoint")
+    if not capturable:
+        # late first gradient: its own step count starts at 1 (bias correction of a fresh Adam state)
+        e = [x.clone().requires_grad_(True) for x in base]
+        oe = AdamW(e, lr=2e-3, weight_decay=0.0)
+        for k in range(2):
+            e[0].grad = grads[k][0].clone(); e[1].grad = grads[k][1].clone(); e[2].grad = None
+            oe.step()
+        e[2].grad = grads[2][2].clone(); e[0].grad = None; e[1].grad = None
+        oe.step()
+        f = [base[2].clone().requires_grad_(True)]
+        of = AdamW(f, lr=2e-3, weight_decay=0.0)
+        f[0].grad = grads[2][2].clone()
+        of.step()
+        close(e[2].detach(), f[0].detach(), 1e-6, 1e-7, "late parameter")
+        assert oe.state[e[2]]["step"] == 1 and oe.state[e[0]]["step"] == 2
+
+
 def test_optimizer_refreshes_bf16_shadows_in_place():
     """After a fused step the cached bf16 weight shadow equals bf16(new fp32 master) without a re-cast."""
     from mmf_amd import functional as Fn

@@ -13,10 +13,12 @@ MI355X-first differences, all internal:
     discards it at :389-398); its parameters still exist and simply receive no gradient, exactly as
     in the reference.
 """
-import torch
-from torch import nn
+from typing import Dict, List, Optional, Tuple
 
-from mmf_amd import functional as Fn
+import torch
+from torch import Tensor, nn
+
+from mmf_amd import ops  # noqa: F401  (registers torch.ops.mmf_amd.*)
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
 from mmf_amd.modules.embeddings import BertVisioLinguisticEmbeddings
@@ -57,30 +59,32 @@ class VisualBERTBase(nn.Module):
     def init_weights(self):
         self.apply(self._init_weights)
 
-    def forward(self, input_ids, attention_mask=None, token_type_ids=None, visual_embeddings=None,
-                visual_embeddings_type=None, image_text_alignment=None):
+    def forward(self, input_ids: Tensor, attention_mask: Optional[Tensor] = None, token_type_ids: Optional[Tensor] = None,
+                visual_embeddings: Optional[Tensor] = None, visual_embeddings_type: Optional[Tensor] = None,
+                image_text_alignment: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], List[Tensor]]:
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         # additive mask (1 - m) * -10000, visual_bert.py:94-106, built by a HIP kernel as fp32 [B, S]
-        am = attention_mask.contiguous()
-        if am.dtype != torch.int64:
-            am = am.long()
-        mask_add = torch.empty(am.shape, dtype=torch.float32, device=am.device)
-        Fn.nat.make_additive_mask(am, mask_add)
-        extended_attention_mask = mask_add.view(am.shape[0], 1, 1, am.shape[1])
+        mask_add = torch.ops.mmf_amd.additive_mask(attention_mask)
+        extended_attention_mask = mask_add.view(mask_add.shape[0], 1, 1, mask_add.shape[1])
 
         embedding_output = self.embeddings(input_ids, token_type_ids, visual_embeddings=visual_embeddings,
                                            visual_embeddings_type=visual_embeddings_type,
                                            image_text_alignment=image_text_alignment)
         if self.bypass_transformer and visual_embeddings is not None:
             raise NotImplementedError("bypass_transformer (visual_bert.py:116-141) needs a [B,1,S,S] mask; not built yet")
-        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
-                                      output_hidden_states=self.output_hidden_states)
-        sequence_output = encoded_layers[0]
-        pooled_output = None if self.skip_pooler else self.pooler(sequence_output)
-        return sequence_output, pooled_output, []
+        hidden: List[Tensor] = []
+        if torch.jit.is_scripting():
+            sequence_output = self.encoder(embedding_output, extended_attention_mask)[0]
+        else:
+            encoded_layers = self.encoder(embedding_output, extended_attention_mask, output_hidden_states=self.output_hidden_states)
+            sequence_output = encoded_layers[0]
+        pooled_output: Optional[Tensor] = None
+        if not self.skip_pooler:
+            pooled_output = self.pooler(sequence_output)
+        return sequence_output, pooled_output, hidden
 
 
 class VisualBERTForClassification(nn.Module):
@@ -123,25 +127,29 @@ class VisualBERTForClassification(nn.Module):
                 if "bce" in loss["type"]:
                     self.classifier[1].bias.data.fill_(self.config.biasfill)
 
-    def forward(self, input_ids, input_mask, attention_mask=None, token_type_ids=None, visual_embeddings=None,
-                visual_embeddings_type=None, image_text_alignment=None, masked_lm_labels=None):
+    def forward(self, input_ids: Tensor, input_mask: Tensor, attention_mask: Optional[Tensor] = None,
+                token_type_ids: Optional[Tensor] = None, visual_embeddings: Optional[Tensor] = None,
+                visual_embeddings_type: Optional[Tensor] = None, image_text_alignment: Optional[Tensor] = None,
+                masked_lm_labels: Optional[Tensor] = None) -> Dict[str, Tensor]:
         sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
                                                       visual_embeddings_type, image_text_alignment)
         if self.training_head_type == "nlvr2":
-            pooled_output = Fn.PairHalvesFn.apply(pooled_output)       # 2B x H -> B x 2H, visual_bert.py:369-374
-        output_dict = {}
+            assert pooled_output is not None
+            pooled_output = torch.ops.mmf_amd.pair_halves(pooled_output)       # 2B x H -> B x 2H, visual_bert.py:369-374
+        output_dict: Dict[str, Tensor] = {}
         if self.output_hidden_states:
             output_dict["sequence_output"] = sequence_output
-            output_dict["pooled_output"] = pooled_output
-        drop = Fn.make_drop(self.dropout_prob, self.training)
+            if pooled_output is not None:
+                output_dict["pooled_output"] = pooled_output
         if self.pooler_strategy == "vqa":
             # representation of the second-to-last text token (visual_bert.py:389-398) + dropout (:400)
             index_to_gather = input_mask.sum(1) - 2
-            pooled = Fn.GatherRowsFn.apply(sequence_output, index_to_gather, drop)
+            pooled = torch.ops.mmf_amd.gather_rows(sequence_output, index_to_gather, self.dropout_prob, self.training)
         else:
-            pooled = Fn.DropoutFn.apply(pooled_output, drop) if drop[1] else pooled_output
+            assert pooled_output is not None
+            pooled = torch.ops.mmf_amd.dropout(pooled_output, self.dropout_prob, self.training)
         hidden = self.classifier[0](pooled)
-        logits = self.classifier[1](hidden, out_f32=True)
+        logits = self.classifier[1](hidden, True)
         output_dict["scores"] = logits.contiguous().view(-1, self.num_labels)
         return output_dict
 
@@ -178,22 +186,29 @@ class VisualBERT(BaseModel):
                 .replace("bert.classifier", "model.classifier"))
 
     # ---- input massaging, visual_bert.py:444-556 ------------------------------------------------
-    def update_sample_list_based_on_head(self, sample_list):
+    def update_sample_list_based_on_head(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
         bert_input_ids, bert_input_mask = sample_list["input_ids"], sample_list["input_mask"]
         bert_input_type_ids = sample_list["segment_ids"]
+        image_dim_variable: Optional[Tensor] = None
         if self.training_head_type == "nlvr2":          # visual_bert.py:490-514: text repeated, the two images stacked
-            bert_input_ids = torch.cat([bert_input_ids, bert_input_ids])
-            bert_input_mask = torch.cat([bert_input_mask, bert_input_mask])
-            bert_input_type_ids = torch.cat([bert_input_type_ids, bert_input_type_ids])
-            img0, img1 = sample_list.get("img0", None) or {}, sample_list.get("img1", None) or {}
-            image_feat_variable = torch.cat([img0["image_feature_0"], img1["image_feature_0"]])
-            d0 = (img0.get("image_info_0", None) or {}).get("max_features", None)
-            d1 = (img1.get("image_info_0", None) or {}).get("max_features", None)
-            image_dim_variable = torch.cat([d0, d1]) if d0 is not None and d1 is not None else None
+            if not torch.jit.is_scripting():
+                bert_input_ids = torch.cat([bert_input_ids, bert_input_ids])
+                bert_input_mask = torch.cat([bert_input_mask, bert_input_mask])
+                bert_input_type_ids = torch.cat([bert_input_type_ids, bert_input_type_ids])
+                img0, img1 = sample_list.get("img0", None) or {}, sample_list.get("img1", None) or {}
+                image_feat_variable = torch.cat([img0["image_feature_0"], img1["image_feature_0"]])
+                d0 = (img0.get("image_info_0", None) or {}).get("max_features", None)
+                d1 = (img1.get("image_info_0", None) or {}).get("max_features", None)
+                image_dim_variable = torch.cat([d0, d1]) if d0 is not None and d1 is not None else None
+            else:
+                raise RuntimeError("nlvr2 head doesn't support scripting as of now")
         else:
-            image_info = sample_list.get("image_info_0", None) or {}
-            image_dim_variable = image_info.get("max_features", None)
-            image_feat_variable = sample_list.get("image_feature_0", None)
+            if not torch.jit.is_scripting():
+                image_info = sample_list.get("image_info_0", None) or {}
+                image_dim_variable = image_info.get("max_features", None)
+                image_feat_variable = sample_list.get("image_feature_0", None)
+            else:
+                image_feat_variable = sample_list["image_feature_0"]      # (a Dict[str, Tensor] cannot nest image_info_0)
         sample_list["input_ids"], sample_list["input_mask"] = bert_input_ids, bert_input_mask
         sample_list["segment_ids"] = bert_input_type_ids
         if image_dim_variable is None:
@@ -204,7 +219,7 @@ class VisualBERT(BaseModel):
         sample_list["token_type_ids"] = sample_list["segment_ids"]
         return sample_list
 
-    def add_custom_params(self, sample_list):
+    def add_custom_params(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
         visual_embeddings = sample_list["visual_embeddings"]
         image_dim = sample_list["image_dim"]
         image_mask = torch.arange(visual_embeddings.size(-2), device=visual_embeddings.device).expand(
@@ -214,16 +229,24 @@ class VisualBERT(BaseModel):
         sample_list["image_mask"] = (image_mask < image_dim).long()
         return sample_list
 
-    def add_post_flatten_params(self, sample_list):
+    def add_post_flatten_params(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
         sample_list["visual_embeddings_type"] = torch.zeros_like(sample_list["image_mask"])
         sample_list["attention_mask"] = torch.cat((sample_list["input_mask"], sample_list["image_mask"]), dim=-1)
         return sample_list
 
-    def forward(self, sample_list):
+    def forward(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        if torch.jit.is_scripting():
+            assert "image_feature_0" in sample_list, "Key 'image_feature_0' is required in TorchScript model"
         sample_list = self.update_sample_list_based_on_head(sample_list)
         sample_list = self.add_custom_params(sample_list)
         sample_list = self.add_post_flatten_params(sample_list)
+        image_text_alignment: Optional[Tensor] = None
+        masked_lm_labels: Optional[Tensor] = None
+        if "image_text_alignment" in sample_list:
+            image_text_alignment = sample_list["image_text_alignment"]
+        if "masked_lm_labels" in sample_list:
+            masked_lm_labels = sample_list["masked_lm_labels"]
         return self.model(
             sample_list["input_ids"], sample_list["input_mask"], sample_list["attention_mask"],
             sample_list["token_type_ids"], sample_list["visual_embeddings"], sample_list["visual_embeddings_type"],
-            sample_list.get("image_text_alignment", None), sample_list.get("masked_lm_labels", None))
+            image_text_alignment, masked_lm_labels)

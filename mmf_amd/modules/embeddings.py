@@ -3,9 +3,10 @@ and a single fused forward: text rows (gather + sum), visual rows (fp32 features
 with bias / type / position added in the epilogue) written into one `[B, T+R, H]` buffer, LayerNorm,
 dropout — all gfx950 kernels (mmf_amd.functional.VisioLinguisticEmbeddingsFn)."""
 from copy import deepcopy
+from typing import Optional
 
 import torch
-from torch import nn
+from torch import Tensor, nn
 
 from mmf_amd import functional as Fn
 from mmf_amd.modules.hf_layers import LayerNorm, Linear
@@ -21,6 +22,7 @@ class BertVisioLinguisticEmbeddings(nn.Module):
         self.token_type_embeddings = nn.Embedding(config.type_vocab_size, H)
         self.LayerNorm = LayerNorm(H, eps=config.layer_norm_eps)
         self.dropout_prob = config.hidden_dropout_prob
+        self.pad_idx = -1 if self.word_embeddings.padding_idx is None else int(self.word_embeddings.padding_idx)
         # visual members (:312-319)
         self.token_type_embeddings_visual = nn.Embedding(config.type_vocab_size, H)
         self.position_embeddings_visual = nn.Embedding(config.max_position_embeddings, H)
@@ -33,18 +35,16 @@ class BertVisioLinguisticEmbeddings(nn.Module):
         self.position_embeddings_visual.weight = nn.Parameter(
             deepcopy(self.position_embeddings.weight.data), requires_grad=True)
 
-    def forward(self, input_ids, token_type_ids=None, visual_embeddings=None, visual_embeddings_type=None,
-                image_text_alignment=None):
+    def forward(self, input_ids: Tensor, token_type_ids: Optional[Tensor] = None, visual_embeddings: Optional[Tensor] = None,
+                visual_embeddings_type: Optional[Tensor] = None, image_text_alignment: Optional[Tensor] = None) -> Tensor:
         if image_text_alignment is not None:
             raise NotImplementedError("image_text_alignment (embeddings.py:376-410) is not on the VQA2 path")
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
-        if visual_embeddings is None or visual_embeddings_type is None:
-            visual_embeddings = visual_embeddings_type = None
-        return Fn.VisioLinguisticEmbeddingsFn.apply(
+        pad = self.pad_idx
+        return torch.ops.mmf_amd.visio_linguistic_embeddings(
             input_ids, token_type_ids, visual_embeddings, visual_embeddings_type,
             self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
             self.LayerNorm.weight, self.LayerNorm.bias, self.token_type_embeddings_visual.weight,
             self.position_embeddings_visual.weight, self.projection.weight, self.projection.bias,
-            Fn.shadows.get(self.projection.weight), self.LayerNorm.eps, Fn.make_drop(self.dropout_prob, self.training),
-            self.word_embeddings.padding_idx)
+            self.LayerNorm.eps, self.dropout_prob, self.training, pad)

@@ -7,10 +7,13 @@ BertIntermediate, BertOutput, BertPooler, BertPredictionHeadTransform).
 unmodified.  Activations are bf16 `[B, S, H]` tensors in HBM; every forward and backward is a
 hand-written gfx950 kernel (mmf_amd/functional.py).  There is no eager fallback.
 """
+from typing import List, Optional, Tuple
+
 import torch
-from torch import nn
+from torch import Tensor, nn
 
 from mmf_amd import functional as Fn
+from mmf_amd import ops  # noqa: F401  (registers torch.ops.mmf_amd.*)
 
 
 class BertConfig:
@@ -42,8 +45,8 @@ class Linear(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_features, in_features))
         self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
 
-    def forward(self, x, out_f32=False):
-        return Fn.linear(x, self.weight, self.bias, out_f32)
+    def forward(self, x: Tensor, out_f32: bool = False) -> Tensor:
+        return torch.ops.mmf_amd.linear(x, self.weight, self.bias, out_f32)
 
 
 class Dropout(nn.Module):
@@ -53,9 +56,8 @@ class Dropout(nn.Module):
         super().__init__()
         self.p = p
 
-    def forward(self, x):
-        drop = Fn.make_drop(self.p, self.training)
-        return Fn.DropoutFn.apply(x, drop) if drop[1] else x
+    def forward(self, x: Tensor) -> Tensor:
+        return torch.ops.mmf_amd.dropout(x, self.p, self.training)
 
 
 class LayerNorm(nn.Module):
@@ -65,8 +67,8 @@ class LayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(hidden_size))
         self.eps = eps
 
-    def forward(self, x):
-        return Fn.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+    def forward(self, x: Tensor) -> Tensor:
+        return torch.ops.mmf_amd.layer_norm(x, self.weight, self.bias, self.eps)
 
 
 def init_bert_weights(module, std=0.02):
@@ -127,6 +129,7 @@ class BertSelfAttentionJit(nn.Module):
         b32 = Fn.shadows.get(self.query.bias, self.key.bias, self.value.bias, dtype=torch.float32)
         return w16, b32
 
+    @torch.jit.unused      # (a scripted BertLayerJit calls torch.ops.mmf_amd.transformer_layer; this sub-module forward stays eager-only)
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None):
         if head_mask is not None or encoder_hidden_states is not None:
@@ -149,6 +152,7 @@ class BertSelfOutput(nn.Module):
         self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.dropout_prob = config.hidden_dropout_prob
 
+    @torch.jit.unused      # (a scripted BertLayerJit calls torch.ops.mmf_amd.transformer_layer; this sub-module forward stays eager-only)
     def forward(self, hidden_states, input_tensor):
         drop = Fn.make_drop(self.dropout_prob, self.training)
         return Fn.DenseDropoutResidualLNFn.apply(hidden_states, input_tensor, self.dense.weight, self.dense.bias,
@@ -165,6 +169,7 @@ class BertIntermediate(nn.Module):
             raise ValueError("only hidden_act == 'gelu' is implemented")
         self.dense = Linear(config.hidden_size, config.intermediate_size)
 
+    @torch.jit.unused      # (a scripted BertLayerJit calls torch.ops.mmf_amd.transformer_layer; this sub-module forward stays eager-only)
     def forward(self, hidden_states):
         return Fn.DenseGeluFn.apply(hidden_states, self.dense.weight, self.dense.bias, Fn.shadows.get(self.dense.weight))
 
@@ -178,6 +183,7 @@ class BertOutput(nn.Module):
         self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.dropout_prob = config.hidden_dropout_prob
 
+    @torch.jit.unused      # (a scripted BertLayerJit calls torch.ops.mmf_amd.transformer_layer; this sub-module forward stays eager-only)
     def forward(self, hidden_states, input_tensor):
         drop = Fn.make_drop(self.dropout_prob, self.training)
         return Fn.DenseDropoutResidualLNFn.apply(hidden_states, input_tensor, self.dense.weight, self.dense.bias,
@@ -193,6 +199,7 @@ class BertAttentionJit(nn.Module):
         self.self = BertSelfAttentionJit(config)
         self.output = BertSelfOutput(config)
 
+    @torch.jit.unused      # (a scripted BertLayerJit calls torch.ops.mmf_amd.transformer_layer; this sub-module forward stays eager-only)
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None):
         if head_mask is not None or encoder_hidden_states is not None:
@@ -218,22 +225,36 @@ class BertLayerJit(nn.Module):
         self.intermediate = BertIntermediate(config)
         self.output = BertOutput(config)
 
-    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
-                encoder_attention_mask=None):
+    def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None,
+                encoder_hidden_states: Optional[Tensor] = None, encoder_attention_mask: Optional[Tensor] = None) -> Tuple[Tensor]:
+        """One `torch.ops.mmf_amd.transformer_layer` call.  `attention_mask`: the additive mask the reference hands the encoder,
+        `[B, 1, 1, S]` (visual_bert.py:94-106) or already `[B, S]`; eager callers may pass M4C's prefix-LM mask as a
+        `functional.PrefixLMMask` (key mask + number of causally visible decoding steps, m4c.py:424-440)."""
         if head_mask is not None or encoder_hidden_states is not None:
             raise NotImplementedError("head_mask / cross-attention are not on the VisualBERT path")
-        B, S, _ = hidden_states.shape
-        at, it, ot = self.attention, self.intermediate, self.output
-        sa, so = at.self, at.output
-        w16, b32 = sa.packed_qkv()
-        layer_output = Fn.TransformerLayerFn.apply(
+        B, S = hidden_states.shape[0], hidden_states.shape[1]
+        causal_tail = 0
+        if not torch.jit.is_scripting():
+            if isinstance(attention_mask, Fn.PrefixLMMask):
+                causal_tail = attention_mask.causal_tail
+                attention_mask = attention_mask.key_mask
+        mask_add: Optional[Tensor] = None
+        if attention_mask is not None:
+            m = attention_mask
+            if m.dim() == 4:
+                if m.shape[1] != 1 or m.shape[2] != 1:
+                    raise NotImplementedError("a materialised per-query mask [B,1,S,S] is not read by the fused kernel; for M4C's "
+                                              "prefix-LM mask pass mmf_amd.functional.PrefixLMMask(key_mask, dec_steps)")
+                m = m.reshape(B, S)
+            mask_add = m.float().contiguous()
+        sa, so = self.attention.self, self.attention.output
+        it, ot = self.intermediate, self.output
+        layer_output = torch.ops.mmf_amd.transformer_layer(
             hidden_states, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
             so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias,
             it.dense.weight, it.dense.bias, ot.dense.weight, ot.dense.bias, ot.LayerNorm.weight, ot.LayerNorm.bias,
-            w16, b32, Fn.shadows.get(so.dense.weight), Fn.shadows.get(it.dense.weight), Fn.shadows.get(ot.dense.weight),
-            additive_key_mask(attention_mask, B, S), sa.num_attention_heads, so.LayerNorm.eps, ot.LayerNorm.eps,
-            Fn.make_drop(sa.dropout_prob, self.training), Fn.make_drop(so.dropout_prob, self.training),
-            Fn.make_drop(ot.dropout_prob, self.training))
+            mask_add, sa.num_attention_heads, so.LayerNorm.eps, ot.LayerNorm.eps,
+            sa.dropout_prob, so.dropout_prob, ot.dropout_prob, self.training, causal_tail)
         return (layer_output,)
 
 
@@ -246,20 +267,24 @@ class BertEncoderJit(nn.Module):
         self.output_hidden_states = getattr(config, "output_hidden_states", False)
         self.layer = nn.ModuleList([BertLayerJit(config) for _ in range(config.num_hidden_layers)])
 
-    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
-                output_attentions=False, output_hidden_states=False, return_dict=False, head_mask=None):
+    def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, encoder_hidden_states: Optional[Tensor] = None,
+                encoder_attention_mask: Optional[Tensor] = None, output_attentions: bool = False,
+                output_hidden_states: bool = False, return_dict: bool = False, head_mask: Optional[Tensor] = None) -> Tuple[Tensor]:
+        """Typed like the reference's scriptable encoder (hf_layers.py:317-355): `Tuple[Tensor]` under TorchScript; the eager
+        call appends the tuple of all hidden states when `output_hidden_states` is set."""
         if output_attentions:
             raise NotImplementedError("attention probabilities are not materialised by the fused kernel")
         all_hidden_states = ()
         for layer_module in self.layer:
-            if output_hidden_states:
+            if not torch.jit.is_scripting() and output_hidden_states:
                 all_hidden_states = all_hidden_states + (hidden_states,)
             hidden_states = layer_module(hidden_states, attention_mask, None, encoder_hidden_states, encoder_attention_mask)[0]
-        if output_hidden_states:
+        if not torch.jit.is_scripting() and output_hidden_states:
             all_hidden_states = all_hidden_states + (hidden_states,)
         outputs = (hidden_states,)
-        if output_hidden_states:
-            outputs = outputs + (all_hidden_states,)
+        if not torch.jit.is_scripting():
+            if output_hidden_states:
+                outputs = outputs + (all_hidden_states,)
         return outputs
 
 
@@ -271,12 +296,12 @@ class BertPooler(nn.Module):
         super().__init__()
         self.dense = Linear(config.hidden_size, config.hidden_size)
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states: Tensor) -> Tensor:
         # row 0 of every sample (gather kernel), then dense + tanh in one GEMM epilogue
         B = hidden_states.shape[0]
         index = torch.zeros(B, dtype=torch.int64, device=hidden_states.device)
-        first = Fn.GatherRowsFn.apply(hidden_states, index, Fn.nat.NO_DROP)
-        return Fn.LinearTanhFn.apply(first, self.dense.weight, self.dense.bias, Fn.shadows.get(self.dense.weight))
+        first = torch.ops.mmf_amd.gather_rows(hidden_states, index, 0.0, False)
+        return torch.ops.mmf_amd.linear_tanh(first, self.dense.weight, self.dense.bias)
 
 
 class BertEmbeddingsJit(nn.Module):
@@ -337,6 +362,6 @@ class BertPredictionHeadTransform(nn.Module):
         self.dense = Linear(config.hidden_size if in_dim is None else in_dim, config.hidden_size)
         self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
 
-    def forward(self, hidden_states):
-        h = Fn.DenseGeluFn.apply(hidden_states, self.dense.weight, self.dense.bias, Fn.shadows.get(self.dense.weight))
+    def forward(self, hidden_states: Tensor) -> Tensor:
+        h = torch.ops.mmf_amd.dense_gelu(hidden_states, self.dense.weight, self.dense.bias)
         return self.LayerNorm(h)

@@ -24,6 +24,7 @@ class Losses(nn.Module):
         for loss in loss_list:
             self.losses.append(MMFLoss(loss))
 
+    @torch.jit.unused      # losses are attached by BaseModel.__call__ (base_model.py:305-337), outside the scripted forward
     def forward(self, sample_list, model_output):
         output = {}
         if "targets" not in sample_list:
@@ -59,6 +60,7 @@ class MMFLoss(nn.Module):
         loss_params = params.get("params", {}) if is_mapping else {}
         self.loss_criterion = loss_class(**loss_params)
 
+    @torch.jit.unused      # losses are attached by BaseModel.__call__ (base_model.py:305-337), outside the scripted forward
     def forward(self, sample_list, model_output):
         loss_dict = {}
         datasets = getattr(self.loss_criterion, "datasets", None)
@@ -82,6 +84,7 @@ class MMFLoss(nn.Module):
 class LogitBinaryCrossEntropy(nn.Module):
     """mean(BCEWithLogits(scores, targets)) * targets.size(1)   (losses.py:225-251)."""
 
+    @torch.jit.unused      # losses are attached by BaseModel.__call__ (base_model.py:305-337), outside the scripted forward
     def forward(self, sample_list, model_output):
         return Fn.LogitBCEFn.apply(model_output["scores"], sample_list["targets"])
 
@@ -98,6 +101,7 @@ class CrossEntropyLoss(nn.Module):
             raise NotImplementedError("cross_entropy: only ignore_index / reduction='mean' are built (got %s)" % sorted(params))
         self.ignore_index = int(params.get("ignore_index", -100))
 
+    @torch.jit.unused      # losses are attached by BaseModel.__call__ (base_model.py:305-337), outside the scripted forward
     def forward(self, sample_list, model_output):
         return Fn.CrossEntropyFn.apply(model_output["scores"], sample_list["targets"], self.ignore_index)
 
@@ -106,6 +110,7 @@ class CrossEntropyLoss(nn.Module):
 class M4CDecodingBCEWithMaskLoss(nn.Module):
     """losses.py:575-592: BCE over the decoding steps, weighted by `train_loss_mask`, normalised by max(sum(mask), 1)."""
 
+    @torch.jit.unused      # losses are attached by BaseModel.__call__ (base_model.py:305-337), outside the scripted forward
     def forward(self, sample_list, model_output):
         scores = model_output["scores"]
         targets = sample_list["targets"]

@@ -1,0 +1,75 @@
+"""Eager == TorchScript on the HIP path, the reference's own check (tests/models/test_visual_bert.py:43-49 ->
+tests/test_utils.py:270-285: random ids [1, 128], features [1, 100, 2048], `torch.allclose` on the scores), plus what the
+custom-op boundary promises: gradients flow through the scripted module and match the eager ones, the scripted module survives
+`torch.jit.save` / `load`, and the ops refuse host tensors."""
+import io
+
+import pytest
+import torch
+
+from oracle import visual_bert_oracle as O
+from tests.golden_utils import load_case
+from tests.model_utils import build_visual_bert, sample_to
+from mmf_amd.common.sample import SampleList
+
+pytestmark = pytest.mark.gpu
+
+
+def _tensors_only(sample):
+    return {k: v for k, v in sample.items() if isinstance(v, torch.Tensor)}
+
+
+def test_scripted_visual_bert_equals_eager_like_the_reference_test():
+    cfg = dict(O.DEFAULT_CONFIG)
+    cfg["num_hidden_layers"] = 2
+    cfg["num_labels"] = 2
+    model = build_visual_bert(cfg, O.init_state_dict(cfg, seed=3)).eval()
+    g = torch.Generator().manual_seed(0)
+    sample = {"input_ids": torch.randint(0, 30255, (1, 128), generator=g), "input_mask": torch.ones(1, 128, dtype=torch.long),
+              "segment_ids": torch.zeros(1, 128, dtype=torch.long), "image_feature_0": torch.rand(1, 100, 2048, generator=g)}
+    batch = sample_to(sample, "cuda")
+    with torch.no_grad():
+        eager = model(SampleList(dict(batch)))["scores"]
+    scripted = torch.jit.script(model)
+    with torch.no_grad():
+        out = scripted(dict(batch))["scores"]
+    assert torch.allclose(eager, out)
+    assert torch.equal(eager, out)                     # same kernels, same launches: bit-identical, not just close
+    buf = io.BytesIO()
+    torch.jit.save(scripted, buf)
+    buf.seek(0)
+    loaded = torch.jit.load(buf, map_location="cuda")
+    with torch.no_grad():
+        again = loaded(dict(batch))["scores"]
+    assert torch.equal(again, eager)
+
+
+def test_gradients_flow_through_the_scripted_model_and_match_eager():
+    z, case, cfg, sd, sample = load_case("small64")
+    model = build_visual_bert(cfg, sd).eval()
+    batch = sample_to(_tensors_only(sample), "cuda")
+    batch["image_feature_0"] = batch["image_feature_0"].contiguous()
+    out = model(SampleList(dict(batch, targets=sample["targets"].cuda(), dataset_name="vqa2", dataset_type="train")))
+    out["scores"].float().square().sum().backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    scripted = torch.jit.script(model)
+    s = scripted(dict(batch))["scores"]
+    s.float().square().sum().backward()
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref) and len(ref) > 30
+    for n in ref:
+        assert torch.equal(got[n], ref[n]), n
+
+
+def test_ops_refuse_host_tensors_and_wrong_dtypes():
+    from mmf_amd._native import NativeLibraryError
+    x = torch.randn(4, 256)
+    with pytest.raises((NativeLibraryError, RuntimeError)):
+        torch.ops.mmf_amd.layer_norm(x, torch.ones(256), torch.zeros(256), 1e-12)
+    xc = torch.randn(4, 256, device="cuda")
+    with pytest.raises((NativeLibraryError, RuntimeError)):      # gamma must be fp32 in HBM
+        torch.ops.mmf_amd.layer_norm(xc, torch.ones(256, device="cuda", dtype=torch.float16), torch.zeros(256, device="cuda"), 1e-12)
+    y = torch.ops.mmf_amd.layer_norm(xc, torch.ones(256, device="cuda"), torch.zeros(256, device="cuda"), 1e-12)
+    ref = torch.nn.functional.layer_norm(xc.bfloat16().float(), (256,))
+    assert float((y.float() - ref).abs().max()) < 3e-2

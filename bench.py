@@ -92,48 +92,63 @@ def synthetic_batch(batch, rank, device):
     return sl.to(device)
 
 
-class GemmProbe:
-    """Times every mmf_gemm_bf16 / mmf_gemm_bf16_grouped launch of ONE step with HIP events on the launch stream."""
+class KernelProbe:
+    """Times every GEMM, attention and LayerNorm launch of ONE step with HIP events on the launch stream (the stream the
+    kernels are launched on is torch's current stream).  GEMM launches are labelled with the kernel family the C side picked."""
 
     def __init__(self):
-        self.rec = []
+        self.rec = []      # (family, flops or bytes, e0, e1)
+
+    def _timed(self, orig, label_of, work_of):
+        def wrapper(*a, **kw):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **kw)
+            e1.record()
+            self.rec.append((label_of(*a, **kw), work_of(*a, **kw), e0, e1))
+            return r
+        return wrapper
 
     def __enter__(self):
         from mmf_amd import _native as nat
-        self.nat, self.orig, self.orig_grouped = nat, nat.gemm, nat.gemm_grouped
+        self.nat = nat
+        self.saved = {n: getattr(nat, n) for n in ("gemm", "gemm_grouped", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd")}
 
-        def timed(A, B, C_out, M, N, K, *a, **kw):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.orig(A, B, C_out, M, N, K, *a, **kw)
-            e1.record()
-            variant = "%s%s%s" % ("T" if kw.get("a_kmajor") else "N", "N" if kw.get("b_kmajor") else "T",
-                                  "_ragged" if (M % 128 or N % 128 or K % 64) else "")
-            self.rec.append((variant, (M, N, K), 2.0 * M * N * K, e0, e1))
+        def gemm_label(A, B, C_out, M, N, K, *a, **kw):
+            form = "%s%s" % ("T" if kw.get("a_kmajor") else "N", "N" if kw.get("b_kmajor") else "T")
+            return "gemm %s | %s%s" % (form, nat.gemm_last_kernel(), " (ragged / small)" if (M % 128 or N % 32 or K % 64 or M < 512) else "")
 
-        def timed_grouped(problems):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.orig_grouped(problems)
-            e1.record()
-            p0 = problems[0]
-            variant = "%s%s_grouped" % ("T" if p0.get("a_kmajor") else "N", "N" if p0.get("b_kmajor") else "T")
-            self.rec.append((variant, None, sum(2.0 * p["M"] * p["N"] * p["K"] for p in problems), e0, e1))
+        def grouped_label(problems):
+            return "gemm TN grouped wgrad | %s" % nat.gemm_last_kernel()
 
-        nat.gemm = timed
-        nat.gemm_grouped = timed_grouped
+        # attention: 4 S^2 d FLOP per (b, head) forward, 10 S^2 d backward (two GEMM-like products + their transposes)
+        def att_f(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, *a, **kw):
+            return 4.0 * B * heads * Sq * Sk * kw.get("head_dim", 64)
+
+        def att_b(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, *a, **kw):
+            return 10.0 * B * heads * Sq * Sk * kw.get("head_dim", 64)
+
+        nat.gemm = self._timed(self.saved["gemm"], gemm_label, lambda A, B, C_out, M, N, K, *a, **kw: 2.0 * M * N * K)
+        nat.gemm_grouped = self._timed(self.saved["gemm_grouped"], grouped_label, lambda ps: sum(2.0 * p["M"] * p["N"] * p["K"] for p in ps))
+        nat.attention_fwd = self._timed(self.saved["attention_fwd"], lambda *a, **k: "attention fwd", att_f)
+        nat.attention_bwd = self._timed(self.saved["attention_bwd"], lambda *a, **k: "attention bwd", att_b)
+        # LayerNorm: algorithmic HBM bytes = 2 B/element in + 2 out (+ statistics) forward; dy, x in, dx (and dlin) out backward
+        nat.layernorm_fwd = self._timed(self.saved["layernorm_fwd"], lambda *a, **k: "layernorm fwd",
+                                        lambda x, g, b, y, mean, rstd, rows, H, eps: 4.0 * rows * H)
+        nat.layernorm_bwd = self._timed(self.saved["layernorm_bwd"], lambda *a, **k: "layernorm bwd",
+                                        lambda dy, x, mean, rstd, gamma, dx, dlin, *a: (8.0 if dlin is not None else 6.0) * x.shape[0] * x.shape[1])
         return self
 
     def __exit__(self, *exc):
-        self.nat.gemm = self.orig
-        self.nat.gemm_grouped = self.orig_grouped
+        for n, f in self.saved.items():
+            setattr(self.nat, n, f)
 
     def summary(self):
         torch.cuda.synchronize()
         by = {}
-        for variant, shape, flops, e0, e1 in self.rec:
-            d = by.setdefault(variant, dict(launches=0, ms=0.0, flops=0.0))
-            d["launches"] += 1; d["ms"] += e0.elapsed_time(e1); d["flops"] += flops
+        for label, work, e0, e1 in self.rec:
+            d = by.setdefault(label, dict(launches=0, ms=0.0, work=0.0))
+            d["launches"] += 1; d["ms"] += e0.elapsed_time(e1); d["work"] += work
         return by
 
 
@@ -152,9 +167,11 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(batch, steps, budget_s=20.0):
-    """The oracle (fp32 PyTorch port of the reference path) on the host cores: forward + logit_bce + backward in
-    train mode.  Bounded: one warm-up step, then timed steps until `steps` are done or `budget_s` is spent."""
+def cpu_baseline(batch, steps, budget_s=24.0):
+    """The oracle (fp32 PyTorch port of the reference path, pinned against the reference's own code) on the host cores of
+    this box: the reference's CPU FORWARD (eval mode — what north_star asks to time beside the GPU run) and one
+    forward + logit_bce + backward step in train mode (like for like with `value`).  Bounded: one warm-up, then timed
+    passes until `steps` are done or the budget is spent; medians."""
     from oracle import visual_bert_oracle as O
     cfg = dict(O.DEFAULT_CONFIG)
     cores = usable_cores()
@@ -162,7 +179,13 @@ def cpu_baseline(batch, steps, budget_s=20.0):
     sd = {k: v.requires_grad_(True) for k, v in O.init_state_dict(cfg, seed=1234).items()}
     sample = O.synthetic_batch(cfg, batch, seed=1234)
 
-    def one():
+    def fwd_eval():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.visual_bert_forward(sd, cfg, sample, train=False)
+        return time.perf_counter() - t0
+
+    def step_train():
         for v in sd.values():
             v.grad = None
         t0 = time.perf_counter()
@@ -170,15 +193,23 @@ def cpu_baseline(batch, steps, budget_s=20.0):
         list(out["losses"].values())[0].backward()
         return time.perf_counter() - t0
 
-    warm = one()
-    times, spent = [], warm
-    while len(times) < steps and (not times or spent + times[-1] < budget_s):
-        times.append(one())
-        spent += times[-1]
-    t = sorted(times)[len(times) // 2]
-    return {"value": round(batch / t, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle (fp32 PyTorch port of the reference path) fwd+bwd, train mode, B=%d, median of %d timed step(s) "
-                      "after 1 warm-up (%.1f s of CPU work)" % (batch, len(times), spent)}
+    def timed(fn, budget):
+        spent = fn()            # warm-up
+        times = []
+        while len(times) < steps and (not times or spent + times[-1] < budget):
+            times.append(fn())
+            spent += times[-1]
+        return sorted(times)[len(times) // 2], len(times), spent
+
+    tf, nf, sf = timed(fwd_eval, budget_s * 0.3)
+    tt, nt, st = timed(step_train, budget_s * 0.7)
+    gf = FWD_BWD_GFLOP_PER_SAMPLE / 3.0
+    return {"value": round(batch / tt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "gflops": round(batch * FWD_BWD_GFLOP_PER_SAMPLE / tt, 1),
+            "forward_eval": {"value": round(batch / tf, 3), "unit": "samples/s", "gflops": round(batch * gf / tf, 1),
+                             "sample": "eval-mode forward, B=%d, median of %d pass(es) (%.1f s)" % (batch, nf, sf)},
+            "sample": "oracle (fp32 PyTorch port of the reference path) fwd+logit_bce+bwd, train mode, B=%d, median of %d timed step(s) "
+                      "after 1 warm-up (%.1f s of CPU work); forward_eval = the reference's CPU forward" % (batch, nt, st)}
 
 
 def main():
@@ -265,32 +296,58 @@ def main():
         fwd_bwd_only = {"value": round(args.batch * args.steps / dt2, 2), "unit": "samples/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3)}
         del plain
 
+    # host-launch headroom of the eager step (what N > 1 runs): time to ENQUEUE a step from Python against the time the GPU needs
+    eager_info = None
+    if world == 1:
+        eopt = make_optimizer(capturable=False) if not args.no_optimizer else None
+        for _ in range(2):
+            eager_step(eopt)
+        torch.cuda.synchronize()
+        n_e = 5
+        t0 = time.perf_counter()
+        for _ in range(n_e):
+            eager_step(eopt)
+        t_host = (time.perf_counter() - t0) / n_e
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t0) / n_e
+        eager_info = {"ms_per_step": round(t_all * 1e3, 3), "host_enqueue_ms_per_step": round(t_host * 1e3, 3),
+                      "note": "eager launch path (no hipGraph), as N > 1 runs it: the host is ahead of the GPU while enqueue < step"}
+        del eopt
+
     # one instrumented step for the roofline of the dominant kernel
-    with GemmProbe() as probe:
+    with KernelProbe() as probe:
         eager_step(None)
     by = probe.summary()
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
-        dom = max(by, key=lambda k: by[k]["ms"])
-        tot_ms = sum(v["ms"] for v in by.values()); tot_fl = sum(v["flops"] for v in by.values())
-        traffic = None
+        gem = {k: v for k, v in by.items() if k.startswith("gemm") and "(ragged / small)" not in k}
+        dom = max(gem, key=lambda k: gem[k]["ms"])
+        tot_ms = sum(v["ms"] for k, v in by.items() if k.startswith("gemm")); tot_fl = sum(v["work"] for k, v in by.items() if k.startswith("gemm"))
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(dom, None)
+                tj = json.load(open(tfile))
+                traffic = tj.get(dom, None)
+                traffic_src = "profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run" % tj.get("_collected", "undated")
             except Exception:
                 traffic = None
+        fam = lambda pre: {k: v for k, v in by.items() if k.startswith(pre)}
+        att = fam("attention"); lnk = fam("layernorm")
         roof = {
-            "bound": "mfma", "kernel": "gemm_bf16_kernel[%s]" % dom,
-            "achieved": round(by[dom]["flops"] / by[dom]["ms"] / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(by[dom]["flops"] / by[dom]["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "bound": "mfma", "kernel": dom,
+            "achieved": round(by[dom]["work"] / by[dom]["ms"] / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(by[dom]["work"] / by[dom]["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
             "avg_launch_ms": round(by[dom]["ms"] / by[dom]["launches"], 4), "launches_per_step": by[dom]["launches"],
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_src,
             "all_gemm": {"tflops": round(tot_fl / tot_ms / 1e9, 2), "ms_per_step": round(tot_ms, 3),
-                         "variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / v["ms"] / 1e9, 1)}
-                                      for k, v in sorted(by.items())}},
+                         "variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["work"] / v["ms"] / 1e9, 1)}
+                                      for k, v in sorted(by.items()) if k.startswith("gemm")}},
+            "attention": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["work"] / v["ms"] / 1e9, 1)} for k, v in sorted(att.items())},
+            "layernorm": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "GBps": round(v["work"] / v["ms"] / 1e6, 0), "hbm_peak_GBps": 8000}
+                          for k, v in sorted(lnk.items())},
             "step_frac_of_mfma_peak": round(value / world * FWD_BWD_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
         }
         line = {
@@ -309,6 +366,8 @@ def main():
             line["fwd_bwd_only"] = fwd_bwd_only
         if h2d is not None:
             line["h2d_inclusive"] = h2d
+        if eager_info is not None:
+            line["eager"] = eager_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(line), flush=True)

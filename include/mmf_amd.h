@@ -110,6 +110,8 @@ int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream);
  * {launch << 32 | block, HW_ID | XCC_ID << 32, entry, first stage landed, K loop done, tile staged, stores drained, tile};
  * word 0 of the buffer counts the records.  NULL switches it off. */
 int mmf_gemm_set_probe(void* buf, int64_t capacity_records);
+/* Measurement aid: family / tile of the kernel the last GEMM call on this thread launched ("gemm_wide_kernel 256x96", ...). */
+const char* mmf_gemm_last_kernel(void);
 /* Number of K splits mmf_gemm_bf16 will use for this shape when given a workspace (1 = no split). */
 int mmf_gemm_splitk_splits(int M, int N, int K);
 

@@ -225,6 +225,13 @@ def gemm_grouped(problems):
     _check(lib().mmf_gemm_bf16_grouped(arr, n, _stream()), "mmf_gemm_bf16_grouped")
 
 
+def gemm_last_kernel():
+    """Family / tile of the kernel the last gemm / gemm_grouped call launched (bench.py labels its roofline with it)."""
+    f = lib().mmf_gemm_last_kernel
+    f.restype = C.c_char_p
+    return f().decode()
+
+
 def gemm_set_probe(buf):
     """Development aid: `buf` = zeroed int64 device tensor of 8 * (1 + capacity) words (or None to switch the probe off);
     while set, every GEMM workgroup appends a timeline record (see gemm.hip Probe)."""

@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// name of the kernel family the last mmf_gemm_bf16 / mmf_gemm_bf16_grouped call on this thread launched (measurement aid)
+static thread_local const char* g_last_kernel = "";
+
 // timeline probe state (host): set by mmf_gemm_set_probe, consumed by every GEMM launch while set
 static Probe g_probe = {nullptr, 0u, 0u};
 static Probe next_probe() {
@@ -313,6 +316,7 @@ int launch_n(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
         if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
         attr_set = true;
     }
+    g_last_kernel = BN_ == 96 ? (KS == 2 ? "gemm_bf16_kernel 128x96 ksplit" : "gemm_bf16_kernel 128x96") : (KS == 2 ? "gemm_bf16_kernel 128x128 ksplit" : "gemm_bf16_kernel 128x128");
     hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS, RS>), dim3(tm * tn * splits), dim3(128 * NWN), lds_bytes, s,
                        reinterpret_cast<const AT*>(d->A), reinterpret_cast<const BT*>(d->B), d->M, d->N, d->K,
                        d->lda, d->ldb, tm, tn, splits, (d->debug_flags >> 4) & 15, e2, next_probe());
@@ -331,6 +335,7 @@ int launch_grouped_n(const GroupArgs& g, hipStream_t s) {
         if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
         attr_set = true;
     }
+    g_last_kernel = "gemm_bf16_grouped_kernel 128x128";
     hipLaunchKernelGGL((gemm_bf16_grouped_kernel<AT, BT, AK, BK_, RG, NWN, BN_, KS, RS>), dim3(g.total), dim3(128 * NWN), lds_bytes, s, g, next_probe());
     MMF_CHECK_LAUNCH();
     return 0;
@@ -351,6 +356,7 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     }
     const bf16* A = reinterpret_cast<const bf16*>(d->A);
     const bf16* B = reinterpret_cast<const bf16*>(d->B);
+    g_last_kernel = BM_ == 192 ? "gemm_wide_kernel 192x192" : (BN_ == 96 ? "gemm_wide_kernel 256x96" : "gemm_wide_kernel 256x128");
 #ifdef MMF_WIDE_ABLATE
     const int abl = (d->debug_flags >> 4) & 7;
 #define MMF_WIDE_ABL_CASE(V)                                                                                                          \
@@ -576,3 +582,5 @@ extern "C" int mmf_gemm_set_probe(void* buf, int64_t capacity_records) {
     g_probe.launch = 0;
     return 0;
 }
+
+extern "C" const char* mmf_gemm_last_kernel(void) { return g_last_kernel; }

@@ -147,6 +147,13 @@ typedef struct mmf_attn_desc {
                         mmf/models/m4c.py:424-440 (a [B,1,L,L] mask there), without materialising it: the last n
                         positions (decoding steps) are visible only to each other, causally (key <= query); all
                         other pairs use `mask`.  Needs Sq == Sk and head_dim 64. */
+    int q_batch_rows;      /* forward only, 0 = Sq: rows between the first query of consecutive batches (queries that live inside a
+                              longer per-sample buffer) */
+    int kv_batch_rows;     /* forward only, 0 = Sk: the same for k / v — a per-sample K|V cache longer than the Sk keys in use.
+                              Incremental greedy decoding of M4C (mmf/models/m4c.py:284-304 re-runs the whole multimodal
+                              transformer per step): step i attends from ONE new row to the cached encoder rows and the i
+                              decoding rows before it, i.e. Sq = 1, Sk = E + i + 1, both strides = E + D */
+    int mask_batch_stride; /* forward only, 0 = Sk: mask entries per batch */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
 

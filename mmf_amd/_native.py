@@ -48,6 +48,7 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("head_dim", C.c_int), ("ctx_f32", C.c_void_p), ("causal_tail", C.c_int),
+        ("q_batch_rows", C.c_int), ("kv_batch_rows", C.c_int), ("mask_batch_stride", C.c_int),
     ]
 
 
@@ -252,9 +253,10 @@ def gemm_rowsum_supported(M, N, K):
 # attention
 # --------------------------------------------------------------------------------------------
 def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim=64, ctx_f32=None,
-               causal_tail=0):
+               causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0):
     d = AttnDesc()
     d.causal_tail = int(causal_tail)
+    d.q_batch_rows, d.kv_batch_rows, d.mask_batch_stride = int(q_batch_rows), int(kv_batch_rows), int(mask_batch_stride)
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):
         _req(t, torch.bfloat16, n)
     _req(mask, torch.float32, "mask"); _req(lse, torch.float32, "lse")
@@ -271,8 +273,11 @@ def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, sc
 
 
 def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP, head_dim=64, ctx_f32=None,
-                  causal_tail=0):
-    d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail)
+                  causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0):
+    """`q_batch_rows` / `kv_batch_rows` / `mask_batch_stride` (forward only): q, k / v and the mask may live inside longer
+    per-sample buffers (a K|V cache); 0 = the dense defaults Sq / Sk / Sk."""
+    d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail,
+                   q_batch_rows, kv_batch_rows, mask_batch_stride)
     _check(lib().mmf_attention_fwd(C.byref(d), _stream()), "mmf_attention_fwd")
 
 

@@ -116,6 +116,7 @@ struct AttnArgs {
     float* lse;
     int B, heads, Sq, Sk, skp, hd;
     int cfrom;           // first key of the causal tail (== Sk when there is none), see mmf_attn_desc.causal_tail
+    int q_bs, kv_bs, m_bs;   // rows between consecutive batches of q / of k, v / mask entries per batch (defaults Sq, Sk, Sk)
     float scale;
     DropoutCfg drop;
     // backward only
@@ -139,15 +140,15 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     const int q0 = blockIdx.y * 128 + wave * 32;
     constexpr int SKP = NKT * 32;
 
-    const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
-    const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
+    const bf16* kbase = a.k + (size_t)b * a.kv_bs * a.ldk + head * HD;
+    const bf16* vbase = a.v + (size_t)b * a.kv_bs * a.ldv + head * HD;
     stage_rows<D>(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
     stage_rows<D>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
     for (int i = tid; i < SKP; i += 256)   // additive mask, already in the log2 domain
-        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.m_bs + i] * 1.4426950408889634f : 0.f) : -INFINITY;
     // Q fragments (B operand: column = query row), fetched while the K / V DMA is still in flight
     const int qrow = min(q0 + x, a.Sq - 1);
-    const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
+    const bf16* qptr = a.q + ((size_t)b * a.q_bs + qrow) * a.ldq + head * HD;
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = frag_global(qptr, s, lane);
@@ -478,6 +479,10 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     MMF_CHECK_ARG(d->causal_tail >= 0 && d->causal_tail <= d->Sk, "attention: causal_tail out of range");
     MMF_CHECK_ARG(d->causal_tail == 0 || (d->Sq == d->Sk && hd == 64), "attention: a causal tail needs self-attention (Sq == Sk) with head_dim 64");
     a.cfrom = d->Sk - d->causal_tail;
+    a.q_bs = d->q_batch_rows > 0 ? d->q_batch_rows : d->Sq;
+    a.kv_bs = d->kv_batch_rows > 0 ? d->kv_batch_rows : d->Sk;
+    a.m_bs = d->mask_batch_stride > 0 ? d->mask_batch_stride : d->Sk;
+    MMF_CHECK_ARG(a.q_bs >= d->Sq && a.kv_bs >= d->Sk && a.m_bs >= d->Sk, "attention: batch strides must cover the sequence");
     a.scale = d->scale;
     a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
@@ -520,6 +525,8 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     MMF_CHECK_ARG(d, "attention_bwd: null desc");
     if (int rc = fill_args(&d->f, a)) return rc;
     MMF_CHECK_ARG(d->f.ctx && d->f.lse && d->dctx && d->dq && d->dk && d->dv && d->delta, "attention_bwd: null operand");
+    MMF_CHECK_ARG(d->f.q_batch_rows == 0 && d->f.kv_batch_rows == 0 && d->f.mask_batch_stride == 0,
+                  "attention_bwd: custom batch strides are a forward-only (decoding) feature");
     a.dctx = (const bf16*)d->dctx; a.dq = (bf16*)d->dq; a.dk = (bf16*)d->dk; a.dv = (bf16*)d->dv; a.delta = d->delta;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 

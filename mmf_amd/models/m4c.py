@@ -354,7 +354,10 @@ class M4C(BaseModel):
             fwd_results["prev_inds"] = sample_list["train_prev_inds"].clone()
             self._forward_mmt(sample_list, fwd_results)
             self._forward_output(sample_list, fwd_results)
+        elif self.config.get("kv_cached_decode", True):
+            self._decode_incremental(sample_list, fwd_results)
         else:
+            # the reference's loop, kept for A/B tests: the whole multimodal transformer once per decoding step (:290-305)
             dec_step_num = sample_list["train_prev_inds"].size(1)
             # fill prev_inds with BOS_IDX at index 0, and zeros elsewhere
             fwd_results["prev_inds"] = torch.zeros_like(sample_list["train_prev_inds"])
@@ -365,6 +368,62 @@ class M4C(BaseModel):
                 self._forward_output(sample_list, fwd_results)
                 argmax_inds = fwd_results["scores"].argmax(dim=-1)
                 fwd_results["prev_inds"][:, 1:] = argmax_inds[:, :-1]
+
+    @torch.no_grad()
+    def _decode_incremental(self, sample_list, fwd_results):
+        """Greedy decoding (m4c.py:290-305) WITHOUT re-encoding: the reference re-runs the multimodal transformer over all
+        T + O + N + D positions D times; under its prefix-LM mask (:424-440) the T + O + N encoder positions never see a
+        decoding position, so they — and their keys / values in every layer — are computed ONCE, and decoding step i runs a
+        single new row per sample through the layers against the per-layer K|V cache (mmf_amd/modules/infer.py).  Row i of
+        the scores is final the moment it is produced (it only ever depends on predictions < i), so the result equals the
+        last iteration of the reference's loop."""
+        from mmf_amd.modules.infer import layer_rows, new_cache
+        if "txt_emb" not in fwd_results:
+            text_bert_out = self.text_bert(txt_inds=fwd_results["txt_inds"], txt_mask=fwd_results["txt_mask"])
+            fwd_results["txt_emb"] = self.text_bert_out_linear(text_bert_out)
+        txt_emb, obj_emb, ocr_emb = fwd_results["txt_emb"], fwd_results["obj_mmt_in"], fwd_results["ocr_mmt_in"]
+        txt_mask, obj_mask, ocr_mask = fwd_results["txt_mask"], fwd_results["obj_mask"], fwd_results["ocr_mask"]
+        B, T, H = txt_emb.shape
+        O, N = obj_emb.shape[1], ocr_emb.shape[1]
+        D = sample_list["train_prev_inds"].size(1)
+        E = T + O + N
+        dev = txt_emb.device
+        layers = self.mmt.encoder.layer
+        # keys: the encoder positions by their masks, the decoding positions all visible (step i only addresses keys <= E + i)
+        key_mask = _additive(torch.cat([txt_mask, obj_mask, ocr_mask, torch.ones(B, D, dtype=txt_mask.dtype, device=dev)], dim=1))
+        cache = new_cache(B, E + D, H, len(layers), dev)
+        x = Fn.ConcatRowsFn.apply(txt_emb, obj_emb, ocr_emb).reshape(B * E, H)
+        for l, layer in enumerate(layers):
+            x = layer_rows(layer, x, cache[l], B, E, E + D, 0, E, key_mask)
+        enc_out = x.view(B, E, H)
+        mmt_ocr_output = enc_out[:, T + O:T + O + N].contiguous()
+        pp = self.mmt.prev_pred_embeddings
+        cls, ptr = self.classifier.module, self.ocr_ptr_net
+        V = cls.weight.shape[0]
+        ans_emb = pp.ans_layer_norm(Fn.ParamRowsFn.apply(cls.weight))          # PrevPredEmbeddings.forward, :523-524, once
+        ocr_ln = pp.ocr_layer_norm(ocr_emb)
+        prev = torch.zeros_like(sample_list["train_prev_inds"])
+        prev[:, 0] = self.answer_processor.BOS_IDX
+        scores = torch.empty(B, D, V + N, dtype=torch.float32, device=dev)
+        zero = torch.zeros(B, 1, H, dtype=torch.bfloat16, device=dev)
+        ocr_mask_add = _additive(ocr_mask)
+        w_cls16, w_q16, w_k16 = Fn.shadows.get(cls.weight), Fn.shadows.get(ptr.query.weight), Fn.shadows.get(ptr.key.weight)
+        for i in range(D):
+            inds = prev[:, i:i + 1].contiguous()
+            raw = Fn.PrevPredGatherFn.apply(ans_emb, ocr_ln, inds)                                      # :525-528
+            emb = Fn.AddPosTypeFn.apply(zero, inds.ge(V).long(), pp.position_embeddings.weight[i:i + 1],
+                                        pp.token_type_embeddings.weight)                                  # :531-538, position i
+            x = Fn.AddFn.apply(raw, pp.emb_layer_norm(emb)).reshape(B, H)                                # :539-541 (dropout off)
+            for l, layer in enumerate(layers):
+                x = layer_rows(layer, x, cache[l], B, 1, E + D, E + i, E + i + 1, key_mask)
+            s_i = Fn.M4CScoresFn.apply(x.view(B, 1, H), mmt_ocr_output, cls.weight, cls.bias, ptr.query.weight, ptr.query.bias,
+                                       ptr.key.weight, ptr.key.bias, ocr_mask_add, w_cls16, w_q16, w_k16)    # :275-283
+            scores[:, i] = s_i[:, 0]
+            if i + 1 < D:
+                prev[:, i + 1] = s_i[:, 0].argmax(dim=-1)
+        fwd_results["scores"] = scores
+        fwd_results["prev_inds"] = prev
+        fwd_results["mmt_ocr_output"] = mmt_ocr_output
 
     def get_optimizer_parameters(self, config):
         """m4c.py:307-329."""

@@ -69,13 +69,15 @@ def _gemm_grouped(problems):
 
 
 def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=N.NO_DROP, head_dim=64, ctx_f32=None,
-                   causal_tail=0):
+                   causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0):
     assert head_dim in (64, 128) and 0 <= causal_tail <= Sk and (causal_tail == 0 or (Sq == Sk and head_dim == 64))
     assert Sq <= 256 and Sk <= 256
-    _need(q, B * Sq, ldq, heads * head_dim, "attention q"); _need(k, B * Sk, ldk, heads * head_dim, "attention k")
-    _need(v, B * Sk, ldv, heads * head_dim, "attention v"); _need(ctx, B * Sq, ldo, heads * head_dim, "attention ctx")
+    qb, kb, mb = q_batch_rows or Sq, kv_batch_rows or Sk, mask_batch_stride or Sk
+    assert qb >= Sq and kb >= Sk and mb >= Sk
+    _need(q, (B - 1) * qb + Sq, ldq, heads * head_dim, "attention q"); _need(k, (B - 1) * kb + Sk, ldk, heads * head_dim, "attention k")
+    _need(v, (B - 1) * kb + Sk, ldv, heads * head_dim, "attention v"); _need(ctx, B * Sq, ldo, heads * head_dim, "attention ctx")
     if mask is not None:
-        assert mask.dtype == torch.float32 and mask.numel() >= B * Sk
+        assert mask.dtype == torch.float32 and mask.numel() >= (B - 1) * mb + Sk
     assert lse.numel() >= B * heads * Sq
     calls.append(("attention_fwd", B, heads, Sq, Sk, causal_tail))
 

@@ -44,8 +44,23 @@ def test_m4c_greedy_decoding_plumbing():
         out = model(SampleList(sample))
     assert tuple(out["scores"].shape) == (case["B"], D, case["num_choices"] + case["N"])
     fwd = [c for c in calls if c[0] == "attention_fwd"]
-    # text_bert once (deterministic in eval mode), the multimodal transformer once per decoding step (m4c.py:297-305)
-    assert len(fwd) == cfg["text_num_hidden_layers"] + D * cfg["num_hidden_layers"]
+    n_txt, n_mmt = cfg["text_num_hidden_layers"], cfg["num_hidden_layers"]
+    E = case["T"] + case["O"] + case["N"]
+    # incremental decoding: text_bert once, the encoder positions ONCE through the multimodal transformer (E queries x E keys),
+    # then one new row per sample and step against the K|V cache (1 query, E + i + 1 keys) — the reference re-encodes all
+    # E + D positions D times (m4c.py:297-305)
+    assert len(fwd) == n_txt + n_mmt + D * n_mmt
+    assert all(c[3] == E and c[4] == E for c in fwd[n_txt:n_txt + n_mmt])
+    steps = fwd[n_txt + n_mmt:]
+    assert [(c[3], c[4]) for c in steps] == [(1, E + i + 1) for i in range(D) for _ in range(n_mmt)]
+    assert all(c[-1] == 0 for c in fwd)               # no causal tail needed: a step only addresses the keys it may see
+    # the reference-style loop stays available for A/B checks
+    from tests.model_utils import m4c_model_config
+    model2 = build_m4c(cfg, sd, device="cpu", kv_cached_decode=False)
+    model2.eval()
+    with native_stub.installed() as calls2, torch.no_grad():
+        model2(SampleList(sample))
+    assert len([c for c in calls2 if c[0] == "attention_fwd"]) == n_txt + D * n_mmt
 
 
 import pytest

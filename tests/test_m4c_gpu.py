@@ -430,3 +430,65 @@ def test_m4c_textvqa_shape_matches_the_oracle():
         assert e <= 2 * TOL, (k, e)
         checked += 1
     assert checked >= 20
+
+
+def test_m4c_incremental_decoding_equals_the_reference_style_loop_and_is_faster():
+    """The K|V-cached greedy decoding against the loop that re-runs the whole multimodal transformer every step (the
+    reference's structure), same weights, at the configured TextVQA shape: same argmax sequence, same scores, less time."""
+    import time
+    import warnings
+    from mmf_amd.common.registry import registry
+    from mmf_amd.utils.configuration import Config
+    registry.register("config", Config({"datasets": "textvqa"}))
+    registry.register("textvqa_num_final_outputs", 5050)
+    registry.register("textvqa_answer_processor", Config({"BOS_IDX": 1}))
+    torch.manual_seed(23)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = registry.get_model_class("m4c")(Config({"model": "m4c", "text_bert_init_from_bert_base": False}))
+        model.build(); model.init_losses()
+    model = model.to("cuda").eval()
+    with torch.no_grad():       # spread the logits so that the greedy choice is well separated (random init gives near-ties)
+        model.classifier.module.weight.mul_(8.0); model.ocr_ptr_net.query.weight.mul_(8.0); model.ocr_ptr_net.key.weight.mul_(8.0)
+    B = 8
+    g = torch.Generator().manual_seed(6)
+    sample = {
+        "text": torch.randint(1, 30522, (B, 20), generator=g), "text_len": torch.randint(3, 21, (B,), generator=g),
+        "image_feature_0": torch.rand(B, 100, 2048, generator=g), "obj_bbox_coordinates": torch.rand(B, 100, 4, generator=g),
+        "image_info_0": {"max_features": torch.randint(10, 101, (B,), generator=g)},
+        "context_feature_0": torch.randn(B, 50, 300, generator=g), "context_feature_1": torch.rand(B, 50, 604, generator=g),
+        "image_feature_1": torch.rand(B, 100, 2048, generator=g), "ocr_bbox_coordinates": torch.rand(B, 50, 4, generator=g),
+        "context_info_0": {"max_features": torch.randint(1, 51, (B,), generator=g)}, "order_vectors": torch.zeros(B, 50, 50),
+        "train_prev_inds": torch.zeros(B, 12, dtype=torch.long), "targets": torch.zeros(B, 12, 5050),
+        "train_loss_mask": torch.ones(B, 12), "dataset_name": "textvqa", "dataset_type": "val"}
+    batch = SampleList(sample_to(sample, "cuda"))
+
+    def run(cached):
+        model.config["kv_cached_decode"] = cached
+        with torch.no_grad():
+            out = model(batch)["scores"].float()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(3):
+                model(batch)
+        torch.cuda.synchronize()
+        return out, (time.perf_counter() - t0) / 3
+
+    inc, t_inc = run(True)
+    ref, t_ref = run(False)
+    top2 = ref.topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 0.5              # steps whose greedy choice is not a bf16-noise tie
+    assert bool(decided.float().mean() > 0.8)
+    # identical greedy prefixes up to the first undecided step of every sample, and the same scores there
+    ai, ar = inc.argmax(-1), ref.argmax(-1)
+    for b in range(B):
+        n = 0
+        while n < 12 and bool(decided[b, n]):
+            n += 1
+        assert torch.equal(ai[b, :n], ar[b, :n]), b
+        valid = ref[b, :n + 1 if n < 12 else n] > -5000
+        d = (inc[b, :valid.shape[0]] - ref[b, :valid.shape[0]]).abs()[valid]
+        assert float(d.max()) <= TOL * (1.0 + float(ref[b][ref[b] > -5000].abs().max())), b
+    print("greedy decoding, B=%d, TextVQA shape: incremental %.1f ms, re-encoding loop %.1f ms" % (B, t_inc * 1e3, t_ref * 1e3))
+    assert t_inc < t_ref

@@ -110,27 +110,37 @@ def test_adapter_train_eval_reach_the_hip_network(fake_mmf):
     assert not m.training and not inner.training and not inner.mmt.training
     m.train()
     assert m.training and inner.training
-    # the branch M4C.forward takes follows the adapter's mode: count multimodal-transformer passes on a dry run
+    # the branch M4C.forward takes follows the adapter's mode: a dry run counts multimodal-transformer passes (teacher
+    # forcing: one) and greedy-decoding calls (eval: the K|V-cached loop, which does not go through mmt.forward)
     from tests import native_stub
     from mmf_amd.common.sample import SampleList
-    calls = {"n": 0}
-    orig = type(inner.mmt).forward
+    calls = {"mmt": 0, "greedy": 0}
+    orig, orig_dec = type(inner.mmt).forward, type(inner)._decode_incremental
 
     def counting(self_, *a, **k):
-        calls["n"] += 1
+        calls["mmt"] += 1
         return orig(self_, *a, **k)
 
+    def counting_dec(self_, *a, **k):
+        calls["greedy"] += 1
+        return orig_dec(self_, *a, **k)
+
     type(inner.mmt).forward = counting
+    type(inner)._decode_incremental = counting_dec
     try:
         with native_stub.installed():
-            m.train(); calls["n"] = 0
+            m.train()
             m(SampleList(sample))
-            teacher_forced = calls["n"]
-            m.eval(); calls["n"] = 0
+            assert calls == {"mmt": 1, "greedy": 0}
+            m.eval(); calls.update(mmt=0, greedy=0)
             import torch
             with torch.no_grad():
                 m(SampleList(sample))
-            greedy = calls["n"]
+            assert calls == {"mmt": 0, "greedy": 1}
+            inner.config["kv_cached_decode"] = False; calls.update(mmt=0, greedy=0)
+            with torch.no_grad():
+                m(SampleList(sample))
+            assert calls == {"mmt": case["D"], "greedy": 0}
     finally:
         type(inner.mmt).forward = orig
-    assert teacher_forced == 1 and greedy == case["D"]
+        type(inner)._decode_incremental = orig_dec

@@ -34,6 +34,7 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_LN_BWD_GRID = 1,    /* workgroups of mmf_layernorm_bwd (<= MMF_LN_BWD_MAX_GRID) */
        MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 */
        MMF_TUN_LN_OLD = 3,         /* 1: LayerNorm with the one-wave-per-row, 8-byte-per-lane kernels even when H % 256 == 0 (A/B measurements) */
+       MMF_TUN_ATTN_BWD_TWO_PASS = 4,   /* 1: head_dim-64 attention backward as the separate dQ and dK/dV kernels (A/B measurements) */
        MMF_TUN_COUNT = 8 };
 int mmf_amd_set_tunable(int which, int value);
 int mmf_amd_get_tunable(int which);
@@ -110,6 +111,10 @@ int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream);
  * {launch << 32 | block, HW_ID | XCC_ID << 32, entry, first stage landed, K loop done, tile staged, stores drained, tile};
  * word 0 of the buffer counts the records.  NULL switches it off. */
 int mmf_gemm_set_probe(void* buf, int64_t capacity_records);
+/* Development aid, attention kernels: like mmf_gemm_set_probe with one 96-byte record per WAVE {kernel (0 fwd, 1 dQ, 2 dK/dV),
+ * batch * heads + head, 4 * blockIdx.y + wave, HW_ID, 8 stamps}.  Only a library built with -DMMF_ATTN_PROBE records (the
+ * stamps are compiled out of the regular build, where the call returns 1); tools/attn_timeline.py. */
+int mmf_attention_set_probe(void* buf, int64_t capacity_records);
 /* Measurement aid: family / tile of the kernel the last GEMM call on this thread launched ("gemm_wide_kernel 256x96", ...). */
 const char* mmf_gemm_last_kernel(void);
 /* Number of K splits mmf_gemm_bf16 will use for this shape when given a workspace (1 = no split). */

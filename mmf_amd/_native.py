@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmf_amd.so")
+# MMF_AMD_LIB: an instrumented development build of the same library (python -m mmf_amd.csrc.build --tag probe), never a fallback
+LIB_PATH = os.environ.get("MMF_AMD_LIB") or os.path.join(_HERE, "libmmf_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmf_amd.h")
 
 
@@ -112,6 +113,8 @@ def lib():
         L.mmf_amd_set_tunable(2, int(os.environ["MMF_AMD_GEMM_WIDE"]))
     if os.environ.get("MMF_AMD_LN_OLD"):
         L.mmf_amd_set_tunable(3, int(os.environ["MMF_AMD_LN_OLD"]))
+    if os.environ.get("MMF_AMD_ATTN_BWD_TWO_PASS"):
+        L.mmf_amd_set_tunable(4, int(os.environ["MMF_AMD_ATTN_BWD_TWO_PASS"]))
     return L
 
 
@@ -241,6 +244,15 @@ def gemm_set_probe(buf):
     else:
         _req(buf, torch.int64, "probe buffer")
         _check(lib().mmf_gemm_set_probe(_p(buf), C.c_int64(buf.numel() // 8 - 1)), "mmf_gemm_set_probe")
+
+
+def attention_set_probe(buf):
+    """Development aid (library built with -DMMF_ATTN_PROBE only): zeroed int64 device tensor of 12 * (1 + capacity) words, or None."""
+    if buf is None:
+        _check(lib().mmf_attention_set_probe(None, C.c_int64(0)), "mmf_attention_set_probe")
+    else:
+        _req(buf, torch.int64, "probe buffer")
+        _check(lib().mmf_attention_set_probe(_p(buf), C.c_int64(buf.numel() // 12 - 1)), "mmf_attention_set_probe")
 
 
 def gemm_rowsum_supported(M, N, K):
@@ -437,7 +449,7 @@ def tanh_bwd(dy, y, dx):
     _check(lib().mmf_tanh_bwd_bf16(_p(dy), _p(y), _p(dx), C.c_int64(dy.numel()), _stream()), "mmf_tanh_bwd_bf16")
 
 
-TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE, TUN_LN_OLD = 0, 1, 2, 3
+TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE, TUN_LN_OLD, TUN_ATTN_BWD_TWO_PASS = 0, 1, 2, 3, 4
 
 
 def set_tunable(which, value):

@@ -45,12 +45,12 @@ static __device__ uint4 g_zero16;
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
-template <int D>
+template <int D, int NW = 4>
 DEVI void stage_rows(const bf16* g, int ld, int nvalid, int npad, unsigned char* lds_rm, int tid) {
     constexpr int CPR = D / 8;          // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;       // rows per wave-instruction
     const int wave = tid >> 6, lane = tid & 63;
-    for (int r0 = wave * RPI; r0 < npad; r0 += 4 * RPI) {
+    for (int r0 = wave * RPI; r0 < npad; r0 += NW * RPI) {
         const int row = r0 + lane / CPR;
         const int logical = (lane % CPR) ^ swz<D>(row);
         const bf16* src = (row < nvalid) ? g + (size_t)row * ld + logical * 8 : reinterpret_cast<const bf16*>(&g_zero16);
@@ -123,6 +123,39 @@ struct AttnArgs {
     const bf16* dctx; bf16* dq; bf16* dk; bf16* dv; float* delta;
 };
 
+// Timeline probe (development aid, compiled in only with -DMMF_ATTN_PROBE; tools/attn_timeline.py): every wave appends one
+// record of 12 u64 {kernel id, bh, 4 * blockIdx.y + wave, HW_ID, t0 .. t7} of s_memrealtime ticks (100 MHz).
+#ifdef MMF_ATTN_PROBE
+__device__ unsigned long long* g_attn_probe;
+__device__ unsigned g_attn_probe_cap;
+struct WaveProbe {
+    unsigned long long t[8];
+    DEVI void at(int i) {
+        __builtin_amdgcn_sched_barrier(0);
+        t[i] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    DEVI void flush(int kernel, int bh, int sub) {
+        unsigned long long* buf = g_attn_probe;
+        if (!buf || (threadIdx.x & 63)) return;
+        const unsigned slot = atomicAdd(reinterpret_cast<unsigned*>(buf), 1u);
+        if (slot >= g_attn_probe_cap) return;
+        unsigned long long* r = buf + 12 * (1 + (size_t)slot);
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        r[0] = kernel; r[1] = bh; r[2] = sub; r[3] = hw;
+        for (int i = 0; i < 8; ++i) r[4 + i] = t[i];
+    }
+};
+#define PROBE_DECL WaveProbe wp = {}
+#define PROBE_AT(i) wp.at(i)
+#define PROBE_FLUSH(k, bh, sub) wp.flush(k, bh, sub)
+#else
+#define PROBE_DECL
+#define PROBE_AT(i)
+#define PROBE_FLUSH(k, bh, sub)
+#endif
+
 // =================================================================================================
 // forward
 // =================================================================================================
@@ -139,6 +172,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
     const int q0 = blockIdx.y * 128 + wave * 32;
     constexpr int SKP = NKT * 32;
+    PROBE_DECL;
+    PROBE_AT(0);
 
     const bf16* kbase = a.k + (size_t)b * a.kv_bs * a.ldk + head * HD;
     const bf16* vbase = a.v + (size_t)b * a.kv_bs * a.ldv + head * HD;
@@ -152,7 +187,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = frag_global(qptr, s, lane);
+    PROBE_AT(1);
     stage_wait();
+    PROBE_AT(2);
     if (q0 >= a.Sq) return;
 
     // scores^T tiles: sc[t][r] = S[q = q0+x][key = 32t + (r&3) + 8(r>>2) + 4h]
@@ -166,6 +203,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
         sc[t] = acc;
     }
 
+    PROBE_AT(3);
     // softmax over keys (exact two-pass, fp32), as nn.functional.softmax(scores/sqrt(d) + mask); evaluated in the
     // log2 domain (t = s * log2e) so each probability costs one subtract and one v_exp_f32.
     constexpr float LOG2E = 1.4426950408889634f;
@@ -198,6 +236,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     const float inv = 1.f / sum;
     if (h == 0 && q0 + x < a.Sq) a.lse[((size_t)bh) * a.Sq + q0 + x] = (mx + log2f(sum)) * 0.6931471805599453f;
 
+    PROBE_AT(4);
     // dropout on the probabilities (hf_layers.py:201), index ((bh*Sq + q)*SKP + key)
     if (a.drop.thr16) {
         const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
@@ -211,6 +250,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
             }
     }
 
+    PROBE_AT(5);
     // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
     f32x16 o[NDT] = {};
 #pragma unroll
@@ -223,6 +263,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_v, 32 * dt, 32 * t, u, lane), pf, o[dt], 0, 0, 0);
         }
 
+    PROBE_AT(6);
     if (q0 + x < a.Sq) {
         bf16* optr = a.ctx + ((size_t)b * a.Sq + q0 + x) * a.ldo + head * HD;
 #pragma unroll
@@ -241,6 +282,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
                         make_float4(o[dt][4 * c + 0] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv);
         }
     }
+    PROBE_AT(7);
+    PROBE_FLUSH(0, bh, 4 * blockIdx.y + wave);
 }
 
 // =================================================================================================
@@ -263,6 +306,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     const int x = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
     const int q0 = blockIdx.y * 128 + wave * 32;
+    PROBE_DECL;
+    PROBE_AT(0);
 
     const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * HD;
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
@@ -315,7 +360,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
         dl += __shfl_xor(dl, 32, 64);
         if (h == 0 && q0 + x < a.Sq) a.delta[(size_t)bh * a.Sq + q0 + x] = dl;
     }
+    PROBE_AT(1);
     stage_wait();
+    PROBE_AT(2);
     if (a.ctx32) dl = lds_delta[wave * 32 + x];
     if (q0 >= a.Sq) return;
     const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
@@ -323,6 +370,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     f32x16 dqo[NDT] = {};
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
+        if (t == 1) PROBE_AT(3);
+        if (t == NKT / 2) PROBE_AT(4);
         f32x16 s_acc = {}, dp_acc = {};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -352,6 +401,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
                 dqo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_k, 32 * dt, 32 * t, u, lane), df, dqo[dt], 0, 0, 0);
         }
     }
+    PROBE_AT(5);
     if (q0 + x < a.Sq) {
         bf16* optr = a.dq + ((size_t)b * a.Sq + q0 + x) * a.ldq + head * HD;
 #pragma unroll
@@ -361,6 +411,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
                 *reinterpret_cast<bf16x4*>(optr + 32 * dt + 8 * c + 4 * h) =
                     pack4(dqo[dt][4 * c + 0], dqo[dt][4 * c + 1], dqo[dt][4 * c + 2], dqo[dt][4 * c + 3]);
     }
+    PROBE_AT(6);
+    PROBE_FLUSH(1, bh, 4 * blockIdx.y + wave);
 }
 
 // dK/dV kernel: wave = 32 key rows, loops over all query tiles.
@@ -379,6 +431,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
     const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
     const int k0 = blockIdx.y * 128 + wave * 32;
     const int SKP = a.skp;
+    PROBE_DECL;
+    PROBE_AT(0);
 
     const bf16* qbase = a.q + (size_t)b * a.Sq * a.ldq + head * HD;
     const bf16* dobase = a.dctx + (size_t)b * a.Sq * a.ldo + head * HD;
@@ -398,13 +452,19 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
 #pragma unroll
     for (int s = 0; s < NS; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
     const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    PROBE_AT(1);
     stage_wait();
+    PROBE_AT(2);
     if (k0 >= a.Sk) return;
     const float sc2 = a.scale * 1.4426950408889634f;
 
     f32x16 dko[NDT] = {}, dvo[NDT] = {};
 #pragma unroll 1
     for (int t = 0; t < NQT; ++t) {
+#ifdef MMF_ATTN_PROBE
+        if (t == 1) PROBE_AT(3);
+        if (t == NQT / 2) PROBE_AT(4);
+#endif
         // S[q][key], dPd[q][key]: rows q = 32t + (r&3)+8(r>>2)+4h, column key = k0 + x
         f32x16 s_acc = {}, dp_acc = {};
 #pragma unroll
@@ -447,6 +507,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
             }
         }
     }
+    PROBE_AT(5);
     if (kvalid) {
         bf16* dkptr = a.dk + ((size_t)b * a.Sk + k0 + x) * a.ldk + head * HD;
         bf16* dvptr = a.dv + ((size_t)b * a.Sk + k0 + x) * a.ldv + head * HD;
@@ -460,6 +521,235 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
                     pack4(dvo[dt][4 * c + 0], dvo[dt][4 * c + 1], dvo[dt][4 * c + 2], dvo[dt][4 * c + 3]);
             }
     }
+    PROBE_AT(6);
+    PROBE_FLUSH(2, bh, 4 * blockIdx.y + wave);
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// One-pass backward (head_dim 64, Sq, Sk <= 256): ONE workgroup of 8 waves per (batch, head); every probability is
+// recomputed, dropped out and turned into dS exactly once (the two-kernel form above pays the exp / dropout-hash VALU work
+// twice, and it is VALU-bound: profiles/r02_attention_timeline.txt).
+//   As a PRODUCER wave w owns key tile w (32 keys): its K and V fragments stay in registers, dK^T / dV^T accumulate in
+//   registers over all query tiles (the orientation of attn_bwd_dkv_kernel: S[q][key], lane = key, registers = q).
+//   dQ needs the other reduction (over keys = over the producer's lanes, and over all producers): the producer drops its
+//   32 x 32 dS tile (bf16, 2 KB) into a patch in LDS; as a CONSUMER wave w owns query tile w, reads the patch back with the
+//   hardware transpose read as the B operand of dQ^T[d][q] += K^T[d][key] dS^T[key][q] and accumulates dQ in registers.
+//   Step i of 8: producer w works on query tile (w + i) mod 8, so the eight patches of a step belong to eight different
+//   consumers; one barrier per step, patches double-buffered.  (LDS float atomics for the dQ reduction were measured at
+//   ~150 cycles per wave instruction — 130 us of a 147 us loop — hence the patch hand-over.)
+// LDS: Q, dO, K 32 KB each (row-major, swizzled: feature reductions by frag_rm, query / key reductions by frag_tr)
+// + 2 x 8 patches of 2 KB + lse / delta = 130 KB.
+// -------------------------------------------------------------------------------------------------
+// a dS patch: [32 keys][32 queries] bf16, 64-byte rows, 16-byte chunks XOR-swizzled by (row >> 2) & 3
+DEVI int patch_off(int row, int byte) { return row * 64 + ((((byte >> 4) ^ (row >> 2)) & 3) << 4) + (byte & 15); }
+// B operand of the dQ product from a patch: slot (h, e) of lane x receives dS^T[key = 16u + 4h + (e&3) + 8(e>>2)][q = x]
+DEVI bf16x8 frag_tr_patch(const unsigned char* patch, int u, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int row = 16 * u + 4 * (g >> 1) + (p >> 2);
+    const int byte = 32 * (g & 1) + 8 * (p & 3);
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(patch + patch_off(row, byte)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(patch + patch_off(row + 8, byte)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// A wave's transposed result tile T^T[d][row] (lane x = row, registers -> d = 32 dt + (r&3) + 8(r>>2) + 4h) -> bf16 rows
+// g[row * ld + 0..63] for row < nvalid, through a wave-private swizzled row-major LDS image (4 KB).
+DEVI void store_tile_rows(const f32x16 (&acc)[2], float mul, unsigned char* img, bf16* g, int ld, int nvalid, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<bf16x4*>(img + rm_off<64>(x, 4 * dt + c) + 8 * h) =
+                pack4(acc[dt][4 * c + 0] * mul, acc[dt][4 * c + 1] * mul, acc[dt][4 * c + 2] * mul, acc[dt][4 * c + 3] * mul);
+    asm volatile("" ::: "memory");      // LDS operations of one wave complete in order; keep the compiler from reordering them
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), chunk = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(img + rm_off<64>(row, chunk));
+        if (row < nvalid) *reinterpret_cast<uint4*>(g + (size_t)row * ld + 8 * chunk) = v;
+    }
+}
+
+template <bool CZ>
+__global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
+    constexpr int D = 64, NS = 4, NDT = 2, ROWB = 128, SP = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_q = smem;                                   // row-major Q   [256][64]
+    unsigned char* lds_do = lds_q + SP * ROWB;                     // row-major dO  [256][64]
+    unsigned char* lds_k = lds_do + SP * ROWB;                     // row-major K   [256][64]
+    unsigned char* patches = lds_k + SP * ROWB;                    // [2][8] dS patches
+    float* lds_lse = reinterpret_cast<float*>(patches + 16 * 2048);
+    float* lds_delta = lds_lse + SP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
+    const int k0 = wave * 32;
+    const int nqt = (a.Sq + 31) >> 5;
+    PROBE_DECL;
+    PROBE_AT(0);
+
+    const bf16* qbase = a.q + (size_t)b * a.Sq * a.ldq + head * D;
+    const bf16* dobase = a.dctx + (size_t)b * a.Sq * a.ldo + head * D;
+    const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * D;
+    stage_rows<D, 8>(kbase, a.ldk, a.Sk, (a.Sk + 31) & ~31, lds_k, tid);
+    stage_rows<D, 8>(qbase, a.ldq, a.Sq, nqt * 32, lds_q, tid);
+    stage_rows<D, 8>(dobase, a.ldo, a.Sq, nqt * 32, lds_do, tid);
+    // V fragments of this wave's keys straight from global memory (B operand of dP = dO V^T)
+    const int krow = min(k0 + x, a.Sk - 1);
+    const bool kvalid = (k0 + x) < a.Sk;
+    const bf16* vptr = a.v + ((size_t)b * a.Sk + krow) * a.ldv + head * D;
+    bf16x8 vf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vf[s] = frag_global(vptr, s, lane);
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses VALU arbitration otherwise (MI355X_MICROARCH.md)
+    const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    // delta[q] = sum_d dO[q][d] O[q][d] (two threads per query row, a contiguous half of the head slice each; from the fp32
+    // copy of O when the forward kept one) and the log-sum-exp in the log2 domain; padded rows: lse = +inf -> p = 0
+    {
+        const int r = tid >> 1, hh = tid & 1;
+        const int qr = min(r, a.Sq - 1);
+        const bf16* drow = a.dctx + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * 32;
+        float part = 0.f;
+        if (a.ctx32) {
+            const float* orow = a.ctx32 + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + 8 * i);
+                const float4 o0 = *reinterpret_cast<const float4*>(orow + 8 * i);
+                const float4 o1 = *reinterpret_cast<const float4*>(orow + 8 * i + 4);
+                part += o0.x * (float)dv[0] + o0.y * (float)dv[1] + o0.z * (float)dv[2] + o0.w * (float)dv[3] +
+                        o1.x * (float)dv[4] + o1.y * (float)dv[5] + o1.z * (float)dv[6] + o1.w * (float)dv[7];
+            }
+        } else {
+            const bf16* orow = a.ctx + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + 8 * i);
+                const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + 8 * i);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += (float)ov[e] * (float)dv[e];
+            }
+        }
+        part += __shfl_xor(part, 1, 64);
+        if (hh == 0) {
+            lds_delta[r] = (r < a.Sq) ? part : 0.f;
+            lds_lse[r] = (r < a.Sq) ? a.lse[(size_t)bh * a.Sq + r] * 1.4426950408889634f : INFINITY;
+        }
+    }
+    PROBE_AT(1);
+    stage_wait();
+    PROBE_AT(2);
+    const bool produce = k0 < a.Sk, consume = wave < nqt;
+    bf16x8 kf[NS];      // B operand of S = Q K^T for this wave's keys
+    if (produce) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kf[s] = frag_rm<D>(lds_k, k0, s, lane);
+    }
+    PROBE_AT(3);
+
+    const float sc2 = a.scale * 1.4426950408889634f;
+    const uint32_t dkey = drop_key(a.drop);
+    f32x16 dko[NDT] = {}, dvo[NDT] = {}, dqo[NDT] = {};
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int t = (wave + it) & 7;          // query tile this wave produces dS for in this step
+        if (produce && t < nqt) {
+            unsigned char* patch = patches + ((it & 1) * 8 + wave) * 2048;
+            // S[q][key], dPd[q][key]: rows q = 32t + (r&3) + 8(r>>2) + 4h, column key = k0 + x
+            f32x16 s_acc = {}, dp_acc = {};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_q, 32 * t, s, lane), kf[s], s_acc, 0, 0, 0);
+                dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_do, 32 * t, s, lane), vf[s], dp_acc, 0, 0, 0);
+            }
+            f32x16 pd;  // dropout(P) for dV
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 L4 = *reinterpret_cast<const float4*>(lds_lse + 32 * t + 8 * c + 4 * h);
+                const float4 D4 = *reinterpret_cast<const float4*>(lds_delta + 32 * t + 8 * c + 4 * h);
+                const float Lv[4] = {L4.x, L4.y, L4.z, L4.w};
+                const float Dv[4] = {D4.x, D4.y, D4.z, D4.w};
+                float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.drop.thr16) {
+                    // one hash serves the two keys of a pair (neighbouring lanes): even lanes hash queries i = 0, 2, odd lanes
+                    // i = 1, 3, and the lanes swap (DPP quad_perm 1,0,3,2) — half the hashing of a per-element draw
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int iq = 2 * j + (x & 1);
+                        const uint32_t q = 32 * t + 8 * c + 4 * h + iq;
+                        const uint32_t idx = ((uint32_t)bh * (uint32_t)a.Sq + q) * (uint32_t)a.skp + (uint32_t)(k0 + x);
+                        const uint32_t mine = drop_hash(dkey, idx >> 1);
+                        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
+                        const uint32_t he = (x & 1) ? other : mine, ho = (x & 1) ? mine : other;   // hashes of queries 2j, 2j+1
+                        const uint32_t ve = (x & 1) ? (he >> 16) : (he & 0xffffu), vo = (x & 1) ? (ho >> 16) : (ho & 0xffffu);
+                        dsc[2 * j] = (ve >= a.drop.thr16) ? a.drop.scale : 0.f;
+                        dsc[2 * j + 1] = (vo >= a.drop.thr16) ? a.drop.scale : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float mkq = mk;
+                    if constexpr (CZ) {   // causal tail (see tail_mask): this lane's key against query q
+                        const int q = 32 * t + 8 * c + 4 * h + i;
+                        if (kvalid && k0 + x >= a.cfrom) mkq = (q >= a.cfrom && k0 + x <= q) ? 0.f : -10000.f * 1.4426950408889634f;
+                    }
+                    const float p = __builtin_amdgcn_exp2f(s_acc[4 * c + i] * sc2 + mkq - Lv[i]);
+                    pd[4 * c + i] = p * dsc[i];
+                    s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * dsc[i] - Dv[i]);      // dS without the 1/sqrt(d): applied to dK, dQ at the end
+                }
+                // dS tile -> patch, row = key (this lane), 4 consecutive queries 8c + 4h .. + 3
+                *reinterpret_cast<bf16x4*>(patch + patch_off(x, 16 * c + 8 * h)) =
+                    pack4(s_acc[4 * c + 0], s_acc[4 * c + 1], s_acc[4 * c + 2], s_acc[4 * c + 3]);
+            }
+            // dV^T[d][key] += sum_q dO^T[d][q] Pd[q][key] ; dK^T[d][key] += sum_q Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 pf = frag_regs(pd, u);
+                const bf16x8 df = frag_regs(s_acc, u);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    dvo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_do, 32 * dt, 32 * t, u, lane), pf, dvo[dt], 0, 0, 0);
+                    dko[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_q, 32 * dt, 32 * t, u, lane), df, dko[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        // consumer: query tile `wave`, the patch of key tile kt (produced in this step by wave kt)
+        const int kt = (wave - it) & 7;
+        if (consume && kt * 32 < a.Sk) {
+            const unsigned char* src = patches + ((it & 1) * 8 + kt) * 2048;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 dst = frag_tr_patch(src, u, lane);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+                    dqo[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_k, 32 * dt, 32 * kt, u, lane), dst, dqo[dt], 0, 0, 0);
+            }
+        }
+    }
+    PROBE_AT(4);
+    // Epilogue: the three 32 x 64 result tiles of a wave (dK, dV of its keys, dQ of its queries) go through a private 4 KB LDS
+    // image each (the operand images are dead after the barrier) so that global memory sees whole 128-byte rows, 16 bytes per
+    // lane, instead of 8-byte pieces at a 4.6 KB stride.
+    __syncthreads();
+    unsigned char* mine = smem + wave * (3 * 4096);
+    if (produce) {
+        store_tile_rows(dko, a.scale, mine, a.dk + ((size_t)b * a.Sk + k0) * a.ldk + head * D, a.ldk, a.Sk - k0, lane);
+        store_tile_rows(dvo, 1.f, mine + 4096, a.dv + ((size_t)b * a.Sk + k0) * a.ldv + head * D, a.ldv, a.Sk - k0, lane);
+    }
+    PROBE_AT(5);
+    if (consume)
+        store_tile_rows(dqo, a.scale, mine + 8192, a.dq + ((size_t)b * a.Sq + k0) * a.ldq + head * D, a.ldq, a.Sq - k0, lane);
+    PROBE_AT(6);
+    PROBE_FLUSH(3, bh, wave);
 }
 
 int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
@@ -535,6 +825,18 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;
     const bool cz = a.cfrom < a.Sk;
+    if (a.hd == 64 && !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS)) {
+        const int lds = 3 * 256 * 128 + 16 * 2048 + 2 * 256 * 4;
+        if (cz) {
+            if (int rc = set_lds(attn_bwd_fused_kernel<true>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<true>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+        } else {
+            if (int rc = set_lds(attn_bwd_fused_kernel<false>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<false>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+        }
+        MMF_CHECK_LAUNCH();
+        return 0;
+    }
     {
         const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
 #define LAUNCH_DQ(N, DD, CZ)                                                                     \
@@ -564,4 +866,23 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         MMF_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// Development aid (see WaveProbe): buf = (1 + capacity) * 96 bytes of zeroed device memory, NULL switches the probe off.  Only a
+// library built with -DMMF_ATTN_PROBE records anything; the regular build returns an error.
+extern "C" int mmf_attention_set_probe(void* buf, int64_t capacity_records) {
+#ifdef MMF_ATTN_PROBE
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    unsigned cap = (unsigned)(capacity_records > 0 ? capacity_records : 0);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_probe), &p, sizeof(p)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_attn_probe_cap), &cap, sizeof(cap)) != hipSuccess) {
+        mmf_amd_set_error("attention_set_probe: hipMemcpyToSymbol failed");
+        return 2;
+    }
+    return 0;
+#else
+    (void)buf; (void)capacity_records;
+    mmf_amd_set_error("attention_set_probe: this library was built without -DMMF_ATTN_PROBE");
+    return 1;
+#endif
 }

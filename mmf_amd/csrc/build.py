@@ -2,6 +2,9 @@
 
     python -m mmf_amd.csrc.build            # incremental
     python -m mmf_amd.csrc.build --force
+    MMF_AMD_EXTRA_HIPCC_FLAGS=-DMMF_ATTN_PROBE python -m mmf_amd.csrc.build --tag probe
+                                            # instrumented copy: objects *.probe.o, mmf_amd/libmmf_amd.probe.so (load it with
+                                            # MMF_AMD_LIB=...); the regular library is left alone
 
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so travels to the GPU box with the
 repo snapshot (it is git-ignored, not gpurun-ignored).
@@ -31,8 +34,8 @@ def _stale(obj, src):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(HERE, src.replace(".hip", ".o"))
+def _compile(src, force, tag=""):
+    obj = os.path.join(HERE, src.replace(".hip", tag + ".o"))
     path = os.path.join(HERE, src)
     if force or _stale(obj, path):
         cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
@@ -44,9 +47,11 @@ def _compile(src, force):
     return obj
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tag=""):
+    tag = "." + tag if tag else ""
+    LIB = os.path.join(os.path.dirname(HERE), "libmmf_amd%s.so" % tag)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, force, tag), SOURCES))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,4 +63,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tag=sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "")

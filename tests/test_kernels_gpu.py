@@ -407,6 +407,43 @@ def test_attention_dropout_consistent_between_forward_and_backward():
         close(g, ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name + " (dropout)")
 
 
+@pytest.mark.parametrize("B,heads,Sq,Sk,tail,p", [(2, 3, 228, 228, 0, 0.1), (1, 2, 37, 37, 0, 0.0), (1, 1, 256, 256, 0, 0.1),
+                                                  (2, 2, 100, 228, 0, 0.1), (2, 2, 228, 100, 0, 0.0), (1, 2, 20, 200, 0, 0.1),
+                                                  (2, 2, 182, 182, 12, 0.1), (1, 1, 32, 32, 5, 0.0)])
+def test_attention_one_pass_backward_agrees_with_the_two_kernel_backward(B, heads, Sq, Sk, tail, p):
+    """head_dim 64: the fused backward (one workgroup per (batch, head), dS transposed through LDS, dQ accumulated in LDS) against
+    the separate dQ and dK/dV kernels (MMF_TUN_ATTN_BWD_TWO_PASS): same dropout decisions, same masks (key mask, prefix-LM tail),
+    same gradients up to bf16 rounding of differently ordered sums; rectangular (cross-attention) shapes included."""
+    H = heads * 64
+    q = rnd(B * Sq, H, scale=1.0); kv = rnd(B * Sk, 2 * H, scale=1.0)
+    mbin = (torch.rand(B, Sk, device=DEV) > 0.2).long(); mbin[:, 0] = 1
+    mask = torch.empty(B, Sk, device=DEV)
+    nat().make_additive_mask(mbin, mask)
+    drop = nat().drop_cfg(p, 4242) if p > 0 else nat().NO_DROP
+    ctx = torch.empty(B * Sq, H, dtype=torch.bfloat16, device=DEV); o32 = torch.empty(B * Sq, H, device=DEV)
+    lse = torch.empty(B, heads, Sq, device=DEV)
+    k, v = kv[:, :H], kv[:, H:]
+    nat().attention_fwd(q, k, v, H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, 0.125, drop, ctx_f32=o32, causal_tail=tail)
+    dctx = rnd(B * Sq, H)
+    outs = {}
+    try:
+        for two_pass in (1, 0):
+            nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, two_pass)
+            for exact in (True, False):
+                dq = torch.full_like(q, 7.0); dkv = torch.full_like(kv, 7.0); delta = torch.empty(B, heads, Sq, device=DEV)
+                nat().attention_bwd(q, k, v, H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, 0.125, dctx, dq, dkv[:, :H], dkv[:, H:],
+                                    delta, drop, ctx_f32=o32 if exact else None, causal_tail=tail)
+                outs[(two_pass, exact)] = (dq.float(), dkv.float())
+    finally:
+        nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, 0)
+    for exact in (True, False):
+        for name, a_, b_ in (("dq", outs[(0, exact)][0], outs[(1, exact)][0]), ("dk|dv", outs[(0, exact)][1], outs[(1, exact)][1])):
+            assert torch.isfinite(a_).all()
+            close(a_, b_, 2e-2, 1e-2 * float(b_.abs().max()), "%s one-pass vs two-kernel (exact delta %s)" % (name, exact))
+            # no systematic difference: the mean signed deviation is far below one bf16 ulp of the typical magnitude
+            assert abs(float((a_ - b_).mean())) <= 1e-3 * float(b_.abs().mean()) + 1e-6, name
+
+
 # ---------------------------------------------------------------------------------------------
 # LayerNorm
 # ---------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """On-hardware sweeps of the tuning knobs (include/mmf_amd.h MMF_TUN_*): LayerNorm-backward grid, split-K count of the
-weight-gradient GEMMs (both GEMM forms).  python tools/micro_sweep.py [ln] [wgrad]"""
+weight-gradient GEMMs (both GEMM forms).  python tools/micro_sweep.py [ln] [wgrad] [attn]"""
 import os
 import sys
 
@@ -56,6 +56,29 @@ def ln_sweep():
         print("ln_bwd grid %3d: plain %6.1f us   dropout+dbias %6.1f us (incl. reduce kernel)" % (grid, t0, t1), flush=True)
     nat.set_tunable(nat.TUN_LN_BWD_GRID, 0)
     nat.set_tunable(nat.TUN_LN_OLD, 0)
+
+
+def attn_sweep():
+    """Attention kernels at the VisualBERT VQA2 shape, steady state (hipGraph replays): forward, one-pass backward, two-kernel backward."""
+    B, A, S, H = 32, 12, 228, 768
+    qkv = (torch.randn(B * S, 3 * H, device="cuda") * 0.5).bfloat16()
+    mask = torch.zeros(B, S, device="cuda")
+    ctx = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16); ctx32 = torch.empty(B * S, H, device="cuda")
+    lse = torch.empty(B * A * S, device="cuda"); delta = torch.empty(B * A * S, device="cuda")
+    dctx = (torch.randn(B * S, H, device="cuda") * 0.1).bfloat16(); dqkv = torch.empty_like(qkv)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    for p in (0.1, 0.0):
+        drop = nat.drop_cfg(p, 99, None) if p else nat.NO_DROP
+        for o32 in (ctx32, None):
+            fwd = lambda: nat.attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, A, S, S, 0.125, drop=drop, ctx_f32=o32)
+            bwd = lambda: nat.attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, A, S, S, 0.125, dctx, dqkv[:, :H],
+                                            dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta, drop=drop, ctx_f32=o32)
+            t_f = timeit(fwd)
+            nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, 0); t_1 = timeit(bwd)
+            nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, 1); t_2 = timeit(bwd)
+            nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, 0)
+            print("attention B=32 S=228 dropout %.1f fp32-ctx %-5s: fwd %6.1f us   bwd one-pass %6.1f us   bwd two-kernel %6.1f us"
+                  % (p, o32 is not None, t_f, t_1, t_2), flush=True)
 
 
 def wgrad_sweep():
@@ -124,3 +147,5 @@ if __name__ == "__main__":
         gemm_variants(ABLATIONS)
     if "wide" in which:       # forward shapes: dispatcher's choice (wide tiles where the model says so) against the 128-row kernel
         gemm_variants((("auto", 0), ("128-row", 1 << 17)))
+    if "attn" in which:
+        attn_sweep()

@@ -96,6 +96,43 @@ DEVI bf16x8 frag_regs(const f32x16& p, int u) {
     return r;
 }
 
+// A wave's transposed result tile T^T[d][row] (lane x = row, registers -> d = 32 dt + (r&3) + 8(r>>2) + 4h) -> bf16 rows
+// g[row * ld + 0..63] for row < nvalid, through a wave-private swizzled row-major LDS image (4 KB).
+DEVI void store_tile_rows(const f32x16 (&acc)[2], float mul, unsigned char* img, bf16* g, int ld, int nvalid, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<bf16x4*>(img + rm_off<64>(x, 4 * dt + c) + 8 * h) =
+                pack4(acc[dt][4 * c + 0] * mul, acc[dt][4 * c + 1] * mul, acc[dt][4 * c + 2] * mul, acc[dt][4 * c + 3] * mul);
+    asm volatile("" ::: "memory");      // LDS operations of one wave complete in order; keep the compiler from reordering them
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), chunk = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(img + rm_off<64>(row, chunk));
+        if (row < nvalid) *reinterpret_cast<uint4*>(g + (size_t)row * ld + 8 * chunk) = v;
+    }
+}
+
+// The same for an fp32 copy of the rows (256-byte rows; 16-byte chunks XOR-swizzled by row & 15), 8 KB image.
+DEVI void store_tile_rows_f32(const f32x16 (&acc)[2], float mul, unsigned char* img, float* g, int ld, int nvalid, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<float4*>(img + x * 256 + (((8 * dt + 2 * c + h) ^ (x & 15)) << 4)) =
+                make_float4(acc[dt][4 * c + 0] * mul, acc[dt][4 * c + 1] * mul, acc[dt][4 * c + 2] * mul, acc[dt][4 * c + 3] * mul);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + (lane >> 4), chunk = lane & 15;
+        const float4 v = *reinterpret_cast<const float4*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
+        if (row < nvalid) *reinterpret_cast<float4*>(g + (size_t)row * ld + 4 * chunk) = v;
+    }
+}
+
 // Prefix-LM mask of M4C's multimodal transformer (mmf/models/m4c.py:424-440), folded into the key mask: keys at or after
 // `cfrom` (the decoding steps) are visible only to queries q >= cfrom with key <= q, whatever the key mask says; every
 // other (query, key) pair keeps the additive key mask.  Values are in the log2 domain like lds_mask.
@@ -190,7 +227,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     PROBE_AT(1);
     stage_wait();
     PROBE_AT(2);
-    if (q0 >= a.Sq) return;
+    if (D != 64 && q0 >= a.Sq) return;     // (the head_dim-64 build has a barrier ahead of its epilogue: idle waves run along)
 
     // scores^T tiles: sc[t][r] = S[q = q0+x][key = 32t + (r&3) + 8(r>>2) + 4h]
     f32x16 sc[NKT];
@@ -228,7 +265,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(sc[t][r] - mx);
+            const float p = __builtin_amdgcn_exp2f(sc[t][r] - mx);     // bare v_exp_f32: arguments <= 0, underflow to 0 is the intent
             sc[t][r] = p;
             sum += p;
         }
@@ -264,6 +301,17 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
         }
 
     PROBE_AT(6);
+    if constexpr (D == 64) {
+        // whole 128-byte (bf16) / 256-byte (fp32) rows to global memory, through a wave-private LDS image laid over the
+        // K / V images once every wave of the workgroup is done with them
+        __syncthreads();
+        unsigned char* mine = smem + wave * (4096 + 8192);
+        if (q0 < a.Sq) {
+            store_tile_rows(o, inv, mine, a.ctx + ((size_t)b * a.Sq + q0) * a.ldo + head * HD, a.ldo, a.Sq - q0, lane);
+            if (a.ctx32)
+                store_tile_rows_f32(o, inv, mine + 4096, a.ctx32 + ((size_t)b * a.Sq + q0) * a.ldo + head * HD, a.ldo, a.Sq - q0, lane);
+        }
+    } else
     if (q0 + x < a.Sq) {
         bf16* optr = a.ctx + ((size_t)b * a.Sq + q0 + x) * a.ldo + head * HD;
 #pragma unroll
@@ -388,7 +436,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
             if (a.drop.thr16) ds = drop_scale4(drop_key(a.drop), rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float p = exp2f(s_acc[4 * c + i] * sc2 + mkv[i] - L);
+                const float p = __builtin_amdgcn_exp2f(s_acc[4 * c + i] * sc2 + mkv[i] - L);
                 s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * ds[i] - dl) * a.scale;
             }
         }
@@ -490,7 +538,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
                 if constexpr (CZ) {   // causal tail (see tail_mask): this lane's key against query q
                     if (kvalid && k0 + x >= a.cfrom) mkq = (q >= a.cfrom && k0 + x <= q) ? 0.f : -10000.f * 1.4426950408889634f;
                 }
-                const float p = exp2f(s_acc[4 * c + i] * sc2 + mkq - Lv[i]);
+                const float p = __builtin_amdgcn_exp2f(s_acc[4 * c + i] * sc2 + mkq - Lv[i]);
                 pd[4 * c + i] = p * dsc;
                 s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * dsc - Dv[i]) * a.scale;
             }
@@ -556,25 +604,6 @@ DEVI bf16x8 frag_tr_patch(const unsigned char* patch, int u, int lane) {
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return __builtin_bit_cast(bf16x8, r);
-}
-
-// A wave's transposed result tile T^T[d][row] (lane x = row, registers -> d = 32 dt + (r&3) + 8(r>>2) + 4h) -> bf16 rows
-// g[row * ld + 0..63] for row < nvalid, through a wave-private swizzled row-major LDS image (4 KB).
-DEVI void store_tile_rows(const f32x16 (&acc)[2], float mul, unsigned char* img, bf16* g, int ld, int nvalid, int lane) {
-    const int x = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            *reinterpret_cast<bf16x4*>(img + rm_off<64>(x, 4 * dt + c) + 8 * h) =
-                pack4(acc[dt][4 * c + 0] * mul, acc[dt][4 * c + 1] * mul, acc[dt][4 * c + 2] * mul, acc[dt][4 * c + 3] * mul);
-    asm volatile("" ::: "memory");      // LDS operations of one wave complete in order; keep the compiler from reordering them
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * i + (lane >> 3), chunk = lane & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(img + rm_off<64>(row, chunk));
-        if (row < nvalid) *reinterpret_cast<uint4*>(g + (size_t)row * ld + 8 * chunk) = v;
-    }
 }
 
 template <bool CZ>
@@ -797,7 +826,8 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
 #define LAUNCH_FWD(N, DD, CZ)                                                                    \
     {                                                                                            \
-        const int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4;                                      \
+        int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4;                                            \
+        if (DD == 64 && lds < 4 * 12288) lds = 4 * 12288;   /* the epilogue's row images */      \
         if (int rc = set_lds(attn_fwd_kernel<N, DD, CZ>, lds)) return rc;                        \
         hipLaunchKernelGGL((attn_fwd_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);            \
     }

@@ -238,7 +238,16 @@ def main():
         return registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8, capturable=capturable)
 
     use_graph = (world == 1) and not args.no_graph
-    opt = None if args.no_optimizer else make_optimizer(capturable=use_graph)
+    # N > 1: the step is a CHAIN of hipGraphs (forward | backward cut at three encoder layers | AdamW) with the bucket all-reduces
+    # launched between them (mmf_amd/utils/graph.py GraphedDataParallelStep); the eager step + GradientReducer hooks is the fallback
+    use_chain = (world > 1) and not args.no_graph and not args.no_optimizer
+    opt = None if args.no_optimizer else make_optimizer(capturable=use_graph or use_chain)
+
+    def chained_step(optimizer):
+        from mmf_amd.utils.graph import GraphedDataParallelStep
+        layers = [m for m in model.modules() if type(m).__name__ == "BertLayerJit"]
+        cuts = [layers[i] for i in (2, 5, 8) if i < len(layers) - 1]
+        return GraphedDataParallelStep(model, batch, cuts, optimizer, warmup=2)
 
     def eager_step(optimizer=None):
         model.zero_grad(set_to_none=True)
@@ -269,13 +278,29 @@ def main():
             dt_ = float(t.item())
         return dt_, float(last.item())
 
+    launch = "eager"
     if use_graph:
         # one hipGraph for forward + loss + backward + AdamW (mmf_amd/utils/graph.py): removes the per-kernel launch cost
         from mmf_amd.utils.graph import GraphedTrainStep
         graphed = GraphedTrainStep(model, batch, warmup=2, optimizer=opt)
         dt, loss_val = timed(lambda: graphed())
+        launch = "hipGraph"
     else:
-        dt, loss_val = timed(lambda: eager_step(opt))
+        chain = None
+        if use_chain:
+            try:
+                reducer.remove()        # the chain packs and reduces the gradients itself
+                chain = chained_step(opt)
+            except Exception as e:      # same kernels either way: fall back to launching them one by one
+                sys.stderr.write("bench: chained hipGraphs unavailable (%s: %s); eager step\n" % (type(e).__name__, e))
+                chain = None
+                reducer = parallelize_model(model)
+                opt = make_optimizer(capturable=False)
+        if chain is not None:
+            dt, loss_val = timed(lambda: chain())
+            launch = "hipGraph chain (forward | 4 backward stages | AdamW), all-reduce between stages"
+        else:
+            dt, loss_val = timed(lambda: eager_step(opt))
     h2d = None
     if use_graph:
         # PCIe-inclusive rate (never `value`): every step consumes a NEW host batch, staged in pinned memory and copied on a
@@ -311,8 +336,16 @@ def main():
         torch.cuda.synchronize()
         t_all = (time.perf_counter() - t0) / n_e
         eager_info = {"ms_per_step": round(t_all * 1e3, 3), "host_enqueue_ms_per_step": round(t_host * 1e3, 3),
-                      "note": "eager launch path (no hipGraph), as N > 1 runs it: the host is ahead of the GPU while enqueue < step"}
+                      "note": "eager launch path (no hipGraph): the fallback of the N > 1 step; host-bound when enqueue > GPU step"}
         del eopt
+        if not args.no_optimizer and not args.no_graph:
+            # the launch structure N > 1 runs (chain of hipGraphs, collectives between the stages), here without the collectives
+            copt = make_optimizer(capturable=True)
+            chain = chained_step(copt)
+            dtc, _ = timed(lambda: chain())
+            eager_info["chained_graphs"] = {"ms_per_step": round(dtc / args.steps * 1e3, 3), "graphs_per_step": 2 + len(chain.g_bwd),
+                                            "note": "the N > 1 launch path at N = 1 (no all-reduce): forward | backward stages | AdamW"}
+            del chain, copt
 
     # one instrumented step for the roofline of the dominant kernel
     with KernelProbe() as probe:
@@ -358,7 +391,7 @@ def main():
             "config": {"workload": "VisualBERT-base single-stream (100 regions + 128 tok) VQA2 bf16, fwd+logit_bce+bwd%s%s"
                                    % ("+AdamW" if opt is not None else "", "" if not args.eval_mode else " (eval mode)"),
                        "global_batch": args.batch * world, "seq_len": 228, "parallelism": "dp%d" % world,
-                       "dropout": not args.eval_mode, "loss": round(loss_val, 4), "launch": "hipGraph" if use_graph else "eager",
+                       "dropout": not args.eval_mode, "loss": round(loss_val, 4), "launch": launch,
                        "optimizer": None if opt is None else "adam_w (fused multi-tensor HIP AdamW, lr 5e-5) inside the timed step"},
             "roofline": roof,
         }

@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(mmf_adamw_multi_desc d
     }
     float gs = d.grad_scale;
     if (d.norm_sq) {   // gradient clipping folded into the update: coef = min(1, max_norm / (||g|| + 1e-6))
-        const float coef = d.max_norm / (sqrtf(d.norm_sq[0]) + 1e-6f);
+        const float coef = d.max_norm / (sqrtf(d.norm_sq[0]) * d.grad_scale + 1e-6f);    // the norm of the SCALED gradients
         gs *= coef < 1.f ? coef : 1.f;
     }
     const int64_t end = (base + MT_CHUNK < n) ? base + MT_CHUNK : n;

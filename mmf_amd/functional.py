@@ -99,7 +99,13 @@ DGRAD_NT = os.environ.get("MMF_AMD_DGRAD_NT", "0") == "1"
 
 class ShadowCache:
     """bf16 copies of fp32 parameters, refreshed (one cast kernel) whenever the parameter's version
-    counter or storage changes.  Several parameters can share one contiguous shadow (Q|K|V)."""
+    counter or storage changes.  Several parameters can share one contiguous shadow (Q|K|V).
+
+    What does NOT refresh a shadow: writes that bypass the version counter — `p.data.copy_(...)`, `p.data.mul_(...)` (EMA
+    averaging, manual re-initialisation after the first forward) or a foreign kernel writing through `data_ptr()`.  After such
+    an edit call `mmf_amd.functional.shadows.clear()` (every shadow is re-cast on its next use).  `load_state_dict`, torch
+    optimizers and in-place ops on the parameter itself bump the version and are picked up automatically; the fused `adam_w`
+    rewrites parameter and shadow in the same kernel."""
 
     def __init__(self):
         self._store = {}  # id(head parameter) -> (signature, buffer, dtype); entry dies with the parameter

@@ -37,6 +37,22 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("schedule=('warmup_linear', warmup_steps, total_steps) needs capturable=True")
         self._schedule = (0, 0.0, 0.0) if schedule is None else (1, float(schedule[1]), float(schedule[2]))
         self._dev_state = None
+        self.grad_scale = 1.0       # every gradient is multiplied by this inside the update (a data-parallel SUM becomes the mean)
+
+    @torch.no_grad()
+    def ensure_state(self, params=None):
+        """Allocate the moments of `params` (default: every parameter) now instead of at their first step: a hipGraph capture of
+        `step()` must not contain the zero-fills."""
+        wanted = None if params is None else {id(p) for p in params}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if (wanted is None or id(p) in wanted) and len(self.state[p]) == 0:
+                    st = self.state[p]
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        if self.capturable and self._dev_state is None:
+            self._dev_state = torch.zeros(2, dtype=torch.float32, device=self.param_groups[0]["params"][0].device)
 
     @torch.no_grad()
     def clip_grad_norm(self, max_norm):
@@ -48,7 +64,7 @@ class AdamW(torch.optim.Optimizer):
         norm_sq = torch.empty(1, dtype=torch.float32, device=grads[0].device)
         nat.l2norm_sq_multi([g if g.is_contiguous() else g.contiguous() for g in grads], norm_sq)
         self._clip = (norm_sq, float(max_norm))
-        return norm_sq.sqrt()[0]
+        return norm_sq.sqrt()[0] * self.grad_scale
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -85,7 +101,7 @@ class AdamW(torch.optim.Optimizer):
             norm_sq, max_norm = self._clip if self._clip is not None else (None, 0.0)
             for step, items in sorted(by_step.items()):       # one launch per distinct step count (normally exactly one)
                 nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
-                                1.0, norm_sq, max_norm, dev_state)
+                                self.grad_scale, norm_sq, max_norm, dev_state)
         self._clip = None
         Fn.shadows.refresh_transposed()     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
         return loss

@@ -14,6 +14,7 @@ The fp32 -> bf16 weight-shadow casts are captured too, so replays see parameter 
 import gc
 
 import torch
+import torch.distributed as dist
 
 from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
@@ -58,7 +59,11 @@ def _copy_batch(dst, src):
 class GraphedTrainStep:
     """`optimizer` (an `adam_w` built with `capturable=True`) puts the parameter update into the graph as well: one
     replay = one full training step.  The optimizer then also keeps the bf16 weight shadows current, so no cast kernel
-    is captured; without it the casts are captured so that replays see updates made between them."""
+    is captured; without it the casts are captured so that replays see updates made between them.
+
+    The eager warm-up passes (they populate the allocator and the weight shadows) run forward + backward only: no
+    parameter is updated and no step is counted before the first replay; the optimizer's moments are allocated up front
+    (`ensure_state`) so that the captured update contains no zero-fill."""
 
     def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None):
         self.model = model
@@ -71,11 +76,13 @@ class GraphedTrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = next(model.parameters()).device
         self.seed = torch.zeros(1, dtype=torch.int32, device=dev)
+        if optimizer is not None:
+            optimizer.ensure_state(self.params)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), Fn.dropout_keys.graph_mode(self.seed):
             for _ in range(warmup):
-                self._eager()
+                self._eager(update=False)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -86,7 +93,7 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph):
                 self.out, self.loss = self._eager()
 
-    def _eager(self):
+    def _eager(self, update=True):
         Fn.nat.seed_advance(self.seed)
         out = self.model(self.static_batch)
         loss = self.loss_of(out)
@@ -97,7 +104,7 @@ class GraphedTrainStep:
         grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g
-        if self.optimizer is not None:
+        if self.optimizer is not None and update:
             self.optimizer.step()
         return out, loss
 
@@ -105,4 +112,198 @@ class GraphedTrainStep:
         if batch is not None:
             _copy_batch(self.static_batch, batch)
         self.graph.replay()
+        return self.loss
+
+
+class GraphedDataParallelStep:
+    """The training step of ONE data-parallel rank as a short chain of hipGraphs with the gradient all-reduces between them
+    (collective C1 of SURVEY.md section 2.3; the reference wraps the model in DistributedDataParallel, mmf/trainers/core/device.py:104-110):
+
+        F (forward + loss) | B_0 | B_1 | ... | B_n (backward, cut at the outputs of `cuts`) | O (unpack + AdamW)
+                             `-> all-reduce of stage 0's gradients on the communicator's stream, while B_1 replays, ...
+
+    so the host enqueues ~2n + 4 operations per step instead of ~450 kernels (the eager N > 1 step is host-bound: bench.py's
+    "eager" leg) and the collectives themselves stay outside the graphs (RCCL launched eagerly between replays — nothing
+    depends on collective-in-graph support).  `cuts` are modules whose output tensor splits the network (e.g. three encoder
+    layers): the forward hands the next module a detached copy, which makes each segment its own autograd graph; stage j of
+    the backward is `torch.autograd.grad` of segment n - j, seeded with the gradient the previous stage produced for the
+    detached copy.  Which parameters belong to which stage is discovered once in the eager warm-up (a parameter used in
+    several segments is summed and travels with the last stage that touches it; parameters that never receive a gradient —
+    the BertPooler under `pooler_strategy: vqa` — are left with `grad = None`, the same set on every rank).
+
+    Gradients of a stage are packed by the stage's graph into one flat buffer per wire type — `comm_dtype` (bf16: half the
+    xGMI bytes) and fp32 for `fp32_params` (default: embedding tables, whose rows collect sparse, differently scaled
+    contributions) — summed over the ranks, and `O` converts to fp32 where needed; the 1 / world_size of the mean is folded
+    into the optimizer's update (`optimizer.grad_scale`).  The optimizer must be `capturable=True`; its state is allocated
+    before the capture (`ensure_state`) and the warm-up runs no optimizer step: the first replay is step 1."""
+
+    def __init__(self, model, batch, cuts, optimizer, process_group=None, comm_dtype=None, fp32_params=None, warmup=2, loss_of=None):
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedDataParallelStep needs an optimizer whose step reads its counters from device memory (capturable=True)")
+        self.model, self.optimizer, self.group = model, optimizer, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        if comm_dtype is None:
+            comm_dtype = torch.bfloat16 if self.world > 1 else torch.float32
+        self.comm_dtype = comm_dtype
+        self.loss_of = loss_of or (lambda out: sum(v.sum() for v in out["losses"].values()))
+        self.cuts = list(cuts)
+        release_autograd_state()
+        self.static_batch = _clone_batch(batch)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if fp32_params is None:
+            fp32_ids = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Embedding)}
+        else:
+            fp32_ids = {id(p) for p in fp32_params}
+        dev = self.params[0].device
+        self.seed = torch.full((1,), 7919 * rank, dtype=torch.int32, device=dev)      # ranks draw different dropout masks
+        self._bounds, self._hooking = [], False
+        handles = [m.register_forward_hook(self._cut_hook) for m in self.cuts]
+        try:
+            optimizer.ensure_state(self.params)
+            optimizer.grad_scale = 1.0 / self.world
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), Fn.dropout_keys.graph_mode(self.seed):
+                # eager warm-up (no optimizer step); the first pass also assigns parameters to backward stages
+                self.stage_params = None
+                for _ in range(max(1, warmup)):
+                    self._forward()
+                    self._discover_or_run()
+                    self._bounds = []
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            model.zero_grad(set_to_none=True)
+            release_autograd_state()
+            self._layout(fp32_ids, dev)
+            pool = torch.cuda.graph_pool_handle()
+            self.g_fwd = torch.cuda.CUDAGraph()
+            self.g_bwd = [torch.cuda.CUDAGraph() for _ in self.stage_params]
+            self.g_opt = torch.cuda.CUDAGraph()
+            with Fn.dropout_keys.graph_mode(self.seed):
+                with torch.cuda.graph(self.g_fwd, pool=pool):
+                    self.out, self.loss = self._forward()
+                carry = None
+                self._keep = []
+                for j, g in enumerate(self.g_bwd):
+                    with torch.cuda.graph(g, pool=pool):
+                        grads, carry = self._stage_grads(j, carry, self.stage_params[j])
+                        self._pack(j, grads)
+                    self._keep.append((grads, carry))
+                with torch.cuda.graph(self.g_opt, pool=pool):
+                    self._unpack()
+                    optimizer.step()
+        finally:
+            for h in handles:
+                h.remove()
+        self._bounds = []
+
+    # ---- forward with cut points --------------------------------------------------------------------------------------
+    def _cut_hook(self, module, inputs, output):
+        if not self._hooking:
+            return None
+        t = output[0] if isinstance(output, tuple) else output
+        d = t.detach().requires_grad_()
+        self._bounds.append((t, d))
+        return (d,) + tuple(output[1:]) if isinstance(output, tuple) else d
+
+    def _forward(self):
+        Fn.nat.seed_advance(self.seed)
+        self._bounds, self._hooking = [], True
+        try:
+            out = self.model(self.static_batch)
+        finally:
+            self._hooking = False
+        if len(self._bounds) != len(self.cuts):
+            raise RuntimeError("GraphedDataParallelStep: %d of the %d cut modules ran in the forward" % (len(self._bounds), len(self.cuts)))
+        self._loss_t = self.loss_of(out)
+        return out, self._loss_t
+
+    # ---- backward, one stage at a time ------------------------------------------------------------------------------------
+    def _stage_grads(self, j, carry, params):
+        """Stage j (0 = the segment that ends in the loss): gradients of `params` and of the detached input of the segment."""
+        n = len(self._bounds)
+        root = self._loss_t if j == 0 else self._bounds[n - j][0]
+        inputs = list(params) + ([self._bounds[n - j - 1][1]] if j < n else [])
+        grads = torch.autograd.grad(root, inputs, grad_outputs=None if j == 0 else carry, allow_unused=True)
+        if j < n:
+            if grads[-1] is None:
+                raise RuntimeError("GraphedDataParallelStep: the loss does not depend on the output of cut %d" % (n - j - 1))
+            return list(grads[:-1]), grads[-1]
+        return list(grads), None
+
+    def _discover_or_run(self):
+        first = self.stage_params is None
+        stages, carry = [], None
+        for j in range(len(self.cuts) + 1):
+            cand = self.params if first else self.stage_params[j]
+            grads, carry = self._stage_grads(j, carry, cand)
+            stages.append([p for p, g in zip(cand, grads) if g is not None])
+        if first:
+            self.stage_params = stages
+            seen = {}
+            for j, plist in enumerate(stages):
+                for p in plist:
+                    seen.setdefault(id(p), []).append(j)
+            self._shared = {k: v for k, v in seen.items() if len(v) > 1}     # id -> stages; packed with the last one
+
+    # ---- flat wire buffers ------------------------------------------------------------------------------------------------
+    def _layout(self, fp32_ids, dev):
+        self.buckets = []        # per stage: dict(p16, o16, wire16, g32, p32, o32, wire32)
+        last_stage = {k: v[-1] for k, v in self._shared.items()}
+        self._partial = {k: None for k in self._shared}      # running sums of shared parameters
+        for j, plist in enumerate(self.stage_params):
+            mine = [p for p in plist if last_stage.get(id(p), j) == j]
+            b = dict(p16=[], o16=[], p32=[], o32=[])
+            n16 = n32 = 0
+            for p in mine:
+                wide = id(p) in fp32_ids or self.comm_dtype == torch.float32
+                (b["p32"] if wide else b["p16"]).append(p)
+                if wide:
+                    b["o32"].append(n32); n32 += (p.numel() + 63) // 64 * 64
+                else:
+                    b["o16"].append(n16); n16 += (p.numel() + 63) // 64 * 64
+            b["wire16"] = torch.zeros(n16, dtype=self.comm_dtype, device=dev) if n16 else None
+            b["g32"] = torch.zeros(n16, dtype=torch.float32, device=dev) if n16 else None
+            b["wire32"] = torch.zeros(n32, dtype=torch.float32, device=dev) if n32 else None
+            self.buckets.append(b)
+
+    def _pack(self, j, grads):
+        b = self.buckets[j]
+        have = {}
+        for p, g in zip(self.stage_params[j], grads):
+            if id(p) in self._shared:
+                acc = self._partial[id(p)]
+                g = g if acc is None else acc + g
+                self._partial[id(p)] = g
+            have[id(p)] = g
+        for plist, offs, flat in ((b["p16"], b["o16"], b["wire16"]), (b["p32"], b["o32"], b["wire32"])):
+            if plist:
+                torch._foreach_copy_([flat[o:o + p.numel()].view_as(p) for p, o in zip(plist, offs)], [have[id(p)] for p in plist])
+
+    def _unpack(self):
+        for b in self.buckets:
+            if b["wire16"] is not None:
+                b["g32"].copy_(b["wire16"])
+                for p, o in zip(b["p16"], b["o16"]):
+                    p.grad = b["g32"][o:o + p.numel()].view_as(p)
+            for p, o in zip(b["p32"], b["o32"]):
+                p.grad = b["wire32"][o:o + p.numel()].view_as(p)
+
+    # ---- one training step ------------------------------------------------------------------------------------------------
+    def __call__(self, batch=None):
+        if batch is not None:
+            _copy_batch(self.static_batch, batch)
+        self.g_fwd.replay()
+        works = []
+        for j, g in enumerate(self.g_bwd):
+            g.replay()
+            if self.world > 1:
+                b = self.buckets[j]
+                for flat in (b["wire16"], b["wire32"]):
+                    if flat is not None:
+                        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        self.g_opt.replay()
         return self.loss

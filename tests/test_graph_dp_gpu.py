@@ -1,0 +1,142 @@
+"""The data-parallel training step as a chain of hipGraphs (mmf_amd/utils/graph.py GraphedDataParallelStep): forward, backward cut
+into stages at encoder layers, optimizer — with the gradient all-reduces launched between the stage graphs.
+
+  * one rank: the chained graphs must train exactly like the eager step (same kernels, same order inside every segment);
+  * two ranks sharing the GPU over gloo: both ranks end every step with the same parameters, and the update is the update
+    of the whole batch (mean gradient) up to bf16 on the wire.
+Reference for the semantics: DistributedDataParallel at mmf/trainers/core/device.py:104-110."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _layers(model):
+    return [m for m in model.modules() if type(m).__name__ == "BertLayerJit"]
+
+
+def _optimizer(model, capturable):
+    from mmf_amd.modules.optimizers import AdamW
+    return AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-8, weight_decay=0.01, capturable=capturable)
+
+
+def test_chained_graphs_train_like_the_eager_step():
+    from mmf_amd.common.sample import SampleList
+    from mmf_amd.utils.graph import GraphedDataParallelStep
+    from tests.golden_utils import load_case
+    from tests.model_utils import build_visual_bert, sample_to
+    z, case, cfg, sd, sample = load_case("small64")
+    batch = SampleList(sample_to(sample, "cuda"))
+    eager = build_visual_bert(cfg, sd); eager.eval()           # eval: no dropout, the two runs see the same arithmetic
+    chained = build_visual_bert(cfg, sd); chained.eval()
+    opt_e, opt_c = _optimizer(eager, False), _optimizer(chained, True)
+    step = GraphedDataParallelStep(chained, batch, _layers(chained), opt_c, warmup=2)
+    assert len(step.g_bwd) == 3 and [len(s) > 0 for s in step.stage_params] == [True, True, True]
+    names = {id(p): n for n, p in chained.named_parameters()}
+    assert all("layer.1" in names[id(p)] for p in step.stage_params[1])           # the middle stage is exactly encoder layer 1
+    assert any("word_embeddings" in names[id(p)] for p in step.stage_params[2])
+    unused = [n for n, p in chained.named_parameters() if not any(id(p) in {id(q) for q in s} for s in step.stage_params)]
+    assert unused and all("pooler" in n for n in unused), unused                  # `vqa` pooling never touches BertPooler
+    losses_e, losses_c = [], []
+    for _ in range(3):
+        eager.zero_grad(set_to_none=True)
+        out = eager(batch)
+        loss = sum(v.sum() for v in out["losses"].values())
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss))
+        losses_c.append(float(step()))
+    assert losses_c == pytest.approx(losses_e, rel=1e-5), (losses_c, losses_e)
+    assert losses_e[2] < losses_e[0]
+    pe, pc = dict(eager.named_parameters()), dict(chained.named_parameters())
+    for n in pe:
+        d = float((pe[n].detach() - pc[n].detach()).abs().max())
+        assert d <= 1e-6 + 1e-5 * float(pe[n].detach().abs().max()), (n, d)
+    assert int(round(float(opt_c._dev_state[0]))) == 3                            # the warm-up ran no optimizer step
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MMF_AMD_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from mmf_amd.common.sample import SampleList
+    from mmf_amd.utils import distributed as D
+    from mmf_amd.utils.graph import GraphedDataParallelStep
+    from tests.golden_utils import load_case
+    from tests.model_utils import build_visual_bert, sample_to
+    from tests.test_distributed_gpu import _batch4, _half
+    D.distributed_init_from_env()
+    z, case, cfg, sd, sample = load_case("small64")
+    full = _batch4(sample)
+    model = build_visual_bert(cfg, sd); model.eval()
+    opt = _optimizer(model, True)
+    step = GraphedDataParallelStep(model, SampleList(sample_to(_half(full, rank), "cuda")), _layers(model), opt, warmup=1)
+    wires = sorted({str(b[k].dtype) for b in step.buckets for k in ("wire16", "wire32") if b[k] is not None})
+    step()
+    torch.cuda.synchronize()
+    # after the step p.grad is bound to the reduced buffers: the SUM over ranks (the 1 / world lives in optimizer.grad_scale)
+    grads = {n: (p.grad.detach().float().cpu().numpy() if p.grad is not None else None) for n, p in model.named_parameters()}
+    step()
+    torch.cuda.synchronize()
+    got = {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()}
+    got["__grads__"] = grads
+    ref = None
+    if rank == 0:       # the whole batch, eagerly, on one rank at the initial parameters (a batch-mean loss: its gradient is the MEAN of the ranks')
+        whole = build_visual_bert(cfg, sd); whole.eval()
+        out = whole(SampleList(sample_to(full, "cuda")))
+        sum(v.sum() for v in out["losses"].values()).backward()
+        ref = {n: (p.grad.detach().float().cpu().numpy() if p.grad is not None else None) for n, p in whole.named_parameters()}
+        ref["__init__"] = {n: p.detach().float().cpu().numpy() for n, p in whole.named_parameters()}
+    q.put((rank, got, ref, wires))
+    D.synchronize()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_chained_graphs_apply_the_whole_batch_update():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            rank, got, ref, wires = q.get(timeout=150)
+            res[rank] = (got, ref, wires)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert res[0][2] == ["torch.bfloat16", "torch.float32"]
+    ref = res[0][1]
+    init = ref.pop("__init__")
+    g0s, g1s = res[0][0].pop("__grads__"), res[1][0].pop("__grads__")
+    checked = 0
+    for name, r in ref.items():
+        p0, p1 = torch.from_numpy(res[0][0][name]), torch.from_numpy(res[1][0][name])
+        assert torch.equal(p0, p1), name                   # replicas stay identical
+        if r is None:
+            assert g0s[name] is None and g1s[name] is None, name
+            assert torch.equal(p0, torch.from_numpy(init[name])), name          # never-used parameters are not touched
+            continue
+        g0, g1, r = torch.from_numpy(g0s[name]), torch.from_numpy(g1s[name]), torch.from_numpy(r)
+        assert torch.equal(g0, g1), name
+        g0 = g0 * 0.5                                      # the buffers hold the SUM; the update applies optimizer.grad_scale = 1 / world
+        scale = float(r.abs().max()) + 1e-12
+        tol = 3e-2 if "embeddings" not in name else 1e-2    # bf16 on the wire (fp32 for the embedding tables) + bf16 kernels at B = 2 vs 4
+        assert float((g0 - r).abs().max()) <= tol * scale, (name, float((g0 - r).abs().max()), scale)
+        assert not torch.equal(p0, torch.from_numpy(init[name])), name          # ... and two optimizer steps moved the parameter
+        checked += 1
+    assert checked > 30

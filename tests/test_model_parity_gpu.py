@@ -225,8 +225,11 @@ def test_graph_with_optimizer_is_one_full_training_step():
         return m, AdamW(m.parameters(), lr=1e-3, weight_decay=0.01, capturable=True)
 
     m1, o1 = fresh()
-    g = GraphedTrainStep(m1, batch, warmup=1, optimizer=o1)      # 1 eager warm-up update (the capture itself runs nothing)
-    g(); g()
+    g = GraphedTrainStep(m1, batch, warmup=1, optimizer=o1)      # neither the eager warm-up pass nor the capture updates anything
+    assert float(o1._dev_state[0]) == 0.0
+    for (n, p) in m1.named_parameters():
+        assert torch.equal(p.detach().cpu(), sd[n[len("model."):]].to(p.dtype)), n
+    g(); g(); g()
     assert float(o1._dev_state[0]) == 3.0
     m2, o2 = fresh()
     s2 = torch.cuda.Stream()

@@ -254,6 +254,18 @@ int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* 2-D casts with leading dimensions (elements); f32->bf16 zero-fills the pad columns [cols, ldd). */
 int mmf_cast2d_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int rows, int cols, void* stream);
 int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int rows, int cols, void* stream);
+/* ViLBERT `dynamic_attention` (mmf/models/vilbert.py:174-176, 199-212): the visual self-attention's queries and keys are
+ * multiplied, per sample, by 1 + sigmoid(Linear(masked mean of the text stream)).
+ *   mmf_masked_mean_fwd : pool[b][c] = sum_t x[b][t][c] mask[b][t] / sum_t mask[b][t]    (:204-205; x bf16 [B,T,H], mask fp32 [B,T])
+ *   mmf_masked_mean_bwd : dx[b][t][c] = dpool[b][c] mask[b][t] / sum_t mask[b][t]         (autograd of the above, bf16 out)
+ *   mmf_rowgroup_scale  : x[g * rows_per_group + r][c] *= gate[g][c] for c < C, in place (:211-212; the Q|K columns of the
+ *                         packed [rows, ld] bf16 projection, gate fp32 [groups, C])
+ *   mmf_rowgroup_scale_bwd : given y = x * gate and dy, writes dx = dy * gate over dy and dgate[g][c] = sum_r dy * x. */
+int mmf_masked_mean_fwd(const void* x, const float* mask, float* pool, int B, int T, int H, void* stream);
+int mmf_masked_mean_bwd(const float* dpool, const float* mask, void* dx, int B, int T, int H, void* stream);
+int mmf_rowgroup_scale(void* x, int ld, const float* gate, int groups, int rows_per_group, int C, void* stream);
+int mmf_rowgroup_scale_bwd(void* dy, const void* y, int ld, const float* gate, float* dgate, int groups, int rows_per_group, int C,
+                           void* stream);
 /* y[i] = x[i] * keep_scale(i): nn.Dropout forward AND backward (embeddings.py:458), bf16, n < 2^32. */
 int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
                      const uint32_t* drop_seed, void* stream);

@@ -374,6 +374,30 @@ def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, ou
            "mmf_rows_scatter_add")
 
 
+def masked_mean_fwd(x, mask, pool, B, T, H):
+    _req(x, torch.bfloat16, "x"); _req(mask, torch.float32, "mask"); _req(pool, torch.float32, "pool")
+    _check(lib().mmf_masked_mean_fwd(_p(x), _p(mask), _p(pool), B, T, H, _stream()), "mmf_masked_mean_fwd")
+
+
+def masked_mean_bwd(dpool, mask, dx, B, T, H):
+    _req(dpool, torch.float32, "dpool"); _req(mask, torch.float32, "mask"); _req(dx, torch.bfloat16, "dx")
+    _check(lib().mmf_masked_mean_bwd(_p(dpool), _p(mask), _p(dx), B, T, H, _stream()), "mmf_masked_mean_bwd")
+
+
+def rowgroup_scale(x, ld, gate, groups, rows_per_group, cols):
+    """x[g * rows_per_group + r, :cols] *= gate[g] in place (bf16 rows of leading dimension ld, gate fp32 [groups, cols])."""
+    _req(x, torch.bfloat16, "x"); _req(gate, torch.float32, "gate")
+    _check(lib().mmf_rowgroup_scale(_p(x), ld, _p(gate), groups, rows_per_group, cols, _stream()), "mmf_rowgroup_scale")
+
+
+def rowgroup_scale_bwd(dy, y, ld, gate, dgate, groups, rows_per_group, cols):
+    for t, n in ((dy, "dy"), (y, "y")):
+        _req(t, torch.bfloat16, n)
+    _req(gate, torch.float32, "gate"); _req(dgate, torch.float32, "dgate")
+    _check(lib().mmf_rowgroup_scale_bwd(_p(dy), _p(y), ld, _p(gate), _p(dgate), groups, rows_per_group, cols, _stream()),
+           "mmf_rowgroup_scale_bwd")
+
+
 def gather_rows(x, index, out, B, S, H, drop=NO_DROP):
     _req(x, torch.bfloat16, "x"); _req(index, torch.int64, "index"); _req(out, torch.bfloat16, "out")
     k, t, sc, sd = _drop4(drop)

@@ -1,0 +1,118 @@
+// mmf_amd :: the kernels ViLBERT's `dynamic_attention` adds around the visual self-attention
+// (mmf/models/vilbert.py:174-176, 199-212):
+//     pool   = (txt_embedding * txt_mask).sum(1) / txt_mask.sum(1)                 masked mean of the text stream   [B, H_t]
+//     gate_q = 1 + sigmoid(dyLinear_q(pool)),  gate_k = 1 + sigmoid(dyLinear_k(pool))                                 [B, H_v]
+//     q = query(x) * gate_q.unsqueeze(1),  k = key(x) * gate_k.unsqueeze(1)
+// The two Linear layers are ordinary GEMM launches; here: the masked mean with its backward, and the per-sample column
+// scale of the packed Q|K columns with its backward (gradient of the gate = column sums of dQ o Q over the sample's rows).
+// A few MB per call at the VQA2 shape (B = 32, 101 regions x 1024, 128 tokens x 768): plain coalesced loops, fp32 sums.
+#include "common.h"
+#include "mmf_amd.h"
+
+namespace {
+
+// pool[b][c] = sum_t x[b][t][c] * mask[b][t] / sum_t mask[b][t]; one thread per column
+__global__ __launch_bounds__(256) void masked_mean_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ mask,
+                                                               float* __restrict__ pool, int T, int H) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    const bf16* xb = x + (size_t)b * T * H + c;
+    const float* mb = mask + (size_t)b * T;
+    float acc = 0.f, cnt = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float m = mb[t];
+        acc += (float)xb[(size_t)t * H] * m;
+        cnt += m;
+    }
+    pool[(size_t)b * H + c] = acc / cnt;       // an all-zero mask divides by zero like the reference does
+}
+// dx[b][t][c] = dpool[b][c] * mask[b][t] / sum_t mask[b][t]
+__global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ dpool, const float* __restrict__ mask,
+                                                               bf16* __restrict__ dx, int T, int H) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    const float* mb = mask + (size_t)b * T;
+    float cnt = 0.f;
+    for (int t = 0; t < T; ++t) cnt += mb[t];
+    const float g = dpool[(size_t)b * H + c] / cnt;
+    bf16* db = dx + (size_t)b * T * H + c;
+    for (int t = 0; t < T; ++t) db[(size_t)t * H] = (bf16)(g * mb[t]);
+}
+
+// x[g * rpg + r][c] *= gate[g][c] for c < C (C % 8 == 0, ld % 8 == 0): 8 columns per thread
+__global__ __launch_bounds__(256) void rowgroup_scale_kernel(bf16* __restrict__ x, int ld, const float* __restrict__ gate, int rpg,
+                                                              int C, int rows) {
+    const int per_row = C >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * per_row) return;
+    const int row = (int)(i / per_row), c = (int)(i - (int64_t)row * per_row) << 3;
+    const float* g = gate + (size_t)(row / rpg) * C + c;
+    bf16x8* p = reinterpret_cast<bf16x8*>(x + (size_t)row * ld + c);
+    bf16x8 v = *p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * g[e]);
+    *p = v;
+}
+// Backward of the scale, in place: with y = x * gate (y is what the attention saw, dy its gradient),
+//   dgate[g][c] = sum_r dy[r][c] * x[r][c] = (sum_r dy[r][c] * y[r][c]) / gate[g][c],   dx = dy * gate  (written over dy).
+// One workgroup per (group, 1024 columns): 128 threads x 8 columns, looping over the group's rows.
+__global__ __launch_bounds__(128) void rowgroup_scale_bwd_kernel(bf16* __restrict__ dy, const bf16* __restrict__ y, int ld,
+                                                                  const float* __restrict__ gate, float* __restrict__ dgate,
+                                                                  int rpg, int C) {
+    const int g = blockIdx.y, c = (blockIdx.x * 128 + threadIdx.x) << 3;
+    if (c >= C) return;
+    float gt[8], acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gt[e] = gate[(size_t)g * C + c + e]; acc[e] = 0.f; }
+    for (int r = 0; r < rpg; ++r) {
+        const size_t off = (size_t)(g * rpg + r) * ld + c;
+        bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + off);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] += (float)d[e] * (float)v[e];
+            d[e] = (bf16)((float)d[e] * gt[e]);
+        }
+        *reinterpret_cast<bf16x8*>(dy + off) = d;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dgate[(size_t)g * C + c + e] = acc[e] / gt[e];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmf_masked_mean_fwd(const void* x, const float* mask, float* pool, int B, int T, int H, void* stream) {
+    MMF_CHECK_ARG(x && mask && pool && B > 0 && T > 0 && H > 0, "masked_mean_fwd: bad operand");
+    hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, mask, pool, T, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_masked_mean_bwd(const float* dpool, const float* mask, void* dx, int B, int T, int H, void* stream) {
+    MMF_CHECK_ARG(dpool && mask && dx && B > 0 && T > 0 && H > 0, "masked_mean_bwd: bad operand");
+    hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dpool, mask, (bf16*)dx, T, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_rowgroup_scale(void* x, int ld, const float* gate, int groups, int rows_per_group, int C, void* stream) {
+    MMF_CHECK_ARG(x && gate && groups > 0 && rows_per_group > 0 && C > 0, "rowgroup_scale: bad operand");
+    MMF_CHECK_ARG((C % 8) == 0 && (ld % 8) == 0 && C <= ld, "rowgroup_scale: C and ld must be multiples of 8 with C <= ld");
+    const int rows = groups * rows_per_group;
+    const int64_t n = (int64_t)rows * (C / 8);
+    hipLaunchKernelGGL(rowgroup_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16*)x, ld, gate,
+                       rows_per_group, C, rows);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_rowgroup_scale_bwd(void* dy, const void* y, int ld, const float* gate, float* dgate, int groups, int rows_per_group, int C,
+                           void* stream) {
+    MMF_CHECK_ARG(dy && y && gate && dgate && groups > 0 && rows_per_group > 0 && C > 0, "rowgroup_scale_bwd: bad operand");
+    MMF_CHECK_ARG((C % 8) == 0 && (ld % 8) == 0 && C <= ld, "rowgroup_scale_bwd: C and ld must be multiples of 8 with C <= ld");
+    hipLaunchKernelGGL(rowgroup_scale_bwd_kernel, dim3((C / 8 + 127) / 128, groups), dim3(128), 0, (hipStream_t)stream, (bf16*)dy,
+                       (const bf16*)y, ld, gate, dgate, rows_per_group, C);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@ Reference ops replaced (paths relative to the reference root):
   GatherRowsFn              torch.gather + Dropout of the `vqa` pooler     (visual_bert.py:389-400)
   LogitBCEFn                LogitBinaryCrossEntropy                        (losses.py:246-251)
 """
+import contextlib
 import math
 import os
 import weakref
@@ -337,11 +338,13 @@ def _split_mask(mask):
     return mask, 0
 
 
-def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail=0):
+def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail=0, qk_gate=None):
     M, H = x2.shape
     dev = x2.device
     qkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
     nat.gemm(x2, wqkv16, qkv, M, 3 * H, H, H, H, 3 * H, bias=bqkv)
+    if qk_gate is not None:       # ViLBERT dynamic_attention: per-sample column gates on the Q|K columns (vilbert.py:211-212)
+        nat.rowgroup_scale(qkv, 3 * H, qk_gate, B, S, 2 * H)
     ctxt = torch.empty(M, H, dtype=BF16, device=dev)
     lse = torch.empty(B, heads, S, dtype=F32, device=dev)
     scale = 1.0 / math.sqrt(H // heads)
@@ -351,7 +354,9 @@ def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail
     return qkv, ctxt, lse, o32
 
 
-def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True, o32=None, tail=0):
+def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True, o32=None, tail=0,
+              qk_gate=None):
+    """Returns (dx, dW_qkv, db_qkv) — and the gradient of `qk_gate` as a fourth element when a gate was applied."""
     M, H = x2.shape
     dev = x2.device
     dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
@@ -359,7 +364,11 @@ def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_
     scale = 1.0 / math.sqrt(H // heads)
     nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
                       dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
-    return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True)
+    if qk_gate is None:
+        return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True)
+    dgate = torch.empty_like(qk_gate)
+    nat.rowgroup_scale_bwd(dqkv, qkv, 3 * H, qk_gate, dgate, B, S, 2 * H)      # dqkv becomes the gradient of the un-gated projection
+    return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True) + (dgate,)
 
 
 class SelfAttentionFn(torch.autograd.Function):
@@ -472,27 +481,56 @@ class AttentionBlockFn(torch.autograd.Function):
     residual-gradient add fused into the QKV dgrad epilogue."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, wqkv16, bqkv, wo16, mask_add, heads, eps, drop_attn, drop_hid):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, wqkv16, bqkv, wo16, mask_add, heads, eps, drop_attn, drop_hid,
+                qk_gate=None):
+        """`qk_gate` (fp32 [B, 2H] or None): ViLBERT's dynamic_attention gates on the queries and keys (vilbert.py:199-212)."""
         B, S, H = x.shape
         x2 = _as_bf16_2d(x)
         mask_add, tail = _split_mask(mask_add)
-        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail)
+        gate = None if qk_gate is None else qk_gate.detach().float().contiguous()
+        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail, gate)
         out, y, mean, rstd = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), gamma.detach(), beta.detach(), eps, drop_hid)
-        ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add, o32)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add, o32, gate)
         ctx.meta = (B, S, H, heads, drop_attn, drop_hid, tail)
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add, o32 = ctx.saved_tensors
+        x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add, o32, gate = ctx.saved_tensors
         B, S, H, heads, drop_attn, drop_hid, tail = ctx.meta
         M = B * S
         dres, dlin, dgamma, dbeta, dbo = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
         dctx, dwo = _linear_bwd(dlin, H, ctxt, wo16, M, H, H)
-        dx, dwqkv, dbqkv = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32,
-                                     tail=tail)
+        res = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32, tail=tail,
+                        qk_gate=gate)
+        dx, dwqkv, dbqkv = res[:3]
         return (dx.view(B, S, H), dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
-                dwo, dbo, dgamma, dbeta, None, None, None, None, None, None, None, None)
+                dwo, dbo, dgamma, dbeta, None, None, None, None, None, None, None, None, res[3] if gate is not None else None)
+
+
+class MaskedMeanFn(torch.autograd.Function):
+    """(x * mask.unsqueeze(-1)).sum(1) / mask.sum(1, keepdim=True): the text pooling of ViLBERT's dynamic_attention
+    (vilbert.py:204-205).  x [B, T, H], mask [B, T] (0 / 1) -> fp32 [B, H]."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        B, T, H = x.shape
+        x3 = x.detach()
+        x3 = (x3 if x3.dtype == BF16 else x3.to(BF16)).contiguous()
+        m = mask.detach().reshape(B, T).float().contiguous()
+        pool = torch.empty(B, H, dtype=F32, device=x.device)
+        nat.masked_mean_fwd(x3, m, pool, B, T, H)
+        ctx.save_for_backward(m)
+        ctx.meta = (B, T, H, x.dtype)
+        return pool
+
+    @staticmethod
+    def backward(ctx, g):
+        m, = ctx.saved_tensors
+        B, T, H, dtype = ctx.meta
+        dx = torch.empty(B, T, H, dtype=BF16, device=g.device)
+        nat.masked_mean_bwd(g.float().contiguous(), m, dx, B, T, H)
+        return (dx if dtype == BF16 else dx.to(dtype)), None
 
 
 class FeedForwardFn(torch.autograd.Function):
@@ -540,6 +578,40 @@ def _wgrad_problem(dy, ldy, x, M, N, K, want_db):
     db = torch.empty(N, dtype=F32, device=dy.device) if want_db else None
     prob = dict(A=dy, B=x, C_out=dw, M=N, N=K, K=M, lda=ldy, ldb=x.stride(0), ldc=K, a_kmajor=True, b_kmajor=True, rowsum_out=db)
     return prob, dw, db
+
+
+class _WgradOverlap:
+    """Opt-in: inside `with wgrad_overlap(stream):` every layer's grouped weight-gradient launch goes to `stream` instead of
+    the current one, so that it runs beside the dgrad chain of the layers below (the weight gradients are consumed only by the
+    optimizer); leaving the block makes the current stream wait for it.  Only for callers that own the whole backward
+    (GraphedTrainStep): autograd itself assumes gradients are ready on the stream backward ran on."""
+
+    def __init__(self):
+        self.stream = None
+
+    @contextlib.contextmanager
+    def __call__(self, stream):
+        old, self.stream = self.stream, stream
+        try:
+            yield
+        finally:
+            self.stream = old
+            if stream is not None:
+                torch.cuda.current_stream().wait_stream(stream)
+
+    def launch(self, problems, tensors):
+        side = self.stream
+        if side is None:
+            nat.gemm_grouped(problems)
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            nat.gemm_grouped(problems)
+        for t in tensors:          # operands were allocated on the launching stream: keep their memory until `side` is done
+            t.record_stream(side)
+
+
+wgrad_overlap = _WgradOverlap()
 
 
 class TransformerLayerFn(torch.autograd.Function):
@@ -597,7 +669,7 @@ class TransformerLayerFn(torch.autograd.Function):
         p_2, dw2, db2 = _wgrad_problem(dlin2, H, hh, M, H, I, True)
         p_q, dwqkv, dbqkv = _wgrad_problem(dqkv, 3 * H, x2, M, 3 * H, H, True)
         p_o, dwo, dbo = _wgrad_problem(dlin1, H, ctxt, M, H, H, True)
-        nat.gemm_grouped([p_1, p_2, p_q, p_o])
+        wgrad_overlap.launch([p_1, p_2, p_q, p_o], (du, a_out, dlin2, hh, dqkv, x2, dlin1, ctxt, dw1, db1, dw2, db2, dwqkv, dbqkv, dwo, dbo))
         return ((dx.view(B, S, H) if dx is not None else None),
                 dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, dbe1,
                 dw1, db1, dw2, db2, dg2, dbe2) + (None,) * 13

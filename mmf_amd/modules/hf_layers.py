@@ -123,6 +123,19 @@ class BertSelfAttentionJit(nn.Module):
         self.key = Linear(config.hidden_size, self.all_head_size)
         self.value = Linear(config.hidden_size, self.all_head_size)
         self.dropout_prob = config.attention_probs_dropout_prob
+        # ViLBERT's BertImageSelfAttention with `dynamic_attention` (mmf/models/vilbert.py:174-176): gates from the text stream
+        self.dynamic_attention = bool(getattr(config, "dynamic_attention", False))
+        if self.dynamic_attention:
+            self.dyLinear_q = Linear(config.dynamic_attention_input_size, self.all_head_size)
+            self.dyLinear_k = Linear(config.dynamic_attention_input_size, self.all_head_size)
+
+    @torch.jit.unused
+    def dynamic_gate(self, txt_embedding, txt_attention_mask):
+        """fp32 [B, 2 * all_head_size]: 1 + sigmoid(dyLinear_{q,k}(masked mean of the text stream)) (vilbert.py:204-209)."""
+        pool = Fn.MaskedMeanFn.apply(txt_embedding, txt_attention_mask)
+        zq = torch.ops.mmf_amd.linear(pool, self.dyLinear_q.weight, self.dyLinear_q.bias, True)
+        zk = torch.ops.mmf_amd.linear(pool, self.dyLinear_k.weight, self.dyLinear_k.bias, True)
+        return torch.cat([1.0 + torch.sigmoid(zq.float()), 1.0 + torch.sigmoid(zk.float())], dim=1)
 
     def packed_qkv(self):
         w16 = Fn.shadows.get(self.query.weight, self.key.weight, self.value.weight)
@@ -211,7 +224,7 @@ class BertAttentionJit(nn.Module):
             hidden_states, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
             so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, w16, b32, Fn.shadows.get(so.dense.weight),
             additive_key_mask(attention_mask, B, S), sa.num_attention_heads, so.LayerNorm.eps,
-            Fn.make_drop(sa.dropout_prob, self.training), Fn.make_drop(so.dropout_prob, self.training))
+            Fn.make_drop(sa.dropout_prob, self.training), Fn.make_drop(so.dropout_prob, self.training), None)
         return (out,)
 
 

@@ -12,6 +12,7 @@ draws fresh masks while forward and backward of the same replay agree (mmf_amd.f
 The fp32 -> bf16 weight-shadow casts are captured too, so replays see parameter updates made between them.
 """
 import gc
+import os
 
 import torch
 import torch.distributed as dist
@@ -65,8 +66,13 @@ class GraphedTrainStep:
     parameter is updated and no step is counted before the first replay; the optimizer's moments are allocated up front
     (`ensure_state`) so that the captured update contains no zero-fill."""
 
-    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None):
+    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None, overlap_wgrad=None):
+        """`overlap_wgrad`: run every layer's grouped weight-gradient GEMM on a second stream (a parallel branch of the graph)
+        beside the dgrad chain of the layers below; default from MMF_AMD_WGRAD_OVERLAP (off)."""
         self.model = model
+        if overlap_wgrad is None:
+            overlap_wgrad = os.environ.get("MMF_AMD_WGRAD_OVERLAP", "0") == "1"
+        self.side_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
         self.optimizer = optimizer
         if optimizer is not None and not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs an optimizer whose step reads its counters from device memory (capturable=True)")
@@ -101,7 +107,8 @@ class GraphedTrainStep:
         # created on; if an earlier eager step created them on the legacy default stream, running them inside the
         # capture drags that stream into it and hipStreamEndCapture crashes.  Capturing the gradients directly keeps
         # every captured node on the capture stream.
-        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        with Fn.wgrad_overlap(self.side_stream):
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g
         if self.optimizer is not None and update:
@@ -176,21 +183,22 @@ class GraphedDataParallelStep:
             model.zero_grad(set_to_none=True)
             release_autograd_state()
             self._layout(fp32_ids, dev)
+            # capture_error_mode="thread_local": the communicator's watchdog thread polls events while we capture
             pool = torch.cuda.graph_pool_handle()
             self.g_fwd = torch.cuda.CUDAGraph()
             self.g_bwd = [torch.cuda.CUDAGraph() for _ in self.stage_params]
             self.g_opt = torch.cuda.CUDAGraph()
             with Fn.dropout_keys.graph_mode(self.seed):
-                with torch.cuda.graph(self.g_fwd, pool=pool):
+                with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):
                     self.out, self.loss = self._forward()
                 carry = None
                 self._keep = []
                 for j, g in enumerate(self.g_bwd):
-                    with torch.cuda.graph(g, pool=pool):
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                         grads, carry = self._stage_grads(j, carry, self.stage_params[j])
                         self._pack(j, grads)
                     self._keep.append((grads, carry))
-                with torch.cuda.graph(self.g_opt, pool=pool):
+                with torch.cuda.graph(self.g_opt, pool=pool, capture_error_mode="thread_local"):
                     self._unpack()
                     optimizer.step()
         finally:

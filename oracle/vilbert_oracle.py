@@ -64,6 +64,10 @@ def parameter_shapes(cfg):
         _layer_shapes(s, "bert.encoder.layer.%d." % i, H, I)
     for i in range(cfg["v_num_hidden_layers"]):
         _layer_shapes(s, "bert.encoder.v_layer.%d." % i, VH, VI)
+        if cfg.get("dynamic_attention", False):      # vilbert.py:174-176: gates fed from the text stream's width
+            for n in ("dyLinear_q", "dyLinear_k"):
+                s["bert.encoder.v_layer.%d.attention.self.%s.weight" % (i, n)] = (VH, H)
+                s["bert.encoder.v_layer.%d.attention.self.%s.bias" % (i, n)] = (VH,)
     for i in range(len(cfg["v_biattention_id"])):
         p = "bert.encoder.c_layer.%d." % i
         for n, din in (("query1", VH), ("key1", VH), ("value1", VH), ("query2", H), ("key2", H), ("value2", H)):
@@ -120,11 +124,17 @@ def attention(q, k, v, n_heads, ext_mask, dropout_p):
     return ctx.view(ctx.shape[0], ctx.shape[1], -1)
 
 
-def stream_layer(sd, p, n_heads, hidden, ext_mask, hidden_dropout, attn_dropout, eps=1e-12):
-    """BertLayer.forward :138-146 (text) and BertImageLayer.forward :320-332 (visual, dynamic_attention off): the HF
-    BertSelfOutput / BertIntermediate / BertOutput blocks and their Image twins (:250-310) are the same arithmetic."""
+def stream_layer(sd, p, n_heads, hidden, ext_mask, hidden_dropout, attn_dropout, eps=1e-12, txt=None, txt_mask2=None):
+    """BertLayer.forward :138-146 (text) and BertImageLayer.forward :320-332 (visual): the HF BertSelfOutput / BertIntermediate /
+    BertOutput blocks and their Image twins (:250-310) are the same arithmetic.  `txt` / `txt_mask2` ([B, T, H_t], [B, T, 1]):
+    BertImageSelfAttention with dynamic_attention, :199-212 — queries and keys gated by 1 + sigmoid(Linear(masked text mean))."""
     lin = lambda x, n: F.linear(x, sd[p + n + ".weight"], sd[p + n + ".bias"])
-    ctx = attention(lin(hidden, "attention.self.query"), lin(hidden, "attention.self.key"), lin(hidden, "attention.self.value"),
+    q, k = lin(hidden, "attention.self.query"), lin(hidden, "attention.self.key")
+    if txt is not None:
+        pool = (txt * txt_mask2).sum(1) / txt_mask2.sum(1)                               # :204-205
+        q = q * (1 + torch.sigmoid(lin(pool, "attention.self.dyLinear_q"))).unsqueeze(1)      # :208, :211
+        k = k * (1 + torch.sigmoid(lin(pool, "attention.self.dyLinear_k"))).unsqueeze(1)      # :209, :212
+    ctx = attention(q, k, lin(hidden, "attention.self.value"),
                     n_heads, ext_mask, attn_dropout)
     a = F.dropout(lin(ctx, "attention.output.dense"), hidden_dropout, training=hidden_dropout > 0)
     a = layer_norm(a + hidden, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], eps)
@@ -160,7 +170,7 @@ def connection_layer(sd, cfg, i, img, img_mask, txt, txt_mask, train):
     return o1, o2
 
 
-def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False):
+def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False, txt_mask2=None):
     """BertEncoder.forward :590-796 with fixed_t_layer = fixed_v_layer = 0, with_coattention, no batch expansion."""
     td = cfg["hidden_dropout_prob"] if train else 0.0
     tad = cfg["attention_probs_dropout_prob"] if train else 0.0
@@ -168,17 +178,20 @@ def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False):
     vad = cfg["v_attention_probs_dropout_prob"] if train else 0.0
     t_layer = lambda i, x: stream_layer(sd, "bert.encoder.layer.%d." % i, cfg["num_attention_heads"], x, txt_mask, td, tad,
                                         cfg["layer_norm_eps"])
-    v_layer = lambda i, x: stream_layer(sd, "bert.encoder.v_layer.%d." % i, cfg["v_num_attention_heads"], x, img_mask, vd, vad)
+    dyn = bool(cfg.get("dynamic_attention", False))
+    # (the visual layers see the text stream as it is when they run, :667-673)
+    v_layer = lambda i, x, t: stream_layer(sd, "bert.encoder.v_layer.%d." % i, cfg["v_num_attention_heads"], x, img_mask, vd, vad,
+                                           txt=t if dyn else None, txt_mask2=txt_mask2)
     v_start = t_start = 0
     for count, (v_end, t_end) in enumerate(zip(cfg["v_biattention_id"], cfg["t_biattention_id"])):
         for i in range(t_start, t_end):
             txt = t_layer(i, txt)
         for i in range(v_start, v_end):
-            img = v_layer(i, img)
+            img = v_layer(i, img, txt)
         img, txt = connection_layer(sd, cfg, count, img, img_mask, txt, txt_mask, train)
         v_start, t_start = v_end, t_end
     for i in range(v_start, cfg["v_num_hidden_layers"]):
-        img = v_layer(i, img)
+        img = v_layer(i, img, txt)
     for i in range(t_start, cfg["num_hidden_layers"]):
         txt = t_layer(i, txt)
     return txt, img
@@ -211,7 +224,8 @@ def vilbert_base(sd, cfg, input_txt, image_feature, image_location, token_type_i
     img = (F.linear(image_feature, sd[v + "image_embeddings.weight"], sd[v + "image_embeddings.bias"])
            + F.linear(image_location, sd[v + "image_location_embeddings.weight"], sd[v + "image_location_embeddings.bias"]))  # :905-910
     img = F.dropout(layer_norm(img, sd[v + "LayerNorm.weight"], sd[v + "LayerNorm.bias"], 1e-12), hd, training=hd > 0)     # :911
-    seq_t, seq_v = encoder(sd, cfg, txt, img, ext_t, ext_v, train)
+    seq_t, seq_v = encoder(sd, cfg, txt, img, ext_t, ext_v, train,
+                           txt_mask2=attention_mask.unsqueeze(2).to(torch.float32))          # extended_attention_mask2, :985
     pre_t = F.linear(seq_t[:, 0], sd["bert.t_pooler.dense.weight"], sd["bert.t_pooler.dense.bias"])   # :805-811
     pre_v = F.linear(seq_v[:, 0], sd["bert.v_pooler.dense.weight"], sd["bert.v_pooler.dense.bias"])   # :820-826
     pooled_t = F.relu(pre_t) if pooler_masks is None else pre_t * pooler_masks[0]

@@ -368,6 +368,13 @@ VILBERT_CASES = {
                           bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
                           v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=211, max_position_embeddings=40,
                           v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=42),   # seed picked for bf16 conditioning, see test_vilbert_gpu.py
+    # the same network with `dynamic_attention: true`: visual self-attention queries / keys gated by 1 + sigmoid(Linear(masked mean
+    # of the text stream)) (vilbert.py:174-176, 199-212)
+    "vilbert_dyn": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=4,
+                        v_hidden_size=256, v_num_attention_heads=2, v_intermediate_size=192, v_num_hidden_layers=3,
+                        bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
+                        v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=211, max_position_embeddings=40,
+                        v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=42, dynamic_attention=True),
 }
 
 
@@ -386,7 +393,7 @@ def vilbert_reference_config(c):
         bi_num_attention_heads=c["bi_num_attention_heads"], bi_intermediate_size=c["bi_intermediate_size"], bi_attention_type=1,
         v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.1, v_initializer_range=0.02,
         v_biattention_id=c["v_biattention_id"], t_biattention_id=c["t_biattention_id"], pooling_method="mul", fusion_method="mul",
-        fast_mode=False, with_coattention=True, dynamic_attention=False, in_batch_pairs=False, task_specific_tokens=False,
+        fast_mode=False, with_coattention=True, dynamic_attention=bool(c.get("dynamic_attention", False)), in_batch_pairs=False, task_specific_tokens=False,
         fixed_v_layer=0, fixed_t_layer=0, visualization=False, visual_target=0, objective=0, num_negative=128, model="vilbert",
         num_labels=c["num_labels"], losses=[dict(type="logit_bce")]))
 

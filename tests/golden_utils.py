@@ -80,7 +80,8 @@ def load_mmft_case(name="mmft_small64"):
 
 
 def load_vilbert_case(name="vilbert_small"):
-    """`vilbert_small`: classification head; `vilbert_nlvr2`: two images per sample (img0 / img1), paired head."""
+    """`vilbert_small`: classification head; `vilbert_nlvr2`: two images per sample (img0 / img1), paired head; `vilbert_dyn`:
+    `vilbert_small` with `dynamic_attention: true`."""
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))
     shapes = {str(n)[len("model."):]: tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
@@ -96,7 +97,7 @@ def load_vilbert_case(name="vilbert_small"):
         bi_hidden_size=case["bi_hidden_size"], bi_num_attention_heads=case["bi_num_attention_heads"],
         bi_intermediate_size=case["bi_intermediate_size"], v_attention_probs_dropout_prob=0.1, v_hidden_dropout_prob=0.1,
         v_biattention_id=list(case["v_biattention_id"]), t_biattention_id=list(case["t_biattention_id"]), fusion_method="mul",
-        num_labels=case["num_labels"], initializer_range=0.02)
+        num_labels=case["num_labels"], initializer_range=0.02, dynamic_attention=bool(case.get("dynamic_attention", False)))
     sample = {
         "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
         "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),

@@ -22,9 +22,19 @@ def test_registered_and_state_dict_matches_reference_tree():
     assert enc.v_layer[0].attention.self.attention_head_size == 128 and enc.layer[0].attention.self.attention_head_size == 64
 
 
+def test_dynamic_attention_adds_the_gate_parameters_of_the_reference():
+    z, case, cfg, sd, sample = load_vilbert_case("vilbert_dyn")
+    model = build_vilbert(cfg, sd, device="cpu")
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    assert ours == ref
+    assert ours["model.bert.encoder.v_layer.0.attention.self.dyLinear_q.weight"] == (cfg["v_hidden_size"], cfg["hidden_size"])
+    assert not any("dyLinear" in k and ".layer." in k for k in ours)          # text layers carry no gates
+
+
 def test_unbuilt_variants_raise():
     z, case, cfg, sd, sample = load_vilbert_case()
-    for over in (dict(training_head_type="pretraining"), dict(dynamic_attention=True),
+    for over in (dict(training_head_type="pretraining"),
                  dict(in_batch_pairs=True), dict(fast_mode=True), dict(task_specific_tokens=True), dict(fixed_t_layer=1),
                  dict(visualization=True)):
         with pytest.raises(NotImplementedError):

@@ -151,12 +151,13 @@ def _check_against(model, out, ref_scores, ref_loss, ref_grads, tol=TOL, sens=No
     return {k: round(e, 4) for k, e in errs.items() if e > max(tol, 6.0 * (sens or {}).get(k, 0.0))}
 
 
-def test_vilbert_golden_forward_loss_and_gradients():
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn"])      # vilbert_dyn: `dynamic_attention: true` (vilbert.py:199-212)
+def test_vilbert_golden_forward_loss_and_gradients(name):
     """Forward and loss against the values recorded from the real reference; gradients against the CPU oracle, which
     tests/test_vilbert_oracle_golden.py pins to the reference's own gradients for this very fixture, evaluated on the
     ReLU-pooler branch the bf16 forward took (with 1536 pooler units some pre-activation always lies within bf16 noise
     of zero; the fixture's seed was chosen so that rounding the weights to bf16 moves no gradient by more than 2 %)."""
-    z, case, cfg, sd, sample = load_vilbert_case()
+    z, case, cfg, sd, sample = load_vilbert_case(name)
     model = build_vilbert(cfg, sd)
     model.eval()
     got = {}
@@ -180,6 +181,43 @@ def test_vilbert_golden_forward_loss_and_gradients():
     sens = _bf16_weight_sensitivity(sd, cfg, sample, sample["targets"], masks)
     bad = _check_against(model, out, ref["scores"].detach(), ref_loss.item(), {k: v.grad for k, v in sdr.items()}, sens=sens)
     assert not bad, (flips, bad, {k: round(sens[k], 4) for k in bad})
+
+
+def test_dynamic_attention_kernels_match_torch():
+    """The masked text mean and the per-sample column gate with their backwards (mmf_amd/csrc/gate_ops.hip) against autograd."""
+    from mmf_amd import functional as Fn
+    nat = Fn.nat
+    torch.manual_seed(3)
+    B, T, H = 5, 23, 136
+    x = (torch.randn(B, T, H, device="cuda")).bfloat16()
+    mask = (torch.rand(B, T, device="cuda") > 0.3).float(); mask[:, 0] = 1
+    xr = x.float().requires_grad_(True)
+    ref = (xr * mask.unsqueeze(2)).sum(1) / mask.unsqueeze(2).sum(1)
+    xg = x.clone().requires_grad_(True)
+    got = Fn.MaskedMeanFn.apply(xg, mask)
+    assert got.dtype == torch.float32 and float((got - ref).abs().max()) <= 1e-5
+    g = torch.randn(B, H, device="cuda")
+    ref.backward(g); got.backward(g)
+    assert float((xg.grad.float() - xr.grad).abs().max()) <= 1e-2 * float(xr.grad.abs().max())
+    # column gate on the first C columns of a wider row
+    R, C, LD = 7, 64, 96
+    y0 = torch.randn(B * R, LD, device="cuda").bfloat16()
+    gate = 1 + torch.sigmoid(torch.randn(B, C, device="cuda"))
+    y = y0.clone()
+    nat.rowgroup_scale(y, LD, gate, B, R, C)
+    want = y0.float().clone(); want[:, :C] *= gate.repeat_interleave(R, 0)
+    assert torch.equal(y[:, C:], y0[:, C:])
+    assert float((y.float() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    dy = torch.randn(B * R, LD, device="cuda").bfloat16()
+    dgate = torch.empty(B, C, device="cuda")
+    dx = dy.clone()
+    nat.rowgroup_scale_bwd(dx, y, LD, gate, dgate, B, R, C)
+    x0 = (y.float()[:, :C] / gate.repeat_interleave(R, 0))          # the un-gated values the gated bf16 rows stand for
+    want_dgate = (dy.float()[:, :C] * x0).view(B, R, C).sum(1)
+    assert float((dgate - want_dgate).abs().max()) <= 1e-4 * float(want_dgate.abs().max()) + 1e-5
+    want_dx = dy.float().clone(); want_dx[:, :C] *= gate.repeat_interleave(R, 0)
+    assert torch.equal(dx[:, C:], dy[:, C:])
+    assert float((dx.float() - want_dx).abs().max()) <= 1e-2 * float(want_dx.abs().max())
 
 
 def test_vilbert_real_stream_widths_match_oracle():

@@ -2,6 +2,7 @@
 ViLBERTForClassification.forward -> ViLBERTBase -> BertEncoder / BertConnectionLayer / BertBiAttention ... + logit_bce);
 see tests/golden/make_golden.py::make_vilbert."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import vilbert_oracle as O
@@ -9,8 +10,10 @@ from oracle.visual_bert_oracle import logit_bce
 from tests.golden_utils import load_vilbert_case
 
 
-def test_vilbert_oracle_matches_reference_forward_loss_and_gradients():
-    z, case, cfg, sd, sample = load_vilbert_case()
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn"])      # vilbert_dyn: dynamic_attention gates (vilbert.py:199-212)
+def test_vilbert_oracle_matches_reference_forward_loss_and_gradients(name):
+    z, case, cfg, sd, sample = load_vilbert_case(name)
+    assert any("dyLinear_q" in k for k in sd) == (name == "vilbert_dyn")
     assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
     sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = O.vilbert_forward(sd, cfg, dict(sample), train=False)

@@ -889,7 +889,13 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
         dev = word.device
         y = torch.empty(B * S, H, dtype=BF16, device=dev)
         wd, pd, td = word.detach(), pos.detach(), typ.detach()
-        mtype = torch.full((B, 1), int(modal_type), dtype=torch.int64, device=dev)
+        # `modal_type`: a Python int or a one-element device tensor (MMBT derives it from the batch's segment ids, mmbt.py:385-410;
+        # keeping it on the device keeps the step free of host read-backs, i.e. capturable in a hipGraph)
+        if isinstance(modal_type, torch.Tensor):
+            mt = modal_type.detach().reshape(1).to(device=dev, dtype=torch.int64)
+        else:
+            mt = torch.full((1,), int(modal_type), dtype=torch.int64, device=dev)
+        mtype = mt.reshape(1, 1).expand(B, 1).contiguous()
         ids = input_ids.contiguous()
         seg = text_type_ids.contiguous()
         st = start_tok.reshape(B, 1).contiguous() if start_tok is not None else None
@@ -904,8 +910,8 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
             f2 = f2.float()
         f2 = f2.contiguous()
         posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
-        nat.gemm(f2, proj_w16, y, B * N, H, D, D, D, H, bias=proj_b.detach(), coladd=td[int(modal_type)], rowtab=pd, rowidx=posidx,
-                 rowtab_ld=H, grp=(N, S - N, s0))
+        nat.gemm(f2, proj_w16, y, B * N, H, D, D, D, H, bias=proj_b.detach(), coladd=td.index_select(0, mt).reshape(H), rowtab=pd,
+                 rowidx=posidx, rowtab_ld=H, grp=(N, S - N, s0))
         out = torch.empty(B * S, H, dtype=BF16, device=dev)
         mean = torch.empty(B * S, dtype=F32, device=dev)
         rstd = torch.empty(B * S, dtype=F32, device=dev)
@@ -914,15 +920,15 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
             out2 = torch.empty_like(out)
             nat.dropout(out, out2, drop)
             out = out2
-        ctx.save_for_backward(ids, seg, st, en, f2, y, mean, rstd, ln_w.detach(), proj_w16)
-        ctx.meta = (B, N, T, S, L, s0, H, drop, int(modal_type), word.shape[0], pos.shape[0], typ.shape[0])
+        ctx.save_for_backward(ids, seg, st, en, f2, y, mean, rstd, ln_w.detach(), proj_w16, mt.reshape(1, 1).expand(B, L).contiguous())
+        ctx.meta = (B, N, T, S, L, s0, H, drop, word.shape[0], pos.shape[0], typ.shape[0])
         ctx.pad_idx = -1 if pad_idx is None else int(pad_idx)
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        ids, seg, st, en, f2, y, mean, rstd, ln_w, proj_w16 = ctx.saved_tensors
-        B, N, T, S, L, s0, H, drop, modal_type, V, P, NT = ctx.meta
+        ids, seg, st, en, f2, y, mean, rstd, ln_w, proj_w16, mtype_rows = ctx.saved_tensors
+        B, N, T, S, L, s0, H, drop, V, P, NT = ctx.meta
         dev = y.device
         dy = _grad_bf16(g, H)
         if drop[1]:
@@ -941,7 +947,7 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
         nat.rows_scatter_add(dpre[L:], H, B, T, S, None, 0, 1, 0, dpos, H, 0)    # text: positions restart at 0
         dtyp = torch.zeros(NT, H, dtype=F32, device=dev)
         nat.rows_scatter_add(dpre[L:], H, B, T, S, seg, T, 0, 0, dtyp, H, 1)
-        nat.rows_scatter_add(dpre, H, B, L, S, None, 0, 0, modal_type, dtyp, H, 1)
+        nat.rows_scatter_add(dpre, H, B, L, S, mtype_rows, L, 0, 0, dtyp, H, 1)
         dvis = dpre.view(B, S, H)[:, s0:s0 + N, :].contiguous().view(B * N, H)
         D = f2.shape[1]
         dproj_w = torch.empty(H, D, dtype=F32, device=dev)

@@ -77,8 +77,9 @@ class MMBTModel(nn.Module):
             token_type_ids = torch.ones_like(input_ids)                                     # :213-216
         if modal_token_type_ids is None:
             modal_type = 0                                                                  # :117-122
-        elif isinstance(modal_token_type_ids, int):
-            modal_type = modal_token_type_ids
+        elif isinstance(modal_token_type_ids, int) or (isinstance(modal_token_type_ids, torch.Tensor)
+                                                       and modal_token_type_ids.numel() == 1):
+            modal_type = modal_token_type_ids          # (a one-element device tensor stays on the device)
         else:
             lo, hi = int(modal_token_type_ids.min()), int(modal_token_type_ids.max())
             if lo != hi:
@@ -178,19 +179,16 @@ class MMBTBase(nn.Module):
         if "modal_token_type_ids" in sample_list:
             modal_token_type_ids = sample_list["modal_token_type_ids"]
         else:
-            # mmbt.py:385-410 — the reference compares device tensors in Python (`if max_id == min_id`), i.e. it also
-            # reads the segment range back to the host here.
-            token_value = 0
+            # mmbt.py:385-410 picks the modal block's segment id from the range of the text segment ids.  The reference compares
+            # device tensors in Python (`if max_id == min_id`), a host read-back per step; the same decision table evaluated
+            # on the device (no synchronisation, so the whole step can be captured in a hipGraph):
+            #   max == min : 1 if max == 0 else 0          max != min : max_segment if max != max_segment else 0
             segment_ids = sample_list["segment_ids"]
-            max_id, min_id = int(segment_ids.max()), int(segment_ids.min())
-            if max_id == min_id:
-                if max_id == 0:
-                    token_value = 1
-            else:
-                max_segment = self.num_max_segment - 1
-                if max_id != max_segment:
-                    token_value = max_segment
-            modal_token_type_ids = token_value
+            max_id, min_id = segment_ids.max(), segment_ids.min()
+            max_segment = self.num_max_segment - 1
+            modal_token_type_ids = torch.where(max_id == min_id, (max_id == 0).to(max_id.dtype),
+                                               torch.where(max_id != max_segment, torch.full_like(max_id, max_segment),
+                                                           torch.zeros_like(max_id))).reshape(1)
         if input_modal.dim() == 2:
             input_modal = input_modal.unsqueeze(dim=1)
         return self.mmbt(input_modal, input_ids=sample_list["input_ids"], modal_start_tokens=modal_start_token,

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import mmf_amd  # noqa: E402,F401
-from bench import GemmProbe  # noqa: E402
+from bench import KernelProbe  # noqa: E402
 from mmf_amd.common.registry import registry  # noqa: E402
 from mmf_amd.common.sample import SampleList  # noqa: E402
 from mmf_amd.utils.configuration import Config  # noqa: E402
@@ -152,10 +152,10 @@ def run(name, steps=10, warmup=3):
     if mode == "graph":       # the step is one replayed hipGraph: no per-GEMM events
         gemm_ms = gemm_fl = float("nan")
     else:
-        with GemmProbe() as probe:
+        with KernelProbe() as probe:
             eager_step()
-        by = probe.summary()
-        gemm_ms = sum(d["ms"] for d in by.values()); gemm_fl = sum(d["flops"] for d in by.values())
+        by = {k: d for k, d in probe.summary().items() if k.startswith("gemm")}
+        gemm_ms = sum(d["ms"] for d in by.values()); gemm_fl = sum(d["work"] for d in by.values())
     rec = dict(model=name, workload=label, batch=B, ms_per_step=round(ms, 3), samples_per_s=round(B / ms * 1e3, 1),
                loss=round(float(last.item()), 4), params=sum(p.numel() for p in model.parameters()),
                gemm_flop_per_step=gemm_fl, gemm_ms_per_step=round(gemm_ms, 3), gemm_tflops=round(gemm_fl / gemm_ms / 1e9, 1),

@@ -187,6 +187,9 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
  * residual add); with thr16 == 0 pass dlin = NULL and use dx.  dgamma/dbeta/dbias (fp32 [H], any
  * may be NULL) get the column sums of dy*xhat, dy and dlin; `accumulate` != 0 adds to them.
  * partials: fp32 workspace of mmf_layernorm_bwd_ws_floats(H) floats.
+ * Deferred column sums: where mmf_layernorm_bwd_deferrable(rows, H) is 1, a call with dgamma = dbeta = dbias = NULL leaves the
+ * per-workgroup partial sums of dgamma / dbeta in `partials`; mmf_layernorm_bwd_reduce_multi finishes up to MMF_MT_MAX such
+ * calls in ONE launch (a training step has 26 LayerNorm backwards whose parameter gradients nobody reads before the optimizer).
  */
 int mmf_layernorm_bwd_ws_floats(int H);
 int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
@@ -380,6 +383,16 @@ int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream);
  * at t - 1 (the scheduler is stepped after the optimizer): (t-1)/warmup while t-1 < warmup, else
  * max(0, (total - (t-1)) / max(1, total - warmup)). */
 int mmf_optim_state_advance(float* state, int schedule, float warmup_steps, float total_steps, void* stream);
+typedef struct mmf_ln_reduce_list {
+    int n;
+    const float* partials[MMF_MT_MAX];      /* the workspace a deferred mmf_layernorm_bwd filled */
+    int rows[MMF_MT_MAX];
+    int H[MMF_MT_MAX];
+    float* dgamma[MMF_MT_MAX];              /* fp32 [H], overwritten */
+    float* dbeta[MMF_MT_MAX];
+} mmf_ln_reduce_list;
+int mmf_layernorm_bwd_deferrable(int rows, int H);
+int mmf_layernorm_bwd_reduce_multi(const mmf_ln_reduce_list* d, void* stream);
 typedef struct mmf_tensor_list {
     int n;
     const void* ptr[MMF_MT_MAX];

@@ -67,6 +67,11 @@ class AdamWMultiDesc(C.Structure):
     ]
 
 
+class LnReduceList(C.Structure):
+    _fields_ = [("n", C.c_int), ("partials", C.c_void_p * MT_MAX), ("rows", C.c_int * MT_MAX), ("H", C.c_int * MT_MAX),
+                ("dgamma", C.c_void_p * MT_MAX), ("dbeta", C.c_void_p * MT_MAX)]
+
+
 class TensorList(C.Structure):
     _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * MT_MAX), ("numel", C.c_int64 * MT_MAX)]
 
@@ -313,6 +318,23 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, H, eps):
     _req(mean, torch.float32, "mean"); _req(rstd, torch.float32, "rstd")
     _check(lib().mmf_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, H, C.c_float(eps), _stream()),
            "mmf_layernorm_fwd")
+
+
+def layernorm_bwd_deferrable(rows, H):
+    return bool(lib().mmf_layernorm_bwd_deferrable(int(rows), int(H)))
+
+
+def layernorm_bwd_reduce_multi(items):
+    """items: (partials, rows, H, dgamma, dbeta) of LayerNorm backwards launched with dgamma = dbeta = dbias = None."""
+    for i0 in range(0, len(items), MT_MAX):
+        chunk = items[i0:i0 + MT_MAX]
+        d = LnReduceList()
+        d.n = len(chunk)
+        for i, (ws, rows, H, dg, db) in enumerate(chunk):
+            for t, n in ((ws, "partials"), (dg, "dgamma"), (db, "dbeta")):
+                _req(t, torch.float32, n)
+            d.partials[i], d.rows[i], d.H[i], d.dgamma[i], d.dbeta[i] = ws.data_ptr(), int(rows), int(H), dg.data_ptr(), db.data_ptr()
+        _check(lib().mmf_layernorm_bwd_reduce_multi(C.byref(d), _stream()), "mmf_layernorm_bwd_reduce_multi")
 
 
 def layernorm_bwd_ws_floats(H):

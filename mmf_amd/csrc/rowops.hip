@@ -368,6 +368,38 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_h_kernel(const float* __re
     }
 }
 
+// The same reduction for up to MMF_MT_MAX LayerNorm backwards in one launch (blockIdx.z = which one): a training step has 26 of
+// them whose dgamma / dbeta nobody reads before the optimizer, so their reductions can run once, at the end of backward.
+struct LnReduceArgs {
+    const float* partials[MMF_MT_MAX];
+    float* o0[MMF_MT_MAX];
+    float* o1[MMF_MT_MAX];
+    int nblk[MMF_MT_MAX];
+    int H[MMF_MT_MAX];
+};
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_multi_kernel(LnReduceArgs a) {
+    __shared__ float red[16][64];
+    const int t = blockIdx.z, H = a.H[t], nblk = a.nblk[t];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int qn = blockIdx.y;
+    if (blockIdx.x * 64 >= H) return;
+    const float* partials = a.partials[t];
+    float s = 0.f;
+    if (col < H) {
+#pragma unroll 4
+        for (int b = rg; b < nblk; b += 16) s += partials[((size_t)b * 3 + qn) * H + col];
+    }
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && col < H) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][c];
+        (qn == 0 ? a.o0[t] : a.o1[t])[col] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // embeddings
 // ------------------------------------------------------------------------------------------------
@@ -947,6 +979,34 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
 
 int mmf_layernorm_bwd_ws_floats(int H) { return LNB_MAX_GRID * 3 * H; }
 
+// workgroups (= partial rows) of the half-wave backward for `rows` rows
+static int lnb_h_grid(int rows) {
+    int grid = (rows + 15) / 16;
+    if (grid > LNB_MAX_GRID) grid = LNB_MAX_GRID;
+    const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
+    if (tg > 0 && tg < grid) grid = tg;
+    return grid;
+}
+static bool lnb_h_path(int H, bool dbias) { return (H % 256) == 0 && H <= 1024 && !(H == 1024 && dbias) && !mmf_amd_get_tunable(MMF_TUN_LN_OLD); }
+
+int mmf_layernorm_bwd_deferrable(int rows, int H) { return rows > 0 && lnb_h_path(H, false) ? 1 : 0; }
+
+int mmf_layernorm_bwd_reduce_multi(const mmf_ln_reduce_list* d, void* stream) {
+    MMF_CHECK_ARG(d && d->n > 0 && d->n <= MMF_MT_MAX, "layernorm_bwd_reduce_multi: bad list");
+    LnReduceArgs a;
+    int hmax = 0;
+    for (int i = 0; i < d->n; ++i) {
+        MMF_CHECK_ARG(d->partials[i] && d->dgamma[i] && d->dbeta[i] && mmf_layernorm_bwd_deferrable(d->rows[i], d->H[i]),
+                      "layernorm_bwd_reduce_multi: entry was not produced by a deferred mmf_layernorm_bwd");
+        a.partials[i] = d->partials[i]; a.o0[i] = d->dgamma[i]; a.o1[i] = d->dbeta[i];
+        a.nblk[i] = lnb_h_grid(d->rows[i]); a.H[i] = d->H[i];
+        hmax = d->H[i] > hmax ? d->H[i] : hmax;
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce_multi_kernel, dim3((hmax + 63) / 64, 2, d->n), dim3(1024), 0, (hipStream_t)stream, a);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
 int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                       void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, float* dgamma,
                       float* dbeta, float* dbias, int accumulate, float* partials, int rows, int H, void* stream) {
@@ -956,10 +1016,8 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     hipStream_t s = (hipStream_t)stream;
     DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
     const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
-    if ((H % 256) == 0 && H <= 1024 && !(H == 1024 && dbias) && !mmf_amd_get_tunable(MMF_TUN_LN_OLD)) {     // half a wave per row, 16-byte accesses
-        int grid = (rows + 15) / 16;
-        if (grid > LNB_MAX_GRID) grid = LNB_MAX_GRID;
-        if (tg > 0 && tg < grid) grid = tg;
+    if (lnb_h_path(H, dbias != nullptr)) {     // half a wave per row, 16-byte accesses
+        const int grid = lnb_h_grid(rows);
         const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
 #define MMF_LNB_H(NC)                                                                                                              \
         if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows); \
@@ -972,10 +1030,12 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
         }
 #undef MMF_LNB_H
         MMF_CHECK_LAUNCH();
+        if (!dgamma && !dbeta && !dbias) return 0;     // deferred: the caller finishes with mmf_layernorm_bwd_reduce_multi
         hipLaunchKernelGGL(ln_bwd_reduce_h_kernel, dim3((H + 63) / 64, dbias ? 3 : 2), dim3(1024), 0, s, partials, grid, H, dgamma, dbeta, dbias, accumulate);
         MMF_CHECK_LAUNCH();
         return 0;
     }
+    MMF_CHECK_ARG(dgamma || dbeta || dbias, "layernorm_bwd: deferring the column sums needs mmf_layernorm_bwd_deferrable(rows, H)");
     const int nch_ = (H + 255) / 256;
     const int grid = grid_for(rows, nch_ >= 5 ? 4 : nch_ >= 4 ? 8 : LNB_WAVES, tg > 0 ? (tg > LNB_MAX_GRID ? LNB_MAX_GRID : tg) : (nch_ >= 4 ? 2 * LNB_GRID : LNB_GRID));
     const int nch = (H + 255) / 256;

@@ -410,6 +410,35 @@ def _ddrln_fwd(h2, resid2, w16, bias, gamma, beta, eps, drop):
     return out, y, mean, rstd
 
 
+class _LnDefer:
+    """Opt-in: inside `with ln_defer():` LayerNorm backwards leave the column sums behind their dgamma / dbeta as per-workgroup
+    partials and ONE multi-tensor launch finishes all of them when the block ends (26 reductions per VisualBERT step become one).
+    The returned dgamma / dbeta tensors are NOT valid before that: only for callers that own the whole backward and consume the
+    parameter gradients after it (the graphed steps in mmf_amd/utils/graph.py)."""
+
+    def __init__(self):
+        self.active = False
+        self.pending = []
+
+    @contextlib.contextmanager
+    def __call__(self):
+        old, self.active = self.active, True
+        try:
+            yield
+        finally:
+            self.active = old
+            if not old:
+                self.flush()
+
+    def flush(self):
+        if self.pending:
+            items, self.pending = self.pending, []
+            nat.layernorm_bwd_reduce_multi(items)
+
+
+ln_defer = _LnDefer()
+
+
 def _ln_bwd(dy, y, mean, rstd, gamma, drop, want_dbias):
     M, N = y.shape
     dev = y.device
@@ -419,7 +448,11 @@ def _ln_bwd(dy, y, mean, rstd, gamma, drop, want_dbias):
     dbeta = torch.empty(N, dtype=F32, device=dev)
     dbias = torch.empty(N, dtype=F32, device=dev) if want_dbias else None
     ws = torch.empty(nat.layernorm_bwd_ws_floats(N), dtype=F32, device=dev)
-    nat.layernorm_bwd(dy, y, mean, rstd, gamma, dx, dlin, drop, dgamma, dbeta, dbias, 0, ws, M, N)
+    if ln_defer.active and not want_dbias and nat.layernorm_bwd_deferrable(M, N):
+        nat.layernorm_bwd(dy, y, mean, rstd, gamma, dx, dlin, drop, None, None, None, 0, ws, M, N)
+        ln_defer.pending.append((ws, M, N, dgamma, dbeta))
+    else:
+        nat.layernorm_bwd(dy, y, mean, rstd, gamma, dx, dlin, drop, dgamma, dbeta, dbias, 0, ws, M, N)
     return dx, (dlin if dlin is not None else dx), dgamma, dbeta, dbias
 
 

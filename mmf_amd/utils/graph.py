@@ -107,7 +107,7 @@ class GraphedTrainStep:
         # created on; if an earlier eager step created them on the legacy default stream, running them inside the
         # capture drags that stream into it and hipStreamEndCapture crashes.  Capturing the gradients directly keeps
         # every captured node on the capture stream.
-        with Fn.wgrad_overlap(self.side_stream):
+        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer():
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g
@@ -233,7 +233,8 @@ class GraphedDataParallelStep:
         n = len(self._bounds)
         root = self._loss_t if j == 0 else self._bounds[n - j][0]
         inputs = list(params) + ([self._bounds[n - j - 1][1]] if j < n else [])
-        grads = torch.autograd.grad(root, inputs, grad_outputs=None if j == 0 else carry, allow_unused=True)
+        with Fn.ln_defer():        # the stage's LayerNorm parameter gradients are finished by one launch at its end
+            grads = torch.autograd.grad(root, inputs, grad_outputs=None if j == 0 else carry, allow_unused=True)
         if j < n:
             if grads[-1] is None:
                 raise RuntimeError("GraphedDataParallelStep: the loss does not depend on the output of cut %d" % (n - j - 1))

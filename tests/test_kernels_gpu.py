@@ -500,6 +500,34 @@ def test_layernorm_half_wave_kernels_agree_with_the_one_wave_per_row_kernels(H):
 # ---------------------------------------------------------------------------------------------
 # embeddings / row utilities / loss / optimizer
 # ---------------------------------------------------------------------------------------------
+def test_layernorm_backward_deferred_column_sums_are_bit_identical():
+    """dgamma / dbeta of several LayerNorm backwards finished by ONE mmf_layernorm_bwd_reduce_multi launch (what the graphed
+    training steps do) against the per-call reduction: same partials, same summation order."""
+    cases = [(7296, 768), (100, 256), (3200, 1024), (37, 512)]
+    direct, items, keep = [], [], []
+    for rows, H in cases:
+        assert nat().layernorm_bwd_deferrable(rows, H)
+        dy = rnd(rows, H); x = rnd(rows, H, scale=1.0)
+        mean = torch.randn(rows, device=DEV) * 0.1; rstd = torch.rand(rows, device=DEV) + 0.5
+        gamma = torch.rand(H, device=DEV) + 0.5
+        outs = []
+        for deferred in (False, True):
+            dx = torch.empty_like(dy)
+            dg = torch.full((H,), 7.0, device=DEV); db = torch.full((H,), 7.0, device=DEV)
+            ws = torch.empty(nat().layernorm_bwd_ws_floats(H), device=DEV)
+            if deferred:
+                nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat().NO_DROP, None, None, None, 0, ws, rows, H)
+                items.append((ws, rows, H, dg, db))
+            else:
+                nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat().NO_DROP, dg, db, None, 0, ws, rows, H)
+            outs.append((dx, dg, db))
+        direct.append(outs)
+    nat().layernorm_bwd_reduce_multi(items)
+    for (a, b), (rows, H) in zip(direct, cases):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (rows, H)
+    assert not nat().layernorm_bwd_deferrable(100, 300)          # (shapes outside the half-wave kernels are reduced per call)
+
+
 def test_embed_text_and_scatter_add():
     B, T, S, H, V = 4, 16, 24, 768, 1000
     ids = torch.randint(0, V, (B, T), device=DEV); seg = torch.randint(0, 2, (B, T), device=DEV)

@@ -3,7 +3,26 @@ summaries under profiles/: per-kernel stats, PMC-derived HBM traffic per launch 
 MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950), SQ counters of the GEMM kernels."""
 import collections, csv, glob, json, os, re, sys
 
+_DEMANGLED = {}
+
+
+def demangle(name):
+    if name.startswith("_Z") and name not in _DEMANGLED:
+        import subprocess
+        try:
+            filt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"       # (binutils' c++filt does not know the bf16 mangling DF16b)
+            _DEMANGLED[name] = subprocess.run([filt if os.path.exists(filt) else "c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        except OSError:
+            _DEMANGLED[name] = name
+    return _DEMANGLED.get(name, name)
+
+
 def short(name):
+    v = variant(name)
+    if v is not None and ("grouped" in v or "wide" in v):
+        return v.split(" | ")[1].replace(" ", "<", 1) + ">"
+    if "gemm_bf16_kernelI" not in name:
+        name = demangle(name)
     name = name.replace("(anonymous namespace)::", "")
     m = re.search(r"gemm_bf16_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d+)E(?:Li(\d)ELb(\d)E)?", name)
     if m:
@@ -17,11 +36,19 @@ def short(name):
     return re.sub(r"\(.*", "", name)[:80]
 
 def variant(name):
-    m = re.search(r"gemm_bf16_kernelI(?:DF16b|f)(?:DF16b|f)Lb(\d)ELb(\d)ELb(\d)E", name)
+    """The label bench.py's KernelProbe gives the launches of this kernel ("gemm <form> | <kernel family and tile>[ ksplit]
+    [ (ragged / small)]"), so that profiles/pmc_traffic.json can be looked up with the bench line's dominant-kernel label."""
+    if "gemm_bf16_grouped_kernel" in name:
+        return "gemm TN grouped wgrad | gemm_bf16_grouped_kernel 128x128"
+    m = re.search(r"gemm_wide_kernel<(\d+), (\d+)", name) or re.search(r"gemm_wide_kernelILi(\d+)ELi(\d+)E", name)
+    if m:
+        return "gemm NT | gemm_wide_kernel %sx%s" % (m.group(1), m.group(2))
+    m = re.search(r"gemm_bf16_kernelI(?:DF16b|f)(?:DF16b|f)Lb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d+)ELi(\d)E", name)
     if not m:
         return None
-    ak, bk, rg = m.groups()
-    return ("T" if ak == "1" else "N") + ("N" if bk == "1" else "T") + ("_ragged" if rg == "1" else "")
+    ak, bk, rg, nwn, bn, ks = m.groups()
+    return "gemm %s%s | gemm_bf16_kernel 128x%s%s%s" % ("T" if ak == "1" else "N", "N" if bk == "1" else "T", bn,
+                                                       " ksplit" if ks == "2" else "", " (ragged / small)" if rg == "1" else "")
 
 def main(tag):
     src = "gpurun_out/profiles_%s" % tag
@@ -32,11 +59,12 @@ def main(tag):
     for r in rows:
         agg[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     tot = sum(sum(v) for v in agg.values())
-    lines = ["# rocprofv3 --kernel-trace --stats of: python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph  (8 steps incl. warm-up + 1 instrumented)",
+    nsteps = max(1, sum(1 for r in rows if "embed_text_kernel" in r["Kernel_Name"]))      # one text-embedding launch per step
+    lines = ["# rocprofv3 --kernel-trace --stats of: python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph  (%d steps incl. warm-up, the eager-enqueue leg and 1 instrumented)" % nsteps,
              "%-8s %-12s %-10s %-10s %-10s %-7s %s" % ("calls", "total_us", "avg_us", "min_us", "max_us", "pct", "kernel")]
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         lines.append("%-8d %-12.1f %-10.2f %-10.2f %-10.2f %-7.2f %s" % (len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot, k))
-    lines.append("TOTAL kernel time %.1f us over %d dispatches (%.2f ms per step)" % (tot, len(rows), tot / 8e3))
+    lines.append("TOTAL kernel time %.1f us over %d dispatches, %d steps (%.2f ms of kernel time per step; optimizer-state zero-fills of the two optimizers included)" % (tot, len(rows), nsteps, tot / nsteps / 1e3))
     open("profiles/%s_kernel_stats.txt" % tag, "w").write("\n".join(lines) + "\n")
     raw = glob.glob(src + "/trace/*kernel_stats.csv")       # rocprofv3's own --stats table, verbatim
     if raw:
@@ -59,7 +87,11 @@ def main(tag):
                       "write_size_kb_raw": round(write_kb, 1), "launches": len(d.get("FETCH_SIZE", [])),
                       "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B for wide coalesced reads)"}
     if traffic:      # a trace-only refresh keeps the PMC summaries of the last full run
-        json.dump({k: v["bytes_per_launch"] for k, v in traffic.items()}, open("profiles/pmc_traffic.json", "w"), indent=1)
+        import subprocess, time
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        flat = {k: v["bytes_per_launch"] for k, v in traffic.items()}
+        flat["_collected"] = "%s, tree at %s, tools/make_profiles.sh %s" % (time.strftime("%Y-%m-%d"), head or "?", tag)
+        json.dump(flat, open("profiles/pmc_traffic.json", "w"), indent=1)
         json.dump(traffic, open("profiles/%s_pmc_traffic_detail.json" % tag, "w"), indent=1)
     # ---- SQ counters
     f = glob.glob(src + "/pmc_sq/*counter_collection.csv")

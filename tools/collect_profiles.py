@@ -17,12 +17,25 @@ def demangle(name):
     return _DEMANGLED.get(name, name)
 
 
+def anon_name(name):
+    """kernel<ints> out of a mangled anonymous-namespace symbol the installed demanglers cannot read (bf16 = DF16b)."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if not m:
+        return None
+    n = int(m.group(1)); p0 = m.end()
+    fname, rest = name[p0:p0 + n], name[p0 + n:]
+    targs = re.findall(r"L[ib](\d+)E", rest.split("EEv")[0]) if rest.startswith("I") else []
+    return fname + ("<%s>" % ", ".join(targs) if targs else "")
+
+
 def short(name):
     v = variant(name)
     if v is not None and ("grouped" in v or "wide" in v):
         return v.split(" | ")[1].replace(" ", "<", 1) + ">"
     if "gemm_bf16_kernelI" not in name:
         name = demangle(name)
+        if name.startswith("_ZN12_GLOBAL__N_1"):
+            return anon_name(name) or name[:80]
     name = name.replace("(anonymous namespace)::", "")
     m = re.search(r"gemm_bf16_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d+)E(?:Li(\d)ELb(\d)E)?", name)
     if m:

@@ -91,11 +91,19 @@ def make_drop(p, training):
 # ---------------------------------------------------------------------------------------------
 # bf16 shadows of fp32 master parameters
 # ---------------------------------------------------------------------------------------------
-# Transposed weight twins for the input-gradient GEMMs (opt-in experiment, MMF_AMD_DGRAD_NT=1).  In the isolated microbenchmark
-# a GEMM with two row operands is ~18 % faster than the same shape with a k-major W (tools/gemm_vs_library.py); inside the
-# training step the same-box A/B shows no gain (11.62 vs 11.53-11.62 ms per full update, 11.09 vs 10.96-11.04 ms forward +
-# backward), so the k-major form - no extra 170 MB, no transpose per update - stays the default.
-DGRAD_NT = os.environ.get("MMF_AMD_DGRAD_NT", "0") == "1"
+# Transposed weight twins for the input-gradient GEMMs (MMF_AMD_DGRAD_NT=0 switches them off).  dX = dY W reads W k-major; with
+# a W^T twin both operands are row operands and the launch can use the forward-form kernels.  On the 128x128 kernel that bought
+# nothing inside the step (round 1: 11.62 vs 11.53-11.62 ms), but it makes the narrow-output dgrads eligible for the 256x96 wide
+# tile, which does pay (see _twin_pays).  Cost: one bf16 transpose per twin and optimizer step (mmf_transpose_bf16_multi).
+DGRAD_NT = os.environ.get("MMF_AMD_DGRAD_NT", "1") == "1"
+
+
+def _twin_pays(out_width):
+    """Input-gradient GEMMs whose OUTPUT is narrow (a multiple of 96 up to 1152 columns: 768 here) run on the 256x96 wide tile
+    when both operands are row operands — 2.15 ms instead of 2.42 ms per step for the QKV / FFN-up / out-proj dgrads of VisualBERT
+    VQA2 (same-box A/B, profiles/r02_bench_line.json) — so their weights keep a transposed twin.  Wide outputs (FFN-down's dgrad,
+    3072 columns) are faster with the k-major W on the 128x128 kernel and keep no twin."""
+    return out_width % 96 == 0 and out_width <= 1152
 
 
 class ShadowCache:
@@ -240,8 +248,8 @@ def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=N
     dx = None
     if need_dx:
         dx = torch.empty(M, K, dtype=BF16, device=dev)
-        wt = shadows.transposed(w16) if N % 8 == 0 else None
-        if wt is not None:     # dX = dY (W^T)^T with two row operands (experiment, see DGRAD_NT)
+        wt = shadows.transposed(w16) if (N % 8 == 0 and _twin_pays(K)) else None
+        if wt is not None:     # dX = dY (W^T)^T with two row operands (see DGRAD_NT)
             nat.gemm(dy, wt, dx, M, K, N, ldy, N, K, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
         else:
             nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
@@ -601,7 +609,11 @@ class FeedForwardFn(torch.autograd.Function):
 def _dgrad(dy, ldy, w16, M, N, K, dx_resid=None, act_aux=None):
     """dX [M, K] = dY [M, N] W [N, K] (W k-major: no transposed copy), residual-gradient add / saved-GELU' multiply fused."""
     dx = torch.empty(M, K, dtype=BF16, device=dy.device)
-    nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
+    wt = shadows.transposed(w16) if (N % 8 == 0 and _twin_pays(K)) else None
+    if wt is not None:      # two row operands (W^T twin): the forward-form kernels, i.e. the 256x96 wide tile for these widths
+        nat.gemm(dy, wt, dx, M, K, N, ldy, N, K, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
+    else:
+        nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
     return dx
 
 

@@ -509,6 +509,19 @@ __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __r
     }
 }
 
+// Position-table gradient: bucket = idx_base + (row index inside the sample), no index array, i.e. out[idx_base + i][c] +=
+// sum_b x[b][i][c] — a plain strided sum over the batch (deterministic; the atomic form has every sample hit the same rows).
+__global__ __launch_bounds__(256) void scatter_add_pos_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride, int idx_base,
+                                                               float* __restrict__ out, int H) {
+    const int i = blockIdx.x, col = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (col >= H) return;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nb; ++b) a += load4(x + ((size_t)b * bstride + i) * ld + col);
+    float* o = out + (size_t)(idx_base + i) * H + col;
+    const f32x4 old = load4(o);
+    *reinterpret_cast<float4*>(o) = make_float4(old[0] + a[0], old[1] + a[1], old[2] + a[2], old[3] + a[3]);
+}
+
 // <= 2 buckets (token-type tables, the single visual position row): deterministic two-stage column sums per bucket.
 // stage 1: grid (FEW_GROUPS, ceil(H/256)); partials [FEW_GROUPS][2][H].  Rows whose bucket is >= 2 fall back to atomics.
 constexpr int FEW_GROUPS = 32;
@@ -1116,6 +1129,9 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
         MMF_CHECK_LAUNCH();
         hipLaunchKernelGGL(scatter_add_few_reduce_kernel, dim3((H + 255) / 256, nbuckets < 2 ? nbuckets : 2), dim3(256), 0,
                            (hipStream_t)stream, ws, groups, H, nbuckets, out);
+    } else if (!idx && per_pos && skip_bucket < 0) {
+        hipLaunchKernelGGL(scatter_add_pos_kernel, dim3(rpb, (H / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb,
+                           bstride, idx_base, out, H);
     } else {
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
                            ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, skip_bucket, nbuckets);

@@ -840,10 +840,18 @@ __global__ void optim_state_advance_kernel(float* state, int schedule, float war
     state[1] = f;
 }
 
-__global__ __launch_bounds__(256) void adamw_multi_kernel(mmf_adamw_multi_desc d, float bc1, float bc2) {
-    const int t = blockIdx.y;
+// One-dimensional grid over the (tensor, chunk) pairs of the launch: cstart[t] = first block of tensor t.  (A 2-D grid sized by
+// the LARGEST tensor launched 56 K empty workgroups beside the 23 M-element word-embedding table: that launch ran at 1.9 TB/s.)
+struct AdamLaunch {
+    mmf_adamw_multi_desc d;
+    int cstart[MMF_MT_MAX + 1];
+};
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc1, float bc2) {
+    const mmf_adamw_multi_desc& d = a.d;
+    int t = 0;
+    for (int i = 1; i < d.n; ++i) t += ((int)blockIdx.x >= a.cstart[i]) ? 1 : 0;
     const int64_t n = d.numel[t];
-    const int64_t base = (int64_t)blockIdx.x * MT_CHUNK;
+    const int64_t base = (int64_t)((int)blockIdx.x - a.cstart[t]) * MT_CHUNK;
     if (base >= n) return;
     float* __restrict__ p = reinterpret_cast<float*>(d.p[t]);
     const float* __restrict__ g = reinterpret_cast<const float*>(d.g[t]);
@@ -1297,14 +1305,16 @@ int mmf_adamw_step(float* p, const float* g, float* m, float* v, void* p16, int6
 
 int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream) {
     MMF_CHECK_ARG(d && d->n > 0 && d->n <= MMF_MT_MAX && (d->step >= 1 || d->dev_state), "adamw_multi: bad descriptor");
-    int64_t mx = 0;
-    for (int i = 0; i < d->n; ++i) {
+    for (int i = 0; i < d->n; ++i)
         MMF_CHECK_ARG(d->p[i] && d->g[i] && d->m[i] && d->v[i] && d->numel[i] > 0, "adamw_multi: null tensor");
-        mx = d->numel[i] > mx ? d->numel[i] : mx;
-    }
     float bc1 = 1.f, bc2 = 1.f;
     if (d->correct_bias && !d->dev_state) { bc1 = 1.f - powf(d->beta1, (float)d->step); bc2 = 1.f - powf(d->beta2, (float)d->step); }
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)((mx + MT_CHUNK - 1) / MT_CHUNK), d->n), dim3(256), 0, (hipStream_t)stream, *d, bc1, bc2);
+    AdamLaunch a;
+    a.d = *d;
+    int blocks = 0;
+    for (int i = 0; i < d->n; ++i) { a.cstart[i] = blocks; blocks += (int)((d->numel[i] + MT_CHUNK - 1) / MT_CHUNK); }
+    for (int i = d->n; i <= MMF_MT_MAX; ++i) a.cstart[i] = blocks;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, bc1, bc2);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -840,8 +840,11 @@ __global__ void optim_state_advance_kernel(float* state, int schedule, float war
     state[1] = f;
 }
 
-// One-dimensional grid over the (tensor, chunk) pairs of the launch: cstart[t] = first block of tensor t.  (A 2-D grid sized by
-// the LARGEST tensor launched 56 K empty workgroups beside the 23 M-element word-embedding table: that launch ran at 1.9 TB/s.)
+// One-dimensional grid over the (tensor, chunk) pairs of the launch: cstart[t] = first block of tensor t (no empty workgroups
+// beside a large tensor).  A workgroup owns ADAM_CHUNK = 4096 elements = ONE pass of 4 x 16 bytes per thread and stream with all
+// loads issued before anything is computed; g, m, v are touched once per step, so they move with non-temporal hints and leave the
+// caches to p / the bf16 shadow the next forward reads (tools/ubench/adam_bench.hip: 4.4 -> 5.8 TB/s on the word-embedding table).
+constexpr int ADAM_CHUNK = 4096;
 struct AdamLaunch {
     mmf_adamw_multi_desc d;
     int cstart[MMF_MT_MAX + 1];
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc
     int t = 0;
     for (int i = 1; i < d.n; ++i) t += ((int)blockIdx.x >= a.cstart[i]) ? 1 : 0;
     const int64_t n = d.numel[t];
-    const int64_t base = (int64_t)((int)blockIdx.x - a.cstart[t]) * MT_CHUNK;
+    const int64_t base = (int64_t)((int)blockIdx.x - a.cstart[t]) * ADAM_CHUNK;
     if (base >= n) return;
     float* __restrict__ p = reinterpret_cast<float*>(d.p[t]);
     const float* __restrict__ g = reinterpret_cast<const float*>(d.g[t]);
@@ -871,31 +874,48 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc
         const float coef = d.max_norm / (sqrtf(d.norm_sq[0]) * d.grad_scale + 1e-6f);    // the norm of the SCALED gradients
         gs *= coef < 1.f ? coef : 1.f;
     }
-    const int64_t end = (base + MT_CHUNK < n) ? base + MT_CHUNK : n;
-    for (int64_t i = base + threadIdx.x * 4; i < end; i += 1024) {
-        const int cnt = (i + 4 <= end) ? 4 : (int)(end - i);
-        const bool vec = (cnt == 4) && ((i & 3) == 0);
-        f32x4 pv, gv, mv, vv;
-        if (vec) { pv = load4(p + i); gv = load4(g + i); mv = load4(m + i); vv = load4(v + i); }
-        else for (int j = 0; j < 4; ++j) { const bool ok = j < cnt; pv[j] = ok ? p[i + j] : 0.f; gv[j] = ok ? g[i + j] : 0.f; mv[j] = ok ? m[i + j] : 0.f; vv[j] = ok ? v[i + j] : 0.f; }
+    const int64_t end = (base + ADAM_CHUNK < n) ? base + ADAM_CHUNK : n;
+    f32x4 pv[4], gv[4], mv[4], vv[4];
+    bool vec[4];
+    int cnt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + threadIdx.x * 4 + 1024 * u;
+        cnt[u] = (i >= end) ? 0 : ((i + 4 <= end) ? 4 : (int)(end - i));
+        vec[u] = (cnt[u] == 4) && ((i & 3) == 0);
+        if (vec[u]) {
+            pv[u] = load4(p + i);
+            gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+            mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + i));
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + i));
+        } else {
+            for (int j = 0; j < 4; ++j) { const bool ok = j < cnt[u]; pv[u][j] = ok ? p[i + j] : 0.f; gv[u][j] = ok ? g[i + j] : 0.f; mv[u][j] = ok ? m[i + j] : 0.f; vv[u][j] = ok ? v[i + j] : 0.f; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (cnt[u] == 0) continue;
+        const int64_t i = base + threadIdx.x * 4 + 1024 * u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float gj = gv[j] * gs;
-            mv[j] = b1 * mv[j] + (1.f - b1) * gj;
-            vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+            const float gj = gv[u][j] * gs;
+            mv[u][j] = b1 * mv[u][j] + (1.f - b1) * gj;
+            vv[u][j] = b2 * vv[u][j] + (1.f - b2) * gj * gj;
             if (d.mode == 0) {   // transformers.AdamW
-                pv[j] -= (lr * sqrtf(bc2) / bc1) * (mv[j] / (sqrtf(vv[j]) + eps));
-                if (wd > 0.f) pv[j] -= lr * wd * pv[j];
+                pv[u][j] -= (lr * sqrtf(bc2) / bc1) * (mv[u][j] / (sqrtf(vv[u][j]) + eps));
+                if (wd > 0.f) pv[u][j] -= lr * wd * pv[u][j];
             } else {             // torch.optim.AdamW
-                pv[j] *= (1.f - lr * wd);
-                pv[j] -= (lr / bc1) * (mv[j] / (sqrtf(vv[j]) / sqrtf(bc2) + eps));
+                pv[u][j] *= (1.f - lr * wd);
+                pv[u][j] -= (lr / bc1) * (mv[u][j] / (sqrtf(vv[u][j]) / sqrtf(bc2) + eps));
             }
         }
-        if (vec) {
-            store4(p + i, pv); store4(m + i, mv); store4(v + i, vv);
-            if (p16) store4(p16 + i, pv);
-            if (p32) store4(p32 + i, pv);
-        } else for (int j = 0; j < cnt; ++j) { p[i + j] = pv[j]; m[i + j] = mv[j]; v[i + j] = vv[j]; if (p16) p16[i + j] = (bf16)pv[j]; if (p32) p32[i + j] = pv[j]; }
+        if (vec[u]) {
+            store4(p + i, pv[u]);
+            __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + i));
+            __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + i));
+            if (p16) store4(p16 + i, pv[u]);
+            if (p32) store4(p32 + i, pv[u]);
+        } else for (int j = 0; j < cnt[u]; ++j) { p[i + j] = pv[u][j]; m[i + j] = mv[u][j]; v[i + j] = vv[u][j]; if (p16) p16[i + j] = (bf16)pv[u][j]; if (p32) p32[i + j] = pv[u][j]; }
     }
 }
 __global__ __launch_bounds__(256) void l2norm_multi_kernel(mmf_tensor_list d, float* __restrict__ partials) {
@@ -1312,7 +1332,7 @@ int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream) {
     AdamLaunch a;
     a.d = *d;
     int blocks = 0;
-    for (int i = 0; i < d->n; ++i) { a.cstart[i] = blocks; blocks += (int)((d->numel[i] + MT_CHUNK - 1) / MT_CHUNK); }
+    for (int i = 0; i < d->n; ++i) { a.cstart[i] = blocks; blocks += (int)((d->numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK); }
     for (int i = d->n; i <= MMF_MT_MAX; ++i) a.cstart[i] = blocks;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, bc1, bc2);
     MMF_CHECK_LAUNCH();

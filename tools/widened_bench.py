@@ -150,7 +150,7 @@ def run(name, steps=10, warmup=3):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     if mode == "graph":       # the step is one replayed hipGraph: no per-GEMM events
-        gemm_ms = gemm_fl = float("nan")
+        gemm_ms = gemm_fl = None
     else:
         with KernelProbe() as probe:
             eager_step()
@@ -158,8 +158,9 @@ def run(name, steps=10, warmup=3):
         gemm_ms = sum(d["ms"] for d in by.values()); gemm_fl = sum(d["work"] for d in by.values())
     rec = dict(model=name, workload=label, batch=B, ms_per_step=round(ms, 3), samples_per_s=round(B / ms * 1e3, 1),
                loss=round(float(last.item()), 4), params=sum(p.numel() for p in model.parameters()),
-               gemm_flop_per_step=gemm_fl, gemm_ms_per_step=round(gemm_ms, 3), gemm_tflops=round(gemm_fl / gemm_ms / 1e9, 1),
-               step_tflops=round(gemm_fl / ms / 1e9, 1), launch=mode or "eager", dtype="bf16", data="synthetic")
+               gemm_flop_per_step=gemm_fl, gemm_ms_per_step=None if gemm_ms is None else round(gemm_ms, 3),
+               gemm_tflops=None if gemm_ms is None else round(gemm_fl / gemm_ms / 1e9, 1),
+               step_tflops=None if gemm_fl is None else round(gemm_fl / ms / 1e9, 1), launch=mode or "eager", dtype="bf16", data="synthetic")
     print("%-8s B=%3d  %8.2f ms/step  %8.1f samples/s  GEMMs %.1f GFLOP in %.2f ms (%.0f TFLOP/s), whole step %.0f TFLOP/s  loss %.4f" % (
         name, B, ms, rec["samples_per_s"], gemm_fl / 1e9, gemm_ms, rec["gemm_tflops"], rec["step_tflops"], rec["loss"]), flush=True)
     del model, opt, batch

@@ -161,8 +161,9 @@ def run(name, steps=10, warmup=3):
                gemm_flop_per_step=gemm_fl, gemm_ms_per_step=None if gemm_ms is None else round(gemm_ms, 3),
                gemm_tflops=None if gemm_ms is None else round(gemm_fl / gemm_ms / 1e9, 1),
                step_tflops=None if gemm_fl is None else round(gemm_fl / ms / 1e9, 1), launch=mode or "eager", dtype="bf16", data="synthetic")
-    print("%-8s B=%3d  %8.2f ms/step  %8.1f samples/s  GEMMs %.1f GFLOP in %.2f ms (%.0f TFLOP/s), whole step %.0f TFLOP/s  loss %.4f" % (
-        name, B, ms, rec["samples_per_s"], gemm_fl / 1e9, gemm_ms, rec["gemm_tflops"], rec["step_tflops"], rec["loss"]), flush=True)
+    detail = "(one hipGraph: no per-GEMM events)" if gemm_ms is None else "GEMMs %.1f GFLOP in %.2f ms (%.0f TFLOP/s), whole step %.0f TFLOP/s" % (
+        gemm_fl / 1e9, gemm_ms, rec["gemm_tflops"], rec["step_tflops"])
+    print("%-8s B=%3d  %8.2f ms/step  %8.1f samples/s  %s  loss %.4f" % (name, B, ms, rec["samples_per_s"], detail, rec["loss"]), flush=True)
     del model, opt, batch
     torch.cuda.empty_cache()
     return rec

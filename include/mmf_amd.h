@@ -415,6 +415,27 @@ typedef struct mmf_transpose_list {
 } mmf_transpose_list;
 int mmf_transpose_bf16_multi(const mmf_transpose_list* d, void* stream);
 
+/* ---- fp32-accurate forward path (mmf_amd/csrc/fp32_path.hip) -----------------------------------
+ * The reference computes in fp32 unless `training.fp16` switches autocast on (mmf/trainers/core/training_loop.py:199); these
+ * entry points evaluate the same operations with fp32 activations on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32:
+ * exact fp32 products, fp32 accumulation), so that outputs agree with the reference to fp32 round-off (the 1e-3 bound).
+ * Forward (inference / evaluation) only.
+ *
+ * mmf_gemm_f32: the forward form of mmf_gemm_bf16 (a_kmajor = b_kmajor = 0) with A, B, C and resid fp32 (set a_f32 = b_f32 =
+ * out_f32 = 1); epilogue bias, coladd, rowtab[rowidx], act 0 / 1 (exact-erf GELU, libm erff) / 3 (tanh), resid, row remap.
+ * K, lda, ldb multiples of 4; no U / aux / dropout / split-K / beta.  Replaces nn.Linear forward at hf_layers.py:169-180,
+ * 248, 289-290, embeddings.py:352, visual_bert.py:146, 328-330.
+ * mmf_attention_f32_fwd: mmf_attention_fwd with q / k / v / ctx fp32, head_dim 64, Sk <= 256, key mask only (hf_layers.py:161-213
+ * in eval mode); lse, ctx_f32, dropout, causal_tail and the K|V-cache strides must be unset.
+ * mmf_layernorm_f32_fwd: nn.LayerNorm over fp32 rows (hf_layers.py:248,290; embeddings.py:456; visual_bert.py:328).
+ * mmf_embed_text_f32_fwd / mmf_gather_rows_f32: mmf_embed_text_fwd / mmf_gather_rows (no dropout) writing / moving fp32 rows. */
+int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream);
+int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream);
+int mmf_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int H, float eps, void* stream);
+int mmf_embed_text_f32_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, float* y,
+                           int B, int T, int S, int H, int row0, int pos0, int V, int P, int NT, void* stream);
+int mmf_gather_rows_f32(const float* x, const int64_t* index, float* out, int B, int S, int H, void* stream);
+
 /* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
 int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */
 int mmf_probe_mfma32(const void* a, const void* b, float* d, void* stream);   /* out 64x16 */

@@ -534,6 +534,61 @@ def cross_entropy_bwd(logits, labels, count, gloss, dlogits, B, Cn, ignore_index
 
 
 # --------------------------------------------------------------------------------------------
+# fp32-accurate forward path (mmf_amd/csrc/fp32_path.hip)
+# --------------------------------------------------------------------------------------------
+def gemm_f32(A, B, C_out, M, N, K, lda, ldb, ldc, bias=None, coladd=None, rowtab=None, rowidx=None, rowtab_ld=0, act=0, resid=None,
+             ldr=0, grp=(0, 0, 0)):
+    """C = epilogue(A B^T) with A [M, K], B [N, K], C and resid all fp32 on the fp32-input MFMA (forward form only)."""
+    for t, n in ((A, "A"), (B, "B"), (C_out, "C"), (resid, "resid"), (bias, "bias"), (coladd, "coladd"), (rowtab, "rowtab")):
+        _req(t, torch.float32, n)
+    _req(rowidx, torch.int64, "rowidx")
+    d = GemmDesc()
+    d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.a_f32 = d.b_f32 = d.out_f32 = 1
+    d.bias, d.coladd, d.rowtab, d.rowidx, d.rowtab_ld = _p(bias), _p(coladd), _p(rowtab), _p(rowidx), rowtab_ld
+    d.act = act
+    d.resid, d.ldr = _p(resid), ldr
+    d.drop_scale = 1.0
+    d.grp_in, d.grp_pad, d.grp_off = grp
+    _check(lib().mmf_gemm_f32(C.byref(d), _stream()), "mmf_gemm_f32")
+
+
+def attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64):
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx"), (mask, "mask")):
+        _req(t, torch.float32, n)
+    d = AttnDesc()
+    d.q, d.k, d.v = _p(q), _p(k), _p(v)
+    d.ldq, d.ldk, d.ldv = ldq, ldk, ldv
+    d.mask, d.ctx, d.ldo = _p(mask), _p(ctx), ldo
+    d.B, d.heads, d.Sq, d.Sk = B, heads, Sq, Sk
+    d.scale = scale
+    d.drop_scale = 1.0
+    d.head_dim = head_dim
+    _check(lib().mmf_attention_f32_fwd(C.byref(d), _stream()), "mmf_attention_f32_fwd")
+
+
+def layernorm_f32_fwd(x, gamma, beta, y, rows, H, eps):
+    for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta"), (y, "y")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_layernorm_f32_fwd(_p(x), _p(gamma), _p(beta), _p(y), rows, H, C.c_float(eps), _stream()), "mmf_layernorm_f32_fwd")
+
+
+def embed_text_f32_fwd(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
+    _req(ids, torch.int64, "ids"); _req(seg, torch.int64, "seg"); _req(y, torch.float32, "y")
+    for t, n in ((word, "word"), (pos, "pos"), (typ, "type")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_embed_text_f32_fwd(_p(ids), _p(seg), _p(word), _p(pos), _p(typ), _p(y), B, T, S, H, row0, pos0,
+                                        int(word.shape[0]), int(pos.shape[0]), int(typ.shape[0]), _stream()), "mmf_embed_text_f32_fwd")
+
+
+def gather_rows_f32(x, index, out, B, S, H):
+    _req(x, torch.float32, "x"); _req(index, torch.int64, "index"); _req(out, torch.float32, "out")
+    _check(lib().mmf_gather_rows_f32(_p(x), _p(index), _p(out), B, S, H, _stream()), "mmf_gather_rows_f32")
+
+
+# --------------------------------------------------------------------------------------------
 # M4C kernels (mmf_amd/csrc/m4c_ops.hip)
 # --------------------------------------------------------------------------------------------
 def l2norm_rows_fwd(x, ldx, y, ldy, inv_norm, rows, D, eps=1e-12):

@@ -404,9 +404,10 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_multi_kernel(LnReduceArgs 
 // embeddings
 // ------------------------------------------------------------------------------------------------
 extern __device__ int g_index_error;
+template <typename OutT>   // bf16 (throughput path) or float (fp32-accurate path, fp32_path.hip)
 __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                           const float* __restrict__ word, const float* __restrict__ pos,
-                                                          const float* __restrict__ type, bf16* __restrict__ y, int B, int T,
+                                                          const float* __restrict__ type, OutT* __restrict__ y, int B, int T,
                                                           int S, int H, int row0, int pos0, int V, int NT) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     const int b = r / T, t = r - b * T;
     const int64_t id = ids[r];
     const int64_t sg = seg ? seg[r] : 0;
-    bf16* yr0 = y + ((size_t)b * S + row0 + t) * H;
+    OutT* yr0 = y + ((size_t)b * S + row0 + t) * H;
     if ((V > 0 && (id < 0 || id >= V)) || (NT > 0 && (sg < 0 || sg >= NT))) {      // out of the table: zero row + error flag
         if (lane == 0) atomicOr(&g_index_error, 1);
         for (int col = lane * 4; col < H; col += 256) store4(yr0 + col, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     const float* w = word + (size_t)id * H;
     const float* p = pos + (size_t)(t + pos0) * H;
     const float* ty = type + (size_t)sg * H;
-    bf16* yr = y + ((size_t)b * S + row0 + t) * H;
+    OutT* yr = y + ((size_t)b * S + row0 + t) * H;
     for (int col = lane * 4; col < H; col += 256) {
         const f32x4 a = load4(w + col), c = load4(p + col), d = load4(ty + col);
         // same association order as embeddings.py:344 (words + position) + token_type
@@ -567,8 +568,9 @@ __global__ __launch_bounds__(256) void scatter_add_few_reduce_kernel(const float
     out[(size_t)k * H + c] += s;
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ x, const int64_t* __restrict__ index,
-                                                           bf16* __restrict__ out, int B, int S, int H, DropoutCfg drop,
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, const int64_t* __restrict__ index,
+                                                           T* __restrict__ out, int B, int S, int H, DropoutCfg drop,
                                                            int scatter) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1108,8 +1110,19 @@ int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word
     MMF_CHECK_ARG(ids && word && pos && type && y, "embed_text_fwd: null operand");
     MMF_CHECK_ARG(B > 0 && T > 0 && row0 >= 0 && S >= row0 + T && pos0 >= 0 && (H % 4) == 0, "embed_text_fwd: bad shape");
     MMF_CHECK_ARG(P <= 0 || pos0 + T <= P, "embed_text_fwd: sequence longer than the position table (max_position_embeddings)");
-    hipLaunchKernelGGL(embed_text_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
+    hipLaunchKernelGGL(embed_text_kernel<bf16>, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
                        (bf16*)y, B, T, S, H, row0, pos0, V, NT);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_embed_text_f32_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, float* y,
+                           int B, int T, int S, int H, int row0, int pos0, int V, int P, int NT, void* stream) {
+    MMF_CHECK_ARG(ids && word && pos && type && y, "embed_text_f32_fwd: null operand");
+    MMF_CHECK_ARG(B > 0 && T > 0 && row0 >= 0 && S >= row0 + T && pos0 >= 0 && (H % 4) == 0, "embed_text_f32_fwd: bad shape");
+    MMF_CHECK_ARG(P <= 0 || pos0 + T <= P, "embed_text_f32_fwd: sequence longer than the position table (max_position_embeddings)");
+    hipLaunchKernelGGL(embed_text_kernel<float>, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
+                       y, B, T, S, H, row0, pos0, V, NT);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -1171,15 +1184,22 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
 int mmf_gather_rows(const void* x, const int64_t* index, void* out, int B, int S, int H, uint32_t drop_key,
                     uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream) {
     MMF_CHECK_ARG(x && index && out && (H % 4) == 0, "gather_rows: bad operand");
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, index, (bf16*)out,
+    hipLaunchKernelGGL(gather_rows_kernel<bf16>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, index, (bf16*)out,
                        B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed}, 0);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_gather_rows_f32(const float* x, const int64_t* index, float* out, int B, int S, int H, void* stream) {
+    MMF_CHECK_ARG(x && index && out && (H % 4) == 0, "gather_rows_f32: bad operand");
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, index, out,
+                       B, S, H, DropoutCfg{0u, 0u, 1.f, nullptr}, 0);
     MMF_CHECK_LAUNCH();
     return 0;
 }
 int mmf_scatter_rows(const void* dout, const int64_t* index, void* dx, int B, int S, int H, uint32_t drop_key,
                      uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream) {
     MMF_CHECK_ARG(dout && index && dx && (H % 4) == 0, "scatter_rows: bad operand");
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, index,
+    hipLaunchKernelGGL(gather_rows_kernel<bf16>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, index,
                        (bf16*)dx, B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed}, 1);
     MMF_CHECK_LAUNCH();
     return 0;

@@ -1,0 +1,170 @@
+"""The fp32-accurate forward path: the same operators, activations kept in fp32, contractions on the fp32-input matrix cores.
+
+The reference computes in fp32 unless `training.fp16` turns autocast on (mmf/trainers/core/training_loop.py:199), and
+BASELINE.json's north_star states two bounds: 5e-2 for bf16 and 1e-3 for fp32.  The throughput path (mmf_amd/functional.py) is
+bf16 and meets the first; inside
+
+    with mmf_amd.fp32_inference():
+        out = model(sample_list)
+
+every `torch.ops.mmf_amd.*` operator routes to the kernels of mmf_amd/csrc/fp32_path.hip instead (`mmf_gemm_f32` on
+`v_mfma_f32_32x32x2_f32` — exact fp32 products, fp32 accumulation — `mmf_attention_f32_fwd`, `mmf_layernorm_f32_fwd`, fp32
+embedding gathers), reading the fp32 master parameters directly (no bf16 shadows).  The context implies `torch.no_grad()`: it is
+an evaluation / inference / parity-checking mode (forward only), and a module in training mode with a non-zero dropout
+probability is an error, not a silent no-op.  Same models, same parameter names, same `forward(sample_list)`.
+
+Reference operations, as in mmf_amd/functional.py: BertVisioLinguisticEmbeddings.forward (mmf/modules/embeddings.py:423-459),
+BertLayerJit.forward (mmf/modules/hf_layers.py:255-292), BertPooler / BertPredictionHeadTransform / classifier Linear
+(mmf/models/visual_bert.py:146,327-330,389-401).
+"""
+import contextlib
+import math
+
+import torch
+
+from mmf_amd import _native as nat
+
+F32 = torch.float32
+_depth = 0
+
+
+def active():
+    return _depth > 0
+
+
+@contextlib.contextmanager
+def fp32_inference():
+    """Run every mmf_amd operator inside the block on the fp32 kernels (forward only, gradients off)."""
+    global _depth
+    _depth += 1
+    try:
+        with torch.no_grad():
+            yield
+    finally:
+        _depth -= 1
+
+
+def check_no_dropout(p, training):
+    if training and p is not None and p > 0.0:
+        raise RuntimeError("mmf_amd.fp32_inference() is a forward-only evaluation mode: call model.eval() first "
+                           "(a dropout site with p = %g is in training mode)" % p)
+
+
+def _rows(x):
+    """fp32, contiguous, token-major [rows, features] view of an activation or input."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype != F32:
+        raise TypeError("fp32 path: expected a float32 tensor, got %s (activations born outside fp32_inference()?)" % x2.dtype)
+    return x2 if x2.is_contiguous() else x2.contiguous()
+
+
+def _w(p):
+    w = p.detach()
+    return w if w.is_contiguous() else w.contiguous()
+
+
+def _linear(x2, weight, bias, out=None, ldc=None, act=0, resid=None, **kw):
+    M, K = x2.shape
+    N = weight.shape[0]
+    if K % 4:
+        raise ValueError("fp32 path: the contraction length (%d) must be a multiple of 4" % K)
+    if out is None:
+        out = torch.empty(M, N, dtype=F32, device=x2.device)
+        ldc = N
+    nat.gemm_f32(x2, _w(weight), out, M, N, K, K, K, ldc, bias=None if bias is None else _w(bias), act=act, resid=resid,
+                 ldr=0 if resid is None else resid.stride(0), **kw)
+    return out
+
+
+def layer_norm(x, gamma, beta, eps):
+    x2 = _rows(x)
+    M, H = x2.shape
+    y = torch.empty(M, H, dtype=F32, device=x2.device)
+    nat.layernorm_f32_fwd(x2, _w(gamma), _w(beta), y, M, H, eps)
+    return y.view(x.shape)
+
+
+def linear(x, weight, bias):
+    return _linear(_rows(x), weight, bias).view(*x.shape[:-1], weight.shape[0])
+
+
+def dense_gelu(x, weight, bias):
+    return _linear(_rows(x), weight, bias, act=1).view(*x.shape[:-1], weight.shape[0])
+
+
+def linear_tanh(x, weight, bias):
+    return _linear(_rows(x), weight, bias, act=3).view(*x.shape[:-1], weight.shape[0])
+
+
+def gather_rows(x, index):
+    B, S, H = x.shape
+    out = torch.empty(B, H, dtype=F32, device=x.device)
+    nat.gather_rows_f32(_rows(x), index.contiguous().long(), out, B, S, H)
+    return out
+
+
+def pair_halves(x):
+    """nlvr2 pairing [2B, H] -> [B, 2H] = cat(x[:B], x[B:], dim=1) (visual_bert.py:369-374): two strided row copies by the row-copy
+    kernel (fp32 rows moved as pairs of 16-bit words)."""
+    x2 = _rows(x)
+    B2, H = x2.shape
+    B = B2 // 2
+    out = torch.empty(B, 2 * H, dtype=F32, device=x2.device)
+    xb = x2.view(torch.bfloat16)                              # [2B, 2H] 16-bit words
+    ob = out.view(torch.bfloat16).view(2 * B, 2 * H)
+    nat.copy_rows(xb, 1, ob, 2, B, 1, 2 * H)                  # first image  -> columns [0, H)
+    nat.copy_rows(xb[B:], 1, ob[1:], 2, B, 1, 2 * H)          # second image -> columns [H, 2H)
+    return out
+
+
+def visio_linguistic_embeddings(input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b,
+                                eps):
+    """embeddings.py:423-459 with image_text_alignment=None: text rows = word + position + type; visual rows = projection(features)
+    + visual type + visual position 0, written by the projection GEMM's epilogue into rows T.. of the joint sequence; LayerNorm."""
+    B, T = input_ids.shape
+    H = word.shape[1]
+    R = 0 if feats is None else feats.shape[1]
+    S = T + R
+    dev = word.device
+    y = torch.empty(B * S, H, dtype=F32, device=dev)
+    nat.embed_text_f32_fwd(input_ids.contiguous(), token_type_ids.contiguous(), _w(word), _w(pos), _w(typ), y, B, T, S, H)
+    if R:
+        D = feats.shape[2]
+        f2 = feats.reshape(B * R, D)
+        f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+        if D % 4:
+            raise ValueError("fp32 path: visual feature width (%d) must be a multiple of 4" % D)
+        nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=_w(typ_vis),
+                     rowidx=vtype.reshape(B * R).contiguous(), rowtab_ld=H, grp=(R, T, T))
+    out = torch.empty(B * S, H, dtype=F32, device=dev)
+    nat.layernorm_f32_fwd(y, _w(ln_w), _w(ln_b), out, B * S, H, eps)
+    return out.view(B, S, H)
+
+
+def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2,
+                      causal_tail=0):
+    """BertLayerJit.forward (hf_layers.py:255-292), eval mode: Q|K|V projections into one [M, 3H] buffer, fused attention,
+    output projection + bias + residual in the GEMM epilogue, LayerNorm, GELU in the up-projection epilogue, down-projection +
+    bias + residual, LayerNorm."""
+    if causal_tail:
+        raise NotImplementedError("fp32 path: the prefix-LM mask (M4C) is not built; key masks only")
+    B, S, H = x.shape
+    if H != heads * 64:
+        raise NotImplementedError("fp32 path: the attention kernel is built for head_dim 64 (hidden %d, heads %d)" % (H, heads))
+    x2 = _rows(x)
+    M = B * S
+    dev = x2.device
+    qkv = torch.empty(M, 3 * H, dtype=F32, device=dev)
+    for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+        _linear(x2, w, b, out=qkv[:, i * H:], ldc=3 * H)
+    ctx = torch.empty(M, H, dtype=F32, device=dev)
+    mask = None if mask_add is None else mask_add.reshape(B, S).contiguous()
+    nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, B, heads, S, S, 1.0 / math.sqrt(64.0))
+    y1 = _linear(ctx, wo, bo, resid=x2)
+    a_out = torch.empty(M, H, dtype=F32, device=dev)
+    nat.layernorm_f32_fwd(y1, _w(ln1_w), _w(ln1_b), a_out, M, H, eps1)
+    hh = _linear(a_out, w1, b1, act=1)
+    y2 = _linear(hh, w2, b2, resid=a_out)
+    out = torch.empty(M, H, dtype=F32, device=dev)
+    nat.layernorm_f32_fwd(y2, _w(ln2_w), _w(ln2_b), out, M, H, eps2)
+    return out.view(B, S, H)

@@ -24,11 +24,15 @@ Q|K|V views) are looked up inside (mmf_amd.functional.ShadowCache), dropout keys
     torch.ops.mmf_amd.linear_tanh         HF BertPooler                                 visual_bert.py:146
     torch.ops.mmf_amd.dropout             nn.Dropout                                    visual_bert.py:400
     torch.ops.mmf_amd.pair_halves         nlvr2 pooled-output pairing                   visual_bert.py:369-374
+
+Inside `with mmf_amd.fp32_inference():` every operator above routes to the fp32-accurate forward kernels instead
+(mmf_amd/fp32_path.py: fp32 activations, fp32-input MFMA; north_star's 1e-3 bound) — same schemas, same modules.
 """
 from typing import Optional
 
 import torch
 
+from mmf_amd import fp32_path as F32P
 from mmf_amd import functional as Fn
 
 LIB = torch.library.Library("mmf_amd", "DEF")
@@ -67,6 +71,10 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, vi
                                 typ_vis, pos_vis, proj_w, proj_b, eps, p, training, pad_idx):
     if visual_embeddings is None or visual_embeddings_type is None:
         visual_embeddings = visual_embeddings_type = None
+    if F32P.active():
+        F32P.check_no_dropout(p, training)
+        return F32P.visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ,
+                                                ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps)
     w16 = Fn.shadows.get(proj_w) if visual_embeddings is not None else None
     return Fn.VisioLinguisticEmbeddingsFn.apply(
         input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w,
@@ -78,6 +86,11 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, vi
      "int heads, float eps1, float eps2, float p_attn, float p_hid1, float p_hid2, bool training, int causal_tail) -> Tensor")
 def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2,
                       p_attn, p_hid1, p_hid2, training, causal_tail):
+    if F32P.active():
+        for p in (p_attn, p_hid1, p_hid2):
+            F32P.check_no_dropout(p, training)
+        return F32P.transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads,
+                                      eps1, eps2, causal_tail)
     wqkv16 = Fn.shadows.get(wq, wk, wv)
     bqkv = Fn.shadows.get(bq, bk, bv, dtype=torch.float32)
     mask = mask_add
@@ -91,31 +104,45 @@ def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w
 
 @_op("linear(Tensor x, Tensor weight, Tensor? bias, bool out_f32) -> Tensor")
 def linear(x, weight, bias, out_f32):
+    if F32P.active():
+        return F32P.linear(x, weight, bias)
     return Fn.LinearFn.apply(x, weight, bias, Fn.shadows.get(weight), out_f32)
 
 
 @_op("layer_norm(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor")
 def layer_norm(x, weight, bias, eps):
+    if F32P.active():
+        return F32P.layer_norm(x, weight, bias, eps)
     return Fn.LayerNormFn.apply(x, weight, bias, eps)
 
 
 @_op("dense_gelu(Tensor x, Tensor weight, Tensor bias) -> Tensor")
 def dense_gelu(x, weight, bias):
+    if F32P.active():
+        return F32P.dense_gelu(x, weight, bias)
     return Fn.DenseGeluFn.apply(x, weight, bias, Fn.shadows.get(weight))
 
 
 @_op("linear_tanh(Tensor x, Tensor weight, Tensor bias) -> Tensor")
 def linear_tanh(x, weight, bias):
+    if F32P.active():
+        return F32P.linear_tanh(x, weight, bias)
     return Fn.LinearTanhFn.apply(x, weight, bias, Fn.shadows.get(weight))
 
 
 @_op("gather_rows(Tensor x, Tensor index, float p, bool training) -> Tensor")
 def gather_rows(x, index, p, training):
+    if F32P.active():
+        F32P.check_no_dropout(p, training)
+        return F32P.gather_rows(x, index)
     return Fn.GatherRowsFn.apply(x, index, Fn.make_drop(p, training))
 
 
 @_op("dropout(Tensor x, float p, bool training) -> Tensor")
 def dropout(x, p, training):
+    if F32P.active():
+        F32P.check_no_dropout(p, training)
+        return x
     drop = Fn.make_drop(p, training)
     if not drop[1]:
         return x
@@ -124,6 +151,8 @@ def dropout(x, p, training):
 
 @_op("pair_halves(Tensor x) -> Tensor")
 def pair_halves(x):
+    if F32P.active():
+        return F32P.pair_halves(x)
     return Fn.PairHalvesFn.apply(x)
 
 

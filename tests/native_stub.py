@@ -90,6 +90,53 @@ def _attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk
     calls[-1] = ("attention_bwd", B, heads, Sq, Sk, causal_tail)
 
 
+def _gemm_f32(A, B, C_out, M, Nn, K, lda, ldb, ldc, bias=None, coladd=None, rowtab=None, rowidx=None, rowtab_ld=0, act=0, resid=None,
+              ldr=0, grp=(0, 0, 0)):
+    for t in (A, B, C_out, resid, bias, coladd, rowtab):
+        assert t is None or t.dtype == torch.float32
+    assert K % 4 == 0 and lda % 4 == 0 and ldb % 4 == 0 and lda >= K and ldb >= K and ldc >= Nn and act in (0, 1, 3)
+    assert A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+    _need(A, M, lda, K, "gemm_f32 A"); _need(B, Nn, ldb, K, "gemm_f32 B")
+    rows_out = M if grp[0] == 0 else (M - 1) + ((M - 1) // grp[0]) * grp[1] + grp[2] + 1
+    _need(C_out, rows_out, ldc, Nn, "gemm_f32 C")
+    for v in (bias, coladd):
+        assert v is None or v.numel() >= Nn
+    if rowtab is not None:
+        assert rowidx.dtype == torch.int64 and rowidx.numel() >= M and rowtab_ld >= Nn
+        assert int(rowidx.min()) >= 0 and int(rowidx.max()) < rowtab.shape[0]
+    if resid is not None:
+        assert ldr >= Nn
+        _need(resid, M, ldr, Nn, "gemm_f32 resid")
+    calls.append(("gemm_f32", M, Nn, K))
+
+
+def _attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64):
+    assert head_dim == 64 and Sk <= 256
+    for t in (q, k, v, ctx):
+        assert t.dtype == torch.float32
+    _need(q, B * Sq, ldq, heads * 64, "attention_f32 q"); _need(k, B * Sk, ldk, heads * 64, "attention_f32 k")
+    _need(v, B * Sk, ldv, heads * 64, "attention_f32 v"); _need(ctx, B * Sq, ldo, heads * 64, "attention_f32 ctx")
+    assert mask is None or (mask.dtype == torch.float32 and mask.numel() >= B * Sk)
+    calls.append(("attention_f32_fwd", B, heads, Sq, Sk))
+
+
+def _layernorm_f32_fwd(x, gamma, beta, y, rows, H, eps):
+    assert H % 4 == 0 and H <= 2048 and gamma.numel() == H == beta.numel()
+    _need(x, rows, H, H, "layernorm_f32 x"); _need(y, rows, H, H, "layernorm_f32 y")
+    calls.append(("layernorm_f32_fwd", rows, H))
+
+
+def _embed_text_f32(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
+    assert y.dtype == torch.float32 and ids.numel() == B * T and pos0 + T <= pos.shape[0]
+    assert int(ids.max()) < word.shape[0] and int(seg.max()) < typ.shape[0]
+    _need(y, (B - 1) * S + row0 + T, H, H, "embed_text_f32 y")
+
+
+def _gather_rows_f32(x, index, out, B, S, H):
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and index.numel() == B
+    _need(x, B * S, H, H, "gather_rows_f32 x"); _need(out, B, H, H, "gather_rows_f32 out")
+
+
 def _copy_rows(src, src_bstride, dst, dst_bstride, nb, rpb, H):
     assert H % 8 == 0
     _need(src, (nb - 1) * src_bstride + rpb, H, H, "copy_rows src"); _need(dst, (nb - 1) * dst_bstride + rpb, H, H, "copy_rows dst")
@@ -142,7 +189,8 @@ def _bce_rowmask_bwd(scores, targets, w, count, gloss, d, rows, Nn):
     assert d.numel() == rows * Nn and gloss.numel() == 1
 
 
-_CHECKED = {"gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
+_CHECKED = {"gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
+            "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,
             "bce_rowmask_fwd": _bce_rowmask_fwd, "bce_rowmask_bwd": _bce_rowmask_bwd}

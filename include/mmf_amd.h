@@ -308,6 +308,18 @@ int mmf_cross_entropy_fwd(const float* logits, const int64_t* labels, float* los
 int mmf_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* count, const float* gloss,
                           float* dlogits, int B, int C, int ignore_index, void* stream);
 
+/* Vocabulary-sized softmax cross-entropy — the masked-LM loss of VisualBERTForPretraining (mmf/models/visual_bert.py:215,270-277:
+ * nn.CrossEntropyLoss(ignore_index=-1) over the [B * (T + R), vocab] prediction scores).  logits fp32 [R, C] with row stride ld;
+ * forward writes lse[r] (log-sum-exp of row r; 0 for ignored rows), rowloss[r], loss[0] = mean over the counted rows (NaN when
+ * none counts, like torch; the reference's own test asserts that, tests/models/test_visual_bert.py:71-98) and count[0];
+ * backward writes d = gloss / count * (softmax - onehot) as bf16 [R, ldd] (ldd % 8 == 0, pad columns and ignored rows zero):
+ * the ready-made operand of the decoder's input- and weight-gradient GEMMs.  A label outside [0, C) other than ignore_index
+ * is skipped and raises the index-error flag (mmf_amd_take_index_error), where torch raises. */
+int mmf_vocab_cross_entropy_fwd(const float* logits, int ld, const int64_t* labels, float* lse, float* rowloss, float* loss, float* count,
+                                int R, int C, int ignore_index, void* stream);
+int mmf_vocab_cross_entropy_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* count, const float* gloss,
+                                void* dlogits, int ldd, int R, int C, int ignore_index, void* stream);
+
 /* ---- M4C (mmf/models/m4c.py) -------------------------------------------------------------------
  * F.normalize(x, dim=-1) of the appearance / FastText / PHOC features (m4c.py:195,212,217,223): y[r, :D] = x[r, :D] /
  * max(||x[r, :D]||_2, eps), written as bf16 at row stride ldy — `y` may point at a column offset inside the wider

@@ -533,6 +533,24 @@ def cross_entropy_bwd(logits, labels, count, gloss, dlogits, B, Cn, ignore_index
            "mmf_cross_entropy_bwd")
 
 
+def vocab_cross_entropy_fwd(logits, labels, lse, rowloss, loss, count, R, Cn, ignore_index=-1):
+    """Masked-LM cross-entropy over [R, Cn] fp32 logits (contiguous rows): per-row log-sum-exp / loss, mean loss, count."""
+    for t, n in ((logits, "logits"), (lse, "lse"), (rowloss, "rowloss"), (loss, "loss"), (count, "count")):
+        _req(t, torch.float32, n)
+    _req(labels, torch.int64, "labels")
+    _check(lib().mmf_vocab_cross_entropy_fwd(_p(logits), logits.stride(0), _p(labels), _p(lse), _p(rowloss), _p(loss), _p(count), R, Cn,
+                                             ignore_index, _stream()), "mmf_vocab_cross_entropy_fwd")
+
+
+def vocab_cross_entropy_bwd(logits, labels, lse, count, gloss, dlogits, ldd, R, Cn, ignore_index=-1):
+    """dlogits: bf16 [R, ldd], ldd = round_up(Cn, 8): the zero-padded GEMM operand."""
+    for t, n in ((logits, "logits"), (lse, "lse"), (count, "count"), (gloss, "gloss")):
+        _req(t, torch.float32, n)
+    _req(labels, torch.int64, "labels"); _req(dlogits, torch.bfloat16, "dlogits")
+    _check(lib().mmf_vocab_cross_entropy_bwd(_p(logits), logits.stride(0), _p(labels), _p(lse), _p(count), _p(gloss), _p(dlogits), ldd, R, Cn,
+                                             ignore_index, _stream()), "mmf_vocab_cross_entropy_bwd")
+
+
 # --------------------------------------------------------------------------------------------
 # fp32-accurate forward path (mmf_amd/csrc/fp32_path.hip)
 # --------------------------------------------------------------------------------------------

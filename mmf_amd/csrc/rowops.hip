@@ -788,6 +788,94 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------
+// vocabulary-sized softmax cross-entropy: the masked-LM loss of VisualBERTForPretraining (mmf/models/visual_bert.py:215,
+// 270-277: nn.CrossEntropyLoss(ignore_index=-1) over [B * S, vocab] logits).  One workgroup per row; rows whose label is
+// ignored (the visual positions and ~85 % of the text positions) cost one label read.  Forward keeps the row's log-sum-exp so
+// that backward writes the gradient in one pass, directly as the zero-padded bf16 operand of the decoder's dgrad / wgrad GEMMs.
+// ------------------------------------------------------------------------------------------------
+DEVI float block_max256(float v, float* sh) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return r;
+}
+DEVI float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+DEVI bool ce_label_counts(int64_t y, int C, int ignore_index) {
+    if (y == ignore_index) return false;
+    if (y < 0 || y >= C) { flag_index_error(); return false; }   // torch raises for a target outside [0, C): flag it
+    return true;
+}
+__global__ __launch_bounds__(256) void vocab_ce_fwd_kernel(const float* __restrict__ x, int ld, const int64_t* __restrict__ lab,
+                                                            float* __restrict__ lse, float* __restrict__ rowloss, int C,
+                                                            int ignore_index) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x;
+    const int64_t y = lab[r];
+    if (y == ignore_index || y < 0 || y >= C) {      // uniform over the workgroup
+        if (threadIdx.x == 0) { ce_label_counts(y, C, ignore_index); lse[r] = 0.f; rowloss[r] = 0.f; }
+        return;
+    }
+    const float* xr = x + (size_t)r * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, xr[c]);
+    mx = block_max256(mx, sh);
+    float z = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) z += expf(xr[c] - mx);
+    z = block_sum256(z, sh);
+    if (threadIdx.x == 0) {
+        const float l = mx + logf(z);
+        lse[r] = l;
+        rowloss[r] = l - xr[y];
+    }
+}
+// loss = sum of the counted rows' losses / their number, in a fixed order (deterministic); 0 / 0 = NaN when every label is
+// ignored, like torch (and as tests/models/test_visual_bert.py:71-98 of the reference asserts)
+__global__ __launch_bounds__(256) void vocab_ce_finalize_kernel(const float* __restrict__ rowloss, const int64_t* __restrict__ lab,
+                                                                 float* __restrict__ loss, float* __restrict__ count, int R, int C,
+                                                                 int ignore_index) {
+    __shared__ float sh[4];
+    float s = 0.f, n = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const int64_t y = lab[r];
+        if (y != ignore_index && y >= 0 && y < C) { s += rowloss[r]; n += 1.f; }
+    }
+    s = block_sum256(s, sh);
+    n = block_sum256(n, sh);
+    if (threadIdx.x == 0) { loss[0] = s / n; count[0] = n; }
+}
+// d[r][c] = gloss / count * (softmax(x[r])[c] - [c == y_r]) for counted rows, 0 elsewhere (ignored rows, pad columns C..ldd)
+__global__ __launch_bounds__(256) void vocab_ce_bwd_kernel(const float* __restrict__ x, int ld, const int64_t* __restrict__ lab,
+                                                            const float* __restrict__ lse, const float* __restrict__ count,
+                                                            const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int C,
+                                                            int ignore_index) {
+    const int r = blockIdx.y;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= ldd) return;
+    const int64_t y = lab[r];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y != ignore_index && y >= 0 && y < C) {
+        const float g = (gloss ? gloss[0] : 1.f) / count[0];
+        const float l = lse[r];
+        const float* xr = x + (size_t)r * ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            if (c < C) v[e] = g * (expf(xr[c] - l) - (c == (int)y ? 1.f : 0.f));
+        }
+    }
+    store4(d + (size_t)r * ldd + c0, v);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused AdamW over a flat arena
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1309,6 +1397,25 @@ int mmf_bce_logits_bwd(const float* scores, const float* targets, const float* g
     const int64_t n = (int64_t)B * ldd;
     hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, targets, gloss,
                        (bf16*)dscores, ldd, B, N);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_vocab_cross_entropy_fwd(const float* logits, int ld, const int64_t* labels, float* lse, float* rowloss, float* loss, float* count,
+                                int R, int C, int ignore_index, void* stream) {
+    MMF_CHECK_ARG(logits && labels && lse && rowloss && loss && count && R > 0 && C > 0 && ld >= C, "vocab_cross_entropy_fwd: bad operand");
+    hipLaunchKernelGGL(vocab_ce_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, lse, rowloss, C, ignore_index);
+    hipLaunchKernelGGL(vocab_ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rowloss, labels, loss, count, R, C, ignore_index);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_vocab_cross_entropy_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* count, const float* gloss,
+                                void* dlogits, int ldd, int R, int C, int ignore_index, void* stream) {
+    MMF_CHECK_ARG(logits && labels && lse && count && dlogits && R > 0 && C > 0 && ld >= C, "vocab_cross_entropy_bwd: bad operand");
+    MMF_CHECK_ARG(ldd >= C && (ldd % 8) == 0, "vocab_cross_entropy_bwd: ldd must be a multiple of 8 covering C (the GEMM operand's leading dimension)");
+    MMF_CHECK_ARG(R <= 65535, "vocab_cross_entropy_bwd: more than 65535 rows in one launch");
+    hipLaunchKernelGGL(vocab_ce_bwd_kernel, dim3((ldd / 4 + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, lse, count,
+                       gloss, (bf16*)dlogits, ldd, C, ignore_index);
     MMF_CHECK_LAUNCH();
     return 0;
 }

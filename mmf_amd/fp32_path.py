@@ -168,3 +168,19 @@ def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w
     out = torch.empty(M, H, dtype=F32, device=dev)
     nat.layernorm_f32_fwd(y2, _w(ln2_w), _w(ln2_b), out, M, H, eps2)
     return out.view(B, S, H)
+
+
+def masked_lm_head(x, weight, bias, labels, ignore_index):
+    """Decoder tied to the word embeddings + CrossEntropyLoss(ignore_index) (visual_bert.py:267-277), forward only:
+    (loss, logits [B, S, vocab])."""
+    x2 = _rows(x)
+    M = x2.shape[0]
+    N = weight.shape[0]
+    logits = _linear(x2, weight, bias)
+    lab = labels.reshape(M).contiguous()
+    lse = torch.empty(M, dtype=F32, device=x2.device)
+    rowloss = torch.empty(M, dtype=F32, device=x2.device)
+    loss = torch.empty(1, dtype=F32, device=x2.device)
+    count = torch.empty(1, dtype=F32, device=x2.device)
+    nat.vocab_cross_entropy_fwd(logits, lab, lse, rowloss, loss, count, M, N, ignore_index)
+    return loss[0], logits.view(*x.shape[:-1], N)

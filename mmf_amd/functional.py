@@ -18,6 +18,7 @@ Reference ops replaced (paths relative to the reference root):
   VisioLinguisticEmbeddingsFn  BertVisioLinguisticEmbeddings.forward       (embeddings.py:423-459)
   GatherRowsFn              torch.gather + Dropout of the `vqa` pooler     (visual_bert.py:389-400)
   LogitBCEFn                LogitBinaryCrossEntropy                        (losses.py:246-251)
+  MaskedLMHeadFn            tied decoder + CrossEntropyLoss(ignore_index=-1) of VisualBERTForPretraining  (visual_bert.py:267-277)
 """
 import contextlib
 import math
@@ -1023,6 +1024,48 @@ class CrossEntropyFn(torch.autograd.Function):
         d = torch.empty(B, Cn, dtype=F32, device=s.device)
         nat.cross_entropy_bwd(s, t, count, g.float().reshape(1).contiguous(), d, B, Cn, ctx.ignore_index)
         return d, None, None
+
+
+class MaskedLMHeadFn(torch.autograd.Function):
+    """The decoder + loss of VisualBERTForPretraining (mmf/models/visual_bert.py:267-277): prediction scores = h W_word^T + b over every
+    position of the joint sequence (HF BertLMPredictionHead.decoder, weight tied to the word embeddings, :227-235), then
+    nn.CrossEntropyLoss(ignore_index) over [B * S, vocab].  Returns (loss, logits [B, S, vocab] fp32).
+
+    ONE autograd node so that backward never materialises an fp32 [B * S, vocab] gradient: the loss kernel keeps each row's
+    log-sum-exp and the backward kernel writes gloss / count * (softmax - onehot) straight into the zero-padded bf16 operand
+    of the decoder's input- and weight-gradient GEMMs (ignored rows — the visual positions and ~85 % of the text — are zeros).
+    `logits` is returned for the output dict (as the reference does) and marked non-differentiable: only the loss carries
+    gradient, which is all MMF's trainer ever differentiates."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, labels, ignore_index):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        N = weight.shape[0]
+        dev = x2.device
+        logits = torch.empty(M, N, dtype=F32, device=dev)
+        nat.gemm(x2, w16, logits, M, N, K, K, K, N, bias=bias.detach())
+        lab = labels.reshape(M).contiguous()
+        lse = torch.empty(M, dtype=F32, device=dev)
+        rowloss = torch.empty(M, dtype=F32, device=dev)
+        loss = torch.empty(1, dtype=F32, device=dev)
+        count = torch.empty(1, dtype=F32, device=dev)
+        nat.vocab_cross_entropy_fwd(logits, lab, lse, rowloss, loss, count, M, N, ignore_index)
+        ctx.save_for_backward(x2, w16, logits, lab, lse, count)
+        ctx.meta = (M, N, K, x.shape, ignore_index)
+        out = logits.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(out)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        x2, w16, logits, lab, lse, count = ctx.saved_tensors
+        M, N, K, xshape, ignore_index = ctx.meta
+        ldd = _pad8(N)
+        d = torch.empty(M, ldd, dtype=BF16, device=x2.device)
+        nat.vocab_cross_entropy_bwd(logits, lab, lse, count, gloss.float().reshape(1).contiguous(), d, ldd, M, N, ignore_index)
+        dx, dw, db = _linear_bwd(d, ldd, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
+        return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """VisualBERT behind MMF's model API, running on the gfx950 kernels.
 
-Mirrors mmf/models/visual_bert.py: `VisualBERTBase` (:43-157), `VisualBERTForClassification`
-(:284-404) and the registered `VisualBERT(BaseModel)` (:407-601) — same constructor arguments, same
+Mirrors mmf/models/visual_bert.py: `VisualBERTBase` (:43-157), `VisualBERTForPretraining` (:160-281),
+`VisualBERTForClassification` (:284-404) and the registered `VisualBERT(BaseModel)` (:407-601) — same constructor arguments, same
 `forward(sample_list) -> {"scores": [B, num_labels]}` contract, same parameter names/shapes (MMF zoo
 checkpoints load unmodified: `model.bert.encoder.layer.3.attention.self.query.weight` ...).
 
@@ -87,6 +87,85 @@ class VisualBERTBase(nn.Module):
         return sequence_output, pooled_output, hidden
 
 
+class BertLMPredictionHead(nn.Module):
+    """HF BertLMPredictionHead as pinned by the reference (transformers <= 4.10.1): transform, a bias-free decoder whose
+    `bias` attribute IS `self.bias` (one tensor under the two state-dict keys `predictions.bias` and `predictions.decoder.bias`)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        self.decoder.bias = self.bias
+
+
+class BertPreTrainingHeads(nn.Module):
+    """HF BertPreTrainingHeads: masked-LM head + the next-sentence classifier (whose score the reference computes and never
+    uses, visual_bert.py:267-269; its parameters exist for checkpoint compatibility and receive no gradient, as there)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+        self.seq_relationship = Linear(config.hidden_size, 2)
+
+
+class VisualBERTForPretraining(nn.Module):
+    """visual_bert.py:160-281: masked-language-model pretraining over the joint text + region sequence."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.output_attentions = self.config.output_attentions
+        self.output_hidden_states = self.config.output_hidden_states
+        self.bert_model_name = self.config.get("bert_model_name", None)
+        self.bert_config = BertConfig.from_dict(to_container(self.config))
+        # (offline: same architecture as `bert_model_name`, weights arrive via load_state_dict — see VisualBERTForClassification)
+        # The pooled output feeds only `cls.seq_relationship`, whose score is dropped (:267-269): the pooler runs only when
+        # `output_hidden_states` asks for `pooled_output` in the output dict.
+        self.bert = VisualBERTBase(
+            self.bert_config, visual_embedding_dim=self.config.visual_embedding_dim,
+            embedding_strategy=self.config.embedding_strategy, bypass_transformer=self.config.bypass_transformer,
+            output_attentions=self.config.output_attentions, output_hidden_states=self.config.output_hidden_states,
+            skip_pooler=not self.config.output_hidden_states)
+        self.vocab_size = self.bert.config.vocab_size
+        self.cls = BertPreTrainingHeads(self.bert.config)
+        self.ignore_index = -1                      # nn.CrossEntropyLoss(ignore_index=-1), :215
+        self.init_weights()
+
+    def init_weights(self):
+        if self.config.get("random_initialize", False) is False:
+            if self.bert_model_name is None:
+                self.bert.init_weights()
+            self.cls.apply(self.bert._init_weights)
+            self.tie_weights()
+
+    def tie_weights(self):
+        """:227-235 — the decoder shares the word-embedding Parameter (no clone: this module is not exported to TorchScript,
+        the reference refuses the pretraining head in script mode, :597-598)."""
+        self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+
+    def forward(self, input_ids: Tensor, input_mask: Tensor, attention_mask: Optional[Tensor] = None,
+                token_type_ids: Optional[Tensor] = None, visual_embeddings: Optional[Tensor] = None,
+                visual_embeddings_type: Optional[Tensor] = None, image_text_alignment: Optional[Tensor] = None,
+                masked_lm_labels: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
+                                                      visual_embeddings_type, image_text_alignment)
+        output_dict: Dict[str, Tensor] = {}
+        if self.output_hidden_states:
+            output_dict["sequence_output"] = sequence_output
+            if pooled_output is not None:
+                output_dict["pooled_output"] = pooled_output
+        if masked_lm_labels is not None:
+            heads = self.cls.predictions
+            hidden = heads.transform(sequence_output)
+            loss, logits = torch.ops.mmf_amd.masked_lm_head(hidden, heads.decoder.weight, heads.bias, masked_lm_labels,
+                                                            self.ignore_index)
+            output_dict["logits"] = logits
+            output_dict["masked_lm_loss"] = loss
+            output_dict["loss"] = loss
+        return output_dict
+
+
 class VisualBERTForClassification(nn.Module):
     """visual_bert.py:284-404."""
 
@@ -169,8 +248,9 @@ class VisualBERT(BaseModel):
 
     def build(self):
         if self.training_head_type == "pretraining":
-            raise NotImplementedError("VisualBERTForPretraining (visual_bert.py:160-281) is a later milestone")
-        self.model = VisualBERTForClassification(self.config)
+            self.model = VisualBERTForPretraining(self.config)
+        else:
+            self.model = VisualBERTForClassification(self.config)
         if self.config.get("special_visual_initialize", False):
             self.model.bert.embeddings.initialize_visual_from_pretrained()
         if getattr(self.config, "freeze_base", False):
@@ -222,6 +302,8 @@ class VisualBERT(BaseModel):
     def add_custom_params(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
         visual_embeddings = sample_list["visual_embeddings"]
         image_dim = sample_list["image_dim"]
+        if self.training_head_type == "pretraining":
+            sample_list["masked_lm_labels"] = sample_list["lm_label_ids"]          # visual_bert.py:539-541
         image_mask = torch.arange(visual_embeddings.size(-2), device=visual_embeddings.device).expand(
             visual_embeddings.size()[:-1])
         if image_dim.dim() < image_mask.dim():
@@ -232,6 +314,13 @@ class VisualBERT(BaseModel):
     def add_post_flatten_params(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
         sample_list["visual_embeddings_type"] = torch.zeros_like(sample_list["image_mask"])
         sample_list["attention_mask"] = torch.cat((sample_list["input_mask"], sample_list["image_mask"]), dim=-1)
+        if self.training_head_type == "pretraining":
+            # visual_bert.py:455-465: labels over the joint sequence, -1 (ignored) on every visual position
+            lm = sample_list["masked_lm_labels"]
+            assert lm.dim() == 2 and lm.size(-1) == sample_list["input_mask"].size(-1)
+            new_lm_labels = torch.full_like(sample_list["attention_mask"], -1)
+            new_lm_labels[: lm.size(0), : lm.size(1)] = lm
+            sample_list["masked_lm_labels"] = new_lm_labels
         return sample_list
 
     def forward(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
@@ -246,7 +335,14 @@ class VisualBERT(BaseModel):
             image_text_alignment = sample_list["image_text_alignment"]
         if "masked_lm_labels" in sample_list:
             masked_lm_labels = sample_list["masked_lm_labels"]
-        return self.model(
+        output_dict = self.model(
             sample_list["input_ids"], sample_list["input_mask"], sample_list["attention_mask"],
             sample_list["token_type_ids"], sample_list["visual_embeddings"], sample_list["visual_embeddings_type"],
             image_text_alignment, masked_lm_labels)
+        if self.training_head_type == "pretraining":                               # visual_bert.py:588-598
+            if not torch.jit.is_scripting():
+                loss_key = "{}/{}".format(sample_list["dataset_name"], sample_list["dataset_type"])
+                output_dict["losses"] = {loss_key + "/masked_lm_loss": output_dict.pop("masked_lm_loss")}
+            else:
+                raise RuntimeError("Pretraining head can't be used in script mode.")
+        return output_dict

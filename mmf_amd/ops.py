@@ -24,6 +24,7 @@ Q|K|V views) are looked up inside (mmf_amd.functional.ShadowCache), dropout keys
     torch.ops.mmf_amd.linear_tanh         HF BertPooler                                 visual_bert.py:146
     torch.ops.mmf_amd.dropout             nn.Dropout                                    visual_bert.py:400
     torch.ops.mmf_amd.pair_halves         nlvr2 pooled-output pairing                   visual_bert.py:369-374
+    torch.ops.mmf_amd.masked_lm_head      tied decoder + masked-LM CrossEntropyLoss      visual_bert.py:267-277
 
 Inside `with mmf_amd.fp32_inference():` every operator above routes to the fp32-accurate forward kernels instead
 (mmf_amd/fp32_path.py: fp32 activations, fp32-input MFMA; north_star's 1e-3 bound) — same schemas, same modules.
@@ -154,6 +155,13 @@ def pair_halves(x):
     if F32P.active():
         return F32P.pair_halves(x)
     return Fn.PairHalvesFn.apply(x)
+
+
+@_op("masked_lm_head(Tensor x, Tensor weight, Tensor bias, Tensor labels, int ignore_index) -> (Tensor, Tensor)")
+def masked_lm_head(x, weight, bias, labels, ignore_index):
+    if F32P.active():
+        return F32P.masked_lm_head(x, weight, bias, labels, ignore_index)
+    return Fn.MaskedLMHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), labels, ignore_index)
 
 
 def schemas():

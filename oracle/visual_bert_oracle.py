@@ -67,6 +67,18 @@ def parameter_shapes(cfg):
         s[p + "output.LayerNorm.bias"] = (H,)
     s["bert.pooler.dense.weight"] = (H, H)
     s["bert.pooler.dense.bias"] = (H,)
+    if cfg.get("training_head_type", "classification") == "pretraining":
+        # VisualBERTForPretraining (visual_bert.py:160-216): `cls` = HF BertPreTrainingHeads; `cls.predictions.decoder.weight` is the
+        # word-embedding table (tie_weights, :227-235) and `cls.predictions.decoder.bias` is `cls.predictions.bias` (HF <= 4.10
+        # BertLMPredictionHead), so neither is a separate tensor
+        s["cls.predictions.bias"] = (cfg["vocab_size"],)
+        s["cls.predictions.transform.dense.weight"] = (H, H)
+        s["cls.predictions.transform.dense.bias"] = (H,)
+        s["cls.predictions.transform.LayerNorm.weight"] = (H,)
+        s["cls.predictions.transform.LayerNorm.bias"] = (H,)
+        s["cls.seq_relationship.weight"] = (2, H)
+        s["cls.seq_relationship.bias"] = (2,)
+        return s
     if cfg.get("training_head_type", "classification") == "nlvr2":
         H = 2 * H   # visual_bert.py:324-325: the head sees the two images' pooled outputs side by side
     s["classifier.0.dense.weight"] = (H, H)
@@ -252,6 +264,34 @@ def visual_bert_forward(sd, cfg, sample_list, train=False, return_hidden=False):
         out["pooled_output"] = pooled
         out["hidden_states"] = all_hidden
     return out
+
+
+def pretraining_head(sd, cfg, sequence_output):
+    """HF BertPreTrainingHeads.predictions (BertLMPredictionHead: BertPredictionHeadTransform = dense -> gelu -> LayerNorm, then
+    the decoder whose weight IS the word-embedding table, visual_bert.py:227-235 `tie_weights`, plus the output-only bias) as
+    VisualBERTForPretraining.forward applies it at visual_bert.py:267-269.  The next-sentence head (`cls.seq_relationship`) is
+    computed there and never used (no loss term, not returned): left out."""
+    x = F.gelu(F.linear(sequence_output, sd["cls.predictions.transform.dense.weight"], sd["cls.predictions.transform.dense.bias"]))
+    x = layer_norm(x, sd["cls.predictions.transform.LayerNorm.weight"], sd["cls.predictions.transform.LayerNorm.bias"],
+                   cfg["layer_norm_eps"])
+    return F.linear(x, sd["bert.embeddings.word_embeddings.weight"], sd["cls.predictions.bias"])
+
+
+def visual_bert_pretraining_forward(sd, cfg, sample_list, train=False):
+    """VisualBERT.forward with training_head_type == "pretraining" (visual_bert.py:567-601): the masked-LM labels `lm_label_ids`
+    [B, T] (:539-541) are extended with -1 over the visual positions (:455-465), the loss is CrossEntropyLoss(ignore_index=-1)
+    over all B * (T + R) positions (:215, :270-277) and lands in `losses` as "{dataset_name}/{dataset_type}/masked_lm_loss"
+    (:588-596).  All labels -1 gives NaN (mean over nothing), which tests/models/test_visual_bert.py:71-98 asserts."""
+    ids, input_mask, attn_mask, tt, feats, vtype = prepare_inputs(sample_list)
+    seq, pooled, _ = visual_bert_base(sd, cfg, ids, attn_mask, tt, feats, vtype, train)
+    logits = pretraining_head(sd, cfg, seq)
+    lm = sample_list["lm_label_ids"]
+    assert lm.size(-1) == input_mask.size(-1)                      # :456-458
+    labels = torch.ones_like(attn_mask) * -1                       # :459
+    labels[: lm.size(0), : lm.size(1)] = lm                        # :462-464
+    loss = F.cross_entropy(logits.contiguous().view(-1, cfg["vocab_size"]), labels.contiguous().view(-1), ignore_index=-1)
+    key = "%s/%s/masked_lm_loss" % (sample_list.get("dataset_name", "random"), sample_list.get("dataset_type", "test"))
+    return {"logits": logits, "loss": loss, "losses": {key: loss}, "sequence_output": seq, "pooled_output": pooled}
 
 
 def logit_bce(scores, targets):

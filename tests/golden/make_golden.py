@@ -932,12 +932,87 @@ def make_visual_bert_nlvr2():
     print("visual_bert_nlvr2 loss", loss.item(), "scores", rec["scores"], "->", path, os.path.getsize(path), "bytes")
 
 
+def make_visual_bert_pretraining():
+    """VisualBERT with `training_head_type: pretraining` (masked-LM head over the joint sequence, decoder tied to the word
+    embeddings) through the reference's own VisualBERT.forward (visual_bert.py:567-601) and VisualBERTForPretraining (:160-281).
+    Two records: mixed labels (loss, logits, every gradient) and all labels -1 (the reference's own test asserts NaN,
+    tests/models/test_visual_bert.py:71-98)."""
+    c = dict(CASES["small64"], seed=71)
+    cfg = reference_config(c)
+    cfg["training_head_type"] = "pretraining"
+    cfg["losses"] = []
+    model = ref_vb.VisualBERT(cfg)
+    model.build()
+    model.eval()
+    heads = model.model.cls.predictions
+    # transformers<=4.10 BertLMPredictionHead.__init__ (the reference's pin): `self.decoder.bias = self.bias` — one tensor under
+    # two state-dict keys; 5.15 keeps two separate parameters, so tie them the pinned way before loading weights
+    heads.decoder.bias = heads.bias
+    assert heads.decoder.weight is model.model.bert.embeddings.word_embeddings.weight      # tie_weights, visual_bert.py:227-235
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()
+              if not k.endswith("position_ids") and not k.startswith("model.cls.predictions.decoder.")}
+    sd = detweights.state_dict(shapes, c["seed"])
+    full = {k: torch.from_numpy(v) for k, v in sd.items()}
+    full["model.cls.predictions.decoder.weight"] = full["model.bert.embeddings.word_embeddings.weight"]
+    full["model.cls.predictions.decoder.bias"] = full["model.cls.predictions.bias"]
+    missing, unexpected = model.load_state_dict(full, strict=False)
+    assert not unexpected and all(k.endswith("position_ids") for k in missing), (missing, unexpected)
+    inp = make_inputs(c)
+    B, T = c["B"], c["T"]
+    pick = detweights.uniform(B * T, c["seed"] + 301).reshape(B, T) < 0.3
+    pick &= inp["input_mask"] == 1
+    pick[:, 1] = True                                   # every sample has at least one masked position
+    lm = np.where(pick, (detweights.uniform(B * T, c["seed"] + 302) * c["vocab_size"]).astype(np.int64).reshape(B, T), -1)
+
+    def sample(labels):
+        return SampleList(
+            input_ids=torch.from_numpy(inp["input_ids"]), input_mask=torch.from_numpy(inp["input_mask"]),
+            segment_ids=torch.from_numpy(inp["segment_ids"]), image_feature_0=torch.from_numpy(inp["image_feature_0"]),
+            image_info_0=SampleList(max_features=torch.from_numpy(inp["max_features"])),
+            lm_label_ids=torch.from_numpy(labels), dataset_name="coco", dataset_type="train")
+
+    out = model.forward(sample(lm))
+    (key, loss), = out["losses"].items()
+    loss.backward()
+    rec = {"in_" + k: v for k, v in inp.items() if k != "targets"}
+    rec["in_lm_label_ids"] = lm
+    rec["logits"] = out["logits"].detach().numpy()
+    rec["sequence_output"] = out["sequence_output"].detach().numpy()
+    rec["loss"] = np.array(loss.item(), dtype=np.float64)
+    rec["loss_key"] = np.array(key)
+    names, norms, sums = [], [], []
+    for k, p in model.named_parameters():
+        g = p.grad
+        names.append(k)
+        norms.append(0.0 if g is None else float(g.double().norm()))
+        sums.append(0.0 if g is None else float(g.double().sum()))
+        if g is not None and g.numel() <= 4096:
+            rec["grad::" + k] = g.numpy()
+    rec["grad::model.bert.embeddings.word_embeddings.weight"] = model.model.bert.embeddings.word_embeddings.weight.grad.numpy()
+    with torch.no_grad():
+        out2 = model.forward(sample(np.full((B, T), -1, dtype=np.int64)))
+    rec["loss_all_ignored_is_nan"] = np.array(bool(torch.isnan(out2["losses"][key])))
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms)
+    rec["grad_sums"] = np.array(sums)
+    rec["param_names"] = np.array(list(shapes.keys()))
+    rec["param_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
+    rec["state_dict_keys"] = np.array(sorted(k for k in model.state_dict().keys() if not k.endswith("position_ids")))
+    rec["case"] = np.array(repr(c))
+    path = os.path.join(HERE, "visual_bert_pretraining.npz")
+    np.savez_compressed(path, **rec)
+    print("visual_bert_pretraining loss", loss.item(), key, "all-ignored NaN:", bool(rec["loss_all_ignored_is_nan"]), "->", path,
+          os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "nlvr2", "mmbt", "mmft", "vilbert", "uniter", "m4c"]
+    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmft", "vilbert", "uniter", "m4c"]
     if "visual_bert" in which:
         main()
     if "nlvr2" in which:
         make_visual_bert_nlvr2()
+    if "pretraining" in which:
+        make_visual_bert_pretraining()
     if "mmbt" in which:
         make_mmbt()
     if "mmft" in which:

@@ -90,6 +90,19 @@ def install():
     def _old_init_weights(self):
         self.apply(self._init_weights)
     PreTrainedModel.init_weights = _old_init_weights
+    # transformers<=4.10 `PreTrainedModel._tie_or_clone_weights` (removed later; visual_bert.py:232 calls it): without
+    # `config.torchscript` the output embedding SHARES the input embedding's Parameter
+    def _old_tie_or_clone_weights(self, output_embeddings, input_embeddings):
+        if getattr(self.config, "torchscript", False):
+            output_embeddings.weight = nn.Parameter(input_embeddings.weight.clone())
+        else:
+            output_embeddings.weight = input_embeddings.weight
+        if getattr(output_embeddings, "bias", None) is not None:
+            output_embeddings.bias.data = nn.functional.pad(
+                output_embeddings.bias.data, (0, output_embeddings.weight.shape[0] - output_embeddings.bias.shape[0]), "constant", 0)
+        if hasattr(output_embeddings, "out_features") and hasattr(input_embeddings, "num_embeddings"):
+            output_embeddings.out_features = input_embeddings.num_embeddings
+    PreTrainedModel._tie_or_clone_weights = _old_tie_or_clone_weights
     sys.modules["transformers.modeling_bert"] = mb
     _fakepkg("mmf", REF + "/mmf")
     for sub in ["common", "modules", "models", "utils", "datasets", "trainers"]:

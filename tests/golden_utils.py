@@ -162,6 +162,28 @@ def load_nlvr2_case():
     return z, case, cfg, sd, sample
 
 
+def load_pretraining_case():
+    """`visual_bert_pretraining`: VisualBERT with the masked-LM pretraining head (decoder tied to the word embeddings)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "visual_bert_pretraining.npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {k: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}
+    cfg = dict(
+        vocab_size=case["vocab_size"], hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"],
+        num_attention_heads=case["num_attention_heads"], intermediate_size=case["intermediate_size"],
+        max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2, layer_norm_eps=1e-12,
+        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, visual_embedding_dim=case["visual_embedding_dim"],
+        num_labels=case["num_labels"], pooler_strategy="default", training_head_type="pretraining", initializer_range=0.02)
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),
+        "image_info_0": {"max_features": torch.from_numpy(z["in_max_features"])},
+        "lm_label_ids": torch.from_numpy(z["in_lm_label_ids"]), "dataset_name": "coco", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample
+
+
 def load_m4c_case(name="m4c_small64"):
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))

@@ -30,6 +30,17 @@ def build_visual_bert(cfg, sd=None, device="cuda", **over):
     return model.to(device)
 
 
+def build_visual_bert_pretraining(cfg, sd=None, device="cuda", **over):
+    """VisualBERT with the masked-LM pretraining head; `sd` holds the reference's parameters (the tied decoder keys are aliases)."""
+    model = build_model(model_config(cfg, training_head_type="pretraining", pooler_strategy="default", losses=[], **over))
+    if sd is not None:
+        full = {"model." + k: v for k, v in sd.items()}
+        full["model.cls.predictions.decoder.weight"] = full["model.bert.embeddings.word_embeddings.weight"]
+        full["model.cls.predictions.decoder.bias"] = full["model.cls.predictions.bias"]
+        model.load_state_dict(full, strict=True)
+    return model.to(device)
+
+
 def sample_to(sample, device):
     out = {}
     for k, v in sample.items():

@@ -137,6 +137,21 @@ def _gather_rows_f32(x, index, out, B, S, H):
     _need(x, B * S, H, H, "gather_rows_f32 x"); _need(out, B, H, H, "gather_rows_f32 out")
 
 
+def _vocab_ce_fwd(logits, labels, lse, rowloss, loss, count, R, Cn, ignore_index=-1):
+    assert logits.dtype == torch.float32 and logits.stride(0) >= Cn and labels.dtype == torch.int64 and labels.numel() == R
+    _need(logits, R, logits.stride(0), Cn, "vocab_ce logits")
+    assert lse.numel() >= R and rowloss.numel() >= R and loss.numel() == 1 and count.numel() == 1
+    ok = labels[labels != ignore_index]
+    assert ok.numel() == 0 or (int(ok.min()) >= 0 and int(ok.max()) < Cn), "label outside the vocabulary"
+    calls.append(("vocab_cross_entropy_fwd", R, Cn))
+
+
+def _vocab_ce_bwd(logits, labels, lse, count, gloss, dlogits, ldd, R, Cn, ignore_index=-1):
+    assert ldd % 8 == 0 and ldd >= Cn and dlogits.dtype == torch.bfloat16 and gloss.numel() == 1
+    _need(dlogits, R, ldd, ldd, "vocab_ce dlogits")
+    calls.append(("vocab_cross_entropy_bwd", R, Cn))
+
+
 def _copy_rows(src, src_bstride, dst, dst_bstride, nb, rpb, H):
     assert H % 8 == 0
     _need(src, (nb - 1) * src_bstride + rpb, H, H, "copy_rows src"); _need(dst, (nb - 1) * dst_bstride + rpb, H, H, "copy_rows dst")
@@ -189,7 +204,7 @@ def _bce_rowmask_bwd(scores, targets, w, count, gloss, d, rows, Nn):
     assert d.numel() == rows * Nn and gloss.numel() == 1
 
 
-_CHECKED = {"gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
+_CHECKED = {"vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
             "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,

@@ -26,6 +26,11 @@ def _nlvr2():
                                    losses=[dict(type="cross_entropy")]), sample, "model."
 
 
+def _pretraining():
+    z, case, cfg, sd, sample = G.load_pretraining_case()
+    return z, MU.build_visual_bert_pretraining(cfg, sd, device="cpu"), sample, "model."
+
+
 def _mmbt():
     z, case, cfg, sd, sample = G.load_mmbt_case()
     from oracle.mmbt_oracle import SHARED
@@ -53,7 +58,7 @@ def _m4c():
     return z, MU.build_m4c(cfg, sd, device="cpu"), sample, ""
 
 
-CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "mmbt": _mmbt, "mmft": _mmft, "vilbert": _vilbert, "uniter": _uniter,
+CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "mmbt": _mmbt, "mmft": _mmft, "vilbert": _vilbert, "uniter": _uniter,
          "m4c": _m4c}
 
 
@@ -61,15 +66,16 @@ CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "mmbt": _mmbt
 def test_training_step_plumbing(name):
     z, model, sample, prefix = CASES[name]()
     model.train()
-    key = name.split("_nlvr2")[0]
+    key = name.split("_nlvr2")[0].split("_pretraining")[0]
     full = Config(model=key, optimizer=dict(params=dict(lr=5e-5)), model_config={key: model.config})
     opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
     with native_stub.installed() as calls:
         out = model(SampleList(sample))
-        assert out["scores"].dtype == torch.float32 and out["scores"].shape[0] > 0
+        head = out["logits"] if name == "visual_bert_pretraining" else out["scores"]        # the pretraining head returns `logits`
+        assert head.dtype == torch.float32 and head.shape[0] > 0
         assert len(out["losses"]) == 1
         (lkey, loss), = out["losses"].items()
-        assert lkey.startswith("train/") and loss.numel() == 1
+        assert (lkey.startswith("train/") or lkey.endswith("/train/masked_lm_loss")) and loss.numel() == 1
         loss.sum().backward()
         opt.step()
     assert any(c[0] == "gemm" for c in calls) and any(c[0] == "attention_bwd" for c in calls) and any(c[0] == "adamw_multi" for c in calls)

@@ -83,3 +83,36 @@ def test_oracle_nlvr2_head_matches_reference():
         if key.endswith("self.key.bias"):
             continue
         assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+
+
+def test_oracle_pretraining_head_matches_reference():
+    """`training_head_type: pretraining` (visual_bert.py:160-281, 455-465, 588-596): masked-LM logits over the joint sequence through
+    the decoder tied to the word embeddings, CrossEntropyLoss(ignore_index=-1), every gradient (the tied table receives the
+    embedding-gather AND the decoder gradient), NaN when every label is ignored (tests/models/test_visual_bert.py:71-98)."""
+    from tests.golden_utils import load_pretraining_case
+    z, case, cfg, sd, sample = load_pretraining_case()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.visual_bert_pretraining_forward(sd, cfg, sample)
+    np.testing.assert_allclose(out["logits"].detach().numpy(), z["logits"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(out["sequence_output"].detach().numpy(), z["sequence_output"], rtol=1e-5, atol=5e-6)
+    (key, loss), = out["losses"].items()
+    assert key == str(z["loss_key"]) == "coco/train/masked_lm_loss"
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        key = str(gname)[len("model."):]
+        g = sd[key].grad
+        if norm == 0.0:       # pooler and next-sentence head: computed (or not) but outside the loss
+            assert g is None or float(g.abs().max()) == 0.0, key
+            continue
+        if key.endswith("self.key.bias"):
+            continue
+        assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+        full = "grad::model." + key
+        if full in z.files:
+            np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
+    assert bool(z["loss_all_ignored_is_nan"])
+    blank = dict(sample, lm_label_ids=torch.full_like(sample["lm_label_ids"], -1))
+    with torch.no_grad():
+        assert torch.isnan(O.visual_bert_pretraining_forward(sd, cfg, blank)["loss"])

@@ -447,6 +447,9 @@ int mmf_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta,
 int mmf_embed_text_f32_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, float* y,
                            int B, int T, int S, int H, int row0, int pos0, int V, int P, int NT, void* stream);
 int mmf_gather_rows_f32(const float* x, const int64_t* index, float* out, int B, int S, int H, void* stream);
+/* mmf_rows_add_embed with fp32 rows (MMF Transformer per-modality embedding sum, huggingface.py:145-155). */
+int mmf_rows_add_embed_f32(const float* x, const int64_t* seg, const float* pos, const float* type, float* y, int B, int L, int S, int H,
+                           int row0, int pos0, void* stream);
 
 /* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
 int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */

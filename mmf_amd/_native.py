@@ -601,6 +601,12 @@ def embed_text_f32_fwd(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
                                         int(word.shape[0]), int(pos.shape[0]), int(typ.shape[0]), _stream()), "mmf_embed_text_f32_fwd")
 
 
+def rows_add_embed_f32(x, seg, pos, typ, y, B, L, S, H, row0=0, pos0=0):
+    _req(x, torch.float32, "x"); _req(y, torch.float32, "y"); _req(seg, torch.int64, "seg")
+    _req(pos, torch.float32, "pos"); _req(typ, torch.float32, "type")
+    _check(lib().mmf_rows_add_embed_f32(_p(x), _p(seg), _p(pos), _p(typ), _p(y), B, L, S, H, row0, pos0, _stream()), "mmf_rows_add_embed_f32")
+
+
 def gather_rows_f32(x, index, out, B, S, H):
     _req(x, torch.float32, "x"); _req(index, torch.int64, "index"); _req(out, torch.float32, "out")
     _check(lib().mmf_gather_rows_f32(_p(x), _p(index), _p(out), B, S, H, _stream()), "mmf_gather_rows_f32")

@@ -433,17 +433,18 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
 }
 
 // y[b*S + row0 + i] = x[b*L + i] + pos[pos0 + i] + type[seg[b,i]]   (pos / seg may be null)
-__global__ __launch_bounds__(256) void rows_add_embed_kernel(const bf16* __restrict__ x, const int64_t* __restrict__ seg,
+template <typename T>   // bf16 rows (throughput path) or fp32 rows (fp32-accurate path)
+__global__ __launch_bounds__(256) void rows_add_embed_kernel(const T* __restrict__ x, const int64_t* __restrict__ seg,
                                                               const float* __restrict__ pos, const float* __restrict__ type,
-                                                              bf16* __restrict__ y, int B, int L, int S, int H, int row0, int pos0) {
+                                                              T* __restrict__ y, int B, int L, int S, int H, int row0, int pos0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= B * L) return;
     const int b = r / L, i = r - b * L;
-    const bf16* xr = x + (size_t)r * H;
+    const T* xr = x + (size_t)r * H;
     const float* p = pos ? pos + (size_t)(i + pos0) * H : nullptr;
     const float* ty = (type && seg) ? type + (size_t)seg[r] * H : nullptr;
-    bf16* yr = y + ((size_t)b * S + row0 + i) * H;
+    T* yr = y + ((size_t)b * S + row0 + i) * H;
     for (int col = lane * 4; col < H; col += 256) {
         f32x4 v = load4(xr + col);
         if (p) { const f32x4 c = load4(p + col); v += c; }
@@ -1219,8 +1220,17 @@ int mmf_rows_add_embed(const void* x, const int64_t* seg, const float* pos, cons
                        int row0, int pos0, void* stream) {
     MMF_CHECK_ARG(x && y, "rows_add_embed: null operand");
     MMF_CHECK_ARG(B > 0 && L > 0 && row0 >= 0 && S >= row0 + L && pos0 >= 0 && (H % 4) == 0, "rows_add_embed: bad shape");
-    hipLaunchKernelGGL(rows_add_embed_kernel, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, seg, pos, type,
+    hipLaunchKernelGGL(rows_add_embed_kernel<bf16>, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, seg, pos, type,
                        (bf16*)y, B, L, S, H, row0, pos0);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_rows_add_embed_f32(const float* x, const int64_t* seg, const float* pos, const float* type, float* y, int B, int L, int S, int H,
+                           int row0, int pos0, void* stream) {
+    MMF_CHECK_ARG(x && y, "rows_add_embed_f32: null operand");
+    MMF_CHECK_ARG(B > 0 && L > 0 && row0 >= 0 && S >= row0 + L && pos0 >= 0 && (H % 4) == 0, "rows_add_embed_f32: bad shape");
+    hipLaunchKernelGGL(rows_add_embed_kernel<float>, dim3((B * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, seg, pos, type, y, B, L, S,
+                       H, row0, pos0);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -184,3 +184,62 @@ def masked_lm_head(x, weight, bias, labels, ignore_index):
     count = torch.empty(1, dtype=F32, device=x2.device)
     nat.vocab_cross_entropy_fwd(logits, lab, lse, rowloss, loss, count, M, N, ignore_index)
     return loss[0], logits.view(*x.shape[:-1], N)
+
+
+def mmbt_embeddings(feats, input_ids, start_tok, end_tok, text_type_ids, modal_type, word, pos, typ, ln_w, ln_b, proj_w, proj_b, eps):
+    """ModalEmbeddings.forward (mmf/models/mmbt.py:84-129) + the text BertEmbeddings (hf_layers.py:108-135), modal block first
+    (mmbt.py:225), in one fp32 buffer [start token | N projected features | end token | T text]; one LayerNorm pass (the two of
+    the reference share their parameters).  Same layout as functional.MMBTEmbeddingsFn."""
+    B, N, D = feats.shape
+    T = input_ids.shape[1]
+    H = word.shape[1]
+    s0 = 1 if start_tok is not None else 0
+    L = N + s0 + (1 if end_tok is not None else 0)
+    S = L + T
+    dev = word.device
+    y = torch.empty(B * S, H, dtype=F32, device=dev)
+    wd, pd, td = _w(word), _w(pos), _w(typ)
+    if isinstance(modal_type, torch.Tensor):
+        mt = modal_type.detach().reshape(1).to(device=dev, dtype=torch.int64)
+    else:
+        mt = torch.full((1,), int(modal_type), dtype=torch.int64, device=dev)
+    mtype = mt.reshape(1, 1).expand(B, 1).contiguous()
+    if start_tok is not None:
+        nat.embed_text_f32_fwd(start_tok.reshape(B, 1).contiguous(), mtype, wd, pd, td, y, B, 1, S, H, 0, 0)
+    if end_tok is not None:
+        nat.embed_text_f32_fwd(end_tok.reshape(B, 1).contiguous(), mtype, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
+    nat.embed_text_f32_fwd(input_ids.contiguous(), text_type_ids.contiguous(), wd, pd, td, y, B, T, S, H, L, 0)
+    f2 = feats.reshape(B * N, D)
+    f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+    if D % 4:
+        raise ValueError("fp32 path: modal feature width (%d) must be a multiple of 4" % D)
+    posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
+    nat.gemm_f32(f2, _w(proj_w), y, B * N, H, D, D, D, H, bias=_w(proj_b), coladd=td.index_select(0, mt).reshape(H), rowtab=pd,
+                 rowidx=posidx, rowtab_ld=H, grp=(N, S - N, s0))
+    out = torch.empty(B * S, H, dtype=F32, device=dev)
+    nat.layernorm_f32_fwd(y, _w(ln_w), _w(ln_b), out, B * S, H, eps)
+    return out.view(B, S, H)
+
+
+def add_pos_type(x, seg, pos, typ):
+    """total = tok + pos_emb(arange(L)) + token_type_embeddings(segment_ids) (mmf/models/transformers/backends/huggingface.py:147-155)."""
+    B, L, H = x.shape
+    y = torch.empty(B * L, H, dtype=F32, device=x.device)
+    sg = seg.contiguous() if (seg is not None and typ is not None) else None
+    nat.rows_add_embed_f32(_rows(x), sg, None if pos is None else _w(pos), _w(typ) if sg is not None else None, y, B, L, L, H)
+    return y.view(B, L, H)
+
+
+def concat_rows(*xs):
+    """torch.cat(list_embeddings, dim=1) (huggingface.py:159) of fp32 [B, L_m, H] blocks: strided copies by the row-copy kernel
+    (fp32 rows moved as pairs of 16-bit words)."""
+    B, _, H = xs[0].shape
+    lens = [int(x.shape[1]) for x in xs]
+    S = sum(lens)
+    out = torch.empty(B, S, H, dtype=F32, device=xs[0].device)
+    ob = out.view(torch.bfloat16).view(B * S, 2 * H)
+    off = 0
+    for x, L in zip(xs, lens):
+        nat.copy_rows(_rows(x).view(torch.bfloat16), L, ob[off:], S, B, L, 2 * H)
+        off += L
+    return out

@@ -18,6 +18,7 @@ instead of two embedding modules + `torch.cat`; the pooler's tanh lives in the G
 import torch
 from torch import nn
 
+from mmf_amd import fp32_path as F32P
 from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
@@ -86,12 +87,19 @@ class MMBTModel(nn.Module):
                 raise NotImplementedError("per-position modal_token_type_ids: the fused modal block adds ONE type row")
             modal_type = lo
         emb, me = self.transformer.embeddings, self.modal_encoder
-        hidden = Fn.MMBTEmbeddingsFn.apply(
-            input_modal, input_ids, modal_start_tokens, modal_end_tokens, token_type_ids, modal_type,
-            emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
-            emb.LayerNorm.weight, emb.LayerNorm.bias, me.proj_embeddings.weight, me.proj_embeddings.bias,
-            Fn.shadows.get(me.proj_embeddings.weight), emb.LayerNorm.eps, Fn.make_drop(emb.dropout_prob, self.training),
-            emb.word_embeddings.padding_idx)
+        if F32P.active():        # fp32-accurate forward (mmf_amd.fp32_inference()): same buffer layout, fp32 kernels
+            F32P.check_no_dropout(emb.dropout_prob, self.training)
+            hidden = F32P.mmbt_embeddings(
+                input_modal, input_ids, modal_start_tokens, modal_end_tokens, token_type_ids, modal_type,
+                emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+                emb.LayerNorm.weight, emb.LayerNorm.bias, me.proj_embeddings.weight, me.proj_embeddings.bias, emb.LayerNorm.eps)
+        else:
+            hidden = Fn.MMBTEmbeddingsFn.apply(
+                input_modal, input_ids, modal_start_tokens, modal_end_tokens, token_type_ids, modal_type,
+                emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+                emb.LayerNorm.weight, emb.LayerNorm.bias, me.proj_embeddings.weight, me.proj_embeddings.bias,
+                Fn.shadows.get(me.proj_embeddings.weight), emb.LayerNorm.eps, Fn.make_drop(emb.dropout_prob, self.training),
+                emb.word_embeddings.padding_idx)
         S = hidden.shape[1]
         dev = hidden.device
         if attention_mask is None:

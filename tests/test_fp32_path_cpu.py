@@ -52,6 +52,26 @@ def test_nlvr2_head_and_pooler_route_to_the_fp32_kernels():
     assert out["scores"].dtype == torch.float32 and out["scores"].shape == tuple(z["scores"].shape)
 
 
+def test_mmbt_and_mmft_route_to_the_fp32_kernels():
+    from oracle.mmbt_oracle import SHARED
+    from oracle.mmft_oracle import shared
+    z, case, cfg, sd, sample = G.load_mmbt_case()
+    model = MU.build_mmbt(cfg, sd, SHARED, device="cpu")
+    model.eval()
+    with native_stub.installed() as calls, mmf_amd.fp32_inference():
+        out = model(SampleList(sample))
+        assert _names(calls) <= FP32_CALLS, _names(calls) - FP32_CALLS
+    assert out["scores"].dtype == torch.float32 and out["scores"].shape == tuple(z["scores"].shape)
+    z, case, cfg, sd, sample = G.load_mmft_case()
+    model = MU.build_mmft(cfg, sd, shared(cfg), device="cpu")
+    model.eval()
+    with native_stub.installed() as calls, mmf_amd.fp32_inference():
+        out = model(SampleList(sample))
+        assert _names(calls) <= FP32_CALLS | {"rows_add_embed_f32"}, _names(calls) - FP32_CALLS
+        assert any(c[0] == "rows_add_embed_f32" for c in calls)
+    assert out["scores"].dtype == torch.float32 and out["scores"].shape == tuple(z["scores"].shape)
+
+
 def test_training_mode_dropout_is_refused_and_bf16_routing_is_untouched_outside():
     z, case, cfg, sd, sample = G.load_case("small64")
     model = MU.build_visual_bert(cfg, sd, device="cpu")

@@ -213,3 +213,39 @@ def test_fp32_mode_refuses_training_dropout_and_leaves_no_state_behind():
     model.eval()
     a = model(SampleList(sample_to(sample, "cuda")))["scores"]          # the bf16 path still runs, with autograd
     assert a.requires_grad
+
+
+def test_mmbt_golden_within_the_fp32_bound():
+    """BASELINE.json configs[0] (MMBT): modal block + text through the same fp32 encoder, against the real reference's fixture."""
+    from oracle.mmbt_oracle import SHARED
+    from tests.model_utils import build_mmbt
+    z, case, cfg, sd, sample = G.load_mmbt_case()
+    model = build_mmbt(cfg, sd, SHARED)
+    model.eval()
+    with mmf_amd.fp32_inference():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    e = np.abs(out["scores"].cpu().numpy() - z["scores"]).max()
+    (key, loss), = out["losses"].items()
+    e_loss = abs(loss.item() - float(z["loss"])) / abs(float(z["loss"]))
+    _record("golden_mmbt", scores_max_abs=e, loss_rel=e_loss)
+    assert out["scores"].dtype == torch.float32 and e <= TOL_FP32 and e_loss <= TOL_FP32, (e, e_loss)
+
+
+def test_mmft_golden_within_the_fp32_bound():
+    """MMF Transformer (per-modality embeddings: fused text block, Linear -> LayerNorm image tokens + position + type, concat)."""
+    from oracle import mmft_oracle
+    from tests.model_utils import build_mmft
+    z, case, cfg, sd, sample = G.load_mmft_case()
+    model = build_mmft(cfg, sd, mmft_oracle.shared(cfg))
+    model.eval()
+    seq = {}
+    hook = model.backend.register_forward_hook(lambda m, i, o: seq.update(seq=o[0]))
+    with mmf_amd.fp32_inference():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    hook.remove()
+    e = np.abs(out["scores"].cpu().numpy() - z["scores"]).max()
+    e_seq = np.abs(seq["seq"].cpu().numpy() - z["sequence_output"]).max()
+    (key, loss), = out["losses"].items()
+    e_loss = abs(loss.item() - float(z["loss"])) / abs(float(z["loss"]))
+    _record("golden_mmft", scores_max_abs=e, sequence_output_max_abs=e_seq, loss_rel=e_loss)
+    assert seq["seq"].dtype == torch.float32 and e <= TOL_FP32 and e_seq <= TOL_FP32 and e_loss <= TOL_FP32, (e, e_seq, e_loss)

@@ -22,7 +22,8 @@ from mmf_amd import fp32_path as F32P
 from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
-from mmf_amd.modules.hf_layers import BertConfig, BertModelJit, BertPredictionHeadTransform, Linear, init_bert_weights
+from mmf_amd.modules.hf_layers import (
+    BertConfig, BertModelJit, BertPredictionHeadTransform, BertPreTrainingHeads, Linear, init_bert_weights)
 from mmf_amd.utils.configuration import to_container
 from mmf_amd.utils.modeling import get_optimizer_parameters_for_bert
 
@@ -204,6 +205,51 @@ class MMBTBase(nn.Module):
                          token_type_ids=sample_list["segment_ids"], modal_token_type_ids=modal_token_type_ids)
 
 
+class MMBTForPreTraining(nn.Module):
+    """mmbt.py:447-523: masked-language-model pretraining; the text positions are the LAST T rows of the joint sequence
+    (modal block first), `cls` = HF BertPreTrainingHeads with the decoder tied to the word embeddings (:467-476)."""
+
+    def __init__(self, config, *args, **kwargs):
+        super().__init__()
+        self.config = config
+        self.bert = MMBTBase(config, *args, **kwargs)
+        self.encoder_config = self.bert.encoder_config
+        if self.encoder_config.output_attentions or self.encoder_config.output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states (`extras`, mmbt.py:486-490) are not built")
+        # (offline: the architecture of `bert_model_name`; weights arrive through load_state_dict / an MMF checkpoint)
+        self.cls = BertPreTrainingHeads(self.encoder_config)
+        self.cls.apply(lambda m: init_bert_weights(m, self.encoder_config.initializer_range))
+        self.ignore_index = -1                                          # nn.CrossEntropyLoss(ignore_index=-1), :464
+        self.tie_weights()
+
+    def tie_weights(self):
+        self.cls.predictions.decoder.weight = self.bert.mmbt.transformer.embeddings.word_embeddings.weight
+
+    def forward(self, sample_list):
+        module_output = self.bert(sample_list)
+        sequence_output = module_output[0]
+        output = {}
+        loss_key = "{}/{}".format(sample_list["dataset_name"], sample_list["dataset_type"])
+        lm_label_ids = sample_list["lm_label_ids"] if "lm_label_ids" in sample_list else None
+        if lm_label_ids is not None:
+            # :494-506 scores only the last T (text) positions: the same mean as CrossEntropyLoss over ALL positions with the
+            # modal block's labels set to ignore_index, which is what the fused decoder + loss takes
+            B, S = sequence_output.shape[0], sequence_output.shape[1]
+            T = lm_label_ids.size(1)
+            labels = torch.full((B, S), self.ignore_index, dtype=torch.int64, device=lm_label_ids.device)
+            labels[:, S - T:] = lm_label_ids
+            heads = self.cls.predictions
+            hidden = heads.transform(sequence_output)
+            loss, logits = torch.ops.mmf_amd.masked_lm_head(hidden, heads.decoder.weight, heads.bias, labels, self.ignore_index)
+            output["logits"] = logits
+            output["losses"] = {loss_key + "/masked_lm_loss": loss}
+        if "image_text_alignment" in sample_list and sample_list["image_text_alignment"] is not None:
+            # :509-518 hands CrossEntropyLoss the flattened [2B] next-sentence scores with a [B] target, which torch rejects for
+            # B > 1: that branch cannot run in the reference either
+            raise NotImplementedError("MMBTForPreTraining alignment loss (mmbt.py:509-518) is not built")
+        return output
+
+
 class MMBTForClassification(nn.Module):
     """mmbt.py:526-563."""
 
@@ -254,8 +300,9 @@ class MMBT(BaseModel):
 
     def build(self):
         if self.config.get("training_head_type", "pretraining") == "pretraining":
-            raise NotImplementedError("MMBTForPreTraining (mmbt.py:447-523) is a later milestone")
-        self.model = MMBTForClassification(self.config)
+            self.model = MMBTForPreTraining(self.config)
+        else:
+            self.model = MMBTForClassification(self.config)
         if self.config.get("freeze_complete_base", False) or self.config.get("freeze_text", False):
             for p in self.model.bert.mmbt.transformer.parameters():
                 p.requires_grad = False

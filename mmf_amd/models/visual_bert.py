@@ -23,7 +23,7 @@ from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
 from mmf_amd.modules.embeddings import BertVisioLinguisticEmbeddings
 from mmf_amd.modules.hf_layers import (
-    BertConfig, BertEncoderJit, BertLayerJit, BertPooler, BertPredictionHeadTransform, Linear, init_bert_weights)
+    BertConfig, BertEncoderJit, BertLayerJit, BertPooler, BertPredictionHeadTransform, BertPreTrainingHeads, Linear, init_bert_weights)
 from mmf_amd.utils.configuration import to_container
 from mmf_amd.utils.modeling import get_optimizer_parameters_for_bert
 
@@ -85,28 +85,6 @@ class VisualBERTBase(nn.Module):
         if not self.skip_pooler:
             pooled_output = self.pooler(sequence_output)
         return sequence_output, pooled_output, hidden
-
-
-class BertLMPredictionHead(nn.Module):
-    """HF BertLMPredictionHead as pinned by the reference (transformers <= 4.10.1): transform, a bias-free decoder whose
-    `bias` attribute IS `self.bias` (one tensor under the two state-dict keys `predictions.bias` and `predictions.decoder.bias`)."""
-
-    def __init__(self, config):
-        super().__init__()
-        self.transform = BertPredictionHeadTransform(config)
-        self.decoder = Linear(config.hidden_size, config.vocab_size, bias=False)
-        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
-        self.decoder.bias = self.bias
-
-
-class BertPreTrainingHeads(nn.Module):
-    """HF BertPreTrainingHeads: masked-LM head + the next-sentence classifier (whose score the reference computes and never
-    uses, visual_bert.py:267-269; its parameters exist for checkpoint compatibility and receive no gradient, as there)."""
-
-    def __init__(self, config):
-        super().__init__()
-        self.predictions = BertLMPredictionHead(config)
-        self.seq_relationship = Linear(config.hidden_size, 2)
 
 
 class VisualBERTForPretraining(nn.Module):

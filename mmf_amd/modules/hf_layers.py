@@ -378,3 +378,25 @@ class BertPredictionHeadTransform(nn.Module):
     def forward(self, hidden_states: Tensor) -> Tensor:
         h = torch.ops.mmf_amd.dense_gelu(hidden_states, self.dense.weight, self.dense.bias)
         return self.LayerNorm(h)
+
+
+class BertLMPredictionHead(nn.Module):
+    """HF BertLMPredictionHead as pinned by the reference (transformers <= 4.10.1): transform, a bias-free decoder whose
+    `bias` attribute IS `self.bias` (one tensor under the two state-dict keys `predictions.bias` and `predictions.decoder.bias`)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        self.decoder.bias = self.bias
+
+
+class BertPreTrainingHeads(nn.Module):
+    """HF BertPreTrainingHeads: masked-LM head + the next-sentence classifier (whose score the reference computes and never
+    uses, visual_bert.py:267-269; its parameters exist for checkpoint compatibility and receive no gradient, as there)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+        self.seq_relationship = Linear(config.hidden_size, 2)

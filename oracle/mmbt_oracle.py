@@ -176,6 +176,22 @@ def mmbt_forward(sd, cfg, sample_list, train=False):
     return {"scores": logits.contiguous().view(-1, cfg["num_labels"]), "sequence_output": seq, "pooled_output": pooled}
 
 
+def mmbt_pretraining_forward(sd, cfg, sample_list, train=False):
+    """MMBTForPreTraining.forward, mmbt.py:479-523 (masked-LM branch): HF BertPreTrainingHeads.predictions over every position
+    (transform = dense -> gelu -> LayerNorm, decoder tied to the word embeddings, :467-476), CrossEntropyLoss(ignore_index=-1)
+    over the LAST T positions only (:497-506), keyed "{dataset_name}/{dataset_type}/masked_lm_loss"."""
+    seq, pooled = mmbt_base_forward(sd, cfg, sample_list, train)
+    x = F.gelu(F.linear(seq, sd["cls.predictions.transform.dense.weight"], sd["cls.predictions.transform.dense.bias"]))
+    x = layer_norm(x, sd["cls.predictions.transform.LayerNorm.weight"], sd["cls.predictions.transform.LayerNorm.bias"],
+                   cfg["layer_norm_eps"])
+    logits = F.linear(x, sd[T_ + "embeddings.word_embeddings.weight"], sd["cls.predictions.bias"])
+    lm = sample_list["lm_label_ids"]
+    text_scores = logits[:, -(lm.size(1)):].contiguous().view(-1, cfg["vocab_size"])      # :499-503
+    loss = F.cross_entropy(text_scores, lm.contiguous().view(-1), ignore_index=-1)
+    key = "%s/%s/masked_lm_loss" % (sample_list["dataset_name"], sample_list["dataset_type"])
+    return {"logits": logits, "losses": {key: loss}, "sequence_output": seq}
+
+
 def cross_entropy(scores, targets, **params):
     """CrossEntropyLoss.forward, mmf/modules/losses.py:595-602."""
     return F.cross_entropy(scores, targets, **params)

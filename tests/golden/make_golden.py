@@ -223,6 +223,101 @@ def make_mmbt():
         np.savez_compressed(path, **rec)
         print(name, "loss", loss.item(), "scores", rec["scores"][0], "->", path, os.path.getsize(path), "bytes")
 
+def make_mmbt_pretraining():
+    """MMBTForPreTraining.forward (mmbt.py:479-523) called on a holder that carries the reference's own parts (MMBTBase.forward over
+    MMBTModel / BertModelJit, HF BertPreTrainingHeads with the decoder tied the pinned-transformers way): masked-LM loss over the
+    text positions, logits over all positions, every gradient."""
+    from torch import nn
+    from transformers import BertConfig
+    from transformers.models.bert.modeling_bert import BertPreTrainingHeads
+    M = refshim.ref_import("mmf.models.mmbt")
+    from mmf.modules.hf_layers import BertModelJit
+    c = dict(MMBT_CASES["mmbt_small64"], seed=81)
+    bcfg = BertConfig(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+                      num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                      vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"], type_vocab_size=2,
+                      hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12)
+    mcfg = M.MMBTConfig(bcfg, num_labels=c["num_labels"], modal_hidden_size=c["modal_hidden_size"])
+
+    class Holder(nn.Module):
+        pass
+
+    class RefMMBT(nn.Module):   # module tree of MMBTForPreTraining: bert.mmbt.*, cls.*
+        def __init__(self):
+            super().__init__()
+            self.bert = Holder()
+            self.bert.mmbt = M.MMBTModel(mcfg, BertModelJit(bcfg), nn.Identity())
+            self.cls = BertPreTrainingHeads(bcfg)
+            # mmbt.py:467-476 tie_weights (+ transformers<=4.10 BertLMPredictionHead: decoder.bias IS predictions.bias)
+            self.cls.predictions.decoder.weight = self.bert.mmbt.transformer.embeddings.word_embeddings.weight
+            self.cls.predictions.decoder.bias = self.cls.predictions.bias
+
+    ref = RefMMBT().eval()
+    uniq = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+            if not k.endswith("position_ids") and not k.endswith("token_type_ids") and "modal_encoder.position_embeddings" not in k
+            and "modal_encoder.token_type_embeddings" not in k and "modal_encoder.word_embeddings" not in k
+            and "modal_encoder.LayerNorm" not in k and not k.startswith("cls.predictions.decoder.")}
+    sd = detweights.state_dict(uniq, c["seed"])
+    missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    base = Holder()
+    base._is_direct_features_input = True
+    base.use_modal_start_token = True
+    base.use_modal_end_token = True
+    base.num_max_segment = 2
+    base.mmbt = ref.bert.mmbt
+    base.extract_modal_end_token = lambda sl: M.MMBTBase.extract_modal_end_token(base, sl)
+    head = Holder()
+    head.bert = lambda sl: M.MMBTBase.forward(base, sl)
+    head.cls = ref.cls
+    head.encoder_config = bcfg
+    head.loss_fct = nn.CrossEntropyLoss(ignore_index=-1)
+
+    B, T, N, seed = c["B"], c["T"], c["N"], c["seed"]
+    ids = (detweights.uniform(B * T, seed + 100) * c["vocab_size"]).astype(np.int64).reshape(B, T)
+    mask = np.ones((B, T), dtype=np.int64)
+    mask[1, T // 2:] = 0
+    mask[2, T - 3:] = 0
+    ids[mask == 0] = 0
+    seg = np.zeros((B, T), dtype=np.int64)
+    feats = detweights.uniform(B * N * c["modal_hidden_size"], seed + 102).astype(np.float32).reshape(B, N, -1)
+    pick = (detweights.uniform(B * T, seed + 301).reshape(B, T) < 0.3) & (mask == 1)
+    pick[:, 2] = True
+    lm = np.where(pick, (detweights.uniform(B * T, seed + 302) * c["vocab_size"]).astype(np.int64).reshape(B, T), -1)
+    sl = SampleList(input_ids=torch.from_numpy(ids.copy()), input_mask=torch.from_numpy(mask.copy()),
+                    segment_ids=torch.from_numpy(seg), image_feature_0=torch.from_numpy(feats),
+                    lm_label_ids=torch.from_numpy(lm), dataset_name="hateful_memes", dataset_type="train")
+    out = M.MMBTForPreTraining.forward(head, sl)
+    (key, loss), = out["losses"].items()
+    loss.backward()
+    rec = {"in_input_ids": ids, "in_input_mask": mask, "in_segment_ids": seg, "in_image_feature_0": feats, "in_lm_label_ids": lm}
+    rec["logits"] = out["logits"].detach().numpy()
+    rec["loss"] = np.array(loss.item(), dtype=np.float64)
+    rec["loss_key"] = np.array(key)
+    names, norms, sums = [], [], []
+    seen = set()
+    for k, p in ref.named_parameters():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        g = p.grad
+        names.append("model." + k)
+        norms.append(0.0 if g is None else float(g.double().norm()))
+        sums.append(0.0 if g is None else float(g.double().sum()))
+        if g is not None and (g.numel() <= 4096 or k.endswith("word_embeddings.weight")):
+            rec["grad::model." + k] = g.numpy()
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms)
+    rec["grad_sums"] = np.array(sums)
+    rec["param_names"] = np.array(["model." + k for k in uniq.keys()])
+    rec["param_shapes"] = np.array([",".join(map(str, s)) for s in uniq.values()])
+    rec["state_dict_keys"] = np.array(["model." + k for k in ref.state_dict().keys()])
+    rec["case"] = np.array(repr(c))
+    path = os.path.join(HERE, "mmbt_pretraining.npz")
+    np.savez_compressed(path, **rec)
+    print("mmbt_pretraining loss", loss.item(), key, "->", path, os.path.getsize(path), "bytes")
+
+
 MMFT_CASES = {
     "mmft_small64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
                          max_position_embeddings=40, embedding_dim=72, num_labels=5, B=3, T=12, R=7, seed=31),
@@ -1006,7 +1101,7 @@ def make_visual_bert_pretraining():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmft", "vilbert", "uniter", "m4c"]
+    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "uniter", "m4c"]
     if "visual_bert" in which:
         main()
     if "nlvr2" in which:
@@ -1015,6 +1110,8 @@ if __name__ == "__main__":
         make_visual_bert_pretraining()
     if "mmbt" in which:
         make_mmbt()
+    if "mmbt_pretraining" in which:
+        make_mmbt_pretraining()
     if "mmft" in which:
         make_mmft()
     if "vilbert" in which:

@@ -48,8 +48,19 @@ def load_mmbt_case(name="mmbt_small64"):
     sample = {
         "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
         "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),
-        "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "hateful_memes", "dataset_type": "train",
+        "dataset_name": "hateful_memes", "dataset_type": "train",
     }
+    if "in_targets" in z.files:
+        sample["targets"] = torch.from_numpy(z["in_targets"])
+    return z, case, cfg, sd, sample
+
+
+def load_mmbt_pretraining_case():
+    """`mmbt_pretraining`: MMBT with the masked-LM pretraining head; parameters under the reference's names (no `model.` prefix),
+    the tied decoder keys are aliases and not listed."""
+    z, case, cfg, sd, sample = load_mmbt_case("mmbt_pretraining")
+    sample.pop("targets", None)
+    sample["lm_label_ids"] = torch.from_numpy(z["in_lm_label_ids"])
     return z, case, cfg, sd, sample
 
 

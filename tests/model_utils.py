@@ -84,6 +84,19 @@ def build_mmbt(cfg, sd=None, shared=None, device="cuda", **over):
     return model.to(device)
 
 
+def build_mmbt_pretraining(cfg, sd=None, shared=None, device="cuda", **over):
+    """MMBT with the masked-LM pretraining head (`training_head_type: pretraining`); the tied decoder keys are filled from their owners."""
+    model = build_model(mmbt_model_config(cfg, training_head_type="pretraining", losses=[], **over))
+    if sd is not None:
+        full = {"model." + k: v for k, v in sd.items()}
+        for alias, src in (shared or {}).items():
+            full["model." + alias] = sd[src]
+        full["model.cls.predictions.decoder.weight"] = full["model.bert.mmbt.transformer.embeddings.word_embeddings.weight"]
+        full["model.cls.predictions.decoder.bias"] = full["model.cls.predictions.bias"]
+        model.load_state_dict(full, strict=True)
+    return model.to(device)
+
+
 def mmft_model_config(cfg, **over):
     """MMF model_config.mmf_transformer (configs/models/mmf_transformer/defaults.yaml) with identity encoders."""
     d = dict(

@@ -37,6 +37,12 @@ def _mmbt():
     return z, MU.build_mmbt(cfg, sd, SHARED, device="cpu"), sample, "model."
 
 
+def _mmbt_pretraining():
+    z, case, cfg, sd, sample = G.load_mmbt_pretraining_case()
+    from oracle.mmbt_oracle import SHARED
+    return z, MU.build_mmbt_pretraining(cfg, sd, SHARED, device="cpu"), sample, "model."
+
+
 def _mmft():
     z, case, cfg, sd, sample = G.load_mmft_case()
     from oracle.mmft_oracle import shared
@@ -58,7 +64,7 @@ def _m4c():
     return z, MU.build_m4c(cfg, sd, device="cpu"), sample, ""
 
 
-CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "mmbt": _mmbt, "mmft": _mmft, "vilbert": _vilbert, "uniter": _uniter,
+CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "mmbt": _mmbt, "mmbt_pretraining": _mmbt_pretraining, "mmft": _mmft, "vilbert": _vilbert, "uniter": _uniter,
          "m4c": _m4c}
 
 
@@ -71,7 +77,7 @@ def test_training_step_plumbing(name):
     opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
     with native_stub.installed() as calls:
         out = model(SampleList(sample))
-        head = out["logits"] if name == "visual_bert_pretraining" else out["scores"]        # the pretraining head returns `logits`
+        head = out["logits"] if name.endswith("_pretraining") else out["scores"]        # the pretraining head returns `logits`
         assert head.dtype == torch.float32 and head.shape[0] > 0
         assert len(out["losses"]) == 1
         (lkey, loss), = out["losses"].items()

@@ -143,3 +143,37 @@ def test_pretraining_train_step_at_bert_vocabulary_size():
     assert losses[-1] < losses[0] - 0.5, losses
     w = model.model.bert.embeddings.word_embeddings.weight
     assert w.grad is not None and w.grad.shape == (30522, cfg["hidden_size"]) and bool(torch.isfinite(w.grad).all())
+
+
+def test_mmbt_pretraining_golden_forward_loss_gradients_and_state_dict():
+    """MMBTForPreTraining (mmf/models/mmbt.py:447-523) against the fixture recorded from the reference's own forward: logits over
+    all positions, masked-LM loss over the text positions, every gradient; state-dict keys equal the reference module tree's."""
+    from oracle.mmbt_oracle import SHARED
+    from tests.model_utils import build_mmbt_pretraining
+    z, case, cfg, sd, sample = G.load_mmbt_pretraining_case()
+    model = build_mmbt_pretraining(cfg, sd, SHARED)
+    assert sorted(model.state_dict().keys()) == sorted(str(k) for k in z["state_dict_keys"] if not str(k).endswith("position_ids"))
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    np.testing.assert_allclose(out["logits"].detach().cpu().numpy(), z["logits"], rtol=TOL, atol=TOL)
+    (key, loss), = out["losses"].items()
+    assert key == str(z["loss_key"])
+    assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    loss.backward()
+    params = dict(model.named_parameters())
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        gname = str(gname)
+        name = "model." + SHARED.get(gname[len("model."):], gname[len("model."):])
+        p = params[name]
+        if norm == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, gname
+            continue
+        if gname.endswith("self.key.bias"):
+            continue
+        assert p.grad is not None and abs(float(p.grad.double().norm()) - norm) <= TOL * norm, gname
+        full = "grad::" + gname
+        if full in z.files:
+            assert rel_err(p.grad, torch.from_numpy(z[full])) <= TOL, gname
+    with mmf_amd.fp32_inference():
+        out32 = model(SampleList(sample_to(sample, "cuda")))
+    assert np.abs(out32["logits"].cpu().numpy() - z["logits"]).max() <= 1e-3

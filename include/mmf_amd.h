@@ -320,6 +320,17 @@ int mmf_vocab_cross_entropy_fwd(const float* logits, int ld, const int64_t* labe
 int mmf_vocab_cross_entropy_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* count, const float* gloss,
                                 void* dlogits, int ldd, int R, int C, int ignore_index, void* stream);
 
+/* Masked soft-target KL divergence — ViLBERT's masked-region classification loss (mmf/models/vilbert.py:1070-1071,1150-1157,
+ * `visual_target: 0`): sum over the rows with row_label == 1 of KLDivLoss(log_softmax(logits[r]), target[r]) (0 where the target
+ * is 0, like torch), divided by the number of such rows.  logits fp32 [R, C] (row stride ld), target fp32 [R, C] (ldt), row_label
+ * int64 [R] (image_label).  Forward writes lse / tsum / rowloss per row, loss[0], count[0]; backward writes gloss / count *
+ * (softmax * sum_c target - target) as bf16 [R, ldd] (ldd % 8 == 0, pad columns and unlabelled rows zero), the operand of the
+ * image-prediction decoder's gradient GEMMs. */
+int mmf_soft_target_kl_fwd(const float* logits, int ld, const float* target, int ldt, const int64_t* row_label, float* lse, float* tsum,
+                           float* rowloss, float* loss, float* count, int R, int C, void* stream);
+int mmf_soft_target_kl_bwd(const float* logits, int ld, const float* target, int ldt, const int64_t* row_label, const float* lse,
+                           const float* tsum, const float* count, const float* gloss, void* dlogits, int ldd, int R, int C, void* stream);
+
 /* ---- M4C (mmf/models/m4c.py) -------------------------------------------------------------------
  * F.normalize(x, dim=-1) of the appearance / FastText / PHOC features (m4c.py:195,212,217,223): y[r, :D] = x[r, :D] /
  * max(||x[r, :D]||_2, eps), written as bf16 at row stride ldy — `y` may point at a column offset inside the wider

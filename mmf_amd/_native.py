@@ -551,6 +551,23 @@ def vocab_cross_entropy_bwd(logits, labels, lse, count, gloss, dlogits, ldd, R, 
                                              ignore_index, _stream()), "mmf_vocab_cross_entropy_bwd")
 
 
+def soft_target_kl_fwd(logits, target, row_label, lse, tsum, rowloss, loss, count, R, Cn):
+    """Masked soft-target KL (ViLBERT masked-region loss): logits / target fp32 [R, Cn], row_label int64 [R] (1 = counted)."""
+    for t, n in ((logits, "logits"), (target, "target"), (lse, "lse"), (tsum, "tsum"), (rowloss, "rowloss"), (loss, "loss"), (count, "count")):
+        _req(t, torch.float32, n)
+    _req(row_label, torch.int64, "row_label")
+    _check(lib().mmf_soft_target_kl_fwd(_p(logits), logits.stride(0), _p(target), target.stride(0), _p(row_label), _p(lse), _p(tsum),
+                                        _p(rowloss), _p(loss), _p(count), R, Cn, _stream()), "mmf_soft_target_kl_fwd")
+
+
+def soft_target_kl_bwd(logits, target, row_label, lse, tsum, count, gloss, dlogits, ldd, R, Cn):
+    for t, n in ((logits, "logits"), (target, "target"), (lse, "lse"), (tsum, "tsum"), (count, "count"), (gloss, "gloss")):
+        _req(t, torch.float32, n)
+    _req(row_label, torch.int64, "row_label"); _req(dlogits, torch.bfloat16, "dlogits")
+    _check(lib().mmf_soft_target_kl_bwd(_p(logits), logits.stride(0), _p(target), target.stride(0), _p(row_label), _p(lse), _p(tsum),
+                                        _p(count), _p(gloss), _p(dlogits), ldd, R, Cn, _stream()), "mmf_soft_target_kl_bwd")
+
+
 # --------------------------------------------------------------------------------------------
 # fp32-accurate forward path (mmf_amd/csrc/fp32_path.hip)
 # --------------------------------------------------------------------------------------------

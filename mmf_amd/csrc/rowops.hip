@@ -877,6 +877,73 @@ __global__ __launch_bounds__(256) void vocab_ce_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// masked soft-target KL divergence: ViLBERT's masked-region classification loss (mmf/models/vilbert.py:1070-1071, 1150-1157,
+// visual_target == 0): sum over the rows with image_label == 1 of KLDivLoss(log_softmax(x_r), t_r) = sum_c t (log t - log p),
+// divided by the number of such rows.  Same shape as the vocabulary cross-entropy above: forward keeps each row's
+// log-sum-exp and target mass, backward writes g / count * (softmax * sum_c t - t) as the bf16 GEMM operand.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void soft_kl_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ tgt, int ldt,
+                                                           const int64_t* __restrict__ lab, float* __restrict__ lse,
+                                                           float* __restrict__ tsum, float* __restrict__ rowloss, int C) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x;
+    if (lab[r] != 1) {
+        if (threadIdx.x == 0) { lse[r] = 0.f; tsum[r] = 0.f; rowloss[r] = 0.f; }
+        return;
+    }
+    const float* xr = x + (size_t)r * ld;
+    const float* tr = tgt + (size_t)r * ldt;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, xr[c]);
+    mx = block_max256(mx, sh);
+    float z = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) z += expf(xr[c] - mx);
+    z = block_sum256(z, sh);
+    const float l = mx + logf(z);
+    float acc = 0.f, ts = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float t = tr[c];
+        ts += t;
+        if (t > 0.f) acc += t * (logf(t) - (xr[c] - l));     // torch's kl_div: 0 where the target is 0 (xlogy)
+        else acc -= t * (xr[c] - l);                          // (a non-positive target contributes -t * log p, as in torch: t = 0 -> 0)
+    }
+    acc = block_sum256(acc, sh);
+    ts = block_sum256(ts, sh);
+    if (threadIdx.x == 0) { lse[r] = l; tsum[r] = ts; rowloss[r] = acc; }
+}
+__global__ __launch_bounds__(256) void soft_kl_finalize_kernel(const float* __restrict__ rowloss, const int64_t* __restrict__ lab,
+                                                                float* __restrict__ loss, float* __restrict__ count, int R) {
+    __shared__ float sh[4];
+    float s = 0.f, n = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256)
+        if (lab[r] == 1) { s += rowloss[r]; n += 1.f; }
+    s = block_sum256(s, sh);
+    n = block_sum256(n, sh);
+    if (threadIdx.x == 0) { loss[0] = s / n; count[0] = n; }     // the reference divides by max(n, 0) = n (vilbert.py:1157)
+}
+__global__ __launch_bounds__(256) void soft_kl_bwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ tgt, int ldt,
+                                                           const int64_t* __restrict__ lab, const float* __restrict__ lse,
+                                                           const float* __restrict__ tsum, const float* __restrict__ count,
+                                                           const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int C) {
+    const int r = blockIdx.y;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= ldd) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (lab[r] == 1) {
+        const float g = (gloss ? gloss[0] : 1.f) / count[0];
+        const float l = lse[r], ts = tsum[r];
+        const float* xr = x + (size_t)r * ld;
+        const float* tr = tgt + (size_t)r * ldt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            if (c < C) v[e] = g * (expf(xr[c] - l) * ts - tr[c]);
+        }
+    }
+    store4(d + (size_t)r * ldd + c0, v);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused AdamW over a flat arena
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1426,6 +1493,27 @@ int mmf_vocab_cross_entropy_bwd(const float* logits, int ld, const int64_t* labe
     MMF_CHECK_ARG(R <= 65535, "vocab_cross_entropy_bwd: more than 65535 rows in one launch");
     hipLaunchKernelGGL(vocab_ce_bwd_kernel, dim3((ldd / 4 + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, lse, count,
                        gloss, (bf16*)dlogits, ldd, C, ignore_index);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_soft_target_kl_fwd(const float* logits, int ld, const float* target, int ldt, const int64_t* row_label, float* lse, float* tsum,
+                           float* rowloss, float* loss, float* count, int R, int C, void* stream) {
+    MMF_CHECK_ARG(logits && target && row_label && lse && tsum && rowloss && loss && count && R > 0 && C > 0 && ld >= C && ldt >= C,
+                  "soft_target_kl_fwd: bad operand");
+    hipLaunchKernelGGL(soft_kl_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ldt, row_label, lse, tsum, rowloss, C);
+    hipLaunchKernelGGL(soft_kl_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rowloss, row_label, loss, count, R);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_soft_target_kl_bwd(const float* logits, int ld, const float* target, int ldt, const int64_t* row_label, const float* lse,
+                           const float* tsum, const float* count, const float* gloss, void* dlogits, int ldd, int R, int C, void* stream) {
+    MMF_CHECK_ARG(logits && target && row_label && lse && tsum && count && dlogits && R > 0 && C > 0 && ld >= C && ldt >= C,
+                  "soft_target_kl_bwd: bad operand");
+    MMF_CHECK_ARG(ldd >= C && (ldd % 8) == 0, "soft_target_kl_bwd: ldd must be a multiple of 8 covering C (the GEMM operand's leading dimension)");
+    MMF_CHECK_ARG(R <= 65535, "soft_target_kl_bwd: more than 65535 rows in one launch");
+    hipLaunchKernelGGL(soft_kl_bwd_kernel, dim3((ldd / 4 + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ldt, row_label,
+                       lse, tsum, count, gloss, (bf16*)dlogits, ldd, C);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -19,6 +19,7 @@ Reference ops replaced (paths relative to the reference root):
   GatherRowsFn              torch.gather + Dropout of the `vqa` pooler     (visual_bert.py:389-400)
   LogitBCEFn                LogitBinaryCrossEntropy                        (losses.py:246-251)
   MaskedLMHeadFn            tied decoder + CrossEntropyLoss(ignore_index=-1) of VisualBERTForPretraining  (visual_bert.py:267-277)
+  MaskedRegionHeadFn        image-prediction decoder + masked KLDivLoss of ViLBERTForPretraining  (vilbert.py:846-858, 1150-1157)
 """
 import contextlib
 import math
@@ -1064,6 +1065,49 @@ class MaskedLMHeadFn(torch.autograd.Function):
         ldd = _pad8(N)
         d = torch.empty(M, ldd, dtype=BF16, device=x2.device)
         nat.vocab_cross_entropy_bwd(logits, lab, lse, count, gloss.float().reshape(1).contiguous(), d, ldd, M, N, ignore_index)
+        dx, dw, db = _linear_bwd(d, ldd, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
+        return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
+
+
+class MaskedRegionHeadFn(torch.autograd.Function):
+    """The decoder + loss of ViLBERT's masked-region classification (mmf/models/vilbert.py:846-858 BertImagePredictionHead.decoder,
+    :1150-1157 `visual_target: 0`): prediction_scores_v = h W^T + b over every region, then KLDivLoss(log_softmax(scores), target)
+    summed over the regions with image_label == 1 and divided by their number.  Returns (loss, scores [B, R, v_target_size] fp32).
+    One autograd node, like MaskedLMHeadFn: backward writes gloss / count * (softmax * sum(target) - target) directly as the
+    zero-padded bf16 operand of the decoder's gradient GEMMs; `scores` is returned non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, target, row_label):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        N = weight.shape[0]
+        dev = x2.device
+        logits = torch.empty(M, N, dtype=F32, device=dev)
+        nat.gemm(x2, w16, logits, M, N, K, K, K, N, bias=bias.detach())
+        tgt = target.reshape(M, N)
+        tgt = (tgt if tgt.dtype == F32 else tgt.float()).contiguous()
+        lab = row_label.reshape(M).contiguous()
+        if lab.dtype != torch.int64:
+            lab = lab.long()
+        lse = torch.empty(M, dtype=F32, device=dev)
+        tsum = torch.empty(M, dtype=F32, device=dev)
+        rowloss = torch.empty(M, dtype=F32, device=dev)
+        loss = torch.empty(1, dtype=F32, device=dev)
+        count = torch.empty(1, dtype=F32, device=dev)
+        nat.soft_target_kl_fwd(logits, tgt, lab, lse, tsum, rowloss, loss, count, M, N)
+        ctx.save_for_backward(x2, w16, logits, tgt, lab, lse, tsum, count)
+        ctx.meta = (M, N, K, x.shape)
+        out = logits.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(out)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        x2, w16, logits, tgt, lab, lse, tsum, count = ctx.saved_tensors
+        M, N, K, xshape = ctx.meta
+        ldd = _pad8(N)
+        d = torch.empty(M, ldd, dtype=BF16, device=x2.device)
+        nat.soft_target_kl_bwd(logits, tgt, lab, lse, tsum, count, gloss.float().reshape(1).contiguous(), d, ldd, M, N)
         dx, dw, db = _linear_bwd(d, ldd, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
 

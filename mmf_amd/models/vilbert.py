@@ -24,7 +24,8 @@ from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
 from mmf_amd.modules.hf_layers import (
-    BertConfig, BertEmbeddingsJit, BertIntermediate, BertLayerJit, BertOutput, BertPredictionHeadTransform, LayerNorm, Linear,
+    BertConfig, BertEmbeddingsJit, BertIntermediate, BertLayerJit, BertLMPredictionHead, BertOutput, BertPredictionHeadTransform, LayerNorm,
+    Linear,
     init_bert_weights)
 from mmf_amd.utils.configuration import to_container
 from mmf_amd.utils.modeling import get_optimizer_parameters_for_bert
@@ -300,6 +301,79 @@ class ViLBERTBase(nn.Module):
                 encoded_layers_t if output_all_encoded_layers else None, encoded_layers_v if output_all_encoded_layers else None)
 
 
+class BertImagePredictionHead(nn.Module):
+    """vilbert.py:829-858: BertImgPredictionHeadTransform (dense -> gelu -> LayerNorm(eps=1e-12) at the visual width) + decoder onto
+    the `v_target_size` region classes."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.get("hidden_act", "gelu") != "gelu":
+            raise NotImplementedError("BertImgPredictionHeadTransform: only hidden_act='gelu' is fused in the GEMM epilogue")
+        self.transform = BertPredictionHeadTransform(BertConfig(hidden_size=config.v_hidden_size, layer_norm_eps=1e-12))
+        self.decoder = Linear(config.v_hidden_size, config.v_target_size)
+
+
+class ViLBERTPreTrainingHeads(nn.Module):
+    """vilbert.py:861-888 `BertPreTrainingHeads`: masked-LM head (decoder tied to the word embeddings), masked-region head and the
+    image-text matching classifier `bi_seq_relationship` — whose score the reference computes and never uses (the
+    next-sentence loss is commented out, :1236-1239): its parameters exist for checkpoints and receive no gradient."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+        self.bi_seq_relationship = Linear(config.bi_hidden_size, 2)
+        self.imagePredictions = BertImagePredictionHead(config)
+        self.fusion_method = config.fusion_method
+
+
+class ViLBERTForPretraining(nn.Module):
+    """vilbert.py:1054-1240: masked language modelling on the text stream + masked region classification on the visual stream."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bert_config = BertConfig.from_dict({k: v for k, v in to_container(config).items()})
+        for k in ("v_biattention_id", "t_biattention_id"):
+            setattr(self.bert_config, k, list(config[k]))
+        self.bert = ViLBERTBase(self.bert_config)
+        self.cls = ViLBERTPreTrainingHeads(self.bert_config)
+        self.vocab_size = self.config.vocab_size
+        self.visual_target = config.visual_target
+        self.num_negative = config.num_negative
+        if self.visual_target != 0:
+            raise NotImplementedError("visual_target=%r: only the KL masked-region classification (visual_target: 0, the reference "
+                                      "default; vilbert.py:1070-1075) is built" % (self.visual_target,))
+        self.init_weights()
+
+    def init_weights(self):
+        if self.config.get("random_initialize", False) is False:
+            self.cls.apply(self.bert._init_weights)
+            self.tie_weights()
+
+    def tie_weights(self):
+        """vilbert.py:1088-1095."""
+        self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+
+    def forward(self, input_ids, image_feature, image_location, token_type_ids=None, attention_mask=None,
+                image_attention_mask=None, masked_lm_labels=None, image_label=None, image_target=None,
+                output_all_attention_masks=False):
+        (sequence_output_t, sequence_output_v, _, _, _, _, _) = self.bert(
+            input_ids, image_feature, image_location, token_type_ids, attention_mask, image_attention_mask,
+            output_all_encoded_layers=False, output_all_attention_masks=output_all_attention_masks)
+        output = {}
+        if image_label is not None and image_target is not None:
+            head = self.cls.imagePredictions
+            hidden_v = head.transform(sequence_output_v)
+            img_loss, _ = torch.ops.mmf_amd.masked_region_head(hidden_v, head.decoder.weight, head.decoder.bias, image_target, image_label)
+            output["masked_img_loss"] = img_loss.unsqueeze(0)
+        if masked_lm_labels is not None:
+            heads = self.cls.predictions
+            hidden_t = heads.transform(sequence_output_t)
+            lm_loss, _ = torch.ops.mmf_amd.masked_lm_head(hidden_t, heads.decoder.weight, heads.bias, masked_lm_labels, -1)
+            output["masked_lm_loss"] = lm_loss.unsqueeze(0)
+        return output
+
+
 class ViLBERTForClassification(nn.Module):
     """vilbert.py:1243-1333."""
 
@@ -365,8 +439,9 @@ class ViLBERT(BaseModel):
 
     def build(self):
         if self.config.training_head_type == "pretraining":
-            raise NotImplementedError("ViLBERTForPretraining (vilbert.py:1054-1240) is a later milestone")
-        self.model = ViLBERTForClassification(self.config)
+            self.model = ViLBERTForPretraining(self.config)
+        else:
+            self.model = ViLBERTForClassification(self.config)
         if self.config.get("freeze_base", False):
             for p in self.model.bert.parameters():
                 p.requires_grad = False
@@ -388,8 +463,19 @@ class ViLBERT(BaseModel):
         return {
             "input_ids": ids, "attention_mask": mask, "token_type_ids": tt, "image_dim": image_info.get("max_features", None),
             "image_feature": sample_list.get("image_feature_0", None), "image_location": image_info.get("bbox", None),
-            "image_target": None, "image_label": sample_list.get("image_labels", None),
+            "image_target": self._image_target(image_info.get("cls_prob", None), ids.device),
+            "image_label": sample_list.get("image_labels", None),
         }
+
+    @staticmethod
+    def _image_target(cls_prob, device):
+        """vilbert.py:1402-1406: the detector's class distribution per region, as a float tensor on the model's device."""
+        if cls_prob is None:
+            return None
+        if isinstance(cls_prob, torch.Tensor):
+            return cls_prob.to(device=device, dtype=torch.float32)
+        import numpy as np
+        return torch.tensor(np.array(cls_prob, dtype=np.float32), dtype=torch.float, device=device)
 
     def get_optimizer_parameters(self, config):
         return get_optimizer_parameters_for_bert(self.model, config)
@@ -407,6 +493,13 @@ class ViLBERT(BaseModel):
         else:
             params["image_attention_mask"] = None
         params.pop("image_dim")
-        return self.model(params["input_ids"], params["image_feature"], params["image_location"], params["token_type_ids"],
-                          params["attention_mask"], params["image_attention_mask"], params["masked_lm_labels"],
-                          params["image_label"], params["image_target"])
+        output_dict = self.model(params["input_ids"], params["image_feature"], params["image_location"], params["token_type_ids"],
+                                 params["attention_mask"], params["image_attention_mask"], params["masked_lm_labels"],
+                                 params["image_label"], params["image_target"])
+        if self.config.training_head_type == "pretraining":           # vilbert.py:1459-1469
+            loss_key = "{}/{}".format(sample_list["dataset_name"], sample_list["dataset_type"])
+            output_dict["losses"] = {
+                loss_key + "/masked_lm_loss": output_dict.pop("masked_lm_loss"),
+                loss_key + "/masked_img_loss": output_dict.pop("masked_img_loss"),
+            }
+        return output_dict

@@ -25,6 +25,7 @@ Q|K|V views) are looked up inside (mmf_amd.functional.ShadowCache), dropout keys
     torch.ops.mmf_amd.dropout             nn.Dropout                                    visual_bert.py:400
     torch.ops.mmf_amd.pair_halves         nlvr2 pooled-output pairing                   visual_bert.py:369-374
     torch.ops.mmf_amd.masked_lm_head      tied decoder + masked-LM CrossEntropyLoss      visual_bert.py:267-277
+    torch.ops.mmf_amd.masked_region_head  image-prediction decoder + masked KLDivLoss    vilbert.py:846-858,1150-1157
 
 Inside `with mmf_amd.fp32_inference():` every operator above routes to the fp32-accurate forward kernels instead
 (mmf_amd/fp32_path.py: fp32 activations, fp32-input MFMA; north_star's 1e-3 bound) — same schemas, same modules.
@@ -162,6 +163,13 @@ def masked_lm_head(x, weight, bias, labels, ignore_index):
     if F32P.active():
         return F32P.masked_lm_head(x, weight, bias, labels, ignore_index)
     return Fn.MaskedLMHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), labels, ignore_index)
+
+
+@_op("masked_region_head(Tensor x, Tensor weight, Tensor bias, Tensor target, Tensor row_label) -> (Tensor, Tensor)")
+def masked_region_head(x, weight, bias, target, row_label):
+    if F32P.active():
+        raise NotImplementedError("fp32 path: ViLBERT's masked-region head is not built")
+    return Fn.MaskedRegionHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), target, row_label)
 
 
 def schemas():

@@ -98,6 +98,23 @@ def parameter_shapes(cfg):
     s["bert.t_pooler.dense.bias"] = (BH,)
     s["bert.v_pooler.dense.weight"] = (BH, VH)
     s["bert.v_pooler.dense.bias"] = (BH,)
+    if cfg.get("training_head_type", "classification") == "pretraining":
+        # ViLBERTForPretraining (vilbert.py:1054-1077): `cls` = vilbert.BertPreTrainingHeads (:861-868).  `cls.predictions.decoder.weight`
+        # is the word-embedding table (:1088-1095) and `.decoder.bias` is `cls.predictions.bias` (HF <= 4.10 BertLMPredictionHead)
+        s["cls.predictions.bias"] = (cfg["vocab_size"],)
+        s["cls.predictions.transform.dense.weight"] = (H, H)
+        s["cls.predictions.transform.dense.bias"] = (H,)
+        s["cls.predictions.transform.LayerNorm.weight"] = (H,)
+        s["cls.predictions.transform.LayerNorm.bias"] = (H,)
+        s["cls.bi_seq_relationship.weight"] = (2, BH)
+        s["cls.bi_seq_relationship.bias"] = (2,)
+        s["cls.imagePredictions.transform.dense.weight"] = (VH, VH)
+        s["cls.imagePredictions.transform.dense.bias"] = (VH,)
+        s["cls.imagePredictions.transform.LayerNorm.weight"] = (VH,)
+        s["cls.imagePredictions.transform.LayerNorm.bias"] = (VH,)
+        s["cls.imagePredictions.decoder.weight"] = (cfg["v_target_size"], VH)
+        s["cls.imagePredictions.decoder.bias"] = (cfg["v_target_size"],)
+        return s
     if cfg.get("training_head_type", "classification") == "nlvr2":
         BH = 2 * BH        # vilbert.py:1262-1265: the head runs on pairs of pooled vectors
     s["classifier.0.dense.weight"] = (BH, BH)
@@ -272,3 +289,29 @@ def vilbert_forward(sd, cfg, sample_list, train=False, pooler_masks=None):
     logits = F.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])
     return {"scores": logits.contiguous().view(-1, cfg["num_labels"]), "sequence_output_t": seq_t, "sequence_output_v": seq_v,
             "pooled_output_t": pooled_t, "pooled_output_v": pooled_v}
+
+
+def vilbert_pretraining_forward(sd, cfg, sample_list, train=False):
+    """ViLBERT.forward (vilbert.py:1423-1472) -> ViLBERTForPretraining.forward (:1097-1240) with `visual_target: 0`:
+    masked_lm_loss = CrossEntropyLoss(ignore_index=-1) over the text stream's prediction scores (HF BertLMPredictionHead, decoder tied
+    to the word embeddings); masked_img_loss = sum over the regions with image_label == 1 of KLDivLoss(log_softmax(scores_v),
+    cls_prob) / their number (:1150-1157); both `unsqueeze(0)`, keyed "{dataset_name}/{dataset_type}/..." (:1459-1469)."""
+    p = prepare_inputs(sample_list)
+    seq_t, seq_v, _, _ = vilbert_base(sd, cfg, p["input_ids"], p["image_feature"], p["image_location"], p["token_type_ids"],
+                                      p["attention_mask"], p["image_attention_mask"], train)
+    eps = cfg["layer_norm_eps"]
+    xt = F.gelu(F.linear(seq_t, sd["cls.predictions.transform.dense.weight"], sd["cls.predictions.transform.dense.bias"]))
+    xt = layer_norm(xt, sd["cls.predictions.transform.LayerNorm.weight"], sd["cls.predictions.transform.LayerNorm.bias"], eps)
+    scores_t = F.linear(xt, sd["bert.embeddings.word_embeddings.weight"], sd["cls.predictions.bias"])
+    xv = F.gelu(F.linear(seq_v, sd["cls.imagePredictions.transform.dense.weight"], sd["cls.imagePredictions.transform.dense.bias"]))
+    xv = layer_norm(xv, sd["cls.imagePredictions.transform.LayerNorm.weight"], sd["cls.imagePredictions.transform.LayerNorm.bias"], 1e-12)
+    scores_v = F.linear(xv, sd["cls.imagePredictions.decoder.weight"], sd["cls.imagePredictions.decoder.bias"])     # :846-858
+    image_label = sample_list["image_labels"]
+    image_target = torch.as_tensor(sample_list["image_info_0"]["cls_prob"], dtype=torch.float32)                    # :1402-1406
+    img_loss = F.kl_div(F.log_softmax(scores_v, dim=2), image_target, reduction="none")                             # :1150-1153
+    picked = torch.eq(image_label, 1)
+    masked_img_loss = torch.sum(img_loss * picked.unsqueeze(2).float()) / max(torch.sum(picked), 0)                 # :1155-1157
+    masked_lm_loss = F.cross_entropy(scores_t.view(-1, cfg["vocab_size"]), sample_list["lm_label_ids"].view(-1), ignore_index=-1)
+    key = "%s/%s" % (sample_list["dataset_name"], sample_list["dataset_type"])
+    return {"losses": {key + "/masked_lm_loss": masked_lm_loss.unsqueeze(0), key + "/masked_img_loss": masked_img_loss.unsqueeze(0)},
+            "prediction_scores_t": scores_t, "prediction_scores_v": scores_v}

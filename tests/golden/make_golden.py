@@ -625,6 +625,112 @@ def make_vilbert():
         print(name, "loss", loss.item(), "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
 
 
+def make_vilbert_pretraining():
+    """ViLBERTForPretraining (vilbert.py:1054-1240, `visual_target: 0`) through the reference's own ViLBERT.forward /
+    get_image_and_text_features, ViLBERTForPretraining.forward, vilbert.BertPreTrainingHeads (HF BertLMPredictionHead tied the
+    pinned-transformers way + BertImagePredictionHead) and ViLBERTBase.  Only `ViLBERTBase.from_pretrained` (network) is
+    replaced by constructing `ViLBERTBase(config)` directly."""
+    from torch import nn
+    from transformers import BertConfig
+    M = refshim.ref_import("mmf.models.vilbert")
+    M.replace_with_jit = lambda: None
+    c = dict(VILBERT_CASES["vilbert_small"], seed=91, v_target_size=53)
+    torch.manual_seed(c["seed"])
+    cfg = vilbert_reference_config(c)
+    cfg["training_head_type"] = "pretraining"
+    cfg["v_target_size"] = c["v_target_size"]
+    cfg["losses"] = []
+    bcfg = BertConfig.from_dict(OmegaConf.to_container(cfg))
+
+    class RefPre(nn.Module):   # module tree of ViLBERTForPretraining (vilbert.py:1055-1077)
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.bert = M.ViLBERTBase(bcfg)
+            self.cls = M.BertPreTrainingHeads(bcfg)
+            self.vocab_size = c["vocab_size"]
+            self.visual_target = 0
+            self.num_negative = 128
+            self.loss_fct = nn.CrossEntropyLoss(ignore_index=-1)
+            self.vis_criterion = nn.KLDivLoss(reduction="none")
+            # tie_weights (:1088-1095) + transformers<=4.10 BertLMPredictionHead (decoder.bias IS predictions.bias)
+            self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+            self.cls.predictions.decoder.bias = self.cls.predictions.bias
+
+        forward = M.ViLBERTForPretraining.forward
+
+    class RefViLBERT(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.model = RefPre()
+
+        get_image_and_text_features = M.ViLBERT.get_image_and_text_features
+        forward = M.ViLBERT.forward
+
+    ref = RefViLBERT().eval()
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+              if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")
+              and not k.startswith("model.cls.predictions.decoder.")}
+    sd = detweights.state_dict(shapes, c["seed"])
+    missing, unexpected = ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    B, T, R, seed = c["B"], c["T"], c["R"], c["seed"]
+    ids = (detweights.uniform(B * T, seed + 100) * c["vocab_size"]).astype(np.int64).reshape(B, T)
+    mask = np.ones((B, T), dtype=np.int64)
+    mask[1, T // 2:] = 0
+    mask[2, T - 3:] = 0
+    ids[mask == 0] = 0
+    seg = np.zeros((B, T), dtype=np.int64)
+    feats = (2.0 * detweights.uniform(B * R * c["v_feature_size"], seed + 102) - 1.0).astype(np.float32).reshape(B, R, -1)
+    bbox = detweights.uniform(B * R * 5, seed + 104).astype(np.float32).reshape(B, R, 5)
+    max_features = np.array([R, R - 2, R - 1], dtype=np.int64)[:B]
+    pick = (detweights.uniform(B * T, seed + 301).reshape(B, T) < 0.3) & (mask == 1)
+    pick[:, 1] = True
+    lm = np.where(pick, (detweights.uniform(B * T, seed + 302) * c["vocab_size"]).astype(np.int64).reshape(B, T), -1)
+    # detector class distributions per region (sparse: exact zeros exercise the 0 * log 0 = 0 convention) and the masked regions
+    raw = detweights.uniform(B * R * c["v_target_size"], seed + 303).reshape(B, R, -1)
+    raw = np.where(raw < 0.6, 0.0, raw) ** 3
+    raw[..., 0] += 1e-3
+    cls_prob = (raw / raw.sum(-1, keepdims=True)).astype(np.float32)
+    image_labels = (detweights.uniform(B * R, seed + 304).reshape(B, R) < 0.4).astype(np.int64)
+    image_labels[:, 2] = 1
+    image_labels[np.arange(R)[None, :] >= max_features[:, None]] = -1          # padded regions carry -1
+    sl = SampleList(input_ids=torch.from_numpy(ids), input_mask=torch.from_numpy(mask), segment_ids=torch.from_numpy(seg),
+                    image_feature_0=torch.from_numpy(feats),
+                    image_info_0=SampleList(max_features=torch.from_numpy(max_features), bbox=torch.from_numpy(bbox), cls_prob=cls_prob),
+                    image_labels=torch.from_numpy(image_labels), lm_label_ids=torch.from_numpy(lm), dataset_name="coco",
+                    dataset_type="train")
+    out = ref(sl)
+    losses = out["losses"]
+    total = sum(v.sum() for v in losses.values())
+    total.backward()
+    rec = {"in_input_ids": ids, "in_input_mask": mask, "in_segment_ids": seg, "in_image_feature_0": feats, "in_bbox": bbox,
+           "in_max_features": max_features, "in_lm_label_ids": lm, "in_cls_prob": cls_prob, "in_image_labels": image_labels}
+    rec["loss_keys"] = np.array(list(losses.keys()))
+    rec["loss_values"] = np.array([float(v.sum()) for v in losses.values()], dtype=np.float64)
+    rec["loss_shapes"] = np.array([",".join(map(str, v.shape)) for v in losses.values()])
+    names, norms, sums = [], [], []
+    for k, p in ref.named_parameters():
+        g = p.grad
+        names.append(k)
+        norms.append(0.0 if g is None else float(g.double().norm()))
+        sums.append(0.0 if g is None else float(g.double().sum()))
+        if g is not None and g.numel() <= 4096:
+            rec["grad::" + k] = g.numpy()
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms)
+    rec["grad_sums"] = np.array(sums)
+    rec["param_names"] = np.array(list(shapes.keys()))
+    rec["param_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
+    rec["state_dict_keys"] = np.array(sorted(k for k in ref.state_dict().keys()
+                                             if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")))
+    rec["case"] = np.array(repr(c))
+    path = os.path.join(HERE, "vilbert_pretraining.npz")
+    np.savez_compressed(path, **rec)
+    print("vilbert_pretraining", dict(zip(rec["loss_keys"], rec["loss_values"])), rec["loss_shapes"], "->", path, os.path.getsize(path), "bytes")
+
+
 UNITER_CASES = {
     "uniter_small64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
                            max_position_embeddings=40, img_dim=72, head_hidden_size=256, num_labels=13, B=3, T=12, R=7, seed=51),
@@ -1101,7 +1207,7 @@ def make_visual_bert_pretraining():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "uniter", "m4c"]
+    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "vilbert_pretraining", "uniter", "m4c"]
     if "visual_bert" in which:
         main()
     if "nlvr2" in which:
@@ -1116,6 +1222,8 @@ if __name__ == "__main__":
         make_mmft()
     if "vilbert" in which:
         make_vilbert()
+    if "vilbert_pretraining" in which:
+        make_vilbert_pretraining()
     if "uniter" in which:
         make_uniter()
     if "m4c" in which:

@@ -195,6 +195,35 @@ def load_pretraining_case():
     return z, case, cfg, sd, sample
 
 
+def load_vilbert_pretraining_case():
+    """`vilbert_pretraining`: ViLBERT with the pretraining heads (masked LM + masked region classification, visual_target 0)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "vilbert_pretraining.npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {k[len("model."):]: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    cfg = dict(
+        vocab_size=case["vocab_size"], hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"],
+        num_attention_heads=case["num_attention_heads"], intermediate_size=case["intermediate_size"],
+        max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2, layer_norm_eps=1e-12,
+        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, pad_token_id=0, v_feature_size=case["v_feature_size"],
+        v_hidden_size=case["v_hidden_size"], v_num_hidden_layers=case["v_num_hidden_layers"],
+        v_num_attention_heads=case["v_num_attention_heads"], v_intermediate_size=case["v_intermediate_size"],
+        bi_hidden_size=case["bi_hidden_size"], bi_num_attention_heads=case["bi_num_attention_heads"],
+        bi_intermediate_size=case["bi_intermediate_size"], v_attention_probs_dropout_prob=0.1, v_hidden_dropout_prob=0.1,
+        v_biattention_id=list(case["v_biattention_id"]), t_biattention_id=list(case["t_biattention_id"]), fusion_method="mul",
+        num_labels=case["num_labels"], initializer_range=0.02, dynamic_attention=False, training_head_type="pretraining",
+        v_target_size=case["v_target_size"])
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),
+        "image_info_0": {"max_features": torch.from_numpy(z["in_max_features"]), "bbox": torch.from_numpy(z["in_bbox"]),
+                         "cls_prob": torch.from_numpy(z["in_cls_prob"])},
+        "image_labels": torch.from_numpy(z["in_image_labels"]), "lm_label_ids": torch.from_numpy(z["in_lm_label_ids"]),
+        "dataset_name": "coco", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample
+
+
 def load_m4c_case(name="m4c_small64"):
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))

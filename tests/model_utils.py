@@ -159,6 +159,17 @@ def build_vilbert(cfg, sd=None, device="cuda", **over):
     return model.to(device)
 
 
+def build_vilbert_pretraining(cfg, sd=None, device="cuda", **over):
+    """ViLBERT with the pretraining heads; the tied masked-LM decoder keys are filled from their owners."""
+    model = build_model(vilbert_model_config(cfg, training_head_type="pretraining", losses=[], v_target_size=cfg["v_target_size"], **over))
+    if sd is not None:
+        full = {"model." + k: v for k, v in sd.items()}
+        full["model.cls.predictions.decoder.weight"] = full["model.bert.embeddings.word_embeddings.weight"]
+        full["model.cls.predictions.decoder.bias"] = full["model.cls.predictions.bias"]
+        model.load_state_dict(full, strict=True)
+    return model.to(device)
+
+
 def uniter_model_config(cfg, **over):
     """MMF model_config.uniter (configs/models/uniter/defaults.yaml), classification on task vqa2."""
     bert = dict(hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],

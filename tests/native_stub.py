@@ -152,6 +152,19 @@ def _vocab_ce_bwd(logits, labels, lse, count, gloss, dlogits, ldd, R, Cn, ignore
     calls.append(("vocab_cross_entropy_bwd", R, Cn))
 
 
+def _soft_kl_fwd(logits, target, row_label, lse, tsum, rowloss, loss, count, R, Cn):
+    assert logits.dtype == torch.float32 and target.dtype == torch.float32 and row_label.dtype == torch.int64 and row_label.numel() == R
+    _need(logits, R, logits.stride(0), Cn, "soft_kl logits"); _need(target, R, target.stride(0), Cn, "soft_kl target")
+    assert lse.numel() >= R and tsum.numel() >= R and rowloss.numel() >= R and loss.numel() == 1 and count.numel() == 1
+    calls.append(("soft_target_kl_fwd", R, Cn))
+
+
+def _soft_kl_bwd(logits, target, row_label, lse, tsum, count, gloss, dlogits, ldd, R, Cn):
+    assert ldd % 8 == 0 and ldd >= Cn and dlogits.dtype == torch.bfloat16 and gloss.numel() == 1
+    _need(dlogits, R, ldd, ldd, "soft_kl dlogits")
+    calls.append(("soft_target_kl_bwd", R, Cn))
+
+
 def _copy_rows(src, src_bstride, dst, dst_bstride, nb, rpb, H):
     assert H % 8 == 0
     _need(src, (nb - 1) * src_bstride + rpb, H, H, "copy_rows src"); _need(dst, (nb - 1) * dst_bstride + rpb, H, H, "copy_rows dst")
@@ -204,7 +217,7 @@ def _bce_rowmask_bwd(scores, targets, w, count, gloss, d, rows, Nn):
     assert d.numel() == rows * Nn and gloss.numel() == 1
 
 
-_CHECKED = {"vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
+_CHECKED = {"soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
             "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,

@@ -177,3 +177,66 @@ def test_mmbt_pretraining_golden_forward_loss_gradients_and_state_dict():
     with mmf_amd.fp32_inference():
         out32 = model(SampleList(sample_to(sample, "cuda")))
     assert np.abs(out32["logits"].cpu().numpy() - z["logits"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("R,C", [(21, 53), (100, 1601)])
+def test_soft_target_kl_kernels_match_torch(R, C):
+    g = torch.Generator().manual_seed(R * C)
+    logits = torch.randn(R, C, generator=g) * 2.0
+    raw = torch.rand(R, C, generator=g)
+    raw = torch.where(raw < 0.5, torch.zeros_like(raw), raw)
+    raw[:, 0] += 1e-3
+    target = raw / raw.sum(1, keepdim=True)
+    label = torch.randint(-1, 2, (R,), generator=g)
+    label[0] = 1
+    x = logits.clone().requires_grad_(True)
+    kl = torch.nn.functional.kl_div(torch.log_softmax(x, 1), target, reduction="none")
+    ref = (kl * (label == 1).unsqueeze(1).float()).sum() / (label == 1).sum()
+    ref.backward()
+    xd, td, ld_ = logits.cuda(), target.cuda(), label.cuda()
+    lse = torch.empty(R, device="cuda"); tsum = torch.empty(R, device="cuda"); rowloss = torch.empty(R, device="cuda")
+    loss = torch.empty(1, device="cuda"); count = torch.empty(1, device="cuda")
+    nat.soft_target_kl_fwd(xd, td, ld_, lse, tsum, rowloss, loss, count, R, C)
+    assert int(count.item()) == int((label == 1).sum()) and abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    ldd = (C + 7) // 8 * 8
+    d = torch.full((R, ldd), 9.0, dtype=torch.bfloat16, device="cuda")
+    nat.soft_target_kl_bwd(xd, td, ld_, lse, tsum, count, torch.tensor([1.5], device="cuda"), d, ldd, R, C)
+    got = d.float().cpu()
+    assert bool((got[:, C:] == 0).all()) and bool((got[label != 1] == 0).all())
+    assert rel_err(got[:, :C], 1.5 * x.grad) <= 6e-3
+
+
+def test_vilbert_pretraining_golden_losses_gradients_and_state_dict():
+    """ViLBERTForPretraining (mmf/models/vilbert.py:1054-1240, visual_target 0) against the reference's own run: masked-LM and
+    masked-region losses (both shaped [1], keyed like the reference), every gradient, state-dict keys."""
+    from tests.model_utils import build_vilbert_pretraining
+    z, case, cfg, sd, sample = G.load_vilbert_pretraining_case()
+    model = build_vilbert_pretraining(cfg, sd)
+    assert sorted(model.state_dict().keys()) == sorted(str(k) for k in z["state_dict_keys"])
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    ref = dict(zip((str(k) for k in z["loss_keys"]), z["loss_values"]))
+    assert set(out["losses"]) == set(ref)
+    for k, v in out["losses"].items():
+        assert tuple(v.shape) == (1,) and abs(v.item() - ref[k]) <= TOL * abs(ref[k]), (k, v.item(), ref[k])
+    sum(v.sum() for v in out["losses"].values()).backward()
+    params = dict(model.named_parameters())
+    bad = {}
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        gname = str(gname)
+        p = params[gname]
+        if norm == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, gname
+            continue
+        if gname.endswith(".key.bias") or gname.endswith("key1.bias") or gname.endswith("key2.bias"):
+            continue
+        assert p.grad is not None, gname
+        e = abs(float(p.grad.double().norm()) - norm) / norm
+        if e > TOL:
+            bad[gname] = e
+        full = "grad::" + gname
+        if full in z.files and norm > 1e-6:
+            e2 = rel_err(p.grad, torch.from_numpy(z[full]))
+            if e2 > TOL:
+                bad[gname + " (full)"] = e2
+    assert not bad, bad

@@ -61,3 +61,29 @@ def test_vilbert_oracle_nlvr2_matches_reference():
         if norm == 0.0 or key.endswith(".key.bias") or key.endswith("key1.bias") or key.endswith("key2.bias"):
             continue
         assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+
+
+def test_vilbert_pretraining_oracle_matches_reference():
+    """ViLBERTForPretraining (vilbert.py:1054-1240, visual_target 0): both losses and every gradient against the reference's own run."""
+    from tests.golden_utils import load_vilbert_pretraining_case
+    z, case, cfg, sd, sample = load_vilbert_pretraining_case()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.vilbert_pretraining_forward(sd, cfg, dict(sample))
+    ref = dict(zip((str(k) for k in z["loss_keys"]), z["loss_values"]))
+    assert set(out["losses"]) == set(ref) == {"coco/train/masked_lm_loss", "coco/train/masked_img_loss"}
+    for k, v in out["losses"].items():
+        assert tuple(v.shape) == (1,) and abs(v.item() - ref[k]) <= 1e-5 * abs(ref[k]), k
+    sum(v.sum() for v in out["losses"].values()).backward()
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        key = str(gname)[len("model."):]
+        g = sd[key].grad
+        if norm == 0.0:       # poolers, bi_seq_relationship, biOutput.q_dense*: outside both losses
+            assert g is None or float(g.abs().max()) == 0.0, key
+            continue
+        if key.endswith(".key.bias") or key.endswith("key1.bias") or key.endswith("key2.bias"):
+            continue
+        assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+        full = "grad::" + str(gname)
+        if full in z.files:
+            np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)

@@ -1000,7 +1000,10 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
         dproj_w = torch.empty(H, D, dtype=F32, device=dev)
         nat.gemm(dvis, f2, dproj_w, H, D, B * N, H, D, D, a_kmajor=True, b_kmajor=True)
         dproj_b = _colsum(dvis, H, B * N, H)
-        return (None, None, None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dproj_w, dproj_b, None, None, None, None)
+        dfeats = None
+        if ctx.needs_input_grad[0]:        # a trainable modal encoder ahead of the projection (finetune_faster_rcnn_fpn_fc7): dX = dY W
+            dfeats = _dgrad(dvis, H, proj_w16, B * N, H, D).view(B, N, D)
+        return (dfeats, None, None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dproj_w, dproj_b, None, None, None, None)
 
 
 class CrossEntropyFn(torch.autograd.Function):

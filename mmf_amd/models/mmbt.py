@@ -22,8 +22,8 @@ from mmf_amd import fp32_path as F32P
 from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
-from mmf_amd.modules.hf_layers import (
-    BertConfig, BertModelJit, BertPredictionHeadTransform, BertPreTrainingHeads, Linear, init_bert_weights)
+from mmf_amd.modules.encoders import MultiModalEncoderBase
+from mmf_amd.modules.hf_layers import BertPredictionHeadTransform, BertPreTrainingHeads, Linear, init_bert_weights
 from mmf_amd.utils.configuration import to_container
 from mmf_amd.utils.modeling import get_optimizer_parameters_for_bert
 
@@ -117,47 +117,30 @@ class MMBTModel(nn.Module):
         return self.transformer.embeddings.word_embeddings
 
 
-def _build_text_config(config):
-    """TransformerEncoder's config: bert-base-uncased defaults overridden by `text_encoder.params`
-    (mmf/modules/encoders.py TransformerEncoder / mmf/utils/modeling... `build_config`)."""
-    te = to_container(config.get("text_encoder", {}) or {})
-    if te and te.get("type", "transformer") != "transformer":
-        raise NotImplementedError("text_encoder.type=%r: only the BERT transformer encoder is built" % te.get("type"))
-    params = dict(te.get("params", {}) or {})
-    params.pop("bert_model_name", None)
-    num_segments = params.pop("num_segments", 2)
-    params.pop("random_init", None)
-    return BertConfig.from_dict(params), num_segments
-
-
-def _build_modal_encoder(config):
-    me = to_container(config.get("modal_encoder", {}) or {})
-    kind = me.get("type", "identity") if me else "identity"
-    if not config.get("direct_features_input", False) or kind not in ("identity", None):
-        raise NotImplementedError(
-            "MMBT modal_encoder type=%r with direct_features_input=%r: only pre-extracted features through the identity "
-            "encoder are on the built path (the CNN / detectron feature extractors are out of scope, SURVEY.md §8)"
-            % (kind, config.get("direct_features_input", False)))
-    return nn.Identity()
-
-
-class MMBTBase(nn.Module):
-    """mmbt.py:327-444 (+ MultiModalEncoderBase, mmf/modules/encoders.py)."""
+class MMBTBase(MultiModalEncoderBase):
+    """mmbt.py:327-444 on `MultiModalEncoderBase` (mmf/modules/encoders.py:588-646): the text encoder is the registered
+    `"transformer"` encoder (`BertModelJit` on the HIP kernels), the modal encoder one of the image-FEATURE encoders (identity, the
+    trainable fc7 layer `finetune_faster_rcnn_fpn_fc7` of projects/hateful_memes/configs/mmbt/with_features.yaml, a linear projection);
+    raw-image CNN encoders raise (out of scope)."""
 
     def __init__(self, config, *args, **kwargs):
-        super().__init__()
-        self.config = config
-        self._is_direct_features_input = config.get("direct_features_input", False)
-        self.build()
+        super().__init__(config, *args, **kwargs)
 
     def build(self):
-        self._encoder_config, self.num_max_segment = _build_text_config(self.config)
-        modal_encoder = _build_modal_encoder(self.config)
+        encoders = self._build_encoders(self.config)
+        text_encoder, modal_encoder = encoders[0], encoders[1]
+        if text_encoder is None or not hasattr(text_encoder, "config"):
+            raise NotImplementedError("MMBT needs a transformer text encoder (text_encoder.type: transformer)")
+        if modal_encoder is None:
+            modal_encoder = nn.Identity()
+        self._encoder_config = text_encoder.config
         self._mmbt_config = MMBTConfig(self._encoder_config, num_labels=self.config.num_labels,
                                        modal_hidden_size=self.config.modal_hidden_size)
         self.use_modal_start_token = self.config.use_modal_start_token
         self.use_modal_end_token = self.config.use_modal_end_token
-        self.mmbt = MMBTModel(self._mmbt_config, BertModelJit(self._encoder_config), modal_encoder)
+        te_params = (self.config.text_encoder.get("params", None) or {}) if self.config.get("text_encoder", None) else {}
+        self.num_max_segment = te_params.get("num_segments", 2)                       # mmbt.py:345
+        self.mmbt = MMBTModel(self._mmbt_config, text_encoder, modal_encoder)
 
     @property
     def encoder_config(self):

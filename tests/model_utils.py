@@ -59,7 +59,7 @@ def mmbt_model_config(cfg, **over):
         model="mmbt", training_head_type="classification", bert_model_name=None, direct_features_input=True,
         freeze_text=False, freeze_modal=False, freeze_complete_base=False, finetune_lr_multiplier=1, fused_feature_only=False,
         modal_hidden_size=cfg["modal_hidden_size"], text_hidden_size=cfg["hidden_size"], num_labels=cfg["num_labels"],
-        modal_encoder=dict(type="identity", params={}), use_modal_start_token=cfg.get("use_modal_start_token", True),
+        modal_encoder=dict(type="identity", params=dict(in_dim=cfg["modal_hidden_size"])), use_modal_start_token=cfg.get("use_modal_start_token", True),
         use_modal_end_token=cfg.get("use_modal_end_token", True),
         text_encoder=dict(type="transformer", params=dict(
             num_segments=cfg.get("num_segments", 2), bert_model_name=None, hidden_size=cfg["hidden_size"],

@@ -168,3 +168,48 @@ def test_mmbt_training_step_is_seed_reproducible_and_updates():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0], losses
+
+
+def test_mmbt_with_trainable_fc7_modal_encoder_matches_oracle():
+    """projects/hateful_memes/configs/mmbt/with_features.yaml: `modal_encoder: finetune_faster_rcnn_fpn_fc7` (mmf/modules/encoders.py:
+    116-180, relu(lc(x)) on the pre-extracted features, trainable) ahead of the modal projection.  The oracle takes the encoded
+    features as a non-leaf tensor, so autograd carries its loss back into `lc`: scores, loss and the encoder's gradients must agree."""
+    z, case, cfg, sd, sample = load_mmbt_case()
+    D = cfg["modal_hidden_size"]
+    from tests.model_utils import mmbt_model_config
+    from mmf_amd.utils.build import build_model
+    import warnings
+    mc = mmbt_model_config(cfg, modal_encoder=dict(type="finetune_faster_rcnn_fpn_fc7", params=dict(
+        in_dim=D, out_dim=D, weights_file="absent_w.pkl", bias_file="absent_b.pkl")))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = build_model(mc)
+    g = torch.Generator().manual_seed(5)
+    lc_w = torch.randn(D, D, generator=g) * 0.1
+    lc_b = torch.randn(D, generator=g) * 0.1
+    full = {"model." + k: v for k, v in sd.items()}
+    for alias, src in O.SHARED.items():
+        full["model." + alias] = sd[src]
+    full["model.bert.mmbt.modal_encoder.encoder.lc.weight"] = lc_w
+    full["model.bert.mmbt.modal_encoder.encoder.lc.bias"] = lc_b
+    model.load_state_dict(full, strict=True)
+    model = model.to("cuda")
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    (key, loss), = out["losses"].items()
+    loss.backward()
+    wr, br = lc_w.clone().requires_grad_(True), lc_b.clone().requires_grad_(True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    s2 = dict(sample)
+    s2["image_feature_0"] = torch.relu(torch.nn.functional.linear(sample["image_feature_0"], wr, br))
+    ref = O.mmbt_forward(sdr, cfg, s2, train=False)
+    ref_loss = O.cross_entropy(ref["scores"], sample["targets"])
+    ref_loss.backward()
+    assert (out["scores"].float().cpu() - ref["scores"]).abs().max().item() <= TOL
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    lc = model.model.bert.mmbt.modal_encoder.encoder.lc
+    assert lc.weight.grad is not None and lc.bias.grad is not None
+    assert rel_err(lc.weight.grad, wr.grad) <= 6e-2, rel_err(lc.weight.grad, wr.grad)
+    assert rel_err(lc.bias.grad, br.grad) <= 6e-2, rel_err(lc.bias.grad, br.grad)
+    pw = model.model.bert.mmbt.modal_encoder.proj_embeddings.weight
+    assert rel_err(pw.grad, sdr["bert.mmbt.modal_encoder.proj_embeddings.weight"].grad) <= TOL

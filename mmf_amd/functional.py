@@ -153,9 +153,12 @@ class ShadowCache:
         self._t[key] = (ent[0], tbuf)
         return tbuf
 
-    def refresh_transposed(self):
-        """Re-transpose every live twin from its (already updated) shadow: called by the fused optimizer's step."""
-        pairs = [(self._store[k][1], t[1]) for k, t in self._t.items() if k in self._store and self._store[k][0] == t[0]]
+    def refresh_transposed(self, only=None, skip=None):
+        """Re-transpose every live twin from its (already updated) shadow: called by the fused optimizer's step.  `only` / `skip`:
+        ids of the head parameters whose twins to refresh / leave alone (the optimizer-in-backward refreshes a layer's twins with
+        that layer's update and the final step skips them)."""
+        pairs = [(self._store[k][1], t[1]) for k, t in self._t.items() if k in self._store and self._store[k][0] == t[0]
+                 and (only is None or k in only) and (skip is None or k not in skip)]
         if pairs:
             nat.transpose_multi(pairs)
 
@@ -661,6 +664,29 @@ class _WgradOverlap:
 wgrad_overlap = _WgradOverlap()
 
 
+class _ParamUpdateHook:
+    """Optimizer-in-backward: inside `with param_update(fn):` every TransformerLayerFn.backward hands the layer's weight and bias
+    parameters with their finished gradients to `fn(params, grads)` right after the grouped weight-gradient launch, instead of
+    leaving them for an optimizer step at the end of the backward pass.  The fused AdamW is HBM-bound while the input-gradient
+    GEMMs of the layers below are MFMA / LDS-bound, so the update of layer L runs beside the backward of layers < L on a second
+    stream (`AdamW.update_in_backward`, a parallel branch of the captured hipGraph).  LayerNorm parameters are not handed over:
+    under `ln_defer` their gradients are finished by the multi-tensor reduction at the end of the step."""
+
+    def __init__(self):
+        self.fn = None
+
+    @contextlib.contextmanager
+    def __call__(self, fn):
+        old, self.fn = self.fn, fn
+        try:
+            yield
+        finally:
+            self.fn = old
+
+
+param_update = _ParamUpdateHook()
+
+
 class TransformerLayerFn(torch.autograd.Function):
     """BertLayerJit.forward (hf_layers.py:255-292) as ONE autograd node: the attention sub-layer (AttentionBlockFn) followed by
     the feed-forward sub-layer (FeedForwardFn), same kernels and same saved tensors.  What the fusion buys is in backward:
@@ -687,6 +713,7 @@ class TransformerLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean1, rstd1, a_out, u, hh, y2, mean2, rstd2, wqkv16, wo16, w1_16, w2_16,
                               g1.detach(), g2.detach(), mask_add, o32)
         ctx.meta = (B, S, H, I, heads, drop_attn, drop_hid1, drop_hid2, tail)
+        ctx.update_params = (wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2)      # leaves: for `param_update` (optimizer in backward)
         return out.view(B, S, H)
 
     @staticmethod
@@ -717,6 +744,9 @@ class TransformerLayerFn(torch.autograd.Function):
         p_q, dwqkv, dbqkv = _wgrad_problem(dqkv, 3 * H, x2, M, 3 * H, H, True)
         p_o, dwo, dbo = _wgrad_problem(dlin1, H, ctxt, M, H, H, True)
         wgrad_overlap.launch([p_1, p_2, p_q, p_o], (du, a_out, dlin2, hh, dqkv, x2, dlin1, ctxt, dw1, db1, dw2, db2, dwqkv, dbqkv, dwo, dbo))
+        if param_update.fn is not None and wgrad_overlap.stream is None:
+            param_update.fn(ctx.update_params, (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
+                                                dwo, dbo, dw1, db1, dw2, db2))
         return ((dx.view(B, S, H) if dx is not None else None),
                 dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, dbe1,
                 dw1, db1, dw2, db2, dg2, dbe2) + (None,) * 13

@@ -38,6 +38,9 @@ class AdamW(torch.optim.Optimizer):
         self._schedule = (0, 0.0, 0.0) if schedule is None else (1, float(schedule[1]), float(schedule[2]))
         self._dev_state = None
         self.grad_scale = 1.0       # every gradient is multiplied by this inside the update (a data-parallel SUM becomes the mean)
+        self._early = None          # ids of the parameters already updated inside this step's backward (update_in_backward)
+        self._early_stream = None
+        self._group_of = None
 
     @torch.no_grad()
     def ensure_state(self, params=None):
@@ -66,23 +69,80 @@ class AdamW(torch.optim.Optimizer):
         self._clip = (norm_sq, float(max_norm))
         return norm_sq.sqrt()[0] * self.grad_scale
 
+    # ---- optimizer in backward ---------------------------------------------------------------------------------------
+    # The update is HBM-bound (30 bytes per parameter), the backward GEMMs are MFMA / LDS-bound: run on a second stream, the
+    # update of an encoder layer hides beside the backward of the layers below it.  Legal whenever nothing needs ALL gradients
+    # before the first update: no gradient clipping (`clip_gradients: false` in the reference's VQA2 config,
+    # mmf/configs/defaults.yaml:101) and no cross-rank reduction (one rank).  Same kernel, same arithmetic, same result
+    # (tests/test_model_parity_gpu.py::test_optimizer_in_backward_equals_end_of_step_update).  OPT-IN (GraphedTrainStep(overlap_update=
+    # True) / MMF_AMD_ADAM_OVERLAP=1): at the VisualBERT VQA2 shape it measured SLOWER (8.53 vs 8.25 ms, same box) — the streamed
+    # 213 MB per layer push the GEMM operand panels out of L2.
+    @torch.no_grad()
+    def begin_step(self, stream):
+        """Open a step whose layer updates arrive through `update_in_backward` (functional.param_update): advances the device-side
+        step count / schedule factor now; `step()` then closes it (updates what is left, joins `stream`)."""
+        if self._clip is not None:
+            raise RuntimeError("optimizer-in-backward cannot be combined with gradient clipping (the clip factor needs every gradient)")
+        if self.capturable:
+            if self._dev_state is None:
+                self._dev_state = torch.zeros(2, dtype=torch.float32, device=self.param_groups[0]["params"][0].device)
+            nat.optim_state_advance(self._dev_state, *self._schedule)
+        self._early, self._early_stream = set(), stream
+        if self._group_of is None:
+            self._group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+
+    @torch.no_grad()
+    def update_in_backward(self, params, grads):
+        if self._early is None:
+            return
+        main, side = torch.cuda.current_stream(), self._early_stream
+        by_group = {}
+        for p, g in zip(params, grads):
+            grp = self._group_of.get(id(p))
+            if grp is None or g is None or not p.requires_grad:
+                continue
+            if id(p) in self._early:
+                raise RuntimeError("optimizer-in-backward: a parameter received a second gradient in one step (shared weights); "
+                                   "use the end-of-step update")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["step"] = int(st.get("step", 0)) + 1
+            self._early.add(id(p))
+            by_group.setdefault((id(grp), st["step"]), (grp, st["step"], []))[2].append(
+                (p, g if g.is_contiguous() else g.contiguous(), st["exp_avg"], st["exp_avg_sq"], Fn.shadows.slot(p), grp["lr"],
+                 grp["weight_decay"]))
+        if not by_group:
+            return
+        side.wait_stream(main)                  # the gradients were produced on the launching stream
+        with torch.cuda.stream(side):
+            for grp, step, items in by_group.values():
+                b1, b2 = grp["betas"]
+                nat.adamw_multi(items, b1, b2, grp["eps"], step, grp["correct_bias"], 1 if self.torch_mode else 0, self.grad_scale,
+                                None, 0.0, self._dev_state if self.capturable else None)
+            Fn.shadows.refresh_transposed(only={id(p) for p in params})
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        early, self._early = self._early, None
         dev_state = None
         if self.capturable:
             if self._dev_state is None:
                 dev = self.param_groups[0]["params"][0].device
                 self._dev_state = torch.zeros(2, dtype=torch.float32, device=dev)
-            nat.optim_state_advance(self._dev_state, *self._schedule)
+            if early is None:          # (begin_step already advanced the counters of a step opened for in-backward updates)
+                nat.optim_state_advance(self._dev_state, *self._schedule)
             dev_state = self._dev_state
         for group in self.param_groups:
             by_step = {}
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (early is not None and id(p) in early):
                     continue
                 if p.grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
@@ -103,7 +163,10 @@ class AdamW(torch.optim.Optimizer):
                 nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
                                 self.grad_scale, norm_sq, max_norm, dev_state)
         self._clip = None
-        Fn.shadows.refresh_transposed()     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
+        Fn.shadows.refresh_transposed(skip=early)     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
+        if early is not None:
+            torch.cuda.current_stream().wait_stream(self._early_stream)      # join the in-backward updates
+            self._early_stream = None
         return loss
 
     # ---- checkpoints ---------------------------------------------------------------------------------------------------

@@ -66,13 +66,23 @@ class GraphedTrainStep:
     parameter is updated and no step is counted before the first replay; the optimizer's moments are allocated up front
     (`ensure_state`) so that the captured update contains no zero-fill."""
 
-    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None, overlap_wgrad=None):
+    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None, overlap_wgrad=None, overlap_update=None):
         """`overlap_wgrad`: run every layer's grouped weight-gradient GEMM on a second stream (a parallel branch of the graph)
-        beside the dgrad chain of the layers below; default from MMF_AMD_WGRAD_OVERLAP (off)."""
+        beside the dgrad chain of the layers below; default from MMF_AMD_WGRAD_OVERLAP (off).
+        `overlap_update`: optimizer in backward — each encoder layer's AdamW update (HBM-bound) is launched on a second stream as
+        soon as the layer's weight gradients exist and runs beside the backward of the layers below (MFMA-bound); default from
+        MMF_AMD_ADAM_OVERLAP (OFF: measured slower at the VisualBERT VQA2 shape, 8.53 against 8.25 ms per step on the same box —
+        the streaming update evicts the GEMMs' operand panels from L2 and costs them more than the 0.33 ms it hides; kept, with its
+        bit-equality test, for shapes whose backward leaves the chip idle).  Same arithmetic as the end-of-step update; not
+        combinable with gradient clipping."""
         self.model = model
         if overlap_wgrad is None:
             overlap_wgrad = os.environ.get("MMF_AMD_WGRAD_OVERLAP", "0") == "1"
+        if overlap_update is None:
+            overlap_update = os.environ.get("MMF_AMD_ADAM_OVERLAP", "0") == "1"
         self.side_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
+        self.update_stream = (torch.cuda.Stream(device=next(model.parameters()).device)
+                              if (overlap_update and optimizer is not None and not overlap_wgrad and hasattr(optimizer, "begin_step")) else None)
         self.optimizer = optimizer
         if optimizer is not None and not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs an optimizer whose step reads its counters from device memory (capturable=True)")
@@ -107,12 +117,15 @@ class GraphedTrainStep:
         # created on; if an earlier eager step created them on the legacy default stream, running them inside the
         # capture drags that stream into it and hipStreamEndCapture crashes.  Capturing the gradients directly keeps
         # every captured node on the capture stream.
-        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer():
+        early = self.update_stream is not None and update
+        if early:
+            self.optimizer.begin_step(self.update_stream)
+        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.param_update(self.optimizer.update_in_backward if early else None):
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g
         if self.optimizer is not None and update:
-            self.optimizer.step()
+            self.optimizer.step()       # (closes a step opened by begin_step: the remaining parameters, then joins the update stream)
         return out, loss
 
     def __call__(self, batch=None):

@@ -56,3 +56,88 @@ def test_optimizer_groups_and_unbuilt_variants():
         build_model(mmft_model_config(cfg, transformer_base="roberta-base"))
     with pytest.raises(RuntimeError):
         build_model(mmft_model_config(cfg, heads=[dict(type="mlm")]))
+
+
+# ---- the reference's own preprocessing tests (tests/models/test_mmf_transformer.py:183-402), ported ----------------------------------
+def _ported_model(extra=(), text_keys=("text",)):
+    from mmf_amd.common.sample import SampleList  # noqa: F401
+    z, case, cfg, sd, sample = load_mmft_case()
+    mods = [dict(type="image", key="image", embedding_dim=256, position_dim=1, segment_id=0, encoder=dict(type="identity"))]
+    for i, k in enumerate(text_keys):
+        mods.append(dict(type="text", key=k, embedding_dim=cfg["hidden_size"], position_dim=128, segment_id=i + 1,
+                         encoder=dict(type="identity")))
+    mods += list(extra)
+    return build_model(mmft_model_config(dict(cfg, max_position_embeddings=128), modalities=mods, num_labels=2))
+
+
+def _eq(a, b):
+    assert torch.equal(a.long(), b.long()), (a, b)
+
+
+def test_one_dim_feature_preprocessing():
+    from mmf_amd.common.sample import SampleList
+    mmft = _ported_model()
+    sl = SampleList(dict(image=torch.rand(2, 256), text=torch.randint(0, 200, (2, 128))))
+    t = mmft.preprocess_sample(sl)
+    ids = t["input_ids"]
+    assert ids["image"].dim() == 3 and list(ids["image"].size()) == [2, 1, 256]
+    assert ids["text"].dim() == 2 and list(ids["text"].size()) == [2, 128]
+    _eq(t["position_ids"]["image"], torch.tensor([[0], [0]]))
+    _eq(t["position_ids"]["text"], torch.arange(0, 128).unsqueeze(0).expand((2, 128)))
+    masks = mmft._infer_masks(sl, ids)
+    _eq(masks["image"], torch.tensor([[1], [1]]))
+    _eq(masks["text"], torch.ones((2, 128)))
+    _eq(t["segment_ids"]["image"], torch.tensor([[0], [0]]))
+    _eq(t["segment_ids"]["text"], torch.ones((2, 128)))
+    _eq(t["mlm_labels"]["combined_labels"], torch.full((2, 129), dtype=torch.long, fill_value=-1))
+
+
+def _compare_processed_for_multimodality(t, lm_labels_sum=0):
+    ids = t["input_ids"]
+    assert list(ids["image"].size()) == [2, 1, 256] and list(ids["body"].size()) == [2, 128] and list(ids["ocr"].size()) == [2, 128]
+    _eq(t["position_ids"]["image"], torch.tensor([[0], [0]]))
+    for k in ("body", "ocr"):
+        _eq(t["position_ids"][k], torch.arange(0, 128).unsqueeze(0).expand((2, 128)))
+        _eq(t["masks"][k], torch.ones((2, 128)))
+    _eq(t["masks"]["image"], torch.tensor([[1], [1]]))
+    _eq(t["segment_ids"]["image"], torch.tensor([[0], [0]]))
+    _eq(t["segment_ids"]["body"], torch.ones((2, 128)))
+    _eq(t["segment_ids"]["ocr"], torch.full((2, 128), dtype=torch.long, fill_value=2))
+    assert list(t["mlm_labels"]["combined_labels"].size()) == [2, 257]
+    assert t["mlm_labels"]["combined_labels"].sum().item() == lm_labels_sum - 2          # -2: the image position's -1 labels
+
+
+def test_stacked_feature_preprocessing():
+    from mmf_amd.common.sample import SampleList
+    mmft = _ported_model(text_keys=("body", "ocr"))
+    lm = torch.randint(-1, 200, (2, 2, 128))
+    sl = SampleList(dict(image=torch.rand(2, 256), input_ids=torch.randint(0, 200, (2, 2, 128)), lm_label_ids=lm))
+    _compare_processed_for_multimodality(mmft.preprocess_sample(sl), lm.sum().item())
+
+
+def test_modality_key_preprocessing():
+    from mmf_amd.common.sample import SampleList
+    mmft = _ported_model(text_keys=("body", "ocr"))
+    lm = torch.randint(-1, 200, (2, 128))
+    sl = SampleList(dict(image=torch.rand(2, 256), body=torch.randint(0, 200, (2, 128)), ocr=torch.randint(0, 200, (2, 128)),
+                         lm_label_ids=lm))
+    _compare_processed_for_multimodality(mmft.preprocess_sample(sl), lm.sum().item() * 2)
+
+
+def test_custom_feature_and_mask_preprocessing():
+    from mmf_amd.common.sample import SampleList
+    extra = dict(type="my_random_feature", key="my_random_feature", embedding_dim=128, position_dim=4, segment_id=3,
+                 encoder=dict(type="identity"))
+    mmft = _ported_model(extra=(extra,))
+    text_mask = torch.ones(2, 128); text_mask[:, 70:] = 0
+    fmask = torch.ones(2, 4); fmask[:, 3:] = 0
+    sl = SampleList(dict(image=torch.rand(2, 256), text=torch.randint(0, 200, (2, 128)), text_mask=text_mask,
+                         my_random_feature=torch.rand(2, 4, 128), my_random_feature_mask=fmask))
+    t = mmft.preprocess_sample(sl)
+    ids = t["input_ids"]
+    assert list(ids["image"].size()) == [2, 1, 256] and list(ids["text"].size()) == [2, 128]
+    assert list(ids["my_random_feature"].size()) == [2, 4, 128]
+    _eq(t["position_ids"]["my_random_feature"], torch.arange(0, 4).unsqueeze(0).expand((2, 4)))
+    assert t["masks"]["text"].sum().item() == 140 and t["masks"]["my_random_feature"].sum().item() == 6
+    _eq(t["segment_ids"]["text"], torch.ones((2, 128)))
+    _eq(t["segment_ids"]["my_random_feature"], torch.full((2, 4), dtype=torch.long, fill_value=3))

@@ -1145,6 +1145,35 @@ class MaskedRegionHeadFn(torch.autograd.Function):
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
 
 
+class TakeRowsFn(torch.autograd.Function):
+    """out[r] = x[idx[r]] for a list of DISTINCT row indices: the `sequence_output[masked_tokens, :]` compaction of the MLM
+    transformer head (mmf/models/transformers/heads/mlm.py:80-83) — only the masked positions go through the vocabulary
+    projection.  Backward puts each gradient row back (the other rows are zero)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        x2 = _as_bf16_2d(x)
+        M, H = x2.shape
+        n = idx.numel()
+        out = torch.empty(n, H, dtype=BF16, device=x2.device)
+        if n:
+            nat.gather_rows2(x2, x2[:0], idx.contiguous(), out, n, H)
+        ctx.save_for_backward(idx)
+        ctx.meta = (x.shape, M, H, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        xshape, M, H, n = ctx.meta
+        d32 = torch.zeros(M, H, dtype=F32, device=g.device)
+        if n:
+            nat.rows_scatter_add(_grad_bf16(g, H), H, 1, n, 0, idx.contiguous(), n, 0, 0, d32, H, 0)
+        dx = torch.empty(M, H, dtype=BF16, device=g.device)
+        nat.cast_f32_to_bf16(d32, dx)
+        return dx.view(xshape), None
+
+
 # ---------------------------------------------------------------------------------------------
 # MMF Transformer pieces (mmf/models/transformers/backends/huggingface.py)
 # ---------------------------------------------------------------------------------------------

@@ -14,6 +14,8 @@ from torch import nn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.transformers.base import BaseTransformer
 from mmf_amd.models.transformers.backends import huggingface as _hf_backend  # noqa: F401  (registers "huggingface")
+from mmf_amd.models.transformers.heads import itm as _itm_head  # noqa: F401  (registers "itm")
+from mmf_amd.models.transformers.heads import mlm as _mlm_head  # noqa: F401  (registers "mlm")
 from mmf_amd.models.transformers.heads import mlp as _mlp_head  # noqa: F401  (registers "mlp")
 
 

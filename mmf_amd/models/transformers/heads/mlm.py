@@ -1,0 +1,70 @@
+"""`MLM` transformer head (mmf/models/transformers/heads/mlm.py:20-97) on the HIP kernels: only the masked positions are projected
+onto the vocabulary — `sequence_output[masked_tokens, :]` becomes a row gather (`functional.TakeRowsFn`) — then HF
+`BertOnlyMLMHead` = transform (dense -> gelu -> LayerNorm) + decoder tied to the text token embedding, and
+CrossEntropyLoss(ignore_index) fused with the decoder GEMM (`torch.ops.mmf_amd.masked_lm_head`)."""
+import warnings
+
+import torch
+from torch import nn
+
+from mmf_amd import functional as Fn
+from mmf_amd.common.registry import registry
+from mmf_amd.models.transformers.base import BaseTransformerHead
+from mmf_amd.modules.hf_layers import BertConfig, BertLMPredictionHead
+
+LABEL_KEY = "mlm_labels"
+COMBINED_LABEL_KEY = "combined_labels"
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+
+@registry.register_transformer_head("mlm")
+class MLM(BaseTransformerHead):
+    Config = dict(type="mlm", vocab_size=30522, hidden_size=768, hidden_dropout_prob=0.1, layer_norm_eps=1e-5, hidden_act="gelu",
+                  ignore_index=-1, loss_name="masked_lm_loss", label_key=None)
+
+    def __init__(self, config, *args, **kwargs):
+        super().__init__(config, *args, **kwargs)
+        if self.config.hidden_act != "gelu":
+            raise NotImplementedError("MLM head: only hidden_act='gelu' is fused in the GEMM epilogue")
+        self.cls = BertOnlyMLMHead(BertConfig(vocab_size=self.config.vocab_size, hidden_size=self.config.hidden_size,
+                                              layer_norm_eps=self.config.layer_norm_eps))
+        self.vocab_size = self.config.vocab_size
+
+    def tie_weights(self, module=None):
+        self.cls.predictions.decoder.weight = module.weight
+
+    def forward(self, sequence_output, encoded_layers=None, processed_sample_list=None):
+        assert processed_sample_list is not None, "MLM head requires 'processed_sample_list' argument"
+        output_dict = {}
+        if self.config.label_key is not None:
+            assert self.config.label_key in processed_sample_list, (
+                "Didn't find label key %s in SampleList required by MLM" % self.config.label_key)
+            masked_labels = processed_sample_list[self.config.label_key]
+        else:
+            assert LABEL_KEY in processed_sample_list and processed_sample_list[LABEL_KEY] is not None, (
+                "MLM pretraining requires %s to be in sample list with value not None." % LABEL_KEY)
+            assert COMBINED_LABEL_KEY in processed_sample_list[LABEL_KEY], (
+                "labels for all modalities must be concatenated in %s" % COMBINED_LABEL_KEY)
+            masked_labels = processed_sample_list[LABEL_KEY][COMBINED_LABEL_KEY]
+        H = sequence_output.shape[-1]
+        flat = masked_labels.reshape(-1)
+        idx = flat.ne(self.config.ignore_index).nonzero().squeeze(1)       # (a host read-back, as the reference's boolean indexing)
+        if idx.numel() == 0:
+            # mlm.py:89-94: the loss over nothing is NaN and is replaced by 0
+            warnings.warn("NaN detected in masked_lm_loss. Replacing it with 0.")
+            output_dict["logits"] = torch.empty(0, self.vocab_size, dtype=torch.float32, device=sequence_output.device)
+            output_dict["losses"] = {self.config.loss_name: torch.zeros((), dtype=torch.float32, device=sequence_output.device)}
+            return output_dict
+        rows = Fn.TakeRowsFn.apply(sequence_output.reshape(-1, H), idx)
+        labels = flat.index_select(0, idx)
+        heads = self.cls.predictions
+        hidden = heads.transform(rows)
+        loss, logits = torch.ops.mmf_amd.masked_lm_head(hidden, heads.decoder.weight, heads.bias, labels, int(self.config.ignore_index))
+        output_dict["logits"] = logits
+        output_dict["losses"] = {self.config.loss_name: loss}
+        return output_dict

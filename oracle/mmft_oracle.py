@@ -170,3 +170,27 @@ def mmft_forward(sd, cfg, sample_list, train=False):
     for i in range(cfg["num_hidden_layers"]):
         hidden, _ = bert_layer(vb, cfg, i, hidden, ext, hd, ad)
     return {"scores": mlp_head(sd, cfg, hidden, train), "sequence_output": hidden}
+
+
+def mlm_head(hsd, table, sequence_output, labels, eps=1e-5, ignore_index=-1):
+    """MLM.forward, mmf/models/transformers/heads/mlm.py:49-97: the masked positions only (`sequence_output[masked_tokens, :]`, :80-83)
+    through HF BertOnlyMLMHead (transform dense -> gelu -> LayerNorm(layer_norm_eps = 1e-5, :30), decoder tied to `table`, :45-46)
+    and CrossEntropyLoss(ignore_index); NaN (nothing masked) becomes 0 (:89-94).  `hsd`: the head's parameters under `cls.*`."""
+    masked = labels.ne(ignore_index)
+    rows = sequence_output[masked, :]
+    x = F.gelu(F.linear(rows, hsd["cls.predictions.transform.dense.weight"], hsd["cls.predictions.transform.dense.bias"]))
+    x = F.layer_norm(x, (x.shape[-1],), hsd["cls.predictions.transform.LayerNorm.weight"], hsd["cls.predictions.transform.LayerNorm.bias"], eps)
+    logits = F.linear(x, table, hsd["cls.predictions.bias"])
+    loss = F.cross_entropy(logits.contiguous().view(-1, table.shape[0]), labels[masked].contiguous().view(-1), ignore_index=ignore_index)
+    if torch.isnan(loss):
+        loss = torch.nan_to_num(loss, nan=0.0)
+    return {"logits": logits, "losses": {"masked_lm_loss": loss}}
+
+
+def itm_head(hsd, sequence_output, is_correct, ignore_index=-1):
+    """ITM.forward, mmf/models/transformers/heads/itm.py:40-74: HF BertPooler (tanh(dense(h[:, 0]))) -> BertOnlyNSPHead
+    (`seq_relationship`: Linear(hidden, 2)) -> CrossEntropyLoss(ignore_index) against `itm_labels.is_correct`."""
+    pooled = torch.tanh(F.linear(sequence_output[:, 0], hsd["pooler.dense.weight"], hsd["pooler.dense.bias"]))
+    score = F.linear(pooled, hsd["cls.seq_relationship.weight"], hsd["cls.seq_relationship.bias"])
+    loss = F.cross_entropy(score.contiguous().view(-1, 2), is_correct.contiguous().view(-1), ignore_index=ignore_index)
+    return {"seq_relationship_score": score, "losses": {"itm_loss": loss}}

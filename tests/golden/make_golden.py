@@ -731,6 +731,58 @@ def make_vilbert_pretraining():
     print("vilbert_pretraining", dict(zip(rec["loss_keys"], rec["loss_values"])), rec["loss_shapes"], "->", path, os.path.getsize(path), "bytes")
 
 
+def make_transformer_heads():
+    """The reference's `mlm` and `itm` transformer heads (mmf/models/transformers/heads/{mlm,itm}.py) run stand-alone on a fixed
+    sequence output: logits, losses, parameter gradients and the gradient handed back to the encoder."""
+    from torch import nn
+    MLM = refshim.ref_import("mmf.models.transformers.heads.mlm").MLM
+    ITM = refshim.ref_import("mmf.models.transformers.heads.itm").ITM
+    c = dict(B=3, S=19, hidden_size=128, vocab_size=211, seed=95)
+    B, S, H, V, seed = c["B"], c["S"], c["hidden_size"], c["vocab_size"], c["seed"]
+    mlm = MLM(OmegaConf.create(dict(type="mlm", vocab_size=V, hidden_size=H))).eval()
+    itm = ITM(OmegaConf.create(dict(type="itm", hidden_size=H))).eval()
+    table = nn.Embedding(V, H)
+    mlm.tie_weights(table)
+    mlm.cls.predictions.decoder.bias = mlm.cls.predictions.bias        # transformers<=4.10 BertLMPredictionHead (the reference's pin)
+    rec = {}
+    for tag, mod in (("mlm", mlm), ("itm", itm), ("table", table)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if not k.startswith("cls.predictions.decoder.")}
+        sd = detweights.state_dict({tag + "." + k: s for k, s in shapes.items()}, seed)
+        missing, unexpected = mod.load_state_dict({k[len(tag) + 1:]: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected, unexpected
+        rec[tag + "_param_names"] = np.array(list(sd.keys()))
+        rec[tag + "_param_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+    assert mlm.cls.predictions.decoder.weight is table.weight
+    seq = torch.from_numpy((2.0 * detweights.uniform(B * S * H, seed + 1) - 1.0).astype(np.float32).reshape(B, S, H)).requires_grad_(True)
+    pick = detweights.uniform(B * S, seed + 2).reshape(B, S) < 0.25
+    pick[:, 3] = True
+    labels = np.where(pick, (detweights.uniform(B * S, seed + 3) * V).astype(np.int64).reshape(B, S), -1)
+    is_correct = np.array([1, 0, 1], dtype=np.int64)[:B]
+    proc = {"mlm_labels": {"combined_labels": torch.from_numpy(labels)}, "itm_labels": {"is_correct": torch.from_numpy(is_correct)}}
+    out_mlm = mlm(seq, processed_sample_list=proc)
+    out_itm = itm(seq, processed_sample_list=proc)
+    total = out_mlm["losses"]["masked_lm_loss"] + out_itm["losses"]["itm_loss"]
+    total.backward()
+    rec.update({"in_sequence_output": seq.detach().numpy(), "in_labels": labels, "in_is_correct": is_correct,
+                "mlm_logits": out_mlm["logits"].detach().numpy(), "mlm_loss": np.array(out_mlm["losses"]["masked_lm_loss"].item()),
+                "itm_loss": np.array(out_itm["losses"]["itm_loss"].item()), "grad_sequence_output": seq.grad.numpy()})
+    for tag, mod in (("mlm", mlm), ("itm", itm)):
+        seen = set()
+        for k, p in mod.named_parameters():
+            if id(p) in seen or p.grad is None:
+                continue
+            seen.add(id(p))
+            rec["grad::%s.%s" % (tag, k)] = p.grad.numpy()
+    rec["grad::table.weight"] = table.weight.grad.numpy()
+    rec["mlm_state_dict_keys"] = np.array(sorted(mlm.state_dict().keys()))
+    rec["itm_state_dict_keys"] = np.array(sorted(itm.state_dict().keys()))
+    rec["case"] = np.array(repr(c))
+    path = os.path.join(HERE, "transformer_heads.npz")
+    np.savez_compressed(path, **rec)
+    print("transformer_heads mlm_loss", float(rec["mlm_loss"]), "itm_loss", float(rec["itm_loss"]), "logits", rec["mlm_logits"].shape, "->", path,
+          os.path.getsize(path), "bytes")
+
+
 UNITER_CASES = {
     "uniter_small64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
                            max_position_embeddings=40, img_dim=72, head_hidden_size=256, num_labels=13, B=3, T=12, R=7, seed=51),
@@ -1207,7 +1259,7 @@ def make_visual_bert_pretraining():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "vilbert_pretraining", "uniter", "m4c"]
+    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "vilbert_pretraining", "heads", "uniter", "m4c"]
     if "visual_bert" in which:
         main()
     if "nlvr2" in which:
@@ -1224,6 +1276,8 @@ if __name__ == "__main__":
         make_vilbert()
     if "vilbert_pretraining" in which:
         make_vilbert_pretraining()
+    if "heads" in which:
+        make_transformer_heads()
     if "uniter" in which:
         make_uniter()
     if "m4c" in which:

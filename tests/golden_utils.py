@@ -224,6 +224,19 @@ def load_vilbert_pretraining_case():
     return z, case, cfg, sd, sample
 
 
+def load_transformer_heads_case():
+    """`transformer_heads`: the reference's `mlm` / `itm` heads run stand-alone; returns (z, case, {tag: state dict}, inputs)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "transformer_heads.npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    sds = {}
+    for tag in ("mlm", "itm", "table"):
+        shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z[tag + "_param_names"], z[tag + "_param_shapes"])}
+        sds[tag] = {k[len(tag) + 1:]: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    inputs = {"sequence_output": torch.from_numpy(z["in_sequence_output"]), "labels": torch.from_numpy(z["in_labels"]),
+              "is_correct": torch.from_numpy(z["in_is_correct"])}
+    return z, case, sds, inputs
+
+
 def load_m4c_case(name="m4c_small64"):
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))

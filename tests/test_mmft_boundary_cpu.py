@@ -55,7 +55,16 @@ def test_optimizer_groups_and_unbuilt_variants():
     with pytest.raises(NotImplementedError):
         build_model(mmft_model_config(cfg, transformer_base="roberta-base"))
     with pytest.raises(RuntimeError):
-        build_model(mmft_model_config(cfg, heads=[dict(type="mlm")]))
+        build_model(mmft_model_config(cfg, heads=[dict(type="wra")]))              # a head that is not built is not registered
+    # `mlm` and `itm` ARE built; the MLM decoder is tied to the text token embedding (mmf_transformer.py:145-174,
+    # tests/models/test_mmf_transformer.py:504-523), state-dict keys equal the reference heads'
+    from tests.golden_utils import load_transformer_heads_case
+    zh = load_transformer_heads_case()[0]
+    m = build_model(mmft_model_config(cfg, heads=[dict(type="mlm", vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"]),
+                                                  dict(type="itm", hidden_size=cfg["hidden_size"])]))
+    assert m.heads[0].cls.predictions.decoder.weight is m.backend.embeddings.token_embeddings[0].weight
+    assert sorted(m.heads[0].state_dict().keys()) == sorted(str(k) for k in zh["mlm_state_dict_keys"])
+    assert sorted(m.heads[1].state_dict().keys()) == sorted(str(k) for k in zh["itm_state_dict_keys"])
 
 
 # ---- the reference's own preprocessing tests (tests/models/test_mmf_transformer.py:183-402), ported ----------------------------------

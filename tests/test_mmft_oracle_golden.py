@@ -44,3 +44,29 @@ def test_reference_state_dict_aliases():
     keys = set(str(k) for k in z["state_dict_keys"])
     for alias, owner in O.shared(cfg).items():
         assert alias in keys and owner in keys
+
+
+def test_transformer_heads_oracle_matches_reference():
+    """`mlm` / `itm` heads (mmf/models/transformers/heads/{mlm,itm}.py): logits, losses, every gradient incl. the tied table's and the
+    one handed back to the encoder."""
+    import numpy as np
+    import torch
+    from tests.golden_utils import load_transformer_heads_case
+    z, case, sds, inp = load_transformer_heads_case()
+    mlm = {k: v.clone().requires_grad_(True) for k, v in sds["mlm"].items()}
+    itm = {k: v.clone().requires_grad_(True) for k, v in sds["itm"].items()}
+    table = sds["table"]["weight"].clone().requires_grad_(True)
+    seq = inp["sequence_output"].clone().requires_grad_(True)
+    a = O.mlm_head(mlm, table, seq, inp["labels"])
+    b = O.itm_head(itm, seq, inp["is_correct"])
+    np.testing.assert_allclose(a["logits"].detach().numpy(), z["mlm_logits"], rtol=1e-5, atol=5e-6)
+    assert abs(a["losses"]["masked_lm_loss"].item() - float(z["mlm_loss"])) <= 1e-5 * float(z["mlm_loss"])
+    assert abs(b["losses"]["itm_loss"].item() - float(z["itm_loss"])) <= 1e-5 * float(z["itm_loss"])
+    (a["losses"]["masked_lm_loss"] + b["losses"]["itm_loss"]).backward()
+    np.testing.assert_allclose(seq.grad.numpy(), z["grad_sequence_output"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(table.grad.numpy(), z["grad::table.weight"], rtol=1e-4, atol=1e-7)
+    for tag, sd in (("mlm", mlm), ("itm", itm)):
+        for k, v in sd.items():
+            np.testing.assert_allclose(v.grad.numpy(), z["grad::%s.%s" % (tag, k)], rtol=1e-4, atol=1e-7, err_msg=k)
+    blank = torch.full_like(inp["labels"], -1)
+    assert O.mlm_head(mlm, table, seq, blank)["losses"]["masked_lm_loss"].item() == 0.0

@@ -20,8 +20,7 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // GEMM: C[m][n] = epilogue(sum_k A[m][k] * B[n][k]), everything fp32.
-// 128x128 tile per 256-thread workgroup, BK = 16; wave w owns a 64x64 quadrant = 2x2 MFMA tiles of 32x32 (64 accumulator
-// registers).  Operands go global -> registers (16-byte loads along K) -> LDS as K-MAJOR images [k][row] (row stride 132
+// 128x128 (or 64x128) tile per 256-thread workgroup, BK = 16; wave w owns a 64x64 (32x64) quadrant = 2x2 (1x2) MFMA tiles of 32x32.  Operands go global -> registers (16-byte loads along K) -> LDS as K-MAJOR images [k][row] (row stride 132
 // floats: the four k-quads of a wave's stores land in disjoint bank groups), so that the MFMA operand of lane l —
 // A[row = l & 31][k = l >> 5] — is a conflict-free ds_read_b32 of consecutive rows.  Register double buffering: the next
 // K-step's global loads are in flight while the MFMAs of the current one run; one barrier per K-step.
@@ -45,36 +44,38 @@ DEVI f32x4 ld_tile4(const float* base, int row, int rows, int ld, int k, int K) 
     return f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+template <int MI>     // MI row tiles of 32 per wave: BM = 64 * MI (128x128 tiles, or 64x128 when 128-row tiles would leave CUs idle)
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
+    constexpr int BM = 64 * MI;
     __shared__ float As[2][GBK][GLD];
     __shared__ float Bs[2][GBK][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    // staging role of this thread: rows r0 and r0 + 64 of the tile, k-quad kq
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GBN;
+    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
+    // staging role of this thread: rows r0 (and r0 + 64) of the tile, k-quad kq
     const int r0 = tid >> 2, kq = (tid & 3) * 4;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (g.K + GBK - 1) / GBK;
-    f32x4 ra[2], rb[2];
-    ra[0] = ld_tile4(g.A, m0 + r0, g.M, g.lda, kq, g.K);
-    ra[1] = ld_tile4(g.A, m0 + r0 + 64, g.M, g.lda, kq, g.K);
+    f32x4 ra[MI], rb[2];
+#pragma unroll
+    for (int h = 0; h < MI; ++h) ra[h] = ld_tile4(g.A, m0 + r0 + 64 * h, g.M, g.lda, kq, g.K);
     rb[0] = ld_tile4(g.B, n0 + r0, g.N, g.ldb, kq, g.K);
     rb[1] = ld_tile4(g.B, n0 + r0 + 64, g.N, g.ldb, kq, g.K);
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            As[0][kq + j][r0 + 64 * h] = ra[h][j];
-            Bs[0][kq + j][r0 + 64 * h] = rb[h][j];
-        }
+        for (int h = 0; h < MI; ++h) As[0][kq + j][r0 + 64 * h] = ra[h][j];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) Bs[0][kq + j][r0 + 64 * h] = rb[h][j];
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -82,32 +83,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
         const bool more = kt + 1 < nk;
         if (more) {
             const int k = (kt + 1) * GBK + kq;
-            ra[0] = ld_tile4(g.A, m0 + r0, g.M, g.lda, k, g.K);
-            ra[1] = ld_tile4(g.A, m0 + r0 + 64, g.M, g.lda, k, g.K);
+#pragma unroll
+            for (int h = 0; h < MI; ++h) ra[h] = ld_tile4(g.A, m0 + r0 + 64 * h, g.M, g.lda, k, g.K);
             rb[0] = ld_tile4(g.B, n0 + r0, g.N, g.ldb, k, g.K);
             rb[1] = ld_tile4(g.B, n0 + r0 + 64, g.N, g.ldb, k, g.K);
         }
 #pragma unroll
         for (int kk = 0; kk < GBK / 2; ++kk) {
             const int k = 2 * kk + (lane >> 5);
-            const float a0 = As[cur][k][wm + (lane & 31)];
-            const float a1 = As[cur][k][wm + 32 + (lane & 31)];
+            float a[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = As[cur][k][wm + 32 * i + (lane & 31)];
             const float b0 = Bs[cur][k][wn + (lane & 31)];
             const float b1 = Bs[cur][k][wn + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
+            }
         }
         if (more) {
             const int nxt = cur ^ 1;   // last read in iteration kt - 1, which every wave left through the barrier below
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    As[nxt][kq + j][r0 + 64 * h] = ra[h][j];
-                    Bs[nxt][kq + j][r0 + 64 * h] = rb[h][j];
-                }
+                for (int h = 0; h < MI; ++h) As[nxt][kq + j][r0 + 64 * h] = ra[h][j];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) Bs[nxt][kq + j][r0 + 64 * h] = rb[h][j];
+            }
         }
         __syncthreads();
     }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
         if (g.bias) cadd += g.bias[n];
         if (g.coladd) cadd += g.coladd[n];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -164,12 +167,18 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AttnF32 a) {
     const int nt = (a.Sk + 31) >> 5;
 
     // Q operand: A[i = query l31][k = e]: aq[j] = Q[q0 + l31][2 j + half]
+    // (rows are read as 16-byte quads — each lane pulls its whole 4 D-byte row, lanes l and l + 32 the same one — and the lane keeps
+    // the even (half 0) or odd (half 1) elements: half as many, four times as wide load instructions as element gathers)
     float aq[D / 2];
     {
         const int qr = min(q0 + l31, a.Sq - 1);
-        const float* qp = a.q + ((size_t)b * a.Sq + qr) * a.ldq + h * D + half;
+        const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.Sq + qr) * a.ldq + h * D);
 #pragma unroll
-        for (int j = 0; j < D / 2; ++j) aq[j] = qp[2 * j];
+        for (int i = 0; i < D / 4; ++i) {
+            const f32x4 t = qp[i];
+            aq[2 * i] = half ? t[1] : t[0];
+            aq[2 * i + 1] = half ? t[3] : t[2];
+        }
     }
 
     f32x16 sc[ATT_MAXT];
@@ -180,10 +189,14 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AttnF32 a) {
         if (t < nt) {
             const int key = 32 * t + l31;
             const int kr = min(key, a.Sk - 1);
-            const float* kp = a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D + half;
+            const f32x4* kp = reinterpret_cast<const f32x4*>(a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D);
             float bk[D / 2];
 #pragma unroll
-            for (int j = 0; j < D / 2; ++j) bk[j] = kp[2 * j];
+            for (int i = 0; i < D / 4; ++i) {
+                const f32x4 t = kp[i];
+                bk[2 * i] = half ? t[1] : t[0];
+                bk[2 * i + 1] = half ? t[3] : t[2];
+            }
 #pragma unroll
             for (int j = 0; j < D / 2; ++j) sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], bk[j], sc[t], 0, 0, 0);
             // this lane's column = key; rows = 16 queries
@@ -314,9 +327,15 @@ extern "C" int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream) {
     g.bias = d->bias; g.coladd = d->coladd; g.rowtab = d->rowtab; g.rowidx = d->rowidx; g.rowtab_ld = d->rowtab_ld;
     g.act = d->act; g.resid = (const float*)d->resid; g.ldr = d->ldr;
     g.grp_in = d->grp_in; g.grp_pad = d->grp_pad; g.grp_off = d->grp_off;
-    const dim3 grid((d->N + GBN - 1) / GBN, (d->M + GBM - 1) / GBM);
+    // 128-row tiles unless they would leave the chip short of work (fewer than two tiles per CU): then 64-row tiles — e.g.
+    // M = 7296, N = 768: 342 tiles of 128x128 on 256 CUs (1.34 rounds) become 684 of 64x128
+    const int nt = (d->N + GBN - 1) / GBN;
+    const bool small = (long)nt * ((d->M + GBM - 1) / GBM) < 512;
+    const int bm = small ? 64 : GBM;
+    const dim3 grid(nt, (d->M + bm - 1) / bm);
     MMF_CHECK_ARG(grid.y <= 65535u, "gemm_f32: M too large for one launch");
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    if (small) hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -331,6 +350,8 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
                   "attention_f32_fwd: inference form only (no dropout, prefix-LM tail, lse, K|V cache strides)");
     const int HD = d->heads * 64;
     MMF_CHECK_ARG(d->ldq >= HD && d->ldk >= HD && d->ldv >= HD && d->ldo >= HD, "attention_f32_fwd: leading dimension < heads * 64");
+    MMF_CHECK_ARG((d->ldq % 4) == 0 && (d->ldk % 4) == 0 && (((uintptr_t)d->q | (uintptr_t)d->k) & 15) == 0,
+                  "attention_f32_fwd: q and k rows are read as 16-byte quads (pointers 16-byte aligned, ldq / ldk multiples of 4)");
     MMF_CHECK_ARG((size_t)d->B * d->heads <= 65535u, "attention_f32_fwd: B * heads too large for one launch");
     AttnF32 a;
     a.q = (const float*)d->q; a.k = (const float*)d->k; a.v = (const float*)d->v; a.o = (float*)d->ctx;

@@ -32,8 +32,8 @@ def test_visual_bert_forward_routes_to_the_fp32_kernels_only():
         names = _names(calls)
         assert names <= FP32_CALLS, names - FP32_CALLS
         L = cfg["num_hidden_layers"]
-        # per layer: Q, K, V, out-proj, FFN-up, FFN-down; plus the visual projection, the head transform and the classifier
-        assert sum(c[0] == "gemm_f32" for c in calls) == 6 * L + 3
+        # per layer: packed Q|K|V, out-proj, FFN-up, FFN-down; plus the visual projection, the head transform and the classifier
+        assert sum(c[0] == "gemm_f32" for c in calls) == 4 * L + 3
         assert sum(c[0] == "attention_f32_fwd" for c in calls) == L
         assert sum(c[0] == "layernorm_f32_fwd" for c in calls) == 2 * L + 2
     assert out["scores"].dtype == torch.float32 and out["sequence_output"].dtype == torch.float32

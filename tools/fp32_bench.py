@@ -38,7 +38,7 @@ def main():
     dev = "cuda"
     res = {"peak_tflops_f32_mfma": PEAK_F32_MFMA, "gemm": [], "note": "fp32 operands and outputs, epilogue = bias only"}
     M = 7296
-    for name, N, K in (("qkv (one of three)", 768, 768), ("out-proj", 768, 768), ("ffn-up", 3072, 768), ("ffn-down", 768, 3072),
+    for name, N, K in (("qkv (packed)", 2304, 768), ("out-proj", 768, 768), ("ffn-up", 3072, 768), ("ffn-down", 768, 3072),
                        ("visual projection", 768, 2048)):
         m = 3200 if name.startswith("visual") else M
         A = torch.randn(m, K, device=dev); W = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)

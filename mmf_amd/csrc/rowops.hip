@@ -1490,9 +1490,12 @@ int mmf_vocab_cross_entropy_bwd(const float* logits, int ld, const int64_t* labe
                                 void* dlogits, int ldd, int R, int C, int ignore_index, void* stream) {
     MMF_CHECK_ARG(logits && labels && lse && count && dlogits && R > 0 && C > 0 && ld >= C, "vocab_cross_entropy_bwd: bad operand");
     MMF_CHECK_ARG(ldd >= C && (ldd % 8) == 0, "vocab_cross_entropy_bwd: ldd must be a multiple of 8 covering C (the GEMM operand's leading dimension)");
-    MMF_CHECK_ARG(R <= 65535, "vocab_cross_entropy_bwd: more than 65535 rows in one launch");
-    hipLaunchKernelGGL(vocab_ce_bwd_kernel, dim3((ldd / 4 + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, lse, count,
-                       gloss, (bf16*)dlogits, ldd, C, ignore_index);
+    for (int r0 = 0; r0 < R; r0 += 65535) {       // (grid.y is limited to 65535 rows per launch)
+        const int rows = R - r0 < 65535 ? R - r0 : 65535;
+        hipLaunchKernelGGL(vocab_ce_bwd_kernel, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
+                           logits + (size_t)r0 * ld, ld, labels + r0, lse + r0, count, gloss, (bf16*)dlogits + (size_t)r0 * ldd, ldd, C,
+                           ignore_index);
+    }
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -1511,9 +1514,12 @@ int mmf_soft_target_kl_bwd(const float* logits, int ld, const float* target, int
     MMF_CHECK_ARG(logits && target && row_label && lse && tsum && count && dlogits && R > 0 && C > 0 && ld >= C && ldt >= C,
                   "soft_target_kl_bwd: bad operand");
     MMF_CHECK_ARG(ldd >= C && (ldd % 8) == 0, "soft_target_kl_bwd: ldd must be a multiple of 8 covering C (the GEMM operand's leading dimension)");
-    MMF_CHECK_ARG(R <= 65535, "soft_target_kl_bwd: more than 65535 rows in one launch");
-    hipLaunchKernelGGL(soft_kl_bwd_kernel, dim3((ldd / 4 + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ldt, row_label,
-                       lse, tsum, count, gloss, (bf16*)dlogits, ldd, C);
+    for (int r0 = 0; r0 < R; r0 += 65535) {       // (grid.y is limited to 65535 rows per launch)
+        const int rows = R - r0 < 65535 ? R - r0 : 65535;
+        hipLaunchKernelGGL(soft_kl_bwd_kernel, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
+                           logits + (size_t)r0 * ld, ld, target + (size_t)r0 * ldt, ldt, row_label + r0, lse + r0, tsum + r0, count, gloss,
+                           (bf16*)dlogits + (size_t)r0 * ldd, ldd, C);
+    }
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -16,6 +16,7 @@ from mmf_amd.models.transformers.base import BaseTransformer
 from mmf_amd.models.transformers.backends import huggingface as _hf_backend  # noqa: F401  (registers "huggingface")
 from mmf_amd.models.transformers.heads import itm as _itm_head  # noqa: F401  (registers "itm")
 from mmf_amd.models.transformers.heads import mlm as _mlm_head  # noqa: F401  (registers "mlm")
+from mmf_amd.models.transformers.heads import mrc as _mrc_head  # noqa: F401  (registers "mrc")
 from mmf_amd.models.transformers.heads import mlp as _mlp_head  # noqa: F401  (registers "mlp")
 
 

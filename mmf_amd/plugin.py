@@ -12,7 +12,7 @@ checkpointing and trainer loop run unchanged around the HIP-backed networks.
 
 Registered: models `visual_bert`, `mmbt`, `vilbert`, `uniter`, `m4c`, `mmft` / `mmf_transformer`; losses `logit_bce`,
 `cross_entropy`, `m4c_decoding_bce_with_mask`; encoders `finetune_faster_rcnn_fpn_fc7`, `transformer` (the HIP-backed `BertModelJit`), `identity`; optimizer `adam_w`; scheduler `warmup_linear`; transformer backend `huggingface`; transformer heads
-`mlp` / `multilayer_mlp`, `mlm`, `itm`.
+`mlp` / `multilayer_mlp`, `mlm`, `itm`, `mrc`.
 """
 
 
@@ -98,7 +98,7 @@ def install():
             mmf_registry.register_model(name)(adapter)
             adapters[name] = adapter
     for kind, names in (("loss", ("logit_bce", "cross_entropy", "m4c_decoding_bce_with_mask")), ("encoder", ("finetune_faster_rcnn_fpn_fc7", "transformer", "identity")), ("optimizer", ("adam_w",)), ("scheduler", ("warmup_linear",)),
-                        ("transformer_backend", ("huggingface",)), ("transformer_head", ("mlp", "multilayer_mlp", "mlm", "itm"))):
+                        ("transformer_backend", ("huggingface",)), ("transformer_head", ("mlp", "multilayer_mlp", "mlm", "itm", "mrc"))):
         for name in names:
             obj = getattr(hip_registry, "get_%s_class" % kind)(name)
             if kind == "encoder":

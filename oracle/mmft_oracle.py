@@ -194,3 +194,18 @@ def itm_head(hsd, sequence_output, is_correct, ignore_index=-1):
     score = F.linear(pooled, hsd["cls.seq_relationship.weight"], hsd["cls.seq_relationship.bias"])
     loss = F.cross_entropy(score.contiguous().view(-1, 2), is_correct.contiguous().view(-1), ignore_index=ignore_index)
     return {"seq_relationship_score": score, "losses": {"itm_loss": loss}}
+
+
+def mrc_head(hsd, sequence_output, region_class, region_mask, use_kl=True, eps=1e-12, ignore_index=-1):
+    """MRC.forward, mmf/models/transformers/heads/mrc.py:47-90: the masked regions (`compute_masked_hidden`, heads/utils.py:169-179)
+    through Linear -> GELU -> LayerNorm -> Linear(label_dim); KLDivLoss(batchmean) against the soft labels, or (use_kl = False)
+    cross-entropy against their argmax over the non-background classes (:73-82)."""
+    rows = sequence_output[region_mask.unsqueeze(-1).expand_as(sequence_output)].contiguous().view(-1, sequence_output.size(-1))
+    x = F.gelu(F.linear(rows, hsd["region_classifier.0.weight"], hsd["region_classifier.0.bias"]))
+    x = F.layer_norm(x, (x.shape[-1],), hsd["region_classifier.2.weight"], hsd["region_classifier.2.bias"], eps)
+    pred = F.linear(x, hsd["region_classifier.3.weight"], hsd["region_classifier.3.bias"])
+    if use_kl:
+        loss = F.kl_div(F.log_softmax(pred, dim=-1), region_class, reduction="batchmean")
+    else:
+        loss = F.cross_entropy(pred, torch.max(region_class[:, 1:], dim=-1)[1] + 1, ignore_index=ignore_index, reduction="mean")
+    return {"losses": {"mrc_loss": loss}}

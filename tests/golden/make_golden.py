@@ -766,6 +766,38 @@ def make_transformer_heads():
     rec.update({"in_sequence_output": seq.detach().numpy(), "in_labels": labels, "in_is_correct": is_correct,
                 "mlm_logits": out_mlm["logits"].detach().numpy(), "mlm_loss": np.array(out_mlm["losses"]["masked_lm_loss"].item()),
                 "itm_loss": np.array(out_itm["losses"]["itm_loss"].item()), "grad_sequence_output": seq.grad.numpy()})
+    # MRC (masked region classification, heads/mrc.py): both loss variants on the same parameters
+    MRC = refshim.ref_import("mmf.models.transformers.heads.mrc").MRC
+    LD = 37
+    mrc = MRC(hidden_size=H, label_dim=LD).eval()
+    shapes = {k: tuple(v.shape) for k, v in mrc.state_dict().items()}
+    sdm = detweights.state_dict({"mrc." + k: s_ for k, s_ in shapes.items()}, seed)
+    mrc.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in sdm.items()}, strict=True)
+    rec["mrc_param_names"] = np.array(list(sdm.keys()))
+    rec["mrc_param_shapes"] = np.array([",".join(map(str, v.shape)) for v in sdm.values()])
+    rmask = detweights.uniform(B * S, seed + 4).reshape(B, S) < 0.3
+    rmask[:, 5] = True
+    nm = int(rmask.sum())
+    raw = detweights.uniform(nm * LD, seed + 5).reshape(nm, LD)
+    raw = np.where(raw < 0.5, 0.0, raw) ** 2
+    raw[:, 1] += 1e-3
+    region_class = (raw / raw.sum(-1, keepdims=True)).astype(np.float32)
+    proc2 = {"region_class": torch.from_numpy(region_class), "image_region_mask": torch.from_numpy(rmask)}
+    seq2 = seq.detach().clone().requires_grad_(True)
+    kl = mrc(seq2, proc2)["losses"]["mrc_loss"]
+    kl.backward()
+    rec.update({"in_region_mask": rmask, "in_region_class": region_class, "mrc_kl_loss": np.array(kl.item()),
+                "mrc_kl_grad_sequence_output": seq2.grad.numpy().copy()})
+    for k, p_ in mrc.named_parameters():
+        rec["grad::mrc_kl." + k] = p_.grad.numpy().copy()
+    mrc.zero_grad()
+    mrc.use_kl = False
+    seq3 = seq.detach().clone().requires_grad_(True)
+    ce = mrc(seq3, proc2)["losses"]["mrc_loss"]
+    ce.backward()
+    rec.update({"mrc_ce_loss": np.array(ce.item()), "mrc_ce_grad_sequence_output": seq3.grad.numpy().copy()})
+    for k, p_ in mrc.named_parameters():
+        rec["grad::mrc_ce." + k] = p_.grad.numpy().copy()
     for tag, mod in (("mlm", mlm), ("itm", itm)):
         seen = set()
         for k, p in mod.named_parameters():
@@ -779,7 +811,7 @@ def make_transformer_heads():
     rec["case"] = np.array(repr(c))
     path = os.path.join(HERE, "transformer_heads.npz")
     np.savez_compressed(path, **rec)
-    print("transformer_heads mlm_loss", float(rec["mlm_loss"]), "itm_loss", float(rec["itm_loss"]), "logits", rec["mlm_logits"].shape, "->", path,
+    print("transformer_heads mrc kl / ce", float(rec["mrc_kl_loss"]), float(rec["mrc_ce_loss"]), "mlm_loss", float(rec["mlm_loss"]), "itm_loss", float(rec["itm_loss"]), "logits", rec["mlm_logits"].shape, "->", path,
           os.path.getsize(path), "bytes")
 
 

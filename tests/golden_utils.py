@@ -229,11 +229,12 @@ def load_transformer_heads_case():
     z = np.load(os.path.join(GOLDEN_DIR, "transformer_heads.npz"), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))
     sds = {}
-    for tag in ("mlm", "itm", "table"):
+    for tag in ("mlm", "itm", "table", "mrc"):
         shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z[tag + "_param_names"], z[tag + "_param_shapes"])}
         sds[tag] = {k[len(tag) + 1:]: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
     inputs = {"sequence_output": torch.from_numpy(z["in_sequence_output"]), "labels": torch.from_numpy(z["in_labels"]),
-              "is_correct": torch.from_numpy(z["in_is_correct"])}
+              "is_correct": torch.from_numpy(z["in_is_correct"]), "region_mask": torch.from_numpy(z["in_region_mask"]),
+              "region_class": torch.from_numpy(z["in_region_class"])}
     return z, case, sds, inputs
 
 

@@ -292,3 +292,61 @@ def test_mmft_pretraining_step_with_mlm_and_itm_heads():
     assert all(np.isfinite(totals)) and totals[-1] < totals[0] - 0.5, totals
     w = model.backend.embeddings.token_embeddings[0].weight
     assert model.heads[0].cls.predictions.decoder.weight is w and w.grad is not None and bool(torch.isfinite(w.grad).all())
+
+
+@pytest.mark.parametrize("use_kl", [True, False])
+def test_mrc_head_matches_the_reference_head(use_kl):
+    """`mrc` (masked region classification, mmf/models/transformers/heads/mrc.py) against the reference head's own run: loss, parameter
+    gradients and the gradient handed back to the encoder (zero outside the masked regions), both loss variants."""
+    from mmf_amd.models.transformers.heads.mrc import MRC
+    from tests.golden_utils import load_transformer_heads_case
+    z, case, sds, inp = load_transformer_heads_case()
+    tag = "kl" if use_kl else "ce"
+    head = MRC(hidden_size=case["hidden_size"], label_dim=inp["region_class"].shape[1], use_kl=use_kl)
+    assert sorted(head.state_dict().keys()) == sorted(sds["mrc"].keys())
+    head.load_state_dict(sds["mrc"], strict=True)
+    head = head.cuda().eval()
+    seq = inp["sequence_output"].cuda().requires_grad_(True)
+    out = head(seq, {"region_class": inp["region_class"].cuda(), "image_region_mask": inp["region_mask"].cuda()})
+    loss = out["losses"]["mrc_loss"]
+    assert loss.shape == torch.Size([]) and abs(loss.item() - float(z["mrc_%s_loss" % tag])) <= TOL * float(z["mrc_%s_loss" % tag])
+    loss.backward()
+    ref_g = torch.from_numpy(z["mrc_%s_grad_sequence_output" % tag])
+    assert rel_err(seq.grad, ref_g) <= TOL
+    assert float(seq.grad.float().cpu()[~inp["region_mask"]].abs().max()) == 0.0
+    for k, p in head.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(z["grad::mrc_%s.%s" % (tag, k)])) <= TOL, k
+
+
+def test_reference_head_unit_tests_ported():
+    """tests/models/transformers/test_heads.py of the reference (MLM :21-62, MLP :65-81, ITM :84-103, multilayer MLP :106-128, MRC :204-236):
+    output keys and shapes of each head on the shapes those tests use."""
+    import warnings
+    from mmf_amd.models.transformers.heads.itm import ITM
+    from mmf_amd.models.transformers.heads.mlm import MLM
+    from mmf_amd.models.transformers.heads.mlp import MLP
+    from mmf_amd.models.transformers.heads.mrc import MRC
+    x = torch.rand(1, 64, 768, device="cuda")
+    module = MLM(dict(type="mlm", freeze=False, vocab_size=1000, hidden_size=768)).cuda()
+    out = module(x, [x, x], {"mlm_labels": {"combined_labels": torch.ones(1, 64, dtype=torch.long, device="cuda")}})
+    assert "logits" in out and "masked_lm_loss" in out["losses"] and out["logits"].shape == torch.Size([64, 1000])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = module(x, [x, x], {"mlm_labels": {"combined_labels": torch.full((1, 64), module.config.ignore_index, dtype=torch.long,
+                                                                                device="cuda")}})
+    assert not torch.isnan(out["losses"]["masked_lm_loss"]) and out["losses"]["masked_lm_loss"] == 0.0
+    ones = torch.ones(1, 64, 768, device="cuda")
+    out = MLP(dict(type="mlp", num_labels=2, hidden_size=768)).cuda()(ones, [ones, ones], {})
+    assert "scores" in out and out["scores"].shape == torch.Size([1, 2])
+    out = MLP(dict(type="mlp", num_labels=2, hidden_size=768, num_layers=2, in_dim=768, pooler_name="bert_pooler")).cuda()(ones, [ones, ones], {})
+    assert out["scores"].shape == torch.Size([1, 2])
+    out = ITM(dict(type="itm", hidden_size=768)).cuda()(ones, [ones, ones], {"itm_labels": {"is_correct": torch.tensor(False, dtype=torch.long,
+                                                                                                                        device="cuda")}})
+    assert "itm_loss" in out["losses"] and out["losses"]["itm_loss"].shape == torch.Size([])
+    bs, num_feat, label_dim = 8, 64, 100
+    seq = torch.ones(bs, num_feat, 768, device="cuda")
+    proc = {"region_class": torch.rand(bs, num_feat, label_dim, device="cuda").view(-1, label_dim),
+            "image_region_mask": torch.ones(bs, num_feat, device="cuda").bool()}
+    for kw in (dict(), dict(use_kl=False)):
+        out = MRC(hidden_size=768, label_dim=label_dim, **kw).cuda()(seq, proc)
+        assert "mrc_loss" in out["losses"] and out["losses"]["mrc_loss"].shape == torch.Size([])

@@ -70,3 +70,19 @@ def test_transformer_heads_oracle_matches_reference():
             np.testing.assert_allclose(v.grad.numpy(), z["grad::%s.%s" % (tag, k)], rtol=1e-4, atol=1e-7, err_msg=k)
     blank = torch.full_like(inp["labels"], -1)
     assert O.mlm_head(mlm, table, seq, blank)["losses"]["masked_lm_loss"].item() == 0.0
+
+
+def test_mrc_head_oracle_matches_reference():
+    """`mrc` head (mmf/models/transformers/heads/mrc.py), KL and cross-entropy variants: loss, parameter gradients, encoder gradient."""
+    import numpy as np
+    from tests.golden_utils import load_transformer_heads_case
+    z, case, sds, inp = load_transformer_heads_case()
+    for tag, use_kl in (("kl", True), ("ce", False)):
+        hsd = {k: v.clone().requires_grad_(True) for k, v in sds["mrc"].items()}
+        seq = inp["sequence_output"].clone().requires_grad_(True)
+        loss = O.mrc_head(hsd, seq, inp["region_class"], inp["region_mask"], use_kl=use_kl)["losses"]["mrc_loss"]
+        assert abs(loss.item() - float(z["mrc_%s_loss" % tag])) <= 1e-5 * float(z["mrc_%s_loss" % tag])
+        loss.backward()
+        np.testing.assert_allclose(seq.grad.numpy(), z["mrc_%s_grad_sequence_output" % tag], rtol=1e-4, atol=1e-7)
+        for k, v in hsd.items():
+            np.testing.assert_allclose(v.grad.numpy(), z["grad::mrc_%s.%s" % (tag, k)], rtol=1e-4, atol=1e-7, err_msg=k)

@@ -209,3 +209,63 @@ def mrc_head(hsd, sequence_output, region_class, region_mask, use_kl=True, eps=1
     else:
         loss = F.cross_entropy(pred, torch.max(region_class[:, 1:], dim=-1)[1] + 1, ignore_index=ignore_index, reduction="mean")
     return {"losses": {"mrc_loss": loss}}
+
+
+def mrfr_head(hsd, img_embedding_weight, sequence_output, feat_targets, region_mask, eps=1e-12):
+    """MRFR.forward (masked region feature regression), mmf/models/transformers/heads/mrfr.py:58-93: the masked regions through
+    Linear -> GELU -> LayerNorm, projected back to the feature space with the TRANSPOSED image-embedding weight (`F.linear(h,
+    W.t(), b)`, W = `img_embeddings.img_linear.weight` [hidden, img_dim], :46,86-88) and regressed onto the original features of the
+    masked regions with mean-squared error.  (Oracle ahead of the HIP path: the head is not built yet.)"""
+    rows = sequence_output[region_mask.unsqueeze(-1).expand_as(sequence_output)].contiguous().view(-1, sequence_output.size(-1))
+    x = F.gelu(F.linear(rows, hsd["feat_regress.0.weight"], hsd["feat_regress.0.bias"]))
+    x = F.layer_norm(x, (x.shape[-1],), hsd["feat_regress.2.weight"], hsd["feat_regress.2.bias"], eps)
+    pred = F.linear(x, img_embedding_weight.t(), hsd["linear_proj_bias"])
+    return {"losses": {"mrfr_loss": F.mse_loss(pred, feat_targets, reduction="mean")}}
+
+
+def optimal_transport_dist(txt_emb, img_emb, txt_pad, img_pad, beta=0.5, iteration=50, k=1, eps=1e-5):
+    """mmf/modules/ot.py:87-110 with `cost_matrix_cosine` (:15-25), `ipot` (:38-84, under no_grad: the transport plan is a constant of
+    the backward pass) and `trace` (:28-35): the IPOT approximation of the optimal-transport distance between the text and the
+    region embeddings of each sample under the cosine cost."""
+    x = F.normalize(txt_emb, p=2, dim=-1, eps=eps)
+    y = F.normalize(img_emb, p=2, dim=-1, eps=eps)
+    cost = 1 - x.matmul(y.transpose(1, 2))                                           # [B, M, N]
+    joint_pad = txt_pad.unsqueeze(-1) | img_pad.unsqueeze(-2)
+    cost = cost.masked_fill(joint_pad, 0)
+    x_len = (txt_pad.size(1) - txt_pad.sum(dim=1)).to(cost.dtype)
+    y_len = (img_pad.size(1) - img_pad.sum(dim=1)).to(cost.dtype)
+    with torch.no_grad():
+        C = cost.detach()
+        b, m, n = C.size()
+        sigma = torch.ones(b, m, dtype=C.dtype) / x_len.unsqueeze(1)
+        T = torch.ones(b, n, m, dtype=C.dtype)
+        A = torch.exp(-C.transpose(1, 2) / beta)
+        sigma = sigma.masked_fill(txt_pad, 0)
+        jp = joint_pad.transpose(1, 2)
+        T = T.masked_fill(jp, 0)
+        A = A.masked_fill(jp, 0)
+        xl, yl = x_len.view(b, 1, 1), y_len.view(b, 1, 1)
+        x_mask = (txt_pad.to(C.dtype) * 1e4).unsqueeze(1)
+        y_mask = (img_pad.to(C.dtype) * 1e4).unsqueeze(1)
+        for _ in range(iteration):
+            Q = A * T
+            sigma = sigma.view(b, m, 1)
+            for _ in range(k):
+                delta = 1 / (yl * Q.matmul(sigma).view(b, 1, n) + y_mask)
+                sigma = 1 / (xl * delta.matmul(Q) + x_mask)
+            T = delta.view(b, n, 1) * Q * sigma
+        T = T.masked_fill(jp, 0)
+    prod = cost.matmul(T)                                                            # [B, M, M]
+    return torch.diagonal(prod, dim1=1, dim2=2).sum(-1)
+
+
+def wra_head(sequence_output, txt_len, img_len, txt_pad, img_pad, is_correct):
+    """WRA.forward (word-region alignment), mmf/models/transformers/heads/wra.py:36-83: OT distance between the text rows [:tl] and
+    the region rows [tl : tl + il] of the joint sequence; loss = (sum over matched pairs - sum over mismatched pairs) / number of
+    pairs.  (Oracle ahead of the HIP path: the head is not built yet.)"""
+    txt_emb = sequence_output[:, :txt_len, :]
+    img_emb = sequence_output[:, txt_len:txt_len + img_len, :]
+    ot = optimal_transport_dist(txt_emb.float(), img_emb.float(), txt_pad.bool(), img_pad.bool()).to(txt_emb)
+    pos = ot.masked_select(is_correct == 1)
+    neg = ot.masked_select(is_correct == 0)
+    return {"losses": {"wra_loss": (pos.sum() - neg.sum()) / (pos.size(0) + neg.size(0))}, "ot_dist": ot}

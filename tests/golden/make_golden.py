@@ -798,6 +798,42 @@ def make_transformer_heads():
     rec.update({"mrc_ce_loss": np.array(ce.item()), "mrc_ce_grad_sequence_output": seq3.grad.numpy().copy()})
     for k, p_ in mrc.named_parameters():
         rec["grad::mrc_ce." + k] = p_.grad.numpy().copy()
+    # MRFR (masked region feature regression) and WRA (word-region alignment by optimal transport): fixtures for the oracles that
+    # precede their HIP implementation
+    MRFR = refshim.ref_import("mmf.models.transformers.heads.mrfr").MRFR
+    WRA = refshim.ref_import("mmf.models.transformers.heads.wra").WRA
+    IMG = 40
+    img_w = nn.Parameter(torch.from_numpy(detweights.state_dict({"img.weight": (H, IMG)}, seed)["img.weight"]))
+    mrfr = MRFR(img_w, hidden_size=H, img_dim=IMG).eval()
+    shapes = {k: tuple(v.shape) for k, v in mrfr.state_dict().items() if k != "linear_proj_weight"}
+    sdf = detweights.state_dict({"mrfr." + k: s_ for k, s_ in shapes.items()}, seed)
+    missing, unexpected = mrfr.load_state_dict({k[5:]: torch.from_numpy(v) for k, v in sdf.items()}, strict=False)
+    assert not unexpected and missing == ["linear_proj_weight"], (missing, unexpected)
+    rec["mrfr_param_names"] = np.array(list(sdf.keys()))
+    rec["mrfr_param_shapes"] = np.array([",".join(map(str, v.shape)) for v in sdf.values()])
+    rec["img_param_names"] = np.array(["img.weight"])
+    rec["img_param_shapes"] = np.array(["%d,%d" % (H, IMG)])
+    feat_targets = (2.0 * detweights.uniform(nm * IMG, seed + 6) - 1.0).astype(np.float32).reshape(nm, IMG)
+    seq4 = seq.detach().clone().requires_grad_(True)
+    lf = mrfr(seq4, {"mrfr_region_target": torch.from_numpy(feat_targets), "mrfr_region_mask": torch.from_numpy(rmask)})["losses"]["mrfr_loss"]
+    lf.backward()
+    rec.update({"in_mrfr_target": feat_targets, "mrfr_loss": np.array(lf.item()), "mrfr_grad_sequence_output": seq4.grad.numpy().copy(),
+                "grad::img.weight": img_w.grad.numpy().copy()})
+    for k, p_ in mrfr.named_parameters():
+        if k != "linear_proj_weight":
+            rec["grad::mrfr." + k] = p_.grad.numpy().copy()
+    TL, IL = 12, 7                                   # S = 19 = 12 text rows + 7 region rows
+    txt_pad = np.zeros((B, TL), dtype=bool); txt_pad[1, 8:] = True; txt_pad[2, 10:] = True
+    img_pad = np.zeros((B, IL), dtype=bool); img_pad[0, 6:] = True; img_pad[2, 4:] = True
+    wra = WRA().eval()
+    seq5 = seq.detach().clone().requires_grad_(True)
+    procw = {"wra_info": {"txt_pad": torch.from_numpy(txt_pad), "img_pad": torch.from_numpy(img_pad)},
+             "is_correct": torch.from_numpy(is_correct), "input_ids": torch.zeros(B, TL, dtype=torch.long),
+             "image_feat": torch.zeros(B, IL, 4)}
+    lw = wra(seq5, procw)["losses"]["wra_loss"]
+    lw.backward()
+    rec.update({"in_txt_pad": txt_pad, "in_img_pad": img_pad, "wra_loss": np.array(lw.item()),
+                "wra_grad_sequence_output": seq5.grad.numpy().copy()})
     for tag, mod in (("mlm", mlm), ("itm", itm)):
         seen = set()
         for k, p in mod.named_parameters():
@@ -811,7 +847,7 @@ def make_transformer_heads():
     rec["case"] = np.array(repr(c))
     path = os.path.join(HERE, "transformer_heads.npz")
     np.savez_compressed(path, **rec)
-    print("transformer_heads mrc kl / ce", float(rec["mrc_kl_loss"]), float(rec["mrc_ce_loss"]), "mlm_loss", float(rec["mlm_loss"]), "itm_loss", float(rec["itm_loss"]), "logits", rec["mlm_logits"].shape, "->", path,
+    print("transformer_heads mrfr", float(rec["mrfr_loss"]), "wra", float(rec["wra_loss"]), "mrc kl / ce", float(rec["mrc_kl_loss"]), float(rec["mrc_ce_loss"]), "mlm_loss", float(rec["mlm_loss"]), "itm_loss", float(rec["itm_loss"]), "logits", rec["mlm_logits"].shape, "->", path,
           os.path.getsize(path), "bytes")
 
 

@@ -238,6 +238,18 @@ def load_transformer_heads_case():
     return z, case, sds, inputs
 
 
+def load_transformer_heads_extra():
+    """The MRFR / WRA records of `transformer_heads` (oracles ahead of their HIP implementation): parameters of the MRFR head, the tied
+    image-embedding weight, the regression targets and the padding masks of the optimal-transport alignment."""
+    z, case, sds, inputs = load_transformer_heads_case()
+    for tag in ("mrfr", "img"):
+        shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z[tag + "_param_names"], z[tag + "_param_shapes"])}
+        sds[tag] = {k[len(tag) + 1:]: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    inputs = dict(inputs, mrfr_target=torch.from_numpy(z["in_mrfr_target"]), txt_pad=torch.from_numpy(z["in_txt_pad"]),
+                  img_pad=torch.from_numpy(z["in_img_pad"]))
+    return z, case, sds, inputs
+
+
 def load_m4c_case(name="m4c_small64"):
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))

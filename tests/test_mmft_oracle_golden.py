@@ -86,3 +86,27 @@ def test_mrc_head_oracle_matches_reference():
         np.testing.assert_allclose(seq.grad.numpy(), z["mrc_%s_grad_sequence_output" % tag], rtol=1e-4, atol=1e-7)
         for k, v in hsd.items():
             np.testing.assert_allclose(v.grad.numpy(), z["grad::mrc_%s.%s" % (tag, k)], rtol=1e-4, atol=1e-7, err_msg=k)
+
+
+def test_mrfr_and_wra_oracles_match_reference():
+    """Oracles for the two UNITER pretraining heads that are NOT built on the HIP side yet (mmf/models/transformers/heads/{mrfr,wra}.py,
+    mmf/modules/ot.py), pinned against the reference heads' own run: losses, parameter gradients (incl. the image-embedding weight MRFR
+    ties to, transposed) and the gradient handed back to the encoder — through the 50 IPOT iterations for WRA."""
+    import numpy as np
+    from tests.golden_utils import load_transformer_heads_extra
+    z, case, sds, inp = load_transformer_heads_extra()
+    hsd = {k: v.clone().requires_grad_(True) for k, v in sds["mrfr"].items()}
+    img_w = sds["img"]["weight"].clone().requires_grad_(True)
+    seq = inp["sequence_output"].clone().requires_grad_(True)
+    loss = O.mrfr_head(hsd, img_w, seq, inp["mrfr_target"], inp["region_mask"])["losses"]["mrfr_loss"]
+    assert abs(loss.item() - float(z["mrfr_loss"])) <= 1e-5 * float(z["mrfr_loss"])
+    loss.backward()
+    np.testing.assert_allclose(seq.grad.numpy(), z["mrfr_grad_sequence_output"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(img_w.grad.numpy(), z["grad::img.weight"], rtol=1e-4, atol=1e-7)
+    for k, v in hsd.items():
+        np.testing.assert_allclose(v.grad.numpy(), z["grad::mrfr." + k], rtol=1e-4, atol=1e-7, err_msg=k)
+    seq = inp["sequence_output"].clone().requires_grad_(True)
+    out = O.wra_head(seq, inp["txt_pad"].shape[1], inp["img_pad"].shape[1], inp["txt_pad"], inp["img_pad"], inp["is_correct"])
+    assert abs(out["losses"]["wra_loss"].item() - float(z["wra_loss"])) <= 1e-5 * abs(float(z["wra_loss"]))
+    out["losses"]["wra_loss"].backward()
+    np.testing.assert_allclose(seq.grad.numpy(), z["wra_grad_sequence_output"], rtol=1e-4, atol=1e-7)

@@ -11,14 +11,23 @@ projected by the MFMA GEMM; the 7-d box geometry goes through the same GEMM zero
 LayerNorms, the sums and the concat are the row kernels of mmf_amd/csrc/rowops.hip; the trunk is the BERT encoder the
 VisualBERT path runs on; heads come from the transformer-head registry (`mlp`).
 
-Not built (raise): `do_pretraining` (UNITERForPretraining and its mlm / itm / mrc / mrfr / wra heads, :350-618)."""
+`do_pretraining`: `UNITERForPretraining` (:350-618) for the tasks whose heads are built — mlm, itm, mrc (mmf_amd/models/transformers/
+heads); mrfr and wra raise at build time (their oracles are pinned, the kernels are not written).  One task per batch, drawn like the
+reference does; the random region masks come from the same numpy / random calls as the reference's `_get_img_mask`."""
+import copy
+import random
+
+import numpy as np
 import torch
 from torch import nn
 
 from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
+from mmf_amd.models.transformers.heads import itm as _itm_head  # noqa: F401  (registers "itm")
+from mmf_amd.models.transformers.heads import mlm as _mlm_head  # noqa: F401  (registers "mlm")
 from mmf_amd.models.transformers.heads import mlp as _mlp_head  # noqa: F401  (registers "mlp")
+from mmf_amd.models.transformers.heads import mrc as _mrc_head  # noqa: F401  (registers "mrc")
 from mmf_amd.modules.hf_layers import (
     BertConfig, BertEmbeddingsJit, BertEncoderJit, BertPooler, Dropout, LayerNorm, Linear, init_bert_weights)
 from mmf_amd.modules.losses import MMFLoss
@@ -136,6 +145,138 @@ def _infer_with_heads(processed_sample_list, uniter_model, heads, losses):
     return {"losses": output, "scores": logits}
 
 
+DEFAULT_PRETRAINING_HEAD_CONFIGS = {"mlm": {"type": "mlm"}, "itm": {"type": "itm"}, "mrc": {"type": "mrc"}, "mrfr": {"type": "mrfr"},
+                                    "wra": {"type": "wra"}}
+DEFAULT_PRETRAINING_TASKS = "mlm,itm,mrc,mrfr,wra"
+
+
+class UNITERForPretraining(nn.Module):
+    """uniter.py:350-618.  The per-task preparation is host-side massaging of ids, masks and the feature block (as in the reference);
+    encoder and heads are the HIP-backed ones."""
+
+    def __init__(self, head_configs=None, loss_configs=None, tasks=DEFAULT_PRETRAINING_TASKS, mask_probability=0, random_init=False,
+                 bert_model_name="bert-base-uncased", img_dim=2048, hidden_size=768, hidden_dropout_prob=0, text_embeddings=None,
+                 encoder=None):
+        super().__init__()
+        if head_configs is None:
+            head_configs = copy.deepcopy(DEFAULT_PRETRAINING_HEAD_CONFIGS)
+        self.loss_configs = loss_configs if loss_configs is not None else {}
+        self.mask_probability = mask_probability
+        self.uniter = UNITERModelBase(random_init=random_init, bert_model_name=bert_model_name, img_dim=img_dim,
+                                      hidden_size=hidden_size, hidden_dropout_prob=hidden_dropout_prob,
+                                      text_embeddings=text_embeddings, encoder=encoder)
+        self.heads = nn.ModuleDict()
+        self.tasks = tasks.split(",") if isinstance(tasks, str) else list(tasks)
+        for task in self.tasks:
+            head_config = dict(head_configs[task])
+            head_type = head_config.get("type", "mlp")
+            if head_type in ("mrfr", "wra"):
+                raise NotImplementedError(
+                    "UNITER pretraining task %r: the %s head (mmf/models/transformers/heads/%s.py) is not built on the HIP side yet "
+                    "(its oracle is pinned: oracle/mmft_oracle.py); configure `tasks` as a subset of mlm,itm,mrc" % (task, head_type, head_type))
+            head_class = registry.get_transformer_head_class(head_type)
+            if head_class is None:
+                raise RuntimeError("No transformer head registered for name: %s" % head_type)
+            if head_type in ("itm", "mlm", "mlp"):
+                self.heads[task] = head_class(head_config)                    # uniter.py:400-401
+            else:
+                head_config.pop("type", None)
+                self.heads[task] = head_class(**head_config)                  # :402-403
+        self.init_losses()
+
+    def init_losses(self):
+        self.losses = nn.ModuleDict()
+        for task in self.tasks:
+            if task not in self.loss_configs:
+                continue          # the head is expected to return a dict with `losses`
+            self.losses[task] = MMFLoss(self.loss_configs[task])
+
+    def forward(self, processed_sample_list):
+        assert "is_correct" in processed_sample_list, (
+            "UNITER pretraining requires mismatched captions. Please add 'false_caption': true under dataset_config in your yaml configs.")
+        self._process_sample_list_for_pretraining(processed_sample_list)
+        task = processed_sample_list["task"]
+        if task == "mlm":
+            self._preprocess_mlm(processed_sample_list)
+        elif task == "itm":
+            self._preprocess_itm(processed_sample_list)
+        elif task == "mrc":
+            self._preprocess_mrc(processed_sample_list)
+        else:
+            raise ValueError("Task %s is not supported for pretraining!" % task)
+        return _infer_with_heads(processed_sample_list, self.uniter, self.heads, self.losses)
+
+    # ---- host-side preparation, uniter.py:449-617 ---------------------------------------------------------------------------------------
+    def _process_sample_list_for_pretraining(self, processed_sample_list):
+        task = processed_sample_list["task"]
+        if task in ("mrfr", "mrc"):
+            self._add_image_feat_masked(processed_sample_list)
+            cls_prob = processed_sample_list["image_info_0"]["cls_prob"]
+            processed_sample_list["cls_prob"] = cls_prob if isinstance(cls_prob, torch.Tensor) else torch.tensor(np.array(cls_prob))
+        if task not in ("wra", "itm"):
+            self._remove_mismatched_captions(processed_sample_list)
+
+    def _add_image_feat_masked(self, processed_sample_list):
+        img_feat_masked = torch.clone(processed_sample_list["image_feat"])
+        num_feat = img_feat_masked.size(1)
+        img_masks = [self._get_img_mask(self.mask_probability, num_feat) for _ in range(img_feat_masked.size(0))]
+        img_masks = torch.tensor(img_masks).bool().to(img_feat_masked.device)
+        img_masks_ext = img_masks.unsqueeze(-1).expand_as(img_feat_masked)
+        processed_sample_list["image_feat_masked"] = img_feat_masked.data.masked_fill(img_masks_ext, 0)
+        processed_sample_list["image_mask"] = img_masks
+
+    def _get_img_mask(self, mask_prob, num_bb):
+        """uniter.py:480-485, the same generator calls: the seeds of a reference run reproduce its masks."""
+        img_mask = list(map(bool, np.random.binomial(1, mask_prob, num_bb)))
+        if not any(img_mask):
+            img_mask[random.choice(range(num_bb))] = True          # at least one region is masked
+        return img_mask
+
+    def _preprocess_mlm(self, processed_sample_list):
+        assert "lm_label_ids" in processed_sample_list
+        assert "input_ids_masked" in processed_sample_list
+        ignore_index = self.heads["mlm"].config.ignore_index
+        mlm_labels = {"text": processed_sample_list["lm_label_ids"]}
+        mlm_labels["image"] = torch.full(processed_sample_list["image_feat"].shape[:2], fill_value=ignore_index, dtype=torch.long,
+                                         device=mlm_labels["text"].device)
+        mlm_labels["combined_labels"] = torch.cat([mlm_labels["text"], mlm_labels["image"]], dim=-1)
+        processed_sample_list["mlm_labels"] = mlm_labels
+        processed_sample_list["input_ids"] = processed_sample_list["input_ids_masked"]
+
+    def _preprocess_itm(self, processed_sample_list):
+        assert "is_correct" in processed_sample_list
+        processed_sample_list["itm_labels"] = {"is_correct": processed_sample_list["is_correct"]}
+
+    def _get_feature_mask(self, image_mask, sentence_len):
+        bs = image_mask.size(0)
+        padding_for_txt = torch.zeros((bs, sentence_len)).to(image_mask)
+        return torch.cat([padding_for_txt, image_mask], dim=-1)
+
+    def _mask_inputs_in_sample_list(self, processed_sample_list, mask_key):
+        assert "image_feat_masked" in processed_sample_list
+        sentence_len = processed_sample_list["input_ids"].size(1)
+        processed_sample_list[mask_key] = self._get_feature_mask(processed_sample_list["image_mask"], sentence_len)
+        processed_sample_list["image_feat"] = processed_sample_list["image_feat_masked"]
+
+    def _preprocess_mrc(self, processed_sample_list):
+        assert "cls_prob" in processed_sample_list
+        assert "image_mask" in processed_sample_list
+        assert "image_feat_masked" in processed_sample_list
+        mrc_label_key = self.heads["mrc"].mrc_label_key
+        mrc_mask_key = self.heads["mrc"].mrc_mask_key
+        image_mask = processed_sample_list["image_mask"]
+        cls_prob = processed_sample_list["cls_prob"].to(image_mask.device)
+        img_masks_ext = image_mask.unsqueeze(-1).expand_as(cls_prob)
+        cls_dim = cls_prob.size(2)
+        processed_sample_list[mrc_label_key] = cls_prob[img_masks_ext].contiguous().view(-1, cls_dim)
+        self._mask_inputs_in_sample_list(processed_sample_list, mrc_mask_key)
+
+    def _remove_mismatched_captions(self, processed_sample_list):
+        """uniter.py:583-617 selects the matched pairs of each tensor and never writes the selection back: it changes nothing.  Kept
+        as the check it effectively is."""
+        assert "is_correct" in processed_sample_list
+
+
 class UNITERForClassification(nn.Module):
     """uniter.py:278-347."""
 
@@ -189,9 +330,18 @@ class UNITER(BaseModel):
         return "configs/models/uniter/defaults.yaml"
 
     def build(self):
-        if self.do_pretraining:
-            raise NotImplementedError("UNITERForPretraining (uniter.py:350-618) is a later milestone")
         c = self.config
+        if self.do_pretraining:
+            kw = dict(head_configs=c.get("heads", None), loss_configs=c.losses, random_init=c.random_init, bert_model_name=c.bert_model_name,
+                      img_dim=c.img_dim, hidden_size=c.hidden_size, hidden_dropout_prob=c.hidden_dropout_prob,
+                      text_embeddings=c.text_embeddings, encoder=c.encoder)
+            for key in ("tasks", "mask_probability"):        # uniter.py:658-663: constructor defaults when the key is absent
+                if key in c:
+                    kw[key] = c[key]
+            self.uniter = UNITERForPretraining(**kw)
+            tasks = c.get("tasks", DEFAULT_PRETRAINING_TASKS)
+            self.tasks = tasks.split(",") if isinstance(tasks, str) else list(tasks)
+            return
         self.uniter = UNITERForClassification(
             head_configs=c.heads, loss_configs=c.losses, tasks=c.tasks, random_init=c.random_init, bert_model_name=c.bert_model_name,
             img_dim=c.img_dim, hidden_size=c.hidden_size, hidden_dropout_prob=c.hidden_dropout_prob,

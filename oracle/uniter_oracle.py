@@ -155,3 +155,53 @@ def uniter_forward(sd, cfg, sample_list, train=False):
     x = layer_norm(x, sd[h + "classifier.1.LayerNorm.weight"], sd[h + "classifier.1.LayerNorm.bias"], cfg.get("head_layer_norm_eps", 1e-6))
     logits = F.linear(x, sd[h + "classifier.2.weight"], sd[h + "classifier.2.bias"])
     return {"scores": logits.contiguous().view(-1, logits.size(-1)), "sequence_output": seq, "img_pos_feat": inp["img_pos_feat"]}
+
+
+def pretraining_preprocess(sample_list, task, region_masks=None, ignore_index=-1):
+    """UNITERForPretraining's host-side preparation for one task, uniter.py:411-617: `_process_sample_list_for_pretraining`
+    (:449-467; `_remove_mismatched_captions`, :583-617, never writes its selection back — a no-op, kept as one),
+    `_add_image_feat_masked` (:469-478: the regions of the random mask `region_masks` — drawn by `_get_img_mask`, :480-485, here an
+    INPUT — are zeroed, and that mask replaces `image_mask`), `_preprocess_mlm` (:487-504), `_preprocess_itm` (:506-511),
+    `_preprocess_mrc` (:528-544) + `_mask_inputs_in_sample_list` (:519-526).  Returns a new dict."""
+    s = dict(sample_list)
+    if task in ("mrfr", "mrc"):
+        m = region_masks.bool()
+        s["image_feat_masked"] = s["image_feat"].masked_fill(m.unsqueeze(-1).expand_as(s["image_feat"]), 0)      # :473-476
+        s["image_mask"] = m                                                                                        # :477
+        s["cls_prob"] = torch.as_tensor(s["image_info_0"]["cls_prob"])                                             # :458-460
+    if task == "mlm":
+        text = s["lm_label_ids"]
+        image = torch.full(s["image_feat"].shape[:2], fill_value=ignore_index, dtype=torch.long)
+        s["mlm_labels"] = {"text": text, "image": image, "combined_labels": torch.cat([text, image], dim=-1)}      # :492-503
+        s["input_ids"] = s["input_ids_masked"]                                                                     # :504
+    elif task == "itm":
+        s["itm_labels"] = {"is_correct": s["is_correct"]}
+    elif task == "mrc":
+        m = s["image_mask"]
+        cls_prob = s["cls_prob"]
+        s["region_class"] = cls_prob[m.unsqueeze(-1).expand_as(cls_prob)].contiguous().view(-1, cls_prob.size(2))  # :536-541
+        pad = torch.zeros((m.size(0), s["input_ids"].size(1))).to(m)
+        s["image_region_mask"] = torch.cat([pad, m], dim=-1)                                                       # :513-517, 523-525
+        s["image_feat"] = s["image_feat_masked"]                                                                   # :526
+    else:
+        raise ValueError("Task %s is not restated (mlm, itm, mrc)" % task)
+    return s
+
+
+def uniter_pretraining_forward(sd, cfg, sample_list, task, region_masks=None):
+    """UNITERForPretraining.forward (uniter.py:411-440) -> `_infer_with_heads` (:249-275) for task in {mlm, itm, mrc}: the heads'
+    own restatements are oracle.mmft_oracle.{mlm_head, itm_head, mrc_head}.  The MLM decoder is NOT tied here (the reference's
+    pretraining wrapper builds the head without calling `tie_weights`): `heads.mlm.cls.predictions.decoder.weight` is its own tensor."""
+    from oracle import mmft_oracle as H
+    s = pretraining_preprocess(sample_list, task, region_masks)
+    seq = model_base(sd, cfg, s)                                             # (img_masks = s["image_mask"], uniter.py:262)
+    pre = "uniter.heads.%s." % task
+    hsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    if task == "mlm":
+        out = H.mlm_head(hsd, hsd["cls.predictions.decoder.weight"], seq, s["mlm_labels"]["combined_labels"])
+    elif task == "itm":
+        out = H.itm_head(hsd, seq, s["itm_labels"]["is_correct"])
+    else:
+        out = H.mrc_head(hsd, seq, s["region_class"], s["image_region_mask"].bool())
+    out["preprocessed"] = s
+    return out

@@ -250,6 +250,30 @@ def load_transformer_heads_extra():
     return z, case, sds, inputs
 
 
+def load_uniter_pretraining_case():
+    """`uniter_pretraining`: the reference's UNITERForPretraining run for the tasks mlm / itm / mrc (tests/golden/make_uniter_pretraining.py).
+    Parameters carry the prefix `uniter.` (the registered model holds the pretraining wrapper under that name)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "uniter_pretraining.npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {"uniter." + k: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    cfg = dict(
+        vocab_size=case["vocab_size"], hidden_size=case["hidden_size"], num_hidden_layers=case["num_hidden_layers"],
+        num_attention_heads=case["num_attention_heads"], intermediate_size=case["intermediate_size"],
+        max_position_embeddings=case["max_position_embeddings"], type_vocab_size=2, layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
+        attention_probs_dropout_prob=0.1, pad_token_id=0, img_dim=case["img_dim"], label_dim=case["label_dim"])
+    T = z["in_input_ids"].shape[1]
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_ids_masked": torch.from_numpy(z["in_input_ids_masked"]),
+        "lm_label_ids": torch.from_numpy(z["in_lm_label_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "position_ids": torch.arange(0, T, dtype=torch.long).unsqueeze(0), "image_feat": torch.from_numpy(z["in_image_feat"]),
+        "img_pos_feat": torch.from_numpy(z["in_img_pos_feat"]), "attention_mask": torch.from_numpy(z["in_attention_mask"]),
+        "image_mask": torch.from_numpy(z["in_image_mask"]), "is_correct": torch.from_numpy(z["in_is_correct"]),
+        "image_info_0": {"cls_prob": torch.from_numpy(z["in_cls_prob"])}, "dataset_name": "coco", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample
+
+
 def load_m4c_case(name="m4c_small64"):
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))

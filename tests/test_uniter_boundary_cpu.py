@@ -31,7 +31,92 @@ def test_pos_features_follow_the_reference():
     assert torch.allclose(sl["img_pos_feat"], torch.from_numpy(z["img_pos_feat"]), rtol=1e-6, atol=1e-7)
 
 
-def test_pretraining_raises():
-    z, case, cfg, sd, sample = load_uniter_case()
-    with pytest.raises(NotImplementedError):
-        build_model(uniter_model_config(cfg, do_pretraining=True))
+def _pretraining_model(tasks=("mlm", "itm", "mrc")):
+    from tests.golden_utils import load_uniter_pretraining_case
+    z, case, cfg, sd, sample = load_uniter_pretraining_case()
+    ucfg = dict(cfg, head_hidden_size=cfg["hidden_size"], num_labels=2)
+    heads = {"mlm": dict(type="mlm", vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"]),
+             "itm": dict(type="itm", hidden_size=cfg["hidden_size"]),
+             "mrc": dict(type="mrc", hidden_size=cfg["hidden_size"], label_dim=cfg["label_dim"]),
+             "mrfr": dict(type="mrfr"), "wra": dict(type="wra")}
+    mc = uniter_model_config(ucfg, do_pretraining=True, tasks=list(tasks), heads={t: heads[t] for t in tasks}, losses={},
+                             mask_probability=case["mask_probability"])
+    return z, case, cfg, sd, sample, mc
+
+
+def _sample_list(sample, task):
+    """(`position_ids` is [1, T]: like UNITER.add_custom_params, uniter.py:739-743, it is set on the built SampleList)"""
+    from mmf_amd.common.sample import SampleList
+    sl = SampleList({k: v for k, v in sample.items() if k != "position_ids"})
+    sl["position_ids"] = sample["position_ids"]
+    sl["task"] = task
+    return sl
+
+
+def test_pretraining_builds_for_the_tasks_whose_heads_exist():
+    """UNITERForPretraining (uniter.py:350-618): tasks mlm / itm / mrc build with the reference's parameter tree; mrfr / wra raise."""
+    z, case, cfg, sd, sample, mc = _pretraining_model()
+    model = build_model(mc)
+    assert type(model.uniter).__name__ == "UNITERForPretraining"
+    ours = sorted(model.state_dict().keys())
+    ref = sorted("uniter." + str(k) for k in z["state_dict_keys"])
+    assert ours == ref, (sorted(set(ours) - set(ref))[:4], sorted(set(ref) - set(ours))[:4])
+    full = dict(sd)
+    full["uniter.heads.mlm.cls.predictions.decoder.bias"] = full["uniter.heads.mlm.cls.predictions.bias"]
+    model.load_state_dict(full, strict=True)
+    for bad in ("mrfr", "wra"):
+        with pytest.raises(NotImplementedError, match="not built on the HIP side yet"):
+            build_model(_pretraining_model(tasks=("mlm", bad))[-1])
+
+
+@pytest.mark.parametrize("task", ["mlm", "itm", "mrc"])
+def test_pretraining_preparation_equals_the_reference_bit_for_bit(task):
+    """What `_process_sample_list_for_pretraining` + `_preprocess_<task>` hand the encoder and the head, against the reference's own run
+    (tests/golden/make_uniter_pretraining.py) under the same numpy / random seeds — the region masks included."""
+    import random
+    import numpy as np
+    from mmf_amd.common.sample import SampleList
+    z, case, cfg, sd, sample, mc = _pretraining_model()
+    pre = build_model(mc).uniter
+    sl = _sample_list(sample, task)
+    np.random.seed(case["seed"] + 7)
+    random.seed(case["seed"] + 7)
+    pre._process_sample_list_for_pretraining(sl)
+    getattr(pre, "_preprocess_" + task)(sl)
+    assert torch.equal(sl["input_ids"], torch.from_numpy(z[task + "_pre_input_ids"]))
+    assert torch.equal(sl["image_feat"], torch.from_numpy(z[task + "_pre_image_feat"]))
+    assert torch.equal(sl["image_mask"].long(), torch.from_numpy(z[task + "_pre_image_mask"]))
+    if task == "mrc":
+        assert torch.equal(sl["region_class"], torch.from_numpy(z["mrc_pre_region_class"]))
+        assert torch.equal(sl["image_region_mask"].long(), torch.from_numpy(z["mrc_pre_image_region_mask"]))
+    if task == "mlm":
+        assert torch.equal(sl["mlm_labels"]["combined_labels"], torch.from_numpy(z["mlm_pre_combined_labels"]))
+    if task == "itm":
+        assert torch.equal(sl["itm_labels"]["is_correct"], sample["is_correct"])
+
+
+@pytest.mark.parametrize("task", ["mlm", "itm", "mrc"])
+def test_pretraining_step_plumbing(task):
+    """Host logic of one pretraining step per task with the kernel wrappers replaced by extent checkers (tests/native_stub.py): the loss
+    key, and WHICH parameters receive a gradient — the same set as in the reference's run."""
+    from mmf_amd.common.sample import SampleList
+    from tests import native_stub
+    z, case, cfg, sd, sample, mc = _pretraining_model()
+    model = build_model(mc)
+    model.train()
+    sl = _sample_list(sample, task)
+    with native_stub.installed():
+        out = model.uniter(sl)
+        (key, loss), = out["losses"].items()
+        assert key == str(z[task + "_loss_key"])
+        loss.sum().backward()
+    params = dict(model.named_parameters())
+    for gname, norm in zip(z[task + "_grad_names"], z[task + "_grad_norms"]):
+        name = "uniter." + str(gname)
+        if name.endswith("predictions.decoder.bias"):
+            continue
+        p = params[name]
+        if norm == 0.0:
+            assert p.grad is None, "%s: the reference leaves this parameter without a gradient" % name
+        else:
+            assert p.grad is not None and p.grad.shape == p.shape, name

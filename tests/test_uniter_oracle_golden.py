@@ -42,3 +42,43 @@ def test_uniter_oracle_matches_reference_forward_loss_and_gradients():
     # the mask embedding's row 0 gets no gradient (padding_idx = 0), row 1 does (added to every valid region)
     mg = sd["uniter.uniter.img_embeddings.mask_embedding.weight"].grad
     assert float(mg[0].abs().max()) == 0.0 and float(mg[1].abs().max()) > 0.0
+
+
+import pytest
+
+
+@pytest.mark.parametrize("task", ["mlm", "itm", "mrc"])
+def test_uniter_pretraining_oracle_matches_reference(task):
+    """UNITERForPretraining (mmf/models/uniter.py:350-618) for the tasks whose heads are built: what the reference's preprocessing hands
+    the encoder and the head (bit for bit, given the region mask it drew), the loss, and every gradient."""
+    from tests.golden_utils import load_uniter_pretraining_case
+    z, case, cfg, sd, sample = load_uniter_pretraining_case()
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    region_masks = torch.from_numpy(z["mrc_pre_image_mask"]) if task == "mrc" else None
+    out = O.uniter_pretraining_forward(sd, cfg, sample, task, region_masks)
+    pre = out["preprocessed"]
+    assert torch.equal(pre["input_ids"], torch.from_numpy(z[task + "_pre_input_ids"]))
+    assert torch.equal(pre["image_feat"], torch.from_numpy(z[task + "_pre_image_feat"]))
+    assert torch.equal(pre["image_mask"].long(), torch.from_numpy(z[task + "_pre_image_mask"]))
+    if task == "mrc":
+        assert torch.equal(pre["region_class"], torch.from_numpy(z["mrc_pre_region_class"]))
+        assert torch.equal(pre["image_region_mask"].long(), torch.from_numpy(z["mrc_pre_image_region_mask"]))
+    if task == "mlm":
+        assert torch.equal(pre["mlm_labels"]["combined_labels"], torch.from_numpy(z["mlm_pre_combined_labels"]))
+    (key, loss), = out["losses"].items()
+    assert key == str(z[task + "_loss_key"]) and abs(loss.item() - float(z[task + "_loss"])) <= 1e-5 * float(z[task + "_loss"])
+    loss.backward()
+    for gname, norm in zip(z[task + "_grad_names"], z[task + "_grad_norms"]):
+        key = "uniter." + str(gname)
+        if key.endswith("predictions.decoder.bias"):
+            continue
+        g = sd[key].grad
+        if norm == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, key
+            continue
+        if key.endswith("self.key.bias"):
+            continue
+        assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+        full = "grad::%s::%s" % (task, str(gname))
+        if full in z.files:
+            np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)

@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from mmf_amd import functional as Fn
 from mmf_amd import ops  # noqa: F401  (registers torch.ops.mmf_amd.*)
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
@@ -59,6 +60,19 @@ class VisualBERTBase(nn.Module):
     def init_weights(self):
         self.apply(self._init_weights)
 
+    @torch.jit.unused      # (eager only, like the reference's bypass model in practice: the joint layer is reached through autograd Functions)
+    def _bypass_forward(self, embedding_output: Tensor, mask_add: Tensor, text_length: int) -> Tuple[Tensor, Tensor]:
+        """visual_bert.py:116-141: the text rows alone go through the encoder (the mask slice `[:, :, :T, :T]` of the [B, 1, 1, S]
+        additive mask keeps the broadcast query dimension and the first T keys), then ONE `additional_layer` sees text + regions."""
+        B, S = mask_add.shape[0], mask_add.shape[1]
+        text_embedding_output = embedding_output[:, :text_length, :]
+        visual_part = embedding_output[:, text_length:, :]
+        text_mask = mask_add[:, :text_length].contiguous().view(B, 1, 1, text_length)
+        sequence_output = self.encoder(text_embedding_output, text_mask)[0]
+        new_input = Fn.ConcatRowsFn.apply(sequence_output, visual_part)                      # torch.cat(dim=1), :135
+        final_sequence_output = self.additional_layer(new_input, mask_add.view(B, 1, 1, S))[0]
+        return final_sequence_output, self.pooler(final_sequence_output)
+
     def forward(self, input_ids: Tensor, attention_mask: Optional[Tensor] = None, token_type_ids: Optional[Tensor] = None,
                 visual_embeddings: Optional[Tensor] = None, visual_embeddings_type: Optional[Tensor] = None,
                 image_text_alignment: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], List[Tensor]]:
@@ -73,9 +87,11 @@ class VisualBERTBase(nn.Module):
         embedding_output = self.embeddings(input_ids, token_type_ids, visual_embeddings=visual_embeddings,
                                            visual_embeddings_type=visual_embeddings_type,
                                            image_text_alignment=image_text_alignment)
-        if self.bypass_transformer and visual_embeddings is not None:
-            raise NotImplementedError("bypass_transformer (visual_bert.py:116-141) needs a [B,1,S,S] mask; not built yet")
         hidden: List[Tensor] = []
+        if self.bypass_transformer and visual_embeddings is not None:
+            assert not self.output_hidden_states       # (not supported on the bypass path, visual_bert.py:121-123)
+            final_sequence_output, bypass_pooled = self._bypass_forward(embedding_output, mask_add, input_ids.size(1))
+            return final_sequence_output, bypass_pooled, hidden
         if torch.jit.is_scripting():
             sequence_output = self.encoder(embedding_output, extended_attention_mask)[0]
         else:

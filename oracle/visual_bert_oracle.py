@@ -67,6 +67,9 @@ def parameter_shapes(cfg):
         s[p + "output.LayerNorm.bias"] = (H,)
     s["bert.pooler.dense.weight"] = (H, H)
     s["bert.pooler.dense.bias"] = (H,)
+    if cfg.get("bypass_transformer", False):         # visual_bert.py:52-56: one more BertLayer, registered after the pooler
+        for k in [k for k in list(s) if k.startswith("bert.encoder.layer.0.")]:
+            s["bert.additional_layer." + k[len("bert.encoder.layer.0."):]] = s[k]
     if cfg.get("training_head_type", "classification") == "pretraining":
         # VisualBERTForPretraining (visual_bert.py:160-216): `cls` = HF BertPreTrainingHeads; `cls.predictions.decoder.weight` is the
         # word-embedding table (tie_weights, :227-235) and `cls.predictions.decoder.bias` is `cls.predictions.bias` (HF <= 4.10
@@ -192,6 +195,20 @@ def visual_bert_base(sd, cfg, input_ids, attention_mask, token_type_ids, visual_
     ext = ext.to(dtype=sd["bert.embeddings.LayerNorm.weight"].dtype)  # :102-105
     ext = (1.0 - ext) * -10000.0  # :106
     hidden = embeddings(sd, cfg, input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, hd)  # :108
+    if cfg.get("bypass_transformer", False) and visual_embeddings is not None:
+        # :116-141 — the text alone goes through the encoder; the visual embeddings join it in ONE `additional_layer`.  The mask
+        # slice `extended_attention_mask[:, :, :text_length, :text_length]` (:129-131) acts on a [B, 1, 1, S] tensor: it keeps the
+        # broadcast query dimension and the first T keys.
+        T = input_ids.size(1)
+        text, visual = hidden[:, :T, :], hidden[:, T:, :]
+        text_ext = ext[:, :, :T, :T]
+        for i in range(cfg["num_hidden_layers"]):
+            text, _ = bert_layer(sd, cfg, i, text, text_ext, hd, ad)
+        joint = torch.cat((text, visual), dim=1)                                                             # :135
+        add = {k.replace("bert.additional_layer.", "bert.encoder.layer.0."): v for k, v in sd.items() if k.startswith("bert.additional_layer.")}
+        final, _ = bert_layer(add, cfg, 0, joint, ext, hd, ad)                                               # :136-138
+        pooled = torch.tanh(F.linear(final[:, 0], sd["bert.pooler.dense.weight"], sd["bert.pooler.dense.bias"]))   # :139
+        return final, pooled, []
     all_hidden = [hidden]
     for i in range(cfg["num_hidden_layers"]):  # BertEncoderJit.forward, hf_layers.py:316-355
         hidden, _ = bert_layer(sd, cfg, i, hidden, ext, hd, ad)

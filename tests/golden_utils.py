@@ -150,6 +150,23 @@ def load_uniter_case(name="uniter_small64"):
     return z, case, cfg, sd, sample
 
 
+def load_bypass_case():
+    """`visual_bert_bypass`: `bypass_transformer: true` (text-only encoder + one joint `additional_layer`), default pooler strategy."""
+    z = np.load(os.path.join(GOLDEN_DIR, "visual_bert_bypass.npz"), allow_pickle=False)
+    zz, case, cfg, sd, sample = load_case("small64")
+    case = ast.literal_eval(str(z["case"]))
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {k[len("model."):]: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    cfg = dict(cfg, bypass_transformer=True, pooler_strategy="default")
+    sample = {
+        "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
+        "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),
+        "image_info_0": {"max_features": torch.from_numpy(z["in_max_features"])},
+        "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "vqa2", "dataset_type": "train",
+    }
+    return z, case, cfg, sd, sample
+
+
 def load_nlvr2_case():
     z = np.load(os.path.join(GOLDEN_DIR, "visual_bert_nlvr2.npz"), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))

@@ -26,6 +26,11 @@ def _nlvr2():
                                    losses=[dict(type="cross_entropy")]), sample, "model."
 
 
+def _bypass():
+    z, case, cfg, sd, sample = G.load_bypass_case()
+    return z, MU.build_visual_bert(cfg, sd, device="cpu", bypass_transformer=True, pooler_strategy="default"), sample, "model."
+
+
 def _pretraining():
     z, case, cfg, sd, sample = G.load_pretraining_case()
     return z, MU.build_visual_bert_pretraining(cfg, sd, device="cpu"), sample, "model."
@@ -69,7 +74,7 @@ def _m4c():
     return z, MU.build_m4c(cfg, sd, device="cpu"), sample, ""
 
 
-CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "mmbt": _mmbt, "mmbt_pretraining": _mmbt_pretraining, "mmft": _mmft, "vilbert": _vilbert, "vilbert_pretraining": _vilbert_pretraining, "uniter": _uniter,
+CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "visual_bert_bypass": _bypass, "mmbt": _mmbt, "mmbt_pretraining": _mmbt_pretraining, "mmft": _mmft, "vilbert": _vilbert, "vilbert_pretraining": _vilbert_pretraining, "uniter": _uniter,
          "m4c": _m4c}
 
 
@@ -77,7 +82,7 @@ CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_
 def test_training_step_plumbing(name):
     z, model, sample, prefix = CASES[name]()
     model.train()
-    key = name.split("_nlvr2")[0].split("_pretraining")[0]
+    key = name.split("_nlvr2")[0].split("_pretraining")[0].split("_bypass")[0]
     full = Config(model=key, optimizer=dict(params=dict(lr=5e-5)), model_config={key: model.config})
     opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
     with native_stub.installed() as calls:

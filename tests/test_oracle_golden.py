@@ -116,3 +116,29 @@ def test_oracle_pretraining_head_matches_reference():
     blank = dict(sample, lm_label_ids=torch.full_like(sample["lm_label_ids"], -1))
     with torch.no_grad():
         assert torch.isnan(O.visual_bert_pretraining_forward(sd, cfg, blank)["loss"])
+
+
+def test_oracle_bypass_transformer_matches_reference():
+    """`bypass_transformer: true` (visual_bert.py:52-56, 116-141): the text alone through the encoder, the regions joining in one
+    `additional_layer`; scores, loss and every gradient against the reference's own run."""
+    from tests.golden_utils import load_bypass_case
+    z, case, cfg, sd, sample = load_bypass_case()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.visual_bert_forward(sd, cfg, sample, train=False)
+    np.testing.assert_allclose(out["scores"].detach().numpy(), z["scores"], rtol=1e-5, atol=2e-6)
+    loss = O.logit_bce(out["scores"], sample["targets"])
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        key = str(gname)[len("model."):]
+        g = sd[key].grad
+        if norm == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, key
+            continue
+        if key.endswith("self.key.bias"):
+            continue
+        assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
+        full = "grad::model." + key
+        if full in z.files:
+            np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)

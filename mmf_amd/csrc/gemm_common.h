@@ -205,7 +205,14 @@ DEVI void store_bf8(bf16* p, f32x8 v) {
     bf16x8 t;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+#ifdef MMF_EPI_NT_STORES
+    // EXPERIMENT BUILD ONLY (python -m mmf_amd.csrc.build --tag nt with MMF_AMD_EXTRA_HIPCC_FLAGS=-DMMF_EPI_NT_STORES, loaded through
+    // MMF_AMD_LIB): epilogue outputs stored non-temporally so that they stream past the operand panels an XCD keeps in its L2
+    // instead of evicting them.  The regular library does not contain this path.
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, t), reinterpret_cast<u32x4*>(p));
+#else
     *reinterpret_cast<bf16x8*>(p) = t;
+#endif
 }
 
 // Epilogue of one output row segment: 8 consecutive columns n..n+7 of row m (fp32 accumulators staged through LDS
@@ -299,8 +306,13 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
         float* C = reinterpret_cast<float*>(e.C) + off;
         if (full && ((e.ldc & 3) == 0)) {
             if (e.beta != 0.f) v += e.beta * load_f8(C);
+#ifdef MMF_EPI_NT_STORES
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(C));
+            __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(C + 4));
+#else
             *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#endif
         } else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (ok[r]) C[r] = v[r] + (e.beta != 0.f ? e.beta * C[r] : 0.f);

@@ -205,13 +205,13 @@ DEVI void store_bf8(bf16* p, f32x8 v) {
     bf16x8 t;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
-#ifdef MMF_EPI_NT_STORES
-    // EXPERIMENT BUILD ONLY (python -m mmf_amd.csrc.build --tag nt with MMF_AMD_EXTRA_HIPCC_FLAGS=-DMMF_EPI_NT_STORES, loaded through
-    // MMF_AMD_LIB): epilogue outputs stored non-temporally so that they stream past the operand panels an XCD keeps in its L2
-    // instead of evicting them.  The regular library does not contain this path.
-    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, t), reinterpret_cast<u32x4*>(p));
-#else
+    // Non-temporal: an epilogue output is never re-read by the kernel that writes it, so it should stream past the operand panels
+    // an XCD keeps in its L2 instead of evicting them.  Measured (profiles/r03_nt_stores_ab.txt, same box, twice): step 8.62 -> 8.41
+    // ms, FETCH_SIZE of the 128 x 128 family 85.4 -> 75.4 MB per launch.  -DMMF_EPI_PLAIN_STORES restores ordinary stores (A/B).
+#ifdef MMF_EPI_PLAIN_STORES
     *reinterpret_cast<bf16x8*>(p) = t;
+#else
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, t), reinterpret_cast<u32x4*>(p));
 #endif
 }
 
@@ -306,12 +306,12 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
         float* C = reinterpret_cast<float*>(e.C) + off;
         if (full && ((e.ldc & 3) == 0)) {
             if (e.beta != 0.f) v += e.beta * load_f8(C);
-#ifdef MMF_EPI_NT_STORES
-            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(C));
-            __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(C + 4));
-#else
+#ifdef MMF_EPI_PLAIN_STORES
             *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#else
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(C));
+            __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(C + 4));
 #endif
         } else {
 #pragma unroll

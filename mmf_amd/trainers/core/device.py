@@ -13,9 +13,12 @@ for xGMI:
   * the bucket LAYOUT is fixed at construction (one 256-byte-aligned slot per parameter, zero-filled when the
     parameter has no gradient on this rank), so every rank always issues collectives of identical size
     whatever its local used-parameter set is;
-  * buckets travel as bf16 by default (`comm_dtype`; half the xGMI bytes: 229 MB instead of 458 MB per step);
-    parameters whose gradient wants fp32 on the wire — by default embedding tables, whose rows receive
-    sparse, differently scaled contributions — go into buckets of their own that stay fp32 (the word
+  * buckets travel as fp32 by default — the reference's DDP all-reduce is fp32 and this class is its drop-in —
+    and as bf16 when asked to (`comm_dtype=torch.bfloat16`: half the xGMI bytes, 229 MB instead of 458 MB per
+    step; each rank's contribution is scaled by 1 / world BEFORE it is rounded, so the bf16 sum cannot overflow
+    and the wire carries the mean; a deviation from the reference's arithmetic held to the bf16 bound in the
+    tests).  With a bf16 wire, parameters whose gradient wants fp32 — by default embedding tables, whose rows
+    receive sparse, differently scaled contributions — go into buckets of their own that stay fp32 (the word
     embedding is also the last gradient backward produces: the un-overlappable tail);
   * a bucket is all-reduced (RCCL, `backend="nccl"`) on the communicator's own stream as soon as its last
     expected gradient has been accumulated (`register_post_accumulate_grad_hook`), overlapping the remaining
@@ -43,14 +46,16 @@ def _wants_fp32_on_the_wire(module):
 
 
 class GradientReducer:
-    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, comm_dtype=torch.bfloat16, fp32_params=None,
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, comm_dtype=torch.float32, fp32_params=None,
                  static_graph=True):
         """`static_graph=True` (DDP's contract of the same name): once the set of parameters that receive a gradient has been
-        identical on all ranks for two consecutive steps it is frozen — `finish()` then needs neither the bitmap exchange nor
-        the host synchronisation that reading it costs, and a later deviation raises instead of hanging a collective."""
+        the same for two consecutive steps AND identical on every rank (each rank's own bitmap equals the agreed one — checked
+        with the same exchange, never assumed) it is frozen — `finish()` then needs neither the bitmap exchange nor the host
+        synchronisation that reading it costs, and a later deviation raises instead of hanging a collective.  A model whose
+        ranks use different parameters (a head drawn per rank, as UNITERForPretraining does) simply never freezes."""
         self.module = module
         self.static_graph = static_graph
-        self._stable, self._frozen, self._last_used = 0, False, None
+        self._stable, self._frozen, self._last_used, self._frozen_local = 0, False, None, None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_dtype = comm_dtype if comm_dtype is not None else torch.float32
@@ -142,7 +147,10 @@ class GradientReducer:
         dense = len(have) == len(plist) and all(p.numel() % 64 == 0 for p in plist)
         flat = (torch.empty if dense else torch.zeros)(total, dtype=dtype, device=device)
         if have:
-            torch._foreach_copy_([flat[o:o + p.numel()].view_as(p) for p, o in have], [p.grad for p, _ in have])
+            srcs = [p.grad for p, _ in have]
+            if dtype != torch.float32:
+                srcs = torch._foreach_mul(srcs, 1.0 / self.world)     # the mean's 1 / world before the rounding (see module docstring)
+            torch._foreach_copy_([flat[o:o + p.numel()].view_as(p) for p, o in have], srcs)
         return flat, have
 
     def _launch(self, bi):
@@ -168,15 +176,16 @@ class GradientReducer:
             self._next += 1
         if self._frozen:
             local = tuple(1 if p.grad is not None else 0 for p in self.params)
-            if local != self._last_used:
+            if local != self._frozen_local:
                 raise RuntimeError("GradientReducer(static_graph=True): the set of parameters that receive a gradient changed "
                                    "after it had been frozen; build the reducer with static_graph=False")
             inv = 1.0 / self.world
             for work, flat, plist, offs in self._inflight:
                 work.wait()
                 if flat.dtype != torch.float32:
-                    flat = flat.float()
-                flat.mul_(inv)
+                    flat = flat.float()      # (already the mean: scaled before the rounding)
+                else:
+                    flat.mul_(inv)
                 for off, p in zip(offs, plist):
                     p.grad = flat[off:off + p.numel()].view_as(p) if local[self.index[id(p)]] else None
             self.reset()
@@ -188,9 +197,10 @@ class GradientReducer:
         used = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32, device=device)
         late_map = torch.tensor([1 if id(p) not in self._included and p.grad is not None else 0 for p in self.params],
                                 dtype=torch.int32, device=device)
-        both = torch.stack([used, late_map])
+        both = torch.stack([used, late_map, 1 - used])
         dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
-        used_any, late_any = both[0].tolist(), both[1].tolist()
+        used_any, late_any, unused_any = both[0].tolist(), both[1].tolist(), both[2].tolist()
+        ranks_agree = not any(u and n for u, n in zip(used_any, unused_any))    # no parameter used on some ranks only
         late_params = [p for p, f in zip(self.params, late_any) if f]        # the same list on every rank
         late_flat = late_offs = None
         if late_params:
@@ -206,26 +216,35 @@ class GradientReducer:
                 torch._foreach_copy_([late_flat[o:o + p.numel()].view_as(p) for p, o in src], [p.grad for p, _ in src])
             dist.all_reduce(late_flat, op=dist.ReduceOp.SUM, group=self.group)
         inv = 1.0 / self.world
+        rebound = set()
         for work, flat, plist, offs in self._inflight:
             work.wait()
             if flat.dtype != torch.float32:
-                flat = flat.float()
-            flat.mul_(inv)   # one multiply per bucket
+                flat = flat.float()      # (already the mean: scaled before the rounding)
+            else:
+                flat.mul_(inv)           # one multiply per bucket
             for off, p in zip(offs, plist):
                 if used_any[self.index[id(p)]]:
                     p.grad = flat[off:off + p.numel()].view_as(p)   # rebind, no copy: the optimizer reads the bucket slice
+                    rebound.add(id(p))
                 else:
                     p.grad = None
         if late_params:
             late_flat.mul_(inv)
             for off, p in zip(late_offs, late_params):
-                p.grad = p.grad + late_flat[off:off + p.numel()].view_as(p)
+                late = late_flat[off:off + p.numel()].view_as(p)
+                # A late parameter whose bucket went out holds (after the rebind above) the mean of the ranks that had it in
+                # time.  If its WHOLE bucket was skipped (nobody used any of its parameters last step: no collective, nothing
+                # rebound) `p.grad` is still this rank's local gradient — or None where it did not fire — and the mean is the
+                # straggler sum alone: assigned, never added to the local value.
+                p.grad = p.grad + late if id(p) in rebound else late
         self._skip = {id(p) for p, f in zip(self.params, used_any) if not f}
         agreed = tuple(used_any)
         self._stable = self._stable + 1 if agreed == self._last_used else 0
         self._last_used = agreed
-        if self.static_graph and self._stable >= 1 and not late_params:
+        if self.static_graph and self._stable >= 1 and not late_params and ranks_agree:
             self._frozen = True
+            self._frozen_local = agreed      # == every rank's own bitmap (ranks_agree)
         self.reset()
 
     def remove(self):

@@ -95,7 +95,7 @@ def _worker2(rank, world, port, q):
             return self.b(torch.tanh(z))
 
     net = Net()
-    red = GradientReducer(net, bucket_bytes=512, static_graph=False)
+    red = GradientReducer(net, bucket_bytes=512, static_graph=False, comm_dtype=torch.bfloat16)
     dts = sorted({str(b["dtype"]) for b in red.buckets})
     emb_bucket = red.buckets[red._bucket_of[id(net.emb.weight)]]
     out = {"dtypes": dts, "emb_fp32_alone": emb_bucket["dtype"] == torch.float32 and all(p is net.emb.weight for p in emb_bucket["params"])}
@@ -158,6 +158,86 @@ def test_gradient_reducer_accumulation_partial_use_and_wire_dtypes():
             tol = 1e-6 if name.startswith("emb") else 2e-2 * float(mean.abs().max()) + 1e-6      # bf16 on the wire elsewhere
             assert r0 is not None and r1 is not None, (step, name)
             assert torch.allclose(torch.tensor(r0), mean, atol=tol) and torch.allclose(torch.tensor(r1), mean, atol=tol), (step, name)
+
+
+def _worker3(rank, world, port, q):
+    """(i) a parameter whose WHOLE bucket was skipped (nobody used any of its parameters in the previous step) and that
+    then fires on ONE rank only must come out as the mean on both ranks (not local + mean, not a TypeError on the rank where it did
+    not fire); (ii) static_graph=True must not freeze — and must not raise later — while some parameter is used on one rank only."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mmf_amd.trainers.core.device import GradientReducer
+    from mmf_amd.utils import distributed as D
+    D.distributed_init_from_env(backend="gloo")
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(8, 16)
+            self.side = torch.nn.Linear(8, 16)      # its weight and bias fill buckets of their own (bucket_bytes is tiny)
+            self.b = torch.nn.Linear(16, 4)
+
+        def forward(self, x, use_side):
+            z = self.a(x)
+            if use_side:
+                z = z + self.side(x)
+            return self.b(torch.tanh(z))
+
+    res, frozen, err = {}, {}, None
+    for static in (False, True):
+        torch.manual_seed(0)
+        net = Net()
+        red = GradientReducer(net, bucket_bytes=64, static_graph=static)
+        try:
+            for step in range(6):
+                net.zero_grad(set_to_none=True)
+                # static_graph=False: steps 0-1 side unused everywhere (its buckets are skipped), from step 2 on used on rank 1 only;
+                # static_graph=True: used on rank 1 only from the first step on (a use pattern that CHANGES after a legitimate
+                # freeze raises by contract, like DDP's static_graph)
+                use_side = rank == 1 and (static or step >= 2)
+                g = torch.Generator().manual_seed(100 * step + rank)
+                x = torch.randn(5, 8, generator=g)
+                net(x, use_side).pow(2).sum().backward()
+                local = {n: (p.grad.clone() if p.grad is not None else None) for n, p in net.named_parameters()}
+                red.finish()
+                res[(static, step)] = (local, {n: (p.grad.clone() if p.grad is not None else None) for n, p in net.named_parameters()})
+            frozen[static] = red._frozen
+        except Exception as e:      # noqa: BLE001 — reported to the parent, which fails the test
+            err = repr(e)
+        red.remove()
+    ser = {"%d_%d" % (int(k[0]), k[1]): tuple({n: (None if t is None else t.tolist()) for n, t in d.items()} for d in v) for k, v in res.items()}
+    q.put((rank, ser, frozen, err))
+    D.synchronize()
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_skipped_bucket_straggler_and_rankwise_use_never_freeze():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker3, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, res, frozen, err = q.get(timeout=180)
+        got[rank] = (res, frozen, err)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][2] is None and got[1][2] is None, (got[0][2], got[1][2])
+    assert got[0][1] == {False: False, True: False} and got[1][1] == {False: False, True: False}     # rank-dependent use: never frozen
+    for key in got[0][0]:
+        (l0, r0), (l1, r1) = got[0][0][key], got[1][0][key]
+        for name in l0:
+            if l0[name] is None and l1[name] is None:
+                assert r0[name] is None and r1[name] is None, (key, name)
+                continue
+            z = torch.zeros_like(torch.tensor(l0[name] if l0[name] is not None else l1[name]))
+            mean = ((torch.tensor(l0[name]) if l0[name] is not None else z) + (torch.tensor(l1[name]) if l1[name] is not None else z)) / 2
+            assert r0[name] is not None and r1[name] is not None, (key, name)
+            assert torch.allclose(torch.tensor(r0[name]), mean, atol=1e-6), (key, name)
+            assert torch.allclose(torch.tensor(r1[name]), mean, atol=1e-6), (key, name)
 
 
 def test_single_process_is_a_noop():

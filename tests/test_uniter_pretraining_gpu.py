@@ -1,10 +1,9 @@
 """UNITERForPretraining (mmf/models/uniter.py:350-618) end to end on the GPU for the tasks mlm / itm / mrc, against the fixture recorded
 from the reference's own run (tests/golden/make_uniter_pretraining.py) under the same numpy / random seeds.
 
-WRITTEN AFTER THIS ROUND'S GPU BUDGET WAS SPENT: it has never run on hardware, so it is opt-in (MMF_AMD_RUN_UNVERIFIED=1) instead of
-part of the default `-m gpu` run — the pieces it composes are verified on their own (encoder: tests/test_uniter_gpu.py, heads:
-tests/test_mmft_gpu.py, host-side preparation bit for bit: tests/test_uniter_boundary_cpu.py).  First run: next round."""
-import os
+First run on hardware: round 3, green (gpurun_out/r03a/unverified.log); part of the default `-m gpu` run since.  The pieces it composes
+are verified on their own as well (encoder: tests/test_uniter_gpu.py, heads: tests/test_mmft_gpu.py, host-side preparation bit for
+bit: tests/test_uniter_boundary_cpu.py)."""
 import random
 
 import numpy as np
@@ -15,8 +14,7 @@ from mmf_amd.utils.build import build_model
 from tests.model_utils import sample_to
 from tests.test_uniter_boundary_cpu import _pretraining_model, _sample_list
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MMF_AMD_RUN_UNVERIFIED") != "1", reason="never run on hardware yet (see module docstring)")]
+pytestmark = pytest.mark.gpu
 TOL = 5e-2
 
 

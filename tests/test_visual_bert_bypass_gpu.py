@@ -1,11 +1,9 @@
 """`bypass_transformer: true` of VisualBERT (mmf/models/visual_bert.py:52-56, 116-141) on the GPU against the fixture recorded from the
 reference's own run (tests/golden/make_visual_bert_bypass.py).
 
-WRITTEN AFTER THIS ROUND'S GPU BUDGET WAS SPENT: never run on hardware, so opt-in (MMF_AMD_RUN_UNVERIFIED=1) instead of part of the
-default `-m gpu` run.  The path is host-side glue over kernels that are verified on their own (encoder layers, row concat, pooler): its
-oracle is pinned (tests/test_oracle_golden.py), its host logic dry-runs with the reference's gradient pattern
-(tests/test_dryrun_models_cpu.py[visual_bert_bypass]).  First run: next round."""
-import os
+First run on hardware: round 3, green; part of the default `-m gpu` run since.  The path is host-side glue over kernels that are verified
+on their own (encoder layers, row concat, pooler): its oracle is pinned (tests/test_oracle_golden.py), its host logic dry-runs with the
+reference's gradient pattern (tests/test_dryrun_models_cpu.py[visual_bert_bypass])."""
 
 import numpy as np
 import pytest
@@ -15,8 +13,7 @@ from mmf_amd.common.sample import SampleList
 from tests.golden_utils import load_bypass_case
 from tests.model_utils import build_visual_bert, sample_to
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MMF_AMD_RUN_UNVERIFIED") != "1", reason="never run on hardware yet (see module docstring)")]
+pytestmark = pytest.mark.gpu
 TOL = 5e-2
 
 

@@ -35,6 +35,7 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 */
        MMF_TUN_LN_OLD = 3,         /* 1: LayerNorm with the one-wave-per-row, 8-byte-per-lane kernels even when H % 256 == 0 (A/B measurements) */
        MMF_TUN_ATTN_BWD_TWO_PASS = 4,   /* 1: head_dim-64 attention backward as the separate dQ and dK/dV kernels (A/B measurements) */
+       MMF_TUN_GEMM_WIDE_KS = 5,   /* wide-tile wave layout: 2 the two ping-pong groups split every K-step (fewer LDS fragment reads), 1 never, 0 where it measured faster (256x96, K >= 1536) */
        MMF_TUN_COUNT = 8 };
 int mmf_amd_set_tunable(int which, int value);
 int mmf_amd_get_tunable(int which);

@@ -343,14 +343,14 @@ int launch_grouped_n(const GroupArgs& g, hipStream_t s) {
 
 
 // ---- wide tiles (gemm_wide.h): one workgroup per CU ---------------------------------------------------------------------
-template <int BM_, int BN_, int WGM, int WGN, int NS>
+template <int BM_, int BN_, int WGM, int WGN, int NS, int KS = 1>
 int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM_ - 1) / BM_, tn = d->N / BN_;
     constexpr int lds_bytes = NS * (BM_ + BN_) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (a0 != hipSuccess || a1 != hipSuccess) { mmf_amd_set_error(hipGetErrorString(a0 != hipSuccess ? a0 : a1)); return 2; }
         attr_set = true;
     }
@@ -361,8 +361,8 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int abl = (d->debug_flags >> 4) & 7;
 #define MMF_WIDE_ABL_CASE(V)                                                                                                          \
     if (abl == V) {                                                                                                                   \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, V>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe()); \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS, V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS, V>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe()); \
         MMF_CHECK_LAUNCH();                                                                                                           \
         return 0;                                                                                                                     \
     }
@@ -370,21 +370,25 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
 #undef MMF_WIDE_ABL_CASE
 #endif
     if (d->M % BM_)
-        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
     else
-        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false, KS>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
     MMF_CHECK_LAUNCH();
     return 0;
 }
 
 // Modelled launch time (us) of a tile shape: rounds x (K-steps x max(staging, MFMA) + fixed), with the measured per-CU staging rate
 // (85 GB/s, profiles/r02_lds_dma_ceiling.txt) and 90 % of the per-CU MFMA peak; `slots` = workgroups resident per CU.
+// Round 3: the K-step is max(staging, MFMA) + half the smaller one — what the ablations of the shipped kernels show
+// (profiles/r02_wide_gemm_ablation.txt: DMA alone 0.46, MFMA alone 0.38 / 0.58 / 0.52, together 0.63 / 0.81 / 0.79 us per step for
+// 256x96 / 192x192 / 256x128) — with the measured rates 100 GB/s per CU and 8.1 TFLOP/s per CU (the sustained clock, not 2.4 GHz).
 static double tile_cost(long M, long N, long K, int bm, int bn, int slots) {
     const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const double rounds = (double)((tiles + 256L * slots - 1) / (256L * slots));
-    const double stage_us = (double)(bm + bn) * 128.0 * slots / 85e3;
-    const double mfma_us = 2.0 * bm * bn * 64.0 * slots / (9.77e6 * 0.9);
-    return rounds * ((double)((K + 63) / 64) * (stage_us > mfma_us ? stage_us : mfma_us) + 5.0);
+    const double stage_us = (double)(bm + bn) * 128.0 * slots / 100e3;
+    const double mfma_us = 2.0 * bm * bn * 64.0 * slots / 8.1e6;
+    const double hi = stage_us > mfma_us ? stage_us : mfma_us, lo = stage_us > mfma_us ? mfma_us : stage_us;
+    return rounds * ((double)((K + 63) / 64) * (hi + 0.5 * lo) + 5.0);
 }
 // 0: keep the 128-row kernel; 1: 256 x 96, 2: 192 x 192, 3: 256 x 128.
 static int wide_choice(const mmf_gemm_desc* d) {
@@ -410,8 +414,16 @@ template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     if constexpr (!AK && !BK_ && is_bf16<AT>::value && is_bf16<BT>::value) {
         if (e.splits <= 1) {
-            switch (wide_choice(d)) {
-                case 1: return launch_wide<256, 96, 4, 2, 3>(d, e, s);
+            // K-split wave layout (gemm_wide.h, KS = 2): measured on the VQA2 shapes (tools/gemm_ab.py, profiles/r03_gemm_ab_ks.txt)
+            // it wins 3 - 5 % on the 256 x 96 tile once the K-loop is long (K = 2304 / 3072: 31.4 -> 30.2, 40.3 -> 38.1, 40.7 -> 39.4 us)
+            // and loses the extra LDS pass of its epilogue at K = 768 (18.6 -> 19.3 us) and on the square tiles (36.4 -> 43.1 us).
+            // MMF_TUN_GEMM_WIDE_KS: 0 that rule, 1 never, 2 always (A/B measurements).
+            const int ks_t = mmf_amd_get_tunable(MMF_TUN_GEMM_WIDE_KS);
+            const int wc = wide_choice(d);
+            // (Only the 256 x 96 tile is instantiated with KS = 2: the square tiles lost with it and would spill registers.)
+            const bool ks2 = wc == 1 && (ks_t == 2 || (ks_t == 0 && d->K >= 1536));
+            switch (wc) {
+                case 1: return ks2 ? launch_wide<256, 96, 4, 1, 3, 2>(d, e, s) : launch_wide<256, 96, 4, 2, 3>(d, e, s);
                 case 2: return launch_wide<192, 192, 2, 4, 3>(d, e, s);
                 case 3: return launch_wide<256, 128, 4, 2, 3>(d, e, s);
                 default: break;

@@ -327,4 +327,32 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
     }
 }
 
+// Lean epilogue of the wide-tile kernels' common cases (gemm_wide.h): bias, act 0 / 2, hash dropout, residual, bf16 output, full
+// 8-column segments, no row remap.  The ONE row-wise bf16 side input (the residual, else the act-2 multiplier) arrives in `side`:
+// the kernel fetched it while its last K-steps were still running (one workgroup per CU has nothing else to hide that latency).
+DEVI bool epilogue_fast_ok(const EpiArgs& e) {
+    return !e.coladd && !e.rowtab && e.grp_in == 0 && !e.out_f32 && (e.act == 0 || e.act == 2) && (e.ldc & 7) == 0 && (e.N & 7) == 0 &&
+           (!e.resid || (e.ldr & 7) == 0) && e.splits <= 1 && !(e.resid && e.act == 2);
+}
+DEVI void epilogue8_fast(const EpiArgs& e, int m, int n, f32x8 v, uint4 side, uint32_t dkey) {
+    if (m >= e.M) return;
+    if (e.bias) v += load_f8(e.bias + n);
+    f32x8 sv;
+    {
+        const bf16x8 t = __builtin_bit_cast(bf16x8, side);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = (float)t[i];
+    }
+    if (e.act == 2) v *= sv;
+    if (e.drop.thr16) {
+        const uint32_t idx = (uint32_t)m * (uint32_t)e.N + (uint32_t)n;
+        const f32x4 s0 = drop_scale4(dkey, idx, e.drop.thr16, e.drop.scale);
+        const f32x4 s1 = drop_scale4(dkey, idx + 4, e.drop.thr16, e.drop.scale);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] *= s0[r]; v[r + 4] *= s1[r]; }
+    }
+    if (e.resid) v += sv;
+    store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v);
+}
+
 }  // namespace gemm

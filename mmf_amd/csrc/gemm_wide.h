@@ -30,13 +30,23 @@ namespace gemm {
 
 template <int N> DEVI void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// BM x BN tile, WGM x WGN wave grid (WGM * WGN == 8), NS ring stages.
-template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int ABL = 0>
+// BM x BN tile, WGM x WGN wave grid, NS ring stages.
+//   KS = 1: WGM * WGN == 8, every wave multiplies both 32-deep halves of a 64-deep K-step over its (BM / WGM) x (BN / WGN) tile.
+//   KS = 2: WGM * WGN == 4, the wave grid covers the tile ONCE per ping-pong group and group g multiplies only half g of every
+//           K-step: same MFMA count per wave and K-step, wave tiles twice as large, so the fragments a wave pulls from LDS per
+//           K-step drop from 2 (NFM + NFN) to NFM' + NFN' ds_read_b128 (256 x 96: 14 -> 10, 192 x 192: 18 -> 12).  The K-loop of
+//           the KS = 1 form is bound by the LDS port, not by the matrix pipe (profiles/r02_wide_gemm_ablation.txt: MFMA alone
+//           0.41 us per step, MFMA + fragment reads 0.58, everything 0.68: a LOAD interval — 4 waves x 14 reads + the DMA writes
+//           landing in the same LDS — is longer than the COMP interval it is meant to hide behind).  The two K-halves are summed
+//           in the epilogue's LDS stage (group 1 adds in place before the row-wise pass).
+template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int KS = 1, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
                                                             int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi, Probe pr) {
     // ABL (ablation builds only, -DMMF_WIDE_ABLATE): bit 0 no DMA issue in the loop, bit 1 no MFMA, bit 2 no fragment reads, bit 3 no epilogue
     constexpr int dbg = ABL;
-    static_assert(WGM * WGN == 8, "eight waves");
+    static_assert(KS == 1 || KS == 2, "K split across the two ping-pong groups");
+    static_assert(WGM * WGN * KS == 8, "eight waves");
+    constexpr int KK = 2 / KS;                   // 32-deep sub-steps a wave multiplies per 64-deep K-step
     static_assert(NS == 3, "the schedule below is written for a three-stage ring");
     static_assert(BM_ % 64 == 0 && BN_ % 32 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -50,7 +60,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int gpos = KS == 2 ? (wave & 3) : wave;   // position in the wave grid (KS = 2: the grid repeats per group, group = K-half)
+    const int wm = gpos / WGN, wn = gpos % WGN;
     const bool probing = pr.buf != nullptr;
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
     if (probing) pt[0] = __builtin_amdgcn_s_memrealtime();
@@ -113,15 +124,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
     for (int i = 0; i < NFM; ++i)
 #pragma unroll
         for (int j = 0; j < NFN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[2][NFM], fb[2][NFN];
+    bf16x8 fa[KK][NFM], fb[KK][NFN];
 
     // fragment addresses: row operand image, fragment f (16 rows), sub-step kk: lane l -> row (l & 15), chunk kk*4 + (l >> 4)
     const int frow = lane & 15, fswz = lane & 7;
     const int a_off = (wm * WTM + frow) * 128, b_off = A_BYTES + (wn * WTN + frow) * 128;
-    const int c0 = (((lane >> 4)) ^ fswz) << 4, c1 = ((4 + (lane >> 4)) ^ fswz) << 4;
+    const int c0_ = (((lane >> 4)) ^ fswz) << 4, c1_ = ((4 + (lane >> 4)) ^ fswz) << 4;
+    const int c0 = (KS == 2 && grp == 1) ? c1_ : c0_, c1 = c1_;     // KS = 2: the wave's only sub-step is K-half `grp`
     // LOAD: all 2 * (NFM + NFN) fragments of a K-step, with the P DMA pieces of the stage issued in between (one piece after
     // every few reads, order pinned): the LDS read port and the address path of the LDS-DMA are different units.
-    constexpr int NREAD = 2 * (NFM + NFN);
+    constexpr int NREAD = KK * (NFM + NFN);
     auto load_frags = [&](int slot, int islot, bool with_issue) {
         if constexpr ((dbg & 4) != 0) { if (with_issue && !(dbg & 1)) issue(islot); return; }
         const unsigned char* st = smem + slot * STAGE;
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
         if constexpr ((dbg & 2) != 0) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int i = 0; i < NFM; ++i)
 #pragma unroll
@@ -176,6 +188,40 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
         __builtin_amdgcn_sched_barrier(0);
     };
     auto wait_one_stage_left = [&]() { if (wave < 4) wait_vm<P_LO>(); else wait_vm<P_HI>(); };
+
+    // ---- side-input prefetch of the epilogue (see epilogue8_fast) -------------------------------------------------------------------
+    // Every thread owns fixed (row, 8-column segment) slots of the row-wise epilogue pass; their residual / multiplier rows are fetched
+    // into registers when the K-loop has two steps left.  The loads are issued unconditionally per wave (clamped addresses) so that
+    // the counted wait of the penultimate K-step can step over exactly NSIDE of them.
+    constexpr int CLD = BN_ + 4;
+    constexpr int RING = NS * STAGE;
+    constexpr int WPP_MAX = RING / (WTM * CLD * 4);
+    constexpr int WPP = WPP_MAX >= WGM ? WGM : (WPP_MAX >= 1 ? WPP_MAX : 1);
+    static_assert(WTM * CLD * 4 <= RING, "one wave-row of the fp32 tile must fit in the ring");
+    static_assert(WGM % WPP == 0, "passes");
+    constexpr int SEG = BN_ / 8;
+    constexpr int NPASS = WGM / WPP, PER_PASS = WPP * WTM * SEG, NIT = (PER_PASS + 511) / 512, NSIDE = NPASS * NIT;
+    const bool fast = epilogue_fast_ok(epi) && !(dbg & 8);
+    const bf16* sidep = fast ? (epi.resid ? epi.resid : (epi.act == 2 ? epi.aux : nullptr)) : nullptr;
+    const int side_ld = epi.resid ? epi.ldr : epi.ldc;
+    uint4 side[NSIDE];
+#pragma unroll
+    for (int i = 0; i < NSIDE; ++i) side[i] = make_uint4(0, 0, 0, 0);
+    auto prefetch_side = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                int idx = tid + 512 * i;
+                idx = idx < PER_PASS ? idx : PER_PASS - 1;
+                const int row = idx / SEG, seg = idx - row * SEG;
+                int m = m0 + p * WPP * WTM + row;
+                m = m < M ? m : M - 1;
+                side[p * NIT + i] = *reinterpret_cast<const uint4*>(sidep + (size_t)m * side_ld + n0 + seg * 8);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // prologue: two stages in flight, wait for stage 0
     issue(0);
@@ -204,14 +250,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
     if (nk >= 2) {
+        if (sidep) prefetch_side();
         load_frags(slot, 0, false);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vm<0>();
+        if (sidep) wait_vm<NSIDE>(); else wait_vm<0>();      // (in-order retirement: the last stage's DMA precedes the side loads)
         bar();
         compute();
         bar();
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
+    if (nk < 2 && sidep) prefetch_side();
     load_frags(slot, 0, false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bar();
@@ -228,17 +276,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
     }
 
     // epilogue: fp32 tile through the (idle) ring, WPP wave-rows per pass, then the row-wise fused epilogue
-    constexpr int CLD = BN_ + 4;
-    constexpr int RING = NS * STAGE;
-    constexpr int WPP_MAX = RING / (WTM * CLD * 4);
-    constexpr int WPP = WPP_MAX >= WGM ? WGM : (WPP_MAX >= 1 ? WPP_MAX : 1);
-    static_assert(WTM * CLD * 4 <= RING, "one wave-row of the fp32 tile must fit in the ring");
-    static_assert(WGM % WPP == 0, "passes");
     float* cs = reinterpret_cast<float*>(smem);
-    constexpr int SEG = BN_ / 8;
-#pragma unroll 1
-    for (int p = 0; p < WGM / WPP; ++p) {
-        if (wm / WPP == p) {
+    const uint32_t dkey = drop_key(epi.drop);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        if (wm / WPP == p && (KS == 1 || grp == 0)) {
             const int lr0 = (wm % WPP) * WTM;
 #pragma unroll
             for (int i = 0; i < NFM; ++i)
@@ -249,12 +291,39 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
                 }
         }
         __syncthreads();
-        if (probing && p == 0) pt[3] = __builtin_amdgcn_s_memrealtime();
-        for (int idx = tid; idx < WPP * WTM * SEG; idx += 512) {
-            const int row = idx / SEG, seg = idx - row * SEG;
-            epilogue8(epi, m0 + p * WPP * WTM + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), 0);
+        if (KS == 2) {          // second K-half: added in place (each (wm, wn) region has exactly one writer per phase)
+            if (wm / WPP == p && grp == 1) {
+                const int lr0 = (wm % WPP) * WTM;
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFN; ++j) {
+                        const int row = lr0 + i * 16 + (lane & 15), col = wn * WTN + j * 16 + (lane >> 4) * 4;
+                        float4* pc = reinterpret_cast<float4*>(cs + row * CLD + col);
+                        const float4 v = *pc;
+                        *pc = make_float4(v.x + acc[i][j][0], v.y + acc[i][j][1], v.z + acc[i][j][2], v.w + acc[i][j][3]);
+                    }
+            }
+            __syncthreads();
         }
-        if (p + 1 < WGM / WPP) __syncthreads();
+        if (probing && p == 0) pt[3] = __builtin_amdgcn_s_memrealtime();
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = tid + 512 * i;
+                if (idx < PER_PASS) {
+                    const int row = idx / SEG, seg = idx - row * SEG;
+                    epilogue8_fast(epi, m0 + p * WPP * WTM + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), side[p * NIT + i], dkey);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int idx = tid; idx < PER_PASS; idx += 512) {
+                const int row = idx / SEG, seg = idx - row * SEG;
+                epilogue8(epi, m0 + p * WPP * WTM + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), 0);
+            }
+        }
+        if (p + 1 < NPASS) __syncthreads();
     }
     if (probing) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -103,9 +103,11 @@ DGRAD_NT = os.environ.get("MMF_AMD_DGRAD_NT", "1") == "1"
 def _twin_pays(out_width):
     """Input-gradient GEMMs whose OUTPUT is narrow (a multiple of 96 up to 1152 columns: 768 here) run on the 256x96 wide tile
     when both operands are row operands — 2.15 ms instead of 2.42 ms per step for the QKV / FFN-up / out-proj dgrads of VisualBERT
-    VQA2 (same-box A/B, profiles/r02_bench_line.json) — so their weights keep a transposed twin.  Wide outputs (FFN-down's dgrad,
-    3072 columns) are faster with the k-major W on the 128x128 kernel and keep no twin."""
-    return out_width % 96 == 0 and out_width <= 1152
+    VQA2 (same-box A/B, profiles/r02_bench_line.json) — so their weights keep a transposed twin.  Round 3: wide outputs (FFN-down's
+    dgrad, 3072 columns, with the saved-gelu' multiply in its epilogue) take the 256x128 wide tile the same way: 52 us against 59-60
+    us for the k-major W on the 128x128 kernel (tools/gemm_ab.py, profiles/r03_gemm_ab_ks.txt); the twin refresh is one transpose
+    launch per optimizer step for all twins together."""
+    return (out_width % 96 == 0 and out_width <= 1152) or out_width % 128 == 0
 
 
 class ShadowCache:

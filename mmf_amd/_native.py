@@ -116,6 +116,10 @@ def lib():
     _lib = L
     if os.environ.get("MMF_AMD_GEMM_WIDE"):      # A/B switch for measurements: -1 never a wide tile, 1..3 force one (see MMF_TUN_GEMM_WIDE)
         L.mmf_amd_set_tunable(2, int(os.environ["MMF_AMD_GEMM_WIDE"]))
+    if os.environ.get("MMF_AMD_EPI_NT"):         # A/B switch: mask + 1 of the GEMM outputs stored non-temporally (see MMF_TUN_EPI_NT)
+        L.mmf_amd_set_tunable(6, int(os.environ["MMF_AMD_EPI_NT"]))
+    if os.environ.get("MMF_AMD_GEMM_WIDE_KS"):
+        L.mmf_amd_set_tunable(5, int(os.environ["MMF_AMD_GEMM_WIDE_KS"]))
     if os.environ.get("MMF_AMD_LN_OLD"):
         L.mmf_amd_set_tunable(3, int(os.environ["MMF_AMD_LN_OLD"]))
     if os.environ.get("MMF_AMD_ATTN_BWD_TWO_PASS"):

@@ -59,7 +59,37 @@ def build(force=False, verbose=True, tag=""):
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
         print("built", LIB)
+    if not tag:
+        build_ops(force=force, verbose=verbose)
     return LIB
+
+
+OPS_SRC = os.path.join(HERE, "torch_ops.cpp")
+OPS_LIB = os.path.join(os.path.dirname(HERE), "libmmf_amd_ops.so")
+
+
+def build_ops(force=False, verbose=True):
+    """libmmf_amd_ops.so: the native PyTorch operator library (torch_ops.cpp — TORCH_LIBRARY(mmf_amd) + C++ autograd nodes over the C ABI).
+    Host code only (g++ against the installed torch headers; the device code is all in libmmf_amd.so, found through $ORIGIN)."""
+    import torch
+    deps = [OPS_SRC, os.path.join(INCLUDE, "mmf_amd.h"), __file__]
+    if not force and os.path.exists(OPS_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(OPS_LIB) for d in deps):
+        if verbose:
+            print("built", OPS_LIB)
+        return OPS_LIB
+    ti = os.path.dirname(torch.__file__)
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % abi, "-I", os.path.join(ti, "include"), "-I", os.path.join(ti, "include", "torch", "csrc", "api", "include"),
+           "-I", "/opt/rocm/include", "-I", INCLUDE, OPS_SRC, "-o", OPS_LIB, "-L", os.path.dirname(HERE), "-lmmf_amd",
+           "-L", os.path.join(ti, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-Wl,-rpath,$ORIGIN",
+           "-Wl,-rpath," + os.path.join(ti, "lib")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building %s failed:\n%s\n%s" % (OPS_LIB, r.stdout, r.stderr))
+    if verbose:
+        print("built", OPS_LIB)
+    return OPS_LIB
 
 
 if __name__ == "__main__":

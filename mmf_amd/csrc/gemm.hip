@@ -29,6 +29,10 @@
 
 using namespace gemm;
 
+#ifndef MMF_EPI_NT_DEFAULT
+#define MMF_EPI_NT_DEFAULT 7
+#endif
+
 
 namespace {
 
@@ -475,6 +479,9 @@ static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     e.grp_in = d->grp_in; e.grp_pad = d->grp_pad; e.grp_off = d->grp_off;
     e.M = d->M; e.N = d->N;
     e.slab_stride = 0; e.splits = 1; e.rowsum_col = -1; e.rowsum_direct = nullptr;
+    // MMF_TUN_EPI_NT: 0 = the default mask below, else (value - 1) is the mask (1 = no non-temporal stores at all)
+    const int ntt = mmf_amd_get_tunable(MMF_TUN_EPI_NT);
+    e.nt = ntt > 0 ? ntt - 1 : MMF_EPI_NT_DEFAULT;
     return 0;
 }
 

@@ -32,6 +32,7 @@ struct EpiArgs {
     int splits;
     int rowsum_col;     // >= 0: also write per-row sums of A (bias-gradient partials) behind the split-K slabs; -1: off
     float* rowsum_direct;  // no split-K: the row sums go straight here ([M] fp32) instead of behind the slabs
+    int nt;             // non-temporal stores: bit 0 the bf16 output C, bit 1 the saved gelu' (U), bit 2 fp32 outputs (MMF_TUN_EPI_NT)
 };
 
 // Timeline probe (development aid; off unless mmf_gemm_set_probe was called).  One record of 8 u64 per workgroup:
@@ -201,18 +202,17 @@ DEVI f32x8 load_bf8(const bf16* p) {
     for (int i = 0; i < 8; ++i) r[i] = (float)t[i];
     return r;
 }
-DEVI void store_bf8(bf16* p, f32x8 v) {
+// Non-temporal (`nt`): an epilogue output is never re-read by the kernel that writes it, so it can stream past the operand panels an
+// XCD keeps in its L2 instead of evicting them.  Measured (profiles/r03_nt_stores_ab.txt, same box, twice) with every output stored
+// that way: step 8.62 -> 8.41 ms, FETCH_SIZE of the 128 x 128 family 85.4 -> 75.4 MB per launch - but the NEXT kernel then finds its
+// input further away (attention forward 28 -> 39 us behind a non-temporally stored Q|K|V), so which outputs get it is a per-output
+// choice (EpiArgs::nt, MMF_TUN_EPI_NT).
+DEVI void store_bf8(bf16* p, f32x8 v, bool nt) {
     bf16x8 t;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
-    // Non-temporal: an epilogue output is never re-read by the kernel that writes it, so it should stream past the operand panels
-    // an XCD keeps in its L2 instead of evicting them.  Measured (profiles/r03_nt_stores_ab.txt, same box, twice): step 8.62 -> 8.41
-    // ms, FETCH_SIZE of the 128 x 128 family 85.4 -> 75.4 MB per launch.  -DMMF_EPI_PLAIN_STORES restores ordinary stores (A/B).
-#ifdef MMF_EPI_PLAIN_STORES
-    *reinterpret_cast<bf16x8*>(p) = t;
-#else
-    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, t), reinterpret_cast<u32x4*>(p));
-#endif
+    if (nt) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, t), reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<bf16x8*>(p) = t;
 }
 
 // Epilogue of one output row segment: 8 consecutive columns n..n+7 of row m (fp32 accumulators staged through LDS
@@ -256,7 +256,7 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) { float hh, gg; gelu_erf_both(v[r], hh, gg); v[r] = hh; gd[r] = gg; }
         if (e.U) {
-            if (vec) store_bf8(e.U + off, gd);
+            if (vec) store_bf8(e.U + off, gd, (e.nt & 2) != 0);
             else {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) if (ok[r]) e.U[off + r] = (bf16)gd[r];
@@ -306,20 +306,20 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
         float* C = reinterpret_cast<float*>(e.C) + off;
         if (full && ((e.ldc & 3) == 0)) {
             if (e.beta != 0.f) v += e.beta * load_f8(C);
-#ifdef MMF_EPI_PLAIN_STORES
-            *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
-#else
-            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(C));
-            __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(C + 4));
-#endif
+            if (e.nt & 4) {
+                __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(C));
+                __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(C + 4));
+            } else {
+                *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (ok[r]) C[r] = v[r] + (e.beta != 0.f ? e.beta * C[r] : 0.f);
         }
     } else {
         bf16* C = reinterpret_cast<bf16*>(e.C) + off;
-        if (vec) store_bf8(C, v);
+        if (vec) store_bf8(C, v, (e.nt & 1) != 0);
         else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (ok[r]) C[r] = (bf16)v[r];
@@ -352,7 +352,7 @@ DEVI void epilogue8_fast(const EpiArgs& e, int m, int n, f32x8 v, uint4 side, ui
         for (int r = 0; r < 4; ++r) { v[r] *= s0[r]; v[r + 4] *= s1[r]; }
     }
     if (e.resid) v += sv;
-    store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v);
+    store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v, (e.nt & 1) != 0);
 }
 
 }  // namespace gemm

@@ -37,12 +37,15 @@ def active():
 def fp32_inference():
     """Run every mmf_amd operator inside the block on the fp32 kernels (forward only, gradients off)."""
     global _depth
+    from mmf_amd import _ops_native
     _depth += 1
+    _ops_native.push_mode(0)        # the native operators forward to the fp32 kernels' Python bindings while this is on
     try:
         with torch.no_grad():
             yield
     finally:
         _depth -= 1
+        _ops_native.pop_mode(0)
 
 
 def check_no_dropout(p, training):

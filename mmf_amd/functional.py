@@ -29,6 +29,12 @@ import weakref
 import torch
 
 from mmf_amd import _native as nat
+from mmf_amd import _ops_native
+
+# With the native operator library loaded (mmf_amd/_ops_native.py) the dropout keys, the weight-shadow cache and the deferred LayerNorm
+# reductions live in libmmf_amd_ops.so; the classes below then forward to it, so that the C++ autograd nodes and the Python ones
+# (the models that are not ported to C++, the experiment hooks) share ONE state.
+NATIVE = _ops_native.NATIVE
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -59,6 +65,9 @@ class _DropoutKeys:
         return (x * 0x94D049BB133111EB >> 16) & 0xFFFFFFFF
 
     def next(self):
+        if NATIVE:
+            key, seed = torch.ops.mmf_amd._drop_next()
+            return key, (seed[0] if seed else None)
         if self.seed_tensor is not None:
             self.counter += 1
             return self._mix(0x5EED, self.counter), self.seed_tensor
@@ -73,9 +82,13 @@ class _DropoutKeys:
         class _Ctx:
             def __enter__(self_):
                 keys.seed_tensor, keys.counter = seed_tensor, 0
+                if NATIVE:
+                    torch.ops.mmf_amd._drop_graph_mode(seed_tensor)
 
             def __exit__(self_, *exc):
                 keys.seed_tensor = None
+                if NATIVE:
+                    torch.ops.mmf_amd._drop_graph_mode(None)
 
         return _Ctx()
 
@@ -128,6 +141,9 @@ class ShadowCache:
 
     def clear(self):
         """Forget every shadow: the next use re-casts (used before hipGraph capture)."""
+        if NATIVE:
+            torch.ops.mmf_amd._shadow_set_twins(DGRAD_NT)      # (the module-level A/B switch is handed over at these sync points)
+            torch.ops.mmf_amd._shadow_clear()
         self._store.clear()
         self._slot.clear()
         self._t.clear()
@@ -138,6 +154,10 @@ class ShadowCache:
         its dimensions are not multiples of 64, or MMF_AMD_DGRAD_NT=0).  Built on first use, re-built when the shadow's
         signature changed (a re-cast after `load_state_dict` / a torch optimizer), and kept current by
         `refresh_transposed()` when the fused optimizer updates parameters and shadows in place."""
+        if NATIVE:
+            torch.ops.mmf_amd._shadow_set_twins(DGRAD_NT)
+            t = torch.ops.mmf_amd._shadow_transposed(w16)
+            return t[0] if t else None
         if not DGRAD_NT or w16.dim() != 2:
             return None
         key = self._by_ptr.get(w16.data_ptr())
@@ -158,7 +178,13 @@ class ShadowCache:
     def refresh_transposed(self, only=None, skip=None):
         """Re-transpose every live twin from its (already updated) shadow: called by the fused optimizer's step.  `only` / `skip`:
         ids of the head parameters whose twins to refresh / leave alone (the optimizer-in-backward refreshes a layer's twins with
-        that layer's update and the final step skips them)."""
+        that layer's update and the final step skips them).  With the native library: the head parameters themselves."""
+        if NATIVE:
+            torch.ops.mmf_amd._shadow_refresh_transposed(list(only) if only is not None else [], only is not None,
+                                                         list(skip) if skip is not None else [], skip is not None)
+            return
+        only = None if only is None else {id(p) for p in only}
+        skip = None if skip is None else {id(p) for p in skip}
         pairs = [(self._store[k][1], t[1]) for k, t in self._t.items() if k in self._store and self._store[k][0] == t[0]
                  and (only is None or k in only) and (skip is None or k not in skip)]
         if pairs:
@@ -168,6 +194,9 @@ class ShadowCache:
         """The mirror rows of parameter `p` (bf16 weight shadow, or its slice of a packed fp32 Q|K|V bias) if it has an
         up-to-date one, else None.  The fused optimizer writes the new value there in the same pass that updates the
         fp32 master: no re-cast / re-pack next step, and the update stays visible to a replayed hipGraph."""
+        if NATIVE:
+            t = torch.ops.mmf_amd._shadow_slot(p)
+            return t[0] if t else None
         ent = self._slot.get(id(p))
         if ent is None:
             return None
@@ -181,6 +210,8 @@ class ShadowCache:
         return st[1][r0:r0 + p.shape[0]]
 
     def get(self, *params, dtype=BF16):
+        if NATIVE:
+            return torch.ops.mmf_amd._shadow_get(list(params), dtype != BF16)
         head = params[0]
         key = id(head)
         ent = self._store.get(key)
@@ -455,14 +486,20 @@ class _LnDefer:
     @contextlib.contextmanager
     def __call__(self):
         old, self.active = self.active, True
+        if NATIVE:
+            torch.ops.mmf_amd._ln_defer_set(True)
         try:
             yield
         finally:
             self.active = old
+            if NATIVE:
+                torch.ops.mmf_amd._ln_defer_set(old)
             if not old:
                 self.flush()
 
     def flush(self):
+        if NATIVE:
+            torch.ops.mmf_amd._ln_defer_flush()       # the reductions the C++ autograd nodes deferred
         if self.pending:
             items, self.pending = self.pending, []
             nat.layernorm_bwd_reduce_multi(items)
@@ -661,11 +698,14 @@ class _WgradOverlap:
     @contextlib.contextmanager
     def __call__(self, stream):
         old, self.stream = self.stream, stream
+        if stream is not None:
+            _ops_native.push_mode(1)      # the hook lives in the Python autograd node: route the layer operator there
         try:
             yield
         finally:
             self.stream = old
             if stream is not None:
+                _ops_native.pop_mode(1)
                 torch.cuda.current_stream().wait_stream(stream)
 
     def launch(self, problems, tensors):
@@ -697,10 +737,14 @@ class _ParamUpdateHook:
     @contextlib.contextmanager
     def __call__(self, fn):
         old, self.fn = self.fn, fn
+        if fn is not None:
+            _ops_native.push_mode(1)      # the hook lives in the Python autograd node: route the layer operator there
         try:
             yield
         finally:
             self.fn = old
+            if fn is not None:
+                _ops_native.pop_mode(1)
 
 
 param_update = _ParamUpdateHook()

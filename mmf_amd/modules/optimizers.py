@@ -122,7 +122,7 @@ class AdamW(torch.optim.Optimizer):
                 b1, b2 = grp["betas"]
                 nat.adamw_multi(items, b1, b2, grp["eps"], step, grp["correct_bias"], 1 if self.torch_mode else 0, self.grad_scale,
                                 None, 0.0, self._dev_state if self.capturable else None)
-            Fn.shadows.refresh_transposed(only={id(p) for p in params})
+            Fn.shadows.refresh_transposed(only=list(params))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -131,6 +131,7 @@ class AdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         early, self._early = self._early, None
+        early_params = None if early is None else [p for g in self.param_groups for p in g["params"] if id(p) in early]
         dev_state = None
         if self.capturable:
             if self._dev_state is None:
@@ -163,7 +164,7 @@ class AdamW(torch.optim.Optimizer):
                 nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
                                 self.grad_scale, norm_sq, max_norm, dev_state)
         self._clip = None
-        Fn.shadows.refresh_transposed(skip=early)     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
+        Fn.shadows.refresh_transposed(skip=early_params)     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
         if early is not None:
             torch.cuda.current_stream().wait_stream(self._early_stream)      # join the in-backward updates
             self._early_stream = None
@@ -182,9 +183,14 @@ class AdamW(torch.optim.Optimizer):
     def state_dict(self):
         dstep = self._device_step()
         if dstep is not None:
+            # Under hipGraph replay this Python never runs, so the per-parameter counts are stale by the number of replays; the device
+            # counter is the truth for the most advanced parameter, and a parameter that started late keeps its lag behind it
+            # (transformers.AdamW keeps state["step"] per parameter: bias correction of a late starter begins at 1).
+            counts = [int(st["step"]) for st in self.state.values() if "step" in st]
+            top = max(counts) if counts else 0
             for st in self.state.values():
                 if "step" in st:
-                    st["step"] = dstep
+                    st["step"] = max(0, dstep - (top - int(st["step"])))
         sd = super().state_dict()
         if self.capturable and self._dev_state is not None:
             sd["mmf_amd_dev_state"] = self._dev_state.detach().cpu().clone()
@@ -197,9 +203,15 @@ class AdamW(torch.optim.Optimizer):
         steps = [int(st["step"]) for st in self.state.values() if "step" in st]
         if self.capturable:
             device = self.param_groups[0]["params"][0].device
+            new = None
             if dev is not None:
-                self._dev_state = dev.to(device=device, dtype=torch.float32).clone()
+                new = dev.to(device=device, dtype=torch.float32)
             elif steps:
                 # a checkpoint written by the reference optimizer: the device counter continues from its step count; the
                 # schedule factor is re-derived by the next optimizer_state_advance
-                self._dev_state = torch.tensor([float(max(steps)), 1.0], dtype=torch.float32, device=device)
+                new = torch.tensor([float(max(steps)), 1.0], dtype=torch.float32, device=device)
+            if new is not None:
+                if self._dev_state is None:
+                    self._dev_state = new.clone()
+                else:
+                    self._dev_state.copy_(new)      # IN PLACE: a hipGraph captured earlier replays against this very buffer

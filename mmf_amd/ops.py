@@ -26,6 +26,7 @@ Q|K|V views) are looked up inside (mmf_amd.functional.ShadowCache), dropout keys
     torch.ops.mmf_amd.pair_halves         nlvr2 pooled-output pairing                   visual_bert.py:369-374
     torch.ops.mmf_amd.masked_lm_head      tied decoder + masked-LM CrossEntropyLoss      visual_bert.py:267-277
     torch.ops.mmf_amd.masked_region_head  image-prediction decoder + masked KLDivLoss    vilbert.py:846-858,1150-1157
+    torch.ops.mmf_amd.logit_bce           LogitBinaryCrossEntropy                       mmf/modules/losses.py:225-251
 
 Inside `with mmf_amd.fp32_inference():` every operator above routes to the fp32-accurate forward kernels instead
 (mmf_amd/fp32_path.py: fp32 activations, fp32-input MFMA; north_star's 1e-3 bound) — same schemas, same modules.
@@ -34,10 +35,16 @@ from typing import Optional
 
 import torch
 
+from mmf_amd import _ops_native
 from mmf_amd import fp32_path as F32P
 from mmf_amd import functional as Fn
 
-LIB = torch.library.Library("mmf_amd", "DEF")
+# Where the operators live: with the native library loaded (any GPU box) the schemas and the kernels of the operators in
+# _ops_native.NATIVE_OPS come from libmmf_amd_ops.so (mmf_amd/csrc/torch_ops.cpp, C++ autograd nodes), and the functions below are bound
+# as their `_py_` twins — entered only inside `mmf_amd.fp32_inference()` or with an experiment hook of mmf_amd/utils/graph.py active —
+# or, for the pretraining heads, as the operator's kernel.  Without a GPU (dry runs against kernel stubs) everything is declared here.
+NATIVE = _ops_native.NATIVE
+LIB = torch.library.Library("mmf_amd", "IMPL" if NATIVE else "DEF")
 _SCHEMAS = {}
 
 
@@ -45,8 +52,13 @@ def _op(schema):
     name = schema.split("(")[0]
 
     def deco(fn):
-        LIB.define(schema)
-        LIB.impl(name, fn, "CompositeImplicitAutograd")
+        if not NATIVE:
+            LIB.define(schema)
+            LIB.impl(name, fn, "CompositeImplicitAutograd")
+        elif name in _ops_native.PY_TWINS:
+            LIB.impl("_py_" + name, fn, "CompositeImplicitAutograd")
+        elif name not in _ops_native.NATIVE_OPS:
+            LIB.impl(name, fn, "CompositeImplicitAutograd")        # (schema defined by the native library, kernel bound here)
         _SCHEMAS[name] = schema
         return fn
     return deco
@@ -170,6 +182,11 @@ def masked_region_head(x, weight, bias, target, row_label):
     if F32P.active():
         raise NotImplementedError("fp32 path: ViLBERT's masked-region head is not built")
     return Fn.MaskedRegionHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), target, row_label)
+
+
+@_op("logit_bce(Tensor scores, Tensor targets) -> Tensor")
+def logit_bce(scores, targets):
+    return Fn.LogitBCEFn.apply(scores, targets)
 
 
 def schemas():

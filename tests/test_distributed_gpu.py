@@ -57,7 +57,7 @@ def _worker(rank, world, port, q):
     z, case, cfg, sd, sample = load_case("small64")
     model = build_visual_bert(cfg, sd)
     model.eval()
-    reducer = parallelize_model(model, bucket_bytes=1 << 18)       # several buckets even for the small model
+    reducer = parallelize_model(model, bucket_bytes=1 << 18, comm_dtype=torch.bfloat16)       # several buckets even for the small model; bf16 wire (opt-in)
     full = _batch4(sample)
     mine = SampleList(sample_to(_half(full, rank), "cuda"))
     frozen = []

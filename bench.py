@@ -111,6 +111,11 @@ class KernelProbe:
 
     def __enter__(self):
         from mmf_amd import _native as nat
+        from mmf_amd import _ops_native
+        # The instrumented step must enter the kernels through these Python wrappers: route the native operators (C++ autograd nodes,
+        # which call the C ABI directly) to their Python twins for its duration — same kernels, same launch order.
+        self._ops_native = _ops_native
+        _ops_native.push_mode(1)
         self.nat = nat
         self.saved = {n: getattr(nat, n) for n in ("gemm", "gemm_grouped", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd")}
 
@@ -142,6 +147,7 @@ class KernelProbe:
     def __exit__(self, *exc):
         for n, f in self.saved.items():
             setattr(self.nat, n, f)
+        self._ops_native.pop_mode(1)
 
     def summary(self):
         torch.cuda.synchronize()

@@ -73,3 +73,71 @@ def test_ops_refuse_host_tensors_and_wrong_dtypes():
     y = torch.ops.mmf_amd.layer_norm(xc, torch.ones(256, device="cuda"), torch.zeros(256, device="cuda"), 1e-12)
     ref = torch.nn.functional.layer_norm(xc.bfloat16().float(), (256,))
     assert float((y.float() - ref).abs().max()) < 3e-2
+
+
+_STANDALONE = r"""
+import sys, torch
+torch.ops.load_library(sys.argv[1])            # libmmf_amd_ops.so (finds libmmf_amd.so beside it); the Python package is NOT imported
+assert "mmf_amd" not in sys.modules
+m = torch.jit.load(sys.argv[2], map_location="cuda")
+blob = torch.load(sys.argv[3])
+batch = {k: v.cuda() for k, v in blob["batch"].items()}
+with torch.no_grad():
+    out = m(batch)["scores"]
+assert torch.equal(out.cpu(), blob["scores"]), float((out.cpu().float() - blob["scores"].float()).abs().max())
+# training through the loaded module: C++ autograd nodes, gradients for the parameters the scripted module carries
+m.train()
+torch.manual_seed(5)
+s = m(batch)["scores"]
+s.float().square().sum().backward()
+n = sum(1 for p in m.parameters() if p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0)
+assert n > 30, n
+try:
+    torch.ops.mmf_amd.layer_norm(torch.randn(4, 256), torch.ones(256), torch.zeros(256), 1e-12)
+    raise SystemExit("a host tensor was accepted")
+except RuntimeError as e:
+    assert "HBM" in str(e) or "CPU" in str(e), e
+print("standalone ok", n)
+"""
+
+
+def test_saved_scripted_model_runs_after_load_library_alone(tmp_path):
+    """SURVEY section 8(b), last row: the operator ABI is a shared library loaded with torch.ops.load_library.  A scripted VisualBERT saved here
+    runs in a FRESH interpreter that never imports the Python package — forward bit-identical, backward through the C++ autograd nodes."""
+    import subprocess
+    import sys
+
+    from mmf_amd import _ops_native
+    if not _ops_native.NATIVE:
+        pytest.skip("MMF_AMD_PY_OPS=1: the operators are declared from Python in this process")
+    cfg = dict(O.DEFAULT_CONFIG)
+    cfg["num_hidden_layers"] = 2
+    cfg["num_labels"] = 16
+    model = build_visual_bert(cfg, O.init_state_dict(cfg, seed=4)).eval()
+    g = torch.Generator().manual_seed(1)
+    sample = {"input_ids": torch.randint(0, 30255, (2, 128), generator=g), "input_mask": torch.ones(2, 128, dtype=torch.long),
+              "segment_ids": torch.zeros(2, 128, dtype=torch.long), "image_feature_0": torch.rand(2, 100, 2048, generator=g)}
+    batch = sample_to(sample, "cuda")
+    with torch.no_grad():
+        eager = model(SampleList(dict(batch)))["scores"]
+    scripted = torch.jit.script(model)
+    mp, bp, sp = str(tmp_path / "vb.pt"), str(tmp_path / "io.pt"), str(tmp_path / "standalone.py")
+    torch.jit.save(scripted, mp)
+    torch.save({"batch": {k: v.cpu() for k, v in batch.items()}, "scores": eager.cpu()}, bp)
+    open(sp, "w").write(_STANDALONE)
+    r = subprocess.run([sys.executable, sp, _ops_native.OPS_LIB_PATH, mp, bp], capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+    assert r.returncode == 0 and "standalone ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_native_library_argument_errors_are_torch_checks():
+    from mmf_amd import _ops_native
+    if not _ops_native.NATIVE:
+        pytest.skip("MMF_AMD_PY_OPS=1")
+    x = torch.randn(2, 8, 768, device="cuda")
+    w = torch.randn(768, 768, device="cuda")
+    with pytest.raises(RuntimeError, match="must be float|Float"):          # fp16 bias
+        torch.ops.mmf_amd.linear(x, w, torch.zeros(768, device="cuda", dtype=torch.float16), False)
+    with pytest.raises(RuntimeError, match="weight must be"):
+        torch.ops.mmf_amd.linear(x, torch.randn(768, 512, device="cuda"), None, False)
+    with pytest.raises(RuntimeError, match="B, S, H"):
+        torch.ops.mmf_amd.gather_rows(torch.randn(4, 768, device="cuda"), torch.zeros(4, dtype=torch.long, device="cuda"), 0.0, False)

@@ -158,6 +158,77 @@ class KernelProbe:
         return by
 
 
+# ---- modelled data-parallel scaling ("until then report 1-GPU measured + modelled comm overlap") ----------------------
+XGMI_LINK_GBPS = 153.0      # per link and direction (7 links per GPU, fully connected 8-GPU node)
+XGMI_EFF = 0.70             # assumed protocol efficiency of a large RCCL all-reduce on those links (to be replaced by the first SCALE run)
+COLL_LATENCY_US = 25.0      # assumed fixed cost per all-reduce call (launch + rendezvous)
+
+
+def allreduce_ms(nbytes, world, links=None):
+    """Bandwidth-optimal all-reduce (reduce-scatter + all-gather) of `nbytes` per rank: every rank moves 2 (N-1)/N of the buffer; on the
+    fully connected xGMI mesh it can use one link per peer (`links` = N - 1 <= 7), a single ring is bound by ONE link."""
+    links = (world - 1) if links is None else links
+    bw = links * XGMI_LINK_GBPS * XGMI_EFF * 1e9
+    return COLL_LATENCY_US * 1e-3 + 2.0 * (world - 1) / world * nbytes / bw * 1e3
+
+
+def scale_model(chain, step_ms_1gpu, batch, model):
+    """Replays the N > 1 launch structure at N = 1 stage by stage (HIP events), then walks the step's timeline with modelled collectives:
+    main stream F | B_0 | B_1 | O_0 | B_2 | O_1 ... ; communicator stream AR_j starts when B_j and AR_(j-1) are done; O_j waits for AR_j."""
+    def t_of(g, n=5):
+        if g is None:
+            return 0.0
+        g.replay(); torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record(); g.replay(); b.record()
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+    f_ms = t_of(chain.g_fwd)
+    b_ms = [t_of(g) for g in chain.g_bwd]
+    o_ms = [t_of(g) for g in chain.g_opt]
+    stages = []
+    emb = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Embedding)}      # (the N > 1 rule: embedding tables travel as fp32)
+    for b in chain.buckets:
+        ps = list(b["p16"]) + list(b["p32"])
+        n16 = sum((p.numel() + 63) // 64 * 64 for p in ps if id(p) not in emb); n32 = sum((p.numel() + 63) // 64 * 64 for p in ps if id(p) in emb)
+        stages.append({"bf16_wire_MB": round(n16 * 2 / 1e6, 1), "fp32_wire_MB": round(n32 * 4 / 1e6, 1)})
+    out = {"measured_at_n1_ms": {"forward": round(f_ms, 3), "backward_stages": [round(x, 3) for x in b_ms], "adamw_stages": [round(x, 3) for x in o_ms]},
+           "wire_per_stage": stages,
+           "assumptions": {"xgmi_link_GBps": XGMI_LINK_GBPS, "links_per_gpu": 7, "efficiency": XGMI_EFF, "latency_us_per_collective": COLL_LATENCY_US,
+                           "note": "bf16 wire for everything but the embedding tables (fp32); all-reduce = 2 (N-1)/N x bytes over (N-1) links, "
+                                   "or over ONE link for a single ring; not measured (1-GPU boxes)"},
+           "predicted": {}}
+    for world in (2, 4, 8):
+        pred = {}
+        for name, links in (("all_links", None), ("single_ring", 1)):
+            t_main = f_ms
+            ar_done, exposed = [], 0.0
+            comm_free = 0.0
+            for j, bj in enumerate(b_ms):
+                t_main += bj
+                ar = 0.0
+                for key, bpe in (("bf16_wire_MB", 1), ("fp32_wire_MB", 1)):
+                    mb = stages[j][key]
+                    if mb > 0:
+                        ar += allreduce_ms(mb * 1e6, world, links)
+                start = max(t_main, comm_free)
+                comm_free = start + ar
+                ar_done.append(comm_free)
+                if j >= 1:
+                    wait = max(0.0, ar_done[j - 1] - t_main)
+                    exposed += wait
+                    t_main += wait + o_ms[j - 1]
+            wait = max(0.0, ar_done[-1] - t_main)
+            exposed += wait
+            t_main += wait + o_ms[-1]
+            pred[name] = {"ms_per_step": round(t_main, 3), "exposed_comm_ms": round(exposed, 3),
+                          "samples_per_s": round(batch * world / t_main * 1e3, 1),
+                          "efficiency_vs_n1": round((batch * world / t_main * 1e3) / (batch * world / step_ms_1gpu * 1e3), 3)}
+        out["predicted"]["n%d" % world] = pred
+    return out
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     try:
@@ -271,13 +342,18 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step HIP events on the launch stream
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        evs[0].record()
+        for i in range(args.steps):
             last = step_fn()
+            evs[i + 1].record()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         dt_ = time.perf_counter() - t0
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        timed.event_median_ms = per[len(per) // 2]
         if world > 1:
             t = torch.tensor([dt_], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -285,12 +361,14 @@ def main():
         return dt_, float(last.item())
 
     launch = "eager"
+    event_median = None
     if use_graph:
         # one hipGraph for forward + loss + backward + AdamW (mmf_amd/utils/graph.py): removes the per-kernel launch cost
         from mmf_amd.utils.graph import GraphedTrainStep
         graphed = GraphedTrainStep(model, batch, warmup=2, optimizer=opt)
         dt, loss_val = timed(lambda: graphed())
         launch = "hipGraph"
+        event_median = timed.event_median_ms
     else:
         chain = None
         if use_chain:
@@ -304,9 +382,10 @@ def main():
                 opt = make_optimizer(capturable=False)
         if chain is not None:
             dt, loss_val = timed(lambda: chain())
-            launch = "hipGraph chain (forward | 4 backward stages | AdamW), all-reduce between stages"
+            launch = "hipGraph chain (forward | 4 backward stages, each followed by the previous stage's AdamW), all-reduce between stages"
         else:
             dt, loss_val = timed(lambda: eager_step(opt))
+        event_median = timed.event_median_ms
     h2d = None
     if use_graph:
         # PCIe-inclusive rate (never `value`): every step consumes a NEW host batch, staged in pinned memory and copied on a
@@ -329,6 +408,7 @@ def main():
 
     # host-launch headroom of the eager step (what N > 1 runs): time to ENQUEUE a step from Python against the time the GPU needs
     eager_info = None
+    scale_info = None
     if world == 1:
         eopt = make_optimizer(capturable=False) if not args.no_optimizer else None
         for _ in range(2):
@@ -349,8 +429,12 @@ def main():
             copt = make_optimizer(capturable=True)
             chain = chained_step(copt)
             dtc, _ = timed(lambda: chain())
-            eager_info["chained_graphs"] = {"ms_per_step": round(dtc / args.steps * 1e3, 3), "graphs_per_step": 2 + len(chain.g_bwd),
-                                            "note": "the N > 1 launch path at N = 1 (no all-reduce): forward | backward stages | AdamW"}
+            eager_info["chained_graphs"] = {"ms_per_step": round(dtc / args.steps * 1e3, 3), "graphs_per_step": 1 + 2 * len(chain.g_bwd),
+                                            "note": "the N > 1 launch path at N = 1 (no all-reduce): forward | backward stages interleaved with per-stage AdamW"}
+            try:
+                scale_info = scale_model(chain, dt / args.steps * 1e3, args.batch, model)
+            except Exception as e:       # a model, never the headline: do not lose the line over it
+                scale_info = {"error": "%s: %s" % (type(e).__name__, e)}
             del chain, copt
 
     # one instrumented step for the roofline of the dominant kernel
@@ -392,7 +476,8 @@ def main():
         line = {
             "metric": baseline_metric(),
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 3), "ms_per_step_event_median": None if event_median is None else round(event_median, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "VisualBERT-base single-stream (100 regions + 128 tok) VQA2 bf16, fwd+logit_bce+bwd%s%s"
                                    % ("+AdamW" if opt is not None else "", "" if not args.eval_mode else " (eval mode)"),
@@ -407,6 +492,8 @@ def main():
             line["h2d_inclusive"] = h2d
         if eager_info is not None:
             line["eager"] = eager_info
+        if scale_info is not None:
+            line["scale_model"] = scale_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(line), flush=True)

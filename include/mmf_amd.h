@@ -401,6 +401,8 @@ typedef struct mmf_adamw_multi_desc {
     const float* dev_state;   /* optional device words {step, lr multiplier}: the update reads the step count (bias
                                  correction) and the schedule factor from HBM, so the launch can be replayed from a
                                  hipGraph; `step` above is then ignored.  Advanced by mmf_optim_state_advance. */
+    uint64_t g_bf16_mask;     /* bit i set: g[i] is a bf16 buffer (the data-parallel step's bf16 wire buffer after the all-reduce,
+                                 mmf/trainers/core/device.py:104-110 there an fp32 DDP bucket): read directly, no fp32 unpack pass */
 } mmf_adamw_multi_desc;
 int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream);
 /* state[0] += 1 (optimizer step count t); state[1] = LR multiplier for step t: schedule 0 -> 1, schedule 1 ->

@@ -64,6 +64,7 @@ class AdamWMultiDesc(C.Structure):
         ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("step", C.c_int), ("correct_bias", C.c_int), ("mode", C.c_int),
         ("grad_scale", C.c_float), ("norm_sq", C.c_void_p), ("max_norm", C.c_float), ("dev_state", C.c_void_p),
+        ("g_bf16_mask", C.c_uint64),
     ]
 
 
@@ -696,13 +697,21 @@ def adamw_step(p, g, m, v, p16, n, seg_end, seg_wd, nseg, lr, beta1, beta2, eps,
 
 
 def adamw_multi(items, beta1, beta2, eps, step, correct_bias, mode, grad_scale=1.0, norm_sq=None, max_norm=0.0, dev_state=None):
-    """items: list of (p, g, m, v, mirror or None, lr, wd); fp32 contiguous tensors, any number (launched MT_MAX at a time).
-    `mirror` is the bf16 weight shadow or the fp32 packed-bias slice that must follow the parameter."""
+    """items: list of (p, g, m, v, mirror or None, lr, wd); fp32 contiguous tensors, any number (launched MT_MAX at a time); `g` may
+    also be bf16 (a wire buffer of the data-parallel step, read directly).  `mirror` is the bf16 weight shadow or the fp32
+    packed-bias slice that must follow the parameter."""
     for i0 in range(0, len(items), MT_MAX):
         chunk = items[i0:i0 + MT_MAX]
         d = AdamWMultiDesc()
         d.n = len(chunk)
+        mask = 0
         for i, (p, g, m, v, p16, lr, wd) in enumerate(chunk):
+            if g.dtype == torch.bfloat16:
+                mask |= 1 << i
+            elif g.dtype != torch.float32:
+                raise NativeLibraryError("adamw_multi: gradients must be fp32 or bf16, got %s" % g.dtype)
+            if g.numel() != p.numel() or not g.is_contiguous():
+                raise NativeLibraryError("adamw_multi: gradient must be contiguous with the parameter's element count")
             d.p[i], d.g[i], d.m[i], d.v[i] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
             d.p16[i] = p16.data_ptr() if (p16 is not None and p16.dtype == torch.bfloat16) else None
             d.p32[i] = p16.data_ptr() if (p16 is not None and p16.dtype == torch.float32) else None
@@ -713,6 +722,7 @@ def adamw_multi(items, beta1, beta2, eps, step, correct_bias, mode, grad_scale=1
         d.norm_sq = norm_sq.data_ptr() if norm_sq is not None else None
         d.max_norm = max_norm
         d.dev_state = dev_state.data_ptr() if dev_state is not None else None
+        d.g_bf16_mask = mask
         _check(lib().mmf_adamw_multi(C.byref(d), _stream()), "mmf_adamw_multi")
 
 

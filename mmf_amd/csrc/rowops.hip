@@ -1016,6 +1016,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc
     if (base >= n) return;
     float* __restrict__ p = reinterpret_cast<float*>(d.p[t]);
     const float* __restrict__ g = reinterpret_cast<const float*>(d.g[t]);
+    const bf16* __restrict__ g16 = reinterpret_cast<const bf16*>(d.g[t]);
+    const bool gb = (d.g_bf16_mask >> t) & 1ull;      // the gradient is a bf16 wire buffer
     float* __restrict__ m = reinterpret_cast<float*>(d.m[t]);
     float* __restrict__ v = reinterpret_cast<float*>(d.v[t]);
     bf16* __restrict__ p16 = reinterpret_cast<bf16*>(d.p16[t]);
@@ -1043,11 +1045,14 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc
         vec[u] = (cnt[u] == 4) && ((i & 3) == 0);
         if (vec[u]) {
             pv[u] = load4(p + i);
-            gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+            if (gb) {
+                const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(g16 + i);
+                gv[u] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
+            } else gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
             mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + i));
             vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + i));
         } else {
-            for (int j = 0; j < 4; ++j) { const bool ok = j < cnt[u]; pv[u][j] = ok ? p[i + j] : 0.f; gv[u][j] = ok ? g[i + j] : 0.f; mv[u][j] = ok ? m[i + j] : 0.f; vv[u][j] = ok ? v[i + j] : 0.f; }
+            for (int j = 0; j < 4; ++j) { const bool ok = j < cnt[u]; pv[u][j] = ok ? p[i + j] : 0.f; gv[u][j] = ok ? (gb ? (float)g16[i + j] : g[i + j]) : 0.f; mv[u][j] = ok ? m[i + j] : 0.f; vv[u][j] = ok ? v[i + j] : 0.f; }
         }
     }
 #pragma unroll

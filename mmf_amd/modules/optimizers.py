@@ -38,6 +38,9 @@ class AdamW(torch.optim.Optimizer):
         self._schedule = (0, 0.0, 0.0) if schedule is None else (1, float(schedule[1]), float(schedule[2]))
         self._dev_state = None
         self.grad_scale = 1.0       # every gradient is multiplied by this inside the update (a data-parallel SUM becomes the mean)
+        self.external_grads = None  # id(parameter) -> tensor to read its gradient from instead of `.grad` (fp32 or bf16, contiguous, same
+                                    # element count): the data-parallel step points this at its wire buffers, so the summed bf16
+                                    # gradients are consumed where the all-reduce left them (no unpack / convert pass)
         self._early = None          # ids of the parameters already updated inside this step's backward (update_in_backward)
         self._early_stream = None
         self._group_of = None
@@ -124,8 +127,18 @@ class AdamW(torch.optim.Optimizer):
                                 None, 0.0, self._dev_state if self.capturable else None)
             Fn.shadows.refresh_transposed(only=list(params))
 
+    def _grad_of(self, p):
+        if self.external_grads is not None:
+            g = self.external_grads.get(id(p))
+            if g is not None:
+                return g
+        return p.grad
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, only=None, advance=True):
+        """`only` (ids of parameters) restricts the update to a subset — the data-parallel step updates one backward stage at a time,
+        each as soon as its all-reduce has landed; `advance=False` on every such call but the first of a step keeps the device-side
+        step count / schedule factor from advancing more than once."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -137,15 +150,18 @@ class AdamW(torch.optim.Optimizer):
             if self._dev_state is None:
                 dev = self.param_groups[0]["params"][0].device
                 self._dev_state = torch.zeros(2, dtype=torch.float32, device=dev)
-            if early is None:          # (begin_step already advanced the counters of a step opened for in-backward updates)
+            if early is None and advance:      # (begin_step already advanced the counters of a step opened for in-backward updates)
                 nat.optim_state_advance(self._dev_state, *self._schedule)
             dev_state = self._dev_state
         for group in self.param_groups:
             by_step = {}
             for p in group["params"]:
-                if p.grad is None or (early is not None and id(p) in early):
+                if only is not None and id(p) not in only:
                     continue
-                if p.grad.is_sparse:
+                grad = self._grad_of(p)
+                if grad is None or (early is not None and id(p) in early):
+                    continue
+                if grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
                 st = self.state[p]
                 if len(st) == 0:
@@ -155,7 +171,7 @@ class AdamW(torch.optim.Optimizer):
                 # per-parameter step count, as transformers.AdamW keeps it (state["step"]): the bias correction of a parameter
                 # that first receives a gradient late starts at 1, and checkpoints exchange with the reference optimizer
                 st["step"] = int(st.get("step", 0)) + 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                g = grad if grad.is_contiguous() else grad.contiguous()
                 by_step.setdefault(st["step"], []).append(
                     (p, g, st["exp_avg"], st["exp_avg_sq"], Fn.shadows.slot(p), group["lr"], group["weight_decay"]))
             b1, b2 = group["betas"]
@@ -164,7 +180,10 @@ class AdamW(torch.optim.Optimizer):
                 nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
                                 self.grad_scale, norm_sq, max_norm, dev_state)
         self._clip = None
-        Fn.shadows.refresh_transposed(skip=early_params)     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
+        if only is not None:
+            Fn.shadows.refresh_transposed(only=[p for g_ in self.param_groups for p in g_["params"] if id(p) in only])
+        else:
+            Fn.shadows.refresh_transposed(skip=early_params)     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
         if early is not None:
             torch.cuda.current_stream().wait_stream(self._early_stream)      # join the in-backward updates
             self._early_stream = None

@@ -139,8 +139,9 @@ class GraphedDataParallelStep:
     """The training step of ONE data-parallel rank as a short chain of hipGraphs with the gradient all-reduces between them
     (collective C1 of SURVEY.md section 2.3; the reference wraps the model in DistributedDataParallel, mmf/trainers/core/device.py:104-110):
 
-        F (forward + loss) | B_0 | B_1 | ... | B_n (backward, cut at the outputs of `cuts`) | O (unpack + AdamW)
-                             `-> all-reduce of stage 0's gradients on the communicator's stream, while B_1 replays, ...
+        F (forward + loss) | B_0 | B_1 | O_0 | B_2 | O_1 | ... | B_n | O_(n-1) | O_n      (B_j: backward stage, cut at the outputs of `cuts`;
+                             `-> all-reduce of stage 0's gradients on the             O_j: AdamW of the parameters of stage j)
+                                 communicator's stream, while B_1 replays, ...
 
     so the host enqueues ~2n + 4 operations per step instead of ~450 kernels (the eager N > 1 step is host-bound: bench.py's
     "eager" leg) and the collectives themselves stay outside the graphs (RCCL launched eagerly between replays — nothing
@@ -153,9 +154,15 @@ class GraphedDataParallelStep:
 
     Gradients of a stage are packed by the stage's graph into one flat buffer per wire type — `comm_dtype` (bf16: half the
     xGMI bytes) and fp32 for `fp32_params` (default: embedding tables, whose rows collect sparse, differently scaled
-    contributions) — summed over the ranks, and `O` converts to fp32 where needed; the 1 / world_size of the mean is folded
-    into the optimizer's update (`optimizer.grad_scale`).  The optimizer must be `capturable=True`; its state is allocated
-    before the capture (`ensure_state`) and the warm-up runs no optimizer step: the first replay is step 1."""
+    contributions) — and summed over the ranks IN PLACE; the optimizer reads the summed wire buffers directly
+    (`AdamW.external_grads`: the fused update converts bf16 gradients while it loads them — round 2 unpacked them into a second
+    fp32 buffer first, 0.7 GB of extra traffic per step), and the 1 / world_size of the mean is folded into the update
+    (`optimizer.grad_scale`).  The update itself is cut per stage: `O_j` replays as soon as stage j's all-reduce has landed, after
+    the NEXT backward stage has been enqueued, so the updates of the early stages run while the later collectives are still on the
+    wire and the only exposed tail is the last stage's collective (the fp32 word-embedding bucket) plus its own update.
+    `gradients()` returns the reduced buffers per parameter (`.grad` stays unset: a bf16 buffer cannot be an fp32 parameter's grad).
+    The optimizer must be `capturable=True`; its state is allocated before the capture (`ensure_state`) and the warm-up runs no
+    optimizer step: the first replay is step 1."""
 
     def __init__(self, model, batch, cuts, optimizer, process_group=None, comm_dtype=None, fp32_params=None, warmup=2, loss_of=None):
         if not getattr(optimizer, "capturable", False):
@@ -200,7 +207,7 @@ class GraphedDataParallelStep:
             pool = torch.cuda.graph_pool_handle()
             self.g_fwd = torch.cuda.CUDAGraph()
             self.g_bwd = [torch.cuda.CUDAGraph() for _ in self.stage_params]
-            self.g_opt = torch.cuda.CUDAGraph()
+            self.g_opt = [torch.cuda.CUDAGraph() for _ in self.stage_params]
             with Fn.dropout_keys.graph_mode(self.seed):
                 with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):
                     self.out, self.loss = self._forward()
@@ -211,9 +218,14 @@ class GraphedDataParallelStep:
                         grads, carry = self._stage_grads(j, carry, self.stage_params[j])
                         self._pack(j, grads)
                     self._keep.append((grads, carry))
-                with torch.cuda.graph(self.g_opt, pool=pool, capture_error_mode="thread_local"):
-                    self._unpack()
-                    optimizer.step()
+                optimizer.external_grads = self._wire_views()
+                for j, g in enumerate(self.g_opt):       # one update graph per stage; only the first advances the step count / schedule
+                    ids = {id(p) for p in self.buckets[j]["p16"]} | {id(p) for p in self.buckets[j]["p32"]}
+                    if not ids and j > 0:
+                        self.g_opt[j] = None                 # (a stage without parameters of its own: nothing to update)
+                        continue
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                        optimizer.step(only=ids, advance=(j == 0))
         finally:
             for h in handles:
                 h.remove()
@@ -271,7 +283,7 @@ class GraphedDataParallelStep:
 
     # ---- flat wire buffers ------------------------------------------------------------------------------------------------
     def _layout(self, fp32_ids, dev):
-        self.buckets = []        # per stage: dict(p16, o16, wire16, g32, p32, o32, wire32)
+        self.buckets = []        # per stage: dict(p16, o16, wire16, p32, o32, wire32)
         last_stage = {k: v[-1] for k, v in self._shared.items()}
         self._partial = {k: None for k in self._shared}      # running sums of shared parameters
         for j, plist in enumerate(self.stage_params):
@@ -286,7 +298,6 @@ class GraphedDataParallelStep:
                 else:
                     b["o16"].append(n16); n16 += (p.numel() + 63) // 64 * 64
             b["wire16"] = torch.zeros(n16, dtype=self.comm_dtype, device=dev) if n16 else None
-            b["g32"] = torch.zeros(n16, dtype=torch.float32, device=dev) if n16 else None
             b["wire32"] = torch.zeros(n32, dtype=torch.float32, device=dev) if n32 else None
             self.buckets.append(b)
 
@@ -303,29 +314,42 @@ class GraphedDataParallelStep:
             if plist:
                 torch._foreach_copy_([flat[o:o + p.numel()].view_as(p) for p, o in zip(plist, offs)], [have[id(p)] for p in plist])
 
-    def _unpack(self):
+    def _wire_views(self):
+        """id(parameter) -> its slice of the stage's wire buffer (after the all-reduce: the SUM over the ranks), in the wire's dtype."""
+        views = {}
         for b in self.buckets:
-            if b["wire16"] is not None:
-                b["g32"].copy_(b["wire16"])
-                for p, o in zip(b["p16"], b["o16"]):
-                    p.grad = b["g32"][o:o + p.numel()].view_as(p)
-            for p, o in zip(b["p32"], b["o32"]):
-                p.grad = b["wire32"][o:o + p.numel()].view_as(p)
+            for plist, offs, flat in ((b["p16"], b["o16"], b["wire16"]), (b["p32"], b["o32"], b["wire32"])):
+                for p, o in zip(plist, offs):
+                    views[id(p)] = flat[o:o + p.numel()].view_as(p)
+        return views
+
+    def gradients(self):
+        """After a step: parameter -> reduced gradient buffer (the sum over the ranks; multiply by `optimizer.grad_scale` for the mean)."""
+        views = self._wire_views()
+        return {p: views[id(p)] for p in self.params if id(p) in views}
 
     # ---- one training step ------------------------------------------------------------------------------------------------
     def __call__(self, batch=None):
         if batch is not None:
             _copy_batch(self.static_batch, batch)
         self.g_fwd.replay()
-        works = []
+        prev = None          # collectives of the previous stage: waited for (and its update replayed) after the next stage is enqueued
         for j, g in enumerate(self.g_bwd):
             g.replay()
+            works = []
             if self.world > 1:
                 b = self.buckets[j]
                 for flat in (b["wire16"], b["wire32"]):
                     if flat is not None:
                         works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
+            if prev is not None:
+                for w in prev:
+                    w.wait()
+                if self.g_opt[j - 1] is not None:
+                    self.g_opt[j - 1].replay()
+            prev = works
+        for w in prev:
             w.wait()
-        self.g_opt.replay()
+        if self.g_opt[-1] is not None:
+            self.g_opt[-1].replay()
         return self.loss

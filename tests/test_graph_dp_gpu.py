@@ -82,8 +82,9 @@ def _worker(rank, world, port, q):
     wires = sorted({str(b[k].dtype) for b in step.buckets for k in ("wire16", "wire32") if b[k] is not None})
     step()
     torch.cuda.synchronize()
-    # after the step p.grad is bound to the reduced buffers: the SUM over ranks (the 1 / world lives in optimizer.grad_scale)
-    grads = {n: (p.grad.detach().float().cpu().numpy() if p.grad is not None else None) for n, p in model.named_parameters()}
+    # after the step the wire buffers hold the SUM over ranks (the 1 / world lives in optimizer.grad_scale); the optimizer read them there
+    red = step.gradients()
+    grads = {n: (red[p].detach().float().cpu().numpy() if p in red else None) for n, p in model.named_parameters()}
     step()
     torch.cuda.synchronize()
     got = {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()}

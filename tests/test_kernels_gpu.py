@@ -705,6 +705,33 @@ def test_multi_tensor_adamw_optimizer_matches_reference_rules():
         close(p.detach(), q, 2e-5, 2e-6, "adamw multi (transformers rule)")
 
 
+def test_adamw_reads_bf16_wire_buffers_and_updates_subsets():
+    """Round 3: `external_grads` — the data-parallel step hands the optimizer its wire buffers; a bf16 buffer is converted while it
+    is loaded (bit-identical to the update from the same values as fp32), ragged tails included — and `step(only=...)` updates a
+    subset per call while the step count advances once."""
+    from mmf_amd.modules.optimizers import AdamW
+    gen = torch.Generator().manual_seed(11)
+    shapes = [(40, 33), (257,), (8, 8), (1024, 64), (3,)]
+    base = [torch.randn(s, generator=gen).to(DEV) for s in shapes]
+    g16 = [(torch.randn(s, generator=gen) * 2).to(DEV).bfloat16() for s in shapes]
+    a = [b.clone().requires_grad_(True) for b in base]; b_ = [b.clone().requires_grad_(True) for b in base]
+    oa = AdamW([{"params": a, "weight_decay": 0.01}], lr=2e-3, eps=1e-8); ob = AdamW([{"params": b_, "weight_decay": 0.01}], lr=2e-3, eps=1e-8)
+    oa.external_grads = {id(p): g for p, g in zip(a, g16)}                       # bf16 buffers, read in place
+    for step in range(2):
+        for p, g in zip(b_, g16):
+            p.grad = g.float()
+        ob.step()
+        oa.step(only={id(p) for p in a[:2]}, advance=True)                      # two calls = one optimizer step
+        oa.step(only={id(p) for p in a[2:]}, advance=False)
+    for p, q in zip(a, b_):
+        assert p.grad is None
+        assert torch.equal(p.detach(), q.detach())
+    assert all(oa.state[p]["step"] == 2 for p in a)
+    with pytest.raises(nat().NativeLibraryError):
+        oa.external_grads = {id(a[0]): g16[0].half()}
+        oa.step()
+
+
 @pytest.mark.parametrize("capturable", [False, True])
 def test_optimizer_checkpoint_resumes_step_count_and_schedule(capturable):
     """state_dict() carries a per-parameter `step` (the transformers.AdamW format) and, for the capturable form, the device

@@ -54,7 +54,81 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one hipGraph")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--config", default=None, choices=["mmbt", "vilbert", "uniter", "mmft", "m4c"],
+                    help="one of BASELINE.json's OTHER configs (parity-test cases, not the headline): the same JSON shape for that model's "
+                         "training step on one GPU (workload named from BASELINE.json.configs; roofline of its dominant GEMM family)")
     return ap.parse_args()
+
+
+# BASELINE.json.configs index of every --config choice (configs[1] is the headline)
+OTHER_CONFIGS = {"mmbt": 0, "vilbert": 2, "uniter": 3, "mmft": 3, "m4c": 4}
+
+
+def config_bench(args):
+    """`python bench.py --config vilbert`: forward + loss + backward + fused AdamW of one of the widened models at the shape BASELINE.json
+    names for it, ONE GPU (a per-GPU share of the multi-GPU configs), train mode, synthetic inputs resident in HBM; eager launches (these
+    models branch on tensor values in their input massaging, as the reference does), per-step HIP-event median beside the wall-clock mean."""
+    import warnings
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import widened_bench as W
+    from mmf_amd.common.registry import registry
+    from mmf_amd.common.sample import SampleList
+    from mmf_amd.utils.configuration import Config
+    name = args.config
+    g = torch.Generator().manual_seed(1234)
+    torch.manual_seed(1234)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        label, B, model, sample = W.CASES[name](g)
+    model = model.to("cuda").train()
+    batch = SampleList(W.to_dev(sample))
+    full = Config(model=name, optimizer=dict(params=dict(lr=5e-5)), model_config={name: model.config})
+    opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(batch)
+        loss = sum(v.sum() for v in out["losses"].values())
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(args.steps):
+        last = step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    with KernelProbe() as probe:
+        step()
+    by = probe.summary()
+    gem = {k: v for k, v in by.items() if k.startswith("gemm") and "(ragged / small)" not in k}
+    dom = max(gem, key=lambda k: gem[k]["ms"])
+    tot_ms = sum(v["ms"] for k, v in by.items() if k.startswith("gemm")); tot_fl = sum(v["work"] for k, v in by.items() if k.startswith("gemm"))
+    configs = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    ms = dt / args.steps * 1e3
+    line = {
+        "metric": "samples/sec, %s training step (fwd+loss+bwd+AdamW), one GPU" % name, "value": round(B * args.steps / dt, 2), "unit": "samples/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "ms_per_step_event_median": round(per[len(per) // 2], 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": configs[OTHER_CONFIGS[name]], "shape": label, "global_batch": B, "parallelism": "dp1", "launch": "eager",
+                   "loss": round(float(last.item()), 4), "params": sum(p.numel() for p in model.parameters()),
+                   "note": "a parity-test configuration of BASELINE.json, not its headline; one GPU's share of the multi-GPU configs"},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(by[dom]["work"] / by[dom]["ms"] / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(by[dom]["work"] / by[dom]["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "avg_launch_ms": round(by[dom]["ms"] / by[dom]["launches"], 4), "launches_per_step": by[dom]["launches"],
+                     "all_gemm": {"tflops": round(tot_fl / tot_ms / 1e9, 2), "ms_per_step": round(tot_ms, 3), "gflop_per_step": round(tot_fl / 1e9, 1)},
+                     "step_frac_of_mfma_peak": round(tot_fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "attention": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["work"] / v["ms"] / 1e9, 1)}
+                                   for k, v in sorted(by.items()) if k.startswith("attention")}},
+    }
+    print(json.dumps(line), flush=True)
 
 
 def build(device, rank):
@@ -291,6 +365,11 @@ def cpu_baseline(batch, steps, budget_s=24.0):
 
 def main():
     args = parse()
+    if args.config is not None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback for the product path")
+        torch.cuda.set_device(0)
+        return config_bench(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     from mmf_amd.utils import distributed as D
     rank, world = D.distributed_init_from_env()

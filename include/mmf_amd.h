@@ -364,6 +364,35 @@ int mmf_bce_rowmask_fwd(const float* scores, const float* targets, const float* 
 int mmf_bce_rowmask_bwd(const float* scores, const float* targets, const float* row_weight, const float* count, const float* gloss,
                         float* dscores, int rows, int N, void* stream);
 
+/* ---- UNITER pretraining heads (mmf/models/uniter.py:36-39: tasks mlm, itm, mrc, mrfr, wra) -------------------------------------
+ * MRFR, mmf/models/transformers/heads/mrfr.py:85-90: F.mse_loss(prediction_feat, feat_targets, reduction="mean") on the fp32 output
+ * of the tied projection GEMM.  fwd writes loss[0] (deterministic two-stage sum through ws, mmf_mse_ws_floats() floats); bwd writes
+ * gloss * 2 (pred - target) / (rows * cols) as bf16 [rows, ldd] (ldd % 8 == 0, pad columns zero): the operand of the projection's
+ * input- and weight-gradient GEMMs. */
+int mmf_mse_ws_floats(void);
+int mmf_mse_fwd(const float* pred, int ldp, const float* target, int ldt, float* loss, float* ws, int rows, int cols, void* stream);
+int mmf_mse_bwd(const float* pred, int ldp, const float* target, int ldt, const float* gloss, void* dpred, int ldd, int rows, int cols, void* stream);
+/* WRA, mmf/models/transformers/heads/wra.py:36-83 over mmf/modules/ot.py: per sample b the optimal-transport distance between the text
+ * rows [0, M) and the region rows [M, M + N) of the joint sequence seq [B, S, H] (bf16, row stride ld, S >= M + N) under the cosine cost
+ * (ot.py:15-25, F.normalize eps), the transport plan by `iterations` IPOT steps (ot.py:38-84, beta, k = 1; a constant of the
+ * backward pass) and loss = (sum of dist over label == 1 - sum over label == 0) / (number of such samples).  fp32 arithmetic, one
+ * workgroup per sample, M, N <= 128.  Saved for the backward: xinv [B, M], yinv [B, N] (1 / max(|row|, eps)), plan [B, N, M], cost
+ * [B, M, N]; dist [B] is also an output.  bwd writes the gradient of the M + N rows of every sample into dseq (bf16, row stride ldd);
+ * rows beyond M + N are not touched. */
+typedef struct mmf_wra_desc {
+    const void* seq; int ld;
+    int B, S, H, M, N;
+    const float* txt_pad;    /* [B, M] 1.0 = padding */
+    const float* img_pad;    /* [B, N] */
+    const int64_t* label;    /* [B] is_correct */
+    float* xinv; float* yinv; float* plan; float* cost; float* dist;
+    float beta;              /* 0 = 0.5 */
+    float eps;               /* 0 = 1e-5 */
+    int iterations;          /* 0 = 50 */
+} mmf_wra_desc;
+int mmf_wra_fwd(const mmf_wra_desc* d, float* loss, float* count, void* stream);
+int mmf_wra_bwd(const mmf_wra_desc* d, const float* gloss, const float* count, void* dseq, int ldd, void* stream);
+
 /* ---- optimizer: AdamW (mmf/modules/optimizers.py:8-17; transformers.AdamW semantics) ----------
  * One fused pass over a flat fp32 parameter arena: p, g, m, v [n].  Weight decay is
  * given per SEGMENT: seg_end[i] (exclusive prefix ends, int64 [nseg]) and seg_wd[i] (weight decay of

@@ -68,6 +68,12 @@ class AdamWMultiDesc(C.Structure):
     ]
 
 
+class WraDesc(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("ld", C.c_int), ("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("M", C.c_int), ("N", C.c_int),
+                ("txt_pad", C.c_void_p), ("img_pad", C.c_void_p), ("label", C.c_void_p), ("xinv", C.c_void_p), ("yinv", C.c_void_p),
+                ("plan", C.c_void_p), ("cost", C.c_void_p), ("dist", C.c_void_p), ("beta", C.c_float), ("eps", C.c_float), ("iterations", C.c_int)]
+
+
 class LnReduceList(C.Structure):
     _fields_ = [("n", C.c_int), ("partials", C.c_void_p * MT_MAX), ("rows", C.c_int * MT_MAX), ("H", C.c_int * MT_MAX),
                 ("dgamma", C.c_void_p * MT_MAX), ("dbeta", C.c_void_p * MT_MAX)]
@@ -632,6 +638,49 @@ def rows_add_embed_f32(x, seg, pos, typ, y, B, L, S, H, row0=0, pos0=0):
 def gather_rows_f32(x, index, out, B, S, H):
     _req(x, torch.float32, "x"); _req(index, torch.int64, "index"); _req(out, torch.float32, "out")
     _check(lib().mmf_gather_rows_f32(_p(x), _p(index), _p(out), B, S, H, _stream()), "mmf_gather_rows_f32")
+
+
+# --------------------------------------------------------------------------------------------
+# UNITER pretraining heads (mmf_amd/csrc/uniter_ops.hip)
+# --------------------------------------------------------------------------------------------
+def mse_fwd(pred, target, loss, rows, cols):
+    """loss[0] = mean((pred - target)^2); pred / target fp32 [rows, cols] (row strides from the tensors)."""
+    for t, n in ((pred, "pred"), (target, "target"), (loss, "loss")):
+        _req(t, torch.float32, n)
+    ws = torch.empty(lib().mmf_mse_ws_floats(), dtype=torch.float32, device=pred.device)
+    _check(lib().mmf_mse_fwd(_p(pred), pred.stride(0), _p(target), target.stride(0), _p(loss), _p(ws), rows, cols, _stream()), "mmf_mse_fwd")
+
+
+def mse_bwd(pred, target, gloss, dpred, ldd, rows, cols):
+    for t, n in ((pred, "pred"), (target, "target"), (gloss, "gloss")):
+        _req(t, torch.float32, n)
+    _req(dpred, torch.bfloat16, "dpred")
+    _check(lib().mmf_mse_bwd(_p(pred), pred.stride(0), _p(target), target.stride(0), _p(gloss), _p(dpred), ldd, rows, cols, _stream()), "mmf_mse_bwd")
+
+
+def _wra_desc(seq, ld, B, S, H, M, N, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist):
+    _req(seq, torch.bfloat16, "seq"); _req(label, torch.int64, "label")
+    for t, n in ((txt_pad, "txt_pad"), (img_pad, "img_pad"), (xinv, "xinv"), (yinv, "yinv"), (plan, "plan"), (cost, "cost"), (dist, "dist")):
+        _req(t, torch.float32, n)
+    d = WraDesc()
+    d.seq, d.ld, d.B, d.S, d.H, d.M, d.N = _p(seq), ld, B, S, H, M, N
+    d.txt_pad, d.img_pad, d.label = _p(txt_pad), _p(img_pad), _p(label)
+    d.xinv, d.yinv, d.plan, d.cost, d.dist = _p(xinv), _p(yinv), _p(plan), _p(cost), _p(dist)
+    d.beta, d.eps, d.iterations = 0.5, 1e-5, 50
+    return d
+
+
+def wra_fwd(seq, ld, B, S, H, M, N, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist, loss, count):
+    """UNITER word-region alignment (heads/wra.py + modules/ot.py): per-sample OT distance by 50 IPOT steps, signed mean."""
+    _req(loss, torch.float32, "loss"); _req(count, torch.float32, "count")
+    d = _wra_desc(seq, ld, B, S, H, M, N, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist)
+    _check(lib().mmf_wra_fwd(C.byref(d), _p(loss), _p(count), _stream()), "mmf_wra_fwd")
+
+
+def wra_bwd(seq, ld, B, S, H, M, N, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist, gloss, count, dseq, ldd):
+    _req(gloss, torch.float32, "gloss"); _req(count, torch.float32, "count"); _req(dseq, torch.bfloat16, "dseq")
+    d = _wra_desc(seq, ld, B, S, H, M, N, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist)
+    _check(lib().mmf_wra_bwd(C.byref(d), _p(gloss), _p(count), _p(dseq), ldd, _stream()), "mmf_wra_bwd")
 
 
 # --------------------------------------------------------------------------------------------

@@ -1202,6 +1202,80 @@ class MaskedRegionHeadFn(torch.autograd.Function):
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
 
 
+class TiedRegressionMSEFn(torch.autograd.Function):
+    """MRFR's last two lines (mmf/models/transformers/heads/mrfr.py:85-90): prediction = F.linear(h, W.t(), b) with the TIED image-embedding
+    weight W [hidden, img_dim] (UNITERImageEmbeddings.img_linear.weight applied transposed), loss = F.mse_loss(prediction, targets).
+    The projection is the GEMM's NN form (W read k-major: no transposed copy) with fp32 output; the loss kernel's backward writes the
+    bf16 operand of the input-gradient (NT against W) and weight-gradient (TN: dW = h^T d) GEMMs; the bias gradient is its column sum."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, w16, targets):
+        h2 = _as_bf16_2d(h)
+        n, K = h2.shape
+        D = weight.shape[1]
+        t = targets.float().contiguous()
+        loss = torch.empty(1, dtype=F32, device=h2.device)
+        pred = torch.empty(max(n, 1), D, dtype=F32, device=h2.device)
+        if n:
+            nat.gemm(h2, w16, pred, n, D, K, K, D, D, b_kmajor=True, bias=bias.detach())
+            nat.mse_fwd(pred, t, loss, n, D)
+        else:
+            loss.fill_(float("nan"))          # (F.mse_loss of an empty tensor)
+        ctx.save_for_backward(h2, w16, pred, t)
+        ctx.meta = (h.shape, n, K, D)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        h2, w16, pred, t = ctx.saved_tensors
+        hshape, n, K, D = ctx.meta
+        dev = h2.device
+        if not n:
+            return torch.zeros(hshape, dtype=BF16, device=dev), torch.zeros(K, D, dtype=F32, device=dev), torch.zeros(D, dtype=F32, device=dev), None, None
+        ldd = _pad8(D)
+        d16 = torch.empty(n, ldd, dtype=BF16, device=dev)
+        nat.mse_bwd(pred, t, g.float().reshape(1).contiguous(), d16, ldd, n, D)
+        dh = torch.empty(n, K, dtype=BF16, device=dev)
+        nat.gemm(d16, w16, dh, n, K, D, ldd, D, K)                                  # dh[m, k] = sum_n d[m, n] W[k, n]
+        dw = torch.empty(K, D, dtype=F32, device=dev)
+        nat.gemm(h2, d16, dw, K, D, n, K, ldd, D, a_kmajor=True, b_kmajor=True)     # dW[k, n] = sum_m h[m, k] d[m, n]
+        db = _colsum(d16, ldd, n, D)
+        return dh.view(hshape), dw, db, None, None
+
+
+class WordRegionAlignmentFn(torch.autograd.Function):
+    """WRA.forward (mmf/models/transformers/heads/wra.py:36-83) over `optimal_transport_dist` (mmf/modules/ot.py:87-110): returns
+    (loss, per-sample OT distance).  One workgroup per sample: cosine cost, 50 IPOT steps with the plan in LDS, trace(C T); the plan is
+    a constant of the backward pass (ot.py:38 `@torch.no_grad()`), which differentiates the cost matrix and the two normalisations."""
+
+    @staticmethod
+    def forward(ctx, sequence_output, txt_len, img_len, txt_pad, img_pad, labels):
+        B, S, H = sequence_output.shape
+        seq = _as_bf16_2d(sequence_output)
+        M, N = int(txt_len), int(img_len)
+        dev = seq.device
+        tp = txt_pad.reshape(B, M).float().contiguous()
+        ip = img_pad.reshape(B, N).float().contiguous()
+        lab = labels.reshape(B).long().contiguous()
+        xinv = torch.empty(B, M, dtype=F32, device=dev); yinv = torch.empty(B, N, dtype=F32, device=dev)
+        plan = torch.empty(B, N, M, dtype=F32, device=dev); cost = torch.empty(B, M, N, dtype=F32, device=dev)
+        dist = torch.empty(B, dtype=F32, device=dev)
+        loss = torch.empty(1, dtype=F32, device=dev); count = torch.empty(1, dtype=F32, device=dev)
+        nat.wra_fwd(seq, H, B, S, H, M, N, tp, ip, lab, xinv, yinv, plan, cost, dist, loss, count)
+        ctx.save_for_backward(seq, tp, ip, lab, xinv, yinv, plan, cost, dist, count)
+        ctx.meta = (B, S, H, M, N, sequence_output.shape)
+        ctx.mark_non_differentiable(dist)
+        return loss[0], dist
+
+    @staticmethod
+    def backward(ctx, g, _gdist):
+        seq, tp, ip, lab, xinv, yinv, plan, cost, dist, count = ctx.saved_tensors
+        B, S, H, M, N, shape = ctx.meta
+        dseq = (torch.zeros if S > M + N else torch.empty)(B * S, H, dtype=BF16, device=seq.device)
+        nat.wra_bwd(seq, H, B, S, H, M, N, tp, ip, lab, xinv, yinv, plan, cost, dist, g.float().reshape(1).contiguous(), count, dseq, H)
+        return dseq.view(shape), None, None, None, None, None
+
+
 class TakeRowsFn(torch.autograd.Function):
     """out[r] = x[idx[r]] for a list of DISTINCT row indices: the `sequence_output[masked_tokens, :]` compaction of the MLM
     transformer head (mmf/models/transformers/heads/mlm.py:80-83) — only the masked positions go through the vocabulary

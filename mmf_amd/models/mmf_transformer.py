@@ -17,6 +17,8 @@ from mmf_amd.models.transformers.backends import huggingface as _hf_backend  # n
 from mmf_amd.models.transformers.heads import itm as _itm_head  # noqa: F401  (registers "itm")
 from mmf_amd.models.transformers.heads import mlm as _mlm_head  # noqa: F401  (registers "mlm")
 from mmf_amd.models.transformers.heads import mrc as _mrc_head  # noqa: F401  (registers "mrc")
+from mmf_amd.models.transformers.heads import mrfr as _mrfr_head  # noqa: F401  (registers "mrfr")
+from mmf_amd.models.transformers.heads import wra as _wra_head  # noqa: F401  (registers "wra")
 from mmf_amd.models.transformers.heads import mlp as _mlp_head  # noqa: F401  (registers "mlp")
 
 

@@ -12,7 +12,7 @@ LayerNorms, the sums and the concat are the row kernels of mmf_amd/csrc/rowops.h
 VisualBERT path runs on; heads come from the transformer-head registry (`mlp`).
 
 `do_pretraining`: `UNITERForPretraining` (:350-618) for the tasks whose heads are built — mlm, itm, mrc (mmf_amd/models/transformers/
-heads); mrfr and wra raise at build time (their oracles are pinned, the kernels are not written).  One task per batch, drawn like the
+heads); mrfr (tied regression + MSE) and wra (optimal-transport alignment, 50 IPOT steps per sample in LDS) since round 3.  One task per batch, drawn like the
 reference does; the random region masks come from the same numpy / random calls as the reference's `_get_img_mask`."""
 import copy
 import random
@@ -28,6 +28,8 @@ from mmf_amd.models.transformers.heads import itm as _itm_head  # noqa: F401  (r
 from mmf_amd.models.transformers.heads import mlm as _mlm_head  # noqa: F401  (registers "mlm")
 from mmf_amd.models.transformers.heads import mlp as _mlp_head  # noqa: F401  (registers "mlp")
 from mmf_amd.models.transformers.heads import mrc as _mrc_head  # noqa: F401  (registers "mrc")
+from mmf_amd.models.transformers.heads import mrfr as _mrfr_head  # noqa: F401  (registers "mrfr")
+from mmf_amd.models.transformers.heads import wra as _wra_head  # noqa: F401  (registers "wra")
 from mmf_amd.modules.hf_layers import (
     BertConfig, BertEmbeddingsJit, BertEncoderJit, BertPooler, Dropout, LayerNorm, Linear, init_bert_weights)
 from mmf_amd.modules.losses import MMFLoss
@@ -170,14 +172,13 @@ class UNITERForPretraining(nn.Module):
         for task in self.tasks:
             head_config = dict(head_configs[task])
             head_type = head_config.get("type", "mlp")
-            if head_type in ("mrfr", "wra"):
-                raise NotImplementedError(
-                    "UNITER pretraining task %r: the %s head (mmf/models/transformers/heads/%s.py) is not built on the HIP side yet "
-                    "(its oracle is pinned: oracle/mmft_oracle.py); configure `tasks` as a subset of mlm,itm,mrc" % (task, head_type, head_type))
             head_class = registry.get_transformer_head_class(head_type)
             if head_class is None:
                 raise RuntimeError("No transformer head registered for name: %s" % head_type)
-            if head_type in ("itm", "mlm", "mlp"):
+            if head_type == "mrfr":
+                head_config.pop("type", None)
+                self.heads[task] = head_class(self.uniter.img_embeddings.img_linear.weight, **head_config)      # uniter.py:397-400: tied weight
+            elif head_type in ("itm", "mlm", "mlp"):
                 self.heads[task] = head_class(head_config)                    # uniter.py:400-401
             else:
                 head_config.pop("type", None)
@@ -202,6 +203,10 @@ class UNITERForPretraining(nn.Module):
             self._preprocess_itm(processed_sample_list)
         elif task == "mrc":
             self._preprocess_mrc(processed_sample_list)
+        elif task == "mrfr":
+            self._preprocess_mrfr(processed_sample_list)
+        elif task == "wra":
+            self._preprocess_wra(processed_sample_list)
         else:
             raise ValueError("Task %s is not supported for pretraining!" % task)
         return _infer_with_heads(processed_sample_list, self.uniter, self.heads, self.losses)
@@ -270,6 +275,38 @@ class UNITERForPretraining(nn.Module):
         cls_dim = cls_prob.size(2)
         processed_sample_list[mrc_label_key] = cls_prob[img_masks_ext].contiguous().view(-1, cls_dim)
         self._mask_inputs_in_sample_list(processed_sample_list, mrc_mask_key)
+
+    def _preprocess_mrfr(self, processed_sample_list):
+        """uniter.py:542-556: the regression targets are the ORIGINAL features of the masked regions."""
+        assert "image_mask" in processed_sample_list
+        assert "image_feat_masked" in processed_sample_list
+        mrfr_target_key = self.heads["mrfr"].mrfr_target_key
+        mrfr_mask_key = self.heads["mrfr"].mrfr_mask_key
+        image_mask = processed_sample_list["image_mask"]
+        image_feat = processed_sample_list["image_feat"]
+        img_masks_ext = image_mask.unsqueeze(-1).expand_as(image_feat)
+        feat_dim = image_feat.size(2)
+        processed_sample_list[mrfr_target_key] = image_feat[img_masks_ext].contiguous().view(-1, feat_dim)
+        self._mask_inputs_in_sample_list(processed_sample_list, mrfr_mask_key)
+
+    def _preprocess_wra(self, processed_sample_list):
+        """uniter.py:558-581: padding masks of the optimal-transport alignment from the per-sample lengths (dense batches: no padding)."""
+        assert "is_correct" in processed_sample_list
+        ot_inputs_key = self.heads["wra"].ot_inputs_key
+        wra_label_key = self.heads["wra"].wra_label_key
+        txt_lens = [i.size(0) for i in processed_sample_list["input_ids"]]
+        num_bbs = [f.size(0) for f in processed_sample_list["image_feat"]]
+
+        def _compute_pad(lens):
+            max_len = max(lens)
+            pad = torch.zeros(len(lens), max_len)
+            for i, n in enumerate(lens):
+                pad.data[i, n:].fill_(1)
+            return pad
+
+        device = processed_sample_list["input_ids"].device
+        processed_sample_list[ot_inputs_key] = {"txt_pad": _compute_pad(txt_lens).to(device).bool(), "img_pad": _compute_pad(num_bbs).to(device).bool()}
+        processed_sample_list[wra_label_key] = processed_sample_list["is_correct"]
 
     def _remove_mismatched_captions(self, processed_sample_list):
         """uniter.py:583-617 selects the matched pairs of each tensor and never writes the selection back: it changes nothing.  Kept

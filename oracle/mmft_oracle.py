@@ -215,7 +215,7 @@ def mrfr_head(hsd, img_embedding_weight, sequence_output, feat_targets, region_m
     """MRFR.forward (masked region feature regression), mmf/models/transformers/heads/mrfr.py:58-93: the masked regions through
     Linear -> GELU -> LayerNorm, projected back to the feature space with the TRANSPOSED image-embedding weight (`F.linear(h,
     W.t(), b)`, W = `img_embeddings.img_linear.weight` [hidden, img_dim], :46,86-88) and regressed onto the original features of the
-    masked regions with mean-squared error.  (Oracle ahead of the HIP path: the head is not built yet.)"""
+    masked regions with mean-squared error."""
     rows = sequence_output[region_mask.unsqueeze(-1).expand_as(sequence_output)].contiguous().view(-1, sequence_output.size(-1))
     x = F.gelu(F.linear(rows, hsd["feat_regress.0.weight"], hsd["feat_regress.0.bias"]))
     x = F.layer_norm(x, (x.shape[-1],), hsd["feat_regress.2.weight"], hsd["feat_regress.2.bias"], eps)
@@ -262,7 +262,7 @@ def optimal_transport_dist(txt_emb, img_emb, txt_pad, img_pad, beta=0.5, iterati
 def wra_head(sequence_output, txt_len, img_len, txt_pad, img_pad, is_correct):
     """WRA.forward (word-region alignment), mmf/models/transformers/heads/wra.py:36-83: OT distance between the text rows [:tl] and
     the region rows [tl : tl + il] of the joint sequence; loss = (sum over matched pairs - sum over mismatched pairs) / number of
-    pairs.  (Oracle ahead of the HIP path: the head is not built yet.)"""
+    pairs."""
     txt_emb = sequence_output[:, :txt_len, :]
     img_emb = sequence_output[:, txt_len:txt_len + img_len, :]
     ot = optimal_transport_dist(txt_emb.float(), img_emb.float(), txt_pad.bool(), img_pad.bool()).to(txt_emb)

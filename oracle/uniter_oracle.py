@@ -183,14 +183,25 @@ def pretraining_preprocess(sample_list, task, region_masks=None, ignore_index=-1
         pad = torch.zeros((m.size(0), s["input_ids"].size(1))).to(m)
         s["image_region_mask"] = torch.cat([pad, m], dim=-1)                                                       # :513-517, 523-525
         s["image_feat"] = s["image_feat_masked"]                                                                   # :526
+    elif task == "mrfr":                                                                                           # :542-556
+        m = s["image_mask"]
+        feat = s["image_feat"]
+        s["mrfr_region_target"] = feat[m.unsqueeze(-1).expand_as(feat)].contiguous().view(-1, feat.size(2))      # the ORIGINAL features
+        pad = torch.zeros((m.size(0), s["input_ids"].size(1))).to(m)
+        s["mrfr_region_mask"] = torch.cat([pad, m], dim=-1)
+        s["image_feat"] = s["image_feat_masked"]
+    elif task == "wra":                                                                                            # :558-581 (dense batch: no padding)
+        B = s["input_ids"].size(0)
+        s["wra_info"] = {"txt_pad": torch.zeros(B, s["input_ids"].size(1), dtype=torch.bool),
+                         "img_pad": torch.zeros(B, s["image_feat"].size(1), dtype=torch.bool)}
     else:
-        raise ValueError("Task %s is not restated (mlm, itm, mrc)" % task)
+        raise ValueError("Task %s is not restated (mlm, itm, mrc, mrfr, wra)" % task)
     return s
 
 
 def uniter_pretraining_forward(sd, cfg, sample_list, task, region_masks=None):
-    """UNITERForPretraining.forward (uniter.py:411-440) -> `_infer_with_heads` (:249-275) for task in {mlm, itm, mrc}: the heads'
-    own restatements are oracle.mmft_oracle.{mlm_head, itm_head, mrc_head}.  The MLM decoder is NOT tied here (the reference's
+    """UNITERForPretraining.forward (uniter.py:411-440) -> `_infer_with_heads` (:249-275) for task in {mlm, itm, mrc, mrfr, wra}: the heads'
+    own restatements are oracle.mmft_oracle.{mlm_head, itm_head, mrc_head, mrfr_head, wra_head}.  The MLM decoder is NOT tied here (the reference's
     pretraining wrapper builds the head without calling `tie_weights`): `heads.mlm.cls.predictions.decoder.weight` is its own tensor."""
     from oracle import mmft_oracle as H
     s = pretraining_preprocess(sample_list, task, region_masks)
@@ -201,6 +212,10 @@ def uniter_pretraining_forward(sd, cfg, sample_list, task, region_masks=None):
         out = H.mlm_head(hsd, hsd["cls.predictions.decoder.weight"], seq, s["mlm_labels"]["combined_labels"])
     elif task == "itm":
         out = H.itm_head(hsd, seq, s["itm_labels"]["is_correct"])
+    elif task == "mrfr":     # the head's projection weight is the image embedding's (uniter.py:397-400), applied transposed
+        out = H.mrfr_head(hsd, sd["uniter.uniter.img_embeddings.img_linear.weight"], seq, s["mrfr_region_target"], s["mrfr_region_mask"].bool())
+    elif task == "wra":
+        out = H.wra_head(seq, s["input_ids"].size(1), s["image_feat"].size(1), s["wra_info"]["txt_pad"], s["wra_info"]["img_pad"], s["is_correct"])
     else:
         out = H.mrc_head(hsd, seq, s["region_class"], s["image_region_mask"].bool())
     out["preprocessed"] = s

@@ -6,7 +6,12 @@ UNITERModelBase.__init__ are replaced (the same HF classes built from a small co
 (`_get_img_mask`: numpy binomial + random.choice) are drawn under fixed seeds and RECORDED, so that the oracle and the HIP path can be
 handed the same masks.
 
-    python tests/golden/make_uniter_pretraining.py
+`--all-tasks` (round 3) writes a SECOND fixture, tests/golden/uniter_pretraining_all.npz, from the wrapper built with the reference's DEFAULT
+task list mlm, itm, mrc, mrfr, wra (uniter.py:36-39; the `mrfr` head tied to `img_embeddings.img_linear.weight`, :397-400) and records
+the two tasks the first fixture lacks: `_preprocess_mrfr` / `_preprocess_wra`, the MRFR and WRA heads (mmf/models/transformers/heads/
+{mrfr,wra}.py over mmf/modules/ot.py).  The first fixture stays as it is (its parameter list is part of what it pins).
+
+    python tests/golden/make_uniter_pretraining.py [--all-tasks]
 """
 import os
 import random
@@ -25,7 +30,7 @@ refshim, detweights, OmegaConf, SampleList = MG.refshim, MG.detweights, MG.Omega
 CASE = dict(MG.UNITER_CASES["uniter_small64"], seed=97, label_dim=29, mask_probability=0.3)
 
 
-def main():
+def main(all_tasks=False):
     from torch import nn
     from transformers import BertConfig
     from transformers.models.bert.modeling_bert import BertEmbeddings, BertModel
@@ -33,6 +38,8 @@ def main():
     MLM = refshim.ref_import("mmf.models.transformers.heads.mlm").MLM
     ITM = refshim.ref_import("mmf.models.transformers.heads.itm").ITM
     MRC = refshim.ref_import("mmf.models.transformers.heads.mrc").MRC
+    MRFR = refshim.ref_import("mmf.models.transformers.heads.mrfr").MRFR
+    WRA = refshim.ref_import("mmf.models.transformers.heads.wra").WRA
     c = CASE
     torch.manual_seed(c["seed"])
     H, V = c["hidden_size"], c["vocab_size"]
@@ -72,15 +79,19 @@ def main():
             self.loss_configs = {}
             self.mask_probability = c["mask_probability"]
             self.uniter = RefBase()
-            self.tasks = ["mlm", "itm", "mrc"]
+            self.tasks = ["mlm", "itm", "mrc"] + (["mrfr", "wra"] if all_tasks else [])
             self.heads = nn.ModuleDict({
                 "mlm": MLM(OmegaConf.create(dict(type="mlm", vocab_size=V, hidden_size=H))),
                 "itm": ITM(OmegaConf.create(dict(type="itm", hidden_size=H))),
                 "mrc": MRC(hidden_size=H, label_dim=c["label_dim"])})
+            if all_tasks:
+                self.heads["mrfr"] = MRFR(self.uniter.img_embeddings.img_linear.weight, hidden_size=H, img_dim=c["img_dim"])   # uniter.py:397-400
+                self.heads["wra"] = WRA()
             self.losses = nn.ModuleDict()
 
     for fn in ("forward", "_process_sample_list_for_pretraining", "_add_image_feat_masked", "_get_img_mask", "_preprocess_mlm",
-               "_preprocess_itm", "_preprocess_mrc", "_get_feature_mask", "_mask_inputs_in_sample_list", "_remove_mismatched_captions"):
+               "_preprocess_itm", "_preprocess_mrc", "_preprocess_mrfr", "_preprocess_wra", "_get_feature_mask", "_mask_inputs_in_sample_list",
+               "_remove_mismatched_captions"):
         setattr(RefPre, fn, getattr(U.UNITERForPretraining, fn))
 
     ref = RefPre().eval()
@@ -130,7 +141,7 @@ def main():
     rec = {"in_input_ids": ids, "in_input_ids_masked": ids_masked, "in_lm_label_ids": lm, "in_input_mask": mask, "in_image_feat": feats,
            "in_img_pos_feat": pos_feat, "in_attention_mask": attention_mask, "in_image_mask": image_valid, "in_is_correct": is_correct,
            "in_cls_prob": cls_prob}
-    for task in ("mlm", "itm", "mrc"):
+    for task in (("mrfr", "wra") if all_tasks else ("mlm", "itm", "mrc")):
         ref.zero_grad()
         np.random.seed(c["seed"] + 7)
         random.seed(c["seed"] + 7)
@@ -149,6 +160,12 @@ def main():
             rec["mrc_pre_image_region_mask"] = sl["image_region_mask"].numpy().astype(np.int64)
         if task == "mlm":
             rec["mlm_pre_combined_labels"] = sl["mlm_labels"]["combined_labels"].numpy()
+        if task == "mrfr":
+            rec["mrfr_pre_region_target"] = sl["mrfr_region_target"].numpy()
+            rec["mrfr_pre_region_mask"] = sl["mrfr_region_mask"].numpy().astype(np.int64)
+        if task == "wra":
+            rec["wra_pre_txt_pad"] = sl["wra_info"]["txt_pad"].numpy().astype(np.int64)
+            rec["wra_pre_img_pad"] = sl["wra_info"]["img_pad"].numpy().astype(np.int64)
         names, norms = [], []
         for k, p in ref.named_parameters():
             g = p.grad
@@ -163,10 +180,11 @@ def main():
     rec["state_dict_keys"] = np.array(sorted(k for k in ref.state_dict().keys()
                                              if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")))
     rec["case"] = np.array(repr(c))
-    path = os.path.join(HERE, "uniter_pretraining.npz")
+    path = os.path.join(HERE, "uniter_pretraining_all.npz" if all_tasks else "uniter_pretraining.npz")
     np.savez_compressed(path, **rec)
-    print("uniter_pretraining", {t: float(rec[t + "_loss"]) for t in ("mlm", "itm", "mrc")}, "->", path, os.path.getsize(path), "bytes")
+    print("uniter_pretraining", {t: float(rec[t + "_loss"]) for t in (("mrfr", "wra") if all_tasks else ("mlm", "itm", "mrc"))}, "->", path,
+          os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    main(all_tasks="--all-tasks" in sys.argv)

@@ -291,6 +291,19 @@ def load_uniter_pretraining_case():
     return z, case, cfg, sd, sample
 
 
+def load_uniter_pretraining_all_case():
+    """`uniter_pretraining_all`: the reference's UNITERForPretraining built with its DEFAULT task list mlm, itm, mrc, mrfr, wra
+    (tests/golden/make_uniter_pretraining.py --all-tasks): the records of the tasks mrfr and wra.  Same inputs as `uniter_pretraining`."""
+    z = np.load(os.path.join(GOLDEN_DIR, "uniter_pretraining_all.npz"), allow_pickle=False)
+    _, case, cfg, _, sample = load_uniter_pretraining_case()
+    shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
+    sd = {"uniter." + k: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
+    # The MRFR head's `linear_proj_weight` IS the image embedding's weight (uniter.py:397-400): the state dict lists the one tensor under
+    # both names, and `load_state_dict` leaves it with the value loaded last (the head's entry).
+    sd["uniter.uniter.img_embeddings.img_linear.weight"] = sd["uniter.heads.mrfr.linear_proj_weight"]
+    return z, case, cfg, sd, sample
+
+
 def load_m4c_case(name="m4c_small64"):
     z = np.load(os.path.join(GOLDEN_DIR, "%s.npz" % name), allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))

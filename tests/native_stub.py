@@ -217,7 +217,35 @@ def _bce_rowmask_bwd(scores, targets, w, count, gloss, d, rows, Nn):
     assert d.numel() == rows * Nn and gloss.numel() == 1
 
 
-_CHECKED = {"soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
+def _mse_fwd(pred, target, loss, rows, cols):
+    assert pred.dtype == torch.float32 == target.dtype and loss.numel() == 1
+    _need(pred, rows, pred.stride(0), cols, "mse pred"); _need(target, rows, target.stride(0), cols, "mse target")
+
+
+def _mse_bwd(pred, target, gloss, d, ldd, rows, cols):
+    assert d.dtype == torch.bfloat16 and ldd % 8 == 0 and ldd >= cols and gloss.numel() == 1
+    _need(d, rows, ldd, ldd, "mse dpred")
+
+
+def _wra_common(seq, ld, B, S, H, M, Nn, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist):
+    assert seq.dtype == torch.bfloat16 and M <= 128 and Nn <= 128 and S >= M + Nn and ld >= H
+    _need(seq, B * S, ld, H, "wra seq")
+    assert txt_pad.numel() == B * M and img_pad.numel() == B * Nn and label.numel() == B and label.dtype == torch.int64
+    assert xinv.numel() == B * M and yinv.numel() == B * Nn and plan.numel() == B * M * Nn == cost.numel() and dist.numel() == B
+
+
+def _wra_fwd(seq, ld, B, S, H, M, Nn, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist, loss, count):
+    _wra_common(seq, ld, B, S, H, M, Nn, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist)
+    assert loss.numel() == 1 and count.numel() == 1
+
+
+def _wra_bwd(seq, ld, B, S, H, M, Nn, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist, gloss, count, dseq, ldd):
+    _wra_common(seq, ld, B, S, H, M, Nn, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist)
+    assert dseq.dtype == torch.bfloat16 and gloss.numel() == 1
+    _need(dseq, B * S, ldd, H, "wra dseq")
+
+
+_CHECKED = {"mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
             "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,

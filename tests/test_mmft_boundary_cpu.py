@@ -55,7 +55,7 @@ def test_optimizer_groups_and_unbuilt_variants():
     with pytest.raises(NotImplementedError):
         build_model(mmft_model_config(cfg, transformer_base="roberta-base"))
     with pytest.raises(RuntimeError):
-        build_model(mmft_model_config(cfg, heads=[dict(type="wra")]))              # a head that is not built is not registered
+        build_model(mmft_model_config(cfg, heads=[dict(type="refiner")]))          # a head that is not built is not registered
     # `mlm` and `itm` ARE built; the MLM decoder is tied to the text token embedding (mmf_transformer.py:145-174,
     # tests/models/test_mmf_transformer.py:504-523), state-dict keys equal the reference heads'
     from tests.golden_utils import load_transformer_heads_case

@@ -350,3 +350,75 @@ def test_reference_head_unit_tests_ported():
     for kw in (dict(), dict(use_kl=False)):
         out = MRC(hidden_size=768, label_dim=label_dim, **kw).cuda()(seq, proc)
         assert "mrc_loss" in out["losses"] and out["losses"]["mrc_loss"].shape == torch.Size([])
+
+
+def test_mrfr_and_wra_heads_match_the_reference_fixture():
+    """The two UNITER pretraining heads built in round 3, stand-alone, against the reference's own heads (tests/golden/make_golden.py,
+    `transformer_heads`): MRFR — compaction, Linear-GELU-LayerNorm, the TIED image-embedding weight applied transposed, MSE — loss, the
+    gradient of the sequence output, of every head parameter and of the tied weight; WRA — optimal-transport distance with ragged text /
+    region lengths (padding masks) and mixed labels — loss and the gradient of the sequence output."""
+    import numpy as np
+    from mmf_amd.models.transformers.heads.mrfr import MRFR
+    from mmf_amd.models.transformers.heads.wra import WRA
+    from tests.golden_utils import load_transformer_heads_extra
+    z, case, sds, inp = load_transformer_heads_extra()
+    seq0 = inp["sequence_output"].cuda()
+    H = seq0.shape[-1]
+    img_w = torch.nn.Parameter(sds["img"]["weight"].clone().cuda())
+    head = MRFR(img_w, hidden_size=H, img_dim=img_w.shape[1]).cuda().eval()
+    missing, unexpected = head.load_state_dict({k: v.cuda() for k, v in sds["mrfr"].items()}, strict=False)
+    assert not unexpected and missing == ["linear_proj_weight"], (missing, unexpected)
+    seq = seq0.clone().requires_grad_(True)
+    loss = head(seq, {"mrfr_region_target": inp["mrfr_target"].cuda(), "mrfr_region_mask": inp["region_mask"].cuda()})["losses"]["mrfr_loss"]
+    assert abs(loss.item() - float(z["mrfr_loss"])) <= 5e-2 * float(z["mrfr_loss"]), (loss.item(), float(z["mrfr_loss"]))
+    loss.backward()
+
+    def rel(a, b):
+        b = torch.from_numpy(np.asarray(b)).double()
+        return float((a.detach().double().cpu() - b).norm() / (b.norm() + 1e-30))
+    assert rel(seq.grad, z["mrfr_grad_sequence_output"]) <= 5e-2
+    assert rel(img_w.grad, z["grad::img.weight"]) <= 5e-2
+    for k, p in head.named_parameters():
+        if k != "linear_proj_weight":
+            assert rel(p.grad, z["grad::mrfr." + k]) <= 5e-2, k
+    # WRA
+    tl, il = inp["txt_pad"].shape[1], inp["img_pad"].shape[1]
+    wra = WRA().cuda().eval()
+    seq = seq0.clone().requires_grad_(True)
+    proc = {"wra_info": {"txt_pad": inp["txt_pad"].cuda(), "img_pad": inp["img_pad"].cuda()}, "is_correct": inp["is_correct"].cuda(),
+            "input_ids": torch.zeros(seq0.shape[0], tl, dtype=torch.long, device="cuda"), "image_feat": torch.zeros(seq0.shape[0], il, 4, device="cuda")}
+    lw = wra(seq, proc)["losses"]["wra_loss"]
+    assert abs(lw.item() - float(z["wra_loss"])) <= 5e-2 * abs(float(z["wra_loss"])), (lw.item(), float(z["wra_loss"]))
+    lw.backward()
+    assert rel(seq.grad, z["wra_grad_sequence_output"]) <= 5e-2
+    # the OT distance itself, per sample, against the oracle on the bf16-rounded sequence (tight: same arithmetic, fp32)
+    from oracle import mmft_oracle as HO
+    from mmf_amd import functional as Fn
+    sq = seq0.bfloat16().float().cpu()
+    want = HO.optimal_transport_dist(sq[:, :tl], sq[:, tl:tl + il], inp["txt_pad"].bool(), inp["img_pad"].bool())
+    _, dist = Fn.WordRegionAlignmentFn.apply(seq0, tl, il, inp["txt_pad"].cuda(), inp["img_pad"].cuda(), inp["is_correct"].cuda())
+    np.testing.assert_allclose(dist.cpu().numpy(), want.numpy(), rtol=2e-3, atol=1e-5)
+
+
+def test_wra_at_the_uniter_shape_matches_the_oracle():
+    """128 tokens + 100 regions, H = 768, B = 8, ragged lengths: distances and the gradient against the oracle (fp32 torch on the host)."""
+    from mmf_amd import functional as Fn
+    from oracle import mmft_oracle as HO
+    g = torch.Generator().manual_seed(5)
+    B, M, N, H = 8, 128, 100, 768
+    seq = (torch.randn(B, M + N, H, generator=g) * 0.7 + 0.2 * torch.randn(1, 1, H, generator=g)).bfloat16()
+    txt_pad = torch.zeros(B, M, dtype=torch.bool); img_pad = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        txt_pad[b, 16 + 14 * b:] = True
+        img_pad[b, 100 - 9 * b:] = True
+    labels = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0])
+    sq = seq.float().clone().requires_grad_(True)
+    want = HO.wra_head(sq, M, N, txt_pad, img_pad, labels)
+    want["losses"]["wra_loss"].backward()
+    x = seq.cuda().requires_grad_(True)
+    loss, dist = Fn.WordRegionAlignmentFn.apply(x, M, N, txt_pad.cuda(), img_pad.cuda(), labels.cuda())
+    loss.backward()
+    assert float((dist.cpu() - want["ot_dist"].detach()).abs().max()) <= 2e-3 * float(want["ot_dist"].abs().max())
+    assert abs(loss.item() - want["losses"]["wra_loss"].item()) <= 2e-3 * abs(want["losses"]["wra_loss"].item()) + 1e-5
+    gr = sq.grad
+    assert float((x.grad.float().cpu() - gr).norm() / gr.norm()) <= 2e-2

@@ -38,7 +38,7 @@ def _pretraining_model(tasks=("mlm", "itm", "mrc")):
     heads = {"mlm": dict(type="mlm", vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"]),
              "itm": dict(type="itm", hidden_size=cfg["hidden_size"]),
              "mrc": dict(type="mrc", hidden_size=cfg["hidden_size"], label_dim=cfg["label_dim"]),
-             "mrfr": dict(type="mrfr"), "wra": dict(type="wra")}
+             "mrfr": dict(type="mrfr", hidden_size=cfg["hidden_size"], img_dim=cfg["img_dim"]), "wra": dict(type="wra")}
     mc = uniter_model_config(ucfg, do_pretraining=True, tasks=list(tasks), heads={t: heads[t] for t in tasks}, losses={},
                              mask_probability=case["mask_probability"])
     return z, case, cfg, sd, sample, mc
@@ -54,7 +54,8 @@ def _sample_list(sample, task):
 
 
 def test_pretraining_builds_for_the_tasks_whose_heads_exist():
-    """UNITERForPretraining (uniter.py:350-618): tasks mlm / itm / mrc build with the reference's parameter tree; mrfr / wra raise."""
+    """UNITERForPretraining (uniter.py:350-618): tasks mlm / itm / mrc build with the reference's parameter tree; so does the reference's
+    DEFAULT task list mlm, itm, mrc, mrfr, wra (round 3), with the MRFR head tied to the image embedding's weight."""
     z, case, cfg, sd, sample, mc = _pretraining_model()
     model = build_model(mc)
     assert type(model.uniter).__name__ == "UNITERForPretraining"
@@ -64,9 +65,63 @@ def test_pretraining_builds_for_the_tasks_whose_heads_exist():
     full = dict(sd)
     full["uniter.heads.mlm.cls.predictions.decoder.bias"] = full["uniter.heads.mlm.cls.predictions.bias"]
     model.load_state_dict(full, strict=True)
-    for bad in ("mrfr", "wra"):
-        with pytest.raises(NotImplementedError, match="not built on the HIP side yet"):
-            build_model(_pretraining_model(tasks=("mlm", bad))[-1])
+    from tests.golden_utils import load_uniter_pretraining_all_case
+    za, _, _, sda, _ = load_uniter_pretraining_all_case()
+    allm = build_model(_pretraining_model(tasks=("mlm", "itm", "mrc", "mrfr", "wra"))[-1])
+    ours = sorted(allm.state_dict().keys())
+    ref = sorted("uniter." + str(k) for k in za["state_dict_keys"])
+    assert ours == ref, (sorted(set(ours) - set(ref))[:4], sorted(set(ref) - set(ours))[:4])
+    assert allm.uniter.heads["mrfr"].linear_proj_weight is allm.uniter.uniter.img_embeddings.img_linear.weight          # uniter.py:397-400
+    full = dict(sda)
+    full["uniter.heads.mlm.cls.predictions.decoder.bias"] = full["uniter.heads.mlm.cls.predictions.bias"]
+    allm.load_state_dict(full, strict=True)
+
+
+@pytest.mark.parametrize("task", ["mrfr", "wra"])
+def test_default_task_list_preparation_and_step_plumbing(task):
+    """`_preprocess_mrfr` / `_preprocess_wra` against the reference's own run (bit for bit, same numpy / random seeds), then one step with
+    the kernel wrappers replaced by extent checkers: the loss key and WHICH parameters receive a gradient."""
+    import random
+    import numpy as np
+    from tests import native_stub
+    from tests.golden_utils import load_uniter_pretraining_all_case
+    z, case, cfg, sd, sample = load_uniter_pretraining_all_case()
+    mc = _pretraining_model(tasks=("mlm", "itm", "mrc", "mrfr", "wra"))[-1]
+    model = build_model(mc)
+    pre = model.uniter
+    sl = _sample_list(sample, task)
+    np.random.seed(case["seed"] + 7)
+    random.seed(case["seed"] + 7)
+    pre._process_sample_list_for_pretraining(sl)
+    getattr(pre, "_preprocess_" + task)(sl)
+    assert torch.equal(sl["input_ids"], torch.from_numpy(z[task + "_pre_input_ids"]))
+    assert torch.equal(sl["image_feat"], torch.from_numpy(z[task + "_pre_image_feat"]))
+    assert torch.equal(sl["image_mask"].long(), torch.from_numpy(z[task + "_pre_image_mask"]))
+    if task == "mrfr":
+        assert torch.equal(sl["mrfr_region_target"], torch.from_numpy(z["mrfr_pre_region_target"]))
+        assert torch.equal(sl["mrfr_region_mask"].long(), torch.from_numpy(z["mrfr_pre_region_mask"]))
+    else:
+        assert torch.equal(sl["wra_info"]["txt_pad"].long(), torch.from_numpy(z["wra_pre_txt_pad"]))
+        assert torch.equal(sl["wra_info"]["img_pad"].long(), torch.from_numpy(z["wra_pre_img_pad"]))
+    model.train()
+    sl = _sample_list(sample, task)
+    np.random.seed(case["seed"] + 7)
+    random.seed(case["seed"] + 7)
+    with native_stub.installed():
+        out = model.uniter(sl)
+        (key, loss), = out["losses"].items()
+        assert key == str(z[task + "_loss_key"])
+        loss.sum().backward()
+    params = dict(model.named_parameters())
+    for gname, norm in zip(z[task + "_grad_names"], z[task + "_grad_norms"]):
+        name = "uniter." + str(gname)
+        if name.endswith("predictions.decoder.bias") or name.endswith("linear_proj_weight"):
+            continue
+        p = params[name]
+        if norm == 0.0:
+            assert p.grad is None, "%s: the reference leaves this parameter without a gradient" % name
+        else:
+            assert p.grad is not None and p.grad.shape == p.shape, name
 
 
 @pytest.mark.parametrize("task", ["mlm", "itm", "mrc"])

@@ -82,3 +82,41 @@ def test_uniter_pretraining_oracle_matches_reference(task):
         full = "grad::%s::%s" % (task, str(gname))
         if full in z.files:
             np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
+
+
+@pytest.mark.parametrize("task", ["mrfr", "wra"])
+def test_uniter_default_task_list_oracle_matches_reference(task):
+    """The wrapper built with the reference's DEFAULT tasks (mlm, itm, mrc, mrfr, wra; uniter.py:36-39): `_preprocess_mrfr` / `_preprocess_wra`,
+    the MRFR head tied to the image embedding's weight and the WRA head (50 IPOT steps), against the reference's own run."""
+    from tests.golden_utils import load_uniter_pretraining_all_case
+    z, case, cfg, sd, sample = load_uniter_pretraining_all_case()
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.endswith("linear_proj_weight")}     # (one tensor, listed twice)
+    region_masks = torch.from_numpy(z["mrfr_pre_image_mask"]) if task == "mrfr" else None
+    out = O.uniter_pretraining_forward(sd, cfg, sample, task, region_masks)
+    pre = out["preprocessed"]
+    assert torch.equal(pre["input_ids"], torch.from_numpy(z[task + "_pre_input_ids"]))
+    assert torch.equal(pre["image_feat"], torch.from_numpy(z[task + "_pre_image_feat"]))
+    if task == "mrfr":
+        assert torch.equal(pre["mrfr_region_target"], torch.from_numpy(z["mrfr_pre_region_target"]))
+        assert torch.equal(pre["mrfr_region_mask"].long(), torch.from_numpy(z["mrfr_pre_region_mask"]))
+    else:
+        assert torch.equal(pre["wra_info"]["txt_pad"].long(), torch.from_numpy(z["wra_pre_txt_pad"]))
+        assert torch.equal(pre["wra_info"]["img_pad"].long(), torch.from_numpy(z["wra_pre_img_pad"]))
+    (key, loss), = out["losses"].items()
+    assert key == str(z[task + "_loss_key"]) and abs(loss.item() - float(z[task + "_loss"])) <= 1e-5 * abs(float(z[task + "_loss"]))
+    loss.backward()
+    checked = 0
+    for gname, norm in zip(z[task + "_grad_names"], z[task + "_grad_norms"]):
+        key = "uniter." + str(gname)
+        if key.endswith("predictions.decoder.bias") or key.endswith("linear_proj_weight"):      # (the tied weight is listed under img_linear)
+            continue
+        g = sd[key].grad
+        if norm == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, key
+            continue
+        if key.endswith("self.key.bias"):
+            continue
+        assert g is not None, key
+        assert abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, (key, float(g.double().norm()), norm)
+        checked += 1
+    assert checked >= 30

@@ -49,3 +49,43 @@ def test_uniter_pretraining_golden_loss_and_gradients(task):
         if e > TOL:
             bad[name] = e
     assert not bad, bad
+
+
+@pytest.mark.parametrize("task", ["mrfr", "wra"])
+def test_uniter_default_task_list_golden_loss_and_gradients(task):
+    """Round 3: the wrapper built with the reference's DEFAULT tasks (mlm, itm, mrc, mrfr, wra; uniter.py:36-39) — MRFR (tied regression GEMM
+    + MSE kernels) and WRA (cosine cost, 50 IPOT steps per sample in LDS, backward through the normalisations) against the reference's own
+    run (tests/golden/make_uniter_pretraining.py --all-tasks)."""
+    from tests.golden_utils import load_uniter_pretraining_all_case
+    from tests.test_uniter_boundary_cpu import _pretraining_model
+    z, case, cfg, sd, sample = load_uniter_pretraining_all_case()
+    mc = _pretraining_model(tasks=("mlm", "itm", "mrc", "mrfr", "wra"))[-1]
+    model = build_model(mc)
+    full = dict(sd)
+    full["uniter.heads.mlm.cls.predictions.decoder.bias"] = full["uniter.heads.mlm.cls.predictions.bias"]
+    model.load_state_dict(full, strict=True)
+    model = model.cuda().eval()
+    sl = _sample_list(sample_to(sample, "cuda"), task)
+    np.random.seed(case["seed"] + 7)
+    random.seed(case["seed"] + 7)
+    out = model.uniter(sl)
+    (key, loss), = out["losses"].items()
+    assert key == str(z[task + "_loss_key"])
+    assert abs(loss.item() - float(z[task + "_loss"])) <= TOL * abs(float(z[task + "_loss"])), (loss.item(), float(z[task + "_loss"]))
+    loss.sum().backward()
+    params = dict(model.named_parameters())
+    bad, checked = {}, 0
+    for gname, norm in zip(z[task + "_grad_names"], z[task + "_grad_norms"]):
+        name = "uniter." + str(gname)
+        if name.endswith("predictions.decoder.bias") or name.endswith("self.key.bias") or name.endswith("linear_proj_weight"):
+            continue
+        p = params[name]
+        if norm == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        e = abs(float(p.grad.double().norm()) - norm) / norm
+        checked += 1
+        if e > TOL:
+            bad[name] = e
+    assert not bad and checked >= 30, (bad, checked)

@@ -1203,8 +1203,8 @@ class MaskedRegionHeadFn(torch.autograd.Function):
 
 
 class TiedRegressionMSEFn(torch.autograd.Function):
-    """MRFR's last two lines (mmf/models/transformers/heads/mrfr.py:85-90): prediction = F.linear(h, W.t(), b) with the TIED image-embedding
-    weight W [hidden, img_dim] (UNITERImageEmbeddings.img_linear.weight applied transposed), loss = F.mse_loss(prediction, targets).
+    """MRFR's last two lines (mmf/models/transformers/heads/mrfr.py:85-90): prediction = h W + b with the TIED image-embedding
+    weight W [hidden, img_dim] (UNITERImageEmbeddings.img_linear.weight applied transposed), loss = mean squared error against the targets.
     The projection is the GEMM's NN form (W read k-major: no transposed copy) with fp32 output; the loss kernel's backward writes the
     bf16 operand of the input-gradient (NT against W) and weight-gradient (TN: dW = h^T d) GEMMs; the bias gradient is its column sum."""
 

@@ -1,8 +1,8 @@
 """`MRFR` transformer head — masked region feature regression of UNITER (mmf/models/transformers/heads/mrfr.py:15-93) on the HIP kernels:
 the masked regions are compacted (`compute_masked_hidden`, heads/utils.py:169-179 -> `functional.TakeRowsFn`), run through
 Linear -> GELU -> LayerNorm (GEMM epilogue + LayerNorm kernel), projected back to feature space with the TIED image-embedding weight
-applied transposed (`F.linear(h, W.t(), b)`, :86-88 — the GEMM reads W k-major, no transposed copy) and regressed onto the original
-features with `F.mse_loss` (:90; loss kernel fused with the projection's backward operands: `functional.TiedRegressionMSEFn`).
+applied transposed (`linear(h, W.t(), b)`, :86-88 — the GEMM reads W k-major, no transposed copy) and regressed onto the original
+features with the mean squared error (:90; loss kernel fused with the projection's backward operands: `functional.TiedRegressionMSEFn`).
 Parameter names as the reference's: `linear_proj_weight` (the very Parameter object of the image embedding), `linear_proj_bias`,
 `feat_regress.{0,2}`."""
 import torch

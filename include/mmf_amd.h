@@ -37,6 +37,7 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_ATTN_BWD_TWO_PASS = 4,   /* 1: head_dim-64 attention backward as the separate dQ and dK/dV kernels (A/B measurements) */
        MMF_TUN_GEMM_WIDE_KS = 5,   /* wide-tile wave layout: 2 the two ping-pong groups split every K-step (fewer LDS fragment reads), 1 never, 0 where it measured faster (256x96, K >= 1536) */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
+       MMF_TUN_ATTN_FWD_OLD = 7,   /* 1: head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head (the round-2 form; A/B) */
        MMF_TUN_COUNT = 8 };
 int mmf_amd_set_tunable(int which, int value);
 int mmf_amd_get_tunable(int which);

@@ -127,6 +127,8 @@ def lib():
         L.mmf_amd_set_tunable(6, int(os.environ["MMF_AMD_EPI_NT"]))
     if os.environ.get("MMF_AMD_GEMM_WIDE_KS"):
         L.mmf_amd_set_tunable(5, int(os.environ["MMF_AMD_GEMM_WIDE_KS"]))
+    if os.environ.get("MMF_AMD_ATTN_FWD_OLD"):
+        L.mmf_amd_set_tunable(7, int(os.environ["MMF_AMD_ATTN_FWD_OLD"]))
     if os.environ.get("MMF_AMD_LN_OLD"):
         L.mmf_amd_set_tunable(3, int(os.environ["MMF_AMD_LN_OLD"]))
     if os.environ.get("MMF_AMD_ATTN_BWD_TWO_PASS"):

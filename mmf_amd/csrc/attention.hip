@@ -334,6 +334,117 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     PROBE_FLUSH(0, bh, 4 * blockIdx.y + wave);
 }
 
+// One-round forward for head_dim 64 and more than 128 queries (VisualBERT VQA2: S = 228): ONE 512-thread workgroup per (batch, head),
+// wave w owns query rows [32 w, 32 w + 32), K / V staged ONCE per head (the 128-query form stages them once per query half) and the
+// scores are computed TWICE instead of being held in 128 registers: pass 1 finds the row maxima, pass 2 recomputes each score tile,
+// exponentiates, accumulates the row sums, applies dropout and feeds P V.  That keeps the kernel under 128 VGPRs, so two workgroups fit
+// on a CU: B * heads = 384 workgroups are ONE round of the 512 slots instead of 768 workgroups on 512 slots (1.5 rounds, the second
+// half-empty; profiles/r02_attention_timeline.txt), with four waves per SIMD to overlap one wave's softmax VALU with another's MFMAs.
+// Same arithmetic in the same order as attn_fwd_kernel (scores, maxima, exponentials, row sums, P V accumulation): bit-identical outputs.
+template <int NKT, bool CZ>
+__global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
+    constexpr int D = 64, HD = 64, NS = 4, NDT = 2, ROWB = 128, SKP = NKT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_k = smem;
+    unsigned char* lds_v = smem + SKP * ROWB;
+    float* lds_mask = reinterpret_cast<float*>(lds_v + SKP * ROWB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
+    const int q0 = wave * 32;
+
+    const bf16* kbase = a.k + (size_t)b * a.kv_bs * a.ldk + head * HD;
+    const bf16* vbase = a.v + (size_t)b * a.kv_bs * a.ldv + head * HD;
+    stage_rows<D, 8>(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
+    stage_rows<D, 8>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
+    for (int i = tid; i < SKP; i += 512)
+        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.m_bs + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    const int qrow = min(q0 + x, a.Sq - 1);
+    const bf16* qptr = a.q + ((size_t)b * a.q_bs + qrow) * a.ldq + head * HD;
+    bf16x8 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = frag_global(qptr, s, lane);
+    stage_wait();
+    const bool active = q0 < a.Sq;          // (idle waves run along to the barrier ahead of the epilogue)
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = a.scale * LOG2E;
+    f32x16 o[NDT] = {};
+    float inv = 0.f;
+    if (active) {
+        // pass 1: row maxima of the masked, scaled scores (log2 domain)
+        float mx = -INFINITY;
+#pragma unroll 2
+        for (int t = 0; t < NKT; ++t) {
+            f32x16 acc = {};
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_k, 32 * t, s, lane), qf[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+                float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+                if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[4 * c + i] * sc2 + mkv[i]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // pass 2: recompute, exponentiate, sum, dropout, P V
+        float sum = 0.f;
+        const uint32_t dkey = drop_key(a.drop);
+        const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
+#pragma unroll 2
+        for (int t = 0; t < NKT; ++t) {
+            f32x16 acc = {};
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_k, 32 * t, s, lane), qf[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+                float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+                if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __builtin_amdgcn_exp2f((acc[4 * c + i] * sc2 + mkv[i]) - mx);
+                    acc[4 * c + i] = p;
+                    sum += p;
+                }
+            }
+            if (a.drop.thr16) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 ds = drop_scale4(dkey, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[4 * c + i] *= ds[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 pf = frag_regs(acc, u);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(lds_v, 32 * dt, 32 * t, u, lane), pf, o[dt], 0, 0, 0);
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        inv = 1.f / sum;
+        if (h == 0 && q0 + x < a.Sq) a.lse[((size_t)bh) * a.Sq + q0 + x] = (mx + log2f(sum)) * 0.6931471805599453f;
+    }
+    // whole 128-byte (bf16) / 256-byte (fp32) rows to global memory through a wave-private 8 KB LDS image laid over the K / V images
+    // (both staged through the same image, one after the other) once every wave of the workgroup is done with them
+    __syncthreads();
+    if (active) {
+        unsigned char* mine = smem + wave * 8192;
+        store_tile_rows(o, inv, mine, a.ctx + ((size_t)b * a.Sq + q0) * a.ldo + head * HD, a.ldo, a.Sq - q0, lane);
+        if (a.ctx32) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the bf16 image has been read back before it is overwritten)
+            store_tile_rows_f32(o, inv, mine, a.ctx32 + ((size_t)b * a.Sq + q0) * a.ldo + head * HD, a.ldo, a.Sq - q0, lane);
+        }
+    }
+}
+
 // =================================================================================================
 // backward
 //   P = softmax row (recomputed from the saved log-sum-exp), Pd = dropout(P)
@@ -832,6 +943,21 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         hipLaunchKernelGGL((attn_fwd_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);            \
     }
     const bool cz = a.cfrom < a.Sk;
+    // head_dim 64 with more than 128 queries: the one-round form (one 8-wave workgroup per (batch, head), two per CU; attn_fwd8_kernel).
+    // MMF_TUN_ATTN_FWD_OLD = 1 keeps the two-workgroups-per-head form (A/B measurements, bit-equality test).
+    if (a.hd == 64 && nkt > 4 && a.Sq > 128 && !mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD)) {
+        const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
+        const dim3 grid8(a.B * a.heads);
+        if (cz) {
+            if (int rc = set_lds(attn_fwd8_kernel<8, true>, lds)) return rc;
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, true>), grid8, dim3(512), lds, s, a);
+        } else {
+            if (int rc = set_lds(attn_fwd8_kernel<8, false>, lds)) return rc;
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, false>), grid8, dim3(512), lds, s, a);
+        }
+        MMF_CHECK_LAUNCH();
+        return 0;
+    }
     if (a.hd == 128) LAUNCH_FWD(4, 128, false)
     else if (nkt <= 4) { if (cz) LAUNCH_FWD(4, 64, true) else LAUNCH_FWD(4, 64, false) }
     else { if (cz) LAUNCH_FWD(8, 64, true) else LAUNCH_FWD(8, 64, false) }

@@ -92,13 +92,20 @@ DEVI float wave_max(float v) {
 // keeps iff its 16-bit half >= thr16 (thr16 = round(p * 65536)).  The same (key, linear index)
 // reproduces the same decision in backward, whatever the thread mapping.
 // ---------------------------------------------------------------------------------------------
-DEVI uint32_t mix32(uint32_t x) {  // "lowbias32" integer finalizer
-    x ^= x >> 16; x *= 0x7feb352du;
-    x ^= x >> 15; x *= 0x846ca68bu;
+// Mixer built from FULL-RATE integer ops only (v_alignbit_b32, v_mad_u32_u24, shifts, xors): 12 instructions, ~24 cycles per wave64
+// hash, against ~38 for a "lowbias32"-style finalizer whose three 32-bit multiplies (v_mul_lo_u32) issue at quarter rate — the dropout
+// hash is the largest single VALU item of the attention kernels (profiles/r02_attention_timeline.txt).  Avalanche on random inputs:
+// every input bit flips every output bit with probability 0.5 +- 0.013 (20000 samples; the 32-bit-multiply mixer measures +- 0.011);
+// keep rates and neighbour / row / key correlations of the 16-bit halves on sequential indices are at sampling noise (tools/hash_quality.py).
+DEVI uint32_t mix24(uint32_t x) {
     x ^= x >> 16;
+    x = __umul24(x, 0xB5297Bu) + __builtin_rotateleft32(x, 9);
+    x ^= x >> 13;
+    x = __umul24(x, 0x68E31Fu) + __builtin_rotateleft32(x, 11);
+    x ^= x >> 15;
     return x;
 }
-DEVI uint32_t drop_hash(uint32_t key, uint32_t pair_idx) { return mix32(pair_idx * 0x9E3779B1u + key); }
+DEVI uint32_t drop_hash(uint32_t key, uint32_t pair_idx) { return mix24(pair_idx + key); }
 // keep-scale factors (0 or scale) for the 4 consecutive elements starting at linear index idx4
 // (idx4 % 4 == 0).
 DEVI f32x4 drop_scale4(uint32_t key, uint32_t idx4, uint32_t thr16, float scale) {
@@ -125,4 +132,5 @@ struct DropoutCfg {
                            // fresh masks on every replay (mmf_seed_advance bumps it inside the graph)
 };
 // effective key of a site for this launch (wave-uniform)
+// (the step seed enters through its own odd multiplier: consecutive replays land far apart in the index stream, not one pair apart)
 DEVI uint32_t drop_key(const DropoutCfg& d) { return d.seed ? d.key + d.seed[0] * 0x9E3779B1u : d.key; }

@@ -330,6 +330,35 @@ def test_attention_forward_backward(B, heads, S):
         close(g, ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name)
 
 
+@pytest.mark.parametrize("B,heads,S,tail,p", [(32, 12, 228, 0, 0.1), (3, 4, 200, 0, 0.0), (2, 2, 256, 0, 0.1), (2, 3, 182, 12, 0.1), (1, 1, 129, 0, 0.0)])
+def test_attention_one_round_forward_is_bit_identical_to_the_two_workgroup_form(B, heads, S, tail, p):
+    """Round 3: head_dim 64 with more than 128 queries runs as ONE 8-wave workgroup per (batch, head) that computes the scores twice
+    (row maxima, then exponentials) instead of holding them in 128 registers — two workgroups per CU, one round.  Same arithmetic in
+    the same order as the two-workgroups-per-head kernel (MMF_TUN_ATTN_FWD_OLD = 1): context (bf16 and fp32 copy) and log-sum-exp
+    bit for bit, with ragged masks, dropout and the prefix-LM tail."""
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, seed=21)
+    mask = torch.zeros(B, S, device=DEV)
+    for b in range(B):
+        mask[b, S - 1 - 7 * (b % 5):] = -10000.0
+    drop = nat().drop_cfg(p, 777) if p > 0 else nat().NO_DROP
+    outs = {}
+    for old in (1, 0):
+        nat().set_tunable(7, old)
+        try:
+            ctx = torch.full((B * S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+            c32 = torch.full((B * S, H), float("nan"), dtype=torch.float32, device=DEV)
+            lse = torch.full((B, heads, S), float("nan"), device=DEV)
+            nat().attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, 0.125, drop, ctx_f32=c32,
+                                causal_tail=tail)
+            outs[old] = (ctx, c32, lse)
+        finally:
+            nat().set_tunable(7, 0)
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b_)
+
+
 def test_attention_exact_delta_reduces_common_mode_leak():
     """A common component in K (e.g. the key bias) must not reach dQ: sum_key dS = 0.  With delta formed from the bf16 O the
     rows of dS sum to ~2^-9 |dO||O| and that times mean(K) lands in dQ; the fp32 copy of O removes that term (what is

@@ -439,6 +439,32 @@ def main():
             dt_ = float(t.item())
         return dt_, float(last.item())
 
+    # The eager step — the loop MMF's own trainer drives: model(batch); loss.backward(); optimizer.step() (training_loop.py:199-231) — through
+    # the native operator library: host time to ENQUEUE a step against the time the GPU needs.  Measured FIRST, in a process that has not
+    # captured a hipGraph yet: after a capture + replay the same loop measures ~1.4 ms slower (host 4.3 -> 6.8 ms; tools/eager_profile.py
+    # --after-graph), an artefact of sharing the process with the graphs' private memory pools, not a property of the eager path.
+    eager_first = None
+    if world == 1 and use_graph and os.environ.get("MMF_AMD_BENCH_NO_EAGER") != "1":
+        eopt = make_optimizer(capturable=False) if not args.no_optimizer else None
+        side = torch.cuda.Stream(device=device)          # (not the legacy default stream: see utils/graph.py::release_autograd_state)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step(eopt)
+            torch.cuda.synchronize()
+            n_e = 10
+            t0 = time.perf_counter()
+            for _ in range(n_e):
+                eager_step(eopt)
+            t_host = (time.perf_counter() - t0) / n_e
+            torch.cuda.synchronize()
+            t_all = (time.perf_counter() - t0) / n_e
+        torch.cuda.current_stream(device).wait_stream(side)
+        eager_first = {"ms_per_step": round(t_all * 1e3, 3), "host_enqueue_ms_per_step": round(t_host * 1e3, 3),
+                       "note": "eager launch path (no hipGraph) through the native operator library: what MMF's own training loop drives; "
+                               "host-bound only when enqueue > GPU step"}
+        del eopt
+        model.zero_grad(set_to_none=True)
     launch = "eager"
     event_median = None
     if use_graph:
@@ -489,20 +515,7 @@ def main():
     eager_info = None
     scale_info = None
     if world == 1:
-        eopt = make_optimizer(capturable=False) if not args.no_optimizer else None
-        for _ in range(2):
-            eager_step(eopt)
-        torch.cuda.synchronize()
-        n_e = 5
-        t0 = time.perf_counter()
-        for _ in range(n_e):
-            eager_step(eopt)
-        t_host = (time.perf_counter() - t0) / n_e
-        torch.cuda.synchronize()
-        t_all = (time.perf_counter() - t0) / n_e
-        eager_info = {"ms_per_step": round(t_all * 1e3, 3), "host_enqueue_ms_per_step": round(t_host * 1e3, 3),
-                      "note": "eager launch path (no hipGraph): the fallback of the N > 1 step; host-bound when enqueue > GPU step"}
-        del eopt
+        eager_info = eager_first if eager_first is not None else {}
         if not args.no_optimizer and not args.no_graph:
             # the launch structure N > 1 runs (chain of hipGraphs, collectives between the stages), here without the collectives
             copt = make_optimizer(capturable=True)
@@ -569,7 +582,7 @@ def main():
             line["fwd_bwd_only"] = fwd_bwd_only
         if h2d is not None:
             line["h2d_inclusive"] = h2d
-        if eager_info is not None:
+        if eager_info:
             line["eager"] = eager_info
         if scale_info is not None:
             line["scale_model"] = scale_info

@@ -733,16 +733,22 @@ class _ParamUpdateHook:
 
     def __init__(self):
         self.fn = None
+        self.beside = None
 
     @contextlib.contextmanager
-    def __call__(self, fn):
+    def __call__(self, fn, beside=None):
+        """`beside` (optional): a context-manager factory the layer's backward wraps around its attention-backward launch — the optimizer
+        uses it to run the update of the layer ABOVE (whose gradients are complete) on a second stream exactly beside that kernel
+        (`AdamW.beside_attention`): the one kernel of a layer's backward that leaves HBM and half the CUs idle (one 8-wave workgroup per
+        (batch, head) = 384 workgroups on 256 CUs, two rounds) and keeps no operand panels in L2 for the update stream to evict."""
         old, self.fn = self.fn, fn
+        old_b, self.beside = self.beside, beside
         if fn is not None:
             _ops_native.push_mode(1)      # the hook lives in the Python autograd node: route the layer operator there
         try:
             yield
         finally:
-            self.fn = old
+            self.fn, self.beside = old, old_b
             if fn is not None:
                 _ops_native.pop_mode(1)
 
@@ -798,8 +804,9 @@ class TransformerLayerFn(torch.autograd.Function):
         dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, S, dtype=F32, device=dev)
         scale = 1.0 / math.sqrt(H // heads)
-        nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
-                          dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
+        with (param_update.beside() if param_update.beside is not None else contextlib.nullcontext()):
+            nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
+                              dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
         dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1) if ctx.needs_input_grad[0] else None
         # the four weight gradients, one launch
         p_1, dw1, db1 = _wgrad_problem(du, I, a_out, M, I, H, True)

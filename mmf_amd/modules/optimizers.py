@@ -41,6 +41,8 @@ class AdamW(torch.optim.Optimizer):
         self.external_grads = None  # id(parameter) -> tensor to read its gradient from instead of `.grad` (fp32 or bf16, contiguous, same
                                     # element count): the data-parallel step points this at its wire buffers, so the summed bf16
                                     # gradients are consumed where the all-reduce left them (no unpack / convert pass)
+        self._pending = None        # (params, grads) of a layer whose update waits for the next attention backward (beside_attention)
+        self.pin_to_attention = False
         self._early = None          # ids of the parameters already updated inside this step's backward (update_in_backward)
         self._early_stream = None
         self._group_of = None
@@ -94,8 +96,41 @@ class AdamW(torch.optim.Optimizer):
         if self._group_of is None:
             self._group_of = {id(p): g for g in self.param_groups for p in g["params"]}
 
+    # Round 3: pinned form.  Free-running beside the backward (above) the update loses: its 213 MB per layer evict the GEMMs' operand
+    # panels from L2.  With `pin_to_attention` the update of layer L is held back until the ATTENTION backward of layer L - 1 is
+    # launched and runs only beside that kernel (fork before it, join after it): attention backward is one 8-wave workgroup per
+    # (batch, head) — 384 workgroups in two rounds on 256 CUs, the second half-empty — latency-bound, with HBM idle outside its
+    # staging burst and nothing in L2 worth keeping.  Layer 0's update (nothing below it) joins the end-of-step update.
     @torch.no_grad()
     def update_in_backward(self, params, grads):
+        if self._early is None:
+            return
+        if self.pin_to_attention:
+            if self._pending is not None:          # (no attention backward came in between: do not lose the previous layer's update)
+                self._launch_update(*self._pending)
+            self._pending = (params, grads)
+            return
+        self._launch_update(params, grads)
+
+    def beside_attention(self):
+        """Context manager for `functional.param_update(..., beside=...)`: wraps ONE kernel launch on the current stream."""
+        opt = self
+
+        class _Beside:
+            def __enter__(self_):
+                self_.ran = False
+                if opt._early is not None and opt._pending is not None:
+                    pend, opt._pending = opt._pending, None
+                    opt._launch_update(*pend)           # fork: side stream waits for everything enqueued so far on the main stream
+                    self_.ran = True
+
+            def __exit__(self_, *exc):
+                if self_.ran:
+                    torch.cuda.current_stream().wait_stream(opt._early_stream)      # join behind the wrapped kernel
+        return _Beside()
+
+    @torch.no_grad()
+    def _launch_update(self, params, grads):
         if self._early is None:
             return
         main, side = torch.cuda.current_stream(), self._early_stream
@@ -143,6 +178,9 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._pending is not None and self._early is not None:      # the lowest layer's update: nothing left to hide it behind
+            pend, self._pending = self._pending, None
+            self._launch_update(*pend)
         early, self._early = self._early, None
         early_params = None if early is None else [p for g in self.param_groups for p in g["params"] if id(p) in early]
         dev_state = None

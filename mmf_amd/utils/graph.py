@@ -79,7 +79,9 @@ class GraphedTrainStep:
         if overlap_wgrad is None:
             overlap_wgrad = os.environ.get("MMF_AMD_WGRAD_OVERLAP", "0") == "1"
         if overlap_update is None:
-            overlap_update = os.environ.get("MMF_AMD_ADAM_OVERLAP", "0") == "1"
+            overlap_update = os.environ.get("MMF_AMD_ADAM_OVERLAP", "0")
+            overlap_update = {"0": False, "1": True, "2": "attention"}.get(overlap_update, False)
+        self.pin_update = overlap_update == "attention"       # each layer's update runs only beside the attention backward of the layer below
         self.side_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
         self.update_stream = (torch.cuda.Stream(device=next(model.parameters()).device)
                               if (overlap_update and optimizer is not None and not overlap_wgrad and hasattr(optimizer, "begin_step")) else None)
@@ -119,8 +121,10 @@ class GraphedTrainStep:
         # every captured node on the capture stream.
         early = self.update_stream is not None and update
         if early:
+            self.optimizer.pin_to_attention = self.pin_update
             self.optimizer.begin_step(self.update_stream)
-        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.param_update(self.optimizer.update_in_backward if early else None):
+        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.param_update(
+                self.optimizer.update_in_backward if early else None, self.optimizer.beside_attention if (early and self.pin_update) else None):
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g

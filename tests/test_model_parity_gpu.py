@@ -280,8 +280,10 @@ def test_nlvr2_head_golden_forward_loss_and_gradients():
     assert not bad, bad
 
 
-def test_optimizer_in_backward_equals_end_of_step_update():
-    """`GraphedTrainStep(overlap_update=True)`: each encoder layer's AdamW update is launched on a second stream as soon as the layer's
+@pytest.mark.parametrize("mode", [True, "attention"])
+def test_optimizer_in_backward_equals_end_of_step_update(mode):
+    """`GraphedTrainStep(overlap_update="attention")` (round 3): the update of layer L runs on a second stream exactly beside the attention
+    backward of layer L - 1 (fork before that kernel, join behind it); `GraphedTrainStep(overlap_update=True)`: each encoder layer's AdamW update is launched on a second stream as soon as the layer's
     weight gradients exist (a parallel branch of the hipGraph beside the backward of the layers below).  Same kernel, same
     arithmetic: after 3 replays every parameter, moment, bf16 shadow and W^T twin equals the end-of-step update's BIT FOR BIT."""
     from mmf_amd import functional as Fn
@@ -290,13 +292,13 @@ def test_optimizer_in_backward_equals_end_of_step_update():
     z, case, cfg, sd, sample = load_case("small64")
     batch = SampleList(sample_to(sample, "cuda"))
     res = []
-    for overlap in (True, False):
+    for overlap in (mode, False):
         m = build_visual_bert(cfg, sd)
         m.eval()
         o = AdamW(m.get_optimizer_parameters(__import__("mmf_amd.utils.configuration", fromlist=["Config"]).Config(
             model="visual_bert", optimizer=dict(params=dict(lr=1e-3)), model_config=dict(visual_bert=m.config))), lr=1e-3, capturable=True)
         g = GraphedTrainStep(m, batch, warmup=1, optimizer=o, overlap_update=overlap)
-        assert (g.update_stream is not None) == overlap
+        assert (g.update_stream is not None) == bool(overlap)
         losses = [float(g()) for _ in range(3)]
         torch.cuda.synchronize()
         att = m.model.bert.encoder.layer[1].attention.self

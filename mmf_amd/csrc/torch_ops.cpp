@@ -21,7 +21,8 @@
 //   mmf_amd::dropout                      nn.Dropout                                   visual_bert.py:400
 //   mmf_amd::pair_halves                  nlvr2 pooled-output pairing                  visual_bert.py:369-374
 //   mmf_amd::logit_bce                    LogitBinaryCrossEntropy                      mmf/modules/losses.py:225-251
-//   mmf_amd::masked_lm_head / masked_region_head : schema here, kernels bound from Python (mmf_amd/ops.py) — pretraining heads
+//   mmf_amd::masked_lm_head               tied decoder + masked-LM CrossEntropyLoss     mmf/models/visual_bert.py:267-277
+//   mmf_amd::masked_region_head           image-prediction decoder + masked KLDivLoss  mmf/models/vilbert.py:846-858, 1150-1157
 //
 // State the operators need lives here, not in Python: the bf16 weight shadows (+ W^T twins) of the fp32 master parameters, the
 // per-site dropout keys (torch's Philox offset in eager mode, a device seed word under hipGraph capture) and the deferred LayerNorm
@@ -753,6 +754,63 @@ struct LogitBCEFn : public torch::autograd::Function<LogitBCEFn> {
     }
 };
 
+// The decoder + loss of the pretraining heads as ONE node each, so that backward never materialises an fp32 [rows, classes] gradient:
+// the loss kernel keeps each row's log-sum-exp and its backward writes the bf16 operand of the decoder's dgrad / wgrad GEMMs directly.
+//   kind 0: masked LM — prediction scores = h W^T + b, nn.CrossEntropyLoss(ignore_index) (mmf/models/visual_bert.py:267-277; HF BertLMPredictionHead)
+//   kind 1: masked region classification — KLDivLoss(log_softmax(scores), target) over the rows with label 1 / their number
+//           (mmf/models/vilbert.py:846-858, 1150-1157, `visual_target: 0`)
+// Returns (loss, scores [*, classes] fp32); the scores are non-differentiable (only the loss carries gradient).
+struct PretrainHeadFn : public torch::autograd::Function<PretrainHeadFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& x, const Tensor& weight, const Tensor& bias, const Tensor& w16, const Tensor& labels,
+                                 const optional<Tensor>& target, int64_t ignore_index, int64_t kind) {
+        Tensor x2 = as_bf16_2d(x);
+        const int64_t M = x2.size(0), K = x2.size(1), N = weight.size(0);
+        TORCH_CHECK(weight.dim() == 2 && weight.size(1) == K, "mmf_amd pretraining head: decoder weight must be [classes, ", K, "]");
+        Tensor logits = empty_f32({M, N}, x2);
+        Gemm(x2, w16, logits, M, N, K, K, K, N).bias(bias.detach()).run();
+        Tensor lab = labels.reshape({M}).contiguous();
+        if (lab.scalar_type() != at::kLong) lab = lab.to(at::kLong);
+        req(lab, at::kLong, "labels");
+        Tensor lse = empty_f32({M}, x2), rowloss = empty_f32({M}, x2), loss = empty_f32({1}, x2), count = empty_f32({1}, x2), tgt, tsum;
+        if (kind == 0) {
+            MMF_RC(mmf_vocab_cross_entropy_fwd(PF(logits), (int)N, lab.data_ptr<int64_t>(), lse.data_ptr<float>(), rowloss.data_ptr<float>(), loss.data_ptr<float>(),
+                                               count.data_ptr<float>(), (int)M, (int)N, (int)ignore_index, sp()), "mmf_vocab_cross_entropy_fwd");
+        } else {
+            TORCH_CHECK(target.has_value() && target->numel() == M * N, "mmf_amd::masked_region_head: target must be [rows, classes]");
+            tgt = target->reshape({M, N}).to(at::kFloat).contiguous();
+            req(tgt, at::kFloat, "target");
+            tsum = empty_f32({M}, x2);
+            MMF_RC(mmf_soft_target_kl_fwd(PF(logits), (int)N, PF(tgt), (int)N, lab.data_ptr<int64_t>(), lse.data_ptr<float>(), tsum.data_ptr<float>(),
+                                          rowloss.data_ptr<float>(), loss.data_ptr<float>(), count.data_ptr<float>(), (int)M, (int)N, sp()), "mmf_soft_target_kl_fwd");
+        }
+        ctx->save_for_backward({x2, w16, logits, lab, lse, count, tgt, tsum});
+        ctx->saved_data["meta"] = std::vector<int64_t>{M, N, K, ignore_index, kind};
+        ctx->saved_data["shape"] = x.sizes().vec();
+        std::vector<int64_t> os(x.sizes().begin(), x.sizes().end() - 1);
+        os.push_back(N);
+        Tensor out = logits.view(os);
+        ctx->mark_non_differentiable({out});
+        return {loss[0], out};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &x2 = sv[0], &w16 = sv[1], &logits = sv[2], &lab = sv[3], &lse = sv[4], &count = sv[5], &tgt = sv[6], &tsum = sv[7];
+        auto m = ctx->saved_data["meta"].toIntVector();
+        const int64_t M = m[0], N = m[1], K = m[2], ignore_index = m[3], kind = m[4];
+        const int ldd = pad8(N);
+        Tensor d = empty_bf16({M, (int64_t)ldd}, x2), g = grads[0].to(at::kFloat).reshape({1}).contiguous();
+        if (kind == 0) {
+            MMF_RC(mmf_vocab_cross_entropy_bwd(PF(logits), (int)N, lab.data_ptr<int64_t>(), PF(lse), PF(count), PF(g), d.data_ptr(), ldd, (int)M, (int)N,
+                                               (int)ignore_index, sp()), "mmf_vocab_cross_entropy_bwd");
+        } else {
+            MMF_RC(mmf_soft_target_kl_bwd(PF(logits), (int)N, PF(tgt), (int)N, lab.data_ptr<int64_t>(), PF(lse), PF(tsum), PF(count), PF(g), d.data_ptr(), ldd, (int)M,
+                                          (int)N, sp()), "mmf_soft_target_kl_bwd");
+        }
+        LinBwd r = linear_bwd(d, ldd, x2, w16, M, N, K, ctx->needs_input_grad(0), Tensor(), Tensor(), true);
+        return {r.dx.defined() ? r.dx.view(ctx->saved_data["shape"].toIntVector()) : Tensor(), r.dw, r.db, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // operators
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -846,6 +904,18 @@ Tensor op_pair_halves(const Tensor& x) {
     return PairHalvesFn::apply(x);
 }
 Tensor op_logit_bce(const Tensor& scores, const Tensor& targets) { return LogitBCEFn::apply(scores, targets); }
+using MlmSig = std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t);
+std::tuple<Tensor, Tensor> op_masked_lm_head(const Tensor& x, const Tensor& weight, const Tensor& bias, const Tensor& labels, int64_t ignore_index) {
+    if (g_py_mode & 1) return call_py<MlmSig>("masked_lm_head", x, weight, bias, labels, ignore_index);
+    auto r = PretrainHeadFn::apply(x, weight, bias, g_shadows.get({weight}, false), labels, optional<Tensor>(), ignore_index, 0);
+    return {r[0], r[1]};
+}
+using MrhSig = std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&);
+std::tuple<Tensor, Tensor> op_masked_region_head(const Tensor& x, const Tensor& weight, const Tensor& bias, const Tensor& target, const Tensor& row_label) {
+    if (g_py_mode & 1) return call_py<MrhSig>("masked_region_head", x, weight, bias, target, row_label);
+    auto r = PretrainHeadFn::apply(x, weight, bias, g_shadows.get({weight}, false), row_label, optional<Tensor>(target), -1, 1);
+    return {r[0], r[1]};
+}
 
 // ---- service operators: the Python package drives the state above through these -------------------------------------------------
 Tensor svc_shadow_get(at::TensorList params, bool as_f32) { return g_shadows.get(params.vec(), as_f32); }
@@ -884,9 +954,10 @@ TORCH_LIBRARY(mmf_amd, m) {
     m.def("dropout(Tensor x, float p, bool training) -> Tensor");
     m.def("pair_halves(Tensor x) -> Tensor");
     m.def("logit_bce(Tensor scores, Tensor targets) -> Tensor");
-    // pretraining heads: schemas only — their kernels are bound by the Python package (mmf_amd/ops.py)
     m.def("masked_lm_head(Tensor x, Tensor weight, Tensor bias, Tensor labels, int ignore_index) -> (Tensor, Tensor)");
     m.def("masked_region_head(Tensor x, Tensor weight, Tensor bias, Tensor target, Tensor row_label) -> (Tensor, Tensor)");
+    m.def("_py_masked_lm_head(Tensor x, Tensor weight, Tensor bias, Tensor labels, int ignore_index) -> (Tensor, Tensor)");
+    m.def("_py_masked_region_head(Tensor x, Tensor weight, Tensor bias, Tensor target, Tensor row_label) -> (Tensor, Tensor)");
     // Python-implemented twins (fp32-accurate forward path, opt-in experiment hooks)
     m.def("_py_visio_linguistic_embeddings(Tensor input_ids, Tensor token_type_ids, Tensor? visual_embeddings, Tensor? visual_embeddings_type, "
           "Tensor word, Tensor pos, Tensor typ, Tensor ln_w, Tensor ln_b, Tensor typ_vis, Tensor pos_vis, Tensor proj_w, Tensor proj_b, "
@@ -927,6 +998,8 @@ TORCH_LIBRARY_IMPL(mmf_amd, CompositeImplicitAutograd, m) {
     m.impl("dropout", op_dropout);
     m.impl("pair_halves", op_pair_halves);
     m.impl("logit_bce", op_logit_bce);
+    m.impl("masked_lm_head", op_masked_lm_head);
+    m.impl("masked_region_head", op_masked_region_head);
     m.impl("_shadow_get", svc_shadow_get);
     m.impl("_shadow_slot", svc_shadow_slot);
     m.impl("_shadow_transposed", svc_shadow_transposed);

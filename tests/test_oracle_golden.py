@@ -142,3 +142,36 @@ def test_oracle_bypass_transformer_matches_reference():
         full = "grad::model." + key
         if full in z.files:
             np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
+
+
+def test_reference_classifier_head_known_answer_vector():
+    """the reference's ONE value-pinning test on this path, tests/modules/test_layers.py:96-114 — `ClassifierLayer("bert", 768, 1)`
+    (= nn.Dropout + HF BertPredictionHeadTransform + nn.Linear, the head shape of mmf/models/visual_bert.py:327-330) under
+    `torch.manual_seed(1234)` on `torch.rand(3, 768)`, in TRAIN mode, expected [0.5452202, -0.0437842, -0.377468] to 3 decimals.
+    That vector is a property of the environment it was recorded in (torch's CPU dropout stream and HF's construction order under the pinned
+    transformers <= 4.10): rebuilt here with the same classes (torch 2.10, transformers 5.15) the same recipe gives [0.7408, 0.4107, -0.2536],
+    so the published numbers cannot be asserted.  What the recipe still pins: the head's structure (3 children, 6 parameters, as the reference
+    asserts) and — on the weights and the dropped input this construction produces — the oracle's restatement of the head, value for value."""
+    from torch import nn
+    from transformers import BertConfig
+    from transformers.models.bert.modeling_bert import BertPredictionHeadTransform
+    torch.manual_seed(1234)
+    cfg = BertConfig(hidden_size=768, hidden_act="gelu", layer_norm_eps=1e-12, hidden_dropout_prob=0.1)
+    clf = nn.Sequential(nn.Dropout(0.1), BertPredictionHeadTransform(cfg), nn.Linear(768, 1))
+    assert len(list(clf.children())) == 3 and len(list(clf.parameters())) == 6
+    inp = torch.rand(3, 768)
+    dropped = clf[0](inp)                          # train mode, as in the reference test
+    out = clf[2](clf[1](dropped))
+    assert out.size() == torch.Size((3, 1))
+    published = np.array([0.5452202, -0.0437842, -0.377468])
+    reproduces = bool(np.abs(out.detach().squeeze().numpy() - published).max() < 5e-4)
+    # the oracle's head on the same weights / dropped input (visual_bert.py:327-330 = dense -> GELU -> LayerNorm -> Linear)
+    sd = {"classifier.0.dense.weight": clf[1].dense.weight, "classifier.0.dense.bias": clf[1].dense.bias,
+          "classifier.0.LayerNorm.weight": clf[1].LayerNorm.weight, "classifier.0.LayerNorm.bias": clf[1].LayerNorm.bias,
+          "classifier.1.weight": clf[2].weight, "classifier.1.bias": clf[2].bias}
+    x = torch.nn.functional.gelu(torch.nn.functional.linear(dropped, sd["classifier.0.dense.weight"], sd["classifier.0.dense.bias"]))
+    x = O.layer_norm(x, sd["classifier.0.LayerNorm.weight"], sd["classifier.0.LayerNorm.bias"], 1e-12)
+    ours = torch.nn.functional.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])
+    np.testing.assert_allclose(ours.detach().numpy(), out.detach().numpy(), rtol=1e-6, atol=1e-6)
+    if reproduces:       # an environment in which the published vector holds: then it is asserted for the oracle as well
+        np.testing.assert_almost_equal(ours.detach().squeeze().tolist(), published.tolist(), decimal=3)

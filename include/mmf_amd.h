@@ -369,10 +369,15 @@ int mmf_bce_rowmask_bwd(const float* scores, const float* targets, const float* 
  * MRFR, mmf/models/transformers/heads/mrfr.py:85-90: F.mse_loss(prediction_feat, feat_targets, reduction="mean") on the fp32 output
  * of the tied projection GEMM.  fwd writes loss[0] (deterministic two-stage sum through ws, mmf_mse_ws_floats() floats); bwd writes
  * gloss * 2 (pred - target) / (rows * cols) as bf16 [rows, ldd] (ldd % 8 == 0, pad columns zero): the operand of the projection's
- * input- and weight-gradient GEMMs. */
+ * input- and weight-gradient GEMMs.
+ * Masked form (row_label != NULL, int64 [rows]) — ViLBERT's masked region REGRESSION, `visual_target: 1`, mmf/models/vilbert.py:1139-1148:
+ * nn.MSELoss(reduction="none") summed over the rows with label == 1 and divided by max(number of their elements, 1); `count` receives that
+ * denominator (it must be given) and the backward reads it: rows without the label get a zero gradient. */
 int mmf_mse_ws_floats(void);
-int mmf_mse_fwd(const float* pred, int ldp, const float* target, int ldt, float* loss, float* ws, int rows, int cols, void* stream);
-int mmf_mse_bwd(const float* pred, int ldp, const float* target, int ldt, const float* gloss, void* dpred, int ldd, int rows, int cols, void* stream);
+int mmf_mse_fwd(const float* pred, int ldp, const float* target, int ldt, const int64_t* row_label, float* loss, float* count, float* ws, int rows, int cols,
+                void* stream);
+int mmf_mse_bwd(const float* pred, int ldp, const float* target, int ldt, const int64_t* row_label, const float* count, const float* gloss, void* dpred, int ldd,
+                int rows, int cols, void* stream);
 /* WRA, mmf/models/transformers/heads/wra.py:36-83 over mmf/modules/ot.py: per sample b the optimal-transport distance between the text
  * rows [0, M) and the region rows [M, M + N) of the joint sequence seq [B, S, H] (bf16, row stride ld, S >= M + N) under the cosine cost
  * (ot.py:15-25, F.normalize eps), the transport plan by `iterations` IPOT steps (ot.py:38-84, beta, k = 1; a constant of the

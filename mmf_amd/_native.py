@@ -645,19 +645,23 @@ def gather_rows_f32(x, index, out, B, S, H):
 # --------------------------------------------------------------------------------------------
 # UNITER pretraining heads (mmf_amd/csrc/uniter_ops.hip)
 # --------------------------------------------------------------------------------------------
-def mse_fwd(pred, target, loss, rows, cols):
-    """loss[0] = mean((pred - target)^2); pred / target fp32 [rows, cols] (row strides from the tensors)."""
-    for t, n in ((pred, "pred"), (target, "target"), (loss, "loss")):
+def mse_fwd(pred, target, loss, rows, cols, row_label=None, count=None):
+    """loss[0] = mean((pred - target)^2); pred / target fp32 [rows, cols] (row strides from the tensors).  With `row_label` (int64 [rows]):
+    the sum over the rows with label 1 divided by max(their element count, 1), which is written to `count`."""
+    for t, n in ((pred, "pred"), (target, "target"), (loss, "loss"), (count, "count")):
         _req(t, torch.float32, n)
+    _req(row_label, torch.int64, "row_label")
     ws = torch.empty(lib().mmf_mse_ws_floats(), dtype=torch.float32, device=pred.device)
-    _check(lib().mmf_mse_fwd(_p(pred), pred.stride(0), _p(target), target.stride(0), _p(loss), _p(ws), rows, cols, _stream()), "mmf_mse_fwd")
+    _check(lib().mmf_mse_fwd(_p(pred), pred.stride(0), _p(target), target.stride(0), _p(row_label), _p(loss), _p(count), _p(ws), rows, cols, _stream()),
+           "mmf_mse_fwd")
 
 
-def mse_bwd(pred, target, gloss, dpred, ldd, rows, cols):
-    for t, n in ((pred, "pred"), (target, "target"), (gloss, "gloss")):
+def mse_bwd(pred, target, gloss, dpred, ldd, rows, cols, row_label=None, count=None):
+    for t, n in ((pred, "pred"), (target, "target"), (gloss, "gloss"), (count, "count")):
         _req(t, torch.float32, n)
-    _req(dpred, torch.bfloat16, "dpred")
-    _check(lib().mmf_mse_bwd(_p(pred), pred.stride(0), _p(target), target.stride(0), _p(gloss), _p(dpred), ldd, rows, cols, _stream()), "mmf_mse_bwd")
+    _req(dpred, torch.bfloat16, "dpred"); _req(row_label, torch.int64, "row_label")
+    _check(lib().mmf_mse_bwd(_p(pred), pred.stride(0), _p(target), target.stride(0), _p(row_label), _p(count), _p(gloss), _p(dpred), ldd, rows, cols,
+                             _stream()), "mmf_mse_bwd")
 
 
 def _wra_desc(seq, ld, B, S, H, M, N, txt_pad, img_pad, label, xinv, yinv, plan, cost, dist):

@@ -19,37 +19,46 @@ namespace {
 // F.mse_loss(pred, target, reduction="mean")
 // ------------------------------------------------------------------------------------------------
 constexpr int MSE_BLOCKS = 256;
+// `row_label` (optional): only rows with label == 1 count (ViLBERT's masked region regression, vilbert.py:1139-1148: the sum over the
+// masked regions divided by max(number of their elements, 1)); ws[MSE_BLOCKS + b] then carries block b's count of selected rows.
 __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target, int ldt,
-                                                           float* __restrict__ ws, int rows, int cols) {
-    __shared__ float red[4];
+                                                           const int64_t* __restrict__ row_label, float* __restrict__ ws, int rows, int cols) {
+    __shared__ float red[8];
     const int64_t n = (int64_t)rows * cols;
-    float s = 0.f;
+    float s = 0.f, cnt = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)MSE_BLOCKS * 256) {
         const int64_t r = i / cols;
         const int c = (int)(i - r * cols);
+        if (row_label && row_label[r] != 1) continue;
         const float d = pred[r * ldp + c] - target[r * ldt + c];
         s += d * d;
+        cnt += 1.f;
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    s = wave_sum(s); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = cnt; }
     __syncthreads();
-    if (threadIdx.x == 0) ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) { ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3]; ws[MSE_BLOCKS + blockIdx.x] = red[4] + red[5] + red[6] + red[7]; }
 }
-__global__ __launch_bounds__(64) void mse_final_kernel(const float* __restrict__ ws, float* __restrict__ loss, float inv_n) {
-    float s = 0.f;
-    for (int i = threadIdx.x; i < MSE_BLOCKS; i += 64) s += ws[i];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) loss[0] = s * inv_n;
+__global__ __launch_bounds__(64) void mse_final_kernel(const float* __restrict__ ws, float* __restrict__ loss, float* __restrict__ count, float inv_n, int masked) {
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < MSE_BLOCKS; i += 64) { s += ws[i]; c += ws[MSE_BLOCKS + i]; }
+    s = wave_sum(s); c = wave_sum(c);
+    if (threadIdx.x == 0) {
+        if (masked) { const float den = fmaxf(c, 1.f); loss[0] = s / den; if (count) count[0] = den; }
+        else { loss[0] = s * inv_n; if (count) count[0] = c; }
+    }
 }
 // d = gloss * 2 (pred - target) / n  as bf16 [rows, ldd] (pad columns zeroed)
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target, int ldt,
+                                                       const int64_t* __restrict__ row_label, const float* __restrict__ count,
                                                        const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int rows, int cols, float two_over_n) {
     const int64_t n = (int64_t)rows * ldd;
-    const float g = (gloss ? gloss[0] : 1.f) * two_over_n;
+    const float g = (gloss ? gloss[0] : 1.f) * (row_label ? 2.f / count[0] : two_over_n);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / ldd;
         const int c = (int)(i - r * ldd);
-        d[i] = (bf16)(c < cols ? g * (pred[r * ldp + c] - target[r * ldt + c]) : 0.f);
+        const bool on = c < cols && (!row_label || row_label[r] == 1);
+        d[i] = (bf16)(on ? g * (pred[r * ldp + c] - target[r * ldt + c]) : 0.f);
     }
 }
 
@@ -291,21 +300,25 @@ __global__ __launch_bounds__(256) void wra_bwd_kernel(WraArgs a, const float* __
 
 extern "C" {
 
-int mmf_mse_ws_floats(void) { return MSE_BLOCKS; }
-int mmf_mse_fwd(const float* pred, int ldp, const float* target, int ldt, float* loss, float* ws, int rows, int cols, void* stream) {
+int mmf_mse_ws_floats(void) { return 2 * MSE_BLOCKS; }
+int mmf_mse_fwd(const float* pred, int ldp, const float* target, int ldt, const int64_t* row_label, float* loss, float* count, float* ws, int rows, int cols,
+                void* stream) {
     MMF_CHECK_ARG(pred && target && loss && ws && rows > 0 && cols > 0 && ldp >= cols && ldt >= cols, "mse_fwd: bad operand");
-    hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, pred, ldp, target, ldt, ws, rows, cols);
+    MMF_CHECK_ARG(!row_label || count, "mse_fwd: the masked form needs `count` (the denominator, reused by the backward)");
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, pred, ldp, target, ldt, row_label, ws, rows, cols);
     MMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, loss, 1.f / ((float)rows * (float)cols));
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, loss, count, 1.f / ((float)rows * (float)cols), row_label ? 1 : 0);
     MMF_CHECK_LAUNCH();
     return 0;
 }
-int mmf_mse_bwd(const float* pred, int ldp, const float* target, int ldt, const float* gloss, void* dpred, int ldd, int rows, int cols, void* stream) {
+int mmf_mse_bwd(const float* pred, int ldp, const float* target, int ldt, const int64_t* row_label, const float* count, const float* gloss, void* dpred, int ldd,
+                int rows, int cols, void* stream) {
     MMF_CHECK_ARG(pred && target && dpred && rows > 0 && cols > 0 && ldd >= cols && (ldd % 8) == 0, "mse_bwd: bad operand (ldd % 8 == 0)");
+    MMF_CHECK_ARG(!row_label || count, "mse_bwd: the masked form needs the forward's `count`");
     const int64_t n = (int64_t)rows * ldd;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(mse_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, ldp, target, ldt, gloss, reinterpret_cast<bf16*>(dpred), ldd, rows,
-                       cols, 2.f / ((float)rows * (float)cols));
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, ldp, target, ldt, row_label, count, gloss,
+                       reinterpret_cast<bf16*>(dpred), ldd, rows, cols, 2.f / ((float)rows * (float)cols));
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -1209,6 +1209,45 @@ class MaskedRegionHeadFn(torch.autograd.Function):
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
 
 
+class MaskedRegionRegressionFn(torch.autograd.Function):
+    """The decoder + loss of ViLBERT's masked-region REGRESSION (`visual_target: 1`, mmf/models/vilbert.py:1074-1075, 1139-1148):
+    prediction_scores_v = h W^T + b (BertImagePredictionHead.decoder, :846-858), nn.MSELoss(reduction="none") against the region targets,
+    summed over the regions with image_label == 1 and divided by max(number of their elements, 1).  Returns (loss, scores fp32); one node:
+    the loss kernel's backward writes the zero-padded bf16 operand of the decoder's gradient GEMMs (unlabelled rows are zeros)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, target, row_label):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        N = weight.shape[0]
+        dev = x2.device
+        pred = torch.empty(M, N, dtype=F32, device=dev)
+        nat.gemm(x2, w16, pred, M, N, K, K, K, N, bias=bias.detach())
+        tgt = target.reshape(M, N)
+        tgt = (tgt if tgt.dtype == F32 else tgt.float()).contiguous()
+        lab = row_label.reshape(M).contiguous()
+        if lab.dtype != torch.int64:
+            lab = lab.long()
+        loss = torch.empty(1, dtype=F32, device=dev)
+        count = torch.empty(1, dtype=F32, device=dev)
+        nat.mse_fwd(pred, tgt, loss, M, N, row_label=lab, count=count)
+        ctx.save_for_backward(x2, w16, pred, tgt, lab, count)
+        ctx.meta = (M, N, K, x.shape)
+        out = pred.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(out)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, gloss, _gscores):
+        x2, w16, pred, tgt, lab, count = ctx.saved_tensors
+        M, N, K, xshape = ctx.meta
+        ldd = _pad8(N)
+        d = torch.empty(M, ldd, dtype=BF16, device=x2.device)
+        nat.mse_bwd(pred, tgt, gloss.float().reshape(1).contiguous(), d, ldd, M, N, row_label=lab, count=count)
+        dx, dw, db = _linear_bwd(d, ldd, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
+        return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
+
+
 class TiedRegressionMSEFn(torch.autograd.Function):
     """MRFR's last two lines (mmf/models/transformers/heads/mrfr.py:85-90): prediction = h W + b with the TIED image-embedding
     weight W [hidden, img_dim] (UNITERImageEmbeddings.img_linear.weight applied transposed), loss = mean squared error against the targets.

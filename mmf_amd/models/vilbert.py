@@ -340,9 +340,10 @@ class ViLBERTForPretraining(nn.Module):
         self.vocab_size = self.config.vocab_size
         self.visual_target = config.visual_target
         self.num_negative = config.num_negative
-        if self.visual_target != 0:
-            raise NotImplementedError("visual_target=%r: only the KL masked-region classification (visual_target: 0, the reference "
-                                      "default; vilbert.py:1070-1075) is built" % (self.visual_target,))
+        if self.visual_target not in (0, 1):
+            raise NotImplementedError("visual_target=%r: the KL masked-region classification (visual_target: 0, the reference default) and "
+                                      "the masked-region regression (visual_target: 1) are built (vilbert.py:1070-1075); the NCE form "
+                                      "with random negatives (visual_target: 2, :1158-1216) is not" % (self.visual_target,))
         self.init_weights()
 
     def init_weights(self):
@@ -364,7 +365,11 @@ class ViLBERTForPretraining(nn.Module):
         if image_label is not None and image_target is not None:
             head = self.cls.imagePredictions
             hidden_v = head.transform(sequence_output_v)
-            img_loss, _ = torch.ops.mmf_amd.masked_region_head(hidden_v, head.decoder.weight, head.decoder.bias, image_target, image_label)
+            if self.visual_target == 1:          # nn.MSELoss(reduction="none") over the masked regions / max(their element count, 1), :1139-1148
+                img_loss, _ = Fn.MaskedRegionRegressionFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
+                                                                image_target, image_label)
+            else:
+                img_loss, _ = torch.ops.mmf_amd.masked_region_head(hidden_v, head.decoder.weight, head.decoder.bias, image_target, image_label)
             output["masked_img_loss"] = img_loss.unsqueeze(0)
         if masked_lm_labels is not None:
             heads = self.cls.predictions

@@ -292,7 +292,8 @@ def vilbert_forward(sd, cfg, sample_list, train=False, pooler_masks=None):
 
 
 def vilbert_pretraining_forward(sd, cfg, sample_list, train=False):
-    """ViLBERT.forward (vilbert.py:1423-1472) -> ViLBERTForPretraining.forward (:1097-1240) with `visual_target: 0`:
+    """ViLBERT.forward (vilbert.py:1423-1472) -> ViLBERTForPretraining.forward (:1097-1240) with `visual_target: 0` (or 1: masked-region
+    regression, nn.MSELoss over the regions with image_label == 1 / max(their element count, 1), :1139-1148):
     masked_lm_loss = CrossEntropyLoss(ignore_index=-1) over the text stream's prediction scores (HF BertLMPredictionHead, decoder tied
     to the word embeddings); masked_img_loss = sum over the regions with image_label == 1 of KLDivLoss(log_softmax(scores_v),
     cls_prob) / their number (:1150-1157); both `unsqueeze(0)`, keyed "{dataset_name}/{dataset_type}/..." (:1459-1469)."""
@@ -308,9 +309,13 @@ def vilbert_pretraining_forward(sd, cfg, sample_list, train=False):
     scores_v = F.linear(xv, sd["cls.imagePredictions.decoder.weight"], sd["cls.imagePredictions.decoder.bias"])     # :846-858
     image_label = sample_list["image_labels"]
     image_target = torch.as_tensor(sample_list["image_info_0"]["cls_prob"], dtype=torch.float32)                    # :1402-1406
-    img_loss = F.kl_div(F.log_softmax(scores_v, dim=2), image_target, reduction="none")                             # :1150-1153
     picked = torch.eq(image_label, 1)
-    masked_img_loss = torch.sum(img_loss * picked.unsqueeze(2).float()) / max(torch.sum(picked), 0)                 # :1155-1157
+    if cfg.get("visual_target", 0) == 1:                                                                            # :1139-1148
+        img_loss = F.mse_loss(scores_v, image_target, reduction="none")
+        masked_img_loss = torch.sum(img_loss * picked.unsqueeze(2).float()) / max(torch.sum(picked.unsqueeze(2).expand_as(img_loss)), 1)
+    else:
+        img_loss = F.kl_div(F.log_softmax(scores_v, dim=2), image_target, reduction="none")                         # :1150-1153
+        masked_img_loss = torch.sum(img_loss * picked.unsqueeze(2).float()) / max(torch.sum(picked), 0)             # :1155-1157
     masked_lm_loss = F.cross_entropy(scores_t.view(-1, cfg["vocab_size"]), sample_list["lm_label_ids"].view(-1), ignore_index=-1)
     key = "%s/%s" % (sample_list["dataset_name"], sample_list["dataset_type"])
     return {"losses": {key + "/masked_lm_loss": masked_lm_loss.unsqueeze(0), key + "/masked_img_loss": masked_img_loss.unsqueeze(0)},

@@ -625,8 +625,10 @@ def make_vilbert():
         print(name, "loss", loss.item(), "scores[0,:4]", rec["scores"][0, :4], "->", path, os.path.getsize(path), "bytes")
 
 
-def make_vilbert_pretraining():
-    """ViLBERTForPretraining (vilbert.py:1054-1240, `visual_target: 0`) through the reference's own ViLBERT.forward /
+def make_vilbert_pretraining(visual_target=0):
+    """`visual_target=1` (round 3) writes vilbert_pretraining_vt1.npz: the masked-region REGRESSION form (nn.MSELoss, vilbert.py:1074-1075,
+    1139-1148) with regression targets in place of the class distributions; the first fixture is unchanged.
+    ViLBERTForPretraining (vilbert.py:1054-1240, `visual_target: 0`) through the reference's own ViLBERT.forward /
     get_image_and_text_features, ViLBERTForPretraining.forward, vilbert.BertPreTrainingHeads (HF BertLMPredictionHead tied the
     pinned-transformers way + BertImagePredictionHead) and ViLBERTBase.  Only `ViLBERTBase.from_pretrained` (network) is
     replaced by constructing `ViLBERTBase(config)` directly."""
@@ -649,10 +651,10 @@ def make_vilbert_pretraining():
             self.bert = M.ViLBERTBase(bcfg)
             self.cls = M.BertPreTrainingHeads(bcfg)
             self.vocab_size = c["vocab_size"]
-            self.visual_target = 0
+            self.visual_target = visual_target
             self.num_negative = 128
             self.loss_fct = nn.CrossEntropyLoss(ignore_index=-1)
-            self.vis_criterion = nn.KLDivLoss(reduction="none")
+            self.vis_criterion = nn.KLDivLoss(reduction="none") if visual_target == 0 else nn.MSELoss(reduction="none")
             # tie_weights (:1088-1095) + transformers<=4.10 BertLMPredictionHead (decoder.bias IS predictions.bias)
             self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
             self.cls.predictions.decoder.bias = self.cls.predictions.bias
@@ -693,6 +695,8 @@ def make_vilbert_pretraining():
     raw = np.where(raw < 0.6, 0.0, raw) ** 3
     raw[..., 0] += 1e-3
     cls_prob = (raw / raw.sum(-1, keepdims=True)).astype(np.float32)
+    if visual_target == 1:       # regression targets (the reference reads them from the same `cls_prob` slot, vilbert.py:1402-1406)
+        cls_prob = (2.0 * detweights.uniform(B * R * c["v_target_size"], seed + 305) - 1.0).astype(np.float32).reshape(B, R, -1)
     image_labels = (detweights.uniform(B * R, seed + 304).reshape(B, R) < 0.4).astype(np.int64)
     image_labels[:, 2] = 1
     image_labels[np.arange(R)[None, :] >= max_features[:, None]] = -1          # padded regions carry -1
@@ -726,7 +730,7 @@ def make_vilbert_pretraining():
     rec["state_dict_keys"] = np.array(sorted(k for k in ref.state_dict().keys()
                                              if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")))
     rec["case"] = np.array(repr(c))
-    path = os.path.join(HERE, "vilbert_pretraining.npz")
+    path = os.path.join(HERE, "vilbert_pretraining.npz" if visual_target == 0 else "vilbert_pretraining_vt%d.npz" % visual_target)
     np.savez_compressed(path, **rec)
     print("vilbert_pretraining", dict(zip(rec["loss_keys"], rec["loss_values"])), rec["loss_shapes"], "->", path, os.path.getsize(path), "bytes")
 
@@ -1344,6 +1348,7 @@ if __name__ == "__main__":
         make_vilbert()
     if "vilbert_pretraining" in which:
         make_vilbert_pretraining()
+        make_vilbert_pretraining(visual_target=1)
     if "heads" in which:
         make_transformer_heads()
     if "uniter" in which:

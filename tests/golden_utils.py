@@ -212,9 +212,11 @@ def load_pretraining_case():
     return z, case, cfg, sd, sample
 
 
-def load_vilbert_pretraining_case():
-    """`vilbert_pretraining`: ViLBERT with the pretraining heads (masked LM + masked region classification, visual_target 0)."""
-    z = np.load(os.path.join(GOLDEN_DIR, "vilbert_pretraining.npz"), allow_pickle=False)
+def load_vilbert_pretraining_case(visual_target=0):
+    """`vilbert_pretraining`: ViLBERT with the pretraining heads (masked LM + masked region classification, visual_target 0);
+    `visual_target=1`: `vilbert_pretraining_vt1`, the masked-region REGRESSION form (nn.MSELoss, vilbert.py:1139-1148)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "vilbert_pretraining.npz" if visual_target == 0 else "vilbert_pretraining_vt%d.npz" % visual_target),
+                allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))
     shapes = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
     sd = {k[len("model."):]: torch.from_numpy(v) for k, v in detweights.state_dict(shapes, case["seed"]).items()}
@@ -229,7 +231,7 @@ def load_vilbert_pretraining_case():
         bi_intermediate_size=case["bi_intermediate_size"], v_attention_probs_dropout_prob=0.1, v_hidden_dropout_prob=0.1,
         v_biattention_id=list(case["v_biattention_id"]), t_biattention_id=list(case["t_biattention_id"]), fusion_method="mul",
         num_labels=case["num_labels"], initializer_range=0.02, dynamic_attention=False, training_head_type="pretraining",
-        v_target_size=case["v_target_size"])
+        v_target_size=case["v_target_size"], visual_target=visual_target)
     sample = {
         "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
         "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),

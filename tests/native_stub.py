@@ -217,12 +217,13 @@ def _bce_rowmask_bwd(scores, targets, w, count, gloss, d, rows, Nn):
     assert d.numel() == rows * Nn and gloss.numel() == 1
 
 
-def _mse_fwd(pred, target, loss, rows, cols):
+def _mse_fwd(pred, target, loss, rows, cols, row_label=None, count=None):
     assert pred.dtype == torch.float32 == target.dtype and loss.numel() == 1
+    assert row_label is None or (row_label.dtype == torch.int64 and row_label.numel() == rows and count is not None and count.numel() == 1)
     _need(pred, rows, pred.stride(0), cols, "mse pred"); _need(target, rows, target.stride(0), cols, "mse target")
 
 
-def _mse_bwd(pred, target, gloss, d, ldd, rows, cols):
+def _mse_bwd(pred, target, gloss, d, ldd, rows, cols, row_label=None, count=None):
     assert d.dtype == torch.bfloat16 and ldd % 8 == 0 and ldd >= cols and gloss.numel() == 1
     _need(d, rows, ldd, ldd, "mse dpred")
 

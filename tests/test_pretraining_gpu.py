@@ -206,12 +206,14 @@ def test_soft_target_kl_kernels_match_torch(R, C):
     assert rel_err(got[:, :C], 1.5 * x.grad) <= 6e-3
 
 
-def test_vilbert_pretraining_golden_losses_gradients_and_state_dict():
-    """ViLBERTForPretraining (mmf/models/vilbert.py:1054-1240, visual_target 0) against the reference's own run: masked-LM and
-    masked-region losses (both shaped [1], keyed like the reference), every gradient, state-dict keys."""
+@pytest.mark.parametrize("visual_target", [0, 1])
+def test_vilbert_pretraining_golden_losses_gradients_and_state_dict(visual_target):
+    """ViLBERTForPretraining (mmf/models/vilbert.py:1054-1240; visual_target 0: KL against the detector's class distribution, 1: masked-region
+    regression with nn.MSELoss, :1139-1148 — round 3) against the reference's own run: masked-LM and masked-region losses (both shaped [1],
+    keyed like the reference), every gradient, state-dict keys."""
     from tests.model_utils import build_vilbert_pretraining
-    z, case, cfg, sd, sample = G.load_vilbert_pretraining_case()
-    model = build_vilbert_pretraining(cfg, sd)
+    z, case, cfg, sd, sample = G.load_vilbert_pretraining_case(visual_target)
+    model = build_vilbert_pretraining(cfg, sd, visual_target=visual_target)
     assert sorted(model.state_dict().keys()) == sorted(str(k) for k in z["state_dict_keys"])
     model.eval()
     out = model(SampleList(sample_to(sample, "cuda")))

@@ -63,10 +63,14 @@ def test_vilbert_oracle_nlvr2_matches_reference():
         assert g is not None and abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, key
 
 
-def test_vilbert_pretraining_oracle_matches_reference():
-    """ViLBERTForPretraining (vilbert.py:1054-1240, visual_target 0): both losses and every gradient against the reference's own run."""
+
+
+@pytest.mark.parametrize("visual_target", [0, 1])
+def test_vilbert_pretraining_oracle_matches_reference(visual_target):
+    """ViLBERTForPretraining (vilbert.py:1054-1240; visual_target 0: masked-region KL, 1: masked-region regression, round 3): both losses and
+    every gradient against the reference's own run."""
     from tests.golden_utils import load_vilbert_pretraining_case
-    z, case, cfg, sd, sample = load_vilbert_pretraining_case()
+    z, case, cfg, sd, sample = load_vilbert_pretraining_case(visual_target)
     assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in O.parameter_shapes(cfg).items()}
     sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = O.vilbert_pretraining_forward(sd, cfg, dict(sample))

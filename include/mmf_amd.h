@@ -211,6 +211,14 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
 int mmf_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
                        const float* type, void* y, int B, int T, int S, int H, int row0, int pos0, int V, int P, int NT,
                        void* stream);
+/* `image_text_alignment` of BertVisioLinguisticEmbeddings.get_position_embeddings_visual (mmf/modules/embeddings.py:373-397): out[r] (fp32
+ * [rows, H]) = mean over the valid a of pos[align[r][a]] (align int64 [rows, A], -1 = padding; no valid entry: zero) + typ[typ_idx[r]]
+ * (optional: the region's visual token-type row) — the per-region addend the visual projection GEMM gathers in its epilogue.  Backward:
+ * dpos[align[r][a]] += dvis[r] / count[r] (fp32 atomics; dvis bf16, row (b, i) at (b * bstride + i) * ld).  An index outside [0, P) other
+ * than -1 is skipped and raises the index-error flag. */
+int mmf_align_pos_fwd(const int64_t* align, const float* pos, const float* typ, const int64_t* typ_idx, float* out, int rows, int A, int H, int P, int NT,
+                      void* stream);
+int mmf_align_pos_bwd(const void* dvis, int ld, int nb, int rpb, int bstride, const int64_t* align, float* dpos, int A, int H, int P, void* stream);
 /* 1 if any index-consuming kernel (embedding gathers, scatter-adds) met an out-of-table index since the last call, else 0;
  * clears the flag.  Synchronises with the device: call it between steps, not inside a captured region. */
 int mmf_amd_take_index_error(void);
@@ -266,7 +274,11 @@ int mmf_cast2d_bf16_to_f32(const void* src, int lds, float* dst, int ldd, int ro
  *   mmf_masked_mean_bwd : dx[b][t][c] = dpool[b][c] mask[b][t] / sum_t mask[b][t]         (autograd of the above, bf16 out)
  *   mmf_rowgroup_scale  : x[g * rows_per_group + r][c] *= gate[g][c] for c < C, in place (:211-212; the Q|K columns of the
  *                         packed [rows, ld] bf16 projection, gate fp32 [groups, C])
- *   mmf_rowgroup_scale_bwd : given y = x * gate and dy, writes dx = dy * gate over dy and dgate[g][c] = sum_r dy * x. */
+ *   mmf_rowgroup_scale_bwd : given y = x * gate and dy, writes dx = dy * gate over dy and dgate[g][c] = sum_r dy * x.
+ *   mmf_gate_sigmoid_fwd / _bwd : gate[b][col0 + c] = 1 + sigmoid(z[b][c]) written into the packed [B, ldg] gate (the Q half at col0 = 0,
+ *                         the K half at col0 = C: no torch.cat), :206-209; backward dz = dgate * s (1 - s), s = gate - 1. */
+int mmf_gate_sigmoid_fwd(const float* z, float* gate, int ldg, int col0, int B, int C, void* stream);
+int mmf_gate_sigmoid_bwd(const float* dgate, const float* gate, int ldg, int col0, float* dz, int B, int C, void* stream);
 int mmf_masked_mean_fwd(const void* x, const float* mask, float* pool, int B, int T, int H, void* stream);
 int mmf_masked_mean_bwd(const float* dpool, const float* mask, void* dx, int B, int T, int H, void* stream);
 int mmf_rowgroup_scale(void* x, int ld, const float* gate, int groups, int rows_per_group, int C, void* stream);

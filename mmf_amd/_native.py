@@ -374,6 +374,20 @@ def embed_text_fwd(ids, seg, word, pos, typ, y, B, T, S, H, row0=0, pos0=0):
                                     int(word.shape[0]), int(pos.shape[0]), int(typ.shape[0]), _stream()), "mmf_embed_text_fwd")
 
 
+def align_pos_fwd(align, pos, typ, typ_idx, out, rows, A, H):
+    """out[r] = mean of pos[align[r, a]] over align != -1 (+ typ[typ_idx[r]]): the image_text_alignment position term, embeddings.py:373-397."""
+    _req(align, torch.int64, "align"); _req(typ_idx, torch.int64, "typ_idx")
+    for t, n in ((pos, "pos"), (typ, "typ"), (out, "out")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_align_pos_fwd(_p(align), _p(pos), _p(typ), _p(typ_idx), _p(out), rows, A, H, int(pos.shape[0]),
+                                   0 if typ is None else int(typ.shape[0]), _stream()), "mmf_align_pos_fwd")
+
+
+def align_pos_bwd(dvis, ld, nb, rpb, bstride, align, dpos, A, H):
+    _req(dvis, torch.bfloat16, "dvis"); _req(align, torch.int64, "align"); _req(dpos, torch.float32, "dpos")
+    _check(lib().mmf_align_pos_bwd(_p(dvis), ld, nb, rpb, bstride, _p(align), _p(dpos), A, H, int(dpos.shape[0]), _stream()), "mmf_align_pos_bwd")
+
+
 def take_index_error():
     """True if an embedding gather / scatter-add met an index outside its table since the last call (the offending rows
     were skipped, nothing was read or written out of bounds); clears the flag.  Synchronises: call between steps."""
@@ -407,6 +421,19 @@ def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, ou
     _check(lib().mmf_rows_scatter_add(_p(x), ld, nb, rpb, bstride, _p(idx), idx_ld, int(per_pos), idx_base, _p(out), H,
                                       int(few_buckets), int(out.shape[0]), _p(ws), int(-1 if skip_bucket is None else skip_bucket), _stream()),
            "mmf_rows_scatter_add")
+
+
+def gate_sigmoid_fwd(z, gate, col0, B, Cn):
+    """gate[:, col0:col0 + Cn] = 1 + sigmoid(z)  (ViLBERT dynamic_attention, vilbert.py:206-209); z fp32 [B, Cn], gate fp32 [B, ldg]."""
+    _req(z, torch.float32, "z"); _req(gate, torch.float32, "gate")
+    _check(lib().mmf_gate_sigmoid_fwd(_p(z), _p(gate), gate.stride(0), col0, B, Cn, _stream()), "mmf_gate_sigmoid_fwd")
+
+
+def gate_sigmoid_bwd(dgate, gate, col0, dz, B, Cn):
+    _req(dgate, torch.float32, "dgate"); _req(gate, torch.float32, "gate"); _req(dz, torch.float32, "dz")
+    if dgate.stride(0) != gate.stride(0):
+        raise NativeLibraryError("gate_sigmoid_bwd: dgate and gate must share their row stride")
+    _check(lib().mmf_gate_sigmoid_bwd(_p(dgate), _p(gate), gate.stride(0), col0, _p(dz), B, Cn, _stream()), "mmf_gate_sigmoid_bwd")
 
 
 def masked_mean_fwd(x, mask, pool, B, T, H):

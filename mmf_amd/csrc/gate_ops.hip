@@ -79,9 +79,43 @@ __global__ __launch_bounds__(128) void rowgroup_scale_bwd_kernel(bf16* __restric
     for (int e = 0; e < 8; ++e) dgate[(size_t)g * C + c + e] = acc[e] / gt[e];
 }
 
+// gate[b][c] = 1 + sigmoid(z[b][c]) written into the packed [B, ldg] gate at column offset `col0` (the Q half or the K half);
+// backward: dz = dgate * s (1 - s) with s = gate - 1   (vilbert.py:206-209: 1 + sigmoid(dyLinear_{q,k}(pool)))
+__global__ __launch_bounds__(256) void gate_sigmoid_fwd_kernel(const float* __restrict__ z, float* __restrict__ gate, int ldg, int col0, int C, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / C;
+    const int c = (int)(i - b * C);
+    gate[b * ldg + col0 + c] = 1.f + 1.f / (1.f + __expf(-z[i]));
+}
+__global__ __launch_bounds__(256) void gate_sigmoid_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, int ldg, int col0, int C,
+                                                                float* __restrict__ dz, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / C;
+    const int c = (int)(i - b * C);
+    const float s = gate[b * ldg + col0 + c] - 1.f;
+    dz[i] = dgate[b * ldg + col0 + c] * s * (1.f - s);
+}
+
 }  // namespace
 
 extern "C" {
+
+int mmf_gate_sigmoid_fwd(const float* z, float* gate, int ldg, int col0, int B, int C, void* stream) {
+    MMF_CHECK_ARG(z && gate && B > 0 && C > 0 && col0 >= 0 && col0 + C <= ldg, "gate_sigmoid_fwd: bad operand");
+    const int64_t n = (int64_t)B * C;
+    hipLaunchKernelGGL(gate_sigmoid_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, gate, ldg, col0, C, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_gate_sigmoid_bwd(const float* dgate, const float* gate, int ldg, int col0, float* dz, int B, int C, void* stream) {
+    MMF_CHECK_ARG(dgate && gate && dz && B > 0 && C > 0 && col0 >= 0 && col0 + C <= ldg, "gate_sigmoid_bwd: bad operand");
+    const int64_t n = (int64_t)B * C;
+    hipLaunchKernelGGL(gate_sigmoid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dgate, gate, ldg, col0, C, dz, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
 
 int mmf_masked_mean_fwd(const void* x, const float* mask, float* pool, int B, int T, int H, void* stream) {
     MMF_CHECK_ARG(x && mask && pool && B > 0 && T > 0 && H > 0, "masked_mean_fwd: bad operand");

@@ -432,6 +432,59 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     }
 }
 
+// image_text_alignment of BertVisioLinguisticEmbeddings.get_position_embeddings_visual (mmf/modules/embeddings.py:373-397): the position
+// embedding of a region is the MEAN of the text position rows of the words aligned with it (align[r][a], -1 = padding; a region with
+// no aligned word gets zero), here with the region's visual token-type row added, as ONE fp32 addend row per region that the visual
+// projection GEMM gathers in its epilogue (rowtab).  One wave per region row.
+__global__ __launch_bounds__(256) void align_pos_fwd_kernel(const int64_t* __restrict__ align, const float* __restrict__ pos, const float* __restrict__ typ,
+                                                             const int64_t* __restrict__ typ_idx, float* __restrict__ out, int rows, int A, int H, int P, int NT) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    int cnt = 0;
+    for (int a = 0; a < A; ++a) {
+        const int64_t ix = align[(size_t)r * A + a];
+        if (ix == -1) continue;
+        if (ix < 0 || ix >= P) { if (lane == 0) atomicOr(&g_index_error, 1); continue; }
+        ++cnt;
+    }
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    int64_t ti = typ ? typ_idx[r] : 0;
+    if (typ && (ti < 0 || ti >= NT)) { if (lane == 0) atomicOr(&g_index_error, 1); ti = 0; }
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < A; ++a) {
+            const int64_t ix = align[(size_t)r * A + a];
+            if (ix < 0 || ix >= P) continue;
+            acc += load4(pos + (size_t)ix * H + col);
+        }
+        acc *= inv;
+        if (typ) acc += load4(typ + (size_t)ti * H + col);
+        store4(out + (size_t)r * H + col, acc);
+    }
+}
+// backward of the mean: dpos[align[r][a]] += dvis[r] / count[r] for every valid a (fp32 atomics, like the word-embedding scatter);
+// row r = (b, i) of the visual block lives at dvis + (b * bstride + i) * ld.
+__global__ __launch_bounds__(256) void align_pos_bwd_kernel(const bf16* __restrict__ dvis, int ld, int rpb, int bstride, const int64_t* __restrict__ align,
+                                                             float* __restrict__ dpos, int rows, int A, int H, int P) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    int cnt = 0;
+    for (int a = 0; a < A; ++a) { const int64_t ix = align[(size_t)r * A + a]; if (ix >= 0 && ix < P) ++cnt; }
+    if (cnt == 0) return;
+    const float inv = 1.f / (float)cnt;
+    const int b = r / rpb, i = r - b * rpb;
+    const bf16* src = dvis + ((size_t)b * bstride + i) * ld;
+    for (int col = lane; col < H; col += 64) {
+        const float g = (float)src[col] * inv;
+        for (int a = 0; a < A; ++a) {
+            const int64_t ix = align[(size_t)r * A + a];
+            if (ix >= 0 && ix < P) atomicAdd(dpos + (size_t)ix * H + col, g);
+        }
+    }
+}
+
 // y[b*S + row0 + i] = x[b*L + i] + pos[pos0 + i] + type[seg[b,i]]   (pos / seg may be null)
 template <typename T>   // bf16 rows (throughput path) or fp32 rows (fp32-accurate path)
 __global__ __launch_bounds__(256) void rows_add_embed_kernel(const T* __restrict__ x, const int64_t* __restrict__ seg,
@@ -1284,6 +1337,23 @@ int mmf_embed_text_f32_fwd(const int64_t* ids, const int64_t* seg, const float* 
     MMF_CHECK_ARG(P <= 0 || pos0 + T <= P, "embed_text_f32_fwd: sequence longer than the position table (max_position_embeddings)");
     hipLaunchKernelGGL(embed_text_kernel<float>, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, seg, word, pos, type,
                        y, B, T, S, H, row0, pos0, V, NT);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_align_pos_fwd(const int64_t* align, const float* pos, const float* typ, const int64_t* typ_idx, float* out, int rows, int A, int H, int P, int NT,
+                      void* stream) {
+    MMF_CHECK_ARG(align && pos && out && rows > 0 && A > 0 && P > 0 && (H % 4) == 0, "align_pos_fwd: bad operand");
+    MMF_CHECK_ARG(!typ || (typ_idx && NT > 0), "align_pos_fwd: a type table needs its indices");
+    hipLaunchKernelGGL(align_pos_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, align, pos, typ, typ_idx, out, rows, A, H, P, NT);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_align_pos_bwd(const void* dvis, int ld, int nb, int rpb, int bstride, const int64_t* align, float* dpos, int A, int H, int P, void* stream) {
+    MMF_CHECK_ARG(dvis && align && dpos && nb > 0 && rpb > 0 && A > 0 && P > 0 && H > 0 && ld >= H, "align_pos_bwd: bad operand");
+    const int rows = nb * rpb;
+    hipLaunchKernelGGL(align_pos_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dvis, ld, rpb, bstride, align, dpos, rows, A,
+                       H, P);
     MMF_CHECK_LAUNCH();
     return 0;
 }

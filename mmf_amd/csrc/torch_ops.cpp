@@ -643,7 +643,7 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
     static Tensor forward(AutogradContext* ctx, const Tensor& input_ids, const Tensor& token_type_ids, const optional<Tensor>& feats_o,
                           const optional<Tensor>& vtype_o, const Tensor& word, const Tensor& pos, const Tensor& typ, const Tensor& ln_w, const Tensor& ln_b,
                           const Tensor& typ_vis, const Tensor& pos_vis, const Tensor& proj_w, const Tensor& proj_b, const Tensor& proj_w16, double eps,
-                          Drop drop, int64_t pad_idx) {
+                          Drop drop, int64_t pad_idx, const optional<Tensor>& align_o) {
         TORCH_CHECK(input_ids.dim() == 2, "mmf_amd::visio_linguistic_embeddings: input_ids must be [B, T]");
         const int64_t B = input_ids.size(0), T = input_ids.size(1), H = word.size(1);
         const bool vis = feats_o.has_value() && feats_o->defined() && vtype_o.has_value() && vtype_o->defined();
@@ -655,7 +655,7 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
         TORCH_CHECK(seg.numel() == B * T, "mmf_amd::visio_linguistic_embeddings: token_type_ids must match input_ids");
         MMF_RC(mmf_embed_text_fwd(ids.data_ptr<int64_t>(), seg.data_ptr<int64_t>(), PF(word), PF(pos), PF(typ), y.data_ptr(), (int)B, (int)T, (int)S, (int)H, 0, 0,
                                   (int)word.size(0), (int)pos.size(0), (int)typ.size(0), sp()), "mmf_embed_text_fwd");
-        Tensor f2, vt;
+        Tensor f2, vt, al;
         if (R) {
             const Tensor& feats = *feats_o;
             const int64_t D = feats.size(2);
@@ -669,7 +669,21 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
             }
             vt = vtype_o->reshape({B * R}).contiguous();
             req(vt, at::kLong, "visual_embeddings_type");
-            Gemm(f2, proj_w16, y, B * R, H, D, D, D, H).bias(proj_b.detach()).coladd(pos_vis.detach()[0]).rowtab(typ_vis.detach(), vt, (int)H).grp((int)R, (int)T, (int)T).run();
+            if (align_o.has_value() && align_o->defined()) {
+                // image_text_alignment (embeddings.py:373-397): the mean text-position row of the words aligned with each region (+ its visual
+                // token-type row) as one fp32 addend row per region, gathered by the projection GEMM's epilogue
+                al = align_o->reshape({B * R, -1}).contiguous();
+                if (al.scalar_type() != at::kLong) al = al.to(at::kLong);
+                req(al, at::kLong, "image_text_alignment");
+                req(typ_vis, at::kFloat, "token_type_embeddings_visual");
+                Tensor addend = empty_f32({B * R, H}, y);
+                MMF_RC(mmf_align_pos_fwd(al.data_ptr<int64_t>(), PF(pos), PF(typ_vis), vt.data_ptr<int64_t>(), addend.data_ptr<float>(), (int)(B * R), (int)al.size(1),
+                                         (int)H, (int)pos.size(0), (int)typ_vis.size(0), sp()), "mmf_align_pos_fwd");
+                Tensor rows = at::arange(B * R, vt.options());
+                Gemm(f2, proj_w16, y, B * R, H, D, D, D, H).bias(proj_b.detach()).coladd(pos_vis.detach()[0]).rowtab(addend, rows, (int)H).grp((int)R, (int)T, (int)T).run();
+            } else {
+                Gemm(f2, proj_w16, y, B * R, H, D, D, D, H).bias(proj_b.detach()).coladd(pos_vis.detach()[0]).rowtab(typ_vis.detach(), vt, (int)H).grp((int)R, (int)T, (int)T).run();
+            }
         }
         Tensor out = empty_bf16({B * S, H}, y), mean = empty_f32({B * S}, y), rstd = empty_f32({B * S}, y);
         req(ln_w, at::kFloat, "LayerNorm.weight"); req(ln_b, at::kFloat, "LayerNorm.bias");
@@ -680,7 +694,7 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
             MMF_RC(mmf_dropout_bf16(out.data_ptr(), o2.data_ptr(), out.numel(), drop.key, drop.thr16, drop.scale, drop.seed_ptr(), sp()), "mmf_dropout_bf16");
             out = o2;
         }
-        ctx->save_for_backward({ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16, drop.seed});
+        ctx->save_for_backward({ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16, drop.seed, al});
         ctx->saved_data["dims"] = std::vector<int64_t>{B, T, R, S, H, word.size(0), pos.size(0), typ.size(0), typ_vis.size(0), pos_vis.size(0), pad_idx};
         ctx->saved_data["drop"] = drop_pack(drop);
         return out.view({B, S, H});
@@ -719,6 +733,9 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
             scatter(vis, H, B, R, S, vt, R, 0, dtyp_vis, H, 1, -1);
             dpos_vis = at::zeros({PV, H}, f32o);
             scatter(vis, H, B, R, S, Tensor(), 0, 0, dpos_vis, H, 1, -1);
+            if (sv[10].defined())       // the aligned words' TEXT position rows collect the regions' gradients / count
+                MMF_RC(mmf_align_pos_bwd(vis, (int)H, (int)B, (int)R, (int)S, sv[10].data_ptr<int64_t>(), dpos.data_ptr<float>(), (int)sv[10].size(1), (int)H, (int)Pn,
+                                         sp()), "mmf_align_pos_bwd");
             Tensor dvis = empty_bf16({B * R, H}, dpre);
             MMF_RC(mmf_copy_rows_bf16(vis, (int)S, dvis.data_ptr(), (int)R, (int)B, (int)R, (int)H, sp()), "mmf_copy_rows_bf16");
             const int64_t D = f2.size(1);
@@ -726,7 +743,8 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
             Gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D).kmajor(true, true).run();
             dproj_b = colsum(dvis, H, B * R, H);
         }
-        return {Tensor(), Tensor(), Tensor(), Tensor(), dword, dpos, dtyp, l.dgamma, l.dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, Tensor(), Tensor(), Tensor(), Tensor()};
+        return {Tensor(), Tensor(), Tensor(), Tensor(), dword, dpos, dtyp, l.dgamma, l.dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, Tensor(), Tensor(), Tensor(), Tensor(),
+                Tensor()};
     }
 };
 
@@ -836,16 +854,17 @@ Tensor op_additive_mask(const Tensor& mask) {
 }
 
 using VleSig = Tensor(const Tensor&, const Tensor&, const optional<Tensor>&, const optional<Tensor>&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
-                      const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, double, bool, int64_t);
+                      const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, double, bool, int64_t, const optional<Tensor>&);
 Tensor op_vle(const Tensor& input_ids, const Tensor& token_type_ids, const optional<Tensor>& vis, const optional<Tensor>& vis_type, const Tensor& word,
               const Tensor& pos, const Tensor& typ, const Tensor& ln_w, const Tensor& ln_b, const Tensor& typ_vis, const Tensor& pos_vis, const Tensor& proj_w,
-              const Tensor& proj_b, double eps, double p, bool training, int64_t pad_idx) {
+              const Tensor& proj_b, double eps, double p, bool training, int64_t pad_idx, const optional<Tensor>& align) {
     if (g_py_mode & 1) return call_py<VleSig>("visio_linguistic_embeddings", input_ids, token_type_ids, vis, vis_type, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis,
-                                              proj_w, proj_b, eps, p, training, pad_idx);
+                                              proj_w, proj_b, eps, p, training, pad_idx, align);
     const bool have = vis.has_value() && vis->defined() && vis_type.has_value() && vis_type->defined();
     Tensor w16 = have ? g_shadows.get({proj_w}, false) : Tensor();
     return VisioLinguisticEmbeddingsFn::apply(input_ids, token_type_ids, have ? vis : optional<Tensor>(), have ? vis_type : optional<Tensor>(), word, pos, typ,
-                                              ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, w16, eps, make_drop(p, training), pad_idx);
+                                              ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, w16, eps, make_drop(p, training), pad_idx,
+                                              have ? align : optional<Tensor>());
 }
 
 using LayerSig = Tensor(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
@@ -942,7 +961,7 @@ TORCH_LIBRARY(mmf_amd, m) {
     m.def("additive_mask(Tensor mask) -> Tensor");
     m.def("visio_linguistic_embeddings(Tensor input_ids, Tensor token_type_ids, Tensor? visual_embeddings, Tensor? visual_embeddings_type, "
           "Tensor word, Tensor pos, Tensor typ, Tensor ln_w, Tensor ln_b, Tensor typ_vis, Tensor pos_vis, Tensor proj_w, Tensor proj_b, "
-          "float eps, float p, bool training, int pad_idx) -> Tensor");
+          "float eps, float p, bool training, int pad_idx, Tensor? image_text_alignment=None) -> Tensor");
     m.def("transformer_layer(Tensor x, Tensor wq, Tensor bq, Tensor wk, Tensor bk, Tensor wv, Tensor bv, Tensor wo, Tensor bo, "
           "Tensor ln1_w, Tensor ln1_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor ln2_w, Tensor ln2_b, Tensor? mask_add, "
           "int heads, float eps1, float eps2, float p_attn, float p_hid1, float p_hid2, bool training, int causal_tail) -> Tensor");
@@ -961,7 +980,7 @@ TORCH_LIBRARY(mmf_amd, m) {
     // Python-implemented twins (fp32-accurate forward path, opt-in experiment hooks)
     m.def("_py_visio_linguistic_embeddings(Tensor input_ids, Tensor token_type_ids, Tensor? visual_embeddings, Tensor? visual_embeddings_type, "
           "Tensor word, Tensor pos, Tensor typ, Tensor ln_w, Tensor ln_b, Tensor typ_vis, Tensor pos_vis, Tensor proj_w, Tensor proj_b, "
-          "float eps, float p, bool training, int pad_idx) -> Tensor");
+          "float eps, float p, bool training, int pad_idx, Tensor? image_text_alignment=None) -> Tensor");
     m.def("_py_transformer_layer(Tensor x, Tensor wq, Tensor bq, Tensor wk, Tensor bk, Tensor wv, Tensor bv, Tensor wo, Tensor bo, "
           "Tensor ln1_w, Tensor ln1_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor ln2_w, Tensor ln2_b, Tensor? mask_add, "
           "int heads, float eps1, float eps2, float p_attn, float p_hid1, float p_hid2, bool training, int causal_tail) -> Tensor");

@@ -635,6 +635,32 @@ class MaskedMeanFn(torch.autograd.Function):
         return (dx if dtype == BF16 else dx.to(dtype)), None
 
 
+class DynamicGateFn(torch.autograd.Function):
+    """ViLBERT `dynamic_attention` gates (mmf/models/vilbert.py:206-209): cat([1 + sigmoid(zq), 1 + sigmoid(zk)], dim=1) as ONE fp32
+    [B, 2 C] tensor — the two halves are written in place by the sigmoid kernel (no ATen sigmoid / add / cat), backward dz = dgate s (1 - s)."""
+
+    @staticmethod
+    def forward(ctx, zq, zk):
+        B, Cn = zq.shape
+        q = zq.float().contiguous(); k = zk.float().contiguous()
+        gate = torch.empty(B, 2 * Cn, dtype=F32, device=zq.device)
+        nat.gate_sigmoid_fwd(q, gate, 0, B, Cn)
+        nat.gate_sigmoid_fwd(k, gate, Cn, B, Cn)
+        ctx.save_for_backward(gate)
+        ctx.meta = (B, Cn, zq.dtype, zk.dtype)
+        return gate
+
+    @staticmethod
+    def backward(ctx, g):
+        (gate,) = ctx.saved_tensors
+        B, Cn, dq_t, dk_t = ctx.meta
+        g = g.float().contiguous()
+        dzq = torch.empty(B, Cn, dtype=F32, device=g.device); dzk = torch.empty(B, Cn, dtype=F32, device=g.device)
+        nat.gate_sigmoid_bwd(g, gate, 0, dzq, B, Cn)
+        nat.gate_sigmoid_bwd(g, gate, Cn, dzk, B, Cn)
+        return dzq.to(dq_t), dzk.to(dk_t)
+
+
 class FeedForwardFn(torch.autograd.Function):
     """BertIntermediate + BertOutput (hf_layers.py:289-290): GELU in the up-projection epilogue,
     dropout + residual in the down-projection epilogue, GELU' in the down-projection dgrad epilogue,
@@ -853,7 +879,7 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b,
-                proj_w16, eps, drop, pad_idx=None):
+                proj_w16, eps, drop, pad_idx=None, align=None):
         B, T = input_ids.shape
         H = word.shape[1]
         R = 0 if feats is None else feats.shape[1]
@@ -868,10 +894,21 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             D = feats.shape[2]
             f2 = _feature_rows(feats, B * R, D)
             vt = vtype.reshape(B * R).contiguous()
-            nat.gemm(f2, proj_w16, y, B * R, H, D, D, D, H, bias=proj_b.detach(), coladd=pos_vis.detach()[0],
-                     rowtab=typ_vis.detach(), rowidx=vt, rowtab_ld=H, grp=(R, T, T))
+            if align is not None:       # image_text_alignment (embeddings.py:373-397): mean text-position row of the aligned words, per region
+                al = align.reshape(B * R, -1).contiguous()
+                if al.dtype != torch.int64:
+                    al = al.long()
+                addend = torch.empty(B * R, H, dtype=F32, device=dev)
+                nat.align_pos_fwd(al, pos.detach(), typ_vis.detach(), vt, addend, B * R, al.shape[1], H)
+                rows = torch.arange(B * R, dtype=torch.int64, device=dev)
+                nat.gemm(f2, proj_w16, y, B * R, H, D, D, D, H, bias=proj_b.detach(), coladd=pos_vis.detach()[0],
+                         rowtab=addend, rowidx=rows, rowtab_ld=H, grp=(R, T, T))
+            else:
+                al = None
+                nat.gemm(f2, proj_w16, y, B * R, H, D, D, D, H, bias=proj_b.detach(), coladd=pos_vis.detach()[0],
+                         rowtab=typ_vis.detach(), rowidx=vt, rowtab_ld=H, grp=(R, T, T))
         else:
-            vt = None
+            vt = al = None
         out = torch.empty(B * S, H, dtype=BF16, device=dev)
         mean = torch.empty(B * S, dtype=F32, device=dev)
         rstd = torch.empty(B * S, dtype=F32, device=dev)
@@ -880,14 +917,14 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             out2 = torch.empty_like(out)
             nat.dropout(out, out2, drop)
             out = out2
-        ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16)
+        ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16, al)
         ctx.meta = (B, T, R, S, H, drop, word.shape[0], pos.shape[0], typ.shape[0], typ_vis.shape[0], pos_vis.shape[0])
         ctx.pad_idx = -1 if pad_idx is None else int(pad_idx)
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        ids, seg, f2, vt, y, mean, rstd, ln_w, proj_w16 = ctx.saved_tensors
+        ids, seg, f2, vt, y, mean, rstd, ln_w, proj_w16, al = ctx.saved_tensors
         B, T, R, S, H, drop, V, P, NT, NTV, PV = ctx.meta
         dev = y.device
         dy = _grad_bf16(g, H)
@@ -909,12 +946,14 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             nat.rows_scatter_add(vis, H, B, R, S, vt, R, 0, 0, dtyp_vis, H, 1)
             dpos_vis = torch.zeros(PV, H, dtype=F32, device=dev)
             nat.rows_scatter_add(vis, H, B, R, S, None, 0, 0, 0, dpos_vis, H, 1)
+            if al is not None:          # the aligned words' TEXT position rows collect the regions' gradients / count
+                nat.align_pos_bwd(vis, H, B, R, S, al, dpos, al.shape[1], H)
             dvis = dpre.view(B, S, H)[:, T:, :].contiguous().view(B * R, H)
             D = f2.shape[1]
             dproj_w = torch.empty(H, D, dtype=F32, device=dev)
             nat.gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D, a_kmajor=True, b_kmajor=True)
             dproj_b = _colsum(dvis, H, B * R, H)
-        return (None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, None, None, None, None)
+        return (None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, None, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1320,6 +1359,21 @@ class WordRegionAlignmentFn(torch.autograd.Function):
         dseq = (torch.zeros if S > M + N else torch.empty)(B * S, H, dtype=BF16, device=seq.device)
         nat.wra_bwd(seq, H, B, S, H, M, N, tp, ip, lab, xinv, yinv, plan, cost, dist, g.float().reshape(1).contiguous(), count, dseq, H)
         return dseq.view(shape), None, None, None, None, None
+
+
+class AttachedZeroFn(torch.autograd.Function):
+    """A scalar 0 that depends on its inputs and hands each of them an all-zero gradient: what the reference's
+    `nan_to_num(cross_entropy(<zero rows>))` is to autograd (mlm.py:89-94) when a batch has no masked token.  The value never
+    reads the inputs, so NaN/inf in them cannot leak into the loss."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.meta = [(t.shape, t.dtype, t.device) for t in tensors]
+        return torch.zeros((), dtype=torch.float32, device=tensors[0].device)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(torch.zeros(s, dtype=d, device=dev) for s, d, dev in ctx.meta)
 
 
 class TakeRowsFn(torch.autograd.Function):

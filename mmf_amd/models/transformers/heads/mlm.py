@@ -55,10 +55,14 @@ class MLM(BaseTransformerHead):
         flat = masked_labels.reshape(-1)
         idx = flat.ne(self.config.ignore_index).nonzero().squeeze(1)       # (a host read-back, as the reference's boolean indexing)
         if idx.numel() == 0:
-            # mlm.py:89-94: the loss over nothing is NaN and is replaced by 0
+            # mlm.py:89-94: the loss over nothing is NaN and is replaced by 0.  The reference's zero is `nan_to_num` of a value that is
+            # still attached to the graph (a cross-entropy over zero rows), so `backward()` works and every head parameter and the
+            # encoder receive an all-zero gradient; under data parallel that keeps this rank's used-parameter set equal to the others'.
+            # Same here: a zero that depends on the sequence output and on the head's parameters.
             warnings.warn("NaN detected in masked_lm_loss. Replacing it with 0.")
+            zero = Fn.AttachedZeroFn.apply(sequence_output, *self.cls.parameters())
             output_dict["logits"] = torch.empty(0, self.vocab_size, dtype=torch.float32, device=sequence_output.device)
-            output_dict["losses"] = {self.config.loss_name: torch.zeros((), dtype=torch.float32, device=sequence_output.device)}
+            output_dict["losses"] = {self.config.loss_name: zero}
             return output_dict
         rows = Fn.TakeRowsFn.apply(sequence_output.reshape(-1, H), idx)
         labels = flat.index_select(0, idx)

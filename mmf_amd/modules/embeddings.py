@@ -37,8 +37,6 @@ class BertVisioLinguisticEmbeddings(nn.Module):
 
     def forward(self, input_ids: Tensor, token_type_ids: Optional[Tensor] = None, visual_embeddings: Optional[Tensor] = None,
                 visual_embeddings_type: Optional[Tensor] = None, image_text_alignment: Optional[Tensor] = None) -> Tensor:
-        if image_text_alignment is not None:
-            raise NotImplementedError("image_text_alignment (embeddings.py:376-410) is not on the VQA2 path")
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         pad = self.pad_idx
@@ -47,4 +45,4 @@ class BertVisioLinguisticEmbeddings(nn.Module):
             self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
             self.LayerNorm.weight, self.LayerNorm.bias, self.token_type_embeddings_visual.weight,
             self.position_embeddings_visual.weight, self.projection.weight, self.projection.bias,
-            self.LayerNorm.eps, self.dropout_prob, self.training, pad)
+            self.LayerNorm.eps, self.dropout_prob, self.training, pad, image_text_alignment)

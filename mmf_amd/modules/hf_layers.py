@@ -135,7 +135,7 @@ class BertSelfAttentionJit(nn.Module):
         pool = Fn.MaskedMeanFn.apply(txt_embedding, txt_attention_mask)
         zq = torch.ops.mmf_amd.linear(pool, self.dyLinear_q.weight, self.dyLinear_q.bias, True)
         zk = torch.ops.mmf_amd.linear(pool, self.dyLinear_k.weight, self.dyLinear_k.bias, True)
-        return torch.cat([1.0 + torch.sigmoid(zq.float()), 1.0 + torch.sigmoid(zk.float())], dim=1)
+        return Fn.DynamicGateFn.apply(zq, zk)
 
     def packed_qkv(self):
         w16 = Fn.shadows.get(self.query.weight, self.key.weight, self.value.weight)

@@ -80,19 +80,21 @@ def additive_mask(mask):
 
 @_op("visio_linguistic_embeddings(Tensor input_ids, Tensor token_type_ids, Tensor? visual_embeddings, Tensor? visual_embeddings_type, "
      "Tensor word, Tensor pos, Tensor typ, Tensor ln_w, Tensor ln_b, Tensor typ_vis, Tensor pos_vis, Tensor proj_w, Tensor proj_b, "
-     "float eps, float p, bool training, int pad_idx) -> Tensor")
+     "float eps, float p, bool training, int pad_idx, Tensor? image_text_alignment=None) -> Tensor")
 def visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ, ln_w, ln_b,
-                                typ_vis, pos_vis, proj_w, proj_b, eps, p, training, pad_idx):
+                                typ_vis, pos_vis, proj_w, proj_b, eps, p, training, pad_idx, image_text_alignment=None):
     if visual_embeddings is None or visual_embeddings_type is None:
-        visual_embeddings = visual_embeddings_type = None
+        visual_embeddings = visual_embeddings_type = image_text_alignment = None
     if F32P.active():
+        if image_text_alignment is not None:
+            raise NotImplementedError("fp32 path: image_text_alignment position embeddings are not built")
         F32P.check_no_dropout(p, training)
         return F32P.visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ,
                                                 ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps)
     w16 = Fn.shadows.get(proj_w) if visual_embeddings is not None else None
     return Fn.VisioLinguisticEmbeddingsFn.apply(
         input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w,
-        proj_b, w16, eps, Fn.make_drop(p, training), pad_idx if pad_idx >= 0 else None)
+        proj_b, w16, eps, Fn.make_drop(p, training), pad_idx if pad_idx >= 0 else None, image_text_alignment)
 
 
 @_op("transformer_layer(Tensor x, Tensor wq, Tensor bq, Tensor wk, Tensor bk, Tensor wv, Tensor bv, Tensor wo, Tensor bo, "

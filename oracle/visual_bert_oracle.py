@@ -121,9 +121,11 @@ def layer_norm(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def embeddings(sd, cfg, input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, dropout_p=0.0):
-    """BertVisioLinguisticEmbeddings.forward, embeddings.py:423-459 (image_text_alignment=None:
-    the else-branch of get_position_embeddings_visual, :411-419)."""
+def embeddings(sd, cfg, input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, dropout_p=0.0,
+               image_text_alignment=None):
+    """BertVisioLinguisticEmbeddings.forward, embeddings.py:423-459.  `image_text_alignment` None: the else-branch of
+    get_position_embeddings_visual (:411-419); a [B, R, A] tensor of text positions (-1 = padding): the masked mean of the
+    text position rows plus the visual position row (:375-410)."""
     e = "bert.embeddings."
     T = input_ids.size(1)
     position_ids = torch.arange(T, device=input_ids.device).unsqueeze(0).expand_as(input_ids)  # :332-335
@@ -135,8 +137,16 @@ def embeddings(sd, cfg, input_ids, token_type_ids, visual_embeddings, visual_emb
     if visual_embeddings is not None and visual_embeddings_type is not None:
         v = F.linear(visual_embeddings, sd[e + "projection.weight"], sd[e + "projection.bias"])  # :352
         vtyp = F.embedding(visual_embeddings_type, sd[e + "token_type_embeddings_visual.weight"])  # :353-355
-        pos_ids_v = torch.zeros(v.shape[:-1], dtype=torch.long, device=v.device)  # :411-415
-        vpos = F.embedding(pos_ids_v, sd[e + "position_embeddings_visual.weight"])  # :416-418
+        pos_ids_v = torch.zeros(v.shape[:-1], dtype=torch.long, device=v.device)  # :411-415 / :400-404
+        vpos = F.embedding(pos_ids_v, sd[e + "position_embeddings_visual.weight"])  # :416-418 / :406-409
+        if image_text_alignment is not None:
+            am = (image_text_alignment != -1).long()                                  # :379-381
+            al = am * image_text_alignment                                            # :383
+            ap = F.embedding(al, sd[e + "position_embeddings.weight"]) * am.unsqueeze(-1)   # :387-389
+            ap = ap.sum(2)                                                            # :390
+            cnt = am.sum(2)                                                           # :393
+            cnt = torch.where(cnt == 0, torch.ones_like(cnt), cnt)                    # :394-396
+            vpos = ap / cnt.unsqueeze(-1) + vpos                                      # :397-409
         v = v + vpos + vtyp  # :364-368
         out = torch.cat((text, v), dim=1)  # :450-452
     out = layer_norm(out, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], cfg["layer_norm_eps"])  # :457
@@ -183,7 +193,7 @@ def bert_layer(sd, cfg, i, hidden, ext_mask, hidden_dropout=0.0, attn_dropout=0.
 
 
 def visual_bert_base(sd, cfg, input_ids, attention_mask, token_type_ids, visual_embeddings, visual_embeddings_type,
-                     train=False):
+                     train=False, image_text_alignment=None):
     """VisualBERTBase.forward, visual_bert.py:74-157 (bypass_transformer=False)."""
     hd = cfg["hidden_dropout_prob"] if train else 0.0
     ad = cfg["attention_probs_dropout_prob"] if train else 0.0
@@ -194,7 +204,8 @@ def visual_bert_base(sd, cfg, input_ids, attention_mask, token_type_ids, visual_
     ext = attention_mask.unsqueeze(1).unsqueeze(2)  # :94
     ext = ext.to(dtype=sd["bert.embeddings.LayerNorm.weight"].dtype)  # :102-105
     ext = (1.0 - ext) * -10000.0  # :106
-    hidden = embeddings(sd, cfg, input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, hd)  # :108
+    hidden = embeddings(sd, cfg, input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, hd,
+                        image_text_alignment)  # :108-114
     if cfg.get("bypass_transformer", False) and visual_embeddings is not None:
         # :116-141 — the text alone goes through the encoder; the visual embeddings join it in ONE `additional_layer`.  The mask
         # slice `extended_attention_mask[:, :, :text_length, :text_length]` (:129-131) acts on a [B, 1, 1, S] tensor: it keeps the
@@ -273,7 +284,8 @@ def prepare_inputs(sample_list):
 def visual_bert_forward(sd, cfg, sample_list, train=False, return_hidden=False):
     """VisualBERT.forward (visual_bert.py:567-601) with training_head_type == "classification"."""
     ids, input_mask, attn_mask, tt, feats, vtype = prepare_inputs(sample_list)
-    seq, pooled, all_hidden = visual_bert_base(sd, cfg, ids, attn_mask, tt, feats, vtype, train)
+    seq, pooled, all_hidden = visual_bert_base(sd, cfg, ids, attn_mask, tt, feats, vtype, train,
+                                               sample_list.get("image_text_alignment", None))   # :585
     scores = classification_head(sd, cfg, seq, pooled, input_mask, train)
     out = {"scores": scores}
     if return_hidden:

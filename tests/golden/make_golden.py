@@ -69,8 +69,19 @@ def make_inputs(c):
                 targets=targets)
 
 
-def main():
-    for name, c in CASES.items():
+def make_alignment(c):
+    """`image_text_alignment` [B, R, A]: text positions each region is aligned to, -1 = padding (embeddings.py:375-378); one region
+    has no aligned word at all (the divide-by-zero guard, :394-396), one is aligned to the same word twice."""
+    B, T, R, A = c["B"], c["T"], c["R"], 3
+    al = (detweights.uniform(B * R * A, c["seed"] + 103) * (T + 3)).astype(np.int64).reshape(B, R, A) - 3
+    al[al < 0] = -1
+    al[0, 1, :] = -1
+    al[1, 2, :] = [4, 4, -1]
+    return al
+
+
+def main(align=False):
+    for name, c in ({"align64": CASES["small64"]} if align else CASES).items():
         cfg = reference_config(c)
         model = ref_vb.VisualBERT(cfg)
         model.build()
@@ -85,6 +96,9 @@ def main():
             segment_ids=torch.from_numpy(inp["segment_ids"]), image_feature_0=torch.from_numpy(inp["image_feature_0"]),
             image_info_0=SampleList(max_features=torch.from_numpy(inp["max_features"])),
             targets=torch.from_numpy(inp["targets"]), dataset_name="vqa2", dataset_type="train")
+        if align:
+            inp["image_text_alignment"] = make_alignment(c)
+            sl["image_text_alignment"] = torch.from_numpy(inp["image_text_alignment"])   # read at visual_bert.py:585
         out = model.forward(sl)
         loss = LogitBinaryCrossEntropy()(sl, out)
         loss.backward()
@@ -1334,6 +1348,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "vilbert_pretraining", "heads", "uniter", "m4c"]
     if "visual_bert" in which:
         main()
+    if "alignment" in which:
+        main(align=True)
     if "nlvr2" in which:
         make_visual_bert_nlvr2()
     if "pretraining" in which:

@@ -28,6 +28,8 @@ def load_case(name):
         "image_info_0": {"max_features": torch.from_numpy(z["in_max_features"])},
         "targets": torch.from_numpy(z["in_targets"]), "dataset_name": "vqa2", "dataset_type": "train",
     }
+    if "in_image_text_alignment" in z.files:
+        sample["image_text_alignment"] = torch.from_numpy(z["in_image_text_alignment"])
     # the reference model prefixes its parameters with "model." (visual_bert.py:420-422)
     sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}
     return z, case, cfg, sd, sample

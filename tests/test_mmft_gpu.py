@@ -249,6 +249,14 @@ def test_mlm_and_itm_heads_match_the_reference_heads():
         blank = mlm(seq, processed_sample_list={"mlm_labels": {"combined_labels": torch.full_like(inp["labels"], -1).cuda()}})
     assert blank["losses"]["masked_lm_loss"].item() == 0.0 and blank["logits"].shape == (0, V)
     assert any("NaN detected in masked_lm_loss" in str(x.message) for x in w)
+    # the zero stays attached to the graph as the reference's nan_to_num(cross_entropy over zero rows) does: backward works and the
+    # encoder output and every head parameter get an all-zero gradient (not None)
+    seq.grad = None
+    for p in mlm.parameters():
+        p.grad = None
+    blank["losses"]["masked_lm_loss"].backward()
+    assert seq.grad is not None and float(seq.grad.abs().max()) == 0.0
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in mlm.parameters())
 
 
 def test_mmft_pretraining_step_with_mlm_and_itm_heads():

@@ -9,7 +9,7 @@ from oracle import visual_bert_oracle as O
 from tests.golden_utils import load_case
 
 
-@pytest.mark.parametrize("name", ["tiny", "small64"])
+@pytest.mark.parametrize("name", ["tiny", "small64", "align64"])   # align64: `image_text_alignment` (embeddings.py:375-410)
 def test_oracle_matches_reference_forward_loss_and_gradients(name):
     z, case, cfg, sd, sample = load_case(name)
     # the oracle's parameter inventory is the reference's state dict, name for name and shape for shape

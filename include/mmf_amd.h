@@ -499,8 +499,9 @@ int mmf_transpose_bf16_multi(const mmf_transpose_list* d, void* stream);
  * out_f32 = 1); epilogue bias, coladd, rowtab[rowidx], act 0 / 1 (exact-erf GELU, libm erff) / 3 (tanh), resid, row remap.
  * K, lda, ldb multiples of 4; no U / aux / dropout / split-K / beta.  Replaces nn.Linear forward at hf_layers.py:169-180,
  * 248, 289-290, embeddings.py:352, visual_bert.py:146, 328-330.
- * mmf_attention_f32_fwd: mmf_attention_fwd with q / k / v / ctx fp32, head_dim 64, Sk <= 256, key mask only (hf_layers.py:161-213
- * in eval mode); lse, ctx_f32, dropout, causal_tail and the K|V-cache strides must be unset.
+ * mmf_attention_f32_fwd: mmf_attention_fwd with q / k / v / ctx fp32 (hf_layers.py:161-213 in eval mode; vilbert.py:153-247, 388-475):
+ * head_dim 64 with Sk <= 256 or head_dim 128 with Sk <= 128, Sq != Sk allowed, key mask and the prefix-LM causal_tail (m4c.py:424-440);
+ * K and V of a (batch, head) are staged once per workgroup in LDS.  lse, ctx_f32, dropout and the K|V-cache strides must be unset.
  * mmf_layernorm_f32_fwd: nn.LayerNorm over fp32 rows (hf_layers.py:248,290; embeddings.py:456; visual_bert.py:328).
  * mmf_embed_text_f32_fwd / mmf_gather_rows_f32: mmf_embed_text_fwd / mmf_gather_rows (no dropout) writing / moving fp32 rows. */
 int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream);
@@ -512,6 +513,14 @@ int mmf_gather_rows_f32(const float* x, const int64_t* index, float* out, int B,
 /* mmf_rows_add_embed with fp32 rows (MMF Transformer per-modality embedding sum, huggingface.py:145-155). */
 int mmf_rows_add_embed_f32(const float* x, const int64_t* seg, const float* pos, const float* type, float* y, int B, int L, int S, int H,
                            int row0, int pos0, void* stream);
+
+/* fp32 row operators of the widened models on the fp32 path: zero-padded copy of short rows (the 5-d / 7-d box geometry operands of
+ * vilbert.py:906 / uniter.py:81 become 16-byte rows), element-wise a * b (op 0), relu (1), a + b (3) (vilbert.py:803,818,1318;
+ * uniter.py:82), and the dynamic_attention pooling / gating of vilbert.py:204-212 (mmf_masked_mean_fwd / mmf_rowgroup_scale on fp32). */
+int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int rows, void* stream);
+int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, void* stream);
+int mmf_masked_mean_f32(const float* x, const float* mask, float* pool, int B, int T, int H, void* stream);
+int mmf_rowgroup_scale_f32(float* x, int ld, const float* gate, int groups, int rows_per_group, int C, void* stream);
 
 /* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
 int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */

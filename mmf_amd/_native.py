@@ -630,7 +630,7 @@ def gemm_f32(A, B, C_out, M, N, K, lda, ldb, ldc, bias=None, coladd=None, rowtab
     _check(lib().mmf_gemm_f32(C.byref(d), _stream()), "mmf_gemm_f32")
 
 
-def attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64):
+def attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64, causal_tail=0):
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx"), (mask, "mask")):
         _req(t, torch.float32, n)
     d = AttnDesc()
@@ -641,6 +641,7 @@ def attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, 
     d.scale = scale
     d.drop_scale = 1.0
     d.head_dim = head_dim
+    d.causal_tail = causal_tail
     _check(lib().mmf_attention_f32_fwd(C.byref(d), _stream()), "mmf_attention_f32_fwd")
 
 
@@ -662,6 +663,26 @@ def rows_add_embed_f32(x, seg, pos, typ, y, B, L, S, H, row0=0, pos0=0):
     _req(x, torch.float32, "x"); _req(y, torch.float32, "y"); _req(seg, torch.int64, "seg")
     _req(pos, torch.float32, "pos"); _req(typ, torch.float32, "type")
     _check(lib().mmf_rows_add_embed_f32(_p(x), _p(seg), _p(pos), _p(typ), _p(y), B, L, S, H, row0, pos0, _stream()), "mmf_rows_add_embed_f32")
+
+
+def pad_rows_f32(src, K, dst, KP, rows):
+    _req(src, torch.float32, "src"); _req(dst, torch.float32, "dst")
+    _check(lib().mmf_pad_rows_f32(_p(src), K, _p(dst), KP, rows, _stream()), "mmf_pad_rows_f32")
+
+
+def eltwise_f32(op, a, b, y):
+    _req(a, torch.float32, "a"); _req(b, torch.float32, "b"); _req(y, torch.float32, "y")
+    _check(lib().mmf_eltwise_f32(op, _p(a), _p(b), _p(y), C.c_long(a.numel()), _stream()), "mmf_eltwise_f32")
+
+
+def masked_mean_f32(x, mask, pool, B, T, H):
+    _req(x, torch.float32, "x"); _req(mask, torch.float32, "mask"); _req(pool, torch.float32, "pool")
+    _check(lib().mmf_masked_mean_f32(_p(x), _p(mask), _p(pool), B, T, H, _stream()), "mmf_masked_mean_f32")
+
+
+def rowgroup_scale_f32(x, ld, gate, groups, rows_per_group, Cn):
+    _req(x, torch.float32, "x"); _req(gate, torch.float32, "gate")
+    _check(lib().mmf_rowgroup_scale_f32(_p(x), ld, _p(gate), groups, rows_per_group, Cn, _stream()), "mmf_rowgroup_scale_f32")
 
 
 def gather_rows_f32(x, index, out, B, S, H):

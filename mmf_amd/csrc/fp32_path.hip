@@ -142,10 +142,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention forward, fp32.  Workgroup = one (batch, head) x 128 queries; wave = 32 queries x ALL keys (Sk <= 256):
-// scores on the fp32 MFMA (A = Q rows, B = K rows), exact two-pass softmax in registers, the normalised probabilities
-// of one 32-key tile go through a per-wave LDS patch to become the A operand of P.V (B = V rows, read straight from
-// L2: lanes 0..31 of an MFMA operand read 128 contiguous bytes of one V row).
+// attention forward, fp32, on v_mfma_f32_16x16x4_f32.  Workgroup = one (batch, head) x 128 queries, 8 waves; wave = 16 queries x ALL
+// keys (Sk <= 16 * MAXT).  Round 3 rewrite (was: 4 waves x 32 queries on the 32x32x2 MFMA with every operand pulled from L2 per MFMA,
+// 215 us per VisualBERT layer; see DESIGN §2a for the measured numbers of this form):
+//   * K and V rows of the (batch, head) are staged ONCE per workgroup in LDS, row-major with a row stride of D + 4 floats: the
+//     16-byte operand reads `K[key = lane % 16][16 m + 4 (lane / 16) ..]` and the scalar reads `V[key][16 eb + lane % 16]` are both
+//     bank-conflict-free at that stride, and no transpose is needed;
+//   * the scores are computed TRANSPOSED, S^T = K Q^T (A = K rows from LDS, B = Q rows held in registers), with the MFMA's k-slot
+//     (lane / 16) mapped to the feature quad 4 (lane / 16) + c: one 16-byte LDS read feeds four MFMAs;
+//   * in that layout the accumulator register r of key tile t holds P[q = lane % 16][key = 16 t + 4 (lane / 16) + r] — exactly the A
+//     operand layout of the P.V product when ITS k-slot is mapped to key 16 t + 4 (lane / 16) + c: the probabilities never leave the
+//     registers (no LDS patch, no barrier between the two products), and a query's softmax statistics are a reduction over the
+//     lane's own registers plus two cross-lane steps;
+//   * 16-query wave tiles keep the whole score row in 64 (head_dim 64, 256 keys) accumulator registers: two waves per SIMD, so one
+//     wave's softmax (VALU) runs under the other's MFMAs.
+// Templated on head_dim (64: Sk <= 256; 128: Sk <= 128 — ViLBERT's image stream and co-attention); Sq != Sk (cross attention) and
+// the prefix-LM tail of M4C (mmf_attn_desc.causal_tail) are handled.  exp(x) = exp2(x log2 e) on v_exp_f32.
 // ------------------------------------------------------------------------------------------------
 struct AttnF32 {
     const float* q; const float* k; const float* v; float* o;
@@ -153,109 +165,116 @@ struct AttnF32 {
     const float* mask;
     int B, heads, Sq, Sk;
     float scale;
+    int cfrom;     // first key of the causal tail (== Sk: none)
 };
 
-constexpr int ATT_MAXT = 8;   // key tiles of 32: Sk <= 256
-
-template <int D>
-__global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AttnF32 a) {
-    __shared__ float Ps[4][32][33];
+template <int D, int MAXT>
+__global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
+    constexpr int RS = D + 4;                     // LDS row stride in floats (== 4 mod 64 for D = 64 and 128)
+    constexpr int NM = D / 16;                    // feature blocks of 16
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ float att_smem[];
+    float* Ks = att_smem;                         // [16 * MAXT][RS]
+    float* Vs = Ks + 16 * MAXT * RS;              // [16 * MAXT][RS]
+    float* Ms = Vs + 16 * MAXT * RS;              // [16 * MAXT]  additive key mask x log2(e); -inf past Sk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int nt = (a.Sk + 31) >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 16;
+    const int nt = (a.Sk + 15) >> 4;
 
-    // Q operand: A[i = query l31][k = e]: aq[j] = Q[q0 + l31][2 j + half]
-    // (rows are read as 16-byte quads — each lane pulls its whole 4 D-byte row, lanes l and l + 32 the same one — and the lane keeps
-    // the even (half 0) or odd (half 1) elements: half as many, four times as wide load instructions as element gathers)
-    float aq[D / 2];
+    // stage K and V rows (rows past Sk repeat the last one: their probabilities are exactly 0) and the key mask
     {
-        const int qr = min(q0 + l31, a.Sq - 1);
-        const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.Sq + qr) * a.ldq + h * D);
-#pragma unroll
-        for (int i = 0; i < D / 4; ++i) {
-            const f32x4 t = qp[i];
-            aq[2 * i] = half ? t[1] : t[0];
-            aq[2 * i + 1] = half ? t[3] : t[2];
-        }
-    }
-
-    f32x16 sc[ATT_MAXT];
-#pragma unroll
-    for (int t = 0; t < ATT_MAXT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
-        if (t < nt) {
-            const int key = 32 * t + l31;
+        constexpr int QPR = D / 4;                // 16-byte quads per row
+        const int quads = nt * 16 * QPR;
+        for (int idx = threadIdx.x; idx < quads; idx += 512) {
+            const int key = idx / QPR, qd = idx - key * QPR;
             const int kr = min(key, a.Sk - 1);
-            const f32x4* kp = reinterpret_cast<const f32x4*>(a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D);
-            float bk[D / 2];
-#pragma unroll
-            for (int i = 0; i < D / 4; ++i) {
-                const f32x4 t = kp[i];
-                bk[2 * i] = half ? t[1] : t[0];
-                bk[2 * i + 1] = half ? t[3] : t[2];
-            }
-#pragma unroll
-            for (int j = 0; j < D / 2; ++j) sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], bk[j], sc[t], 0, 0, 0);
-            // this lane's column = key; rows = 16 queries
-            const float madd = (key < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + key] : 0.f) : -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[t][r] = sc[t][r] * a.scale + madd;
+            const f32x4 kq = *reinterpret_cast<const f32x4*>(a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D + 4 * qd);
+            const f32x4 vq = *reinterpret_cast<const f32x4*>(a.v + ((size_t)b * a.Sk + kr) * a.ldv + h * D + 4 * qd);
+            *reinterpret_cast<f32x4*>(Ks + key * RS + 4 * qd) = kq;
+            *reinterpret_cast<f32x4*>(Vs + key * RS + 4 * qd) = vq;
         }
+        for (int key = threadIdx.x; key < nt * 16; key += 512)
+            Ms[key] = key < a.Sk ? (a.mask ? a.mask[(size_t)b * a.Sk + key] * LOG2E : 0.f) : -INFINITY;
     }
-
-    // softmax over keys: row r of this lane's half lives in the 32 lanes of the half, across the nt tiles
-    float inv[16];
+    // Q operand (B[k][j = query]): qv[m][c] = Q[q0 + j][16 m + 4 g + c]
+    f32x4 qv[NM];
+    {
+        const int qr = min(q0 + j, a.Sq - 1);
+        const float* qp = a.q + ((size_t)b * a.Sq + qr) * a.ldq + h * D + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < ATT_MAXT; ++t) if (t < nt) m = fmaxf(m, sc[t][r]);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < ATT_MAXT; ++t) if (t < nt) { const float p = expf(sc[t][r] - m); sc[t][r] = p; s += p; }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        inv[r] = s;
+        for (int m = 0; m < NM; ++m) qv[m] = *reinterpret_cast<const f32x4*>(qp + 16 * m);
     }
+    __syncthreads();
+    if (q0 >= a.Sq) return;                       // (no barrier below)
 
-    f32x16 oc[D / 32];
+    const float sl2 = a.scale * LOG2E;
+    const int qme = q0 + j;                       // this lane's query
+    f32x4 sc[MAXT];
+    float mx = -INFINITY;
 #pragma unroll
-    for (int eb = 0; eb < D / 32; ++eb)
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* kr = Ks + (16 * t + j) * RS + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oc[eb][r] = 0.f;
-
+            for (int m = 0; m < NM; ++m) {
+                const f32x4 kq = *reinterpret_cast<const f32x4*>(kr + 16 * m);
 #pragma unroll
-    for (int t = 0; t < ATT_MAXT; ++t) {
-        if (t < nt) {     // nt is uniform over the workgroup: every wave meets the same barriers
-            __syncthreads();     // the patch's previous tile has been consumed
+                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[c], qv[m][c], acc, 0, 0, 0);
+            }
+            // acc[r] = S[query q0 + j][key 16 t + 4 g + r]
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + 16 * t + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Ps[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = sc[t][r] / inv[r];
-            __syncthreads();
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const int kin = 2 * kk + half;              // key inside the tile = the MFMA's k index of this lane
-                const float pa = Ps[wave][l31][kin];        // A[i = query l31][k = key]
-                const int kr = min(32 * t + kin, a.Sk - 1); // (keys past Sk carry probability 0)
-                const float* vp = a.v + ((size_t)b * a.Sk + kr) * a.ldv + h * D + l31;
-#pragma unroll
-                for (int eb = 0; eb < D / 32; ++eb)
-                    oc[eb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, vp[32 * eb], oc[eb], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * g + r;
+                float madd = mk[r];
+                if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
+                const float x = acc[r] * sl2 + madd;
+                sc[t][r] = x;
+                mx = fmaxf(mx, x);
             }
         }
     }
-
+    // softmax of query q0 + j: its keys live in this lane's registers and in the three other lane groups
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(sc[t][r] - mx); sc[t][r] = p; sum += p; }
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+
+    // O = P V with the un-normalised probabilities straight from the score registers
+    f32x4 oc[NM];
+#pragma unroll
+    for (int eb = 0; eb < NM; ++eb) oc[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* vr = Vs + (16 * t + 4 * g + c) * RS + j;
+#pragma unroll
+                for (int eb = 0; eb < NM; ++eb) oc[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[t][c], vr[16 * eb], oc[eb], 0, 0, 0);
+            }
+        }
+    }
+    // oc[eb][r] = O[query q0 + 4 g + r][feature 16 eb + j]: that query's sum lives in lane 4 g + r (of every group)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float inv = 1.0f / __shfl(sum, 4 * g + r, 64);
+        const int qr = q0 + 4 * g + r;
         if (qr < a.Sq) {
-            float* op = a.o + ((size_t)b * a.Sq + qr) * a.ldo + h * D + l31;
+            float* op = a.o + ((size_t)b * a.Sq + qr) * a.ldo + h * D + j;
 #pragma unroll
-            for (int eb = 0; eb < D / 32; ++eb) op[32 * eb] = oc[eb][r];
+            for (int eb = 0; eb < NM; ++eb) op[16 * eb] = oc[eb][r] * inv;
         }
     }
 }
@@ -304,6 +323,48 @@ __global__ __launch_bounds__(256) void ln_f32_fwd_kernel(const float* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Small fp32 row operators of the widened models (ViLBERT, UNITER) on the fp32 path.
+// ------------------------------------------------------------------------------------------------
+// dst[r][0..KP) = src[r][0..K) followed by zeros: operands whose contraction length is not a multiple of 4 (the 5-d box geometry of
+// ViLBERT, the 7-d one of UNITER) become 16-byte rows for the fp32 GEMM.
+__global__ __launch_bounds__(256) void pad_rows_f32_kernel(const float* __restrict__ src, int K, float* __restrict__ dst, int KP, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long r = i / KP;
+    const int c = (int)(i - r * KP);
+    dst[i] = c < K ? src[r * K + c] : 0.f;
+}
+// op 0: a * b, 1: max(a, 0), 3: a + b   (the op codes of mmf_eltwise)
+__global__ __launch_bounds__(256) void eltwise_f32_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    y[i] = op == 0 ? x * b[i] : (op == 1 ? fmaxf(x, 0.f) : x + b[i]);
+}
+// pool[b][c] = sum_t x[b][t][c] mask[b][t] / sum_t mask[b][t]   (ViLBERT dynamic_attention, vilbert.py:204-205)
+__global__ __launch_bounds__(256) void masked_mean_f32_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ pool, int T, int H) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    const float* xb = x + (size_t)b * T * H + c;
+    const float* mb = mask + (size_t)b * T;
+    float acc = 0.f, cnt = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float m = mb[t];
+        acc += xb[(size_t)t * H] * m;
+        cnt += m;
+    }
+    pool[(size_t)b * H + c] = acc / cnt;
+}
+// x[row][c] *= gate[row / rpg][c] for c < C   (the Q | K gates, vilbert.py:211-212)
+__global__ __launch_bounds__(256) void rowgroup_scale_f32_kernel(float* __restrict__ x, int ld, const float* __restrict__ gate, int rpg, int C, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    x[row * ld + c] *= gate[(row / rpg) * C + c];
+}
 }  // namespace
 
 extern "C" int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream) {
@@ -340,26 +401,40 @@ extern "C" int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream) {
     return 0;
 }
 
+template <int D, int MAXT>
+static int launch_attn_f32(const AttnF32& a, hipStream_t s) {
+    constexpr int lds = (2 * 16 * MAXT * (D + 4) + 16 * MAXT) * (int)sizeof(float);
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_fwd_kernel<D, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        once = true;
+    }
+    hipLaunchKernelGGL((attn_f32_fwd_kernel<D, MAXT>), dim3((a.Sq + 127) / 128, a.B * a.heads), dim3(512), lds, s, a);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
     MMF_CHECK_ARG(d && d->q && d->k && d->v && d->ctx, "attention_f32_fwd: null operand");
     MMF_CHECK_ARG(d->B > 0 && d->heads > 0 && d->Sq > 0 && d->Sk > 0, "attention_f32_fwd: empty problem");
-    MMF_CHECK_ARG(d->head_dim == 0 || d->head_dim == 64, "attention_f32_fwd: head_dim must be 64");
-    MMF_CHECK_ARG(d->Sk <= 32 * ATT_MAXT, "attention_f32_fwd: Sk <= 256");
-    MMF_CHECK_ARG(d->drop_thr16 == 0 && d->causal_tail == 0 && !d->ctx_f32 && !d->lse && d->q_batch_rows == 0 &&
-                  d->kv_batch_rows == 0 && d->mask_batch_stride == 0,
-                  "attention_f32_fwd: inference form only (no dropout, prefix-LM tail, lse, K|V cache strides)");
-    const int HD = d->heads * 64;
-    MMF_CHECK_ARG(d->ldq >= HD && d->ldk >= HD && d->ldv >= HD && d->ldo >= HD, "attention_f32_fwd: leading dimension < heads * 64");
-    MMF_CHECK_ARG((d->ldq % 4) == 0 && (d->ldk % 4) == 0 && (((uintptr_t)d->q | (uintptr_t)d->k) & 15) == 0,
-                  "attention_f32_fwd: q and k rows are read as 16-byte quads (pointers 16-byte aligned, ldq / ldk multiples of 4)");
+    const int hd = d->head_dim ? d->head_dim : 64;
+    MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_fwd: head_dim must be 64 or 128");
+    MMF_CHECK_ARG(d->Sk <= (hd == 64 ? 256 : 128), "attention_f32_fwd: Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
+    MMF_CHECK_ARG(d->drop_thr16 == 0 && !d->ctx_f32 && !d->lse && d->q_batch_rows == 0 && d->kv_batch_rows == 0 && d->mask_batch_stride == 0,
+                  "attention_f32_fwd: inference form only (no dropout, lse, K|V cache strides)");
+    MMF_CHECK_ARG(d->causal_tail >= 0 && d->causal_tail <= d->Sk && (d->causal_tail == 0 || d->Sq == d->Sk),
+                  "attention_f32_fwd: a causal tail needs self-attention (Sq == Sk)");
+    const int HD = d->heads * hd;
+    MMF_CHECK_ARG(d->ldq >= HD && d->ldk >= HD && d->ldv >= HD && d->ldo >= HD, "attention_f32_fwd: leading dimension < heads * head_dim");
+    MMF_CHECK_ARG((d->ldq % 4) == 0 && (d->ldk % 4) == 0 && (d->ldv % 4) == 0 && (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) == 0,
+                  "attention_f32_fwd: q / k / v rows are read as 16-byte quads (pointers 16-byte aligned, leading dimensions multiples of 4)");
     MMF_CHECK_ARG((size_t)d->B * d->heads <= 65535u, "attention_f32_fwd: B * heads too large for one launch");
     AttnF32 a;
     a.q = (const float*)d->q; a.k = (const float*)d->k; a.v = (const float*)d->v; a.o = (float*)d->ctx;
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
     a.mask = d->mask; a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk; a.scale = d->scale;
-    hipLaunchKernelGGL(attn_f32_fwd_kernel<64>, dim3((d->Sq + 127) / 128, d->B * d->heads), dim3(256), 0, (hipStream_t)stream, a);
-    MMF_CHECK_LAUNCH();
-    return 0;
+    a.cfrom = d->Sk - d->causal_tail;
+    return hd == 64 ? launch_attn_f32<64, 16>(a, (hipStream_t)stream) : launch_attn_f32<128, 8>(a, (hipStream_t)stream);
 }
 
 extern "C" int mmf_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int H, float eps,
@@ -368,6 +443,33 @@ extern "C" int mmf_layernorm_f32_fwd(const float* x, const float* gamma, const f
     MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 2048, "layernorm_f32_fwd: H % 4 == 0, H <= 2048");
     MMF_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_f32_fwd: 16-byte alignment");
     hipLaunchKernelGGL(ln_f32_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, H, eps);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int rows, void* stream) {
+    MMF_CHECK_ARG(src && dst && rows > 0 && K > 0 && KP >= K, "pad_rows_f32: bad operand");
+    const long n = (long)rows * KP;
+    hipLaunchKernelGGL(pad_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, K, dst, KP, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, void* stream) {
+    MMF_CHECK_ARG(a && y && n > 0 && (op == 0 || op == 1 || op == 3) && (op == 1 || b), "eltwise_f32: bad operand (op 0 mul, 1 relu, 3 add)");
+    hipLaunchKernelGGL(eltwise_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, y, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmf_masked_mean_f32(const float* x, const float* mask, float* pool, int B, int T, int H, void* stream) {
+    MMF_CHECK_ARG(x && mask && pool && B > 0 && T > 0 && H > 0, "masked_mean_f32: bad operand");
+    hipLaunchKernelGGL(masked_mean_f32_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mask, pool, T, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmf_rowgroup_scale_f32(float* x, int ld, const float* gate, int groups, int rows_per_group, int C, void* stream) {
+    MMF_CHECK_ARG(x && gate && groups > 0 && rows_per_group > 0 && C > 0 && C <= ld, "rowgroup_scale_f32: bad operand");
+    const long n = (long)groups * rows_per_group * C;
+    hipLaunchKernelGGL(rowgroup_scale_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, gate, rows_per_group, C, n);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -170,23 +170,31 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, feats, vtype, word, p
     return out.view(B, S, H)
 
 
+def _check_head(hd, Sk):
+    if hd not in (64, 128):
+        raise NotImplementedError("fp32 path: the attention kernel is built for head_dim 64 and 128, got %d" % hd)
+    if Sk > (256 if hd == 64 else 128):
+        raise NotImplementedError("fp32 path: %d keys exceed what one workgroup stages (256 at head_dim 64, 128 at head_dim 128)" % Sk)
+
+
 def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2,
-                      causal_tail=0):
+                      causal_tail=0, qk_gate=None):
     """BertLayerJit.forward (hf_layers.py:255-292), eval mode: the packed Q|K|V projection into one [M, 3H] buffer, fused attention,
     output projection + bias + residual in the GEMM epilogue, LayerNorm, GELU in the up-projection epilogue, down-projection +
     bias + residual, LayerNorm."""
-    if causal_tail:
-        raise NotImplementedError("fp32 path: the prefix-LM mask (M4C) is not built; key masks only")
     B, S, H = x.shape
-    if H != heads * 64:
-        raise NotImplementedError("fp32 path: the attention kernel is built for head_dim 64 (hidden %d, heads %d)" % (H, heads))
+    hd = H // heads
+    _check_head(hd, S)
     x2 = _rows(x)
     M = B * S
     dev = x2.device
     qkv = _linear(x2, _packed(wq, wk, wv), _packed(bq, bk, bv))      # one [M, 3H] projection (2304 columns fill the chip; 3 x 768 do not)
+    if qk_gate is not None:                                          # ViLBERT dynamic_attention gates on the Q | K columns (vilbert.py:211-212)
+        nat.rowgroup_scale_f32(qkv, 3 * H, qk_gate.contiguous(), B, S, 2 * H)
     ctx = torch.empty(M, H, dtype=F32, device=dev)
     mask = None if mask_add is None else mask_add.reshape(B, S).contiguous()
-    nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, B, heads, S, S, 1.0 / math.sqrt(64.0))
+    nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, B, heads, S, S, 1.0 / math.sqrt(hd), head_dim=hd,
+                          causal_tail=int(causal_tail))
     y1 = _linear(ctx, wo, bo, resid=x2)
     a_out = torch.empty(M, H, dtype=F32, device=dev)
     nat.layernorm_f32_fwd(y1, _w(ln1_w), _w(ln1_b), a_out, M, H, eps1)
@@ -270,3 +278,145 @@ def concat_rows(*xs):
         nat.copy_rows(_rows(x).view(torch.bfloat16), L, ob[off:], S, B, L, 2 * H)
         off += L
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# ViLBERT (mmf/models/vilbert.py) and UNITER (mmf/models/uniter.py) on the fp32 kernels
+# ---------------------------------------------------------------------------------------------
+def _pad_k(x2, K, KP):
+    out = torch.empty(x2.shape[0], KP, dtype=F32, device=x2.device)
+    nat.pad_rows_f32(x2, K, out, KP, x2.shape[0])
+    return out
+
+
+def small_k_linear(x, weight, bias, resid=None):
+    """nn.Linear over a handful of input features (vilbert.py:906: 5-d, uniter.py:81: 7-d box geometry): operand and weight rows
+    zero-padded to a multiple of 4 columns (16-byte rows for the fp32 GEMM loader)."""
+    K = x.shape[-1]
+    KP = (K + 3) // 4 * 4
+    x2 = x.reshape(-1, K)
+    x2 = (x2 if x2.dtype == F32 else x2.float()).contiguous()
+    w = _w(weight)
+    N = w.shape[0]
+    if KP != K:
+        x2, w = _pad_k(x2, K, KP), _pad_k(w, K, KP)
+    M = x2.shape[0]
+    out = torch.empty(M, N, dtype=F32, device=x2.device)
+    nat.gemm_f32(x2, w, out, M, N, KP, KP, KP, N, bias=_w(bias), resid=resid, ldr=0 if resid is None else resid.stride(0))
+    return out.view(*x.shape[:-1], N)
+
+
+def image_feature_embeddings(feats, loc, w_img, b_img, w_loc, b_loc, ln_w, ln_b, eps):
+    """BertImageFeatureEmbeddings.forward (vilbert.py:904-913), eval mode: LayerNorm(Linear(features) + Linear(5-d location))."""
+    B, R, D = feats.shape
+    f2 = feats.reshape(B * R, D)
+    f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+    y0 = _linear(f2, w_img, b_img)
+    y = small_k_linear(loc.reshape(B * R, loc.shape[-1]), w_loc, b_loc, resid=y0)
+    out = torch.empty_like(y)
+    nat.layernorm_f32_fwd(y, _w(ln_w), _w(ln_b), out, B * R, y.shape[1], eps)
+    return out.view(B, R, -1)
+
+
+def bi_attention(img, txt, q1, k1, v1, q2, k2, v2, img_mask_add, txt_mask_add, heads):
+    """BertBiAttention.forward (vilbert.py:388-475), eval mode: (context_layer1 [B, T, bi] = text queries over image keys / values under
+    the image mask, context_layer2 [B, R, bi] = image queries over text keys / values under the text mask).  q1..v2 are the six
+    nn.Linear modules; each stream's Q | K | V is one packed fp32 GEMM."""
+    B, R, _ = img.shape
+    T = txt.shape[1]
+    BH = q1.weight.shape[0]
+    hd = BH // heads
+    _check_head(hd, max(R, T))
+    qkv1 = _linear(_rows(img), _packed(q1.weight, k1.weight, v1.weight), _packed(q1.bias, k1.bias, v1.bias))
+    qkv2 = _linear(_rows(txt), _packed(q2.weight, k2.weight, v2.weight), _packed(q2.bias, k2.bias, v2.bias))
+    dev = qkv1.device
+    scale = 1.0 / math.sqrt(hd)
+    ctx1 = torch.empty(B * T, BH, dtype=F32, device=dev)
+    nat.attention_f32_fwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, img_mask_add.reshape(B, R).contiguous(), ctx1, BH,
+                          B, heads, T, R, scale, head_dim=hd)
+    ctx2 = torch.empty(B * R, BH, dtype=F32, device=dev)
+    nat.attention_f32_fwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add.reshape(B, T).contiguous(), ctx2, BH,
+                          B, heads, R, T, scale, head_dim=hd)
+    return ctx1.view(B, T, BH), ctx2.view(B, R, BH)
+
+
+def dense_residual_ln(h, resid, weight, bias, ln_w, ln_b, eps):
+    """BertSelfOutput / BertBiOutput halves: LayerNorm(dense(h) + resid) (hf_layers.py:245-252, vilbert.py:497-512), eval mode."""
+    r2 = _rows(resid)
+    y = _linear(_rows(h), weight, bias, resid=r2)
+    out = torch.empty_like(y)
+    nat.layernorm_f32_fwd(y, _w(ln_w), _w(ln_b), out, y.shape[0], y.shape[1], eps)
+    return out.view(resid.shape)
+
+
+def feed_forward(x, w1, b1, w2, b2, ln_w, ln_b, eps):
+    """BertIntermediate + BertOutput (hf_layers.py:286-292): LayerNorm(dense2(gelu(dense1(x))) + x), eval mode."""
+    x2 = _rows(x)
+    hh = _linear(x2, w1, b1, act=1)
+    y = _linear(hh, w2, b2, resid=x2)
+    out = torch.empty_like(y)
+    nat.layernorm_f32_fwd(y, _w(ln_w), _w(ln_b), out, y.shape[0], y.shape[1], eps)
+    return out.view(x.shape)
+
+
+def attention_block(x, wq, bq, wk, bk, wv, bv, wo, bo, ln_w, ln_b, mask_add, heads, eps, qk_gate=None):
+    """BertAttentionJit.forward (hf_layers.py:233-252), eval mode, with ViLBERT's optional Q | K gates."""
+    B, S, H = x.shape
+    hd = H // heads
+    _check_head(hd, S)
+    x2 = _rows(x)
+    qkv = _linear(x2, _packed(wq, wk, wv), _packed(bq, bk, bv))
+    if qk_gate is not None:
+        nat.rowgroup_scale_f32(qkv, 3 * H, qk_gate.contiguous(), B, S, 2 * H)
+    ctx = torch.empty(B * S, H, dtype=F32, device=x2.device)
+    nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None if mask_add is None else mask_add.reshape(B, S).contiguous(),
+                          ctx, H, B, heads, S, S, 1.0 / math.sqrt(hd), head_dim=hd)
+    return dense_residual_ln(ctx.view(B, S, H), x, wo, bo, ln_w, ln_b, eps)
+
+
+def masked_mean(x, mask):
+    """(x * mask.unsqueeze(-1)).sum(1) / mask.sum(1, keepdim=True) (vilbert.py:204-205): [B, T, H], [B, T] -> [B, H]."""
+    B, T, H = x.shape
+    pool = torch.empty(B, H, dtype=F32, device=x.device)
+    nat.masked_mean_f32(_rows(x), mask.reshape(B, T).float().contiguous(), pool, B, T, H)
+    return pool
+
+
+def dynamic_gate(zq, zk):
+    """cat([1 + sigmoid(zq), 1 + sigmoid(zk)], dim=1) (vilbert.py:206-209) — the gate kernel of the throughput path is fp32 already."""
+    B, Cn = zq.shape
+    gate = torch.empty(B, 2 * Cn, dtype=F32, device=zq.device)
+    nat.gate_sigmoid_fwd(zq.contiguous(), gate, 0, B, Cn)
+    nat.gate_sigmoid_fwd(zk.contiguous(), gate, Cn, B, Cn)
+    return gate
+
+
+def _eltwise(op, a, b=None):
+    a2 = _rows(a)
+    out = torch.empty_like(a2)
+    nat.eltwise_f32(op, a2, None if b is None else _rows(b), out)
+    return out.view(a.shape)
+
+
+def eltwise_mul(a, b):
+    return _eltwise(0, a, b)
+
+
+def relu(a):
+    return _eltwise(1, a)
+
+
+def add(a, b):
+    return _eltwise(3, a, b)
+
+
+def feature_table_add(feats, idx, table):
+    """img_feat + mask_embedding(img_masks) (uniter.py:74-78) on fp32 rows; without masks the features pass through."""
+    B, R, D = feats.shape
+    f2 = feats.reshape(B * R, D)
+    f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+    if idx is None:
+        return f2.view(B, R, D)
+    y = torch.empty(B * R, D, dtype=F32, device=f2.device)
+    nat.rows_add_embed_f32(f2, idx.reshape(B, R).long().contiguous(), None, _w(table), y, B, R, R, D)
+    return y.view(B, R, D)

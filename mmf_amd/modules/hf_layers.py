@@ -13,6 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from mmf_amd import functional as Fn
+from mmf_amd import fp32_path as F32P
 from mmf_amd import ops  # noqa: F401  (registers torch.ops.mmf_amd.*)
 
 
@@ -132,6 +133,10 @@ class BertSelfAttentionJit(nn.Module):
     @torch.jit.unused
     def dynamic_gate(self, txt_embedding, txt_attention_mask):
         """fp32 [B, 2 * all_head_size]: 1 + sigmoid(dyLinear_{q,k}(masked mean of the text stream)) (vilbert.py:204-209)."""
+        if F32P.active():      # fp32-accurate forward (mmf_amd.fp32_inference())
+            pool = F32P.masked_mean(txt_embedding, txt_attention_mask)
+            return F32P.dynamic_gate(F32P.linear(pool, self.dyLinear_q.weight, self.dyLinear_q.bias),
+                                     F32P.linear(pool, self.dyLinear_k.weight, self.dyLinear_k.bias))
         pool = Fn.MaskedMeanFn.apply(txt_embedding, txt_attention_mask)
         zq = torch.ops.mmf_amd.linear(pool, self.dyLinear_q.weight, self.dyLinear_q.bias, True)
         zk = torch.ops.mmf_amd.linear(pool, self.dyLinear_k.weight, self.dyLinear_k.bias, True)
@@ -334,6 +339,11 @@ class BertEmbeddingsJit(nn.Module):
             raise NotImplementedError("explicit position_ids / inputs_embeds are not on the built paths")
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
+        if F32P.active():      # fp32-accurate forward (mmf_amd.fp32_inference())
+            F32P.check_no_dropout(self.dropout_prob, self.training)
+            return F32P.visio_linguistic_embeddings(input_ids, token_type_ids, None, None, self.word_embeddings.weight,
+                                                    self.position_embeddings.weight, self.token_type_embeddings.weight, self.LayerNorm.weight,
+                                                    self.LayerNorm.bias, None, None, None, None, self.LayerNorm.eps)
         z = self.word_embeddings.weight.new_zeros(1, self.word_embeddings.weight.shape[1])
         return Fn.VisioLinguisticEmbeddingsFn.apply(
             input_ids, token_type_ids, None, None, self.word_embeddings.weight, self.position_embeddings.weight,

@@ -110,12 +110,14 @@ def _gemm_f32(A, B, C_out, M, Nn, K, lda, ldb, ldc, bias=None, coladd=None, rowt
     calls.append(("gemm_f32", M, Nn, K))
 
 
-def _attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64):
-    assert head_dim == 64 and Sk <= 256
+def _attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64, causal_tail=0):
+    assert (head_dim == 64 and Sk <= 256) or (head_dim == 128 and Sk <= 128)
+    assert 0 <= causal_tail <= Sk and (causal_tail == 0 or Sq == Sk)
     for t in (q, k, v, ctx):
         assert t.dtype == torch.float32
-    _need(q, B * Sq, ldq, heads * 64, "attention_f32 q"); _need(k, B * Sk, ldk, heads * 64, "attention_f32 k")
-    _need(v, B * Sk, ldv, heads * 64, "attention_f32 v"); _need(ctx, B * Sq, ldo, heads * 64, "attention_f32 ctx")
+    hd = head_dim
+    _need(q, B * Sq, ldq, heads * hd, "attention_f32 q"); _need(k, B * Sk, ldk, heads * hd, "attention_f32 k")
+    _need(v, B * Sk, ldv, heads * hd, "attention_f32 v"); _need(ctx, B * Sq, ldo, heads * hd, "attention_f32 ctx")
     assert mask is None or (mask.dtype == torch.float32 and mask.numel() >= B * Sk)
     calls.append(("attention_f32_fwd", B, heads, Sq, Sk))
 

@@ -92,7 +92,34 @@ def test_unsupported_shapes_fail_loudly():
     x = torch.zeros(2, 8, 96)
     w = torch.zeros(96, 96); b = torch.zeros(96); g = torch.ones(96)
     with native_stub.installed(), mmf_amd.fp32_inference():
-        with pytest.raises(NotImplementedError, match="head_dim 64"):
+        with pytest.raises(NotImplementedError, match="head_dim 64 and 128"):
             fp32_path.transformer_layer(x, w, b, w, b, w, b, w, b, g, b, w, b, w, b, g, b, None, 3, 1e-12, 1e-12)
         with pytest.raises(TypeError, match="float32"):
             fp32_path.layer_norm(x.bfloat16(), g, b, 1e-12)
+
+
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_nlvr2"])
+def test_vilbert_routes_to_the_fp32_kernels_only(name):
+    """Every kernel a ViLBERT forward launches inside fp32_inference() is an fp32 one (no bf16 GEMM / attention / LayerNorm)."""
+    z, case, cfg, sd, sample = G.load_vilbert_case(name)
+    over = dict(training_head_type="nlvr2", losses=[dict(type="cross_entropy")]) if name == "vilbert_nlvr2" else {}
+    model = MU.build_vilbert(cfg, sd, device="cpu", **over)
+    model.eval()
+    extra = {"pad_rows_f32", "eltwise_f32", "masked_mean_f32", "rowgroup_scale_f32", "gate_sigmoid_fwd"}
+    with native_stub.installed() as calls, mmf_amd.fp32_inference():
+        out = model(SampleList(sample))
+        assert _names(calls) <= FP32_CALLS | extra, _names(calls) - FP32_CALLS - extra
+        assert any(c[0] == "attention_f32_fwd" and c[3] != c[4] for c in calls)          # the co-attention: Sq != Sk
+        assert ("rowgroup_scale_f32" in _names(calls)) == (name == "vilbert_dyn")
+    assert out["scores"].dtype == torch.float32 and out["scores"].shape == tuple(z["scores"].shape)
+
+
+def test_uniter_routes_to_the_fp32_kernels_only():
+    z, case, cfg, sd, sample = G.load_uniter_case()
+    model = MU.build_uniter(cfg, sd, device="cpu")
+    model.eval()
+    extra = {"pad_rows_f32", "eltwise_f32", "rows_add_embed_f32"}
+    with native_stub.installed() as calls, mmf_amd.fp32_inference():
+        out = model(SampleList(sample))
+        assert _names(calls) <= FP32_CALLS | extra, _names(calls) - FP32_CALLS - extra
+    assert out["scores"].dtype == torch.float32 and out["scores"].shape == tuple(z["scores"].shape)

@@ -75,29 +75,56 @@ def test_gemm_f32_rejects_what_it_does_not_compute():
         nat.gemm_f32(a.bfloat16(), w, c, 8, 8, 4, 8, 8, 8)
 
 
-@pytest.mark.parametrize("B,heads,Sq,Sk", [(2, 2, 24, 24), (3, 2, 100, 100), (2, 12, 228, 228), (1, 1, 256, 256), (2, 3, 40, 150), (2, 2, 1, 33)])
-def test_attention_f32_matches_float64(B, heads, Sq, Sk):
-    H = heads * 64
+@pytest.mark.parametrize("B,heads,Sq,Sk,hd", [(2, 2, 24, 24, 64), (3, 2, 100, 100, 64), (2, 12, 228, 228, 64), (1, 1, 256, 256, 64), (2, 3, 40, 150, 64),
+                                              (2, 2, 1, 33, 64), (2, 8, 101, 101, 128), (2, 8, 101, 128, 128), (3, 2, 128, 37, 128), (1, 1, 1, 128, 128)])
+def test_attention_f32_matches_float64(B, heads, Sq, Sk, hd):
+    """head_dim 64 (Sk <= 256) and 128 (Sk <= 128: ViLBERT's image stream 8 x 128 and both co-attention directions)."""
+    H = heads * hd
+    scale = 1.0 / hd ** 0.5
     q, k, v = _rand(B * Sq, H, seed=1), _rand(B * Sk, H, seed=2), _rand(B * Sk, H, seed=3)
     mask = torch.zeros(B, Sk)
     mask[0, Sk // 2:] = -10000.0
     mask[-1, ::3] = -10000.0
     mask[-1, 0] = 0.0
     out = torch.full((B * Sq, H), float("nan"), device="cuda")
-    nat.attention_f32_fwd(q.cuda(), k.cuda(), v.cuda(), H, H, H, mask.cuda(), out, H, B, heads, Sq, Sk, 0.125)
-    qd = q.double().view(B, Sq, heads, 64).transpose(1, 2)
-    kd = k.double().view(B, Sk, heads, 64).transpose(1, 2)
-    vd = v.double().view(B, Sk, heads, 64).transpose(1, 2)
-    s = qd @ kd.transpose(-1, -2) * 0.125 + mask.double()[:, None, None, :]
+    nat.attention_f32_fwd(q.cuda(), k.cuda(), v.cuda(), H, H, H, mask.cuda(), out, H, B, heads, Sq, Sk, scale, head_dim=hd)
+    qd = q.double().view(B, Sq, heads, hd).transpose(1, 2)
+    kd = k.double().view(B, Sk, heads, hd).transpose(1, 2)
+    vd = v.double().view(B, Sk, heads, hd).transpose(1, 2)
+    s = qd @ kd.transpose(-1, -2) * scale + mask.double()[:, None, None, :]
     ref = (torch.softmax(s, -1) @ vd).transpose(1, 2).reshape(B * Sq, H)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=KERNEL_TOL, atol=KERNEL_TOL)
     # packed Q|K|V operand (ld = 3H), no mask
     if Sq == Sk:
         qkv = torch.cat([q, k, v], dim=1).cuda()
         out2 = torch.empty(B * Sq, H, device="cuda")
-        nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, out2, H, B, heads, Sq, Sk, 0.125)
-        ref2 = (torch.softmax(qd @ kd.transpose(-1, -2) * 0.125, -1) @ vd).transpose(1, 2).reshape(B * Sq, H)
+        nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, out2, H, B, heads, Sq, Sk, scale, head_dim=hd)
+        ref2 = (torch.softmax(qd @ kd.transpose(-1, -2) * scale, -1) @ vd).transpose(1, 2).reshape(B * Sq, H)
         torch.testing.assert_close(out2.cpu().double(), ref2, rtol=KERNEL_TOL, atol=KERNEL_TOL)
+
+
+@pytest.mark.parametrize("S,tail,hd", [(70, 12, 64), (228, 12, 64), (40, 40, 64), (128, 5, 128)])
+def test_attention_f32_prefix_lm_tail(S, tail, hd):
+    """M4C's prefix-LM mask (m4c.py:424-440) without the [B,1,L,L] tensor: the last `tail` keys are visible only to the tail's own
+    queries, causally, whatever the key mask says; every other pair uses the key mask."""
+    B, heads = 2, 2
+    H = heads * hd
+    scale = 1.0 / hd ** 0.5
+    q, k, v = _rand(B * S, H, seed=4), _rand(B * S, H, seed=5), _rand(B * S, H, seed=6)
+    key_mask = torch.ones(B, S)
+    key_mask[0, 3:9] = 0
+    key_mask[:, S - tail:] = 0                                    # dec_mask = zeros, m4c.py:424
+    ext = key_mask[:, None, None, :].repeat(1, 1, S, 1)           # m4c.py:431-433
+    ext[:, :, S - tail:, S - tail:] = torch.tril(torch.ones(tail, tail))   # :437-439
+    ext = (1.0 - ext) * -10000.0
+    out = torch.full((B * S, H), float("nan"), device="cuda")
+    nat.attention_f32_fwd(q.cuda(), k.cuda(), v.cuda(), H, H, H, ((1.0 - key_mask) * -10000.0).cuda(), out, H, B, heads, S, S, scale, head_dim=hd,
+                          causal_tail=tail)
+    qd = q.double().view(B, S, heads, hd).transpose(1, 2)
+    kd = k.double().view(B, S, heads, hd).transpose(1, 2)
+    vd = v.double().view(B, S, heads, hd).transpose(1, 2)
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) * scale + ext.double(), -1) @ vd).transpose(1, 2).reshape(B * S, H)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=KERNEL_TOL, atol=KERNEL_TOL)
 
 
 @pytest.mark.parametrize("rows,H", [(5, 32), (37, 128), (300, 768), (9, 1024), (3, 2048)])
@@ -249,3 +276,81 @@ def test_mmft_golden_within_the_fp32_bound():
     e_loss = abs(loss.item() - float(z["loss"])) / abs(float(z["loss"]))
     _record("golden_mmft", scores_max_abs=e, sequence_output_max_abs=e_seq, loss_rel=e_loss)
     assert seq["seq"].dtype == torch.float32 and e <= TOL_FP32 and e_seq <= TOL_FP32 and e_loss <= TOL_FP32, (e, e_seq, e_loss)
+
+
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_nlvr2"])
+def test_vilbert_golden_within_the_fp32_bound(name):
+    """ViLBERT (a file north_star names) on the fp32 kernels: two streams, co-attention, the `dynamic_attention` gates and the nlvr2
+    pairing against the fixtures the real reference produced — scores, both sequence outputs, both pooled outputs and the loss."""
+    from tests.model_utils import build_vilbert
+    z, case, cfg, sd, sample = G.load_vilbert_case(name)
+    over = dict(training_head_type="nlvr2", losses=[dict(type="cross_entropy")]) if name == "vilbert_nlvr2" else {}
+    model = build_vilbert(cfg, sd, **over)
+    model.eval()
+    got = {}
+    hook = model.model.bert.register_forward_hook(lambda m, i, o: got.update(sequence_output_t=o[0], sequence_output_v=o[1],
+                                                                             pooled_output_t=o[2], pooled_output_v=o[3]))
+    with mmf_amd.fp32_inference():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    hook.remove()
+    errs = {"scores": float(np.abs(out["scores"].cpu().numpy() - z["scores"]).max())}
+    for k, v in got.items():
+        assert v.dtype == torch.float32, k
+        if k in z.files:
+            errs[k] = float(np.abs(v.cpu().numpy() - z[k]).max())
+    (key, loss), = out["losses"].items()
+    errs["loss_rel"] = abs(loss.item() - float(z["loss"])) / abs(float(z["loss"]))
+    _record("golden_" + name, **errs)
+    assert len(errs) >= 4 and all(e <= TOL_FP32 for e in errs.values()), errs
+
+
+def test_vilbert_real_stream_widths_within_the_fp32_bound():
+    """BASELINE.json configs[3]'s widths (text 768 / 12 heads, visual 1024 / 8, co-attention 1024 / 8: head_dim 128; T = 128, R = 100,
+    3129 labels) with fewer layers, against the pinned CPU oracle."""
+    from oracle import vilbert_oracle as VO
+    from tests.model_utils import build_vilbert
+    cfg = dict(VO.DEFAULT_CONFIG)
+    cfg.update(num_hidden_layers=3, v_num_hidden_layers=2, v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=2000,
+               max_position_embeddings=128, initializer_range=0.02)
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for k, shp in VO.parameter_shapes(cfg).items():
+        sd[k] = (1.0 + 0.05 * torch.randn(shp, generator=g)) if "LayerNorm" in k and k.endswith(".weight") else 0.02 * torch.randn(shp, generator=g)
+    sd["bert.embeddings.word_embeddings.weight"][0].zero_()
+    B, T, R = 4, 128, 100
+    ids = torch.randint(1, cfg["vocab_size"], (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.long); mask[1, 90:] = 0; ids[mask == 0] = 0
+    targets = torch.zeros(B, cfg["num_labels"]); targets[0, 5] = 1.0; targets[1, 17] = 0.6
+    sample = {"input_ids": ids, "input_mask": mask, "segment_ids": torch.zeros(B, T, dtype=torch.long),
+              "image_feature_0": torch.randn(B, R, cfg["v_feature_size"], generator=g),
+              "image_info_0": {"max_features": torch.tensor([100, 73, 100, 12]), "bbox": torch.rand(B, R, 5, generator=g)},
+              "targets": targets, "dataset_name": "vqa2", "dataset_type": "train"}
+    model = build_vilbert(cfg, sd)
+    model.eval()
+    with mmf_amd.fp32_inference():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    with torch.no_grad():
+        ref = VO.vilbert_forward(sd, cfg, dict(sample))
+    e = (out["scores"].cpu() - ref["scores"]).abs().max().item()
+    _record("vilbert_real_widths", scores_max_abs=e)
+    assert out["scores"].dtype == torch.float32 and e <= TOL_FP32, e
+
+
+def test_uniter_golden_within_the_fp32_bound():
+    """UNITER (feature + mask-embedding rows, 7-d box geometry Linear, three LayerNorms, text block, concat, encoder, MLP head) on the
+    fp32 kernels against the real reference's fixture."""
+    from tests.model_utils import build_uniter
+    z, case, cfg, sd, sample = G.load_uniter_case()
+    model = build_uniter(cfg, sd)
+    model.eval()
+    got = {}
+    hook = model.uniter.uniter.register_forward_hook(lambda m, i, o: got.update(seq=o[0]))
+    with mmf_amd.fp32_inference():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    hook.remove()
+    e = float(np.abs(out["scores"].cpu().numpy() - z["scores"]).max())
+    e_seq = float(np.abs(got["seq"].cpu().numpy() - z["sequence_output"]).max())
+    (key, loss), = out["losses"].items()
+    e_loss = abs(loss.sum().item() - float(z["loss"])) / abs(float(z["loss"]))
+    _record("golden_uniter", scores_max_abs=e, sequence_output_max_abs=e_seq, loss_rel=e_loss)
+    assert got["seq"].dtype == torch.float32 and e <= TOL_FP32 and e_seq <= TOL_FP32 and e_loss <= TOL_FP32, (e, e_seq, e_loss)

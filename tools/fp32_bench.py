@@ -54,6 +54,16 @@ def main():
     qkv = torch.randn(B * S, 3 * H, device=dev); ctx = torch.empty(B * S, H, device=dev); mask = torch.zeros(B, S, device=dev)
     t = timed(lambda: nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, B, heads, S, S, 0.125))
     res["attention_f32_fwd"] = dict(us=round(t * 1e3, 1), tflops=round(4.0 * B * heads * S * S * 64 / t / 1e9, 1))
+    # ViLBERT (BASELINE configs[3]): visual stream 8 heads x 128 over 101 regions; co-attention 128 text queries over 101 region keys
+    Bv, hv, R, T, Hv = 32, 8, 101, 128, 1024
+    qv = torch.randn(Bv * R, 3 * Hv, device=dev); qt = torch.randn(Bv * T, 3 * Hv, device=dev)
+    cv = torch.empty(Bv * R, Hv, device=dev); ct = torch.empty(Bv * T, Hv, device=dev)
+    sc = 1.0 / math.sqrt(128.0)
+    t = timed(lambda: nat.attention_f32_fwd(qv, qv[:, Hv:], qv[:, 2 * Hv:], 3 * Hv, 3 * Hv, 3 * Hv, None, cv, Hv, Bv, hv, R, R, sc, head_dim=128))
+    res["attention_f32_fwd_d128_self_101"] = dict(us=round(t * 1e3, 1), tflops=round(4.0 * Bv * hv * R * R * 128 / t / 1e9, 1))
+    t = timed(lambda: nat.attention_f32_fwd(qt, qv[:, Hv:], qv[:, 2 * Hv:], 3 * Hv, 3 * Hv, 3 * Hv, None, ct, Hv, Bv, hv, T, R, sc, head_dim=128))
+    res["attention_f32_fwd_d128_cross_128x101"] = dict(us=round(t * 1e3, 1), tflops=round(4.0 * Bv * hv * T * R * 128 / t / 1e9, 1))
+    print(res["attention_f32_fwd_d128_self_101"], res["attention_f32_fwd_d128_cross_128x101"], flush=True)
     x = torch.randn(B * S, H, device=dev); g = torch.ones(H, device=dev); be = torch.zeros(H, device=dev); y = torch.empty_like(x)
     t = timed(lambda: nat.layernorm_f32_fwd(x, g, be, y, B * S, H, 1e-12))
     res["layernorm_f32_fwd"] = dict(us=round(t * 1e3, 1), gbps=round(2.0 * x.numel() * 4 / t / 1e6, 1))

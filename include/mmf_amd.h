@@ -495,16 +495,20 @@ int mmf_transpose_bf16_multi(const mmf_transpose_list* d, void* stream);
  * exact fp32 products, fp32 accumulation), so that outputs agree with the reference to fp32 round-off (the 1e-3 bound).
  * Forward (inference / evaluation) only.
  *
- * mmf_gemm_f32: the forward form of mmf_gemm_bf16 (a_kmajor = b_kmajor = 0) with A, B, C and resid fp32 (set a_f32 = b_f32 =
- * out_f32 = 1); epilogue bias, coladd, rowtab[rowidx], act 0 / 1 (exact-erf GELU, libm erff) / 3 (tanh), resid, row remap.
- * K, lda, ldb multiples of 4; no U / aux / dropout / split-K / beta.  Replaces nn.Linear forward at hf_layers.py:169-180,
- * 248, 289-290, embeddings.py:352, visual_bert.py:146, 328-330.
+ * mmf_gemm_f32: mmf_gemm_bf16 with A, B, C, U, aux and resid fp32 (set a_f32 = b_f32 = out_f32 = 1) on v_mfma_f32_16x16x4_f32: the
+ * forward (row, row), dgrad (row, k-major) and weight-gradient (k-major, k-major) layouts; the epilogue of mmf_gemm_bf16 (bias,
+ * coladd, rowtab[rowidx], act 0-4 with exact-erf GELU and its saved derivative U, dropout, resid, beta, row remap) except
+ * rowsum_out (mmf_colsum_f32); deterministic split-K through splitk_ws (no epilogue besides beta then).  lda, ldb multiples of 4;
+ * a row operand's leading dimension must cover round_up(K, 4) with zeros in the padding.  Replaces nn.Linear forward at hf_layers.py:169-180, 248, 289-290, embeddings.py:352,
+ * visual_bert.py:146, 328-330 and, for fp32 training (training_loop.py:199-211), its autograd dgrad / wgrad.
  * mmf_attention_f32_fwd: mmf_attention_fwd with q / k / v / ctx fp32 (hf_layers.py:161-213 in eval mode; vilbert.py:153-247, 388-475):
  * head_dim 64 with Sk <= 256 or head_dim 128 with Sk <= 128, Sq != Sk allowed, key mask and the prefix-LM causal_tail (m4c.py:424-440);
- * K and V of a (batch, head) are staged once per workgroup in LDS.  lse, ctx_f32, dropout and the K|V-cache strides must be unset.
+ * K and V of a (batch, head) are staged once per workgroup in LDS.  Optional lse output and probability dropout (training); ctx_f32 and
+ * the K|V-cache strides must be unset.
  * mmf_layernorm_f32_fwd: nn.LayerNorm over fp32 rows (hf_layers.py:248,290; embeddings.py:456; visual_bert.py:328).
  * mmf_embed_text_f32_fwd / mmf_gather_rows_f32: mmf_embed_text_fwd / mmf_gather_rows (no dropout) writing / moving fp32 rows. */
 int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream);
+int mmf_gemm_f32_splits(int M, int N, int K);   /* K splits mmf_gemm_f32 uses for this shape when given splitk_ws (>= splits * M * N * 4 bytes) */
 int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream);
 int mmf_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int H, float eps, void* stream);
 int mmf_embed_text_f32_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos, const float* type, float* y,
@@ -514,8 +518,36 @@ int mmf_gather_rows_f32(const float* x, const int64_t* index, float* out, int B,
 int mmf_rows_add_embed_f32(const float* x, const int64_t* seg, const float* pos, const float* type, float* y, int B, int L, int S, int H,
                            int row0, int pos0, void* stream);
 
+/* ---- fp32 training (round 3): the backward kernels of the fp32 path (mmf_amd/csrc/fp32_train.hip, attention in fp32_path.hip) ----
+ * The reference trains in fp32 unless `training.fp16` is set (mmf/trainers/core/training_loop.py:199-211); `mmf_amd.fp32_training()`
+ * runs the VisualBERT training step on these kernels plus mmf_gemm_f32's dgrad / weight-gradient layouts.
+ * mmf_attention_f32_bwd: autograd of mmf_attention_f32_fwd (hf_layers.py:161-213).  All tensors fp32; f.ctx = the forward output O,
+ *   f.lse = the row statistic the forward saved (row maximum + log2 of the row sum of the scaled, masked scores in log2 units),
+ *   delta = workspace [B, heads, Sq]; dq / dk / dv in the layouts of q / k / v; same dropout key as the forward; two launches
+ *   (dQ with K, V staged in LDS; dK, dV with Q, dO staged), no atomics.
+ * mmf_layernorm_f32_fwd_stats: mmf_layernorm_f32_fwd that also returns mean and rstd [rows]; mmf_layernorm_f32_bwd: dx, dgamma, dbeta
+ *   (partials: workspace of mmf_layernorm_f32_bwd_blocks(rows) * 2 * H floats).
+ * mmf_colsum_f32: out[n] (+)= sum_rows x[row][n] (bias gradients), ws >= mmf_colsum_f32_slices(rows) * N floats.
+ * mmf_dropout_f32: y = x * keepscale(hash(key, element index)), forward and backward of nn.Dropout on fp32 rows.
+ * mmf_scatter_add_rows_f32: out[idx[r] + r * dst_stride] += g[src(r)] with src(r) = (r / grp) * grp_stride + grp_off + r % grp for
+ *   grp > 0 (else r): autograd of the embedding gathers (rows with idx == skip, nn.Embedding's padding_idx, are dropped) and of the
+ *   pooling gather (dst_stride = S).  fp32 atomics. */
+int mmf_attention_f32_bwd(const mmf_attn_bwd_desc* d, void* stream);
+int mmf_layernorm_f32_fwd_stats(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows, int H,
+                                float eps, void* stream);
+int mmf_layernorm_f32_bwd_blocks(int rows);
+int mmf_layernorm_f32_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
+                          float* dbeta, float* partials, int rows, int H, void* stream);
+int mmf_colsum_f32_slices(int rows);
+int mmf_colsum_f32(const float* x, int ld, int rows, int N, float* out, int accumulate, float* ws, void* stream);
+int mmf_dropout_f32(const float* x, float* y, long n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream);
+int mmf_scatter_add_rows_f32(const float* g, int ld, int rows, int H, int grp, int grp_stride, int grp_off, const int64_t* idx, long dst_stride,
+                             long skip, int NT, float* out, int ldo, void* stream);
+/* mmf_bce_logits_bwd with an fp32 gradient (exact expf). */
+int mmf_bce_logits_f32_bwd(const float* scores, const float* targets, const float* gloss, float* dscores, int B, int N, void* stream);
+
 /* fp32 row operators of the widened models on the fp32 path: zero-padded copy of short rows (the 5-d / 7-d box geometry operands of
- * vilbert.py:906 / uniter.py:81 become 16-byte rows), element-wise a * b (op 0), relu (1), a + b (3) (vilbert.py:803,818,1318;
+ * vilbert.py:906 / uniter.py:81 become 16-byte rows), element-wise a * b (op 0), relu (1), a + b (3), a (1 - b^2) (4: tanh backward) (vilbert.py:803,818,1318;
  * uniter.py:82), and the dynamic_attention pooling / gating of vilbert.py:204-212 (mmf_masked_mean_fwd / mmf_rowgroup_scale on fp32). */
 int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int rows, void* stream);
 int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, void* stream);

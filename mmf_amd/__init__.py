@@ -7,6 +7,7 @@ the same way `mmf.utils.env.setup_imports` fills MMF's registry.
 from mmf_amd.common.registry import registry  # noqa: F401
 from mmf_amd.common.sample import Sample, SampleList  # noqa: F401
 from mmf_amd.fp32_path import fp32_inference  # noqa: F401
+from mmf_amd.fp32_train import fp32_training  # noqa: F401
 from mmf_amd.modules import losses as _losses  # noqa: F401
 from mmf_amd.modules import optimizers as _optimizers  # noqa: F401
 from mmf_amd.modules import schedulers as _schedulers  # noqa: F401

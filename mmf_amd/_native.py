@@ -612,37 +612,102 @@ def soft_target_kl_bwd(logits, target, row_label, lse, tsum, count, gloss, dlogi
 # fp32-accurate forward path (mmf_amd/csrc/fp32_path.hip)
 # --------------------------------------------------------------------------------------------
 def gemm_f32(A, B, C_out, M, N, K, lda, ldb, ldc, bias=None, coladd=None, rowtab=None, rowidx=None, rowtab_ld=0, act=0, resid=None,
-             ldr=0, grp=(0, 0, 0)):
-    """C = epilogue(A B^T) with A [M, K], B [N, K], C and resid all fp32 on the fp32-input MFMA (forward form only)."""
-    for t, n in ((A, "A"), (B, "B"), (C_out, "C"), (resid, "resid"), (bias, "bias"), (coladd, "coladd"), (rowtab, "rowtab")):
+             ldr=0, grp=(0, 0, 0), a_kmajor=False, b_kmajor=False, U=None, aux=None, drop=NO_DROP, beta=0.0, split_k=False):
+    """C = epilogue(A B^T) on the fp32-input MFMA, everything fp32.  Layouts: forward (A [M, K], B [N, K]), dgrad (b_kmajor: B [K, N]),
+    weight gradient (a_kmajor and b_kmajor: A [K, M], B [K, N]; `split_k` lets the library split the long contraction over slabs)."""
+    for t, n in ((A, "A"), (B, "B"), (C_out, "C"), (resid, "resid"), (bias, "bias"), (coladd, "coladd"), (rowtab, "rowtab"), (U, "U"), (aux, "aux")):
         _req(t, torch.float32, n)
     _req(rowidx, torch.int64, "rowidx")
     d = GemmDesc()
     d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
     d.a_f32 = d.b_f32 = d.out_f32 = 1
+    d.beta = beta
     d.bias, d.coladd, d.rowtab, d.rowidx, d.rowtab_ld = _p(bias), _p(coladd), _p(rowtab), _p(rowidx), rowtab_ld
     d.act = act
+    d.U, d.aux = _p(U), _p(aux)
     d.resid, d.ldr = _p(resid), ldr
-    d.drop_scale = 1.0
+    d.drop_key, d.drop_thr16, d.drop_scale, d.drop_seed = _drop4(drop)
     d.grp_in, d.grp_pad, d.grp_off = grp
+    if split_k:
+        sp = lib().mmf_gemm_f32_splits(M, N, K)
+        if sp > 1:
+            ws = torch.empty(sp * M * N, dtype=torch.float32, device=C_out.device)
+            d.splitk_ws, d.splitk_ws_bytes = _p(ws), ws.numel() * 4
     _check(lib().mmf_gemm_f32(C.byref(d), _stream()), "mmf_gemm_f32")
 
 
-def attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64, causal_tail=0):
-    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx"), (mask, "mask")):
+def _attn_f32_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim, causal_tail, lse, drop):
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx"), (mask, "mask"), (lse, "lse")):
         _req(t, torch.float32, n)
     d = AttnDesc()
     d.q, d.k, d.v = _p(q), _p(k), _p(v)
     d.ldq, d.ldk, d.ldv = ldq, ldk, ldv
-    d.mask, d.ctx, d.ldo = _p(mask), _p(ctx), ldo
+    d.mask, d.ctx, d.ldo, d.lse = _p(mask), _p(ctx), ldo, _p(lse)
     d.B, d.heads, d.Sq, d.Sk = B, heads, Sq, Sk
     d.scale = scale
-    d.drop_scale = 1.0
+    d.drop_key, d.drop_thr16, d.drop_scale, d.drop_seed = _drop4(drop)
     d.head_dim = head_dim
     d.causal_tail = causal_tail
+    return d
+
+
+def attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64, causal_tail=0, lse=None, drop=NO_DROP):
+    """`lse` (fp32 [B, heads, Sq], optional) receives the row statistic mmf_attention_f32_bwd needs; `drop`: probability dropout (training)."""
+    d = _attn_f32_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim, causal_tail, lse, drop)
     _check(lib().mmf_attention_f32_fwd(C.byref(d), _stream()), "mmf_attention_f32_fwd")
+
+
+def attention_f32_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta, head_dim=64, causal_tail=0,
+                      drop=NO_DROP):
+    d = AttnBwdDesc()
+    d.f = _attn_f32_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim, causal_tail, lse, drop)
+    for t, n in ((dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv"), (delta, "delta")):
+        _req(t, torch.float32, n)
+    d.dctx, d.dq, d.dk, d.dv, d.delta = _p(dctx), _p(dq), _p(dk), _p(dv), _p(delta)
+    _check(lib().mmf_attention_f32_bwd(C.byref(d), _stream()), "mmf_attention_f32_bwd")
+
+
+def layernorm_f32_fwd_stats(x, gamma, beta, y, mean, rstd, rows, H, eps):
+    for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta"), (y, "y"), (mean, "mean"), (rstd, "rstd")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_layernorm_f32_fwd_stats(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, H, C.c_float(eps), _stream()),
+           "mmf_layernorm_f32_fwd_stats")
+
+
+def layernorm_f32_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, H):
+    for t, n in ((dy, "dy"), (x, "x"), (mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (dx, "dx"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _req(t, torch.float32, n)
+    ws = torch.empty(lib().mmf_layernorm_f32_bwd_blocks(rows) * 2 * H, dtype=torch.float32, device=dy.device)
+    _check(lib().mmf_layernorm_f32_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, H, _stream()),
+           "mmf_layernorm_f32_bwd")
+
+
+def colsum_f32(x, ld, rows, N, out, accumulate=False):
+    _req(x, torch.float32, "x"); _req(out, torch.float32, "out")
+    ws = torch.empty(lib().mmf_colsum_f32_slices(rows) * N, dtype=torch.float32, device=x.device)
+    _check(lib().mmf_colsum_f32(_p(x), ld, rows, N, _p(out), int(accumulate), _p(ws), _stream()), "mmf_colsum_f32")
+
+
+def dropout_f32(x, y, drop):
+    _req(x, torch.float32, "x"); _req(y, torch.float32, "y")
+    key, thr, scale, seed = _drop4(drop)
+    _check(lib().mmf_dropout_f32(_p(x), _p(y), C.c_long(x.numel()), key, thr, C.c_float(scale), seed, _stream()), "mmf_dropout_f32")
+
+
+def bce_logits_f32_bwd(scores, targets, gloss, dscores, B, N):
+    for t, n in ((scores, "scores"), (targets, "targets"), (gloss, "gloss"), (dscores, "dscores")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_bce_logits_f32_bwd(_p(scores), _p(targets), _p(gloss), _p(dscores), B, N, _stream()), "mmf_bce_logits_f32_bwd")
+
+
+def scatter_add_rows_f32(g, ld, rows, H, idx, out, ldo, grp=(0, 0, 0), dst_stride=0, skip=-1):
+    """out[idx[r] + r * dst_stride] += g[src(r)], src(r) = (r // grp[0]) * grp[1] + grp[2] + r % grp[0] when grp[0] > 0 (else r)."""
+    _req(g, torch.float32, "g"); _req(out, torch.float32, "out"); _req(idx, torch.int64, "idx")
+    _check(lib().mmf_scatter_add_rows_f32(_p(g), ld, rows, H, grp[0], grp[1], grp[2], _p(idx), C.c_long(dst_stride), C.c_long(skip),
+                                          int(out.shape[0]), _p(out), ldo, _stream()), "mmf_scatter_add_rows_f32")
 
 
 def layernorm_f32_fwd(x, gamma, beta, y, rows, H, eps):

@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 INCLUDE = os.path.join(ROOT, "include")
-SOURCES = ["lib.hip", "gemm.hip", "attention.hip", "rowops.hip", "m4c_ops.hip", "gate_ops.hip", "transpose.hip", "fp32_path.hip", "uniter_ops.hip"]
+SOURCES = ["lib.hip", "gemm.hip", "attention.hip", "rowops.hip", "m4c_ops.hip", "gate_ops.hip", "transpose.hip", "fp32_path.hip", "fp32_train.hip", "uniter_ops.hip"]
 LIB = os.path.join(os.path.dirname(HERE), "libmmf_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [

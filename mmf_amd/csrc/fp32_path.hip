@@ -19,126 +19,234 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// GEMM: C[m][n] = epilogue(sum_k A[m][k] * B[n][k]), everything fp32.
-// 128x128 (or 64x128) tile per 256-thread workgroup, BK = 16; wave w owns a 64x64 (32x64) quadrant = 2x2 (1x2) MFMA tiles of 32x32.  Operands go global -> registers (16-byte loads along K) -> LDS as K-MAJOR images [k][row] (row stride 132
-// floats: the four k-quads of a wave's stores land in disjoint bank groups), so that the MFMA operand of lane l —
-// A[row = l & 31][k = l >> 5] — is a conflict-free ds_read_b32 of consecutive rows.  Register double buffering: the next
-// K-step's global loads are in flight while the MFMAs of the current one run; one barrier per K-step.
+// GEMM: C[m][n] = epilogue(sum_k A(m,k) * B(n,k)), everything fp32, on v_mfma_f32_16x16x4_f32 (round 3 rewrite; the round-2 kernel
+// ran the 32x32x2 MFMA from k-major LDS images with one scalar LDS read per operand register: 80-98 TFLOP/s).
+// 128x128 (or 64x128) tile per 256-thread workgroup, BK = 16; wave w owns a 64x64 (32x64) quadrant = 4x4 (4x2) MFMA blocks.
+// Both operand tiles live in LDS ROW-major, [row][k] at a row stride of BK + 4 = 20 floats, whatever their layout in memory:
+//   * a row operand (k contiguous in memory) is copied 16 bytes at a time;
+//   * a k-major operand (the dgrad's weight, both operands of a weight gradient) is transposed by the staging stores, with the lanes
+//     of a wave laid out 16 k x 4 row-quads so that the scalar stores hit 64 distinct banks.
+// The MFMA's k-slot (lane / 16) is mapped to the k QUAD 4 (lane / 16) + c, so ONE 16-byte LDS read per 16-row block feeds four MFMAs
+// (the operand rows of a wave are 8 ds_read_b128 per K-step for 64 MFMAs).  The product is formed TRANSPOSED (MFMA A operand = the
+// B tile's rows): the accumulator register r of lane l then holds C[m = block row l % 16][n = 4 (l / 16) + r], four consecutive
+// columns — bias / residual / saved-derivative reads and the C stores are 16 bytes per lane.
+// Register double buffering: the next K-step's global loads are in flight while the MFMAs of the current one run; one barrier per
+// K-step; split-K over gridDim.z into fp32 slabs (weight gradients: K = B S rows, few output tiles) summed by splitk_f32_reduce.
 // ------------------------------------------------------------------------------------------------
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
+constexpr int GBM = 128, GBN = 128, GBK = 16, GRS = GBK + 4;    // (BK = 16: 41 KB of LDS, a barrier every 64 MFMAs per wave; 32: 74 KB, every 128)
 
 struct GemmF32 {
     const float* A; const float* B; float* C;
     int M, N, K, lda, ldb, ldc;
     const float* bias; const float* coladd; const float* rowtab; const int64_t* rowidx; int rowtab_ld;
     int act;
+    float* U; const float* aux;
     const float* resid; int ldr;
+    DropoutCfg drop;
+    float beta;
     int grp_in, grp_pad, grp_off;
+    int ksplit;        // K-steps per z-slice (0: no split); slabs of M * N floats at C
+    int vec_ok;        // ldc, ldr, rowtab_ld multiples of 4 and 16-byte aligned bases: 16-byte epilogue accesses
 };
 
 DEVI float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-DEVI f32x4 ld_tile4(const float* base, int row, int rows, int ld, int k, int K) {
-    // 4 consecutive k of one row, zero outside the matrix (K % 4 == 0 and ld % 4 == 0 are checked by the host)
-    if (row < rows && k < K) return *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + k);
-    return f32x4{0.f, 0.f, 0.f, 0.f};
+DEVI float gelu_exact_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
-template <int MI>     // MI row tiles of 32 per wave: BM = 64 * MI (128x128 tiles, or 64x128 when 128-row tiles would leave CUs idle)
+// One operand tile's share of a K-step: global -> registers.  ROWS = tile rows (64 or 128); a pass of the 256 threads covers GPR rows.
+constexpr int GKQ = GBK / 4, GPR = 1024 / GBK;     // k-quads per tile row; rows per pass (64 at BK = 16, 32 at BK = 32)
+template <bool KM, int ROWS>
+DEVI void gemm_f32_fetch(f32x4 (&r)[ROWS / GPR], const float* __restrict__ base, int row0, int rows, int ld, int k0, int K, int tid) {
+    if constexpr (!KM) {     // [row][k]: thread = row (tid / GKQ) + GPR h, k-quad 4 (tid % GKQ)
+        const int kq = k0 + (tid % GKQ) * 4;
+#pragma unroll
+        for (int h = 0; h < ROWS / GPR; ++h) {
+            const int row = row0 + (tid / GKQ) + GPR * h;
+            r[h] = (row < rows && kq < K) ? *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {                 // [k][row]: thread = k (tid % GBK), row-quad 4 (tid / GBK) + GPR h
+        const int k = k0 + (tid % GBK);
+#pragma unroll
+        for (int h = 0; h < ROWS / GPR; ++h) {
+            const int row = row0 + (tid / GBK) * 4 + GPR * h;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < K) {
+                const float* p = base + (size_t)k * ld + row;
+                if (row + 3 < rows) v = *reinterpret_cast<const f32x4*>(p);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (row + e < rows) v[e] = p[e];
+                }
+            }
+            r[h] = v;
+        }
+    }
+}
+template <bool KM, int ROWS>
+DEVI void gemm_f32_stash(const f32x4 (&r)[ROWS / GPR], float* __restrict__ tile, int tid) {
+    if constexpr (!KM) {
+#pragma unroll
+        for (int h = 0; h < ROWS / GPR; ++h) *reinterpret_cast<f32x4*>(tile + ((tid / GKQ) + GPR * h) * GRS + (tid % GKQ) * 4) = r[h];
+    } else {
+#pragma unroll
+        for (int h = 0; h < ROWS / GPR; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[((tid / GBK) * 4 + GPR * h + e) * GRS + (tid % GBK)] = r[h][e];
+    }
+}
+
+template <int MI, bool AKM, bool BKM>     // MI: 16-row blocks per wave along M / 2 (BM = 64 * MI)
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
-    constexpr int BM = 64 * MI;
-    __shared__ float As[2][GBK][GLD];
-    __shared__ float Bs[2][GBK][GLD];
+    constexpr int BM = 64 * MI, MB = 2 * MI;      // MB m-blocks x 4 n-blocks of 16 x 16 per wave
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    float (*As)[BM * GRS] = reinterpret_cast<float (*)[BM * GRS]>(gemm_smem);
+    float (*Bs)[GBN * GRS] = reinterpret_cast<float (*)[GBN * GRS]>(gemm_smem + 2 * BM * GRS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q4 = (lane >> 4) * 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GBN;
     const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
-    // staging role of this thread: rows r0 (and r0 + 64) of the tile, k-quad kq
-    const int r0 = tid >> 2, kq = (tid & 3) * 4;
 
-    f32x16 acc[MI][2];
+    f32x4 acc[4][MB];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (g.K + GBK - 1) / GBK;
-    f32x4 ra[MI], rb[2];
-#pragma unroll
-    for (int h = 0; h < MI; ++h) ra[h] = ld_tile4(g.A, m0 + r0 + 64 * h, g.M, g.lda, kq, g.K);
-    rb[0] = ld_tile4(g.B, n0 + r0, g.N, g.ldb, kq, g.K);
-    rb[1] = ld_tile4(g.B, n0 + r0 + 64, g.N, g.ldb, kq, g.K);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int h = 0; h < MI; ++h) As[0][kq + j][r0 + 64 * h] = ra[h][j];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) Bs[0][kq + j][r0 + 64 * h] = rb[h][j];
-    }
+    const int nk_all = (g.K + GBK - 1) / GBK;
+    const int kt0 = g.ksplit ? blockIdx.z * g.ksplit : 0;
+    const int kt1 = g.ksplit ? min(nk_all, kt0 + g.ksplit) : nk_all;
+    f32x4 ra[BM / GPR], rb[GBN / GPR];
+    gemm_f32_fetch<AKM, BM>(ra, g.A, m0, g.M, g.lda, kt0 * GBK, g.K, tid);
+    gemm_f32_fetch<BKM, GBN>(rb, g.B, n0, g.N, g.ldb, kt0 * GBK, g.K, tid);
+    gemm_f32_stash<AKM, BM>(ra, As[0], tid);
+    gemm_f32_stash<BKM, GBN>(rb, Bs[0], tid);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
         if (more) {
-            const int k = (kt + 1) * GBK + kq;
-#pragma unroll
-            for (int h = 0; h < MI; ++h) ra[h] = ld_tile4(g.A, m0 + r0 + 64 * h, g.M, g.lda, k, g.K);
-            rb[0] = ld_tile4(g.B, n0 + r0, g.N, g.ldb, k, g.K);
-            rb[1] = ld_tile4(g.B, n0 + r0 + 64, g.N, g.ldb, k, g.K);
+            gemm_f32_fetch<AKM, BM>(ra, g.A, m0, g.M, g.lda, (kt + 1) * GBK, g.K, tid);
+            gemm_f32_fetch<BKM, GBN>(rb, g.B, n0, g.N, g.ldb, (kt + 1) * GBK, g.K, tid);
         }
 #pragma unroll
-        for (int kk = 0; kk < GBK / 2; ++kk) {
-            const int k = 2 * kk + (lane >> 5);
-            float a[MI];
+        for (int kg = 0; kg < GBK / 16; ++kg) {
+            f32x4 bn[4], am[MB];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = As[cur][k][wm + 32 * i + (lane & 31)];
-            const float b0 = Bs[cur][k][wn + (lane & 31)];
-            const float b1 = Bs[cur][k][wn + 32 + (lane & 31)];
+            for (int nb = 0; nb < 4; ++nb) bn[nb] = *reinterpret_cast<const f32x4*>(&Bs[cur][(wn + 16 * nb + j) * GRS + 16 * kg + q4]);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
-            }
+            for (int mb = 0; mb < MB; ++mb) am[mb] = *reinterpret_cast<const f32x4*>(&As[cur][(wm + 16 * mb + j) * GRS + 16 * kg + q4]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[nb][c], am[mb][c], acc[nb][mb], 0, 0, 0);
         }
         if (more) {
             const int nxt = cur ^ 1;   // last read in iteration kt - 1, which every wave left through the barrier below
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int h = 0; h < MI; ++h) As[nxt][kq + j][r0 + 64 * h] = ra[h][j];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) Bs[nxt][kq + j][r0 + 64 * h] = rb[h][j];
-            }
+            gemm_f32_stash<AKM, BM>(ra, As[nxt], tid);
+            gemm_f32_stash<BKM, GBN>(rb, Bs[nxt], tid);
         }
         __syncthreads();
     }
 
-    // epilogue: C/D map of the 32x32 MFMA — col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // epilogue: acc[nb][mb][r] = C[m = wm + 16 mb + j][n = wn + 16 nb + q4 + r]
+    const uint32_t dkey = g.drop.thr16 ? drop_key(g.drop) : 0u;
+    float* Cz = g.ksplit ? g.C + (size_t)blockIdx.z * g.M * g.N : g.C;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn + 32 * j + (lane & 31);
-        if (n >= g.N) continue;
-        float cadd = 0.f;
-        if (g.bias) cadd += g.bias[n];
-        if (g.coladd) cadd += g.coladd[n];
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = m0 + wm + 16 * mb + j;
+        if (m >= g.M) continue;
+        const int orow = g.grp_in > 0 ? m + (m / g.grp_in) * g.grp_pad + g.grp_off : m;
+        const float* rt = g.rowtab ? g.rowtab + (size_t)g.rowidx[m] * g.rowtab_ld : nullptr;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int nb = 0; nb < 4; ++nb) {
+            const int n = n0 + wn + 16 * nb + q4;
+            if (n >= g.N) continue;
+            f32x4 v = acc[nb][mb];
+            if (g.ksplit) {        // raw partial sums: the epilogue runs in splitk_f32_reduce
+                float* cp = Cz + (size_t)m * g.N + n;
+                if (n + 3 < g.N && (g.N & 3) == 0) *reinterpret_cast<f32x4*>(cp) = v;
+                else
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] + cadd;
-                if (g.rowtab) v += g.rowtab[(size_t)g.rowidx[m] * g.rowtab_ld + n];
-                if (g.act == 1) v = gelu_exact(v);
-                else if (g.act == 3) v = tanhf(v);
-                if (g.resid) v += g.resid[(size_t)m * g.ldr + n];
-                const int orow = g.grp_in > 0 ? m + (m / g.grp_in) * g.grp_pad + g.grp_off : m;
-                g.C[(size_t)orow * g.ldc + n] = v;
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = v[r];
+                continue;
+            }
+            const bool vec = g.vec_ok && n + 3 < g.N;
+            const size_t coff = (size_t)orow * g.ldc + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r >= g.N) { v[r] = 0.f; continue; }
+                if (g.bias) v[r] += g.bias[n + r];
+                if (g.coladd) v[r] += g.coladd[n + r];
+                if (rt) v[r] += rt[n + r];
+            }
+            if (g.act == 1) {
+                if (g.U) {
+                    f32x4 u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) u[r] = gelu_exact_grad(v[r]);
+                    if (vec) *reinterpret_cast<f32x4*>(g.U + coff) = u;
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) g.U[coff + r] = u[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+            } else if (g.act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            } else if (g.act == 2 || g.act == 4) {
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (vec) x = *reinterpret_cast<const f32x4*>(g.aux + coff);
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) x[r] = g.aux[coff + r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (g.act == 2) ? x[r] : 1.f - x[r] * x[r];
+            }
+            if (g.drop.thr16) {
+                const uint32_t idx = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+                if ((idx & 3u) == 0u) {
+                    const f32x4 sc = drop_scale4(dkey, idx, g.drop.thr16, g.drop.scale);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= drop_scale1(dkey, idx + r, g.drop.thr16, g.drop.scale);
+                }
+            }
+            if (g.resid) {
+                const float* rp = g.resid + (size_t)m * g.ldr + n;
+                if (vec) { const f32x4 x = *reinterpret_cast<const f32x4*>(rp); v += x; }
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += rp[r];
+            }
+            float* cp = g.C + coff;
+            if (vec) {
+                if (g.beta != 0.f) v += g.beta * *reinterpret_cast<const f32x4*>(cp);
+                *reinterpret_cast<f32x4*>(cp) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < g.N) cp[r] = g.beta != 0.f ? v[r] + g.beta * cp[r] : v[r];
             }
         }
     }
+}
+
+// C[m][n] = beta C[m][n] + sum_z slab[z][m][n]   (split-K weight gradients; no other epilogue)
+__global__ __launch_bounds__(256) void splitk_f32_reduce_kernel(const float* __restrict__ ws, int splits, long n, int N, float* __restrict__ C, int ldc, float beta) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = ws[i];
+    for (int z = 1; z < splits; ++z) a += ws[(long)z * n + i];
+    const long m = i / N;
+    float* c = C + m * ldc + (i - m * N);
+    *c = beta != 0.f ? a + beta * *c : a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,13 +268,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 // the prefix-LM tail of M4C (mmf_attn_desc.causal_tail) are handled.  exp(x) = exp2(x log2 e) on v_exp_f32.
 // ------------------------------------------------------------------------------------------------
 struct AttnF32 {
-    const float* q; const float* k; const float* v; float* o;
+    const float* q; const float* k; const float* v; float* out;
     int ldq, ldk, ldv, ldo;
     const float* mask;
     int B, heads, Sq, Sk;
     float scale;
     int cfrom;     // first key of the causal tail (== Sk: none)
+    float* lse;    // [B, heads, Sq]: row maximum + log2(row sum) of the scaled scores in log2 units (training: saved for the backward)
+    DropoutCfg drop;   // attention-probability dropout, element index ((b heads + head) Sq + q) Sk + key
+    // backward only
+    const float* o; const float* d_o; float* dq; float* dk; float* dv; float* delta;
 };
+
+// keep-scale of the probability of (query q, key) under attention dropout (1 when dropout is off)
+DEVI float attn_drop(const AttnF32& a, uint32_t dkey, int bh, int q, int key) {
+    return drop_scale1(dkey, ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Sk + (uint32_t)key, a.drop.thr16, a.drop.scale);
+}
 
 template <int D, int MAXT>
 __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
@@ -250,6 +367,17 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
+    if (a.lse && g == 0 && qme < a.Sq) a.lse[(size_t)bh * a.Sq + qme] = mx + __builtin_amdgcn_logf(sum);     // v_log_f32 = log2
+    if (a.drop.thr16) {
+        const uint32_t dkey = drop_key(a.drop);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] *= attn_drop(a, dkey, bh, min(qme, a.Sq - 1), min(16 * t + 4 * g + r, a.Sk - 1));
+            }
+        }
+    }
 
     // O = P V with the un-normalised probabilities straight from the score registers
     f32x4 oc[NM];
@@ -272,9 +400,217 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
         const float inv = 1.0f / __shfl(sum, 4 * g + r, 64);
         const int qr = q0 + 4 * g + r;
         if (qr < a.Sq) {
-            float* op = a.o + ((size_t)b * a.Sq + qr) * a.ldo + h * D + j;
+            float* op = a.out + ((size_t)b * a.Sq + qr) * a.ldo + h * D + j;
 #pragma unroll
             for (int eb = 0; eb < NM; ++eb) op[16 * eb] = oc[eb][r] * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention backward, fp32 (fp32 training: the reference's default arithmetic, training_loop.py:199-211), two launches built like the
+// forward.  With P = softmax(S), Pd = dropout(P), O = Pd V:   dPd = dO V^T,  delta = rowsum(dO o O),  dS = P o (dropmask o dPd - delta),
+// dQ = scale dS K,  dK = scale dS^T Q,  dV = Pd^T dO.  P is recomputed from the saved row statistic lse (one exp2 per element).
+//   attn_f32_bwd_dq_kernel:  the forward's roles — K, V rows in LDS, wave = 16 queries: S^T and dPd^T blocks (A = K / V rows, B = the
+//     query's Q / dO row in registers), dS formed in the accumulator layout, which IS the A-operand layout of dQ = dS K (k-slot = key
+//     quad), per key tile: nothing but the dQ accumulators lives across tiles.  Writes delta for the second launch.
+//   attn_f32_bwd_dkv_kernel: the roles swapped — Q, dO rows in LDS, wave = 16 KEYS whose K, V rows sit in registers: S and dPd blocks
+//     with A = Q / dO rows, B = K / V; the accumulator layout (rows = queries 4 (lane / 16) + r, column = the lane's key) is the
+//     A-operand layout of dV = Pd^T dO and dK = dS^T Q (k-slot = query quad); dK / dV accumulate in registers over the query tiles.
+// No atomics, fixed summation order.
+// ------------------------------------------------------------------------------------------------
+template <int D, int MAXT>
+__global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
+    constexpr int RS = D + 4, NM = D / 16;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ float att_smem[];
+    float* Ks = att_smem;
+    float* Vs = Ks + 16 * MAXT * RS;
+    float* Ms = Vs + 16 * MAXT * RS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int q0 = blockIdx.x * 128 + wave * 16;
+    const int nt = (a.Sk + 15) >> 4;
+    {
+        constexpr int QPR = D / 4;
+        const int quads = nt * 16 * QPR;
+        for (int idx = threadIdx.x; idx < quads; idx += 512) {
+            const int key = idx / QPR, qd = idx - key * QPR;
+            const int kr = min(key, a.Sk - 1);
+            *reinterpret_cast<f32x4*>(Ks + key * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D + 4 * qd);
+            *reinterpret_cast<f32x4*>(Vs + key * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.v + ((size_t)b * a.Sk + kr) * a.ldv + h * D + 4 * qd);
+        }
+        for (int key = threadIdx.x; key < nt * 16; key += 512)
+            Ms[key] = key < a.Sk ? (a.mask ? a.mask[(size_t)b * a.Sk + key] * LOG2E : 0.f) : -INFINITY;
+    }
+    const int qme = min(q0 + j, a.Sq - 1);
+    f32x4 qv[NM], dov[NM];
+    float dl = 0.f;
+    {
+        const size_t ro = (size_t)b * a.Sq + qme;
+        const float* qp = a.q + ro * a.ldq + h * D + 4 * g;
+        const float* dp = a.d_o + ro * a.ldo + h * D + 4 * g;
+        const float* op = a.o + ro * a.ldo + h * D + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            qv[m] = *reinterpret_cast<const f32x4*>(qp + 16 * m);
+            dov[m] = *reinterpret_cast<const f32x4*>(dp + 16 * m);
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(op + 16 * m);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dl += dov[m][c] * ov[c];
+        }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);                 // delta of query q0 + j
+    __syncthreads();
+    if (q0 >= a.Sq) return;
+    if (g == 0 && q0 + j < a.Sq) a.delta[(size_t)bh * a.Sq + q0 + j] = dl;
+    const float lse = a.lse[(size_t)bh * a.Sq + qme];
+    const float sl2 = a.scale * LOG2E;
+    const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
+
+    f32x4 dq[NM];
+#pragma unroll
+    for (int eb = 0; eb < NM; ++eb) dq[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int t = 0; t < nt; ++t) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        const float* kr = Ks + (16 * t + j) * RS + 4 * g;
+        const float* vr = Vs + (16 * t + j) * RS + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const f32x4 kq = *reinterpret_cast<const f32x4*>(kr + 16 * m);
+            const f32x4 vq = *reinterpret_cast<const f32x4*>(vr + 16 * m);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[c], qv[m][c], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[c], dov[m][c], dp, 0, 0, 0);
+            }
+        }
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + 16 * t + 4 * g);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * g + r;
+            float madd = mk[r];
+            if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
+            const float p = __builtin_amdgcn_exp2f(s[r] * sl2 + madd - lse);
+            const float m = a.drop.thr16 ? attn_drop(a, dkey, bh, qme, min(key, a.Sk - 1)) : 1.f;
+            ds[r] = p * (dp[r] * m - dl) * a.scale;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* kc = Ks + (16 * t + 4 * g + c) * RS + j;
+#pragma unroll
+            for (int eb = 0; eb < NM; ++eb) dq[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[c], kc[16 * eb], dq[eb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qr = q0 + 4 * g + r;
+        if (qr < a.Sq) {
+            float* op = a.dq + ((size_t)b * a.Sq + qr) * a.ldq + h * D + j;
+#pragma unroll
+            for (int eb = 0; eb < NM; ++eb) op[16 * eb] = dq[eb][r];
+        }
+    }
+}
+
+template <int D, int MAXT>     // MAXT: QUERY tiles of 16 (Sq <= 16 * MAXT)
+__global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) {
+    constexpr int RS = D + 4, NM = D / 16;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ float att_smem[];
+    float* Qs = att_smem;                         // [16 * MAXT][RS]
+    float* Os = Qs + 16 * MAXT * RS;              // dO rows
+    float* Ls = Os + 16 * MAXT * RS;              // [16 * MAXT] lse (+inf past Sq: probability 0)
+    float* Ds = Ls + 16 * MAXT;                   // [16 * MAXT] delta
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int k0 = blockIdx.x * 128 + wave * 16;
+    const int nq = (a.Sq + 15) >> 4;
+    {
+        constexpr int QPR = D / 4;
+        const int quads = nq * 16 * QPR;
+        for (int idx = threadIdx.x; idx < quads; idx += 512) {
+            const int q = idx / QPR, qd = idx - q * QPR;
+            const int qr = min(q, a.Sq - 1);
+            *reinterpret_cast<f32x4*>(Qs + q * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.Sq + qr) * a.ldq + h * D + 4 * qd);
+            *reinterpret_cast<f32x4*>(Os + q * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.d_o + ((size_t)b * a.Sq + qr) * a.ldo + h * D + 4 * qd);
+        }
+        for (int q = threadIdx.x; q < nq * 16; q += 512) {
+            Ls[q] = q < a.Sq ? a.lse[(size_t)bh * a.Sq + q] : INFINITY;
+            Ds[q] = q < a.Sq ? a.delta[(size_t)bh * a.Sq + q] : 0.f;
+        }
+    }
+    const int kme = k0 + j;                        // this lane's key
+    const int kcl = min(kme, a.Sk - 1);
+    f32x4 kv[NM], vv[NM];
+    {
+        const float* kp = a.k + ((size_t)b * a.Sk + kcl) * a.ldk + h * D + 4 * g;
+        const float* vp = a.v + ((size_t)b * a.Sk + kcl) * a.ldv + h * D + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { kv[m] = *reinterpret_cast<const f32x4*>(kp + 16 * m); vv[m] = *reinterpret_cast<const f32x4*>(vp + 16 * m); }
+    }
+    __syncthreads();
+    if (k0 >= a.Sk) return;
+    const float sl2 = a.scale * LOG2E;
+    const float mkey = kme < a.Sk ? (a.mask ? a.mask[(size_t)b * a.Sk + kme] * LOG2E : 0.f) : -INFINITY;
+    const bool tail = kme >= a.cfrom && kme < a.Sk;
+    const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
+
+    f32x4 dk[NM], dv[NM];
+#pragma unroll
+    for (int eb = 0; eb < NM; ++eb) { dk[eb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[eb] = dk[eb]; }
+#pragma unroll 2
+    for (int u = 0; u < nq; ++u) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        const float* qr = Qs + (16 * u + j) * RS + 4 * g;
+        const float* orow = Os + (16 * u + j) * RS + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(qr + 16 * m);
+            const f32x4 oq = *reinterpret_cast<const f32x4*>(orow + 16 * m);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[c], kv[m][c], s, 0, 0, 0);       // s[r] = S[query 16 u + 4 g + r][key k0 + j]
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(oq[c], vv[m][c], dp, 0, 0, 0);
+            }
+        }
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(Ls + 16 * u + 4 * g);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(Ds + 16 * u + 4 * g);
+        f32x4 pd, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 16 * u + 4 * g + r;
+            float madd = mkey;
+            if (tail) madd = (q >= a.cfrom && kme <= q) ? 0.f : -10000.f * LOG2E;
+            const float p = __builtin_amdgcn_exp2f(s[r] * sl2 + madd - ls[r]);
+            const float m = a.drop.thr16 ? attn_drop(a, dkey, bh, min(q, a.Sq - 1), kcl) : 1.f;
+            pd[r] = p * m;
+            ds[r] = p * (dp[r] * m - dl[r]) * a.scale;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* oc = Os + (16 * u + 4 * g + c) * RS + j;
+            const float* qc = Qs + (16 * u + 4 * g + c) * RS + j;
+#pragma unroll
+            for (int eb = 0; eb < NM; ++eb) {
+                dv[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[c], oc[16 * eb], dv[eb], 0, 0, 0);
+                dk[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[c], qc[16 * eb], dk[eb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kr = k0 + 4 * g + r;
+        if (kr < a.Sk) {
+            float* kp = a.dk + ((size_t)b * a.Sk + kr) * a.ldk + h * D + j;
+            float* vp = a.dv + ((size_t)b * a.Sk + kr) * a.ldv + h * D + j;
+#pragma unroll
+            for (int eb = 0; eb < NM; ++eb) { kp[16 * eb] = dk[eb][r]; vp[16 * eb] = dv[eb][r]; }
         }
     }
 }
@@ -285,7 +621,7 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_f32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y, int rows, int H,
-                                                          float eps) {
+                                                          float eps, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -309,6 +645,7 @@ __global__ __launch_bounds__(256) void ln_f32_fwd_kernel(const float* __restrict
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+    if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }      // training: saved for mmf_layernorm_f32_bwd
     float* yr = y + (size_t)row * H;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -336,12 +673,12 @@ __global__ __launch_bounds__(256) void pad_rows_f32_kernel(const float* __restri
     const int c = (int)(i - r * KP);
     dst[i] = c < K ? src[r * K + c] : 0.f;
 }
-// op 0: a * b, 1: max(a, 0), 3: a + b   (the op codes of mmf_eltwise)
+// op 0: a * b, 1: max(a, 0), 3: a + b   (the op codes of mmf_eltwise); 4: a * (1 - b^2) (backward of tanh, b = the saved output)
 __global__ __launch_bounds__(256) void eltwise_f32_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float x = a[i];
-    y[i] = op == 0 ? x * b[i] : (op == 1 ? fmaxf(x, 0.f) : x + b[i]);
+    y[i] = op == 0 ? x * b[i] : (op == 1 ? fmaxf(x, 0.f) : (op == 3 ? x + b[i] : x * (1.f - b[i] * b[i])));
 }
 // pool[b][c] = sum_t x[b][t][c] mask[b][t] / sum_t mask[b][t]   (ViLBERT dynamic_attention, vilbert.py:204-205)
 __global__ __launch_bounds__(256) void masked_mean_f32_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ pool, int T, int H) {
@@ -367,37 +704,93 @@ __global__ __launch_bounds__(256) void rowgroup_scale_f32_kernel(float* __restri
 }
 }  // namespace
 
+template <int MI, bool AKM, bool BKM>
+static void launch_gemm_f32_one(const GemmF32& g, dim3 grid, hipStream_t s) {
+    constexpr int lds = 2 * (64 * MI + GBN) * GRS * (int)sizeof(float);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<MI, AKM, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        once = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<MI, AKM, BKM>), grid, dim3(256), lds, s, g);
+}
+template <int MI>
+static void launch_gemm_f32(const mmf_gemm_desc* d, const GemmF32& g, dim3 grid, hipStream_t s) {
+    if (d->a_kmajor) launch_gemm_f32_one<MI, true, true>(g, grid, s);
+    else if (d->b_kmajor) launch_gemm_f32_one<MI, false, true>(g, grid, s);
+    else launch_gemm_f32_one<MI, false, false>(g, grid, s);
+}
+
+// K splits of a (weight-gradient shaped) problem given a workspace: enough z-slices to put ~2 tiles on every CU, >= 8 K-steps each
+extern "C" int mmf_gemm_f32_splits(int M, int N, int K) {
+    const long tiles = (long)((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+    const int nk = (K + GBK - 1) / GBK;
+    if (tiles >= 384 || nk < 32) return 1;
+    int sp = (int)((512 + tiles - 1) / tiles);
+    if (sp > nk / 8) sp = nk / 8;
+    if (sp > 32) sp = 32;
+    return sp < 1 ? 1 : sp;
+}
+
 extern "C" int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream) {
     MMF_CHECK_ARG(d && d->A && d->B && d->C, "gemm_f32: null operand");
     MMF_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm_f32: empty problem");
     MMF_CHECK_ARG(d->a_f32 && d->b_f32 && d->out_f32, "gemm_f32: operands and output are fp32 (a_f32 = b_f32 = out_f32 = 1)");
-    MMF_CHECK_ARG(!d->a_kmajor && !d->b_kmajor, "gemm_f32: forward form only (row operands)");
-    MMF_CHECK_ARG((d->K % 4) == 0 && (d->lda % 4) == 0 && (d->ldb % 4) == 0 && d->lda >= d->K && d->ldb >= d->K,
-                  "gemm_f32: K, lda, ldb must be multiples of 4 and lda, ldb >= K");
-    MMF_CHECK_ARG((((uintptr_t)d->A | (uintptr_t)d->B) & 15) == 0, "gemm_f32: A and B must be 16-byte aligned");
+    MMF_CHECK_ARG(!d->a_kmajor || d->b_kmajor, "gemm_f32: layouts are forward (row, row), dgrad (row, k-major) and weight gradient (k-major, k-major)");
+    MMF_CHECK_ARG((d->lda % 4) == 0 && (d->ldb % 4) == 0 && (((uintptr_t)d->A | (uintptr_t)d->B) & 15) == 0,
+                  "gemm_f32: lda, ldb must be multiples of 4 and A, B 16-byte aligned");
+    // a row operand is read in 4-element quads along K: its leading dimension must cover round_up(K, 4) and the padding must hold zeros
+    const int k4 = (d->K + 3) / 4 * 4;
+    MMF_CHECK_ARG(d->a_kmajor ? d->lda >= d->M : d->lda >= k4, "gemm_f32: lda must cover round_up(K, 4) for a row operand (k-major: lda >= M)");
+    MMF_CHECK_ARG(d->b_kmajor ? d->ldb >= d->N : d->ldb >= k4, "gemm_f32: ldb must cover round_up(K, 4) for a row operand (k-major: ldb >= N)");
     MMF_CHECK_ARG(d->ldc >= d->N, "gemm_f32: ldc < N");
-    MMF_CHECK_ARG(d->act == 0 || d->act == 1 || d->act == 3, "gemm_f32: act must be 0 (none), 1 (gelu) or 3 (tanh)");
-    MMF_CHECK_ARG(!d->U && !d->aux && d->drop_thr16 == 0 && !d->splitk_ws && !d->rowsum_out && d->beta == 0.f,
-                  "gemm_f32: forward-only inference epilogue (no saved derivative, dropout, split-K, row sums or beta)");
+    MMF_CHECK_ARG(d->act >= 0 && d->act <= 4, "gemm_f32: act must be 0 (none), 1 (gelu), 2 (x aux), 3 (tanh) or 4 (x (1 - aux^2))");
+    MMF_CHECK_ARG((d->act != 2 && d->act != 4) || d->aux, "gemm_f32: act 2 / 4 need aux");
+    MMF_CHECK_ARG(!d->U || d->act == 1, "gemm_f32: U (the saved gelu') goes with act 1");
+    MMF_CHECK_ARG(!d->rowsum_out, "gemm_f32: no fused row sums (use mmf_colsum_f32 for the bias gradient)");
     MMF_CHECK_ARG(!d->rowtab || (d->rowidx && d->rowtab_ld >= d->N), "gemm_f32: rowtab needs rowidx and rowtab_ld >= N");
     MMF_CHECK_ARG(!d->resid || d->ldr >= d->N, "gemm_f32: ldr < N");
     MMF_CHECK_ARG(d->grp_in >= 0, "gemm_f32: grp_in < 0");
+    hipStream_t s = (hipStream_t)stream;
     GemmF32 g;
     g.A = (const float*)d->A; g.B = (const float*)d->B; g.C = (float*)d->C;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
     g.bias = d->bias; g.coladd = d->coladd; g.rowtab = d->rowtab; g.rowidx = d->rowidx; g.rowtab_ld = d->rowtab_ld;
-    g.act = d->act; g.resid = (const float*)d->resid; g.ldr = d->ldr;
+    g.act = d->act; g.U = (float*)d->U; g.aux = (const float*)d->aux; g.resid = (const float*)d->resid; g.ldr = d->ldr;
+    g.drop = DropoutCfg{d->drop_key, d->drop_thr16, d->drop_scale, d->drop_seed};
+    g.beta = d->beta;
     g.grp_in = d->grp_in; g.grp_pad = d->grp_pad; g.grp_off = d->grp_off;
+    g.ksplit = 0;
+    g.vec_ok = (d->ldc % 4) == 0 && (((uintptr_t)d->C | (uintptr_t)d->U | (uintptr_t)d->aux | (uintptr_t)d->resid | (uintptr_t)d->rowtab) & 15) == 0 &&
+               (!d->resid || (d->ldr % 4) == 0) && (!d->rowtab || (d->rowtab_ld % 4) == 0);
     // 128-row tiles unless they would leave the chip short of work (fewer than two tiles per CU): then 64-row tiles — e.g.
     // M = 7296, N = 768: 342 tiles of 128x128 on 256 CUs (1.34 rounds) become 684 of 64x128
     const int nt = (d->N + GBN - 1) / GBN;
-    const bool small = (long)nt * ((d->M + GBM - 1) / GBM) < 512;
+    int splits = 1;
+    if (d->splitk_ws) {
+        splits = mmf_gemm_f32_splits(d->M, d->N, d->K);
+        MMF_CHECK_ARG(d->splitk_ws_bytes >= (int64_t)splits * d->M * d->N * 4, "gemm_f32: split-K workspace too small (mmf_gemm_f32_splits(M, N, K) * M * N * 4 bytes)");
+        MMF_CHECK_ARG(splits == 1 || (!d->bias && !d->coladd && !d->rowtab && d->act == 0 && !d->resid && d->drop_thr16 == 0 && d->grp_in == 0),
+                      "gemm_f32: split-K takes no epilogue besides beta");
+    }
+    const bool small = splits == 1 && (long)nt * ((d->M + GBM - 1) / GBM) < 512;
     const int bm = small ? 64 : GBM;
-    const dim3 grid(nt, (d->M + bm - 1) / bm);
+    dim3 grid(nt, (d->M + bm - 1) / bm, splits);
     MMF_CHECK_ARG(grid.y <= 65535u, "gemm_f32: M too large for one launch");
-    if (small) hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    if (splits > 1) {
+        const int nk = (d->K + GBK - 1) / GBK;
+        g.ksplit = (nk + splits - 1) / splits;
+        g.C = (float*)d->splitk_ws;
+    }
+    if (small) launch_gemm_f32<1>(d, g, grid, s);
+    else launch_gemm_f32<2>(d, g, grid, s);
     MMF_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long n = (long)d->M * d->N;
+        hipLaunchKernelGGL(splitk_f32_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)d->splitk_ws, splits, n, d->N,
+                           (float*)d->C, d->ldc, d->beta);
+        MMF_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -406,7 +799,7 @@ static int launch_attn_f32(const AttnF32& a, hipStream_t s) {
     constexpr int lds = (2 * 16 * MAXT * (D + 4) + 16 * MAXT) * (int)sizeof(float);
     static bool once = false;
     if (!once) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_fwd_kernel<D, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_fwd_kernel<D, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         once = true;
     }
     hipLaunchKernelGGL((attn_f32_fwd_kernel<D, MAXT>), dim3((a.Sq + 127) / 128, a.B * a.heads), dim3(512), lds, s, a);
@@ -420,8 +813,8 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
     const int hd = d->head_dim ? d->head_dim : 64;
     MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_fwd: head_dim must be 64 or 128");
     MMF_CHECK_ARG(d->Sk <= (hd == 64 ? 256 : 128), "attention_f32_fwd: Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
-    MMF_CHECK_ARG(d->drop_thr16 == 0 && !d->ctx_f32 && !d->lse && d->q_batch_rows == 0 && d->kv_batch_rows == 0 && d->mask_batch_stride == 0,
-                  "attention_f32_fwd: inference form only (no dropout, lse, K|V cache strides)");
+    MMF_CHECK_ARG(!d->ctx_f32 && d->q_batch_rows == 0 && d->kv_batch_rows == 0 && d->mask_batch_stride == 0,
+                  "attention_f32_fwd: no ctx_f32 (ctx IS fp32) and no K|V cache strides");
     MMF_CHECK_ARG(d->causal_tail >= 0 && d->causal_tail <= d->Sk && (d->causal_tail == 0 || d->Sq == d->Sk),
                   "attention_f32_fwd: a causal tail needs self-attention (Sq == Sk)");
     const int HD = d->heads * hd;
@@ -430,11 +823,59 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
                   "attention_f32_fwd: q / k / v rows are read as 16-byte quads (pointers 16-byte aligned, leading dimensions multiples of 4)");
     MMF_CHECK_ARG((size_t)d->B * d->heads <= 65535u, "attention_f32_fwd: B * heads too large for one launch");
     AttnF32 a;
-    a.q = (const float*)d->q; a.k = (const float*)d->k; a.v = (const float*)d->v; a.o = (float*)d->ctx;
+    a.q = (const float*)d->q; a.k = (const float*)d->k; a.v = (const float*)d->v; a.out = (float*)d->ctx;
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
     a.mask = d->mask; a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk; a.scale = d->scale;
     a.cfrom = d->Sk - d->causal_tail;
+    a.lse = d->lse;
+    a.drop = DropoutCfg{d->drop_key, d->drop_thr16, d->drop_scale, d->drop_seed};
+    a.o = nullptr; a.d_o = nullptr; a.dq = a.dk = a.dv = a.delta = nullptr;
     return hd == 64 ? launch_attn_f32<64, 16>(a, (hipStream_t)stream) : launch_attn_f32<128, 8>(a, (hipStream_t)stream);
+}
+
+template <int D, int MAXT>
+static int launch_attn_f32_bwd(const AttnF32& a, hipStream_t s) {
+    constexpr int lds1 = (2 * 16 * MAXT * (D + 4) + 16 * MAXT) * (int)sizeof(float);
+    constexpr int lds2 = (2 * 16 * MAXT * (D + 4) + 2 * 16 * MAXT) * (int)sizeof(float);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_bwd_dq_kernel<D, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_bwd_dkv_kernel<D, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        once = true;
+    }
+    hipLaunchKernelGGL((attn_f32_bwd_dq_kernel<D, MAXT>), dim3((a.Sq + 127) / 128, a.B * a.heads), dim3(512), lds1, s, a);
+    MMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_f32_bwd_dkv_kernel<D, MAXT>), dim3((a.Sk + 127) / 128, a.B * a.heads), dim3(512), lds2, s, a);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmf_attention_f32_bwd(const mmf_attn_bwd_desc* d, void* stream) {
+    MMF_CHECK_ARG(d && d->f.q && d->f.k && d->f.v && d->f.ctx && d->f.lse && d->dctx && d->dq && d->dk && d->dv && d->delta,
+                  "attention_f32_bwd: null operand (q, k, v, ctx = O, lse, dctx, dq, dk, dv, delta)");
+    const mmf_attn_desc* f = &d->f;
+    MMF_CHECK_ARG(f->B > 0 && f->heads > 0 && f->Sq > 0 && f->Sk > 0, "attention_f32_bwd: empty problem");
+    const int hd = f->head_dim ? f->head_dim : 64;
+    MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_bwd: head_dim must be 64 or 128");
+    const int smax = hd == 64 ? 256 : 128;
+    MMF_CHECK_ARG(f->Sk <= smax && f->Sq <= smax, "attention_f32_bwd: Sq, Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
+    MMF_CHECK_ARG(!f->ctx_f32 && f->q_batch_rows == 0 && f->kv_batch_rows == 0 && f->mask_batch_stride == 0, "attention_f32_bwd: no ctx_f32 / K|V cache strides");
+    MMF_CHECK_ARG(f->causal_tail >= 0 && f->causal_tail <= f->Sk && (f->causal_tail == 0 || f->Sq == f->Sk), "attention_f32_bwd: a causal tail needs Sq == Sk");
+    const int HD = f->heads * hd;
+    MMF_CHECK_ARG(f->ldq >= HD && f->ldk >= HD && f->ldv >= HD && f->ldo >= HD, "attention_f32_bwd: leading dimension < heads * head_dim");
+    MMF_CHECK_ARG((f->ldq % 4) == 0 && (f->ldk % 4) == 0 && (f->ldv % 4) == 0 && (f->ldo % 4) == 0 &&
+                  (((uintptr_t)f->q | (uintptr_t)f->k | (uintptr_t)f->v | (uintptr_t)f->ctx | (uintptr_t)d->dctx) & 15) == 0,
+                  "attention_f32_bwd: rows are read as 16-byte quads (aligned pointers, leading dimensions multiples of 4)");
+    MMF_CHECK_ARG((size_t)f->B * f->heads <= 65535u, "attention_f32_bwd: B * heads too large for one launch");
+    AttnF32 a;
+    a.q = (const float*)f->q; a.k = (const float*)f->k; a.v = (const float*)f->v; a.out = nullptr;
+    a.ldq = f->ldq; a.ldk = f->ldk; a.ldv = f->ldv; a.ldo = f->ldo;
+    a.mask = f->mask; a.B = f->B; a.heads = f->heads; a.Sq = f->Sq; a.Sk = f->Sk; a.scale = f->scale;
+    a.cfrom = f->Sk - f->causal_tail;
+    a.lse = f->lse;
+    a.drop = DropoutCfg{f->drop_key, f->drop_thr16, f->drop_scale, f->drop_seed};
+    a.o = (const float*)f->ctx; a.d_o = (const float*)d->dctx; a.dq = (float*)d->dq; a.dk = (float*)d->dk; a.dv = (float*)d->dv; a.delta = d->delta;
+    return hd == 64 ? launch_attn_f32_bwd<64, 16>(a, (hipStream_t)stream) : launch_attn_f32_bwd<128, 8>(a, (hipStream_t)stream);
 }
 
 extern "C" int mmf_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int H, float eps,
@@ -442,7 +883,16 @@ extern "C" int mmf_layernorm_f32_fwd(const float* x, const float* gamma, const f
     MMF_CHECK_ARG(x && gamma && beta && y, "layernorm_f32_fwd: null operand");
     MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 2048, "layernorm_f32_fwd: H % 4 == 0, H <= 2048");
     MMF_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_f32_fwd: 16-byte alignment");
-    hipLaunchKernelGGL(ln_f32_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, H, eps);
+    hipLaunchKernelGGL(ln_f32_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, H, eps, (float*)nullptr, (float*)nullptr);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmf_layernorm_f32_fwd_stats(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows, int H,
+                                           float eps, void* stream) {
+    MMF_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_f32_fwd_stats: null operand");
+    MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 2048, "layernorm_f32_fwd_stats: H % 4 == 0, H <= 2048");
+    MMF_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_f32_fwd_stats: 16-byte alignment");
+    hipLaunchKernelGGL(ln_f32_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, H, eps, mean, rstd);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -455,7 +905,7 @@ extern "C" int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int
     return 0;
 }
 extern "C" int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, void* stream) {
-    MMF_CHECK_ARG(a && y && n > 0 && (op == 0 || op == 1 || op == 3) && (op == 1 || b), "eltwise_f32: bad operand (op 0 mul, 1 relu, 3 add)");
+    MMF_CHECK_ARG(a && y && n > 0 && (op == 0 || op == 1 || op == 3 || op == 4) && (op == 1 || b), "eltwise_f32: bad operand (op 0 mul, 1 relu, 3 add, 4 tanh backward)");
     hipLaunchKernelGGL(eltwise_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, y, n);
     MMF_CHECK_LAUNCH();
     return 0;

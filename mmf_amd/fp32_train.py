@@ -1,0 +1,442 @@
+"""fp32 TRAINING on the fp32 kernels: the reference's default arithmetic for a training step.
+
+The reference computes forward AND backward in fp32 unless `training.fp16` turns autocast on (mmf/trainers/core/training_loop.py:199-211).
+The throughput path is bf16 (north_star's 5e-2 bound); `mmf_amd.fp32_inference()` is the fp32 forward.  Inside
+
+    with mmf_amd.fp32_training():
+        out = model(sample_list)            # train or eval mode; dropout works
+    out["losses"][...].backward()           # the backward kernels are launched by the autograd nodes built above
+    optimizer.step()                        # the fused AdamW takes the fp32 gradients as they are
+
+every `torch.ops.mmf_amd.*` operator of the VisualBERT training step builds an autograd node whose forward and backward run on
+mmf_amd/csrc/fp32_path.hip (`mmf_gemm_f32` in its forward / dgrad / weight-gradient layouts, `mmf_attention_f32_fwd` / `_bwd`) and
+mmf_amd/csrc/fp32_train.hip (LayerNorm backward, column sums, dropout, row scatters): fp32 activations, fp32 master parameters read
+directly, fp32 gradients.  Parity: every parameter gradient of the reference's fixture and of the full VisualBERT-base VQA2 configuration
+against the CPU oracle within north_star's fp32 bound (tests/test_fp32_train_gpu.py).
+
+Built for the operators VisualBERT's classification / nlvr2 step uses (embeddings, encoder layers, pooler, prediction-head transform,
+classifier, logit_bce); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
+
+Reference operations, as in mmf_amd/functional.py: BertVisioLinguisticEmbeddings.forward (mmf/modules/embeddings.py:423-459), BertLayerJit
+.forward (mmf/modules/hf_layers.py:255-292), BertPooler / BertPredictionHeadTransform / classifier Linear (mmf/models/visual_bert.py:146,
+327-330, 389-401), LogitBinaryCrossEntropy (mmf/modules/losses.py:246-251)."""
+import contextlib
+import math
+
+import torch
+
+from mmf_amd import _native as nat
+from mmf_amd import fp32_path as P
+
+F32 = torch.float32
+_depth = 0
+_site = 0          # dropout site counter: every dropout site of a step gets its own key
+
+
+def active():
+    return _depth > 0
+
+
+@contextlib.contextmanager
+def fp32_training():
+    """Run every mmf_amd operator inside the block on the fp32 kernels WITH autograd (forward here, backward when `.backward()` runs)."""
+    global _depth
+    from mmf_amd import _ops_native
+    _depth += 1
+    _ops_native.push_mode(0)        # the native operators forward to their Python twins, which route here
+    try:
+        yield
+    finally:
+        _depth -= 1
+        _ops_native.pop_mode(0)
+
+
+def make_drop(p, training):
+    """Dropout configuration of one site: a fresh key per site from torch's generator (reproducible under torch.manual_seed)."""
+    if not training or p is None or p <= 0.0:
+        return nat.NO_DROP
+    key = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return nat.drop_cfg(p, key)
+
+
+def _rows(x):
+    return P._rows(x)
+
+
+def _w(p):
+    return P._w(p)
+
+
+def _empty(*shape, like):
+    return torch.empty(*shape, dtype=F32, device=like.device)
+
+
+def _gemm(x2, w, out_cols, bias=None, **kw):
+    """x2 [M, K] @ w[N, K]^T (+ epilogue) -> [M, N]"""
+    M, K = x2.shape
+    out = _empty(M, out_cols, like=x2)
+    nat.gemm_f32(x2, w, out, M, out_cols, K, x2.stride(0), w.stride(0), out_cols, bias=bias, **kw)
+    return out
+
+
+def _dgrad(dz, w, resid=None, act=0, aux=None):
+    """dX = dZ W (+ resid): dZ [M, N], W [N, K] as stored -> [M, K]; optional saved-derivative multiply in the epilogue."""
+    M, N = dz.shape
+    K = w.shape[1]
+    out = _empty(M, K, like=dz)
+    nat.gemm_f32(dz, w, out, M, K, N, dz.stride(0), w.stride(0), K, b_kmajor=True, resid=resid, ldr=0 if resid is None else resid.stride(0),
+                 act=act, aux=aux)
+    return out
+
+
+def _wgrad(dz, x2):
+    """dW = dZ^T X: dZ [M, N], X [M, K] -> [N, K]; split-K over the M rows."""
+    M, N = dz.shape
+    K = x2.shape[1]
+    out = _empty(N, K, like=dz)
+    nat.gemm_f32(dz, x2, out, N, K, M, dz.stride(0), x2.stride(0), K, a_kmajor=True, b_kmajor=True, split_k=True)
+    return out
+
+
+def _colsum(dz):
+    M, N = dz.shape
+    out = _empty(N, like=dz)
+    nat.colsum_f32(dz, dz.stride(0), M, N, out)
+    return out
+
+
+def _contig_cols(x2):
+    return x2 if x2.stride(1) == 1 else x2.contiguous()
+
+
+def _ln_fwd(y, gamma, beta, eps):
+    M, H = y.shape
+    out = _empty(M, H, like=y)
+    mean = _empty(M, like=y); rstd = _empty(M, like=y)
+    nat.layernorm_f32_fwd_stats(y, _w(gamma), _w(beta), out, mean, rstd, M, H, eps)
+    return out, mean, rstd
+
+
+def _ln_bwd(g2, y, mean, rstd, gamma):
+    M, H = y.shape
+    dx = _empty(M, H, like=y); dg = _empty(H, like=y); db = _empty(H, like=y)
+    nat.layernorm_f32_bwd(g2, y, mean, rstd, _w(gamma), dx, dg, db, M, H)
+    return dx, dg, db
+
+
+def _drop_bwd(g2, drop):
+    if not drop[1]:
+        return g2
+    out = torch.empty_like(g2)
+    nat.dropout_f32(g2, out, drop)
+    return out
+
+
+def _grad2(g, cols):
+    g2 = g.reshape(-1, cols)
+    g2 = g2 if g2.dtype == F32 else g2.float()
+    return g2 if g2.is_contiguous() else g2.contiguous()
+
+
+def _pad4(dz):
+    """A gradient whose width is not a multiple of 4 (the 3129 answer logits) as a zero-padded buffer with 16-byte rows; the returned
+    view keeps the true width, its stride is the padded one."""
+    M, N = dz.shape
+    if N % 4 == 0:
+        return dz
+    NP = (N + 3) // 4 * 4
+    out = _empty(M, NP, like=dz)
+    nat.pad_rows_f32(dz, N, out, NP, M)
+    return out[:, :N]
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b): act 0 none, 1 exact-erf GELU (its derivative saved by the epilogue), 3 tanh."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x2 = _rows(x)
+        w = _w(weight)
+        N = w.shape[0]
+        if x2.shape[1] % 4:
+            raise ValueError("fp32 path: the contraction length (%d) must be a multiple of 4" % x2.shape[1])
+        U = _empty(x2.shape[0], N, like=x2) if act == 1 else None
+        y = _gemm(x2, w, N, bias=None if bias is None else _w(bias), act=act, U=U)
+        ctx.save_for_backward(x2, w, U if act == 1 else (y if act == 3 else None))
+        ctx.meta = (x.shape, act, bias is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, aux = ctx.saved_tensors
+        xshape, act, has_bias = ctx.meta
+        dz = _grad2(g, w.shape[0])
+        if act == 1 or act == 3:
+            t = torch.empty_like(dz)
+            nat.eltwise_f32(0 if act == 1 else 4, dz, aux, t)       # dy * gelu'(pre)  |  dy * (1 - y^2)
+            dz = t
+        dz = _pad4(dz)
+        dx = _dgrad(dz, w).view(xshape) if ctx.needs_input_grad[0] else None
+        return dx, _wgrad(dz, x2), (_colsum(dz) if has_bias else None), None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = _rows(x)
+        out, mean, rstd = _ln_fwd(x2, gamma, beta, eps)
+        ctx.save_for_backward(x2, mean, rstd, gamma.detach())
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        dx, dg, db = _ln_bwd(_grad2(g, x2.shape[1]), x2, mean, rstd, gamma)
+        return dx.view(g.shape), dg, db, None
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        x2 = _rows(x)
+        y = torch.empty_like(x2)
+        nat.dropout_f32(x2, y, drop)
+        ctx.drop = drop
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _drop_bwd(_grad2(g, g.shape[-1]), ctx.drop).view(g.shape), None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[b] = x[b, index[b]] (the `vqa` pooling, visual_bert.py:389-398)."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        B, S, H = x.shape
+        out = _empty(B, H, like=x)
+        ix = index.contiguous().long()
+        nat.gather_rows_f32(_rows(x), ix, out, B, S, H)
+        ctx.save_for_backward(ix)
+        ctx.meta = (B, S, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ix,) = ctx.saved_tensors
+        B, S, H = ctx.meta
+        dx = torch.zeros(B * S, H, dtype=F32, device=g.device)
+        nat.scatter_add_rows_f32(_grad2(g, H), H, B, H, ix, dx, H, dst_stride=S)
+        return dx.view(B, S, H), None
+
+
+class AttentionBlockFn(torch.autograd.Function):
+    """BertAttentionJit.forward (hf_layers.py:233-252): packed Q|K|V projection, fused attention, output projection + bias + dropout +
+    residual in one GEMM epilogue, LayerNorm.  Backward: LayerNorm, dropout, the output projection's dgrad / wgrad, the attention
+    backward into one [M, 3H] buffer, and the Q|K|V dgrad with the residual gradient added in ITS epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask_add, heads, eps, drop_attn, drop_hid, tail):
+        B, S, H = x.shape
+        hd = H // heads
+        P._check_head(hd, S)
+        x2 = _rows(x)
+        M = B * S
+        wqkv, bqkv = P._packed(wq, wk, wv), P._packed(bq, bk, bv)
+        qkv = _gemm(x2, wqkv, 3 * H, bias=bqkv)
+        ctxt = _empty(M, H, like=x2)
+        lse = _empty(B, heads, S, like=x2)
+        mask = None if mask_add is None else mask_add.reshape(B, S).float().contiguous()
+        nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctxt, H, B, heads, S, S, 1.0 / math.sqrt(hd), head_dim=hd,
+                              causal_tail=int(tail), lse=lse, drop=drop_attn)
+        wo_ = _w(wo)
+        y1 = _gemm(ctxt, wo_, H, bias=_w(bo), drop=drop_hid, resid=x2, ldr=H)
+        out, mean, rstd = _ln_fwd(y1, gamma, beta, eps)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean, rstd, wqkv.clone(), wo_, gamma.detach(), mask)
+        ctx.meta = (B, S, H, heads, drop_attn, drop_hid, int(tail))
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, qkv, ctxt, lse, y1, mean, rstd, wqkv, wo, gamma, mask = ctx.saved_tensors
+        B, S, H, heads, drop_attn, drop_hid, tail = ctx.meta
+        hd = H // heads
+        M = B * S
+        dy1, dgamma, dbeta = _ln_bwd(_grad2(g, H), y1, mean, rstd, gamma)
+        dz = _drop_bwd(dy1, drop_hid)
+        dctx = _dgrad(dz, wo)
+        dwo, dbo = _wgrad(dz, ctxt), _colsum(dz)
+        dqkv = _empty(M, 3 * H, like=x2)
+        delta = _empty(B, heads, S, like=x2)
+        nat.attention_f32_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctxt, H, lse, B, heads, S, S, 1.0 / math.sqrt(hd), dctx,
+                              dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, head_dim=hd, causal_tail=tail, drop=drop_attn)
+        dx = _dgrad(dqkv, wqkv, resid=dy1)
+        dw, db = _wgrad(dqkv, x2), _colsum(dqkv)
+        return (dx.view(B, S, H), dw[:H], db[:H], dw[H:2 * H], db[H:2 * H], dw[2 * H:], db[2 * H:], dwo, dbo, dgamma, dbeta,
+                None, None, None, None, None, None)
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """BertIntermediate + BertOutput (hf_layers.py:286-292): GELU in the up-projection epilogue (its derivative saved), down-projection +
+    bias + dropout + residual, LayerNorm.  Backward: the down-projection's dgrad multiplies by the saved derivative in its epilogue,
+    the up-projection's dgrad adds the residual gradient in its own."""
+
+    @staticmethod
+    def forward(ctx, a, w1, b1, w2, b2, gamma, beta, eps, drop):
+        B, S, H = a.shape
+        a2 = _rows(a)
+        M = B * S
+        w1_, w2_ = _w(w1), _w(w2)
+        I = w1_.shape[0]
+        U = _empty(M, I, like=a2)
+        hh = _gemm(a2, w1_, I, bias=_w(b1), act=1, U=U)
+        y2 = _gemm(hh, w2_, H, bias=_w(b2), drop=drop, resid=a2, ldr=H)
+        out, mean, rstd = _ln_fwd(y2, gamma, beta, eps)
+        ctx.save_for_backward(a2, hh, U, y2, mean, rstd, w1_, w2_, gamma.detach())
+        ctx.meta = (B, S, H, drop)
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, hh, U, y2, mean, rstd, w1, w2, gamma = ctx.saved_tensors
+        B, S, H, drop = ctx.meta
+        dy2, dgamma, dbeta = _ln_bwd(_grad2(g, H), y2, mean, rstd, gamma)
+        dz2 = _drop_bwd(dy2, drop)
+        dpre = _dgrad(dz2, w2, act=2, aux=U)                    # d(hh) * gelu'(pre)
+        dw2, db2 = _wgrad(dz2, hh), _colsum(dz2)
+        da = _dgrad(dpre, w1, resid=dy2)
+        dw1, db1 = _wgrad(dpre, a2), _colsum(dpre)
+        return da.view(B, S, H), dw1, db1, dw2, db2, dgamma, dbeta, None, None
+
+
+class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
+    """BertVisioLinguisticEmbeddings.forward (embeddings.py:423-459): text rows = word + position + type, visual rows = projection(features)
+    + visual type + visual position 0 written by the projection GEMM's epilogue into rows T.. of the joint sequence; LayerNorm; dropout.
+    Backward: dropout, LayerNorm, row scatters into the three text tables (the padding row of the word table dropped) and the visual
+    type table, the projection's weight gradient over the gathered visual rows."""
+
+    @staticmethod
+    def forward(ctx, input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps, drop, pad_idx):
+        B, T = input_ids.shape
+        H = word.shape[1]
+        R = 0 if feats is None else feats.shape[1]
+        S = T + R
+        dev = word.device
+        ids, seg = input_ids.contiguous(), token_type_ids.contiguous()
+        y = torch.empty(B * S, H, dtype=F32, device=dev)
+        nat.embed_text_f32_fwd(ids, seg, _w(word), _w(pos), _w(typ), y, B, T, S, H)
+        f2 = vt = None
+        if R:
+            D = feats.shape[2]
+            if D % 4:
+                raise ValueError("fp32 path: visual feature width (%d) must be a multiple of 4" % D)
+            f2 = feats.reshape(B * R, D)
+            f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+            vt = vtype.reshape(B * R).contiguous()
+            nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=_w(typ_vis), rowidx=vt,
+                         rowtab_ld=H, grp=(R, T, T))
+        out, mean, rstd = _ln_fwd(y, ln_w, ln_b, eps)
+        if drop[1]:
+            o2 = torch.empty_like(out)
+            nat.dropout_f32(out, o2, drop)
+            out = o2
+        ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach())
+        ctx.meta = (B, T, R, H, drop, pad_idx, word.shape[0], pos.shape[0], typ.shape[0], 0 if typ_vis is None else typ_vis.shape[0],
+                    0 if pos_vis is None else pos_vis.shape[0])
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, seg, f2, vt, y, mean, rstd, ln_w = ctx.saved_tensors
+        B, T, R, H, drop, pad_idx, V, NP, NT, NTV, NPV = ctx.meta
+        S = T + R
+        dev = y.device
+        dy, dln_w, dln_b = _ln_bwd(_drop_bwd(_grad2(g, H), drop), y, mean, rstd, ln_w)
+        dword = torch.zeros(V, H, dtype=F32, device=dev)
+        nat.scatter_add_rows_f32(dy, H, B * T, H, ids.reshape(-1), dword, H, grp=(T, S, 0), skip=-1 if pad_idx is None else int(pad_idx))
+        dpos = torch.zeros(NP, H, dtype=F32, device=dev)
+        nat.scatter_add_rows_f32(dy, H, B * T, H, torch.arange(T, device=dev).repeat(B), dpos, H, grp=(T, S, 0))
+        dtyp = torch.zeros(NT, H, dtype=F32, device=dev)
+        nat.scatter_add_rows_f32(dy, H, B * T, H, seg.reshape(-1), dtyp, H, grp=(T, S, 0))
+        dtv = dpv = dpw = dpb = None
+        if R:
+            dvis = torch.empty(B * R, H, dtype=F32, device=dev)      # the visual rows of dy, gathered (fp32 rows moved as pairs of 16-bit words)
+            nat.copy_rows(dy.view(torch.bfloat16)[T:], S, dvis.view(torch.bfloat16), R, B, R, 2 * H)
+            dpw = _wgrad(dvis, f2)
+            dpb = _colsum(dvis)
+            dtv = torch.zeros(NTV, H, dtype=F32, device=dev)
+            nat.scatter_add_rows_f32(dvis, H, B * R, H, vt, dtv, H)
+            dpv = torch.zeros(NPV, H, dtype=F32, device=dev)
+            dpv[0].copy_(dpb)                                        # every visual row takes position row 0 (embeddings.py:411-418)
+        return None, None, None, None, dword, dpos, dtyp, dln_w, dln_b, dtv, dpv, dpw, dpb, None, None, None
+
+
+class LogitBCEFn(torch.autograd.Function):
+    """mean(BCEWithLogits(scores, targets)) * num_labels (losses.py:246-251) with an fp32 gradient."""
+
+    @staticmethod
+    def forward(ctx, scores, targets):
+        B, N = scores.shape
+        s = scores.float().contiguous()
+        t = targets.float().contiguous()
+        loss = torch.empty(1, dtype=F32, device=s.device)
+        nat.bce_logits_fwd(s, t, loss, B, N)
+        ctx.save_for_backward(s, t)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t = ctx.saved_tensors
+        d = torch.empty_like(s)
+        nat.bce_logits_f32_bwd(s, t, g.float().reshape(1).contiguous(), d, s.shape[0], s.shape[1])
+        return d, None
+
+
+# ---- the operator surface (called from mmf_amd/ops.py while `active()`) ---------------------------------------------------------------
+def visio_linguistic_embeddings(input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps, p,
+                                training, pad_idx, image_text_alignment=None):
+    if image_text_alignment is not None:
+        raise NotImplementedError("fp32 training: image_text_alignment position embeddings are not built")
+    return VisioLinguisticEmbeddingsFn.apply(input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b,
+                                             eps, make_drop(p, training), pad_idx if pad_idx is not None and pad_idx >= 0 else None)
+
+
+def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2, p_attn, p_hid1,
+                      p_hid2, training, causal_tail):
+    a = AttentionBlockFn.apply(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, mask_add, heads, eps1, make_drop(p_attn, training),
+                               make_drop(p_hid1, training), causal_tail)
+    return FeedForwardFn.apply(a, w1, b1, w2, b2, ln2_w, ln2_b, eps2, make_drop(p_hid2, training))
+
+
+def linear(x, weight, bias):
+    return LinearFn.apply(x, weight, bias, 0)
+
+
+def dense_gelu(x, weight, bias):
+    return LinearFn.apply(x, weight, bias, 1)
+
+
+def linear_tanh(x, weight, bias):
+    return LinearFn.apply(x, weight, bias, 3)
+
+
+def layer_norm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def dropout(x, p, training):
+    drop = make_drop(p, training)
+    return DropoutFn.apply(x, drop) if drop[1] else x
+
+
+def gather_rows(x, index, p, training):
+    return dropout(GatherRowsFn.apply(x, index), p, training)
+
+
+def logit_bce(scores, targets):
+    return LogitBCEFn.apply(scores, targets)
+
+
+def unsupported(name):
+    raise NotImplementedError("mmf_amd.fp32_training(): operator `%s` has no fp32 backward yet (built: the VisualBERT classification step)" % name)

@@ -7,6 +7,7 @@ import warnings
 import torch
 from torch import nn
 
+from mmf_amd import fp32_train as F32T
 from mmf_amd import functional as Fn
 from mmf_amd import ops  # noqa: F401  (registers torch.ops.mmf_amd.*)
 from mmf_amd.common.registry import registry
@@ -87,6 +88,8 @@ class LogitBinaryCrossEntropy(nn.Module):
 
     @torch.jit.unused      # losses are attached by BaseModel.__call__ (base_model.py:305-337), outside the scripted forward
     def forward(self, sample_list, model_output):
+        if F32T.active():       # mmf_amd.fp32_training(): the fp32 gradient (the operator's own backward hands bf16-rounded values on)
+            return F32T.logit_bce(model_output["scores"], sample_list["targets"])
         return torch.ops.mmf_amd.logit_bce(model_output["scores"], sample_list["targets"])
 
 

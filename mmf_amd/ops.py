@@ -37,6 +37,7 @@ import torch
 
 from mmf_amd import _ops_native
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd import functional as Fn
 
 # Where the operators live: with the native library loaded (any GPU box) the schemas and the kernels of the operators in
@@ -85,6 +86,9 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, vi
                                 typ_vis, pos_vis, proj_w, proj_b, eps, p, training, pad_idx, image_text_alignment=None):
     if visual_embeddings is None or visual_embeddings_type is None:
         visual_embeddings = visual_embeddings_type = image_text_alignment = None
+    if F32T.active():
+        return F32T.visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ, ln_w, ln_b,
+                                                typ_vis, pos_vis, proj_w, proj_b, eps, p, training, pad_idx, image_text_alignment)
     if F32P.active():
         if image_text_alignment is not None:
             raise NotImplementedError("fp32 path: image_text_alignment position embeddings are not built")
@@ -102,6 +106,9 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, vi
      "int heads, float eps1, float eps2, float p_attn, float p_hid1, float p_hid2, bool training, int causal_tail) -> Tensor")
 def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2,
                       p_attn, p_hid1, p_hid2, training, causal_tail):
+    if F32T.active():
+        return F32T.transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2,
+                                      p_attn, p_hid1, p_hid2, training, causal_tail)
     if F32P.active():
         for p in (p_attn, p_hid1, p_hid2):
             F32P.check_no_dropout(p, training)
@@ -120,6 +127,8 @@ def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w
 
 @_op("linear(Tensor x, Tensor weight, Tensor? bias, bool out_f32) -> Tensor")
 def linear(x, weight, bias, out_f32):
+    if F32T.active():
+        return F32T.linear(x, weight, bias)
     if F32P.active():
         return F32P.linear(x, weight, bias)
     return Fn.LinearFn.apply(x, weight, bias, Fn.shadows.get(weight), out_f32)
@@ -127,6 +136,8 @@ def linear(x, weight, bias, out_f32):
 
 @_op("layer_norm(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor")
 def layer_norm(x, weight, bias, eps):
+    if F32T.active():
+        return F32T.layer_norm(x, weight, bias, eps)
     if F32P.active():
         return F32P.layer_norm(x, weight, bias, eps)
     return Fn.LayerNormFn.apply(x, weight, bias, eps)
@@ -134,6 +145,8 @@ def layer_norm(x, weight, bias, eps):
 
 @_op("dense_gelu(Tensor x, Tensor weight, Tensor bias) -> Tensor")
 def dense_gelu(x, weight, bias):
+    if F32T.active():
+        return F32T.dense_gelu(x, weight, bias)
     if F32P.active():
         return F32P.dense_gelu(x, weight, bias)
     return Fn.DenseGeluFn.apply(x, weight, bias, Fn.shadows.get(weight))
@@ -141,6 +154,8 @@ def dense_gelu(x, weight, bias):
 
 @_op("linear_tanh(Tensor x, Tensor weight, Tensor bias) -> Tensor")
 def linear_tanh(x, weight, bias):
+    if F32T.active():
+        return F32T.linear_tanh(x, weight, bias)
     if F32P.active():
         return F32P.linear_tanh(x, weight, bias)
     return Fn.LinearTanhFn.apply(x, weight, bias, Fn.shadows.get(weight))
@@ -148,6 +163,8 @@ def linear_tanh(x, weight, bias):
 
 @_op("gather_rows(Tensor x, Tensor index, float p, bool training) -> Tensor")
 def gather_rows(x, index, p, training):
+    if F32T.active():
+        return F32T.gather_rows(x, index, p, training)
     if F32P.active():
         F32P.check_no_dropout(p, training)
         return F32P.gather_rows(x, index)
@@ -156,6 +173,8 @@ def gather_rows(x, index, p, training):
 
 @_op("dropout(Tensor x, float p, bool training) -> Tensor")
 def dropout(x, p, training):
+    if F32T.active():
+        return F32T.dropout(x, p, training)
     if F32P.active():
         F32P.check_no_dropout(p, training)
         return x
@@ -167,6 +186,8 @@ def dropout(x, p, training):
 
 @_op("pair_halves(Tensor x) -> Tensor")
 def pair_halves(x):
+    if F32T.active():
+        F32T.unsupported("pair_halves")
     if F32P.active():
         return F32P.pair_halves(x)
     return Fn.PairHalvesFn.apply(x)
@@ -174,6 +195,8 @@ def pair_halves(x):
 
 @_op("masked_lm_head(Tensor x, Tensor weight, Tensor bias, Tensor labels, int ignore_index) -> (Tensor, Tensor)")
 def masked_lm_head(x, weight, bias, labels, ignore_index):
+    if F32T.active():
+        F32T.unsupported("masked_lm_head")
     if F32P.active():
         return F32P.masked_lm_head(x, weight, bias, labels, ignore_index)
     return Fn.MaskedLMHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), labels, ignore_index)
@@ -181,6 +204,8 @@ def masked_lm_head(x, weight, bias, labels, ignore_index):
 
 @_op("masked_region_head(Tensor x, Tensor weight, Tensor bias, Tensor target, Tensor row_label) -> (Tensor, Tensor)")
 def masked_region_head(x, weight, bias, target, row_label):
+    if F32T.active():
+        F32T.unsupported("masked_region_head")
     if F32P.active():
         raise NotImplementedError("fp32 path: ViLBERT's masked-region head is not built")
     return Fn.MaskedRegionHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), target, row_label)
@@ -188,6 +213,8 @@ def masked_region_head(x, weight, bias, target, row_label):
 
 @_op("logit_bce(Tensor scores, Tensor targets) -> Tensor")
 def logit_bce(scores, targets):
+    if F32T.active():
+        return F32T.logit_bce(scores, targets)
     return Fn.LogitBCEFn.apply(scores, targets)
 
 

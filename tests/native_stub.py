@@ -90,13 +90,43 @@ def _attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk
     calls[-1] = ("attention_bwd", B, heads, Sq, Sk, causal_tail)
 
 
+def _attention_f32_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta, head_dim=64, causal_tail=0,
+                       drop=None):
+    hd = head_dim
+    for t in (q, k, v, ctx, dctx, dq, dk, dv, lse, delta):
+        assert t.dtype == torch.float32
+    _need(q, B * Sq, ldq, heads * hd, "attention_f32_bwd q"); _need(dq, B * Sq, ldq, heads * hd, "attention_f32_bwd dq")
+    _need(k, B * Sk, ldk, heads * hd, "attention_f32_bwd k"); _need(dk, B * Sk, ldk, heads * hd, "attention_f32_bwd dk")
+    _need(v, B * Sk, ldv, heads * hd, "attention_f32_bwd v"); _need(dv, B * Sk, ldv, heads * hd, "attention_f32_bwd dv")
+    _need(ctx, B * Sq, ldo, heads * hd, "attention_f32_bwd ctx"); _need(dctx, B * Sq, ldo, heads * hd, "attention_f32_bwd dctx")
+    assert lse.numel() == B * heads * Sq == delta.numel()
+    calls.append(("attention_f32_bwd", B, heads, Sq, Sk))
+
+
 def _gemm_f32(A, B, C_out, M, Nn, K, lda, ldb, ldc, bias=None, coladd=None, rowtab=None, rowidx=None, rowtab_ld=0, act=0, resid=None,
-              ldr=0, grp=(0, 0, 0)):
-    for t in (A, B, C_out, resid, bias, coladd, rowtab):
+              ldr=0, grp=(0, 0, 0), a_kmajor=False, b_kmajor=False, U=None, aux=None, drop=None, beta=0.0, split_k=False):
+    for t in (A, B, C_out, resid, bias, coladd, rowtab, U, aux):
         assert t is None or t.dtype == torch.float32
-    assert K % 4 == 0 and lda % 4 == 0 and ldb % 4 == 0 and lda >= K and ldb >= K and ldc >= Nn and act in (0, 1, 3)
+    assert lda % 4 == 0 and ldb % 4 == 0 and ldc >= Nn and act in (0, 1, 2, 3, 4)
+    assert not a_kmajor or b_kmajor
     assert A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
-    _need(A, M, lda, K, "gemm_f32 A"); _need(B, Nn, ldb, K, "gemm_f32 B")
+    if a_kmajor:
+        assert lda >= M
+        _need(A, K, lda, M, "gemm_f32 A (k-major)")
+    else:
+        assert lda >= (K + 3) // 4 * 4
+        _need(A, M, lda, K, "gemm_f32 A")
+    if b_kmajor:
+        assert ldb >= Nn
+        _need(B, K, ldb, Nn, "gemm_f32 B (k-major)")
+    else:
+        assert ldb >= (K + 3) // 4 * 4
+        _need(B, Nn, ldb, K, "gemm_f32 B")
+    assert (act not in (2, 4)) or aux is not None
+    assert U is None or act == 1
+    for t in (U, aux):
+        if t is not None:
+            _need(t, M, ldc, Nn, "gemm_f32 U / aux")
     rows_out = M if grp[0] == 0 else (M - 1) + ((M - 1) // grp[0]) * grp[1] + grp[2] + 1
     _need(C_out, rows_out, ldc, Nn, "gemm_f32 C")
     for v in (bias, coladd):
@@ -110,7 +140,8 @@ def _gemm_f32(A, B, C_out, M, Nn, K, lda, ldb, ldc, bias=None, coladd=None, rowt
     calls.append(("gemm_f32", M, Nn, K))
 
 
-def _attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64, causal_tail=0):
+def _attention_f32_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, scale, head_dim=64, causal_tail=0, lse=None, drop=None):
+    assert lse is None or (lse.dtype == torch.float32 and lse.numel() == B * heads * Sq)
     assert (head_dim == 64 and Sk <= 256) or (head_dim == 128 and Sk <= 128)
     assert 0 <= causal_tail <= Sk and (causal_tail == 0 or Sq == Sk)
     for t in (q, k, v, ctx):
@@ -248,7 +279,7 @@ def _wra_bwd(seq, ld, B, S, H, M, Nn, txt_pad, img_pad, label, xinv, yinv, plan,
     _need(dseq, B * S, ldd, H, "wra dseq")
 
 
-_CHECKED = {"mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
+_CHECKED = {"mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "attention_f32_bwd": _attention_f32_bwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
             "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,

@@ -67,6 +67,54 @@ def test_gemm_f32_row_remap_table_adds_and_strided_output():
     assert bool((got[:, :H] == -3.0).all()) and bool((got[:, 2 * H:] == -3.0).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(37, 50, 24), (300, 768, 3072), (1000, 3072, 768), (130, 3129, 1536)])
+def test_gemm_f32_dgrad_layout(M, N, K):
+    """dX = dY W: A = dY [M, K] rows, B = W [K, N] k-major (the weight as stored, hf_layers.py:169-180 backward), with the saved-derivative
+    multiply (act 2), beta accumulation and a residual gradient in the epilogue."""
+    dy, W = _rand(M, K, seed=1), _rand(K, N + (4 - N % 4) % 4, seed=2, scale=K ** -0.5)
+    ldb = W.shape[1]
+    aux, acc0, resid = _rand(M, N, seed=3), _rand(M, N, seed=4), _rand(M, N, seed=5)
+    ref = (dy.double() @ W.double()[:, :N]) * aux.double() + resid.double() + 0.5 * acc0.double()
+    out = acc0.clone().cuda()
+    nat.gemm_f32(dy.cuda(), W.cuda(), out, M, N, K, K, ldb, N, b_kmajor=True, act=2, aux=aux.cuda(), resid=resid.cuda(), ldr=N, beta=0.5)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=KERNEL_TOL, atol=KERNEL_TOL)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(24, 40, 50, False), (768, 768, 7296, True), (3072, 768, 3000, True), (100, 2304, 7296, True), (3129, 1536, 64, False)])
+def test_gemm_f32_weight_gradient_layout(M, N, K, split):
+    """dW = dY^T X: both operands k-major ([rows, M] and [rows, N] as stored), K = B S rows; deterministic split-K slabs."""
+    dy, x = _rand(K, M + (4 - M % 4) % 4, seed=1), _rand(K, N, seed=2)
+    lda = dy.shape[1]
+    ref = dy.double()[:, :M].t() @ x.double()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    nat.gemm_f32(dy.cuda(), x.cuda(), out, M, N, K, lda, N, N, a_kmajor=True, b_kmajor=True, split_k=split)
+    tol = KERNEL_TOL * max(1.0, (K / 3072.0) ** 0.5)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max()) / 50))
+    out2 = torch.full((M, N), float("nan"), device="cuda")
+    nat.gemm_f32(dy.cuda(), x.cuda(), out2, M, N, K, lda, N, N, a_kmajor=True, b_kmajor=True, split_k=split)
+    assert torch.equal(out, out2)                                   # fixed summation order
+
+
+def test_gemm_f32_gelu_saves_its_derivative_and_dropout_is_reproducible():
+    M, N, K = 200, 256, 64
+    A, W, bias = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    pre = A.double() @ W.double().t() + bias.double()
+    out = torch.empty(M, N, device="cuda"); U = torch.empty(M, N, device="cuda")
+    nat.gemm_f32(A.cuda(), W.cuda(), out, M, N, K, K, K, N, bias=bias.cuda(), act=1, U=U)
+    phi = torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+    cdf = 0.5 * (1.0 + torch.erf(pre / math.sqrt(2.0)))
+    torch.testing.assert_close(out.cpu().double(), pre * cdf, rtol=KERNEL_TOL, atol=KERNEL_TOL)
+    torch.testing.assert_close(U.cpu().double(), cdf + pre * phi, rtol=KERNEL_TOL, atol=KERNEL_TOL)
+    drop = nat.drop_cfg(0.25, 1234)
+    d1 = torch.empty(M, N, device="cuda"); d2 = torch.empty(M, N, device="cuda")
+    nat.gemm_f32(A.cuda(), W.cuda(), d1, M, N, K, K, K, N, bias=bias.cuda(), drop=drop)
+    nat.gemm_f32(A.cuda(), W.cuda(), d2, M, N, K, K, K, N, bias=bias.cuda(), drop=drop)
+    assert torch.equal(d1, d2)
+    kept = d1 != 0
+    assert abs(float(kept.float().mean()) - 0.75) < 0.01
+    torch.testing.assert_close(d1.cpu().double()[kept.cpu()], (pre / 0.75)[kept.cpu()], rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_f32_rejects_what_it_does_not_compute():
     a = torch.zeros(8, 6, device="cuda"); w = torch.zeros(8, 6, device="cuda"); c = torch.zeros(8, 8, device="cuda")
     with pytest.raises(nat.NativeLibraryError, match="multiples of 4"):

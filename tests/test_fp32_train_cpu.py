@@ -1,0 +1,46 @@
+"""Host logic of `mmf_amd.fp32_training()` without a GPU: the kernel wrappers are replaced by recorders (tests/native_stub.py), the
+VisualBERT step runs forward and backward through the fp32 autograd nodes, and what is checked is the plumbing — every launch is an
+fp32 kernel, every parameter receives an fp32 gradient of its own shape, operators without a backward refuse."""
+import pytest
+import torch
+
+import mmf_amd
+from mmf_amd.common.sample import SampleList
+from tests import golden_utils as G
+from tests import model_utils as MU
+from tests import native_stub
+
+BF16_KERNELS = {"gemm", "gemm_grouped", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd", "embed_text_fwd", "dropout",
+                "gather_rows", "bce_logits_bwd", "cast_f32_to_bf16"}
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_visual_bert_step_builds_an_fp32_graph_only(train):
+    z, case, cfg, sd, sample = G.load_case("small64")
+    model = MU.build_visual_bert(cfg, sd, device="cpu")
+    model.train(train)
+    with native_stub.installed() as calls:
+        with mmf_amd.fp32_training():
+            out = model(SampleList(sample))
+        (key, loss), = out["losses"].items()
+        assert out["scores"].dtype == torch.float32 and loss.requires_grad
+        loss.backward()
+        names = {c[0] for c in calls}
+    assert not (names & BF16_KERNELS), names & BF16_KERNELS
+    assert {"gemm_f32", "attention_f32_fwd", "attention_f32_bwd", "layernorm_f32_fwd_stats", "layernorm_f32_bwd", "colsum_f32",
+            "scatter_add_rows_f32", "bce_logits_f32_bwd"} <= names, names
+    assert ("dropout_f32" in names) == train
+    for k, p in model.named_parameters():
+        if "pooler" in k:            # computed and discarded under pooler_strategy == "vqa": no gradient, as in the reference
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape, k
+
+
+def test_operators_without_an_fp32_backward_refuse():
+    z, case, cfg, sd, sample = G.load_nlvr2_case()
+    model = MU.build_visual_bert(cfg, sd, device="cpu", training_head_type="nlvr2", pooler_strategy="default", losses=[dict(type="cross_entropy")])
+    model.eval()
+    with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32_training"):
+        with mmf_amd.fp32_training():
+            model(SampleList(sample))

@@ -1,0 +1,297 @@
+"""fp32 training kernels (mmf_amd/csrc/fp32_train.hip, the attention backward in fp32_path.hip) against float64 PyTorch autograd of the
+same operations, and the fp32 VisualBERT training step (`mmf_amd.fp32_training()`) against the real reference's fixture and the CPU
+oracle: every parameter gradient within north_star's fp32 bound (1e-3)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import mmf_amd
+from mmf_amd import _native as nat
+from mmf_amd.common.sample import SampleList
+from oracle import visual_bert_oracle as O
+from tests import golden_utils as G
+from tests.model_utils import build_visual_bert, sample_to
+
+pytestmark = pytest.mark.gpu
+TOL_FP32 = 1e-3
+KERNEL_TOL = 5e-5
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def _ref_attention(q, k, v, ext, scale, B, heads, Sq, Sk, hd, keep=None):
+    qd = q.view(B, Sq, heads, hd).transpose(1, 2)
+    kd = k.view(B, Sk, heads, hd).transpose(1, 2)
+    vd = v.view(B, Sk, heads, hd).transpose(1, 2)
+    p = torch.softmax(qd @ kd.transpose(-1, -2) * scale + ext, -1)
+    if keep is not None:
+        p = p * keep
+    return (p @ vd).transpose(1, 2).reshape(B * Sq, heads * hd)
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,hd,tail", [(2, 2, 24, 24, 64, 0), (2, 12, 228, 228, 64, 0), (3, 2, 40, 150, 64, 0), (2, 2, 70, 70, 64, 12),
+                                                    (2, 8, 101, 128, 128, 0), (2, 4, 128, 37, 128, 0), (1, 2, 256, 256, 64, 0)])
+def test_attention_f32_backward_matches_float64_autograd(B, heads, Sq, Sk, hd, tail):
+    H = heads * hd
+    scale = 1.0 / math.sqrt(hd)
+    q, k, v, do = _rand(B * Sq, H, seed=1), _rand(B * Sk, H, seed=2), _rand(B * Sk, H, seed=3), _rand(B * Sq, H, seed=4)
+    key_mask = torch.ones(B, Sk)
+    key_mask[0, Sk // 2: Sk // 2 + 5] = 0
+    key_mask[-1, ::3] = 0
+    key_mask[-1, 0] = 1
+    if tail:
+        key_mask[:, Sk - tail:] = 0
+    ext = key_mask[:, None, None, :].repeat(1, 1, Sq, 1)
+    if tail:
+        ext[:, :, Sq - tail:, Sk - tail:] = torch.tril(torch.ones(tail, tail))
+    ext = ((1.0 - ext) * -10000.0).double()
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = _ref_attention(qd, kd, vd, ext, scale, B, heads, Sq, Sk, hd)
+    ref.backward(do.double())
+    qc, kc, vc, doc = q.cuda(), k.cuda(), v.cuda(), do.cuda()
+    mask = ((1.0 - key_mask) * -10000.0).cuda()
+    out = torch.full((B * Sq, H), float("nan"), device="cuda")
+    lse = torch.empty(B, heads, Sq, device="cuda")
+    nat.attention_f32_fwd(qc, kc, vc, H, H, H, mask, out, H, B, heads, Sq, Sk, scale, head_dim=hd, causal_tail=tail, lse=lse)
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=KERNEL_TOL, atol=KERNEL_TOL)
+    dq, dk, dv = (torch.full_like(t, float("nan")) for t in (qc, kc, vc))
+    delta = torch.empty(B, heads, Sq, device="cuda")
+    nat.attention_f32_bwd(qc, kc, vc, H, H, H, mask, out, H, lse, B, heads, Sq, Sk, scale, doc, dq, dk, dv, delta, head_dim=hd, causal_tail=tail)
+    for name, got, want in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2 * KERNEL_TOL, atol=2 * KERNEL_TOL, msg=lambda m, n=name: n + ": " + m)
+
+
+def test_attention_f32_dropout_forward_and_backward_use_the_same_mask():
+    """Probability dropout: the mask is recovered from the forward itself (V = unit rows, 64 keys at a time), then forward and backward are
+    checked against float64 autograd with THAT mask; keep rate ~ 1 - p; the same key reproduces the same mask."""
+    B, heads, S, hd, p = 2, 2, 100, 64, 0.25
+    H = heads * hd
+    scale = 1.0 / math.sqrt(hd)
+    q, k, v, do = _rand(B * S, H, seed=1), _rand(B * S, H, seed=2), _rand(B * S, H, seed=3), _rand(B * S, H, seed=4)
+    drop = nat.drop_cfg(p, 4242)
+    qc, kc, vc, doc = q.cuda(), k.cuda(), v.cuda(), do.cuda()
+
+    def fwd(vv, dr):
+        out = torch.empty(B * S, H, device="cuda"); lse = torch.empty(B, heads, S, device="cuda")
+        nat.attention_f32_fwd(qc, kc, vv, H, H, H, None, out, H, B, heads, S, S, scale, lse=lse, drop=dr)
+        return out, lse
+    pd = torch.zeros(B, heads, S, S, dtype=torch.float64)
+    for c0 in range(0, S, hd):
+        ve = torch.zeros(B, S, heads, hd)
+        for kk in range(c0, min(S, c0 + hd)):
+            ve[:, kk, :, kk - c0] = 1.0
+        o, _ = fwd(ve.reshape(B * S, H).cuda(), drop)
+        pd[..., c0:c0 + hd] = o.cpu().double().view(B, S, heads, hd).transpose(1, 2)[..., : min(S, c0 + hd) - c0]
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    pfull = torch.softmax(qd.view(B, S, heads, hd).transpose(1, 2) @ kd.view(B, S, heads, hd).transpose(1, 2).transpose(-1, -2) * scale, -1)
+    keep = torch.where(pfull.detach() > 1e-12, pd / pfull.detach(), torch.ones_like(pd))
+    kept = keep > 0.5
+    assert abs(float(kept.double().mean()) - (1 - p)) < 0.01
+    torch.testing.assert_close(keep[kept], torch.full_like(keep[kept], 1.0 / (1 - p)), rtol=1e-4, atol=1e-4)
+    keep = kept.double() / (1 - p)
+    ref = _ref_attention(qd, kd, vd, 0.0, scale, B, heads, S, S, hd, keep=keep)
+    ref.backward(do.double())
+    out, lse = fwd(vc, drop)
+    out2, _ = fwd(vc, drop)
+    assert torch.equal(out, out2)
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=KERNEL_TOL, atol=KERNEL_TOL)
+    dq, dk, dv = (torch.empty_like(t) for t in (qc, kc, vc))
+    delta = torch.empty(B, heads, S, device="cuda")
+    nat.attention_f32_bwd(qc, kc, vc, H, H, H, None, out, H, lse, B, heads, S, S, scale, doc, dq, dk, dv, delta, drop=drop)
+    for name, got, want in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2 * KERNEL_TOL, atol=2 * KERNEL_TOL, msg=lambda m, n=name: n + ": " + m)
+
+
+@pytest.mark.parametrize("rows,H", [(5, 128), (7296, 768), (300, 1024), (33, 2048)])
+def test_layernorm_f32_backward(rows, H):
+    x, dy = _rand(rows, H, seed=1, scale=2.0) + 0.3, _rand(rows, H, seed=2)
+    gamma, beta = _rand(H, seed=3) * 0.1 + 1.0, _rand(H, seed=4) * 0.1
+    xd, gd, bd = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (H,), gd, bd, 1e-12)
+    ref.backward(dy.double())
+    xc, gc = x.cuda(), gamma.cuda()
+    y = torch.empty(rows, H, device="cuda"); mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    nat.layernorm_f32_fwd_stats(xc, gc, beta.cuda(), y, mean, rstd, rows, H, 1e-12)
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=KERNEL_TOL, atol=KERNEL_TOL)
+    dx = torch.full((rows, H), float("nan"), device="cuda"); dg = torch.empty(H, device="cuda"); db = torch.empty(H, device="cuda")
+    nat.layernorm_f32_bwd(dy.cuda(), xc, mean, rstd, gc, dx, dg, db, rows, H)
+    torch.testing.assert_close(dx.cpu().double(), xd.grad, rtol=KERNEL_TOL, atol=KERNEL_TOL)
+    tol = KERNEL_TOL * max(1.0, math.sqrt(rows / 100.0))
+    torch.testing.assert_close(dg.cpu().double(), gd.grad, rtol=tol, atol=tol)
+    torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=tol, atol=tol)
+
+
+def test_colsum_dropout_and_row_scatter_f32():
+    rows, N = 7296, 3072
+    x = _rand(rows, N, seed=1)
+    out = torch.empty(N, device="cuda")
+    nat.colsum_f32(x.cuda(), N, rows, N, out)
+    torch.testing.assert_close(out.cpu().double(), x.double().sum(0), rtol=1e-4, atol=2e-4)
+    nat.colsum_f32(x.cuda(), N, rows, N, out, accumulate=True)
+    torch.testing.assert_close(out.cpu().double(), 2 * x.double().sum(0), rtol=1e-4, atol=4e-4)
+    narrow = torch.empty(37, device="cuda")
+    nat.colsum_f32(x.cuda()[:, 5:], N, 100, 37, narrow)                                          # a column slice of a wider buffer
+    torch.testing.assert_close(narrow.cpu().double(), x.double()[:100, 5:42].sum(0), rtol=1e-4, atol=1e-4)
+    drop = nat.drop_cfg(0.1, 77)
+    xs = x.cuda()[:1000].contiguous()
+    y1, y2 = torch.empty_like(xs), torch.empty_like(xs)
+    nat.dropout_f32(xs, y1, drop); nat.dropout_f32(xs, y2, drop)
+    assert torch.equal(y1, y2)
+    kept = y1 != 0
+    assert abs(float(kept.float().mean()) - 0.9) < 0.005
+    torch.testing.assert_close(y1[kept], (xs / (1 - round(0.1 * 65536) / 65536))[kept], rtol=1e-5, atol=1e-6)
+    # embedding backward: rows b * S + t (t < T) of a [B, S, H] gradient scattered by token id, the padding id dropped
+    B, T, S, H, V = 4, 6, 10, 64, 9
+    g = _rand(B * S, H, seed=5)
+    ids = torch.randint(0, V, (B * T,), generator=torch.Generator().manual_seed(6))
+    table = torch.zeros(V, H, device="cuda")
+    nat.scatter_add_rows_f32(g.cuda(), H, B * T, H, ids.cuda(), table, H, grp=(T, S, 0), skip=0)
+    ref = torch.zeros(V, H, dtype=torch.float64)
+    src = g.double().view(B, S, H)[:, :T].reshape(B * T, H)
+    ref.index_add_(0, ids, src)
+    ref[0] = 0
+    torch.testing.assert_close(table.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    # pooling-gather backward: one row per sample at b * S + index[b]
+    idx = torch.tensor([3, 0, 9, 5])
+    gp = _rand(B, H, seed=7)
+    full = torch.zeros(B * S, H, device="cuda")
+    nat.scatter_add_rows_f32(gp.cuda(), H, B, H, idx.cuda(), full, H, dst_stride=S)
+    want = torch.zeros(B, S, H); want[torch.arange(B), idx] = gp
+    assert torch.equal(full.cpu(), want.view(B * S, H))
+
+
+def _rel(a, b):
+    a = a.detach().double().flatten().cpu(); b = b.detach().double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _check_all_gradients(model, sdr, tol):
+    params = dict(model.named_parameters())
+    errs = {}
+    for k, v in sdr.items():
+        p = params["model." + k]
+        if v.grad is None or float(v.grad.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None and p.grad.dtype == torch.float32, k
+        if k.endswith("self.key.bias"):
+            # d/d(key bias) is identically zero in exact arithmetic (a per-query constant shift of the scores cancels in the softmax):
+            # both sides hold rounding noise only
+            qn = float(params["model." + k.replace("key.bias", "query.bias")].grad.double().norm())
+            assert float(p.grad.double().norm()) <= tol * qn + 1e-6, k
+            continue
+        errs[k] = _rel(p.grad, v.grad)
+    bad = {k: e for k, e in errs.items() if e > tol}
+    assert not bad, bad
+    return errs
+
+
+def test_fp32_training_golden_small64_gradients_within_the_fp32_bound():
+    """The reference's own fixture (tests/golden/make_golden.py ran /root/reference's VisualBERT + LogitBinaryCrossEntropy, forward and
+    backward, in fp32): loss, scores, gradient norms and sums of every parameter, full gradients of the small ones."""
+    z, case, cfg, sd, sample = G.load_case("small64")
+    model = build_visual_bert(cfg, sd, output_hidden_states=True)
+    model.eval()
+    with mmf_amd.fp32_training():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    assert out["scores"].dtype == torch.float32 and out["scores"].requires_grad
+    np.testing.assert_allclose(out["scores"].detach().cpu().numpy(), z["scores"], rtol=TOL_FP32, atol=TOL_FP32)
+    (key, loss), = out["losses"].items()
+    assert key == "train/vqa2/logit_bce" and abs(loss.item() - float(z["loss"])) <= TOL_FP32 * abs(float(z["loss"]))
+    loss.backward()
+    params = dict(model.named_parameters())
+    for gname, norm, gsum in zip(z["grad_names"], z["grad_norms"], z["grad_sums"]):
+        gname = str(gname)
+        p = params[gname]
+        if norm == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, gname
+            continue
+        assert p.grad is not None, gname
+        if gname.endswith("self.key.bias"):
+            continue
+        assert abs(float(p.grad.double().norm()) - norm) <= TOL_FP32 * norm, gname
+        assert abs(float(p.grad.double().sum()) - gsum) <= TOL_FP32 * norm + 1e-7, gname
+        full = "grad::" + gname
+        if full in z.files:
+            assert _rel(p.grad, torch.from_numpy(z[full])) <= TOL_FP32, gname
+
+
+def test_fp32_training_full_config_every_gradient_matches_the_oracle():
+    """VisualBERT-base VQA2 (12 layers, 128 tokens + 100 regions, ragged lengths), eval mode (dropout off), B = 4: every parameter
+    gradient against the CPU oracle's autograd, relative L2 error <= 1e-3 (observed ~1e-6)."""
+    cfg = dict(O.DEFAULT_CONFIG)
+    cfg["num_hidden_layers"] = 12
+    sd = O.init_state_dict(cfg, seed=7)
+    g = torch.Generator().manual_seed(8)
+    for k in sd:
+        if k.endswith(".bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+        elif k.endswith("LayerNorm.weight"):
+            sd[k] = 1.0 + torch.randn(sd[k].shape, generator=g) * 0.05
+    sample = O.synthetic_batch(cfg, 4, seed=99)
+    sample["input_mask"][1, 90:] = 0
+    sample["image_info_0"]["max_features"][0] = 73
+    model = build_visual_bert(cfg, sd)
+    model.eval()
+    with mmf_amd.fp32_training():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    (key, loss), = out["losses"].items()
+    loss.backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.visual_bert_forward(sdr, cfg, sample, train=False)
+    ref_loss = O.logit_bce(ref["scores"], sample["targets"])
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= TOL_FP32 * abs(ref_loss.item())
+    assert (out["scores"].detach().cpu() - ref["scores"].detach()).abs().max().item() <= TOL_FP32
+    errs = _check_all_gradients(model, sdr, TOL_FP32)
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    json.dump({"parameters_compared": len(errs), "worst_rel_l2": worst, "loss": loss.item(), "oracle_loss": ref_loss.item()},
+              open("gpurun_out/fp32_training_grad_errors.json", "w"), indent=1)
+
+
+def test_fp32_training_step_with_dropout_and_fused_adamw():
+    """Train mode (dropout 0.1 everywhere, the hash masks regenerated in the backward), a few steps of the fused AdamW on the fp32
+    gradients: reproducible under torch.manual_seed (to the summation order of the embedding scatters), the loss on the fixed batch goes down, nothing is left in the bf16 routing afterwards."""
+    from mmf_amd.modules.optimizers import AdamW
+    z, case, cfg, sd, sample = G.load_case("small64")
+
+    def run(steps):
+        torch.manual_seed(1234)
+        model = build_visual_bert(cfg, sd)
+        model.train()
+        opt = AdamW(model.parameters(), lr=2e-3, weight_decay=0.01)
+        batch = SampleList(sample_to(sample, "cuda"))
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            with mmf_amd.fp32_training():
+                out = model(batch)
+            (key, loss), = out["losses"].items()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return losses, model
+    a, model = run(6)
+    b, _ = run(6)
+    # same dropout masks, same arithmetic; only the embedding-table scatter adds (fp32 atomics) may reorder sums between runs
+    assert a[0] == b[0] and all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(a, b)), (a, b)
+    assert a[-1] < a[0], a
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))           # the bf16 path still runs afterwards
+    assert out["scores"].requires_grad
+
+
+def test_fp32_training_refuses_operators_without_a_backward():
+    z, case, cfg, sd, sample = G.load_nlvr2_case()
+    model = build_visual_bert(cfg, sd, training_head_type="nlvr2", pooler_strategy="default", losses=[dict(type="cross_entropy")])
+    model.eval()
+    with pytest.raises(NotImplementedError, match="fp32_training"):
+        with mmf_amd.fp32_training():
+            model(SampleList(sample_to(sample, "cuda")))

@@ -80,12 +80,44 @@ def main():
         with torch.no_grad():
             return model(batch)["scores"]
 
+    # attention backward (dQ launch + dK / dV launch) at the VisualBERT shape
+    dq = torch.empty_like(qkv); dctx = torch.randn(B * S, H, device=dev); lse = torch.empty(B, heads, S, device=dev); dl = torch.empty(B, heads, S, device=dev)
+    nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, B, heads, S, S, 0.125, lse=lse)
+    t = timed(lambda: nat.attention_f32_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, 0.125, dctx,
+                                            dq, dq[:, H:], dq[:, 2 * H:], dl))
+    res["attention_f32_bwd"] = dict(us=round(t * 1e3, 1), tflops=round(14.0 * B * heads * S * S * 64 / t / 1e9, 1),
+                                    note="7 S x S x 64 products per (batch, head): S^T, dP^T, dQ in the first launch; S, dP, dV, dK in the second")
+    # weight-gradient layout (split-K) and dgrad layout of the FFN shapes
+    dy = torch.randn(M, 3072, device=dev); xx = torch.randn(M, 768, device=dev); dw = torch.empty(3072, 768, device=dev)
+    t = timed(lambda: nat.gemm_f32(dy, xx, dw, 3072, 768, M, 3072, 768, 768, a_kmajor=True, b_kmajor=True, split_k=True))
+    res["gemm_wgrad_3072x768_K7296"] = dict(us=round(t * 1e3, 1), tflops=round(2.0 * M * 3072 * 768 / t / 1e9, 1))
+    W = torch.randn(3072, 768, device=dev); dx = torch.empty(M, 768, device=dev)
+    t = timed(lambda: nat.gemm_f32(dy, W, dx, M, 768, 3072, 3072, 768, 768, b_kmajor=True))
+    res["gemm_dgrad_768_K3072"] = dict(us=round(t * 1e3, 1), tflops=round(2.0 * M * 3072 * 768 / t / 1e9, 1))
+    print(res["attention_f32_bwd"], res["gemm_wgrad_3072x768_K7296"], res["gemm_dgrad_768_K3072"], flush=True)
+
     t32, t16 = timed(fwd32, iters=5), timed(fwd16, iters=5)
     flops = 32 * 40.97e9
     res["eval_forward_B32"] = dict(fp32_ms=round(t32, 2), fp32_samples_per_s=round(32e3 / t32, 1), fp32_tflops=round(flops / t32 / 1e9, 1),
                                    bf16_ms=round(t16, 2), bf16_samples_per_s=round(32e3 / t16, 1),
                                    max_abs_score_diff_bf16_vs_fp32=float((fwd32() - fwd16().float()).abs().max()))
     print(res["eval_forward_B32"], flush=True)
+    # the fp32 TRAINING step (mmf_amd.fp32_training(): forward + logit_bce + backward on the fp32 kernels, fused AdamW), train mode, B = 32
+    from mmf_amd.modules.optimizers import AdamW
+    model.train()
+    opt = AdamW(model.parameters(), lr=5e-5, weight_decay=0.01)
+
+    def train32():
+        opt.zero_grad()
+        with mmf_amd.fp32_training():
+            out = model(batch)
+        list(out["losses"].values())[0].backward()
+        opt.step()
+
+    tt = timed(train32, iters=4, warm=2)
+    res["train_step_fp32_B32"] = dict(ms=round(tt, 2), samples_per_s=round(32e3 / tt, 1), tflops=round(32 * 122.9e9 / tt / 1e9, 1),
+                                      frac_of_fp32_mfma_peak=round(32 * 122.9e9 / tt / 1e9 / PEAK_F32_MFMA, 3))
+    print(res["train_step_fp32_B32"], flush=True)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(res, open(os.path.join(out, "fp32_bench.json"), "w"), indent=1)

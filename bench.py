@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (not the headline)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward + loss + backward only (no AdamW update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-path side leg (eval forward + fp32 training step, ~0.3 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one hipGraph")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -534,6 +535,44 @@ def main():
         eager_step(None)
     by = probe.summary()
 
+    # the fp32-accurate path on the same model and batch (north_star's "within 1e-3 fp32" arithmetic; never the headline): eval forward
+    # and the fp32 training step (forward + logit_bce + backward on the fp32 kernels; no optimizer step here, the gradients are dropped)
+    fp32_info = None
+    if world == 1 and not args.no_fp32:
+        try:
+            import mmf_amd
+
+            def ev_ms(fn, iters=2):
+                fn(); torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / iters
+
+            def f32_train():
+                with mmf_amd.fp32_training():
+                    out = model(batch)
+                list(out["losses"].values())[0].backward()
+                model.zero_grad(set_to_none=True)
+
+            def f32_eval():
+                model.eval()
+                with mmf_amd.fp32_inference():
+                    model(batch)
+                model.train(not args.eval_mode)
+
+            t_tr, t_ev = ev_ms(f32_train), ev_ms(f32_eval)
+            fp32_info = {"train_step_ms": round(t_tr, 2), "train_samples_per_s": round(args.batch * 1e3 / t_tr, 1),
+                         "train_tflops": round(args.batch * FWD_BWD_GFLOP_PER_SAMPLE / t_tr, 1),
+                         "eval_forward_ms": round(t_ev, 2), "eval_samples_per_s": round(args.batch * 1e3 / t_ev, 1),
+                         "peak_tflops_fp32_mfma": 157.3, "train_frac_of_fp32_mfma_peak": round(args.batch * FWD_BWD_GFLOP_PER_SAMPLE / t_tr / 157.3, 3),
+                         "note": "mmf_amd.fp32_training() / fp32_inference(): fp32 activations, parameters, gradients on v_mfma_f32_16x16x4_f32; "
+                                 "forward + loss + backward (no optimizer step), train mode with dropout; parity: tests/test_fp32_train_gpu.py"}
+        except Exception as e:          # never lose the headline line over the side leg
+            fp32_info = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
@@ -586,6 +625,8 @@ def main():
             line["eager"] = eager_info
         if scale_info is not None:
             line["scale_model"] = scale_info
+        if fp32_info is not None:
+            line["fp32_path"] = fp32_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(line), flush=True)

@@ -21,11 +21,12 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // GEMM: C[m][n] = epilogue(sum_k A(m,k) * B(n,k)), everything fp32, on v_mfma_f32_16x16x4_f32 (round 3 rewrite; the round-2 kernel
 // ran the 32x32x2 MFMA from k-major LDS images with one scalar LDS read per operand register: 80-98 TFLOP/s).
-// 128x128 (or 64x128) tile per 256-thread workgroup, BK = 16; wave w owns a 64x64 (32x64) quadrant = 4x4 (4x2) MFMA blocks.
-// Both operand tiles live in LDS ROW-major, [row][k] at a row stride of BK + 4 = 20 floats, whatever their layout in memory:
+// 64x128 tile per 256-thread workgroup (the template also builds 128x128: measured no better), BK = 16; wave w owns a 32x64 quadrant
+// = 2x4 MFMA blocks of 16x16.
+// Both operand tiles live in LDS ROW-major, [row][k] with XOR-swizzled 16-byte quads (gemm_f32_lds), whatever their layout in memory:
 //   * a row operand (k contiguous in memory) is copied 16 bytes at a time;
 //   * a k-major operand (the dgrad's weight, both operands of a weight gradient) is transposed by the staging stores, with the lanes
-//     of a wave laid out 16 k x 4 row-quads so that the scalar stores hit 64 distinct banks.
+//     of a wave laid out 16 k x 4 row-quads (2-way conflicts on these scalar stores at worst).
 // The MFMA's k-slot (lane / 16) is mapped to the k QUAD 4 (lane / 16) + c, so ONE 16-byte LDS read per 16-row block feeds four MFMAs
 // (the operand rows of a wave are 8 ds_read_b128 per K-step for 64 MFMAs).  The product is formed TRANSPOSED (MFMA A operand = the
 // B tile's rows): the accumulator register r of lane l then holds C[m = block row l % 16][n = 4 (l / 16) + r], four consecutive
@@ -33,7 +34,11 @@ namespace {
 // Register double buffering: the next K-step's global loads are in flight while the MFMAs of the current one run; one barrier per
 // K-step; split-K over gridDim.z into fp32 slabs (weight gradients: K = B S rows, few output tiles) summed by splitk_f32_reduce.
 // ------------------------------------------------------------------------------------------------
-constexpr int GBM = 128, GBN = 128, GBK = 16, GRS = GBK + 4;    // (BK = 16: 41 KB of LDS, a barrier every 64 MFMAs per wave; 32: 74 KB, every 128)
+constexpr int GBN = 128, GBK = 16, GRS = GBK;        // (BK = 32 measured no better: 77-93 vs 81-96 TFLOP/s)
+// LDS tile address of (row, k): rows of GBK floats, NO padding, the 16-byte quad index XOR-swizzled by (row >> 1) & 3 — the layout for which
+// the four non-contiguous 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS) AND the 8-lane groups of ds_write_b128 are conflict-free
+// (a padded stride of 20 floats measured SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles: its quads collide inside those lane groups).
+DEVI int gemm_f32_lds(int row, int k) { return row * GRS + ((((k >> 2) ^ (row >> 1)) & 3) << 2) + (k & ~15) + (k & 3); }
 
 struct GemmF32 {
     const float* A; const float* B; float* C;
@@ -56,48 +61,58 @@ DEVI float gelu_exact_grad(float x) {
 
 // One operand tile's share of a K-step: global -> registers.  ROWS = tile rows (64 or 128); a pass of the 256 threads covers GPR rows.
 constexpr int GKQ = GBK / 4, GPR = 1024 / GBK;     // k-quads per tile row; rows per pass (64 at BK = 16, 32 at BK = 32)
+// Every load is issued unconditionally from a clamped (always valid) address and zeroed by a select afterwards: no control flow around the
+// loads, so the compiler's s_waitcnt insertion can COUNT (vmcnt(n) for the older register set while the younger set stays in flight).  With
+// the bounds checks as branches it fell back to vmcnt(0) at every stash: the full memory latency was exposed once per K-step on every
+// wave (MFMA pipe 62 % busy, the waves 66 % of their cycles in s_waitcnt; profiles/r03_fp32_gemm_pmc.txt).
 template <bool KM, int ROWS>
 DEVI void gemm_f32_fetch(f32x4 (&r)[ROWS / GPR], const float* __restrict__ base, int row0, int rows, int ld, int k0, int K, int tid) {
     if constexpr (!KM) {     // [row][k]: thread = row (tid / GKQ) + GPR h, k-quad 4 (tid % GKQ)
-        const int kq = k0 + (tid % GKQ) * 4;
+        const int kc = min(k0 + (tid % GKQ) * 4, ((K + 3) & ~3) - 4);
 #pragma unroll
-        for (int h = 0; h < ROWS / GPR; ++h) {
-            const int row = row0 + (tid / GKQ) + GPR * h;
-            r[h] = (row < rows && kq < K) ? *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int h = 0; h < ROWS / GPR; ++h)
+            r[h] = *reinterpret_cast<const f32x4*>(base + (size_t)min(row0 + (tid / GKQ) + GPR * h, rows - 1) * ld + kc);
     } else {                 // [k][row]: thread = k (tid % GBK), row-quad 4 (tid / GBK) + GPR h
-        const int k = k0 + (tid % GBK);
+        const float* kp = base + (size_t)min(k0 + (tid % GBK), K - 1) * ld;
+        const int rlast = (rows - 1) & ~3;           // first row of the last (possibly partial) quad
 #pragma unroll
         for (int h = 0; h < ROWS / GPR; ++h) {
             const int row = row0 + (tid / GBK) * 4 + GPR * h;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < K) {
-                const float* p = base + (size_t)k * ld + row;
-                if (row + 3 < rows) v = *reinterpret_cast<const f32x4*>(p);
-                else {
+            if (rows % 4 == 0 || row < rlast) {      // (uniform per launch except on the one ragged quad)
+                r[h] = *reinterpret_cast<const f32x4*>(kp + min(row, rlast));
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (row + e < rows) v[e] = p[e];
-                }
+                for (int e = 0; e < 4; ++e) r[h][e] = kp[min(row + e, rows - 1)];
             }
-            r[h] = v;
         }
     }
 }
+// registers -> LDS; what lies outside the matrix (or past the K slice) is zeroed HERE, a step after the loads were issued: a select at
+// fetch time would make the wave wait for its youngest loads
 template <bool KM, int ROWS>
-DEVI void gemm_f32_stash(const f32x4 (&r)[ROWS / GPR], float* __restrict__ tile, int tid) {
+DEVI void gemm_f32_stash(const f32x4 (&r)[ROWS / GPR], float* __restrict__ tile, int row0, int rows, int k0, int K, int tid) {
     if constexpr (!KM) {
+        const bool kok = k0 + (tid % GKQ) * 4 < K;
 #pragma unroll
-        for (int h = 0; h < ROWS / GPR; ++h) *reinterpret_cast<f32x4*>(tile + ((tid / GKQ) + GPR * h) * GRS + (tid % GKQ) * 4) = r[h];
+        for (int h = 0; h < ROWS / GPR; ++h) {
+            const int lr = (tid / GKQ) + GPR * h;
+            const f32x4 v = (kok && row0 + lr < rows) ? r[h] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(tile + gemm_f32_lds(lr, (tid % GKQ) * 4)) = v;
+        }
     } else {
+        const bool kok = k0 + (tid % GBK) < K;
 #pragma unroll
         for (int h = 0; h < ROWS / GPR; ++h)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tile[((tid / GBK) * 4 + GPR * h + e) * GRS + (tid % GBK)] = r[h][e];
+            for (int e = 0; e < 4; ++e) {
+                const int lr = (tid / GBK) * 4 + GPR * h + e;
+                tile[gemm_f32_lds(lr, tid % GBK)] = (kok && row0 + lr < rows) ? r[h][e] : 0.f;
+            }
     }
 }
 
 template <int MI, bool AKM, bool BKM>     // MI: 16-row blocks per wave along M / 2 (BM = 64 * MI)
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_f32_kernel(const GemmF32 g) {
     constexpr int BM = 64 * MI, MB = 2 * MI;      // MB m-blocks x 4 n-blocks of 16 x 16 per wave
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
     float (*As)[BM * GRS] = reinterpret_cast<float (*)[BM * GRS]>(gemm_smem);
@@ -116,42 +131,47 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
     const int nk_all = (g.K + GBK - 1) / GBK;
     const int kt0 = g.ksplit ? blockIdx.z * g.ksplit : 0;
     const int kt1 = g.ksplit ? min(nk_all, kt0 + g.ksplit) : nk_all;
-    f32x4 ra[BM / GPR], rb[GBN / GPR];
-    gemm_f32_fetch<AKM, BM>(ra, g.A, m0, g.M, g.lda, kt0 * GBK, g.K, tid);
-    gemm_f32_fetch<BKM, GBN>(rb, g.B, n0, g.N, g.ldb, kt0 * GBK, g.K, tid);
-    gemm_f32_stash<AKM, BM>(ra, As[0], tid);
-    gemm_f32_stash<BKM, GBN>(rb, Bs[0], tid);
+    // Two K-steps of operands are in flight in registers besides the two LDS stages: at the top of step kt the loads of step kt + 2 are
+    // issued into one register set while the other set — step kt + 1, loaded a whole step ago — is stashed into the free LDS stage at
+    // the bottom.  The loop is unrolled by two so that the sets swap roles without register copies (a copy would wait for the loads it
+    // copies), and the loads are pinned at the top of the step (sched_barrier): a load has two steps of MFMAs to land.
+    const int Kend = min(g.K, kt1 * GBK);          // k past this slice reads as zero (split-K slices; the odd extra step of the unrolled loop)
+    f32x4 ra[BM / GPR], rb[GBN / GPR], sa[BM / GPR], sb[GBN / GPR];
+    gemm_f32_fetch<AKM, BM>(ra, g.A, m0, g.M, g.lda, kt0 * GBK, Kend, tid);
+    gemm_f32_fetch<BKM, GBN>(rb, g.B, n0, g.N, g.ldb, kt0 * GBK, Kend, tid);
+    gemm_f32_stash<AKM, BM>(ra, As[0], m0, g.M, kt0 * GBK, Kend, tid);
+    gemm_f32_stash<BKM, GBN>(rb, Bs[0], n0, g.N, kt0 * GBK, Kend, tid);
+    gemm_f32_fetch<AKM, BM>(ra, g.A, m0, g.M, g.lda, (kt0 + 1) * GBK, Kend, tid);
+    gemm_f32_fetch<BKM, GBN>(rb, g.B, n0, g.N, g.ldb, (kt0 + 1) * GBK, Kend, tid);
     __syncthreads();
 
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) {
-            gemm_f32_fetch<AKM, BM>(ra, g.A, m0, g.M, g.lda, (kt + 1) * GBK, g.K, tid);
-            gemm_f32_fetch<BKM, GBN>(rb, g.B, n0, g.N, g.ldb, (kt + 1) * GBK, g.K, tid);
-        }
-#pragma unroll
-        for (int kg = 0; kg < GBK / 16; ++kg) {
-            f32x4 bn[4], am[MB];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) bn[nb] = *reinterpret_cast<const f32x4*>(&Bs[cur][(wn + 16 * nb + j) * GRS + 16 * kg + q4]);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) am[mb] = *reinterpret_cast<const f32x4*>(&As[cur][(wm + 16 * mb + j) * GRS + 16 * kg + q4]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[nb][c], am[mb][c], acc[nb][mb], 0, 0, 0);
-        }
-        if (more) {
-            const int nxt = cur ^ 1;   // last read in iteration kt - 1, which every wave left through the barrier below
-            gemm_f32_stash<AKM, BM>(ra, As[nxt], tid);
-            gemm_f32_stash<BKM, GBN>(rb, Bs[nxt], tid);
-        }
-        __syncthreads();
+#define MMF_F32_STEP(KT, CUR, HOLD_A, HOLD_B, LOAD_A, LOAD_B)                                                                          \
+    {                                                                                                                                  \
+        gemm_f32_fetch<AKM, BM>(LOAD_A, g.A, m0, g.M, g.lda, ((KT) + 2) * GBK, Kend, tid);                                             \
+        gemm_f32_fetch<BKM, GBN>(LOAD_B, g.B, n0, g.N, g.ldb, ((KT) + 2) * GBK, Kend, tid);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        _Pragma("unroll") for (int kg = 0; kg < GBK / 16; ++kg) {                                                                      \
+            f32x4 bn[4], am[MB];                                                                                                       \
+            _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                           \
+                bn[nb] = *reinterpret_cast<const f32x4*>(&Bs[CUR][gemm_f32_lds(wn + 16 * nb + j, 16 * kg + q4)]);                      \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                          \
+                am[mb] = *reinterpret_cast<const f32x4*>(&As[CUR][gemm_f32_lds(wm + 16 * mb + j, 16 * kg + q4)]);                      \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                              \
+                _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                       \
+                    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                  \
+                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[nb][c], am[mb][c], acc[nb][mb], 0, 0, 0);               \
+        }                                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        /* stage CUR ^ 1 was last read in the previous step, which every wave left through the barrier */                             \
+        gemm_f32_stash<AKM, BM>(HOLD_A, As[(CUR) ^ 1], m0, g.M, ((KT) + 1) * GBK, Kend, tid);                                          \
+        gemm_f32_stash<BKM, GBN>(HOLD_B, Bs[(CUR) ^ 1], n0, g.N, ((KT) + 1) * GBK, Kend, tid);                                         \
+        __syncthreads();                                                                                                               \
     }
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        MMF_F32_STEP(kt, 0, ra, rb, sa, sb)
+        MMF_F32_STEP(kt + 1, 1, sa, sb, ra, rb)        // (kt + 1 == kt1 on an odd step count: a step of zeros)
+    }
+#undef MMF_F32_STEP
 
     // epilogue: acc[nb][mb][r] = C[m = wm + 16 mb + j][n = wn + 16 nb + q4 + r]
     const uint32_t dkey = g.drop.thr16 ? drop_key(g.drop) : 0u;
@@ -714,19 +734,20 @@ static void launch_gemm_f32_one(const GemmF32& g, dim3 grid, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemm_f32_kernel<MI, AKM, BKM>), grid, dim3(256), lds, s, g);
 }
-template <int MI>
-static void launch_gemm_f32(const mmf_gemm_desc* d, const GemmF32& g, dim3 grid, hipStream_t s) {
-    if (d->a_kmajor) launch_gemm_f32_one<MI, true, true>(g, grid, s);
-    else if (d->b_kmajor) launch_gemm_f32_one<MI, false, true>(g, grid, s);
-    else launch_gemm_f32_one<MI, false, false>(g, grid, s);
+// (the k-major layouts exist with 64-row tiles only: their staging keeps more registers live, and three waves per SIMD — 168 registers —
+// measured better than 128-row tiles at two)
+static void launch_gemm_f32_64(const mmf_gemm_desc* d, const GemmF32& g, dim3 grid, hipStream_t s) {
+    if (d->a_kmajor) launch_gemm_f32_one<1, true, true>(g, grid, s);
+    else if (d->b_kmajor) launch_gemm_f32_one<1, false, true>(g, grid, s);
+    else launch_gemm_f32_one<1, false, false>(g, grid, s);
 }
 
 // K splits of a (weight-gradient shaped) problem given a workspace: enough z-slices to put ~2 tiles on every CU, >= 8 K-steps each
 extern "C" int mmf_gemm_f32_splits(int M, int N, int K) {
-    const long tiles = (long)((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+    const long tiles = (long)((M + 63) / 64) * ((N + GBN - 1) / GBN);      // (the weight-gradient layout runs 64-row tiles)
     const int nk = (K + GBK - 1) / GBK;
-    if (tiles >= 384 || nk < 32) return 1;
-    int sp = (int)((512 + tiles - 1) / tiles);
+    if (tiles >= 512 || nk < 32) return 1;
+    int sp = (int)((768 + tiles - 1) / tiles);
     if (sp > nk / 8) sp = nk / 8;
     if (sp > 32) sp = 32;
     return sp < 1 ? 1 : sp;
@@ -763,8 +784,6 @@ extern "C" int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream) {
     g.ksplit = 0;
     g.vec_ok = (d->ldc % 4) == 0 && (((uintptr_t)d->C | (uintptr_t)d->U | (uintptr_t)d->aux | (uintptr_t)d->resid | (uintptr_t)d->rowtab) & 15) == 0 &&
                (!d->resid || (d->ldr % 4) == 0) && (!d->rowtab || (d->rowtab_ld % 4) == 0);
-    // 128-row tiles unless they would leave the chip short of work (fewer than two tiles per CU): then 64-row tiles — e.g.
-    // M = 7296, N = 768: 342 tiles of 128x128 on 256 CUs (1.34 rounds) become 684 of 64x128
     const int nt = (d->N + GBN - 1) / GBN;
     int splits = 1;
     if (d->splitk_ws) {
@@ -773,8 +792,9 @@ extern "C" int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream) {
         MMF_CHECK_ARG(splits == 1 || (!d->bias && !d->coladd && !d->rowtab && d->act == 0 && !d->resid && d->drop_thr16 == 0 && d->grp_in == 0),
                       "gemm_f32: split-K takes no epilogue besides beta");
     }
-    const bool small = splits == 1 && (long)nt * ((d->M + GBM - 1) / GBM) < 512;
-    const int bm = small ? 64 : GBM;
+    // 64-row tiles everywhere: 96-140 registers = three waves per SIMD, and more, smaller tiles round off better on 256 CUs; the 128-row
+    // instantiation measured 82.6 / 91.8 TFLOP/s on the QKV / FFN-up shapes against 84.7 / 93.1 (tools/fp32_bench.py) and was dropped
+    const int bm = 64;
     dim3 grid(nt, (d->M + bm - 1) / bm, splits);
     MMF_CHECK_ARG(grid.y <= 65535u, "gemm_f32: M too large for one launch");
     if (splits > 1) {
@@ -782,8 +802,7 @@ extern "C" int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream) {
         g.ksplit = (nk + splits - 1) / splits;
         g.C = (float*)d->splitk_ws;
     }
-    if (small) launch_gemm_f32<1>(d, g, grid, s);
-    else launch_gemm_f32<2>(d, g, grid, s);
+    launch_gemm_f32_64(d, g, grid, s);
     MMF_CHECK_LAUNCH();
     if (splits > 1) {
         const long n = (long)d->M * d->N;

@@ -14,8 +14,8 @@ mmf_amd/csrc/fp32_train.hip (LayerNorm backward, column sums, dropout, row scatt
 directly, fp32 gradients.  Parity: every parameter gradient of the reference's fixture and of the full VisualBERT-base VQA2 configuration
 against the CPU oracle within north_star's fp32 bound (tests/test_fp32_train_gpu.py).
 
-Built for the operators VisualBERT's classification / nlvr2 step uses (embeddings, encoder layers, pooler, prediction-head transform,
-classifier, logit_bce); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
+Built for the operators VisualBERT's classification / nlvr2 step uses (embeddings, encoder layers, pooler, nlvr2 pairing, prediction-head
+transform, classifier, logit_bce; cross_entropy is fp32 already); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
 
 Reference operations, as in mmf_amd/functional.py: BertVisioLinguisticEmbeddings.forward (mmf/modules/embeddings.py:423-459), BertLayerJit
 .forward (mmf/modules/hf_layers.py:255-292), BertPooler / BertPredictionHeadTransform / classifier Linear (mmf/models/visual_bert.py:146,
@@ -372,6 +372,26 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
         return None, None, None, None, dword, dpos, dtyp, dln_w, dln_b, dtv, dpv, dpw, dpb, None, None, None
 
 
+class PairHalvesFn(torch.autograd.Function):
+    """nlvr2 pairing [2B, H] -> [B, 2H] = cat(x[:B], x[B:], dim=1) (visual_bert.py:369-374); backward = the two row copies reversed."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return P.pair_halves(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = _grad2(g, g.shape[-1])
+        B, H2 = g2.shape
+        H = H2 // 2
+        dx = _empty(2 * B, H, like=g2)
+        gb = g2.view(torch.bfloat16).view(2 * B, 2 * H)               # fp32 rows moved as pairs of 16-bit words: row 2b | 2b + 1 = the halves of sample b
+        db = dx.view(torch.bfloat16)
+        nat.copy_rows(gb, 2, db, 1, B, 1, 2 * H)
+        nat.copy_rows(gb[1:], 2, db[B:], 1, B, 1, 2 * H)
+        return dx
+
+
 class LogitBCEFn(torch.autograd.Function):
     """mean(BCEWithLogits(scores, targets)) * num_labels (losses.py:246-251) with an fp32 gradient."""
 
@@ -436,6 +456,10 @@ def gather_rows(x, index, p, training):
 
 def logit_bce(scores, targets):
     return LogitBCEFn.apply(scores, targets)
+
+
+def pair_halves(x):
+    return PairHalvesFn.apply(x)
 
 
 def unsupported(name):

@@ -187,7 +187,7 @@ def dropout(x, p, training):
 @_op("pair_halves(Tensor x) -> Tensor")
 def pair_halves(x):
     if F32T.active():
-        F32T.unsupported("pair_halves")
+        return F32T.pair_halves(x)
     if F32P.active():
         return F32P.pair_halves(x)
     return Fn.PairHalvesFn.apply(x)

@@ -37,9 +37,25 @@ def test_visual_bert_step_builds_an_fp32_graph_only(train):
         assert p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape, k
 
 
-def test_operators_without_an_fp32_backward_refuse():
+def test_nlvr2_step_builds_an_fp32_graph():
     z, case, cfg, sd, sample = G.load_nlvr2_case()
     model = MU.build_visual_bert(cfg, sd, device="cpu", training_head_type="nlvr2", pooler_strategy="default", losses=[dict(type="cross_entropy")])
+    model.eval()
+    with native_stub.installed() as calls:
+        with mmf_amd.fp32_training():
+            out = model(SampleList(sample))
+        (key, loss), = out["losses"].items()
+        loss.backward()
+        names = {c[0] for c in calls}
+    assert not (names & BF16_KERNELS), names & BF16_KERNELS
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in model.parameters())     # the pooler is in use here
+
+
+def test_operators_without_an_fp32_backward_refuse():
+    z, case, cfg, sd, sample = G.load_pretraining_case()
+    if isinstance(sample, (list, tuple)):
+        sample = sample[0]
+    model = MU.build_visual_bert_pretraining(cfg, sd, device="cpu")
     model.eval()
     with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32_training"):
         with mmf_amd.fp32_training():

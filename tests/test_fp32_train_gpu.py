@@ -288,9 +288,36 @@ def test_fp32_training_step_with_dropout_and_fused_adamw():
     assert out["scores"].requires_grad
 
 
-def test_fp32_training_refuses_operators_without_a_backward():
+def test_fp32_training_nlvr2_head_golden():
+    """`training_head_type: nlvr2` (two images per sample, BertPooler's tanh, the pairing of the two halves, cross_entropy) against the
+    reference's fixture: loss, scores, every gradient norm / sum."""
     z, case, cfg, sd, sample = G.load_nlvr2_case()
     model = build_visual_bert(cfg, sd, training_head_type="nlvr2", pooler_strategy="default", losses=[dict(type="cross_entropy")])
+    model.eval()
+    with mmf_amd.fp32_training():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    np.testing.assert_allclose(out["scores"].detach().cpu().numpy(), z["scores"], rtol=TOL_FP32, atol=TOL_FP32)
+    (key, loss), = out["losses"].items()
+    assert abs(loss.item() - float(z["loss"])) <= TOL_FP32 * abs(float(z["loss"]))
+    loss.backward()
+    params = dict(model.named_parameters())
+    checked = 0
+    for gname, norm, gsum in zip(z["grad_names"], z["grad_norms"], z["grad_sums"]):
+        gname = str(gname)
+        if norm == 0.0 or gname.endswith("self.key.bias"):
+            continue
+        p = params[gname]
+        assert p.grad is not None, gname
+        assert abs(float(p.grad.double().norm()) - norm) <= TOL_FP32 * norm, gname
+        assert abs(float(p.grad.double().sum()) - gsum) <= TOL_FP32 * norm + 1e-7, gname
+        checked += 1
+    assert checked > 30
+
+
+def test_fp32_training_refuses_operators_without_a_backward():
+    from tests.model_utils import build_visual_bert_pretraining
+    z, case, cfg, sd, sample = G.load_pretraining_case()
+    model = build_visual_bert_pretraining(cfg, sd)
     model.eval()
     with pytest.raises(NotImplementedError, match="fp32_training"):
         with mmf_amd.fp32_training():

@@ -17,6 +17,8 @@ Not built (raise): the pretraining heads (:1054-1240),
 `in_batch_pairs` / `fast_mode` batch expansion (:684-735), `task_specific_tokens`, `fixed_{t,v}_layer` > 0 and
 attention-map outputs (`visualization`, `output_all_attention_masks`: the fused kernel never materialises them).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -185,6 +187,35 @@ class BertImageLayer(BertLayerJit):
         return (_feed_forward(self.intermediate, self.output, attention_output, self.training),)
 
 
+# Two HIP streams for the two modality streams (round 3).  Between connection points the text layers and the visual layers are independent,
+# and inside a connection layer so are the two output blocks and the two feed-forward blocks — and each of them alone under-fills the
+# chip (B = 32: 4096 text rows x 768 and 3232 region rows x 1024 give 128 and 104 wide GEMM tiles for 256 CUs).  The visual side runs
+# on a side stream forked from / joined to the caller's stream (captured as parallel branches by a hipGraph; autograd replays each
+# node's backward on its forward stream, so the backward overlaps the same way).  MMF_AMD_VILBERT_STREAMS=0 keeps one stream (A/B).
+_TWO_STREAMS = os.environ.get("MMF_AMD_VILBERT_STREAMS", "1") != "0"
+_side_streams = {}
+
+
+def _fork(x):
+    """(main, side) streams when the visual side may run beside the text side, else None."""
+    if not (_TWO_STREAMS and x.is_cuda) or F32P.active():
+        return None
+    dev = x.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    return main, side
+
+
+def _join(streams, *tensors):
+    main, side = streams
+    main.wait_stream(side)
+    for t in tensors:
+        t.record_stream(main)      # allocated on the side stream, consumed on the caller's from here on
+
+
 class BertConnectionLayer(nn.Module):
     """vilbert.py:515-556."""
 
@@ -202,9 +233,23 @@ class BertConnectionLayer(nn.Module):
                 use_co_attention_mask=False):
         bi_output1, bi_output2, co_attention_probs = self.biattention(
             input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask, use_co_attention_mask)
-        attention_output1, attention_output2 = self.biOutput(bi_output2, input_tensor1, bi_output1, input_tensor2)
-        layer_output1 = _feed_forward(self.v_intermediate, self.v_output, attention_output1, self.training)
-        layer_output2 = _feed_forward(self.t_intermediate, self.t_output, attention_output2, self.training)
+        streams = _fork(input_tensor1)
+        if streams is None:
+            attention_output1, attention_output2 = self.biOutput(bi_output2, input_tensor1, bi_output1, input_tensor2)
+            layer_output1 = _feed_forward(self.v_intermediate, self.v_output, attention_output1, self.training)
+            layer_output2 = _feed_forward(self.t_intermediate, self.t_output, attention_output2, self.training)
+            return layer_output1, layer_output2, co_attention_probs
+        bo = self.biOutput
+        with torch.cuda.stream(streams[1]):     # the visual half: output block + feed-forward block
+            a1 = Fn.DenseDropoutResidualLNFn.apply(
+                bi_output2, input_tensor1, bo.dense1.weight, bo.dense1.bias, bo.LayerNorm1.weight, bo.LayerNorm1.bias,
+                Fn.shadows.get(bo.dense1.weight), bo.LayerNorm1.eps, Fn.make_drop(bo.dropout1_prob, self.training))
+            layer_output1 = _feed_forward(self.v_intermediate, self.v_output, a1, self.training)
+        a2 = Fn.DenseDropoutResidualLNFn.apply(
+            bi_output1, input_tensor2, bo.dense2.weight, bo.dense2.bias, bo.LayerNorm2.weight, bo.LayerNorm2.bias,
+            Fn.shadows.get(bo.dense2.weight), bo.LayerNorm2.eps, Fn.make_drop(bo.dropout2_prob, self.training))
+        layer_output2 = _feed_forward(self.t_intermediate, self.t_output, a2, self.training)
+        _join(streams, layer_output1)
         return layer_output1, layer_output2, co_attention_probs
 
 
@@ -233,11 +278,21 @@ class BertEncoder(nn.Module):
             raise NotImplementedError("attention maps are never materialised by the fused kernel")
         v_start = t_start = 0
         all_t, all_v = [], []
+        dynamic = any(l.attention.self.dynamic_attention for l in self.v_layer)     # then a visual layer reads the text stream: no overlap
         for count, (v_end, t_end) in enumerate(zip(self.v_biattention_id, self.t_biattention_id)):
-            for idx in range(t_start, t_end):
-                txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
-            for idx in range(v_start, v_end):
-                image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
+            streams = _fork(image_embedding) if (not dynamic and v_end > v_start and t_end > t_start) else None
+            if streams is not None:
+                with torch.cuda.stream(streams[1]):
+                    for idx in range(v_start, v_end):
+                        image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
+                for idx in range(t_start, t_end):
+                    txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
+                _join(streams, image_embedding)
+            else:
+                for idx in range(t_start, t_end):
+                    txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
+                for idx in range(v_start, v_end):
+                    image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
             if self.with_coattention:
                 image_embedding, txt_embedding, _ = self.c_layer[count](image_embedding, image_attention_mask, txt_embedding,
                                                                         txt_attention_mask)
@@ -245,10 +300,19 @@ class BertEncoder(nn.Module):
             if output_all_encoded_layers:
                 all_t.append(txt_embedding)
                 all_v.append(image_embedding)
-        for idx in range(v_start, len(self.v_layer)):
-            image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
-        for idx in range(t_start, len(self.layer)):
-            txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
+        streams = _fork(image_embedding) if (not dynamic and v_start < len(self.v_layer) and t_start < len(self.layer)) else None
+        if streams is not None:
+            with torch.cuda.stream(streams[1]):
+                for idx in range(v_start, len(self.v_layer)):
+                    image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
+            for idx in range(t_start, len(self.layer)):
+                txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
+            _join(streams, image_embedding)
+        else:
+            for idx in range(v_start, len(self.v_layer)):
+                image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
+            for idx in range(t_start, len(self.layer)):
+                txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
         if not output_all_encoded_layers:
             all_t.append(txt_embedding)
             all_v.append(image_embedding)

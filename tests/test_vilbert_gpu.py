@@ -310,3 +310,27 @@ def test_vilbert_training_mode_is_seed_reproducible():
     torch.manual_seed(4)
     c = model(SampleList(dict(batch)))["scores"].float().clone()
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_two_hip_streams_equal_one_stream():
+    """The visual stream on a side HIP stream (mmf_amd/models/vilbert.py `_fork` / `_join`) changes the launch order, not the arithmetic:
+    eval-mode scores and every gradient are bit-identical to the single-stream run."""
+    from mmf_amd.models import vilbert as V
+    z, case, cfg, sd, sample = load_vilbert_case("vilbert_small")
+    res = []
+    for two in (True, False):
+        old = V._TWO_STREAMS
+        V._TWO_STREAMS = two
+        try:
+            model = build_vilbert(cfg, sd)
+            model.eval()
+            out = model(SampleList(sample_to(sample, "cuda")))
+            list(out["losses"].values())[0].sum().backward()
+            torch.cuda.synchronize()
+            res.append((out["scores"].detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            V._TWO_STREAMS = old
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k

@@ -63,7 +63,7 @@ def parse():
 
 # BASELINE.json.configs index of every --config choice (configs[1] is the headline)
 OTHER_CONFIGS = {"mmbt": 0, "vilbert": 2, "uniter": 3, "mmft": 3, "m4c": 4}
-GRAPH_CONFIGS = {"vilbert"}      # --config choices whose training step is captured as one hipGraph (verified capturable)
+GRAPH_CONFIGS = {"vilbert", "mmbt", "m4c"}      # --config choices whose training step is captured as one hipGraph (verified capturable)
 
 
 def config_bench(args):

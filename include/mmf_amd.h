@@ -547,7 +547,7 @@ int mmf_scatter_add_rows_f32(const float* g, int ld, int rows, int H, int grp, i
 int mmf_bce_logits_f32_bwd(const float* scores, const float* targets, const float* gloss, float* dscores, int B, int N, void* stream);
 
 /* fp32 row operators of the widened models on the fp32 path: zero-padded copy of short rows (the 5-d / 7-d box geometry operands of
- * vilbert.py:906 / uniter.py:81 become 16-byte rows), element-wise a * b (op 0), relu (1), a + b (3), a (1 - b^2) (4: tanh backward) (vilbert.py:803,818,1318;
+ * vilbert.py:906 / uniter.py:81 become 16-byte rows), element-wise a * b (op 0), relu (1), a + b (3), a (1 - b^2) (4: tanh backward), a [b > 0] (5: relu backward) (vilbert.py:803,818,1318;
  * uniter.py:82), and the dynamic_attention pooling / gating of vilbert.py:204-212 (mmf_masked_mean_fwd / mmf_rowgroup_scale on fp32). */
 int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int rows, void* stream);
 int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, void* stream);

@@ -693,12 +693,13 @@ __global__ __launch_bounds__(256) void pad_rows_f32_kernel(const float* __restri
     const int c = (int)(i - r * KP);
     dst[i] = c < K ? src[r * K + c] : 0.f;
 }
-// op 0: a * b, 1: max(a, 0), 3: a + b   (the op codes of mmf_eltwise); 4: a * (1 - b^2) (backward of tanh, b = the saved output)
+// op 0: a * b, 1: max(a, 0), 3: a + b   (the op codes of mmf_eltwise); 4: a * (1 - b^2) (backward of tanh, b = the saved output);
+// 5: a where b > 0 else 0 (backward of relu, b = the saved output)
 __global__ __launch_bounds__(256) void eltwise_f32_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float x = a[i];
-    y[i] = op == 0 ? x * b[i] : (op == 1 ? fmaxf(x, 0.f) : (op == 3 ? x + b[i] : x * (1.f - b[i] * b[i])));
+    y[i] = op == 0 ? x * b[i] : (op == 1 ? fmaxf(x, 0.f) : (op == 3 ? x + b[i] : (op == 4 ? x * (1.f - b[i] * b[i]) : (b[i] > 0.f ? x : 0.f))));
 }
 // pool[b][c] = sum_t x[b][t][c] mask[b][t] / sum_t mask[b][t]   (ViLBERT dynamic_attention, vilbert.py:204-205)
 __global__ __launch_bounds__(256) void masked_mean_f32_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ pool, int T, int H) {
@@ -924,7 +925,7 @@ extern "C" int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int
     return 0;
 }
 extern "C" int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, void* stream) {
-    MMF_CHECK_ARG(a && y && n > 0 && (op == 0 || op == 1 || op == 3 || op == 4) && (op == 1 || b), "eltwise_f32: bad operand (op 0 mul, 1 relu, 3 add, 4 tanh backward)");
+    MMF_CHECK_ARG(a && y && n > 0 && (op == 0 || op == 1 || (op >= 3 && op <= 5)) && (op == 1 || b), "eltwise_f32: bad operand (op 0 mul, 1 relu, 3 add, 4 tanh backward, 5 relu backward)");
     hipLaunchKernelGGL(eltwise_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, y, n);
     MMF_CHECK_LAUNCH();
     return 0;

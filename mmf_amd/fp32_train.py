@@ -14,8 +14,8 @@ mmf_amd/csrc/fp32_train.hip (LayerNorm backward, column sums, dropout, row scatt
 directly, fp32 gradients.  Parity: every parameter gradient of the reference's fixture and of the full VisualBERT-base VQA2 configuration
 against the CPU oracle within north_star's fp32 bound (tests/test_fp32_train_gpu.py).
 
-Built for the operators VisualBERT's classification / nlvr2 step uses (embeddings, encoder layers, pooler, nlvr2 pairing, prediction-head
-transform, classifier, logit_bce; cross_entropy is fp32 already); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
+Built for the operators the classification / nlvr2 steps of VisualBERT and ViLBERT use (embeddings, encoder layers, ViLBERT's image embeddings,
+co-attention and output blocks, poolers, nlvr2 pairing, prediction-head transform, classifier, logit_bce; cross_entropy is fp32 already); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
 
 Reference operations, as in mmf_amd/functional.py: BertVisioLinguisticEmbeddings.forward (mmf/modules/embeddings.py:423-459), BertLayerJit
 .forward (mmf/modules/hf_layers.py:255-292), BertPooler / BertPredictionHeadTransform / classifier Linear (mmf/models/visual_bert.py:146,
@@ -392,6 +392,148 @@ class PairHalvesFn(torch.autograd.Function):
         return dx
 
 
+# ---- ViLBERT (mmf/models/vilbert.py) -----------------------------------------------------------------------------------------------------
+class DenseResidualLNFn(torch.autograd.Function):
+    """LayerNorm(dropout(dense(h)) + resid): BertSelfOutput / the two halves of BertBiOutput (hf_layers.py:245-252, vilbert.py:497-512); `h` and
+    `resid` may have different widths."""
+
+    @staticmethod
+    def forward(ctx, h, resid, weight, bias, gamma, beta, eps, drop):
+        h2, r2 = _rows(h), _rows(resid)
+        w = _w(weight)
+        N = w.shape[0]
+        y = _gemm(h2, w, N, bias=_w(bias), drop=drop, resid=r2, ldr=r2.stride(0))
+        out, mean, rstd = _ln_fwd(y, gamma, beta, eps)
+        ctx.save_for_backward(h2, w, y, mean, rstd, gamma.detach())
+        ctx.meta = (h.shape, resid.shape, drop)
+        return out.view(resid.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        h2, w, y, mean, rstd, gamma = ctx.saved_tensors
+        hshape, rshape, drop = ctx.meta
+        dy, dgamma, dbeta = _ln_bwd(_grad2(g, y.shape[1]), y, mean, rstd, gamma)
+        dz = _drop_bwd(dy, drop)
+        return _dgrad(dz, w).view(hshape), dy.view(rshape), _wgrad(dz, h2), _colsum(dz), dgamma, dbeta, None, None
+
+
+class BiAttentionFn(torch.autograd.Function):
+    """BertBiAttention.forward (vilbert.py:388-475): each stream's Q | K | V as one packed fp32 GEMM; context_layer1 = text queries over image
+    keys / values (image mask, dropout1), context_layer2 = image queries over text keys / values (text mask, dropout2).  Backward: the two
+    attention backwards write disjoint column blocks of the two packed gradient buffers, then each stream's dgrad / wgrad."""
+
+    @staticmethod
+    def forward(ctx, img, txt, q1w, q1b, k1w, k1b, v1w, v1b, q2w, q2b, k2w, k2b, v2w, v2b, img_mask_add, txt_mask_add, heads, drop1, drop2):
+        B, R, _ = img.shape
+        T = txt.shape[1]
+        BH = q1w.shape[0]
+        hd = BH // heads
+        P._check_head(hd, max(R, T))
+        i2, t2 = _rows(img), _rows(txt)
+        w1, b1 = P._packed(q1w, k1w, v1w).clone(), P._packed(q1b, k1b, v1b)
+        w2, b2 = P._packed(q2w, k2w, v2w).clone(), P._packed(q2b, k2b, v2b)
+        qkv1 = _gemm(i2, w1, 3 * BH, bias=b1)
+        qkv2 = _gemm(t2, w2, 3 * BH, bias=b2)
+        scale = 1.0 / math.sqrt(hd)
+        m1 = img_mask_add.reshape(B, R).float().contiguous()
+        m2 = txt_mask_add.reshape(B, T).float().contiguous()
+        ctx1 = _empty(B * T, BH, like=i2); lse1 = _empty(B, heads, T, like=i2)
+        nat.attention_f32_fwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, m1, ctx1, BH, B, heads, T, R, scale, head_dim=hd, lse=lse1,
+                              drop=drop1)
+        ctx2 = _empty(B * R, BH, like=i2); lse2 = _empty(B, heads, R, like=i2)
+        nat.attention_f32_fwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, m2, ctx2, BH, B, heads, R, T, scale, head_dim=hd, lse=lse2,
+                              drop=drop2)
+        ctx.save_for_backward(i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1, w2, m1, m2)
+        ctx.meta = (B, R, T, BH, heads, drop1, drop2, img.shape, txt.shape)
+        return ctx1.view(B, T, BH), ctx2.view(B, R, BH)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1, w2, m1, m2 = ctx.saved_tensors
+        B, R, T, BH, heads, drop1, drop2, ishape, tshape = ctx.meta
+        hd = BH // heads
+        scale = 1.0 / math.sqrt(hd)
+        dqkv1 = _empty(B * R, 3 * BH, like=i2); dqkv2 = _empty(B * T, 3 * BH, like=i2)
+        delta1 = _empty(B, heads, T, like=i2); delta2 = _empty(B, heads, R, like=i2)
+        nat.attention_f32_bwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, m1, ctx1, BH, lse1, B, heads, T, R, scale, _grad2(g1, BH),
+                              dqkv2, dqkv1[:, BH:], dqkv1[:, 2 * BH:], delta1, head_dim=hd, drop=drop1)
+        nat.attention_f32_bwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, m2, ctx2, BH, lse2, B, heads, R, T, scale, _grad2(g2, BH),
+                              dqkv1, dqkv2[:, BH:], dqkv2[:, 2 * BH:], delta2, head_dim=hd, drop=drop2)
+        dimg, dw1, db1 = _dgrad(dqkv1, w1), _wgrad(dqkv1, i2), _colsum(dqkv1)
+        dtxt, dw2, db2 = _dgrad(dqkv2, w2), _wgrad(dqkv2, t2), _colsum(dqkv2)
+        return (dimg.view(ishape), dtxt.view(tshape),
+                dw1[:BH], db1[:BH], dw1[BH:2 * BH], db1[BH:2 * BH], dw1[2 * BH:], db1[2 * BH:],
+                dw2[:BH], db2[:BH], dw2[BH:2 * BH], db2[BH:2 * BH], dw2[2 * BH:], db2[2 * BH:],
+                None, None, None, None, None)
+
+
+class ImageFeatureEmbeddingsFn(torch.autograd.Function):
+    """BertImageFeatureEmbeddings.forward (vilbert.py:904-913): LayerNorm(Linear(features) + Linear(5-d location)), dropout.  The inputs get no
+    gradient (pre-extracted features)."""
+
+    @staticmethod
+    def forward(ctx, feats, loc, w_img, b_img, w_loc, b_loc, ln_w, ln_b, eps, drop):
+        B, R, D = feats.shape
+        f2 = feats.reshape(B * R, D)
+        f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+        KL = loc.shape[-1]
+        KP = (KL + 3) // 4 * 4
+        l2 = loc.reshape(B * R, KL)
+        l2 = (l2 if l2.dtype == F32 else l2.float()).contiguous()
+        lp = P._pad_k(l2, KL, KP) if KP != KL else l2
+        wl = P._pad_k(_w(w_loc), KL, KP) if KP != KL else _w(w_loc)
+        wi = _w(w_img)
+        VH = wi.shape[0]
+        y0 = _gemm(f2, wi, VH, bias=_w(b_img))
+        y = _gemm(lp, wl, VH, bias=_w(b_loc), resid=y0, ldr=VH)
+        out, mean, rstd = _ln_fwd(y, ln_w, ln_b, eps)
+        if drop[1]:
+            o2 = torch.empty_like(out)
+            nat.dropout_f32(out, o2, drop)
+            out = o2
+        ctx.save_for_backward(f2, lp, y, mean, rstd, ln_w.detach())
+        ctx.meta = (B, R, VH, KL, drop)
+        return out.view(B, R, VH)
+
+    @staticmethod
+    def backward(ctx, g):
+        f2, lp, y, mean, rstd, ln_w = ctx.saved_tensors
+        B, R, VH, KL, drop = ctx.meta
+        dy, dgamma, dbeta = _ln_bwd(_drop_bwd(_grad2(g, VH), drop), y, mean, rstd, ln_w)
+        db = _colsum(dy)
+        dwl = _wgrad(dy, lp)
+        return None, None, _wgrad(dy, f2), db, dwl[:, :KL].contiguous(), db.clone(), dgamma, dbeta, None, None
+
+
+class EltwiseFn(torch.autograd.Function):
+    """op 0: a * b (vilbert.py:1318), op 1: relu(a) (the poolers, vilbert.py:803,818), op 3: a + b (vilbert.py:1320)."""
+
+    @staticmethod
+    def forward(ctx, op, a, b):
+        a2 = _rows(a)
+        b2 = None if b is None else _rows(b)
+        y = torch.empty_like(a2)
+        nat.eltwise_f32(op, a2, b2, y)
+        ctx.op = op
+        ctx.save_for_backward(a2, b2, y)
+        return y.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2, y = ctx.saved_tensors
+        g2 = _grad2(g, g.shape[-1])
+        if ctx.op == 3:
+            return None, g, g
+        if ctx.op == 1:
+            d = torch.empty_like(g2)
+            nat.eltwise_f32(5, g2, y, d)              # g where y > 0
+            return None, d.view(g.shape), None
+        da, db = torch.empty_like(g2), torch.empty_like(g2)
+        nat.eltwise_f32(0, g2, b2, da)
+        nat.eltwise_f32(0, g2, a2, db)
+        return None, da.view(g.shape), db.view(g.shape)
+
+
 class LogitBCEFn(torch.autograd.Function):
     """mean(BCEWithLogits(scores, targets)) * num_labels (losses.py:246-251) with an fp32 gradient."""
 
@@ -460,6 +602,35 @@ def logit_bce(scores, targets):
 
 def pair_halves(x):
     return PairHalvesFn.apply(x)
+
+
+def dense_residual_ln(h, resid, weight, bias, gamma, beta, eps, p, training):
+    return DenseResidualLNFn.apply(h, resid, weight, bias, gamma, beta, eps, make_drop(p, training))
+
+
+def feed_forward(x, w1, b1, w2, b2, gamma, beta, eps, p, training):
+    return FeedForwardFn.apply(x, w1, b1, w2, b2, gamma, beta, eps, make_drop(p, training))
+
+
+def bi_attention(img, txt, q1, k1, v1, q2, k2, v2, img_mask_add, txt_mask_add, heads, p1, p2, training):
+    return BiAttentionFn.apply(img, txt, q1.weight, q1.bias, k1.weight, k1.bias, v1.weight, v1.bias, q2.weight, q2.bias, k2.weight, k2.bias,
+                               v2.weight, v2.bias, img_mask_add, txt_mask_add, heads, make_drop(p1, training), make_drop(p2, training))
+
+
+def image_feature_embeddings(feats, loc, w_img, b_img, w_loc, b_loc, ln_w, ln_b, eps, p, training):
+    return ImageFeatureEmbeddingsFn.apply(feats, loc, w_img, b_img, w_loc, b_loc, ln_w, ln_b, eps, make_drop(p, training))
+
+
+def eltwise_mul(a, b):
+    return EltwiseFn.apply(0, a, b)
+
+
+def relu(a):
+    return EltwiseFn.apply(1, a, None)
+
+
+def add(a, b):
+    return EltwiseFn.apply(3, a, b)
 
 
 def unsupported(name):

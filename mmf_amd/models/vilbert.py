@@ -24,6 +24,7 @@ from torch import nn
 
 from mmf_amd import functional as Fn
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
 from mmf_amd.modules.hf_layers import (
@@ -65,6 +66,9 @@ class BertImageFeatureEmbeddings(nn.Module):
 
     def forward(self, image_feature, image_location):
         ie, le = self.image_embeddings, self.image_location_embeddings
+        if F32T.active():      # mmf_amd.fp32_training(): fp32 forward + backward
+            return F32T.image_feature_embeddings(image_feature, image_location, ie.weight, ie.bias, le.weight, le.bias, self.LayerNorm.weight,
+                                                 self.LayerNorm.bias, self.LayerNorm.eps, self.dropout_prob, self.training)
         if F32P.active():      # fp32-accurate forward (mmf_amd.fp32_inference()): same operations on the fp32 kernels
             F32P.check_no_dropout(self.dropout_prob, self.training)
             return F32P.image_feature_embeddings(image_feature, image_location, ie.weight, ie.bias, le.weight, le.bias,
@@ -102,6 +106,11 @@ class BertBiAttention(nn.Module):
         context_layer2 [B, R, bi], {})."""
         if use_co_attention_mask:
             raise NotImplementedError("use_co_attention_mask is dead code in the reference (vilbert.py:421,448) and is not built")
+        if F32T.active():
+            c1, c2 = F32T.bi_attention(input_tensor1, input_tensor2, self.query1, self.key1, self.value1, self.query2, self.key2, self.value2,
+                                       attention_mask1, attention_mask2, self.num_attention_heads, self.dropout1_prob, self.dropout2_prob,
+                                       self.training)
+            return c1, c2, {}
         if F32P.active():
             F32P.check_no_dropout(max(self.dropout1_prob, self.dropout2_prob), self.training)
             c1, c2 = F32P.bi_attention(input_tensor1, input_tensor2, self.query1, self.key1, self.value1, self.query2, self.key2,
@@ -135,6 +144,11 @@ class BertBiOutput(nn.Module):
         self.q_dense2 = Linear(config.bi_hidden_size, config.hidden_size)
 
     def forward(self, hidden_states1, input_tensor1, hidden_states2, input_tensor2):
+        if F32T.active():
+            return (F32T.dense_residual_ln(hidden_states1, input_tensor1, self.dense1.weight, self.dense1.bias, self.LayerNorm1.weight,
+                                           self.LayerNorm1.bias, self.LayerNorm1.eps, self.dropout1_prob, self.training),
+                    F32T.dense_residual_ln(hidden_states2, input_tensor2, self.dense2.weight, self.dense2.bias, self.LayerNorm2.weight,
+                                           self.LayerNorm2.bias, self.LayerNorm2.eps, self.dropout2_prob, self.training))
         if F32P.active():
             F32P.check_no_dropout(max(self.dropout1_prob, self.dropout2_prob), self.training)
             return (F32P.dense_residual_ln(hidden_states1, input_tensor1, self.dense1.weight, self.dense1.bias, self.LayerNorm1.weight,
@@ -151,6 +165,9 @@ class BertBiOutput(nn.Module):
 
 
 def _feed_forward(it, ot, x, training):
+    if F32T.active():
+        return F32T.feed_forward(x, it.dense.weight, it.dense.bias, ot.dense.weight, ot.dense.bias, ot.LayerNorm.weight, ot.LayerNorm.bias,
+                                 ot.LayerNorm.eps, ot.dropout_prob, training)
     if F32P.active():
         F32P.check_no_dropout(ot.dropout_prob, training)
         return F32P.feed_forward(x, it.dense.weight, it.dense.bias, ot.dense.weight, ot.dense.bias, ot.LayerNorm.weight, ot.LayerNorm.bias,
@@ -170,6 +187,8 @@ class BertImageLayer(BertLayerJit):
         if not sa.dynamic_attention:
             return super().forward(hidden_states, attention_mask)
         B, S, _ = hidden_states.shape
+        if F32T.active():
+            F32T.unsupported("dynamic_attention gate")
         gate = sa.dynamic_gate(txt_embedding, txt_attention_mask)
         if F32P.active():
             F32P.check_no_dropout(max(sa.dropout_prob, so.dropout_prob), self.training)
@@ -198,7 +217,7 @@ _side_streams = {}
 
 def _fork(x):
     """(main, side) streams when the visual side may run beside the text side, else None."""
-    if not (_TWO_STREAMS and x.is_cuda) or F32P.active():
+    if not (_TWO_STREAMS and x.is_cuda) or F32P.active() or F32T.active():
         return None
     dev = x.device
     side = _side_streams.get(dev)
@@ -327,6 +346,8 @@ class _ReluPooler(nn.Module):
     def forward(self, hidden_states):
         B = hidden_states.shape[0]
         index = torch.zeros(B, dtype=torch.int64, device=hidden_states.device)
+        if F32T.active():
+            return F32T.relu(self.dense(F32T.GatherRowsFn.apply(hidden_states, index)))
         if F32P.active():
             return F32P.relu(self.dense(F32P.gather_rows(hidden_states, index)))
         first = Fn.GatherRowsFn.apply(hidden_states, index, Fn.nat.NO_DROP)
@@ -504,14 +525,17 @@ class ViLBERTForClassification(nn.Module):
             input_ids, image_feature, image_location, token_type_ids, attention_mask, image_attention_mask,
             output_all_encoded_layers=False, output_all_attention_masks=output_all_attention_masks)
         output = {}
-        if F32P.active():
+        if F32T.active():
+            fused = (F32T.eltwise_mul if self.fusion_method == "mul" else F32T.add)(pooled_output_t, pooled_output_v)
+            fused = F32T.dropout(fused, self.dropout_prob, self.training)
+        elif F32P.active():
             F32P.check_no_dropout(self.dropout_prob, self.training)
             fused = (F32P.eltwise_mul if self.fusion_method == "mul" else F32P.add)(pooled_output_t, pooled_output_v)
         elif self.fusion_method == "mul":
             fused = Fn.EltwiseMulFn.apply(pooled_output_t, pooled_output_v)
         else:
             fused = pooled_output_t + pooled_output_v
-        drop = Fn.make_drop(self.dropout_prob, self.training)
+        drop = Fn.nat.NO_DROP if (F32T.active() or F32P.active()) else Fn.make_drop(self.dropout_prob, self.training)
         pooled_output = Fn.DropoutFn.apply(fused, drop) if drop[1] else fused
         if self.training_head_type == "nlvr2":
             # pairs CONSECUTIVE rows of the stacked [img0 batch; img1 batch] exactly as the reference's view does (:1322-1323)

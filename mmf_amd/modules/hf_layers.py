@@ -14,6 +14,7 @@ from torch import Tensor, nn
 
 from mmf_amd import functional as Fn
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd import ops  # noqa: F401  (registers torch.ops.mmf_amd.*)
 
 
@@ -339,6 +340,10 @@ class BertEmbeddingsJit(nn.Module):
             raise NotImplementedError("explicit position_ids / inputs_embeds are not on the built paths")
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
+        if F32T.active():      # mmf_amd.fp32_training()
+            return F32T.visio_linguistic_embeddings(input_ids, token_type_ids, None, None, self.word_embeddings.weight, self.position_embeddings.weight,
+                                                    self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias, None, None, None, None,
+                                                    self.LayerNorm.eps, self.dropout_prob, self.training, self.word_embeddings.padding_idx)
         if F32P.active():      # fp32-accurate forward (mmf_amd.fp32_inference())
             F32P.check_no_dropout(self.dropout_prob, self.training)
             return F32P.visio_linguistic_embeddings(input_ids, token_type_ids, None, None, self.word_embeddings.weight,

@@ -60,3 +60,22 @@ def test_operators_without_an_fp32_backward_refuse():
     with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32_training"):
         with mmf_amd.fp32_training():
             model(SampleList(sample))
+
+
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_nlvr2"])
+def test_vilbert_step_builds_an_fp32_graph_only(name):
+    z, case, cfg, sd, sample = G.load_vilbert_case(name)
+    over = dict(training_head_type="nlvr2", losses=[dict(type="cross_entropy")]) if name == "vilbert_nlvr2" else {}
+    model = MU.build_vilbert(cfg, sd, device="cpu", **over)
+    model.train()
+    with native_stub.installed() as calls:
+        with mmf_amd.fp32_training():
+            out = model(SampleList(sample))
+        (key, loss), = out["losses"].items()
+        loss.backward()
+        names = {c[0] for c in calls}
+    assert not (names & BF16_KERNELS), names & BF16_KERNELS
+    assert any(c[0] == "attention_f32_bwd" and c[3] != c[4] for c in calls)          # the co-attention backward: Sq != Sk
+    missing = [k for k, p in model.named_parameters() if p.grad is None and "q_dense" not in k]
+    assert not missing, missing          # (q_dense1 / q_dense2 exist in the reference's parameter tree and are never called)
+    assert all(p.grad is None or p.grad.dtype == torch.float32 for p in model.parameters())

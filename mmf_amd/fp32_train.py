@@ -14,8 +14,9 @@ mmf_amd/csrc/fp32_train.hip (LayerNorm backward, column sums, dropout, row scatt
 directly, fp32 gradients.  Parity: every parameter gradient of the reference's fixture and of the full VisualBERT-base VQA2 configuration
 against the CPU oracle within north_star's fp32 bound (tests/test_fp32_train_gpu.py).
 
-Built for the operators the classification / nlvr2 steps of VisualBERT and ViLBERT use (embeddings, encoder layers, ViLBERT's image embeddings,
-co-attention and output blocks, poolers, nlvr2 pairing, prediction-head transform, classifier, logit_bce; cross_entropy is fp32 already); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
+Built for the operators the classification steps of VisualBERT, ViLBERT, MMBT and the MMF Transformer use (their embedding stages, encoder
+layers, ViLBERT's co-attention and output blocks, poolers, nlvr2 pairing, prediction-head transform, classifiers, logit_bce; cross_entropy is
+fp32 already); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
 
 Reference operations, as in mmf_amd/functional.py: BertVisioLinguisticEmbeddings.forward (mmf/modules/embeddings.py:423-459), BertLayerJit
 .forward (mmf/modules/hf_layers.py:255-292), BertPooler / BertPredictionHeadTransform / classifier Linear (mmf/models/visual_bert.py:146,
@@ -534,6 +535,130 @@ class EltwiseFn(torch.autograd.Function):
         return None, da.view(g.shape), db.view(g.shape)
 
 
+# ---- MMBT (mmf/models/mmbt.py) and the MMF Transformer backend (mmf/models/transformers/backends/huggingface.py) ------------------------------
+class MMBTEmbeddingsFn(torch.autograd.Function):
+    """ModalEmbeddings.forward (mmbt.py:84-129) + the text BertEmbeddings (hf_layers.py:108-135), modal block first (mmbt.py:225): one fp32
+    buffer [start token | N projected features | end token | T text], one LayerNorm, dropout (fp32_path.mmbt_embeddings is the forward).
+    Backward: dropout, LayerNorm, then the rows go back where they came from — start / end / text rows into the word, position and type
+    tables, the modal rows into the projection's weight gradient, its bias, the position rows s0 .. s0 + N - 1 and the modal type row."""
+
+    @staticmethod
+    def forward(ctx, feats, input_ids, start_tok, end_tok, text_type_ids, modal_type, word, pos, typ, ln_w, ln_b, proj_w, proj_b, eps, drop, pad_idx):
+        B, N, D = feats.shape
+        T = input_ids.shape[1]
+        H = word.shape[1]
+        s0 = 1 if start_tok is not None else 0
+        L = N + s0 + (1 if end_tok is not None else 0)
+        S = L + T
+        dev = word.device
+        y = torch.empty(B * S, H, dtype=F32, device=dev)
+        wd, pd, td = _w(word), _w(pos), _w(typ)
+        if isinstance(modal_type, torch.Tensor):
+            mt = modal_type.detach().reshape(1).to(device=dev, dtype=torch.int64)
+        else:
+            mt = torch.full((1,), int(modal_type), dtype=torch.int64, device=dev)
+        mtype = mt.reshape(1, 1).expand(B, 1).contiguous()
+        ids = input_ids.contiguous(); tt = text_type_ids.contiguous()
+        st = None if start_tok is None else start_tok.reshape(B, 1).contiguous()
+        en = None if end_tok is None else end_tok.reshape(B, 1).contiguous()
+        if st is not None:
+            nat.embed_text_f32_fwd(st, mtype, wd, pd, td, y, B, 1, S, H, 0, 0)
+        if en is not None:
+            nat.embed_text_f32_fwd(en, mtype, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
+        nat.embed_text_f32_fwd(ids, tt, wd, pd, td, y, B, T, S, H, L, 0)
+        if D % 4:
+            raise ValueError("fp32 path: modal feature width (%d) must be a multiple of 4" % D)
+        f2 = feats.reshape(B * N, D)
+        f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+        posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
+        nat.gemm_f32(f2, _w(proj_w), y, B * N, H, D, D, D, H, bias=_w(proj_b), coladd=td.index_select(0, mt).reshape(H), rowtab=pd, rowidx=posidx,
+                     rowtab_ld=H, grp=(N, S - N, s0))
+        out, mean, rstd = _ln_fwd(y, ln_w, ln_b, eps)
+        if drop[1]:
+            o2 = torch.empty_like(out)
+            nat.dropout_f32(out, o2, drop)
+            out = o2
+        ctx.save_for_backward(ids, tt, st, en, mt, f2, posidx, y, mean, rstd, ln_w.detach())
+        ctx.meta = (B, N, T, H, s0, L, S, drop, pad_idx, word.shape[0], pos.shape[0], typ.shape[0])
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, tt, st, en, mt, f2, posidx, y, mean, rstd, ln_w = ctx.saved_tensors
+        B, N, T, H, s0, L, S, drop, pad_idx, V, NP, NT = ctx.meta
+        dev = y.device
+        dy, dln_w, dln_b = _ln_bwd(_drop_bwd(_grad2(g, H), drop), y, mean, rstd, ln_w)
+        dword = torch.zeros(V, H, dtype=F32, device=dev); dpos = torch.zeros(NP, H, dtype=F32, device=dev); dtyp = torch.zeros(NT, H, dtype=F32, device=dev)
+        skip = -1 if pad_idx is None else int(pad_idx)
+
+        def rows(idx, tab, n, off, sk=-1):         # rows off .. off + n - 1 of every sample's block scattered into `tab` by idx [B * n]
+            nat.scatter_add_rows_f32(dy, H, B * n, H, idx, tab, H, grp=(n, S, off), skip=sk)
+        mtb = mt.expand(B).contiguous()
+        for tok, off in ((st, 0), (en, s0 + N)):
+            if tok is not None:
+                rows(tok.reshape(-1), dword, 1, off, skip)
+                rows(torch.full((B,), off, dtype=torch.int64, device=dev), dpos, 1, off)
+                rows(mtb, dtyp, 1, off)
+        rows(ids.reshape(-1), dword, T, L, skip)
+        rows(torch.arange(T, device=dev).repeat(B), dpos, T, L)
+        rows(tt.reshape(-1), dtyp, T, L)
+        # the modal rows: projection weight / bias gradients, their position rows, the modal type row
+        dmod = torch.empty(B * N, H, dtype=F32, device=dev)
+        nat.copy_rows(dy.view(torch.bfloat16)[s0:], S, dmod.view(torch.bfloat16), N, B, N, 2 * H)
+        dpw, dpb = _wgrad(dmod, f2), _colsum(dmod)
+        nat.scatter_add_rows_f32(dmod, H, B * N, H, posidx, dpos, H)
+        nat.scatter_add_rows_f32(dpb.view(1, H), H, 1, H, mt, dtyp, H)
+        return None, None, None, None, None, None, dword, dpos, dtyp, dln_w, dln_b, dpw, dpb, None, None, None
+
+
+class AddPosTypeFn(torch.autograd.Function):
+    """total = tok + pos_emb(arange(L)) + token_type_embeddings(segment_ids) (huggingface.py:147-155) on fp32 rows."""
+
+    @staticmethod
+    def forward(ctx, x, seg, pos, typ):
+        B, L, H = x.shape
+        sg = seg.contiguous() if (seg is not None and typ is not None) else None
+        y = P.add_pos_type(x, sg, pos, typ if sg is not None else None)
+        ctx.save_for_backward(sg)
+        ctx.meta = (B, L, H, None if pos is None else pos.shape[0], None if (typ is None or sg is None) else typ.shape[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (sg,) = ctx.saved_tensors
+        B, L, H, NP, NT = ctx.meta
+        g2 = _grad2(g, H)
+        dpos = dtyp = None
+        if NP is not None:
+            dpos = torch.zeros(NP, H, dtype=F32, device=g2.device)
+            nat.scatter_add_rows_f32(g2, H, B * L, H, torch.arange(L, device=g2.device).repeat(B), dpos, H)
+        if NT is not None:
+            dtyp = torch.zeros(NT, H, dtype=F32, device=g2.device)
+            nat.scatter_add_rows_f32(g2, H, B * L, H, sg.reshape(-1), dtyp, H)
+        return g, None, dpos, dtyp
+
+
+class ConcatRowsFn(torch.autograd.Function):
+    """torch.cat(list_embeddings, dim=1) (huggingface.py:159) of fp32 [B, L_m, H] blocks; backward = the row copies reversed."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.lens = [int(x.shape[1]) for x in xs]
+        return P.concat_rows(*xs)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, H = g.shape
+        g2 = _grad2(g, H).view(torch.bfloat16)            # [B * S, 2H] 16-bit words
+        outs, off = [], 0
+        for L in ctx.lens:
+            d = torch.empty(B * L, H, dtype=F32, device=g.device)
+            nat.copy_rows(g2[off:], S, d.view(torch.bfloat16), L, B, L, 2 * H)
+            outs.append(d.view(B, L, H))
+            off += L
+        return tuple(outs)
+
+
 class LogitBCEFn(torch.autograd.Function):
     """mean(BCEWithLogits(scores, targets)) * num_labels (losses.py:246-251) with an fp32 gradient."""
 
@@ -631,6 +756,20 @@ def relu(a):
 
 def add(a, b):
     return EltwiseFn.apply(3, a, b)
+
+
+def mmbt_embeddings(feats, input_ids, start_tok, end_tok, text_type_ids, modal_type, word, pos, typ, ln_w, ln_b, proj_w, proj_b, eps, p, training,
+                    pad_idx):
+    return MMBTEmbeddingsFn.apply(feats, input_ids, start_tok, end_tok, text_type_ids, modal_type, word, pos, typ, ln_w, ln_b, proj_w, proj_b, eps,
+                                  make_drop(p, training), pad_idx)
+
+
+def add_pos_type(x, seg, pos, typ):
+    return AddPosTypeFn.apply(x, seg, pos, typ)
+
+
+def concat_rows(*xs):
+    return ConcatRowsFn.apply(*xs)
 
 
 def unsupported(name):

@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
@@ -88,7 +89,13 @@ class MMBTModel(nn.Module):
                 raise NotImplementedError("per-position modal_token_type_ids: the fused modal block adds ONE type row")
             modal_type = lo
         emb, me = self.transformer.embeddings, self.modal_encoder
-        if F32P.active():        # fp32-accurate forward (mmf_amd.fp32_inference()): same buffer layout, fp32 kernels
+        if F32T.active():        # mmf_amd.fp32_training(): fp32 forward + backward
+            hidden = F32T.mmbt_embeddings(
+                input_modal, input_ids, modal_start_tokens, modal_end_tokens, token_type_ids, modal_type,
+                emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+                emb.LayerNorm.weight, emb.LayerNorm.bias, me.proj_embeddings.weight, me.proj_embeddings.bias, emb.LayerNorm.eps,
+                emb.dropout_prob, self.training, emb.word_embeddings.padding_idx)
+        elif F32P.active():        # fp32-accurate forward (mmf_amd.fp32_inference()): same buffer layout, fp32 kernels
             F32P.check_no_dropout(emb.dropout_prob, self.training)
             hidden = F32P.mmbt_embeddings(
                 input_modal, input_ids, modal_start_tokens, modal_end_tokens, token_type_ids, modal_type,
@@ -258,9 +265,7 @@ class MMBTForClassification(nn.Module):
         module_output = self.bert(sample_list)
         pooled_output = module_output[1]
         output = {}
-        drop = Fn.make_drop(self.dropout_prob, self.training)
-        if drop[1]:
-            pooled_output = Fn.DropoutFn.apply(pooled_output, drop)
+        pooled_output = torch.ops.mmf_amd.dropout(pooled_output, self.dropout_prob, self.training)
         if self.fused_feature_only:
             output["fused_feature"] = self.classifier[0](pooled_output)
             return output

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd import functional as Fn
 from mmf_amd.common.registry import registry
 from mmf_amd.models.transformers.base import BaseTransformerBackend
@@ -95,6 +96,10 @@ class HuggingfaceEmbeddings(nn.Module):
                 if seg is None:
                     seg, typ_w = torch.zeros_like(x), torch.zeros_like(self.token_type_embeddings.weight)
                 z = typ_w.new_zeros(1, typ_w.shape[1])
+                if F32T.active():     # mmf_amd.fp32_training(): fp32 forward + backward
+                    blocks.append(F32T.visio_linguistic_embeddings(x, seg, None, None, tok.weight, pos_w, typ_w, ln.weight, ln.bias, None, None,
+                                                                   None, None, ln.eps, dropout.p, self.training, tok.padding_idx))
+                    continue
                 if F32P.active():     # fp32-accurate forward (mmf_amd.fp32_inference())
                     F32P.check_no_dropout(dropout.p, self.training)
                     blocks.append(F32P.visio_linguistic_embeddings(x, seg, None, None, tok.weight, pos_w, typ_w, ln.weight, ln.bias,
@@ -107,10 +112,15 @@ class HuggingfaceEmbeddings(nn.Module):
             # Linear -> LayerNorm (the modality's token embedding), + position + type, LayerNorm, dropout
             h = tok[1](tok[0](x))
             typ_w = self.token_type_embeddings.weight if seg is not None else None
-            h = F32P.add_pos_type(h, seg, pos_w, typ_w) if F32P.active() else Fn.AddPosTypeFn.apply(h, seg, pos_w, typ_w)
+            if F32T.active():
+                h = F32T.add_pos_type(h, seg, pos_w, typ_w)
+            else:
+                h = F32P.add_pos_type(h, seg, pos_w, typ_w) if F32P.active() else Fn.AddPosTypeFn.apply(h, seg, pos_w, typ_w)
             blocks.append(dropout(ln(h)))
         if len(blocks) == 1:
             return blocks[0]
+        if F32T.active():
+            return F32T.concat_rows(*blocks)
         return F32P.concat_rows(*blocks) if F32P.active() else Fn.ConcatRowsFn.apply(*blocks)
 
 

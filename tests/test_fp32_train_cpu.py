@@ -79,3 +79,23 @@ def test_vilbert_step_builds_an_fp32_graph_only(name):
     missing = [k for k, p in model.named_parameters() if p.grad is None and "q_dense" not in k]
     assert not missing, missing          # (q_dense1 / q_dense2 exist in the reference's parameter tree and are never called)
     assert all(p.grad is None or p.grad.dtype == torch.float32 for p in model.parameters())
+
+
+def test_mmbt_and_mmft_steps_build_fp32_graphs():
+    from oracle.mmbt_oracle import SHARED
+    from oracle.mmft_oracle import shared
+    for load, build, extra in ((G.load_mmbt_case, lambda cfg, sd: MU.build_mmbt(cfg, sd, SHARED, device="cpu"), set()),
+                               (G.load_mmft_case, lambda cfg, sd: MU.build_mmft(cfg, sd, shared(cfg), device="cpu"), set())):
+        z, case, cfg, sd, sample = load()
+        model = build(cfg, sd)
+        model.train()
+        with native_stub.installed() as calls:
+            with mmf_amd.fp32_training():
+                out = model(SampleList(sample))
+            (key, loss), = out["losses"].items()
+            loss.backward()
+            names = {c[0] for c in calls}
+        assert not (names & BF16_KERNELS), names & BF16_KERNELS
+        assert "attention_f32_bwd" in names and "scatter_add_rows_f32" in names
+        assert all(p.grad is None or p.grad.dtype == torch.float32 for p in model.parameters())
+        assert sum(p.grad is not None for p in model.parameters()) > 20

@@ -400,3 +400,58 @@ def test_fp32_training_vilbert_real_widths_with_dropout_runs():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0], losses
+
+
+def _golden_norm_check(z, params, alias=None):
+    checked = 0
+    for gname, norm in zip(z["grad_names"], z["grad_norms"]):
+        gname = str(gname)
+        p = params[(alias or {}).get(gname, gname)]
+        if norm == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, gname
+            continue
+        if gname.endswith("self.key.bias"):
+            continue
+        assert p.grad is not None and p.grad.dtype == torch.float32, gname
+        assert abs(float(p.grad.double().norm()) - norm) <= TOL_FP32 * norm, (gname, float(p.grad.double().norm()), norm)
+        full = "grad::" + gname
+        if full in z.files:
+            assert _rel(p.grad, torch.from_numpy(z[full])) <= TOL_FP32, gname
+        checked += 1
+    return checked
+
+
+def test_fp32_training_mmbt_golden():
+    """BASELINE.json configs[0] (MMBT): modal block (start token, projected features with their position rows and the modal type row, end
+    token) + text through the fp32 encoder, forward + backward, against the reference's fixture."""
+    from oracle.mmbt_oracle import SHARED
+    from tests.model_utils import build_mmbt
+    z, case, cfg, sd, sample = G.load_mmbt_case()
+    model = build_mmbt(cfg, sd, SHARED)
+    model.eval()
+    with mmf_amd.fp32_training():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    np.testing.assert_allclose(out["scores"].detach().cpu().numpy(), z["scores"], rtol=TOL_FP32, atol=TOL_FP32)
+    (key, loss), = out["losses"].items()
+    assert abs(loss.item() - float(z["loss"])) <= TOL_FP32 * abs(float(z["loss"]))
+    loss.backward()
+    assert _golden_norm_check(z, dict(model.named_parameters())) > 30
+
+
+def test_fp32_training_mmft_golden():
+    """MMF Transformer (text block + Linear -> LayerNorm image tokens with position / type rows, concat, encoder, MLP head), forward +
+    backward on the fp32 kernels, against the reference's fixture; the [PAD] row of the word table gets no gradient."""
+    from oracle import mmft_oracle
+    from tests.model_utils import build_mmft
+    z, case, cfg, sd, sample = G.load_mmft_case()
+    model = build_mmft(cfg, sd, mmft_oracle.shared(cfg))
+    model.eval()
+    with mmf_amd.fp32_training():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    np.testing.assert_allclose(out["scores"].detach().cpu().numpy(), z["scores"], rtol=TOL_FP32, atol=TOL_FP32)
+    (key, loss), = out["losses"].items()
+    assert abs(loss.item() - float(z["loss"])) <= TOL_FP32 * abs(float(z["loss"]))
+    loss.backward()
+    params = dict(model.named_parameters())
+    assert _golden_norm_check(z, params, mmft_oracle.shared(cfg)) > 30
+    assert float(params["backend.transformer.embeddings.word_embeddings.weight"].grad[0].abs().max()) == 0.0

@@ -31,7 +31,6 @@ from mmf_amd import fp32_path as P
 
 F32 = torch.float32
 _depth = 0
-_site = 0          # dropout site counter: every dropout site of a step gets its own key
 
 
 def active():
@@ -53,11 +52,10 @@ def fp32_training():
 
 
 def make_drop(p, training):
-    """Dropout configuration of one site: a fresh key per site from torch's generator (reproducible under torch.manual_seed)."""
-    if not training or p is None or p <= 0.0:
-        return nat.NO_DROP
-    key = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-    return nat.drop_cfg(p, key)
+    """Dropout configuration of one site: the key stream of the throughput path (functional.dropout_keys: one base key per step from torch's
+    generator, a host-side counter per site — reproducible under torch.manual_seed, no device read-back per site)."""
+    from mmf_amd import functional as Fn
+    return Fn.make_drop(p, training)
 
 
 def _rows(x):

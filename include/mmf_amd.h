@@ -259,6 +259,9 @@ int mmf_gather_rows(const void* x, const int64_t* index, void* out, int B, int S
 int mmf_scatter_rows(const void* dout, const int64_t* index, void* dx, int B, int S, int H,
                      uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed,
                      void* stream);
+/* The same backward as ONE pass that writes the whole [B, S, H] gradient (the selected row, zeros elsewhere): no zero fill before it. */
+int mmf_scatter_rows_full(const void* dout, const int64_t* index, void* dx, int B, int S, int H, uint32_t drop_key, uint32_t drop_thr16,
+                          float drop_scale, const uint32_t* drop_seed, void* stream);
 /* out[n] = beta*out[n] + sum over rows of x (bf16); rows = nb groups of rpb rows, group stride
  * bstride rows, row stride ld.  Bias gradients. */
 int mmf_colsum_bf16(const void* x, int ld, int nb, int rpb, int bstride, int N, float* out, float beta,

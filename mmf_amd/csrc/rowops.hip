@@ -644,6 +644,32 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
     }
 }
 
+// backward of the pooling gather as ONE pass over the whole [B, S, H] gradient: row (b, index[b]) = dropout(dout[b]), every other row zero
+// (the zero fill + row scatter of the two-launch form in one launch; one wave per row, 16-byte stores)
+__global__ __launch_bounds__(256) void scatter_rows_full_kernel(const bf16* __restrict__ dout, const int64_t* __restrict__ index, bf16* __restrict__ dx,
+                                                                 int B, int S, int H, DropoutCfg drop) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)B * S) return;
+    const int b = (int)(r / S);
+    int64_t ix = index[b];
+    ix = ix < 0 ? 0 : (ix >= S ? S - 1 : ix);
+    const bool hit = r - (long)b * S == ix;
+    for (int col = lane * 8; col < H; col += 512) {
+        f32x8r v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hit) {
+            v = load8(dout + (size_t)b * H + col);
+            if (drop.thr16) {
+                const uint32_t idx = (uint32_t)b * (uint32_t)H + (uint32_t)col;
+                const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale), s1 = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] *= s0[i]; v[i + 4] *= s1[i]; }
+            }
+        }
+        store8(dx + (size_t)r * H + col, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // column sums: grid (CS_GROUPS, ceil(N/256)); partials [CS_GROUPS][N]
 // ------------------------------------------------------------------------------------------------
@@ -1441,6 +1467,16 @@ int mmf_scatter_rows(const void* dout, const int64_t* index, void* dx, int B, in
     MMF_CHECK_ARG(dout && index && dx && (H % 4) == 0, "scatter_rows: bad operand");
     hipLaunchKernelGGL(gather_rows_kernel<bf16>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, index,
                        (bf16*)dx, B, S, H, DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed}, 1);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_scatter_rows_full(const void* dout, const int64_t* index, void* dx, int B, int S, int H, uint32_t drop_key, uint32_t drop_thr16,
+                          float drop_scale, const uint32_t* drop_seed, void* stream) {
+    MMF_CHECK_ARG(dout && index && dx && B > 0 && S > 0 && (H % 8) == 0, "scatter_rows_full: bad operand (H % 8 == 0)");
+    const long rows = (long)B * S;
+    hipLaunchKernelGGL(scatter_rows_full_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, index, (bf16*)dx, B,
+                       S, H, DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed});
     MMF_CHECK_LAUNCH();
     return 0;
 }

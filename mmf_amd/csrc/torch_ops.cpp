@@ -588,9 +588,15 @@ struct GatherRowsFn : public torch::autograd::Function<GatherRowsFn> {
         auto d = ctx->saved_data["dims"].toIntVector();
         const Drop drop = drop_unpack(ctx->saved_data["drop"], sv[1]);
         Tensor g = grad_bf16(grads[0], d[2]);
-        Tensor dx = at::zeros({d[0] * d[1], d[2]}, g.options());
-        MMF_RC(mmf_scatter_rows(g.data_ptr(), sv[0].data_ptr<int64_t>(), dx.data_ptr(), (int)d[0], (int)d[1], (int)d[2], drop.key, drop.thr16, drop.scale,
-                                drop.seed_ptr(), sp()), "mmf_scatter_rows");
+        Tensor dx = at::empty({d[0] * d[1], d[2]}, g.options());
+        if (d[2] % 8 == 0) {        // one pass writes the selected rows AND the zeros
+            MMF_RC(mmf_scatter_rows_full(g.data_ptr(), sv[0].data_ptr<int64_t>(), dx.data_ptr(), (int)d[0], (int)d[1], (int)d[2], drop.key, drop.thr16,
+                                         drop.scale, drop.seed_ptr(), sp()), "mmf_scatter_rows_full");
+        } else {
+            dx.zero_();
+            MMF_RC(mmf_scatter_rows(g.data_ptr(), sv[0].data_ptr<int64_t>(), dx.data_ptr(), (int)d[0], (int)d[1], (int)d[2], drop.key, drop.thr16, drop.scale,
+                                    drop.seed_ptr(), sp()), "mmf_scatter_rows");
+        }
         return {dx.view({d[0], d[1], d[2]}), Tensor(), Tensor()};
     }
 };
@@ -722,16 +728,18 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
         LnBwd l = ln_bwd(dy, y, mean, rstd, ln_w, Drop(), false);
         const Tensor& dpre = l.dx;
         auto f32o = dpre.options().dtype(at::kFloat);
-        Tensor dword = at::zeros({V, H}, f32o), dpos = at::zeros({Pn, H}, f32o), dtyp = at::zeros({NT, H}, f32o);
+        // ONE zero fill for the five table gradients (row blocks of one buffer: each gradient is a contiguous [rows, H] view of it)
+        Tensor tabs = at::zeros({V + Pn + NT + (R ? NTV + PV : 0), H}, f32o);
+        Tensor dword = tabs.narrow(0, 0, V), dpos = tabs.narrow(0, V, Pn), dtyp = tabs.narrow(0, V + Pn, NT);
         scatter(dpre.data_ptr(), H, B, T, S, ids, T, 0, dword, H, 0, pad);      // padding_idx rows get no gradient
         scatter(dpre.data_ptr(), H, B, T, S, Tensor(), 0, 1, dpos, H, 0, -1);
         scatter(dpre.data_ptr(), H, B, T, S, seg, T, 0, dtyp, H, 1, -1);
         Tensor dtyp_vis, dpos_vis, dproj_w, dproj_b;
         if (R) {
             const char* vis = reinterpret_cast<const char*>(dpre.data_ptr()) + T * H * 2;   // row (b, r) of the visual block lives at dpre[b*S + T + r]
-            dtyp_vis = at::zeros({NTV, H}, f32o);
+            dtyp_vis = tabs.narrow(0, V + Pn + NT, NTV);
             scatter(vis, H, B, R, S, vt, R, 0, dtyp_vis, H, 1, -1);
-            dpos_vis = at::zeros({PV, H}, f32o);
+            dpos_vis = tabs.narrow(0, V + Pn + NT + NTV, PV);
             scatter(vis, H, B, R, S, Tensor(), 0, 0, dpos_vis, H, 1, -1);
             if (sv[10].defined())       // the aligned words' TEXT position rows collect the regions' gradients / count
                 MMF_RC(mmf_align_pos_bwd(vis, (int)H, (int)B, (int)R, (int)S, sv[10].data_ptr<int64_t>(), dpos.data_ptr<float>(), (int)sv[10].size(1), (int)H, (int)Pn,
@@ -765,9 +773,9 @@ struct LogitBCEFn : public torch::autograd::Function<LogitBCEFn> {
         const int64_t B = sv[0].size(0), N = sv[0].size(1);
         const int ldd = pad8(N);
         Tensor g = grads[0].to(at::kFloat).reshape({1}).contiguous();
-        Tensor d16 = empty_bf16({B, (int64_t)ldd}, sv[0]), d = empty_f32({B, N}, sv[0]);
-        MMF_RC(mmf_bce_logits_bwd(PF(sv[0]), PF(sv[1]), PF(g), d16.data_ptr(), ldd, (int)B, (int)N, sp()), "mmf_bce_logits_bwd");
-        MMF_RC(mmf_cast2d_bf16_to_f32(d16.data_ptr(), ldd, d.data_ptr<float>(), (int)N, (int)B, (int)N, sp()), "mmf_cast2d_bf16_to_f32");
+        Tensor d = empty_f32({B, N}, sv[0]);        // fp32 directly (one launch; the classifier's backward rounds it to its bf16 GEMM operand)
+        (void)ldd;
+        MMF_RC(mmf_bce_logits_f32_bwd(PF(sv[0]), PF(sv[1]), PF(g), d.data_ptr<float>(), (int)B, (int)N, sp()), "mmf_bce_logits_f32_bwd");
         return {d, Tensor()};
     }
 };

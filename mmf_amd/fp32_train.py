@@ -104,9 +104,6 @@ def _colsum(dz):
     return out
 
 
-def _contig_cols(x2):
-    return x2 if x2.stride(1) == 1 else x2.contiguous()
-
 
 def _ln_fwd(y, gamma, beta, eps):
     M, H = y.shape

@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=gpurun_out/profiles_$tag
 export TMPDIR=/tmp
 mkdir -p $out
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph"
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph --no-fp32"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $CMD > $out/trace.log 2>&1
 [ "$2" = "trace-only" ] && { grep -h metric $out/trace.log | cut -c1-300; exit 0; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- $CMD > $out/pmc_fetch.log 2>&1

@@ -546,7 +546,9 @@ int mmf_colsum_f32(const float* x, int ld, int rows, int N, float* out, int accu
 int mmf_dropout_f32(const float* x, float* y, long n, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream);
 int mmf_scatter_add_rows_f32(const float* g, int ld, int rows, int H, int grp, int grp_stride, int grp_off, const int64_t* idx, long dst_stride,
                              long skip, int NT, float* out, int ldo, void* stream);
-/* mmf_bce_logits_bwd with an fp32 gradient (exact expf). */
+/* mmf_bce_logits_bwd / mmf_vocab_cross_entropy_bwd with fp32 gradients (fp32 training); ldd: a multiple of 4 covering C, the pad columns are zeroed. */
+int mmf_vocab_cross_entropy_f32_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* count, const float* gloss,
+                                    float* dlogits, int ldd, int R, int C, int ignore_index, void* stream);
 int mmf_bce_logits_f32_bwd(const float* scores, const float* targets, const float* gloss, float* dscores, int B, int N, void* stream);
 
 /* fp32 row operators of the widened models on the fp32 path: zero-padded copy of short rows (the 5-d / 7-d box geometry operands of

@@ -697,6 +697,14 @@ def dropout_f32(x, y, drop):
     _check(lib().mmf_dropout_f32(_p(x), _p(y), C.c_long(x.numel()), key, thr, C.c_float(scale), seed, _stream()), "mmf_dropout_f32")
 
 
+def vocab_cross_entropy_f32_bwd(logits, labels, lse, count, gloss, dlogits, ldd, R, Cn, ignore_index=-1):
+    for t, n in ((logits, "logits"), (lse, "lse"), (count, "count"), (gloss, "gloss"), (dlogits, "dlogits")):
+        _req(t, torch.float32, n)
+    _req(labels, torch.int64, "labels")
+    _check(lib().mmf_vocab_cross_entropy_f32_bwd(_p(logits), logits.stride(0), _p(labels), _p(lse), _p(count), _p(gloss), _p(dlogits), ldd, R, Cn,
+                                                 ignore_index, _stream()), "mmf_vocab_cross_entropy_f32_bwd")
+
+
 def bce_logits_f32_bwd(scores, targets, gloss, dscores, B, N):
     for t, n in ((scores, "scores"), (targets, "targets"), (gloss, "gloss"), (dscores, "dscores")):
         _req(t, torch.float32, n)

@@ -933,9 +933,10 @@ __global__ __launch_bounds__(256) void vocab_ce_finalize_kernel(const float* __r
     if (threadIdx.x == 0) { loss[0] = s / n; count[0] = n; }
 }
 // d[r][c] = gloss / count * (softmax(x[r])[c] - [c == y_r]) for counted rows, 0 elsewhere (ignored rows, pad columns C..ldd)
+template <typename T>     // bf16: the zero-padded GEMM operand of the throughput path; float: the fp32 training path
 __global__ __launch_bounds__(256) void vocab_ce_bwd_kernel(const float* __restrict__ x, int ld, const int64_t* __restrict__ lab,
                                                             const float* __restrict__ lse, const float* __restrict__ count,
-                                                            const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int C,
+                                                            const float* __restrict__ gloss, T* __restrict__ d, int ldd, int C,
                                                             int ignore_index) {
     const int r = blockIdx.y;
     const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -1603,9 +1604,21 @@ int mmf_vocab_cross_entropy_bwd(const float* logits, int ld, const int64_t* labe
     MMF_CHECK_ARG(ldd >= C && (ldd % 8) == 0, "vocab_cross_entropy_bwd: ldd must be a multiple of 8 covering C (the GEMM operand's leading dimension)");
     for (int r0 = 0; r0 < R; r0 += 65535) {       // (grid.y is limited to 65535 rows per launch)
         const int rows = R - r0 < 65535 ? R - r0 : 65535;
-        hipLaunchKernelGGL(vocab_ce_bwd_kernel, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(vocab_ce_bwd_kernel<bf16>, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
                            logits + (size_t)r0 * ld, ld, labels + r0, lse + r0, count, gloss, (bf16*)dlogits + (size_t)r0 * ldd, ldd, C,
                            ignore_index);
+    }
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_vocab_cross_entropy_f32_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* count, const float* gloss,
+                                    float* dlogits, int ldd, int R, int C, int ignore_index, void* stream) {
+    MMF_CHECK_ARG(logits && labels && lse && count && dlogits && R > 0 && C > 0 && ld >= C, "vocab_cross_entropy_f32_bwd: bad operand");
+    MMF_CHECK_ARG(ldd >= C && (ldd % 4) == 0, "vocab_cross_entropy_f32_bwd: ldd must be a multiple of 4 covering C");
+    for (int r0 = 0; r0 < R; r0 += 65535) {
+        const int rows = R - r0 < 65535 ? R - r0 : 65535;
+        hipLaunchKernelGGL(vocab_ce_bwd_kernel<float>, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
+                           logits + (size_t)r0 * ld, ld, labels + r0, lse + r0, count, gloss, dlogits + (size_t)r0 * ldd, ldd, C, ignore_index);
     }
     MMF_CHECK_LAUNCH();
     return 0;

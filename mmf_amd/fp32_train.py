@@ -14,7 +14,7 @@ mmf_amd/csrc/fp32_train.hip (LayerNorm backward, column sums, dropout, row scatt
 directly, fp32 gradients.  Parity: every parameter gradient of the reference's fixture and of the full VisualBERT-base VQA2 configuration
 against the CPU oracle within north_star's fp32 bound (tests/test_fp32_train_gpu.py).
 
-Built for the operators the classification steps of VisualBERT, ViLBERT, MMBT and the MMF Transformer use (their embedding stages, encoder
+Built for the operators the classification steps of VisualBERT, ViLBERT, MMBT, the MMF Transformer and UNITER use (their embedding stages, encoder
 layers, ViLBERT's co-attention and output blocks, poolers, nlvr2 pairing, prediction-head transform, classifiers, logit_bce; cross_entropy is
 fp32 already); operators outside that set raise NotImplementedError inside the context instead of silently dropping to bf16.
 
@@ -654,6 +654,89 @@ class ConcatRowsFn(torch.autograd.Function):
         return tuple(outs)
 
 
+# ---- UNITER (mmf/models/uniter.py) -------------------------------------------------------------------------------------------------------
+class FeatureTableAddFn(torch.autograd.Function):
+    """img_feat + mask_embedding(img_masks) (uniter.py:74-78) on fp32 rows; the features get no gradient, the table's row `padding_idx` neither."""
+
+    @staticmethod
+    def forward(ctx, feats, idx, table, padding_idx):
+        y = P.feature_table_add(feats, idx, table)
+        ix = None if idx is None else idx.reshape(-1).long().contiguous()
+        ctx.save_for_backward(ix)
+        ctx.meta = (table.shape[0], padding_idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (ix,) = ctx.saved_tensors
+        NT, pad = ctx.meta
+        if ix is None:
+            return None, None, None, None
+        D = g.shape[-1]
+        g2 = _grad2(g, D)
+        dt = torch.zeros(NT, D, dtype=F32, device=g2.device)
+        nat.scatter_add_rows_f32(g2, D, g2.shape[0], D, ix, dt, D, skip=-1 if pad is None else int(pad))
+        return None, None, dt, None
+
+
+class SmallKLinearFn(torch.autograd.Function):
+    """nn.Linear over a handful of input features (UNITER's 7-d box geometry, uniter.py:64,81), operand zero-padded to 16-byte rows; the input
+    gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K = x.shape[-1]
+        KP = (K + 3) // 4 * 4
+        x2 = x.reshape(-1, K)
+        x2 = (x2 if x2.dtype == F32 else x2.float()).contiguous()
+        w = _w(weight)
+        if KP != K:
+            x2, w = P._pad_k(x2, K, KP), P._pad_k(w, K, KP)
+        y = _gemm(x2, w, w.shape[0], bias=_w(bias))
+        ctx.save_for_backward(x2)
+        ctx.meta = (x.shape, K)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2,) = ctx.saved_tensors
+        xshape, K = ctx.meta
+        dz = _pad4(_grad2(g, g.shape[-1]))
+        return None, _wgrad(dz, x2)[:, :K].contiguous(), _colsum(dz)
+
+
+class MaskedLMHeadFn(torch.autograd.Function):
+    """Decoder tied to the word embeddings + CrossEntropyLoss(ignore_index) (visual_bert.py:267-277; HF BertLMPredictionHead) in fp32:
+    (loss, logits [*, vocab]); only the loss carries gradient.  The backward materialises the fp32 [rows, vocab] gradient (the throughput path
+    writes a bf16 GEMM operand instead) and runs the decoder's dgrad / weight gradient on it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, labels, ignore_index):
+        x2 = _rows(x)
+        M = x2.shape[0]
+        w = _w(weight)
+        N = w.shape[0]
+        logits = _gemm(x2, w, N, bias=_w(bias))
+        lab = labels.reshape(M).contiguous().long()
+        lse = _empty(M, like=x2); rowloss = _empty(M, like=x2); loss = _empty(1, like=x2); count = _empty(1, like=x2)
+        nat.vocab_cross_entropy_fwd(logits, lab, lse, rowloss, loss, count, M, N, ignore_index)
+        ctx.save_for_backward(x2, w, logits, lab, lse, count)
+        ctx.meta = (x.shape, ignore_index)
+        ctx.mark_non_differentiable(logits)
+        return loss[0], logits.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g, _glogits):
+        x2, w, logits, lab, lse, count = ctx.saved_tensors
+        xshape, ignore_index = ctx.meta
+        M, N = logits.shape
+        NP = (N + 3) // 4 * 4
+        dl = _empty(M, NP, like=x2)
+        nat.vocab_cross_entropy_f32_bwd(logits, lab, lse, count, g.float().reshape(1).contiguous(), dl, NP, M, N, ignore_index)
+        dz = dl[:, :N]
+        return _dgrad(dz, w).view(xshape), _wgrad(dz, x2), _colsum(dz), None, None
+
+
 class LogitBCEFn(torch.autograd.Function):
     """mean(BCEWithLogits(scores, targets)) * num_labels (losses.py:246-251) with an fp32 gradient."""
 
@@ -765,6 +848,18 @@ def add_pos_type(x, seg, pos, typ):
 
 def concat_rows(*xs):
     return ConcatRowsFn.apply(*xs)
+
+
+def feature_table_add(feats, idx, table, padding_idx=0):
+    return FeatureTableAddFn.apply(feats, idx, table, padding_idx)
+
+
+def small_k_linear(x, weight, bias):
+    return SmallKLinearFn.apply(x, weight, bias)
+
+
+def masked_lm_head(x, weight, bias, labels, ignore_index):
+    return MaskedLMHeadFn.apply(x, weight, bias, labels, ignore_index)
 
 
 def unsupported(name):

@@ -23,6 +23,7 @@ from torch import nn
 
 from mmf_amd import functional as Fn
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
 from mmf_amd.models.transformers.heads import itm as _itm_head  # noqa: F401  (registers "itm")
@@ -68,6 +69,14 @@ class UNITERImageEmbeddings(nn.Module):
     def forward(self, img_feat, img_pos_feat, type_embeddings, img_masks=None):
         """`type_embeddings` is `(type_ids [B, R], token_type table)`: the lookup is part of the fused sum here."""
         type_ids, type_table = type_embeddings
+        if F32T.active():      # mmf_amd.fp32_training(): fp32 forward + backward
+            if img_masks is not None:
+                self.mask_embedding.weight.data[0, :].fill_(0)
+            feats = F32T.feature_table_add(img_feat, None if img_masks is None else img_masks.long(), self.mask_embedding.weight, 0)
+            transformed_im = self.img_layer_norm(self.img_linear(feats))
+            transformed_pos = self.pos_layer_norm(F32T.small_k_linear(img_pos_feat, self.pos_linear.weight, self.pos_linear.bias))
+            embeddings = F32T.add_pos_type(F32T.add(transformed_im, transformed_pos), type_ids, None, type_table)
+            return self.dropout(self.final_layer_norm(embeddings))
         if F32P.active():      # fp32-accurate forward (mmf_amd.fp32_inference()): same operations on the fp32 kernels
             if img_masks is not None:
                 self.mask_embedding.weight.data[0, :].fill_(0)
@@ -121,6 +130,8 @@ class UNITERModelBase(nn.Module):
                                     img_type_ids=None):
         txt_emb = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
         img_emb = self._compute_img_embeddings(img_feat, img_pos_feat, img_masks, img_type_ids)
+        if F32T.active():
+            return F32T.concat_rows(txt_emb, img_emb)
         return F32P.concat_rows(txt_emb, img_emb) if F32P.active() else Fn.ConcatRowsFn.apply(txt_emb, img_emb)   # :195
 
     def forward(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, img_masks=None, txt_type_ids=None,

@@ -196,7 +196,7 @@ def pair_halves(x):
 @_op("masked_lm_head(Tensor x, Tensor weight, Tensor bias, Tensor labels, int ignore_index) -> (Tensor, Tensor)")
 def masked_lm_head(x, weight, bias, labels, ignore_index):
     if F32T.active():
-        F32T.unsupported("masked_lm_head")
+        return F32T.masked_lm_head(x, weight, bias, labels, ignore_index)
     if F32P.active():
         return F32P.masked_lm_head(x, weight, bias, labels, ignore_index)
     return Fn.MaskedLMHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), labels, ignore_index)

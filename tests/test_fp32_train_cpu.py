@@ -52,14 +52,28 @@ def test_nlvr2_step_builds_an_fp32_graph():
 
 
 def test_operators_without_an_fp32_backward_refuse():
-    z, case, cfg, sd, sample = G.load_pretraining_case()
-    if isinstance(sample, (list, tuple)):
-        sample = sample[0]
-    model = MU.build_visual_bert_pretraining(cfg, sd, device="cpu")
+    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_dyn")          # `dynamic_attention`: the gate has no fp32 backward
+    model = MU.build_vilbert(cfg, sd, device="cpu")
     model.eval()
     with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32_training"):
         with mmf_amd.fp32_training():
             model(SampleList(sample))
+
+
+def test_visual_bert_pretraining_step_builds_an_fp32_graph():
+    z, case, cfg, sd, sample = G.load_pretraining_case()
+    model = MU.build_visual_bert_pretraining(cfg, sd, device="cpu")
+    model.train()
+    with native_stub.installed() as calls:
+        with mmf_amd.fp32_training():
+            out = model(SampleList(sample))
+        (key, loss), = out["losses"].items()
+        loss.backward()
+        names = {c[0] for c in calls}
+    assert not (names & BF16_KERNELS), names & BF16_KERNELS
+    assert "vocab_cross_entropy_f32_bwd" in names
+    word = model.model.bert.embeddings.word_embeddings.weight
+    assert word.grad is not None and word.grad.dtype == torch.float32 and model.model.cls.predictions.decoder.weight is word
 
 
 @pytest.mark.parametrize("name", ["vilbert_small", "vilbert_nlvr2"])
@@ -99,3 +113,18 @@ def test_mmbt_and_mmft_steps_build_fp32_graphs():
         assert "attention_f32_bwd" in names and "scatter_add_rows_f32" in names
         assert all(p.grad is None or p.grad.dtype == torch.float32 for p in model.parameters())
         assert sum(p.grad is not None for p in model.parameters()) > 20
+
+
+def test_uniter_step_builds_an_fp32_graph():
+    z, case, cfg, sd, sample = G.load_uniter_case()
+    model = MU.build_uniter(cfg, sd, device="cpu")
+    model.train()
+    with native_stub.installed() as calls:
+        with mmf_amd.fp32_training():
+            out = model(SampleList(sample))
+        (key, loss), = out["losses"].items()
+        loss.sum().backward()
+        names = {c[0] for c in calls}
+    assert not (names & BF16_KERNELS), names & BF16_KERNELS
+    assert all(p.grad is None or p.grad.dtype == torch.float32 for p in model.parameters())
+    assert sum(p.grad is not None for p in model.parameters()) > 20

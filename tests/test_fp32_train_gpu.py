@@ -315,13 +315,30 @@ def test_fp32_training_nlvr2_head_golden():
 
 
 def test_fp32_training_refuses_operators_without_a_backward():
-    from tests.model_utils import build_visual_bert_pretraining
-    z, case, cfg, sd, sample = G.load_pretraining_case()
-    model = build_visual_bert_pretraining(cfg, sd)
+    from tests.model_utils import build_vilbert
+    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_dyn")          # `dynamic_attention`: the gate has no fp32 backward
+    model = build_vilbert(cfg, sd)
     model.eval()
     with pytest.raises(NotImplementedError, match="fp32_training"):
         with mmf_amd.fp32_training():
             model(SampleList(sample_to(sample, "cuda")))
+
+
+def test_fp32_training_visual_bert_pretraining_golden():
+    """`training_head_type: pretraining` (masked LM over the joint sequence, decoder tied to the word embeddings): loss and logits against the
+    reference's fixture, every gradient norm — the tied table collects the gather's AND the decoder's gradient."""
+    from tests.model_utils import build_visual_bert_pretraining
+    z, case, cfg, sd, sample = G.load_pretraining_case()
+    model = build_visual_bert_pretraining(cfg, sd)
+    model.eval()
+    with mmf_amd.fp32_training():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    (key, loss), = out["losses"].items()
+    assert abs(loss.item() - float(z["loss"])) <= TOL_FP32 * abs(float(z["loss"]))
+    if "logits" in z.files and "logits" in out:
+        np.testing.assert_allclose(out["logits"].detach().cpu().numpy().reshape(z["logits"].shape), z["logits"], rtol=TOL_FP32, atol=TOL_FP32)
+    loss.backward()
+    assert _golden_norm_check(z, dict(model.named_parameters())) > 30
 
 
 def _vilbert_grad_check(model, sdr, tol):
@@ -455,3 +472,19 @@ def test_fp32_training_mmft_golden():
     params = dict(model.named_parameters())
     assert _golden_norm_check(z, params, mmft_oracle.shared(cfg)) > 30
     assert float(params["backend.transformer.embeddings.word_embeddings.weight"].grad[0].abs().max()) == 0.0
+
+
+def test_fp32_training_uniter_golden():
+    """UNITER (feature + mask-embedding rows, 7-d box geometry Linear, three LayerNorms, text block, concat, encoder, MLP head): forward +
+    backward on the fp32 kernels against the reference's fixture."""
+    from tests.model_utils import build_uniter
+    z, case, cfg, sd, sample = G.load_uniter_case()
+    model = build_uniter(cfg, sd)
+    model.eval()
+    with mmf_amd.fp32_training():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    np.testing.assert_allclose(out["scores"].detach().cpu().numpy(), z["scores"], rtol=TOL_FP32, atol=TOL_FP32)
+    (key, loss), = out["losses"].items()
+    assert abs(loss.sum().item() - float(z["loss"])) <= TOL_FP32 * abs(float(z["loss"]))
+    loss.sum().backward()
+    assert _golden_norm_check(z, dict(model.named_parameters())) > 30

@@ -559,6 +559,13 @@ int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, vo
 int mmf_masked_mean_f32(const float* x, const float* mask, float* pool, int B, int T, int H, void* stream);
 int mmf_rowgroup_scale_f32(float* x, int ld, const float* gate, int groups, int rows_per_group, int C, void* stream);
 
+/* M4C's row operators on fp32 rows (the fp32-accurate forward path): mmf_l2norm_rows_fwd, mmf_gather_rows2 and mmf_ptr_scores_fwd with fp32
+ * operands (m4c.py:195,212-223; :526-528; :474-493). */
+int mmf_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int D, float eps, void* stream);
+int mmf_gather_rows2_f32(const float* a, int64_t rows_a, const float* b, int64_t rows_b, const int64_t* idx, float* out, int n, int H, void* stream);
+int mmf_ptr_scores_f32(const float* q, const float* k, const float* mask_add, float* out, int ldo, int B, int T, int N, int HQ, float scale,
+                       void* stream);
+
 /* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
 int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */
 int mmf_probe_mfma32(const void* a, const void* b, float* d, void* stream);   /* out 64x16 */

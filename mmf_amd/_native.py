@@ -738,6 +738,24 @@ def rows_add_embed_f32(x, seg, pos, typ, y, B, L, S, H, row0=0, pos0=0):
     _check(lib().mmf_rows_add_embed_f32(_p(x), _p(seg), _p(pos), _p(typ), _p(y), B, L, S, H, row0, pos0, _stream()), "mmf_rows_add_embed_f32")
 
 
+def l2norm_rows_f32(x, ldx, y, ldy, rows, D, eps=1e-12):
+    _req(x, torch.float32, "x"); _req(y, torch.float32, "y")
+    _check(lib().mmf_l2norm_rows_f32(_p(x), ldx, _p(y), ldy, rows, D, C.c_float(eps), _stream()), "mmf_l2norm_rows_f32")
+
+
+def gather_rows2_f32(a, b, idx, out, n, H):
+    for t, nm in ((a, "a"), (b, "b"), (out, "out")):
+        _req(t, torch.float32, nm)
+    _req(idx, torch.int64, "idx")
+    _check(lib().mmf_gather_rows2_f32(_p(a), C.c_int64(a.shape[0]), _p(b), C.c_int64(b.shape[0]), _p(idx), _p(out), n, H, _stream()), "mmf_gather_rows2_f32")
+
+
+def ptr_scores_f32(q, k, mask_add, out, ldo, B, T, N, HQ, scale):
+    for t, nm in ((q, "q"), (k, "k"), (mask_add, "mask_add"), (out, "out")):
+        _req(t, torch.float32, nm)
+    _check(lib().mmf_ptr_scores_f32(_p(q), _p(k), _p(mask_add), _p(out), ldo, B, T, N, HQ, C.c_float(scale), _stream()), "mmf_ptr_scores_f32")
+
+
 def pad_rows_f32(src, K, dst, KP, rows):
     _req(src, torch.float32, "src"); _req(dst, torch.float32, "dst")
     _check(lib().mmf_pad_rows_f32(_p(src), K, _p(dst), KP, rows, _stream()), "mmf_pad_rows_f32")

@@ -723,6 +723,49 @@ __global__ __launch_bounds__(256) void rowgroup_scale_f32_kernel(float* __restri
     const int c = (int)(i - row * C);
     x[row * ld + c] *= gate[(row / rpg) * C + c];
 }
+// ---- M4C (mmf/models/m4c.py) on fp32 rows ----------------------------------------------------------------------------------------------
+// F.normalize(x, dim=-1): y[r, :D] = x[r, :D] / max(||x[r, :D]||, eps) at row strides ldx / ldy (y may be a column slice of the wider
+// concatenated OCR feature row, m4c.py:235-237).  One wave per row.
+__global__ __launch_bounds__(256) void l2norm_rows_f32_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * ldx;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = xr[c]; s += v * v; }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), eps);
+    float* yr = y + (size_t)r * ldy;
+    for (int c = lane; c < D; c += 64) yr[c] = xr[c] * inv;
+}
+// out[r] = idx[r] < rows_a ? a[idx[r]] : b[idx[r] - rows_a]   (PrevPredEmbeddings' two-source gather, m4c.py:526-528)
+__global__ __launch_bounds__(256) void gather_rows2_f32_kernel(const float* __restrict__ a, long rows_a, const float* __restrict__ b, long rows_b,
+                                                                const int64_t* __restrict__ idx, float* __restrict__ out, int n, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    long ix = idx[r];
+    ix = ix < 0 ? 0 : (ix >= rows_a + rows_b ? rows_a + rows_b - 1 : ix);
+    const float* src = ix < rows_a ? a + (size_t)ix * H : b + (size_t)(ix - rows_a) * H;
+    for (int c = lane * 4; c < H; c += 256) *reinterpret_cast<f32x4*>(out + (size_t)r * H + c) = *reinterpret_cast<const f32x4*>(src + c);
+}
+// OcrPtrNet.forward (m4c.py:474-493): out[b, t, n] = scale <q[b, t], k[b, n]> + mask_add[b, n]; one workgroup per (b, t), a wave per n
+__global__ __launch_bounds__(256) void ptr_scores_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ mask_add,
+                                                              float* __restrict__ out, int ldo, int T, int N, int HQ, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bt = blockIdx.x, b = bt / T;
+    const float* qr = q + (size_t)bt * HQ;
+    for (int n = wave; n < N; n += 4) {
+        const float* kr = k + ((size_t)b * N + n) * HQ;
+        float s = 0.f;
+        for (int c = lane * 4; c < HQ; c += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qr + c), bb = *reinterpret_cast<const f32x4*>(kr + c);
+            s += (a[0] * bb[0] + a[1] * bb[1]) + (a[2] * bb[2] + a[3] * bb[3]);
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)bt * ldo + n] = s * scale + (mask_add ? mask_add[(size_t)b * N + n] : 0.f);
+    }
+}
+
 }  // namespace
 
 template <int MI, bool AKM, bool BKM>
@@ -940,6 +983,28 @@ extern "C" int mmf_rowgroup_scale_f32(float* x, int ld, const float* gate, int g
     MMF_CHECK_ARG(x && gate && groups > 0 && rows_per_group > 0 && C > 0 && C <= ld, "rowgroup_scale_f32: bad operand");
     const long n = (long)groups * rows_per_group * C;
     hipLaunchKernelGGL(rowgroup_scale_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, gate, rows_per_group, C, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmf_l2norm_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int D, float eps, void* stream) {
+    MMF_CHECK_ARG(x && y && rows > 0 && D > 0 && ldx >= D && ldy >= D, "l2norm_rows_f32: bad operand");
+    hipLaunchKernelGGL(l2norm_rows_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, D, eps);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmf_gather_rows2_f32(const float* a, int64_t rows_a, const float* b, int64_t rows_b, const int64_t* idx, float* out, int n, int H, void* stream) {
+    MMF_CHECK_ARG(a && b && idx && out && n > 0 && H > 0 && (H % 4) == 0 && rows_a >= 0 && rows_b >= 0 && rows_a + rows_b > 0, "gather_rows2_f32: bad operand");
+    MMF_CHECK_ARG((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "gather_rows2_f32: 16-byte alignment");
+    hipLaunchKernelGGL(gather_rows2_f32_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, (long)rows_a, b, (long)rows_b, idx, out, n, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmf_ptr_scores_f32(const float* q, const float* k, const float* mask_add, float* out, int ldo, int B, int T, int N, int HQ, float scale,
+                                  void* stream) {
+    MMF_CHECK_ARG(q && k && out && B > 0 && T > 0 && N > 0 && HQ > 0 && (HQ % 4) == 0 && ldo >= N, "ptr_scores_f32: bad operand");
+    MMF_CHECK_ARG((((uintptr_t)q | (uintptr_t)k) & 15) == 0, "ptr_scores_f32: 16-byte alignment");
+    hipLaunchKernelGGL(ptr_scores_f32_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, q, k, mask_add, out, ldo, T, N, HQ, scale);
     MMF_CHECK_LAUNCH();
     return 0;
 }

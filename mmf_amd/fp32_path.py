@@ -420,3 +420,87 @@ def feature_table_add(feats, idx, table):
     y = torch.empty(B * R, D, dtype=F32, device=f2.device)
     nat.rows_add_embed_f32(f2, idx.reshape(B, R).long().contiguous(), None, _w(table), y, B, R, R, D)
     return y.view(B, R, D)
+
+
+# ---------------------------------------------------------------------------------------------
+# M4C (mmf/models/m4c.py) on the fp32 kernels
+# ---------------------------------------------------------------------------------------------
+def l2norm_rows(x):
+    """F.normalize(x, dim=-1) (m4c.py:195)."""
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    x2 = (x2 if x2.dtype == F32 else x2.float()).contiguous()
+    y = torch.empty_like(x2)
+    nat.l2norm_rows_f32(x2, D, y, D, x2.shape[0], D)
+    return y.view(x.shape)
+
+
+def ocr_feature_concat(fasttext, phoc, fc7, order_dim):
+    """cat([normalize(fasttext), normalize(phoc), normalize(fc7), zeros(order vectors)], -1) (m4c.py:211-237) written once as fp32 rows
+    padded to a multiple of 4 columns (16-byte rows for the GEMM loader)."""
+    B, N, _ = fasttext.shape
+    rows = B * N
+    d0, d1, d2 = fasttext.shape[-1], phoc.shape[-1], fc7.shape[-1]
+    K = d0 + d1 + d2 + int(order_dim)
+    KP = (K + 3) // 4 * 4
+    out = torch.zeros(rows, KP, dtype=F32, device=fc7.device)
+    off = 0
+    for f, d in ((fasttext, d0), (phoc, d1), (fc7, d2)):
+        f2 = f.reshape(rows, d)
+        f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
+        nat.l2norm_rows_f32(f2, d, out[:, off:], KP, rows, d)
+        off += d
+    return out.view(B, N, KP), K
+
+
+def padded_linear(x, weight, bias):
+    """nn.Linear on rows already zero-padded to a multiple of 4 columns (the 3002-wide OCR feature, m4c.py:243)."""
+    K = weight.shape[1]
+    KP = x.shape[-1]
+    x2 = _rows(x)
+    w = _w(weight)
+    if KP != K:
+        w = _pad_k(w, K, KP)
+    M = x2.shape[0]
+    out = torch.empty(M, w.shape[0], dtype=F32, device=x2.device)
+    nat.gemm_f32(x2, w, out, M, w.shape[0], KP, KP, KP, w.shape[0], bias=_w(bias))
+    return out.view(*x.shape[:-1], w.shape[0])
+
+
+def prev_pred_gather(ans, ocr, prev_inds):
+    """_batch_gather(cat([ans_emb.expand(B), ocr_emb], 1), prev_inds) (m4c.py:526-528) as one two-source row gather."""
+    V, H = ans.shape
+    B, N, _ = ocr.shape
+    T = prev_inds.shape[1]
+    batch = torch.arange(B, device=prev_inds.device, dtype=torch.int64).unsqueeze(1) * N
+    flat = torch.where(prev_inds < V, prev_inds, prev_inds + batch).contiguous()
+    out = torch.empty(B * T, H, dtype=F32, device=ocr.device)
+    nat.gather_rows2_f32(_rows(ans), _rows(ocr), flat, out, B * T, H)
+    return out.view(B, T, H)
+
+
+def split_rows(x, lens):
+    """torch.split along dim 1 into contiguous fp32 blocks (m4c.py:446-449)."""
+    B, S, H = x.shape
+    xb = _rows(x).view(torch.bfloat16)
+    outs, off = [], 0
+    for L in lens:
+        d = torch.empty(B * L, H, dtype=F32, device=x.device)
+        nat.copy_rows(xb[off:], S, d.view(torch.bfloat16), L, B, L, 2 * H)
+        outs.append(d.view(B, L, H))
+        off += L
+    return tuple(outs)
+
+
+def m4c_scores(dec, ocr, cls_w, cls_b, q_w, q_b, k_w, k_b, ocr_mask_add):
+    """M4C._forward_output (m4c.py:275-283): classifier scores and OCR pointer scores written into one fp32 [B, T, V + N] buffer."""
+    B, T, H = dec.shape
+    N = ocr.shape[1]
+    V, HQ = cls_w.shape[0], q_w.shape[0]
+    d2, o2 = _rows(dec), _rows(ocr)
+    out = torch.empty(B * T, V + N, dtype=F32, device=d2.device)
+    nat.gemm_f32(d2, _w(cls_w), out, B * T, V, H, H, H, V + N, bias=_w(cls_b))
+    q = _linear(d2, q_w, q_b)
+    k = _linear(o2, k_w, k_b)
+    nat.ptr_scores_f32(q, k, ocr_mask_add.reshape(B, N).float().contiguous(), out[:, V:], V + N, B, T, N, HQ, 1.0 / math.sqrt(HQ))
+    return out.view(B, T, V + N)

@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from mmf_amd import functional as Fn
+from mmf_amd import fp32_path as F32P
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
 from mmf_amd.modules.encoders import FinetuneFasterRcnnFpnFc7
@@ -99,6 +100,13 @@ class PrevPredEmbeddings(nn.Module):
         assert ans_emb.dim() == 2
         batch_size, seq_length = prev_inds.shape
         ans_num = ans_emb.size(0)
+        if F32P.active():      # fp32-accurate forward (mmf_amd.fp32_inference()): the same operations on the fp32 kernels
+            ans_emb = self.ans_layer_norm(ans_emb.detach())
+            ocr_emb = self.ocr_layer_norm(ocr_emb)
+            raw_dec_emb = F32P.prev_pred_gather(ans_emb, ocr_emb, prev_inds)
+            zero = torch.zeros(batch_size, seq_length, ans_emb.size(-1), dtype=torch.float32, device=ocr_emb.device)
+            embeddings = F32P.add_pos_type(zero, prev_inds.ge(ans_num).long(), self.position_embeddings.weight, self.token_type_embeddings.weight)
+            return F32P.add(raw_dec_emb, self.emb_dropout(self.emb_layer_norm(embeddings)))
         if ans_emb.dtype != torch.bfloat16:
             ans_emb = Fn.ParamRowsFn.apply(ans_emb)                     # the classifier weight used as a lookup table (:268)
         ans_emb = self.ans_layer_norm(ans_emb)                          # :523
@@ -129,14 +137,18 @@ class MMT(nn.Module):
     def forward(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, fixed_ans_emb, prev_inds):
         dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds)                     # :399
         dec_mask = torch.zeros(dec_emb.size(0), dec_emb.size(1), dtype=torch.float32, device=dec_emb.device)   # :405-407
-        encoder_inputs = Fn.ConcatRowsFn.apply(txt_emb, obj_emb, ocr_emb, dec_emb)                 # :408
+        if F32P.active():
+            encoder_inputs = F32P.concat_rows(txt_emb, obj_emb, ocr_emb, dec_emb)
+        else:
+            encoder_inputs = Fn.ConcatRowsFn.apply(txt_emb, obj_emb, ocr_emb, dec_emb)             # :408
         attention_mask = torch.cat([txt_mask, obj_mask, ocr_mask, dec_mask], dim=1)                # :409
         txt_max_num, obj_max_num = txt_mask.size(-1), obj_mask.size(-1)
         ocr_max_num, dec_max_num = ocr_mask.size(-1), dec_mask.size(-1)
         # prefix LM (:424-440): all positions see the encoding steps; decoding steps see each other causally
         mask = Fn.PrefixLMMask(_additive(attention_mask), dec_max_num)
         mmt_seq_output = self.encoder(encoder_inputs, mask)[0]
-        mmt_txt_output, _, mmt_ocr_output, mmt_dec_output = Fn.SplitRowsFn.apply(
+        split = F32P.split_rows if F32P.active() else Fn.SplitRowsFn.apply
+        mmt_txt_output, _, mmt_ocr_output, mmt_dec_output = split(
             mmt_seq_output, (txt_max_num, obj_max_num, ocr_max_num, dec_max_num))                  # :446-449
         return {"mmt_seq_output": mmt_seq_output, "mmt_txt_output": mmt_txt_output, "mmt_ocr_output": mmt_ocr_output,
                 "mmt_dec_output": mmt_dec_output}
@@ -296,11 +308,12 @@ class M4C(BaseModel):
 
     def _forward_obj_encoding(self, sample_list, fwd_results):
         obj_fc6 = sample_list["image_feature_0"]
-        obj_fc7 = Fn.L2NormRowsFn.apply(self.obj_faster_rcnn_fc7(obj_fc6))                                   # :193-195
+        f32 = F32P.active()      # fp32-accurate forward (mmf_amd.fp32_inference()): the same operations on the fp32 kernels
+        obj_fc7 = (F32P.l2norm_rows if f32 else Fn.L2NormRowsFn.apply)(self.obj_faster_rcnn_fc7(obj_fc6))   # :193-195
         feat = self.obj_feat_layer_norm(self.linear_obj_feat_to_mmt_in(obj_fc7))
-        bbox = self.obj_bbox_layer_norm(Fn.SmallKLinearFn.apply(
+        bbox = self.obj_bbox_layer_norm((F32P.small_k_linear if f32 else Fn.SmallKLinearFn.apply)(
             sample_list["obj_bbox_coordinates"], self.linear_obj_bbox_to_mmt_in.weight, self.linear_obj_bbox_to_mmt_in.bias))
-        fwd_results["obj_mmt_in"] = self.obj_drop(Fn.AddFn.apply(feat, bbox))                                # :199-203
+        fwd_results["obj_mmt_in"] = self.obj_drop((F32P.add if f32 else Fn.AddFn.apply)(feat, bbox))        # :199-203
         obj_nums = sample_list["image_info_0"]["max_features"]
         fwd_results["obj_mask"] = _get_mask(obj_nums, obj_fc6.size(1))
 
@@ -320,15 +333,21 @@ class M4C(BaseModel):
         ocr_fc7 = self.ocr_faster_rcnn_fc7(ocr_fc6.contiguous())
         if self.remove_ocr_frcn or self.remove_ocr_semantics:
             ocr_fc7 = ocr_fc7.detach() * 0
-        ocr_feat = Fn.OcrFeatureConcatFn.apply(ocr_fasttext, ocr_phoc, ocr_fc7, order_dim)                  # :211-237
         ocr_bbox = sample_list["ocr_bbox_coordinates"]
         if self.remove_ocr_bbox:
             ocr_bbox = torch.zeros_like(ocr_bbox)
-        feat = self.ocr_feat_layer_norm(Fn.PaddedLinearFn.apply(
-            ocr_feat, self.linear_ocr_feat_to_mmt_in.weight, self.linear_ocr_feat_to_mmt_in.bias))
-        bbox = self.ocr_bbox_layer_norm(Fn.SmallKLinearFn.apply(
-            ocr_bbox, self.linear_ocr_bbox_to_mmt_in.weight, self.linear_ocr_bbox_to_mmt_in.bias))
-        fwd_results["ocr_mmt_in"] = self.ocr_drop(Fn.AddFn.apply(feat, bbox))                                # :243-247
+        if F32P.active():
+            ocr_feat, _ = F32P.ocr_feature_concat(ocr_fasttext, ocr_phoc, ocr_fc7, order_dim)
+            feat = self.ocr_feat_layer_norm(F32P.padded_linear(ocr_feat, self.linear_ocr_feat_to_mmt_in.weight, self.linear_ocr_feat_to_mmt_in.bias))
+            bbox = self.ocr_bbox_layer_norm(F32P.small_k_linear(ocr_bbox, self.linear_ocr_bbox_to_mmt_in.weight, self.linear_ocr_bbox_to_mmt_in.bias))
+            fwd_results["ocr_mmt_in"] = self.ocr_drop(F32P.add(feat, bbox))
+        else:
+            ocr_feat = Fn.OcrFeatureConcatFn.apply(ocr_fasttext, ocr_phoc, ocr_fc7, order_dim)              # :211-237
+            feat = self.ocr_feat_layer_norm(Fn.PaddedLinearFn.apply(
+                ocr_feat, self.linear_ocr_feat_to_mmt_in.weight, self.linear_ocr_feat_to_mmt_in.bias))
+            bbox = self.ocr_bbox_layer_norm(Fn.SmallKLinearFn.apply(
+                ocr_bbox, self.linear_ocr_bbox_to_mmt_in.weight, self.linear_ocr_bbox_to_mmt_in.bias))
+            fwd_results["ocr_mmt_in"] = self.ocr_drop(Fn.AddFn.apply(feat, bbox))                            # :243-247
         ocr_nums = sample_list["context_info_0"]["max_features"]
         fwd_results["ocr_mask"] = _get_mask(ocr_nums, ocr_fasttext.size(1))
 
@@ -344,6 +363,10 @@ class M4C(BaseModel):
 
     def _forward_output(self, sample_list, fwd_results):
         cls, ptr = self.classifier.module, self.ocr_ptr_net
+        if F32P.active():
+            fwd_results["scores"] = F32P.m4c_scores(fwd_results["mmt_dec_output"], fwd_results["mmt_ocr_output"], cls.weight, cls.bias, ptr.query.weight,
+                                                    ptr.query.bias, ptr.key.weight, ptr.key.bias, _additive(fwd_results["ocr_mask"]))
+            return
         fwd_results["scores"] = Fn.M4CScoresFn.apply(
             fwd_results["mmt_dec_output"], fwd_results["mmt_ocr_output"], cls.weight, cls.bias, ptr.query.weight, ptr.query.bias,
             ptr.key.weight, ptr.key.bias, _additive(fwd_results["ocr_mask"]), Fn.shadows.get(cls.weight),
@@ -354,7 +377,7 @@ class M4C(BaseModel):
             fwd_results["prev_inds"] = sample_list["train_prev_inds"].clone()
             self._forward_mmt(sample_list, fwd_results)
             self._forward_output(sample_list, fwd_results)
-        elif self.config.get("kv_cached_decode", True):
+        elif self.config.get("kv_cached_decode", True) and not F32P.active():
             self._decode_incremental(sample_list, fwd_results)
         else:
             # the reference's loop, kept for A/B tests: the whole multimodal transformer once per decoding step (:290-305)

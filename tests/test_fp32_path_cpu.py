@@ -123,3 +123,17 @@ def test_uniter_routes_to_the_fp32_kernels_only():
         out = model(SampleList(sample))
         assert _names(calls) <= FP32_CALLS | extra, _names(calls) - FP32_CALLS - extra
     assert out["scores"].dtype == torch.float32 and out["scores"].shape == tuple(z["scores"].shape)
+
+
+def test_m4c_routes_to_the_fp32_kernels_only():
+    """M4C inside fp32_inference(): teacher-forcing pass and the greedy decoding loop (the reference's re-encoding loop: the K|V-cached decoder
+    is a bf16-path optimisation) launch fp32 kernels only; the prefix-LM tail reaches the fp32 attention."""
+    z, case, cfg, sd, sample = G.load_m4c_case()
+    model = MU.build_m4c(cfg, sd, device="cpu")
+    model.eval()
+    extra = {"pad_rows_f32", "eltwise_f32", "rows_add_embed_f32", "l2norm_rows_f32", "gather_rows2_f32", "ptr_scores_f32", "bce_rowmask_fwd"}
+    with native_stub.installed() as calls, mmf_amd.fp32_inference():
+        out = model(SampleList(sample))
+        assert _names(calls) <= FP32_CALLS | extra, _names(calls) - FP32_CALLS - extra
+        assert {"l2norm_rows_f32", "gather_rows2_f32", "ptr_scores_f32"} <= _names(calls)
+    assert out["scores"].dtype == torch.float32 and out["scores"].shape == tuple(z["decode_scores"].shape)

@@ -402,3 +402,30 @@ def test_uniter_golden_within_the_fp32_bound():
     e_loss = abs(loss.sum().item() - float(z["loss"])) / abs(float(z["loss"]))
     _record("golden_uniter", scores_max_abs=e, sequence_output_max_abs=e_seq, loss_rel=e_loss)
     assert got["seq"].dtype == torch.float32 and e <= TOL_FP32 and e_seq <= TOL_FP32 and e_loss <= TOL_FP32, (e, e_seq, e_loss)
+
+
+def test_m4c_golden_within_the_fp32_bound():
+    """M4C (BASELINE configs[4]) on the fp32 kernels: the teacher-forcing pass (prefix-LM attention tail, two-source gather, pointer scores)
+    against the reference fixture's scores, multimodal-transformer output and loss; the greedy decoding loop against its decoded scores and
+    argmax sequence."""
+    from tests.model_utils import build_m4c
+    z, case, cfg, sd, sample = G.load_m4c_case()
+    model = build_m4c(cfg, sd)
+    model.eval()
+    model.training = True          # teacher forcing with every dropout off (tests/test_m4c_gpu.py::_teacher_forcing)
+    got = {}
+    hook = model.mmt.register_forward_hook(lambda m, i, o: got.update(seq=o["mmt_seq_output"]))
+    with mmf_amd.fp32_inference():
+        out = model(SampleList(sample_to(sample, "cuda")))
+    hook.remove()
+    e = float(np.abs(out["scores"].cpu().numpy() - z["scores"]).max())
+    e_seq = float(np.abs(got["seq"].cpu().numpy() - z["mmt_seq_output"]).max())
+    (key, loss), = out["losses"].items()
+    e_loss = abs(loss.sum().item() - float(z["loss"])) / abs(float(z["loss"]))
+    model.training = False
+    with mmf_amd.fp32_inference():
+        dec = model(SampleList(sample_to(sample, "cuda")))["scores"].cpu()
+    e_dec = float(np.abs(dec.numpy() - z["decode_scores"]).max())
+    np.testing.assert_array_equal(dec.argmax(-1).numpy(), z["decode_argmax"])
+    _record("golden_m4c", scores_max_abs=e, mmt_seq_output_max_abs=e_seq, loss_rel=e_loss, decode_scores_max_abs=e_dec)
+    assert got["seq"].dtype == torch.float32 and max(e, e_seq, e_loss, e_dec) <= TOL_FP32, (e, e_seq, e_loss, e_dec)

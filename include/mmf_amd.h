@@ -566,6 +566,17 @@ int mmf_gather_rows2_f32(const float* a, int64_t rows_a, const float* b, int64_t
 int mmf_ptr_scores_f32(const float* q, const float* k, const float* mask_add, float* out, int ldo, int B, int T, int N, int HQ, float scale,
                        void* stream);
 
+/* ViLBERT's masked-region NCE loss (`visual_target: 2`, mmf/models/vilbert.py:1158-1227): pred fp32 [M, N] = the image-prediction head's output
+ * for all M = B * R regions, target fp32 [M, N] the region features, neg int64 [M, K] flat indices (into the M regions) of each region's K
+ * negatives, label int64 [M] (1 = masked region).  score[r][j] = <sample_j, pred[r]> with sample_0 = target[r], sample_j = target[neg[r][j-1]];
+ * loss = mean over the labelled regions of (logsumexp_j score - score_0) (CrossEntropyLoss against class 0); NaN when nothing is labelled.
+ * fwd saves scores [M, K + 1] and lse [M]; bwd writes g / count * (sum_j softmax_j sample_j - sample_0) as the zero-padded bf16 operand
+ * (row stride ldd, a multiple of 8) of the decoder's gradient GEMMs, zeros on unlabelled rows.  N % 4 == 0, K <= 1024. */
+int mmf_nce_fwd(const float* pred, const float* target, const int64_t* neg, const int64_t* label, float* scores, float* lse, float* rowloss, float* loss,
+                float* count, int M, int N, int K, void* stream);
+int mmf_nce_bwd(const float* target, const int64_t* neg, const int64_t* label, const float* scores, const float* lse, const float* count, const float* gloss,
+                void* dpred, int ldd, int M, int N, int K, void* stream);
+
 /* ---- layout probes (tests only): dump what the hardware does so tests can pin the assumptions -- */
 int mmf_probe_mfma16(const void* a, const void* b, float* d, void* stream);   /* 64 lanes x 8 bf16 each, out 64x4 */
 int mmf_probe_mfma32(const void* a, const void* b, float* d, void* stream);   /* out 64x16 */

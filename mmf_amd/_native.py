@@ -697,6 +697,20 @@ def dropout_f32(x, y, drop):
     _check(lib().mmf_dropout_f32(_p(x), _p(y), C.c_long(x.numel()), key, thr, C.c_float(scale), seed, _stream()), "mmf_dropout_f32")
 
 
+def nce_fwd(pred, target, neg, label, scores, lse, rowloss, loss, count, M, N, K):
+    for t, n in ((pred, "pred"), (target, "target"), (scores, "scores"), (lse, "lse"), (rowloss, "rowloss"), (loss, "loss"), (count, "count")):
+        _req(t, torch.float32, n)
+    _req(neg, torch.int64, "neg"); _req(label, torch.int64, "label")
+    _check(lib().mmf_nce_fwd(_p(pred), _p(target), _p(neg), _p(label), _p(scores), _p(lse), _p(rowloss), _p(loss), _p(count), M, N, K, _stream()), "mmf_nce_fwd")
+
+
+def nce_bwd(target, neg, label, scores, lse, count, gloss, dpred, ldd, M, N, K):
+    for t, n in ((target, "target"), (scores, "scores"), (lse, "lse"), (count, "count"), (gloss, "gloss")):
+        _req(t, torch.float32, n)
+    _req(neg, torch.int64, "neg"); _req(label, torch.int64, "label"); _req(dpred, torch.bfloat16, "dpred")
+    _check(lib().mmf_nce_bwd(_p(target), _p(neg), _p(label), _p(scores), _p(lse), _p(count), _p(gloss), _p(dpred), ldd, M, N, K, _stream()), "mmf_nce_bwd")
+
+
 def vocab_cross_entropy_f32_bwd(logits, labels, lse, count, gloss, dlogits, ldd, R, Cn, ignore_index=-1):
     for t, n in ((logits, "logits"), (lse, "lse"), (count, "count"), (gloss, "gloss"), (dlogits, "dlogits")):
         _req(t, torch.float32, n)

@@ -100,6 +100,98 @@ __global__ __launch_bounds__(256) void gate_sigmoid_bwd_kernel(const float* __re
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------
+// ViLBERT masked-region NCE loss (`visual_target: 2`, mmf/models/vilbert.py:1158-1227): for every region r with image_label == 1 the
+// prediction pred[r] is scored against its own target feature and K negative target features picked by flat indices into the [B * R]
+// regions, score[r][j] = <sample_j, pred[r]> (torch.bmm, :1221), loss = CrossEntropyLoss(score, class 0) = mean over those regions of
+// (logsumexp_j score - score_0).  One workgroup per region: a wave per sample for the dot products (rows of N fp32, 16-byte loads),
+// the K + 1 scores stay in LDS for the log-sum-exp; backward: d pred[r] = g / count * (sum_j softmax_j sample_j - sample_0), written as
+// the zero-padded bf16 operand of the image-prediction decoder's gradient GEMMs (rows without label: zeros).
+// ------------------------------------------------------------------------------------------------
+constexpr int NCE_MAXK = 1024;
+DEVI f32x4 nce_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+DEVI void nce_store4(bf16* p, f32x4 v) { p[0] = (bf16)v[0]; p[1] = (bf16)v[1]; p[2] = (bf16)v[2]; p[3] = (bf16)v[3]; }
+__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const int64_t* __restrict__ neg,
+                                                       const int64_t* __restrict__ label, float* __restrict__ scores, float* __restrict__ lse,
+                                                       float* __restrict__ rowloss, int M, int N, int K) {
+    __shared__ float sc[NCE_MAXK + 1];
+    __shared__ float red[4];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (label[r] != 1) { if (threadIdx.x == 0) { rowloss[r] = 0.f; lse[r] = 0.f; } return; }      // (uniform per workgroup)
+    const float* p = pred + (size_t)r * N;
+    for (int j = wave; j <= K; j += 4) {
+        long src = j == 0 ? r : neg[(size_t)r * K + (j - 1)];
+        src = src < 0 ? 0 : (src >= M ? M - 1 : src);
+        const float* t = target + (size_t)src * N;
+        float s = 0.f;
+        for (int c = lane * 4; c < N; c += 256) {
+            const f32x4 a = nce_load4(p + c), b = nce_load4(t + c);
+            s += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+        }
+        s = wave_sum(s);
+        if (lane == 0) { sc[j] = s; scores[(size_t)r * (K + 1) + j] = s; }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j <= K; j += 256) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float e = 0.f;
+    for (int j = threadIdx.x; j <= K; j += 256) e += expf(sc[j] - m);
+    e = wave_sum(e);
+    if (lane == 0) red[wave] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+        lse[r] = l;
+        rowloss[r] = l - sc[0];
+    }
+}
+__global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restrict__ rowloss, const int64_t* __restrict__ label, float* __restrict__ loss,
+                                                            float* __restrict__ count, int M) {
+    __shared__ float rs[4], rc[4];
+    float s = 0.f, c = 0.f;
+    for (int r = threadIdx.x; r < M; r += 256) if (label[r] == 1) { s += rowloss[r]; c += 1.f; }
+    s = wave_sum(s); c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float cs = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+        count[0] = cs;
+        loss[0] = ((rs[0] + rs[1]) + (rs[2] + rs[3])) / cs;        // no labelled region: 0 / 0 = NaN, like CrossEntropyLoss over nothing
+    }
+}
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ target, const int64_t* __restrict__ neg, const int64_t* __restrict__ label,
+                                                       const float* __restrict__ scores, const float* __restrict__ lse, const float* __restrict__ count,
+                                                       const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int M, int N, int K) {
+    __shared__ float w[NCE_MAXK + 1];
+    __shared__ long srcs[NCE_MAXK + 1];
+    const int r = blockIdx.x;
+    bf16* dr = d + (size_t)r * ldd;
+    if (label[r] != 1) {
+        for (int c = threadIdx.x; c < ldd; c += 256) dr[c] = (bf16)0.f;
+        return;
+    }
+    const float g = gloss[0] / count[0], l = lse[r];
+    for (int j = threadIdx.x; j <= K; j += 256) {
+        w[j] = g * (expf(scores[(size_t)r * (K + 1) + j] - l) - (j == 0 ? 1.f : 0.f));
+        long src = j == 0 ? r : neg[(size_t)r * K + (j - 1)];
+        srcs[j] = src < 0 ? 0 : (src >= M ? M - 1 : src);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < ldd; c += 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (c < N) {
+            for (int j = 0; j <= K; ++j) acc += w[j] * nce_load4(target + (size_t)srcs[j] * N + c);
+        }
+        nce_store4(dr + c, acc);
+    }
+}
+
 extern "C" {
 
 int mmf_gate_sigmoid_fwd(const float* z, float* gate, int ldg, int col0, int B, int C, void* stream) {
@@ -145,6 +237,24 @@ int mmf_rowgroup_scale_bwd(void* dy, const void* y, int ld, const float* gate, f
     MMF_CHECK_ARG((C % 8) == 0 && (ld % 8) == 0 && C <= ld, "rowgroup_scale_bwd: C and ld must be multiples of 8 with C <= ld");
     hipLaunchKernelGGL(rowgroup_scale_bwd_kernel, dim3((C / 8 + 127) / 128, groups), dim3(128), 0, (hipStream_t)stream, (bf16*)dy,
                        (const bf16*)y, ld, gate, dgate, rows_per_group, C);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_nce_fwd(const float* pred, const float* target, const int64_t* neg, const int64_t* label, float* scores, float* lse, float* rowloss, float* loss,
+                float* count, int M, int N, int K, void* stream) {
+    MMF_CHECK_ARG(pred && target && neg && label && scores && lse && rowloss && loss && count, "nce_fwd: null operand");
+    MMF_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && K <= NCE_MAXK, "nce_fwd: N % 4 == 0, 1 <= K <= 1024");
+    hipLaunchKernelGGL(nce_fwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, pred, target, neg, label, scores, lse, rowloss, M, N, K);
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rowloss, label, loss, count, M);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_nce_bwd(const float* target, const int64_t* neg, const int64_t* label, const float* scores, const float* lse, const float* count, const float* gloss,
+                void* dpred, int ldd, int M, int N, int K, void* stream) {
+    MMF_CHECK_ARG(target && neg && label && scores && lse && count && gloss && dpred, "nce_bwd: null operand");
+    MMF_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && K <= NCE_MAXK && ldd >= N && (ldd % 8) == 0, "nce_bwd: bad shape (ldd: a multiple of 8 covering N)");
+    hipLaunchKernelGGL(nce_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, target, neg, label, scores, lse, count, gloss, (bf16*)dpred, ldd, M, N, K);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -1287,6 +1287,50 @@ class MaskedRegionRegressionFn(torch.autograd.Function):
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
 
 
+class MaskedRegionNCEFn(torch.autograd.Function):
+    """The decoder + loss of ViLBERT's masked-region NCE form (`visual_target: 2`, mmf/models/vilbert.py:1158-1227): prediction_scores_v =
+    h W^T + b, each masked region's prediction scored against its own target feature and K sampled negatives (the batched product of :1221),
+    CrossEntropyLoss against class 0.  `neg_index` int64 [B, R, K]: flat indices into the B * R regions (:1176, :1200).  Returns (loss, scores
+    fp32); the loss kernel's backward writes the zero-padded bf16 operand of the decoder's gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, target, row_label, neg_index):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        N = weight.shape[0]
+        dev = x2.device
+        pred = torch.empty(M, N, dtype=F32, device=dev)
+        nat.gemm(x2, w16, pred, M, N, K, K, K, N, bias=bias.detach())
+        tgt = target.reshape(M, N)
+        tgt = (tgt if tgt.dtype == F32 else tgt.float()).contiguous()
+        lab = row_label.reshape(M).contiguous()
+        if lab.dtype != torch.int64:
+            lab = lab.long()
+        neg = neg_index.reshape(M, -1).contiguous()
+        if neg.dtype != torch.int64:
+            neg = neg.long()
+        NK = neg.shape[1]
+        scores = torch.empty(M, NK + 1, dtype=F32, device=dev)
+        lse = torch.empty(M, dtype=F32, device=dev); rowloss = torch.empty(M, dtype=F32, device=dev)
+        loss = torch.empty(1, dtype=F32, device=dev); count = torch.empty(1, dtype=F32, device=dev)
+        nat.nce_fwd(pred, tgt, neg, lab, scores, lse, rowloss, loss, count, M, N, NK)
+        ctx.save_for_backward(x2, w16, tgt, neg, lab, scores, lse, count)
+        ctx.meta = (M, N, K, NK, x.shape)
+        out = pred.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(out)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, gloss, _gscores):
+        x2, w16, tgt, neg, lab, scores, lse, count = ctx.saved_tensors
+        M, N, K, NK, xshape = ctx.meta
+        ldd = _pad8(N)
+        d = torch.empty(M, ldd, dtype=BF16, device=x2.device)
+        nat.nce_bwd(tgt, neg, lab, scores, lse, count, gloss.float().reshape(1).contiguous(), d, ldd, M, N, NK)
+        dx, dw, db = _linear_bwd(d, ldd, x2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
+        return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None, None
+
+
 class TiedRegressionMSEFn(torch.autograd.Function):
     """MRFR's last two lines (mmf/models/transformers/heads/mrfr.py:85-90): prediction = h W + b with the TIED image-embedding
     weight W [hidden, img_dim] (UNITERImageEmbeddings.img_linear.weight applied transposed), loss = mean squared error against the targets.

@@ -454,10 +454,9 @@ class ViLBERTForPretraining(nn.Module):
         self.vocab_size = self.config.vocab_size
         self.visual_target = config.visual_target
         self.num_negative = config.num_negative
-        if self.visual_target not in (0, 1):
-            raise NotImplementedError("visual_target=%r: the KL masked-region classification (visual_target: 0, the reference default) and "
-                                      "the masked-region regression (visual_target: 1) are built (vilbert.py:1070-1075); the NCE form "
-                                      "with random negatives (visual_target: 2, :1158-1216) is not" % (self.visual_target,))
+        if self.visual_target not in (0, 1, 2):
+            raise NotImplementedError("visual_target=%r: 0 (KL masked-region classification, the reference default), 1 (masked-region regression) "
+                                      "and 2 (NCE with sampled negatives) are the forms of vilbert.py:1070-1075" % (self.visual_target,))
         self.init_weights()
 
     def init_weights(self):
@@ -469,6 +468,22 @@ class ViLBERTForPretraining(nn.Module):
         """vilbert.py:1088-1095."""
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
 
+    def negative_index(self, batch_size, num_regions, like):
+        """The sampled negatives of `visual_target: 2` (vilbert.py:1158-1203): flat region indices [B, R, num_negative], 70 % drawn from the
+        OTHER samples of the batch, 30 % from the other regions of the same image — the same sequence of `random_` draws on tensors of the
+        same shapes as the reference (index massaging on the host side of the boundary, as there)."""
+        n_across, n_inside = int(self.num_negative * 0.7), int(self.num_negative * 0.3)
+        B, R = batch_size, num_regions
+        assert B != 0
+        row_across = torch.ones(B, R, n_across, dtype=like.dtype, device=like.device).random_(0, B - 1)
+        col_across = torch.ones(B, R, n_across, dtype=like.dtype, device=like.device).random_(0, R)
+        own = torch.arange(B, device=like.device, dtype=like.dtype).view(B, 1, 1)
+        row_across = torch.where(row_across == own, torch.full_like(row_across, B - 1), row_across)      # (row B - 1 never draws itself: values < B - 1)
+        col_inside = torch.ones(B, R, n_inside, dtype=like.dtype, device=like.device).random_(0, R - 1)
+        region = torch.arange(R, device=like.device, dtype=like.dtype).view(1, R, 1)
+        col_inside = torch.where((col_inside == region) & (region < R - 1), torch.full_like(col_inside, R - 1), col_inside)
+        return torch.cat((row_across * R + col_across, own * R + col_inside), dim=2)
+
     def forward(self, input_ids, image_feature, image_location, token_type_ids=None, attention_mask=None,
                 image_attention_mask=None, masked_lm_labels=None, image_label=None, image_target=None,
                 output_all_attention_masks=False):
@@ -479,7 +494,12 @@ class ViLBERTForPretraining(nn.Module):
         if image_label is not None and image_target is not None:
             head = self.cls.imagePredictions
             hidden_v = head.transform(sequence_output_v)
-            if self.visual_target == 1:          # nn.MSELoss(reduction="none") over the masked regions / max(their element count, 1), :1139-1148
+            if self.visual_target == 2:          # NCE against sampled negatives, CrossEntropyLoss on class 0, :1158-1227
+                B, R = image_label.shape[0], image_label.shape[1]
+                neg = self.negative_index(B, R, input_ids)
+                img_loss, _ = Fn.MaskedRegionNCEFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
+                                                         image_target, image_label, neg)
+            elif self.visual_target == 1:        # nn.MSELoss(reduction="none") over the masked regions / max(their element count, 1), :1139-1148
                 img_loss, _ = Fn.MaskedRegionRegressionFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
                                                                 image_target, image_label)
             else:

@@ -310,7 +310,17 @@ def vilbert_pretraining_forward(sd, cfg, sample_list, train=False):
     image_label = sample_list["image_labels"]
     image_target = torch.as_tensor(sample_list["image_info_0"]["cls_prob"], dtype=torch.float32)                    # :1402-1406
     picked = torch.eq(image_label, 1)
-    if cfg.get("visual_target", 0) == 1:                                                                            # :1139-1148
+    if cfg.get("visual_target", 0) == 2:                                                                            # :1158-1227
+        # `_negative_index` [B, R, K]: the flat region indices the sampling of :1158-1203 produced (test infrastructure hands them in)
+        neg = torch.as_tensor(sample_list["_negative_index"]).long()
+        B, R, Dv = scores_v.shape
+        predict_v = scores_v[picked]                                           # :1205
+        neg_v = neg[picked]                                                    # :1206
+        flat_target = image_target.reshape(B * R, -1)                          # :1208
+        sample_v = torch.cat((image_target[picked].unsqueeze(1), flat_target[neg_v]), dim=1)     # :1210-1212
+        score = torch.bmm(sample_v, predict_v.unsqueeze(2)).squeeze(2)         # :1215
+        masked_img_loss = F.cross_entropy(score, torch.zeros(score.size(0), dtype=torch.long))  # :1216-1221
+    elif cfg.get("visual_target", 0) == 1:                                                                          # :1139-1148
         img_loss = F.mse_loss(scores_v, image_target, reduction="none")
         masked_img_loss = torch.sum(img_loss * picked.unsqueeze(2).float()) / max(torch.sum(picked.unsqueeze(2).expand_as(img_loss)), 1)
     else:

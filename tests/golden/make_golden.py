@@ -650,7 +650,7 @@ def make_vilbert_pretraining(visual_target=0):
     from transformers import BertConfig
     M = refshim.ref_import("mmf.models.vilbert")
     M.replace_with_jit = lambda: None
-    c = dict(VILBERT_CASES["vilbert_small"], seed=91, v_target_size=53)
+    c = dict(VILBERT_CASES["vilbert_small"], seed=91, v_target_size=52 if visual_target == 2 else 53)
     torch.manual_seed(c["seed"])
     cfg = vilbert_reference_config(c)
     cfg["training_head_type"] = "pretraining"
@@ -666,9 +666,10 @@ def make_vilbert_pretraining(visual_target=0):
             self.cls = M.BertPreTrainingHeads(bcfg)
             self.vocab_size = c["vocab_size"]
             self.visual_target = visual_target
-            self.num_negative = 128
+            self.num_negative = 10 if visual_target == 2 else 128
             self.loss_fct = nn.CrossEntropyLoss(ignore_index=-1)
-            self.vis_criterion = nn.KLDivLoss(reduction="none") if visual_target == 0 else nn.MSELoss(reduction="none")
+            self.vis_criterion = (nn.KLDivLoss(reduction="none") if visual_target == 0 else nn.MSELoss(reduction="none") if visual_target == 1
+                                  else nn.CrossEntropyLoss())          # vilbert.py:1070-1075
             # tie_weights (:1088-1095) + transformers<=4.10 BertLMPredictionHead (decoder.bias IS predictions.bias)
             self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
             self.cls.predictions.decoder.bias = self.cls.predictions.bias
@@ -719,12 +720,40 @@ def make_vilbert_pretraining(visual_target=0):
                     image_info_0=SampleList(max_features=torch.from_numpy(max_features), bbox=torch.from_numpy(bbox), cls_prob=cls_prob),
                     image_labels=torch.from_numpy(image_labels), lm_label_ids=torch.from_numpy(lm), dataset_name="coco",
                     dataset_type="train")
-    out = ref(sl)
+    draws = []
+    if visual_target == 2:
+        # `visual_target: 2` samples its negatives with Tensor.random_ (vilbert.py:1158-1203): the draws are made deterministic and recorded,
+        # so that the oracle and the HIP-backed model can be handed the same negatives
+        cls_prob = (2.0 * detweights.uniform(B * R * c["v_target_size"], seed + 306) - 1.0).astype(np.float32).reshape(B, R, -1)
+        sl["image_info_0"]["cls_prob"] = cls_prob
+        real_random_ = torch.Tensor.random_
+
+        def fake_random_(self, lo=0, hi=None):
+            vals = np.minimum((detweights.uniform(self.numel(), seed + 900 + len(draws)) * (hi - lo)).astype(np.int64) + lo, hi - 1)
+            draws.append(vals.reshape(tuple(self.shape)))
+            return self.copy_(torch.from_numpy(draws[-1]))
+        torch.Tensor.random_ = fake_random_
+    try:
+        out = ref(sl)
+    finally:
+        if visual_target == 2:
+            torch.Tensor.random_ = real_random_
     losses = out["losses"]
     total = sum(v.sum() for v in losses.values())
     total.backward()
     rec = {"in_input_ids": ids, "in_input_mask": mask, "in_segment_ids": seg, "in_image_feature_0": feats, "in_bbox": bbox,
            "in_max_features": max_features, "in_lm_label_ids": lm, "in_cls_prob": cls_prob, "in_image_labels": image_labels}
+    if visual_target == 2:
+        assert len(draws) == 3, [d.shape for d in draws]
+        for i, dr in enumerate(draws):
+            rec["in_draw%d" % i] = dr
+        # the flat negative indices those draws give (own restatement of :1158-1203; the oracle test checks it reproduces the recorded loss)
+        ra, ca, ci = (d.copy() for d in draws)
+        for i in range(B - 1):
+            ra[i][ra[i] == i] = B - 1
+        for i in range(R - 1):
+            ci[:, i, :][ci[:, i, :] == i] = R - 1
+        rec["in_negative_index"] = np.concatenate([ra * R + ca, np.arange(B).reshape(B, 1, 1) * R + ci], axis=2).astype(np.int64)
     rec["loss_keys"] = np.array(list(losses.keys()))
     rec["loss_values"] = np.array([float(v.sum()) for v in losses.values()], dtype=np.float64)
     rec["loss_shapes"] = np.array([",".join(map(str, v.shape)) for v in losses.values()])
@@ -1362,6 +1391,8 @@ if __name__ == "__main__":
         make_mmft()
     if "vilbert" in which:
         make_vilbert()
+    if "vilbert_pretraining_vt2" in which:
+        make_vilbert_pretraining(visual_target=2)
     if "vilbert_pretraining" in which:
         make_vilbert_pretraining()
         make_vilbert_pretraining(visual_target=1)

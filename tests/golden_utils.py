@@ -216,7 +216,8 @@ def load_pretraining_case():
 
 def load_vilbert_pretraining_case(visual_target=0):
     """`vilbert_pretraining`: ViLBERT with the pretraining heads (masked LM + masked region classification, visual_target 0);
-    `visual_target=1`: `vilbert_pretraining_vt1`, the masked-region REGRESSION form (nn.MSELoss, vilbert.py:1139-1148)."""
+    `visual_target=1`: `vilbert_pretraining_vt1`, the masked-region REGRESSION form (nn.MSELoss, vilbert.py:1139-1148); `visual_target=2`:
+    `vilbert_pretraining_vt2`, the NCE form with sampled negatives (:1158-1227)."""
     z = np.load(os.path.join(GOLDEN_DIR, "vilbert_pretraining.npz" if visual_target == 0 else "vilbert_pretraining_vt%d.npz" % visual_target),
                 allow_pickle=False)
     case = ast.literal_eval(str(z["case"]))
@@ -242,7 +243,32 @@ def load_vilbert_pretraining_case(visual_target=0):
         "image_labels": torch.from_numpy(z["in_image_labels"]), "lm_label_ids": torch.from_numpy(z["in_lm_label_ids"]),
         "dataset_name": "coco", "dataset_type": "train",
     }
+    if visual_target == 2:      # NCE: the reference ran with `num_negative: 10`; its (recorded, deterministic) draws give these flat indices
+        cfg["num_negative"] = 10
+        sample["_negative_index"] = torch.from_numpy(z["in_negative_index"])
     return z, case, cfg, sd, sample
+
+
+class recorded_random:
+    """Context manager: `Tensor.random_` returns the draws recorded in a `visual_target: 2` fixture, in order (the reference ran with the
+    same replacement, tests/golden/make_golden.py::make_vilbert_pretraining)."""
+
+    def __init__(self, z):
+        self.draws = [z["in_draw%d" % i] for i in range(3)]
+
+    def __enter__(self):
+        self.real = torch.Tensor.random_
+        it = iter(self.draws)
+
+        def fake(t, lo=0, hi=None):
+            d = next(it)
+            assert tuple(t.shape) == d.shape, (tuple(t.shape), d.shape)
+            return t.copy_(torch.from_numpy(d).to(t.device))
+        torch.Tensor.random_ = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.random_ = self.real
 
 
 def load_transformer_heads_case():

@@ -115,6 +115,31 @@ def test_training_step_plumbing(name):
             assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == torch.float32, n
 
 
+def test_vilbert_nce_negative_sampling_replays_the_reference_draws():
+    """`visual_target: 2` (vilbert.py:1158-1203): with Tensor.random_ replaying the draws the reference run recorded, the model's sampling
+    gives the same flat negative indices (70 % from other samples, 30 % from other regions of the same image), and the step runs through
+    the NCE node with them."""
+    z, case, cfg, sd, sample = G.load_vilbert_pretraining_case(2)
+    model = MU.build_vilbert_pretraining(cfg, sd, device="cpu", visual_target=2, num_negative=cfg["num_negative"])
+    B, R = z["in_image_labels"].shape
+    with G.recorded_random(z):
+        neg = model.model.negative_index(B, R, sample["input_ids"])
+    assert torch.equal(neg, torch.from_numpy(z["in_negative_index"]))
+    own = torch.arange(B).view(B, 1, 1)
+    n_across = int(cfg["num_negative"] * 0.7)
+    assert bool((neg[..., :n_across] // R != own).all()) and bool((neg[..., n_across:] // R == own).all())
+    assert bool((neg[..., n_across:] % R != torch.arange(R).view(1, R, 1)).all())
+    model.train()
+    batch = {k: v for k, v in sample.items() if not k.startswith("_")}
+    with native_stub.installed() as calls, G.recorded_random(z):
+        out = model(SampleList(batch))
+        sum(v.sum() for v in out["losses"].values()).backward()
+    names = {c[0] for c in calls}
+    assert "nce_fwd" in names and "nce_bwd" in names
+    head = model.model.cls.imagePredictions.decoder
+    assert head.weight.grad is not None and head.weight.grad.shape == head.weight.shape
+
+
 def _step(model, sample):
     model.train()
     with native_stub.installed():

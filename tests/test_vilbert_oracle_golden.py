@@ -65,7 +65,7 @@ def test_vilbert_oracle_nlvr2_matches_reference():
 
 
 
-@pytest.mark.parametrize("visual_target", [0, 1])
+@pytest.mark.parametrize("visual_target", [0, 1, 2])        # 2: NCE with the recorded negatives (vilbert.py:1158-1227)
 def test_vilbert_pretraining_oracle_matches_reference(visual_target):
     """ViLBERTForPretraining (vilbert.py:1054-1240; visual_target 0: masked-region KL, 1: masked-region regression, round 3): both losses and
     every gradient against the reference's own run."""

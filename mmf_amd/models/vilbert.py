@@ -280,8 +280,10 @@ class BertEncoder(nn.Module):
         for flag in ("fast_mode", "in_batch_pairs"):
             if getattr(config, flag, False):
                 raise NotImplementedError("ViLBERT %s (vilbert.py:684-735) is not built" % flag)
-        if getattr(config, "fixed_t_layer", 0) or getattr(config, "fixed_v_layer", 0):
-            raise NotImplementedError("fixed_t_layer / fixed_v_layer > 0 (no-grad prefix layers, vilbert.py:625-666) are not built")
+        # vilbert.py:625-666, as the reference BEHAVES: its loop runs `forward_no_grad` on the layer at t_start and sets t_start = fixed_t_layer
+        # in that same iteration, so only the first such layer executes (without gradient) and layers t_start + 1 .. fixed_t_layer - 1 never run
+        self.fixed_t_layer = int(getattr(config, "fixed_t_layer", 0) or 0)
+        self.fixed_v_layer = int(getattr(config, "fixed_v_layer", 0) or 0)
         self.with_coattention = config.with_coattention
         self.v_biattention_id = list(config.v_biattention_id)
         self.t_biattention_id = list(config.t_biattention_id)
@@ -299,6 +301,20 @@ class BertEncoder(nn.Module):
         all_t, all_v = [], []
         dynamic = any(l.attention.self.dynamic_attention for l in self.v_layer)     # then a visual layer reads the text stream: no overlap
         for count, (v_end, t_end) in enumerate(zip(self.v_biattention_id, self.t_biattention_id)):
+            assert self.fixed_t_layer <= t_end and self.fixed_v_layer <= v_end            # vilbert.py:622-623
+            if t_start < self.fixed_t_layer:
+                with torch.no_grad():
+                    txt_embedding = self.layer[t_start](txt_embedding, txt_attention_mask)[0]
+                t_start = self.fixed_t_layer
+            if v_start < self.fixed_v_layer:
+                # (reference order: after this block's text layers; with dynamic_attention the gate reads the text stream as it is then)
+                if dynamic:
+                    for idx in range(t_start, t_end):
+                        txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
+                    t_start = t_end
+                with torch.no_grad():
+                    image_embedding = self.v_layer[v_start](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
+                v_start = self.fixed_v_layer
             streams = _fork(image_embedding) if (not dynamic and v_end > v_start and t_end > t_start) else None
             if streams is not None:
                 with torch.cuda.stream(streams[1]):

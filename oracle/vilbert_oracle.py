@@ -188,7 +188,9 @@ def connection_layer(sd, cfg, i, img, img_mask, txt, txt_mask, train):
 
 
 def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False, txt_mask2=None):
-    """BertEncoder.forward :590-796 with fixed_t_layer = fixed_v_layer = 0, with_coattention, no batch expansion."""
+    """BertEncoder.forward :590-796, with_coattention, no batch expansion.  `fixed_t_layer` / `fixed_v_layer` (:625-666): the reference runs
+    `forward_no_grad` on the layer at t_start and sets t_start = fixed_t_layer inside that very loop iteration, so only the FIRST such layer
+    executes (detached) and layers t_start + 1 .. fixed_t_layer - 1 are never run; restated as it behaves."""
     td = cfg["hidden_dropout_prob"] if train else 0.0
     tad = cfg["attention_probs_dropout_prob"] if train else 0.0
     vd = cfg["v_hidden_dropout_prob"] if train else 0.0
@@ -200,9 +202,19 @@ def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False, txt_mask2=None):
     v_layer = lambda i, x, t: stream_layer(sd, "bert.encoder.v_layer.%d." % i, cfg["v_num_attention_heads"], x, img_mask, vd, vad,
                                            txt=t if dyn else None, txt_mask2=txt_mask2)
     v_start = t_start = 0
+    fixed_t, fixed_v = int(cfg.get("fixed_t_layer", 0)), int(cfg.get("fixed_v_layer", 0))
     for count, (v_end, t_end) in enumerate(zip(cfg["v_biattention_id"], cfg["t_biattention_id"])):
+        assert fixed_t <= t_end and fixed_v <= v_end                                  # :622-623
+        if t_start < fixed_t:                                                         # :626-634
+            with torch.no_grad():
+                txt = t_layer(t_start, txt)
+            t_start = fixed_t
         for i in range(t_start, t_end):
             txt = t_layer(i, txt)
+        if v_start < fixed_v:                                                         # :646-661
+            with torch.no_grad():
+                img = v_layer(v_start, img, txt)
+            v_start = fixed_v
         for i in range(v_start, v_end):
             img = v_layer(i, img, txt)
         img, txt = connection_layer(sd, cfg, count, img, img_mask, txt, txt_mask, train)

@@ -484,6 +484,13 @@ VILBERT_CASES = {
                         bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
                         v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=211, max_position_embeddings=40,
                         v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=42, dynamic_attention=True),
+    # `fixed_t_layer: 2, fixed_v_layer: 1` (vilbert.py:625-666): the first text / visual layer runs without gradient; the reference's loop
+    # sets t_start = fixed_t_layer at that first layer, so text layer 1 is SKIPPED (never executed) — recorded as the reference behaves
+    "vilbert_fixed": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=4,
+                          v_hidden_size=256, v_num_attention_heads=2, v_intermediate_size=192, v_num_hidden_layers=3,
+                          bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
+                          v_biattention_id=[1, 2], t_biattention_id=[2, 3], vocab_size=211, max_position_embeddings=40,
+                          v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=44, fixed_t_layer=2, fixed_v_layer=1),
 }
 
 
@@ -503,11 +510,12 @@ def vilbert_reference_config(c):
         v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.1, v_initializer_range=0.02,
         v_biattention_id=c["v_biattention_id"], t_biattention_id=c["t_biattention_id"], pooling_method="mul", fusion_method="mul",
         fast_mode=False, with_coattention=True, dynamic_attention=bool(c.get("dynamic_attention", False)), in_batch_pairs=False, task_specific_tokens=False,
-        fixed_v_layer=0, fixed_t_layer=0, visualization=False, visual_target=0, objective=0, num_negative=128, model="vilbert",
+        fixed_v_layer=int(c.get("fixed_v_layer", 0)), fixed_t_layer=int(c.get("fixed_t_layer", 0)), visualization=False, visual_target=0, objective=0,
+        num_negative=128, model="vilbert",
         num_labels=c["num_labels"], losses=[dict(type="logit_bce")]))
 
 
-def make_vilbert():
+def make_vilbert(only=None):
     """ViLBERT (two streams + co-attention, classification head) through the reference's own ViLBERT.forward /
     get_image_and_text_features, ViLBERTForClassification.forward, ViLBERTBase, BertEncoder, BertConnectionLayer,
     BertBiAttention, BertImageLayer, ... (mmf/models/vilbert.py).  Only `ViLBERTBase.from_pretrained` (network) is replaced
@@ -524,6 +532,8 @@ def make_vilbert():
 
     cases = dict(VILBERT_CASES)
     cases["vilbert_nlvr2"] = VILBERT_NLVR2
+    if only is not None:
+        cases = {k: v for k, v in cases.items() if k in only}
     for name, c in cases.items():
         nlvr2 = bool(c.get("nlvr2", False))
         torch.manual_seed(c["seed"])
@@ -1391,6 +1401,8 @@ if __name__ == "__main__":
         make_mmft()
     if "vilbert" in which:
         make_vilbert()
+    if "vilbert_fixed" in which:
+        make_vilbert(only=("vilbert_fixed",))
     if "vilbert_pretraining_vt2" in which:
         make_vilbert_pretraining(visual_target=2)
     if "vilbert_pretraining" in which:

@@ -151,7 +151,8 @@ def _check_against(model, out, ref_scores, ref_loss, ref_grads, tol=TOL, sens=No
     return {k: round(e, 4) for k, e in errs.items() if e > max(tol, 6.0 * (sens or {}).get(k, 0.0))}
 
 
-@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn"])      # vilbert_dyn: `dynamic_attention: true` (vilbert.py:199-212)
+# vilbert_dyn: `dynamic_attention: true` (vilbert.py:199-212); vilbert_fixed: fixed_t_layer 2 / fixed_v_layer 1 (:625-666)
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed"])
 def test_vilbert_golden_forward_loss_and_gradients(name):
     """Forward and loss against the values recorded from the real reference; gradients against the CPU oracle, which
     tests/test_vilbert_oracle_golden.py pins to the reference's own gradients for this very fixture, evaluated on the

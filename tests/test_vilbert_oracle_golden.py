@@ -10,7 +10,8 @@ from oracle.visual_bert_oracle import logit_bce
 from tests.golden_utils import load_vilbert_case
 
 
-@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn"])      # vilbert_dyn: dynamic_attention gates (vilbert.py:199-212)
+# vilbert_dyn: dynamic_attention gates (vilbert.py:199-212); vilbert_fixed: fixed_t_layer 2 / fixed_v_layer 1 (:625-666 — one detached layer, one skipped)
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed"])
 def test_vilbert_oracle_matches_reference_forward_loss_and_gradients(name):
     z, case, cfg, sd, sample = load_vilbert_case(name)
     assert any("dyLinear_q" in k for k in sd) == (name == "vilbert_dyn")
@@ -27,8 +28,10 @@ def test_vilbert_oracle_matches_reference_forward_loss_and_gradients(name):
     for gname, norm, gsum in zip(z["grad_names"], z["grad_norms"], z["grad_sums"]):
         key = str(gname)[len("model."):]
         g = sd[key].grad
-        if norm == 0.0:   # biOutput.q_dense1/2 are declared but never used (vilbert.py:486,493)
-            assert "q_dense" in key and (g is None or float(g.abs().max()) == 0.0), key
+        if norm == 0.0:   # biOutput.q_dense1/2 are declared but never used (vilbert.py:486,493); vilbert_fixed: the detached / skipped layers
+            frozen = name == "vilbert_fixed" and (".encoder.layer.0." in key or ".encoder.layer.1." in key or ".encoder.v_layer.0." in key
+                                                  or key.startswith("bert.embeddings.") or key.startswith("bert.v_embeddings."))
+            assert ("q_dense" in key or frozen) and (g is None or float(g.abs().max()) == 0.0), key
             continue
         checked += 1
         assert g is not None, key
@@ -41,7 +44,8 @@ def test_vilbert_oracle_matches_reference_forward_loss_and_gradients(name):
         full = "grad::" + str(gname)
         if full in z.files:
             np.testing.assert_allclose(g.numpy(), z[full], rtol=1e-4, atol=1e-6 + 1e-5 * norm, err_msg=key)
-    assert checked == len(sd) - 8
+    # 8 unused q_dense tensors; vilbert_fixed: + the embeddings (5 + 6), text layers 0 (detached) and 1 (skipped) and visual layer 0: 3 x 16
+    assert checked == len(sd) - 8 - (5 + 6 + 3 * 16 if name == "vilbert_fixed" else 0)
 
 
 def test_vilbert_oracle_nlvr2_matches_reference():

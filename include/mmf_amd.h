@@ -306,6 +306,12 @@ int mmf_tanh_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* 
 int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* mask_add[b][s] = (1 - mask[b][s]) * -10000  (visual_bert.py:94-106); mask int64 [B,S]. */
 int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream);
+/* VisualBERT.forward's input massaging in one launch (visual_bert.py:444-467, 525-556; the `vqa` pooling index of :389-392): from the
+ * text mask int64 [B, T] and the per-sample region counts image_dim int64 [B] (NULL: all R regions valid) it writes image_mask [B, R]
+ * (r < image_dim), attention_mask [B, T + R] (their concatenation), visual_embeddings_type [B, R] (zeros), the additive mask
+ * (1 - attention_mask) * -10000 as fp32 [B, T + R] and pool_index[b] = sum_t input_mask[b][t] - 2. */
+int mmf_visual_masks(const int64_t* input_mask, const int64_t* image_dim, int B, int T, int R, int64_t* image_mask, int64_t* attention_mask,
+                     int64_t* visual_embeddings_type, float* mask_add, int64_t* pool_index, void* stream);
 
 /* ---- loss: LogitBinaryCrossEntropy, mmf/modules/losses.py:225-251 ---------------------------
  * loss = mean(BCEWithLogits(scores, targets)) * N.  scores/targets fp32 [B, N] (row stride N).

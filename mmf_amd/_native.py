@@ -542,6 +542,15 @@ def set_tunable(which, value):
     _check(lib().mmf_amd_set_tunable(int(which), int(value)), "mmf_amd_set_tunable")
 
 
+def visual_masks(input_mask, image_dim, B, T, R, image_mask, attention_mask, vtype, mask_add, pool_index):
+    for t, n in ((input_mask, "input_mask"), (image_dim, "image_dim"), (image_mask, "image_mask"), (attention_mask, "attention_mask"), (vtype, "vtype"),
+                 (pool_index, "pool_index")):
+        _req(t, torch.int64, n)
+    _req(mask_add, torch.float32, "mask_add")
+    _check(lib().mmf_visual_masks(_p(input_mask), _p(image_dim), B, T, R, _p(image_mask), _p(attention_mask), _p(vtype), _p(mask_add), _p(pool_index),
+                                  _stream()), "mmf_visual_masks")
+
+
 def make_additive_mask(mask, out):
     _req(mask, torch.int64, "mask"); _req(out, torch.float32, "out")
     _check(lib().mmf_make_additive_mask(_p(mask), _p(out), C.c_int64(mask.numel()), _stream()), "mmf_make_additive_mask")

@@ -30,7 +30,7 @@ def _decide():
 NATIVE = _decide()
 
 # operators whose kernels the native library provides; with NATIVE the Python implementation of each is registered as `_py_<name>`
-NATIVE_OPS = ("additive_mask", "visio_linguistic_embeddings", "transformer_layer", "linear", "layer_norm", "dense_gelu", "linear_tanh",
+NATIVE_OPS = ("additive_mask", "visual_masks", "visio_linguistic_embeddings", "transformer_layer", "linear", "layer_norm", "dense_gelu", "linear_tanh",
               "gather_rows", "dropout", "pair_halves", "logit_bce", "masked_lm_head", "masked_region_head")
 PY_TWINS = ("visio_linguistic_embeddings", "transformer_layer", "linear", "layer_norm", "dense_gelu", "linear_tanh", "gather_rows",
             "dropout", "pair_halves", "masked_lm_head", "masked_region_head")

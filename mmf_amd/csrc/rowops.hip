@@ -743,6 +743,31 @@ __global__ void additive_mask_kernel(const int64_t* __restrict__ m, float* __res
     if (i < n) out[i] = (1.0f - (float)m[i]) * -10000.0f;
 }
 
+// VisualBERT's input massaging (visual_bert.py:444-467, 525-556, 389-392) in ONE launch, one workgroup per sample:
+//   image_mask[b][r] = r < image_dim[b] (all ones without image_dim);  attention_mask[b] = input_mask[b] | image_mask[b];
+//   visual_embeddings_type[b][r] = 0;  mask_add = (1 - attention_mask) * -10000;  pool_index[b] = sum_t input_mask[b][t] - 2
+// (arange / compare / cast / zeros_like / cat / sum / subtract / additive-mask launches of the unfused form).
+__global__ __launch_bounds__(256) void visual_masks_kernel(const int64_t* __restrict__ input_mask, const int64_t* __restrict__ image_dim, int T, int R,
+                                                            int64_t* __restrict__ image_mask, int64_t* __restrict__ attention_mask,
+                                                            int64_t* __restrict__ vtype, float* __restrict__ mask_add, int64_t* __restrict__ pool_index) {
+    __shared__ long red[4];
+    const int b = blockIdx.x, S = T + R;
+    const long dim = image_dim ? image_dim[b] : (long)R;
+    long cnt = 0;
+    for (int i = threadIdx.x; i < S; i += 256) {
+        long m;
+        if (i < T) { m = input_mask[(size_t)b * T + i]; cnt += m; }
+        else { m = (i - T) < dim ? 1 : 0; image_mask[(size_t)b * R + (i - T)] = m; vtype[(size_t)b * R + (i - T)] = 0; }
+        attention_mask[(size_t)b * S + i] = m;
+        mask_add[(size_t)b * S + i] = (1.0f - (float)m) * -10000.0f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) pool_index[b] = (red[0] + red[1]) + (red[2] + red[3]) - 2;
+}
+
 // y = x * keep_scale(index)  (forward and backward of nn.Dropout are the same map)
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n, DropoutCfg d) {
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
@@ -1513,6 +1538,16 @@ int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
 int mmf_make_additive_mask(const int64_t* mask, float* out, int64_t n, void* stream) {
     MMF_CHECK_ARG(mask && out && n > 0, "additive_mask: bad operand");
     hipLaunchKernelGGL(additive_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, out, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_visual_masks(const int64_t* input_mask, const int64_t* image_dim, int B, int T, int R, int64_t* image_mask, int64_t* attention_mask,
+                     int64_t* visual_embeddings_type, float* mask_add, int64_t* pool_index, void* stream) {
+    MMF_CHECK_ARG(input_mask && image_mask && attention_mask && visual_embeddings_type && mask_add && pool_index && B > 0 && T > 0 && R > 0,
+                  "visual_masks: bad operand");
+    hipLaunchKernelGGL(visual_masks_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, input_mask, image_dim, T, R, image_mask, attention_mask,
+                       visual_embeddings_type, mask_add, pool_index);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -852,6 +852,26 @@ auto call_py(const char* name, A&&... a) {
     return it->second.typed<Sig>().call(std::forward<A>(a)...);
 }
 
+// VisualBERT.forward's input massaging as one launch: (image_mask, attention_mask, visual_embeddings_type, additive mask, pooling index)
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> op_visual_masks(const Tensor& input_mask, const optional<Tensor>& image_dim, int64_t R) {
+    TORCH_CHECK(input_mask.is_cuda(), "mmf_amd::visual_masks: the mask must live in HBM; there is no CPU path");
+    TORCH_CHECK(input_mask.dim() == 2 && R > 0, "mmf_amd::visual_masks: input_mask must be [B, T] and R > 0");
+    Tensor im = input_mask.to(at::kLong).contiguous();
+    const int64_t B = im.size(0), T = im.size(1);
+    Tensor dim;
+    if (image_dim.has_value() && image_dim->defined()) {
+        dim = image_dim->to(at::kLong).reshape({-1}).contiguous();
+        TORCH_CHECK(dim.numel() == B && dim.is_cuda(), "mmf_amd::visual_masks: image_dim must hold one region count per sample, in HBM");
+    }
+    auto lo = im.options();
+    Tensor image_mask = at::empty({B, R}, lo), attention_mask = at::empty({B, T + R}, lo), vtype = at::empty({B, R}, lo), pool = at::empty({B}, lo);
+    Tensor mask_add = at::empty({B, T + R}, lo.dtype(at::kFloat));
+    MMF_RC(mmf_visual_masks(im.data_ptr<int64_t>(), dim.defined() ? dim.data_ptr<int64_t>() : nullptr, (int)B, (int)T, (int)R, image_mask.data_ptr<int64_t>(),
+                            attention_mask.data_ptr<int64_t>(), vtype.data_ptr<int64_t>(), mask_add.data_ptr<float>(), pool.data_ptr<int64_t>(), sp()),
+           "mmf_visual_masks");
+    return {image_mask, attention_mask, vtype, mask_add, pool};
+}
+
 Tensor op_additive_mask(const Tensor& mask) {
     TORCH_CHECK(mask.is_cuda(), "mmf_amd::additive_mask: the mask must live in HBM; there is no CPU path");
     Tensor am = mask.contiguous();
@@ -967,6 +987,7 @@ int64_t svc_set_py_mode(int64_t mode) { const int64_t old = g_py_mode; g_py_mode
 
 TORCH_LIBRARY(mmf_amd, m) {
     m.def("additive_mask(Tensor mask) -> Tensor");
+    m.def("visual_masks(Tensor input_mask, Tensor? image_dim, int R) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("visio_linguistic_embeddings(Tensor input_ids, Tensor token_type_ids, Tensor? visual_embeddings, Tensor? visual_embeddings_type, "
           "Tensor word, Tensor pos, Tensor typ, Tensor ln_w, Tensor ln_b, Tensor typ_vis, Tensor pos_vis, Tensor proj_w, Tensor proj_b, "
           "float eps, float p, bool training, int pad_idx, Tensor? image_text_alignment=None) -> Tensor");
@@ -1015,6 +1036,7 @@ TORCH_LIBRARY(mmf_amd, m) {
 
 TORCH_LIBRARY_IMPL(mmf_amd, CompositeImplicitAutograd, m) {
     m.impl("additive_mask", op_additive_mask);
+    m.impl("visual_masks", op_visual_masks);
     m.impl("visio_linguistic_embeddings", op_vle);
     m.impl("transformer_layer", op_transformer_layer);
     m.impl("linear", op_linear);

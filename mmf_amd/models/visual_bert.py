@@ -75,13 +75,16 @@ class VisualBERTBase(nn.Module):
 
     def forward(self, input_ids: Tensor, attention_mask: Optional[Tensor] = None, token_type_ids: Optional[Tensor] = None,
                 visual_embeddings: Optional[Tensor] = None, visual_embeddings_type: Optional[Tensor] = None,
-                image_text_alignment: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], List[Tensor]]:
+                image_text_alignment: Optional[Tensor] = None, mask_add: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], List[Tensor]]:
+        """`mask_add` (optional, not in the reference's signature): the additive mask of `attention_mask` when the caller already has it
+        (VisualBERT.forward builds it in the same launch as the masks themselves, torch.ops.mmf_amd.visual_masks)."""
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         # additive mask (1 - m) * -10000, visual_bert.py:94-106, built by a HIP kernel as fp32 [B, S]
-        mask_add = torch.ops.mmf_amd.additive_mask(attention_mask)
+        if mask_add is None:
+            mask_add = torch.ops.mmf_amd.additive_mask(attention_mask)
         extended_attention_mask = mask_add.view(mask_add.shape[0], 1, 1, mask_add.shape[1])
 
         embedding_output = self.embeddings(input_ids, token_type_ids, visual_embeddings=visual_embeddings,
@@ -141,9 +144,10 @@ class VisualBERTForPretraining(nn.Module):
     def forward(self, input_ids: Tensor, input_mask: Tensor, attention_mask: Optional[Tensor] = None,
                 token_type_ids: Optional[Tensor] = None, visual_embeddings: Optional[Tensor] = None,
                 visual_embeddings_type: Optional[Tensor] = None, image_text_alignment: Optional[Tensor] = None,
-                masked_lm_labels: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                masked_lm_labels: Optional[Tensor] = None, mask_add: Optional[Tensor] = None,
+                pool_index: Optional[Tensor] = None) -> Dict[str, Tensor]:
         sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
-                                                      visual_embeddings_type, image_text_alignment)
+                                                      visual_embeddings_type, image_text_alignment, mask_add)
         output_dict: Dict[str, Tensor] = {}
         if self.output_hidden_states:
             output_dict["sequence_output"] = sequence_output
@@ -203,9 +207,12 @@ class VisualBERTForClassification(nn.Module):
     def forward(self, input_ids: Tensor, input_mask: Tensor, attention_mask: Optional[Tensor] = None,
                 token_type_ids: Optional[Tensor] = None, visual_embeddings: Optional[Tensor] = None,
                 visual_embeddings_type: Optional[Tensor] = None, image_text_alignment: Optional[Tensor] = None,
-                masked_lm_labels: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                masked_lm_labels: Optional[Tensor] = None, mask_add: Optional[Tensor] = None,
+                pool_index: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """`mask_add` / `pool_index` (optional, not in the reference's signature): the additive attention mask and `input_mask.sum(1) - 2`
+        when VisualBERT.forward has already computed them (one launch, torch.ops.mmf_amd.visual_masks)."""
         sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
-                                                      visual_embeddings_type, image_text_alignment)
+                                                      visual_embeddings_type, image_text_alignment, mask_add)
         if self.training_head_type == "nlvr2":
             assert pooled_output is not None
             pooled_output = torch.ops.mmf_amd.pair_halves(pooled_output)       # 2B x H -> B x 2H, visual_bert.py:369-374
@@ -216,7 +223,7 @@ class VisualBERTForClassification(nn.Module):
                 output_dict["pooled_output"] = pooled_output
         if self.pooler_strategy == "vqa":
             # representation of the second-to-last text token (visual_bert.py:389-398) + dropout (:400)
-            index_to_gather = input_mask.sum(1) - 2
+            index_to_gather = pool_index if pool_index is not None else input_mask.sum(1) - 2
             pooled = torch.ops.mmf_amd.gather_rows(sequence_output, index_to_gather, self.dropout_prob, self.training)
         else:
             assert pooled_output is not None
@@ -298,16 +305,25 @@ class VisualBERT(BaseModel):
         image_dim = sample_list["image_dim"]
         if self.training_head_type == "pretraining":
             sample_list["masked_lm_labels"] = sample_list["lm_label_ids"]          # visual_bert.py:539-541
-        image_mask = torch.arange(visual_embeddings.size(-2), device=visual_embeddings.device).expand(
-            visual_embeddings.size()[:-1])
-        if image_dim.dim() < image_mask.dim():
-            image_dim = image_dim.unsqueeze(-1)
-        sample_list["image_mask"] = (image_mask < image_dim).long()
+        # image_mask = arange(R) < image_dim (visual_bert.py:544-555) and, in the SAME launch, what add_post_flatten_params, VisualBERTBase and
+        # the `vqa` pooling derive from the masks next: visual_embeddings_type (zeros), attention_mask (the concatenation), its additive
+        # form and input_mask.sum(1) - 2 — one kernel instead of arange / compare / cast / zeros_like / cat / sum / subtract / additive mask
+        image_mask, attention_mask, vtype, mask_add, pool_index = torch.ops.mmf_amd.visual_masks(
+            sample_list["input_mask"], image_dim, visual_embeddings.size(-2))
+        sample_list["image_mask"] = image_mask
+        sample_list["_fused_attention_mask"] = attention_mask
+        sample_list["_fused_visual_embeddings_type"] = vtype
+        sample_list["_fused_mask_add"] = mask_add
+        sample_list["_fused_pool_index"] = pool_index
         return sample_list
 
     def add_post_flatten_params(self, sample_list: Dict[str, Tensor]) -> Dict[str, Tensor]:
-        sample_list["visual_embeddings_type"] = torch.zeros_like(sample_list["image_mask"])
-        sample_list["attention_mask"] = torch.cat((sample_list["input_mask"], sample_list["image_mask"]), dim=-1)
+        if "_fused_attention_mask" in sample_list:      # computed with the image mask (add_custom_params)
+            sample_list["visual_embeddings_type"] = sample_list["_fused_visual_embeddings_type"]
+            sample_list["attention_mask"] = sample_list["_fused_attention_mask"]
+        else:
+            sample_list["visual_embeddings_type"] = torch.zeros_like(sample_list["image_mask"])
+            sample_list["attention_mask"] = torch.cat((sample_list["input_mask"], sample_list["image_mask"]), dim=-1)
         if self.training_head_type == "pretraining":
             # visual_bert.py:455-465: labels over the joint sequence, -1 (ignored) on every visual position
             lm = sample_list["masked_lm_labels"]
@@ -329,10 +345,15 @@ class VisualBERT(BaseModel):
             image_text_alignment = sample_list["image_text_alignment"]
         if "masked_lm_labels" in sample_list:
             masked_lm_labels = sample_list["masked_lm_labels"]
+        mask_add: Optional[Tensor] = None
+        pool_index: Optional[Tensor] = None
+        if "_fused_mask_add" in sample_list:
+            mask_add = sample_list["_fused_mask_add"]
+            pool_index = sample_list["_fused_pool_index"]
         output_dict = self.model(
             sample_list["input_ids"], sample_list["input_mask"], sample_list["attention_mask"],
             sample_list["token_type_ids"], sample_list["visual_embeddings"], sample_list["visual_embeddings_type"],
-            image_text_alignment, masked_lm_labels)
+            image_text_alignment, masked_lm_labels, mask_add, pool_index)
         if self.training_head_type == "pretraining":                               # visual_bert.py:588-598
             if not torch.jit.is_scripting():
                 loss_key = "{}/{}".format(sample_list["dataset_name"], sample_list["dataset_type"])

@@ -69,6 +69,22 @@ def _op(schema):
 # NativeLibraryError for a host tensor or a wrong dtype, the C ABI's MMF_CHECK_ARG for shapes; there is no CPU path.)
 
 
+@_op("visual_masks(Tensor input_mask, Tensor? image_dim, int R) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+def visual_masks(input_mask, image_dim, R):
+    """(image_mask, attention_mask, visual_embeddings_type, additive mask, `vqa` pooling index) of VisualBERT.forward's input massaging
+    (visual_bert.py:444-467, 525-556, 389-392) in one launch."""
+    im = input_mask.long().contiguous()
+    B, T = im.shape
+    dim = None if image_dim is None else image_dim.long().reshape(-1).contiguous()
+    image_mask = torch.empty(B, R, dtype=torch.int64, device=im.device)
+    attention_mask = torch.empty(B, T + R, dtype=torch.int64, device=im.device)
+    vtype = torch.empty(B, R, dtype=torch.int64, device=im.device)
+    mask_add = torch.empty(B, T + R, dtype=torch.float32, device=im.device)
+    pool = torch.empty(B, dtype=torch.int64, device=im.device)
+    Fn.nat.visual_masks(im, dim, B, T, R, image_mask, attention_mask, vtype, mask_add, pool)
+    return image_mask, attention_mask, vtype, mask_add, pool
+
+
 @_op("additive_mask(Tensor mask) -> Tensor")
 def additive_mask(mask):
     am = mask.contiguous()

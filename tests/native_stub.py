@@ -279,7 +279,20 @@ def _wra_bwd(seq, ld, B, S, H, M, Nn, txt_pad, img_pad, label, xinv, yinv, plan,
     _need(dseq, B * S, ldd, H, "wra dseq")
 
 
-_CHECKED = {"mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "attention_f32_bwd": _attention_f32_bwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
+def _visual_masks(input_mask, image_dim, B, T, R, image_mask, attention_mask, vtype, mask_add, pool_index):
+    """The one stub that has to PRODUCE values: the index tensors it writes are validated by the other checkers downstream."""
+    assert input_mask.dtype == torch.int64 and tuple(input_mask.shape) == (B, T)
+    assert image_dim is None or (image_dim.dtype == torch.int64 and image_dim.numel() == B)
+    dim = torch.full((B, 1), R, dtype=torch.int64) if image_dim is None else image_dim.reshape(B, 1)
+    image_mask.copy_((torch.arange(R).expand(B, R) < dim).long())
+    attention_mask.copy_(torch.cat((input_mask, image_mask), dim=1))
+    vtype.zero_()
+    mask_add.copy_((1.0 - attention_mask.float()) * -10000.0)
+    pool_index.copy_(input_mask.sum(1) - 2)
+    calls.append(("visual_masks", B, T, R))
+
+
+_CHECKED = {"visual_masks": _visual_masks, "mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "attention_f32_bwd": _attention_f32_bwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
             "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,

@@ -141,3 +141,25 @@ def test_native_library_argument_errors_are_torch_checks():
         torch.ops.mmf_amd.linear(x, torch.randn(768, 512, device="cuda"), None, False)
     with pytest.raises(RuntimeError, match="B, S, H"):
         torch.ops.mmf_amd.gather_rows(torch.randn(4, 768, device="cuda"), torch.zeros(4, dtype=torch.long, device="cuda"), 0.0, False)
+
+
+def test_visual_masks_op_matches_the_unfused_massaging():
+    """torch.ops.mmf_amd.visual_masks = the arange / compare / zeros_like / cat / additive-mask / sum - 2 sequence of VisualBERT.forward's input
+    massaging (visual_bert.py:444-467, 525-556, 389-392) in one launch."""
+    g = torch.Generator().manual_seed(0)
+    B, T, R = 5, 128, 100
+    input_mask = (torch.rand(B, T, generator=g) < 0.8).long()
+    input_mask[:, 0] = 1
+    dims = torch.tensor([100, 73, 1, 0, 55])
+    for image_dim in (dims, dims.view(B, 1), None):
+        out = torch.ops.mmf_amd.visual_masks(input_mask.cuda(), None if image_dim is None else image_dim.cuda(), R)
+        image_mask, attention_mask, vtype, mask_add, pool = (t.cpu() for t in out)
+        d = torch.full((B, 1), R) if image_dim is None else image_dim.view(B, 1)
+        want_im = (torch.arange(R).expand(B, R) < d).long()
+        want_am = torch.cat((input_mask, want_im), dim=-1)
+        assert torch.equal(image_mask, want_im) and torch.equal(attention_mask, want_am) and attention_mask.dtype == torch.int64
+        assert torch.equal(vtype, torch.zeros_like(want_im))
+        assert torch.equal(mask_add, (1.0 - want_am.float()) * -10000.0) and mask_add.dtype == torch.float32
+        assert torch.equal(pool, input_mask.sum(1) - 2)
+    with pytest.raises(RuntimeError, match="HBM"):
+        torch.ops.mmf_amd.visual_masks(input_mask, None, R)

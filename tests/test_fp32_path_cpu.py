@@ -12,7 +12,7 @@ from tests import golden_utils as G
 from tests import model_utils as MU
 from tests import native_stub
 
-FP32_CALLS = {"gemm_f32", "attention_f32_fwd", "layernorm_f32_fwd", "embed_text_f32_fwd", "gather_rows_f32", "make_additive_mask",
+FP32_CALLS = {"gemm_f32", "attention_f32_fwd", "layernorm_f32_fwd", "embed_text_f32_fwd", "gather_rows_f32", "make_additive_mask", "visual_masks",
               "bce_logits_fwd", "cross_entropy_fwd", "copy_rows"}
 
 

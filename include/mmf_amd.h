@@ -572,6 +572,12 @@ int mmf_gather_rows2_f32(const float* a, int64_t rows_a, const float* b, int64_t
 int mmf_ptr_scores_f32(const float* q, const float* k, const float* mask_add, float* out, int ldo, int B, int T, int N, int HQ, float scale,
                        void* stream);
 
+/* ViLBERT `in_batch_pairs` / `fast_mode` batch expansion (mmf/models/vilbert.py:678-725) on bf16 activations [Bs, n] -> [reps * Bs, n]:
+ * mode 0: out[i * Bs + j] = x[j] (`unsqueeze(0).expand`, the image side / fast_mode's text), mode 1: out[i * reps + j] = x[i] (`unsqueeze(1).expand`, the
+ * text side); mmf_reduce_batch_bf16 is the backward (the sum over the broadcast index, fp32 accumulation).  n % 8 == 0. */
+int mmf_expand_batch_bf16(const void* x, void* out, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream);
+int mmf_reduce_batch_bf16(const void* g, void* dx, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream);
+
 /* ViLBERT's masked-region NCE loss (`visual_target: 2`, mmf/models/vilbert.py:1158-1227): pred fp32 [M, N] = the image-prediction head's output
  * for all M = B * R regions, target fp32 [M, N] the region features, neg int64 [M, K] flat indices (into the M regions) of each region's K
  * negatives, label int64 [M] (1 = masked region).  score[r][j] = <sample_j, pred[r]> with sample_0 = target[r], sample_j = target[neg[r][j-1]];

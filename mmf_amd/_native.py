@@ -706,6 +706,16 @@ def dropout_f32(x, y, drop):
     _check(lib().mmf_dropout_f32(_p(x), _p(y), C.c_long(x.numel()), key, thr, C.c_float(scale), seed, _stream()), "mmf_dropout_f32")
 
 
+def expand_batch(x, out, Bs, reps, n, mode):
+    _req(x, torch.bfloat16, "x"); _req(out, torch.bfloat16, "out")
+    _check(lib().mmf_expand_batch_bf16(_p(x), _p(out), C.c_int64(Bs), C.c_int64(reps), C.c_int64(n), mode, _stream()), "mmf_expand_batch_bf16")
+
+
+def reduce_batch(g, dx, Bs, reps, n, mode):
+    _req(g, torch.bfloat16, "g"); _req(dx, torch.bfloat16, "dx")
+    _check(lib().mmf_reduce_batch_bf16(_p(g), _p(dx), C.c_int64(Bs), C.c_int64(reps), C.c_int64(n), mode, _stream()), "mmf_reduce_batch_bf16")
+
+
 def nce_fwd(pred, target, neg, label, scores, lse, rowloss, loss, count, M, N, K):
     for t, n in ((pred, "pred"), (target, "target"), (scores, "scores"), (lse, "lse"), (rowloss, "rowloss"), (loss, "loss"), (count, "count")):
         _req(t, torch.float32, n)

@@ -192,6 +192,38 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ViLBERT `in_batch_pairs` / `fast_mode` batch expansion (mmf/models/vilbert.py:678-725): every text of the batch against every image.
+//   mode 0 (the image side, `x.unsqueeze(0).expand(reps, ...)`):  out[i * Bs + j] = x[j]      (the whole batch tiled `reps` times)
+//   mode 1 (the text side,  `x.unsqueeze(1).expand(.., reps, ...)`): out[i * reps + j] = x[i]  (every sample repeated `reps` times)
+// n = elements per sample; 16-byte accesses.  Backward: the sum over the broadcast index, accumulated in fp32.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_batch_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, long Bs, long reps, long n8, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;            // over reps * Bs * n8 chunks of 8 elements
+    if (i >= reps * Bs * n8) return;
+    const long sample = i / n8, c = i - sample * n8;
+    const long src = mode == 0 ? sample % Bs : sample / reps;
+    reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(x)[src * n8 + c];
+}
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const bf16* __restrict__ g, bf16* __restrict__ dx, long Bs, long reps, long n8, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;            // over Bs * n8 chunks
+    if (i >= Bs * n8) return;
+    const long s = i / n8, c = i - s * n8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long r = 0; r < reps; ++r) {
+        const long sample = mode == 0 ? r * Bs + s : s * reps + r;
+        const uint4 v = reinterpret_cast<const uint4*>(g)[sample * n8 + c];
+        const bf16* e = reinterpret_cast<const bf16*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (float)e[k];
+    }
+    uint4 o;
+    bf16* e = reinterpret_cast<bf16*>(&o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = (bf16)acc[k];
+    reinterpret_cast<uint4*>(dx)[i] = o;
+}
+
 extern "C" {
 
 int mmf_gate_sigmoid_fwd(const float* z, float* gate, int ldg, int col0, int B, int C, void* stream) {
@@ -255,6 +287,23 @@ int mmf_nce_bwd(const float* target, const int64_t* neg, const int64_t* label, c
     MMF_CHECK_ARG(target && neg && label && scores && lse && count && gloss && dpred, "nce_bwd: null operand");
     MMF_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && K <= NCE_MAXK && ldd >= N && (ldd % 8) == 0, "nce_bwd: bad shape (ldd: a multiple of 8 covering N)");
     hipLaunchKernelGGL(nce_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, target, neg, label, scores, lse, count, gloss, (bf16*)dpred, ldd, M, N, K);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_expand_batch_bf16(const void* x, void* out, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream) {
+    MMF_CHECK_ARG(x && out && Bs > 0 && reps > 0 && n > 0 && (n % 8) == 0 && (mode == 0 || mode == 1), "expand_batch: bad operand (n % 8 == 0, mode 0 / 1)");
+    const long total = reps * Bs * (n / 8);
+    hipLaunchKernelGGL(expand_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, (long)Bs,
+                       (long)reps, (long)(n / 8), mode);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_reduce_batch_bf16(const void* g, void* dx, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream) {
+    MMF_CHECK_ARG(g && dx && Bs > 0 && reps > 0 && n > 0 && (n % 8) == 0 && (mode == 0 || mode == 1), "reduce_batch: bad operand (n % 8 == 0, mode 0 / 1)");
+    const long total = Bs * (n / 8);
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, (bf16*)dx, (long)Bs,
+                       (long)reps, (long)(n / 8), mode);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -1287,6 +1287,29 @@ class MaskedRegionRegressionFn(torch.autograd.Function):
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None
 
 
+class ExpandBatchFn(torch.autograd.Function):
+    """ViLBERT's `in_batch_pairs` / `fast_mode` batch expansion (mmf/models/vilbert.py:678-725) of a bf16 activation [Bs, L, H] -> [reps * Bs, L, H]:
+    mode 0 `x.unsqueeze(0).expand(reps, ...)` (pair (i, j) takes sample j), mode 1 `x.unsqueeze(1).expand(.., reps, ...)` (pair (i, j) takes sample i).
+    Backward: the sum over the broadcast index (fp32 accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x, reps, mode):
+        Bs, L, H = x.shape
+        x2 = _as_bf16_2d(x)
+        out = torch.empty(reps * Bs * L, H, dtype=BF16, device=x2.device)
+        nat.expand_batch(x2, out, Bs, reps, L * H, mode)
+        ctx.meta = (Bs, L, H, reps, mode)
+        return out.view(reps * Bs, L, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        Bs, L, H, reps, mode = ctx.meta
+        g2 = _grad_bf16(g, H)
+        dx = torch.empty(Bs * L, H, dtype=BF16, device=g2.device)
+        nat.reduce_batch(g2, dx, Bs, reps, L * H, mode)
+        return dx.view(Bs, L, H), None, None
+
+
 class MaskedRegionNCEFn(torch.autograd.Function):
     """The decoder + loss of ViLBERT's masked-region NCE form (`visual_target: 2`, mmf/models/vilbert.py:1158-1227): prediction_scores_v =
     h W^T + b, each masked region's prediction scored against its own target feature and K sampled negatives (the batched product of :1221),

@@ -13,9 +13,10 @@ bi-attention node (two packed Q|K|V GEMMs + two cross attentions that read the o
 dense+dropout+residual+LayerNorm nodes and two feed-forward nodes.
 
 The `nlvr2` head (two images per sample, :1262-1265, 1322-1323, 1369-1394) is built.
-Not built (raise): the pretraining heads (:1054-1240),
-`in_batch_pairs` / `fast_mode` batch expansion (:684-735), `task_specific_tokens`, `fixed_{t,v}_layer` > 0 and
-attention-map outputs (`visualization`, `output_all_attention_masks`: the fused kernel never materialises them).
+The pretraining head (:1054-1240, `visual_target` 0 / 1 / 2), `fixed_{t,v}_layer` (:625-666) and the `in_batch_pairs` / `fast_mode` batch
+expansion (:678-725, `expand_batch_kernel` / `reduce_batch_kernel`; bf16 path) are built too.
+Not built (raise): `task_specific_tokens`, `in_batch_pairs` / `fast_mode` together with `dynamic_attention`, and attention-map outputs
+(`visualization`, `output_all_attention_masks`: the fused kernel never materialises them).
 """
 import os
 
@@ -277,9 +278,12 @@ class BertEncoder(nn.Module):
 
     def __init__(self, config):
         super().__init__()
-        for flag in ("fast_mode", "in_batch_pairs"):
-            if getattr(config, flag, False):
-                raise NotImplementedError("ViLBERT %s (vilbert.py:684-735) is not built" % flag)
+        # `in_batch_pairs` / `fast_mode` (vilbert.py:678-725): at the first connection point the batch becomes every text against every image
+        self.in_batch_pairs = bool(getattr(config, "in_batch_pairs", False))
+        self.fast_mode = bool(getattr(config, "fast_mode", False))
+        if (self.in_batch_pairs or self.fast_mode) and bool(getattr(config, "dynamic_attention", False)):
+            raise NotImplementedError("in_batch_pairs / fast_mode with dynamic_attention: the reference does not expand the mask its gates pool "
+                                      "with (vilbert.py:678-725 leave extended_attention_mask2 at the old batch size)")
         # vilbert.py:625-666, as the reference BEHAVES: its loop runs `forward_no_grad` on the layer at t_start and sets t_start = fixed_t_layer
         # in that same iteration, so only the first such layer executes (without gradient) and layers t_start + 1 .. fixed_t_layer - 1 never run
         self.fixed_t_layer = int(getattr(config, "fixed_t_layer", 0) or 0)
@@ -328,6 +332,22 @@ class BertEncoder(nn.Module):
                     txt_embedding = self.layer[idx](txt_embedding, txt_attention_mask)[0]
                 for idx in range(v_start, v_end):
                     image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
+            if count == 0 and (self.in_batch_pairs or self.fast_mode):
+                if F32P.active() or F32T.active():
+                    raise NotImplementedError("fp32 path: in_batch_pairs / fast_mode are built on the bf16 path only")
+                if self.in_batch_pairs:          # new batch size = batch_size ^ 2 (:678-710): pair (i, j) = text i with image j
+                    B = txt_embedding.shape[0]
+                    image_embedding = Fn.ExpandBatchFn.apply(image_embedding, B, 0)
+                    image_attention_mask = image_attention_mask.unsqueeze(0).expand(B, B, -1).reshape(B * B, -1).contiguous()
+                    txt_embedding = Fn.ExpandBatchFn.apply(txt_embedding, B, 1)
+                    txt_attention_mask = txt_attention_mask.unsqueeze(1).expand(B, B, -1).reshape(B * B, -1).contiguous()
+                if self.fast_mode:               # one text against N images (:712-723)
+                    N = image_embedding.shape[0]
+                    if txt_embedding.shape[0] != N:
+                        if txt_embedding.shape[0] != 1:
+                            raise ValueError("fast_mode expands a text batch of 1 to the image batch (got %d texts, %d images)" % (txt_embedding.shape[0], N))
+                        txt_embedding = Fn.ExpandBatchFn.apply(txt_embedding, N, 0)
+                        txt_attention_mask = txt_attention_mask.expand(N, -1).contiguous()
             if self.with_coattention:
                 image_embedding, txt_embedding, _ = self.c_layer[count](image_embedding, image_attention_mask, txt_embedding,
                                                                         txt_attention_mask)

@@ -2,12 +2,13 @@
 
 fp32 PyTorch restatement of mmf/models/vilbert.py: `BertSelfAttention` :46-114 / `BertImageSelfAttention` :153-247
 (dynamic_attention=False), `BertLayer` :131-146 / `BertImageLayer` :313-332, `BertBiAttention` :347-475, `BertBiOutput`
-:478-512, `BertConnectionLayer` :515-556, `BertEncoder.forward` :590-796 (fixed_*_layer=0, no in_batch_pairs / fast mode),
+:478-512, `BertConnectionLayer` :515-556, `BertEncoder.forward` :590-796 (fixed_{t,v}_layer :625-666, in_batch_pairs / fast mode :678-725),
 `BertTextPooler` / `BertImagePooler` :799-826, `BertImageFeatureEmbeddings` :891-913, `ViLBERTBase.forward` :936-1051,
 `ViLBERTForClassification.forward` :1281-1333 and `ViLBERT.forward` :1364-1446 (input massaging).
 
 Parity status: PINNED against tests/golden/vilbert_small.npz, produced by running those reference classes
-(tests/golden/make_golden.py::make_vilbert; text heads d=64, visual and co-attention heads d=128 as in the real config).
+(tests/golden/make_golden.py::make_vilbert; text heads d=64, visual and co-attention heads d=128 as in the real config), and the variants
+against vilbert_dyn / vilbert_fixed / vilbert_pairs (in_batch_pairs) / vilbert_nlvr2 / vilbert_pretraining*.npz; fast_mode has no fixture.
 """
 import math
 from collections import OrderedDict
@@ -217,6 +218,18 @@ def encoder(sd, cfg, txt, img, txt_mask, img_mask, train=False, txt_mask2=None):
             v_start = fixed_v
         for i in range(v_start, v_end):
             img = v_layer(i, img, txt)
+        if count == 0 and cfg.get("in_batch_pairs", False):                           # :678-710, batch_size ^ 2 pairs (text i, image j)
+            B = txt.shape[0]
+            img = img.unsqueeze(0).expand(B, *img.shape).reshape(B * B, *img.shape[1:])
+            img_mask = img_mask.unsqueeze(0).expand(B, *img_mask.shape).reshape(B * B, *img_mask.shape[1:])
+            txt = txt.unsqueeze(1).expand(B, B, *txt.shape[1:]).reshape(B * B, *txt.shape[1:])
+            txt_mask = txt_mask.unsqueeze(1).expand(B, B, *txt_mask.shape[1:]).reshape(B * B, *txt_mask.shape[1:])
+            t_layer = lambda i, x, m=txt_mask: stream_layer(sd, "bert.encoder.layer.%d." % i, cfg["num_attention_heads"], x, m, td, tad, cfg["layer_norm_eps"])
+            v_layer = lambda i, x, t, m=img_mask: stream_layer(sd, "bert.encoder.v_layer.%d." % i, cfg["v_num_attention_heads"], x, m, vd, vad)
+        if count == 0 and cfg.get("fast_mode", False) and txt.shape[0] != img.shape[0]:    # :712-723
+            txt = txt.expand(img.shape[0], *txt.shape[1:])
+            txt_mask = txt_mask.expand(img.shape[0], *txt_mask.shape[1:])
+            t_layer = lambda i, x, m=txt_mask: stream_layer(sd, "bert.encoder.layer.%d." % i, cfg["num_attention_heads"], x, m, td, tad, cfg["layer_norm_eps"])
         img, txt = connection_layer(sd, cfg, count, img, img_mask, txt, txt_mask, train)
         v_start, t_start = v_end, t_end
     for i in range(v_start, cfg["v_num_hidden_layers"]):

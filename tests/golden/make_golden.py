@@ -491,6 +491,13 @@ VILBERT_CASES = {
                           bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
                           v_biattention_id=[1, 2], t_biattention_id=[2, 3], vocab_size=211, max_position_embeddings=40,
                           v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=44, fixed_t_layer=2, fixed_v_layer=1),
+    # `in_batch_pairs: true` (vilbert.py:678-710): at the first connection point the batch becomes every text against every image (B^2
+    # pairs); the scores are [B^2, num_labels], the targets of this case too
+    "vilbert_pairs": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=4,
+                          v_hidden_size=256, v_num_attention_heads=2, v_intermediate_size=192, v_num_hidden_layers=3,
+                          bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
+                          v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=211, max_position_embeddings=40,
+                          v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=45, in_batch_pairs=True),
 }
 
 
@@ -509,7 +516,8 @@ def vilbert_reference_config(c):
         bi_num_attention_heads=c["bi_num_attention_heads"], bi_intermediate_size=c["bi_intermediate_size"], bi_attention_type=1,
         v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.1, v_initializer_range=0.02,
         v_biattention_id=c["v_biattention_id"], t_biattention_id=c["t_biattention_id"], pooling_method="mul", fusion_method="mul",
-        fast_mode=False, with_coattention=True, dynamic_attention=bool(c.get("dynamic_attention", False)), in_batch_pairs=False, task_specific_tokens=False,
+        fast_mode=False, with_coattention=True, dynamic_attention=bool(c.get("dynamic_attention", False)), in_batch_pairs=bool(c.get("in_batch_pairs", False)),
+        task_specific_tokens=False,
         fixed_v_layer=int(c.get("fixed_v_layer", 0)), fixed_t_layer=int(c.get("fixed_t_layer", 0)), visualization=False, visual_target=0, objective=0,
         num_negative=128, model="vilbert",
         num_labels=c["num_labels"], losses=[dict(type="logit_bce")]))
@@ -584,8 +592,9 @@ def make_vilbert(only=None):
         feats = (2.0 * detweights.uniform(B * R * c["v_feature_size"], seed + 102) - 1.0).astype(np.float32).reshape(B, R, -1)
         bbox = detweights.uniform(B * R * 5, seed + 104).astype(np.float32).reshape(B, R, 5)
         max_features = np.array([R, R - 2, R - 1], dtype=np.int64)[:B]
-        targets = np.zeros((B, c["num_labels"]), dtype=np.float32)
-        for b in range(B):
+        NB = B * B if c.get("in_batch_pairs", False) else B          # in_batch_pairs: one score row per (text, image) pair
+        targets = np.zeros((NB, c["num_labels"]), dtype=np.float32)
+        for b in range(NB):
             targets[b, (3 * b + 1) % c["num_labels"]] = 1.0
             targets[b, (5 * b + 2) % c["num_labels"]] = 0.6
         sl = SampleList(input_ids=torch.from_numpy(ids), input_mask=torch.from_numpy(mask), segment_ids=torch.from_numpy(seg),
@@ -1403,6 +1412,8 @@ if __name__ == "__main__":
         make_vilbert()
     if "vilbert_fixed" in which:
         make_vilbert(only=("vilbert_fixed",))
+    if "vilbert_pairs" in which:
+        make_vilbert(only=("vilbert_pairs",))
     if "vilbert_pretraining_vt2" in which:
         make_vilbert_pretraining(visual_target=2)
     if "vilbert_pretraining" in which:

@@ -146,7 +146,7 @@ def vilbert_model_config(cfg, **over):
         v_biattention_id=list(cfg["v_biattention_id"]), t_biattention_id=list(cfg["t_biattention_id"]), pooling_method="mul",
         fusion_method=cfg.get("fusion_method", "mul"), fast_mode=False, with_coattention=True,
         dynamic_attention=bool(cfg.get("dynamic_attention", False)),
-        in_batch_pairs=False, task_specific_tokens=False, fixed_v_layer=int(cfg.get("fixed_v_layer", 0)), fixed_t_layer=int(cfg.get("fixed_t_layer", 0)),
+        in_batch_pairs=bool(cfg.get("in_batch_pairs", False)), task_specific_tokens=False, fixed_v_layer=int(cfg.get("fixed_v_layer", 0)), fixed_t_layer=int(cfg.get("fixed_t_layer", 0)),
         visualization=False, visual_target=0,
         objective=0, num_negative=128, num_labels=cfg["num_labels"], losses=[dict(type="logit_bce")])
     d.update(over)

@@ -292,7 +292,19 @@ def _visual_masks(input_mask, image_dim, B, T, R, image_mask, attention_mask, vt
     calls.append(("visual_masks", B, T, R))
 
 
-_CHECKED = {"visual_masks": _visual_masks, "mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "attention_f32_bwd": _attention_f32_bwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
+def _expand_batch(x, out, Bs, reps, n, mode):
+    assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and mode in (0, 1)
+    assert _room(x) >= Bs * n and _room(out) >= reps * Bs * n, "expand_batch: %d x %d x %d does not fit" % (reps, Bs, n)
+    calls.append(("expand_batch", Bs, reps, n, mode))
+
+
+def _reduce_batch(g, dx, Bs, reps, n, mode):
+    assert g.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and mode in (0, 1)
+    assert _room(g) >= reps * Bs * n and _room(dx) >= Bs * n
+    calls.append(("reduce_batch", Bs, reps, n, mode))
+
+
+_CHECKED = {"expand_batch": _expand_batch, "reduce_batch": _reduce_batch, "visual_masks": _visual_masks, "mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "attention_f32_bwd": _attention_f32_bwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
             "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
             "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,

@@ -59,6 +59,11 @@ def _vilbert():
     return z, MU.build_vilbert(cfg, sd, device="cpu"), sample, "model."
 
 
+def _vilbert_pairs():
+    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_pairs")
+    return z, MU.build_vilbert(cfg, sd, device="cpu"), sample, "model."
+
+
 def _vilbert_pretraining():
     z, case, cfg, sd, sample = G.load_vilbert_pretraining_case()
     return z, MU.build_vilbert_pretraining(cfg, sd, device="cpu"), sample, "model."
@@ -74,7 +79,7 @@ def _m4c():
     return z, MU.build_m4c(cfg, sd, device="cpu"), sample, ""
 
 
-CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "visual_bert_bypass": _bypass, "mmbt": _mmbt, "mmbt_pretraining": _mmbt_pretraining, "mmft": _mmft, "vilbert": _vilbert, "vilbert_pretraining": _vilbert_pretraining, "uniter": _uniter,
+CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "visual_bert_bypass": _bypass, "mmbt": _mmbt, "mmbt_pretraining": _mmbt_pretraining, "mmft": _mmft, "vilbert": _vilbert, "vilbert_pairs": _vilbert_pairs, "vilbert_pretraining": _vilbert_pretraining, "uniter": _uniter,
          "m4c": _m4c}
 
 
@@ -82,23 +87,32 @@ CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_
 def test_training_step_plumbing(name):
     z, model, sample, prefix = CASES[name]()
     model.train()
-    key = name.split("_nlvr2")[0].split("_pretraining")[0].split("_bypass")[0]
+    key = name.split("_nlvr2")[0].split("_pretraining")[0].split("_bypass")[0].split("_pairs")[0]
     full = Config(model=key, optimizer=dict(params=dict(lr=5e-5)), model_config={key: model.config})
     opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
     with native_stub.installed() as calls:
-        out = model(SampleList(sample))
+        if name == "vilbert_pairs":                  # B^2 target rows do not pass SampleList's equal-batch check (the reference's neither): loss applied here
+            out = model(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+            out["losses"] = {"train/golden/logit_bce": torch.ops.mmf_amd.logit_bce(out["scores"], sample["targets"])}
+        else:
+            out = model(SampleList(sample))
         if name == "vilbert_pretraining":            # two losses, no scores in the output (vilbert.py:1459-1469)
             assert sorted(out["losses"]) == ["coco/train/masked_img_loss", "coco/train/masked_lm_loss"]
             loss = sum(v.sum() for v in out["losses"].values())
         else:
             head = out["logits"] if name.endswith("_pretraining") else out["scores"]        # the pretraining heads return `logits`
             assert head.dtype == torch.float32 and head.shape[0] > 0
+            if name == "vilbert_pairs":              # in_batch_pairs: one score row per (text, image) pair (vilbert.py:678-710)
+                B = sample["input_ids"].shape[0]
+                assert head.shape[0] == B * B
             assert len(out["losses"]) == 1
             (lkey, loss), = out["losses"].items()
             assert (lkey.startswith("train/") or lkey.endswith("/train/masked_lm_loss")) and loss.numel() == 1
         loss.sum().backward()
         opt.step()
     assert any(c[0] == "gemm" for c in calls) and any(c[0] == "attention_bwd" for c in calls) and any(c[0] == "adamw_multi" for c in calls)
+    if name == "vilbert_pairs":                      # image rows broadcast over the text index (mode 0), text rows over the image index (mode 1)
+        assert sorted(c[4] for c in calls if c[0] == "expand_batch") == [0, 1] and sorted(c[4] for c in calls if c[0] == "reduce_batch") == [0, 1]
     params = dict(model.named_parameters())
     # every parameter in exactly one optimizer group
     seen = [id(p) for g in opt.param_groups for p in g["params"]]

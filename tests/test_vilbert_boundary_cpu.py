@@ -35,7 +35,7 @@ def test_dynamic_attention_adds_the_gate_parameters_of_the_reference():
 def test_unbuilt_variants_raise():
     z, case, cfg, sd, sample = load_vilbert_case()
     for over in (dict(training_head_type="pretraining", visual_target=3),
-                 dict(in_batch_pairs=True), dict(fast_mode=True), dict(task_specific_tokens=True),
+                 dict(in_batch_pairs=True, dynamic_attention=True), dict(fast_mode=True, dynamic_attention=True), dict(task_specific_tokens=True),
                  dict(visualization=True)):
         with pytest.raises(NotImplementedError):
             build_model(vilbert_model_config(cfg, **over))

@@ -151,8 +151,9 @@ def _check_against(model, out, ref_scores, ref_loss, ref_grads, tol=TOL, sens=No
     return {k: round(e, 4) for k, e in errs.items() if e > max(tol, 6.0 * (sens or {}).get(k, 0.0))}
 
 
-# vilbert_dyn: `dynamic_attention: true` (vilbert.py:199-212); vilbert_fixed: fixed_t_layer 2 / fixed_v_layer 1 (:625-666)
-@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed"])
+# vilbert_dyn: `dynamic_attention: true` (vilbert.py:199-212); vilbert_fixed: fixed_t_layer 2 / fixed_v_layer 1 (:625-666);
+# vilbert_pairs: `in_batch_pairs: true` (:678-710, B^2 (text, image) pairs from the first connection point on)
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed", "vilbert_pairs"])
 def test_vilbert_golden_forward_loss_and_gradients(name):
     """Forward and loss against the values recorded from the real reference; gradients against the CPU oracle, which
     tests/test_vilbert_oracle_golden.py pins to the reference's own gradients for this very fixture, evaluated on the
@@ -163,7 +164,12 @@ def test_vilbert_golden_forward_loss_and_gradients(name):
     model.eval()
     got = {}
     hook = model.model.bert.register_forward_hook(lambda m, i, o: got.update(t=o[0], v=o[1], pt=o[2], pv=o[3]))
-    out = model(SampleList(sample_to(sample, "cuda")))
+    if name == "vilbert_pairs":      # B^2 target rows do not pass SampleList's equal-batch check (the reference's neither): the loss is applied here
+        out = model(SampleList(sample_to({k: v for k, v in sample.items() if k != "targets"}, "cuda")))
+        out["losses"] = {"train/vqa2/logit_bce": torch.ops.mmf_amd.logit_bce(out["scores"], sample["targets"].cuda())}
+        assert out["scores"].shape[0] == sample["input_ids"].shape[0] ** 2
+    else:
+        out = model(SampleList(sample_to(sample, "cuda")))
     hook.remove()
     np.testing.assert_allclose(out["scores"].detach().float().cpu().numpy(), z["scores"], rtol=TOL, atol=TOL)
     for name, key in (("t", "sequence_output_t"), ("v", "sequence_output_v"), ("pt", "pooled_output_t"), ("pv", "pooled_output_v")):
@@ -335,3 +341,20 @@ def test_two_hip_streams_equal_one_stream():
     assert res[0][1].keys() == res[1][1].keys()
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("Bs,reps,L,H", [(3, 3, 7, 256), (5, 5, 12, 128), (1, 6, 23, 136)])
+def test_expand_batch_kernels_match_torch(mode, Bs, reps, L, H):
+    """The in_batch_pairs / fast_mode broadcast (vilbert.py:678-725) and its backward (the sum over the broadcast index) against torch.expand."""
+    import mmf_amd.functional as Fn
+    torch.manual_seed(5)
+    x = torch.randn(Bs, L, H, device=DEV).bfloat16()
+    xr = x.float().requires_grad_(True)
+    ref = (xr.unsqueeze(0).expand(reps, Bs, L, H) if mode == 0 else xr.unsqueeze(1).expand(Bs, reps, L, H)).reshape(reps * Bs, L, H)
+    xg = x.clone().requires_grad_(True)
+    got = Fn.ExpandBatchFn.apply(xg, reps, mode)
+    assert got.dtype == torch.bfloat16 and torch.equal(got.float(), ref.detach())
+    g = torch.randn(reps * Bs, L, H, device=DEV).bfloat16()
+    ref.backward(g.float()); got.backward(g)
+    assert float((xg.grad.float() - xr.grad).abs().max()) <= 1e-2 * float(xr.grad.abs().max())

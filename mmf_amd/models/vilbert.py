@@ -411,7 +411,9 @@ class ViLBERTBase(nn.Module):
         super().__init__()
         self.config = config
         if getattr(config, "task_specific_tokens", False):
-            raise NotImplementedError("task_specific_tokens (vilbert.py:977-980) is not built")
+            # the reference's own path fails here: it extends the text mask by one token (vilbert.py:971-974) that its embeddings never add (no caller passes
+            # task_ids, and HF's BertEmbeddings would take them as position_ids, :1018) -> a size mismatch in the first text layer
+            raise NotImplementedError("task_specific_tokens (vilbert.py:971-974): the reference path itself fails with a size mismatch; not built")
         if getattr(config, "visualization", False):
             raise NotImplementedError("visualization: the fused attention kernel never materialises the probabilities")
         self.embeddings = BertEmbeddingsJit(config)

@@ -8,7 +8,7 @@ fp32 PyTorch restatement of mmf/models/vilbert.py: `BertSelfAttention` :46-114 /
 
 Parity status: PINNED against tests/golden/vilbert_small.npz, produced by running those reference classes
 (tests/golden/make_golden.py::make_vilbert; text heads d=64, visual and co-attention heads d=128 as in the real config), and the variants
-against vilbert_dyn / vilbert_fixed / vilbert_pairs (in_batch_pairs) / vilbert_nlvr2 / vilbert_pretraining*.npz; fast_mode has no fixture.
+against vilbert_dyn / vilbert_fixed / vilbert_pairs (in_batch_pairs) / vilbert_fast (fast_mode) / vilbert_nlvr2 / vilbert_pretraining*.npz.
 """
 import math
 from collections import OrderedDict

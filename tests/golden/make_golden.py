@@ -498,6 +498,13 @@ VILBERT_CASES = {
                           bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
                           v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=211, max_position_embeddings=40,
                           v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=45, in_batch_pairs=True),
+    # `fast_mode: true` (vilbert.py:712-723): ONE text against B images, the text stream expanded at the first connection point.  The batch
+    # sizes differ, so this case calls ViLBERTForClassification.forward directly (a SampleList cannot hold it)
+    "vilbert_fast": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=4,
+                         v_hidden_size=256, v_num_attention_heads=2, v_intermediate_size=192, v_num_hidden_layers=3,
+                         bi_hidden_size=256, bi_num_attention_heads=2, bi_intermediate_size=256,
+                         v_biattention_id=[0, 1], t_biattention_id=[1, 2], vocab_size=211, max_position_embeddings=40,
+                         v_feature_size=72, num_labels=11, B=3, T=12, R=7, seed=46, fast_mode=True),
 }
 
 
@@ -516,7 +523,7 @@ def vilbert_reference_config(c):
         bi_num_attention_heads=c["bi_num_attention_heads"], bi_intermediate_size=c["bi_intermediate_size"], bi_attention_type=1,
         v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.1, v_initializer_range=0.02,
         v_biattention_id=c["v_biattention_id"], t_biattention_id=c["t_biattention_id"], pooling_method="mul", fusion_method="mul",
-        fast_mode=False, with_coattention=True, dynamic_attention=bool(c.get("dynamic_attention", False)), in_batch_pairs=bool(c.get("in_batch_pairs", False)),
+        fast_mode=bool(c.get("fast_mode", False)), with_coattention=True, dynamic_attention=bool(c.get("dynamic_attention", False)), in_batch_pairs=bool(c.get("in_batch_pairs", False)),
         task_specific_tokens=False,
         fixed_v_layer=int(c.get("fixed_v_layer", 0)), fixed_t_layer=int(c.get("fixed_t_layer", 0)), visualization=False, visual_target=0, objective=0,
         num_negative=128, model="vilbert",
@@ -623,7 +630,12 @@ def make_vilbert(only=None):
             return out
 
         ref.model.bert.forward = spy
-        out = ref(sl)
+        if c.get("fast_mode", False):
+            ids, mask, seg = ids[1:2], mask[1:2], seg[1:2]              # the half-padded text of sample 1, alone
+            image_mask = (torch.arange(R).expand(B, R) < torch.from_numpy(max_features).unsqueeze(-1)).long()      # vilbert.py:1405-1413
+            out = ref.model(torch.from_numpy(ids), torch.from_numpy(feats), torch.from_numpy(bbox), torch.from_numpy(seg), torch.from_numpy(mask), image_mask)
+        else:
+            out = ref(sl)
         if nlvr2:
             from mmf.modules.losses import CrossEntropyLoss
             loss = CrossEntropyLoss()(sl, out)
@@ -1414,6 +1426,8 @@ if __name__ == "__main__":
         make_vilbert(only=("vilbert_fixed",))
     if "vilbert_pairs" in which:
         make_vilbert(only=("vilbert_pairs",))
+    if "vilbert_fast" in which:
+        make_vilbert(only=("vilbert_fast",))
     if "vilbert_pretraining_vt2" in which:
         make_vilbert_pretraining(visual_target=2)
     if "vilbert_pretraining" in which:

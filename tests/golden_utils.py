@@ -112,7 +112,7 @@ def load_vilbert_case(name="vilbert_small"):
         v_biattention_id=list(case["v_biattention_id"]), t_biattention_id=list(case["t_biattention_id"]), fusion_method="mul",
         num_labels=case["num_labels"], initializer_range=0.02, dynamic_attention=bool(case.get("dynamic_attention", False)),
         fixed_t_layer=int(case.get("fixed_t_layer", 0)), fixed_v_layer=int(case.get("fixed_v_layer", 0)),
-        in_batch_pairs=bool(case.get("in_batch_pairs", False)))
+        in_batch_pairs=bool(case.get("in_batch_pairs", False)), fast_mode=bool(case.get("fast_mode", False)))
     sample = {
         "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
         "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),

@@ -144,7 +144,7 @@ def vilbert_model_config(cfg, **over):
         bi_attention_type=1, v_attention_probs_dropout_prob=cfg.get("v_attention_probs_dropout_prob", 0.1), v_hidden_act="gelu",
         v_hidden_dropout_prob=cfg.get("v_hidden_dropout_prob", 0.1), v_initializer_range=0.02,
         v_biattention_id=list(cfg["v_biattention_id"]), t_biattention_id=list(cfg["t_biattention_id"]), pooling_method="mul",
-        fusion_method=cfg.get("fusion_method", "mul"), fast_mode=False, with_coattention=True,
+        fusion_method=cfg.get("fusion_method", "mul"), fast_mode=bool(cfg.get("fast_mode", False)), with_coattention=True,
         dynamic_attention=bool(cfg.get("dynamic_attention", False)),
         in_batch_pairs=bool(cfg.get("in_batch_pairs", False)), task_specific_tokens=False, fixed_v_layer=int(cfg.get("fixed_v_layer", 0)), fixed_t_layer=int(cfg.get("fixed_t_layer", 0)),
         visualization=False, visual_target=0,

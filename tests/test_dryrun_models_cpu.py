@@ -64,6 +64,11 @@ def _vilbert_pairs():
     return z, MU.build_vilbert(cfg, sd, device="cpu"), sample, "model."
 
 
+def _vilbert_fast():
+    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_fast")
+    return z, MU.build_vilbert(cfg, sd, device="cpu"), sample, "model."
+
+
 def _vilbert_pretraining():
     z, case, cfg, sd, sample = G.load_vilbert_pretraining_case()
     return z, MU.build_vilbert_pretraining(cfg, sd, device="cpu"), sample, "model."
@@ -79,7 +84,7 @@ def _m4c():
     return z, MU.build_m4c(cfg, sd, device="cpu"), sample, ""
 
 
-CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "visual_bert_bypass": _bypass, "mmbt": _mmbt, "mmbt_pretraining": _mmbt_pretraining, "mmft": _mmft, "vilbert": _vilbert, "vilbert_pairs": _vilbert_pairs, "vilbert_pretraining": _vilbert_pretraining, "uniter": _uniter,
+CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_pretraining": _pretraining, "visual_bert_bypass": _bypass, "mmbt": _mmbt, "mmbt_pretraining": _mmbt_pretraining, "mmft": _mmft, "vilbert": _vilbert, "vilbert_pairs": _vilbert_pairs, "vilbert_fast": _vilbert_fast, "vilbert_pretraining": _vilbert_pretraining, "uniter": _uniter,
          "m4c": _m4c}
 
 
@@ -87,12 +92,18 @@ CASES = {"visual_bert": _visual_bert, "visual_bert_nlvr2": _nlvr2, "visual_bert_
 def test_training_step_plumbing(name):
     z, model, sample, prefix = CASES[name]()
     model.train()
-    key = name.split("_nlvr2")[0].split("_pretraining")[0].split("_bypass")[0].split("_pairs")[0]
+    key = name.split("_nlvr2")[0].split("_pretraining")[0].split("_bypass")[0].split("_pairs")[0].split("_fast")[0]
     full = Config(model=key, optimizer=dict(params=dict(lr=5e-5)), model_config={key: model.config})
     opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8)
     with native_stub.installed() as calls:
         if name == "vilbert_pairs":                  # B^2 target rows do not pass SampleList's equal-batch check (the reference's neither): loss applied here
             out = model(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+            out["losses"] = {"train/golden/logit_bce": torch.ops.mmf_amd.logit_bce(out["scores"], sample["targets"])}
+        elif name == "vilbert_fast":                 # one text against B images (vilbert.py:712-723): ViLBERTForClassification.forward directly
+            from oracle.vilbert_oracle import prepare_inputs
+            p = prepare_inputs(dict(sample))
+            out = model.model(p["input_ids"], p["image_feature"], p["image_location"], p["token_type_ids"], p["attention_mask"], p["image_attention_mask"])
+            assert out["scores"].shape[0] == p["image_feature"].shape[0] and p["input_ids"].shape[0] == 1
             out["losses"] = {"train/golden/logit_bce": torch.ops.mmf_amd.logit_bce(out["scores"], sample["targets"])}
         else:
             out = model(SampleList(sample))
@@ -113,6 +124,8 @@ def test_training_step_plumbing(name):
     assert any(c[0] == "gemm" for c in calls) and any(c[0] == "attention_bwd" for c in calls) and any(c[0] == "adamw_multi" for c in calls)
     if name == "vilbert_pairs":                      # image rows broadcast over the text index (mode 0), text rows over the image index (mode 1)
         assert sorted(c[4] for c in calls if c[0] == "expand_batch") == [0, 1] and sorted(c[4] for c in calls if c[0] == "reduce_batch") == [0, 1]
+    if name == "vilbert_fast":                       # the single text broadcast over the image batch
+        assert [c[1:] for c in calls if c[0] == "expand_batch"] == [(1, 3, 12 * 128, 0)] and [c[1:] for c in calls if c[0] == "reduce_batch"] == [(1, 3, 12 * 128, 0)]
     params = dict(model.named_parameters())
     # every parameter in exactly one optimizer group
     seen = [id(p) for g in opt.param_groups for p in g["params"]]

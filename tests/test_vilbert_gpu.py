@@ -152,8 +152,9 @@ def _check_against(model, out, ref_scores, ref_loss, ref_grads, tol=TOL, sens=No
 
 
 # vilbert_dyn: `dynamic_attention: true` (vilbert.py:199-212); vilbert_fixed: fixed_t_layer 2 / fixed_v_layer 1 (:625-666);
-# vilbert_pairs: `in_batch_pairs: true` (:678-710, B^2 (text, image) pairs from the first connection point on)
-@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed", "vilbert_pairs"])
+# vilbert_pairs: `in_batch_pairs: true` (:678-710, B^2 (text, image) pairs from the first connection point on); vilbert_fast: `fast_mode: true`
+# (:712-723, one text against B images)
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed", "vilbert_pairs", "vilbert_fast"])
 def test_vilbert_golden_forward_loss_and_gradients(name):
     """Forward and loss against the values recorded from the real reference; gradients against the CPU oracle, which
     tests/test_vilbert_oracle_golden.py pins to the reference's own gradients for this very fixture, evaluated on the
@@ -168,6 +169,11 @@ def test_vilbert_golden_forward_loss_and_gradients(name):
         out = model(SampleList(sample_to({k: v for k, v in sample.items() if k != "targets"}, "cuda")))
         out["losses"] = {"train/vqa2/logit_bce": torch.ops.mmf_amd.logit_bce(out["scores"], sample["targets"].cuda())}
         assert out["scores"].shape[0] == sample["input_ids"].shape[0] ** 2
+    elif name == "vilbert_fast":     # one text, B images: not a SampleList either -> ViLBERTForClassification.forward directly, as the fixture's generator does
+        p = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in O.prepare_inputs(dict(sample)).items()}
+        assert p["input_ids"].shape[0] == 1 and p["image_feature"].shape[0] == 3
+        out = model.model(p["input_ids"], p["image_feature"], p["image_location"], p["token_type_ids"], p["attention_mask"], p["image_attention_mask"])
+        out["losses"] = {"train/vqa2/logit_bce": torch.ops.mmf_amd.logit_bce(out["scores"], sample["targets"].cuda())}
     else:
         out = model(SampleList(sample_to(sample, "cuda")))
     hook.remove()

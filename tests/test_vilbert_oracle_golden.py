@@ -11,8 +11,8 @@ from tests.golden_utils import load_vilbert_case
 
 
 # vilbert_dyn: dynamic_attention gates (vilbert.py:199-212); vilbert_fixed: fixed_t_layer 2 / fixed_v_layer 1 (:625-666 — one detached layer, one skipped);
-# vilbert_pairs: in_batch_pairs (:678-710 — every text against every image, B^2 score rows)
-@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed", "vilbert_pairs"])
+# vilbert_pairs: in_batch_pairs (:678-710 — every text against every image, B^2 score rows); vilbert_fast: fast_mode (:712-723 — one text, B images)
+@pytest.mark.parametrize("name", ["vilbert_small", "vilbert_dyn", "vilbert_fixed", "vilbert_pairs", "vilbert_fast"])
 def test_vilbert_oracle_matches_reference_forward_loss_and_gradients(name):
     z, case, cfg, sd, sample = load_vilbert_case(name)
     assert any("dyLinear_q" in k for k in sd) == (name == "vilbert_dyn")

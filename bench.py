@@ -497,6 +497,8 @@ def main():
             try:
                 reducer.remove()        # the chain packs and reduces the gradients itself
                 chain = chained_step(opt)
+                chain()                 # one untimed replay with its collectives: a launch-path problem shows here, on every rank alike
+                torch.cuda.synchronize()
             except Exception as e:      # same kernels either way: fall back to launching them one by one
                 sys.stderr.write("bench: chained hipGraphs unavailable (%s: %s); eager step\n" % (type(e).__name__, e))
                 chain = None

@@ -165,6 +165,8 @@ typedef struct mmf_attn_desc {
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
 
+/* Backward of the same operator (what autograd derives for BertSelfAttentionJit.forward, mmf/modules/hf_layers.py:138-213, in the reference):
+ * dQ, dK, dV from dctx with the probabilities recomputed from the saved row log-sum-exp and the dropout decisions replayed from the key. */
 typedef struct mmf_attn_bwd_desc {
     mmf_attn_desc f;   /* forward operands (ctx = forward output O, lse = saved) */
     const void* dctx;  /* bf16, same layout as ctx (ldo) */

@@ -1405,7 +1405,9 @@ def make_visual_bert_pretraining():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["visual_bert", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "vilbert_pretraining", "heads", "uniter", "m4c"]
+    # no arguments: EVERY fixture this script owns (vilbert = all of VILBERT_CASES incl. dyn / fixed / pairs / fast + nlvr2)
+    which = sys.argv[1:] or ["visual_bert", "alignment", "nlvr2", "pretraining", "mmbt", "mmbt_pretraining", "mmft", "vilbert", "vilbert_pretraining",
+                             "vilbert_pretraining_vt2", "heads", "uniter", "m4c"]
     if "visual_bert" in which:
         main()
     if "alignment" in which:

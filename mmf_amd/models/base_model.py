@@ -63,7 +63,12 @@ class BaseModel(nn.Module):
             return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
     def __call__(self, sample_list, *args, **kwargs):
-        sample_list = to_device(sample_list, self._device())
+        moved = to_device(sample_list, self._device())
+        if moved is sample_list and isinstance(moved, SampleList):
+            # already on the device: `to_device` hands the same object back (sample.py:453-455).  The models' forwards attach fields to the
+            # batch they are given (as the reference's do), and a captured step calls forward on ONE batch several times: work on a copy
+            moved = moved.to(self._device())
+        sample_list = moved
         model_output = super().__call__(sample_list, *args, **kwargs)
         if self.is_pretrained:
             return model_output

@@ -16,6 +16,10 @@ def build_model(config):
         raise RuntimeError("No model registered for name: %s" % model_name)
     model = model_class(config)
     if hasattr(model, "build"):
+        # build.py:132-150 lets the main rank download / build first and the others wait at a barrier (collective C3 of SURVEY.md
+        # section 2.3): building here touches no shared files and downloads nothing, so every rank builds at once, without a barrier
+        if hasattr(model_class, "load_requirements"):
+            model_class.load_requirements(model_class, config=config)
         model.build()
         model.init_losses()
     return model

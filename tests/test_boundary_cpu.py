@@ -118,3 +118,22 @@ def test_nlvr2_head_parameter_tree_matches_the_reference():
     ref = {str(n): tuple(int(x) for x in str(s).split(",")) for n, s in zip(z["param_names"], z["param_shapes"])}
     assert ours == ref
     assert ours["model.classifier.0.dense.weight"] == (2 * cfg["hidden_size"], 2 * cfg["hidden_size"])
+
+
+def test_optional_base_model_hooks_follow_the_reference():
+    """base_model.py:129-136 (`_run_format_state_key`, in place), :299-303 (`_ensure_sample_list`), :339-351 (`load_requirements`,
+    `format_for_prediction`); `build_model` calls `load_requirements` before `build()` (utils/build.py:143-144)."""
+    from mmf_amd.common.sample import SampleList
+    z, case, cfg, sd, sample = load_case("small64")
+    model = build_model(model_config(cfg))
+    legacy = {"bert.bert.embeddings.word_embeddings.weight": 1, "bert.classifier.1.weight": 2, "untouched": 3}
+    model._run_format_state_key(legacy)
+    assert set(legacy) == {model.format_state_key(k) for k in ("bert.bert.embeddings.word_embeddings.weight", "bert.classifier.1.weight", "untouched")}
+    assert "untouched" in legacy and "bert.bert.embeddings.word_embeddings.weight" not in legacy
+    assert model.format_for_prediction([1, 2], report=None) == [1, 2]
+    sl = model._ensure_sample_list({"a": torch.zeros(2)})
+    assert isinstance(sl, SampleList) and model._ensure_sample_list(sl) is sl
+    with pytest.raises(RuntimeError, match="zoo_requirements"):
+        build_model(model_config(cfg, zoo_requirements=["visual_bert.pretrained.coco"]))
+    with pytest.raises(RuntimeError, match="zoo_requirements"):
+        build_model(model_config(cfg, zoo_requirements="visual_bert.pretrained.coco"))

@@ -38,7 +38,20 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_GEMM_WIDE_KS = 5,   /* wide-tile wave layout: 2 the two ping-pong groups split every K-step (fewer LDS fragment reads), 1 never, 0 where it measured faster (256x96, K >= 1536) */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
        MMF_TUN_ATTN_FWD_OLD = 7,   /* 1: head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head (the round-2 form; A/B) */
-       MMF_TUN_COUNT = 8 };
+       MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
+                                      kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B, tools/nt_site_ab.sh) */
+       MMF_TUN_COUNT = 9 };
+/* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
+ * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
+#define MMF_GEMM_SITE(s) (((s) & 15) << 20)
+enum { MMF_SITE_QKV_FWD = 1,        /* Q|K|V projection -> read next by the attention forward */
+       MMF_SITE_ATTN_OUT_FWD = 2,   /* attention output projection (+ residual) -> read next by the LayerNorm */
+       MMF_SITE_FFN_UP_FWD = 3,     /* intermediate GELU(h W1^T) -> the A operand of the FFN-down GEMM */
+       MMF_SITE_FFN_DOWN_FWD = 4,   /* FFN output projection (+ residual) -> LayerNorm */
+       MMF_SITE_FFN_DOWN_DGRAD = 5, /* du = (dlin2 W2) * gelu' -> the A operand of the FFN-up dgrad (and of its weight gradient) */
+       MMF_SITE_FFN_UP_DGRAD = 6,   /* da = du W1 + dres -> LayerNorm backward */
+       MMF_SITE_ATTN_OUT_DGRAD = 7, /* dctx = dlin1 Wo -> attention backward */
+       MMF_SITE_QKV_DGRAD = 8 };    /* dx = dqkv Wqkv + dres -> the layer below */
 int mmf_amd_set_tunable(int which, int value);
 int mmf_amd_get_tunable(int which);
 const char* mmf_amd_last_error(void);

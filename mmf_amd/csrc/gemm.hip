@@ -482,6 +482,9 @@ static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     // MMF_TUN_EPI_NT: 0 = the default mask below, else (value - 1) is the mask (1 = no non-temporal stores at all)
     const int ntt = mmf_amd_get_tunable(MMF_TUN_EPI_NT);
     e.nt = ntt > 0 ? ntt - 1 : MMF_EPI_NT_DEFAULT;
+    // call-site exception (MMF_TUN_NT_SITE_KEEP, default 0 = none): the tagged call's bf16 output is read by the very next kernel
+    const int site = (d->debug_flags >> 20) & 15;
+    if (site != 0 && ((mmf_amd_get_tunable(MMF_TUN_NT_SITE_KEEP) >> site) & 1)) e.nt &= ~1;
     return 0;
 }
 

@@ -314,6 +314,7 @@ struct Gemm {
     Gemm& drop(const Drop& dr) { d.drop_key = dr.key; d.drop_thr16 = dr.thr16; d.drop_scale = dr.scale; d.drop_seed = dr.seed_ptr(); return *this; }
     Gemm& grp(int in, int pad, int off) { d.grp_in = in; d.grp_pad = pad; d.grp_off = off; return *this; }
     Gemm& rowsum(const Tensor& t) { if (t.defined()) d.rowsum_out = t.data_ptr<float>(); return *this; }
+    Gemm& site(int s) { d.debug_flags |= MMF_GEMM_SITE(s); return *this; }      // names the call for MMF_TUN_NT_SITE_KEEP (no effect by itself)
     void run() {
         Tensor ws;
         if (d.out_f32 && d.a_kmajor && d.b_kmajor && !d.bias && !d.resid && d.act == 0) {
@@ -335,11 +336,11 @@ Tensor colsum(const Tensor& x, int64_t ld, int64_t rows, int64_t N) {
 
 // dX [M, K] = dY [M, N] W [N, K], residual-gradient add / saved-gelu' multiply fused
 Tensor dgrad(const Tensor& dy, int64_t ldy, const Tensor& w16, int64_t M, int64_t N, int64_t K, const Tensor& dx_resid = Tensor(),
-             const Tensor& act_aux = Tensor()) {
+             const Tensor& act_aux = Tensor(), int site = 0) {
     Tensor dx = empty_bf16({M, K}, dy);
     Tensor wt = (N % 8 == 0 && twin_pays(K)) ? g_shadows.transposed(w16) : Tensor();
-    if (wt.defined()) Gemm(dy, wt, dx, M, K, N, ldy, N, K).resid(dx_resid, K).act(act_aux.defined() ? 2 : 0, Tensor(), act_aux).run();
-    else Gemm(dy, w16, dx, M, K, N, ldy, K, K).kmajor(false, true).resid(dx_resid, K).act(act_aux.defined() ? 2 : 0, Tensor(), act_aux).run();
+    if (wt.defined()) Gemm(dy, wt, dx, M, K, N, ldy, N, K).resid(dx_resid, K).act(act_aux.defined() ? 2 : 0, Tensor(), act_aux).site(site).run();
+    else Gemm(dy, w16, dx, M, K, N, ldy, K, K).kmajor(false, true).resid(dx_resid, K).act(act_aux.defined() ? 2 : 0, Tensor(), act_aux).site(site).run();
     return dx;
 }
 struct LinBwd { Tensor dx, dw, db; };
@@ -393,11 +394,11 @@ LnBwd ln_bwd(const Tensor& dy, const Tensor& y, const Tensor& mean, const Tensor
 // dense -> dropout -> (+ residual) -> LayerNorm   (HF BertSelfOutput / BertOutput)
 struct Ddrln { Tensor out, y, mean, rstd; };
 Ddrln ddrln_fwd(const Tensor& h2, const Tensor& resid2, const Tensor& w16, const Tensor& bias, const Tensor& gamma, const Tensor& beta, double eps,
-                const Drop& drop) {
+                const Drop& drop, int site = 0) {
     const int64_t M = h2.size(0), K = h2.size(1), N = w16.size(0);
     Ddrln r;
     r.y = empty_bf16({M, N}, h2);
-    Gemm(h2, w16, r.y, M, N, K, K, K, N).bias(bias).resid(resid2, N).drop(drop).run();
+    Gemm(h2, w16, r.y, M, N, K, K, K, N).bias(bias).resid(resid2, N).drop(drop).site(site).run();
     r.out = empty_bf16({M, N}, h2); r.mean = empty_f32({M}, h2); r.rstd = empty_f32({M}, h2);
     req(gamma, at::kFloat, "LayerNorm.weight"); req(beta, at::kFloat, "LayerNorm.bias");
     MMF_RC(mmf_layernorm_fwd(r.y.data_ptr(), PF(gamma), PF(beta), r.out.data_ptr(), r.mean.data_ptr<float>(), r.rstd.data_ptr<float>(), (int)M, (int)N,
@@ -439,17 +440,17 @@ struct TransformerLayerFn : public torch::autograd::Function<TransformerLayerFn>
         Tensor mask = mask_opt.has_value() ? *mask_opt : Tensor();
         // attention
         Tensor qkv = empty_bf16({M, 3 * H}, x2);
-        Gemm(x2, wqkv16, qkv, M, 3 * H, H, H, H, 3 * H).bias(bqkv).run();
+        Gemm(x2, wqkv16, qkv, M, 3 * H, H, H, H, 3 * H).bias(bqkv).site(MMF_SITE_QKV_FWD).run();
         Tensor ctxt = empty_bf16({M, H}, x2), lse = empty_f32({B, heads, S}, x2);
         Tensor o32 = need_bwd ? empty_f32({M, H}, x2) : Tensor();
         mmf_attn_desc ad;
         attn_desc(ad, qkv, H, mask, ctxt, lse, o32, B, heads, S, drop_attn, tail);
         MMF_RC(mmf_attention_fwd(&ad, sp()), "mmf_attention_fwd");
-        Ddrln a = ddrln_fwd(ctxt, x2, wo16, bo, g1, be1, eps1, drop_hid1);
+        Ddrln a = ddrln_fwd(ctxt, x2, wo16, bo, g1, be1, eps1, drop_hid1, MMF_SITE_ATTN_OUT_FWD);
         // feed-forward
         Tensor u = empty_bf16({M, I}, x2), hh = empty_bf16({M, I}, x2);
-        Gemm(a.out, w1_16, hh, M, I, H, H, H, I).bias(b1).act(1, u).run();
-        Ddrln f = ddrln_fwd(hh, a.out, w2_16, b2, g2, be2, eps2, drop_hid2);
+        Gemm(a.out, w1_16, hh, M, I, H, H, H, I).bias(b1).act(1, u).site(MMF_SITE_FFN_UP_FWD).run();
+        Ddrln f = ddrln_fwd(hh, a.out, w2_16, b2, g2, be2, eps2, drop_hid2, MMF_SITE_FFN_DOWN_FWD);
         ctx->save_for_backward({x2, qkv, ctxt, lse, a.y, a.mean, a.rstd, a.out, u, hh, f.y, f.mean, f.rstd, wqkv16, wo16, w1_16, w2_16, g1.detach(),
                                 g2.detach(), mask, o32, drop_attn.seed, drop_hid1.seed, drop_hid2.seed});
         ctx->saved_data["dims"] = std::vector<int64_t>{B, S, H, I, heads, tail};
@@ -468,18 +469,18 @@ struct TransformerLayerFn : public torch::autograd::Function<TransformerLayerFn>
                    drop_hid2 = drop_unpack(ctx->saved_data["d2"], sv[23]);
         // feed-forward sub-layer (bias gradients of the two output projections ride on the grouped weight-gradient launch)
         LnBwd l2 = ln_bwd(grad_bf16(grads[0], H), y2, mean2, rstd2, g2, drop_hid2, false);
-        Tensor du = dgrad(l2.dlin, H, w2_16, M, H, I, Tensor(), u);            // (dlin2 W2) * gelu'(u)
-        Tensor da = dgrad(du, I, w1_16, M, I, H, l2.dx);                      // du W1 + dres2
+        Tensor du = dgrad(l2.dlin, H, w2_16, M, H, I, Tensor(), u, MMF_SITE_FFN_DOWN_DGRAD);      // (dlin2 W2) * gelu'(u)
+        Tensor da = dgrad(du, I, w1_16, M, I, H, l2.dx, Tensor(), MMF_SITE_FFN_UP_DGRAD);         // du W1 + dres2
         // attention sub-layer
         LnBwd l1 = ln_bwd(da, y1, mean1, rstd1, g1, drop_hid1, false);
-        Tensor dctx = dgrad(l1.dlin, H, wo16, M, H, H);
+        Tensor dctx = dgrad(l1.dlin, H, wo16, M, H, H, Tensor(), Tensor(), MMF_SITE_ATTN_OUT_DGRAD);
         Tensor dqkv = empty_bf16({M, 3 * H}, x2), delta = empty_f32({B, heads, S}, x2);
         mmf_attn_bwd_desc bd;
         attn_desc(bd.f, qkv, H, mask, ctxt, lse, o32, B, heads, S, drop_attn, tail);
         char* dbase = reinterpret_cast<char*>(dqkv.data_ptr());
         bd.dctx = dctx.data_ptr(); bd.dq = dbase; bd.dk = dbase + 2 * H; bd.dv = dbase + 4 * H; bd.delta = delta.data_ptr<float>();
         MMF_RC(mmf_attention_bwd(&bd, sp()), "mmf_attention_bwd");
-        Tensor dx = ctx->needs_input_grad(0) ? dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, l1.dx) : Tensor();
+        Tensor dx = ctx->needs_input_grad(0) ? dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, l1.dx, Tensor(), MMF_SITE_QKV_DGRAD) : Tensor();
         // the four weight gradients, one launch
         Tensor dw1 = empty_f32({I, H}, x2), db1 = empty_f32({I}, x2), dw2 = empty_f32({H, I}, x2), db2 = empty_f32({H}, x2);
         Tensor dwqkv = empty_f32({3 * H, H}, x2), dbqkv = empty_f32({3 * H}, x2), dwo = empty_f32({H, H}, x2), dbo = empty_f32({H}, x2);

@@ -83,3 +83,25 @@ def test_library_is_not_older_than_its_sources():
         [os.path.join(root, "include", "mmf_amd.h")]
     newest = max(srcs, key=os.path.getmtime)
     assert os.path.getmtime(so) >= os.path.getmtime(newest), "rebuild: %s is newer than libmmf_amd.so" % os.path.relpath(newest, root)
+
+
+def test_tunables_round_trip_and_the_site_tags_stay_clear_of_the_other_flag_bits(built_lib):
+    """MMF_TUN_NT_SITE_KEEP (the per-call-site exception to the non-temporal epilogue stores) is the last tunable; the site tag occupies
+    bits 20..23 of mmf_gemm_desc::debug_flags, which no other switch reads."""
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(_native.HEADER_PATH).read()
+    count = int(re.search(r"MMF_TUN_COUNT = (\d+)", header).group(1))
+    keep = int(re.search(r"MMF_TUN_NT_SITE_KEEP = (\d+)", header).group(1))
+    assert keep == count - 1
+    assert built_lib.mmf_amd_get_tunable(keep) == 0                      # default: no exception, the round-3 behaviour
+    try:
+        assert built_lib.mmf_amd_set_tunable(keep, 0x1FE) == 0 and built_lib.mmf_amd_get_tunable(keep) == 0x1FE
+    finally:
+        assert built_lib.mmf_amd_set_tunable(keep, 0) == 0
+    assert built_lib.mmf_amd_set_tunable(count, 1) != 0                  # unknown tunable: refused
+    sites = {n: int(v) for n, v in re.findall(r"(MMF_SITE_[A-Z_]+) = (\d+)", header)}
+    assert sorted(sites.values()) == list(range(1, 9))
+    used = [int(x) for x in re.findall(r"debug_flags & (\d+)", open(os.path.join(ROOT, "mmf_amd", "csrc", "gemm.hip")).read())]
+    assert used and all(u < (1 << 20) for u in used)
+    ops = open(os.path.join(ROOT, "mmf_amd", "csrc", "torch_ops.cpp")).read()
+    assert all(n in ops for n in sites), [n for n in sites if n not in ops]

@@ -212,3 +212,24 @@ def test_vilbert_sum_fusion_and_frozen_base_plumbing():
     m = MU.build_vilbert(cfg, sd, device="cpu", freeze_base=True)
     _step(m, sample)
     assert all(p.grad is None for n, p in m.named_parameters() if n.startswith("model.bert."))
+
+
+@pytest.mark.parametrize("name", ["visual_bert", "mmbt", "vilbert", "uniter", "m4c"])
+def test_a_cloned_static_batch_runs_through_the_model_twice(name):
+    """What GraphedTrainStep does with its batch (mmf_amd/utils/graph.py::_clone_batch: a SampleList filled by item assignment, no tensor field
+    recorded) and what the model makes of it: `to_device` rebuilds it (sample.py:400-420) and the forward works on a copy, so calling the model
+    again on the SAME static batch sees the caller's fields only (MMBT shifts `input_ids` in its forward, VisualBERT attaches masks)."""
+    from mmf_amd.utils.graph import _clone_batch
+    z, model, sample, prefix = CASES[name]()
+    model.train()
+    static = _clone_batch(SampleList(sample))
+    assert static._get_tensor_field() is None
+    before = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in static.items()}
+    with native_stub.installed():
+        for _ in range(2):
+            out = model(static)
+            assert "losses" in out and len(out["losses"]) >= 1
+            assert list(static.keys()) == list(before.keys())
+            for k, v in before.items():
+                if isinstance(v, torch.Tensor):
+                    assert static[k] is not None and torch.equal(static[k], v), k

@@ -40,7 +40,9 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_ATTN_FWD_OLD = 7,   /* 1: head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head (the round-2 form; A/B) */
        MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
                                       kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B, tools/nt_site_ab.sh) */
-       MMF_TUN_COUNT = 9 };
+       MMF_TUN_GELU_WIDE = 9,      /* tile of the forward GEMMs with the GELU epilogue (act 1): 0 the 128-row kernel (two workgroups per CU hide the erf / exp
+                                      of one behind the other's K-loop: 60.5 vs 70.7 us when last measured, before the non-temporal stores), 1 / 2 / 3 force a wide tile (A/B) */
+       MMF_TUN_COUNT = 10 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)

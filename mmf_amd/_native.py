@@ -127,6 +127,8 @@ def lib():
         L.mmf_amd_set_tunable(6, int(os.environ["MMF_AMD_EPI_NT"]))
     if os.environ.get("MMF_AMD_NT_SITE_KEEP"):   # A/B switch: bit s = the tagged GEMM call site s keeps its bf16 output temporal (see MMF_TUN_NT_SITE_KEEP)
         L.mmf_amd_set_tunable(8, int(os.environ["MMF_AMD_NT_SITE_KEEP"], 0))
+    if os.environ.get("MMF_AMD_GELU_WIDE"):      # A/B switch: wide tile 1..3 for the GELU up-projection (see MMF_TUN_GELU_WIDE)
+        L.mmf_amd_set_tunable(9, int(os.environ["MMF_AMD_GELU_WIDE"]))
     if os.environ.get("MMF_AMD_GEMM_WIDE_KS"):
         L.mmf_amd_set_tunable(5, int(os.environ["MMF_AMD_GEMM_WIDE_KS"]))
     if os.environ.get("MMF_AMD_ATTN_FWD_OLD"):

@@ -402,7 +402,10 @@ static int wide_choice(const mmf_gemm_desc* d) {
     if (force >= 1 && force <= 3) return (d->N % BNs[force]) == 0 ? force : 0;
     // One workgroup per CU cannot hide a heavy epilogue behind a co-resident workgroup's K loop: the GELU up-projection (two
     // bf16 outputs, erf + exp per element) measured 70.7 us with wide tiles against 60.5 us inside the training step.
-    if (d->act == 1) return 0;
+    if (d->act == 1) {      // MMF_TUN_GELU_WIDE re-opens the question on a later tree (A/B): 1 / 2 / 3 = that wide tile for the GELU GEMMs
+        const int g = mmf_amd_get_tunable(MMF_TUN_GELU_WIDE);
+        return (g >= 1 && g <= 3 && (d->N % BNs[g]) == 0) ? g : 0;
+    }
     double best = tile_cost(d->M, d->N, d->K, 128, 128, 2);
     if ((d->N % 96) == 0) { const double c = tile_cost(d->M, d->N, d->K, 128, 96, 2); if (c < best) best = c; }
     int pick = 0;

@@ -18,3 +18,5 @@ if [ "$1" = "quick" ]; then MASKS="0 0x08 0x28 0x2a 0x1fe 0"; else MASKS="0 0x02
 for m in $MASKS; do run $m; done
 for m in $MASKS; do run $m; done
 sort -k2 -n $out/ab.log | head -8
+# second question on the same box: the GELU up-projection on a wide tile (MMF_TUN_GELU_WIDE; 70.7 vs 60.5 us before the non-temporal stores)
+for g in 0 3 1 0 3 1; do MMF_AMD_GELU_WIDE=$g python bench.py --no-cpu-baseline --no-fp32 2>/dev/null | line "gelu_wide=$g" | tee -a $out/gelu.log; done

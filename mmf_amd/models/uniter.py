@@ -16,6 +16,7 @@ heads); mrfr (tied regression + MSE) and wra (optimal-transport alignment, 50 IP
 reference does; the random region masks come from the same numpy / random calls as the reference's `_get_img_mask`."""
 import copy
 import random
+from collections import namedtuple
 
 import numpy as np
 import torch
@@ -53,6 +54,9 @@ def _bert_config(bert_model_name, overrides):
     return BertConfig.from_dict(d)
 
 
+TransformerOutput = namedtuple("TransformerOutput", ["final_layer", "hidden_layers"])
+
+
 class UNITERImageEmbeddings(nn.Module):
     """uniter.py:45-87."""
 
@@ -67,7 +71,10 @@ class UNITERImageEmbeddings(nn.Module):
         self.dropout = Dropout(hidden_dropout_prob)
 
     def forward(self, img_feat, img_pos_feat, type_embeddings, img_masks=None):
-        """`type_embeddings` is `(type_ids [B, R], token_type table)`: the lookup is part of the fused sum here."""
+        """`type_embeddings`: `(type_ids [B, R], token_type table)` — the lookup is then part of the fused sum (what UNITERModelBase passes) —
+        or, as in the reference's signature (uniter.py:69-87), a tensor that broadcasts against [B, R, hidden] and is simply added."""
+        if isinstance(type_embeddings, torch.Tensor):
+            return self._forward_with_type_tensor(img_feat, img_pos_feat, type_embeddings, img_masks)
         type_ids, type_table = type_embeddings
         if F32T.active():      # mmf_amd.fp32_training(): fp32 forward + backward
             if img_masks is not None:
@@ -95,6 +102,20 @@ class UNITERImageEmbeddings(nn.Module):
             Fn.SmallKLinearFn.apply(img_pos_feat, self.pos_linear.weight, self.pos_linear.bias))             # :81
         embeddings = Fn.AddPosTypeFn.apply(Fn.AddFn.apply(transformed_im, transformed_pos), type_ids, None, type_table)  # :82
         return self.dropout(self.final_layer_norm(embeddings))                                               # :83-84
+
+
+    def _forward_with_type_tensor(self, img_feat, img_pos_feat, type_embeddings, img_masks):
+        if F32T.active() or F32P.active():
+            raise NotImplementedError("UNITERImageEmbeddings: a tensor of type embeddings is taken on the bf16 path only; pass (type_ids, table)")
+        if img_masks is not None:
+            self.mask_embedding.weight.data[0, :].fill_(0)
+        feats = Fn.FeatureTableAddFn.apply(img_feat, None if img_masks is None else img_masks.long(), self.mask_embedding.weight, 0)
+        transformed_im = self.img_layer_norm(self.img_linear(feats))
+        transformed_pos = self.pos_layer_norm(Fn.SmallKLinearFn.apply(img_pos_feat, self.pos_linear.weight, self.pos_linear.bias))
+        summed = Fn.AddFn.apply(transformed_im, transformed_pos)
+        t = type_embeddings if type_embeddings.is_floating_point() else type_embeddings.float()
+        t = t.to(summed.device).expand(summed.shape).contiguous()
+        return self.dropout(self.final_layer_norm(Fn.AddFn.apply(summed, t)))
 
 
 class UNITERModelBase(nn.Module):
@@ -147,7 +168,7 @@ class UNITERModelBase(nn.Module):
             embedding_output = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_feat, img_masks,
                                                                 txt_type_ids, img_type_ids)
         encoded = self.encoder(embedding_output, mask_add.view(am.shape[0], 1, 1, am.shape[1]), output_hidden_states=True)
-        return encoded[0], encoded[1]            # (final_layer, hidden_layers)
+        return TransformerOutput(encoded[0], encoded[1])          # the reference's named pair (uniter.py:245-247)
 
 
 def _infer_with_heads(processed_sample_list, uniter_model, heads, losses):

@@ -62,7 +62,22 @@ class MMFTransformer(BaseTransformer):
         if "text" in self.modality_type:
             idx = self.modality_type.index("text")
             for head in self.heads:
+                if self.config.get("tie_weight_to_encoder", None):
+                    # :150-170: tie to the token embedding of a TRANSFORMER text encoder in front of the backend.  Only identity encoders
+                    # are on the built path, and for those the reference raises the same error (no `transformer` / `embeddings` to tie to)
+                    self._find_unique_encoder_key(self.config.tie_weight_to_encoder)
+                    raise NotImplementedError("Current encoder module arch not supported.")
                 head.tie_weights(self.backend.embeddings.token_embeddings[idx])
+
+    def _find_unique_encoder_key(self, key):
+        """mmf_transformer.py:433-445."""
+        assert key in self.encoders, "MMFT doesn't have %s encoder." % key
+        for modality in self.config.modalities:
+            if modality["key"] == key:
+                assert len([m for m in self.config.modalities if m["key"] == key]) == 1, "MMFT has multiple modalities with the same key %s." % key
+                assert len([m for m in self.config.modalities if m["type"] == modality["type"]]) == 1, \
+                    "Encoder %s should be the only encoder for %s." % (key, modality["type"])
+                return key
 
     # ---- preprocess_sample, mmf_transformer.py:180-401 ------------------------------------------
     def preprocess_sample(self, sample_list):

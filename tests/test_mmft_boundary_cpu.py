@@ -65,6 +65,14 @@ def test_optimizer_groups_and_unbuilt_variants():
     assert m.heads[0].cls.predictions.decoder.weight is m.backend.embeddings.token_embeddings[0].weight
     assert sorted(m.heads[0].state_dict().keys()) == sorted(str(k) for k in zh["mlm_state_dict_keys"])
     assert sorted(m.heads[1].state_dict().keys()) == sorted(str(k) for k in zh["itm_state_dict_keys"])
+    # `tie_weight_to_encoder` (mmf_transformer.py:150-170) names a TRANSFORMER text encoder whose token table the head shares; with the
+    # identity encoders of the built path the reference raises too — never a silent tie to some other table
+    text_key = [mm["key"] for mm in cfg["modalities"] if mm["type"] == "text"][0]
+    mlm = [dict(type="mlm", vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"])]
+    with pytest.raises(NotImplementedError, match="Current encoder module arch not supported"):
+        build_model(mmft_model_config(cfg, heads=mlm, tie_weight_to_encoder=text_key))
+    with pytest.raises(AssertionError, match="MMFT doesn't have nope encoder"):
+        build_model(mmft_model_config(cfg, heads=mlm, tie_weight_to_encoder="nope"))
 
 
 # ---- the reference's own preprocessing tests (tests/models/test_mmf_transformer.py:183-402), ported ----------------------------------

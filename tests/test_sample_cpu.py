@@ -146,3 +146,19 @@ def test_pin_memory():
     sample_list.pin_memory()
     assert sample_list.y.is_pinned() and sample_list.z.y.is_pinned()
     assert not any(hasattr(v, "is_pinned") and v.is_pinned() for v in (sample_list.x, sample_list.z.x))
+
+
+def test_batch_collator_call():
+    """/root/reference/tests/common/test_batch_collator.py, ported: the collate function in front of the model."""
+    from mmf_amd.common.batch_collator import BatchCollator
+    batch_collator = BatchCollator("vqa2", "train")
+    sample_list = build_random_sample_list()
+    sample_list = batch_collator(sample_list)
+    assert sample_list.dataset_name == "vqa2" and sample_list.dataset_type == "train"      # an already built sample list
+    sample = Sample()
+    sample.a = torch.tensor([1, 2], dtype=torch.int)
+    sample_list = batch_collator([sample, sample])                                         # a list of samples
+    assert torch.equal(sample_list.a, torch.tensor([[1, 2], [1, 2]], dtype=torch.int))
+    sample_list = build_random_sample_list()                                               # the IterableDataset case
+    new_sample_list = batch_collator([sample_list])
+    assert new_sample_list == sample_list

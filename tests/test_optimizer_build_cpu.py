@@ -116,9 +116,15 @@ def test_build_scheduler():
     assert lrs == pytest.approx([0.0, 0.5, 1.0, 0.875])
     with pytest.raises(ValueError, match="No scheduler class of type"):
         build_scheduler(opt, Config(scheduler=dict(type="no_such_scheduler", params={})))
-    with pytest.warns(UserWarning):
-        with pytest.raises(ValueError):      # the reference's default name ("pythia") is not a scheduler of this path
-            build_scheduler(opt, Config())
+    from mmf_amd.common.registry import registry
+    saved = registry.mapping["state"].pop("config", None)
+    try:
+        with pytest.warns(UserWarning, match="setting default to 'Pythia'"):
+            with pytest.raises(RuntimeError):    # the default, 'pythia', needs the global configuration (none is registered here)
+                build_scheduler(opt, Config())
+    finally:
+        if saved is not None:
+            registry.register("config", saved)
 
 
 def test_clip_gradients_modes():
@@ -149,3 +155,63 @@ def test_clip_gradients_modes():
     assert float(clip_gradients(model, Own(), 0, None, cfg)) == 5.0 and seen["asked"] == 1.0     # the optimizer's own reduction is preferred
     with pytest.raises(NotImplementedError, match="Clip norm mode question not implemented"):
         clip_gradients(model, opt, 0, None, Config(training=dict(max_grad_l2_norm=1.0, clip_norm_mode="question")))
+
+
+def _sgd(lr=1.0):
+    model = SimpleModel({})
+    model.build()
+    return torch.optim.SGD(model.parameters(), lr=lr)
+
+
+def _run(opt, sched, n):
+    out = []
+    for _ in range(n):
+        out.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+    return out
+
+
+def test_schedules_equal_the_transformers_functions():
+    """`warmup_linear` / `warmup_cosine` are transformers' get_*_schedule_with_warmup in the reference (schedulers.py:34-43)."""
+    import transformers
+    from mmf_amd.common.registry import registry
+    for name, ref_fn in (("warmup_linear", transformers.get_linear_schedule_with_warmup), ("warmup_cosine", transformers.get_cosine_schedule_with_warmup)):
+        a, b = _sgd(0.3), _sgd(0.3)
+        ours = registry.get_scheduler_class(name)(a, num_warmup_steps=3, num_training_steps=11)
+        theirs = ref_fn(b, num_warmup_steps=3, num_training_steps=11)
+        assert _run(a, ours, 13) == pytest.approx(_run(b, theirs, 13), abs=1e-12), name
+
+
+def test_pythia_and_multi_step_schedules_follow_lr_lambda_update():
+    """M4C's schedule (projects/m4c/configs/textvqa/defaults.yaml:76-86): warm-up from warmup_factor, then lr_ratio per lr_step passed."""
+    from mmf_amd.common.registry import registry
+    from mmf_amd.modules.schedulers import lr_lambda_update
+    training = dict(use_warmup=True, warmup_iterations=4, warmup_factor=0.2, lr_steps=[6, 8], lr_ratio=0.1)
+    cfg = Config(training=training)
+    want = [0.2, 0.4, 0.6, 0.8, 1.0, 1.0, 0.1, 0.1, 0.01, 0.01]
+    assert [lr_lambda_update(i, cfg) for i in range(10)] == pytest.approx(want)
+    with pytest.raises(RuntimeError, match="'pythia' scheduler reads"):
+        saved = registry.mapping["state"].pop("config", None)
+        try:
+            registry.get_scheduler_class("pythia")(_sgd())
+        finally:
+            if saved is not None:
+                registry.register("config", saved)
+    saved = registry.mapping["state"].get("config", None)
+    registry.register("config", cfg)
+    try:
+        opt = _sgd(2.0)
+        sched = build_scheduler(opt, Config(scheduler=dict(params={})))            # no type: the reference's default, 'pythia' (with its warning)
+        assert _run(opt, sched, 10) == pytest.approx([2.0 * w for w in want])
+    finally:
+        if saved is None:
+            registry.mapping["state"].pop("config", None)
+        else:
+            registry.register("config", saved)
+    opt = _sgd(2.0)
+    sched = registry.get_scheduler_class("multi_step")(opt, **training)
+    assert _run(opt, sched, 10) == pytest.approx([2.0 * w for w in want])
+    with pytest.raises(AssertionError):
+        registry.get_scheduler_class("multi_step")(_sgd(), **dict(training, warmup_iterations=7))
+    assert lr_lambda_update(100, Config(training=dict(training, use_warmup=False))) == pytest.approx(0.01)

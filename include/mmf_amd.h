@@ -42,7 +42,9 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
                                       kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B, tools/nt_site_ab.sh) */
        MMF_TUN_GELU_WIDE = 9,      /* tile of the forward GEMMs with the GELU epilogue (act 1): 0 the 128-row kernel (two workgroups per CU hide the erf / exp
                                       of one behind the other's K-loop: 60.5 vs 70.7 us when last measured, before the non-temporal stores), 1 / 2 / 3 force a wide tile (A/B) */
-       MMF_TUN_COUNT = 10 };
+       MMF_TUN_WGRAD_WIDE = 10,    /* grouped weight-gradient launch: 0 the 256x128 wide tile when every problem is a whole number of such tiles and the launch fills
+                                      most of a round of the 256 CUs, 1 never (the 128x128 tiles, two workgroups per CU), 2 whenever the shapes allow (A/B) */
+       MMF_TUN_COUNT = 11 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)

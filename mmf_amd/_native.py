@@ -135,6 +135,10 @@ def lib():
         L.mmf_amd_set_tunable(7, int(os.environ["MMF_AMD_ATTN_FWD_OLD"]))
     if os.environ.get("MMF_AMD_LN_OLD"):
         L.mmf_amd_set_tunable(3, int(os.environ["MMF_AMD_LN_OLD"]))
+    if os.environ.get("MMF_AMD_TUN"):            # generic A/B switch: "id:value,id:value" (include/mmf_amd.h MMF_TUN_*)
+        for kv in os.environ["MMF_AMD_TUN"].split(","):
+            k, v = kv.split(":")
+            L.mmf_amd_set_tunable(int(k), int(v, 0))
     if os.environ.get("MMF_AMD_ATTN_BWD_TWO_PASS"):
         L.mmf_amd_set_tunable(4, int(os.environ["MMF_AMD_ATTN_BWD_TWO_PASS"]))
     return L
@@ -540,6 +544,7 @@ def tanh_bwd(dy, y, dx):
 
 
 TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE, TUN_LN_OLD, TUN_ATTN_BWD_TWO_PASS = 0, 1, 2, 3, 4
+TUN_WGRAD_WIDE = 10
 
 
 def set_tunable(which, value):

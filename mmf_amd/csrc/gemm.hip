@@ -271,6 +271,24 @@ __global__ __launch_bounds__(128 * NWN, NWN) void gemm_bf16_grouped_kernel(Group
                                                                   P.lda, P.ldb, tile_m, tile_n, 0, 1, 0, P.epi, smem, pr);
 }
 
+// The same grouping on the wide tile (gemm_wide.h, one workgroup per CU, ping-pong K-loop on a three-stage LDS-DMA ring): the weight
+// gradients of a layer are 114 K-steps long, so the K-loop rate is all that matters, and the 128-row kernel's two workgroups per CU
+// stage 64 FLOP per byte against 85 for 256 x 128.  216 tiles for the VisualBERT layer (72 + 72 + 54 + 18): one round on 256 CUs.
+template <int BM_, int BN_, int WGM, int WGN, bool AKM, bool BKM, bool RS>
+__global__ __launch_bounds__(512, 2) void gemm_wide_grouped_kernel(GroupArgs g, Probe pr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int bid = wide_xcd_remap(blockIdx.x, g.total);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXG; ++i) gi += (i < g.count && bid >= g.start[i]) ? 1 : 0;
+    const GroupProblem& P = g.p[gi];
+    bid -= g.start[gi];
+    int tile_m, tile_n;
+    wide_super_row(bid, P.tiles_m, P.tiles_n, tile_m, tile_n);
+    wide_tile<BM_, BN_, WGM, WGN, 3, false, 1, 0, AKM, BKM, RS>(reinterpret_cast<const bf16*>(P.A), reinterpret_cast<const bf16*>(P.B), P.M, P.N, P.K, P.lda,
+                                                               P.ldb, tile_m, tile_n, P.epi, pr, smem);
+}
+
 // C[m][n] = beta * C[m][n] + sum_s slab[s][m][n]   (N % 4 == 0).  Behind the `splits` slabs the workspace holds
 // [splits][M] row-sum partials (bias gradient); the threads past the last float4 group sum those into rowsum[m].
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long n, int N, int M,
@@ -345,6 +363,22 @@ int launch_grouped_n(const GroupArgs& g, hipStream_t s) {
     return 0;
 }
 
+
+template <int BM_, int BN_, int WGM, int WGN, bool AKM, bool BKM, bool RS>
+int launch_wide_grouped(const GroupArgs& g, hipStream_t s) {
+    constexpr int lds_bytes = 3 * (BM_ + BN_) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_grouped_kernel<BM_, BN_, WGM, WGN, AKM, BKM, RS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
+        attr_set = true;
+    }
+    g_last_kernel = "gemm_wide_grouped_kernel 256x128";
+    hipLaunchKernelGGL((gemm_wide_grouped_kernel<BM_, BN_, WGM, WGN, AKM, BKM, RS>), dim3(g.total), dim3(512), lds_bytes, s, g, next_probe());
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
 
 // ---- wide tiles (gemm_wide.h): one workgroup per CU ---------------------------------------------------------------------
 template <int BM_, int BN_, int WGM, int WGN, int NS, int KS = 1>
@@ -587,6 +621,29 @@ extern "C" int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void
     }
     for (int i = count; i <= MAXG; ++i) g.start[i] = total;
     g.total = total;
+    // weight-gradient form on the wide tile: every problem a whole number of 256 x 128 tiles and 64-deep K-steps, plain fp32 outputs
+    if (key == 3 && mmf_amd_get_tunable(MMF_TUN_WGRAD_WIDE) != 1) {
+        bool ok = true;
+        int wtotal = 0;
+        for (int i = 0; i < count; ++i) {
+            const mmf_gemm_desc* d = descs + i;
+            ok = ok && (d->M % 256) == 0 && (d->N % 128) == 0 && (d->K % 64) == 0 && d->K >= 192 && d->out_f32 && !d->bias && !d->coladd && !d->rowtab &&
+                 d->act == 0 && !d->resid && !d->drop_thr16 && d->grp_in == 0 && (d->ldc % 4) == 0;
+            wtotal += (d->M / 256) * (d->N / 128);
+        }
+        // (a launch far below one round of the 256 CUs is better off on the 128-row tiles: twice the workgroups, two per CU)
+        if (ok && (wtotal >= 160 || mmf_amd_get_tunable(MMF_TUN_WGRAD_WIDE) == 2)) {
+            int t = 0;
+            for (int i = 0; i < count; ++i) {
+                g.p[i].tiles_m = descs[i].M / 256; g.p[i].tiles_n = descs[i].N / 128;
+                g.start[i] = t;
+                t += g.p[i].tiles_m * g.p[i].tiles_n;
+            }
+            for (int i = count; i <= MAXG; ++i) g.start[i] = t;
+            g.total = t;
+            return rowsum ? launch_wide_grouped<256, 128, 4, 2, true, true, true>(g, s) : launch_wide_grouped<256, 128, 4, 2, true, true, false>(g, s);
+        }
+    }
     switch (key) {
         case 0: return ragged ? launch_grouped_n<bf16, bf16, false, false, true, 4, 128>(g, s) : launch_grouped_n<bf16, bf16, false, false, false, 4, 128>(g, s);
         case 2: return ragged ? launch_grouped_n<bf16, bf16, false, true, true, 4, 128>(g, s) : launch_grouped_n<bf16, bf16, false, true, false, 4, 128>(g, s);

@@ -39,9 +39,15 @@ template <int N> DEVI void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(
 //           0.41 us per step, MFMA + fragment reads 0.58, everything 0.68: a LOAD interval — 4 waves x 14 reads + the DMA writes
 //           landing in the same LDS — is longer than the COMP interval it is meant to hide behind).  The two K-halves are summed
 //           in the epilogue's LDS stage (group 1 adds in place before the row-wise pass).
-template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int KS = 1, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
-                                                            int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi, Probe pr) {
+// AKM / BKM: the operand is k-major (A(m,k) = A[k * lda + m]): the weight-gradient form dW = dY^T X, both operands token-major with the
+//   reduction running over their rows.  Its LDS image is the 128-row kernel's ([64 k-rows][256 B] per 128 tile rows, bytes rotated per
+//   k-row, read with ds_read_b64_tr_b16: gemm_common.h), one 16 KiB sub-image per 128 tile rows; a DMA piece is 32 k-rows of one
+//   sub-image, so pieces, ring slots and the whole schedule are those of the row-major form.
+// RS: the bias gradient rides on the launch (EpiArgs::rowsum_direct): the tile_n == 0 workgroups multiply every A fragment once more
+//   against an all-ones operand (see gemm_tile in gemm.hip).
+template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int KS, int ABL, bool AKM, bool BKM, bool RS>
+DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb, int tile_m, int tile_n,
+                    const EpiArgs& epi, const Probe& pr, unsigned char* smem) {
     // ABL (ablation builds only, -DMMF_WIDE_ABLATE): bit 0 no DMA issue in the loop, bit 1 no MFMA, bit 2 no fragment reads, bit 3 no epilogue
     constexpr int dbg = ABL;
     static_assert(KS == 1 || KS == 2, "K split across the two ping-pong groups");
@@ -49,7 +55,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
     constexpr int KK = 2 / KS;                   // 32-deep sub-steps a wave multiplies per 64-deep K-step
     static_assert(NS == 3, "the schedule below is written for a three-stage ring");
     static_assert(BM_ % 64 == 0 && BN_ % 32 == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(!AKM || (BM_ % 128 == 0 && !RAGGED_M), "k-major A: whole 128-row sub-images");
+    static_assert(!BKM || BN_ % 128 == 0, "k-major B: whole 128-row sub-images");
+    static_assert(!RS || (AKM && KS == 1), "row sums ride on the weight-gradient form");
     constexpr int WTM = BM_ / WGM, WTN = BN_ / WGN, NFM = WTM / 16, NFN = WTN / 16;
     constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int PA = BM_ / 64;                 // LDS-DMA wave-instructions per wave for the A image (64 rows each, all 8 waves)
@@ -66,21 +74,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
     if (probing) pt[0] = __builtin_amdgcn_s_memrealtime();
 
-    // tile order: XCD-aware contiguous runs, 4-row super-rows (column-major inside) so an XCD's resident tiles share panels
-    const int ntile = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    int tile_m, tile_n;
-    {
-        const int per_sr = 4 * tiles_n;
-        const int sr = bid / per_sr, rem = bid - sr * per_sr;
-        const int h = min(4, tiles_m - sr * 4);
-        tile_n = rem / h;
-        tile_m = sr * 4 + (rem - tile_n * h);
-    }
     const int m0 = tile_m * BM_, n0 = tile_n * BN_;
     const int nk = K / BK;
 
@@ -90,33 +83,45 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
     const int kchunk = ((tid & 7) ^ sw) * 8;
     const bf16* pa[PA];
     const bf16* pb[PB_FULL + 1];          // (the last entry is the trailing half piece; unused unless B_HALF)
+    // k-major piece i: k-rows (tid >> 4) + 32 * (i & 1) of sub-image i >> 1; the row's rotation is applied to the source column
+    const int km_kr = tid >> 4;
+    const int km_col = (((tid & 15) - (rot_kmajor(km_kr) >> 4)) & 15) * 8;      // (the rotation repeats every 16 k-rows: same for both halves)
+    const size_t a_step = AKM ? (size_t)BK * lda : (size_t)BK, b_step = BKM ? (size_t)BK * ldb : (size_t)BK;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        int row = m0 + (tid >> 3) + 64 * i;
-        if (RAGGED_M) row = row < M ? row : M - 1;
-        pa[i] = A + (size_t)row * lda + kchunk;
+        if constexpr (AKM) {
+            pa[i] = A + (size_t)(km_kr + 32 * (i & 1)) * lda + m0 + (i >> 1) * 128 + km_col;
+        } else {
+            int row = m0 + (tid >> 3) + 64 * i;
+            if (RAGGED_M) row = row < M ? row : M - 1;
+            pa[i] = A + (size_t)row * lda + kchunk;
+        }
     }
 #pragma unroll
     for (int i = 0; i < PB_FULL + 1; ++i) {
-        int row = n0 + (tid >> 3) + 64 * i;
-        row = row < N ? row : N - 1;            // (only the never-issued upper half of a trailing half piece can be out of range)
-        pb[i] = B + (size_t)row * ldb + kchunk;
+        if constexpr (BKM) {
+            pb[i] = B + (size_t)(km_kr + 32 * (i & 1)) * ldb + n0 + (i >> 1) * 128 + km_col;
+        } else {
+            int row = n0 + (tid >> 3) + 64 * i;
+            row = row < N ? row : N - 1;            // (only the never-issued upper half of a trailing half piece can be out of range)
+            pb[i] = B + (size_t)row * ldb + kchunk;
+        }
     }
     auto issue = [&](int slot) {
         unsigned char* st = smem + slot * STAGE + wave * 1024;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             __builtin_amdgcn_global_load_lds((glb_vp)pa[i], (lds_vp)(st + i * 8192), 16, 0, 0);
-            pa[i] += BK;
+            pa[i] += a_step;
         }
 #pragma unroll
         for (int i = 0; i < PB_FULL; ++i) {
             __builtin_amdgcn_global_load_lds((glb_vp)pb[i], (lds_vp)(st + A_BYTES + i * 8192), 16, 0, 0);
-            pb[i] += BK;
+            pb[i] += b_step;
         }
         if (B_HALF) {
             if (wave < 4) __builtin_amdgcn_global_load_lds((glb_vp)pb[PB_FULL], (lds_vp)(st + A_BYTES + PB_FULL * 8192), 16, 0, 0);
-            pb[PB_FULL] += BK;
+            pb[PB_FULL] += b_step;
         }
     };
     f32x4 acc[NFM][NFN];
@@ -125,12 +130,54 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
 #pragma unroll
         for (int j = 0; j < NFN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[KK][NFM], fb[KK][NFN];
+    // bias gradient riding on the weight-gradient form: rowsum[m] = sum_k A(m, k), one extra MFMA per A fragment against all-ones
+    // (every row of that 16 x 16 result holds the sums); only the first column of tiles and of waves does it
+    const bool do_rowsum = RS && epi.rowsum_direct != nullptr && tile_n == 0 && wn == 0;
+    f32x4 accr[RS ? NFM : 1];
+#pragma unroll
+    for (int i = 0; i < (RS ? NFM : 1); ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 
     // fragment addresses: row operand image, fragment f (16 rows), sub-step kk: lane l -> row (l & 15), chunk kk*4 + (l >> 4)
     const int frow = lane & 15, fswz = lane & 7;
     const int a_off = (wm * WTM + frow) * 128, b_off = A_BYTES + (wn * WTN + frow) * 128;
     const int c0_ = (((lane >> 4)) ^ fswz) << 4, c1_ = ((4 + (lane >> 4)) ^ fswz) << 4;
     const int c0 = (KS == 2 && grp == 1) ? c1_ : c0_, c1 = c1_;     // KS = 2: the wave's only sub-step is K-half `grp`
+    // k-major image (read_frag<true> of gemm_common.h, addresses hoisted): lane (g = l >> 4, p = l & 15) reads 8 bytes at k-row
+    // 32 kk + 8 g + (p >> 2) (+ 4 for the second half) of its sub-image, byte column ((col * 2 + rot) & 255), col = the fragment's
+    // first tile row + 4 (p & 3), rot = 32 ((p >> 2) + 4 (g & 1)); sub-step kk adds 32 k-rows = 8192 bytes.
+    int ka_off[AKM ? NFM : 1], kb_off[BKM ? NFN : 1];
+    if constexpr (AKM || BKM) {
+        const int g = lane >> 4, p = lane & 15;
+        const int rot = 32 * ((p >> 2) + 4 * (g & 1)), krow = (8 * g + (p >> 2)) * 256;
+        const int kk0 = (KS == 2 && grp == 1) ? 8192 : 0;
+        if constexpr (AKM) {
+#pragma unroll
+            for (int f = 0; f < NFM; ++f) {
+                const int r = wm * WTM + f * 16;          // tile row of the fragment
+                ka_off[f] = (r >> 7) * 16384 + krow + ((((r & 127) + (p & 3) * 4) * 2 + rot) & 255) + kk0;
+            }
+        }
+        if constexpr (BKM) {
+#pragma unroll
+            for (int f = 0; f < NFN; ++f) {
+                const int r = wn * WTN + f * 16;
+                kb_off[f] = A_BYTES + (r >> 7) * 16384 + krow + ((((r & 127) + (p & 3) * 4) * 2 + rot) & 255) + kk0;
+            }
+        }
+    }
+    auto read_km = [&](const unsigned char* q) {
+        typedef s16x4 __attribute__((address_space(3))) * lds_p;
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(q));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(q + 1024));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, r);
+    };
     // LOAD: all 2 * (NFM + NFN) fragments of a K-step, with the P DMA pieces of the stage issued in between (one piece after
     // every few reads, order pinned): the LDS read port and the address path of the LDS-DMA are different units.
     constexpr int NREAD = KK * (NFM + NFN);
@@ -144,8 +191,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
         for (int r = 0; r < NREAD; ++r) {
             const int kk = r / (NFM + NFN), f = r % (NFM + NFN);
             const int coff = kk ? c1 : c0;
-            if (f < NFN) fb[kk][f] = *reinterpret_cast<const bf16x8*>(st + b_off + f * 2048 + coff);
-            else fa[kk][f - NFN] = *reinterpret_cast<const bf16x8*>(st + a_off + (f - NFN) * 2048 + coff);
+            if (f < NFN) {
+                if constexpr (BKM) fb[kk][f] = read_km(st + kb_off[f] + kk * 8192);
+                else fb[kk][f] = *reinterpret_cast<const bf16x8*>(st + b_off + f * 2048 + coff);
+            } else {
+                if constexpr (AKM) fa[kk][f - NFN] = read_km(st + ka_off[f - NFN] + kk * 8192);
+                else fa[kk][f - NFN] = *reinterpret_cast<const bf16x8*>(st + a_off + (f - NFN) * 2048 + coff);
+            }
             // after read r, issue the pieces that are due: piece q goes after read floor((q + 1) * NREAD / (PT + 1)) - 1
 #pragma unroll
             for (int q = 0; q < PT; ++q) {
@@ -154,13 +206,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
                     if (with_issue && !(dbg & 1)) {
                         if (q < PA) {
                             __builtin_amdgcn_global_load_lds((glb_vp)pa[q], (lds_vp)(ist + q * 8192), 16, 0, 0);
-                            pa[q] += BK;
+                            pa[q] += a_step;
                         } else if (q < PA + PB_FULL) {
                             __builtin_amdgcn_global_load_lds((glb_vp)pb[q - PA], (lds_vp)(ist + A_BYTES + (q - PA) * 8192), 16, 0, 0);
-                            pb[q - PA] += BK;
+                            pb[q - PA] += b_step;
                         } else {
                             if (wave < 4) __builtin_amdgcn_global_load_lds((glb_vp)pb[PB_FULL], (lds_vp)(ist + A_BYTES + PB_FULL * 8192), 16, 0, 0);
-                            pb[PB_FULL] += BK;
+                            pb[PB_FULL] += b_step;
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -180,6 +232,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
 #pragma unroll
                 for (int j = 0; j < NFN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+        if constexpr (RS) {
+            if (do_rowsum) {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int i = 0; i < NFM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[kk][i], accr[i], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
@@ -275,6 +335,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
         return;
     }
 
+    if constexpr (RS) {
+        if (do_rowsum && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < NFM; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + lane;
+                if (m < M) epi.rowsum_direct[m] = accr[i][0];
+            }
+        }
+    }
     // epilogue: fp32 tile through the (idle) ring, WPP wave-rows per pass, then the row-wise fused epilogue
     float* cs = reinterpret_cast<float*>(smem);
     const uint32_t dkey = drop_key(epi.drop);
@@ -340,6 +409,28 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
             }
         }
     }
+}
+
+// tile order: XCD-aware contiguous runs, 4-row super-rows (column-major inside) so an XCD's resident tiles share panels
+DEVI int wide_xcd_remap(int bid, int ntile) {
+    const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+DEVI void wide_super_row(int bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    const int per_sr = 4 * tiles_n;
+    const int sr = bid / per_sr, rem = bid - sr * per_sr;
+    const int h = min(4, tiles_m - sr * 4);
+    tile_n = rem / h;
+    tile_m = sr * 4 + (rem - tile_n * h);
+}
+
+template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int KS = 1, int ABL = 0, bool AKM = false, bool BKM = false, bool RS = false>
+__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
+                                                            int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi, Probe pr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile_m, tile_n;
+    wide_super_row(wide_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tile_m, tile_n);
+    wide_tile<BM_, BN_, WGM, WGN, NS, RAGGED_M, KS, ABL, AKM, BKM, RS>(A, B, M, N, K, lda, ldb, tile_m, tile_n, epi, pr, smem);
 }
 
 }  // namespace gemm

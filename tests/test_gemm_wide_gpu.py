@@ -129,3 +129,87 @@ def test_wide_repeated_launches_are_stable(cfg, N, force_wide):
         C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         nat().gemm(A, B, C, M, N, K, K, K, N)
         assert torch.equal(C, C0), i
+
+
+# ---- weight-gradient form (both operands k-major) on the wide tile: the grouped launch of a layer's four weight gradients ----------
+@pytest.fixture
+def wgrad_tun():
+    def set_(v):
+        nat().set_tunable(nat().TUN_WGRAD_WIDE, v)
+    yield set_
+    nat().set_tunable(nat().TUN_WGRAD_WIDE, 0)
+
+
+def _layer_wgrad_problems(T, H, I, with_db, fill=float("nan")):
+    du = rnd(T, I, seed=1); a_out = rnd(T, H, seed=2); dlin2 = rnd(T, H, seed=3); hh = rnd(T, I, seed=4)
+    dqkv = rnd(T, 3 * H, seed=5); x = rnd(T, H, seed=6); dlin1 = rnd(T, H, seed=7); ctxt = rnd(T, H, seed=8)
+    specs = [(du, a_out, I, H), (dlin2, hh, H, I), (dqkv, x, 3 * H, H), (dlin1, ctxt, H, H)]
+    probs, outs = [], []
+    for dy, xx, N, K in specs:
+        dw = torch.full((N, K), fill, device=DEV)
+        db = torch.full((N,), fill, device=DEV) if with_db else None
+        probs.append(dict(A=dy, B=xx, C_out=dw, M=N, N=K, K=T, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True, rowsum_out=db))
+        outs.append((dw, db))
+    return specs, probs, outs
+
+
+@pytest.mark.parametrize("T", [7296, 640, 192])
+@pytest.mark.parametrize("with_db", [True, False])
+def test_wide_grouped_weight_gradients_match_torch_and_the_128_row_tiles(T, with_db, wgrad_tun):
+    """dW = dY^T X (+ db = column sums of dY) for the four GEMMs of a layer on 256 x 128 tiles (k-major LDS images read with the
+    transpose read, three-stage ring) against fp32 torch and against the 128 x 128 grouped launch: with the bias gradient riding along
+    both add the 32-deep K sub-steps in the same order into fp32 accumulators, so the results are bit-identical."""
+    import math
+    H, I = 768, 3072
+    specs, probs, outs = _layer_wgrad_problems(T, H, I, with_db)
+    wgrad_tun(2)
+    nat().gemm_grouped(probs)
+    assert "wide_grouped" in nat().gemm_last_kernel()
+    specs2, probs2, outs2 = _layer_wgrad_problems(T, H, I, with_db)
+    wgrad_tun(1)
+    nat().gemm_grouped(probs2)
+    assert "wide" not in nat().gemm_last_kernel()
+    for (dy, xx, N, K), (dw, db), (dw2, db2) in zip(specs, outs, outs2):
+        close(dw, dy.float().t() @ xx.float(), 1e-4, 2e-3 * math.sqrt(T) / 8, "wide grouped dW %dx%d" % (N, K))
+        if with_db:      # (without the bias gradient the 128-row launch splits every K-step between two wave groups: another fp32 summation order)
+            assert torch.equal(dw, dw2), "wide vs 128-row tiles, dW %dx%d: %g" % (N, K, float((dw - dw2).abs().max()))
+        else:
+            close(dw, dw2, 1e-5, 2e-4 * math.sqrt(T) / 8, "wide vs 128-row tiles")
+        if with_db:
+            close(db, dy.float().sum(0), 1e-5, 1e-3 * math.sqrt(T) / 8, "wide grouped bias gradient")
+            assert torch.equal(db, db2)
+
+
+def test_wide_grouped_weight_gradients_accumulate_with_beta(wgrad_tun):
+    """beta = 1 (gradient accumulation): the fp32 output is read back and added in the epilogue."""
+    T, H = 1280, 768
+    dy = rnd(T, 2 * H, seed=11); x = rnd(T, H, seed=12)
+    base = torch.randn(2 * H, H, device=DEV)
+    dw = base.clone()
+    wgrad_tun(2)
+    nat().gemm_grouped([dict(A=dy, B=x, C_out=dw, M=2 * H, N=H, K=T, lda=2 * H, ldb=H, ldc=H, a_kmajor=True, b_kmajor=True, beta=1.0)])
+    assert "wide_grouped" in nat().gemm_last_kernel()
+    close(dw, base + dy.float().t() @ x.float(), 1e-4, 2e-3, "accumulated dW")
+
+
+def test_wide_grouped_falls_back_when_a_problem_is_not_whole_tiles(wgrad_tun):
+    T, H = 640, 768
+    dy = rnd(T, 384, seed=21); x = rnd(T, H, seed=22)         # 384 output rows: not a multiple of 256
+    dw = torch.empty(384, H, device=DEV)
+    wgrad_tun(2)
+    nat().gemm_grouped([dict(A=dy, B=x, C_out=dw, M=384, N=H, K=T, lda=384, ldb=H, ldc=H, a_kmajor=True, b_kmajor=True)])
+    assert "wide" not in nat().gemm_last_kernel()
+    close(dw, dy.float().t() @ x.float(), 1e-4, 2e-3, "fallback dW")
+
+
+def test_wide_grouped_repeated_launches_are_stable(wgrad_tun):
+    """Race screen of the k-major ring (LDS-DMA pieces against transpose reads): 20 launches, identical bits."""
+    specs, probs, outs = _layer_wgrad_problems(7296, 768, 3072, True)
+    wgrad_tun(0)
+    nat().gemm_grouped(probs)
+    assert "wide_grouped" in nat().gemm_last_kernel()      # the default dispatch takes the wide tile for the encoder layer
+    first = [(dw.clone(), db.clone()) for dw, db in outs]
+    for _ in range(20):
+        nat().gemm_grouped(probs)
+    for (dw, db), (f_dw, f_db) in zip(outs, first):
+        assert torch.equal(dw, f_dw) and torch.equal(db, f_db)

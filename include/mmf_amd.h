@@ -44,7 +44,9 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
                                       of one behind the other's K-loop: 60.5 vs 70.7 us when last measured, before the non-temporal stores), 1 / 2 / 3 force a wide tile (A/B) */
        MMF_TUN_WGRAD_WIDE = 10,    /* grouped weight-gradient launch: 0 the 256x128 wide tile when every problem is a whole number of such tiles and the launch fills
                                       most of a round of the 256 CUs, 1 never (the 128x128 tiles, two workgroups per CU), 2 whenever the shapes allow (A/B) */
-       MMF_TUN_COUNT = 11 };
+       MMF_TUN_ADAM_GRID = 11,     /* > 0: cap on the workgroups of one mmf_adamw_multi launch (they stride over the 4096-element chunks): the form that runs beside
+                                      a GEMM launch; 0: one workgroup per chunk */
+       MMF_TUN_COUNT = 12 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)
@@ -131,6 +133,9 @@ int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream);
  * {launch << 32 | block, HW_ID | XCC_ID << 32, entry, first stage landed, K loop done, tile staged, stores drained, tile};
  * word 0 of the buffer counts the records.  NULL switches it off. */
 int mmf_gemm_set_probe(void* buf, int64_t capacity_records);
+/* Host-side log of the launches probed since mmf_gemm_set_probe: 5 int64 per launch {launch id, layout (bit 0 A k-major, bit 1 B k-major,
+ * bit 2 grouped), M, N, K} (grouped: problems, tiles, K) copied into out_host; returns the number of launches logged. */
+int mmf_gemm_probe_log(int64_t* out_host, int capacity);
 /* Development aid, attention kernels: like mmf_gemm_set_probe with one 96-byte record per WAVE {kernel (0 fwd, 1 dQ, 2 dK/dV),
  * batch * heads + head, 4 * blockIdx.y + wave, HW_ID, 8 stamps}.  Only a library built with -DMMF_ATTN_PROBE records (the
  * stamps are compiled out of the regular build, where the call returns 1); tools/attn_timeline.py. */

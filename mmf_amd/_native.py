@@ -262,6 +262,16 @@ def gemm_last_kernel():
     return f().decode()
 
 
+def gemm_probe_log():
+    """Host-side log of the launches probed since the last `gemm_set_probe(buf)`: list of (launch id, layout, M, N, K); layout bit 0 / 1 = A / B
+    k-major, bit 2 = grouped launch (then M, N = problems, tiles)."""
+    arr = (C.c_int64 * (5 * 4096))()
+    f = lib().mmf_gemm_probe_log
+    f.restype = C.c_int
+    n = min(int(f(arr, C.c_int(4096))), 4096)
+    return [tuple(int(arr[i * 5 + j]) for j in range(5)) for i in range(n)]
+
+
 def gemm_set_probe(buf):
     """Development aid: `buf` = zeroed int64 device tensor of 8 * (1 + capacity) words (or None to switch the probe off);
     while set, every GEMM workgroup appends a timeline record (see gemm.hip Probe)."""
@@ -545,6 +555,7 @@ def tanh_bwd(dy, y, dx):
 
 TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE, TUN_LN_OLD, TUN_ATTN_BWD_TWO_PASS = 0, 1, 2, 3, 4
 TUN_WGRAD_WIDE = 10
+TUN_ADAM_GRID = 11
 
 
 def set_tunable(which, value):

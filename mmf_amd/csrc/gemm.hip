@@ -318,9 +318,19 @@ static thread_local const char* g_last_kernel = "";
 
 // timeline probe state (host): set by mmf_gemm_set_probe, consumed by every GEMM launch while set
 static Probe g_probe = {nullptr, 0u, 0u};
+// host-side log of the probed launches: {launch id, layout (bit 0 A k-major, bit 1 B k-major, 4 = grouped), M, N, K} per launch
+static int64_t g_probe_log[4096][5];
+static int g_probe_nlog = 0;
+static int g_note[4] = {0, 0, 0, 0};        // layout, M, N, K of the call being launched (set by the entry points while probing)
 static Probe next_probe() {
     Probe p = g_probe;
-    if (p.buf) g_probe.launch++;
+    if (p.buf) {
+        if (g_probe_nlog < 4096) {
+            int64_t* r = g_probe_log[g_probe_nlog++];
+            r[0] = p.launch; r[1] = g_note[0]; r[2] = g_note[1]; r[3] = g_note[2]; r[4] = g_note[3];
+        }
+        g_probe.launch++;
+    }
     return p;
 }
 
@@ -529,6 +539,7 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     EpiArgs e;
     if (int rc = check_and_fill(d, e)) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g_probe.buf) { g_note[0] = (d->a_kmajor ? 1 : 0) | (d->b_kmajor ? 2 : 0); g_note[1] = d->M; g_note[2] = d->N; g_note[3] = d->K; }
     // Split-K: a weight-gradient GEMM has few output tiles (768x768 -> 36) and a long reduction (K = tokens).
     // With a workspace, the K range is spread over `splits` workgroups per tile; each writes an fp32 partial slab
     // and a second kernel sums the slabs in a fixed order (deterministic, no atomics).
@@ -621,6 +632,7 @@ extern "C" int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void
     }
     for (int i = count; i <= MAXG; ++i) g.start[i] = total;
     g.total = total;
+    if (g_probe.buf) { g_note[0] = 4 | key; g_note[1] = count; g_note[2] = total; g_note[3] = descs[0].K; }
     // weight-gradient form on the wide tile: every problem a whole number of 256 x 128 tiles and 64-deep K-steps, plain fp32 outputs
     if (key == 3 && mmf_amd_get_tunable(MMF_TUN_WGRAD_WIDE) != 1) {
         bool ok = true;
@@ -662,7 +674,16 @@ extern "C" int mmf_gemm_set_probe(void* buf, int64_t capacity_records) {
     g_probe.buf = reinterpret_cast<unsigned long long*>(buf);
     g_probe.cap = (unsigned)(capacity_records > 0 ? capacity_records : 0);
     g_probe.launch = 0;
+    if (buf) g_probe_nlog = 0;       // (the log of the last probed span stays readable after the probe is switched off)
     return 0;
+}
+// Copies the host-side log of the launches probed since mmf_gemm_set_probe (5 int64 per launch: launch id, layout — bit 0 A k-major, bit 1
+// B k-major, bit 2 grouped —, M, N, K; grouped: problems, 128-row tiles, K) into `out`; returns the number of launches logged.
+extern "C" int mmf_gemm_probe_log(int64_t* out_host, int capacity) {
+    const int n = g_probe_nlog < capacity ? g_probe_nlog : capacity;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < 5; ++j) out_host[i * 5 + j] = g_probe_log[i][j];
+    return g_probe_nlog;
 }
 
 extern "C" const char* mmf_gemm_last_kernel(void) { return g_last_kernel; }

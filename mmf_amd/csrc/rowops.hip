@@ -1112,13 +1112,17 @@ struct AdamLaunch {
     mmf_adamw_multi_desc d;
     int cstart[MMF_MT_MAX + 1];
 };
-__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc1, float bc2) {
+// (`total` chunks over gridDim.x workgroups: one chunk each by default; MMF_TUN_ADAM_GRID caps the grid and the workgroups stride over
+// the chunk list — the form that runs beside a GEMM launch on the CUs it leaves idle.)
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc1_in, float bc2_in, int total) {
     const mmf_adamw_multi_desc& d = a.d;
+  for (int blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    float bc1 = bc1_in, bc2 = bc2_in;
     int t = 0;
-    for (int i = 1; i < d.n; ++i) t += ((int)blockIdx.x >= a.cstart[i]) ? 1 : 0;
+    for (int i = 1; i < d.n; ++i) t += (blk >= a.cstart[i]) ? 1 : 0;
     const int64_t n = d.numel[t];
-    const int64_t base = (int64_t)((int)blockIdx.x - a.cstart[t]) * ADAM_CHUNK;
-    if (base >= n) return;
+    const int64_t base = (int64_t)(blk - a.cstart[t]) * ADAM_CHUNK;
+    if (base >= n) continue;
     float* __restrict__ p = reinterpret_cast<float*>(d.p[t]);
     const float* __restrict__ g = reinterpret_cast<const float*>(d.g[t]);
     const bf16* __restrict__ g16 = reinterpret_cast<const bf16*>(d.g[t]);
@@ -1185,6 +1189,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc
             if (p32) store4(p32 + i, pv[u]);
         } else for (int j = 0; j < cnt[u]; ++j) { p[i + j] = pv[u][j]; m[i + j] = mv[u][j]; v[i + j] = vv[u][j]; if (p16) p16[i + j] = (bf16)pv[u][j]; if (p32) p32[i + j] = pv[u][j]; }
     }
+  }
 }
 __global__ __launch_bounds__(256) void l2norm_multi_kernel(mmf_tensor_list d, float* __restrict__ partials) {
     __shared__ float red[4];
@@ -1724,7 +1729,9 @@ int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream) {
     int blocks = 0;
     for (int i = 0; i < d->n; ++i) { a.cstart[i] = blocks; blocks += (int)((d->numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK); }
     for (int i = d->n; i <= MMF_MT_MAX; ++i) a.cstart[i] = blocks;
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, bc1, bc2);
+    const int cap = mmf_amd_get_tunable(MMF_TUN_ADAM_GRID);
+    const int grid = (cap > 0 && cap < blocks) ? cap : blocks;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, bc1, bc2, blocks);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -760,21 +760,23 @@ class _ParamUpdateHook:
     def __init__(self):
         self.fn = None
         self.beside = None
+        self.beside_wgrad = False
 
     @contextlib.contextmanager
-    def __call__(self, fn, beside=None):
+    def __call__(self, fn, beside=None, beside_wgrad=False):
         """`beside` (optional): a context-manager factory the layer's backward wraps around its attention-backward launch — the optimizer
         uses it to run the update of the layer ABOVE (whose gradients are complete) on a second stream exactly beside that kernel
         (`AdamW.beside_attention`): the one kernel of a layer's backward that leaves HBM and half the CUs idle (one 8-wave workgroup per
         (batch, head) = 384 workgroups on 256 CUs, two rounds) and keeps no operand panels in L2 for the update stream to evict."""
         old, self.fn = self.fn, fn
         old_b, self.beside = self.beside, beside
+        old_w, self.beside_wgrad = self.beside_wgrad, beside_wgrad     # wrap the grouped weight-gradient launch instead of the attention backward
         if fn is not None:
             _ops_native.push_mode(1)      # the hook lives in the Python autograd node: route the layer operator there
         try:
             yield
         finally:
-            self.fn, self.beside = old, old_b
+            self.fn, self.beside, self.beside_wgrad = old, old_b, old_w
             if fn is not None:
                 _ops_native.pop_mode(1)
 
@@ -830,7 +832,7 @@ class TransformerLayerFn(torch.autograd.Function):
         dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, S, dtype=F32, device=dev)
         scale = 1.0 / math.sqrt(H // heads)
-        with (param_update.beside() if param_update.beside is not None else contextlib.nullcontext()):
+        with (param_update.beside() if (param_update.beside is not None and not param_update.beside_wgrad) else contextlib.nullcontext()):
             nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
                               dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
         dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1) if ctx.needs_input_grad[0] else None
@@ -839,7 +841,8 @@ class TransformerLayerFn(torch.autograd.Function):
         p_2, dw2, db2 = _wgrad_problem(dlin2, H, hh, M, H, I, True)
         p_q, dwqkv, dbqkv = _wgrad_problem(dqkv, 3 * H, x2, M, 3 * H, H, True)
         p_o, dwo, dbo = _wgrad_problem(dlin1, H, ctxt, M, H, H, True)
-        wgrad_overlap.launch([p_1, p_2, p_q, p_o], (du, a_out, dlin2, hh, dqkv, x2, dlin1, ctxt, dw1, db1, dw2, db2, dwqkv, dbqkv, dwo, dbo))
+        with (param_update.beside() if (param_update.beside is not None and param_update.beside_wgrad) else contextlib.nullcontext()):
+            wgrad_overlap.launch([p_1, p_2, p_q, p_o], (du, a_out, dlin2, hh, dqkv, x2, dlin1, ctxt, dw1, db1, dw2, db2, dwqkv, dbqkv, dwo, dbo))
         if param_update.fn is not None and wgrad_overlap.stream is None:
             param_update.fn(ctx.update_params, (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
                                                 dwo, dbo, dw1, db1, dw2, db2))

@@ -5,6 +5,8 @@ gradient clipping (`clip_gradients`, mmf/utils/general.py:33-50) into the update
 
     optimizer = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(config), lr=5e-5, eps=1e-8)
 """
+import os
+
 import torch
 
 from mmf_amd import _native as nat
@@ -116,21 +118,30 @@ class AdamW(torch.optim.Optimizer):
         """Context manager for `functional.param_update(..., beside=...)`: wraps ONE kernel launch on the current stream."""
         opt = self
 
+        after = os.environ.get("MMF_AMD_ADAM_ORDER", "before") == "after"     # enqueue the update behind the wrapped kernel (still parallel to it)
+
         class _Beside:
             def __enter__(self_):
                 self_.ran = False
+                self_.pend = None
                 if opt._early is not None and opt._pending is not None:
                     pend, opt._pending = opt._pending, None
-                    opt._launch_update(*pend)           # fork: side stream waits for everything enqueued so far on the main stream
+                    if after:
+                        self_.pend = pend
+                        self_.ev = torch.cuda.current_stream().record_event()      # the fork point: everything before the wrapped kernel
+                    else:
+                        opt._launch_update(*pend)           # fork: side stream waits for everything enqueued so far on the main stream
                     self_.ran = True
 
             def __exit__(self_, *exc):
                 if self_.ran:
+                    if self_.pend is not None:
+                        opt._launch_update(*self_.pend, fork_event=self_.ev)
                     torch.cuda.current_stream().wait_stream(opt._early_stream)      # join behind the wrapped kernel
         return _Beside()
 
     @torch.no_grad()
-    def _launch_update(self, params, grads):
+    def _launch_update(self, params, grads, fork_event=None):
         if self._early is None:
             return
         main, side = torch.cuda.current_stream(), self._early_stream
@@ -154,12 +165,20 @@ class AdamW(torch.optim.Optimizer):
                  grp["weight_decay"]))
         if not by_group:
             return
-        side.wait_stream(main)                  # the gradients were produced on the launching stream
+        if fork_event is not None:
+            side.wait_event(fork_event)
+        else:
+            side.wait_stream(main)              # the gradients were produced on the launching stream
+        side_grid = int(os.environ.get("MMF_AMD_ADAM_SIDE_GRID", "0"))      # workgroup cap of the in-backward launches only (they stride over the chunks)
         with torch.cuda.stream(side):
+            if side_grid:
+                nat.set_tunable(nat.TUN_ADAM_GRID, side_grid)
             for grp, step, items in by_group.values():
                 b1, b2 = grp["betas"]
                 nat.adamw_multi(items, b1, b2, grp["eps"], step, grp["correct_bias"], 1 if self.torch_mode else 0, self.grad_scale,
                                 None, 0.0, self._dev_state if self.capturable else None)
+            if side_grid:
+                nat.set_tunable(nat.TUN_ADAM_GRID, 0)
             Fn.shadows.refresh_transposed(only=list(params))
 
     def _grad_of(self, p):

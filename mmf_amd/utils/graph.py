@@ -80,8 +80,9 @@ class GraphedTrainStep:
             overlap_wgrad = os.environ.get("MMF_AMD_WGRAD_OVERLAP", "0") == "1"
         if overlap_update is None:
             overlap_update = os.environ.get("MMF_AMD_ADAM_OVERLAP", "0")
-            overlap_update = {"0": False, "1": True, "2": "attention"}.get(overlap_update, False)
-        self.pin_update = overlap_update == "attention"       # each layer's update runs only beside the attention backward of the layer below
+            overlap_update = {"0": False, "1": True, "2": "attention", "3": "wgrad"}.get(overlap_update, False)
+        self.pin_update = overlap_update in ("attention", "wgrad")    # each layer's update runs only beside ONE kernel of the layer below: its attention backward,
+        self.pin_wgrad = overlap_update == "wgrad"                    # or its grouped weight-gradient launch (216 tiles of the wide kernel: 40 CUs idle for ~100 us)
         self.side_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
         self.update_stream = (torch.cuda.Stream(device=next(model.parameters()).device)
                               if (overlap_update and optimizer is not None and not overlap_wgrad and hasattr(optimizer, "begin_step")) else None)
@@ -112,6 +113,20 @@ class GraphedTrainStep:
                 self.out, self.loss = self._eager()
 
     def _eager(self, update=True):
+        # The opt-in hooks (weight gradients / optimizer on a second stream) live in the PYTHON autograd node of the encoder layer: the
+        # forward has to build that node, so the operator is routed to its Python twin for the whole pass, not only for the backward
+        # (with the native operator library the backward otherwise runs the C++ node and the hooks never fire).
+        hooks = self.side_stream is not None or (self.update_stream is not None and update)
+        if hooks:
+            from mmf_amd import _ops_native
+            _ops_native.push_mode(1)
+        try:
+            return self._eager_body(update)
+        finally:
+            if hooks:
+                _ops_native.pop_mode(1)
+
+    def _eager_body(self, update):
         Fn.nat.seed_advance(self.seed)
         out = self.model(self.static_batch)
         loss = self.loss_of(out)
@@ -124,7 +139,8 @@ class GraphedTrainStep:
             self.optimizer.pin_to_attention = self.pin_update
             self.optimizer.begin_step(self.update_stream)
         with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.param_update(
-                self.optimizer.update_in_backward if early else None, self.optimizer.beside_attention if (early and self.pin_update) else None):
+                self.optimizer.update_in_backward if early else None, self.optimizer.beside_attention if (early and self.pin_update) else None,
+                beside_wgrad=self.pin_wgrad):
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g

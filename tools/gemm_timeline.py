@@ -35,18 +35,7 @@ def main():
     # calibrate the tick: a probed launch bracketed by HIP events
     cap = 400000
     buf = torch.zeros(8 * (1 + cap), dtype=torch.int64, device=dev)
-    shapes = []
-    orig, orig_g = nat.gemm, nat.gemm_grouped
 
-    def rec_gemm(A, B, C_out, M, N, K, *a, **kw):
-        shapes.append(("%s%s" % ("T" if kw.get("a_kmajor") else "N", "N" if kw.get("b_kmajor") else "T"), M, N, K))
-        orig(A, B, C_out, M, N, K, *a, **kw)
-
-    def rec_grouped(problems):
-        shapes.append(("grouped", len(problems), sum(p["M"] * p["N"] for p in problems) // 16384, problems[0]["K"]))
-        orig_g(problems)
-
-    nat.gemm, nat.gemm_grouped = rec_gemm, rec_grouped
     nat.gemm_set_probe(buf)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -54,7 +43,8 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     nat.gemm_set_probe(None)
-    nat.gemm, nat.gemm_grouped = orig, orig_g
+    LAY = {0: "NT", 1: "TT", 2: "NN", 3: "TN"}
+    shapes = {l: (("grouped " + LAY[lay & 3]) if lay & 4 else LAY[lay], M_, N_, K_) for l, lay, M_, N_, K_ in nat.gemm_probe_log()}
     n = min(int(buf[0].item()), cap)
     rec = buf[8:8 * (1 + n)].view(n, 8).cpu()
     launch = (rec[:, 0] >> 32).tolist()
@@ -70,7 +60,7 @@ def main():
     for l in sorted(by):
         idx = by[l]
         r = rec[idx].double()
-        key = shapes[l] if l < len(shapes) else ("?",)
+        key = shapes.get(l, ("?",)) + (len(idx),)
         t0 = r[:, 2].min()
         env = (r[:, 6].max() - t0) * tick_us
         pro = ((r[:, 3] - r[:, 2]) * tick_us).mean(); kl = ((r[:, 4] - r[:, 3]) * tick_us).mean()

@@ -95,8 +95,26 @@ def report(path, out_json=None):
     return res
 
 
+def timeline(path):
+    """Start offset / duration / name of every kernel of the LAST replay, in start order (overlapping branches show as overlapping rows)."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    cuts = [i for i, r in enumerate(rows) if "seed_advance_kernel" in r[2]]
+    a, b = cuts[-2], cuts[-1]
+    t0 = rows[a][0]
+    prev_end = t0
+    for s, e, name in rows[a:b]:
+        print("%9.1f  %8.1f us  %s%s" % ((s - t0) / 1e3, (e - s) / 1e3, "|| " if s < prev_end - 500 else "   ", short(name)))
+        prev_end = max(prev_end, e)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2])
     else:
         report(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(const bf16* __restrict__ 
 // Backward: a workgroup of 4 waves = 8 half-waves; half-wave h owns rows blockIdx * 8 + h + 8 * gridDim * i (two rows each at the
 // VQA2 shape: 456 workgroups, two co-resident per CU so that one streams while the other reduces); all loads of a row are issued before anything is reduced.  Column-sum partials (dgamma, dbeta, optionally dbias) are combined across the
 // workgroup's 32 half-waves in LDS and written once per workgroup: partials[blk][q][H], q < NQ.
-template <int NC, bool DBIAS>
+template <int NC, bool DBIAS, int NR>
 __global__ __launch_bounds__(256) void ln_bwd_h_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, bf16* __restrict__ dx,
@@ -280,47 +280,62 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(const bf16* __restrict__ 
     }
     // (gamma is re-read per chunk from L1 / L2 in both passes instead of being held: the register budget is what decides how
     // many workgroups - rows in flight - a CU holds)
-    for (int row = blockIdx.x * 8 + half; row < rows; row += 8 * gridDim.x) {
-        const size_t off = (size_t)row * H + hl * 8;
-        f32x8r xv[NC], dv[NC];
+    // NR rows of a half-wave are in flight together: every load of both rows is issued before anything is reduced (the VQA2 shape gives each
+    // half-wave exactly two rows; with one row at a time the second row's HBM latency was exposed: 13.4 us per launch for 45 MB).
+    const int rstride = 8 * gridDim.x;
+    for (int row0 = blockIdx.x * 8 + half; row0 < rows; row0 += NR * rstride) {
+        f32x8r xv[NR][NC], dv[NR][NC];
+        float mu[NR], rs[NR];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { xv[c] = load8(x + off + 256 * c); dv[c] = load8(dy + off + 256 * c); }
-        const float mu = mean[row], rs = rstd[row];
-        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < NR; ++r) {
+            const int row = row0 + r * rstride;
+            const int rowc = row < rows ? row : row0;          // (a missing second row re-reads the first; its results are dropped)
+            const size_t off = (size_t)rowc * H + hl * 8;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const f32x8r gm = load8(gamma + hl * 8 + 256 * c);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                xv[c][i] = (xv[c][i] - mu) * rs;                  // xhat
-                const float g = dv[c][i] * gm[i];
-                s1 += g;
-                s2 += g * xv[c][i];
-            }
+            for (int c = 0; c < NC; ++c) { xv[r][c] = load8(x + off + 256 * c); dv[r][c] = load8(dy + off + 256 * c); }
+            mu[r] = mean[rowc]; rs[r] = rstd[rowc];
         }
-        const float c1 = half_sum(s1) * (1.f / (float)H), c2 = half_sum(s2) * (1.f / (float)H);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const f32x8r gm = load8(gamma + hl * 8 + 256 * c);
-            f32x8r d;
+        for (int r = 0; r < NR; ++r) {
+            const int row = row0 + r * rstride;
+            if (row >= rows) continue;
+            const size_t off = (size_t)row * H + hl * 8;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                d[i] = rs * (dv[c][i] * gm[i] - c1 - xv[c][i] * c2);
-                ag[c][i] += dv[c][i] * xv[c][i];
-                ab[c][i] += dv[c][i];
+            for (int c = 0; c < NC; ++c) {
+                const f32x8r gm = load8(gamma + hl * 8 + 256 * c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xv[r][c][i] = (xv[r][c][i] - mu[r]) * rs[r];                  // xhat
+                    const float g = dv[r][c][i] * gm[i];
+                    s1 += g;
+                    s2 += g * xv[r][c][i];
+                }
             }
-            store8(dx + off + 256 * c, d);
-            if (dlin) {
-                const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
-                const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale);
-                const f32x4 s1_ = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
+            const float c1 = half_sum(s1) * (1.f / (float)H), c2 = half_sum(s2) * (1.f / (float)H);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { d[i] *= s0[i]; d[i + 4] *= s1_[i]; }
-                store8(dlin + off + 256 * c, d);
-            }
-            if (DBIAS) {     // the bias gradient uses the same rounding the weight-gradient GEMM will see
+            for (int c = 0; c < NC; ++c) {
+                const f32x8r gm = load8(gamma + hl * 8 + 256 * c);
+                f32x8r d;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) al[c][i] += (float)(bf16)d[i];
+                for (int i = 0; i < 8; ++i) {
+                    d[i] = rs[r] * (dv[r][c][i] * gm[i] - c1 - xv[r][c][i] * c2);
+                    ag[c][i] += dv[r][c][i] * xv[r][c][i];
+                    ab[c][i] += dv[r][c][i];
+                }
+                store8(dx + off + 256 * c, d);
+                if (dlin) {
+                    const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
+                    const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale);
+                    const f32x4 s1_ = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { d[i] *= s0[i]; d[i + 4] *= s1_[i]; }
+                    store8(dlin + off + 256 * c, d);
+                }
+                if (DBIAS) {     // the bias gradient uses the same rounding the weight-gradient GEMM will see
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) al[c][i] += (float)(bf16)d[i];
+                }
             }
         }
     }
@@ -1269,7 +1284,7 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
     hipStream_t s = (hipStream_t)stream;
     const int nch = (H + 255) / 256;
     const bf16* xp = (const bf16*)x; bf16* yp = (bf16*)y;
-    if ((H % 256) == 0 && H <= 1024 && !mmf_amd_get_tunable(MMF_TUN_LN_OLD)) {     // half a wave per row, 16-byte accesses
+    if ((H % 256) == 0 && H <= 1024 && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 1) {     // half a wave per row, 16-byte accesses
         const dim3 grid((rows + 7) / 8);
         switch (H / 256) {
             case 1: hipLaunchKernelGGL(ln_fwd_h_kernel<1>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
@@ -1301,7 +1316,7 @@ static int lnb_h_grid(int rows) {
     if (tg > 0 && tg < grid) grid = tg;
     return grid;
 }
-static bool lnb_h_path(int H, bool dbias) { return (H % 256) == 0 && H <= 1024 && !(H == 1024 && dbias) && !mmf_amd_get_tunable(MMF_TUN_LN_OLD); }
+static bool lnb_h_path(int H, bool dbias) { return (H % 256) == 0 && H <= 1024 && !(H == 1024 && dbias) && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 1; }
 
 int mmf_layernorm_bwd_deferrable(int rows, int H) { return rows > 0 && lnb_h_path(H, false) ? 1 : 0; }
 
@@ -1333,9 +1348,12 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     if (lnb_h_path(H, dbias != nullptr)) {     // half a wave per row, 16-byte accesses
         const int grid = lnb_h_grid(rows);
         const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
+        // two rows of a half-wave in flight whenever it owns more than one (MMF_TUN_LN_OLD = 2: one at a time, the round-3 form; A/B)
+        const bool two = rows > 8 * grid && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 2;
 #define MMF_LNB_H(NC)                                                                                                              \
-        if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows); \
-        else hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows);
+        if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows); \
+        else if (two) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 2>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows); \
+        else hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows);
         switch (H / 256) {
             case 1: MMF_LNB_H(1) break;
             case 2: MMF_LNB_H(2) break;

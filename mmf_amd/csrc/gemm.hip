@@ -185,9 +185,25 @@ DEVI void gemm_tile(const AT* __restrict__ A, const BT* __restrict__ B, int M, i
     }
     if (probing) pt[3] = probe_now();
     constexpr int SEG = BN_ / 8;
-    for (int idx = tid; idx < BM * SEG; idx += NTH) {
-        const int row = idx / SEG, seg = idx - row * SEG;
-        epilogue8(epi, m0 + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), split);
+    if (epilogue_fast_ok(epi) && splits <= 1) {
+        // the lean epilogue of the common cases (bias, GELU + saved derivative / multiplier / dropout / residual, bf16 output): no per-column
+        // range flags, one 16-byte side-input load
+        const uint32_t dkey = drop_key(epi.drop);
+        const bf16* sidep = epi.resid ? epi.resid : (epi.act == 2 ? epi.aux : nullptr);
+        const int side_ld = epi.resid ? epi.ldr : epi.ldc;
+        for (int idx = tid; idx < BM * SEG; idx += NTH) {
+            const int row = idx / SEG, seg = idx - row * SEG;
+            const int m = m0 + row, n = n0 + seg * 8;
+            if (m >= M || n >= N) continue;
+            uint4 side = make_uint4(0, 0, 0, 0);
+            if (sidep) side = *reinterpret_cast<const uint4*>(sidep + (size_t)m * side_ld + n);
+            epilogue8_fast(epi, m, n, load_f8(cs + row * CLD + seg * 8), side, dkey);
+        }
+    } else {
+        for (int idx = tid; idx < BM * SEG; idx += NTH) {
+            const int row = idx / SEG, seg = idx - row * SEG;
+            epilogue8(epi, m0 + row, n0 + seg * 8, load_f8(cs + row * CLD + seg * 8), split);
+        }
     }
     if (RS && epi.rowsum_col >= 0 && tile_n == 0 && tid < BM && m0 + tid < M) {
         if (epi.rowsum_direct) epi.rowsum_direct[m0 + tid] = rs[tid];     // no split-K: this tile saw the whole reduction

@@ -331,7 +331,8 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
 // 8-column segments, no row remap.  The ONE row-wise bf16 side input (the residual, else the act-2 multiplier) arrives in `side`:
 // the kernel fetched it while its last K-steps were still running (one workgroup per CU has nothing else to hide that latency).
 DEVI bool epilogue_fast_ok(const EpiArgs& e) {
-    return !e.coladd && !e.rowtab && e.grp_in == 0 && !e.out_f32 && (e.act == 0 || e.act == 2) && (e.ldc & 7) == 0 && (e.N & 7) == 0 &&
+    const bool gelu = e.act == 1 && e.U != nullptr && !e.resid && !e.drop.thr16;       // HF BertIntermediate: bias, GELU, saved derivative
+    return !e.coladd && !e.rowtab && e.grp_in == 0 && !e.out_f32 && (e.act == 0 || e.act == 2 || gelu) && (e.ldc & 7) == 0 && (e.N & 7) == 0 &&
            (!e.resid || (e.ldr & 7) == 0) && e.splits <= 1 && !(e.resid && e.act == 2);
 }
 DEVI void epilogue8_fast(const EpiArgs& e, int m, int n, f32x8 v, uint4 side, uint32_t dkey) {
@@ -342,6 +343,14 @@ DEVI void epilogue8_fast(const EpiArgs& e, int m, int n, f32x8 v, uint4 side, ui
         const bf16x8 t = __builtin_bit_cast(bf16x8, side);
 #pragma unroll
         for (int i = 0; i < 8; ++i) sv[i] = (float)t[i];
+    }
+    if (e.act == 1) {          // (no side input: `side` is all zeros)
+        f32x8 gd;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { float hh, gg; gelu_erf_both(v[r], hh, gg); v[r] = hh; gd[r] = gg; }
+        store_bf8(e.U + (size_t)m * e.ldc + n, gd, (e.nt & 2) != 0);
+        store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v, (e.nt & 1) != 0);
+        return;
     }
     if (e.act == 2) v *= sv;
     if (e.drop.thr16) {

@@ -46,7 +46,10 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
                                       most of a round of the 256 CUs, 1 never (the 128x128 tiles, two workgroups per CU), 2 whenever the shapes allow (A/B) */
        MMF_TUN_ADAM_GRID = 11,     /* > 0: cap on the workgroups of one mmf_adamw_multi launch (they stride over the 4096-element chunks): the form that runs beside
                                       a GEMM launch; 0: one workgroup per chunk */
-       MMF_TUN_COUNT = 12 };
+       MMF_TUN_EPI_SC1 = 12,       /* GEMM epilogue write-through (`sc1`) stores, mask like MMF_TUN_EPI_NT's (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C): the lines
+                                      leave the XCD's L2 as they are written instead of at the end-of-kernel release (A/B) */
+       MMF_TUN_SKINNY_OFF = 13,    /* 1: never the skinny split-K path (mmf_gemm_skinny_splits returns 1; A/B) */
+       MMF_TUN_COUNT = 14 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)
@@ -119,9 +122,13 @@ typedef struct mmf_gemm_desc {
                                  of nn.Linear, hf_layers.py:169-180) computed by the same launch with one extra MFMA per A
                                  fragment against a ones operand; with split-K it travels through the workspace (behind the
                                  slabs) and is summed by the slab reduction, else it is written directly */
-    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches, bit 17: never a wide (one workgroup per CU) tile */
+    int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches, bit 17: never a wide (one workgroup per CU) tile; (bit 18 is the Python binding's: no skinny-path workspace) */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
+/* Skinny problems (a row-major A of at most 64 rows and a long reduction: the classification heads of visual_bert.py:349-404 and their input
+ * gradients): number of K-slices mmf_gemm_bf16 spreads over the chip when `splitk_ws` holds splits * M * round_up(N, 8) floats — ANY epilogue,
+ * it runs on the slab sums in a second kernel.  Returns 1 when the problem is not skinny (no workspace needed). */
+int mmf_gemm_skinny_splits(int M, int N, int K, int a_kmajor);
 /* `count` (1..8) independent GEMMs of ONE operand layout (a_kmajor, b_kmajor, a_f32, b_f32 equal) in one launch: the tile
  * lists are concatenated, so small problems fill the chip together.  No split-K (splitk_ws ignored); each problem keeps its
  * own epilogue and rowsum_out.  Replaces the four weight-gradient GEMMs autograd issues per transformer layer

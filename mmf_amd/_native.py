@@ -236,6 +236,11 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
         if sp > 1:
             ws = torch.empty(sp * M * (N + 1), dtype=torch.float32, device=C_out.device)
             d.splitk_ws, d.splitk_ws_bytes = _p(ws), ws.numel() * 4
+    elif rowsum_out is None and not (debug_flags & (1 << 18)):      # skinny problems (the heads): K-slices over the chip, epilogue on the slab sums
+        sp = lib().mmf_gemm_skinny_splits(M, N, K, 1 if a_kmajor else 0)
+        if sp > 1:
+            ws = torch.empty(sp * M * ((N + 7) // 8 * 8), dtype=torch.float32, device=C_out.device)
+            d.splitk_ws, d.splitk_ws_bytes = _p(ws), ws.numel() * 4
     _check(lib().mmf_gemm_bf16(C.byref(d), _stream()), "mmf_gemm_bf16")
 
 
@@ -556,6 +561,7 @@ def tanh_bwd(dy, y, dx):
 TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE, TUN_LN_OLD, TUN_ATTN_BWD_TWO_PASS = 0, 1, 2, 3, 4
 TUN_WGRAD_WIDE = 10
 TUN_ADAM_GRID = 11
+TUN_SKINNY_OFF = 13
 
 
 def set_tunable(which, value):

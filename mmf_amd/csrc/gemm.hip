@@ -329,6 +329,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// Skinny problems (M <= 64 rows: the classification heads, mmf/models/visual_bert.py:349-404, and their input gradients): a handful of
+// 128-row tiles each walking the whole reduction leaves the chip idle (6 workgroups x 49 K-steps for the classifier's input gradient),
+// so the K range is split over ~128 workgroups whatever the epilogue: the GEMM pass writes raw fp32 partial tiles (slab s = K-slice s,
+// rows of round_up(N, 8) floats), this kernel adds the slabs in a fixed order and runs the ORIGINAL fused epilogue on the sums.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ ws, int splits, long slab, int n8, EpiArgs e) {
+    const int seg = n8 >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= e.M * seg) return;
+    const int m = idx / seg, n = (idx - m * seg) * 8;
+    const float* p = ws + (size_t)m * n8 + n;
+    f32x8 v = load_f8(p);
+    for (int s = 1; s < splits; ++s) v += load_f8(p + (size_t)s * slab);
+    epilogue8(e, m, n, v, 0);
+}
+
 // name of the kernel family the last mmf_gemm_bf16 / mmf_gemm_bf16_grouped call on this thread launched (measurement aid)
 static thread_local const char* g_last_kernel = "";
 
@@ -545,6 +560,7 @@ static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     // MMF_TUN_EPI_NT: 0 = the default mask below, else (value - 1) is the mask (1 = no non-temporal stores at all)
     const int ntt = mmf_amd_get_tunable(MMF_TUN_EPI_NT);
     e.nt = ntt > 0 ? ntt - 1 : MMF_EPI_NT_DEFAULT;
+    e.sc1 = mmf_amd_get_tunable(MMF_TUN_EPI_SC1) & 7;
     // call-site exception (MMF_TUN_NT_SITE_KEEP, default 0 = none): the tagged call's bf16 output is read by the very next kernel
     const int site = (d->debug_flags >> 20) & 15;
     if (site != 0 && ((mmf_amd_get_tunable(MMF_TUN_NT_SITE_KEEP) >> site) & 1)) e.nt &= ~1;
@@ -571,6 +587,21 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
             e.C = d->splitk_ws; e.ldc = d->N; e.beta = 0.f;
         }
     }
+    // skinny path: any epilogue, applied by splitk_epilogue_kernel after the slab sum
+    bool skinny = false;
+    EpiArgs e_final;
+    int n8 = 0;
+    if (!final_c && !d->rowsum_out) {
+        const int sp = mmf_gemm_skinny_splits(d->M, d->N, d->K, d->a_kmajor);
+        n8 = (d->N + 7) / 8 * 8;
+        if (sp > 1 && d->splitk_ws && d->splitk_ws_bytes >= (long)sp * d->M * n8 * (long)sizeof(float)) {
+            skinny = true;
+            e_final = e;
+            e = EpiArgs{};
+            e.C = d->splitk_ws; e.ldc = n8; e.out_f32 = 1; e.M = d->M; e.N = d->N;
+            e.splits = sp; e.slab_stride = (long)d->M * n8; e.rowsum_col = -1;
+        }
+    }
     if (d->rowsum_out) {
         MMF_CHECK_ARG(d->a_kmajor && d->b_kmajor && !d->a_f32 && !d->b_f32,
                       "mmf_gemm_bf16: rowsum_out needs the weight-gradient form (both operands k-major, bf16)");
@@ -593,6 +624,14 @@ extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
             return 1;
     }
     if (rc != 0) return rc;
+    if (skinny) {
+        const int threads = d->M * (n8 / 8);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(d->splitk_ws), e.splits, e.slab_stride, n8, e_final);
+        MMF_CHECK_LAUNCH();
+        g_last_kernel = "gemm_bf16_kernel 128x128 skinny split-K";
+        return 0;
+    }
     if (final_c) {
         const long n = (long)d->M * d->N;
         const long threads = n / 4 + (d->rowsum_out ? d->M : 0);
@@ -618,6 +657,21 @@ extern "C" int mmf_gemm_splitk_splits(int M, int N, int K) {
         if (c < bc - 1e-9) { bc = c; best = sp; }
     }
     return best;
+}
+
+// K-slices of the skinny path (splitk_epilogue_kernel): 0 / 1 = not a skinny problem.  Row operand A with at most 64 rows, at least 24
+// K-steps; slices of >= 2 K-steps, about 128 workgroups in all.  Workspace: splits * M * round_up(N, 8) floats (mmf_gemm_desc::splitk_ws).
+extern "C" int mmf_gemm_skinny_splits(int M, int N, int K, int a_kmajor) {
+    if (a_kmajor || M > 64 || mmf_amd_get_tunable(MMF_TUN_SKINNY_OFF)) return 1;
+    const int tiles = (N + BN - 1) / BN, nk = (K + BK - 1) / BK;
+    // (a short reduction gains nothing that the second launch does not cost again: 15 -> 10 us on the device for K = 768, one more kernel to
+    // enqueue in a host-bound decoding loop; the path is for the LONG reductions — 49 K-steps through 6 workgroups for the classifier's
+    // input gradient, 47 us)
+    if (nk < 24 || tiles >= 96) return 1;
+    int sp = 128 / tiles;
+    if (sp > nk / 2) sp = nk / 2;
+    if (sp > 32) sp = 32;
+    return sp < 2 ? 1 : sp;
 }
 
 // Several GEMMs of ONE operand layout in one grid (see gemm_bf16_grouped_kernel).  Every problem runs without split-K and with its

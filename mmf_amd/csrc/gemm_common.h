@@ -33,6 +33,7 @@ struct EpiArgs {
     int rowsum_col;     // >= 0: also write per-row sums of A (bias-gradient partials) behind the split-K slabs; -1: off
     float* rowsum_direct;  // no split-K: the row sums go straight here ([M] fp32) instead of behind the slabs
     int nt;             // non-temporal stores: bit 0 the bf16 output C, bit 1 the saved gelu' (U), bit 2 fp32 outputs (MMF_TUN_EPI_NT)
+    int sc1;            // write-through stores, same bits (MMF_TUN_EPI_SC1)
 };
 
 // Timeline probe (development aid; off unless mmf_gemm_set_probe was called).  One record of 8 u64 per workgroup:
@@ -207,13 +208,22 @@ DEVI f32x8 load_bf8(const bf16* p) {
 // that way: step 8.62 -> 8.41 ms, FETCH_SIZE of the 128 x 128 family 85.4 -> 75.4 MB per launch - but the NEXT kernel then finds its
 // input further away (attention forward 28 -> 39 us behind a non-temporally stored Q|K|V), so which outputs get it is a per-output
 // choice (EpiArgs::nt, MMF_TUN_EPI_NT).
-DEVI void store_bf8(bf16* p, f32x8 v, bool nt) {
+// A 16-byte store in one of the cache policies: 0 plain, 1 non-temporal (`nt`), 2 write-through (`sc1`: the line leaves the XCD's L2 as it is
+// written, so the end-of-kernel release has nothing of it left to write back; MMF_TUN_EPI_SC1), 3 both.
+DEVI void store16_policy(void* p, u32x4 v, int policy) {
+    if (policy == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    else if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if (policy == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<u32x4*>(p) = v;
+}
+DEVI void store_bf8(bf16* p, f32x8 v, int policy) {
     bf16x8 t;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
-    if (nt) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, t), reinterpret_cast<u32x4*>(p));
-    else *reinterpret_cast<bf16x8*>(p) = t;
+    store16_policy(p, __builtin_bit_cast(u32x4, t), policy);
 }
+// policy of output `bit` (0 the bf16 C, 1 the saved gelu' U, 2 fp32 C) from EpiArgs::nt (bits 0-2: nt) and EpiArgs::sc1 (bits 0-2: sc1)
+#define MMF_EPI_POLICY(e, bit) ((((e).nt >> (bit)) & 1) | ((((e).sc1 >> (bit)) & 1) << 1))
 
 // Epilogue of one output row segment: 8 consecutive columns n..n+7 of row m (fp32 accumulators staged through LDS
 // so that every global access of the epilogue is a full 16/32-byte-per-lane, row-contiguous transaction).
@@ -256,7 +266,7 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) { float hh, gg; gelu_erf_both(v[r], hh, gg); v[r] = hh; gd[r] = gg; }
         if (e.U) {
-            if (vec) store_bf8(e.U + off, gd, (e.nt & 2) != 0);
+            if (vec) store_bf8(e.U + off, gd, MMF_EPI_POLICY(e, 1));
             else {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) if (ok[r]) e.U[off + r] = (bf16)gd[r];
@@ -306,20 +316,15 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
         float* C = reinterpret_cast<float*>(e.C) + off;
         if (full && ((e.ldc & 3) == 0)) {
             if (e.beta != 0.f) v += e.beta * load_f8(C);
-            if (e.nt & 4) {
-                __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(C));
-                __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(C + 4));
-            } else {
-                *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            }
+            store16_policy(C, __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), MMF_EPI_POLICY(e, 2));
+            store16_policy(C + 4, __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), MMF_EPI_POLICY(e, 2));
         } else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (ok[r]) C[r] = v[r] + (e.beta != 0.f ? e.beta * C[r] : 0.f);
         }
     } else {
         bf16* C = reinterpret_cast<bf16*>(e.C) + off;
-        if (vec) store_bf8(C, v, (e.nt & 1) != 0);
+        if (vec) store_bf8(C, v, MMF_EPI_POLICY(e, 0));
         else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (ok[r]) C[r] = (bf16)v[r];
@@ -348,8 +353,8 @@ DEVI void epilogue8_fast(const EpiArgs& e, int m, int n, f32x8 v, uint4 side, ui
         f32x8 gd;
 #pragma unroll
         for (int r = 0; r < 8; ++r) { float hh, gg; gelu_erf_both(v[r], hh, gg); v[r] = hh; gd[r] = gg; }
-        store_bf8(e.U + (size_t)m * e.ldc + n, gd, (e.nt & 2) != 0);
-        store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v, (e.nt & 1) != 0);
+        store_bf8(e.U + (size_t)m * e.ldc + n, gd, MMF_EPI_POLICY(e, 1));
+        store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v, MMF_EPI_POLICY(e, 0));
         return;
     }
     if (e.act == 2) v *= sv;
@@ -361,7 +366,7 @@ DEVI void epilogue8_fast(const EpiArgs& e, int m, int n, f32x8 v, uint4 side, ui
         for (int r = 0; r < 4; ++r) { v[r] *= s0[r]; v[r + 4] *= s1[r]; }
     }
     if (e.resid) v += sv;
-    store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v, (e.nt & 1) != 0);
+    store_bf8(reinterpret_cast<bf16*>(e.C) + (size_t)m * e.ldc + n, v, MMF_EPI_POLICY(e, 0));
 }
 
 }  // namespace gemm

@@ -324,6 +324,13 @@ struct Gemm {
                 d.splitk_ws = ws.data_ptr(); d.splitk_ws_bytes = ws.numel() * 4;
             }
         }
+        if (!ws.defined() && !d.rowsum_out) {      // skinny problems (the heads): K-slices over the chip, the epilogue runs on the slab sums
+            const int sp_ = mmf_gemm_skinny_splits(d.M, d.N, d.K, d.a_kmajor);
+            if (sp_ > 1) {
+                ws = at::empty({(int64_t)sp_ * d.M * ((d.N + 7) / 8 * 8)}, at::TensorOptions().dtype(at::kFloat).device(c10::Device(c10::kCUDA, c10::hip::current_device())));
+                d.splitk_ws = ws.data_ptr(); d.splitk_ws_bytes = ws.numel() * 4;
+            }
+        }
         MMF_RC(mmf_gemm_bf16(&d, sp()), "mmf_gemm_bf16");
     }
 };

@@ -891,3 +891,66 @@ def test_capturable_adamw_matches_host_counters_and_warmup_linear():
         oc.step(); od.step()
     for q, r in zip(pc, pd):
         assert torch.allclose(q, r, rtol=1e-5, atol=1e-7)
+
+
+# ---- skinny problems: K-slices over the chip, the fused epilogue runs on the slab sums (mmf_gemm_skinny_splits) -------------------------
+NO_SKINNY = 1 << 18
+
+
+@pytest.mark.parametrize("M", [32, 8, 64])
+def test_gemm_skinny_head_shapes_match_torch_and_the_unsplit_launch(M):
+    """The classification head's GEMMs (visual_bert.py:349-404: dense + GELU, classifier 768 -> 3129) and their input gradients at
+    batch-sized M: split over ~128 workgroups, epilogue applied after the slab sum; against fp32 torch and against the same call
+    without the workspace (one workgroup per tile walking the whole reduction)."""
+    H, L = 768, 3129
+    assert nat().lib().mmf_gemm_skinny_splits(M, H, L, 0) > 1 and nat().lib().mmf_gemm_skinny_splits(M, H, 2048, 0) > 1
+    assert nat().lib().mmf_gemm_skinny_splits(M, H, H, 0) == 1          # (short reductions stay one launch)
+    assert nat().lib().mmf_gemm_skinny_splits(7296, H, L, 0) == 1 and nat().lib().mmf_gemm_skinny_splits(L, H, 32, 1) == 1
+    KD = 2048
+    x = rnd(M, KD, seed=1); Wd = rnd(H, KD, seed=2, scale=0.03); bd = rnd(H, dtype=torch.float32, seed=3)
+    # dense + exact-erf GELU with the saved derivative over a long reduction
+    h = torch.empty(M, H, dtype=torch.bfloat16, device=DEV); u = torch.empty_like(h)
+    nat().gemm(x, Wd, h, M, H, KD, KD, KD, H, bias=bd, act=1, U=u)
+    assert "skinny" in nat().gemm_last_kernel()
+    pre = x.float() @ Wd.float().t() + bd
+    close(h, torch.nn.functional.gelu(pre), 1e-2, 2e-2, "skinny dense + gelu")
+    h2 = torch.empty_like(h); u2 = torch.empty_like(u)
+    nat().gemm(x, Wd, h2, M, H, KD, KD, KD, H, bias=bd, act=1, U=u2, debug_flags=NO_SKINNY)
+    assert "skinny" not in nat().gemm_last_kernel()
+    close(h, h2, 1e-2, 1e-2, "skinny vs unsplit"); close(u, u2, 1e-2, 1e-2, "saved gelu'")
+    # 3129 outputs (not a multiple of 8), fp32 scores
+    Wc = rnd(L, H, seed=4, scale=0.05); bc = rnd(L, dtype=torch.float32, seed=5)
+    Wl = rnd(L, KD, seed=8, scale=0.03)
+    sc = torch.full((M, L), float("nan"), device=DEV)
+    nat().gemm(x, Wl, sc, M, L, KD, KD, KD, L, bias=bc)
+    assert "skinny" in nat().gemm_last_kernel()
+    close(sc, x.float() @ Wl.float().t() + bc, 1e-3, 3e-3, "skinny wide classifier")
+    # input gradient of the classifier: reduction over the 3129 labels (49 K-steps), k-major weight, bf16 output
+    LP = 3136                                   # the row operand's leading dimension covers round_up(K, 8), zero padding
+    dsc_p = torch.zeros(M, LP, dtype=torch.bfloat16, device=DEV); dsc_p[:, :L] = rnd(M, L, seed=6)
+    dsc = dsc_p[:, :L]
+    dh = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(dsc_p, Wc, dh, M, H, L, LP, H, H, b_kmajor=True)
+    assert "skinny" in nat().gemm_last_kernel()
+    close(dh, dsc.float() @ Wc.float(), 1e-2, 2e-2, "skinny classifier dgrad")
+    # ... times the saved derivative, plus a residual gradient, with dropout (mask = hash of the element index: same with and without)
+    res = rnd(M, H, seed=7)
+    d1 = torch.empty_like(dh); d2 = torch.empty_like(dh)
+    drop = nat().drop_cfg(0.1, 4321, None)
+    nat().gemm(dsc_p, Wc, d1, M, H, L, LP, H, H, b_kmajor=True, act=2, aux=u, drop=drop)
+    nat().gemm(dsc_p, Wc, d2, M, H, L, LP, H, H, b_kmajor=True, act=2, aux=u, drop=drop, debug_flags=NO_SKINNY)
+    close(d1, d2, 1e-2, 1e-2, "skinny act-2 + dropout vs unsplit")
+    nat().gemm(dsc_p, Wc, d1, M, H, L, LP, H, H, b_kmajor=True, resid=res, ldr=H)
+    close(d1, dsc.float() @ Wc.float() + res.float(), 1e-2, 2e-2, "skinny dgrad + residual")
+
+
+def test_gemm_skinny_repeated_launches_are_stable():
+    M, H, L = 32, 768, 3129
+    dsc = torch.zeros(M, 3136, dtype=torch.bfloat16, device=DEV); dsc[:, :L] = rnd(M, L, seed=6)
+    Wc = rnd(L, H, seed=4, scale=0.05)
+    dh = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    nat().gemm(dsc, Wc, dh, M, H, L, 3136, H, H, b_kmajor=True)
+    first = dh.clone()
+    for _ in range(20):
+        nat().gemm(dsc, Wc, dh, M, H, L, 3136, H, H, b_kmajor=True)
+    assert torch.equal(dh, first)

@@ -49,7 +49,11 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_EPI_SC1 = 12,       /* GEMM epilogue write-through (`sc1`) stores, mask like MMF_TUN_EPI_NT's (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C): the lines
                                       leave the XCD's L2 as they are written instead of at the end-of-kernel release (A/B) */
        MMF_TUN_SKINNY_OFF = 13,    /* 1: never the skinny split-K path (mmf_gemm_skinny_splits returns 1; A/B) */
-       MMF_TUN_COUNT = 14 };
+       MMF_TUN_SC1_SITE = 14,      /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored write-through (`sc1`, not `nt`): the line is dropped from
+                                      the writing XCD's L2 like a streaming store but allocates in the Infinity Cache, where the next kernel finds it (an `nt` store
+                                      bypasses it: tools/cold_operand_probe.py, profiles/r04_store_policy.txt).  0: the measured default (MMF_SITE_SC1_DEFAULT: the FFN
+                                      up-projection's GELU output and the FFN-down dgrad's du, the two A operands of the K = 3072 GEMMs); 1: no site at all (A/B) */
+       MMF_TUN_COUNT = 15 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)

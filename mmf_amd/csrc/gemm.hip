@@ -32,6 +32,14 @@ using namespace gemm;
 #ifndef MMF_EPI_NT_DEFAULT
 #define MMF_EPI_NT_DEFAULT 7
 #endif
+// Call sites (MMF_SITE_*) whose bf16 output is stored write-through (`sc1`) instead of non-temporally: a non-temporal store bypasses the Infinity
+// Cache, and the GEMM that reads the 45 MB activation next as its A operand then streams it from HBM with a K-loop ring that covers ~1.5 us of
+// latency: 49 instead of 39 us for the FFN-down forward (tools/cold_operand_probe.py).  In the step the producer pays part of it back; per
+// site, same process, interleaved (profiles/r04_store_policy.txt): FFN-up forward -0.02 .. -0.03 ms, FFN-down dgrad -0.06 ms, every other site
+// +0.00 .. +0.04 ms with `sc1` and +0.01 .. +0.13 ms with plain stores.
+#ifndef MMF_SITE_SC1_DEFAULT
+#define MMF_SITE_SC1_DEFAULT ((1 << MMF_SITE_FFN_UP_FWD) | (1 << MMF_SITE_FFN_DOWN_DGRAD))
+#endif
 
 
 namespace {
@@ -564,6 +572,10 @@ static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     // call-site exception (MMF_TUN_NT_SITE_KEEP, default 0 = none): the tagged call's bf16 output is read by the very next kernel
     const int site = (d->debug_flags >> 20) & 15;
     if (site != 0 && ((mmf_amd_get_tunable(MMF_TUN_NT_SITE_KEEP) >> site) & 1)) e.nt &= ~1;
+    // write-through instead of non-temporal for the outputs whose consumer is a long-K GEMM (MMF_TUN_SC1_SITE; measured in the step, round 4)
+    int sc1_sites = mmf_amd_get_tunable(MMF_TUN_SC1_SITE);
+    if (sc1_sites == 0) sc1_sites = MMF_SITE_SC1_DEFAULT;
+    if (site != 0 && ((sc1_sites >> site) & 1)) { e.nt &= ~1; e.sc1 |= 1; }
     return 0;
 }
 

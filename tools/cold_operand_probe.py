@@ -1,0 +1,93 @@
+"""Where does a layer GEMM's "in-situ penalty" come from?  (DESIGN round-3 section 7 item 0: the same kernels run 15 - 30 % slower inside
+the training step than on warm operands in isolation.)
+
+    python tools/cold_operand_probe.py [shape-name-filter ...]
+
+One consumer GEMM (a layer shape with its real epilogue) is timed per launch (HIP events around that launch only) while the state of its
+A operand is varied:
+
+    warm      the same A every launch (what tools/gemm_ab.py measures: A sits in the Infinity Cache / L2)
+    rotate    8 different A buffers in turn (8 x 45 MB > the 256 MB Infinity Cache for the K = 3072 shapes): A comes from HBM
+    fresh     A was written by an elementwise kernel (plain stores, 16 B per lane) immediately before the launch
+    fresh-nt  the same through this library's GEMM epilogue (the in-step producer: FFN-up's GELU epilogue, non-temporal stores)
+    fresh-gemm-t / -ct   that producer with temporal stores (MMF_TUN_EPI_NT = 1: every output; = 3: the bf16 output only, gelu' still nt)
+    hot       warm A, but a heavy unrelated GEMM runs immediately before (the chip at the step's power / clock state)
+
+`fresh` ~ `warm` would say the freshly written activation is served from cache and the penalty is clocks; `fresh` ~ `rotate` says the
+consumer pulls it from HBM whatever the producer's store policy."""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from mmf_amd import _native as nat
+from tools.gemm_ab import SHAPES, make, M
+
+
+def timed_launches(fn_before, fn, n):
+    ts = []
+    for _ in range(n):
+        if fn_before is not None:
+            fn_before()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        ts.append((e0, e1))
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) * 1e3 for a, b in ts]
+
+
+def main():
+    filt = sys.argv[1:]
+    dev = "cuda"
+    # an unrelated heavy GEMM (the `hot` mode's neighbour) and the in-step producer of the K = 3072 operands (FFN-up + GELU)
+    Xh = torch.randn(M, 768, device=dev).bfloat16(); Wh = (torch.randn(3072, 768, device=dev) * 0.05).bfloat16()
+    Ch = torch.empty(M, 3072, device=dev, dtype=torch.bfloat16); Uh = torch.empty_like(Ch)
+    bias_h = torch.zeros(3072, device=dev)
+    for name, N, K, kind in SHAPES:
+        if filt and not any(f in name for f in filt):
+            continue
+        A, B, C, kw, tkw, ref, K, N = make(name, N, K, kind)
+        rot = [A] + [A.clone() for _ in range(7)]
+        src = A.clone()
+        run = lambda a=A: nat.gemm(a, B, C, M, N, K, K, K, N, **tkw)
+        res = {}
+        for rnd in range(5):
+            for mode in ("warm", "rotate", "fresh", "fresh-nt", "fresh-gemm-t", "fresh-gemm-ct", "fresh-gemm-sc1", "fresh-gemm-csc1", "hot"):
+                if mode == "warm":
+                    run(); t = timed_launches(None, run, 16)
+                elif mode == "rotate":
+                    idx = [0]
+                    def f():
+                        idx[0] = (idx[0] + 1) % 8
+                        nat.gemm(rot[idx[0]], B, C, M, N, K, K, K, N, **tkw)
+                    t = timed_launches(None, f, 16)
+                elif mode == "fresh":
+                    t = timed_launches(lambda: torch.add(src, 0.0, out=A), run, 16)
+                elif mode == "fresh-nt":
+                    if K != 3072:
+                        continue
+                    # FFN-up writes its [M, 3072] output straight into A (same bytes, the real producer's store pattern and policy)
+                    t = timed_launches(lambda: nat.gemm(Xh, Wh, A, M, 3072, 768, 768, 768, 3072, bias=bias_h, act=1, U=Uh), run, 16)
+                elif mode.startswith("fresh-gemm-"):
+                    if K != 3072:
+                        continue
+                    # the same producer with other store policies (MMF_TUN_EPI_NT, MMF_TUN_EPI_SC1): t every output temporal; ct the bf16 output C
+                    # temporal, the saved gelu' still nt; sc1 every output write-through (no nt); csc1 C write-through, gelu' nt
+                    pol, sc1 = {"fresh-gemm-t": (1, 0), "fresh-gemm-ct": (3, 0), "fresh-gemm-sc1": (1, 7), "fresh-gemm-csc1": (3, 1)}[mode]
+                    def prod():
+                        nat.set_tunable(6, pol); nat.set_tunable(12, sc1)
+                        nat.gemm(Xh, Wh, A, M, 3072, 768, 768, 768, 3072, bias=bias_h, act=1, U=Uh)
+                        nat.set_tunable(6, 0); nat.set_tunable(12, 0)
+                    t = timed_launches(prod, run, 16)
+                else:
+                    t = timed_launches(lambda: nat.gemm(Xh, Wh, Ch, M, 3072, 768, 768, 768, 3072, bias=bias_h, act=1, U=Uh), run, 16)
+                res.setdefault(mode, []).append(statistics.median(t))
+        fl = 2.0 * M * N * K
+        print("%-11s N=%4d K=%4d %-24s" % (name, N, K, nat.gemm_last_kernel()[-24:]) +
+              "  ".join("%s %5.1f us (%3.0f TF)" % (m, statistics.median(v), fl / statistics.median(v) / 1e6) for m, v in res.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()

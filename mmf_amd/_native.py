@@ -260,6 +260,15 @@ def gemm_grouped(problems):
     _check(lib().mmf_gemm_bf16_grouped(arr, n, _stream()), "mmf_gemm_bf16_grouped")
 
 
+# call-site tags of the encoder layer's GEMMs (include/mmf_amd.h MMF_SITE_*, MMF_GEMM_SITE): they name a call for the per-site store policy
+SITE_QKV_FWD, SITE_ATTN_OUT_FWD, SITE_FFN_UP_FWD, SITE_FFN_DOWN_FWD, SITE_FFN_DOWN_DGRAD, SITE_FFN_UP_DGRAD, SITE_ATTN_OUT_DGRAD, SITE_QKV_DGRAD = range(1, 9)
+
+
+def gemm_site(s):
+    """`debug_flags` value that tags a GEMM call as site `s` (0: untagged)."""
+    return (int(s) & 15) << 20
+
+
 def gemm_last_kernel():
     """Family / tile of the kernel the last gemm / gemm_grouped call launched (bench.py labels its roofline with it)."""
     f = lib().mmf_gemm_last_kernel

@@ -401,11 +401,11 @@ def _split_mask(mask):
     return mask, 0
 
 
-def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail=0, qk_gate=None):
+def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail=0, qk_gate=None, site=0):
     M, H = x2.shape
     dev = x2.device
     qkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
-    nat.gemm(x2, wqkv16, qkv, M, 3 * H, H, H, H, 3 * H, bias=bqkv)
+    nat.gemm(x2, wqkv16, qkv, M, 3 * H, H, H, H, 3 * H, bias=bqkv, debug_flags=nat.gemm_site(site))
     if qk_gate is not None:       # ViLBERT dynamic_attention: per-sample column gates on the Q|K columns (vilbert.py:211-212)
         nat.rowgroup_scale(qkv, 3 * H, qk_gate, B, S, 2 * H)
     ctxt = torch.empty(M, H, dtype=BF16, device=dev)
@@ -460,12 +460,12 @@ class SelfAttentionFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # dense -> dropout -> (+ residual) -> LayerNorm      (BertSelfOutput / BertOutput)
 # ---------------------------------------------------------------------------------------------
-def _ddrln_fwd(h2, resid2, w16, bias, gamma, beta, eps, drop):
+def _ddrln_fwd(h2, resid2, w16, bias, gamma, beta, eps, drop, site=0):
     M, K = h2.shape
     N = w16.shape[0]
     dev = h2.device
     y = torch.empty(M, N, dtype=BF16, device=dev)
-    nat.gemm(h2, w16, y, M, N, K, K, K, N, bias=bias, resid=resid2, ldr=N, drop=drop)
+    nat.gemm(h2, w16, y, M, N, K, K, K, N, bias=bias, resid=resid2, ldr=N, drop=drop, debug_flags=nat.gemm_site(site))
     out = torch.empty(M, N, dtype=BF16, device=dev)
     mean = torch.empty(M, dtype=F32, device=dev)
     rstd = torch.empty(M, dtype=F32, device=dev)
@@ -693,14 +693,16 @@ class FeedForwardFn(torch.autograd.Function):
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
 
 
-def _dgrad(dy, ldy, w16, M, N, K, dx_resid=None, act_aux=None):
-    """dX [M, K] = dY [M, N] W [N, K] (W k-major: no transposed copy), residual-gradient add / saved-GELU' multiply fused."""
+def _dgrad(dy, ldy, w16, M, N, K, dx_resid=None, act_aux=None, site=0):
+    """dX [M, K] = dY [M, N] W [N, K] (W k-major: no transposed copy), residual-gradient add / saved-GELU' multiply fused.
+    `site`: the call's MMF_SITE_* tag (include/mmf_amd.h: names the call for the per-site store policy, like the native layer node's)."""
     dx = torch.empty(M, K, dtype=BF16, device=dy.device)
     wt = shadows.transposed(w16) if (N % 8 == 0 and _twin_pays(K)) else None
     if wt is not None:      # two row operands (W^T twin): the forward-form kernels, i.e. the 256x96 wide tile for these widths
-        nat.gemm(dy, wt, dx, M, K, N, ldy, N, K, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
+        nat.gemm(dy, wt, dx, M, K, N, ldy, N, K, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux, debug_flags=nat.gemm_site(site))
     else:
-        nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux)
+        nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K, act=2 if act_aux is not None else 0, aux=act_aux,
+                 debug_flags=nat.gemm_site(site))
     return dx
 
 
@@ -801,12 +803,12 @@ class TransformerLayerFn(torch.autograd.Function):
         I = w1_16.shape[0]
         dev = x2.device
         mask_add, tail = _split_mask(mask_add)
-        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail)
-        a_out, y1, mean1, rstd1 = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), g1.detach(), be1.detach(), eps1, drop_hid1)
+        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail, site=nat.SITE_QKV_FWD)
+        a_out, y1, mean1, rstd1 = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), g1.detach(), be1.detach(), eps1, drop_hid1, site=nat.SITE_ATTN_OUT_FWD)
         u = torch.empty(M, I, dtype=BF16, device=dev)
         hh = torch.empty(M, I, dtype=BF16, device=dev)
-        nat.gemm(a_out, w1_16, hh, M, I, H, H, H, I, bias=b1.detach(), act=1, U=u)
-        out, y2, mean2, rstd2 = _ddrln_fwd(hh, a_out, w2_16, b2.detach(), g2.detach(), be2.detach(), eps2, drop_hid2)
+        nat.gemm(a_out, w1_16, hh, M, I, H, H, H, I, bias=b1.detach(), act=1, U=u, debug_flags=nat.gemm_site(nat.SITE_FFN_UP_FWD))
+        out, y2, mean2, rstd2 = _ddrln_fwd(hh, a_out, w2_16, b2.detach(), g2.detach(), be2.detach(), eps2, drop_hid2, site=nat.SITE_FFN_DOWN_FWD)
         ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean1, rstd1, a_out, u, hh, y2, mean2, rstd2, wqkv16, wo16, w1_16, w2_16,
                               g1.detach(), g2.detach(), mask_add, o32)
         ctx.meta = (B, S, H, I, heads, drop_attn, drop_hid1, drop_hid2, tail)
@@ -824,18 +826,18 @@ class TransformerLayerFn(torch.autograd.Function):
         # (the bias gradients of the two output projections are column sums of dlin2 / dlin1, i.e. of the A operands of their
         # weight-gradient GEMMs: the grouped launch below delivers them, the LayerNorm backward does not have to)
         dres2, dlin2, dg2, dbe2, _ = _ln_bwd(_grad_bf16(g, H), y2, mean2, rstd2, g2, drop_hid2, False)
-        du = _dgrad(dlin2, H, w2_16, M, H, I, act_aux=u)                  # (dlin2 W2) * gelu'(u)
-        da = _dgrad(du, I, w1_16, M, I, H, dx_resid=dres2)                # du W1 + dres2  = gradient of the attention block's output
+        du = _dgrad(dlin2, H, w2_16, M, H, I, act_aux=u, site=nat.SITE_FFN_DOWN_DGRAD)                  # (dlin2 W2) * gelu'(u)
+        da = _dgrad(du, I, w1_16, M, I, H, dx_resid=dres2, site=nat.SITE_FFN_UP_DGRAD)     # du W1 + dres2  = gradient of the attention block's output
         # attention sub-layer
         dres1, dlin1, dg1, dbe1, _ = _ln_bwd(da, y1, mean1, rstd1, g1, drop_hid1, False)
-        dctx = _dgrad(dlin1, H, wo16, M, H, H)
+        dctx = _dgrad(dlin1, H, wo16, M, H, H, site=nat.SITE_ATTN_OUT_DGRAD)
         dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, S, dtype=F32, device=dev)
         scale = 1.0 / math.sqrt(H // heads)
         with (param_update.beside() if (param_update.beside is not None and not param_update.beside_wgrad) else contextlib.nullcontext()):
             nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
                               dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
-        dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1, site=nat.SITE_QKV_DGRAD) if ctx.needs_input_grad[0] else None
         # the four weight gradients, one launch
         p_1, dw1, db1 = _wgrad_problem(du, I, a_out, M, I, H, True)
         p_2, dw2, db2 = _wgrad_problem(dlin2, H, hh, M, H, I, True)

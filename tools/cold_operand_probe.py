@@ -12,6 +12,10 @@ A operand is varied:
     fresh-nt  the same through this library's GEMM epilogue (the in-step producer: FFN-up's GELU epilogue, non-temporal stores)
     fresh-gemm-t / -ct   that producer with temporal stores (MMF_TUN_EPI_NT = 1: every output; = 3: the bf16 output only, gelu' still nt)
     hot       warm A, but a heavy unrelated GEMM runs immediately before (the chip at the step's power / clock state)
+    side-rotate / side-A-rotate   the epilogue's row-wise side input (residual / saved gelu') from 8 buffers in turn (cold), A warm / cold too
+    out-sc1   warm operands, the consumer's own output stored write-through instead of non-temporally
+    flush     600 MB of unrelated data written before every launch: A, the side input AND the weights come from HBM (the in-step state of a
+              weight panel: 283 MB of bf16 weights and twins, 1.4 GB of activation traffic per step)
 
 `fresh` ~ `warm` would say the freshly written activation is served from cache and the penalty is clocks; `fresh` ~ `rotate` says the
 consumer pulls it from HBM whatever the producer's store policy."""
@@ -45,6 +49,7 @@ def main():
     Xh = torch.randn(M, 768, device=dev).bfloat16(); Wh = (torch.randn(3072, 768, device=dev) * 0.05).bfloat16()
     Ch = torch.empty(M, 3072, device=dev, dtype=torch.bfloat16); Uh = torch.empty_like(Ch)
     bias_h = torch.zeros(3072, device=dev)
+    big = torch.zeros(150 * 1024 * 1024, device=dev)
     for name, N, K, kind in SHAPES:
         if filt and not any(f in name for f in filt):
             continue
@@ -54,7 +59,7 @@ def main():
         run = lambda a=A: nat.gemm(a, B, C, M, N, K, K, K, N, **tkw)
         res = {}
         for rnd in range(5):
-            for mode in ("warm", "rotate", "fresh", "fresh-nt", "fresh-gemm-t", "fresh-gemm-ct", "fresh-gemm-sc1", "fresh-gemm-csc1", "hot"):
+            for mode in ("warm", "rotate", "fresh", "fresh-nt", "fresh-gemm-t", "fresh-gemm-ct", "fresh-gemm-sc1", "fresh-gemm-csc1", "hot", "side-rotate", "side-A-rotate", "out-sc1", "flush"):
                 if mode == "warm":
                     run(); t = timed_launches(None, run, 16)
                 elif mode == "rotate":
@@ -81,12 +86,35 @@ def main():
                         nat.gemm(Xh, Wh, A, M, 3072, 768, 768, 768, 3072, bias=bias_h, act=1, U=Uh)
                         nat.set_tunable(6, 0); nat.set_tunable(12, 0)
                     t = timed_launches(prod, run, 16)
+                elif mode in ("side-rotate", "side-A-rotate"):
+                    # the epilogue's row-wise side input (residual rows / the act-2 multiplier = the saved gelu') from HBM: 8 buffers in turn
+                    key = "aux" if "aux" in tkw else ("resid" if "resid" in tkw else None)
+                    if key is None:
+                        continue
+                    if "side_rot" not in res:
+                        res["side_rot"] = None
+                        side_rot = [tkw[key]] + [tkw[key].clone() for _ in range(7)]
+                    idx = [0]
+                    def f2():
+                        idx[0] = (idx[0] + 1) % 8
+                        kw2 = dict(tkw); kw2[key] = side_rot[idx[0]]
+                        nat.gemm(rot[idx[0]] if mode == "side-A-rotate" else A, B, C, M, N, K, K, K, N, **kw2)
+                    t = timed_launches(None, f2, 16)
+                elif mode == "flush":
+                    # everything cold, the weights too: 600 MB of other data go through the caches before every launch
+                    t = timed_launches(lambda: big.add_(1.0), run, 16)
+                elif mode == "out-sc1":
+                    def f3():
+                        nat.set_tunable(6, 1); nat.set_tunable(12, 7)
+                        run()
+                        nat.set_tunable(6, 0); nat.set_tunable(12, 0)
+                    t = timed_launches(None, f3, 16)
                 else:
                     t = timed_launches(lambda: nat.gemm(Xh, Wh, Ch, M, 3072, 768, 768, 768, 3072, bias=bias_h, act=1, U=Uh), run, 16)
                 res.setdefault(mode, []).append(statistics.median(t))
         fl = 2.0 * M * N * K
         print("%-11s N=%4d K=%4d %-24s" % (name, N, K, nat.gemm_last_kernel()[-24:]) +
-              "  ".join("%s %5.1f us (%3.0f TF)" % (m, statistics.median(v), fl / statistics.median(v) / 1e6) for m, v in res.items()), flush=True)
+              "  ".join("%s %5.1f us (%3.0f TF)" % (m, statistics.median(v), fl / statistics.median(v) / 1e6) for m, v in res.items() if v), flush=True)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@ A operand is varied:
     hot       warm A, but a heavy unrelated GEMM runs immediately before (the chip at the step's power / clock state)
     side-rotate / side-A-rotate   the epilogue's row-wise side input (residual / saved gelu') from 8 buffers in turn (cold), A warm / cold too
     out-sc1   warm operands, the consumer's own output stored write-through instead of non-temporally
+    l2flush   64 MB of unrelated data written before every launch: the L2s lose the operands, the Infinity Cache keeps them
     flush     600 MB of unrelated data written before every launch: A, the side input AND the weights come from HBM (the in-step state of a
               weight panel: 283 MB of bf16 weights and twins, 1.4 GB of activation traffic per step)
 
@@ -50,6 +51,7 @@ def main():
     Ch = torch.empty(M, 3072, device=dev, dtype=torch.bfloat16); Uh = torch.empty_like(Ch)
     bias_h = torch.zeros(3072, device=dev)
     big = torch.zeros(150 * 1024 * 1024, device=dev)
+    mid = torch.zeros(16 * 1024 * 1024, device=dev)
     for name, N, K, kind in SHAPES:
         if filt and not any(f in name for f in filt):
             continue
@@ -59,7 +61,7 @@ def main():
         run = lambda a=A: nat.gemm(a, B, C, M, N, K, K, K, N, **tkw)
         res = {}
         for rnd in range(5):
-            for mode in ("warm", "rotate", "fresh", "fresh-nt", "fresh-gemm-t", "fresh-gemm-ct", "fresh-gemm-sc1", "fresh-gemm-csc1", "hot", "side-rotate", "side-A-rotate", "out-sc1", "flush"):
+            for mode in ("warm", "rotate", "fresh", "fresh-nt", "fresh-gemm-t", "fresh-gemm-ct", "fresh-gemm-sc1", "fresh-gemm-csc1", "hot", "side-rotate", "side-A-rotate", "out-sc1", "flush", "l2flush"):
                 if mode == "warm":
                     run(); t = timed_launches(None, run, 16)
                 elif mode == "rotate":
@@ -103,6 +105,9 @@ def main():
                 elif mode == "flush":
                     # everything cold, the weights too: 600 MB of other data go through the caches before every launch
                     t = timed_launches(lambda: big.add_(1.0), run, 16)
+                elif mode == "l2flush":
+                    # 64 MB of unrelated data in between: every XCD's 4 MB L2 is refilled, the 256 MB Infinity Cache still holds the operands
+                    t = timed_launches(lambda: mid.add_(1.0), run, 16)
                 elif mode == "out-sc1":
                     def f3():
                         nat.set_tunable(6, 1); nat.set_tunable(12, 7)

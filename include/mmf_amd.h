@@ -35,7 +35,8 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 */
        MMF_TUN_LN_OLD = 3,         /* 1: LayerNorm with the one-wave-per-row, 8-byte-per-lane kernels even when H % 256 == 0 (A/B measurements) */
        MMF_TUN_ATTN_BWD_TWO_PASS = 4,   /* 1: head_dim-64 attention backward as the separate dQ and dK/dV kernels (A/B measurements) */
-       MMF_TUN_GEMM_WIDE_KS = 5,   /* wide-tile wave layout: 2 the two ping-pong groups split every K-step (fewer LDS fragment reads), 1 never, 0 where it measured faster (256x96, K >= 1536) */
+       MMF_TUN_GEMM_WIDE_KS = 5,   /* wide-tile wave layout: 2 the two ping-pong groups split every K-step (fewer LDS fragment reads), 0 / 1 never (the default since
+                                      round 4: faster in isolation at long K, slower inside the step), 3 the round-3 rule (256x96, K >= 1536) */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
        MMF_TUN_ATTN_FWD_OLD = 7,   /* 1: head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head (the round-2 form; A/B) */
        MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
@@ -53,7 +54,9 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
                                       the writing XCD's L2 like a streaming store but allocates in the Infinity Cache, where the next kernel finds it (an `nt` store
                                       bypasses it: tools/cold_operand_probe.py, profiles/r04_store_policy.txt).  0: the measured default (MMF_SITE_SC1_DEFAULT: the FFN
                                       up-projection's GELU output and the FFN-down dgrad's du, the two A operands of the K = 3072 GEMMs); 1: no site at all (A/B) */
-       MMF_TUN_COUNT = 15 };
+       MMF_TUN_ACT2_TILE = 15,     /* 1: the act-2 (times saved gelu') dgrad of the FFN takes the cost model's tile (256x128) instead of 256x96, the tile that measured
+                                      0.22 - 0.32 ms per step faster INSIDE the step (round 4; A/B) */
+       MMF_TUN_COUNT = 16 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)

@@ -483,6 +483,10 @@ static int wide_choice(const mmf_gemm_desc* d) {
     if (force < 0 || (d->debug_flags & 131072) || d->M < 512 || (d->K % 64) != 0 || d->K < 128) return 0;
     static const int BMs[4] = {0, 256, 192, 256}, BNs[4] = {0, 96, 192, 128};
     if (force >= 1 && force <= 3) return (d->N % BNs[force]) == 0 ? force : 0;
+    // Measured INSIDE the step (round 4, tools/step_ab.py, profiles/r04_in_step_choices.txt): the FFN-down dgrad (N = 3072, K = 768, times the saved gelu')
+    // on the 256 x 96 tile, 928 tiles in 3.6 rounds, instead of the 256 x 128 tile the isolated measurements and the cost model pick (44.5 us isolated,
+    // 54 - 60 us in the step): 7.63 against 7.89, 7.53 against 7.85 and 7.64 against 7.86 ms per step on three boxes.  MMF_TUN_ACT2_TILE = 1: the model's choice (A/B).
+    if (d->act == 2 && (d->N % 96) == 0 && d->N >= 2304 && d->K <= 1024 && mmf_amd_get_tunable(MMF_TUN_ACT2_TILE) != 1) return 1;
     // One workgroup per CU cannot hide a heavy epilogue behind a co-resident workgroup's K loop: the GELU up-projection (two
     // bf16 outputs, erf + exp per element) measured 70.7 us with wide tiles against 60.5 us inside the training step.
     if (d->act == 1) {      // MMF_TUN_GELU_WIDE re-opens the question on a later tree (A/B): 1 / 2 / 3 = that wide tile for the GELU GEMMs
@@ -504,14 +508,15 @@ template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     if constexpr (!AK && !BK_ && is_bf16<AT>::value && is_bf16<BT>::value) {
         if (e.splits <= 1) {
-            // K-split wave layout (gemm_wide.h, KS = 2): measured on the VQA2 shapes (tools/gemm_ab.py, profiles/r03_gemm_ab_ks.txt)
-            // it wins 3 - 5 % on the 256 x 96 tile once the K-loop is long (K = 2304 / 3072: 31.4 -> 30.2, 40.3 -> 38.1, 40.7 -> 39.4 us)
-            // and loses the extra LDS pass of its epilogue at K = 768 (18.6 -> 19.3 us) and on the square tiles (36.4 -> 43.1 us).
-            // MMF_TUN_GEMM_WIDE_KS: 0 that rule, 1 never, 2 always (A/B measurements).
+            // K-split wave layout (gemm_wide.h, KS = 2).  In isolation (tools/gemm_ab.py, profiles/r03_gemm_ab_ks.txt) it wins 3 - 5 % on the 256 x 96
+            // tile once the K-loop is long (K = 2304 / 3072: 31.4 -> 30.2, 40.3 -> 38.1, 40.7 -> 39.4 us) and loses the extra LDS pass of its epilogue
+            // at K = 768 and on the square tiles.  INSIDE the step it loses: round 4's same-process A/B of the whole graphed step (tools/step_ab.py,
+            // profiles/r04_in_step_choices.txt) measures 7.95 against 8.28 ms and 7.68 against 7.79 ms (two boxes) without it, so the default is now
+            // "never".  MMF_TUN_GEMM_WIDE_KS: 0 / 1 never, 2 always, 3 the round-3 rule (256 x 96 with K >= 1536) (A/B measurements).
             const int ks_t = mmf_amd_get_tunable(MMF_TUN_GEMM_WIDE_KS);
             const int wc = wide_choice(d);
             // (Only the 256 x 96 tile is instantiated with KS = 2: the square tiles lost with it and would spill registers.)
-            const bool ks2 = wc == 1 && (ks_t == 2 || (ks_t == 0 && d->K >= 1536));
+            const bool ks2 = wc == 1 && (ks_t == 2 || (ks_t == 3 && d->K >= 1536));
             switch (wc) {
                 case 1: return ks2 ? launch_wide<256, 96, 4, 1, 3, 2>(d, e, s) : launch_wide<256, 96, 4, 2, 3>(d, e, s);
                 case 2: return launch_wide<192, 192, 2, 4, 3>(d, e, s);

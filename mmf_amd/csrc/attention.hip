@@ -115,7 +115,9 @@ DEVI void store_tile_rows(const f32x16 (&acc)[2], float mul, unsigned char* img,
     }
 }
 
-// The same for an fp32 copy of the rows (256-byte rows; 16-byte chunks XOR-swizzled by row & 15), 8 KB image.
+// The same for an fp32 copy of the rows (256-byte rows; 16-byte chunks XOR-swizzled by row & 15), 8 KB image.  The copy is read again only by the
+// backward pass, a few milliseconds later: it is stored non-temporally (it would only push the next kernels' operands out of the Infinity Cache;
+// -0.01 .. -0.08 ms per step on three boxes, profiles/r04_store_policy.txt section 9).
 DEVI void store_tile_rows_f32(const f32x16 (&acc)[2], float mul, unsigned char* img, float* g, int ld, int nvalid, int lane) {
     const int x = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -129,7 +131,7 @@ DEVI void store_tile_rows_f32(const f32x16 (&acc)[2], float mul, unsigned char* 
     for (int i = 0; i < 8; ++i) {
         const int row = 4 * i + (lane >> 4), chunk = lane & 15;
         const float4 v = *reinterpret_cast<const float4*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
-        if (row < nvalid) *reinterpret_cast<float4*>(g + (size_t)row * ld + 4 * chunk) = v;
+        if (row < nvalid) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(g + (size_t)row * ld + 4 * chunk));
     }
 }
 
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
             for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    *reinterpret_cast<float4*>(o32 + 32 * dt + 8 * c + 4 * h) =
-                        make_float4(o[dt][4 * c + 0] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv);
+                    __builtin_nontemporal_store(f32x4{o[dt][4 * c + 0] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv},
+                                                reinterpret_cast<f32x4*>(o32 + 32 * dt + 8 * c + 4 * h));
         }
     }
     PROBE_AT(7);

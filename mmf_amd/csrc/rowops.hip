@@ -1120,8 +1120,8 @@ __global__ void optim_state_advance_kernel(float* state, int schedule, float war
 
 // One-dimensional grid over the (tensor, chunk) pairs of the launch: cstart[t] = first block of tensor t (no empty workgroups
 // beside a large tensor).  A workgroup owns ADAM_CHUNK = 4096 elements = ONE pass of 4 x 16 bytes per thread and stream with all
-// loads issued before anything is computed; g, m, v are touched once per step, so they move with non-temporal hints and leave the
-// caches to p / the bf16 shadow the next forward reads (tools/ubench/adam_bench.hip: 4.4 -> 5.8 TB/s on the word-embedding table).
+// loads issued before anything is computed; g, m, v and (round 4: -0.04 ms per step, tools/step_ab.py) the fp32 master p are touched once per step, so
+// they move with non-temporal hints and leave the caches to the bf16 shadow the next forward reads (tools/ubench/adam_bench.hip: 4.4 -> 5.8 TB/s on the word-embedding table).
 constexpr int ADAM_CHUNK = 4096;
 struct AdamLaunch {
     mmf_adamw_multi_desc d;
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc
         cnt[u] = (i >= end) ? 0 : ((i + 4 <= end) ? 4 : (int)(end - i));
         vec[u] = (cnt[u] == 4) && ((i & 3) == 0);
         if (vec[u]) {
-            pv[u] = load4(p + i);
+            pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i));
             if (gb) {
                 const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(g16 + i);
                 gv[u] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc
             }
         }
         if (vec[u]) {
-            store4(p + i, pv[u]);
+            __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4*>(p + i));
             __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(m + i));
             __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + i));
             if (p16) store4(p16 + i, pv[u]);

@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(mmf_transpose_list
             bf16x8 v;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = tile[c8 + j][c];
-            *reinterpret_cast<bf16x8*>(dst + (size_t)(c0 + c) * R + r0 + c8) = v;
+            // (the twins are read by the NEXT step's backward pass: non-temporal, they would only push the bf16 shadows the next forward reads out of the
+            // Infinity Cache; -0.04 ms per step, profiles/r04_store_policy.txt section 11)
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst + (size_t)(c0 + c) * R + r0 + c8));
         }
         __syncthreads();
     }

@@ -141,3 +141,57 @@ def test_two_ranks_chained_graphs_apply_the_whole_batch_update():
         assert not torch.equal(p0, torch.from_numpy(init[name])), name          # ... and two optimizer steps moved the parameter
         checked += 1
     assert checked > 30
+
+
+def _rccl_worker(port, q):
+    """One rank, the REAL backend ("nccl" = RCCL): the chained step with its all-reduce calls issued between the stage graphs (a 1-rank
+    communicator makes every sum the identity) against the same step without any collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.pop("MMF_AMD_DIST_BACKEND", None)
+    import torch.distributed as dist
+    from mmf_amd.common.sample import SampleList
+    from mmf_amd.utils.graph import GraphedDataParallelStep
+    from tests.golden_utils import load_case
+    from tests.model_utils import build_visual_bert, sample_to
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    t = torch.ones(4096, device="cuda", dtype=torch.bfloat16)
+    dist.all_reduce(t, async_op=True).wait()
+    torch.cuda.synchronize()
+    assert float(t.float().sum()) == 4096.0
+    z, case, cfg, sd, sample = load_case("small64")
+    batch = SampleList(sample_to(sample, "cuda"))
+    out = {}
+    for forced in (False, True):
+        model = build_visual_bert(cfg, sd); model.eval()
+        opt = _optimizer(model, True)
+        step = GraphedDataParallelStep(model, batch, _layers(model), opt, warmup=1, comm_dtype=torch.bfloat16)
+        if forced:
+            step.world = 2              # issue the collectives (bf16 and fp32 wire buffers, async, waited for one stage later)
+            opt.grad_scale = 1.0        # ... whose sum over the ONE rank is the identity
+        losses = [float(step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        out[forced] = (losses, {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()})
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_chained_graphs_with_rccl_collectives_between_the_stages():
+    """The N > 1 launch structure with the real communicator library: RCCL's all_reduce (bf16 and fp32 buffers, async_op, wait one stage later)
+    interleaved with hipGraph replays on one rank must leave losses and parameters bit-identical to the chain without collectives."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q), daemon=True)
+    p.start()
+    try:
+        out = q.get(timeout=200)
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    finally:
+        if p.is_alive():
+            p.kill()
+    (l0, p0), (l1, p1) = out[False], out[True]
+    assert l0 == l1, (l0, l1)
+    assert l0[2] < l0[0]
+    for n in p0:
+        assert (p0[n] == p1[n]).all(), n

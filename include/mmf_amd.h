@@ -475,7 +475,7 @@ int mmf_adamw_step(float* p, const float* g, float* m, float* v, void* p16, int6
  * min(1, max_norm / (sqrt(norm_sq[0]) + 1e-6)) on the fly: clip_gradients (mmf/utils/general.py:33-50) folded
  * into the update.  mmf_l2norm_sq_multi computes (or accumulates) sum(g^2) over a tensor list deterministically;
  * ws: mmf_l2norm_sq_ws_floats(list) floats. */
-#define MMF_MT_MAX 40
+#define MMF_MT_MAX 52
 typedef struct mmf_adamw_multi_desc {
     int n;
     void* p[MMF_MT_MAX];

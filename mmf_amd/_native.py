@@ -53,7 +53,7 @@ class AttnDesc(C.Structure):
     ]
 
 
-MT_MAX = 40
+MT_MAX = 52
 
 
 class AdamWMultiDesc(C.Structure):

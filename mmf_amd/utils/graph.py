@@ -57,6 +57,16 @@ def _copy_batch(dst, src):
             _copy_batch(v, src[k])
 
 
+def total_loss(out):
+    """The scalar the trainer differentiates: the sum over the loss dict of each entry's sum (mmf/trainers/core/training_loop.py:199-213 sums the
+    entries' means; every loss of this package is already a scalar).  A single scalar entry is returned as it is: `tensor.sum()` of a 0-dim tensor
+    and Python's `0 + tensor` are two more kernels (a reduction and an add) that compute nothing."""
+    vals = list(out["losses"].values())
+    if len(vals) == 1 and vals[0].dim() == 0:
+        return vals[0]
+    return sum(v.sum() for v in vals)
+
+
 class GraphedTrainStep:
     """`optimizer` (an `adam_w` built with `capturable=True`) puts the parameter update into the graph as well: one
     replay = one full training step.  The optimizer then also keeps the bf16 weight shadows current, so no cast kernel
@@ -89,7 +99,7 @@ class GraphedTrainStep:
         self.optimizer = optimizer
         if optimizer is not None and not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs an optimizer whose step reads its counters from device memory (capturable=True)")
-        self.loss_of = loss_of or (lambda out: sum(v.sum() for v in out["losses"].values()))
+        self.loss_of = loss_of or total_loss
         release_autograd_state()
         self.static_batch = _clone_batch(batch)
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -141,7 +151,10 @@ class GraphedTrainStep:
         with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.param_update(
                 self.optimizer.update_in_backward if early else None, self.optimizer.beside_attention if (early and self.pin_update) else None,
                 beside_wgrad=self.pin_wgrad):
-            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            # (the seed of the backward pass is a tensor made once, ahead of the capture: `grad_outputs=None` fills a new ones tensor per step)
+            if getattr(self, "_one", None) is None or self._one.dtype != loss.dtype:
+                self._one = torch.ones_like(loss)
+            grads = torch.autograd.grad(loss, self.params, grad_outputs=self._one, allow_unused=True)
         for p, g in zip(self.params, grads):
             p.grad = g
         if self.optimizer is not None and update:
@@ -193,7 +206,7 @@ class GraphedDataParallelStep:
         if comm_dtype is None:
             comm_dtype = torch.bfloat16 if self.world > 1 else torch.float32
         self.comm_dtype = comm_dtype
-        self.loss_of = loss_of or (lambda out: sum(v.sum() for v in out["losses"].values()))
+        self.loss_of = loss_of or total_loss
         self.cuts = list(cuts)
         release_autograd_state()
         self.static_batch = _clone_batch(batch)
@@ -279,7 +292,9 @@ class GraphedDataParallelStep:
         root = self._loss_t if j == 0 else self._bounds[n - j][0]
         inputs = list(params) + ([self._bounds[n - j - 1][1]] if j < n else [])
         with Fn.ln_defer():        # the stage's LayerNorm parameter gradients are finished by one launch at its end
-            grads = torch.autograd.grad(root, inputs, grad_outputs=None if j == 0 else carry, allow_unused=True)
+            if j == 0 and (getattr(self, "_one", None) is None or self._one.dtype != root.dtype):
+                self._one = torch.ones_like(root)
+            grads = torch.autograd.grad(root, inputs, grad_outputs=self._one if j == 0 else carry, allow_unused=True)
         if j < n:
             if grads[-1] is None:
                 raise RuntimeError("GraphedDataParallelStep: the loss does not depend on the output of cut %d" % (n - j - 1))

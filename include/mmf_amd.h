@@ -197,7 +197,12 @@ typedef struct mmf_attn_desc {
                               Incremental greedy decoding of M4C (mmf/models/m4c.py:284-304 re-runs the whole multimodal
                               transformer per step): step i attends from ONE new row to the cached encoder rows and the i
                               decoding rows before it, i.e. Sq = 1, Sk = E + i + 1, both strides = E + D */
-    int mask_batch_stride; /* forward only, 0 = Sk: mask entries per batch */
+    int mask_batch_stride; /* 0 = Sk (Sq * mask_query_stride with a per-query mask): mask entries per batch; a custom value is forward only */
+    int mask_query_stride; /* 0: `mask` is the additive KEY mask [B, Sk] every model of the path uses (the reference's [B, 1, 1, S]).  n >= Sk: `mask` is a
+                              materialised additive mask per (query, key) pair, entry (b, q, key) at mask[b * mask_batch_stride + q * n + key] — what
+                              BertSelfAttentionJit.forward accepts as a [B, 1, S, S] attention_mask (`attention_scores + attention_mask`,
+                              mmf/modules/hf_layers.py:187-190; MMT.forward builds one, mmf/models/m4c.py:424-440).  head_dim 64, forward and backward;
+                              replaces `causal_tail` (which is the cheaper form of M4C's mask). */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
 

@@ -49,7 +49,7 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("head_dim", C.c_int), ("ctx_f32", C.c_void_p), ("causal_tail", C.c_int),
-        ("q_batch_rows", C.c_int), ("kv_batch_rows", C.c_int), ("mask_batch_stride", C.c_int),
+        ("q_batch_rows", C.c_int), ("kv_batch_rows", C.c_int), ("mask_batch_stride", C.c_int), ("mask_query_stride", C.c_int),
     ]
 
 
@@ -317,6 +317,12 @@ def gemm_rowsum_supported(M, N, K):
 def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim=64, ctx_f32=None,
                causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0):
     d = AttnDesc()
+    # a 3-D mask [B, Sq, Sk] is a materialised additive mask per (query, key) pair (mmf_attn_desc.mask_query_stride); 2-D: the key mask [B, Sk]
+    d.mask_query_stride = int(mask.stride(1)) if (mask is not None and mask.dim() == 3) else 0
+    if d.mask_query_stride and not mask_batch_stride:
+        if tuple(mask.shape) != (B, Sq, Sk) or mask.stride(2) != 1:
+            raise NativeLibraryError("a per-query attention mask must be [B, Sq, Sk] with contiguous rows, got %s" % (tuple(mask.shape),))
+        mask_batch_stride = int(mask.stride(0)) if mask.stride(0) != Sq * mask.stride(1) else 0
     d.causal_tail = int(causal_tail)
     d.q_batch_rows, d.kv_batch_rows, d.mask_batch_stride = int(q_batch_rows), int(kv_batch_rows), int(mask_batch_stride)
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):

@@ -146,6 +146,22 @@ DEVI void tail_mask(float (&mkv)[4], int key0, int q, int cfrom, int Sk) {
     }
 }
 
+// Mask modes of the kernels: the additive key mask [B, Sk] (every model of the path), the same plus M4C's causal tail, or a materialised
+// additive mask per (query, key) pair, [B, Sq, Sk] — what `BertSelfAttentionJit.forward` accepts as a `[B, 1, S, S]` attention_mask
+// (mmf/modules/hf_layers.py:161-213: `attention_scores + attention_mask`, any broadcastable shape).
+enum { MASK_KEY = 0, MASK_TAIL = 1, MASK_QUERY = 2 };
+
+// Four mask values of ONE query row (log2 domain) for keys key0 .. key0 + 3; keys >= Sk are padding (-inf).
+DEVI void query_mask4(float (&mkv)[4], const float* mrow, int key0, int Sk, bool vec) {
+    if (vec && key0 + 3 < Sk) {
+        const float4 m = *reinterpret_cast<const float4*>(mrow + key0);
+        mkv[0] = m.x * 1.4426950408889634f; mkv[1] = m.y * 1.4426950408889634f; mkv[2] = m.z * 1.4426950408889634f; mkv[3] = m.w * 1.4426950408889634f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mkv[i] = (key0 + i < Sk) ? mrow[key0 + i] * 1.4426950408889634f : -INFINITY;
+    }
+}
+
 struct AttnArgs {
     const bf16* q; const bf16* k; const bf16* v;
     int ldq, ldk, ldv;
@@ -156,6 +172,7 @@ struct AttnArgs {
     int B, heads, Sq, Sk, skp, hd;
     int cfrom;           // first key of the causal tail (== Sk when there is none), see mmf_attn_desc.causal_tail
     int q_bs, kv_bs, m_bs;   // rows between consecutive batches of q / of k, v / mask entries per batch (defaults Sq, Sk, Sk)
+    int m_qs;                // per-query mask (mmf_attn_desc.mask_query_stride): mask entries between consecutive query rows; 0 = one mask row per batch
     float scale;
     DropoutCfg drop;
     // backward only
@@ -198,8 +215,9 @@ struct WaveProbe {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int NKT, int D, bool CZ>
+template <int NKT, int D, int MM>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs a) {
+    constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
     constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_k = smem;                         // row-major K  [NKT*32][D]
@@ -218,10 +236,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     const bf16* vbase = a.v + (size_t)b * a.kv_bs * a.ldv + head * HD;
     stage_rows<D>(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
     stage_rows<D>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
-    for (int i = tid; i < SKP; i += 256)   // additive mask, already in the log2 domain
-        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.m_bs + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    if constexpr (!MQ) {
+        for (int i = tid; i < SKP; i += 256)   // additive mask, already in the log2 domain
+            lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.m_bs + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    }
     // Q fragments (B operand: column = query row), fetched while the K / V DMA is still in flight
     const int qrow = min(q0 + x, a.Sq - 1);
+    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)qrow * a.m_qs : nullptr;      // this lane's row of the per-query mask
+    const bool mvec = MQ && ((a.m_qs | a.m_bs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
     const bf16* qptr = a.q + ((size_t)b * a.q_bs + qrow) * a.ldq + head * HD;
     bf16x8 qf[NS];
 #pragma unroll
@@ -252,8 +274,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
-            float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            float mkv[4];
+            if constexpr (MQ) query_mask4(mkv, mrow, 32 * t + 8 * c + 4 * h, a.Sk, mvec);
+            else {
+                const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+                mkv[0] = mk.x; mkv[1] = mk.y; mkv[2] = mk.z; mkv[3] = mk.w;
+            }
             if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -343,8 +369,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
 // on a CU: B * heads = 384 workgroups are ONE round of the 512 slots instead of 768 workgroups on 512 slots (1.5 rounds, the second
 // half-empty; profiles/r02_attention_timeline.txt), with four waves per SIMD to overlap one wave's softmax VALU with another's MFMAs.
 // Same arithmetic in the same order as attn_fwd_kernel (scores, maxima, exponentials, row sums, P V accumulation): bit-identical outputs.
-template <int NKT, bool CZ>
+template <int NKT, int MM>
 __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
+    constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
     constexpr int D = 64, HD = 64, NS = 4, NDT = 2, ROWB = 128, SKP = NKT * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_k = smem;
@@ -359,9 +386,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
     const bf16* vbase = a.v + (size_t)b * a.kv_bs * a.ldv + head * HD;
     stage_rows<D, 8>(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
     stage_rows<D, 8>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
-    for (int i = tid; i < SKP; i += 512)
-        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.m_bs + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    if constexpr (!MQ) {
+        for (int i = tid; i < SKP; i += 512)
+            lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.m_bs + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    }
     const int qrow = min(q0 + x, a.Sq - 1);
+    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)qrow * a.m_qs : nullptr;
+    const bool mvec = MQ && ((a.m_qs | a.m_bs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
     const bf16* qptr = a.q + ((size_t)b * a.q_bs + qrow) * a.ldq + head * HD;
     bf16x8 qf[NS];
 #pragma unroll
@@ -384,8 +415,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_k, 32 * t, s, lane), qf[s], acc, 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
-                float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+                float mkv[4];
+                if constexpr (MQ) query_mask4(mkv, mrow, 32 * t + 8 * c + 4 * h, a.Sk, mvec);
+                else {
+                    const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+                    mkv[0] = mk.x; mkv[1] = mk.y; mkv[2] = mk.z; mkv[3] = mk.w;
+                }
                 if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[4 * c + i] * sc2 + mkv[i]);
@@ -404,8 +439,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm<D>(lds_k, 32 * t, s, lane), qf[s], acc, 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
-                float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+                float mkv[4];
+                if constexpr (MQ) query_mask4(mkv, mrow, 32 * t + 8 * c + 4 * h, a.Sk, mvec);
+                else {
+                    const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+                    mkv[0] = mk.x; mkv[1] = mk.y; mkv[2] = mk.z; mkv[3] = mk.w;
+                }
                 if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -719,8 +758,9 @@ DEVI bf16x8 frag_tr_patch(const unsigned char* patch, int u, int lane) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool CZ>
+template <int MM>
 __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
+    constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
     constexpr int D = 64, NS = 4, NDT = 2, ROWB = 128, SP = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_q = smem;                                   // row-major Q   [256][64]
@@ -752,7 +792,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) vf[s] = frag_global(vptr, s, lane);
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses VALU arbitration otherwise (MI355X_MICROARCH.md)
-    const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    const float mk = kvalid ? ((a.mask && !MQ) ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    const float* mcol = MQ ? a.mask + (size_t)b * a.m_bs + krow : nullptr;      // per-query mask: this lane's key column, one entry per query row
     // delta[q] = sum_d dO[q][d] O[q][d] (two threads per query row, a contiguous half of the head slice each; from the fp32
     // copy of O when the forward kept one) and the log-sum-exp in the log2 domain; padded rows: lse = +inf -> p = 0
     {
@@ -843,6 +884,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
                         const int q = 32 * t + 8 * c + 4 * h + i;
                         if (kvalid && k0 + x >= a.cfrom) mkq = (q >= a.cfrom && k0 + x <= q) ? 0.f : -10000.f * 1.4426950408889634f;
                     }
+                    if constexpr (MQ) {   // (padded query rows carry lse = +inf: p = 0 whatever is read for them)
+                        const int q = min(32 * t + 8 * c + 4 * h + i, a.Sq - 1);
+                        if (kvalid) mkq = mcol[(size_t)q * a.m_qs] * 1.4426950408889634f;
+                    }
                     const float p = __builtin_amdgcn_exp2f(s_acc[4 * c + i] * sc2 + mkq - Lv[i]);
                     pd[4 * c + i] = p * dsc[i];
                     s_acc[4 * c + i] = p * (dp_acc[4 * c + i] * dsc[i] - Dv[i]);      // dS without the 1/sqrt(d): applied to dK, dQ at the end
@@ -913,8 +958,12 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.cfrom = d->Sk - d->causal_tail;
     a.q_bs = d->q_batch_rows > 0 ? d->q_batch_rows : d->Sq;
     a.kv_bs = d->kv_batch_rows > 0 ? d->kv_batch_rows : d->Sk;
-    a.m_bs = d->mask_batch_stride > 0 ? d->mask_batch_stride : d->Sk;
+    a.m_qs = d->mask_query_stride;
+    MMF_CHECK_ARG(a.m_qs == 0 || (d->mask && a.m_qs >= d->Sk), "attention: mask_query_stride must cover a mask row (>= Sk)");
+    MMF_CHECK_ARG(a.m_qs == 0 || (hd == 64 && d->causal_tail == 0), "attention: a per-query mask is built for head_dim 64 (and replaces the causal tail)");
+    a.m_bs = d->mask_batch_stride > 0 ? d->mask_batch_stride : (a.m_qs ? d->Sq * a.m_qs : d->Sk);
     MMF_CHECK_ARG(a.q_bs >= d->Sq && a.kv_bs >= d->Sk && a.m_bs >= d->Sk, "attention: batch strides must cover the sequence");
+    MMF_CHECK_ARG(a.m_qs == 0 || a.m_bs >= (d->Sq - 1) * a.m_qs + d->Sk, "attention: mask_batch_stride must cover the per-query mask of a sample");
     a.scale = d->scale;
     a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
@@ -945,24 +994,34 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         hipLaunchKernelGGL((attn_fwd_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);            \
     }
     const bool cz = a.cfrom < a.Sk;
+    if (a.m_qs) {      // per-query mask [B, Sq, Sk] (head_dim 64): the same two kernel forms, mask read per (query, key) from global memory
+        if (nkt > 4 && a.Sq > 128 && !mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD)) {
+            const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
+            if (int rc = set_lds(attn_fwd8_kernel<8, MASK_QUERY>, lds)) return rc;
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_QUERY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+        } else if (nkt <= 4) LAUNCH_FWD(4, 64, MASK_QUERY)
+        else LAUNCH_FWD(8, 64, MASK_QUERY)
+        MMF_CHECK_LAUNCH();
+        return 0;
+    }
     // head_dim 64 with more than 128 queries: the one-round form (one 8-wave workgroup per (batch, head), two per CU; attn_fwd8_kernel).
     // MMF_TUN_ATTN_FWD_OLD = 1 keeps the two-workgroups-per-head form (A/B measurements, bit-equality test).
     if (a.hd == 64 && nkt > 4 && a.Sq > 128 && !mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD)) {
         const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
         const dim3 grid8(a.B * a.heads);
         if (cz) {
-            if (int rc = set_lds(attn_fwd8_kernel<8, true>, lds)) return rc;
-            hipLaunchKernelGGL((attn_fwd8_kernel<8, true>), grid8, dim3(512), lds, s, a);
+            if (int rc = set_lds(attn_fwd8_kernel<8, MASK_TAIL>, lds)) return rc;
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_TAIL>), grid8, dim3(512), lds, s, a);
         } else {
-            if (int rc = set_lds(attn_fwd8_kernel<8, false>, lds)) return rc;
-            hipLaunchKernelGGL((attn_fwd8_kernel<8, false>), grid8, dim3(512), lds, s, a);
+            if (int rc = set_lds(attn_fwd8_kernel<8, MASK_KEY>, lds)) return rc;
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_KEY>), grid8, dim3(512), lds, s, a);
         }
         MMF_CHECK_LAUNCH();
         return 0;
     }
-    if (a.hd == 128) LAUNCH_FWD(4, 128, false)
-    else if (nkt <= 4) { if (cz) LAUNCH_FWD(4, 64, true) else LAUNCH_FWD(4, 64, false) }
-    else { if (cz) LAUNCH_FWD(8, 64, true) else LAUNCH_FWD(8, 64, false) }
+    if (a.hd == 128) LAUNCH_FWD(4, 128, MASK_KEY)
+    else if (nkt <= 4) { if (cz) LAUNCH_FWD(4, 64, MASK_TAIL) else LAUNCH_FWD(4, 64, MASK_KEY) }
+    else { if (cz) LAUNCH_FWD(8, 64, MASK_TAIL) else LAUNCH_FWD(8, 64, MASK_KEY) }
 #undef LAUNCH_FWD
     MMF_CHECK_LAUNCH();
     return 0;
@@ -983,14 +1042,17 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;
     const bool cz = a.cfrom < a.Sk;
-    if (a.hd == 64 && !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS)) {
+    if (a.hd == 64 && (a.m_qs || !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS))) {
         const int lds = 3 * 256 * 128 + 16 * 2048 + 2 * 256 * 4;
-        if (cz) {
-            if (int rc = set_lds(attn_bwd_fused_kernel<true>, lds)) return rc;
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<true>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+        if (a.m_qs) {      // per-query mask: the one-pass kernel only
+            if (int rc = set_lds(attn_bwd_fused_kernel<MASK_QUERY>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<MASK_QUERY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+        } else if (cz) {
+            if (int rc = set_lds(attn_bwd_fused_kernel<MASK_TAIL>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<MASK_TAIL>), dim3(a.B * a.heads), dim3(512), lds, s, a);
         } else {
-            if (int rc = set_lds(attn_bwd_fused_kernel<false>, lds)) return rc;
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<false>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+            if (int rc = set_lds(attn_bwd_fused_kernel<MASK_KEY>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<MASK_KEY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
         }
         MMF_CHECK_LAUNCH();
         return 0;

@@ -419,7 +419,15 @@ void attn_desc(mmf_attn_desc& d, const Tensor& qkv, int64_t H, const Tensor& mas
     char* base = reinterpret_cast<char*>(qkv.data_ptr());
     d.q = base; d.k = base + 2 * H; d.v = base + 4 * H;       // bf16: H elements = 2H bytes
     d.ldq = d.ldk = d.ldv = (int)(3 * H);
-    if (mask.defined()) { req(mask, at::kFloat, "attention mask"); d.mask = mask.data_ptr<float>(); }
+    if (mask.defined()) {
+        req(mask, at::kFloat, "attention mask"); d.mask = mask.data_ptr<float>();
+        if (mask.dim() == 3) {      // materialised additive mask per (query, key) pair, [B, S, S] (mmf_attn_desc.mask_query_stride)
+            TORCH_CHECK(mask.size(0) == B && mask.size(1) == S && mask.size(2) == S && mask.is_contiguous(), "mmf_amd: a per-query attention mask must be a contiguous [B, S, S] tensor");
+            d.mask_query_stride = (int)S;
+        } else {
+            TORCH_CHECK(mask.numel() == B * S, "mmf_amd: the additive key mask must hold B * S entries");
+        }
+    }
     d.ctx = ctx.data_ptr(); d.ldo = (int)H; d.lse = lse.data_ptr<float>();
     d.B = (int)B; d.heads = (int)heads; d.Sq = d.Sk = (int)S;
     d.scale = (float)(1.0 / std::sqrt((double)(H / heads)));

@@ -98,10 +98,17 @@ def additive_key_mask(attention_mask, batch, seq):
         return Fn.PrefixLMMask(additive_key_mask(attention_mask.key_mask, batch, seq), attention_mask.causal_tail)
     m = attention_mask
     if m.dim() == 4:
-        if m.shape[1] != 1 or m.shape[2] != 1:
-            raise NotImplementedError("a materialised per-query mask [B,1,S,S] is not read by the fused kernel; for M4C's "
-                                      "prefix-LM mask pass mmf_amd.functional.PrefixLMMask(key_mask, dec_steps)")
-        m = m.reshape(batch, seq)
+        if m.shape[1] != 1:
+            raise NotImplementedError("a per-head attention mask [B, heads, S, S] is not read by the fused kernel (one mask per sample: [B,1,1,S] or [B,1,S,S])")
+        if m.shape[2] != 1:
+            # A materialised additive mask per (query, key) pair, as `attention_scores + attention_mask` takes it (hf_layers.py:187-190;
+            # MMT.forward builds one, m4c.py:424-440): the kernels read it from global memory (mmf_attn_desc.mask_query_stride).  For M4C's
+            # prefix-LM structure `mmf_amd.functional.PrefixLMMask(key_mask, dec_steps)` is the cheaper form (nothing is materialised).
+            if tuple(m.shape) != (batch, 1, seq, seq):
+                raise ValueError("attention_mask of shape %s does not match hidden states [%d, %d, ...]" % (tuple(m.shape), batch, seq))
+            m = m.reshape(batch, seq, seq)
+        else:
+            m = m.reshape(batch, seq)
     if m.dtype != torch.float32:
         m = m.float()
     return m.contiguous()
@@ -261,10 +268,12 @@ class BertLayerJit(nn.Module):
         if attention_mask is not None:
             m = attention_mask
             if m.dim() == 4:
-                if m.shape[1] != 1 or m.shape[2] != 1:
-                    raise NotImplementedError("a materialised per-query mask [B,1,S,S] is not read by the fused kernel; for M4C's "
-                                              "prefix-LM mask pass mmf_amd.functional.PrefixLMMask(key_mask, dec_steps)")
-                m = m.reshape(B, S)
+                if m.shape[1] != 1:
+                    raise NotImplementedError("a per-head attention mask [B, heads, S, S] is not read by the fused kernel")
+                if m.shape[2] != 1:       # a materialised additive mask per (query, key) pair (see additive_key_mask)
+                    m = m.reshape(B, S, S)
+                else:
+                    m = m.reshape(B, S)
             mask_add = m.float().contiguous()
         sa, so = self.attention.self, self.attention.output
         it, ot = self.intermediate, self.output

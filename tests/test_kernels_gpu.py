@@ -526,6 +526,83 @@ def test_layernorm_half_wave_kernels_agree_with_the_one_wave_per_row_kernels(H):
     assert torch.equal(res[0][4] == 0, res[1][4] == 0)      # same dropout mask
 
 
+def _attn_run(qkv, mask, B, heads, S, drop, tail=0):
+    H = heads * 64
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    ctx = torch.full((B * S, H), float("nan"), dtype=torch.bfloat16, device=DEV); c32 = torch.full((B * S, H), float("nan"), device=DEV)
+    lse = torch.full((B, heads, S), float("nan"), device=DEV)
+    nat().attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, 0.125, drop, ctx_f32=c32, causal_tail=tail)
+    dctx = rnd(B * S, H, seed=77)
+    dqkv = torch.full_like(qkv, 5.0); delta = torch.empty(B, heads, S, device=DEV)
+    nat().attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, 0.125, dctx, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
+                        delta, drop, ctx_f32=c32, causal_tail=tail)
+    return ctx, c32, lse, dqkv
+
+
+@pytest.mark.parametrize("B,heads,S", [(2, 3, 228), (2, 2, 100), (1, 2, 182), (1, 1, 33), (1, 2, 256)])
+def test_attention_per_query_mask_against_reference(B, heads, S):
+    """A materialised additive mask per (query, key) pair, [B, S, S] — `attention_scores + attention_mask` with a [B, 1, S, S] mask
+    (mmf/modules/hf_layers.py:187-190) — read by the forward kernels (both forms) and the one-pass backward: against fp32 torch."""
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, scale=1.0, seed=31)
+    g = torch.Generator(device="cpu").manual_seed(S)
+    vis = torch.rand(B, S, S, generator=g) > 0.3
+    vis[:, torch.arange(S), torch.arange(S)] = True          # every query sees itself
+    mask3 = ((~vis).float() * -10000.0).to(DEV)
+    # mixed-magnitude entries too: the mask is ADDED, not a switch
+    mask3 = mask3 + (torch.rand(B, S, S, generator=g) * 2.0 - 1.0).to(DEV)
+    ctx, c32, lse, dqkv = _attn_run(qkv, mask3, B, heads, S, nat().NO_DROP)
+    qf = split_heads(qkv[:, :H].contiguous(), B, S, heads).requires_grad_(True)
+    kf = split_heads(qkv[:, H:2 * H].contiguous(), B, S, heads).requires_grad_(True)
+    vf = split_heads(qkv[:, 2 * H:].contiguous(), B, S, heads).requires_grad_(True)
+    s_ = torch.matmul(qf, kf.transpose(-1, -2)) * 0.125 + mask3[:, None]
+    o_ref = torch.matmul(torch.softmax(s_, dim=-1), vf)
+    close(split_heads(ctx, B, S, heads), o_ref, 2e-2, 2e-2, "ctx")
+    close(lse, torch.logsumexp(s_, dim=-1), 1e-4, 2e-3, "lse")
+    assert torch.equal(c32.bfloat16(), ctx)
+    o_ref.backward(split_heads(rnd(B * S, H, seed=77), B, S, heads))
+    for name, got_, ref_ in (("dq", dqkv[:, :H], qf.grad), ("dk", dqkv[:, H:2 * H], kf.grad), ("dv", dqkv[:, 2 * H:], vf.grad)):
+        close(split_heads(got_.contiguous(), B, S, heads), ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name)
+
+
+@pytest.mark.parametrize("B,heads,S,tail", [(2, 3, 228, 0), (2, 2, 96, 0), (2, 2, 182, 12), (1, 2, 64, 7)])
+def test_attention_per_query_mask_is_bit_identical_to_the_structured_forms(B, heads, S, tail):
+    """The same mask handed over as the key mask [B, S] (+ M4C's causal tail, mmf/models/m4c.py:424-440) and materialised as [B, S, S]: context,
+    its fp32 copy, log-sum-exp and dQ | dK | dV are bit-identical, dropout included (same decisions: they depend on the element index only)."""
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, scale=1.0, seed=41)
+    key = torch.zeros(B, S, device=DEV)
+    for b in range(B):
+        key[b, S - tail - 3 - 5 * b:S - tail] = -10000.0
+    mask3 = key[:, None, :].expand(B, S, S).clone()
+    if tail:
+        q = torch.arange(S, device=DEV)[:, None]; k = torch.arange(S, device=DEV)[None, :]
+        c0 = S - tail
+        dec = (k >= c0)
+        mask3[:, dec & ~((q >= c0) & (k <= q))] = -10000.0
+        mask3[:, dec & (q >= c0) & (k <= q)] = 0.0
+    drop = nat().drop_cfg(0.1, 4321)
+    a = _attn_run(qkv, key, B, heads, S, drop, tail)
+    b_ = _attn_run(qkv, mask3.contiguous(), B, heads, S, drop, 0)
+    for name, x, y in zip(("ctx", "ctx32", "lse", "dqkv"), a, b_):
+        assert torch.isfinite(x.float()).all(), name
+        assert torch.equal(x, y), name
+
+
+def test_attention_per_query_mask_is_refused_where_it_is_not_built():
+    from mmf_amd._native import NativeLibraryError
+    B, heads, S, H = 1, 1, 64, 128
+    qkv = rnd(B * S, 3 * H)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, S, device=DEV)
+    m3 = torch.zeros(B, S, S, device=DEV)
+    with pytest.raises(NativeLibraryError, match="head_dim 64"):
+        nat().attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, m3, ctx, H, lse, B, heads, S, S, 0.1, head_dim=128)
+    with pytest.raises(NativeLibraryError, match="causal tail"):
+        nat().attention_fwd(qkv, qkv[:, 64:], qkv[:, 128:], 3 * H, 3 * H, 3 * H, m3, ctx, 64, lse, B, 1, S, S, 0.1, causal_tail=4)
+    with pytest.raises(NativeLibraryError, match=r"\[B, Sq, Sk\]"):
+        nat().attention_fwd(qkv, qkv[:, 64:], qkv[:, 128:], 3 * H, 3 * H, 3 * H, torch.zeros(B, S, S + 8, device=DEV), ctx, 64, lse, B, 1, S, S, 0.1)
+
+
 # ---------------------------------------------------------------------------------------------
 # embeddings / row utilities / loss / optimizer
 # ---------------------------------------------------------------------------------------------

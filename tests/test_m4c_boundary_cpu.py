@@ -70,5 +70,10 @@ def test_prefix_lm_mask_is_handed_to_the_attention_op_unmaterialised():
     m = additive_key_mask(Fn.PrefixLMMask(key.view(2, 1, 1, 10), 3), 2, 10)
     assert isinstance(m, Fn.PrefixLMMask) and m.causal_tail == 3 and tuple(m.key_mask.shape) == (2, 10)
     assert Fn._split_mask(m)[1] == 3 and Fn._split_mask(key) == (key, 0)
-    with pytest.raises(NotImplementedError):
-        additive_key_mask(torch.zeros(2, 1, 10, 10), 2, 10)
+    # a materialised [B, 1, S, S] mask (what MMT.forward builds, m4c.py:424-440) is accepted as it is: the kernels read it per (query, key) pair
+    m3 = additive_key_mask(torch.zeros(2, 1, 10, 10), 2, 10)
+    assert tuple(m3.shape) == (2, 10, 10) and m3.dtype == torch.float32 and m3.is_contiguous()
+    with pytest.raises(NotImplementedError):        # one mask per sample, not per head
+        additive_key_mask(torch.zeros(2, 4, 10, 10), 2, 10)
+    with pytest.raises(ValueError):
+        additive_key_mask(torch.zeros(2, 1, 9, 10), 2, 10)

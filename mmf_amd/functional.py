@@ -309,6 +309,12 @@ def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=N
         else:
             nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
                      act=2 if act_aux is not None else 0, aux=act_aux)
+    if wgrad_defer.active and x.dtype == BF16 and dy.dtype == BF16 and x.stride(1) == 1 and M >= 64:
+        # the weight gradient (and the bias gradient riding on it) joins a grouped launch that runs when eight problems are waiting or the
+        # deferral block ends: dW / db are returned now and FILLED then (see _WgradDefer)
+        prob, dw, db = _wgrad_problem(dy, ldy, x, M, N, K, want_db)
+        wgrad_defer.push(prob, (dy, x, dw, db))
+        return (dx, dw, db) if want_db else (dx, dw)
     dw = torch.empty(N, K, dtype=F32, device=dev)
     fused = want_db and x.dtype == BF16 and _FUSED_DB and nat.gemm_rowsum_supported(N, K, M)
     db = torch.empty(N, dtype=F32, device=dev) if fused else None
@@ -712,6 +718,58 @@ def _wgrad_problem(dy, ldy, x, M, N, K, want_db):
     db = torch.empty(N, dtype=F32, device=dy.device) if want_db else None
     prob = dict(A=dy, B=x, C_out=dw, M=N, N=K, K=M, lda=ldy, ldb=x.stride(0), ldc=K, a_kmajor=True, b_kmajor=True, rowsum_out=db)
     return prob, dw, db
+
+
+class _WgradDefer:
+    """Opt-in: inside `with wgrad_defer():` the weight gradients of the autograd nodes that are NOT the fused encoder layer (ViLBERT's connection
+    layers: bi-attention, two output blocks, two feed-forward blocks; the heads) are not launched one by one — each a split-K GEMM over a few
+    dozen tiles plus the kernel that sums its slabs — but queued and launched eight at a time as ONE grouped GEMM (`nat.gemm_grouped`, the
+    launch the fused layer node uses for its own four): every tile reduces over all token rows itself, no slabs, and the launch fills the chip.
+    Problems that are whole 256 x 128 tiles with a 64-aligned token count go to the wide-tile queue, the others to the 128-row one.  The
+    returned dW / db tensors are NOT valid before the flush: only for callers that own the whole backward and read the parameter gradients
+    after it (the graphed steps in mmf_amd/utils/graph.py), like `ln_defer`."""
+
+    def __init__(self):
+        self.active = False
+        self.queues = {}      # (wide-tile eligible, stream) -> list of (problem, tensors kept alive)
+        self.enabled = os.environ.get("MMF_AMD_WGRAD_DEFER", "1") != "0"       # (A/B switch)
+
+    @contextlib.contextmanager
+    def __call__(self):
+        old, self.active = self.active, self.enabled
+        try:
+            yield
+        finally:
+            self.active = old
+            if not old:
+                self.flush()
+
+    @staticmethod
+    def _wide(prob):
+        return prob["M"] % 256 == 0 and prob["N"] % 128 == 0 and prob["K"] % 64 == 0 and prob["K"] >= 192
+
+    def push(self, prob, keep):
+        # One queue per stream: a full queue is launched on the stream its problems were produced on (ViLBERT runs its visual stream on a
+        # side HIP stream; autograd replays a node on its forward stream).  What is left at the end is launched by `flush` on the caller's
+        # stream, after the autograd engine has joined every stream the backward pass used.
+        key = (self._wide(prob), torch.cuda.current_stream().cuda_stream)
+        q = self.queues.setdefault(key, [])
+        q.append((prob, keep))
+        if len(q) == nat.GEMM_GROUP_MAX:
+            self._launch(q)
+
+    def _launch(self, q):
+        if q:
+            nat.gemm_grouped([p for p, _ in q])
+            del q[:]
+
+    def flush(self):
+        for q in self.queues.values():
+            self._launch(q)
+        self.queues.clear()
+
+
+wgrad_defer = _WgradDefer()
 
 
 class _WgradOverlap:

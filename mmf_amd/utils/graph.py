@@ -148,7 +148,7 @@ class GraphedTrainStep:
         if early:
             self.optimizer.pin_to_attention = self.pin_update
             self.optimizer.begin_step(self.update_stream)
-        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.param_update(
+        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.wgrad_defer(), Fn.param_update(
                 self.optimizer.update_in_backward if early else None, self.optimizer.beside_attention if (early and self.pin_update) else None,
                 beside_wgrad=self.pin_wgrad):
             # (the seed of the backward pass is a tensor made once, ahead of the capture: `grad_outputs=None` fills a new ones tensor per step)
@@ -291,7 +291,7 @@ class GraphedDataParallelStep:
         n = len(self._bounds)
         root = self._loss_t if j == 0 else self._bounds[n - j][0]
         inputs = list(params) + ([self._bounds[n - j - 1][1]] if j < n else [])
-        with Fn.ln_defer():        # the stage's LayerNorm parameter gradients are finished by one launch at its end
+        with Fn.ln_defer(), Fn.wgrad_defer():        # the stage's LayerNorm parameter gradients / queued weight gradients are finished at its end
             if j == 0 and (getattr(self, "_one", None) is None or self._one.dtype != root.dtype):
                 self._one = torch.ones_like(root)
             grads = torch.autograd.grad(root, inputs, grad_outputs=self._one if j == 0 else carry, allow_unused=True)

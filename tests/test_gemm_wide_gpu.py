@@ -213,3 +213,44 @@ def test_wide_grouped_repeated_launches_are_stable(wgrad_tun):
         nat().gemm_grouped(probs)
     for (dw, db), (f_dw, f_db) in zip(outs, first):
         assert torch.equal(dw, f_dw) and torch.equal(db, f_db)
+
+
+def test_deferred_weight_gradients_join_grouped_launches():
+    """functional.wgrad_defer (round 4; active inside the graphed steps): the weight gradients of the autograd nodes that are not the fused encoder
+    layer are queued and launched eight at a time as ONE grouped GEMM — per HIP stream — instead of one split-K GEMM + slab reduction each.
+    Nothing is written before the flush; afterwards dW / db equal the immediate launches up to fp32 summation order."""
+    from mmf_amd import functional as Fn
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = [(4096, 1024, 1024, True), (3232, 1024, 1024, False), (4096, 768, 3072, True), (3232, 1024, 768, True), (4096, 3072, 768, False),
+              (4096, 1024, 1024, True), (4096, 256, 128, True), (4096, 1024, 1024, False), (4096, 768, 768, True), (4096, 1024, 1024, True)]      # (tokens, out, in, bias)
+    ops = []
+    for M, N, K, want_db in shapes:
+        dy = (torch.randn(M, N, generator=g) * 0.1).bfloat16().to(dev)
+        x = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(dev)
+        w16 = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(dev)
+        ops.append((dy, x, w16, M, N, K, want_db))
+    ref = [Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db) for dy, x, w16, M, N, K, want_db in ops]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    got = []
+    with Fn.wgrad_defer():
+        assert Fn.wgrad_defer.active
+        for i, (dy, x, w16, M, N, K, want_db) in enumerate(ops):
+            if i == 3:      # one problem from another stream: its own queue
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    got.append(Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db))
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                got.append(Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db))
+        queued = sum(len(q) for q in Fn.wgrad_defer.queues.values())
+        assert 0 < queued < len(ops) and len(Fn.wgrad_defer.queues) >= 3      # wide-tile queue (launched once at eight), 128-row queue, the side stream's
+    assert not Fn.wgrad_defer.active and not Fn.wgrad_defer.queues              # leaving the block launched what was left
+    torch.cuda.synchronize()
+    for r, o, (dy, x, w16, M, N, K, want_db) in zip(ref, got, ops):
+        assert (o[0] is None) and (r[0] is None)
+        scale = float(r[1].abs().max())
+        assert float((o[1] - r[1]).abs().max()) <= 2e-5 * scale + 1e-6, (M, N, K)
+        if want_db:
+            assert float((o[2] - r[2]).abs().max()) <= 2e-5 * float(r[2].abs().max()) + 1e-5, (M, N, K)

@@ -549,8 +549,10 @@ class DenseDropoutResidualLNFn(torch.autograd.Function):
         hshape, rshape, drop = ctx.meta
         M, N = y.shape
         K = h2.shape[1]
-        dx, dlin, dgamma, dbeta, dbias = _ln_bwd(_grad_bf16(g, N), y, mean, rstd, gamma, drop, True)
-        dh, dw = _linear_bwd(dlin, N, h2, w16, M, N, K, need_dx=ctx.needs_input_grad[0])
+        # (the bias gradient of the output projection is a column sum of dlin, the A operand of its weight-gradient GEMM: it rides on that GEMM —
+        # the fused layer node does the same — so the LayerNorm backward carries no third column sum and its reduction can be deferred: ln_defer)
+        dx, dlin, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, N), y, mean, rstd, gamma, drop, False)
+        dh, dw, dbias = _linear_bwd(dlin if dlin is not None else dx, N, h2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
         return ((dh.view(hshape) if dh is not None else None), dx.view(rshape), dw, dbias, dgamma, dbeta, None, None, None)
 
 
@@ -607,8 +609,10 @@ class AttentionBlockFn(torch.autograd.Function):
         x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add, o32, gate = ctx.saved_tensors
         B, S, H, heads, drop_attn, drop_hid, tail = ctx.meta
         M = B * S
-        dres, dlin, dgamma, dbeta, dbo = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
-        dctx, dwo = _linear_bwd(dlin, H, ctxt, wo16, M, H, H)
+        # (the bias gradient of the output projection is a column sum of dlin, the A operand of its weight-gradient GEMM: it rides on that GEMM —
+        # the fused layer node does the same — so the LayerNorm backward carries no third column sum and its reduction can be deferred: ln_defer)
+        dres, dlin, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, False)
+        dctx, dwo, dbo = _linear_bwd(dlin if dlin is not None else dres, H, ctxt, wo16, M, H, H, want_db=True)
         res = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32, tail=tail,
                         qk_gate=gate)
         dx, dwqkv, dbqkv = res[:3]
@@ -693,8 +697,10 @@ class FeedForwardFn(torch.autograd.Function):
         shape, drop_hid = ctx.meta
         M, H = x2.shape
         I = w1_16.shape[0]
-        dres, dlin, dgamma, dbeta, db2 = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, True)
-        du, dw2 = _linear_bwd(dlin, H, hh, w2_16, M, H, I, act_aux=u)        # du = (dlin W2) * gelu'(u), gelu' saved by the forward
+        # (the bias gradient of the output projection is a column sum of dlin, the A operand of its weight-gradient GEMM: it rides on that GEMM —
+        # the fused layer node does the same — so the LayerNorm backward carries no third column sum and its reduction can be deferred: ln_defer)
+        dres, dlin, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, False)
+        du, dw2, db2 = _linear_bwd(dlin if dlin is not None else dres, H, hh, w2_16, M, H, I, act_aux=u, want_db=True)        # du = (dlin W2) * gelu'(u), gelu' saved by the forward
         dx, dw1, db1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres, want_db=True)     # dx = du W1 + dres
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
 

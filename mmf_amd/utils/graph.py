@@ -62,8 +62,8 @@ def total_loss(out):
     entries' means; every loss of this package is already a scalar).  A single scalar entry is returned as it is: `tensor.sum()` of a 0-dim tensor
     and Python's `0 + tensor` are two more kernels (a reduction and an add) that compute nothing."""
     vals = list(out["losses"].values())
-    if len(vals) == 1 and vals[0].dim() == 0:
-        return vals[0]
+    if len(vals) == 1 and vals[0].numel() == 1:      # (MMFLoss hands scalars on as shape [1], like the reference: losses.py `loss.view(1)`)
+        return vals[0].reshape(())
     return sum(v.sum() for v in vals)
 
 

@@ -106,3 +106,25 @@ def test_tunables_round_trip_and_the_site_tags_stay_clear_of_the_other_flag_bits
     assert used and all(u < (1 << 20) for u in used)
     ops = open(os.path.join(ROOT, "mmf_amd", "csrc", "torch_ops.cpp")).read()
     assert all(n in ops for n in sites), [n for n in sites if n not in ops]
+
+
+def test_python_site_tags_and_descriptor_mirror_match_the_header():
+    """The Python twin of the layer node tags its GEMM calls with the header's MMF_SITE_* values (the per-site store policy of round 4 reads them),
+    and the ctypes mirror of mmf_attn_desc carries every field of the C struct in order (round 4 added mask_query_stride)."""
+    header = open(_native.HEADER_PATH).read()
+    sites = {n: int(v) for n, v in re.findall(r"MMF_SITE_([A-Z_]+) = (\d+)", header)}
+    for name, value in sites.items():
+        assert getattr(_native, "SITE_" + name) == value, name
+    assert _native.gemm_site(3) == 3 << 20 and _native.gemm_site(0) == 0
+    body = re.search(r"typedef struct mmf_attn_desc \{(.*?)\} mmf_attn_desc;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1] if " " in decl else decl
+        for part in names.split(","):
+            c_fields.append(part.replace("*", " ").split()[-1])
+    assert c_fields == [f[0] for f in _native.AttnDesc._fields_], (c_fields, [f[0] for f in _native.AttnDesc._fields_])
+    assert int(re.search(r"#define MMF_MT_MAX (\d+)", header).group(1)) == _native.MT_MAX

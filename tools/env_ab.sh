@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box A/B of bench.py under several settings of ONE environment variable:  bash tools/env_ab.sh VAR "v1 v2 ..." [rounds]
 # Prints ms_per_step, samples/s, all-GEMM TFLOP/s and the attention / LayerNorm times per setting, interleaved over the rounds.
+# (Separate processes: +-0.03 ms between identical runs.  For anything a tunable of the library can express prefer tools/step_ab.py: one process,
+# one captured hipGraph per setting, +-0.01 ms.)
 export TMPDIR=/tmp
 var=$1; vals=$2; rounds=${3:-2}
 for r in $(seq $rounds); do

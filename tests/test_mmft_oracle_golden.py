@@ -89,7 +89,7 @@ def test_mrc_head_oracle_matches_reference():
 
 
 def test_mrfr_and_wra_oracles_match_reference():
-    """Oracles for the two UNITER pretraining heads that are NOT built on the HIP side yet (mmf/models/transformers/heads/{mrfr,wra}.py,
+    """Oracles for the two remaining UNITER pretraining heads (built on the HIP side in round 3: tests/test_uniter_pretraining_gpu.py; mmf/models/transformers/heads/{mrfr,wra}.py,
     mmf/modules/ot.py), pinned against the reference heads' own run: losses, parameter gradients (incl. the image-embedding weight MRFR
     ties to, transposed) and the gradient handed back to the encoder — through the 50 IPOT iterations for WRA."""
     import numpy as np

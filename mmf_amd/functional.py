@@ -294,6 +294,9 @@ _FUSED_DB = os.environ.get("MMF_AMD_NO_FUSED_DB", "0") != "1"   # A/B switch for
 _FEATS_CAST = os.environ.get("MMF_AMD_FEATS_CAST", "1") == "1"  # A/B switch: region features cast to bf16 once (see VisioLinguisticEmbeddingsFn)
 
 
+_WGRAD_DEFER_MIN_ROWS = 64      # token rows below which a weight gradient is not worth queueing (the heads: a handful of rows, their own skinny paths)
+
+
 def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=None, want_db=False):
     """dy [M,N] bf16 (row stride ldy, pad columns zero), x [M,K] bf16, w16 [N,K].
     Returns (dx [M,K] bf16 or None, dW [N,K] fp32) and, with `want_db`, the bias gradient [N] fp32 as a third value —
@@ -309,7 +312,7 @@ def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=N
         else:
             nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
                      act=2 if act_aux is not None else 0, aux=act_aux)
-    if wgrad_defer.active and x.dtype == BF16 and dy.dtype == BF16 and x.stride(1) == 1 and M >= 64:
+    if wgrad_defer.active and x.dtype == BF16 and dy.dtype == BF16 and x.stride(1) == 1 and M >= _WGRAD_DEFER_MIN_ROWS:
         # the weight gradient (and the bias gradient riding on it) joins a grouped launch that runs when eight problems are waiting or the
         # deferral block ends: dW / db are returned now and FILLED then (see _WgradDefer)
         prob, dw, db = _wgrad_problem(dy, ldy, x, M, N, K, want_db)
@@ -758,7 +761,7 @@ class _WgradDefer:
         # One queue per stream: a full queue is launched on the stream its problems were produced on (ViLBERT runs its visual stream on a
         # side HIP stream; autograd replays a node on its forward stream).  What is left at the end is launched by `flush` on the caller's
         # stream, after the autograd engine has joined every stream the backward pass used.
-        key = (self._wide(prob), torch.cuda.current_stream().cuda_stream)
+        key = (self._wide(prob), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)      # (no GPU: the host-logic dry runs)
         q = self.queues.setdefault(key, [])
         q.append((prob, keep))
         if len(q) == nat.GEMM_GROUP_MAX:

@@ -12,7 +12,7 @@ _INT_RETURNS = {
     "layernorm_bwd_ws_floats": lambda H: 64 * 3 * H, "colsum_ws_floats": lambda n: 64 * n,
     "gemm_rowsum_supported": lambda M, Nn, K: True,
 }
-_KEEP = {"drop_cfg", "_drop4", "lib", "_check", "_stream", "_p", "_req"}
+_KEEP = {"drop_cfg", "_drop4", "lib", "_check", "_stream", "_p", "_req", "gemm_site"}
 calls = []
 
 
@@ -76,10 +76,13 @@ def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk
     assert qb >= Sq and kb >= Sk and mb >= Sk
     _need(q, (B - 1) * qb + Sq, ldq, heads * head_dim, "attention q"); _need(k, (B - 1) * kb + Sk, ldk, heads * head_dim, "attention k")
     _need(v, (B - 1) * kb + Sk, ldv, heads * head_dim, "attention v"); _need(ctx, B * Sq, ldo, heads * head_dim, "attention ctx")
-    if mask is not None:
+    if mask is not None and mask.dim() == 3:       # a materialised per-query mask (mmf_attn_desc.mask_query_stride): head_dim 64, no causal tail beside it
+        assert mask.dtype == torch.float32 and tuple(mask.shape) == (B, Sq, Sk) and mask.stride(2) == 1
+        assert head_dim == 64 and causal_tail == 0 and not mask_batch_stride
+    elif mask is not None:
         assert mask.dtype == torch.float32 and mask.numel() >= (B - 1) * mb + Sk
     assert lse.numel() >= B * heads * Sq
-    calls.append(("attention_fwd", B, heads, Sq, Sk, causal_tail))
+    calls.append(("attention_fwd", B, heads, Sq, Sk, causal_tail) + (("per-query mask",) if (mask is not None and mask.dim() == 3) else ()))
 
 
 def _attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta, drop=N.NO_DROP,
@@ -87,7 +90,7 @@ def _attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk
     _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail)
     _need(dctx, B * Sq, ldo, heads * head_dim, "attention dctx"); _need(dq, B * Sq, ldq, heads * head_dim, "attention dq")
     _need(dk, B * Sk, ldk, heads * head_dim, "attention dk"); _need(dv, B * Sk, ldv, heads * head_dim, "attention dv")
-    calls[-1] = ("attention_bwd", B, heads, Sq, Sk, causal_tail)
+    calls[-1] = ("attention_bwd",) + calls[-1][1:]
 
 
 def _attention_f32_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta, head_dim=64, causal_tail=0,

@@ -4,6 +4,8 @@ of each path — every autograd Function's forward and backward, buffer sizes, a
 groups — and compares WHICH parameters receive a gradient with the reference (the fixtures record the reference's gradient
 norms: a parameter the reference leaves without gradient must stay without one here, and vice versa).  The numbers are the
 `-m gpu` tests' job."""
+import contextlib
+
 import pytest
 import torch
 
@@ -233,3 +235,59 @@ def test_a_cloned_static_batch_runs_through_the_model_twice(name):
             for k, v in before.items():
                 if isinstance(v, torch.Tensor):
                     assert static[k] is not None and torch.equal(static[k], v), k
+
+
+def test_deferred_weight_gradients_plumbing(monkeypatch):
+    """functional.wgrad_defer (round 4): with the deferral on (what the graphed steps do) ViLBERT's connection layers hand their weight gradients to
+    grouped launches of at most eight — the same set of GEMM problems as the one-by-one launches, nothing left queued when the block ends, and every
+    parameter still receives a gradient tensor of its own shape."""
+    from mmf_amd import functional as Fn
+    from mmf_amd import _native as N
+    z, model, sample, prefix = CASES["vilbert"]()
+    model.train()
+    seen = {}
+    monkeypatch.setattr(Fn, "_WGRAD_DEFER_MIN_ROWS", 1)       # (the fixture has fewer token rows than the production threshold)
+    for deferred in (False, True):
+        model.zero_grad(set_to_none=True)
+        with native_stub.installed() as calls:
+            groups = []
+            grouped = N.gemm_grouped
+
+            def counting(problems, _g=grouped):
+                groups.append(len(problems))
+                return _g(problems)
+            N.gemm_grouped = counting
+            out = model(SampleList(sample))
+            (lkey, loss), = out["losses"].items()
+            ctx = Fn.wgrad_defer() if deferred else contextlib.nullcontext()
+            with ctx:
+                loss.sum().backward()
+                if deferred:
+                    assert Fn.wgrad_defer.active
+            assert not Fn.wgrad_defer.active and not Fn.wgrad_defer.queues
+            seen[deferred] = (sorted(c for c in calls if c[0] == "gemm"), list(groups))
+        for n, p in model.named_parameters():
+            assert p.grad is None or p.grad.shape == p.shape, n
+    plain, deferred = seen[False], seen[True]
+    assert plain[0] == deferred[0]                                   # the same GEMM problems either way
+    assert sum(deferred[1]) > sum(plain[1]) and max(deferred[1]) <= N.GEMM_GROUP_MAX and len(deferred[1]) > len(plain[1])
+
+
+def test_encoder_hands_a_materialised_per_query_mask_to_the_attention_kernels():
+    """A [B, 1, S, S] additive attention mask (hf_layers.py:187-190 adds any broadcastable mask to the scores; m4c.py:424-440 builds one) reaches the
+    attention launches as a [B, S, S] tensor (mmf_attn_desc.mask_query_stride), forward and backward; a per-head mask is refused."""
+    from transformers import BertConfig
+    from mmf_amd.modules.hf_layers import BertEncoderJit
+    B, S, H = 2, 40, 128
+    enc = BertEncoderJit(BertConfig(hidden_size=H, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2)).train()
+    x = torch.randn(B, S, H, requires_grad=True)
+    with native_stub.installed() as calls:
+        out = enc(x, torch.zeros(B, 1, S, S))[0]
+        out.float().sum().backward()
+        att = [c for c in calls if c[0] in ("attention_fwd", "attention_bwd")]
+        assert len(att) == 4 and all(c[-1] == "per-query mask" for c in att), att
+        del calls[:]
+        out = enc(x, torch.zeros(B, 1, 1, S))[0]
+        assert [c[-1] for c in calls if c[0] == "attention_fwd"] == [0, 0]          # the key-mask form: (…, causal_tail = 0), no per-query marker
+        with pytest.raises(NotImplementedError):
+            enc(x, torch.zeros(B, 2, S, S))

@@ -245,6 +245,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
 
 
 GEMM_GROUP_MAX = 8
+GEMM_NO_SKINNY = 1 << 18     # mmf_gemm_desc.debug_flags: never the skinny split-K path (M <= 64, K >= 1536), whatever workspace is offered
 
 
 def gemm_grouped(problems):

@@ -876,9 +876,9 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
     const int hd = d->head_dim ? d->head_dim : 64;
     MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_fwd: head_dim must be 64 or 128");
     MMF_CHECK_ARG(d->Sk <= (hd == 64 ? 256 : 128), "attention_f32_fwd: Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
+    MMF_CHECK_ARG(d->mask_query_stride == 0, "attention_f32_fwd: a per-query mask (mask_query_stride) is read by the bf16 kernels only");
     MMF_CHECK_ARG(!d->ctx_f32 && d->q_batch_rows == 0 && d->kv_batch_rows == 0 && d->mask_batch_stride == 0,
                   "attention_f32_fwd: no ctx_f32 (ctx IS fp32) and no K|V cache strides");
-    MMF_CHECK_ARG(d->mask_query_stride == 0, "attention_f32_fwd: a per-query mask (mask_query_stride) is read by the bf16 kernels only");
     MMF_CHECK_ARG(d->causal_tail >= 0 && d->causal_tail <= d->Sk && (d->causal_tail == 0 || d->Sq == d->Sk),
                   "attention_f32_fwd: a causal tail needs self-attention (Sq == Sk)");
     const int HD = d->heads * hd;

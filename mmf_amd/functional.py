@@ -297,11 +297,16 @@ _FEATS_CAST = os.environ.get("MMF_AMD_FEATS_CAST", "1") == "1"  # A/B switch: re
 _WGRAD_DEFER_MIN_ROWS = 64      # token rows below which a weight gradient is not worth queueing (the heads: a handful of rows, their own skinny paths)
 
 
-def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=None, want_db=False):
+def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=None, want_db=False, defer=False):
     """dy [M,N] bf16 (row stride ldy, pad columns zero), x [M,K] bf16, w16 [N,K].
     Returns (dx [M,K] bf16 or None, dW [N,K] fp32) and, with `want_db`, the bias gradient [N] fp32 as a third value —
     carried by the weight-gradient GEMM itself when that runs split-K (one extra MFMA per A fragment against a ones
-    operand, no separate pass over dy), else by the column-sum kernels."""
+    operand, no separate pass over dy), else by the column-sum kernels.
+    `defer`: the caller's weight is an encoder-layer-internal matrix that receives exactly ONE gradient contribution per backward, so
+    inside `wgrad_defer()` its dW / db may be returned unfilled and written by a later grouped launch.  Nodes whose weight can be
+    shared with another node (a decoder tied to an embedding table, M4C's classifier that is also PrevPredEmbeddings' lookup table,
+    plain `LinearFn`) never pass it: autograd sums the contributions of a shared parameter as soon as the second one arrives — before any
+    flush — and would add an unfilled buffer."""
     dev = dy.device
     dx = None
     if need_dx:
@@ -312,7 +317,8 @@ def _linear_bwd(dy, ldy, x, w16, M, N, K, need_dx=True, dx_resid=None, act_aux=N
         else:
             nat.gemm(dy, w16, dx, M, K, N, ldy, K, K, b_kmajor=True, resid=dx_resid, ldr=K,
                      act=2 if act_aux is not None else 0, aux=act_aux)
-    if wgrad_defer.active and x.dtype == BF16 and dy.dtype == BF16 and x.stride(1) == 1 and M >= _WGRAD_DEFER_MIN_ROWS:
+    if (defer and wgrad_defer.active and x.dtype == BF16 and dy.dtype == BF16 and x.stride(1) == 1 and M >= _WGRAD_DEFER_MIN_ROWS
+            and wgrad_defer.first_use(w16)):
         # the weight gradient (and the bias gradient riding on it) joins a grouped launch that runs when eight problems are waiting or the
         # deferral block ends: dW / db are returned now and FILLED then (see _WgradDefer)
         prob, dw, db = _wgrad_problem(dy, ldy, x, M, N, K, want_db)
@@ -437,10 +443,10 @@ def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_
     nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
                       dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
     if qk_gate is None:
-        return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True)
+        return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True, defer=True)
     dgate = torch.empty_like(qk_gate)
     nat.rowgroup_scale_bwd(dqkv, qkv, 3 * H, qk_gate, dgate, B, S, 2 * H)      # dqkv becomes the gradient of the un-gated projection
-    return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True) + (dgate,)
+    return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True, defer=True) + (dgate,)
 
 
 class SelfAttentionFn(torch.autograd.Function):
@@ -555,7 +561,7 @@ class DenseDropoutResidualLNFn(torch.autograd.Function):
         # (the bias gradient of the output projection is a column sum of dlin, the A operand of its weight-gradient GEMM: it rides on that GEMM —
         # the fused layer node does the same — so the LayerNorm backward carries no third column sum and its reduction can be deferred: ln_defer)
         dx, dlin, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, N), y, mean, rstd, gamma, drop, False)
-        dh, dw, dbias = _linear_bwd(dlin if dlin is not None else dx, N, h2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True)
+        dh, dw, dbias = _linear_bwd(dlin if dlin is not None else dx, N, h2, w16, M, N, K, need_dx=ctx.needs_input_grad[0], want_db=True, defer=True)
         return ((dh.view(hshape) if dh is not None else None), dx.view(rshape), dw, dbias, dgamma, dbeta, None, None, None)
 
 
@@ -615,7 +621,7 @@ class AttentionBlockFn(torch.autograd.Function):
         # (the bias gradient of the output projection is a column sum of dlin, the A operand of its weight-gradient GEMM: it rides on that GEMM —
         # the fused layer node does the same — so the LayerNorm backward carries no third column sum and its reduction can be deferred: ln_defer)
         dres, dlin, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, False)
-        dctx, dwo, dbo = _linear_bwd(dlin if dlin is not None else dres, H, ctxt, wo16, M, H, H, want_db=True)
+        dctx, dwo, dbo = _linear_bwd(dlin if dlin is not None else dres, H, ctxt, wo16, M, H, H, want_db=True, defer=True)
         res = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32, tail=tail,
                         qk_gate=gate)
         dx, dwqkv, dbqkv = res[:3]
@@ -703,8 +709,8 @@ class FeedForwardFn(torch.autograd.Function):
         # (the bias gradient of the output projection is a column sum of dlin, the A operand of its weight-gradient GEMM: it rides on that GEMM —
         # the fused layer node does the same — so the LayerNorm backward carries no third column sum and its reduction can be deferred: ln_defer)
         dres, dlin, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, False)
-        du, dw2, db2 = _linear_bwd(dlin if dlin is not None else dres, H, hh, w2_16, M, H, I, act_aux=u, want_db=True)        # du = (dlin W2) * gelu'(u), gelu' saved by the forward
-        dx, dw1, db1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres, want_db=True)     # dx = du W1 + dres
+        du, dw2, db2 = _linear_bwd(dlin if dlin is not None else dres, H, hh, w2_16, M, H, I, act_aux=u, want_db=True, defer=True)        # du = (dlin W2) * gelu'(u), gelu' saved by the forward
+        dx, dw1, db1 = _linear_bwd(du, I, x2, w1_16, M, I, H, dx_resid=dres, want_db=True, defer=True)     # dx = du W1 + dres
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
 
 
@@ -730,8 +736,9 @@ def _wgrad_problem(dy, ldy, x, M, N, K, want_db):
 
 
 class _WgradDefer:
-    """Opt-in: inside `with wgrad_defer():` the weight gradients of the autograd nodes that are NOT the fused encoder layer (ViLBERT's connection
-    layers: bi-attention, two output blocks, two feed-forward blocks; the heads) are not launched one by one — each a split-K GEMM over a few
+    """Opt-in: inside `with wgrad_defer():` the weight gradients of the encoder-internal autograd nodes that are NOT the fused encoder layer
+    (ViLBERT's connection layers: bi-attention, two output blocks, two feed-forward blocks — the nodes that pass `defer=True` to `_linear_bwd`;
+    never a node whose weight may be tied to another node's: `LinearFn`, the vocabulary / classifier heads) are not launched one by one — each a split-K GEMM over a few
     dozen tiles plus the kernel that sums its slabs — but queued and launched eight at a time as ONE grouped GEMM (`nat.gemm_grouped`, the
     launch the fused layer node uses for its own four): every tile reduces over all token rows itself, no slabs, and the launch fills the chip.
     Problems that are whole 256 x 128 tiles with a 64-aligned token count go to the wide-tile queue, the others to the 128-row one.  The
@@ -741,6 +748,7 @@ class _WgradDefer:
     def __init__(self):
         self.active = False
         self.queues = {}      # (wide-tile eligible, stream) -> list of (problem, tensors kept alive)
+        self.seen = set()     # weights (their bf16 shadows) that already have a queued gradient in this deferral block
         self.enabled = os.environ.get("MMF_AMD_WGRAD_DEFER", "1") != "0"       # (A/B switch)
 
     @contextlib.contextmanager
@@ -756,6 +764,19 @@ class _WgradDefer:
     @staticmethod
     def _wide(prob):
         return prob["M"] % 256 == 0 and prob["N"] % 128 == 0 and prob["K"] % 64 == 0 and prob["K"] >= 192
+
+    def first_use(self, w16):
+        """True when `w16`'s weight has no gradient queued yet.  A weight that comes a second time in one backward (a layer applied twice:
+        tied layers) must not be queued again — autograd sums the two contributions the moment the second node returns — so everything
+        queued is launched now (the first contribution is filled, in stream order, before that sum) and the caller computes this one
+        immediately."""
+        key = w16.data_ptr()
+        if key in self.seen:
+            self.flush()
+            self.seen.add(key)      # (a third application is immediate as well)
+            return False
+        self.seen.add(key)
+        return True
 
     def push(self, prob, keep):
         # One queue per stream: a full queue is launched on the stream its problems were produced on (ViLBERT runs its visual stream on a
@@ -773,9 +794,19 @@ class _WgradDefer:
             del q[:]
 
     def flush(self):
-        for q in self.queues.values():
+        cur = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+        for (_, stream), q in self.queues.items():
+            if q and stream != cur and not torch.cuda.is_current_stream_capturing():
+                # leftovers of another stream's queue (ViLBERT's visual stream) run on the caller's stream: their buffers belong to that
+                # stream's pool of the caching allocator, which must not hand them out again while this launch / the optimizer that reads
+                # dW, db on the caller's stream is pending
+                for _, keep in q:
+                    for t in keep:
+                        if t is not None:
+                            t.record_stream(torch.cuda.current_stream())
             self._launch(q)
         self.queues.clear()
+        self.seen.clear()
 
 
 wgrad_defer = _WgradDefer()
@@ -1658,8 +1689,8 @@ class BiAttentionFn(torch.autograd.Function):
                           scale, _grad_bf16(g1, BH), dqkv2, dqkv1[:, BH:], dqkv1[:, 2 * BH:], delta1, drop1, head_dim=hd, ctx_f32=o1)
         nat.attention_bwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add, ctx2, BH, lse2, B, heads, R, T,
                           scale, _grad_bf16(g2, BH), dqkv1, dqkv2[:, BH:], dqkv2[:, 2 * BH:], delta2, drop2, head_dim=hd, ctx_f32=o2)
-        dimg, dw1, db1 = _linear_bwd(dqkv1, 3 * BH, i2, w1_16, B * R, 3 * BH, VH, want_db=True)
-        dtxt, dw2, db2 = _linear_bwd(dqkv2, 3 * BH, t2, w2_16, B * T, 3 * BH, H, want_db=True)
+        dimg, dw1, db1 = _linear_bwd(dqkv1, 3 * BH, i2, w1_16, B * R, 3 * BH, VH, want_db=True, defer=True)
+        dtxt, dw2, db2 = _linear_bwd(dqkv2, 3 * BH, t2, w2_16, B * T, 3 * BH, H, want_db=True, defer=True)
         return (dimg.view(B, R, VH), dtxt.view(B, T, H),
                 dw1[:BH], db1[:BH], dw1[BH:2 * BH], db1[BH:2 * BH], dw1[2 * BH:], db1[2 * BH:],
                 dw2[:BH], db2[:BH], dw2[BH:2 * BH], db2[BH:2 * BH], dw2[2 * BH:], db2[2 * BH:],

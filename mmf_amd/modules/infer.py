@@ -47,7 +47,10 @@ def layer_rows(layer, x2, cache, B, rows_per_sample, cache_rows, row0, Sk, key_m
     hh = torch.empty(M, I, dtype=BF16, device=dev)
     nat.gemm(a_out, Fn.shadows.get(it.dense.weight), hh, M, I, H, H, H, I, bias=it.dense.bias.detach(), act=1)
     y2 = torch.empty(M, H, dtype=BF16, device=dev)
-    nat.gemm(hh, Fn.shadows.get(ot.dense.weight), y2, M, H, I, I, I, H, bias=ot.dense.bias.detach(), resid=a_out, ldr=H)
+    # (one launch: the skinny split-K path — a workspace allocation and a second kernel per call — is for the training heads' long
+    # reductions, not for a host-bound decoding loop; bit 18 of debug_flags keeps this K = 3072 GEMM on the single-kernel path)
+    nat.gemm(hh, Fn.shadows.get(ot.dense.weight), y2, M, H, I, I, I, H, bias=ot.dense.bias.detach(), resid=a_out, ldr=H,
+             debug_flags=nat.GEMM_NO_SKINNY)
     out = torch.empty(M, H, dtype=BF16, device=dev)
     nat.layernorm_fwd(y2, ot.LayerNorm.weight.detach(), ot.LayerNorm.bias.detach(), out, None, None, M, H, ot.LayerNorm.eps)
     return out

@@ -273,6 +273,69 @@ def test_deferred_weight_gradients_plumbing(monkeypatch):
     assert sum(deferred[1]) > sum(plain[1]) and max(deferred[1]) <= N.GEMM_GROUP_MAX and len(deferred[1]) > len(plain[1])
 
 
+@pytest.mark.parametrize("name", ["m4c", "visual_bert_pretraining", "mmbt_pretraining", "vilbert_pretraining", "uniter", "mmft"])
+def test_shareable_weights_are_never_deferred(name, monkeypatch):
+    """autograd sums the gradient contributions of a shared parameter the moment the second one arrives — before any
+    flush — so a node whose weight can be tied to another node's must not hand back an unfilled dW under `wgrad_defer`: M4C's classifier
+    weight is the GEMM weight of the scores node AND the lookup table of `PrevPredEmbeddings` (m4c.py:111, 361), the masked-LM decoder is tied
+    to the word embeddings (visual_bert.py:179-184).  With the deferral on, every queued problem belongs to an encoder-internal matrix: no
+    queued dW has the shape of a parameter that receives a second contribution, and every multiply-contributed parameter ends with a gradient."""
+    from mmf_amd import functional as Fn
+    z, model, sample, prefix = CASES[name]()
+    model.train()
+    monkeypatch.setattr(Fn, "_WGRAD_DEFER_MIN_ROWS", 1)
+    pushed = []
+    push = Fn.wgrad_defer.push
+
+    def recording(prob, keep):
+        pushed.append((prob["M"], prob["N"]))
+        return push(prob, keep)
+    monkeypatch.setattr(Fn.wgrad_defer, "push", recording)
+    with native_stub.installed():
+        out = model(SampleList(sample))
+        loss = sum(v.sum() for v in out["losses"].values())
+        with Fn.wgrad_defer():
+            loss.backward()
+        assert not Fn.wgrad_defer.queues and not Fn.wgrad_defer.seen
+    params = dict(model.named_parameters())
+    tables = {tuple(p.shape) for n, p in params.items() if "embeddings" in n or n.endswith("classifier.module.weight") or "decoder" in n or "predictions" in n}
+    assert not (set(pushed) & tables), (set(pushed) & tables)
+    if name == "m4c":
+        w = params["classifier.module.weight"]
+        assert tuple(w.shape) not in pushed and w.grad is not None and w.grad.shape == w.shape
+
+
+def test_a_layer_applied_twice_is_not_queued_twice(monkeypatch):
+    """Tied layers (one FeedForward node applied twice in a forward): the second weight gradient of the same matrix flushes what is queued and is
+    computed immediately — the sum autograd forms right after the second node returns then reads two filled buffers, in stream order."""
+    from mmf_amd import functional as Fn
+    from mmf_amd import _native as N
+    monkeypatch.setattr(Fn, "_WGRAD_DEFER_MIN_ROWS", 1)
+    H, I, M = 64, 128, 16
+    w1 = torch.nn.Parameter(torch.randn(I, H)); b1 = torch.nn.Parameter(torch.zeros(I))
+    w2 = torch.nn.Parameter(torch.randn(H, I)); b2 = torch.nn.Parameter(torch.zeros(H))
+    g = torch.nn.Parameter(torch.ones(H)); be = torch.nn.Parameter(torch.zeros(H))
+    x = torch.randn(2, M // 2, H, requires_grad=True)
+    with native_stub.installed() as calls:
+        groups = []
+        grouped = N.gemm_grouped
+
+        def counting(problems, _g=grouped):
+            groups.append((len(calls), len(problems)))
+            return _g(problems)
+        N.gemm_grouped = counting
+        ff = lambda t: Fn.FeedForwardFn.apply(t, w1, b1, w2, b2, g, be, Fn.shadows.get(w1), Fn.shadows.get(w2), 1e-12, N.NO_DROP)
+        y = ff(ff(x))
+        with Fn.wgrad_defer():
+            y.float().sum().backward()
+            # the second application came first in backward and queued its two problems; the first application (same weights) found them
+            # queued, launched them, and ran its own two weight gradients as plain GEMMs
+            assert groups and groups[0][1] == 2
+            wg = [c for c in calls if c[0] == "gemm"]
+        assert not Fn.wgrad_defer.queues
+    assert w1.grad is not None and w1.grad.shape == w1.shape and w2.grad is not None
+
+
 def test_encoder_hands_a_materialised_per_query_mask_to_the_attention_kernels():
     """A [B, 1, S, S] additive attention mask (hf_layers.py:187-190 adds any broadcastable mask to the scores; m4c.py:424-440 builds one) reaches the
     attention launches as a [B, S, S] tensor (mmf_attn_desc.mask_query_stride), forward and backward; a per-head mask is refused."""

@@ -1021,6 +1021,31 @@ def test_gemm_skinny_head_shapes_match_torch_and_the_unsplit_launch(M):
     close(d1, dsc.float() @ Wc.float() + res.float(), 1e-2, 2e-2, "skinny dgrad + residual")
 
 
+def test_gemm_skinny_row_remap_and_decode_opt_out():
+    """The remaining epilogue of `splitk_epilogue_kernel`: the row remap `grp` (output row = m + (m / R) * skip + row0, what the
+    decoding cache writes use) through the skinny path against the one-kernel launch, bit for bit on the rows written and nothing else touched;
+    and the incremental M4C decoder's K = 3072 GEMM opts out of the path (mmf_amd/modules/infer.py: one launch per call in a host-bound loop)."""
+    M, N, K, R, skip, row0 = 16, 768, 3072, 2, 5, 3
+    assert nat().lib().mmf_gemm_skinny_splits(M, N, K, 0) > 1
+    x = rnd(M, K, seed=11); W = rnd(N, K, seed=12, scale=0.03); bias = rnd(N, dtype=torch.float32, seed=13)
+    rows = (M // R) * (R + skip) + row0
+    outs = []
+    for flags in (0, NO_SKINNY):
+        out = torch.full((rows, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        nat().gemm(x, W, out, M, N, K, K, K, N, bias=bias, grp=(R, skip, row0), debug_flags=flags)
+        assert ("skinny" in nat().gemm_last_kernel()) == (flags == 0)
+        outs.append(out)
+    ref = x.float() @ W.float().t() + bias
+    dst = torch.tensor([m + (m // R) * skip + row0 for m in range(M)], device=DEV)
+    close(outs[0][dst], ref, 1e-2, 2e-2, "skinny + row remap")
+    close(outs[0][dst], outs[1][dst], 1e-2, 1e-2, "skinny vs unsplit, remapped rows")
+    untouched = torch.ones(rows, dtype=torch.bool, device=DEV); untouched[dst] = False
+    assert bool((outs[0][untouched] == 7.0).all()) and bool((outs[1][untouched] == 7.0).all())
+    import inspect
+    from mmf_amd.modules import infer
+    assert "GEMM_NO_SKINNY" in inspect.getsource(infer.layer_rows)
+
+
 def test_gemm_skinny_repeated_launches_are_stable():
     M, H, L = 32, 768, 3129
     dsc = torch.zeros(M, 3136, dtype=torch.bfloat16, device=DEV); dsc[:, :L] = rnd(M, L, seed=6)

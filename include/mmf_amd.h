@@ -162,8 +162,10 @@ int mmf_gemm_splitk_splits(int M, int N, int K);
 /* ---- fused multi-head attention -------------------------------------------------------------
  * Replaces BertSelfAttentionJit.forward, mmf/modules/hf_layers.py:161-213 (scores = QK^T /
  * sqrt(d) + mask; softmax; dropout; PV; head merge) without materialising the [B,A,S,S] tensors,
- * and its autograd backward.  head_dim is 64 (Sq, Sk <= 256) or 128 (Sq, Sk <= 128: the visual and co-attention
- * streams of mmf/models/vilbert.py:153-247,347-475; q and k/v may come from different sequences, Sq != Sk).
+ * and its autograd backward.  head_dim is 64 (Sq, Sk <= 512 = BERT's max_position_embeddings; the tuned forms — two workgroups per CU forward,
+ * one-pass backward — up to 256, the same kernels with more key tiles and the two-kernel backward beyond) or 128 (Sq, Sk <= 256; tuned up to 128: the
+ * visual and co-attention streams of mmf/models/vilbert.py:153-247,347-475; q and k/v may come from different sequences, Sq != Sk).  A head's K and V
+ * are always staged whole in LDS, so the softmax is the reference's exact two-pass form at every length.
  * q/k/v/ctx are token-major: element (b, s, head, e) at ptr[(b*S + s)*ld + head*head_dim + e]  (for the packed QKV projection output: q = qkv, k = qkv+H,
  * v = qkv+2H, ld = 3H).  `mask` is the ADDITIVE key mask of visual_bert.py:94-106, shape [B, Sk]
  * fp32 (0 or -10000), or NULL.  lse[b][head][s] = log-sum-exp of the masked, scaled scores row.

@@ -1,5 +1,8 @@
-// mmf_amd :: fused multi-head attention forward / backward for gfx950 (head_dim 64 with Sk <= 256, or head_dim 128 —
-// ViLBERT's visual and co-attention streams, mmf/models/vilbert.py:153-247,347-475 — with Sq, Sk <= 128).
+// mmf_amd :: fused multi-head attention forward / backward for gfx950 (head_dim 64 with Sq, Sk <= 512 = BERT's
+// max_position_embeddings, or head_dim 128 — ViLBERT's visual and co-attention streams, mmf/models/vilbert.py:153-247,347-475 —
+// with Sq, Sk <= 256).  A whole head's K and V always sit in LDS (128 KB at the caps), so the softmax stays the reference's exact
+// two-pass form at every length; up to 256 keys (128 at head_dim 128) the tuned forms below run — two workgroups per CU forward, the
+// one-pass backward — beyond that the same kernels with more key tiles, one workgroup per CU, and the two-kernel backward.
 //
 // Replaces BertSelfAttentionJit.forward (mmf/modules/hf_layers.py:161-213):
 //     scores = Q K^T / sqrt(d) + mask ; probs = softmax(scores) ; probs = dropout(probs) ;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / a.heads, head = bh - b * a.heads;
-    const int q0 = wave * 32;
+    const int q0 = blockIdx.y * 256 + wave * 32;       // (blockIdx.y > 0 only beyond 256 queries: NKT 12 / 16, one workgroup per CU)
 
     const bf16* kbase = a.k + (size_t)b * a.kv_bs * a.ldk + head * HD;
     const bf16* vbase = a.v + (size_t)b * a.kv_bs * a.ldv + head * HD;
@@ -944,8 +947,8 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     MMF_CHECK_ARG(d->B > 0 && d->heads > 0 && d->Sq > 0 && d->Sk > 0, "attention: empty shape");
     const int hd = d->head_dim ? d->head_dim : 64;
     MMF_CHECK_ARG(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
-    MMF_CHECK_ARG(d->Sk <= 256 && d->Sq <= 256, "attention: Sq and Sk must be <= 256 in this build");
-    MMF_CHECK_ARG(hd == 64 || (d->Sk <= 128 && d->Sq <= 128), "attention: head_dim 128 is built for Sq, Sk <= 128");
+    MMF_CHECK_ARG(d->Sk <= 512 && d->Sq <= 512, "attention: Sq and Sk must be <= 512 (a head's K and V are staged whole in LDS)");
+    MMF_CHECK_ARG(hd == 64 || (d->Sk <= 256 && d->Sq <= 256), "attention: head_dim 128 is built for Sq, Sk <= 256");
     MMF_CHECK_ARG((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0 && (d->ldo % 8) == 0,
                   "attention: leading dimensions must be multiples of 8 elements");
     a.q = (const bf16*)d->q; a.k = (const bf16*)d->k; a.v = (const bf16*)d->v;
@@ -961,6 +964,7 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.m_qs = d->mask_query_stride;
     MMF_CHECK_ARG(a.m_qs == 0 || (d->mask && a.m_qs >= d->Sk), "attention: mask_query_stride must cover a mask row (>= Sk)");
     MMF_CHECK_ARG(a.m_qs == 0 || (hd == 64 && d->causal_tail == 0), "attention: a per-query mask is built for head_dim 64 (and replaces the causal tail)");
+    MMF_CHECK_ARG(a.m_qs == 0 || (d->Sk <= 256 && d->Sq <= 256), "attention: a per-query mask is built for Sq, Sk <= 256 (the one-pass backward reads it)");
     a.m_bs = d->mask_batch_stride > 0 ? d->mask_batch_stride : (a.m_qs ? d->Sq * a.m_qs : d->Sk);
     MMF_CHECK_ARG(a.q_bs >= d->Sq && a.kv_bs >= d->Sk && a.m_bs >= d->Sk, "attention: batch strides must cover the sequence");
     MMF_CHECK_ARG(a.m_qs == 0 || a.m_bs >= (d->Sq - 1) * a.m_qs + d->Sk, "attention: mask_batch_stride must cover the per-query mask of a sample");
@@ -994,11 +998,27 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         hipLaunchKernelGGL((attn_fwd_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);            \
     }
     const bool cz = a.cfrom < a.Sk;
+    if (a.hd == 64 && nkt > 8) {
+        // more than 256 keys (head_dim 64): the one-round kernel with 12 or 16 key tiles — K and V of the head whole in LDS (96 / 128 KB), one
+        // workgroup per CU and per 256 queries, scores computed twice, same arithmetic in the same order as the shorter forms
+        const dim3 gridL(a.B * a.heads, (a.Sq + 255) / 256);
+#define LAUNCH_FWD_LONG(N, MMODE)                                                                 \
+    {                                                                                            \
+        const int lds = 2 * N * 32 * 128 + N * 32 * 4;                                           \
+        if (int rc = set_lds(attn_fwd8_kernel<N, MMODE>, lds)) return rc;                        \
+        hipLaunchKernelGGL((attn_fwd8_kernel<N, MMODE>), gridL, dim3(512), lds, s, a);           \
+    }
+        if (nkt <= 12) { if (cz) LAUNCH_FWD_LONG(12, MASK_TAIL) else LAUNCH_FWD_LONG(12, MASK_KEY) }
+        else { if (cz) LAUNCH_FWD_LONG(16, MASK_TAIL) else LAUNCH_FWD_LONG(16, MASK_KEY) }
+#undef LAUNCH_FWD_LONG
+        MMF_CHECK_LAUNCH();
+        return 0;
+    }
     if (a.m_qs) {      // per-query mask [B, Sq, Sk] (head_dim 64): the same two kernel forms, mask read per (query, key) from global memory
         if (nkt > 4 && a.Sq > 128 && !mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD)) {
             const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
             if (int rc = set_lds(attn_fwd8_kernel<8, MASK_QUERY>, lds)) return rc;
-            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_QUERY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_QUERY>), dim3(a.B * a.heads, (a.Sq + 255) / 256), dim3(512), lds, s, a);
         } else if (nkt <= 4) LAUNCH_FWD(4, 64, MASK_QUERY)
         else LAUNCH_FWD(8, 64, MASK_QUERY)
         MMF_CHECK_LAUNCH();
@@ -1008,7 +1028,7 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     // MMF_TUN_ATTN_FWD_OLD = 1 keeps the two-workgroups-per-head form (A/B measurements, bit-equality test).
     if (a.hd == 64 && nkt > 4 && a.Sq > 128 && !mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD)) {
         const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
-        const dim3 grid8(a.B * a.heads);
+        const dim3 grid8(a.B * a.heads, (a.Sq + 255) / 256);
         if (cz) {
             if (int rc = set_lds(attn_fwd8_kernel<8, MASK_TAIL>, lds)) return rc;
             hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_TAIL>), grid8, dim3(512), lds, s, a);
@@ -1019,7 +1039,7 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         MMF_CHECK_LAUNCH();
         return 0;
     }
-    if (a.hd == 128) LAUNCH_FWD(4, 128, MASK_KEY)
+    if (a.hd == 128) { if (nkt <= 4) LAUNCH_FWD(4, 128, MASK_KEY) else LAUNCH_FWD(8, 128, MASK_KEY) }
     else if (nkt <= 4) { if (cz) LAUNCH_FWD(4, 64, MASK_TAIL) else LAUNCH_FWD(4, 64, MASK_KEY) }
     else { if (cz) LAUNCH_FWD(8, 64, MASK_TAIL) else LAUNCH_FWD(8, 64, MASK_KEY) }
 #undef LAUNCH_FWD
@@ -1042,7 +1062,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;
     const bool cz = a.cfrom < a.Sk;
-    if (a.hd == 64 && (a.m_qs || !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS))) {
+    if (a.hd == 64 && nkt <= 8 && nqt <= 8 && (a.m_qs || !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS))) {
         const int lds = 3 * 256 * 128 + 16 * 2048 + 2 * 256 * 4;
         if (a.m_qs) {      // per-query mask: the one-pass kernel only
             if (int rc = set_lds(attn_bwd_fused_kernel<MASK_QUERY>, lds)) return rc;
@@ -1065,9 +1085,10 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         if (int rc = set_lds(attn_bwd_dq_kernel<N, DD, CZ>, lds)) return rc;                     \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);         \
     }
-        if (a.hd == 128) LAUNCH_DQ(4, 128, false)
+        if (a.hd == 128) { if (nkt <= 4) LAUNCH_DQ(4, 128, false) else LAUNCH_DQ(8, 128, false) }
         else if (nkt <= 4) { if (cz) LAUNCH_DQ(4, 64, true) else LAUNCH_DQ(4, 64, false) }
-        else { if (cz) LAUNCH_DQ(8, 64, true) else LAUNCH_DQ(8, 64, false) }
+        else if (nkt <= 8) { if (cz) LAUNCH_DQ(8, 64, true) else LAUNCH_DQ(8, 64, false) }
+        else { if (cz) LAUNCH_DQ(16, 64, true) else LAUNCH_DQ(16, 64, false) }      // 257 .. 512 keys: K, V whole in LDS (128 KB), one workgroup per CU
 #undef LAUNCH_DQ
         MMF_CHECK_LAUNCH();
     }
@@ -1079,9 +1100,10 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         if (int rc = set_lds(attn_bwd_dkv_kernel<N, DD, CZ>, lds)) return rc;                    \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);        \
     }
-        if (a.hd == 128) LAUNCH_DKV(4, 128, false)
+        if (a.hd == 128) { if (nqt <= 4) LAUNCH_DKV(4, 128, false) else LAUNCH_DKV(8, 128, false) }
         else if (nqt <= 4) { if (cz) LAUNCH_DKV(4, 64, true) else LAUNCH_DKV(4, 64, false) }
-        else { if (cz) LAUNCH_DKV(8, 64, true) else LAUNCH_DKV(8, 64, false) }
+        else if (nqt <= 8) { if (cz) LAUNCH_DKV(8, 64, true) else LAUNCH_DKV(8, 64, false) }
+        else { if (cz) LAUNCH_DKV(16, 64, true) else LAUNCH_DKV(16, 64, false) }    // 257 .. 512 queries: Q, dO whole in LDS
 #undef LAUNCH_DKV
         MMF_CHECK_LAUNCH();
     }

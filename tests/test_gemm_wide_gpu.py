@@ -240,10 +240,10 @@ def test_deferred_weight_gradients_join_grouped_launches():
             if i == 3:      # one problem from another stream: its own queue
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    got.append(Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db))
+                    got.append(Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db, defer=True))
                 torch.cuda.current_stream().wait_stream(side)
             else:
-                got.append(Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db))
+                got.append(Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db, defer=True))
         queued = sum(len(q) for q in Fn.wgrad_defer.queues.values())
         assert 0 < queued < len(ops) and len(Fn.wgrad_defer.queues) >= 3      # wide-tile queue (launched once at eight), 128-row queue, the side stream's
     assert not Fn.wgrad_defer.active and not Fn.wgrad_defer.queues              # leaving the block launched what was left
@@ -254,3 +254,17 @@ def test_deferred_weight_gradients_join_grouped_launches():
         assert float((o[1] - r[1]).abs().max()) <= 2e-5 * scale + 1e-6, (M, N, K)
         if want_db:
             assert float((o[2] - r[2]).abs().max()) <= 2e-5 * float(r[2].abs().max()) + 1e-5, (M, N, K)
+    # round 5 (ADVICE, high): deferral is opt-in per call (`defer=True`: encoder-internal matrices with ONE gradient contribution per backward);
+    # a node that does not opt in — LinearFn, the vocabulary heads, M4C's scores — launches immediately even inside the block, and the SAME
+    # weight a second time is never queued twice (autograd would sum an unfilled buffer)
+    dy, x, w16, M, N, K, want_db = ops[0]
+    with Fn.wgrad_defer():
+        Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db)
+        assert not any(Fn.wgrad_defer.queues.values())
+        first = Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db, defer=True)
+        assert sum(len(q) for q in Fn.wgrad_defer.queues.values()) == 1
+        second = Fn._linear_bwd(dy, N, x, w16, M, N, K, need_dx=False, want_db=want_db, defer=True)       # same weight again: flush, then immediate
+        assert not any(Fn.wgrad_defer.queues.values())
+        torch.cuda.synchronize()
+        assert torch.equal(first[1], ref[0][1]) or float((first[1] - ref[0][1]).abs().max()) <= 2e-5 * float(ref[0][1].abs().max()) + 1e-6
+        assert torch.equal(second[1], ref[0][1])

@@ -473,6 +473,94 @@ def test_attention_one_pass_backward_agrees_with_the_two_kernel_backward(B, head
             assert abs(float((a_ - b_).mean())) <= 1e-3 * float(b_.abs().mean()) + 1e-6, name
 
 
+def _host_dropout_keep(key, thr16, B, heads, Sq, Sk):
+    """The attention kernels' dropout decisions restated on the host (mmf_amd/csrc/common.h mix24 / drop_hash; element index
+    ((b * heads + head) * Sq + q) * round_up(Sk, 32) + key, one 32-bit hash per PAIR of elements, 16-bit halves against thr16)."""
+    import numpy as np
+    M32 = np.uint64(0xFFFFFFFF)
+    skp = (Sk + 31) // 32 * 32
+    bh = np.arange(B * heads, dtype=np.uint64)[:, None, None]
+    q = np.arange(Sq, dtype=np.uint64)[None, :, None]
+    k = np.arange(Sk, dtype=np.uint64)[None, None, :]
+    e = ((bh * np.uint64(Sq) + q) * np.uint64(skp) + k) & M32
+    x = ((e >> np.uint64(1)) + np.uint64(key)) & M32
+    rotl = lambda v, r: ((v << np.uint64(r)) | (v >> np.uint64(32 - r))) & M32
+    mul24 = lambda v, c: ((v & np.uint64(0xFFFFFF)) * np.uint64(c)) & M32
+    x ^= x >> np.uint64(16)
+    x = (mul24(x, 0xB5297B) + rotl(x, 9)) & M32
+    x ^= x >> np.uint64(13)
+    x = (mul24(x, 0x68E31F) + rotl(x, 11)) & M32
+    x ^= x >> np.uint64(15)
+    half = np.where((e & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    return torch.from_numpy((half >= np.uint64(thr16)).astype(np.float32)).view(B, heads, Sq, Sk).to(DEV)
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,d,tail,p", [
+    (2, 2, 320, 320, 64, 0, 0.0), (1, 3, 512, 512, 64, 0, 0.1), (2, 2, 100, 400, 64, 0, 0.1), (1, 2, 300, 120, 64, 0, 0.0), (1, 2, 384, 384, 64, 20, 0.1),
+    (1, 1, 1, 300, 64, 0, 0.0), (2, 2, 200, 200, 128, 0, 0.1), (1, 2, 256, 256, 128, 0, 0.0), (1, 2, 60, 250, 128, 0, 0.1), (1, 1, 228, 228, 64, 0, 0.1)])
+def test_attention_long_sequences_forward_backward(B, heads, Sq, Sk, d, tail, p):
+    """Round 5: any length up to BERT's max_position_embeddings (512) at head_dim 64, up to 256 at head_dim 128 — `BertSelfAttentionJit.forward`
+    (mmf/modules/hf_layers.py:161-213) and `BertBiAttention` (mmf/models/vilbert.py:347-475) take any length; round 4 refused more than
+    256 / 128.  K and V of a head still sit whole in LDS (128 KB at the caps), the softmax is the same exact two-pass form.  Forward and
+    backward against fp32 torch with ragged key masks, the prefix-LM tail, rectangular shapes and dropout (the keep decisions restated on
+    the host from the hash); the last case is the VQA2 shape through the same comparison (the tuned kernels)."""
+    H = heads * d
+    hof = lambda x, S: x.reshape(B, S, heads, d).permute(0, 2, 1, 3).float()
+    qbuf = rnd(B * Sq, 3 * H, seed=31); kvbuf = rnd(B * Sk, 3 * H, seed=32) if (Sq != Sk or tail == 0) else None
+    if tail:
+        kvbuf = qbuf
+    q, k, v = qbuf[:, :H], kvbuf[:, H:2 * H], kvbuf[:, 2 * H:]
+    mbin = (torch.rand(B, Sk, device=DEV) > 0.2).long(); mbin[:, 0] = 1
+    if tail:
+        mbin[:, Sk - tail:] = 1
+    mask = torch.empty(B, Sk, device=DEV); nat().make_additive_mask(mbin, mask)
+    scale = 1.0 / math.sqrt(d)
+    drop = nat().drop_cfg(p, 99173) if p > 0 else nat().NO_DROP
+    ctx = torch.full((B * Sq, H), float("nan"), dtype=torch.bfloat16, device=DEV); lse = torch.full((B, heads, Sq), float("nan"), device=DEV)
+    o32 = torch.full((B * Sq, H), float("nan"), device=DEV)
+    nat().attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, Sq, Sk, scale, drop, head_dim=d, ctx_f32=o32, causal_tail=tail)
+    qf = hof(q.contiguous(), Sq).requires_grad_(True); kf = hof(k.contiguous(), Sk).requires_grad_(True); vf = hof(v.contiguous(), Sk).requires_grad_(True)
+    add = mask[:, None, None, :].expand(B, 1, Sq, Sk).clone()
+    if tail:      # m4c.py:424-440: a decoding key (the last `tail` positions) is visible to the decoding queries at or after it only, whatever the key mask says
+        cf = Sk - tail
+        qi = torch.arange(Sq, device=DEV)[:, None]; ki = torch.arange(Sk, device=DEV)[None, :]
+        causal = torch.where((qi >= cf) & (ki <= qi), 0.0, -10000.0).to(DEV)
+        add = torch.where((ki >= cf)[None, None], causal[None, None], add)
+    sc = torch.matmul(qf, kf.transpose(-1, -2)) * scale + add
+    pr = torch.softmax(sc, dim=-1)
+    lse_ref = torch.logsumexp(sc, dim=-1)
+    if p > 0:
+        pr = pr * _host_dropout_keep(drop[0], drop[1], B, heads, Sq, Sk) * drop[2]
+    o_ref = torch.matmul(pr, vf)
+    assert torch.isfinite(ctx.float()).all() and torch.isfinite(lse).all()
+    close(hof(ctx, Sq), o_ref, 2e-2, 2e-2, "ctx")
+    close(lse, lse_ref, 1e-4, 3e-3, "lse")
+    assert torch.equal(o32.bfloat16(), ctx)
+    dctx = rnd(B * Sq, H, seed=33)
+    dqb = torch.zeros_like(qbuf); dkvb = torch.zeros_like(kvbuf) if kvbuf is not qbuf else dqb
+    delta = torch.empty(B, heads, Sq, device=DEV)
+    nat().attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, Sq, Sk, scale, dctx,
+                        dqb[:, :H], dkvb[:, H:2 * H], dkvb[:, 2 * H:], delta, drop, head_dim=d, ctx_f32=o32, causal_tail=tail)
+    o_ref.backward(hof(dctx, Sq))
+    for name, got, ref, S in (("dq", dqb[:, :H], qf.grad, Sq), ("dk", dkvb[:, H:2 * H], kf.grad, Sk), ("dv", dkvb[:, 2 * H:], vf.grad, Sk)):
+        close(hof(got.contiguous(), S), ref, 3e-2, 3e-2 * float(ref.abs().max()), name)
+
+
+def test_attention_length_caps_are_reported():
+    from mmf_amd._native import NativeLibraryError
+    H = 64
+    qkv = rnd(520, 3 * H)
+    ctx = torch.empty(520, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(1, 1, 520, device=DEV)
+    with pytest.raises(NativeLibraryError, match="<= 512"):
+        nat().attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, ctx, H, lse, 1, 1, 520, 520, 0.125)
+    q2 = rnd(300, 3 * 128)
+    with pytest.raises(NativeLibraryError, match="head_dim 128 is built for Sq, Sk <= 256"):
+        nat().attention_fwd(q2, q2[:, 128:], q2[:, 256:], 384, 384, 384, None, torch.empty(300, 128, dtype=torch.bfloat16, device=DEV), 128,
+                            torch.empty(1, 1, 300, device=DEV), 1, 1, 300, 300, 0.1, head_dim=128)
+    with pytest.raises(NativeLibraryError, match="per-query mask is built for Sq, Sk <= 256"):
+        nat().attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, torch.zeros(1, 300, 300, device=DEV), ctx, H, lse, 1, 1, 300, 300, 0.125)
+
+
 # ---------------------------------------------------------------------------------------------
 # LayerNorm
 # ---------------------------------------------------------------------------------------------

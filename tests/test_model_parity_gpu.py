@@ -113,6 +113,47 @@ def test_full_config_forward_backward_matches_oracle(B):
     assert not bad, bad
 
 
+def test_max_seq_length_256_forward_backward_matches_oracle():
+    """`max_seq_length: 256` + 100 regions = 356 positions (round 4 refused more than 256): two BERT-base layers, ragged lengths, every
+    gradient against the oracle — the attention forward with 12 key tiles per head and the two-kernel backward inside the model."""
+    cfg = dict(O.DEFAULT_CONFIG)
+    cfg["num_hidden_layers"] = 2
+    sd = O.init_state_dict(cfg, seed=17)
+    g = torch.Generator().manual_seed(18)
+    for k in sd:
+        if k.endswith(".bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+    sample = O.synthetic_batch(cfg, 3, text_len=256, seed=199)
+    sample["input_mask"][1, 190:] = 0
+    sample["image_info_0"]["max_features"][2] = 61
+    model = build_visual_bert(cfg, sd, output_hidden_states=True)
+    model.eval()
+    out = model(SampleList(sample_to(sample, "cuda")))
+    assert out["sequence_output"].shape[1] == 356
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.visual_bert_forward(sdr, cfg, sample, train=False, return_hidden=True)
+    assert rel_err(out["sequence_output"], ref["sequence_output"]) <= TOL
+    assert (out["scores"].float().cpu() - ref["scores"]).abs().max().item() <= TOL
+    (key, loss), = out["losses"].items()
+    ref_loss = O.logit_bce(ref["scores"], sample["targets"])
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    loss.sum().backward()
+    ref_loss.backward()
+    params = dict(model.named_parameters())
+    bad = {}
+    for k, v in sdr.items():
+        if v.grad is None or float(v.grad.abs().max()) == 0.0 or k.endswith("self.key.bias"):
+            continue
+        e = rel_err(params["model." + k].grad, v.grad)
+        if e > TOL:
+            bad[k] = round(e, 4)
+    assert not bad, bad
+    model.train()                                    # and the training mode runs at this length (dropout inside the long kernels)
+    out = model(SampleList(sample_to(sample, "cuda")))
+    list(out["losses"].values())[0].sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
 def test_training_mode_runs_and_is_seed_reproducible():
     z, case, cfg, sd, sample = load_case("small64")
     model = build_visual_bert(cfg, sd)

@@ -81,6 +81,33 @@ def main():
     out["eval_propagates"] = (not hip_model._inner[0].training) and (not hip_model.model.training)
     hip_model.train()
     out["train_propagates"] = hip_model._inner[0].training and hip_model.model.training
+    # the adapter's forward under the REAL BaseModel.__call__ (base_model.py:305-337: device move, Mapping assertion, MMF's own `Losses` applied to the
+    # model output) with the REAL SampleList — on this CPU-only box every kernel launch is replaced by its extent / dtype checker
+    # (tests/native_stub.py), so this proves the plumbing, not the numbers (those are the `-m gpu` tests' job)
+    try:
+        from tests import native_stub
+        sample_mod = refshim.ref_import("mmf.common.sample")
+        B, T, R = 2, 128, 100
+        sl = sample_mod.SampleList()
+        sl.add_field("input_ids", torch.randint(1, 30000, (B, T)))
+        sl.add_field("input_mask", torch.ones(B, T, dtype=torch.long))
+        sl.add_field("segment_ids", torch.zeros(B, T, dtype=torch.long))
+        sl.add_field("image_feature_0", torch.rand(B, R, 2048))
+        sl.add_field("targets", torch.zeros(B, 3129))
+        sl.dataset_name = "vqa2"
+        sl.dataset_type = "train"
+        hip_model.train()
+        with native_stub.installed() as calls:
+            res = hip_model(sl)
+            loss = sum(v.sum() for v in res["losses"].values())
+            loss.backward()
+        out["call_scores_shape"] = list(res["scores"].shape)
+        out["call_loss_keys"] = sorted(res["losses"].keys())
+        out["call_launched"] = sorted({c[0] for c in calls})[:40]
+        out["call_grads"] = sum(1 for p in hip_model.parameters() if p.grad is not None)
+    except Exception as e:
+        import traceback
+        out["call_error"] = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc()[-800:])
     out["optimizer_type"] = proj["optimizer"]["type"]
     out["registered_optimizer_is_hip"] = registry.get_optimizer_class("adam_w").__module__.startswith("mmf_amd")
     out["registered_scheduler_is_hip"] = registry.get_scheduler_class("warmup_linear").__module__.startswith("mmf_amd")

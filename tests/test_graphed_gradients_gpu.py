@@ -52,7 +52,12 @@ def test_m4c_graphed_gradients_equal_eager(monkeypatch):
     from tests.golden_utils import load_m4c_case
     from tests.model_utils import build_m4c, sample_to
     z, case, cfg, sd, sample = load_m4c_case()
-    model = build_m4c(cfg, sd); model.eval()                 # eval: no dropout, both runs see the same arithmetic
+    model = build_m4c(cfg, sd)
+    model.train()                                            # teacher forcing (eval mode decodes greedily, without autograd: m4c.py:286-305)
+    for m in model.modules():                                # ... with every dropout site off: both runs see the same arithmetic
+        for attr in ("dropout_prob", "p"):
+            if isinstance(getattr(m, attr, None), float):
+                setattr(m, attr, 0.0)
     batch = SampleList(sample_to(sample, "cuda"))
     ge = _eager_grads(model, batch)
     gg = _graphed_grads(model, batch, monkeypatch)

@@ -558,7 +558,8 @@ int mmf_transpose_bf16_multi(const mmf_transpose_list* d, void* stream);
  * mmf_attention_f32_fwd: mmf_attention_fwd with q / k / v / ctx fp32 (hf_layers.py:161-213 in eval mode; vilbert.py:153-247, 388-475):
  * head_dim 64 with Sk <= 256 or head_dim 128 with Sk <= 128, Sq != Sk allowed, key mask and the prefix-LM causal_tail (m4c.py:424-440);
  * K and V of a (batch, head) are staged once per workgroup in LDS.  Optional lse output and probability dropout (training); ctx_f32 and
- * the K|V-cache strides must be unset.
+ * the K|V-cache strides must be unset.  Round 5: a materialised per-query mask (mask_query_stride / mask_batch_stride, as for mmf_attention_fwd)
+ * is read per (query, key) by the forward and both backward kernels.
  * mmf_layernorm_f32_fwd: nn.LayerNorm over fp32 rows (hf_layers.py:248,290; embeddings.py:456; visual_bert.py:328).
  * mmf_embed_text_f32_fwd / mmf_gather_rows_f32: mmf_embed_text_fwd / mmf_gather_rows (no dropout) writing / moving fp32 rows. */
 int mmf_gemm_f32(const mmf_gemm_desc* d, void* stream);
@@ -609,6 +610,26 @@ int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int rows, void
 int mmf_eltwise_f32(int op, const float* a, const float* b, float* y, long n, void* stream);
 int mmf_masked_mean_f32(const float* x, const float* mask, float* pool, int B, int T, int H, void* stream);
 int mmf_rowgroup_scale_f32(float* x, int ld, const float* gate, int groups, int rows_per_group, int C, void* stream);
+
+/* fp32 backwards of the operators round 5 added to `mmf_amd.fp32_training()` (the reference trains all of them in fp32 unless `training.fp16` is
+ * set, mmf/trainers/core/training_loop.py:199-211) — the bf16 kernels of the same names templated on fp32 rows:
+ *   mmf_masked_mean_f32_bwd / mmf_rowgroup_scale_f32_bwd : ViLBERT dynamic_attention pooling and Q | K gating (vilbert.py:204-212), see
+ *       mmf_masked_mean_bwd / mmf_rowgroup_scale_bwd;
+ *   mmf_align_pos_f32_bwd : the image_text_alignment position term (mmf/modules/embeddings.py:373-397), see mmf_align_pos_bwd;
+ *   mmf_soft_target_kl_f32_bwd : ViLBERT's masked-region KL loss (vilbert.py:1150-1157), gradient as fp32 [R, ldd] (ldd % 4 == 0);
+ *   mmf_l2norm_rows_f32_bwd : autograd of F.normalize (m4c.py:195,212,217,223): dx = (g - y <g, y>) / max(||x||, eps), the factor recomputed from
+ *       x into inv_ws [rows];
+ *   mmf_ptr_scores_f32_bwd : autograd of OcrPtrNet's scores (m4c.py:474-493): dq = scale ds k, dk = scale ds^T q per sample. */
+int mmf_slice_rows_f32(const float* src, int ld_src, int K, float* dst, int KP, int rows, void* stream);   /* dst[r][:KP] = src[r * ld_src + :K], zero padded */
+int mmf_masked_mean_f32_bwd(const float* dpool, const float* mask, float* dx, int B, int T, int H, void* stream);
+int mmf_rowgroup_scale_f32_bwd(float* dy, const float* y, int ld, const float* gate, float* dgate, int groups, int rows_per_group, int C, void* stream);
+int mmf_align_pos_f32_bwd(const float* dvis, int ld, int nb, int rpb, int bstride, const int64_t* align, float* dpos, int A, int H, int P, void* stream);
+int mmf_soft_target_kl_f32_bwd(const float* logits, int ld, const float* target, int ldt, const int64_t* row_label, const float* lse,
+                               const float* tsum, const float* count, const float* gloss, float* dlogits, int ldd, int R, int C, void* stream);
+int mmf_l2norm_rows_f32_bwd(const float* g, int ldg, const float* y, int ldy, const float* x, int ldx, float* inv_ws, float* dx, int lddx, int rows,
+                            int D, float eps, void* stream);
+int mmf_ptr_scores_f32_bwd(const float* dscores, int ldd, const float* q, const float* k, float* dq, float* dk, int B, int T, int N, int HQ,
+                           float scale, void* stream);
 
 /* M4C's row operators on fp32 rows (the fp32-accurate forward path): mmf_l2norm_rows_fwd, mmf_gather_rows2 and mmf_ptr_scores_fwd with fp32
  * operands (m4c.py:195,212-223; :526-528; :474-493). */

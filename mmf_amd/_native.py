@@ -702,6 +702,12 @@ def _attn_f32_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, sca
     d.drop_key, d.drop_thr16, d.drop_scale, d.drop_seed = _drop4(drop)
     d.head_dim = head_dim
     d.causal_tail = causal_tail
+    # a 3-D mask [B, Sq, Sk] is a materialised additive mask per (query, key) pair (mmf_attn_desc.mask_query_stride), as on the bf16 path
+    if mask is not None and mask.dim() == 3:
+        if tuple(mask.shape) != (B, Sq, Sk) or mask.stride(2) != 1:
+            raise NativeLibraryError("a per-query attention mask must be [B, Sq, Sk] with contiguous rows, got %s" % (tuple(mask.shape),))
+        d.mask_query_stride = int(mask.stride(1))
+        d.mask_batch_stride = int(mask.stride(0))
     return d
 
 
@@ -849,6 +855,53 @@ def masked_mean_f32(x, mask, pool, B, T, H):
 def rowgroup_scale_f32(x, ld, gate, groups, rows_per_group, Cn):
     _req(x, torch.float32, "x"); _req(gate, torch.float32, "gate")
     _check(lib().mmf_rowgroup_scale_f32(_p(x), ld, _p(gate), groups, rows_per_group, Cn, _stream()), "mmf_rowgroup_scale_f32")
+
+
+# ---- fp32 backwards of the operators round 5 added to mmf_amd.fp32_training() (gate_ops.hip, m4c_ops.hip, rowops.hip) -----------------
+def slice_rows_f32(src, ld_src, K, dst, KP, rows):
+    """dst[r, :KP] = src[r * ld_src + :K] followed by zeros (a column slice of wider fp32 rows as a 16-byte-row GEMM operand)."""
+    _req(src, torch.float32, "src"); _req(dst, torch.float32, "dst")
+    _check(lib().mmf_slice_rows_f32(_p(src), ld_src, K, _p(dst), KP, rows, _stream()), "mmf_slice_rows_f32")
+
+
+def masked_mean_f32_bwd(dpool, mask, dx, B, T, H):
+    _req(dpool, torch.float32, "dpool"); _req(mask, torch.float32, "mask"); _req(dx, torch.float32, "dx")
+    _check(lib().mmf_masked_mean_f32_bwd(_p(dpool), _p(mask), _p(dx), B, T, H, _stream()), "mmf_masked_mean_f32_bwd")
+
+
+def rowgroup_scale_f32_bwd(dy, y, ld, gate, dgate, groups, rows_per_group, Cn):
+    """In place: dy becomes the gradient of the un-gated rows; dgate[g][c] = sum_r dy * x."""
+    for t, n in ((dy, "dy"), (y, "y"), (gate, "gate"), (dgate, "dgate")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_rowgroup_scale_f32_bwd(_p(dy), _p(y), ld, _p(gate), _p(dgate), groups, rows_per_group, Cn, _stream()), "mmf_rowgroup_scale_f32_bwd")
+
+
+def align_pos_f32_bwd(dvis, ld, nb, rpb, bstride, align, dpos, A, H):
+    _req(dvis, torch.float32, "dvis"); _req(align, torch.int64, "align"); _req(dpos, torch.float32, "dpos")
+    _check(lib().mmf_align_pos_f32_bwd(_p(dvis), ld, nb, rpb, bstride, _p(align), _p(dpos), A, H, int(dpos.shape[0]), _stream()), "mmf_align_pos_f32_bwd")
+
+
+def soft_target_kl_f32_bwd(logits, target, row_label, lse, tsum, count, gloss, dlogits, ldd, R, Cn):
+    for t, n in ((logits, "logits"), (target, "target"), (lse, "lse"), (tsum, "tsum"), (count, "count"), (gloss, "gloss"), (dlogits, "dlogits")):
+        _req(t, torch.float32, n)
+    _req(row_label, torch.int64, "row_label")
+    _check(lib().mmf_soft_target_kl_f32_bwd(_p(logits), logits.stride(0), _p(target), target.stride(0), _p(row_label), _p(lse), _p(tsum),
+                                            _p(count), _p(gloss), _p(dlogits), ldd, R, Cn, _stream()), "mmf_soft_target_kl_f32_bwd")
+
+
+def l2norm_rows_f32_bwd(g, ldg, y, ldy, x, ldx, dx, lddx, rows, D, eps=1e-12):
+    """dx = (g - y <g, y>) / max(||x||, eps): autograd of F.normalize on fp32 rows (the factor is recomputed from x)."""
+    for t, n in ((g, "g"), (y, "y"), (x, "x"), (dx, "dx")):
+        _req(t, torch.float32, n)
+    inv = torch.empty(rows, dtype=torch.float32, device=g.device)
+    _check(lib().mmf_l2norm_rows_f32_bwd(_p(g), ldg, _p(y), ldy, _p(x), ldx, _p(inv), _p(dx), lddx, rows, D, C.c_float(eps), _stream()),
+           "mmf_l2norm_rows_f32_bwd")
+
+
+def ptr_scores_f32_bwd(dscores, ldd, q, k, dq, dk, B, T, N, HQ, scale):
+    for t, n in ((dscores, "dscores"), (q, "q"), (k, "k"), (dq, "dq"), (dk, "dk")):
+        _req(t, torch.float32, n)
+    _check(lib().mmf_ptr_scores_f32_bwd(_p(dscores), ldd, _p(q), _p(k), _p(dq), _p(dk), B, T, N, HQ, C.c_float(scale), _stream()), "mmf_ptr_scores_f32_bwd")
 
 
 def gather_rows_f32(x, index, out, B, S, H):

@@ -294,12 +294,18 @@ struct AttnF32 {
     int B, heads, Sq, Sk;
     float scale;
     int cfrom;     // first key of the causal tail (== Sk: none)
+    int mqs, mbs;  // per-query mask (mmf_attn_desc.mask_query_stride / mask_batch_stride): mask entries between query rows (0: the key mask [B, Sk]) / samples
     float* lse;    // [B, heads, Sq]: row maximum + log2(row sum) of the scaled scores in log2 units (training: saved for the backward)
     DropoutCfg drop;   // attention-probability dropout, element index ((b heads + head) Sq + q) Sk + key
     // backward only
     const float* o; const float* d_o; float* dq; float* dk; float* dv; float* delta;
 };
 
+// additive mask of (query q, key) in log2 units for the per-query form (what BertSelfAttentionJit.forward accepts as a [B, 1, S, S] mask,
+// hf_layers.py:187-190); q is clamped by the caller, keys past Sk are padding
+DEVI float query_mask(const AttnF32& a, int b, int q, int key) {
+    return key < a.Sk ? a.mask[(size_t)b * a.mbs + (size_t)q * a.mqs + key] * 1.4426950408889634f : -INFINITY;
+}
 // keep-scale of the probability of (query q, key) under attention dropout (1 when dropout is off)
 DEVI float attn_drop(const AttnF32& a, uint32_t dkey, int bh, int q, int key) {
     return drop_scale1(dkey, ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)a.Sk + (uint32_t)key, a.drop.thr16, a.drop.scale);
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
             *reinterpret_cast<f32x4*>(Vs + key * RS + 4 * qd) = vq;
         }
         for (int key = threadIdx.x; key < nt * 16; key += 512)
-            Ms[key] = key < a.Sk ? (a.mask ? a.mask[(size_t)b * a.Sk + key] * LOG2E : 0.f) : -INFINITY;
+            Ms[key] = key < a.Sk ? ((a.mask && !a.mqs) ? a.mask[(size_t)b * a.Sk + key] * LOG2E : 0.f) : -INFINITY;
     }
     // Q operand (B[k][j = query]): qv[m][c] = Q[q0 + j][16 m + 4 g + c]
     f32x4 qv[NM];
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * t + 4 * g + r;
                 float madd = mk[r];
+                if (a.mqs) madd = query_mask(a, b, min(qme, a.Sq - 1), key);
                 if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
                 const float x = acc[r] * sl2 + madd;
                 sc[t][r] = x;
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
             *reinterpret_cast<f32x4*>(Vs + key * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.v + ((size_t)b * a.Sk + kr) * a.ldv + h * D + 4 * qd);
         }
         for (int key = threadIdx.x; key < nt * 16; key += 512)
-            Ms[key] = key < a.Sk ? (a.mask ? a.mask[(size_t)b * a.Sk + key] * LOG2E : 0.f) : -INFINITY;
+            Ms[key] = key < a.Sk ? ((a.mask && !a.mqs) ? a.mask[(size_t)b * a.Sk + key] * LOG2E : 0.f) : -INFINITY;
     }
     const int qme = min(q0 + j, a.Sq - 1);
     f32x4 qv[NM], dov[NM];
@@ -514,6 +521,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * t + 4 * g + r;
             float madd = mk[r];
+            if (a.mqs) madd = query_mask(a, b, qme, key);
             if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
             const float p = __builtin_amdgcn_exp2f(s[r] * sl2 + madd - lse);
             const float m = a.drop.thr16 ? attn_drop(a, dkey, bh, qme, min(key, a.Sk - 1)) : 1.f;
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
     __syncthreads();
     if (k0 >= a.Sk) return;
     const float sl2 = a.scale * LOG2E;
-    const float mkey = kme < a.Sk ? (a.mask ? a.mask[(size_t)b * a.Sk + kme] * LOG2E : 0.f) : -INFINITY;
+    const float mkey = kme < a.Sk ? ((a.mask && !a.mqs) ? a.mask[(size_t)b * a.Sk + kme] * LOG2E : 0.f) : -INFINITY;
     const bool tail = kme >= a.cfrom && kme < a.Sk;
     const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
 
@@ -606,6 +614,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
         for (int r = 0; r < 4; ++r) {
             const int q = 16 * u + 4 * g + r;
             float madd = mkey;
+            if (a.mqs) madd = query_mask(a, b, min(q, a.Sq - 1), kme);       // (padded query rows carry lse = +inf: p = 0 whatever is read for them)
             if (tail) madd = (q >= a.cfrom && kme <= q) ? 0.f : -10000.f * LOG2E;
             const float p = __builtin_amdgcn_exp2f(s[r] * sl2 + madd - ls[r]);
             const float m = a.drop.thr16 ? attn_drop(a, dkey, bh, min(q, a.Sq - 1), kcl) : 1.f;
@@ -686,12 +695,12 @@ __global__ __launch_bounds__(256) void ln_f32_fwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // dst[r][0..KP) = src[r][0..K) followed by zeros: operands whose contraction length is not a multiple of 4 (the 5-d box geometry of
 // ViLBERT, the 7-d one of UNITER) become 16-byte rows for the fp32 GEMM.
-__global__ __launch_bounds__(256) void pad_rows_f32_kernel(const float* __restrict__ src, int K, float* __restrict__ dst, int KP, long n) {
+__global__ __launch_bounds__(256) void pad_rows_f32_kernel(const float* __restrict__ src, long lds, int K, float* __restrict__ dst, int KP, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const long r = i / KP;
     const int c = (int)(i - r * KP);
-    dst[i] = c < K ? src[r * K + c] : 0.f;
+    dst[i] = c < K ? src[r * lds + c] : 0.f;
 }
 // op 0: a * b, 1: max(a, 0), 3: a + b   (the op codes of mmf_eltwise); 4: a * (1 - b^2) (backward of tanh, b = the saved output);
 // 5: a where b > 0 else 0 (backward of relu, b = the saved output)
@@ -876,8 +885,9 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
     const int hd = d->head_dim ? d->head_dim : 64;
     MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_fwd: head_dim must be 64 or 128");
     MMF_CHECK_ARG(d->Sk <= (hd == 64 ? 256 : 128), "attention_f32_fwd: Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
-    MMF_CHECK_ARG(d->mask_query_stride == 0, "attention_f32_fwd: a per-query mask (mask_query_stride) is read by the bf16 kernels only");
-    MMF_CHECK_ARG(!d->ctx_f32 && d->q_batch_rows == 0 && d->kv_batch_rows == 0 && d->mask_batch_stride == 0,
+    MMF_CHECK_ARG(d->mask_query_stride == 0 || (d->mask && d->mask_query_stride >= d->Sk && d->causal_tail == 0),
+                  "attention_f32_fwd: mask_query_stride must cover a mask row (>= Sk) and replaces the causal tail");
+    MMF_CHECK_ARG(!d->ctx_f32 && d->q_batch_rows == 0 && d->kv_batch_rows == 0 && (d->mask_batch_stride == 0 || d->mask_query_stride != 0),
                   "attention_f32_fwd: no ctx_f32 (ctx IS fp32) and no K|V cache strides");
     MMF_CHECK_ARG(d->causal_tail >= 0 && d->causal_tail <= d->Sk && (d->causal_tail == 0 || d->Sq == d->Sk),
                   "attention_f32_fwd: a causal tail needs self-attention (Sq == Sk)");
@@ -891,6 +901,9 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
     a.mask = d->mask; a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk; a.scale = d->scale;
     a.cfrom = d->Sk - d->causal_tail;
+    a.mqs = d->mask_query_stride;
+    a.mbs = d->mask_batch_stride > 0 ? d->mask_batch_stride : d->Sq * d->mask_query_stride;
+    MMF_CHECK_ARG(a.mqs == 0 || a.mbs >= (d->Sq - 1) * a.mqs + d->Sk, "attention_f32_fwd: mask_batch_stride must cover the per-query mask of a sample");
     a.lse = d->lse;
     a.drop = DropoutCfg{d->drop_key, d->drop_thr16, d->drop_scale, d->drop_seed};
     a.o = nullptr; a.d_o = nullptr; a.dq = a.dk = a.dv = a.delta = nullptr;
@@ -923,8 +936,10 @@ extern "C" int mmf_attention_f32_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_bwd: head_dim must be 64 or 128");
     const int smax = hd == 64 ? 256 : 128;
     MMF_CHECK_ARG(f->Sk <= smax && f->Sq <= smax, "attention_f32_bwd: Sq, Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
-    MMF_CHECK_ARG(f->mask_query_stride == 0, "attention_f32_bwd: a per-query mask (mask_query_stride) is read by the bf16 kernels only");
-    MMF_CHECK_ARG(!f->ctx_f32 && f->q_batch_rows == 0 && f->kv_batch_rows == 0 && f->mask_batch_stride == 0, "attention_f32_bwd: no ctx_f32 / K|V cache strides");
+    MMF_CHECK_ARG(f->mask_query_stride == 0 || (f->mask && f->mask_query_stride >= f->Sk && f->causal_tail == 0),
+                  "attention_f32_bwd: mask_query_stride must cover a mask row (>= Sk) and replaces the causal tail");
+    MMF_CHECK_ARG(!f->ctx_f32 && f->q_batch_rows == 0 && f->kv_batch_rows == 0 && (f->mask_batch_stride == 0 || f->mask_query_stride != 0),
+                  "attention_f32_bwd: no ctx_f32 / K|V cache strides");
     MMF_CHECK_ARG(f->causal_tail >= 0 && f->causal_tail <= f->Sk && (f->causal_tail == 0 || f->Sq == f->Sk), "attention_f32_bwd: a causal tail needs Sq == Sk");
     const int HD = f->heads * hd;
     MMF_CHECK_ARG(f->ldq >= HD && f->ldk >= HD && f->ldv >= HD && f->ldo >= HD, "attention_f32_bwd: leading dimension < heads * head_dim");
@@ -936,6 +951,9 @@ extern "C" int mmf_attention_f32_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     a.q = (const float*)f->q; a.k = (const float*)f->k; a.v = (const float*)f->v; a.out = nullptr;
     a.ldq = f->ldq; a.ldk = f->ldk; a.ldv = f->ldv; a.ldo = f->ldo;
     a.mask = f->mask; a.B = f->B; a.heads = f->heads; a.Sq = f->Sq; a.Sk = f->Sk; a.scale = f->scale;
+    a.mqs = f->mask_query_stride;
+    a.mbs = f->mask_batch_stride > 0 ? f->mask_batch_stride : f->Sq * f->mask_query_stride;
+    MMF_CHECK_ARG(a.mqs == 0 || a.mbs >= (f->Sq - 1) * a.mqs + f->Sk, "attention_f32_bwd: mask_batch_stride must cover the per-query mask of a sample");
     a.cfrom = f->Sk - f->causal_tail;
     a.lse = f->lse;
     a.drop = DropoutCfg{f->drop_key, f->drop_thr16, f->drop_scale, f->drop_seed};
@@ -965,7 +983,16 @@ extern "C" int mmf_layernorm_f32_fwd_stats(const float* x, const float* gamma, c
 extern "C" int mmf_pad_rows_f32(const float* src, int K, float* dst, int KP, int rows, void* stream) {
     MMF_CHECK_ARG(src && dst && rows > 0 && K > 0 && KP >= K, "pad_rows_f32: bad operand");
     const long n = (long)rows * KP;
-    hipLaunchKernelGGL(pad_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, K, dst, KP, n);
+    hipLaunchKernelGGL(pad_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)K, K, dst, KP, n);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+// the same from a column slice of wider rows: dst[r][0..KP) = src[r * ld_src + 0..K) followed by zeros (the fixed-vocabulary part of M4C's
+// [B T, 5000 + 50] score gradient as a 16-byte-row GEMM operand)
+extern "C" int mmf_slice_rows_f32(const float* src, int ld_src, int K, float* dst, int KP, int rows, void* stream) {
+    MMF_CHECK_ARG(src && dst && rows > 0 && K > 0 && KP >= K && ld_src >= K, "slice_rows_f32: bad operand");
+    const long n = (long)rows * KP;
+    hipLaunchKernelGGL(pad_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, K, dst, KP, n);
     MMF_CHECK_LAUNCH();
     return 0;
 }

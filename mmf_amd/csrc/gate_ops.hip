@@ -27,16 +27,17 @@ __global__ __launch_bounds__(256) void masked_mean_fwd_kernel(const bf16* __rest
     pool[(size_t)b * H + c] = acc / cnt;       // an all-zero mask divides by zero like the reference does
 }
 // dx[b][t][c] = dpool[b][c] * mask[b][t] / sum_t mask[b][t]
+template <typename RT>   // bf16 rows (throughput path) or fp32 rows (mmf_amd.fp32_training())
 __global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ dpool, const float* __restrict__ mask,
-                                                               bf16* __restrict__ dx, int T, int H) {
+                                                               RT* __restrict__ dx, int T, int H) {
     const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= H) return;
     const float* mb = mask + (size_t)b * T;
     float cnt = 0.f;
     for (int t = 0; t < T; ++t) cnt += mb[t];
     const float g = dpool[(size_t)b * H + c] / cnt;
-    bf16* db = dx + (size_t)b * T * H + c;
-    for (int t = 0; t < T; ++t) db[(size_t)t * H] = (bf16)(g * mb[t]);
+    RT* db = dx + (size_t)b * T * H + c;
+    for (int t = 0; t < T; ++t) db[(size_t)t * H] = (RT)(g * mb[t]);
 }
 
 // x[g * rpg + r][c] *= gate[g][c] for c < C (C % 8 == 0, ld % 8 == 0): 8 columns per thread
@@ -96,6 +97,22 @@ __global__ __launch_bounds__(256) void gate_sigmoid_bwd_kernel(const float* __re
     const int c = (int)(i - b * C);
     const float s = gate[b * ldg + col0 + c] - 1.f;
     dz[i] = dgate[b * ldg + col0 + c] * s * (1.f - s);
+}
+
+// the same backward of the per-sample column scale on fp32 rows: one thread per column, looping over the group's rows
+__global__ __launch_bounds__(256) void rowgroup_scale_f32_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, int ld,
+                                                                      const float* __restrict__ gate, float* __restrict__ dgate, int rpg, int C) {
+    const int g = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float gt = gate[(size_t)g * C + c];
+    float acc = 0.f;
+    for (int r = 0; r < rpg; ++r) {
+        const size_t off = (size_t)(g * rpg + r) * ld + c;
+        const float d = dy[off];
+        acc += d * y[off];
+        dy[off] = d * gt;
+    }
+    dgate[(size_t)g * C + c] = acc / gt;
 }
 
 }  // namespace
@@ -249,7 +266,20 @@ int mmf_masked_mean_fwd(const void* x, const float* mask, float* pool, int B, in
 }
 int mmf_masked_mean_bwd(const float* dpool, const float* mask, void* dx, int B, int T, int H, void* stream) {
     MMF_CHECK_ARG(dpool && mask && dx && B > 0 && T > 0 && H > 0, "masked_mean_bwd: bad operand");
-    hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dpool, mask, (bf16*)dx, T, H);
+    hipLaunchKernelGGL(masked_mean_bwd_kernel<bf16>, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dpool, mask, (bf16*)dx, T, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_masked_mean_f32_bwd(const float* dpool, const float* mask, float* dx, int B, int T, int H, void* stream) {
+    MMF_CHECK_ARG(dpool && mask && dx && B > 0 && T > 0 && H > 0, "masked_mean_f32_bwd: bad operand");
+    hipLaunchKernelGGL(masked_mean_bwd_kernel<float>, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dpool, mask, dx, T, H);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_rowgroup_scale_f32_bwd(float* dy, const float* y, int ld, const float* gate, float* dgate, int groups, int rows_per_group, int C, void* stream) {
+    MMF_CHECK_ARG(dy && y && gate && dgate && groups > 0 && rows_per_group > 0 && C > 0 && C <= ld, "rowgroup_scale_f32_bwd: bad operand");
+    hipLaunchKernelGGL(rowgroup_scale_f32_bwd_kernel, dim3((C + 255) / 256, groups), dim3(256), 0, (hipStream_t)stream, dy, y, ld, gate, dgate,
+                       rows_per_group, C);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -28,20 +28,32 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const XT* __restrict__ 
     if (lane == 0) inv[row] = r;
 }
 // dx = (g - y * <g, y>) * inv   (y = the normalised row, inv = 1 / ||x||)
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const bf16* __restrict__ g, int ldg, const bf16* __restrict__ y, int ldy,
-                                                          const float* __restrict__ inv, bf16* __restrict__ dx, int lddx, int rows,
+template <typename T>   // bf16 rows (throughput path) or fp32 rows (mmf_amd.fp32_training())
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ y, int ldy,
+                                                          const float* __restrict__ inv, T* __restrict__ dx, int lddx, int rows,
                                                           int D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16* gr = g + (size_t)row * ldg;
-    const bf16* yr = y + (size_t)row * ldy;
+    const T* gr = g + (size_t)row * ldg;
+    const T* yr = y + (size_t)row * ldy;
     float dot = 0.f;
     for (int c = lane; c < D; c += 64) dot += (float)gr[c] * (float)yr[c];
     dot = wave_sum(dot);
     const float r = inv[row];
-    bf16* dr = dx + (size_t)row * lddx;
-    for (int c = lane; c < D; c += 64) dr[c] = (bf16)(((float)gr[c] - (float)yr[c] * dot) * r);
+    T* dr = dx + (size_t)row * lddx;
+    for (int c = lane; c < D; c += 64) dr[c] = (T)(((float)gr[c] - (float)yr[c] * dot) * r);
+}
+// inv[r] = 1 / max(||x[r, :D]||, eps): the factor the fp32 forward (mmf_l2norm_rows_f32) applied, recomputed for its backward
+__global__ __launch_bounds__(256) void l2norm_inv_f32_kernel(const float* __restrict__ x, int ldx, float* __restrict__ inv, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = xr[c]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -85,24 +97,26 @@ __global__ __launch_bounds__(256) void ptr_scores_fwd_kernel(const bf16* __restr
     }
 }
 // dq[b, t, :] = scale * sum_n ds[b, t, n] * k[b, n, :]          (workgroup per (b, t), thread per feature)
-__global__ __launch_bounds__(256) void ptr_scores_dq_kernel(const float* __restrict__ ds, int ldd, const bf16* __restrict__ k,
-                                                             bf16* __restrict__ dq, int T, int N, int HQ, float scale) {
+template <typename RT>
+__global__ __launch_bounds__(256) void ptr_scores_dq_kernel(const float* __restrict__ ds, int ldd, const RT* __restrict__ k,
+                                                             RT* __restrict__ dq, int T, int N, int HQ, float scale) {
     const int bt = blockIdx.x, b = bt / T;
     const float* dr = ds + (size_t)bt * ldd;
     for (int c = threadIdx.x; c < HQ; c += 256) {
         float acc = 0.f;
         for (int n = 0; n < N; ++n) acc += dr[n] * (float)k[((size_t)b * N + n) * HQ + c];
-        dq[(size_t)bt * HQ + c] = (bf16)(acc * scale);
+        dq[(size_t)bt * HQ + c] = (RT)(acc * scale);
     }
 }
 // dk[b, n, :] = scale * sum_t ds[b, t, n] * q[b, t, :]          (workgroup per (b, n))
-__global__ __launch_bounds__(256) void ptr_scores_dk_kernel(const float* __restrict__ ds, int ldd, const bf16* __restrict__ q,
-                                                             bf16* __restrict__ dk, int T, int N, int HQ, float scale) {
+template <typename RT>
+__global__ __launch_bounds__(256) void ptr_scores_dk_kernel(const float* __restrict__ ds, int ldd, const RT* __restrict__ q,
+                                                             RT* __restrict__ dk, int T, int N, int HQ, float scale) {
     const int bn = blockIdx.x, b = bn / N, n = bn - b * N;
     for (int c = threadIdx.x; c < HQ; c += 256) {
         float acc = 0.f;
         for (int t = 0; t < T; ++t) acc += ds[((size_t)b * T + t) * ldd + n] * (float)q[((size_t)b * T + t) * HQ + c];
-        dk[(size_t)bn * HQ + c] = (bf16)(acc * scale);
+        dk[(size_t)bn * HQ + c] = (RT)(acc * scale);
     }
 }
 
@@ -160,8 +174,16 @@ int mmf_l2norm_rows_fwd(const void* x, int x_f32, int ldx, void* y, int ldy, flo
 int mmf_l2norm_rows_bwd(const void* g, int ldg, const void* y, int ldy, const float* inv_norm, void* dx, int lddx, int rows, int D,
                         void* stream) {
     MMF_CHECK_ARG(g && y && inv_norm && dx && rows > 0 && D > 0 && ldg >= D && ldy >= D && lddx >= D, "l2norm_rows_bwd: bad operand");
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, ldg, (const bf16*)y, ldy,
+    hipLaunchKernelGGL(l2norm_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, ldg, (const bf16*)y, ldy,
                        inv_norm, (bf16*)dx, lddx, rows, D);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_l2norm_rows_f32_bwd(const float* g, int ldg, const float* y, int ldy, const float* x, int ldx, float* inv_ws, float* dx, int lddx, int rows,
+                            int D, float eps, void* stream) {
+    MMF_CHECK_ARG(g && y && x && inv_ws && dx && rows > 0 && D > 0 && ldg >= D && ldy >= D && ldx >= D && lddx >= D, "l2norm_rows_f32_bwd: bad operand");
+    hipLaunchKernelGGL(l2norm_inv_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, inv_ws, rows, D, eps);
+    hipLaunchKernelGGL(l2norm_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, g, ldg, y, ldy, inv_ws, dx, lddx, rows, D);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -186,9 +208,18 @@ int mmf_ptr_scores_fwd(const void* q, const void* k, const float* mask_add, floa
 int mmf_ptr_scores_bwd(const float* dscores, int ldd, const void* q, const void* k, void* dq, void* dk, int B, int T, int N, int HQ,
                        float scale, void* stream) {
     MMF_CHECK_ARG(dscores && q && k && dq && dk && B > 0 && T > 0 && N > 0 && HQ > 0 && ldd >= N, "ptr_scores_bwd: bad operand");
-    hipLaunchKernelGGL(ptr_scores_dq_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, dscores, ldd, (const bf16*)k, (bf16*)dq, T, N, HQ, scale);
+    hipLaunchKernelGGL(ptr_scores_dq_kernel<bf16>, dim3(B * T), dim3(256), 0, (hipStream_t)stream, dscores, ldd, (const bf16*)k, (bf16*)dq, T, N, HQ, scale);
     MMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ptr_scores_dk_kernel, dim3(B * N), dim3(256), 0, (hipStream_t)stream, dscores, ldd, (const bf16*)q, (bf16*)dk, T, N, HQ, scale);
+    hipLaunchKernelGGL(ptr_scores_dk_kernel<bf16>, dim3(B * N), dim3(256), 0, (hipStream_t)stream, dscores, ldd, (const bf16*)q, (bf16*)dk, T, N, HQ, scale);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_ptr_scores_f32_bwd(const float* dscores, int ldd, const float* q, const float* k, float* dq, float* dk, int B, int T, int N, int HQ,
+                           float scale, void* stream) {
+    MMF_CHECK_ARG(dscores && q && k && dq && dk && B > 0 && T > 0 && N > 0 && HQ > 0 && ldd >= N, "ptr_scores_f32_bwd: bad operand");
+    hipLaunchKernelGGL(ptr_scores_dq_kernel<float>, dim3(B * T), dim3(256), 0, (hipStream_t)stream, dscores, ldd, k, dq, T, N, HQ, scale);
+    MMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ptr_scores_dk_kernel<float>, dim3(B * N), dim3(256), 0, (hipStream_t)stream, dscores, ldd, q, dk, T, N, HQ, scale);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -480,7 +480,8 @@ __global__ __launch_bounds__(256) void align_pos_fwd_kernel(const int64_t* __res
 }
 // backward of the mean: dpos[align[r][a]] += dvis[r] / count[r] for every valid a (fp32 atomics, like the word-embedding scatter);
 // row r = (b, i) of the visual block lives at dvis + (b * bstride + i) * ld.
-__global__ __launch_bounds__(256) void align_pos_bwd_kernel(const bf16* __restrict__ dvis, int ld, int rpb, int bstride, const int64_t* __restrict__ align,
+template <typename T>   // bf16 gradient rows (throughput path) or fp32 rows (mmf_amd.fp32_training())
+__global__ __launch_bounds__(256) void align_pos_bwd_kernel(const T* __restrict__ dvis, int ld, int rpb, int bstride, const int64_t* __restrict__ align,
                                                              float* __restrict__ dpos, int rows, int A, int H, int P) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void align_pos_bwd_kernel(const bf16* __restri
     if (cnt == 0) return;
     const float inv = 1.f / (float)cnt;
     const int b = r / rpb, i = r - b * rpb;
-    const bf16* src = dvis + ((size_t)b * bstride + i) * ld;
+    const T* src = dvis + ((size_t)b * bstride + i) * ld;
     for (int col = lane; col < H; col += 64) {
         const float g = (float)src[col] * inv;
         for (int a = 0; a < A; ++a) {
@@ -1041,10 +1042,11 @@ __global__ __launch_bounds__(256) void soft_kl_finalize_kernel(const float* __re
     n = block_sum256(n, sh);
     if (threadIdx.x == 0) { loss[0] = s / n; count[0] = n; }     // the reference divides by max(n, 0) = n (vilbert.py:1157)
 }
+template <typename T>     // bf16: the zero-padded GEMM operand of the throughput path; float: the fp32 training path
 __global__ __launch_bounds__(256) void soft_kl_bwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ tgt, int ldt,
                                                            const int64_t* __restrict__ lab, const float* __restrict__ lse,
                                                            const float* __restrict__ tsum, const float* __restrict__ count,
-                                                           const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int C) {
+                                                           const float* __restrict__ gloss, T* __restrict__ d, int ldd, int C) {
     const int r = blockIdx.y;
     const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c0 >= ldd) return;
@@ -1427,8 +1429,15 @@ int mmf_align_pos_fwd(const int64_t* align, const float* pos, const float* typ, 
 int mmf_align_pos_bwd(const void* dvis, int ld, int nb, int rpb, int bstride, const int64_t* align, float* dpos, int A, int H, int P, void* stream) {
     MMF_CHECK_ARG(dvis && align && dpos && nb > 0 && rpb > 0 && A > 0 && P > 0 && H > 0 && ld >= H, "align_pos_bwd: bad operand");
     const int rows = nb * rpb;
-    hipLaunchKernelGGL(align_pos_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dvis, ld, rpb, bstride, align, dpos, rows, A,
+    hipLaunchKernelGGL(align_pos_bwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dvis, ld, rpb, bstride, align, dpos, rows, A,
                        H, P);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_align_pos_f32_bwd(const float* dvis, int ld, int nb, int rpb, int bstride, const int64_t* align, float* dpos, int A, int H, int P, void* stream) {
+    MMF_CHECK_ARG(dvis && align && dpos && nb > 0 && rpb > 0 && A > 0 && P > 0 && H > 0 && ld >= H, "align_pos_f32_bwd: bad operand");
+    const int rows = nb * rpb;
+    hipLaunchKernelGGL(align_pos_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dvis, ld, rpb, bstride, align, dpos, rows, A, H, P);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -1698,9 +1707,23 @@ int mmf_soft_target_kl_bwd(const float* logits, int ld, const float* target, int
     MMF_CHECK_ARG(ldd >= C && (ldd % 8) == 0, "soft_target_kl_bwd: ldd must be a multiple of 8 covering C (the GEMM operand's leading dimension)");
     for (int r0 = 0; r0 < R; r0 += 65535) {       // (grid.y is limited to 65535 rows per launch)
         const int rows = R - r0 < 65535 ? R - r0 : 65535;
-        hipLaunchKernelGGL(soft_kl_bwd_kernel, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(soft_kl_bwd_kernel<bf16>, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
                            logits + (size_t)r0 * ld, ld, target + (size_t)r0 * ldt, ldt, row_label + r0, lse + r0, tsum + r0, count, gloss,
                            (bf16*)dlogits + (size_t)r0 * ldd, ldd, C);
+    }
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_soft_target_kl_f32_bwd(const float* logits, int ld, const float* target, int ldt, const int64_t* row_label, const float* lse,
+                               const float* tsum, const float* count, const float* gloss, float* dlogits, int ldd, int R, int C, void* stream) {
+    MMF_CHECK_ARG(logits && target && row_label && lse && tsum && count && dlogits && R > 0 && C > 0 && ld >= C && ldt >= C,
+                  "soft_target_kl_f32_bwd: bad operand");
+    MMF_CHECK_ARG(ldd >= C && (ldd % 4) == 0, "soft_target_kl_f32_bwd: ldd must be a multiple of 4 covering C");
+    for (int r0 = 0; r0 < R; r0 += 65535) {
+        const int rows = R - r0 < 65535 ? R - r0 : 65535;
+        hipLaunchKernelGGL(soft_kl_bwd_kernel<float>, dim3((ldd / 4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream,
+                           logits + (size_t)r0 * ld, ld, target + (size_t)r0 * ldt, ldt, row_label + r0, lse + r0, tsum + r0, count, gloss,
+                           dlogits + (size_t)r0 * ldd, ldd, C);
     }
     MMF_CHECK_LAUNCH();
     return 0;

@@ -147,7 +147,7 @@ def pair_halves(x):
 
 
 def visio_linguistic_embeddings(input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b,
-                                eps):
+                                eps, align=None):
     """embeddings.py:423-459 with image_text_alignment=None: text rows = word + position + type; visual rows = projection(features)
     + visual type + visual position 0, written by the projection GEMM's epilogue into rows T.. of the joint sequence; LayerNorm."""
     B, T = input_ids.shape
@@ -163,8 +163,16 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, feats, vtype, word, p
         f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
         if D % 4:
             raise ValueError("fp32 path: visual feature width (%d) must be a multiple of 4" % D)
-        nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=_w(typ_vis),
-                     rowidx=vtype.reshape(B * R).contiguous(), rowtab_ld=H, grp=(R, T, T))
+        vt = vtype.reshape(B * R).contiguous()
+        if align is not None:        # image_text_alignment (embeddings.py:373-397): per region, the mean text-position row of its aligned words + visual type
+            al = align.reshape(B * R, -1).long().contiguous()
+            addend = torch.empty(B * R, H, dtype=F32, device=dev)
+            nat.align_pos_fwd(al, _w(pos), _w(typ_vis), vt, addend, B * R, al.shape[1], H)
+            nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=addend,
+                         rowidx=torch.arange(B * R, dtype=torch.int64, device=dev), rowtab_ld=H, grp=(R, T, T))
+        else:
+            nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=_w(typ_vis),
+                         rowidx=vt, rowtab_ld=H, grp=(R, T, T))
     out = torch.empty(B * S, H, dtype=F32, device=dev)
     nat.layernorm_f32_fwd(y, _w(ln_w), _w(ln_b), out, B * S, H, eps)
     return out.view(B, S, H)
@@ -175,6 +183,15 @@ def _check_head(hd, Sk):
         raise NotImplementedError("fp32 path: the attention kernel is built for head_dim 64 and 128, got %d" % hd)
     if Sk > (256 if hd == 64 else 128):
         raise NotImplementedError("fp32 path: %d keys exceed what one workgroup stages (256 at head_dim 64, 128 at head_dim 128)" % Sk)
+
+
+def _attn_mask(mask_add, B, S):
+    """The additive mask in the form the fp32 attention takes it: the key mask [B, S], or — a materialised [B, 1, S, S] mask, hf_layers.py:187-190 —
+    one row per query [B, S, S] (mmf_attn_desc.mask_query_stride)."""
+    if mask_add is None:
+        return None
+    m = mask_add.float()
+    return (m.reshape(B, S) if m.numel() == B * S else m.reshape(B, S, S)).contiguous()
 
 
 def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2,
@@ -192,7 +209,7 @@ def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w
     if qk_gate is not None:                                          # ViLBERT dynamic_attention gates on the Q | K columns (vilbert.py:211-212)
         nat.rowgroup_scale_f32(qkv, 3 * H, qk_gate.contiguous(), B, S, 2 * H)
     ctx = torch.empty(M, H, dtype=F32, device=dev)
-    mask = None if mask_add is None else mask_add.reshape(B, S).contiguous()
+    mask = _attn_mask(mask_add, B, S)
     nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctx, H, B, heads, S, S, 1.0 / math.sqrt(hd), head_dim=hd,
                           causal_tail=int(causal_tail))
     y1 = _linear(ctx, wo, bo, resid=x2)
@@ -218,6 +235,21 @@ def masked_lm_head(x, weight, bias, labels, ignore_index):
     loss = torch.empty(1, dtype=F32, device=x2.device)
     count = torch.empty(1, dtype=F32, device=x2.device)
     nat.vocab_cross_entropy_fwd(logits, lab, lse, rowloss, loss, count, M, N, ignore_index)
+    return loss[0], logits.view(*x.shape[:-1], N)
+
+
+def masked_region_head(x, weight, bias, target, row_label):
+    """ViLBERT's masked-region classification head (vilbert.py:846-858, 1150-1157, `visual_target: 0`), forward: decoder GEMM + masked soft-target
+    KL divergence.  Returns (loss, scores)."""
+    x2 = _rows(x)
+    M = x2.shape[0]
+    N = weight.shape[0]
+    logits = _linear(x2, weight, bias)
+    lab = row_label.reshape(M).long().contiguous()
+    tgt = target.reshape(M, N).float().contiguous()
+    e = lambda *sh: torch.empty(*sh, dtype=F32, device=x2.device)
+    lse, tsum, rowloss, loss, count = e(M), e(M), e(M), e(1), e(1)
+    nat.soft_target_kl_fwd(logits, tgt, lab, lse, tsum, rowloss, loss, count, M, N)
     return loss[0], logits.view(*x.shape[:-1], N)
 
 

@@ -233,7 +233,7 @@ class AttentionBlockFn(torch.autograd.Function):
     backward into one [M, 3H] buffer, and the Q|K|V dgrad with the residual gradient added in ITS epilogue."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask_add, heads, eps, drop_attn, drop_hid, tail):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask_add, heads, eps, drop_attn, drop_hid, tail, qk_gate=None):
         B, S, H = x.shape
         hd = H // heads
         P._check_head(hd, S)
@@ -241,21 +241,25 @@ class AttentionBlockFn(torch.autograd.Function):
         M = B * S
         wqkv, bqkv = P._packed(wq, wk, wv), P._packed(bq, bk, bv)
         qkv = _gemm(x2, wqkv, 3 * H, bias=bqkv)
+        gate = None
+        if qk_gate is not None:      # ViLBERT dynamic_attention: per-sample column gates on the Q | K columns (vilbert.py:211-212)
+            gate = qk_gate.detach().float().contiguous()
+            nat.rowgroup_scale_f32(qkv, 3 * H, gate, B, S, 2 * H)
         ctxt = _empty(M, H, like=x2)
         lse = _empty(B, heads, S, like=x2)
-        mask = None if mask_add is None else mask_add.reshape(B, S).float().contiguous()
+        mask = P._attn_mask(mask_add, B, S)
         nat.attention_f32_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctxt, H, B, heads, S, S, 1.0 / math.sqrt(hd), head_dim=hd,
                               causal_tail=int(tail), lse=lse, drop=drop_attn)
         wo_ = _w(wo)
         y1 = _gemm(ctxt, wo_, H, bias=_w(bo), drop=drop_hid, resid=x2, ldr=H)
         out, mean, rstd = _ln_fwd(y1, gamma, beta, eps)
-        ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean, rstd, wqkv.clone(), wo_, gamma.detach(), mask)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean, rstd, wqkv.clone(), wo_, gamma.detach(), mask, gate)
         ctx.meta = (B, S, H, heads, drop_attn, drop_hid, int(tail))
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        x2, qkv, ctxt, lse, y1, mean, rstd, wqkv, wo, gamma, mask = ctx.saved_tensors
+        x2, qkv, ctxt, lse, y1, mean, rstd, wqkv, wo, gamma, mask, gate = ctx.saved_tensors
         B, S, H, heads, drop_attn, drop_hid, tail = ctx.meta
         hd = H // heads
         M = B * S
@@ -267,10 +271,14 @@ class AttentionBlockFn(torch.autograd.Function):
         delta = _empty(B, heads, S, like=x2)
         nat.attention_f32_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask, ctxt, H, lse, B, heads, S, S, 1.0 / math.sqrt(hd), dctx,
                               dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, head_dim=hd, causal_tail=tail, drop=drop_attn)
+        dgate = None
+        if gate is not None:         # dqkv becomes the gradient of the un-gated projection; dgate[b][c] = sum_rows dqk * (un-gated qk)
+            dgate = torch.empty_like(gate)
+            nat.rowgroup_scale_f32_bwd(dqkv, qkv, 3 * H, gate, dgate, B, S, 2 * H)
         dx = _dgrad(dqkv, wqkv, resid=dy1)
         dw, db = _wgrad(dqkv, x2), _colsum(dqkv)
         return (dx.view(B, S, H), dw[:H], db[:H], dw[H:2 * H], db[H:2 * H], dw[2 * H:], db[2 * H:], dwo, dbo, dgamma, dbeta,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, dgate)
 
 
 class FeedForwardFn(torch.autograd.Function):
@@ -313,7 +321,8 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
     type table, the projection's weight gradient over the gathered visual rows."""
 
     @staticmethod
-    def forward(ctx, input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps, drop, pad_idx):
+    def forward(ctx, input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps, drop, pad_idx,
+                align=None):
         B, T = input_ids.shape
         H = word.shape[1]
         R = 0 if feats is None else feats.shape[1]
@@ -330,21 +339,31 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             f2 = feats.reshape(B * R, D)
             f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
             vt = vtype.reshape(B * R).contiguous()
-            nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=_w(typ_vis), rowidx=vt,
-                         rowtab_ld=H, grp=(R, T, T))
+            if align is not None:    # image_text_alignment (embeddings.py:373-397): per region, the mean TEXT position row of its aligned words + visual type
+                al = align.reshape(B * R, -1).long().contiguous()
+                addend = torch.empty(B * R, H, dtype=F32, device=dev)
+                nat.align_pos_fwd(al, _w(pos), _w(typ_vis), vt, addend, B * R, al.shape[1], H)
+                nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=addend,
+                             rowidx=torch.arange(B * R, dtype=torch.int64, device=dev), rowtab_ld=H, grp=(R, T, T))
+            else:
+                al = None
+                nat.gemm_f32(f2, _w(proj_w), y, B * R, H, D, D, D, H, bias=_w(proj_b), coladd=_w(pos_vis)[0], rowtab=_w(typ_vis), rowidx=vt,
+                             rowtab_ld=H, grp=(R, T, T))
+        else:
+            al = None
         out, mean, rstd = _ln_fwd(y, ln_w, ln_b, eps)
         if drop[1]:
             o2 = torch.empty_like(out)
             nat.dropout_f32(out, o2, drop)
             out = o2
-        ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach())
+        ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), al)
         ctx.meta = (B, T, R, H, drop, pad_idx, word.shape[0], pos.shape[0], typ.shape[0], 0 if typ_vis is None else typ_vis.shape[0],
                     0 if pos_vis is None else pos_vis.shape[0])
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        ids, seg, f2, vt, y, mean, rstd, ln_w = ctx.saved_tensors
+        ids, seg, f2, vt, y, mean, rstd, ln_w, al = ctx.saved_tensors
         B, T, R, H, drop, pad_idx, V, NP, NT, NTV, NPV = ctx.meta
         S = T + R
         dev = y.device
@@ -365,7 +384,9 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
             nat.scatter_add_rows_f32(dvis, H, B * R, H, vt, dtv, H)
             dpv = torch.zeros(NPV, H, dtype=F32, device=dev)
             dpv[0].copy_(dpb)                                        # every visual row takes position row 0 (embeddings.py:411-418)
-        return None, None, None, None, dword, dpos, dtyp, dln_w, dln_b, dtv, dpv, dpw, dpb, None, None, None
+            if al is not None:                                       # the aligned words' TEXT position rows collect the regions' gradients / count
+                nat.align_pos_f32_bwd(dvis, H, B, R, R, al, dpos, al.shape[1], H)
+        return None, None, None, None, dword, dpos, dtyp, dln_w, dln_b, dtv, dpv, dpw, dpb, None, None, None, None
 
 
 class PairHalvesFn(torch.autograd.Function):
@@ -737,6 +758,250 @@ class MaskedLMHeadFn(torch.autograd.Function):
         return _dgrad(dz, w).view(xshape), _wgrad(dz, x2), _colsum(dz), None, None
 
 
+class MaskedMeanFn(torch.autograd.Function):
+    """(x * mask.unsqueeze(-1)).sum(1) / mask.sum(1, keepdim=True): the text pooling of ViLBERT's dynamic_attention (vilbert.py:204-205) on
+    fp32 rows.  x [B, T, H], mask [B, T] (0 / 1) -> [B, H]."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        B, T, H = x.shape
+        m = mask.detach().reshape(B, T).float().contiguous()
+        pool = _empty(B, H, like=x)
+        nat.masked_mean_f32(_rows(x), m, pool, B, T, H)
+        ctx.save_for_backward(m)
+        ctx.meta = (B, T, H)
+        return pool
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        B, T, H = ctx.meta
+        dx = _empty(B * T, H, like=m)
+        nat.masked_mean_f32_bwd(g.float().contiguous(), m, dx, B, T, H)
+        return dx.view(B, T, H), None
+
+
+class MaskedRegionHeadFn(torch.autograd.Function):
+    """The decoder + loss of ViLBERT's masked-region classification (vilbert.py:846-858 BertImagePredictionHead.decoder, :1150-1157
+    `visual_target: 0`) in fp32: KLDivLoss(log_softmax(h W^T + b), target) summed over the regions with image_label == 1, divided by their number.
+    Returns (loss, scores); only the loss carries gradient.  Backward: the fp32 [rows, classes] gradient, then the decoder's dgrad / weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target, row_label):
+        x2 = _rows(x)
+        M = x2.shape[0]
+        w = _w(weight)
+        N = w.shape[0]
+        logits = _gemm(x2, w, N, bias=_w(bias))
+        lab = row_label.reshape(M).long().contiguous()
+        tgt = target.reshape(M, N).float().contiguous()
+        lse = _empty(M, like=x2); tsum = _empty(M, like=x2); rowloss = _empty(M, like=x2); loss = _empty(1, like=x2); count = _empty(1, like=x2)
+        nat.soft_target_kl_fwd(logits, tgt, lab, lse, tsum, rowloss, loss, count, M, N)
+        ctx.save_for_backward(x2, w, logits, tgt, lab, lse, tsum, count)
+        ctx.meta = (x.shape,)
+        out = logits.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(out)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, g, _gscores):
+        x2, w, logits, tgt, lab, lse, tsum, count = ctx.saved_tensors
+        (xshape,) = ctx.meta
+        M, N = logits.shape
+        NP = (N + 3) // 4 * 4
+        dl = _empty(M, NP, like=x2)
+        nat.soft_target_kl_f32_bwd(logits, tgt, lab, lse, tsum, count, g.float().reshape(1).contiguous(), dl, NP, M, N)
+        dz = dl[:, :N]
+        return _dgrad(dz, w).view(xshape), _wgrad(dz, x2), _colsum(dz), None, None
+
+
+# ---- M4C's stages (mmf/models/m4c.py:185-304) in fp32, forward and backward ------------------------------------------------------------
+class L2NormRowsFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) (m4c.py:195) on fp32 rows; backward dx = (g - y <g, y>) / max(||x||, eps)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        D = x.shape[-1]
+        x2 = _rows(x)
+        y = torch.empty_like(x2)
+        nat.l2norm_rows_f32(x2, D, y, D, x2.shape[0], D)
+        ctx.save_for_backward(x2, y)
+        ctx.xshape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, y = ctx.saved_tensors
+        rows, D = y.shape
+        dx = torch.empty_like(y)
+        nat.l2norm_rows_f32_bwd(_grad2(g, D), D, y, D, x2, D, dx, D, rows, D)
+        return dx.view(ctx.xshape)
+
+
+class OcrFeatureConcatFn(torch.autograd.Function):
+    """cat([normalize(fasttext), normalize(phoc), normalize(fc7), zeros(order vectors)], -1) (m4c.py:211-237) as fp32 rows padded to a multiple
+    of 4 columns; only the appearance feature (`fc7`, an activation) carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, fasttext, phoc, fc7, order_dim):
+        B, N, _ = fasttext.shape
+        rows = B * N
+        d0, d1, d2 = fasttext.shape[-1], phoc.shape[-1], fc7.shape[-1]
+        K = d0 + d1 + d2 + int(order_dim)
+        KP = (K + 3) // 4 * 4
+        out = torch.zeros(rows, KP, dtype=F32, device=fc7.device)
+        f0, f1, f2 = (t.reshape(rows, d).float().contiguous() for t, d in ((fasttext, d0), (phoc, d1), (fc7.detach(), d2)))
+        nat.l2norm_rows_f32(f0, d0, out, KP, rows, d0)
+        nat.l2norm_rows_f32(f1, d1, out[:, d0:], KP, rows, d1)
+        nat.l2norm_rows_f32(f2, d2, out[:, d0 + d1:], KP, rows, d2)
+        ctx.save_for_backward(out, f2)
+        ctx.meta = (B, N, d0 + d1, d2, KP)
+        return out.view(B, N, KP)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, f2 = ctx.saved_tensors
+        B, N, off, d2, KP = ctx.meta
+        rows = B * N
+        g2 = _grad2(g, KP)
+        dx = _empty(rows, d2, like=out)
+        nat.l2norm_rows_f32_bwd(g2[:, off:], KP, out[:, off:], KP, f2, d2, dx, d2, rows, d2)
+        return None, None, dx.view(B, N, d2), None
+
+
+class PaddedLinearFn(torch.autograd.Function):
+    """nn.Linear on rows already zero-padded to KP = round_up(K, 4) columns (the 3002-wide OCR feature, m4c.py:243): the weight is padded the
+    same way for the GEMMs; its gradient is cut back to K columns."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, K = weight.shape
+        KP = x.shape[-1]
+        x2 = _rows(x)
+        w = _w(weight)
+        if KP != K:
+            w = P._pad_k(w, K, KP)
+        y = _gemm(x2, w, N, bias=_w(bias))
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (x.shape, N, K)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        xshape, N, K = ctx.meta
+        dz = _grad2(g, N)
+        dx = _dgrad(dz, w).view(xshape) if ctx.needs_input_grad[0] else None
+        return dx, _wgrad(dz, x2)[:, :K].contiguous(), _colsum(dz)
+
+
+class PrevPredGatherFn(torch.autograd.Function):
+    """_batch_gather(cat([ans_emb.expand(B), ocr_emb], 1), prev_inds) (m4c.py:526-528) as one two-source row gather; backward scatter-adds the
+    row gradients into the two sources (repeated indices collide: fp32 atomics)."""
+
+    @staticmethod
+    def forward(ctx, ans, ocr, prev_inds):
+        V, H = ans.shape
+        B, N, _ = ocr.shape
+        T = prev_inds.shape[1]
+        batch = torch.arange(B, device=prev_inds.device, dtype=torch.int64).unsqueeze(1) * N
+        flat = torch.where(prev_inds < V, prev_inds, prev_inds + batch).contiguous()     # OCR row (b, i) -> V + b N + i
+        out = _empty(B * T, H, like=ocr)
+        nat.gather_rows2_f32(_rows(ans), _rows(ocr), flat, out, B * T, H)
+        ctx.save_for_backward(flat)
+        ctx.meta = (V, B, N, T, H)
+        return out.view(B, T, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        V, B, N, T, H = ctx.meta
+        g2 = _grad2(g, H)
+        idx = flat.reshape(-1)
+        dans = torch.zeros(V, H, dtype=F32, device=g2.device)
+        docr = torch.zeros(B * N, H, dtype=F32, device=g2.device)
+        nat.scatter_add_rows_f32(g2, H, B * T, H, idx, dans, H)                 # rows with idx >= V fall outside this table: dropped by the kernel
+        nat.scatter_add_rows_f32(g2, H, B * T, H, idx - V, docr, H)             # rows with idx < V become negative: dropped
+        return dans, docr.view(B, N, H), None
+
+
+class SplitRowsFn(torch.autograd.Function):
+    """The slices `mmt_seq_output[:, a:b]` of MMT.forward (m4c.py:446-449) as strided copies of fp32 rows (moved as pairs of 16-bit words);
+    backward writes the block gradients back into one [B, S, H] buffer, blocks nobody used stay zero."""
+
+    @staticmethod
+    def forward(ctx, x, lens):
+        B, S, H = x.shape
+        lens = [int(l) for l in lens]
+        assert sum(lens) == S
+        xb = _rows(x).view(torch.bfloat16)
+        outs, off = [], 0
+        for L in lens:
+            d = _empty(B * L, H, like=x)
+            nat.copy_rows(xb[off:], S, d.view(torch.bfloat16), L, B, L, 2 * H)
+            outs.append(d.view(B, L, H))
+            off += L
+        ctx.meta = (B, S, H, lens)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, S, H, lens = ctx.meta
+        dev = next(g.device for g in gs if g is not None)
+        dx = torch.zeros(B * S, H, dtype=F32, device=dev)
+        dxb = dx.view(torch.bfloat16)
+        off = 0
+        for g, L in zip(gs, lens):
+            if g is not None:
+                nat.copy_rows(_grad2(g, H).view(torch.bfloat16), L, dxb[off:], S, B, L, 2 * H)
+            off += L
+        return dx.view(B, S, H), None
+
+
+class M4CScoresFn(torch.autograd.Function):
+    """M4C._forward_output (m4c.py:275-283) in fp32: `classifier(dec)` and the OCR pointer scores (:474-493) written by the two producers into
+    one [B, T, V + N] buffer.  Backward: the classifier's dgrad / weight gradient on the fixed-vocabulary columns (copied out as 16-byte rows), the
+    pointer scores' dq = ds k / sqrt(d), dk = ds^T q / sqrt(d), then the query / key projections' gradients."""
+
+    @staticmethod
+    def forward(ctx, dec, ocr, cls_w, cls_b, q_w, q_b, k_w, k_b, ocr_mask_add):
+        B, T, H = dec.shape
+        N = ocr.shape[1]
+        V, HQ = cls_w.shape[0], q_w.shape[0]
+        d2, o2 = _rows(dec), _rows(ocr)
+        cw, qw, kw = _w(cls_w), _w(q_w), _w(k_w)
+        out = _empty(B * T, V + N, like=d2)
+        nat.gemm_f32(d2, cw, out, B * T, V, H, H, H, V + N, bias=_w(cls_b))
+        q = _gemm(d2, qw, HQ, bias=_w(q_b))
+        k = _gemm(o2, kw, HQ, bias=_w(k_b))
+        scale = 1.0 / math.sqrt(HQ)
+        nat.ptr_scores_f32(q, k, ocr_mask_add.reshape(B, N).float().contiguous(), out[:, V:], V + N, B, T, N, HQ, scale)
+        ctx.save_for_backward(d2, o2, q, k, cw, qw, kw)
+        ctx.meta = (B, T, N, H, V, HQ, scale)
+        return out.view(B, T, V + N)
+
+    @staticmethod
+    def backward(ctx, g):
+        d2, o2, q, k, cw, qw, kw = ctx.saved_tensors
+        B, T, N, H, V, HQ, scale = ctx.meta
+        M = B * T
+        g2 = _grad2(g, V + N)
+        VP = (V + 3) // 4 * 4
+        dfix_p = _empty(M, VP, like=d2)
+        nat.slice_rows_f32(g2, V + N, V, dfix_p, VP, M)
+        dfix = dfix_p[:, :V]
+        ddec = _dgrad(dfix, cw)
+        dcw, dcb = _wgrad(dfix, d2), _colsum(dfix)
+        dq = _empty(M, HQ, like=d2); dk = _empty(B * N, HQ, like=d2)
+        nat.ptr_scores_f32_bwd(g2[:, V:], V + N, q, k, dq, dk, B, T, N, HQ, scale)
+        ddec = _dgrad(dq, qw, resid=ddec)
+        dqw, dqb = _wgrad(dq, d2), _colsum(dq)
+        docr = _dgrad(dk, kw)
+        dkw, dkb = _wgrad(dk, o2), _colsum(dk)
+        return ddec.view(B, T, H), docr.view(B, N, H), dcw, dcb, dqw, dqb, dkw, dkb, None
+
+
 class LogitBCEFn(torch.autograd.Function):
     """mean(BCEWithLogits(scores, targets)) * num_labels (losses.py:246-251) with an fp32 gradient."""
 
@@ -761,10 +1026,9 @@ class LogitBCEFn(torch.autograd.Function):
 # ---- the operator surface (called from mmf_amd/ops.py while `active()`) ---------------------------------------------------------------
 def visio_linguistic_embeddings(input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps, p,
                                 training, pad_idx, image_text_alignment=None):
-    if image_text_alignment is not None:
-        raise NotImplementedError("fp32 training: image_text_alignment position embeddings are not built")
     return VisioLinguisticEmbeddingsFn.apply(input_ids, token_type_ids, feats, vtype, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b,
-                                             eps, make_drop(p, training), pad_idx if pad_idx is not None and pad_idx >= 0 else None)
+                                             eps, make_drop(p, training), pad_idx if pad_idx is not None and pad_idx >= 0 else None,
+                                             image_text_alignment)
 
 
 def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2, p_attn, p_hid1,
@@ -860,6 +1124,43 @@ def small_k_linear(x, weight, bias):
 
 def masked_lm_head(x, weight, bias, labels, ignore_index):
     return MaskedLMHeadFn.apply(x, weight, bias, labels, ignore_index)
+
+
+def masked_region_head(x, weight, bias, target, row_label):
+    return MaskedRegionHeadFn.apply(x, weight, bias, target, row_label)
+
+
+def masked_mean(x, mask):
+    return MaskedMeanFn.apply(x, mask)
+
+
+def attention_block(x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask_add, heads, eps, p_attn, p_hid, training, qk_gate=None, causal_tail=0):
+    return AttentionBlockFn.apply(x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask_add, heads, eps, make_drop(p_attn, training),
+                                  make_drop(p_hid, training), causal_tail, qk_gate)
+
+
+def l2norm_rows(x):
+    return L2NormRowsFn.apply(x)
+
+
+def ocr_feature_concat(fasttext, phoc, fc7, order_dim):
+    return OcrFeatureConcatFn.apply(fasttext, phoc, fc7, order_dim)
+
+
+def padded_linear(x, weight, bias):
+    return PaddedLinearFn.apply(x, weight, bias)
+
+
+def prev_pred_gather(ans, ocr, prev_inds):
+    return PrevPredGatherFn.apply(ans, ocr, prev_inds)
+
+
+def split_rows(x, lens):
+    return SplitRowsFn.apply(x, lens)
+
+
+def m4c_scores(dec, ocr, cls_w, cls_b, q_w, q_b, k_w, k_b, ocr_mask_add):
+    return M4CScoresFn.apply(dec, ocr, cls_w, cls_b, q_w, q_b, k_w, k_b, ocr_mask_add)
 
 
 def unsupported(name):

@@ -29,6 +29,7 @@ from torch import nn
 
 from mmf_amd import functional as Fn
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd.common.registry import registry
 from mmf_amd.models.base_model import BaseModel
 from mmf_amd.modules.encoders import FinetuneFasterRcnnFpnFc7
@@ -100,6 +101,13 @@ class PrevPredEmbeddings(nn.Module):
         assert ans_emb.dim() == 2
         batch_size, seq_length = prev_inds.shape
         ans_num = ans_emb.size(0)
+        if F32T.active():      # mmf_amd.fp32_training(): the same operations on the fp32 kernels, with autograd (the classifier weight IS the lookup table: fp32 rows in, fp32 gradient out)
+            ans_emb = self.ans_layer_norm(ans_emb)
+            ocr_emb = self.ocr_layer_norm(ocr_emb)
+            raw_dec_emb = F32T.prev_pred_gather(ans_emb, ocr_emb, prev_inds)
+            zero = torch.zeros(batch_size, seq_length, ans_emb.size(-1), dtype=torch.float32, device=ocr_emb.device)
+            embeddings = F32T.add_pos_type(zero, prev_inds.ge(ans_num).long(), self.position_embeddings.weight, self.token_type_embeddings.weight)
+            return F32T.add(raw_dec_emb, self.emb_dropout(self.emb_layer_norm(embeddings)))
         if F32P.active():      # fp32-accurate forward (mmf_amd.fp32_inference()): the same operations on the fp32 kernels
             ans_emb = self.ans_layer_norm(ans_emb.detach())
             ocr_emb = self.ocr_layer_norm(ocr_emb)
@@ -137,7 +145,9 @@ class MMT(nn.Module):
     def forward(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, fixed_ans_emb, prev_inds):
         dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds)                     # :399
         dec_mask = torch.zeros(dec_emb.size(0), dec_emb.size(1), dtype=torch.float32, device=dec_emb.device)   # :405-407
-        if F32P.active():
+        if F32T.active():
+            encoder_inputs = F32T.concat_rows(txt_emb, obj_emb, ocr_emb, dec_emb)
+        elif F32P.active():
             encoder_inputs = F32P.concat_rows(txt_emb, obj_emb, ocr_emb, dec_emb)
         else:
             encoder_inputs = Fn.ConcatRowsFn.apply(txt_emb, obj_emb, ocr_emb, dec_emb)             # :408
@@ -147,7 +157,7 @@ class MMT(nn.Module):
         # prefix LM (:424-440): all positions see the encoding steps; decoding steps see each other causally
         mask = Fn.PrefixLMMask(_additive(attention_mask), dec_max_num)
         mmt_seq_output = self.encoder(encoder_inputs, mask)[0]
-        split = F32P.split_rows if F32P.active() else Fn.SplitRowsFn.apply
+        split = F32T.split_rows if F32T.active() else (F32P.split_rows if F32P.active() else Fn.SplitRowsFn.apply)
         mmt_txt_output, _, mmt_ocr_output, mmt_dec_output = split(
             mmt_seq_output, (txt_max_num, obj_max_num, ocr_max_num, dec_max_num))                  # :446-449
         return {"mmt_seq_output": mmt_seq_output, "mmt_txt_output": mmt_txt_output, "mmt_ocr_output": mmt_ocr_output,
@@ -308,12 +318,13 @@ class M4C(BaseModel):
 
     def _forward_obj_encoding(self, sample_list, fwd_results):
         obj_fc6 = sample_list["image_feature_0"]
-        f32 = F32P.active()      # fp32-accurate forward (mmf_amd.fp32_inference()): the same operations on the fp32 kernels
-        obj_fc7 = (F32P.l2norm_rows if f32 else Fn.L2NormRowsFn.apply)(self.obj_faster_rcnn_fc7(obj_fc6))   # :193-195
+        # fp32: mmf_amd.fp32_training() (F32T: with autograd) or the fp32-accurate forward mmf_amd.fp32_inference() (F32P): the same operations on the fp32 kernels
+        X = F32T if F32T.active() else (F32P if F32P.active() else None)
+        obj_fc7 = (X.l2norm_rows if X else Fn.L2NormRowsFn.apply)(self.obj_faster_rcnn_fc7(obj_fc6))   # :193-195
         feat = self.obj_feat_layer_norm(self.linear_obj_feat_to_mmt_in(obj_fc7))
-        bbox = self.obj_bbox_layer_norm((F32P.small_k_linear if f32 else Fn.SmallKLinearFn.apply)(
+        bbox = self.obj_bbox_layer_norm((X.small_k_linear if X else Fn.SmallKLinearFn.apply)(
             sample_list["obj_bbox_coordinates"], self.linear_obj_bbox_to_mmt_in.weight, self.linear_obj_bbox_to_mmt_in.bias))
-        fwd_results["obj_mmt_in"] = self.obj_drop((F32P.add if f32 else Fn.AddFn.apply)(feat, bbox))        # :199-203
+        fwd_results["obj_mmt_in"] = self.obj_drop((X.add if X else Fn.AddFn.apply)(feat, bbox))        # :199-203
         obj_nums = sample_list["image_info_0"]["max_features"]
         fwd_results["obj_mask"] = _get_mask(obj_nums, obj_fc6.size(1))
 
@@ -336,7 +347,12 @@ class M4C(BaseModel):
         ocr_bbox = sample_list["ocr_bbox_coordinates"]
         if self.remove_ocr_bbox:
             ocr_bbox = torch.zeros_like(ocr_bbox)
-        if F32P.active():
+        if F32T.active():
+            ocr_feat = F32T.ocr_feature_concat(ocr_fasttext, ocr_phoc, ocr_fc7, order_dim)
+            feat = self.ocr_feat_layer_norm(F32T.padded_linear(ocr_feat, self.linear_ocr_feat_to_mmt_in.weight, self.linear_ocr_feat_to_mmt_in.bias))
+            bbox = self.ocr_bbox_layer_norm(F32T.small_k_linear(ocr_bbox, self.linear_ocr_bbox_to_mmt_in.weight, self.linear_ocr_bbox_to_mmt_in.bias))
+            fwd_results["ocr_mmt_in"] = self.ocr_drop(F32T.add(feat, bbox))
+        elif F32P.active():
             ocr_feat, _ = F32P.ocr_feature_concat(ocr_fasttext, ocr_phoc, ocr_fc7, order_dim)
             feat = self.ocr_feat_layer_norm(F32P.padded_linear(ocr_feat, self.linear_ocr_feat_to_mmt_in.weight, self.linear_ocr_feat_to_mmt_in.bias))
             bbox = self.ocr_bbox_layer_norm(F32P.small_k_linear(ocr_bbox, self.linear_ocr_bbox_to_mmt_in.weight, self.linear_ocr_bbox_to_mmt_in.bias))
@@ -363,6 +379,10 @@ class M4C(BaseModel):
 
     def _forward_output(self, sample_list, fwd_results):
         cls, ptr = self.classifier.module, self.ocr_ptr_net
+        if F32T.active():
+            fwd_results["scores"] = F32T.m4c_scores(fwd_results["mmt_dec_output"], fwd_results["mmt_ocr_output"], cls.weight, cls.bias, ptr.query.weight,
+                                                    ptr.query.bias, ptr.key.weight, ptr.key.bias, _additive(fwd_results["ocr_mask"]))
+            return
         if F32P.active():
             fwd_results["scores"] = F32P.m4c_scores(fwd_results["mmt_dec_output"], fwd_results["mmt_ocr_output"], cls.weight, cls.bias, ptr.query.weight,
                                                     ptr.query.bias, ptr.key.weight, ptr.key.bias, _additive(fwd_results["ocr_mask"]))
@@ -377,7 +397,7 @@ class M4C(BaseModel):
             fwd_results["prev_inds"] = sample_list["train_prev_inds"].clone()
             self._forward_mmt(sample_list, fwd_results)
             self._forward_output(sample_list, fwd_results)
-        elif self.config.get("kv_cached_decode", True) and not F32P.active():
+        elif self.config.get("kv_cached_decode", True) and not F32P.active() and not F32T.active():
             self._decode_incremental(sample_list, fwd_results)
         else:
             # the reference's loop, kept for A/B tests: the whole multimodal transformer once per decoding step (:290-305)

@@ -188,9 +188,13 @@ class BertImageLayer(BertLayerJit):
         if not sa.dynamic_attention:
             return super().forward(hidden_states, attention_mask)
         B, S, _ = hidden_states.shape
-        if F32T.active():
-            F32T.unsupported("dynamic_attention gate")
         gate = sa.dynamic_gate(txt_embedding, txt_attention_mask)
+        if F32T.active():      # mmf_amd.fp32_training(): the gate, the gated attention block and the feed-forward block on the fp32 kernels, with backward
+            attention_output = F32T.attention_block(
+                hidden_states, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias, so.dense.weight,
+                so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, attention_mask.reshape(B, S).float(), sa.num_attention_heads,
+                so.LayerNorm.eps, sa.dropout_prob, so.dropout_prob, self.training, qk_gate=gate)
+            return (_feed_forward(self.intermediate, self.output, attention_output, self.training),)
         if F32P.active():
             F32P.check_no_dropout(max(sa.dropout_prob, so.dropout_prob), self.training)
             attention_output = F32P.attention_block(
@@ -533,10 +537,16 @@ class ViLBERTForPretraining(nn.Module):
             head = self.cls.imagePredictions
             hidden_v = head.transform(sequence_output_v)
             if self.visual_target == 2:          # NCE against sampled negatives, CrossEntropyLoss on class 0, :1158-1227
+                if F32T.active():
+                    raise NotImplementedError("mmf_amd.fp32_training(): visual_target 2 (NCE) has its backward on the bf16 path only; "
+                                              "visual_target 0 (the reference default) is built in fp32")
                 B, R = image_label.shape[0], image_label.shape[1]
                 neg = self.negative_index(B, R, input_ids)
                 img_loss, _ = Fn.MaskedRegionNCEFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
                                                          image_target, image_label, neg)
+            elif self.visual_target == 1 and F32T.active():
+                raise NotImplementedError("mmf_amd.fp32_training(): visual_target 1 (masked-region regression) has its backward on the bf16 path only; "
+                                          "visual_target 0 (the reference default) is built in fp32")
             elif self.visual_target == 1:        # nn.MSELoss(reduction="none") over the masked regions / max(their element count, 1), :1139-1148
                 img_loss, _ = Fn.MaskedRegionRegressionFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
                                                                 image_target, image_label)

@@ -21,6 +21,7 @@ from torch import nn
 
 from mmf_amd import functional as Fn
 from mmf_amd import fp32_path as F32P
+from mmf_amd import fp32_train as F32T
 from mmf_amd.common.registry import registry
 from mmf_amd.modules.hf_layers import BertConfig, BertModelJit, Linear
 from mmf_amd.utils.configuration import Config, to_container
@@ -312,4 +313,4 @@ class FinetuneFasterRcnnFpnFc7(Encoder):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, image):
-        return (F32P.relu if F32P.active() else Fn.ReluFn.apply)(self.lc(image))      # encoders.py:177-180
+        return (F32T.relu if F32T.active() else (F32P.relu if F32P.active() else Fn.ReluFn.apply))(self.lc(image))      # encoders.py:177-180

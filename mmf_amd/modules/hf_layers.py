@@ -145,7 +145,7 @@ class BertSelfAttentionJit(nn.Module):
             pool = F32P.masked_mean(txt_embedding, txt_attention_mask)
             return F32P.dynamic_gate(F32P.linear(pool, self.dyLinear_q.weight, self.dyLinear_q.bias),
                                      F32P.linear(pool, self.dyLinear_k.weight, self.dyLinear_k.bias))
-        pool = Fn.MaskedMeanFn.apply(txt_embedding, txt_attention_mask)
+        pool = (F32T.masked_mean if F32T.active() else Fn.MaskedMeanFn.apply)(txt_embedding, txt_attention_mask)   # (fp32 training: fp32 rows both ways)
         zq = torch.ops.mmf_amd.linear(pool, self.dyLinear_q.weight, self.dyLinear_q.bias, True)
         zk = torch.ops.mmf_amd.linear(pool, self.dyLinear_k.weight, self.dyLinear_k.bias, True)
         return Fn.DynamicGateFn.apply(zq, zk)

@@ -106,11 +106,9 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, vi
         return F32T.visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ, ln_w, ln_b,
                                                 typ_vis, pos_vis, proj_w, proj_b, eps, p, training, pad_idx, image_text_alignment)
     if F32P.active():
-        if image_text_alignment is not None:
-            raise NotImplementedError("fp32 path: image_text_alignment position embeddings are not built")
         F32P.check_no_dropout(p, training)
         return F32P.visio_linguistic_embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ,
-                                                ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps)
+                                                ln_w, ln_b, typ_vis, pos_vis, proj_w, proj_b, eps, image_text_alignment)
     w16 = Fn.shadows.get(proj_w) if visual_embeddings is not None else None
     return Fn.VisioLinguisticEmbeddingsFn.apply(
         input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, word, pos, typ, ln_w, ln_b, typ_vis, pos_vis, proj_w,
@@ -221,9 +219,9 @@ def masked_lm_head(x, weight, bias, labels, ignore_index):
 @_op("masked_region_head(Tensor x, Tensor weight, Tensor bias, Tensor target, Tensor row_label) -> (Tensor, Tensor)")
 def masked_region_head(x, weight, bias, target, row_label):
     if F32T.active():
-        F32T.unsupported("masked_region_head")
+        return F32T.masked_region_head(x, weight, bias, target, row_label)
     if F32P.active():
-        raise NotImplementedError("fp32 path: ViLBERT's masked-region head is not built")
+        return F32P.masked_region_head(x, weight, bias, target, row_label)
     return Fn.MaskedRegionHeadFn.apply(x, weight, bias, Fn.shadows.get(weight), target, row_label)
 
 

@@ -52,12 +52,52 @@ def test_nlvr2_step_builds_an_fp32_graph():
 
 
 def test_operators_without_an_fp32_backward_refuse():
-    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_dyn")          # `dynamic_attention`: the gate has no fp32 backward
-    model = MU.build_vilbert(cfg, sd, device="cpu")
+    z, case, cfg, sd, sample = G.load_vilbert_pretraining_case(1)           # `visual_target: 1` (regression): its backward is on the bf16 path only
+    model = MU.build_vilbert_pretraining(cfg, sd, device="cpu", visual_target=1)
     model.eval()
+    sample = {k: v for k, v in sample.items() if not k.startswith("_")}
     with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32_training"):
         with mmf_amd.fp32_training():
             model(SampleList(sample))
+
+
+def _fp32_step(model, sample, train=True):
+    model.train(train)
+    with native_stub.installed() as calls:
+        with mmf_amd.fp32_training():
+            out = model(SampleList(sample))
+        loss = sum(v.sum() for v in out["losses"].values())
+        loss.backward()
+        names = {c[0] for c in calls}
+    assert not (names & (BF16_KERNELS | {"masked_mean_fwd", "masked_mean_bwd", "rowgroup_scale", "rowgroup_scale_bwd", "align_pos_bwd", "soft_target_kl_bwd",
+                                         "l2norm_rows_fwd", "l2norm_rows_bwd", "gather_rows2", "ptr_scores_fwd", "ptr_scores_bwd", "rows_scatter_add",
+                                         "cast_bf16_to_f32", "cast2d_f32_to_bf16"})), names
+    assert all(p.grad is None or p.grad.dtype == torch.float32 for p in model.parameters())
+    return names
+
+
+def test_round5_operators_build_fp32_graphs():
+    """What round 5 added to mmf_amd.fp32_training(): ViLBERT's dynamic_attention gate and masked-region head,
+    VisualBERT's image_text_alignment, M4C's stages — every launch an fp32 kernel, every gradient fp32."""
+    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_dyn")
+    model = MU.build_vilbert(cfg, sd, device="cpu")
+    names = _fp32_step(model, sample)
+    assert {"masked_mean_f32", "masked_mean_f32_bwd", "rowgroup_scale_f32", "rowgroup_scale_f32_bwd", "gate_sigmoid_fwd", "gate_sigmoid_bwd"} <= names
+    assert all(p.grad is not None for n, p in model.named_parameters() if "dyLinear" in n)
+    z, case, cfg, sd, sample = G.load_vilbert_pretraining_case(0)
+    model = MU.build_vilbert_pretraining(cfg, sd, device="cpu", visual_target=0)
+    names = _fp32_step(model, {k: v for k, v in sample.items() if not k.startswith("_")})
+    assert {"soft_target_kl_fwd", "soft_target_kl_f32_bwd", "vocab_cross_entropy_f32_bwd"} <= names
+    assert model.model.cls.imagePredictions.decoder.weight.grad is not None
+    z, case, cfg, sd, sample = G.load_case("align64")
+    model = MU.build_visual_bert(cfg, sd, device="cpu")
+    names = _fp32_step(model, sample)
+    assert {"align_pos_fwd", "align_pos_f32_bwd"} <= names
+    z, case, cfg, sd, sample = G.load_m4c_case()
+    model = MU.build_m4c(cfg, sd, device="cpu")
+    names = _fp32_step(model, sample)
+    assert {"l2norm_rows_f32", "l2norm_rows_f32_bwd", "gather_rows2_f32", "ptr_scores_f32", "ptr_scores_f32_bwd", "slice_rows_f32"} <= names
+    assert all(p.grad is not None and p.grad.shape == p.shape for n, p in model.named_parameters())
 
 
 def test_visual_bert_pretraining_step_builds_an_fp32_graph():

@@ -65,7 +65,8 @@ def parse():
 
 # BASELINE.json.configs index of every --config choice (configs[1] is the headline)
 OTHER_CONFIGS = {"mmbt": 0, "vilbert": 2, "uniter": 3, "mmft": 3, "m4c": 4}
-GRAPH_CONFIGS = {"vilbert", "mmbt", "m4c"}      # --config choices whose training step is captured as one hipGraph (verified capturable)
+GRAPH_CONFIGS = {"vilbert", "mmbt", "m4c", "uniter", "mmft"}      # --config choices whose training step is captured as one hipGraph (verified capturable;
+                                                                  # round 5: UNITER / MMF Transformer classification steps are free of host read-backs)
 
 
 def config_bench(args):
@@ -113,11 +114,16 @@ def measure_config(name, steps, warmup, no_graph=False):
         # branches of the graph); the other models branch on tensor values in their input massaging, as the reference does, and stay eager
         from mmf_amd.utils.graph import GraphedTrainStep
         model.zero_grad(set_to_none=True)
-        del opt
         gopt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8, capturable=True)
-        graphed = GraphedTrainStep(model, batch, warmup=2, optimizer=gopt)
-        step = lambda: graphed()      # noqa: E731
-        launch = "hipGraph"
+        try:
+            graphed = GraphedTrainStep(model, batch, warmup=2, optimizer=gopt)
+            del opt
+            step = lambda: graphed()      # noqa: E731
+            launch = "hipGraph"
+        except Exception as e:       # a host read-back inside the step: the same kernels launched one by one (never lose the line over it)
+            sys.stderr.write("bench: %s is not capturable as one hipGraph (%s: %s); eager launches\n" % (name, type(e).__name__, e))
+            torch.cuda.synchronize()
+            launch = "eager (hipGraph capture failed: %s)" % type(e).__name__
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()

@@ -138,7 +138,11 @@ class UNITERModelBase(nn.Module):
     def _compute_txt_embeddings(self, input_ids, position_ids, token_type_ids=None):
         if position_ids is not None:
             T = input_ids.shape[1]
-            if position_ids.shape[-1] != T or not bool((position_ids.reshape(-1, T)[0] == torch.arange(T, device=position_ids.device)).all()):
+            # (the value check reads the ids back to the host: not possible while a hipGraph is being captured — GraphedTrainStep's eager warm-up
+            # passes have run it on the same static batch, and UNITER.add_custom_params builds the ids from the shape alone, uniter.py:738-743)
+            capturing = position_ids.is_cuda and torch.cuda.is_current_stream_capturing()
+            if position_ids.shape[-1] != T or (not capturing and not bool(
+                    (position_ids.reshape(-1, T)[0] == torch.arange(T, device=position_ids.device)).all())):
                 raise NotImplementedError("only consecutive position ids 0..T-1 (uniter.py:738-743) are on the fused embedding path")
         return self.text_embeddings(input_ids, token_type_ids)
 
@@ -438,10 +442,14 @@ class UNITER(BaseModel):
         info = sample_list["image_info_0"]
         bboxs = torch.as_tensor(info["bbox"], device=feats.device)[:, :, :4].float()
         norm_xy = bboxs.clone()
-        if bool(norm_xy[0, 0, 0] < 1):
+        # the reference branches on `norm_xy[0, 0, 0] < 1` (uniter.py:697: "boxes still need normalising"), a host read of one device element;
+        # the same selection as a device-side `where` keeps the step free of read-backs (capturable as one hipGraph: bench.py GRAPH_CONFIGS)
+        if "image_height" in info and "image_width" in info:
             img_h = torch.as_tensor(info["image_height"], device=feats.device).unsqueeze(1).unsqueeze(1)
             img_w = torch.as_tensor(info["image_width"], device=feats.device).unsqueeze(1).unsqueeze(1)
-            norm_xy = norm_xy / torch.cat([img_w, img_h, img_w, img_h], dim=-1)
+            norm_xy = torch.where(norm_xy[0, 0, 0] < 1, norm_xy / torch.cat([img_w, img_h, img_w, img_h], dim=-1), norm_xy)
+        elif bool(norm_xy[0, 0, 0] < 1):     # (no image sizes to divide by: the reference fails with a KeyError here — keep its behaviour)
+            raise KeyError("image_height")
         bbox_w = (norm_xy[:, :, 2] - norm_xy[:, :, 0]).unsqueeze(-1)
         bbox_h = (norm_xy[:, :, 3] - norm_xy[:, :, 1]).unsqueeze(-1)
         sample_list["img_pos_feat"] = torch.cat([norm_xy, bbox_w, bbox_h, bbox_w * bbox_h], dim=-1).to(feats)

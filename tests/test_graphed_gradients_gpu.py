@@ -96,3 +96,30 @@ def test_vilbert_graphed_gradients_equal_eager(monkeypatch):
     gg = _graphed_grads(model, batch, monkeypatch)
     assert pushed, "the connection layers' weight gradients are expected to join grouped launches"
     _compare(ge, gg, ["c_layer", "v_layer"])
+
+
+@pytest.mark.parametrize("name", ["uniter", "mmft"])
+def test_uniter_and_mmft_classification_steps_capture_as_one_graph(name, monkeypatch):
+    """Round 5: the classification steps of UNITER and the MMF Transformer contain no host read-back (UNITER's
+    "boxes still need normalising" test, uniter.py:697, is a device-side select; its position-id check runs in the eager warm-up), so the
+    whole step replays as ONE hipGraph: same loss, same gradients as the eager step."""
+    from mmf_amd.common.sample import SampleList
+    from mmf_amd.utils.graph import total_loss
+    from tests import golden_utils as G
+    from tests import model_utils as MU
+    if name == "uniter":
+        z, case, cfg, sd, sample = G.load_uniter_case()
+        model = MU.build_uniter(cfg, sd)
+    else:
+        from oracle import mmft_oracle
+        z, case, cfg, sd, sample = G.load_mmft_case()
+        model = MU.build_mmft(cfg, sd, mmft_oracle.shared(cfg))
+    model.eval()
+    batch = SampleList(MU.sample_to(sample, "cuda"))
+    loss_e = float(total_loss(model(batch)))
+    ge = _eager_grads(model, batch)
+    gg = _graphed_grads(model, batch, monkeypatch)
+    _compare(ge, gg, ["word_embeddings.weight"])
+    from mmf_amd.utils.graph import GraphedTrainStep
+    step = GraphedTrainStep(model, batch, warmup=1)
+    assert float(step()) == pytest.approx(loss_e, rel=1e-6)

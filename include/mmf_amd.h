@@ -528,6 +528,13 @@ typedef struct mmf_tensor_list {
 } mmf_tensor_list;
 int mmf_l2norm_sq_ws_floats(const mmf_tensor_list* d);
 int mmf_l2norm_sq_multi(const mmf_tensor_list* d, float* out, int accumulate, float* ws, void* stream);
+/* The gradient bucket of the data-parallel reducer (DistributedDataParallel's bucket copy, mmf/trainers/core/device.py:104-110) packed in ONE
+ * launch: dst[off[t] + i] = scale * src_t[i] for up to MMF_MT_MAX fp32 tensors, dst fp32 or (dst_bf16) the bf16 wire type; scale = the mean's
+ * 1 / world applied before the rounding. */
+typedef struct mmf_offset_list {
+    int64_t off[MMF_MT_MAX];                /* element offset of tensor t inside dst */
+} mmf_offset_list;
+int mmf_pack_f32_multi(const mmf_tensor_list* d, const mmf_offset_list* off, void* dst, int dst_bf16, float scale, void* stream);
 
 /* ---- transposed weight shadows -------------------------------------------------------------------------------------
  * dst[i] (bf16 [cols, rows]) = transpose of src[i] (bf16 [rows, cols], row-major), for up to MMF_MT_MAX matrices per

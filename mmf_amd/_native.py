@@ -1068,6 +1068,27 @@ def l2norm_sq_multi(tensors, out):
         _check(lib().mmf_l2norm_sq_multi(C.byref(d), _p(out), int(i0 > 0), _p(ws), _stream()), "mmf_l2norm_sq_multi")
 
 
+class OffsetList(C.Structure):
+    _fields_ = [("off", C.c_int64 * MT_MAX)]
+
+
+def pack_f32_multi(tensors, offsets, dst, scale=1.0):
+    """dst[offsets[t] : offsets[t] + tensors[t].numel()] = scale * tensors[t] (fp32 sources; dst fp32 or bf16), MT_MAX tensors per launch."""
+    if dst.dtype not in (torch.float32, torch.bfloat16):
+        raise NativeLibraryError("pack_f32_multi: dst must be fp32 or bf16")
+    for i0 in range(0, len(tensors), MT_MAX):
+        chunk = tensors[i0:i0 + MT_MAX]
+        d, o = TensorList(), OffsetList()
+        d.n = len(chunk)
+        for i, t in enumerate(chunk):
+            _req(t, torch.float32, "tensor")
+            if not t.is_contiguous():
+                raise NativeLibraryError("pack_f32_multi: contiguous gradients expected")
+            d.ptr[i], d.numel[i], o.off[i] = t.data_ptr(), t.numel(), int(offsets[i0 + i])
+        _check(lib().mmf_pack_f32_multi(C.byref(d), C.byref(o), _p(dst), int(dst.dtype == torch.bfloat16), C.c_float(scale), _stream()),
+               "mmf_pack_f32_multi")
+
+
 def transpose_multi(pairs):
     """dst = src^T for every (src bf16 [R, C], dst bf16 [C, R]) pair; R, C multiples of 64; MT_MAX matrices per launch."""
     for i0 in range(0, len(pairs), MT_MAX):

@@ -1227,6 +1227,23 @@ __global__ __launch_bounds__(256) void l2norm_multi_kernel(mmf_tensor_list d, fl
     __syncthreads();
     if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// dst[off_t + i] = scale * src_t[i] for up to MMF_MT_MAX fp32 tensors in one launch ((chunk, tensor) grid like the kernels above): the
+// gradient bucket of the data-parallel reducer packed and pre-scaled in ONE pass — dst bf16 (the wire type) or fp32
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(mmf_tensor_list d, mmf_offset_list o, T* __restrict__ dst, float scale) {
+    const int t = blockIdx.y;
+    const int64_t n = d.numel[t];
+    const int64_t base = (int64_t)blockIdx.x * MT_CHUNK;
+    if (base >= n) return;
+    const float* __restrict__ g = reinterpret_cast<const float*>(d.ptr[t]);
+    T* __restrict__ out = dst + o.off[t];
+    const int64_t end = (base + MT_CHUNK < n) ? base + MT_CHUNK : n;
+    const bool vec = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & (4 * sizeof(T) - 1)) == 0);
+    for (int64_t i = base + threadIdx.x * 4; i < end; i += 1024) {
+        if (vec && i + 4 <= end) { f32x4 x = load4(g + i); x *= scale; store4(out + i, x); }
+        else for (int64_t j = i; j < end && j < i + 4; ++j) out[j] = (T)(g[j] * scale);
+    }
+}
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int n, float* __restrict__ out, int accumulate) {
     __shared__ float red[4];
     float s = 0.f;
@@ -1795,6 +1812,20 @@ int mmf_l2norm_sq_multi(const mmf_tensor_list* d, float* out, int accumulate, fl
     hipLaunchKernelGGL(l2norm_multi_kernel, dim3(gx, d->n), dim3(256), 0, (hipStream_t)stream, *d, ws);
     MMF_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, (int)(gx * d->n), out, accumulate);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_pack_f32_multi(const mmf_tensor_list* d, const mmf_offset_list* off, void* dst, int dst_bf16, float scale, void* stream) {
+    MMF_CHECK_ARG(d && off && dst && d->n > 0 && d->n <= MMF_MT_MAX, "pack_f32_multi: bad descriptor");
+    int64_t mx = 0;
+    for (int i = 0; i < d->n; ++i) {
+        MMF_CHECK_ARG(d->ptr[i] && d->numel[i] > 0 && off->off[i] >= 0, "pack_f32_multi: null tensor / negative offset");
+        mx = d->numel[i] > mx ? d->numel[i] : mx;
+    }
+    const unsigned gx = (unsigned)((mx + MT_CHUNK - 1) / MT_CHUNK);
+    if (dst_bf16) hipLaunchKernelGGL(pack_multi_kernel<bf16>, dim3(gx, d->n), dim3(256), 0, (hipStream_t)stream, *d, *off, (bf16*)dst, scale);
+    else hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(gx, d->n), dim3(256), 0, (hipStream_t)stream, *d, *off, (float*)dst, scale);
     MMF_CHECK_LAUNCH();
     return 0;
 }

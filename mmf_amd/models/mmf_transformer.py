@@ -159,7 +159,9 @@ class MMFTransformer(BaseTransformer):
     def _infer_itm_labels(self, sample_list, input_ids):
         if "is_correct" in sample_list:
             return {"is_correct": sample_list["is_correct"]}
-        return {"is_correct": torch.tensor(True, dtype=torch.long, device=input_ids[self.modality_keys[0]].device)}
+        # `torch.tensor(True, dtype=torch.long)` of the reference (:364-373) as a fill kernel: a host scalar copied to the device is a synchronous
+        # memcpy, which a hipGraph capture of the step refuses
+        return {"is_correct": torch.ones((), dtype=torch.long, device=input_ids[self.modality_keys[0]].device)}
 
     def _infer_mlm_labels(self, sample_list, input_ids):
         mlm_labels, current_text_idx = {}, 0

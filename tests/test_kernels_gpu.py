@@ -1134,6 +1134,26 @@ def test_gemm_skinny_row_remap_and_decode_opt_out():
     assert "GEMM_NO_SKINNY" in inspect.getsource(infer.layer_rows)
 
 
+def test_pack_f32_multi_packs_scales_and_converts_in_one_launch():
+    """The data-parallel reducer's bucket packing (mmf_amd/trainers/core/device.py): many fp32 gradients -> one flat fp32 / bf16 buffer at given
+    offsets, scaled by 1 / world before the rounding; ragged sizes, more tensors than one launch holds, untouched gaps."""
+    g = torch.Generator().manual_seed(5)
+    sizes = [768, 768 * 768, 5, 3129, 64, 1, 30522 * 4 + 3] + [96] * 60
+    ts = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    for dtype in (torch.float32, torch.bfloat16):
+        flat = torch.full((total,), 7.0, dtype=dtype, device=DEV)
+        nat().pack_f32_multi(ts, offs, flat, 0.5)
+        seen = torch.zeros(total, dtype=torch.bool, device=DEV)
+        for t, o in zip(ts, offs):
+            assert torch.equal(flat[o:o + t.numel()], (t * 0.5).to(dtype))
+            seen[o:o + t.numel()] = True
+        assert bool((flat[~seen] == 7.0).all())
+
+
 def test_gemm_skinny_repeated_launches_are_stable():
     M, H, L = 32, 768, 3129
     dsc = torch.zeros(M, 3136, dtype=torch.bfloat16, device=DEV); dsc[:, :L] = rnd(M, L, seed=6)

@@ -118,6 +118,31 @@ DEVI void store_tile_rows(const f32x16 (&acc)[2], float mul, unsigned char* img,
     }
 }
 
+// head_dim 128: the tile is T^T[d][row] in four accumulators (d = 32 dt + ...), rows of 256 bytes through a wave-private 8 KB image
+DEVI void store_tile_rows128(const f32x16 (&acc)[4], float mul, unsigned char* img, bf16* g, int ld, int nvalid, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<bf16x4*>(img + rm_off<128>(x, 4 * dt + c) + 8 * h) =
+                pack4(acc[dt][4 * c + 0] * mul, acc[dt][4 * c + 1] * mul, acc[dt][4 * c + 2] * mul, acc[dt][4 * c + 3] * mul);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + (lane >> 4), chunk = lane & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(img + rm_off<128>(row, chunk));
+        if (row < nvalid) *reinterpret_cast<uint4*>(g + (size_t)row * ld + 8 * chunk) = v;
+    }
+}
+template <int D> DEVI void store_tile_rows_d(const f32x16 (&acc)[D / 32], float mul, unsigned char* img, bf16* g, int ld, int nvalid, int lane);
+template <> DEVI void store_tile_rows_d<64>(const f32x16 (&acc)[2], float mul, unsigned char* img, bf16* g, int ld, int nvalid, int lane) {
+    store_tile_rows(acc, mul, img, g, ld, nvalid, lane);
+}
+template <> DEVI void store_tile_rows_d<128>(const f32x16 (&acc)[4], float mul, unsigned char* img, bf16* g, int ld, int nvalid, int lane) {
+    store_tile_rows128(acc, mul, img, g, ld, nvalid, lane);
+}
+
 // The same for an fp32 copy of the rows (256-byte rows; 16-byte chunks XOR-swizzled by row & 15), 8 KB image.  The copy is read again only by the
 // backward pass, a few milliseconds later: it is stored non-temporally (it would only push the next kernels' operands out of the Infinity Cache;
 // -0.01 .. -0.08 ms per step on three boxes, profiles/r04_store_policy.txt section 9).
@@ -761,16 +786,20 @@ DEVI bf16x8 frag_tr_patch(const unsigned char* patch, int u, int lane) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int MM>
-__global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
+// Round 5: templated on the head width and the number of waves (= key tiles = query tiles): <64, 8> is the kernel above for up to 256 positions;
+// <128, 4> serves ViLBERT's visual stream and co-attention (head_dim 128, up to 128 queries / keys: 101 regions, 128 tokens) — the same 96 KB of
+// operand images, four waves with the whole register file each (dK, dV, dQ accumulators of a wave: 192 registers), B x 8 heads = 256 workgroups =
+// one per CU — instead of the two-kernel backward that pays the exp / dropout-hash work twice (30 + 40 us per launch at the VQA2 shape).
+template <int D, int NW, int MM>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_kernel(AttnArgs a) {
     constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
-    constexpr int D = 64, NS = 4, NDT = 2, ROWB = 128, SP = 256;
+    constexpr int NS = D / 16, NDT = D / 32, ROWB = 2 * D, SP = NW * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_q = smem;                                   // row-major Q   [256][64]
     unsigned char* lds_do = lds_q + SP * ROWB;                     // row-major dO  [256][64]
     unsigned char* lds_k = lds_do + SP * ROWB;                     // row-major K   [256][64]
-    unsigned char* patches = lds_k + SP * ROWB;                    // [2][8] dS patches
-    float* lds_lse = reinterpret_cast<float*>(patches + 16 * 2048);
+    unsigned char* patches = lds_k + SP * ROWB;                    // [2][NW] dS patches
+    float* lds_lse = reinterpret_cast<float*>(patches + 2 * NW * 2048);
     float* lds_delta = lds_lse + SP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -784,9 +813,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
     const bf16* qbase = a.q + (size_t)b * a.Sq * a.ldq + head * D;
     const bf16* dobase = a.dctx + (size_t)b * a.Sq * a.ldo + head * D;
     const bf16* kbase = a.k + (size_t)b * a.Sk * a.ldk + head * D;
-    stage_rows<D, 8>(kbase, a.ldk, a.Sk, (a.Sk + 31) & ~31, lds_k, tid);
-    stage_rows<D, 8>(qbase, a.ldq, a.Sq, nqt * 32, lds_q, tid);
-    stage_rows<D, 8>(dobase, a.ldo, a.Sq, nqt * 32, lds_do, tid);
+    stage_rows<D, NW>(kbase, a.ldk, a.Sk, (a.Sk + 31) & ~31, lds_k, tid);
+    stage_rows<D, NW>(qbase, a.ldq, a.Sq, nqt * 32, lds_q, tid);
+    stage_rows<D, NW>(dobase, a.ldo, a.Sq, nqt * 32, lds_do, tid);
     // V fragments of this wave's keys straight from global memory (B operand of dP = dO V^T)
     const int krow = min(k0 + x, a.Sk - 1);
     const bool kvalid = (k0 + x) < a.Sk;
@@ -794,7 +823,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
     bf16x8 vf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) vf[s] = frag_global(vptr, s, lane);
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses VALU arbitration otherwise (MI355X_MICROARCH.md)
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses VALU arbitration otherwise (MI355X_MICROARCH.md)
     const float mk = kvalid ? ((a.mask && !MQ) ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
     const float* mcol = MQ ? a.mask + (size_t)b * a.m_bs + krow : nullptr;      // per-query mask: this lane's key column, one entry per query row
     // delta[q] = sum_d dO[q][d] O[q][d] (two threads per query row, a contiguous half of the head slice each; from the fp32
@@ -802,12 +831,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
     {
         const int r = tid >> 1, hh = tid & 1;
         const int qr = min(r, a.Sq - 1);
-        const bf16* drow = a.dctx + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * 32;
+        const bf16* drow = a.dctx + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * (D / 2);
         float part = 0.f;
         if (a.ctx32) {
-            const float* orow = a.ctx32 + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * 32;
+            const float* orow = a.ctx32 + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * (D / 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < D / 16; ++i) {
                 const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + 8 * i);
                 const float4 o0 = *reinterpret_cast<const float4*>(orow + 8 * i);
                 const float4 o1 = *reinterpret_cast<const float4*>(orow + 8 * i + 4);
@@ -815,9 +844,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
                         o1.x * (float)dv[4] + o1.y * (float)dv[5] + o1.z * (float)dv[6] + o1.w * (float)dv[7];
             }
         } else {
-            const bf16* orow = a.ctx + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * 32;
+            const bf16* orow = a.ctx + ((size_t)b * a.Sq + qr) * a.ldo + head * D + hh * (D / 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < D / 16; ++i) {
                 const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + 8 * i);
                 const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + 8 * i);
 #pragma unroll
@@ -845,10 +874,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
     const uint32_t dkey = drop_key(a.drop);
     f32x16 dko[NDT] = {}, dvo[NDT] = {}, dqo[NDT] = {};
 #pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-        const int t = (wave + it) & 7;          // query tile this wave produces dS for in this step
+    for (int it = 0; it < NW; ++it) {
+        const int t = (wave + it) & (NW - 1);          // query tile this wave produces dS for in this step
         if (produce && t < nqt) {
-            unsigned char* patch = patches + ((it & 1) * 8 + wave) * 2048;
+            unsigned char* patch = patches + ((it & 1) * NW + wave) * 2048;
             // S[q][key], dPd[q][key]: rows q = 32t + (r&3) + 8(r>>2) + 4h, column key = k0 + x
             f32x16 s_acc = {}, dp_acc = {};
 #pragma unroll
@@ -913,9 +942,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
         }
         __syncthreads();
         // consumer: query tile `wave`, the patch of key tile kt (produced in this step by wave kt)
-        const int kt = (wave - it) & 7;
+        const int kt = (wave - it) & (NW - 1);
         if (consume && kt * 32 < a.Sk) {
-            const unsigned char* src = patches + ((it & 1) * 8 + kt) * 2048;
+            const unsigned char* src = patches + ((it & 1) * NW + kt) * 2048;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const bf16x8 dst = frag_tr_patch(src, u, lane);
@@ -930,14 +959,15 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(AttnArgs a) {
     // image each (the operand images are dead after the barrier) so that global memory sees whole 128-byte rows, 16 bytes per
     // lane, instead of 8-byte pieces at a 4.6 KB stride.
     __syncthreads();
-    unsigned char* mine = smem + wave * (3 * 4096);
+    constexpr int IMG = 32 * ROWB;              // one 32-row result tile as whole rows: 4 KB (head_dim 64) / 8 KB (128)
+    unsigned char* mine = smem + wave * (3 * IMG);
     if (produce) {
-        store_tile_rows(dko, a.scale, mine, a.dk + ((size_t)b * a.Sk + k0) * a.ldk + head * D, a.ldk, a.Sk - k0, lane);
-        store_tile_rows(dvo, 1.f, mine + 4096, a.dv + ((size_t)b * a.Sk + k0) * a.ldv + head * D, a.ldv, a.Sk - k0, lane);
+        store_tile_rows_d<D>(dko, a.scale, mine, a.dk + ((size_t)b * a.Sk + k0) * a.ldk + head * D, a.ldk, a.Sk - k0, lane);
+        store_tile_rows_d<D>(dvo, 1.f, mine + IMG, a.dv + ((size_t)b * a.Sk + k0) * a.ldv + head * D, a.ldv, a.Sk - k0, lane);
     }
     PROBE_AT(5);
     if (consume)
-        store_tile_rows(dqo, a.scale, mine + 8192, a.dq + ((size_t)b * a.Sq + k0) * a.ldq + head * D, a.ldq, a.Sq - k0, lane);
+        store_tile_rows_d<D>(dqo, a.scale, mine + 2 * IMG, a.dq + ((size_t)b * a.Sq + k0) * a.ldq + head * D, a.ldq, a.Sq - k0, lane);
     PROBE_AT(6);
     PROBE_FLUSH(3, bh, wave);
 }
@@ -1065,15 +1095,23 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     if (a.hd == 64 && nkt <= 8 && nqt <= 8 && (a.m_qs || !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS))) {
         const int lds = 3 * 256 * 128 + 16 * 2048 + 2 * 256 * 4;
         if (a.m_qs) {      // per-query mask: the one-pass kernel only
-            if (int rc = set_lds(attn_bwd_fused_kernel<MASK_QUERY>, lds)) return rc;
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<MASK_QUERY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+            if (int rc = set_lds(attn_bwd_fused_kernel<64, 8, MASK_QUERY>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 8, MASK_QUERY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
         } else if (cz) {
-            if (int rc = set_lds(attn_bwd_fused_kernel<MASK_TAIL>, lds)) return rc;
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<MASK_TAIL>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+            if (int rc = set_lds(attn_bwd_fused_kernel<64, 8, MASK_TAIL>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 8, MASK_TAIL>), dim3(a.B * a.heads), dim3(512), lds, s, a);
         } else {
-            if (int rc = set_lds(attn_bwd_fused_kernel<MASK_KEY>, lds)) return rc;
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<MASK_KEY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
+            if (int rc = set_lds(attn_bwd_fused_kernel<64, 8, MASK_KEY>, lds)) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<64, 8, MASK_KEY>), dim3(a.B * a.heads), dim3(512), lds, s, a);
         }
+        MMF_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a.hd == 128 && nkt <= 4 && nqt <= 4 && !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS)) {
+        // head_dim 128 (ViLBERT's visual stream and co-attention), up to 128 queries / keys: the one-pass kernel with four waves per (batch, head)
+        const int lds = 3 * 128 * 256 + 8 * 2048 + 2 * 128 * 4;
+        if (int rc = set_lds(attn_bwd_fused_kernel<128, 4, MASK_KEY>, lds)) return rc;
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<128, 4, MASK_KEY>), dim3(a.B * a.heads), dim3(256), lds, s, a);
         MMF_CHECK_LAUNCH();
         return 0;
     }

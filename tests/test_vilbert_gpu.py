@@ -57,6 +57,42 @@ def test_cross_attention_forward_backward(B, heads, Sq, Sk, d):
     assert float(dqb[:, H:].abs().max()) == 0 and float(dkvb[:, :H].abs().max()) == 0   # nothing written outside the views
 
 
+@pytest.mark.parametrize("B,heads,Sq,Sk,p", [(2, 8, 101, 101, 0.1), (2, 8, 128, 101, 0.1), (2, 8, 101, 128, 0.0), (1, 2, 7, 12, 0.1), (3, 2, 128, 128, 0.1), (32, 8, 101, 101, 0.1)])
+def test_attention_d128_one_pass_backward_agrees_with_the_two_kernel_backward(B, heads, Sq, Sk, p):
+    """Round 5: head_dim 128 with up to 128 queries / keys (the visual stream: 101 regions; co-attention: 128 tokens x 101 regions) runs the ONE-PASS
+    backward too — four waves per (batch, head), every probability recomputed, dropped out and turned into dS once — against the separate dQ and
+    dK/dV kernels it replaces (MMF_TUN_ATTN_BWD_TWO_PASS): same dropout decisions, same masks, gradients equal up to bf16 rounding of differently
+    ordered sums, no systematic difference; with and without the fp32 copy of O."""
+    d = 128
+    H = heads * d
+    q = rnd(B * Sq, H, seed=41); kv = rnd(B * Sk, 2 * H, seed=42)
+    mbin = (torch.rand(B, Sk, device=DEV) > 0.2).long(); mbin[:, 0] = 1
+    mask = torch.empty(B, Sk, device=DEV); nat().make_additive_mask(mbin, mask)
+    drop = nat().drop_cfg(p, 5151) if p > 0 else nat().NO_DROP
+    ctx = torch.empty(B * Sq, H, dtype=torch.bfloat16, device=DEV); o32 = torch.empty(B * Sq, H, device=DEV)
+    lse = torch.empty(B, heads, Sq, device=DEV)
+    k, v = kv[:, :H], kv[:, H:]
+    scale = 1.0 / math.sqrt(d)
+    nat().attention_fwd(q, k, v, H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, scale, drop, head_dim=d, ctx_f32=o32)
+    dctx = rnd(B * Sq, H, seed=43)
+    outs = {}
+    try:
+        for two_pass in (1, 0):
+            nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, two_pass)
+            for exact in (True, False):
+                dq = torch.full_like(q, 7.0); dkv = torch.full_like(kv, 7.0); delta = torch.empty(B, heads, Sq, device=DEV)
+                nat().attention_bwd(q, k, v, H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, scale, dctx, dq, dkv[:, :H], dkv[:, H:],
+                                    delta, drop, head_dim=d, ctx_f32=o32 if exact else None)
+                outs[(two_pass, exact)] = (dq.float(), dkv.float())
+    finally:
+        nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, 0)
+    for exact in (True, False):
+        for name, a_, b_ in (("dq", outs[(0, exact)][0], outs[(1, exact)][0]), ("dk|dv", outs[(0, exact)][1], outs[(1, exact)][1])):
+            assert torch.isfinite(a_).all()
+            close(a_, b_, 2e-2, 1e-2 * float(b_.abs().max()), "%s one-pass vs two-kernel (exact delta %s)" % (name, exact))
+            assert abs(float((a_ - b_).mean())) <= 1e-3 * float(b_.abs().mean()) + 1e-6, name
+
+
 def test_attention_d128_dropout_consistent_between_forward_and_backward():
     B, heads, S, d = 2, 2, 128, 128
     H = heads * d

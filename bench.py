@@ -295,6 +295,14 @@ def allreduce_ms(nbytes, world, links=None):
     return COLL_LATENCY_US * 1e-3 + 2.0 * (world - 1) / world * nbytes / bw * 1e3
 
 
+def allgather_ms(nbytes_per_rank, world, links=None):
+    """All-gather of `nbytes_per_rank` from every rank: each rank receives (N - 1) blocks — one per link on the fully connected mesh, or all of them
+    through ONE link on a single ring."""
+    links = (world - 1) if links is None else links
+    bw = links * XGMI_LINK_GBPS * XGMI_EFF * 1e9
+    return COLL_LATENCY_US * 1e-3 + (world - 1) * nbytes_per_rank / bw * 1e3
+
+
 def scale_model(chain, step_ms_1gpu, batch, model):
     """Replays the N > 1 launch structure at N = 1 stage by stage (HIP events), then walks the step's timeline with modelled collectives:
     main stream F | B_0 | B_1 | O_0 | B_2 | O_1 ... ; communicator stream AR_j starts when B_j and AR_(j-1) are done; O_j waits for AR_j."""
@@ -315,12 +323,15 @@ def scale_model(chain, step_ms_1gpu, batch, model):
     for b in chain.buckets:
         ps = list(b["p16"]) + list(b["p32"])
         n16 = sum((p.numel() + 63) // 64 * 64 for p in ps if id(p) not in emb); n32 = sum((p.numel() + 63) // 64 * 64 for p in ps if id(p) in emb)
-        stages.append({"bf16_wire_MB": round(n16 * 2 / 1e6, 1), "fp32_wire_MB": round(n32 * 4 / 1e6, 1)})
+        j = len(stages)
+        rows = sum(sp.n * (sp.p.shape[1] * 4 + 8) for sp in getattr(chain, "sparse", []) if sp.stage == j)      # touched rows + their ids, per rank
+        stages.append({"bf16_wire_MB": round(n16 * 2 / 1e6, 1), "fp32_wire_MB": round(n32 * 4 / 1e6, 1), "touched_rows_MB": round(rows / 1e6, 1)})
     out = {"measured_at_n1_ms": {"forward": round(f_ms, 3), "backward_stages": [round(x, 3) for x in b_ms], "adamw_stages": [round(x, 3) for x in o_ms]},
            "wire_per_stage": stages,
            "assumptions": {"xgmi_link_GBps": XGMI_LINK_GBPS, "links_per_gpu": 7, "efficiency": XGMI_EFF, "latency_us_per_collective": COLL_LATENCY_US,
                            "note": "bf16 wire for everything but the embedding tables (fp32); all-reduce = 2 (N-1)/N x bytes over (N-1) links, "
-                                   "or over ONE link for a single ring; not measured (1-GPU boxes)"},
+                                   "or over ONE link for a single ring; the word-embedding gradient as an all-gather of each rank's touched rows "
+                                   "(round 5; the dense table was 96.9 MB of the last stage's fp32 wire); not measured (1-GPU boxes)"},
            "predicted": {}}
     for world in (2, 4, 8):
         pred = {}
@@ -335,6 +346,8 @@ def scale_model(chain, step_ms_1gpu, batch, model):
                     mb = stages[j][key]
                     if mb > 0:
                         ar += allreduce_ms(mb * 1e6, world, links)
+                if stages[j]["touched_rows_MB"] > 0:      # the word-embedding gradient: all-gather of the ranks' touched rows (mmf_amd/utils/graph.py _SparseRows)
+                    ar += allgather_ms(stages[j]["touched_rows_MB"] * 1e6, world, links)
                 start = max(t_main, comm_free)
                 comm_free = start + ar
                 ar_done.append(comm_free)
@@ -448,11 +461,11 @@ def main():
     use_chain = (world > 1) and not args.no_graph and not args.no_optimizer
     opt = None if args.no_optimizer else make_optimizer(capturable=use_graph or use_chain)
 
-    def chained_step(optimizer):
+    def chained_step(optimizer, sparse_rows=None):
         from mmf_amd.utils.graph import GraphedDataParallelStep
         layers = [m for m in model.modules() if type(m).__name__ == "BertLayerJit"]
         cuts = [layers[i] for i in (2, 5, 8) if i < len(layers) - 1]
-        return GraphedDataParallelStep(model, batch, cuts, optimizer, warmup=2)
+        return GraphedDataParallelStep(model, batch, cuts, optimizer, warmup=2, sparse_rows=sparse_rows)
 
     def eager_step(optimizer=None):
         model.zero_grad(set_to_none=True)
@@ -570,7 +583,7 @@ def main():
         if not args.no_optimizer and not args.no_graph:
             # the launch structure N > 1 runs (chain of hipGraphs, collectives between the stages), here without the collectives
             copt = make_optimizer(capturable=True)
-            chain = chained_step(copt)
+            chain = chained_step(copt, sparse_rows=True)      # (what N > 1 runs: the word-embedding gradient travels as touched rows; forced on here so that its pack / merge kernels are in the measured stage graphs)
             dtc, _ = timed(lambda: chain())
             eager_info["chained_graphs"] = {"ms_per_step": round(dtc / args.steps * 1e3, 3), "graphs_per_step": 1 + 2 * len(chain.g_bwd),
                                             "note": "the N > 1 launch path at N = 1 (no all-reduce): forward | backward stages interleaved with per-stage AdamW"}

@@ -627,6 +627,11 @@ int mmf_rowgroup_scale_f32(float* x, int ld, const float* gate, int groups, int 
  *   mmf_l2norm_rows_f32_bwd : autograd of F.normalize (m4c.py:195,212,217,223): dx = (g - y <g, y>) / max(||x||, eps), the factor recomputed from
  *       x into inv_ws [rows];
  *   mmf_ptr_scores_f32_bwd : autograd of OcrPtrNet's scores (m4c.py:474-493): dq = scale ds k, dk = scale ds^T q per sample. */
+/* Touched-row exchange of an embedding-table gradient between data-parallel ranks (the reference all-reduces the dense table,
+ * mmf/trainers/core/device.py:104-110): out[id] = sum of rows[perm[j]] over the segment of equal ids in `sorted_ids` (a STABLE sort of the ids gathered
+ * from all ranks, `perm` its permutation), added in sorted order without atomics — bit-identical on every rank.  ids < 0 (duplicates removed by the
+ * sender) and ids >= V are skipped; rows of `out` that no id names are left untouched. */
+int mmf_segment_sum_rows_f32(const int64_t* sorted_ids, const int64_t* perm, const float* rows, float* out, int M, int H, int64_t V, void* stream);
 int mmf_slice_rows_f32(const float* src, int ld_src, int K, float* dst, int KP, int rows, void* stream);   /* dst[r][:KP] = src[r * ld_src + :K], zero padded */
 int mmf_masked_mean_f32_bwd(const float* dpool, const float* mask, float* dx, int B, int T, int H, void* stream);
 int mmf_rowgroup_scale_f32_bwd(float* dy, const float* y, int ld, const float* gate, float* dgate, int groups, int rows_per_group, int C, void* stream);

@@ -858,6 +858,13 @@ def rowgroup_scale_f32(x, ld, gate, groups, rows_per_group, Cn):
 
 
 # ---- fp32 backwards of the operators round 5 added to mmf_amd.fp32_training() (gate_ops.hip, m4c_ops.hip, rowops.hip) -----------------
+def segment_sum_rows_f32(sorted_ids, perm, rows, out):
+    """out[id] = sum over the segment of equal ids (stable-sorted) of rows[perm[j]], in sorted order, no atomics (see include/mmf_amd.h)."""
+    _req(sorted_ids, torch.int64, "sorted_ids"); _req(perm, torch.int64, "perm"); _req(rows, torch.float32, "rows"); _req(out, torch.float32, "out")
+    M, H = rows.shape
+    _check(lib().mmf_segment_sum_rows_f32(_p(sorted_ids), _p(perm), _p(rows), _p(out), M, H, C.c_int64(out.shape[0]), _stream()), "mmf_segment_sum_rows_f32")
+
+
 def slice_rows_f32(src, ld_src, K, dst, KP, rows):
     """dst[r, :KP] = src[r * ld_src + :K] followed by zeros (a column slice of wider fp32 rows as a 16-byte-row GEMM operand)."""
     _req(src, torch.float32, "src"); _req(dst, torch.float32, "dst")

@@ -129,6 +129,26 @@ __global__ __launch_bounds__(256) void scatter_add_rows_f32_kernel(const float* 
     }
 }
 
+// Touched-row exchange of an embedding-table gradient (data parallelism, mmf/trainers/core/device.py:104-110 reduces the dense table): the ranks
+// exchange only the rows their batches touched — ids [M] and rows [M, H] gathered over all ranks — and every rank rebuilds the SUM with this kernel
+// from the ids in STABLE-sorted order: one wave per sorted position that starts a segment (the previous id differs) walks its segment and adds
+// the rows in that fixed order — no atomics, so every rank computes bit-identical sums — and writes out[id] = sum (rows nobody touched are
+// left alone: the local dense gradient holds zeros there).  ids < 0 mark duplicates removed on the sending rank; they sort first and are skipped.
+__global__ __launch_bounds__(256) void segment_sum_rows_f32_kernel(const int64_t* __restrict__ sorted_ids, const int64_t* __restrict__ perm,
+                                                                    const float* __restrict__ rows, float* __restrict__ out, int M, int H, long V) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    const long id = sorted_ids[i];
+    if (id < 0 || id >= V) return;
+    if (i > 0 && sorted_ids[i - 1] == id) return;
+    for (int col = lane * 4; col < H; col += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = i; j < M && sorted_ids[j] == id; ++j) acc += *reinterpret_cast<const f32x4*>(rows + (size_t)perm[j] * H + col);
+        *reinterpret_cast<f32x4*>(out + (size_t)id * H + col) = acc;
+    }
+}
+
 // d[b][n] = gloss (sigmoid(x) - t) / B: autograd of mean(BCEWithLogits) * num_labels (losses.py:246-251), fp32 out
 __global__ __launch_bounds__(256) void bce_f32_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ gloss,
                                                            float* __restrict__ d, long n, int B) {
@@ -140,6 +160,14 @@ __global__ __launch_bounds__(256) void bce_f32_bwd_kernel(const float* __restric
 }  // namespace
 
 extern "C" {
+
+int mmf_segment_sum_rows_f32(const int64_t* sorted_ids, const int64_t* perm, const float* rows, float* out, int M, int H, int64_t V, void* stream) {
+    MMF_CHECK_ARG(sorted_ids && perm && rows && out && M > 0 && H > 0 && (H % 4) == 0 && V > 0, "segment_sum_rows_f32: bad operand");
+    MMF_CHECK_ARG((((uintptr_t)rows | (uintptr_t)out) & 15) == 0, "segment_sum_rows_f32: 16-byte alignment");
+    hipLaunchKernelGGL(segment_sum_rows_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, sorted_ids, perm, rows, out, M, H, (long)V);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
 
 int mmf_bce_logits_f32_bwd(const float* scores, const float* targets, const float* gloss, float* dscores, int B, int N, void* stream) {
     MMF_CHECK_ARG(scores && targets && gloss && dscores && B > 0 && N > 0, "bce_logits_f32_bwd: bad operand");

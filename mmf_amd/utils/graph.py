@@ -168,6 +168,62 @@ class GraphedTrainStep:
         return self.loss
 
 
+class _SparseRows:
+    """Touched-row exchange of ONE embedding-table gradient between data-parallel ranks: the reference's DDP all-reduces the dense
+    [30522, 768] fp32 word-embedding gradient (97 MB, the last gradient backward produces: the un-overlappable tail of the step,
+    mmf/trainers/core/device.py:104-110) although a rank's batch touches at most B * T = 4096 of its rows.  Here every rank sends its ids and its
+    rows (12.6 MB), all-gathered, and rebuilds the SUM itself:
+
+      backward stage graph   ids sorted, duplicates marked -1 (the local dense gradient already holds their sum in ONE row), rows gathered
+                             from the dense gradient into the wire buffer                                              [`pack`]
+      between the graphs     all_gather of ids and rows (RCCL; a zero-padded all_reduce over gloo, which has no CUDA all_gather)      [`exchange`]
+      update stage graph     STABLE sort of the gathered ids, then `mmf_segment_sum_rows_f32`: one wave per id adds that id's rows in sorted
+                             (= rank) order without atomics and writes the sum into the dense gradient the fused AdamW reads        [`merge`]
+
+    Every rank computes the same function of the same gathered data in the same order: the replicas stay bit-identical (tested with two ranks).
+    Rows no rank touched keep the zeros of the local dense gradient; rows touched elsewhere only are written by the merge."""
+
+    def __init__(self, p, stage, n_ids, world, rank, group, dev):
+        self.p, self.stage, self.n, self.world, self.rank, self.group = p, stage, int(n_ids), world, rank, group
+        H = p.shape[1]
+        self.ids_wire = torch.full((self.n,), -1, dtype=torch.int64, device=dev)
+        self.rows_wire = torch.zeros(self.n, H, dtype=torch.float32, device=dev)
+        one = world <= 1
+        self.ids_all = self.ids_wire if one else torch.full((world * self.n,), -1, dtype=torch.int64, device=dev)
+        self.rows_all = self.rows_wire if one else torch.zeros(world * self.n, H, dtype=torch.float32, device=dev)
+        self.dense = None
+        self.nccl = (not one) and dist.get_backend(group) == "nccl"
+
+    def pack(self, g, ids):          # captured in the backward stage's graph
+        flat = ids.reshape(-1)
+        sorted_ids, _ = flat.sort()
+        dup = torch.zeros_like(sorted_ids, dtype=torch.bool)
+        dup[1:] = sorted_ids[1:] == sorted_ids[:-1]
+        self.ids_wire.copy_(torch.where(dup, torch.full_like(sorted_ids, -1), sorted_ids))
+        Fn.nat.gather_rows2_f32(g, g, self.ids_wire, self.rows_wire, self.n, g.shape[1])      # (-1 reads row 0: the receivers skip the entry)
+        self.dense = g               # the stage graph's own gradient tensor (kept alive by the step): the merge rewrites its touched rows in place
+
+    def exchange(self):              # eager, between the graph replays
+        if self.world <= 1:
+            return []
+        if self.nccl:
+            return [dist.all_gather_into_tensor(self.ids_all, self.ids_wire, group=self.group, async_op=True),
+                    dist.all_gather_into_tensor(self.rows_all, self.rows_wire, group=self.group, async_op=True)]
+        # gloo (tests: two ranks sharing one GPU) has no all_gather for device tensors: every rank fills its slot of a zero buffer, summed
+        self.ids_all.zero_()
+        self.ids_all.view(self.world, self.n)[self.rank].copy_(self.ids_wire + 1)
+        self.rows_all.zero_()
+        self.rows_all.view(self.world, self.n, -1)[self.rank].copy_(self.rows_wire)
+        dist.all_reduce(self.ids_all, group=self.group)
+        dist.all_reduce(self.rows_all, group=self.group)
+        self.ids_all.sub_(1)
+        return []
+
+    def merge(self):                 # captured in the update stage's graph, ahead of the fused AdamW
+        sorted_all, perm = self.ids_all.sort(stable=True)
+        Fn.nat.segment_sum_rows_f32(sorted_all, perm, self.rows_all, self.dense)
+
+
 class GraphedDataParallelStep:
     """The training step of ONE data-parallel rank as a short chain of hipGraphs with the gradient all-reduces between them
     (collective C1 of SURVEY.md section 2.3; the reference wraps the model in DistributedDataParallel, mmf/trainers/core/device.py:104-110):
@@ -197,7 +253,11 @@ class GraphedDataParallelStep:
     The optimizer must be `capturable=True`; its state is allocated before the capture (`ensure_state`) and the warm-up runs no
     optimizer step: the first replay is step 1."""
 
-    def __init__(self, model, batch, cuts, optimizer, process_group=None, comm_dtype=None, fp32_params=None, warmup=2, loss_of=None):
+    def __init__(self, model, batch, cuts, optimizer, process_group=None, comm_dtype=None, fp32_params=None, warmup=2, loss_of=None,
+                 sparse_rows=None):
+        """`sparse_rows`: exchange only the TOUCHED rows of embedding tables whose gradient is row-sparse (the word embeddings: <= B * T of 30522
+        rows receive a gradient) instead of all-reducing the dense table — see `_SparseRows`.  None = on when world > 1 (MMF_AMD_SPARSE_ROWS=0
+        switches it off), True forces it (a one-rank run then exercises the whole path), False = never."""
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedDataParallelStep needs an optimizer whose step reads its counters from device memory (capturable=True)")
         self.model, self.optimizer, self.group = model, optimizer, process_group
@@ -218,7 +278,13 @@ class GraphedDataParallelStep:
         dev = self.params[0].device
         self.seed = torch.full((1,), 7919 * rank, dtype=torch.int32, device=dev)      # ranks draw different dropout masks
         self._bounds, self._hooking = [], False
+        if sparse_rows is None:
+            sparse_rows = self.world > 1 and os.environ.get("MMF_AMD_SPARSE_ROWS", "1") != "0"
+        self._sparse_on, self._ids, self._probe, self.sparse, self._rank = bool(sparse_rows), {}, {}, [], rank
         handles = [m.register_forward_hook(self._cut_hook) for m in self.cuts]
+        if self._sparse_on:      # the ids every embedding stage looks up in its word table (the module's first positional argument)
+            handles += [m.register_forward_pre_hook(self._ids_hook) for m in model.modules()
+                        if isinstance(getattr(m, "word_embeddings", None), torch.nn.Embedding)]
         try:
             optimizer.ensure_state(self.params)
             optimizer.grad_scale = 1.0 / self.world
@@ -235,6 +301,8 @@ class GraphedDataParallelStep:
             torch.cuda.synchronize(dev)
             model.zero_grad(set_to_none=True)
             release_autograd_state()
+            self._pick_sparse(dev)
+            self._probe = {}
             self._layout(fp32_ids, dev)
             # capture_error_mode="thread_local": the communicator's watchdog thread polls events while we capture
             pool = torch.cuda.graph_pool_handle()
@@ -253,11 +321,14 @@ class GraphedDataParallelStep:
                     self._keep.append((grads, carry))
                 optimizer.external_grads = self._wire_views()
                 for j, g in enumerate(self.g_opt):       # one update graph per stage; only the first advances the step count / schedule
-                    ids = {id(p) for p in self.buckets[j]["p16"]} | {id(p) for p in self.buckets[j]["p32"]}
+                    ids = {id(p) for p in self.buckets[j]["p16"]} | {id(p) for p in self.buckets[j]["p32"]} | {id(sp.p) for sp in self.sparse if sp.stage == j}
                     if not ids and j > 0:
                         self.g_opt[j] = None                 # (a stage without parameters of its own: nothing to update)
                         continue
                     with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                        for sp in self.sparse:
+                            if sp.stage == j:
+                                sp.merge()                   # the ranks' touched rows -> the summed dense gradient the update reads
                         optimizer.step(only=ids, advance=(j == 0))
         finally:
             for h in handles:
@@ -273,7 +344,13 @@ class GraphedDataParallelStep:
         self._bounds.append((t, d))
         return (d,) + tuple(output[1:]) if isinstance(output, tuple) else d
 
+    def _ids_hook(self, module, args):
+        if self._hooking and args and isinstance(args[0], torch.Tensor) and args[0].dtype == torch.int64:
+            k = id(module.word_embeddings.weight)
+            self._ids[k] = args[0] if k not in self._ids else None      # (a table looked up by TWO embedding stages in one forward is not a candidate)
+
     def _forward(self):
+        self._ids = {}
         Fn.nat.seed_advance(self.seed)
         self._bounds, self._hooking = [], True
         try:
@@ -304,10 +381,15 @@ class GraphedDataParallelStep:
     def _discover_or_run(self):
         first = self.stage_params is None
         stages, carry = [], None
+        self._probe = {}
         for j in range(len(self.cuts) + 1):
             cand = self.params if first else self.stage_params[j]
             grads, carry = self._stage_grads(j, carry, cand)
             stages.append([p for p, g in zip(cand, grads) if g is not None])
+            if self._sparse_on:
+                for p, g in zip(cand, grads):
+                    if g is not None and self._ids.get(id(p)) is not None:
+                        self._probe.setdefault(id(p), []).append((j, g))
         if first:
             self.stage_params = stages
             seen = {}
@@ -326,6 +408,8 @@ class GraphedDataParallelStep:
             b = dict(p16=[], o16=[], p32=[], o32=[])
             n16 = n32 = 0
             for p in mine:
+                if any(sp.p is p for sp in self.sparse):
+                    continue             # exchanged as touched rows (_SparseRows), not inside a wire buffer
                 wide = id(p) in fp32_ids or self.comm_dtype == torch.float32
                 (b["p32"] if wide else b["p16"]).append(p)
                 if wide:
@@ -345,9 +429,18 @@ class GraphedDataParallelStep:
                 g = g if acc is None else acc + g
                 self._partial[id(p)] = g
             have[id(p)] = g
+        for sp in self.sparse:
+            if sp.stage == j:
+                sp.pack(have[id(sp.p)], self._ids[id(sp.p)])
         for plist, offs, flat in ((b["p16"], b["o16"], b["wire16"]), (b["p32"], b["o32"], b["wire32"])):
             if plist:
-                torch._foreach_copy_([flat[o:o + p.numel()].view_as(p) for p, o in zip(plist, offs)], [have[id(p)] for p in plist])
+                srcs = [have[id(p)] for p in plist]
+                if all(g.dtype == torch.float32 and g.is_contiguous() for g in srcs):
+                    # ONE multi-tensor HIP launch per wire buffer: every gradient read once, converted to the wire type, written once (round 4:
+                    # `_foreach_copy_`, one converting kernel per gradient inside the stage graph)
+                    Fn.nat.pack_f32_multi(srcs, offs, flat, 1.0)
+                else:
+                    torch._foreach_copy_([flat[o:o + p.numel()].view_as(p) for p, o in zip(plist, offs)], srcs)
 
     def _wire_views(self):
         """id(parameter) -> its slice of the stage's wire buffer (after the all-reduce: the SUM over the ranks), in the wire's dtype."""
@@ -356,7 +449,33 @@ class GraphedDataParallelStep:
             for plist, offs, flat in ((b["p16"], b["o16"], b["wire16"]), (b["p32"], b["o32"], b["wire32"])):
                 for p, o in zip(plist, offs):
                     views[id(p)] = flat[o:o + p.numel()].view_as(p)
+        for sp in self.sparse:
+            views[id(sp.p)] = sp.dense
         return views
+
+    def _pick_sparse(self, dev):
+        """Which parameters travel as touched rows: embedding tables whose ONLY gradient contributions in the warm-up were the rows of the ids
+        their embedding stage looked up (a decoder tied to the table, a second lookup of other ids — MMBT's start / end tokens — make the gradient
+        dense or name other rows: those stay in the wire buffers), with at least four table rows per looked-up id, living in ONE backward stage.
+        The decision is agreed over the ranks (MIN), so every rank issues the same collectives."""
+        if not self._sparse_on:
+            return
+        cands = []
+        for p in self.params:
+            ent, ids = self._probe.get(id(p)), self._ids.get(id(p))
+            ok = ent is not None and len(ent) == 1 and ids is not None and p.dim() == 2 and p.shape[0] >= 4 * ids.numel() and p.shape[1] % 4 == 0
+            if ok:
+                j, g = ent[0]
+                touched = torch.zeros(p.shape[0], dtype=torch.bool, device=dev)
+                touched[ids.reshape(-1).clamp(0, p.shape[0] - 1)] = True
+                ok = g.dtype == torch.float32 and not bool((g[~touched] != 0).any())      # (a host read-back: this is the eager warm-up)
+            cands.append((p, ok, ent[0][0] if ent else -1))
+        flags = torch.tensor([1 if ok else 0 for _, ok, _ in cands], dtype=torch.int32, device=dev)
+        if self.world > 1 and flags.numel():
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=self.group)
+        for (p, _, j), f in zip(cands, flags.tolist()):
+            if f:
+                self.sparse.append(_SparseRows(p, j, self._ids[id(p)].numel(), self.world, self._rank, self.group, dev))
 
     def gradients(self):
         """After a step: parameter -> reduced gradient buffer (the sum over the ranks; multiply by `optimizer.grad_scale` for the mean)."""
@@ -377,6 +496,9 @@ class GraphedDataParallelStep:
                 for flat in (b["wire16"], b["wire32"]):
                     if flat is not None:
                         works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                for sp in self.sparse:
+                    if sp.stage == j:
+                        works += sp.exchange()
             if prev is not None:
                 for w in prev:
                     w.wait()

@@ -80,6 +80,8 @@ def _worker(rank, world, port, q):
     opt = _optimizer(model, True)
     step = GraphedDataParallelStep(model, SampleList(sample_to(_half(full, rank), "cuda")), _layers(model), opt, warmup=1)
     wires = sorted({str(b[k].dtype) for b in step.buckets for k in ("wire16", "wire32") if b[k] is not None})
+    names = {id(p): n for n, p in model.named_parameters()}
+    wires.append("rows:" + ",".join(sorted(names[id(sp.p)] for sp in step.sparse)))       # what travels as touched rows (round 5)
     step()
     torch.cuda.synchronize()
     # after the step the wire buffers hold the SUM over ranks (the 1 / world lives in optimizer.grad_scale); the optimizer read them there
@@ -120,7 +122,9 @@ def test_two_ranks_chained_graphs_apply_the_whole_batch_update():
         for p in procs:
             if p.is_alive():
                 p.kill()
-    assert res[0][2] == ["torch.bfloat16", "torch.float32"]
+    # bf16 wire, fp32 wire for the small embedding tables, and (round 5) the word-embedding gradient as touched rows: every rank sends the rows
+    # its batch touched, every rank rebuilds the sum in the same order — the `torch.equal(g0, g1)` / `torch.equal(p0, p1)` below include that table
+    assert res[0][2] == ["torch.bfloat16", "torch.float32", "rows:model.bert.embeddings.word_embeddings.weight"], res[0][2]
     ref = res[0][1]
     init = ref.pop("__init__")
     g0s, g1s = res[0][0].pop("__grads__"), res[1][0].pop("__grads__")
@@ -195,3 +199,54 @@ def test_chained_graphs_with_rccl_collectives_between_the_stages():
     assert l0[2] < l0[0]
     for n in p0:
         assert (p0[n] == p1[n]).all(), n
+
+
+def test_touched_row_exchange_one_rank_is_bit_identical_to_the_dense_path():
+    """`sparse_rows=True` on one rank runs the whole touched-row path of the word-embedding gradient (duplicate ids marked, rows gathered from the
+    dense gradient in the backward stage graph, stable sort + segment sum ahead of AdamW in the update graph): the sums are the rows themselves, so
+    losses and every parameter must equal the dense path bit for bit; the table is picked automatically (the other tables are too small, and
+    a table with a second kind of contribution would be refused)."""
+    from mmf_amd.common.sample import SampleList
+    from mmf_amd.utils.graph import GraphedDataParallelStep
+    from tests.golden_utils import load_case
+    from tests.model_utils import build_visual_bert, sample_to
+    z, case, cfg, sd, sample = load_case("small64")
+    batch = SampleList(sample_to(sample, "cuda"))
+    out = {}
+    for sparse in (False, True):
+        model = build_visual_bert(cfg, sd); model.eval()
+        opt = _optimizer(model, True)
+        step = GraphedDataParallelStep(model, batch, _layers(model), opt, warmup=1, sparse_rows=sparse)
+        names = {id(p): n for n, p in model.named_parameters()}
+        assert [names[id(sp.p)] for sp in step.sparse] == (["model.bert.embeddings.word_embeddings.weight"] if sparse else [])
+        losses = [float(step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        out[sparse] = (losses, {n: p.detach().clone() for n, p in model.named_parameters()})
+    assert out[False][0] == out[True][0]
+    for n in out[False][1]:
+        assert torch.equal(out[False][1][n], out[True][1][n]), n
+
+
+def test_segment_sum_rows_is_deterministic_and_matches_index_add():
+    from mmf_amd import _native as nat
+    g = torch.Generator().manual_seed(9)
+    V, H, M = 500, 96, 4096
+    ids = torch.randint(-1, 60, (M,), generator=g)                 # many collisions, some -1 (removed duplicates)
+    rows = torch.randn(M, H, generator=g)
+    sorted_ids, perm = ids.cuda().sort(stable=True)
+    out = torch.full((V, H), 3.0, device="cuda")
+    nat.segment_sum_rows_f32(sorted_ids, perm, rows.cuda(), out)
+    ref = torch.full((V, H), 3.0, dtype=torch.float64)
+    touched = sorted({int(i) for i in ids.tolist() if i >= 0})
+    ref[touched] = 0.0
+    keep = ids >= 0
+    ref.index_add_(0, ids[keep], rows[keep].double())
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    again = torch.full((V, H), 3.0, device="cuda")
+    nat.segment_sum_rows_f32(sorted_ids, perm, rows.cuda(), again)
+    assert torch.equal(out, again)
+    # fixed order: the sum of a segment is the left-to-right fp32 sum in stable-sorted order
+    seq = torch.zeros(H)
+    for j in torch.nonzero(ids == touched[0]).flatten().tolist():
+        seq = seq + rows[j]
+    assert torch.equal(out[touched[0]].cpu(), seq)

@@ -638,6 +638,10 @@ int mmf_rowgroup_scale_f32_bwd(float* dy, const float* y, int ld, const float* g
 int mmf_align_pos_f32_bwd(const float* dvis, int ld, int nb, int rpb, int bstride, const int64_t* align, float* dpos, int A, int H, int P, void* stream);
 int mmf_soft_target_kl_f32_bwd(const float* logits, int ld, const float* target, int ldt, const int64_t* row_label, const float* lse,
                                const float* tsum, const float* count, const float* gloss, float* dlogits, int ldd, int R, int C, void* stream);
+int mmf_mse_f32_bwd(const float* pred, int ldp, const float* target, int ldt, const int64_t* row_label, const float* count, const float* gloss, float* dpred, int ldd,
+                    int rows, int cols, void* stream);      /* mmf_mse_bwd with an fp32 gradient (ViLBERT visual_target 1, vilbert.py:1139-1148); ldd % 4 == 0 */
+int mmf_nce_f32_bwd(const float* target, const int64_t* neg, const int64_t* label, const float* scores, const float* lse, const float* count, const float* gloss,
+                    float* dpred, int ldd, int M, int N, int K, void* stream);      /* mmf_nce_bwd with an fp32 gradient (visual_target 2, vilbert.py:1158-1227) */
 int mmf_l2norm_rows_f32_bwd(const float* g, int ldg, const float* y, int ldy, const float* x, int ldx, float* inv_ws, float* dx, int lddx, int rows,
                             int D, float eps, void* stream);
 int mmf_ptr_scores_f32_bwd(const float* dscores, int ldd, const float* q, const float* k, float* dq, float* dk, int B, int T, int N, int HQ,

@@ -896,6 +896,21 @@ def soft_target_kl_f32_bwd(logits, target, row_label, lse, tsum, count, gloss, d
                                             _p(count), _p(gloss), _p(dlogits), ldd, R, Cn, _stream()), "mmf_soft_target_kl_f32_bwd")
 
 
+def mse_f32_bwd(pred, target, gloss, dpred, ldd, rows, cols, row_label=None, count=None):
+    for t, n in ((pred, "pred"), (target, "target"), (gloss, "gloss"), (count, "count"), (dpred, "dpred")):
+        _req(t, torch.float32, n)
+    _req(row_label, torch.int64, "row_label")
+    _check(lib().mmf_mse_f32_bwd(_p(pred), pred.stride(0), _p(target), target.stride(0), _p(row_label), _p(count), _p(gloss), _p(dpred), ldd, rows, cols,
+                                 _stream()), "mmf_mse_f32_bwd")
+
+
+def nce_f32_bwd(target, neg, label, scores, lse, count, gloss, dpred, ldd, M, N, K):
+    for t, n in ((target, "target"), (scores, "scores"), (lse, "lse"), (count, "count"), (gloss, "gloss"), (dpred, "dpred")):
+        _req(t, torch.float32, n)
+    _req(neg, torch.int64, "neg"); _req(label, torch.int64, "label")
+    _check(lib().mmf_nce_f32_bwd(_p(target), _p(neg), _p(label), _p(scores), _p(lse), _p(count), _p(gloss), _p(dpred), ldd, M, N, K, _stream()), "mmf_nce_f32_bwd")
+
+
 def l2norm_rows_f32_bwd(g, ldg, y, ldy, x, ldx, dx, lddx, rows, D, eps=1e-12):
     """dx = (g - y <g, y>) / max(||x||, eps): autograd of F.normalize on fp32 rows (the factor is recomputed from x)."""
     for t, n in ((g, "g"), (y, "y"), (x, "x"), (dx, "dx")):

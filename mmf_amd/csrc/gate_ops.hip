@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void rowgroup_scale_f32_bwd_kernel(float* __re
 constexpr int NCE_MAXK = 1024;
 DEVI f32x4 nce_load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 DEVI void nce_store4(bf16* p, f32x4 v) { p[0] = (bf16)v[0]; p[1] = (bf16)v[1]; p[2] = (bf16)v[2]; p[3] = (bf16)v[3]; }
+DEVI void nce_store4(float* p, f32x4 v) { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3]; }
 __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const int64_t* __restrict__ neg,
                                                        const int64_t* __restrict__ label, float* __restrict__ scores, float* __restrict__ lse,
                                                        float* __restrict__ rowloss, int M, int N, int K) {
@@ -182,15 +183,16 @@ __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restri
         loss[0] = ((rs[0] + rs[1]) + (rs[2] + rs[3])) / cs;        // no labelled region: 0 / 0 = NaN, like CrossEntropyLoss over nothing
     }
 }
+template <typename RT>   // bf16: the GEMM operand of the throughput path; float: mmf_amd.fp32_training()
 __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ target, const int64_t* __restrict__ neg, const int64_t* __restrict__ label,
                                                        const float* __restrict__ scores, const float* __restrict__ lse, const float* __restrict__ count,
-                                                       const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int M, int N, int K) {
+                                                       const float* __restrict__ gloss, RT* __restrict__ d, int ldd, int M, int N, int K) {
     __shared__ float w[NCE_MAXK + 1];
     __shared__ long srcs[NCE_MAXK + 1];
     const int r = blockIdx.x;
-    bf16* dr = d + (size_t)r * ldd;
+    RT* dr = d + (size_t)r * ldd;
     if (label[r] != 1) {
-        for (int c = threadIdx.x; c < ldd; c += 256) dr[c] = (bf16)0.f;
+        for (int c = threadIdx.x; c < ldd; c += 256) dr[c] = (RT)0.f;
         return;
     }
     const float g = gloss[0] / count[0], l = lse[r];
@@ -316,7 +318,15 @@ int mmf_nce_bwd(const float* target, const int64_t* neg, const int64_t* label, c
                 void* dpred, int ldd, int M, int N, int K, void* stream) {
     MMF_CHECK_ARG(target && neg && label && scores && lse && count && gloss && dpred, "nce_bwd: null operand");
     MMF_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && K <= NCE_MAXK && ldd >= N && (ldd % 8) == 0, "nce_bwd: bad shape (ldd: a multiple of 8 covering N)");
-    hipLaunchKernelGGL(nce_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, target, neg, label, scores, lse, count, gloss, (bf16*)dpred, ldd, M, N, K);
+    hipLaunchKernelGGL(nce_bwd_kernel<bf16>, dim3(M), dim3(256), 0, (hipStream_t)stream, target, neg, label, scores, lse, count, gloss, (bf16*)dpred, ldd, M, N, K);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_nce_f32_bwd(const float* target, const int64_t* neg, const int64_t* label, const float* scores, const float* lse, const float* count, const float* gloss,
+                    float* dpred, int ldd, int M, int N, int K, void* stream) {
+    MMF_CHECK_ARG(target && neg && label && scores && lse && count && gloss && dpred, "nce_f32_bwd: null operand");
+    MMF_CHECK_ARG(M > 0 && N > 0 && (N % 4) == 0 && K > 0 && K <= NCE_MAXK && ldd >= N && (ldd % 4) == 0, "nce_f32_bwd: bad shape (ldd: a multiple of 4 covering N)");
+    hipLaunchKernelGGL(nce_bwd_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, target, neg, label, scores, lse, count, gloss, dpred, ldd, M, N, K);
     MMF_CHECK_LAUNCH();
     return 0;
 }

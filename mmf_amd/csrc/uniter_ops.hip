@@ -49,16 +49,17 @@ __global__ __launch_bounds__(64) void mse_final_kernel(const float* __restrict__
     }
 }
 // d = gloss * 2 (pred - target) / n  as bf16 [rows, ldd] (pad columns zeroed)
+template <typename RT>   // bf16: the GEMM operand of the throughput path; float: mmf_amd.fp32_training()
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target, int ldt,
                                                        const int64_t* __restrict__ row_label, const float* __restrict__ count,
-                                                       const float* __restrict__ gloss, bf16* __restrict__ d, int ldd, int rows, int cols, float two_over_n) {
+                                                       const float* __restrict__ gloss, RT* __restrict__ d, int ldd, int rows, int cols, float two_over_n) {
     const int64_t n = (int64_t)rows * ldd;
     const float g = (gloss ? gloss[0] : 1.f) * (row_label ? 2.f / count[0] : two_over_n);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / ldd;
         const int c = (int)(i - r * ldd);
         const bool on = c < cols && (!row_label || row_label[r] == 1);
-        d[i] = (bf16)(on ? g * (pred[r * ldp + c] - target[r * ldt + c]) : 0.f);
+        d[i] = (RT)(on ? g * (pred[r * ldp + c] - target[r * ldt + c]) : 0.f);
     }
 }
 
@@ -317,8 +318,19 @@ int mmf_mse_bwd(const float* pred, int ldp, const float* target, int ldt, const 
     MMF_CHECK_ARG(!row_label || count, "mse_bwd: the masked form needs the forward's `count`");
     const int64_t n = (int64_t)rows * ldd;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(mse_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, ldp, target, ldt, row_label, count, gloss,
+    hipLaunchKernelGGL(mse_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, ldp, target, ldt, row_label, count, gloss,
                        reinterpret_cast<bf16*>(dpred), ldd, rows, cols, 2.f / ((float)rows * (float)cols));
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_mse_f32_bwd(const float* pred, int ldp, const float* target, int ldt, const int64_t* row_label, const float* count, const float* gloss, float* dpred, int ldd,
+                    int rows, int cols, void* stream) {
+    MMF_CHECK_ARG(pred && target && dpred && rows > 0 && cols > 0 && ldd >= cols && (ldd % 4) == 0, "mse_f32_bwd: bad operand (ldd % 4 == 0)");
+    MMF_CHECK_ARG(!row_label || count, "mse_f32_bwd: the masked form needs the forward's `count`");
+    const int64_t n = (int64_t)rows * ldd;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(mse_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, ldp, target, ldt, row_label, count, gloss, dpred, ldd, rows,
+                       cols, 2.f / ((float)rows * (float)cols));
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -815,6 +815,75 @@ class MaskedRegionHeadFn(torch.autograd.Function):
         return _dgrad(dz, w).view(xshape), _wgrad(dz, x2), _colsum(dz), None, None
 
 
+class MaskedRegionRegressionFn(torch.autograd.Function):
+    """ViLBERT `visual_target: 1` (vilbert.py:1074-1075, 1139-1148) in fp32: decoder GEMM, nn.MSELoss(reduction="none") over the regions with
+    image_label == 1 divided by max(their element count, 1).  Returns (loss, scores); only the loss carries gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target, row_label):
+        x2 = _rows(x)
+        M = x2.shape[0]
+        w = _w(weight)
+        N = w.shape[0]
+        pred = _gemm(x2, w, N, bias=_w(bias))
+        tgt = target.reshape(M, N).float().contiguous()
+        lab = row_label.reshape(M).long().contiguous()
+        loss = _empty(1, like=x2); count = _empty(1, like=x2)
+        nat.mse_fwd(pred, tgt, loss, M, N, row_label=lab, count=count)
+        ctx.save_for_backward(x2, w, pred, tgt, lab, count)
+        ctx.meta = (x.shape,)
+        out = pred.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(out)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, g, _gscores):
+        x2, w, pred, tgt, lab, count = ctx.saved_tensors
+        (xshape,) = ctx.meta
+        M, N = pred.shape
+        NP = (N + 3) // 4 * 4
+        dl = _empty(M, NP, like=x2)
+        nat.mse_f32_bwd(pred, tgt, g.float().reshape(1).contiguous(), dl, NP, M, N, row_label=lab, count=count)
+        dz = dl[:, :N]
+        return _dgrad(dz, w).view(xshape), _wgrad(dz, x2), _colsum(dz), None, None
+
+
+class MaskedRegionNCEFn(torch.autograd.Function):
+    """ViLBERT `visual_target: 2` (vilbert.py:1158-1227) in fp32: decoder GEMM, every masked region's prediction scored against its own target
+    and K sampled negatives, CrossEntropyLoss against class 0.  `neg_index`: flat region indices [B, R, K] drawn on the host side of the boundary."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target, row_label, neg_index):
+        x2 = _rows(x)
+        M = x2.shape[0]
+        w = _w(weight)
+        N = w.shape[0]
+        pred = _gemm(x2, w, N, bias=_w(bias))
+        tgt = target.reshape(M, N).float().contiguous()
+        lab = row_label.reshape(M).long().contiguous()
+        neg = neg_index.reshape(M, -1).long().contiguous()
+        NK = neg.shape[1]
+        scores = _empty(M, NK + 1, like=x2)
+        lse = _empty(M, like=x2); rowloss = _empty(M, like=x2); loss = _empty(1, like=x2); count = _empty(1, like=x2)
+        nat.nce_fwd(pred, tgt, neg, lab, scores, lse, rowloss, loss, count, M, N, NK)
+        ctx.save_for_backward(x2, w, tgt, neg, lab, scores, lse, count)
+        ctx.meta = (x.shape, N, NK)
+        out = pred.view(*x.shape[:-1], N)
+        ctx.mark_non_differentiable(out)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, g, _gscores):
+        x2, w, tgt, neg, lab, scores, lse, count = ctx.saved_tensors
+        xshape, N, NK = ctx.meta
+        M = x2.shape[0]
+        NP = (N + 3) // 4 * 4
+        dl = _empty(M, NP, like=x2)
+        nat.nce_f32_bwd(tgt, neg, lab, scores, lse, count, g.float().reshape(1).contiguous(), dl, NP, M, N, NK)
+        dz = dl[:, :N]
+        return _dgrad(dz, w).view(xshape), _wgrad(dz, x2), _colsum(dz), None, None, None
+
+
 # ---- M4C's stages (mmf/models/m4c.py:185-304) in fp32, forward and backward ------------------------------------------------------------
 class L2NormRowsFn(torch.autograd.Function):
     """F.normalize(x, dim=-1) (m4c.py:195) on fp32 rows; backward dx = (g - y <g, y>) / max(||x||, eps)."""
@@ -1128,6 +1197,14 @@ def masked_lm_head(x, weight, bias, labels, ignore_index):
 
 def masked_region_head(x, weight, bias, target, row_label):
     return MaskedRegionHeadFn.apply(x, weight, bias, target, row_label)
+
+
+def masked_region_regression(x, weight, bias, target, row_label):
+    return MaskedRegionRegressionFn.apply(x, weight, bias, target, row_label)
+
+
+def masked_region_nce(x, weight, bias, target, row_label, neg_index):
+    return MaskedRegionNCEFn.apply(x, weight, bias, target, row_label, neg_index)
 
 
 def masked_mean(x, mask):

@@ -537,16 +537,15 @@ class ViLBERTForPretraining(nn.Module):
             head = self.cls.imagePredictions
             hidden_v = head.transform(sequence_output_v)
             if self.visual_target == 2:          # NCE against sampled negatives, CrossEntropyLoss on class 0, :1158-1227
-                if F32T.active():
-                    raise NotImplementedError("mmf_amd.fp32_training(): visual_target 2 (NCE) has its backward on the bf16 path only; "
-                                              "visual_target 0 (the reference default) is built in fp32")
                 B, R = image_label.shape[0], image_label.shape[1]
                 neg = self.negative_index(B, R, input_ids)
-                img_loss, _ = Fn.MaskedRegionNCEFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
+                if F32T.active():      # mmf_amd.fp32_training(): the same draws, decoder and loss on the fp32 kernels
+                    img_loss, _ = F32T.masked_region_nce(hidden_v, head.decoder.weight, head.decoder.bias, image_target, image_label, neg)
+                else:
+                    img_loss, _ = Fn.MaskedRegionNCEFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
                                                          image_target, image_label, neg)
             elif self.visual_target == 1 and F32T.active():
-                raise NotImplementedError("mmf_amd.fp32_training(): visual_target 1 (masked-region regression) has its backward on the bf16 path only; "
-                                          "visual_target 0 (the reference default) is built in fp32")
+                img_loss, _ = F32T.masked_region_regression(hidden_v, head.decoder.weight, head.decoder.bias, image_target, image_label)
             elif self.visual_target == 1:        # nn.MSELoss(reduction="none") over the masked regions / max(their element count, 1), :1139-1148
                 img_loss, _ = Fn.MaskedRegionRegressionFn.apply(hidden_v, head.decoder.weight, head.decoder.bias, Fn.shadows.get(head.decoder.weight),
                                                                 image_target, image_label)

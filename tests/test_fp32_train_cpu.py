@@ -52,13 +52,12 @@ def test_nlvr2_step_builds_an_fp32_graph():
 
 
 def test_operators_without_an_fp32_backward_refuse():
-    z, case, cfg, sd, sample = G.load_vilbert_pretraining_case(1)           # `visual_target: 1` (regression): its backward is on the bf16 path only
-    model = MU.build_vilbert_pretraining(cfg, sd, device="cpu", visual_target=1)
+    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_pairs")          # `in_batch_pairs`: the batch expansion is on the bf16 path only
+    model = MU.build_vilbert(cfg, sd, device="cpu")
     model.eval()
-    sample = {k: v for k, v in sample.items() if not k.startswith("_")}
-    with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32_training"):
+    with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32"):
         with mmf_amd.fp32_training():
-            model(SampleList(sample))
+            model(SampleList({k: v for k, v in sample.items() if k != "targets"}))
 
 
 def _fp32_step(model, sample, train=True):
@@ -89,6 +88,11 @@ def test_round5_operators_build_fp32_graphs():
     names = _fp32_step(model, {k: v for k, v in sample.items() if not k.startswith("_")})
     assert {"soft_target_kl_fwd", "soft_target_kl_f32_bwd", "vocab_cross_entropy_f32_bwd"} <= names
     assert model.model.cls.imagePredictions.decoder.weight.grad is not None
+    for vt, kernel in ((1, "mse_f32_bwd"), (2, "nce_f32_bwd")):      # the non-default masked-region targets
+        z, case, cfg, sd, sample = G.load_vilbert_pretraining_case(vt)
+        model = MU.build_vilbert_pretraining(cfg, sd, device="cpu", visual_target=vt, **(dict(num_negative=cfg["num_negative"]) if vt == 2 else {}))
+        names = _fp32_step(model, {k: v for k, v in sample.items() if not k.startswith("_")})
+        assert kernel in names and "mse_bwd" not in names and "nce_bwd" not in names
     z, case, cfg, sd, sample = G.load_case("align64")
     model = MU.build_visual_bert(cfg, sd, device="cpu")
     names = _fp32_step(model, sample)

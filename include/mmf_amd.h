@@ -244,6 +244,16 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
                       void* dx, void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale,
                       const uint32_t* drop_seed, float* dgamma, float* dbeta, float* dbias, int accumulate,
                       float* partials, int rows, int H, void* stream);
+/* LayerNorm followed by nn.Dropout as ONE launch each way (BertVisioLinguisticEmbeddings, mmf/modules/embeddings.py:343-345: `self.dropout(self.LayerNorm(
+ * embeddings))`): forward y = dropout(LN(x)) — the LayerNorm output rounded to bf16, then the keep scale, element index row*H + col, bit-identical to
+ * mmf_layernorm_fwd + mmf_dropout_bf16; backward mmf_layernorm_bwd_din applies the same mask to the incoming gradient while loading it (= mmf_dropout_bf16 +
+ * mmf_layernorm_bwd without dlin / dbias).  Widths with mmf_layernorm_dropout_fusable(H) != 0 only (H % 256 == 0, H <= 1024); deferral of the column sums
+ * as for mmf_layernorm_bwd. */
+int mmf_layernorm_dropout_fusable(int H);
+int mmf_layernorm_dropout_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int H, float eps,
+                              uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream);
+int mmf_layernorm_bwd_din(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx, uint32_t in_key, uint32_t in_thr16,
+                          float in_scale, const uint32_t* in_seed, float* dgamma, float* dbeta, int accumulate, float* partials, int rows, int H, void* stream);
 
 /* ---- embeddings (BertVisioLinguisticEmbeddings, mmf/modules/embeddings.py:329-345) ------------
  * Text rows of the joint pre-LayerNorm sequence: y[b*S + t] = word[ids[b,t]] + pos[t] + type[seg[b,t]].
@@ -290,6 +300,14 @@ int mmf_copy_rows_bf16(const void* src, int src_bstride, void* dst, int dst_bstr
  * [PAD] row's gradient at zero (HF BertEmbeddings word_embeddings; reached from embeddings.py:309).
  */
 int mmf_rows_scatter_add_ws_floats(int H);
+/* The four small table gradients of BertVisioLinguisticEmbeddings' backward (embeddings.py:329-345, 411-419) in two launches instead of seven
+ * mmf_rows_scatter_add ones: x = gradient of the pre-LayerNorm sum, bf16 [B, S = T + R, ld]; dpos[pos0 + t] += sum_b x[b][t] (text positions),
+ * dtyp[seg[b][t]] += x[b][t] (text token types), dtyp_vis[vt[b][r]] += x[b][T + r], dpos_vis[0] += sum over every visual row (position_ids_visual == 0).
+ * Any output may be NULL; R may be 0.  Buckets 0 / 1 are summed deterministically (fixed order), larger in-range ones by atomics, ids outside
+ * [0, NT) / [0, NTV) are skipped and raise the index-error flag.  ws: mmf_embed_tables_bwd_ws_floats(T + R, H) floats. */
+int mmf_embed_tables_bwd_ws_floats(int S, int H);
+int mmf_embed_tables_bwd(const void* x, int ld, int B, int T, int R, const int64_t* seg, const int64_t* vt, int pos0, float* dpos, int P, float* dtyp, int NT,
+                         float* dtyp_vis, int NTV, float* dpos_vis, int H, float* ws, void* stream);
 int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, const int64_t* idx, int idx_ld,
                          int per_pos, int idx_base, float* out, int H, int few_buckets, int nbuckets, float* ws,
                          int skip_bucket, void* stream);
@@ -339,6 +357,8 @@ int mmf_dropout_bf16(const void* x, void* y, int64_t n, uint32_t drop_key, uint3
  * drop_seed pointer is given (else key' = drop_key).  mmf_seed_advance increments that device word; put it at the
  * head of a captured step so every hipGraph replay draws fresh masks while forward and backward still agree. */
 int mmf_seed_advance(uint32_t* seed, void* stream);
+/* mmf_seed_advance and mmf_optim_state_advance (below) as ONE one-thread launch at the head of a captured training step; either pointer may be NULL. */
+int mmf_step_advance(uint32_t* seed, float* state, int schedule, float warmup_steps, float total_steps, void* stream);
 /* du = dh * g with g = gelu_erf'(u) as saved by the forward epilogue (act == 1): backward of HF
  * BertIntermediate's activation when it is not fused into a dgrad GEMM epilogue (act == 2). */
 int mmf_gelu_bwd_bf16(const void* dh, const void* g, void* du, int64_t n, void* stream);

@@ -372,6 +372,31 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, H, eps):
            "mmf_layernorm_fwd")
 
 
+def layernorm_dropout_fusable(H):
+    return bool(lib().mmf_layernorm_dropout_fusable(int(H)))
+
+
+def layernorm_dropout_fwd(x, gamma, beta, y, mean, rstd, rows, H, eps, drop):
+    """y = dropout(LayerNorm(x)) in one launch (embeddings.py:343-345), bit-identical to layernorm_fwd + dropout."""
+    _req(x, torch.bfloat16, "x"); _req(y, torch.bfloat16, "y")
+    _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    _req(mean, torch.float32, "mean"); _req(rstd, torch.float32, "rstd")
+    k, t, sc, sd = _drop4(drop)
+    _check(lib().mmf_layernorm_dropout_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, H, C.c_float(eps), C.c_uint32(k), C.c_uint32(t),
+                                           C.c_float(sc), sd, _stream()), "mmf_layernorm_dropout_fwd")
+
+
+def layernorm_bwd_din(dy, x, mean, rstd, gamma, dx, in_drop, dgamma, dbeta, accumulate, partials, rows, H):
+    """layernorm_bwd of a LayerNorm whose OUTPUT went through dropout `in_drop`: the mask is applied to dy while it is loaded."""
+    for t, n in ((dy, "dy"), (x, "x"), (dx, "dx")):
+        _req(t, torch.bfloat16, n)
+    for t, n in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta"), (partials, "partials")):
+        _req(t, torch.float32, n)
+    k, t, sc, sd = _drop4(in_drop)
+    _check(lib().mmf_layernorm_bwd_din(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), C.c_uint32(k), C.c_uint32(t), C.c_float(sc), sd, _p(dgamma),
+                                       _p(dbeta), int(accumulate), _p(partials), rows, H, _stream()), "mmf_layernorm_bwd_din")
+
+
 def layernorm_bwd_deferrable(rows, H):
     return bool(lib().mmf_layernorm_bwd_deferrable(int(rows), int(H)))
 
@@ -462,6 +487,17 @@ def rows_scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, ou
            "mmf_rows_scatter_add")
 
 
+def embed_tables_bwd(x, ld, B, T, R, seg, vt, pos0, dpos, dtyp, dtyp_vis, dpos_vis, H):
+    """The four small table gradients of BertVisioLinguisticEmbeddings' backward in two launches (see mmf_embed_tables_bwd); outputs are added to."""
+    _req(x, torch.bfloat16, "x"); _req(seg, torch.int64, "seg"); _req(vt, torch.int64, "vt")
+    for t, n in ((dpos, "dpos"), (dtyp, "dtyp"), (dtyp_vis, "dtyp_vis"), (dpos_vis, "dpos_vis")):
+        _req(t, torch.float32, n)
+    ws = torch.empty(lib().mmf_embed_tables_bwd_ws_floats(T + R, H), dtype=torch.float32, device=x.device)
+    rows = lambda t: 0 if t is None else int(t.shape[0])
+    _check(lib().mmf_embed_tables_bwd(_p(x), ld, B, T, R, _p(seg), _p(vt), pos0, _p(dpos), rows(dpos), _p(dtyp), rows(dtyp), _p(dtyp_vis), rows(dtyp_vis),
+                                      _p(dpos_vis), H, _p(ws), _stream()), "mmf_embed_tables_bwd")
+
+
 def gate_sigmoid_fwd(z, gate, col0, B, Cn):
     """gate[:, col0:col0 + Cn] = 1 + sigmoid(z)  (ViLBERT dynamic_attention, vilbert.py:206-209); z fp32 [B, Cn], gate fp32 [B, ldg]."""
     _req(z, torch.float32, "z"); _req(gate, torch.float32, "gate")
@@ -550,6 +586,12 @@ def dropout(x, y, drop):
     k, t, sc, sd = _drop4(drop)
     _check(lib().mmf_dropout_bf16(_p(x), _p(y), C.c_int64(x.numel()), C.c_uint32(k), C.c_uint32(t), C.c_float(sc), sd, _stream()),
            "mmf_dropout_bf16")
+
+
+def step_advance(seed, state, schedule=0, warmup=0.0, total=0.0):
+    """seed_advance and optim_state_advance as one launch (either tensor may be None)."""
+    _req(seed, torch.int32, "seed"); _req(state, torch.float32, "state")
+    _check(lib().mmf_step_advance(_p(seed), _p(state), int(schedule), C.c_float(warmup), C.c_float(total), _stream()), "mmf_step_advance")
 
 
 def seed_advance(seed):

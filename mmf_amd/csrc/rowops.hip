@@ -225,7 +225,7 @@ DEVI float half_sum(float v) {      // sum over the 32 lanes of this half-wave
 template <int NC>   // NC = H / 256
 __global__ __launch_bounds__(256) void ln_fwd_h_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16* __restrict__ y,
-                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps) {
+                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps, DropoutCfg drop) {
     constexpr int H = NC * 256;
     const int hl = threadIdx.x & 31;
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -253,6 +253,13 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(const bf16* __restrict__ 
         f32x8r o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * g[i] + b[i];
+        if (drop.thr16) {      // nn.Dropout on the LayerNorm output (embeddings.py:345), element index row * H + col like mmf_dropout_bf16: the value is
+                               // rounded to bf16 first, as the two-launch form stores it between its kernels
+            const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
+            const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale), s1 = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i] = (float)(bf16)o[i] * s0[i]; o[i + 4] = (float)(bf16)o[i + 4] * s1[i]; }
+        }
         store8(yr + 256 * c, o);
     }
     if (hl == 0) {
@@ -268,7 +275,7 @@ template <int NC, bool DBIAS, int NR>
 __global__ __launch_bounds__(256) void ln_bwd_h_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, bf16* __restrict__ dx,
-                                                         bf16* __restrict__ dlin, DropoutCfg drop, float* __restrict__ partials, int rows) {
+                                                         bf16* __restrict__ dlin, DropoutCfg drop, float* __restrict__ partials, int rows, DropoutCfg din) {
     constexpr int H = NC * 256, NQ = DBIAS ? 3 : 2;
     __shared__ float red[8][H / 8 + 1][8];        // one quantity at a time: [half-wave][lane chunk][8]   (+1: bank spread)
     const int hl = threadIdx.x & 31, half = threadIdx.x >> 5;
@@ -294,6 +301,21 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(const bf16* __restrict__ 
 #pragma unroll
             for (int c = 0; c < NC; ++c) { xv[r][c] = load8(x + off + 256 * c); dv[r][c] = load8(dy + off + 256 * c); }
             mu[r] = mean[rowc]; rs[r] = rstd[rowc];
+        }
+        if (din.thr16) {      // the LayerNorm's OUTPUT went through nn.Dropout in the forward (embeddings.py:345): dy = dropout_backward(incoming), element
+                              // index row * H + col, rounded to bf16 like the separate mmf_dropout_bf16 launch stored it
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int row = row0 + r * rstride;
+                const int rowc = row < rows ? row : row0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t idx = (uint32_t)rowc * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
+                    const f32x4 s0 = drop_scale4(drop_key(din), idx, din.thr16, din.scale), s1 = drop_scale4(drop_key(din), idx + 4, din.thr16, din.scale);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { dv[r][c][i] = (float)(bf16)(dv[r][c][i] * s0[i]); dv[r][c][i + 4] = (float)(bf16)(dv[r][c][i + 4] * s1[i]); }
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -636,6 +658,83 @@ __global__ __launch_bounds__(256) void scatter_add_few_reduce_kernel(const float
     float s = 0.f;
     for (int g = 0; g < ngroups; ++g) s += partials[((size_t)g * 2 + k) * H + c];
     out[(size_t)k * H + c] += s;
+}
+
+// The four SMALL table gradients of BertVisioLinguisticEmbeddings' backward (embeddings.py:329-345, 411-419: text positions, text token types,
+// visual token types, the single visual position row) in ONE pass over the pre-LayerNorm gradient x [B, S = T + R, H] instead of
+// scatter_add_pos + 3 x (scatter_add_few + its reduction): seven short launches, ~80 us of a training step, each a serial walk of a few waves.
+// Workgroup (i, column block) owns sequence position i of EVERY sample: it adds the B rows x[b][i] in sample order, which is already the final
+// position row (text) and one partial of the bucket sums (token types 0 / 1; every visual row for position_ids_visual == 0).  partials
+// [S][3][H]: slots 0 / 1 = the rows with bucket 0 / 1, slot 2 = all rows; embed_tables_reduce_kernel adds them over i in a fixed order
+// (deterministic, no atomics for buckets 0 and 1; a bucket >= 2 — never produced by the path's tokenizers — falls back to atomics like scatter_add_few).
+__global__ __launch_bounds__(256) void embed_tables_bwd_kernel(const bf16* __restrict__ x, int ld, int B, int T, int R, const int64_t* __restrict__ seg,
+                                                                const int64_t* __restrict__ vt, int pos0, float* __restrict__ dpos,
+                                                                float* __restrict__ dtyp, int NT, float* __restrict__ dtyp_vis, int NTV,
+                                                                float* __restrict__ partials, int H) {
+    const int i = blockIdx.x, S = T + R;
+    const int col = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (col >= H) return;
+    const bool text = i < T;
+    const int64_t* ids = text ? seg : vt;
+    const int ild = text ? T : R, ii = text ? i : i - T;
+    float* tab = text ? dtyp : dtyp_vis;
+    const int nb = ids ? (text ? NT : NTV) : 1;
+    f32x4 all = {0.f, 0.f, 0.f, 0.f}, a0 = all, a1 = all;
+    constexpr int UN = 8;
+    for (int b0 = 0; b0 < B; b0 += UN) {
+        f32x4 v[UN];
+        int bk[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int b = b0 + u < B ? b0 + u : B - 1;
+            v[u] = load4(x + ((size_t)b * S + i) * ld + col);
+            bk[u] = ids ? (int)ids[(size_t)b * ild + ii] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (b0 + u < B) {
+                all += v[u];
+                if (bk[u] < 0 || bk[u] >= nb) { if (threadIdx.x == 0) flag_index_error(); }
+                else if (bk[u] == 0) a0 += v[u];
+                else if (bk[u] == 1) a1 += v[u];
+                else if (tab) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(tab + (size_t)bk[u] * H + col + j, v[u][j]);
+                }
+            }
+        }
+    }
+    if (text && dpos) {
+        float* o = dpos + (size_t)(pos0 + i) * H + col;
+        const f32x4 old = load4(o);
+        *reinterpret_cast<float4*>(o) = make_float4(old[0] + all[0], old[1] + all[1], old[2] + all[2], old[3] + all[3]);
+    }
+    float* p = partials + (size_t)i * 3 * H + col;
+    *reinterpret_cast<float4*>(p) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    *reinterpret_cast<float4*>(p + H) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    *reinterpret_cast<float4*>(p + 2 * H) = make_float4(all[0], all[1], all[2], all[3]);
+}
+// blockIdx.y = q: 0, 1 -> dtyp[q] += sum_{i < T} partials[i][q]; 2, 3 -> dtyp_vis[q - 2] += sum_{i >= T} partials[i][q - 2];
+// 4 -> dpos_vis[0] += sum_{i >= T} partials[i][2]
+__global__ __launch_bounds__(256) void embed_tables_reduce_kernel(const float* __restrict__ partials, int T, int R, int H, float* __restrict__ dtyp, int NT,
+                                                                   float* __restrict__ dtyp_vis, int NTV, float* __restrict__ dpos_vis) {
+    const int c = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
+    if (c >= H) return;
+    const bool text = q < 2;
+    const int slot = q == 4 ? 2 : (q & 1);
+    float* out = q == 4 ? dpos_vis : (text ? dtyp : dtyp_vis);
+    if (!out || (q < 4 && slot >= (text ? NT : NTV))) return;
+    const int i0 = text ? 0 : T, i1 = text ? T : T + R;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four interleaved chains (fixed association), loads independent of each other
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {
+        s0 += partials[((size_t)i * 3 + slot) * H + c];
+        s1 += partials[((size_t)(i + 1) * 3 + slot) * H + c];
+        s2 += partials[((size_t)(i + 2) * 3 + slot) * H + c];
+        s3 += partials[((size_t)(i + 3) * 3 + slot) * H + c];
+    }
+    for (; i < i1; ++i) s0 += partials[((size_t)i * 3 + slot) * H + c];
+    out[(size_t)(q == 4 ? 0 : slot) * H + c] += (s0 + s1) + (s2 + s3);
 }
 
 template <typename T>
@@ -1296,20 +1395,22 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 
 extern "C" {
 
-int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
-                      int H, float eps, void* stream) {
+static bool ln_h_path(int H) { return (H % 256) == 0 && H <= 1024 && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 1; }
+static int layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int H, float eps,
+                              DropoutCfg dc, void* stream) {
     MMF_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null operand");
     MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 2048, "layernorm_fwd: need H % 4 == 0 and H <= 2048");
+    MMF_CHECK_ARG(dc.thr16 == 0 || ln_h_path(H), "layernorm_dropout_fwd: the fused dropout is built for mmf_layernorm_dropout_fusable(H) widths");
     hipStream_t s = (hipStream_t)stream;
     const int nch = (H + 255) / 256;
     const bf16* xp = (const bf16*)x; bf16* yp = (bf16*)y;
-    if ((H % 256) == 0 && H <= 1024 && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 1) {     // half a wave per row, 16-byte accesses
+    if (ln_h_path(H)) {     // half a wave per row, 16-byte accesses
         const dim3 grid((rows + 7) / 8);
         switch (H / 256) {
-            case 1: hipLaunchKernelGGL(ln_fwd_h_kernel<1>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
-            case 2: hipLaunchKernelGGL(ln_fwd_h_kernel<2>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
-            case 3: hipLaunchKernelGGL(ln_fwd_h_kernel<3>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
-            default: hipLaunchKernelGGL(ln_fwd_h_kernel<4>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps); break;
+            case 1: hipLaunchKernelGGL(ln_fwd_h_kernel<1>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps, dc); break;
+            case 2: hipLaunchKernelGGL(ln_fwd_h_kernel<2>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps, dc); break;
+            case 3: hipLaunchKernelGGL(ln_fwd_h_kernel<3>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps, dc); break;
+            default: hipLaunchKernelGGL(ln_fwd_h_kernel<4>, grid, dim3(256), 0, s, xp, gamma, beta, yp, mean, rstd, rows, eps, dc); break;
         }
         MMF_CHECK_LAUNCH();
         return 0;
@@ -1323,6 +1424,14 @@ int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
     }
     MMF_CHECK_LAUNCH();
     return 0;
+}
+int mmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int H, float eps, void* stream) {
+    return layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, rows, H, eps, DropoutCfg{0u, 0u, 1.f, nullptr}, stream);
+}
+int mmf_layernorm_dropout_fusable(int H) { return ln_h_path(H) ? 1 : 0; }
+int mmf_layernorm_dropout_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int H, float eps,
+                              uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, void* stream) {
+    return layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, rows, H, eps, DropoutCfg{drop_key, drop_thr16, drop_scale, drop_seed}, stream);
 }
 
 int mmf_layernorm_bwd_ws_floats(int H) { return LNB_MAX_GRID * 3 * H; }
@@ -1355,10 +1464,11 @@ int mmf_layernorm_bwd_reduce_multi(const mmf_ln_reduce_list* d, void* stream) {
     return 0;
 }
 
-int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+static int layernorm_bwd_impl(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                       void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, float* dgamma,
-                      float* dbeta, float* dbias, int accumulate, float* partials, int rows, int H, void* stream) {
+                      float* dbeta, float* dbias, int accumulate, float* partials, int rows, int H, DropoutCfg din, void* stream) {
     MMF_CHECK_ARG(dy && x && mean && rstd && gamma && dx && partials, "layernorm_bwd: null operand");
+    MMF_CHECK_ARG(din.thr16 == 0 || lnb_h_path(H, dbias != nullptr), "layernorm_bwd_din: the fused input dropout is built for mmf_layernorm_dropout_fusable(H) widths");
     MMF_CHECK_ARG(rows > 0 && H > 0 && (H % 4) == 0 && H <= 2048, "layernorm_bwd: need H % 4 == 0 and H <= 2048");
     MMF_CHECK_ARG(drop_thr16 == 0 || dlin, "layernorm_bwd: dropout needs dlin");
     hipStream_t s = (hipStream_t)stream;
@@ -1370,9 +1480,9 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
         // two rows of a half-wave in flight whenever it owns more than one (MMF_TUN_LN_OLD = 2: one at a time, the round-3 form; A/B)
         const bool two = rows > 8 * grid && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 2;
 #define MMF_LNB_H(NC)                                                                                                              \
-        if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows); \
-        else if (two) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 2>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows); \
-        else hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows);
+        if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \
+        else if (two) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 2>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \
+        else hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din);
         switch (H / 256) {
             case 1: MMF_LNB_H(1) break;
             case 2: MMF_LNB_H(2) break;
@@ -1404,6 +1514,17 @@ int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
                        accumulate);
     MMF_CHECK_LAUNCH();
     return 0;
+}
+int mmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                      void* dlin, uint32_t drop_key, uint32_t drop_thr16, float drop_scale, const uint32_t* drop_seed, float* dgamma,
+                      float* dbeta, float* dbias, int accumulate, float* partials, int rows, int H, void* stream) {
+    return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dlin, drop_key, drop_thr16, drop_scale, drop_seed, dgamma, dbeta, dbias, accumulate, partials, rows, H,
+                              DropoutCfg{0u, 0u, 1.f, nullptr}, stream);
+}
+int mmf_layernorm_bwd_din(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx, uint32_t in_key, uint32_t in_thr16,
+                          float in_scale, const uint32_t* in_seed, float* dgamma, float* dbeta, int accumulate, float* partials, int rows, int H, void* stream) {
+    return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, nullptr, 0u, 0u, 1.f, nullptr, dgamma, dbeta, nullptr, accumulate, partials, rows, H,
+                              DropoutCfg{in_key, in_thr16, in_scale, in_seed}, stream);
 }
 
 int mmf_amd_take_index_error(void) {
@@ -1518,6 +1639,20 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
                            ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, skip_bucket, nbuckets);
     }
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmf_embed_tables_bwd_ws_floats(int S, int H) { return S * 3 * H; }
+int mmf_embed_tables_bwd(const void* x, int ld, int B, int T, int R, const int64_t* seg, const int64_t* vt, int pos0, float* dpos, int P, float* dtyp, int NT,
+                         float* dtyp_vis, int NTV, float* dpos_vis, int H, float* ws, void* stream) {
+    MMF_CHECK_ARG(x && ws && B > 0 && T > 0 && R >= 0 && (H % 4) == 0 && (ld % 4) == 0 && ld >= H, "embed_tables_bwd: bad operand");
+    MMF_CHECK_ARG(!dpos || (pos0 >= 0 && pos0 + T <= P), "embed_tables_bwd: positions outside the table");
+    MMF_CHECK_ARG((!dtyp || (seg && NT >= 1)) && (!dtyp_vis || (vt && NTV >= 1 && R > 0)) && (!dpos_vis || R > 0), "embed_tables_bwd: a table gradient without its index / rows");
+    hipLaunchKernelGGL(embed_tables_bwd_kernel, dim3(T + R, (H / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, B, T, R, dtyp ? seg : nullptr,
+                       dtyp_vis ? vt : nullptr, pos0, dpos, dtyp, NT, dtyp_vis, NTV, ws, H);
+    MMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(embed_tables_reduce_kernel, dim3((H + 255) / 256, R > 0 ? 5 : 2), dim3(256), 0, (hipStream_t)stream, ws, T, R, H, dtyp, NT, dtyp_vis, NTV, dpos_vis);
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -1790,6 +1925,27 @@ int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream) {
     const int cap = mmf_amd_get_tunable(MMF_TUN_ADAM_GRID);
     const int grid = (cap > 0 && cap < blocks) ? cap : blocks;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, bc1, bc2, blocks);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+// The two one-thread bookkeeping kernels at the head of a captured training step (dropout seed, optimizer step count / schedule factor) as ONE
+// launch: a launch costs ~4.7 us inside a replayed hipGraph whatever it computes (profiles/r05_graph_replay_kernels.txt).
+__global__ void step_advance_kernel(uint32_t* seed, float* state, int schedule, float warmup, float total) {
+    if (seed) seed[0] += 1u;
+    if (state) {
+        const float t = state[0] + 1.f;
+        state[0] = t;
+        float f = 1.f;
+        if (schedule == 1) {
+            const float s = t - 1.f;
+            f = (s < warmup) ? s / fmaxf(1.f, warmup) : fmaxf(0.f, (total - s) / fmaxf(1.f, total - warmup));
+        }
+        state[1] = f;
+    }
+}
+int mmf_step_advance(uint32_t* seed, float* state, int schedule, float warmup_steps, float total_steps, void* stream) {
+    MMF_CHECK_ARG((seed || state) && (schedule == 0 || schedule == 1), "step_advance: bad argument");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed, state, schedule, warmup_steps, total_steps);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -398,6 +398,22 @@ LnBwd ln_bwd(const Tensor& dy, const Tensor& y, const Tensor& mean, const Tensor
     return r;
 }
 
+// backward of dropout(LayerNorm(y)) with the dropout backward folded into the load of dy (embeddings.py:343-345)
+LnBwd ln_bwd_din(const Tensor& dy, const Tensor& y, const Tensor& mean, const Tensor& rstd, const Tensor& gamma, const Drop& in_drop) {
+    const int64_t M = y.size(0), N = y.size(1);
+    LnBwd r;
+    r.dx = empty_bf16({M, N}, y);
+    r.dgamma = empty_f32({N}, y); r.dbeta = empty_f32({N}, y);
+    Tensor ws = empty_f32({(int64_t)mmf_layernorm_bwd_ws_floats((int)N)}, y);
+    const bool defer = g_ln_defer && mmf_layernorm_bwd_deferrable((int)M, (int)N);
+    MMF_RC(mmf_layernorm_bwd_din(dy.data_ptr(), y.data_ptr(), PF(mean), PF(rstd), PF(gamma), r.dx.data_ptr(), in_drop.key, in_drop.thr16, in_drop.scale,
+                                 in_drop.seed_ptr(), defer ? nullptr : r.dgamma.data_ptr<float>(), defer ? nullptr : r.dbeta.data_ptr<float>(), 0,
+                                 ws.data_ptr<float>(), (int)M, (int)N, sp()), "mmf_layernorm_bwd_din");
+    if (defer) g_ln_pending.push_back(LnPending{ws, (int)M, (int)N, r.dgamma, r.dbeta});
+    r.dlin = r.dx;
+    return r;
+}
+
 // dense -> dropout -> (+ residual) -> LayerNorm   (HF BertSelfOutput / BertOutput)
 struct Ddrln { Tensor out, y, mean, rstd; };
 Ddrln ddrln_fwd(const Tensor& h2, const Tensor& resid2, const Tensor& w16, const Tensor& bias, const Tensor& gamma, const Tensor& beta, double eps,
@@ -709,12 +725,17 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
         }
         Tensor out = empty_bf16({B * S, H}, y), mean = empty_f32({B * S}, y), rstd = empty_f32({B * S}, y);
         req(ln_w, at::kFloat, "LayerNorm.weight"); req(ln_b, at::kFloat, "LayerNorm.bias");
-        MMF_RC(mmf_layernorm_fwd(y.data_ptr(), PF(ln_w), PF(ln_b), out.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(), (int)(B * S), (int)H, (float)eps,
-                                 sp()), "mmf_layernorm_fwd");
-        if (drop.on()) {
-            Tensor o2 = at::empty_like(out);
-            MMF_RC(mmf_dropout_bf16(out.data_ptr(), o2.data_ptr(), out.numel(), drop.key, drop.thr16, drop.scale, drop.seed_ptr(), sp()), "mmf_dropout_bf16");
-            out = o2;
+        if (drop.on() && mmf_layernorm_dropout_fusable((int)H)) {      // LayerNorm + nn.Dropout (embeddings.py:343-345) as one launch, same bits as the two below
+            MMF_RC(mmf_layernorm_dropout_fwd(y.data_ptr(), PF(ln_w), PF(ln_b), out.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(), (int)(B * S), (int)H,
+                                             (float)eps, drop.key, drop.thr16, drop.scale, drop.seed_ptr(), sp()), "mmf_layernorm_dropout_fwd");
+        } else {
+            MMF_RC(mmf_layernorm_fwd(y.data_ptr(), PF(ln_w), PF(ln_b), out.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(), (int)(B * S), (int)H,
+                                     (float)eps, sp()), "mmf_layernorm_fwd");
+            if (drop.on()) {
+                Tensor o2 = at::empty_like(out);
+                MMF_RC(mmf_dropout_bf16(out.data_ptr(), o2.data_ptr(), out.numel(), drop.key, drop.thr16, drop.scale, drop.seed_ptr(), sp()), "mmf_dropout_bf16");
+                out = o2;
+            }
         }
         ctx->save_for_backward({ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16, drop.seed, al});
         ctx->saved_data["dims"] = std::vector<int64_t>{B, T, R, S, H, word.size(0), pos.size(0), typ.size(0), typ_vis.size(0), pos_vis.size(0), pad_idx};
@@ -736,27 +757,36 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
         const int64_t B = d[0], T = d[1], R = d[2], S = d[3], H = d[4], V = d[5], Pn = d[6], NT = d[7], NTV = d[8], PV = d[9], pad = d[10];
         const Drop drop = drop_unpack(ctx->saved_data["drop"], sv[9]);
         Tensor dy = grad_bf16(grads[0], H);
-        if (drop.on()) {
-            Tensor d2 = at::empty_like(dy);
-            MMF_RC(mmf_dropout_bf16(dy.data_ptr(), d2.data_ptr(), dy.numel(), drop.key, drop.thr16, drop.scale, drop.seed_ptr(), sp()), "mmf_dropout_bf16");
-            dy = d2;
+        LnBwd l;
+        if (drop.on() && mmf_layernorm_dropout_fusable((int)H)) {      // dropout backward applied while the LayerNorm backward loads dy (same bits as the two launches)
+            l = ln_bwd_din(dy, y, mean, rstd, ln_w, drop);
+        } else {
+            if (drop.on()) {
+                Tensor d2 = at::empty_like(dy);
+                MMF_RC(mmf_dropout_bf16(dy.data_ptr(), d2.data_ptr(), dy.numel(), drop.key, drop.thr16, drop.scale, drop.seed_ptr(), sp()), "mmf_dropout_bf16");
+                dy = d2;
+            }
+            l = ln_bwd(dy, y, mean, rstd, ln_w, Drop(), false);
         }
-        LnBwd l = ln_bwd(dy, y, mean, rstd, ln_w, Drop(), false);
         const Tensor& dpre = l.dx;
         auto f32o = dpre.options().dtype(at::kFloat);
         // ONE zero fill for the five table gradients (row blocks of one buffer: each gradient is a contiguous [rows, H] view of it)
         Tensor tabs = at::zeros({V + Pn + NT + (R ? NTV + PV : 0), H}, f32o);
         Tensor dword = tabs.narrow(0, 0, V), dpos = tabs.narrow(0, V, Pn), dtyp = tabs.narrow(0, V + Pn, NT);
         scatter(dpre.data_ptr(), H, B, T, S, ids, T, 0, dword, H, 0, pad);      // padding_idx rows get no gradient
-        scatter(dpre.data_ptr(), H, B, T, S, Tensor(), 0, 1, dpos, H, 0, -1);
-        scatter(dpre.data_ptr(), H, B, T, S, seg, T, 0, dtyp, H, 1, -1);
         Tensor dtyp_vis, dpos_vis, dproj_w, dproj_b;
         if (R) {
-            const char* vis = reinterpret_cast<const char*>(dpre.data_ptr()) + T * H * 2;   // row (b, r) of the visual block lives at dpre[b*S + T + r]
             dtyp_vis = tabs.narrow(0, V + Pn + NT, NTV);
-            scatter(vis, H, B, R, S, vt, R, 0, dtyp_vis, H, 1, -1);
             dpos_vis = tabs.narrow(0, V + Pn + NT + NTV, PV);
-            scatter(vis, H, B, R, S, Tensor(), 0, 0, dpos_vis, H, 1, -1);
+        }
+        {   // text positions, text token types, visual token types, the visual position row: one pass over dpre (two launches instead of seven)
+            Tensor ws = empty_f32({(int64_t)mmf_embed_tables_bwd_ws_floats((int)S, (int)H)}, tabs);
+            MMF_RC(mmf_embed_tables_bwd(dpre.data_ptr(), (int)H, (int)B, (int)T, (int)R, seg.data_ptr<int64_t>(), R ? vt.data_ptr<int64_t>() : nullptr, 0,
+                                        dpos.data_ptr<float>(), (int)Pn, dtyp.data_ptr<float>(), (int)NT, R ? dtyp_vis.data_ptr<float>() : nullptr, (int)NTV,
+                                        R ? dpos_vis.data_ptr<float>() : nullptr, (int)H, ws.data_ptr<float>(), sp()), "mmf_embed_tables_bwd");
+        }
+        if (R) {
+            const char* vis = reinterpret_cast<const char*>(dpre.data_ptr()) + T * H * 2;   // row (b, r) of the visual block lives at dpre[b*S + T + r]
             if (sv[10].defined())       // the aligned words' TEXT position rows collect the regions' gradients / count
                 MMF_RC(mmf_align_pos_bwd(vis, (int)H, (int)B, (int)R, (int)S, sv[10].data_ptr<int64_t>(), dpos.data_ptr<float>(), (int)sv[10].size(1), (int)H, (int)Pn,
                                          sp()), "mmf_align_pos_bwd");
@@ -764,8 +794,13 @@ struct VisioLinguisticEmbeddingsFn : public torch::autograd::Function<VisioLingu
             MMF_RC(mmf_copy_rows_bf16(vis, (int)S, dvis.data_ptr(), (int)R, (int)B, (int)R, (int)H, sp()), "mmf_copy_rows_bf16");
             const int64_t D = f2.size(1);
             dproj_w = at::empty({H, D}, f32o);
-            Gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D).kmajor(true, true).run();
-            dproj_b = colsum(dvis, H, B * R, H);
+            if (f2.scalar_type() == at::kBFloat16) {      // the bias gradient = row sums of the GEMM's A operand: delivered by the same launch
+                dproj_b = at::empty({H}, f32o);
+                Gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D).kmajor(true, true).rowsum(dproj_b).run();
+            } else {                                     // (fp32 features staged by the GEMM: its row-sum form takes bf16 operands)
+                Gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D).kmajor(true, true).run();
+                dproj_b = colsum(dvis, H, B * R, H);
+            }
         }
         return {Tensor(), Tensor(), Tensor(), Tensor(), dword, dpos, dtyp, l.dgamma, l.dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, Tensor(), Tensor(), Tensor(), Tensor(),
                 Tensor()};

@@ -540,6 +540,22 @@ def _ln_bwd(dy, y, mean, rstd, gamma, drop, want_dbias):
     return dx, (dlin if dlin is not None else dx), dgamma, dbeta, dbias
 
 
+def _ln_bwd_din(dy, y, mean, rstd, gamma, in_drop):
+    """Backward of dropout(LayerNorm(y)) with the dropout backward folded into the load of dy (embeddings.py:343-345); returns (dx, dgamma, dbeta)."""
+    M, N = y.shape
+    dev = y.device
+    dx = torch.empty(M, N, dtype=BF16, device=dev)
+    dgamma = torch.empty(N, dtype=F32, device=dev)
+    dbeta = torch.empty(N, dtype=F32, device=dev)
+    ws = torch.empty(nat.layernorm_bwd_ws_floats(N), dtype=F32, device=dev)
+    if ln_defer.active and nat.layernorm_bwd_deferrable(M, N):
+        nat.layernorm_bwd_din(dy, y, mean, rstd, gamma, dx, in_drop, None, None, 0, ws, M, N)
+        ln_defer.pending.append((ws, M, N, dgamma, dbeta))
+    else:
+        nat.layernorm_bwd_din(dy, y, mean, rstd, gamma, dx, in_drop, dgamma, dbeta, 0, ws, M, N)
+    return dx, dgamma, dbeta
+
+
 class DenseDropoutResidualLNFn(torch.autograd.Function):
     """LayerNorm(dropout(h W^T + b) + residual)."""
 
@@ -1015,11 +1031,14 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
         out = torch.empty(B * S, H, dtype=BF16, device=dev)
         mean = torch.empty(B * S, dtype=F32, device=dev)
         rstd = torch.empty(B * S, dtype=F32, device=dev)
-        nat.layernorm_fwd(y, ln_w.detach(), ln_b.detach(), out, mean, rstd, B * S, H, eps)
-        if drop[1]:
-            out2 = torch.empty_like(out)
-            nat.dropout(out, out2, drop)
-            out = out2
+        if drop[1] and nat.layernorm_dropout_fusable(H):      # LayerNorm + nn.Dropout (embeddings.py:343-345) as one launch, same bits as the two below
+            nat.layernorm_dropout_fwd(y, ln_w.detach(), ln_b.detach(), out, mean, rstd, B * S, H, eps, drop)
+        else:
+            nat.layernorm_fwd(y, ln_w.detach(), ln_b.detach(), out, mean, rstd, B * S, H, eps)
+            if drop[1]:
+                out2 = torch.empty_like(out)
+                nat.dropout(out, out2, drop)
+                out = out2
         ctx.save_for_backward(ids, seg, f2, vt, y, mean, rstd, ln_w.detach(), proj_w16, al)
         ctx.meta = (B, T, R, S, H, drop, word.shape[0], pos.shape[0], typ.shape[0], typ_vis.shape[0], pos_vis.shape[0])
         ctx.pad_idx = -1 if pad_idx is None else int(pad_idx)
@@ -1031,31 +1050,37 @@ class VisioLinguisticEmbeddingsFn(torch.autograd.Function):
         B, T, R, S, H, drop, V, P, NT, NTV, PV = ctx.meta
         dev = y.device
         dy = _grad_bf16(g, H)
-        if drop[1]:
-            d2 = torch.empty_like(dy)
-            nat.dropout(dy, d2, drop)
-            dy = d2
-        dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, nat.NO_DROP, False)
-        dword = torch.zeros(V, H, dtype=F32, device=dev)
+        if drop[1] and nat.layernorm_dropout_fusable(H):      # dropout backward applied while the LayerNorm backward loads dy (same bits as the two launches)
+            dpre, dgamma, dbeta = _ln_bwd_din(dy, y, mean, rstd, ln_w, drop)
+        else:
+            if drop[1]:
+                d2 = torch.empty_like(dy)
+                nat.dropout(dy, d2, drop)
+                dy = d2
+            dpre, _, dgamma, dbeta, _ = _ln_bwd(dy, y, mean, rstd, ln_w, nat.NO_DROP, False)
+        # ONE zero fill for the five table gradients (row blocks of one buffer: each gradient is a contiguous [rows, H] view of it)
+        tabs = torch.zeros(V + P + NT + ((NTV + PV) if R else 0), H, dtype=F32, device=dev)
+        dword, dpos, dtyp = tabs[:V], tabs[V:V + P], tabs[V + P:V + P + NT]
         nat.rows_scatter_add(dpre, H, B, T, S, ids, T, 0, 0, dword, H, 0, ctx.pad_idx)   # padding_idx rows get no gradient
-        dpos = torch.zeros(P, H, dtype=F32, device=dev)
-        nat.rows_scatter_add(dpre, H, B, T, S, None, 0, 1, 0, dpos, H, 0)
-        dtyp = torch.zeros(NT, H, dtype=F32, device=dev)
-        nat.rows_scatter_add(dpre, H, B, T, S, seg, T, 0, 0, dtyp, H, 1)
         dtyp_vis = dpos_vis = dproj_w = dproj_b = None
         if R:
+            dtyp_vis, dpos_vis = tabs[V + P + NT:V + P + NT + NTV], tabs[V + P + NT + NTV:]
+        # text positions, text token types, visual token types, the visual position row: one pass over dpre (two launches instead of seven)
+        nat.embed_tables_bwd(dpre, H, B, T, R, seg, vt, 0, dpos, dtyp, dtyp_vis, dpos_vis, H)
+        if R:
             vis = dpre[T:]  # row (b, r) of the visual block lives at dpre[b*S + T + r]
-            dtyp_vis = torch.zeros(NTV, H, dtype=F32, device=dev)
-            nat.rows_scatter_add(vis, H, B, R, S, vt, R, 0, 0, dtyp_vis, H, 1)
-            dpos_vis = torch.zeros(PV, H, dtype=F32, device=dev)
-            nat.rows_scatter_add(vis, H, B, R, S, None, 0, 0, 0, dpos_vis, H, 1)
             if al is not None:          # the aligned words' TEXT position rows collect the regions' gradients / count
                 nat.align_pos_bwd(vis, H, B, R, S, al, dpos, al.shape[1], H)
-            dvis = dpre.view(B, S, H)[:, T:, :].contiguous().view(B * R, H)
+            dvis = torch.empty(B * R, H, dtype=BF16, device=dev)
+            nat.copy_rows(vis, S, dvis, R, B, R, H)
             D = f2.shape[1]
             dproj_w = torch.empty(H, D, dtype=F32, device=dev)
-            nat.gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D, a_kmajor=True, b_kmajor=True)
-            dproj_b = _colsum(dvis, H, B * R, H)
+            if f2.dtype == BF16:      # the bias gradient = row sums of the GEMM's A operand: delivered by the same launch
+                dproj_b = torch.empty(H, dtype=F32, device=dev)
+                nat.gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D, a_kmajor=True, b_kmajor=True, rowsum_out=dproj_b)
+            else:                     # (fp32 features staged by the GEMM: its row-sum form takes bf16 operands)
+                nat.gemm(dvis, f2, dproj_w, H, D, B * R, H, D, D, a_kmajor=True, b_kmajor=True)
+                dproj_b = _colsum(dvis, H, B * R, H)
         return (None, None, None, None, dword, dpos, dtyp, dgamma, dbeta, dtyp_vis, dpos_vis, dproj_w, dproj_b, None, None, None, None, None)
 
 

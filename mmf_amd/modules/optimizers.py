@@ -181,6 +181,16 @@ class AdamW(torch.optim.Optimizer):
                 nat.set_tunable(nat.TUN_ADAM_GRID, 0)
             Fn.shadows.refresh_transposed(only=list(params))
 
+    @torch.no_grad()
+    def advance(self, seed=None):
+        """Advance the device-side step count / schedule factor now — and, in the SAME one-thread launch, the dropout seed word of a captured step
+        (`mmf_step_advance`) — instead of at the start of `step()`; the caller then passes `advance=False` to `step()`."""
+        if not self.capturable:
+            raise RuntimeError("advance() is for capturable=True optimizers (the counters live in device memory)")
+        if self._dev_state is None:
+            self._dev_state = torch.zeros(2, dtype=torch.float32, device=self.param_groups[0]["params"][0].device)
+        nat.step_advance(seed, self._dev_state, *self._schedule)
+
     def _grad_of(self, p):
         if self.external_grads is not None:
             g = self.external_grads.get(id(p))
@@ -210,8 +220,11 @@ class AdamW(torch.optim.Optimizer):
             if early is None and advance:      # (begin_step already advanced the counters of a step opened for in-backward updates)
                 nat.optim_state_advance(self._dev_state, *self._schedule)
             dev_state = self._dev_state
+        # Learning rate and weight decay travel per tensor, so parameter groups that share betas / eps / correct_bias (the two BERT groups of
+        # mmf/utils/modeling.py:18-46 and a finetune-LR group always do) share launches: ceil(tensors / MMF_MT_MAX) launches per step instead of that per group.
+        launches = {}
         for group in self.param_groups:
-            by_step = {}
+            b1, b2 = group["betas"]
             for p in group["params"]:
                 if only is not None and id(p) not in only:
                     continue
@@ -229,13 +242,11 @@ class AdamW(torch.optim.Optimizer):
                 # that first receives a gradient late starts at 1, and checkpoints exchange with the reference optimizer
                 st["step"] = int(st.get("step", 0)) + 1
                 g = grad if grad.is_contiguous() else grad.contiguous()
-                by_step.setdefault(st["step"], []).append(
+                launches.setdefault((st["step"], float(b1), float(b2), float(group["eps"]), bool(group["correct_bias"])), []).append(
                     (p, g, st["exp_avg"], st["exp_avg_sq"], Fn.shadows.slot(p), group["lr"], group["weight_decay"]))
-            b1, b2 = group["betas"]
-            norm_sq, max_norm = self._clip if self._clip is not None else (None, 0.0)
-            for step, items in sorted(by_step.items()):       # one launch per distinct step count (normally exactly one)
-                nat.adamw_multi(items, b1, b2, group["eps"], step, group["correct_bias"], 1 if self.torch_mode else 0,
-                                self.grad_scale, norm_sq, max_norm, dev_state)
+        norm_sq, max_norm = self._clip if self._clip is not None else (None, 0.0)
+        for (step, b1, b2, eps, correct_bias), items in sorted(launches.items(), key=lambda kv: kv[0]):       # (normally exactly one key)
+            nat.adamw_multi(items, b1, b2, eps, step, correct_bias, 1 if self.torch_mode else 0, self.grad_scale, norm_sq, max_norm, dev_state)
         self._clip = None
         if only is not None:
             Fn.shadows.refresh_transposed(only=[p for g_ in self.param_groups for p in g_["params"] if id(p) in only])

@@ -137,14 +137,19 @@ class GraphedTrainStep:
                 _ops_native.pop_mode(1)
 
     def _eager_body(self, update):
-        Fn.nat.seed_advance(self.seed)
+        early = self.update_stream is not None and update
+        # the dropout seed word and the optimizer's step count / schedule factor advance in ONE one-thread launch at the head of the step
+        head_advance = self.optimizer is not None and update and not early and hasattr(self.optimizer, "advance")
+        if head_advance:
+            self.optimizer.advance(self.seed)
+        else:
+            Fn.nat.seed_advance(self.seed)
         out = self.model(self.static_batch)
         loss = self.loss_of(out)
         # torch.autograd.grad instead of loss.backward(): AccumulateGrad nodes are bound to the stream they were first
         # created on; if an earlier eager step created them on the legacy default stream, running them inside the
         # capture drags that stream into it and hipStreamEndCapture crashes.  Capturing the gradients directly keeps
         # every captured node on the capture stream.
-        early = self.update_stream is not None and update
         if early:
             self.optimizer.pin_to_attention = self.pin_update
             self.optimizer.begin_step(self.update_stream)
@@ -158,7 +163,8 @@ class GraphedTrainStep:
         for p, g in zip(self.params, grads):
             p.grad = g
         if self.optimizer is not None and update:
-            self.optimizer.step()       # (closes a step opened by begin_step: the remaining parameters, then joins the update stream)
+            # (closes a step opened by begin_step: the remaining parameters, then joins the update stream)
+            self.optimizer.step(**({"advance": False} if head_advance else {}))
         return out, loss
 
     def __call__(self, batch=None):

@@ -11,6 +11,7 @@ from mmf_amd import _native as N
 _INT_RETURNS = {
     "layernorm_bwd_ws_floats": lambda H: 64 * 3 * H, "colsum_ws_floats": lambda n: 64 * n,
     "gemm_rowsum_supported": lambda M, Nn, K: True,
+    "layernorm_dropout_fusable": lambda H: H % 256 == 0 and H <= 1024,
 }
 _KEEP = {"drop_cfg", "_drop4", "lib", "_check", "_stream", "_p", "_req", "gemm_site"}
 calls = []
@@ -240,6 +241,20 @@ def _scatter_add(x, ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H
     assert out.dtype == torch.float32 and out.shape[1] == H
 
 
+def _embed_tables_bwd(x, ld, B, T, R, seg, vt, pos0, dpos, dtyp, dtyp_vis, dpos_vis, H):
+    calls.append(("embed_tables_bwd",))
+    _need(x, B * (T + R), ld, H, "embed_tables_bwd x")
+    assert seg is None or (seg.dtype == torch.int64 and seg.numel() == B * T)
+    assert (R == 0) == (vt is None) or dtyp_vis is None
+    assert vt is None or (vt.dtype == torch.int64 and vt.numel() == B * R)
+    for t, need in ((dpos, pos0 + T), (dtyp, 1), (dtyp_vis, 1), (dpos_vis, 1)):
+        assert t is None or (t.dtype == torch.float32 and t.shape[1] == H and t.shape[0] >= need and t.is_contiguous())
+    if seg is not None and dtyp is not None:
+        assert int(seg.max()) < dtyp.shape[0]
+    if vt is not None and dtyp_vis is not None:
+        assert int(vt.max()) < dtyp_vis.shape[0]
+
+
 def _cast2d_f32(src, lds, dst, ldd, rows, cols):
     assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16
     _need(src, rows, lds, cols, "cast2d src"); _need(dst, rows, ldd, ldd, "cast2d dst")
@@ -310,7 +325,7 @@ def _reduce_batch(g, dx, Bs, reps, n, mode):
 _CHECKED = {"expand_batch": _expand_batch, "reduce_batch": _reduce_batch, "visual_masks": _visual_masks, "mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "attention_f32_bwd": _attention_f32_bwd, "layernorm_f32_fwd": _layernorm_f32_fwd,
             "embed_text_f32_fwd": _embed_text_f32, "gather_rows_f32": _gather_rows_f32, "gemm": _gemm, "gemm_grouped": _gemm_grouped, "attention_fwd": _attention_fwd, "attention_bwd": _attention_bwd, "copy_rows": _copy_rows,
             "l2norm_rows_fwd": _l2norm_fwd, "l2norm_rows_bwd": _l2norm_bwd, "gather_rows2": _gather_rows2, "ptr_scores_fwd": _ptr_fwd,
-            "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "cast2d_f32_to_bf16": _cast2d_f32,
+            "ptr_scores_bwd": _ptr_bwd, "rows_scatter_add": _scatter_add, "embed_tables_bwd": _embed_tables_bwd, "cast2d_f32_to_bf16": _cast2d_f32,
             "bce_rowmask_fwd": _bce_rowmask_fwd, "bce_rowmask_bwd": _bce_rowmask_bwd}
 
 

@@ -748,6 +748,89 @@ def test_embed_text_and_scatter_add():
     close(dpv[0], d3[:, T:].sum((0, 1)), 1e-4, 1e-3, "dpos_visual")
 
 
+@pytest.mark.parametrize("B,T,R,H", [(32, 128, 100, 768), (3, 7, 0, 256), (5, 16, 9, 1024), (2, 4, 3, 100)])
+def test_embed_tables_bwd_is_the_four_scatter_adds(B, T, R, H):
+    """mmf_embed_tables_bwd (text positions, text token types, visual token types, the visual position row in two launches) against torch and against
+    the per-table mmf_rows_scatter_add launches it replaces; outputs are added to (the aligned-position term lands in dpos afterwards)."""
+    S, P, NT, NTV, PV = T + R, T + 5, 2, 2, 1
+    d = rnd(B * S, H, seed=B * 1000 + H)
+    d3 = d.view(B, S, H).float()
+    seg = torch.randint(0, NT, (B, T), device=DEV)
+    vt = torch.randint(0, NTV, (B, R), device=DEV) if R else None
+    base = rnd(P + NT + NTV + PV, H, dtype=torch.float32, seed=7)
+    got = base.clone()
+    dpos, dtyp, dtv, dpv = got[:P], got[P:P + NT], got[P + NT:P + NT + NTV], got[P + NT + NTV:]
+    nat().embed_tables_bwd(d, H, B, T, R, seg, vt, 2, dpos, dtyp, dtv if R else None, dpv if R else None, H)
+    ref = base.clone().double()
+    ref[2:2 + T] += d3[:, :T].double().sum(0)
+    ref[P:P + NT].index_add_(0, seg.view(-1), d3[:, :T].reshape(-1, H).double())
+    if R:
+        ref[P + NT:P + NT + NTV].index_add_(0, vt.view(-1), d3[:, T:].reshape(-1, H).double())
+        ref[P + NT + NTV] += d3[:, T:].double().sum((0, 1))
+    close(got, ref.float(), 1e-5, 1e-4 * math.sqrt(B * max(T, R, 1)), "embed_tables_bwd")
+    if H % 4 == 0:
+        old = torch.zeros_like(base)
+        nat().rows_scatter_add(d, H, B, T, S, None, 0, 1, 2, old[:P], H, 0)
+        nat().rows_scatter_add(d, H, B, T, S, seg, T, 0, 0, old[P:P + NT], H, 1)
+        if R:
+            nat().rows_scatter_add(d[T:], H, B, R, S, vt, R, 0, 0, old[P + NT:P + NT + NTV], H, 1)
+            nat().rows_scatter_add(d[T:], H, B, R, S, None, 0, 0, 0, old[P + NT + NTV:], H, 1)
+        close(got - base, old, 1e-5, 1e-4 * math.sqrt(B * max(T, R, 1)), "embed_tables_bwd vs rows_scatter_add")
+    assert nat().take_index_error() is False
+    # a token type outside its table is skipped and flagged; the position sums do not depend on it
+    bad = seg.clone(); bad[0, 0] = NT + 3
+    got2 = torch.zeros_like(base)
+    nat().embed_tables_bwd(d, H, B, T, R, bad, vt, 2, got2[:P], got2[P:P + NT], got2[P + NT:P + NT + NTV] if R else None, got2[P + NT + NTV:] if R else None, H)
+    assert nat().take_index_error() is True
+    close(got2[:P], (got - base)[:P], 1e-5, 1e-5, "positions unaffected by a bad type id")      # (`got` carries `base`: one fp32 rounding apart)
+    keep = torch.ones(B, T, dtype=torch.bool, device=DEV); keep[0, 0] = False
+    ok = torch.zeros(NT, H, device=DEV, dtype=torch.float64).index_add_(0, seg[keep], d3[:, :T][keep].double())
+    close(got2[P:P + NT], ok.float(), 1e-5, 1e-4 * math.sqrt(B * T), "in-range rows still accumulate")
+
+
+@pytest.mark.parametrize("rows,H", [(7296, 768), (100, 256), (33, 1024)])
+def test_layernorm_with_fused_dropout_is_bit_identical_to_two_launches(rows, H):
+    """dropout(LayerNorm(x)) of BertVisioLinguisticEmbeddings (embeddings.py:343-345) as one launch each way == mmf_layernorm_fwd + mmf_dropout_bf16 and
+    mmf_dropout_bf16 + mmf_layernorm_bwd, bit for bit (deferred and immediate column sums)."""
+    assert nat().layernorm_dropout_fusable(H) and not nat().layernorm_dropout_fusable(300)
+    x = rnd(rows, H, seed=rows + H); gamma = rnd(H, dtype=torch.float32, seed=1) + 1.0; beta = rnd(H, dtype=torch.float32, seed=2)
+    drop = nat().drop_cfg(0.1, 1234567)
+    y0 = torch.empty_like(x); y1 = torch.empty_like(x); y = torch.empty_like(x)
+    mean0 = torch.empty(rows, device=DEV); rstd0 = torch.empty(rows, device=DEV); mean1 = torch.empty(rows, device=DEV); rstd1 = torch.empty(rows, device=DEV)
+    nat().layernorm_fwd(x, gamma, beta, y0, mean0, rstd0, rows, H, 1e-12)
+    nat().dropout(y0, y1, drop)
+    nat().layernorm_dropout_fwd(x, gamma, beta, y, mean1, rstd1, rows, H, 1e-12, drop)
+    assert torch.equal(y, y1) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    assert 0.05 < float((y == 0).float().mean()) < 0.15
+    dy = rnd(rows, H, seed=5)
+    d2 = torch.empty_like(dy)
+    nat().dropout(dy, d2, drop)
+    ws = torch.empty(nat().layernorm_bwd_ws_floats(H), device=DEV)
+    dx0 = torch.empty_like(x); dg0 = torch.empty(H, device=DEV); db0 = torch.empty(H, device=DEV)
+    nat().layernorm_bwd(d2, x, mean0, rstd0, gamma, dx0, None, nat().NO_DROP, dg0, db0, None, 0, ws, rows, H)
+    dx1 = torch.empty_like(x); dg1 = torch.empty(H, device=DEV); db1 = torch.empty(H, device=DEV)
+    nat().layernorm_bwd_din(dy, x, mean0, rstd0, gamma, dx1, drop, dg1, db1, 0, ws, rows, H)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    if nat().layernorm_bwd_deferrable(rows, H):
+        dx2 = torch.empty_like(x); dg2 = torch.empty(H, device=DEV); db2 = torch.empty(H, device=DEV)
+        nat().layernorm_bwd_din(dy, x, mean0, rstd0, gamma, dx2, drop, None, None, 0, ws, rows, H)
+        nat().layernorm_bwd_reduce_multi([(ws, rows, H, dg2, db2)])
+        assert torch.equal(dx0, dx2) and torch.equal(dg0, dg2) and torch.equal(db0, db2)
+    with pytest.raises(nat().NativeLibraryError):
+        nat().layernorm_dropout_fwd(x[:, :300].contiguous(), gamma[:300].contiguous(), beta[:300].contiguous(), y[:, :300].contiguous(), mean1, rstd1, rows, 300, 1e-12, drop)
+
+
+def test_step_advance_is_seed_advance_plus_optim_state_advance():
+    seed = torch.tensor([41], dtype=torch.int32, device=DEV); state = torch.tensor([9.0, 0.0], device=DEV)
+    seed2 = seed.clone(); state2 = state.clone()
+    nat().seed_advance(seed2); nat().optim_state_advance(state2, 1, 4.0, 100.0)
+    nat().step_advance(seed, state, 1, 4.0, 100.0)
+    assert torch.equal(seed, seed2) and torch.equal(state, state2) and int(seed) == 42 and float(state[0]) == 10.0
+    nat().step_advance(None, state, 0)
+    nat().step_advance(seed, None)
+    assert int(seed) == 43 and state.tolist() == [11.0, 1.0]
+
+
 def test_embedding_indices_are_bounded_like_nn_embedding():
     """nn.Embedding raises IndexError for an id outside its table; here the host cannot see device ids without a sync, so the
     kernels skip the offending rows (forward: zero row; backward: no atomic write out of bounds) and raise a device flag that

@@ -56,7 +56,9 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
                                       up-projection's GELU output and the FFN-down dgrad's du, the two A operands of the K = 3072 GEMMs); 1: no site at all (A/B) */
        MMF_TUN_ACT2_TILE = 15,     /* 1: the act-2 (times saved gelu') dgrad of the FFN takes the cost model's tile (256x128) instead of 256x96, the tile that measured
                                       0.22 - 0.32 ms per step faster INSIDE the step (round 4; A/B) */
-       MMF_TUN_COUNT = 16 };
+       MMF_TUN_ATTN_KEEP_BITS_OFF = 16,   /* 1: mmf_attention_keep_bits_words returns 0 — the attention backward hashes its dropout decisions again instead of reading
+                                             the forward's keep-bit table (A/B: tools/step_ab.py 16:1 16:0) */
+       MMF_TUN_COUNT = 17 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)
@@ -205,8 +207,16 @@ typedef struct mmf_attn_desc {
                               BertSelfAttentionJit.forward accepts as a [B, 1, S, S] attention_mask (`attention_scores + attention_mask`,
                               mmf/modules/hf_layers.py:187-190; MMT.forward builds one, mmf/models/m4c.py:424-440).  head_dim 64, forward and backward;
                               replaces `causal_tail` (which is the cheaper form of M4C's mask). */
+    uint32_t* keep_bits;   /* optional, NULL = off.  The probability-dropout decisions of the forward as a bit table: the forward writes it while it draws them
+                              (one ballot per MFMA register, no second hash), the backward reads ONE word per lane and key tile instead of hashing every
+                              probability again — the counter hash is the largest VALU item of the backward (12.6 of 58 us at the VQA2 shape,
+                              profiles/r05_experiments.txt).  Same decisions, bit for bit.  mmf_attention_keep_bits_words(...) 32-bit words, 0 = this
+                              shape's kernels do not take a table (pass NULL).  Word ((bh * nqt + qt) * nkt + kt) * 32 + j, bit x = keep(query 32 qt + x,
+                              key 32 kt + j); nqt = ceil(Sq / 32), nkt = ceil(Sk / 32). */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
+/* Words of mmf_attn_desc.keep_bits for this shape, 0 when its kernels hash in both directions (head_dim 128, <= 128 queries or keys, > 256 of either). */
+int64_t mmf_attention_keep_bits_words(int B, int heads, int Sq, int Sk, int head_dim);
 
 /* Backward of the same operator (what autograd derives for BertSelfAttentionJit.forward, mmf/modules/hf_layers.py:138-213, in the reference):
  * dQ, dK, dV from dctx with the probabilities recomputed from the saved row log-sum-exp and the dropout decisions replayed from the key. */

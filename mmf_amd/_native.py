@@ -50,6 +50,7 @@ class AttnDesc(C.Structure):
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("head_dim", C.c_int), ("ctx_f32", C.c_void_p), ("causal_tail", C.c_int),
         ("q_batch_rows", C.c_int), ("kv_batch_rows", C.c_int), ("mask_batch_stride", C.c_int), ("mask_query_stride", C.c_int),
+        ("keep_bits", C.c_void_p),
     ]
 
 
@@ -315,9 +316,18 @@ def gemm_rowsum_supported(M, N, K):
 # --------------------------------------------------------------------------------------------
 # attention
 # --------------------------------------------------------------------------------------------
+def attention_keep_bits_words(B, heads, Sq, Sk, head_dim=64):
+    """int32 words of the dropout keep-bit table the forward can hand to the backward for this shape (`keep_bits=`), 0 = these kernels take none."""
+    f = lib().mmf_attention_keep_bits_words
+    f.restype = C.c_int64
+    return int(f(int(B), int(heads), int(Sq), int(Sk), int(head_dim)))
+
+
 def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim=64, ctx_f32=None,
-               causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0):
+               causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None):
     d = AttnDesc()
+    _req(keep_bits, torch.int32, "keep_bits")
+    d.keep_bits = _p(keep_bits)
     # a 3-D mask [B, Sq, Sk] is a materialised additive mask per (query, key) pair (mmf_attn_desc.mask_query_stride); 2-D: the key mask [B, Sk]
     d.mask_query_stride = int(mask.stride(1)) if (mask is not None and mask.dim() == 3) else 0
     if d.mask_query_stride and not mask_batch_stride:
@@ -342,18 +352,19 @@ def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, sc
 
 
 def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP, head_dim=64, ctx_f32=None,
-                  causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0):
+                  causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None):
     """`q_batch_rows` / `kv_batch_rows` / `mask_batch_stride` (forward only): q, k / v and the mask may live inside longer
-    per-sample buffers (a K|V cache); 0 = the dense defaults Sq / Sk / Sk."""
+    per-sample buffers (a K|V cache); 0 = the dense defaults Sq / Sk / Sk.  `keep_bits`: int32 [attention_keep_bits_words(...)], the forward
+    writes its dropout decisions there for `attention_bwd(..., keep_bits=)` (which then does not hash them again)."""
     d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail,
-                   q_batch_rows, kv_batch_rows, mask_batch_stride)
+                   q_batch_rows, kv_batch_rows, mask_batch_stride, keep_bits)
     _check(lib().mmf_attention_fwd(C.byref(d), _stream()), "mmf_attention_fwd")
 
 
 def attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta,
-                  drop=NO_DROP, head_dim=64, ctx_f32=None, causal_tail=0):
+                  drop=NO_DROP, head_dim=64, ctx_f32=None, causal_tail=0, keep_bits=None):
     d = AttnBwdDesc()
-    d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail)
+    d.f = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail, keep_bits=keep_bits)
     for t, n in ((dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, torch.bfloat16, n)
     _req(delta, torch.float32, "delta")

@@ -203,6 +203,7 @@ struct AttnArgs {
     int m_qs;                // per-query mask (mmf_attn_desc.mask_query_stride): mask entries between consecutive query rows; 0 = one mask row per batch
     float scale;
     DropoutCfg drop;
+    uint32_t* keep;          // optional dropout keep-bit table (mmf_attn_desc.keep_bits): written by attn_fwd8_kernel<8, *>, read by attn_bwd_fused_kernel<64, 8, *>
     // backward only
     const bf16* dctx; bf16* dq; bf16* dk; bf16* dv; float* delta;
 };
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
         float sum = 0.f;
         const uint32_t dkey = drop_key(a.drop);
         const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
+        const int NKT_RT = a.skp >> 5;      // key tiles of the keep-bit table (tiles past it hold padding keys only: nothing to record)
 #pragma unroll 2
         for (int t = 0; t < NKT; ++t) {
             f32x16 acc = {};
@@ -482,11 +484,41 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
                 }
             }
             if (a.drop.thr16) {
+                if (a.keep) {
+                    // The decisions also go to the keep-bit table the backward reads: the compare of register (c, i) IS a 64-bit lane mask — low
+                    // half = key 8c + i of this tile against the wave's 32 queries, high half = key 8c + 4 + i — i.e. two finished table words;
+                    // lane j < 32 collects the word of key j (v_writelane) and the half-wave stores 128 contiguous bytes per tile.
+                    int kw = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 ds = drop_scale4(dkey, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t idx4 = rowbase + 32 * t + 8 * c + 4 * h;
+                        const uint32_t h0 = drop_hash(dkey, idx4 >> 1), h1 = drop_hash(dkey, (idx4 >> 1) + 1);
+                        const uint32_t half[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+                        unsigned long long m[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[4 * c + i] *= ds[i];
+                        for (int i = 0; i < 4; ++i) {
+                            const bool keep = half[i] >= a.drop.thr16;
+                            m[i] = __builtin_amdgcn_ballot_w64(keep);
+                            acc[4 * c + i] *= keep ? a.drop.scale : 0.f;
+                        }
+                        // (s_nop: a lane mask written by a VALU compare is not yet visible to v_writelane as DATA in the next slots — measured: without it
+                        // nine of the 32 words of a tile come out stale; the compiler's hazard recognizer does not look into inline assembly)
+                        asm volatile("s_nop 4\n\t"
+                                     "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
+                                     "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\tv_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
+                                     : "+v"(kw)
+                                     : "s"((uint32_t)m[0]), "s"((uint32_t)m[1]), "s"((uint32_t)m[2]), "s"((uint32_t)m[3]), "s"((uint32_t)(m[0] >> 32)),
+                                       "s"((uint32_t)(m[1] >> 32)), "s"((uint32_t)(m[2] >> 32)), "s"((uint32_t)(m[3] >> 32)), "n"(8 * c), "n"(8 * c + 1),
+                                       "n"(8 * c + 2), "n"(8 * c + 3), "n"(8 * c + 4), "n"(8 * c + 5), "n"(8 * c + 6), "n"(8 * c + 7));
+                    }
+                    if (lane < 32 && t < NKT_RT) a.keep[(((size_t)bh * ((a.Sq + 31) >> 5) + (q0 >> 5)) * NKT_RT + t) * 32 + lane] = (uint32_t)kw;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 ds = drop_scale4(dkey, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[4 * c + i] *= ds[i];
+                    }
                 }
             }
 #pragma unroll
@@ -873,9 +905,20 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_kernel(AttnArgs a) 
     const float sc2 = a.scale * 1.4426950408889634f;
     const uint32_t dkey = drop_key(a.drop);
     f32x16 dko[NDT] = {}, dvo[NDT] = {}, dqo[NDT] = {};
+    // keep-bit table of the forward (mmf_attn_desc.keep_bits): this lane's key against the 32 queries of tile t is ONE word; the word of the next step is
+    // fetched a step ahead
+    const int nkt_rt = a.skp >> 5;
+    const uint32_t* kbits = a.keep ? a.keep + ((size_t)bh * nqt * nkt_rt + wave) * 32 + x : nullptr;
+    uint32_t kw_next = 0;
+    if (kbits && produce && wave < nqt) kw_next = kbits[(size_t)wave * nkt_rt * 32];      // (step 0: query tile = wave)
 #pragma unroll 1
     for (int it = 0; it < NW; ++it) {
         const int t = (wave + it) & (NW - 1);          // query tile this wave produces dS for in this step
+        const uint32_t kw = kw_next >> (4 * h);        // bit 8c + i = keep(query 32t + 8c + 4h + i, this key)
+        if (kbits && produce) {
+            const int tn = (wave + it + 1) & (NW - 1);
+            if (it + 1 < NW && tn < nqt) kw_next = kbits[(size_t)tn * nkt_rt * 32];
+        }
         if (produce && t < nqt) {
             unsigned char* patch = patches + ((it & 1) * NW + wave) * 2048;
             // S[q][key], dPd[q][key]: rows q = 32t + (r&3) + 8(r>>2) + 4h, column key = k0 + x
@@ -893,7 +936,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_kernel(AttnArgs a) 
                 const float Lv[4] = {L4.x, L4.y, L4.z, L4.w};
                 const float Dv[4] = {D4.x, D4.y, D4.z, D4.w};
                 float dsc[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.drop.thr16) {
+                if (kbits) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsc[i] = (kw & (1u << (8 * c + i))) ? a.drop.scale : 0.f;
+                } else if (a.drop.thr16) {
                     // one hash serves the two keys of a pair (neighbouring lanes): even lanes hash queries i = 0, 2, odd lanes
                     // i = 1, 3, and the lanes swap (DPP quad_perm 1,0,3,2) — half the hashing of a per-element draw
 #pragma unroll
@@ -972,6 +1018,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_kernel(AttnArgs a) 
     PROBE_FLUSH(3, bh, wave);
 }
 
+// shapes whose forward is attn_fwd8_kernel<8, *> with one workgroup per (batch, head) AND whose backward is attn_bwd_fused_kernel<64, 8, *>
+bool keep_bits_shape(int hd, int Sq, int Sk) { return hd == 64 && Sq > 128 && Sq <= 256 && Sk > 128 && Sk <= 256; }
+
 int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     MMF_CHECK_ARG(d && d->q && d->k && d->v, "attention: null operand");
     MMF_CHECK_ARG(d->B > 0 && d->heads > 0 && d->Sq > 0 && d->Sk > 0, "attention: empty shape");
@@ -1001,6 +1050,9 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.scale = d->scale;
     a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
+    a.keep = d->keep_bits;
+    MMF_CHECK_ARG(!a.keep || (d->drop_thr16 != 0 && keep_bits_shape(hd, d->Sq, d->Sk) && d->q_batch_rows == 0 && d->kv_batch_rows == 0),
+                  "attention: keep_bits is taken by the head_dim-64 kernels for 129..256 queries and keys with dropout on (mmf_attention_keep_bits_words)");
     return 0;
 }
 
@@ -1012,6 +1064,14 @@ int set_lds(K kern, int bytes) {
 }
 
 }  // namespace
+
+extern "C" int64_t mmf_attention_keep_bits_words(int B, int heads, int Sq, int Sk, int head_dim) {
+    const int hd = head_dim ? head_dim : 64;
+    if (B <= 0 || heads <= 0 || !keep_bits_shape(hd, Sq, Sk)) return 0;
+    if (mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD) || mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS) || mmf_amd_get_tunable(MMF_TUN_ATTN_KEEP_BITS_OFF))
+        return 0;      // (the A/B forms hash in both directions)
+    return (int64_t)B * heads * ((Sq + 31) / 32) * ((Sk + 31) / 32) * 32;
+}
 
 extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     AttnArgs a;

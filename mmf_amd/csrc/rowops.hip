@@ -715,26 +715,30 @@ __global__ __launch_bounds__(256) void embed_tables_bwd_kernel(const bf16* __res
     *reinterpret_cast<float4*>(p + 2 * H) = make_float4(all[0], all[1], all[2], all[3]);
 }
 // blockIdx.y = q: 0, 1 -> dtyp[q] += sum_{i < T} partials[i][q]; 2, 3 -> dtyp_vis[q - 2] += sum_{i >= T} partials[i][q - 2];
-// 4 -> dpos_vis[0] += sum_{i >= T} partials[i][2]
+// 4 -> dpos_vis[0] += sum_{i >= T} partials[i][2].  64 columns per workgroup; the positions are dealt to its four waves (i = i0 + wave, step 4) and the four
+// partial sums are added in a fixed order: deterministic, 32 independent loads per thread at the VQA2 shape instead of 128.
 __global__ __launch_bounds__(256) void embed_tables_reduce_kernel(const float* __restrict__ partials, int T, int R, int H, float* __restrict__ dtyp, int NT,
                                                                    float* __restrict__ dtyp_vis, int NTV, float* __restrict__ dpos_vis) {
-    const int c = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
-    if (c >= H) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, q = blockIdx.y;
     const bool text = q < 2;
     const int slot = q == 4 ? 2 : (q & 1);
     float* out = q == 4 ? dpos_vis : (text ? dtyp : dtyp_vis);
-    if (!out || (q < 4 && slot >= (text ? NT : NTV))) return;
+    if (!out || (q < 4 && slot >= (text ? NT : NTV))) return;      // (uniform over the workgroup)
     const int i0 = text ? 0 : T, i1 = text ? T : T + R;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four interleaved chains (fixed association), loads independent of each other
-    int i = i0;
-    for (; i + 4 <= i1; i += 4) {
-        s0 += partials[((size_t)i * 3 + slot) * H + c];
-        s1 += partials[((size_t)(i + 1) * 3 + slot) * H + c];
-        s2 += partials[((size_t)(i + 2) * 3 + slot) * H + c];
-        s3 += partials[((size_t)(i + 3) * 3 + slot) * H + c];
+    float s0 = 0.f, s1 = 0.f;
+    if (c < H) {
+        int i = i0 + wave;
+        for (; i + 4 < i1; i += 8) {
+            s0 += partials[((size_t)i * 3 + slot) * H + c];
+            s1 += partials[((size_t)(i + 4) * 3 + slot) * H + c];
+        }
+        if (i < i1) s0 += partials[((size_t)i * 3 + slot) * H + c];
     }
-    for (; i < i1; ++i) s0 += partials[((size_t)i * 3 + slot) * H + c];
-    out[(size_t)(q == 4 ? 0 : slot) * H + c] += (s0 + s1) + (s2 + s3);
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && c < H) out[(size_t)(q == 4 ? 0 : slot) * H + c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 template <typename T>
@@ -1652,7 +1656,7 @@ int mmf_embed_tables_bwd(const void* x, int ld, int B, int T, int R, const int64
     hipLaunchKernelGGL(embed_tables_bwd_kernel, dim3(T + R, (H / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, B, T, R, dtyp ? seg : nullptr,
                        dtyp_vis ? vt : nullptr, pos0, dpos, dtyp, NT, dtyp_vis, NTV, ws, H);
     MMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(embed_tables_reduce_kernel, dim3((H + 255) / 256, R > 0 ? 5 : 2), dim3(256), 0, (hipStream_t)stream, ws, T, R, H, dtyp, NT, dtyp_vis, NTV, dpos_vis);
+    hipLaunchKernelGGL(embed_tables_reduce_kernel, dim3((H + 63) / 64, R > 0 ? 5 : 2), dim3(256), 0, (hipStream_t)stream, ws, T, R, H, dtyp, NT, dtyp_vis, NTV, dpos_vis);
     MMF_CHECK_LAUNCH();
     return 0;
 }

@@ -474,8 +474,15 @@ struct TransformerLayerFn : public torch::autograd::Function<TransformerLayerFn>
         Gemm(x2, wqkv16, qkv, M, 3 * H, H, H, H, 3 * H).bias(bqkv).site(MMF_SITE_QKV_FWD).run();
         Tensor ctxt = empty_bf16({M, H}, x2), lse = empty_f32({B, heads, S}, x2);
         Tensor o32 = need_bwd ? empty_f32({M, H}, x2) : Tensor();
+        // the forward's dropout decisions as a bit table for the backward, where this shape's kernels take one (mmf_attn_desc.keep_bits)
+        Tensor kb;
+        if (need_bwd && drop_attn.on()) {
+            const int64_t words = mmf_attention_keep_bits_words((int)B, (int)heads, (int)S, (int)S, (int)(H / heads));
+            if (words > 0) kb = at::empty({words}, x2.options().dtype(at::kInt));
+        }
         mmf_attn_desc ad;
         attn_desc(ad, qkv, H, mask, ctxt, lse, o32, B, heads, S, drop_attn, tail);
+        ad.keep_bits = kb.defined() ? reinterpret_cast<uint32_t*>(kb.data_ptr<int32_t>()) : nullptr;
         MMF_RC(mmf_attention_fwd(&ad, sp()), "mmf_attention_fwd");
         Ddrln a = ddrln_fwd(ctxt, x2, wo16, bo, g1, be1, eps1, drop_hid1, MMF_SITE_ATTN_OUT_FWD);
         // feed-forward
@@ -483,7 +490,7 @@ struct TransformerLayerFn : public torch::autograd::Function<TransformerLayerFn>
         Gemm(a.out, w1_16, hh, M, I, H, H, H, I).bias(b1).act(1, u).site(MMF_SITE_FFN_UP_FWD).run();
         Ddrln f = ddrln_fwd(hh, a.out, w2_16, b2, g2, be2, eps2, drop_hid2, MMF_SITE_FFN_DOWN_FWD);
         ctx->save_for_backward({x2, qkv, ctxt, lse, a.y, a.mean, a.rstd, a.out, u, hh, f.y, f.mean, f.rstd, wqkv16, wo16, w1_16, w2_16, g1.detach(),
-                                g2.detach(), mask, o32, drop_attn.seed, drop_hid1.seed, drop_hid2.seed});
+                                g2.detach(), mask, o32, drop_attn.seed, drop_hid1.seed, drop_hid2.seed, kb});
         ctx->saved_data["dims"] = std::vector<int64_t>{B, S, H, I, heads, tail};
         ctx->saved_data["da"] = drop_pack(drop_attn); ctx->saved_data["d1"] = drop_pack(drop_hid1); ctx->saved_data["d2"] = drop_pack(drop_hid2);
         return f.out.view({B, S, H});
@@ -508,6 +515,7 @@ struct TransformerLayerFn : public torch::autograd::Function<TransformerLayerFn>
         Tensor dqkv = empty_bf16({M, 3 * H}, x2), delta = empty_f32({B, heads, S}, x2);
         mmf_attn_bwd_desc bd;
         attn_desc(bd.f, qkv, H, mask, ctxt, lse, o32, B, heads, S, drop_attn, tail);
+        bd.f.keep_bits = sv[24].defined() ? reinterpret_cast<uint32_t*>(sv[24].data_ptr<int32_t>()) : nullptr;
         char* dbase = reinterpret_cast<char*>(dqkv.data_ptr());
         bd.dctx = dctx.data_ptr(); bd.dq = dbase; bd.dk = dbase + 2 * H; bd.dv = dbase + 4 * H; bd.delta = delta.data_ptr<float>();
         MMF_RC(mmf_attention_bwd(&bd, sp()), "mmf_attention_bwd");

@@ -399,6 +399,15 @@ def _o32(M, H, dev, need):
     return torch.empty(M, H, dtype=F32, device=dev) if (need and EXACT_ATTENTION_DELTA) else None
 
 
+def _keep_bits(B, heads, Sq, Sk, head_dim, drop, dev, need):
+    """The table through which the attention forward hands its dropout decisions to the backward (mmf_attn_desc.keep_bits) where this shape's kernels
+    take one — VisualBERT's, MMBT's, UNITER's and the MMF Transformer's self-attention (head_dim 64, 129..256 positions) — else None (both directions hash)."""
+    if not (need and drop[1]):
+        return None
+    words = nat.attention_keep_bits_words(B, heads, Sq, Sk, head_dim)
+    return torch.empty(words, dtype=torch.int32, device=dev) if words else None
+
+
 class PrefixLMMask:
     """What M4C's multimodal transformer hands its encoder as a [B, 1, L, L] tensor (MMT.forward, mmf/models/m4c.py:424-440),
     in the form the fused attention kernel takes it: the additive key mask [B, L] fp32 plus the number of trailing
@@ -427,13 +436,14 @@ def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail
     lse = torch.empty(B, heads, S, dtype=F32, device=dev)
     scale = 1.0 / math.sqrt(H // heads)
     o32 = _o32(M, H, dev, need_bwd)
+    kb = _keep_bits(B, heads, S, S, H // heads, drop, dev, need_bwd)
     nat.attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale, drop,
-                      head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
-    return qkv, ctxt, lse, o32
+                      head_dim=H // heads, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
+    return qkv, ctxt, lse, o32, kb
 
 
 def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_resid=None, need_dx=True, o32=None, tail=0,
-              qk_gate=None):
+              qk_gate=None, kb=None):
     """Returns (dx, dW_qkv, db_qkv) — and the gradient of `qk_gate` as a fourth element when a gate was applied."""
     M, H = x2.shape
     dev = x2.device
@@ -441,7 +451,7 @@ def _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop, dx_
     delta = torch.empty(B, heads, S, dtype=F32, device=dev)
     scale = 1.0 / math.sqrt(H // heads)
     nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
-                      dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
+                      dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop, head_dim=H // heads, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
     if qk_gate is None:
         return _linear_bwd(dqkv, 3 * H, x2, wqkv16, M, 3 * H, H, need_dx=need_dx, dx_resid=dx_resid, want_db=True, defer=True)
     dgate = torch.empty_like(qk_gate)
@@ -457,17 +467,17 @@ class SelfAttentionFn(torch.autograd.Function):
         B, S, H = x.shape
         x2 = _as_bf16_2d(x)
         mask_add, tail = _split_mask(mask_add)
-        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, any(ctx.needs_input_grad), tail)
-        ctx.save_for_backward(x2, qkv, ctxt, lse, wqkv16, mask_add, o32)
+        qkv, ctxt, lse, o32, kb = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, any(ctx.needs_input_grad), tail)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, wqkv16, mask_add, o32, kb)
         ctx.meta = (B, S, H, heads, drop, tail)
         return ctxt.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        x2, qkv, ctxt, lse, wqkv16, mask_add, o32 = ctx.saved_tensors
+        x2, qkv, ctxt, lse, wqkv16, mask_add, o32, kb = ctx.saved_tensors
         B, S, H, heads, drop, tail = ctx.meta
         dx, dw, db = _attn_bwd(_grad_bf16(g, H), x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop,
-                               need_dx=ctx.needs_input_grad[0], o32=o32, tail=tail)
+                               need_dx=ctx.needs_input_grad[0], o32=o32, tail=tail, kb=kb)
         return ((dx.view(B, S, H) if dx is not None else None), dw[:H], db[:H], dw[H:2 * H], db[H:2 * H], dw[2 * H:], db[2 * H:],
                 None, None, None, None, None)
 
@@ -623,22 +633,22 @@ class AttentionBlockFn(torch.autograd.Function):
         x2 = _as_bf16_2d(x)
         mask_add, tail = _split_mask(mask_add)
         gate = None if qk_gate is None else qk_gate.detach().float().contiguous()
-        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail, gate)
+        qkv, ctxt, lse, o32, kb = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail, gate)
         out, y, mean, rstd = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), gamma.detach(), beta.detach(), eps, drop_hid)
-        ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add, o32, gate)
+        ctx.save_for_backward(x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma.detach(), mask_add, o32, gate, kb)
         ctx.meta = (B, S, H, heads, drop_attn, drop_hid, tail)
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add, o32, gate = ctx.saved_tensors
+        x2, qkv, ctxt, lse, y, mean, rstd, wqkv16, wo16, gamma, mask_add, o32, gate, kb = ctx.saved_tensors
         B, S, H, heads, drop_attn, drop_hid, tail = ctx.meta
         M = B * S
         # (the bias gradient of the output projection is a column sum of dlin, the A operand of its weight-gradient GEMM: it rides on that GEMM —
         # the fused layer node does the same — so the LayerNorm backward carries no third column sum and its reduction can be deferred: ln_defer)
         dres, dlin, dgamma, dbeta, _ = _ln_bwd(_grad_bf16(g, H), y, mean, rstd, gamma, drop_hid, False)
         dctx, dwo, dbo = _linear_bwd(dlin if dlin is not None else dres, H, ctxt, wo16, M, H, H, want_db=True, defer=True)
-        res = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32, tail=tail,
+        res = _attn_bwd(dctx, x2, qkv, ctxt, lse, wqkv16, mask_add, B, S, heads, drop_attn, dx_resid=dres, o32=o32, tail=tail, kb=kb,
                         qk_gate=gate)
         dx, dwqkv, dbqkv = res[:3]
         return (dx.view(B, S, H), dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
@@ -917,14 +927,14 @@ class TransformerLayerFn(torch.autograd.Function):
         I = w1_16.shape[0]
         dev = x2.device
         mask_add, tail = _split_mask(mask_add)
-        qkv, ctxt, lse, o32 = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail, site=nat.SITE_QKV_FWD)
+        qkv, ctxt, lse, o32, kb = _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop_attn, any(ctx.needs_input_grad), tail, site=nat.SITE_QKV_FWD)
         a_out, y1, mean1, rstd1 = _ddrln_fwd(ctxt, x2, wo16, bo.detach(), g1.detach(), be1.detach(), eps1, drop_hid1, site=nat.SITE_ATTN_OUT_FWD)
         u = torch.empty(M, I, dtype=BF16, device=dev)
         hh = torch.empty(M, I, dtype=BF16, device=dev)
         nat.gemm(a_out, w1_16, hh, M, I, H, H, H, I, bias=b1.detach(), act=1, U=u, debug_flags=nat.gemm_site(nat.SITE_FFN_UP_FWD))
         out, y2, mean2, rstd2 = _ddrln_fwd(hh, a_out, w2_16, b2.detach(), g2.detach(), be2.detach(), eps2, drop_hid2, site=nat.SITE_FFN_DOWN_FWD)
         ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean1, rstd1, a_out, u, hh, y2, mean2, rstd2, wqkv16, wo16, w1_16, w2_16,
-                              g1.detach(), g2.detach(), mask_add, o32)
+                              g1.detach(), g2.detach(), mask_add, o32, kb)
         ctx.meta = (B, S, H, I, heads, drop_attn, drop_hid1, drop_hid2, tail)
         ctx.update_params = (wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2)      # leaves: for `param_update` (optimizer in backward)
         return out.view(B, S, H)
@@ -932,7 +942,7 @@ class TransformerLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x2, qkv, ctxt, lse, y1, mean1, rstd1, a_out, u, hh, y2, mean2, rstd2, wqkv16, wo16, w1_16, w2_16, g1, g2, mask_add,
-         o32) = ctx.saved_tensors
+         o32, kb) = ctx.saved_tensors
         B, S, H, I, heads, drop_attn, drop_hid1, drop_hid2, tail = ctx.meta
         M = B * S
         dev = x2.device
@@ -950,7 +960,7 @@ class TransformerLayerFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(H // heads)
         with (param_update.beside() if (param_update.beside is not None and not param_update.beside_wgrad) else contextlib.nullcontext()):
             nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
-                              dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail)
+                              dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
         dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1, site=nat.SITE_QKV_DGRAD) if ctx.needs_input_grad[0] else None
         # the four weight gradients, one launch
         p_1, dw1, db1 = _wgrad_problem(du, I, a_out, M, I, H, True)

@@ -12,6 +12,8 @@ _INT_RETURNS = {
     "layernorm_bwd_ws_floats": lambda H: 64 * 3 * H, "colsum_ws_floats": lambda n: 64 * n,
     "gemm_rowsum_supported": lambda M, Nn, K: True,
     "layernorm_dropout_fusable": lambda H: H % 256 == 0 and H <= 1024,
+    "attention_keep_bits_words": lambda B, heads, Sq, Sk, head_dim=64: (B * heads * ((Sq + 31) // 32) * ((Sk + 31) // 32) * 32
+                                                                        if (head_dim == 64 and 128 < Sq <= 256 and 128 < Sk <= 256) else 0),
 }
 _KEEP = {"drop_cfg", "_drop4", "lib", "_check", "_stream", "_p", "_req", "gemm_site"}
 calls = []
@@ -70,8 +72,11 @@ def _gemm_grouped(problems):
 
 
 def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=N.NO_DROP, head_dim=64, ctx_f32=None,
-                   causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0):
+                   causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None):
     assert head_dim in (64, 128) and 0 <= causal_tail <= Sk and (causal_tail == 0 or (Sq == Sk and head_dim == 64))
+    if keep_bits is not None:      # the dropout keep-bit table (mmf_attn_desc.keep_bits): only where the kernels take one, only with dropout on
+        assert keep_bits.dtype == torch.int32 and drop[1] and head_dim == 64 and 128 < Sq <= 256 and 128 < Sk <= 256
+        assert keep_bits.numel() == B * heads * ((Sq + 31) // 32) * ((Sk + 31) // 32) * 32 and not q_batch_rows and not kv_batch_rows
     assert Sq <= 256 and Sk <= 256
     qb, kb, mb = q_batch_rows or Sq, kv_batch_rows or Sk, mask_batch_stride or Sk
     assert qb >= Sq and kb >= Sk and mb >= Sk
@@ -87,8 +92,8 @@ def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk
 
 
 def _attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta, drop=N.NO_DROP,
-                   head_dim=64, ctx_f32=None, causal_tail=0):
-    _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail)
+                   head_dim=64, ctx_f32=None, causal_tail=0, keep_bits=None):
+    _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail, keep_bits=keep_bits)
     _need(dctx, B * Sq, ldo, heads * head_dim, "attention dctx"); _need(dq, B * Sq, ldq, heads * head_dim, "attention dq")
     _need(dk, B * Sk, ldk, heads * head_dim, "attention dk"); _need(dv, B * Sk, ldv, heads * head_dim, "attention dv")
     calls[-1] = ("attention_bwd",) + calls[-1][1:]

@@ -359,6 +359,82 @@ def test_attention_one_round_forward_is_bit_identical_to_the_two_workgroup_form(
         assert torch.equal(a, b_)
 
 
+@pytest.mark.parametrize("S,mode", [(228, "key"), (160, "key"), (256, "tail"), (200, "query"), (129, "key")])
+def test_attention_keep_bit_table_replays_the_forwards_dropout_decisions(S, mode):
+    """mmf_attn_desc.keep_bits: the forward writes its probability-dropout decisions as a bit table while it draws them, the one-pass backward reads one
+    word per lane and key tile instead of hashing every probability again.  Same decisions: forward output and all three gradients are bit-identical to
+    the hashing path, for the key mask, M4C's causal tail and a materialised per-query mask; shapes whose kernels take no table report 0 words."""
+    B, heads, d = 3, 4, 64
+    H = heads * d
+    qkv = rnd(B * S, 3 * H, scale=0.5, seed=S)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    keym = torch.zeros(B, S, device=DEV); keym[:, S - 7:] = -10000.0
+    tail = 12 if mode == "tail" else 0
+    mask = keym
+    if mode == "query":
+        mask = (keym[:, None, :] + torch.where(torch.rand(B, S, S, device=DEV) < 0.1, -10000.0, 0.0)).contiguous()
+    drop = nat().drop_cfg(0.1, 424242)
+    dctx = rnd(B * S, H, scale=0.1, seed=3)
+    words = nat().attention_keep_bits_words(B, heads, S, S, d)
+    assert words == B * heads * ((S + 31) // 32) ** 2 * 32
+    outs = []
+    for use in (False, True):
+        kb = torch.full((words,), -1 if use else 0, dtype=torch.int32, device=DEV) if use else None
+        ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, S, device=DEV); o32 = torch.empty(B * S, H, device=DEV)
+        nat().attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, 0.125, drop, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
+        dqkv = torch.zeros_like(qkv); delta = torch.empty(B, heads, S, device=DEV)
+        nat().attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, heads, S, S, 0.125, dctx, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
+                            delta, drop, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
+        outs.append((ctx, lse, dqkv, kb))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    # the table: ~10 % of the bits of valid (query, key) pairs are zero
+    kb = outs[1][3].view(B * heads, (S + 31) // 32, (S + 31) // 32, 32)
+    word = kb[:, 0, 0, :].contiguous().view(-1)       # tile (0, 0): 32 x 32 valid pairs per word set
+    zeros = sum(int(((word >> b) & 1 == 0).sum()) for b in range(32))
+    assert 0.07 < zeros / (word.numel() * 32) < 0.13
+    # shapes without a table
+    for (sq, sk, hd) in ((128, 128, 64), (100, 228, 64), (300, 300, 64), (228, 228, 128)):
+        assert nat().attention_keep_bits_words(B, heads, sq, sk, hd) == 0
+    with pytest.raises(nat().NativeLibraryError):       # a table where the kernels take none is an error, not silently ignored
+        S2 = 96
+        x = rnd(B * S2, 3 * H)
+        nat().attention_fwd(x[:, :H], x[:, H:2 * H], x[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, torch.empty(B * S2, H, dtype=torch.bfloat16, device=DEV), H,
+                            torch.empty(B, heads, S2, device=DEV), B, heads, S2, S2, 0.125, drop, keep_bits=torch.zeros(1024, dtype=torch.int32, device=DEV))
+
+
+def test_attention_keep_bit_table_is_the_counter_hash():
+    """Every bit of the table against a host restatement of the dropout RNG (mmf_amd/csrc/common.h: mix24 of (pair index + key), the 16-bit half of the
+    element's parity against thr16; element index ((b * heads + head) * Sq + q) * Sk_pad + key): a wrong or stale word cannot hide behind statistics."""
+    M32 = 0xFFFFFFFF
+
+    def mix24(x):
+        x = x & M32
+        x = x ^ (x >> 16)
+        x = (((x & 0xFFFFFF) * 0xB5297B) + (((x << 9) | (x >> 23)) & M32)) & M32
+        x = x ^ (x >> 13)
+        x = (((x & 0xFFFFFF) * 0x68E31F) + (((x << 11) | (x >> 21)) & M32)) & M32
+        return x ^ (x >> 15)
+
+    for B, heads, S in ((2, 3, 228), (1, 2, 256), (3, 1, 130)):
+        H = heads * 64
+        qkv = rnd(B * S, 3 * H, scale=0.5, seed=S + 1)
+        drop = nat().drop_cfg(0.1, 424242 + S)
+        kb = torch.zeros(nat().attention_keep_bits_words(B, heads, S, S, 64), dtype=torch.int32, device=DEV)
+        ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, S, device=DEV)
+        nat().attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, ctx, H, lse, B, heads, S, S, 0.125, drop, keep_bits=kb)
+        nt = (S + 31) // 32
+        skp = nt * 32
+        tab = kb.view(B * heads, nt, nt, 32).long() & M32                                   # [bh, query tile, key tile, key] bit x = query
+        bits = torch.stack([(tab >> x) & 1 for x in range(32)], dim=-1)                     # [bh, qt, kt, key, query]
+        got = bits.permute(0, 1, 4, 2, 3).reshape(B * heads, skp, skp).bool()[:, :S, :S]    # [bh, q, key]
+        bh = torch.arange(B * heads, device=DEV)[:, None, None]; q = torch.arange(S, device=DEV)[None, :, None]; k = torch.arange(S, device=DEV)[None, None, :]
+        idx = ((bh * S + q) * skp + k) & M32
+        h = mix24((idx >> 1) + drop[0])
+        exp = torch.where((k & 1) == 1, h >> 16, h & 0xFFFF) >= drop[1]
+        assert torch.equal(got, exp), (B, heads, S, int((got != exp).sum()))
+
+
 def test_attention_exact_delta_reduces_common_mode_leak():
     """A common component in K (e.g. the key bias) must not reach dQ: sum_key dS = 0.  With delta formed from the bf16 O the
     rows of dS sum to ~2^-9 |dO||O| and that times mean(K) lands in dQ; the fp32 copy of O removes that term (what is

@@ -79,6 +79,12 @@ def attn_sweep():
             nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, 0)
             print("attention B=32 S=228 dropout %.1f fp32-ctx %-5s: fwd %6.1f us   bwd one-pass %6.1f us   bwd two-kernel %6.1f us"
                   % (p, o32 is not None, t_f, t_1, t_2), flush=True)
+            if p:      # the forward hands its dropout decisions to the one-pass backward as a bit table (mmf_attn_desc.keep_bits)
+                kb = torch.empty(nat.attention_keep_bits_words(B, A, S, S, 64), dtype=torch.int32, device="cuda")
+                t_fk = timeit(lambda: nat.attention_fwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, A, S, S, 0.125, drop=drop, ctx_f32=o32, keep_bits=kb))
+                t_bk = timeit(lambda: nat.attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, A, S, S, 0.125, dctx, dqkv[:, :H],
+                                                        dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta, drop=drop, ctx_f32=o32, keep_bits=kb))
+                print("          ... with the keep-bit table      : fwd %6.1f us   bwd one-pass %6.1f us" % (t_fk, t_bk), flush=True)
 
 
 def wgrad_sweep():

@@ -41,8 +41,10 @@ class VisualBERTBase(nn.Module):
         config.bypass_transformer = bypass_transformer
         config.output_attentions = output_attentions
         config.output_hidden_states = output_hidden_states
-        if output_attentions:
-            raise NotImplementedError("output_attentions: the fused attention kernel never materialises the probabilities")
+        # `output_attentions: true` is accepted like the reference accepts it — and yields what the reference yields: VisualBERTBase.forward calls the encoder
+        # WITHOUT asking for the layers' probabilities (visual_bert.py:143-157 `self.encoder(embedding_output, extended_attention_mask)`;
+        # BertEncoderJit.forward collects them only when its own `output_attentions` argument is set, hf_layers.py:322-356), so
+        # `attn_data_list = encoded_layers[1:]` — the `attention_weights` entry of the model output — is EMPTY there.  Nothing to materialise.
         self.embeddings = BertVisioLinguisticEmbeddings(config)
         self.encoder = BertEncoderJit(config)
         self.pooler = BertPooler(config)
@@ -146,9 +148,12 @@ class VisualBERTForPretraining(nn.Module):
                 visual_embeddings_type: Optional[Tensor] = None, image_text_alignment: Optional[Tensor] = None,
                 masked_lm_labels: Optional[Tensor] = None, mask_add: Optional[Tensor] = None,
                 pool_index: Optional[Tensor] = None) -> Dict[str, Tensor]:
-        sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
-                                                      visual_embeddings_type, image_text_alignment, mask_add)
+        sequence_output, pooled_output, attention_weights = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
+                                                                      visual_embeddings_type, image_text_alignment, mask_add)
         output_dict: Dict[str, Tensor] = {}
+        if not torch.jit.is_scripting():
+            if self.output_attentions:      # :258-259 (empty in the reference as well: see VisualBERTBase.__init__)
+                output_dict["attention_weights"] = attention_weights
         if self.output_hidden_states:
             output_dict["sequence_output"] = sequence_output
             if pooled_output is not None:
@@ -211,12 +216,15 @@ class VisualBERTForClassification(nn.Module):
                 pool_index: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """`mask_add` / `pool_index` (optional, not in the reference's signature): the additive attention mask and `input_mask.sum(1) - 2`
         when VisualBERT.forward has already computed them (one launch, torch.ops.mmf_amd.visual_masks)."""
-        sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
-                                                      visual_embeddings_type, image_text_alignment, mask_add)
+        sequence_output, pooled_output, attention_weights = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
+                                                                      visual_embeddings_type, image_text_alignment, mask_add)
         if self.training_head_type == "nlvr2":
             assert pooled_output is not None
             pooled_output = torch.ops.mmf_amd.pair_halves(pooled_output)       # 2B x H -> B x 2H, visual_bert.py:369-374
         output_dict: Dict[str, Tensor] = {}
+        if not torch.jit.is_scripting():
+            if self.output_attentions:      # :378-379 (empty in the reference as well: see VisualBERTBase.__init__)
+                output_dict["attention_weights"] = attention_weights
         if self.output_hidden_states:
             output_dict["sequence_output"] = sequence_output
             if pooled_output is not None:

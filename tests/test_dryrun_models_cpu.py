@@ -192,6 +192,22 @@ def test_visual_bert_config_branches_plumbing():
     assert m.model.classifier[1].weight.grad is not None
 
 
+def test_visual_bert_output_attentions_is_accepted_and_empty_like_the_reference():
+    """`output_attentions: true` builds and runs; the `attention_weights` entry is what the reference produces: VisualBERTBase.forward calls
+    `self.encoder(embedding_output, extended_attention_mask)` without `output_attentions`, so `encoded_layers[1:]` is empty
+    (visual_bert.py:143-157, hf_layers.py:322-356)."""
+    z, case, cfg, sd, sample = G.load_case("small64")
+    m = MU.build_visual_bert(cfg, sd, device="cpu", output_attentions=True)
+    m.eval()
+    with native_stub.installed():
+        out = m(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+    assert "attention_weights" in out and len(out["attention_weights"]) == 0
+    m2 = MU.build_visual_bert(cfg, sd, device="cpu")
+    m2.eval()
+    with native_stub.installed():
+        assert "attention_weights" not in m2(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+
+
 def test_mmbt_config_branches_plumbing():
     """No modal start / end tokens, `fused_feature_only`, frozen text / modal halves (mmbt.py:173-178,229-231,253-259)."""
     from oracle.mmbt_oracle import SHARED

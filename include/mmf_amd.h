@@ -215,7 +215,8 @@ typedef struct mmf_attn_desc {
                               key 32 kt + j); nqt = ceil(Sq / 32), nkt = ceil(Sk / 32). */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
-/* Words of mmf_attn_desc.keep_bits for this shape, 0 when its kernels hash in both directions (head_dim 128, <= 128 queries or keys, > 256 of either). */
+/* Words of mmf_attn_desc.keep_bits for this shape, 0 when its backward is the two-kernel form, which hashes (head_dim 64 beyond 256 queries or keys, head_dim 128
+ * beyond 128). */
 int64_t mmf_attention_keep_bits_words(int B, int heads, int Sq, int Sk, int head_dim);
 
 /* Backward of the same operator (what autograd derives for BertSelfAttentionJit.forward, mmf/modules/hf_layers.py:138-213, in the reference):

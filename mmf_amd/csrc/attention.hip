@@ -203,7 +203,7 @@ struct AttnArgs {
     int m_qs;                // per-query mask (mmf_attn_desc.mask_query_stride): mask entries between consecutive query rows; 0 = one mask row per batch
     float scale;
     DropoutCfg drop;
-    uint32_t* keep;          // optional dropout keep-bit table (mmf_attn_desc.keep_bits): written by attn_fwd8_kernel<8, *>, read by attn_bwd_fused_kernel<64, 8, *>
+    uint32_t* keep;          // optional dropout keep-bit table (mmf_attn_desc.keep_bits): written by the forward kernels, read by attn_bwd_fused_kernel
     // backward only
     const bf16* dctx; bf16* dq; bf16* dk; bf16* dv; float* delta;
 };
@@ -240,6 +240,46 @@ struct WaveProbe {
 #define PROBE_AT(i)
 #define PROBE_FLUSH(k, bh, sub)
 #endif
+
+// Probability dropout of one 32 x 32 score tile held as S^T (lane = query x, half h; register 4c + i = key 8c + 4h + i of the tile), element index
+// rowbase + key.  With `keep` != NULL the decisions also go to the keep-bit table the one-pass backward reads (mmf_attn_desc.keep_bits): the compare
+// of register (c, i) IS a 64-bit lane mask — low half = key 8c + i against the wave's 32 queries, high half = key 8c + 4 + i — i.e. two finished table
+// words; lane j < 32 collects the word of key j (v_writelane) and the half-wave stores 128 contiguous bytes per tile.
+DEVI void drop_tile(f32x16& acc, uint32_t dkey, uint32_t tilebase, int h, int lane, const DropoutCfg& drop, uint32_t* keep) {
+    if (!keep) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 ds = drop_scale4(dkey, tilebase + 8 * c + 4 * h, drop.thr16, drop.scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * c + i] *= ds[i];
+        }
+        return;
+    }
+    int kw = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t idx4 = tilebase + 8 * c + 4 * h;
+        const uint32_t h0 = drop_hash(dkey, idx4 >> 1), h1 = drop_hash(dkey, (idx4 >> 1) + 1);
+        const uint32_t half[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+        unsigned long long m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool on = half[i] >= drop.thr16;
+            m[i] = __builtin_amdgcn_ballot_w64(on);
+            acc[4 * c + i] *= on ? drop.scale : 0.f;
+        }
+        // (s_nop: a lane mask written by a VALU compare is not yet visible to v_writelane as DATA in the next slots — measured: without it
+        // nine of the 32 words of a tile come out stale; the compiler's hazard recognizer does not look into inline assembly)
+        asm volatile("s_nop 4\n\t"
+                     "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
+                     "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\tv_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
+                     : "+v"(kw)
+                     : "s"((uint32_t)m[0]), "s"((uint32_t)m[1]), "s"((uint32_t)m[2]), "s"((uint32_t)m[3]), "s"((uint32_t)(m[0] >> 32)),
+                       "s"((uint32_t)(m[1] >> 32)), "s"((uint32_t)(m[2] >> 32)), "s"((uint32_t)(m[3] >> 32)), "n"(8 * c), "n"(8 * c + 1),
+                       "n"(8 * c + 2), "n"(8 * c + 3), "n"(8 * c + 4), "n"(8 * c + 5), "n"(8 * c + 6), "n"(8 * c + 7));
+    }
+    if (lane < 32) keep[lane] = (uint32_t)kw;
+}
 
 // =================================================================================================
 // forward
@@ -334,14 +374,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     // dropout on the probabilities (hf_layers.py:201), index ((bh*Sq + q)*SKP + key)
     if (a.drop.thr16) {
         const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
+        const uint32_t dkey = drop_key(a.drop);
+        const int nkt_rt = a.skp >> 5;      // key tiles of the keep-bit table (template tiles past it hold padding keys only)
+        const bool rec = a.keep && q0 < a.Sq;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 ds = drop_scale4(drop_key(a.drop), rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sc[t][4 * c + i] *= ds[i];
-            }
+            drop_tile(sc[t], dkey, rowbase + 32 * t, h, lane, a.drop,
+                      (rec && t < nkt_rt) ? a.keep + (((size_t)bh * ((a.Sq + 31) >> 5) + (q0 >> 5)) * nkt_rt + t) * 32 : nullptr);
     }
 
     PROBE_AT(5);
@@ -483,44 +522,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
                     sum += p;
                 }
             }
-            if (a.drop.thr16) {
-                if (a.keep) {
-                    // The decisions also go to the keep-bit table the backward reads: the compare of register (c, i) IS a 64-bit lane mask — low
-                    // half = key 8c + i of this tile against the wave's 32 queries, high half = key 8c + 4 + i — i.e. two finished table words;
-                    // lane j < 32 collects the word of key j (v_writelane) and the half-wave stores 128 contiguous bytes per tile.
-                    int kw = 0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const uint32_t idx4 = rowbase + 32 * t + 8 * c + 4 * h;
-                        const uint32_t h0 = drop_hash(dkey, idx4 >> 1), h1 = drop_hash(dkey, (idx4 >> 1) + 1);
-                        const uint32_t half[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
-                        unsigned long long m[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const bool keep = half[i] >= a.drop.thr16;
-                            m[i] = __builtin_amdgcn_ballot_w64(keep);
-                            acc[4 * c + i] *= keep ? a.drop.scale : 0.f;
-                        }
-                        // (s_nop: a lane mask written by a VALU compare is not yet visible to v_writelane as DATA in the next slots — measured: without it
-                        // nine of the 32 words of a tile come out stale; the compiler's hazard recognizer does not look into inline assembly)
-                        asm volatile("s_nop 4\n\t"
-                                     "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
-                                     "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\tv_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
-                                     : "+v"(kw)
-                                     : "s"((uint32_t)m[0]), "s"((uint32_t)m[1]), "s"((uint32_t)m[2]), "s"((uint32_t)m[3]), "s"((uint32_t)(m[0] >> 32)),
-                                       "s"((uint32_t)(m[1] >> 32)), "s"((uint32_t)(m[2] >> 32)), "s"((uint32_t)(m[3] >> 32)), "n"(8 * c), "n"(8 * c + 1),
-                                       "n"(8 * c + 2), "n"(8 * c + 3), "n"(8 * c + 4), "n"(8 * c + 5), "n"(8 * c + 6), "n"(8 * c + 7));
-                    }
-                    if (lane < 32 && t < NKT_RT) a.keep[(((size_t)bh * ((a.Sq + 31) >> 5) + (q0 >> 5)) * NKT_RT + t) * 32 + lane] = (uint32_t)kw;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f32x4 ds = drop_scale4(dkey, rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[4 * c + i] *= ds[i];
-                    }
-                }
-            }
+            if (a.drop.thr16)
+                drop_tile(acc, dkey, rowbase + 32 * t, h, lane, a.drop,
+                          (a.keep && t < NKT_RT) ? a.keep + (((size_t)bh * ((a.Sq + 31) >> 5) + (q0 >> 5)) * NKT_RT + t) * 32 : nullptr);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const bf16x8 pf = frag_regs(acc, u);
@@ -1018,8 +1022,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_kernel(AttnArgs a) 
     PROBE_FLUSH(3, bh, wave);
 }
 
-// shapes whose forward is attn_fwd8_kernel<8, *> with one workgroup per (batch, head) AND whose backward is attn_bwd_fused_kernel<64, 8, *>
-bool keep_bits_shape(int hd, int Sq, int Sk) { return hd == 64 && Sq > 128 && Sq <= 256 && Sk > 128 && Sk <= 256; }
+// shapes whose backward is the one-pass kernel (attn_bwd_fused_kernel<64, 8, *> / <128, 4, *>); every forward form of those shapes writes the table
+bool keep_bits_shape(int hd, int Sq, int Sk) { return hd == 64 ? (Sq <= 256 && Sk <= 256) : (Sq <= 128 && Sk <= 128); }
 
 int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     MMF_CHECK_ARG(d && d->q && d->k && d->v, "attention: null operand");
@@ -1052,7 +1056,7 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
     a.keep = d->keep_bits;
     MMF_CHECK_ARG(!a.keep || (d->drop_thr16 != 0 && keep_bits_shape(hd, d->Sq, d->Sk) && d->q_batch_rows == 0 && d->kv_batch_rows == 0),
-                  "attention: keep_bits is taken by the head_dim-64 kernels for 129..256 queries and keys with dropout on (mmf_attention_keep_bits_words)");
+                  "attention: keep_bits is taken where the backward is the one-pass kernel (head_dim 64: <= 256 positions, 128: <= 128), with dropout on (mmf_attention_keep_bits_words)");
     return 0;
 }
 
@@ -1068,8 +1072,7 @@ int set_lds(K kern, int bytes) {
 extern "C" int64_t mmf_attention_keep_bits_words(int B, int heads, int Sq, int Sk, int head_dim) {
     const int hd = head_dim ? head_dim : 64;
     if (B <= 0 || heads <= 0 || !keep_bits_shape(hd, Sq, Sk)) return 0;
-    if (mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD) || mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS) || mmf_amd_get_tunable(MMF_TUN_ATTN_KEEP_BITS_OFF))
-        return 0;      // (the A/B forms hash in both directions)
+    if (mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS) || mmf_amd_get_tunable(MMF_TUN_ATTN_KEEP_BITS_OFF)) return 0;      // (the two-kernel backward hashes)
     return (int64_t)B * heads * ((Sq + 31) / 32) * ((Sk + 31) / 32) * 32;
 }
 

@@ -400,8 +400,9 @@ def _o32(M, H, dev, need):
 
 
 def _keep_bits(B, heads, Sq, Sk, head_dim, drop, dev, need):
-    """The table through which the attention forward hands its dropout decisions to the backward (mmf_attn_desc.keep_bits) where this shape's kernels
-    take one — VisualBERT's, MMBT's, UNITER's and the MMF Transformer's self-attention (head_dim 64, 129..256 positions) — else None (both directions hash)."""
+    """The table through which the attention forward hands its dropout decisions to the backward (mmf_attn_desc.keep_bits) where the backward is the
+    one-pass kernel — head_dim 64 up to 256 positions, head_dim 128 up to 128: every model of the path at BASELINE's shapes — else None (both directions
+    hash)."""
     if not (need and drop[1]):
         return None
     words = nat.attention_keep_bits_words(B, heads, Sq, Sk, head_dim)
@@ -1699,19 +1700,20 @@ class BiAttentionFn(torch.autograd.Function):
         lse1 = torch.empty(B, heads, T, dtype=F32, device=dev)
         need = any(ctx.needs_input_grad)
         o1, o2 = _o32(B * T, BH, dev, need), _o32(B * R, BH, dev, need)
+        kb1, kb2 = _keep_bits(B, heads, T, R, hd, drop1, dev, need), _keep_bits(B, heads, R, T, hd, drop2, dev, need)
         nat.attention_fwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, img_mask_add, ctx1, BH, lse1, B, heads, T, R,
-                          scale, drop1, head_dim=hd, ctx_f32=o1)
+                          scale, drop1, head_dim=hd, ctx_f32=o1, keep_bits=kb1)
         ctx2 = torch.empty(B * R, BH, dtype=BF16, device=dev)
         lse2 = torch.empty(B, heads, R, dtype=F32, device=dev)
         nat.attention_fwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add, ctx2, BH, lse2, B, heads, R, T,
-                          scale, drop2, head_dim=hd, ctx_f32=o2)
-        ctx.save_for_backward(i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1_16, w2_16, img_mask_add, txt_mask_add, o1, o2)
+                          scale, drop2, head_dim=hd, ctx_f32=o2, keep_bits=kb2)
+        ctx.save_for_backward(i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1_16, w2_16, img_mask_add, txt_mask_add, o1, o2, kb1, kb2)
         ctx.meta = (B, R, T, VH, H, BH, heads, drop1, drop2)
         return ctx1.view(B, T, BH), ctx2.view(B, R, BH)
 
     @staticmethod
     def backward(ctx, g1, g2):
-        i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1_16, w2_16, img_mask_add, txt_mask_add, o1, o2 = ctx.saved_tensors
+        i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1_16, w2_16, img_mask_add, txt_mask_add, o1, o2, kb1, kb2 = ctx.saved_tensors
         B, R, T, VH, H, BH, heads, drop1, drop2 = ctx.meta
         hd = BH // heads
         dev = i2.device
@@ -1721,9 +1723,9 @@ class BiAttentionFn(torch.autograd.Function):
         delta1 = torch.empty(B, heads, T, dtype=F32, device=dev)
         delta2 = torch.empty(B, heads, R, dtype=F32, device=dev)
         nat.attention_bwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, img_mask_add, ctx1, BH, lse1, B, heads, T, R,
-                          scale, _grad_bf16(g1, BH), dqkv2, dqkv1[:, BH:], dqkv1[:, 2 * BH:], delta1, drop1, head_dim=hd, ctx_f32=o1)
+                          scale, _grad_bf16(g1, BH), dqkv2, dqkv1[:, BH:], dqkv1[:, 2 * BH:], delta1, drop1, head_dim=hd, ctx_f32=o1, keep_bits=kb1)
         nat.attention_bwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add, ctx2, BH, lse2, B, heads, R, T,
-                          scale, _grad_bf16(g2, BH), dqkv1, dqkv2[:, BH:], dqkv2[:, 2 * BH:], delta2, drop2, head_dim=hd, ctx_f32=o2)
+                          scale, _grad_bf16(g2, BH), dqkv1, dqkv2[:, BH:], dqkv2[:, 2 * BH:], delta2, drop2, head_dim=hd, ctx_f32=o2, keep_bits=kb2)
         dimg, dw1, db1 = _linear_bwd(dqkv1, 3 * BH, i2, w1_16, B * R, 3 * BH, VH, want_db=True, defer=True)
         dtxt, dw2, db2 = _linear_bwd(dqkv2, 3 * BH, t2, w2_16, B * T, 3 * BH, H, want_db=True, defer=True)
         return (dimg.view(B, R, VH), dtxt.view(B, T, H),

@@ -13,7 +13,7 @@ _INT_RETURNS = {
     "gemm_rowsum_supported": lambda M, Nn, K: True,
     "layernorm_dropout_fusable": lambda H: H % 256 == 0 and H <= 1024,
     "attention_keep_bits_words": lambda B, heads, Sq, Sk, head_dim=64: (B * heads * ((Sq + 31) // 32) * ((Sk + 31) // 32) * 32
-                                                                        if (head_dim == 64 and 128 < Sq <= 256 and 128 < Sk <= 256) else 0),
+                                                                        if max(Sq, Sk) <= (256 if head_dim == 64 else 128) else 0),
 }
 _KEEP = {"drop_cfg", "_drop4", "lib", "_check", "_stream", "_p", "_req", "gemm_site"}
 calls = []
@@ -75,7 +75,7 @@ def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk
                    causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None):
     assert head_dim in (64, 128) and 0 <= causal_tail <= Sk and (causal_tail == 0 or (Sq == Sk and head_dim == 64))
     if keep_bits is not None:      # the dropout keep-bit table (mmf_attn_desc.keep_bits): only where the kernels take one, only with dropout on
-        assert keep_bits.dtype == torch.int32 and drop[1] and head_dim == 64 and 128 < Sq <= 256 and 128 < Sk <= 256
+        assert keep_bits.dtype == torch.int32 and drop[1] and max(Sq, Sk) <= (256 if head_dim == 64 else 128)
         assert keep_bits.numel() == B * heads * ((Sq + 31) // 32) * ((Sk + 31) // 32) * 32 and not q_batch_rows and not kv_batch_rows
     assert Sq <= 256 and Sk <= 256
     qb, kb, mb = q_batch_rows or Sq, kv_batch_rows or Sk, mask_batch_stride or Sk

@@ -359,7 +359,7 @@ def test_attention_one_round_forward_is_bit_identical_to_the_two_workgroup_form(
         assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize("S,mode", [(228, "key"), (160, "key"), (256, "tail"), (200, "query"), (129, "key")])
+@pytest.mark.parametrize("S,mode", [(228, "key"), (160, "key"), (256, "tail"), (200, "query"), (129, "key"), (128, "key"), (100, "tail"), (40, "query"), (7, "key")])
 def test_attention_keep_bit_table_replays_the_forwards_dropout_decisions(S, mode):
     """mmf_attn_desc.keep_bits: the forward writes its probability-dropout decisions as a bit table while it draws them, the one-pass backward reads one
     word per lane and key tile instead of hashing every probability again.  Same decisions: forward output and all three gradients are bit-identical to
@@ -394,13 +394,37 @@ def test_attention_keep_bit_table_replays_the_forwards_dropout_decisions(S, mode
     zeros = sum(int(((word >> b) & 1 == 0).sum()) for b in range(32))
     assert 0.07 < zeros / (word.numel() * 32) < 0.13
     # shapes without a table
-    for (sq, sk, hd) in ((128, 128, 64), (100, 228, 64), (300, 300, 64), (228, 228, 128)):
+    for (sq, sk, hd) in ((300, 300, 64), (100, 257, 64), (228, 228, 128), (129, 64, 128)):
         assert nat().attention_keep_bits_words(B, heads, sq, sk, hd) == 0
     with pytest.raises(nat().NativeLibraryError):       # a table where the kernels take none is an error, not silently ignored
-        S2 = 96
+        S2 = 288
         x = rnd(B * S2, 3 * H)
         nat().attention_fwd(x[:, :H], x[:, H:2 * H], x[:, 2 * H:], 3 * H, 3 * H, 3 * H, None, torch.empty(B * S2, H, dtype=torch.bfloat16, device=DEV), H,
                             torch.empty(B, heads, S2, device=DEV), B, heads, S2, S2, 0.125, drop, keep_bits=torch.zeros(1024, dtype=torch.int32, device=DEV))
+
+
+@pytest.mark.parametrize("Sq,Sk,d", [(128, 101, 128), (101, 128, 128), (36, 20, 128), (128, 101, 64), (200, 64, 64)])
+def test_attention_keep_bit_table_cross_attention_and_head_dim_128(Sq, Sk, d):
+    """The same for q and k / v from different sequences (ViLBERT's co-attention, vilbert.py:388-475) and head_dim 128 (its visual stream)."""
+    B, heads = 2, 3
+    H = heads * d
+    q = rnd(B * Sq, H, scale=0.5, seed=Sq); kv = rnd(B * Sk, 2 * H, scale=0.5, seed=Sk + 1)
+    mask = torch.zeros(B, Sk, device=DEV); mask[:, Sk - 3:] = -10000.0
+    drop = nat().drop_cfg(0.1, 777)
+    dctx = rnd(B * Sq, H, scale=0.1, seed=9)
+    words = nat().attention_keep_bits_words(B, heads, Sq, Sk, d)
+    assert words == B * heads * ((Sq + 31) // 32) * ((Sk + 31) // 32) * 32
+    outs = []
+    for use in (False, True):
+        kb = torch.zeros(words, dtype=torch.int32, device=DEV) if use else None
+        ctx = torch.empty(B * Sq, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, Sq, device=DEV)
+        nat().attention_fwd(q, kv, kv[:, H:], H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, 1.0 / math.sqrt(d), drop, head_dim=d, keep_bits=kb)
+        dq = torch.zeros_like(q); dkv = torch.zeros_like(kv); delta = torch.empty(B, heads, Sq, device=DEV)
+        nat().attention_bwd(q, kv, kv[:, H:], H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, 1.0 / math.sqrt(d), dctx, dq, dkv, dkv[:, H:], delta, drop,
+                            head_dim=d, keep_bits=kb)
+        outs.append((ctx, dq, dkv))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
 
 
 def test_attention_keep_bit_table_is_the_counter_hash():
@@ -416,7 +440,7 @@ def test_attention_keep_bit_table_is_the_counter_hash():
         x = (((x & 0xFFFFFF) * 0x68E31F) + (((x << 11) | (x >> 21)) & M32)) & M32
         return x ^ (x >> 15)
 
-    for B, heads, S in ((2, 3, 228), (1, 2, 256), (3, 1, 130)):
+    for B, heads, S in ((2, 3, 228), (1, 2, 256), (3, 1, 130), (2, 2, 100), (1, 1, 33)):
         H = heads * 64
         qkv = rnd(B * S, 3 * H, scale=0.5, seed=S + 1)
         drop = nat().drop_cfg(0.1, 424242 + S)

@@ -4,7 +4,7 @@
     python tools/graph_gaps.py report OUT/g_kernel_trace.csv                                       # anywhere
 
 `run` replays bench.py's step (VisualBERT VQA2, B = 32, forward + loss + backward + AdamW as ONE hipGraph) 12 times.  `report` cuts
-the kernel trace at the graph's first node (`seed_advance_kernel`), and for the last replays prints wall time per replay, the sum
+the kernel trace at the graph's first node (`step_advance_kernel`; `seed_advance_kernel` before round 5), and for the last replays prints wall time per replay, the sum
 of kernel durations, their difference (idle gaps between dependent graph nodes) and the kernels grouped by name with launch counts:
 the gap total divided by the node count is the cost of ONE more kernel in the graph, i.e. what fusing a tiny kernel away buys."""
 import collections
@@ -50,7 +50,7 @@ def report(path, out_json=None):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    cuts = [i for i, r in enumerate(rows) if "seed_advance_kernel" in r[2]]
+    cuts = [i for i, r in enumerate(rows) if ("seed_advance_kernel" in r[2] or "step_advance_kernel" in r[2])]
     # the last 13 cuts delimit the 12 replays (earlier ones are the eager warm-up passes and the capture)
     cuts = cuts[-12:]
     steps = []
@@ -102,7 +102,7 @@ def timeline(path):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    cuts = [i for i, r in enumerate(rows) if "seed_advance_kernel" in r[2]]
+    cuts = [i for i, r in enumerate(rows) if ("seed_advance_kernel" in r[2] or "step_advance_kernel" in r[2])]
     a, b = cuts[-2], cuts[-1]
     t0 = rows[a][0]
     prev_end = t0

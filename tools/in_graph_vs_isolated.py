@@ -17,7 +17,7 @@ with open(base + "graph/g_kernel_trace.csv") as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-cuts = [i for i, r in enumerate(rows) if "seed_advance_kernel" in r[2]]
+cuts = [i for i, r in enumerate(rows) if ("seed_advance_kernel" in r[2] or "step_advance_kernel" in r[2])]
 
 
 def short(n):

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(const bf16* __restrict__ 
 // Backward: a workgroup of 4 waves = 8 half-waves; half-wave h owns rows blockIdx * 8 + h + 8 * gridDim * i (two rows each at the
 // VQA2 shape: 456 workgroups, two co-resident per CU so that one streams while the other reduces); all loads of a row are issued before anything is reduced.  Column-sum partials (dgamma, dbeta, optionally dbias) are combined across the
 // workgroup's 32 half-waves in LDS and written once per workgroup: partials[blk][q][H], q < NQ.
-template <int NC, bool DBIAS, int NR>
+template <int NC, bool DBIAS, int NR, bool DIN = false>      // DIN: dropout backward applied to dy as it is loaded (its own instantiation: the register budget of the hot form decides its occupancy)
 __global__ __launch_bounds__(256) void ln_bwd_h_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, bf16* __restrict__ dx,
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(const bf16* __restrict__ 
             for (int c = 0; c < NC; ++c) { xv[r][c] = load8(x + off + 256 * c); dv[r][c] = load8(dy + off + 256 * c); }
             mu[r] = mean[rowc]; rs[r] = rstd[rowc];
         }
-        if (din.thr16) {      // the LayerNorm's OUTPUT went through nn.Dropout in the forward (embeddings.py:345): dy = dropout_backward(incoming), element
+        if (DIN && din.thr16) {      // the LayerNorm's OUTPUT went through nn.Dropout in the forward (embeddings.py:345): dy = dropout_backward(incoming), element
                               // index row * H + col, rounded to bf16 like the separate mmf_dropout_bf16 launch stored it
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -1484,7 +1484,9 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* mean, 
         // two rows of a half-wave in flight whenever it owns more than one (MMF_TUN_LN_OLD = 2: one at a time, the round-3 form; A/B)
         const bool two = rows > 8 * grid && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 2;
 #define MMF_LNB_H(NC)                                                                                                              \
-        if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \
+        /* (input dropout: one row in flight per half-wave — with two the H = 768 form needs all 256 registers and a single wave per SIMD) */ \
+        if (din.thr16) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 1, true>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \
+        else if (dbias) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, true, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \
         else if (two) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 2>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \
         else hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 1>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din);
         switch (H / 256) {

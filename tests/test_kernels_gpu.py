@@ -907,7 +907,16 @@ def test_layernorm_with_fused_dropout_is_bit_identical_to_two_launches(rows, H):
     nat().dropout(dy, d2, drop)
     ws = torch.empty(nat().layernorm_bwd_ws_floats(H), device=DEV)
     dx0 = torch.empty_like(x); dg0 = torch.empty(H, device=DEV); db0 = torch.empty(H, device=DEV)
-    nat().layernorm_bwd(d2, x, mean0, rstd0, gamma, dx0, None, nat().NO_DROP, dg0, db0, None, 0, ws, rows, H)
+    # (the fused form keeps ONE row in flight per half-wave — with two, the extra hash registers would cost the H = 768 kernel its second wave per SIMD —
+    # so the two-launch reference runs the same row schedule: MMF_TUN_LN_OLD = 2)
+    nat().set_tunable(nat().TUN_LN_OLD, 2)
+    try:
+        nat().layernorm_bwd(d2, x, mean0, rstd0, gamma, dx0, None, nat().NO_DROP, dg0, db0, None, 0, ws, rows, H)
+    finally:
+        nat().set_tunable(nat().TUN_LN_OLD, 0)
+    dxn = torch.empty_like(x); dgn = torch.empty(H, device=DEV); dbn = torch.empty(H, device=DEV)
+    nat().layernorm_bwd(d2, x, mean0, rstd0, gamma, dxn, None, nat().NO_DROP, dgn, dbn, None, 0, ws, rows, H)      # the default (two-row) schedule
+    close(dxn, dx0, 1e-2, 1e-3, "two-row vs one-row schedule dx"); close(dgn, dg0, 1e-5, 1e-3, "dgamma"); close(dbn, db0, 1e-5, 1e-3, "dbeta")
     dx1 = torch.empty_like(x); dg1 = torch.empty(H, device=DEV); db1 = torch.empty(H, device=DEV)
     nat().layernorm_bwd_din(dy, x, mean0, rstd0, gamma, dx1, drop, dg1, db1, 0, ws, rows, H)
     assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)

@@ -40,14 +40,14 @@ def ln_sweep():
     dg = torch.empty(H, device=dev); db = torch.empty(H, device=dev); dbias = torch.empty(H, device=dev)
     ws = torch.empty(nat.layernorm_bwd_ws_floats(H), device=dev)
     y = torch.empty_like(x)
-    for old in (0, 1):
+    for old in (0, 2, 1):      # 0: half-wave kernels, two rows in flight; 2: the same, one row in flight; 1: the one-wave-per-row kernels
         nat.set_tunable(nat.TUN_LN_OLD, old)
         tf = timeit(lambda: nat.layernorm_fwd(x, gamma, gamma, y, mean, rstd, rows, H, 1e-12))
         t0 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat.NO_DROP, dg, db, None, False, ws, rows, H))
         t1 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, None, False, ws, rows, H))
         t2 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, dbias, False, ws, rows, H))
         print("%s kernels: fwd %5.1f us (%.2f TB/s)  bwd plain %5.1f  bwd+dropout %5.1f (%.2f TB/s incl. reduce)  +dbias %5.1f" % (
-            "one-wave-per-row" if old else "half-wave-per-row", tf, 22.4e6 / tf / 1e6, t0, t1, 44.8e6 / t1 / 1e6, t2), flush=True)
+            {0: "half-wave-per-row", 2: "half-wave, 1 row  ", 1: "one-wave-per-row "}[old], tf, 22.4e6 / tf / 1e6, t0, t1, 44.8e6 / t1 / 1e6, t2), flush=True)
     nat.set_tunable(nat.TUN_LN_OLD, 1)
     for grid in (128, 192, 256, 384, 512):
         nat.set_tunable(nat.TUN_LN_BWD_GRID, grid)

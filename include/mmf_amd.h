@@ -33,7 +33,8 @@ int mmf_amd_abi_version(void);
 enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
        MMF_TUN_LN_BWD_GRID = 1,    /* workgroups of mmf_layernorm_bwd (<= MMF_LN_BWD_MAX_GRID) */
        MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 */
-       MMF_TUN_LN_OLD = 3,         /* 1: LayerNorm with the one-wave-per-row, 8-byte-per-lane kernels even when H % 256 == 0 (A/B measurements) */
+       MMF_TUN_LN_OLD = 3,         /* 1: LayerNorm with the one-wave-per-row, 8-byte-per-lane kernels even when H % 256 == 0; 2: half-wave backward with one row in flight;
+                                      3: two rows in flight at H = 1024 too (A/B measurements) */
        MMF_TUN_ATTN_BWD_TWO_PASS = 4,   /* 1: head_dim-64 attention backward as the separate dQ and dK/dV kernels (A/B measurements) */
        MMF_TUN_GEMM_WIDE_KS = 5,   /* wide-tile wave layout: 2 the two ping-pong groups split every K-step (fewer LDS fragment reads), 0 / 1 never (the default since
                                       round 4: faster in isolation at long K, slower inside the step), 3 the round-3 rule (256x96, K >= 1536) */

@@ -1481,8 +1481,10 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* mean, 
     if (lnb_h_path(H, dbias != nullptr)) {     // half a wave per row, 16-byte accesses
         const int grid = lnb_h_grid(rows);
         const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
-        // two rows of a half-wave in flight whenever it owns more than one (MMF_TUN_LN_OLD = 2: one at a time, the round-3 form; A/B)
-        const bool two = rows > 8 * grid && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 2;
+        // two rows of a half-wave in flight whenever it owns more than one (MMF_TUN_LN_OLD = 2: one at a time, the round-3 form; A/B) — except at H = 1024, where
+        // the two-row form needs all 256 registers = ONE wave per SIMD and loses to the one-row form at two (isolated, backward + dropout + reduce: 14.1 vs 13.0 us
+        // at 3232 rows, 36.5 vs 28.7 at 14592: profiles/r05_experiments.txt section 14)
+        const bool two = rows > 8 * grid && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 2 && (H < 1024 || mmf_amd_get_tunable(MMF_TUN_LN_OLD) == 3);      // (3: two rows at H = 1024 too, A/B)
 #define MMF_LNB_H(NC)                                                                                                              \
         /* (input dropout: one row in flight per half-wave — with two the H = 768 form needs all 256 registers and a single wave per SIMD) */ \
         if (din.thr16) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 1, true>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \

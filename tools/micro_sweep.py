@@ -32,7 +32,7 @@ def timeit(f, iters=30):
 
 
 def ln_sweep():
-    rows, H = 7296, 768
+    rows, H = int(os.environ.get("LN_ROWS", "7296")), int(os.environ.get("LN_H", "768"))      # (ViLBERT's visual stream: LN_ROWS=3232 LN_H=1024)
     dev = "cuda"
     dy = torch.randn(rows, H, device=dev).bfloat16(); x = torch.randn(rows, H, device=dev).bfloat16()
     mean = torch.randn(rows, device=dev); rstd = torch.rand(rows, device=dev) + 0.5; gamma = torch.randn(H, device=dev)
@@ -47,7 +47,7 @@ def ln_sweep():
         t1 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, None, False, ws, rows, H))
         t2 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, dbias, False, ws, rows, H))
         print("%s kernels: fwd %5.1f us (%.2f TB/s)  bwd plain %5.1f  bwd+dropout %5.1f (%.2f TB/s incl. reduce)  +dbias %5.1f" % (
-            {0: "half-wave-per-row", 2: "half-wave, 1 row  ", 1: "one-wave-per-row "}[old], tf, 22.4e6 / tf / 1e6, t0, t1, 44.8e6 / t1 / 1e6, t2), flush=True)
+            {0: "half-wave-per-row", 2: "half-wave, 1 row  ", 1: "one-wave-per-row "}[old], tf, 4.0 * rows * H / tf / 1e6, t0, t1, 8.0 * rows * H / t1 / 1e6, t2), flush=True)
     nat.set_tunable(nat.TUN_LN_OLD, 1)
     for grid in (128, 192, 256, 384, 512):
         nat.set_tunable(nat.TUN_LN_BWD_GRID, grid)

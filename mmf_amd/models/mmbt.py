@@ -116,9 +116,12 @@ class MMBTModel(nn.Module):
             am = torch.cat([torch.ones(B, L, dtype=torch.int64, device=dev), attention_mask.long()], dim=1)  # :232-238
         mask_add = torch.empty(B, S, dtype=torch.float32, device=dev)
         Fn.nat.make_additive_mask(am.contiguous(), mask_add)                                # (1 - m) * -10000, :283
-        sequence_output = self.transformer.encoder(hidden, mask_add.view(B, 1, 1, S))[0]
+        encoder_outputs = self.transformer.encoder(hidden, mask_add.view(B, 1, 1, S))
+        sequence_output = encoder_outputs[0]
         pooled_output = self.transformer.pooler(sequence_output)
-        return sequence_output, pooled_output
+        # :302-316 — `encoder_outputs[1:]`: the reference calls the (JIT-replaced) encoder without its `output_hidden_states` / `output_attentions` arguments
+        # (hf_layers.py:317-356 collects them only when the ARGUMENTS are set), so this tail is empty there too, whatever the config flags say
+        return sequence_output, pooled_output, encoder_outputs[1:]
 
     def get_input_embeddings(self):
         return self.transformer.embeddings.word_embeddings
@@ -204,8 +207,6 @@ class MMBTForPreTraining(nn.Module):
         self.config = config
         self.bert = MMBTBase(config, *args, **kwargs)
         self.encoder_config = self.bert.encoder_config
-        if self.encoder_config.output_attentions or self.encoder_config.output_hidden_states:
-            raise NotImplementedError("output_attentions / output_hidden_states (`extras`, mmbt.py:486-490) are not built")
         # (offline: the architecture of `bert_model_name`; weights arrive through load_state_dict / an MMF checkpoint)
         self.cls = BertPreTrainingHeads(self.encoder_config)
         self.cls.apply(lambda m: init_bert_weights(m, self.encoder_config.initializer_range))
@@ -219,6 +220,8 @@ class MMBTForPreTraining(nn.Module):
         module_output = self.bert(sample_list)
         sequence_output = module_output[0]
         output = {}
+        if self.encoder_config.output_hidden_states or self.encoder_config.output_attentions:      # :486-490 (an empty tail in the reference as well: see MMBTModel.forward)
+            output["extras"] = module_output[2:]
         loss_key = "{}/{}".format(sample_list["dataset_name"], sample_list["dataset_type"])
         lm_label_ids = sample_list["lm_label_ids"] if "lm_label_ids" in sample_list else None
         if lm_label_ids is not None:
@@ -251,8 +254,6 @@ class MMBTForClassification(nn.Module):
         self.num_labels = self.config.num_labels
         self.output_hidden_states = self.encoder_config.output_hidden_states
         self.output_attentions = self.encoder_config.output_attentions
-        if self.output_attentions:
-            raise NotImplementedError("output_attentions: the fused attention kernel never materialises the probabilities")
         self.fused_feature_only = self.config.get("fused_feature_only", False)
         self.dropout_prob = self.encoder_config.hidden_dropout_prob
         self.classifier = nn.Sequential(
@@ -265,6 +266,8 @@ class MMBTForClassification(nn.Module):
         module_output = self.bert(sample_list)
         pooled_output = module_output[1]
         output = {}
+        if self.output_hidden_states or self.output_attentions:      # :545-547 (an empty tail in the reference as well: see MMBTModel.forward)
+            output["extras"] = module_output[2:]
         pooled_output = torch.ops.mmf_amd.dropout(pooled_output, self.dropout_prob, self.training)
         if self.fused_feature_only:
             output["fused_feature"] = self.classifier[0](pooled_output)

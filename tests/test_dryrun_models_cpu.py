@@ -208,6 +208,23 @@ def test_visual_bert_output_attentions_is_accepted_and_empty_like_the_reference(
         assert "attention_weights" not in m2(SampleList({k: v for k, v in sample.items() if k != "targets"}))
 
 
+def test_mmbt_extras_are_accepted_and_empty_like_the_reference():
+    """`output_attentions` / `output_hidden_states` of MMBT's text encoder: the reference hands `module_output[2:]` on as `extras` (mmbt.py:486-490, 545-547),
+    and that tail is `(encoder_outputs[1:],)` of an encoder called WITHOUT the two arguments (mmbt.py:302-316, hf_layers.py:317-356): one empty tuple."""
+    z, case, cfg, sd, sample = G.load_mmbt_case()
+    from oracle.mmbt_oracle import SHARED
+    conf = MU.mmbt_model_config(cfg)
+    conf["text_encoder"]["params"]["output_attentions"] = True
+    from mmf_amd.utils.build import build_model
+    m = build_model(conf).eval()
+    with native_stub.installed():
+        out = m(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+    assert "extras" in out and len(out["extras"]) == 1 and len(out["extras"][0]) == 0
+    m2 = MU.build_mmbt(cfg, sd, SHARED, device="cpu").eval()
+    with native_stub.installed():
+        assert "extras" not in m2(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+
+
 def test_mmbt_config_branches_plumbing():
     """No modal start / end tokens, `fused_feature_only`, frozen text / modal halves (mmbt.py:173-178,229-231,253-259)."""
     from oracle.mmbt_oracle import SHARED

@@ -69,8 +69,9 @@ class MMBTModel(nn.Module):
     def forward(self, input_modal, input_ids, modal_start_tokens=None, modal_end_tokens=None, attention_mask=None,
                 token_type_ids=None, modal_token_type_ids=None, position_ids=None, modal_position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None):
-        if position_ids is not None or modal_position_ids is not None or inputs_embeds is not None or head_mask is not None:
-            raise NotImplementedError("explicit position ids / inputs_embeds / head_mask are not on the built MMBT path")
+        if position_ids is not None or modal_position_ids is not None or inputs_embeds is not None:
+            raise NotImplementedError("explicit position ids / inputs_embeds are not on the built MMBT path")
+        # (`head_mask` is accepted and unused, as in the reference: MMBTModel.forward never hands it to the encoder, mmbt.py:302-307)
         input_modal = self.modal_encoder.encoder(input_modal)
         if input_modal.dim() == 2:
             input_modal = input_modal.unsqueeze(1)

@@ -403,7 +403,7 @@ def test_attention_keep_bit_table_replays_the_forwards_dropout_decisions(S, mode
                             torch.empty(B, heads, S2, device=DEV), B, heads, S2, S2, 0.125, drop, keep_bits=torch.zeros(1024, dtype=torch.int32, device=DEV))
 
 
-@pytest.mark.parametrize("Sq,Sk,d", [(128, 101, 128), (101, 128, 128), (36, 20, 128), (128, 101, 64), (200, 64, 64)])
+@pytest.mark.parametrize("Sq,Sk,d", [(128, 101, 128), (101, 128, 128), (36, 20, 128), (128, 101, 64), (200, 64, 64), (100, 228, 64), (64, 256, 64), (256, 130, 64)])
 def test_attention_keep_bit_table_cross_attention_and_head_dim_128(Sq, Sk, d):
     """The same for q and k / v from different sequences (ViLBERT's co-attention, vilbert.py:388-475) and head_dim 128 (its visual stream)."""
     B, heads = 2, 3

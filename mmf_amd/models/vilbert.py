@@ -15,8 +15,9 @@ dense+dropout+residual+LayerNorm nodes and two feed-forward nodes.
 The `nlvr2` head (two images per sample, :1262-1265, 1322-1323, 1369-1394) is built.
 The pretraining head (:1054-1240, `visual_target` 0 / 1 / 2), `fixed_{t,v}_layer` (:625-666) and the `in_batch_pairs` / `fast_mode` batch
 expansion (:678-725, `expand_batch_kernel` / `reduce_batch_kernel`; bf16 path) are built too.
-Not built (raise): `task_specific_tokens`, `in_batch_pairs` / `fast_mode` together with `dynamic_attention`, and attention-map outputs
-(`visualization`, `output_all_attention_masks`: the fused kernel never materialises them).
+Not built (raise): `task_specific_tokens`, `in_batch_pairs` / `fast_mode` together with `dynamic_attention`, and asking the inner modules for the
+attention maps (`output_all_attention_masks=True`: the fused kernels never materialise them; the `visualization` config flag itself is accepted — through the
+registered model the reference never returns the maps either).
 """
 import os
 
@@ -418,8 +419,10 @@ class ViLBERTBase(nn.Module):
             # the reference's own path fails here: it extends the text mask by one token (vilbert.py:971-974) that its embeddings never add (no caller passes
             # task_ids, and HF's BertEmbeddings would take them as position_ids, :1018) -> a size mismatch in the first text layer
             raise NotImplementedError("task_specific_tokens (vilbert.py:971-974): the reference path itself fails with a size mismatch; not built")
-        if getattr(config, "visualization", False):
-            raise NotImplementedError("visualization: the fused attention kernel never materialises the probabilities")
+        # `visualization: true` is accepted: in the reference it only makes the attention modules return their probabilities in `attn_data`
+        # (vilbert.py:105-114, 238-247, 465-475), which the encoder collects when `output_all_attention_masks` is set (:599-795) — an argument the registered
+        # model never passes (ViLBERT.forward -> self.model(...), :1445-1455), so through MMF's interface the flag changes no output.  Asking the inner
+        # modules for the maps directly (`output_all_attention_masks=True`) raises in ViLBERTBase / BertEncoder: the fused kernels do not materialise them.
         self.embeddings = BertEmbeddingsJit(config)
         self.v_embeddings = BertImageFeatureEmbeddings(config)
         self.encoder = BertEncoder(config)

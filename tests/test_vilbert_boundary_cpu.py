@@ -35,7 +35,11 @@ def test_dynamic_attention_adds_the_gate_parameters_of_the_reference():
 def test_unbuilt_variants_raise():
     z, case, cfg, sd, sample = load_vilbert_case()
     for over in (dict(training_head_type="pretraining", visual_target=3),
-                 dict(in_batch_pairs=True, dynamic_attention=True), dict(fast_mode=True, dynamic_attention=True), dict(task_specific_tokens=True),
-                 dict(visualization=True)):
+                 dict(in_batch_pairs=True, dynamic_attention=True), dict(fast_mode=True, dynamic_attention=True), dict(task_specific_tokens=True)):
         with pytest.raises(NotImplementedError):
             build_model(vilbert_model_config(cfg, **over))
+    # `visualization: true` builds: through the registered model the reference never asks its encoder for the collected maps (ViLBERT.forward does not pass
+    # `output_all_attention_masks`, vilbert.py:1445-1455), so the flag changes no output; asking the inner modules directly raises
+    model = build_model(vilbert_model_config(cfg, visualization=True))
+    with pytest.raises(NotImplementedError):
+        model.model.bert.encoder(None, None, None, None, None, output_all_attention_masks=True)

@@ -59,7 +59,9 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
                                       0.22 - 0.32 ms per step faster INSIDE the step (round 4; A/B) */
        MMF_TUN_ATTN_KEEP_BITS_OFF = 16,   /* 1: mmf_attention_keep_bits_words returns 0 — the attention backward hashes its dropout decisions again instead of reading
                                              the forward's keep-bit table (A/B: tools/step_ab.py 16:1 16:0) */
-       MMF_TUN_COUNT = 17 };
+       MMF_TUN_SCATTER_ATOMIC = 17,   /* 1: mmf_rows_scatter_add with an index array always takes the fp32-atomic kernel (the round-1 form; A/B and the fallback beyond
+                                          16384 rows) instead of the deterministic owner-wave kernel */
+       MMF_TUN_COUNT = 18 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)
@@ -303,7 +305,8 @@ int mmf_copy_rows_bf16(const void* src, int src_bstride, void* dst, int dst_bstr
                        void* stream);
 /* out[idx[r]] += x[row r] for r in [0, nb*rpb): row r = (b, i) lives at x + (b*bstride + i)*ld.
  * idx == NULL means bucket (i + idx_base) (position ids) when per_pos != 0, else bucket idx_base.
- * fp32 atomics into `out` [nbuckets, H] (caller zero-fills when not accumulating).
+ * `out` [nbuckets, H] fp32 is added to (caller zero-fills when not accumulating).  With an index array and up to 16384 source rows the sums are formed WITHOUT atomics, in
+ * source-row order (one owner wave per distinct bucket): deterministic; beyond that, and for idx == NULL with per_pos == 0, fp32 atomics.
  * few_buckets != 0: the table has `nbuckets` rows and (almost) every index is 0 or 1 (token-type tables,
  * position_ids_visual == 0): deterministic two-stage column sums through `ws`
  * (mmf_rows_scatter_add_ws_floats(H) floats) instead of atomics.

@@ -602,6 +602,68 @@ __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __r
     }
 }
 
+// The same without atomics, deterministic (round 5): one wave per source row r = (b, i).  The wave scans the index array — 64 entries per step, ballot — and
+// leaves unless r is the FIRST row with its bucket ("owner"); the owner goes on through the rows behind it, adds every row of the same bucket in increasing row
+// order and writes out[bucket] once.  No two waves write the same output row, the order of the additions is fixed: the word-embedding gradient (the one
+// atomically accumulated tensor of the VisualBERT step) is bit-reproducible, and 4096 rows x 768 columns take ~12 us instead of 46 us of fp32 atomics.
+// O(rows^2 / 64) index comparisons in total (262144 wave steps at 4096 rows): used up to SCATTER_UNIQUE_MAX rows, the atomic form beyond.
+constexpr int SCATTER_UNIQUE_MAX = 16384;
+__global__ __launch_bounds__(256) void scatter_add_unique_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
+                                                                  const int64_t* __restrict__ idx, int idx_ld, float* __restrict__ out, int H, int skip,
+                                                                  int nbuckets) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = nb * rpb;
+    if (r >= total) return;
+    const int b = r / rpb, i = r - b * rpb;
+    const int64_t bk = idx[(size_t)b * idx_ld + i];
+    if (bk == skip) return;
+    if (nbuckets > 0 && (bk < 0 || bk >= nbuckets)) { if (lane == 0) flag_index_error(); return; }
+    auto bucket_at = [&](int q) -> int64_t {      // bucket of source row q (rows are numbered b * rpb + i)
+        const int qb = q / rpb;
+        return idx[(size_t)qb * idx_ld + (q - qb * rpb)];
+    };
+    // an earlier row with this bucket owns it
+    for (int q0 = 0; q0 < r; q0 += 64) {
+        const int q = q0 + lane;
+        const bool hit = q < r && bucket_at(q) == bk;
+        if (__builtin_amdgcn_ballot_w64(hit)) return;
+    }
+    // owner: this row, then every later row of the bucket, in row order
+    f32x4 acc[4];      // columns 4 * lane + 256 * c, c < 4 (H <= 1024; wider rows loop over column blocks below)
+    for (int c0 = 0; c0 < H; c0 += 1024) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = c0 + 256 * c + 4 * lane;
+            acc[c] = col < H ? load4(x + ((size_t)b * bstride + i) * ld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int q0 = r + 1; q0 < total; q0 += 64) {
+            const int q = q0 + lane;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(q < total && bucket_at(q) == bk);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const int qq = q0 + j, qb = qq / rpb, qi = qq - qb * rpb;
+                const bf16* src = x + ((size_t)qb * bstride + qi) * ld;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = c0 + 256 * c + 4 * lane;
+                    if (col < H) acc[c] += load4(src + col);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = c0 + 256 * c + 4 * lane;
+            if (col < H) {
+                float* o = out + (size_t)bk * H + col;
+                const f32x4 old = load4(o);
+                *reinterpret_cast<float4*>(o) = make_float4(old[0] + acc[c][0], old[1] + acc[c][1], old[2] + acc[c][2], old[3] + acc[c][3]);
+            }
+        }
+    }
+}
+
 // Position-table gradient: bucket = idx_base + (row index inside the sample), no index array, i.e. out[idx_base + i][c] +=
 // sum_b x[b][i][c] — a plain strided sum over the batch (deterministic; the atomic form has every sample hit the same rows).
 __global__ __launch_bounds__(256) void scatter_add_pos_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride, int idx_base,
@@ -1643,6 +1705,9 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
     } else if (!idx && per_pos && skip_bucket < 0) {
         hipLaunchKernelGGL(scatter_add_pos_kernel, dim3(rpb, (H / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb,
                            bstride, idx_base, out, H);
+    } else if (idx && total <= SCATTER_UNIQUE_MAX && mmf_amd_get_tunable(MMF_TUN_SCATTER_ATOMIC) != 1) {      // deterministic, no atomics (index array given: idx_base / per_pos unused)
+        hipLaunchKernelGGL(scatter_add_unique_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb, bstride, idx,
+                           idx_ld, out, H, skip_bucket, nbuckets);
     } else {
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
                            ld, nb, rpb, bstride, idx, idx_ld, per_pos, idx_base, out, H, skip_bucket, nbuckets);

@@ -940,6 +940,46 @@ def test_step_advance_is_seed_advance_plus_optim_state_advance():
     assert int(seed) == 43 and state.tolist() == [11.0, 1.0]
 
 
+@pytest.mark.parametrize("B,T,S,H,V,dups", [(32, 128, 228, 768, 30522, 0.0), (8, 64, 64, 768, 50, 0.0), (3, 40, 57, 1024, 1000, 0.9), (2, 30, 30, 1280, 7, 0.0)])
+def test_rows_scatter_add_with_an_index_array_is_deterministic_and_atomic_free(B, T, S, H, V, dups):
+    """mmf_rows_scatter_add with an index array (the word-embedding gradient, embeddings.py:329-345 backward): one owner wave per distinct id adds that id's
+    rows in row order and writes the output row once — against float64 torch, bit-identical from run to run and in row order (a float32 running sum in
+    that order reproduces it exactly), and against the fp32-atomic kernel it replaces; the padding id is skipped, the output is added to."""
+    g = torch.Generator(device="cpu"); g.manual_seed(B * T + H)
+    ids = torch.randint(0, V, (B, T), generator=g)
+    if dups:
+        ids[torch.rand(B, T, generator=g) < dups] = 3          # one id for most rows: a long run for a single owner
+    ids[0, :2] = 0                                             # some padding tokens
+    ids = ids.to(DEV)
+    d = rnd(B * S, H, seed=V)
+    base = rnd(V, H, dtype=torch.float32, seed=1)
+    outs = []
+    for rep in range(3):
+        out = base.clone()
+        nat().rows_scatter_add(d, H, B, T, S, ids, T, 0, 0, out, H, 0, 0)       # skip_bucket = 0: nn.Embedding(padding_idx=0)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    rows = d.view(B, S, H)[:, :T].reshape(-1, H).float()
+    flat = ids.view(-1)
+    keep = flat != 0
+    ref = base.double().index_add_(0, flat[keep], rows[keep].double())
+    close(outs[0], ref.float(), 1e-5, 1e-4 * math.sqrt(B * T), "owner-wave scatter add")
+    assert torch.equal(outs[0][0], base[0])                    # the padding row received nothing
+    # exact order: float32 running sums in row order
+    for bucket in flat[keep].unique()[:5].tolist():
+        acc = torch.zeros(H, device=DEV)
+        for r in torch.nonzero(flat == bucket).view(-1).tolist():
+            acc = acc + rows[r]
+        assert torch.equal(outs[0][bucket], base[bucket] + acc), bucket
+    nat().set_tunable(17, 1)                                   # MMF_TUN_SCATTER_ATOMIC: the fp32-atomic kernel
+    try:
+        old = base.clone()
+        nat().rows_scatter_add(d, H, B, T, S, ids, T, 0, 0, old, H, 0, 0)
+    finally:
+        nat().set_tunable(17, 0)
+    close(outs[0], old, 1e-5, 1e-4 * math.sqrt(B * T), "owner-wave vs atomics")
+
+
 def test_embedding_indices_are_bounded_like_nn_embedding():
     """nn.Embedding raises IndexError for an id outside its table; here the host cannot see device ids without a sync, so the
     kernels skip the offending rows (forward: zero row; backward: no atomic write out of bounds) and raise a device flag that

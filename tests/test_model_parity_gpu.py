@@ -330,6 +330,39 @@ def test_nlvr2_head_golden_forward_loss_and_gradients():
     assert not bad, bad
 
 
+def test_training_step_is_bit_reproducible_from_run_to_run():
+    """Train mode (dropout on, masks keyed off the same seed word), a batch whose text repeats a handful of token ids many times (every word-table gradient row
+    is a sum of several source rows): two independently built and captured steps end three updates with the same loss and the same bits in every parameter
+    and moment.  The step holds no fp32 atomics any more: the word-embedding scatter (`mmf_rows_scatter_add` with an index array) adds each id's rows in row
+    order from one owner wave."""
+    from mmf_amd.modules.optimizers import AdamW
+    from mmf_amd.utils.configuration import Config
+    from mmf_amd.utils.graph import GraphedTrainStep
+    z, case, cfg, sd, sample = load_case("small64")
+    sample = dict(sample)
+    sample["input_ids"] = sample["input_ids"] % 5 + 1
+    batch = SampleList(sample_to(sample, "cuda"))
+    res = []
+    for rep in range(2):
+        m = build_visual_bert(cfg, sd)
+        m.train()
+        o = AdamW(m.get_optimizer_parameters(Config(model="visual_bert", optimizer=dict(params=dict(lr=1e-3)), model_config=dict(visual_bert=m.config))),
+                  lr=1e-3, capturable=True)
+        g = GraphedTrainStep(m, batch, warmup=1, optimizer=o)
+        losses = [float(g()) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()},
+                    {n: o.state[p]["exp_avg"].clone() for n, p in m.named_parameters() if p in o.state and len(o.state[p])}))
+        del g
+    (la, pa, ma), (lb, pb, mb) = res
+    assert la == lb
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
+    for n in ma:
+        assert torch.equal(ma[n], mb[n]), n
+    assert float(ma["model.bert.embeddings.word_embeddings.weight"].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("mode", [True, "attention"])
 def test_optimizer_in_backward_equals_end_of_step_update(mode):
     """`GraphedTrainStep(overlap_update="attention")` (round 3): the update of layer L runs on a second stream exactly beside the attention

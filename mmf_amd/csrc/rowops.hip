@@ -611,55 +611,72 @@ constexpr int SCATTER_UNIQUE_MAX = 16384;
 __global__ __launch_bounds__(256) void scatter_add_unique_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                   const int64_t* __restrict__ idx, int idx_ld, float* __restrict__ out, int H, int skip,
                                                                   int nbuckets) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ int sb[];      // the bucket of every source row (rows are numbered b * rpb + i): staged once per workgroup — scanned from global
+                                     // memory the 64 dependent steps of a wave cost a cache round trip each (48 us per launch, no better than the atomics)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nb * rpb;
-    if (r >= total) return;
-    const int b = r / rpb, i = r - b * rpb;
-    const int64_t bk = idx[(size_t)b * idx_ld + i];
+    const int r = blockIdx.x;                 // one WORKGROUP per source row: its four waves share the scan and take a quarter of the columns each, so the
+                                              // longest run of equal ids (frequent tokens) moves through four waves' worth of loads instead of one
+    const int bk = [&]() { const int qb = r / rpb; const int64_t v = idx[(size_t)qb * idx_ld + (r - qb * rpb)]; return (v < 0 || v > 0x7ffffffe) ? -2 : (int)v; }();
     if (bk == skip) return;
-    if (nbuckets > 0 && (bk < 0 || bk >= nbuckets)) { if (lane == 0) flag_index_error(); return; }
-    auto bucket_at = [&](int q) -> int64_t {      // bucket of source row q (rows are numbered b * rpb + i)
-        const int qb = q / rpb;
-        return idx[(size_t)qb * idx_ld + (q - qb * rpb)];
-    };
-    // an earlier row with this bucket owns it
-    for (int q0 = 0; q0 < r; q0 += 64) {
+    if (bk < 0 || (nbuckets > 0 && bk >= nbuckets)) { if (threadIdx.x == 0) flag_index_error(); return; }
+    // an earlier row with this bucket owns it (every wave checks the rows [0, r) a quarter each; the verdict is shared through LDS)
+    __shared__ int owned;
+    if (threadIdx.x == 0) owned = 0;
+    __syncthreads();
+    for (int q0 = wave * 64; q0 < r; q0 += 256) {
         const int q = q0 + lane;
-        const bool hit = q < r && bucket_at(q) == bk;
-        if (__builtin_amdgcn_ballot_w64(hit)) return;
+        bool hit = false;
+        if (q < r) { const int qb = q / rpb; hit = idx[(size_t)qb * idx_ld + (q - qb * rpb)] == (int64_t)bk; }
+        if (__builtin_amdgcn_ballot_w64(hit)) { if (lane == 0) owned = 1; break; }
     }
-    // owner: this row, then every later row of the bucket, in row order
-    f32x4 acc[4];      // columns 4 * lane + 256 * c, c < 4 (H <= 1024; wider rows loop over column blocks below)
-    for (int c0 = 0; c0 < H; c0 += 1024) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = c0 + 256 * c + 4 * lane;
-            acc[c] = col < H ? load4(x + ((size_t)b * bstride + i) * ld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        for (int q0 = r + 1; q0 < total; q0 += 64) {
+    __syncthreads();
+    if (owned) return;
+    // owner: stage the buckets of the rows behind this one, then every wave adds its quarter of the columns of this row and of every later row of the
+    // bucket, in row order
+    const int rest = total - (r + 1);
+    for (int q = threadIdx.x; q < rest; q += 256) {
+        const int qq = r + 1 + q, qb = qq / rpb;
+        const int64_t v = idx[(size_t)qb * idx_ld + (qq - qb * rpb)];
+        sb[q] = (v < 0 || v > 0x7ffffffe) ? -2 : (int)v;
+    }
+    __syncthreads();
+    const int wq = H >> 2;                    // columns per wave (a multiple of 4)
+    const int b = r / rpb, i = r - b * rpb;
+    for (int c0 = 0; c0 < wq; c0 += 256) {
+        const int col = wave * wq + c0 + 4 * lane;
+        const bool on = c0 + 4 * lane < wq;
+        f32x4 acc = on ? load4(x + ((size_t)b * bstride + i) * ld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < rest; q0 += 64) {
             const int q = q0 + lane;
-            unsigned long long m = __builtin_amdgcn_ballot_w64(q < total && bucket_at(q) == bk);
-            while (m) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                const int qq = q0 + j, qb = qq / rpb, qi = qq - qb * rpb;
-                const bf16* src = x + ((size_t)qb * bstride + qi) * ld;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(q < rest && sb[q] == bk);
+            constexpr int RF = 4;
+            while (m) {      // up to four rows of the run in flight, added in row order (more in flight measured no faster)
+                const bf16* src[RF];
+                int n = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int col = c0 + 256 * c + 4 * lane;
-                    if (col < H) acc[c] += load4(src + col);
+                for (int u = 0; u < RF; ++u) {
+                    src[u] = x;
+                    if (m) {
+                        const int j = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int qq = r + 1 + q0 + j, qb = qq / rpb, qi = qq - qb * rpb;
+                        src[u] = x + ((size_t)qb * bstride + qi) * ld;
+                        n = u + 1;
+                    }
                 }
+                f32x4 v[RF];
+#pragma unroll
+                for (int u = 0; u < RF; ++u) v[u] = (u < n && on) ? load4(src[u] + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < RF; ++u)
+                    if (u < n) acc += v[u];
             }
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = c0 + 256 * c + 4 * lane;
-            if (col < H) {
-                float* o = out + (size_t)bk * H + col;
-                const f32x4 old = load4(o);
-                *reinterpret_cast<float4*>(o) = make_float4(old[0] + acc[c][0], old[1] + acc[c][1], old[2] + acc[c][2], old[3] + acc[c][3]);
-            }
+        if (on) {
+            float* o = out + (size_t)bk * H + col;
+            const f32x4 old = load4(o);
+            *reinterpret_cast<float4*>(o) = make_float4(old[0] + acc[0], old[1] + acc[1], old[2] + acc[2], old[3] + acc[3]);
         }
     }
 }
@@ -1705,8 +1722,14 @@ int mmf_rows_scatter_add(const void* x, int ld, int nb, int rpb, int bstride, co
     } else if (!idx && per_pos && skip_bucket < 0) {
         hipLaunchKernelGGL(scatter_add_pos_kernel, dim3(rpb, (H / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb,
                            bstride, idx_base, out, H);
-    } else if (idx && total <= SCATTER_UNIQUE_MAX && mmf_amd_get_tunable(MMF_TUN_SCATTER_ATOMIC) != 1) {      // deterministic, no atomics (index array given: idx_base / per_pos unused)
-        hipLaunchKernelGGL(scatter_add_unique_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb, bstride, idx,
+    } else if (idx && total <= SCATTER_UNIQUE_MAX && (H % 16) == 0 && mmf_amd_get_tunable(MMF_TUN_SCATTER_ATOMIC) != 1) {      // deterministic, no atomics (index array given: idx_base / per_pos unused)
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_add_unique_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SCATTER_UNIQUE_MAX * 4);
+            if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(scatter_add_unique_kernel, dim3(total), dim3(256), total * 4, (hipStream_t)stream, (const bf16*)x, ld, nb, rpb, bstride, idx,
                            idx_ld, out, H, skip_bucket, nbuckets);
     } else {
         hipLaunchKernelGGL(scatter_add_direct_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,

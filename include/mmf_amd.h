@@ -305,8 +305,8 @@ int mmf_copy_rows_bf16(const void* src, int src_bstride, void* dst, int dst_bstr
                        void* stream);
 /* out[idx[r]] += x[row r] for r in [0, nb*rpb): row r = (b, i) lives at x + (b*bstride + i)*ld.
  * idx == NULL means bucket (i + idx_base) (position ids) when per_pos != 0, else bucket idx_base.
- * `out` [nbuckets, H] fp32 is added to (caller zero-fills when not accumulating).  With an index array and up to 16384 source rows the sums are formed WITHOUT atomics, in
- * source-row order (one owner wave per distinct bucket): deterministic; beyond that, and for idx == NULL with per_pos == 0, fp32 atomics.
+ * `out` [nbuckets, H] fp32 is added to (caller zero-fills when not accumulating).  With an index array, up to 16384 source rows and H a multiple of 16 the sums are formed WITHOUT
+ * atomics, in source-row order (one owner workgroup per distinct bucket): deterministic; beyond that, and for idx == NULL with per_pos == 0, fp32 atomics.
  * few_buckets != 0: the table has `nbuckets` rows and (almost) every index is 0 or 1 (token-type tables,
  * position_ids_visual == 0): deterministic two-stage column sums through `ws`
  * (mmf_rows_scatter_add_ws_floats(H) floats) instead of atomics.

@@ -124,6 +124,13 @@ def test_training_step_plumbing(name):
         loss.sum().backward()
         opt.step()
     assert any(c[0] == "gemm" for c in calls) and any(c[0] == "attention_bwd" for c in calls) and any(c[0] == "adamw_multi" for c in calls)
+    if name.startswith("visual_bert"):               # round 5's fused launches of the embedding stage are the ones that run
+        names = [c[0] for c in calls]
+        H = model.config.hidden_size
+        fused_ln = H % 256 == 0 and H <= 1024        # (the fixtures are 128 wide: LayerNorm + dropout stay two launches there, as mmf_layernorm_dropout_fusable says)
+        assert names.count("embed_tables_bwd") == 1          # the four small table gradients in one call (only the word table is left to rows_scatter_add)
+        assert ("layernorm_dropout_fwd" in names) == fused_ln and ("layernorm_bwd_din" in names) == fused_ln
+        assert sum(n == "adamw_multi" for n in names) == 1 and len(opt.param_groups) >= 2       # ONE call for all parameter groups (lr / weight decay travel per tensor)
     if name == "vilbert_pairs":                      # image rows broadcast over the text index (mode 0), text rows over the image index (mode 1)
         assert sorted(c[4] for c in calls if c[0] == "expand_batch") == [0, 1] and sorted(c[4] for c in calls if c[0] == "reduce_batch") == [0, 1]
     if name == "vilbert_fast":                       # the single text broadcast over the image batch

@@ -61,7 +61,10 @@ enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
                                              the forward's keep-bit table (A/B: tools/step_ab.py 16:1 16:0) */
        MMF_TUN_SCATTER_ATOMIC = 17,   /* 1: mmf_rows_scatter_add with an index array always takes the fp32-atomic kernel (the round-1 form; A/B and the fallback beyond
                                           16384 rows) instead of the deterministic owner-wave kernel */
-       MMF_TUN_COUNT = 18 };
+       MMF_TUN_GEMM_PERSIST = 18,  /* NT-form GEMMs on the persistent kernel (gemm_persist.h: one workgroup per CU walks several tiles, the epilogue of a tile runs
+                                      under the K-loop of the next): 0 where the measured rule says so (several tiles per workgroup, short K-loops), -1 never, 1 / 2 / 3 always, on the
+                                      256x96 / 192x192 / 256x128 tile, 256 + mask: exactly the calls tagged MMF_GEMM_SITE(s) with bit s of mask set (A/B) */
+       MMF_TUN_COUNT = 19 };
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)

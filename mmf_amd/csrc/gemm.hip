@@ -26,6 +26,7 @@
 // for one m; the fp32 tile is then staged through LDS and written row-wise (16 bytes per lane, full cache lines).
 #include "gemm_common.h"
 #include "gemm_wide.h"
+#include "gemm_persist.h"
 
 using namespace gemm;
 
@@ -464,6 +465,92 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     return 0;
 }
 
+// ---- persistent tiles (gemm_persist.h): one workgroup per CU walks its tiles, a tile's epilogue runs under the next tile's K-loop -------------
+template <int BM_, int BN_, int WGM, int WGN, int EPI>
+int launch_persist_e(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    const int tm = (d->M + BM_ - 1) / BM_, tn = d->N / BN_;
+    const int lds_bytes = 3 * (BM_ + BN_) * 128 + d->N * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<BM_, BN_, WGM, WGN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (a0 != hipSuccess) { mmf_amd_set_error(hipGetErrorString(a0)); return 2; }
+        attr_set = true;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        if (cus <= 0) cus = 256;
+    }
+    const int ntile = tm * tn;
+    int grid = (ntile + 7) / 8 * 8;
+    if (grid > cus / 8 * 8) grid = cus / 8 * 8;
+    g_last_kernel = BM_ == 192 ? "gemm_persist_kernel 192x192" : (BN_ == 96 ? "gemm_persist_kernel 256x96" : "gemm_persist_kernel 256x128");
+    // The bf16 output is stored PLAIN (write-back) here unless a tunable asks otherwise: this kernel's stores trickle out under the K-loops instead of
+    // arriving as one burst per round, and leaving them to the L2 / Infinity Cache hands the next kernel its input on chip.  In the step (same process,
+    // profiles/r06_persist_experiments.txt): QKV forward 7.49 (nt) / 7.46 (sc1) / 7.35 (plain) ms per step; the one-burst kernels of gemm_wide.h lose
+    // with plain stores (7.66 against 7.48).  The saved gelu' keeps its non-temporal stores (read a whole backward pass later).
+    EpiArgs e2 = e;
+    if (mmf_amd_get_tunable(MMF_TUN_EPI_NT) == 0 && mmf_amd_get_tunable(MMF_TUN_SC1_SITE) == 0 && mmf_amd_get_tunable(MMF_TUN_EPI_SC1) == 0) { e2.nt &= ~1; e2.sc1 &= ~1; }
+    hipLaunchKernelGGL((gemm_persist_kernel<BM_, BN_, WGM, WGN, EPI>), dim3(grid), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
+                       reinterpret_cast<const bf16*>(d->B), d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e2);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+// epilogue class of the persistent kernel, or -1 when it has none for this call
+static int persist_epi(const EpiArgs& e) {
+    if (!epilogue_fast_ok(e)) return -1;
+    if (e.act == 1) return PEPI_GELU;
+    if (e.act == 2 || e.resid) return PEPI_SIDE;
+    if (e.drop.thr16) return -1;
+    return PEPI_PLAIN;
+}
+template <int BM_, int BN_, int WGM, int WGN>
+int launch_persist(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
+    switch (persist_epi(e)) {
+        case PEPI_PLAIN: return launch_persist_e<BM_, BN_, WGM, WGN, PEPI_PLAIN>(d, e, s);
+        case PEPI_GELU: return launch_persist_e<BM_, BN_, WGM, WGN, PEPI_GELU>(d, e, s);
+        default:
+            if constexpr (BM_ == 192) return 1;          // (192 x 192 with a side input does not fit the register file: never chosen, never built)
+            else return launch_persist_e<BM_, BN_, WGM, WGN, PEPI_SIDE>(d, e, s);
+    }
+}
+// 0: not on the persistent kernel; 1 / 2 / 3: on its 256 x 96 / 192 x 192 / 256 x 128 tile
+static int persist_choice(const mmf_gemm_desc* d, const EpiArgs& e) {
+    int t = mmf_amd_get_tunable(MMF_TUN_GEMM_PERSIST);
+    if (t < 0 || (d->debug_flags & 131072) || persist_epi(e) < 0) return 0;
+    bool by_rule = t == 0;
+    if (t >= 256) {       // 256 + mask: exactly the calls tagged with one of these sites, on the model's tile (per-site A/B inside the step)
+        const int site = (d->debug_flags >> 20) & 15;
+        if (site == 0 || !(((t - 256) >> site) & 1)) return 0;
+        t = 0;
+    }
+    static const int BNs[4] = {0, 96, 192, 128};
+    const long maxld = (long)(d->lda > d->ldc ? d->lda : d->ldc) > (long)d->ldr ? (long)(d->lda > d->ldc ? d->lda : d->ldc) : (long)d->ldr;
+    if ((d->K % 64) != 0 || (d->M % 64) != 0 || d->M < 512 || (long)d->M * maxld * 2 >= (1L << 31) || (long)d->N * d->ldb * 2 >= (1L << 31)) return 0;
+    const int pe = persist_epi(e);
+    auto fits = [&](int c) { return !(c == 2 && pe == PEPI_SIDE) && (d->N % BNs[c]) == 0 && d->K / 64 >= 12 && 3 * ((c == 2 ? 192 : 256) + BNs[c]) * 128 + d->N * 4 <= 163840; };
+    if (t >= 1 && t <= 3) return fits(t) ? t : 0;
+    // rounds of the 32 workgroups of an XCD x K-steps x the measured step time of the tile's K-loop (profiles/r02_wide_gemm_ablation.txt)
+    static const double step_us[4] = {0, 0.68, 0.81, 0.79};
+    static const int BMs[4] = {0, 256, 192, 256};
+    int pick = 0;
+    double best = 1e30;
+    long pick_rounds = 0;
+    for (int c = 1; c <= 3; ++c) {
+        if (!fits(c)) continue;
+        const long tiles = (long)((d->M + BMs[c] - 1) / BMs[c]) * (d->N / BNs[c]);
+        const long rounds = ((tiles + 7) / 8 + 31) / 32;
+        const double us = rounds * (d->K / 64) * step_us[c];
+        if (us < best) { best = us; pick = c; pick_rounds = rounds; }
+    }
+    // Where it pays (profiles/r06_persist_experiments.txt): only where a workgroup walks SEVERAL tiles with SHORT K-loops - there the ring that never
+    // drains and the epilogue under the next K-loop replace a prologue and an epilogue per tile.  One tile per workgroup has nothing to overlap with
+    // (its deferred units then cost more than the LDS-staged row-wise epilogue of gemm_wide.h: 47 vs 39 us at N = 768, K = 3072).
+    if (by_rule && (pick_rounds < 2 || d->K / 64 > 24)) return 0;
+    return pick;
+}
+
 // Modelled launch time (us) of a tile shape: rounds x (K-steps x max(staging, MFMA) + fixed), with the measured per-CU staging rate
 // (85 GB/s, profiles/r02_lds_dma_ceiling.txt) and 90 % of the per-CU MFMA peak; `slots` = workgroups resident per CU.
 // Round 3: the K-step is max(staging, MFMA) + half the smaller one — what the ablations of the shipped kernels show
@@ -508,6 +595,12 @@ template <typename AT, typename BT, bool AK, bool BK_, bool RG>
 int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     if constexpr (!AK && !BK_ && is_bf16<AT>::value && is_bf16<BT>::value) {
         if (e.splits <= 1) {
+            switch (persist_choice(d, e)) {
+                case 1: return launch_persist<256, 96, 4, 2>(d, e, s);
+                case 2: return launch_persist<192, 192, 2, 4>(d, e, s);
+                case 3: return launch_persist<256, 128, 4, 2>(d, e, s);
+                default: break;
+            }
             // K-split wave layout (gemm_wide.h, KS = 2).  In isolation (tools/gemm_ab.py, profiles/r03_gemm_ab_ks.txt) it wins 3 - 5 % on the 256 x 96
             // tile once the K-loop is long (K = 2304 / 3072: 31.4 -> 30.2, 40.3 -> 38.1, 40.7 -> 39.4 us) and loses the extra LDS pass of its epilogue
             // at K = 768 and on the square tiles.  INSIDE the step it loses: round 4's same-process A/B of the whole graphed step (tools/step_ab.py,

@@ -335,7 +335,7 @@ DEVI void epilogue8(const EpiArgs& e, int m, int n, f32x8 v, int split) {
 // Lean epilogue of the wide-tile kernels' common cases (gemm_wide.h): bias, act 0 / 2, hash dropout, residual, bf16 output, full
 // 8-column segments, no row remap.  The ONE row-wise bf16 side input (the residual, else the act-2 multiplier) arrives in `side`:
 // the kernel fetched it while its last K-steps were still running (one workgroup per CU has nothing else to hide that latency).
-DEVI bool epilogue_fast_ok(const EpiArgs& e) {
+__host__ __device__ __forceinline__ bool epilogue_fast_ok(const EpiArgs& e) {
     const bool gelu = e.act == 1 && e.U != nullptr && !e.resid && !e.drop.thr16;       // HF BertIntermediate: bias, GELU, saved derivative
     return !e.coladd && !e.rowtab && e.grp_in == 0 && !e.out_f32 && (e.act == 0 || e.act == 2 || gelu) && (e.ldc & 7) == 0 && (e.N & 7) == 0 &&
            (!e.resid || (e.ldr & 7) == 0) && e.splits <= 1 && !(e.resid && e.act == 2);

@@ -79,14 +79,29 @@ def main():
         if filt and not any(f in name for f in filt):
             continue
         A, B, C, kw, tkw, ref, K, N = make(name, N, K, kind)
-        errs, kern = {}, {}
+        errs, kern, dd = {}, {}, {}
+        first_drop = None
         for v in vals:
             L.mmf_amd_set_tunable(tun, v)
-            C.zero_()
+            C.fill_(float("nan"))
+            if "U" in kw:
+                kw["U"].fill_(float("nan"))
             nat.gemm(A, B, C, M, N, K, K, K, N, **kw)
             torch.cuda.synchronize()
             kern[v] = nat.gemm_last_kernel()
             errs[v] = float((C.float() - ref).abs().max() / ref.abs().max())
+            if "U" in kw:      # the saved gelu' against autograd's
+                x = (A.float() @ B.float().t() + kw["bias"]).requires_grad_(True)
+                g, = torch.autograd.grad(torch.nn.functional.gelu(x).sum(), x)
+                errs[v] = max(errs[v], float((kw["U"].float() - g).abs().max()))
+            # with the timed epilogue (dropout on): every variant must draw the same mask -> outputs equal up to the summation order
+            C.fill_(float("nan"))
+            nat.gemm(A, B, C, M, N, K, K, K, N, **tkw)
+            torch.cuda.synchronize()
+            if first_drop is None:
+                first_drop = C.clone(); dd[v] = 0.0
+            else:
+                dd[v] = float((C.float() - first_drop.float()).abs().max())
         times = {v: [] for v in vals}
         for r in range(rounds):
             for v in vals:
@@ -104,7 +119,7 @@ def main():
         row = "%-11s N=%4d K=%4d " % (name, N, K)
         for v in vals:
             med = statistics.median(times[v]); tot[v] += med
-            row += "| v=%d %-22s med %6.1f us min %6.1f (%4.0f TF) relerr %.1e " % (v, kern[v][-18:], med, min(times[v]), fl / med / 1e6, errs[v])
+            row += "| v=%d %-22s med %6.1f us min %6.1f (%4.0f TF) relerr %.1e dvs0 %.1e " % (v, kern[v][-18:], med, min(times[v]), fl / med / 1e6, errs[v], dd[v])
         print(row, flush=True)
     print("sum of medians: " + "  ".join("v=%d %.1f us (%.0f TF)" % (v, tot[v], flops / tot[v] / 1e6) for v in vals))
     L.mmf_amd_set_tunable(tun, 0)

@@ -520,6 +520,7 @@ static int persist_choice(const mmf_gemm_desc* d, const EpiArgs& e) {
     int t = mmf_amd_get_tunable(MMF_TUN_GEMM_PERSIST);
     if (t < 0 || (d->debug_flags & 131072) || persist_epi(e) < 0) return 0;
     bool by_rule = t == 0;
+    if (by_rule && mmf_amd_get_tunable(MMF_TUN_GEMM_WIDE) != 0) return 0;       // (a forced one-tile kernel is an A/B of THAT kernel)
     if (t >= 256) {       // 256 + mask: exactly the calls tagged with one of these sites, on the model's tile (per-site A/B inside the step)
         const int site = (d->debug_flags >> 20) & 15;
         if (site == 0 || !(((t - 256) >> site) & 1)) return 0;

@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact block of BASELINE.json's other configs (~20 s)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-path side leg (eval forward + fp32 training step, ~0.3 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one hipGraph")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--config", default=None, choices=["mmbt", "vilbert", "uniter", "mmft", "m4c"],
                     help="one of BASELINE.json's OTHER configs (parity-test cases, not the headline): the same JSON shape for that model's "
@@ -567,6 +567,24 @@ def main():
         h2d = {"value": round(args.batch * args.steps / dt3, 2), "unit": "samples/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
                "note": "26.6 MB of fp32 features + ids per step over PCIe, prefetched on a copy stream; not the headline"}
         del feed
+    padded = None
+    if use_graph:
+        # SURVEY.md section 8(d)'s secondary run: realistic padding, text lengths ~ U{8..24} of the 128 positions (ids beyond the length are [PAD] = 0,
+        # input_mask 0 there).  The reference masks padded keys and never compacts (mmf/models/visual_bert.py:94-106), and so does this path: the
+        # run reports what padding costs / saves, it is never the headline.
+        gp = torch.Generator().manual_seed(4321 + rank)
+        pb = synthetic_batch(args.batch, rank, None)
+        lens = torch.randint(8, 25, (args.batch,), generator=gp)
+        keep = (torch.arange(128)[None, :] < lens[:, None]).long()
+        pb["input_mask"] = keep
+        pb["input_ids"] = pb["input_ids"] * keep
+        pb = pb.to(device)
+        dtp, _ = timed(lambda: graphed(pb))
+        padded = {"text_len": "U{8..24} of 128", "mean_text_len": round(float(lens.float().mean()), 1), "ms_per_step": round(dtp / args.steps * 1e3, 3),
+                  "value": round(args.batch * args.steps / dtp, 2), "unit": "samples/s",
+                  "note": "same graph, padded batch: 228 positions per sample are computed whatever the mask (as in the reference); the word-embedding "
+                          "gradient skips [PAD] rows"}
+        del pb
     fwd_bwd_only = None
     if use_graph and opt is not None:
         del graphed
@@ -687,6 +705,8 @@ def main():
             line["fwd_bwd_only"] = fwd_bwd_only
         if h2d is not None:
             line["h2d_inclusive"] = h2d
+        if padded is not None:
+            line["padded"] = padded
         if eager_info:
             line["eager"] = eager_info
         if scale_info is not None:

@@ -48,16 +48,34 @@ def short(name):
         return "gemm_bf16_kernel<%s>" % m.group(1)
     return re.sub(r"\(.*", "", name)[:80]
 
+OTHER_FAMILIES = [("attn_fwd8_kernel", "attention fwd | attn_fwd8_kernel"), ("attn_fwd_kernel", "attention fwd | attn_fwd_kernel"),
+                  ("attn_bwd_fused_kernel", "attention bwd | attn_bwd_fused_kernel"), ("attn_bwd_dq_kernel", "attention bwd | attn_bwd_dq_kernel"),
+                  ("attn_bwd_dkv_kernel", "attention bwd | attn_bwd_dkv_kernel"), ("ln_bwd_h_kernel", "layernorm bwd | ln_bwd_h_kernel"),
+                  ("ln_fwd_h_kernel", "layernorm fwd | ln_fwd_h_kernel"), ("adamw_multi_kernel", "adamw | adamw_multi_kernel"),
+                  ("transpose_multi_kernel", "weight twins | transpose_multi_kernel"), ("scatter_add_unique_kernel", "word-embedding gradient | scatter_add_unique_kernel"),
+                  ("ln_bwd_reduce_multi_kernel", "layernorm bwd | ln_bwd_reduce_multi_kernel"), ("splitk_epilogue_kernel", "gemm skinny | splitk_epilogue_kernel"),
+                  ("splitk_reduce_kernel", "gemm split-K | splitk_reduce_kernel")]
+
+
 def variant(name):
     """The label bench.py's KernelProbe gives the launches of this kernel ("gemm <form> | <kernel family and tile>[ ksplit]
     [ (ragged / small)]"), so that profiles/pmc_traffic.json can be looked up with the bench line's dominant-kernel label."""
+    if "gemm_wide_grouped_kernel" in name:
+        return "gemm TN grouped wgrad | gemm_wide_grouped_kernel 256x128"
     if "gemm_bf16_grouped_kernel" in name:
         return "gemm TN grouped wgrad | gemm_bf16_grouped_kernel 128x128"
+    m = re.search(r"gemm_persist_kernel<(\d+), (\d+)", name) or re.search(r"gemm_persist_kernelILi(\d+)ELi(\d+)E", name)
+    if m:
+        return "gemm NT | gemm_persist_kernel %sx%s" % (m.group(1), m.group(2))
     m = re.search(r"gemm_wide_kernel<(\d+), (\d+)", name) or re.search(r"gemm_wide_kernelILi(\d+)ELi(\d+)E", name)
     if m:
         return "gemm NT | gemm_wide_kernel %sx%s" % (m.group(1), m.group(2))
     m = re.search(r"gemm_bf16_kernelI(?:DF16b|f)(?:DF16b|f)Lb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d+)ELi(\d)E", name)
     if not m:
+        # every other kernel family that takes a visible share of the step, under the name bench.py's roofline block uses for it
+        for key, label in OTHER_FAMILIES:
+            if key in name:
+                return label
         return None
     ak, bk, rg, nwn, bn, ks = m.groups()
     return "gemm %s%s | gemm_bf16_kernel 128x%s%s%s" % ("T" if ak == "1" else "N", "N" if bk == "1" else "T", bn,
@@ -122,7 +140,7 @@ def main(tag):
                       "wait_any_frac": round(a.get("SQ_WAIT_ANY", 0) / wc, 3), "wait_inst_frac": round(a.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
                       "active_frac": round(a.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
                       "lds_bank_conflict_per_lds_cycle": round(a.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, a.get("SQ_LDS_IDX_ACTIVE", 1)), 4)}
-        json.dump(out, open("profiles/%s_pmc_sq_gemm.json" % tag, "w"), indent=1)
+        json.dump(out, open("profiles/%s_pmc_sq.json" % tag, "w"), indent=1)
     print(open("profiles/%s_kernel_stats.txt" % tag).read()[:3000])
     print(json.dumps(traffic, indent=1))
 

@@ -245,6 +245,7 @@ struct WaveProbe {
 // rowbase + key.  With `keep` != NULL the decisions also go to the keep-bit table the one-pass backward reads (mmf_attn_desc.keep_bits): the compare
 // of register (c, i) IS a 64-bit lane mask — low half = key 8c + i against the wave's 32 queries, high half = key 8c + 4 + i — i.e. two finished table
 // words; lane j < 32 collects the word of key j (v_writelane) and the half-wave stores 128 contiguous bytes per tile.
+extern "C" __device__ int mmf_writelane(int value_sgpr, int lane, int old) __asm("llvm.amdgcn.writelane.i32");       // v_writelane_b32: lane `lane` of the result = value, the others keep `old`
 DEVI void drop_tile(f32x16& acc, uint32_t dkey, uint32_t tilebase, int h, int lane, const DropoutCfg& drop, uint32_t* keep) {
     if (!keep) {
 #pragma unroll
@@ -268,15 +269,15 @@ DEVI void drop_tile(f32x16& acc, uint32_t dkey, uint32_t tilebase, int h, int la
             m[i] = __builtin_amdgcn_ballot_w64(on);
             acc[4 * c + i] *= on ? drop.scale : 0.f;
         }
-        // (s_nop: a lane mask written by a VALU compare is not yet visible to v_writelane as DATA in the next slots — measured: without it
-        // nine of the 32 words of a tile come out stale; the compiler's hazard recognizer does not look into inline assembly)
-        asm volatile("s_nop 4\n\t"
-                     "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
-                     "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\tv_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
-                     : "+v"(kw)
-                     : "s"((uint32_t)m[0]), "s"((uint32_t)m[1]), "s"((uint32_t)m[2]), "s"((uint32_t)m[3]), "s"((uint32_t)(m[0] >> 32)),
-                       "s"((uint32_t)(m[1] >> 32)), "s"((uint32_t)(m[2] >> 32)), "s"((uint32_t)(m[3] >> 32)), "n"(8 * c), "n"(8 * c + 1),
-                       "n"(8 * c + 2), "n"(8 * c + 3), "n"(8 * c + 4), "n"(8 * c + 5), "n"(8 * c + 6), "n"(8 * c + 7));
+        // v_writelane through the LLVM intrinsic (this clang has no __builtin_amdgcn_writelane; see mmf_writelane), so that the backend's hazard
+        // recognizer spaces the VALU compare that wrote the lane mask and the v_writelane that reads it as DATA.  Round 5 used inline assembly
+        // with a hand-measured s_nop (nine of 32 words came out stale without it): invisible to the recognizer, i.e. one compiler upgrade away
+        // from corrupt backward-only masks.  tests/test_kernels_gpu.py (keep-bit tests) compare every kernel form against the hashing path.
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kw = mmf_writelane((int)(uint32_t)m[i], 8 * c + i, kw);
+            kw = mmf_writelane((int)(uint32_t)(m[i] >> 32), 8 * c + 4 + i, kw);
+        }
     }
     if (lane < 32) keep[lane] = (uint32_t)kw;
 }

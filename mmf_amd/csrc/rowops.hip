@@ -602,54 +602,76 @@ __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __r
     }
 }
 
-// The same without atomics, deterministic (round 5): one wave per source row r = (b, i).  The wave scans the index array — 64 entries per step, ballot — and
-// leaves unless r is the FIRST row with its bucket ("owner"); the owner goes on through the rows behind it, adds every row of the same bucket in increasing row
-// order and writes out[bucket] once.  No two waves write the same output row, the order of the additions is fixed: the word-embedding gradient (the one
-// atomically accumulated tensor of the VisualBERT step) is bit-reproducible, and 4096 rows x 768 columns take ~12 us instead of 46 us of fp32 atomics.
-// O(rows^2 / 64) index comparisons in total (262144 wave steps at 4096 rows): used up to SCATTER_UNIQUE_MAX rows, the atomic form beyond.
+// The same without atomics, deterministic (round 5): one workgroup per source row r = (b, i).  It stages the index array in LDS, counts the rows that share
+// its bucket (ballot + popcount, a quarter of the array per wave) and leaves unless r is the FIRST row of the bucket ("owner"); the owner goes on through
+// the rows behind it, adds every row of the same bucket in increasing row order and writes out[bucket] once.  No two workgroups write the same output
+// row, the order of the additions is fixed: the word-embedding gradient (the one atomically accumulated tensor of the VisualBERT step) is bit-reproducible,
+// and 4096 rows x 768 columns take ~12 us instead of 46 us of fp32 atomics.  O(rows^2 / 64) index comparisons in total (262144 wave steps at 4096 rows):
+// used up to SCATTER_UNIQUE_MAX rows, the atomic form beyond.
+// Round 6 - bounded runs: an owner walks its run serially (four rows per dependent step), so ONE id on a quarter of the rows made the launch 270 us
+// against 162 us of atomics (M4C's previous-prediction gather: ~1000 of 1536 rows carry index 0; MLM batches with a frequent token).  Every workgroup
+// now knows its bucket's multiplicity: a bucket with more than SCATTER_RUN_MAX rows is added with fp32 atomics by ALL of its rows in parallel (the order
+// inside such a bucket is then the hardware's; every other bucket stays bit-reproducible).
 constexpr int SCATTER_UNIQUE_MAX = 16384;
+constexpr int SCATTER_RUN_MAX = 64;
 __global__ __launch_bounds__(256) void scatter_add_unique_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                   const int64_t* __restrict__ idx, int idx_ld, float* __restrict__ out, int H, int skip,
                                                                   int nbuckets) {
-    extern __shared__ int sb[];      // the bucket of every source row (rows are numbered b * rpb + i): staged once per workgroup — scanned from global
-                                     // memory the 64 dependent steps of a wave cost a cache round trip each (48 us per launch, no better than the atomics)
+    extern __shared__ int sb[];      // the bucket of every source row (rows are numbered b * rpb + i), staged once per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nb * rpb;
-    const int r = blockIdx.x;                 // one WORKGROUP per source row: its four waves share the scan and take a quarter of the columns each, so the
-                                              // longest run of equal ids (frequent tokens) moves through four waves' worth of loads instead of one
+    const int r = blockIdx.x;                 // one WORKGROUP per source row: its four waves share the scan and take a quarter of the columns each
     const int bk = [&]() { const int qb = r / rpb; const int64_t v = idx[(size_t)qb * idx_ld + (r - qb * rpb)]; return (v < 0 || v > 0x7ffffffe) ? -2 : (int)v; }();
     if (bk == skip) return;
     if (bk < 0 || (nbuckets > 0 && bk >= nbuckets)) { if (threadIdx.x == 0) flag_index_error(); return; }
-    // an earlier row with this bucket owns it (every wave checks the rows [0, r) a quarter each; the verdict is shared through LDS)
-    __shared__ int owned;
-    if (threadIdx.x == 0) owned = 0;
-    __syncthreads();
-    for (int q0 = wave * 64; q0 < r; q0 += 256) {
-        const int q = q0 + lane;
-        bool hit = false;
-        if (q < r) { const int qb = q / rpb; hit = idx[(size_t)qb * idx_ld + (q - qb * rpb)] == (int64_t)bk; }
-        if (__builtin_amdgcn_ballot_w64(hit)) { if (lane == 0) owned = 1; break; }
-    }
-    __syncthreads();
-    if (owned) return;
-    // owner: stage the buckets of the rows behind this one, then every wave adds its quarter of the columns of this row and of every later row of the
-    // bucket, in row order
-    const int rest = total - (r + 1);
-    for (int q = threadIdx.x; q < rest; q += 256) {
-        const int qq = r + 1 + q, qb = qq / rpb;
-        const int64_t v = idx[(size_t)qb * idx_ld + (qq - qb * rpb)];
+    __shared__ int cnt[2];                    // rows of this bucket before r / behind r
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    for (int q = threadIdx.x; q < total; q += 256) {
+        const int qb = q / rpb;
+        const int64_t v = idx[(size_t)qb * idx_ld + (q - qb * rpb)];
         sb[q] = (v < 0 || v > 0x7ffffffe) ? -2 : (int)v;
     }
     __syncthreads();
+    {
+        int before = 0, behind = 0;
+        for (int q0 = wave * 64; q0 < total; q0 += 256) {
+            const int q = q0 + lane;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(q < total && sb[q] == bk);
+            const int rel = r - q0;           // rows q0 .. q0 + 63 against r
+            const unsigned long long lo = rel <= 0 ? 0ull : (rel >= 64 ? ~0ull : ((1ull << rel) - 1ull));          // rows before r
+            const unsigned long long hi = rel < 0 ? ~0ull : (rel >= 63 ? 0ull : ~((2ull << rel) - 1ull));           // rows behind r
+            before += __builtin_popcountll(m & lo);
+            behind += __builtin_popcountll(m & hi);
+        }
+        if (lane == 0) { atomicAdd(&cnt[0], before); atomicAdd(&cnt[1], behind); }
+    }
+    __syncthreads();
+    const int n_before = cnt[0], n_behind = cnt[1];
     const int wq = H >> 2;                    // columns per wave (a multiple of 4)
     const int b = r / rpb, i = r - b * rpb;
+    if (n_before + 1 + n_behind > SCATTER_RUN_MAX) {       // a long run: all of its rows add themselves, in parallel
+        for (int c0 = 0; c0 < wq; c0 += 256) {
+            const int col = wave * wq + c0 + 4 * lane;
+            if (c0 + 4 * lane < wq) {
+                const f32x4 v = load4(x + ((size_t)b * bstride + i) * ld + col);
+                float* o = out + (size_t)bk * H + col;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(o + j, v[j]);
+            }
+        }
+        return;
+    }
+    if (n_before) return;                     // an earlier row owns the bucket
+    // owner: every wave adds its quarter of the columns of this row and of every later row of the bucket, in row order
+    const int rest = total - (r + 1);
+    const int* sbr = sb + r + 1;
     for (int c0 = 0; c0 < wq; c0 += 256) {
         const int col = wave * wq + c0 + 4 * lane;
         const bool on = c0 + 4 * lane < wq;
         f32x4 acc = on ? load4(x + ((size_t)b * bstride + i) * ld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         for (int q0 = 0; q0 < rest; q0 += 64) {
             const int q = q0 + lane;
-            unsigned long long m = __builtin_amdgcn_ballot_w64(q < rest && sb[q] == bk);
+            unsigned long long m = __builtin_amdgcn_ballot_w64(q < rest && sbr[q] == bk);
             constexpr int RF = 4;
             while (m) {      // up to four rows of the run in flight, added in row order (more in flight measured no faster)
                 const bf16* src[RF];
@@ -767,7 +789,8 @@ __global__ __launch_bounds__(256) void embed_tables_bwd_kernel(const bf16* __res
         for (int u = 0; u < UN; ++u) {
             const int b = b0 + u < B ? b0 + u : B - 1;
             v[u] = load4(x + ((size_t)b * S + i) * ld + col);
-            bk[u] = ids ? (int)ids[(size_t)b * ild + ii] : 0;
+            if (ids) { const int64_t t = ids[(size_t)b * ild + ii]; bk[u] = (t < 0 || t >= (int64_t)nb) ? -1 : (int)t; }     // (range check in 64 bits: 1 << 32 is not bucket 0)
+            else bk[u] = 0;
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {

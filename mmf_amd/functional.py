@@ -776,6 +776,7 @@ class _WgradDefer:
         self.active = False
         self.queues = {}      # (wide-tile eligible, stream) -> list of (problem, tensors kept alive)
         self.seen = set()     # weights (their bf16 shadows) that already have a queued gradient in this deferral block
+        self.streams = {}     # stream handle -> torch stream object of the queues above (a mid-backward flush orders itself behind them)
         self.enabled = os.environ.get("MMF_AMD_WGRAD_DEFER", "1") != "0"       # (A/B switch)
 
     @contextlib.contextmanager
@@ -799,7 +800,7 @@ class _WgradDefer:
         immediately."""
         key = w16.data_ptr()
         if key in self.seen:
-            self.flush()
+            self.flush(mid_backward=True)
             self.seen.add(key)      # (a third application is immediate as well)
             return False
         self.seen.add(key)
@@ -810,6 +811,8 @@ class _WgradDefer:
         # side HIP stream; autograd replays a node on its forward stream).  What is left at the end is launched by `flush` on the caller's
         # stream, after the autograd engine has joined every stream the backward pass used.
         key = (self._wide(prob), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)      # (no GPU: the host-logic dry runs)
+        if torch.cuda.is_available():
+            self.streams[key[1]] = torch.cuda.current_stream()
         q = self.queues.setdefault(key, [])
         q.append((prob, keep))
         if len(q) == nat.GEMM_GROUP_MAX:
@@ -820,9 +823,13 @@ class _WgradDefer:
             nat.gemm_grouped([p for p, _ in q])
             del q[:]
 
-    def flush(self):
+    def flush(self, mid_backward=False):
+        """`mid_backward` (first_use: a tied weight met in the middle of backward): the other streams are still running, so the caller's stream first
+        waits for the stream that produced a foreign queue's dy / x - at the end of backward the autograd engine has already joined them."""
         cur = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
         for (_, stream), q in self.queues.items():
+            if q and stream != cur and mid_backward and stream in self.streams:
+                torch.cuda.current_stream().wait_stream(self.streams[stream])
             if q and stream != cur and not torch.cuda.is_current_stream_capturing():
                 # leftovers of another stream's queue (ViLBERT's visual stream) run on the caller's stream: their buffers belong to that
                 # stream's pool of the caching allocator, which must not hand them out again while this launch / the optimizer that reads
@@ -833,6 +840,7 @@ class _WgradDefer:
                             t.record_stream(torch.cuda.current_stream())
             self._launch(q)
         self.queues.clear()
+        self.streams.clear()
         self.seen.clear()
 
 

@@ -174,6 +174,9 @@ class GraphedTrainStep:
         return self.loss
 
 
+_SPARSE_CHECK = int(os.environ.get("MMF_AMD_SPARSE_CHECK", "0") or 0)      # k > 0: every k-th step verifies the touched-row contract (a host read-back)
+
+
 class _SparseRows:
     """Touched-row exchange of ONE embedding-table gradient between data-parallel ranks: the reference's DDP all-reduces the dense
     [30522, 768] fp32 word-embedding gradient (97 MB, the last gradient backward produces: the un-overlappable tail of the step,
@@ -224,6 +227,17 @@ class _SparseRows:
         dist.all_reduce(self.rows_all, group=self.group)
         self.ids_all.sub_(1)
         return []
+
+    def verify(self):                # debugging (MMF_AMD_SPARSE_CHECK=k: every k-th step), eager, right after the backward stage's replay
+        """The contract of the touched-row exchange: the stage's dense gradient is zero outside the rows its packed ids name.  The choice was made
+        once, from the eager warm-up batch (`_pick_sparse`); a contribution to another row - ids passed by keyword past the hook, a second lookup
+        the warm-up batch happened to cover - would be dropped on the OTHER ranks without any error.  This check reads back and raises."""
+        ids = self.ids_wire[self.ids_wire >= 0]
+        touched = torch.zeros(self.dense.shape[0], dtype=torch.bool, device=self.dense.device)
+        touched[ids] = True
+        if bool((self.dense[~touched] != 0).any()):
+            raise RuntimeError("touched-row exchange: the gradient of a [%d, %d] table has non-zero rows outside the ids its embedding stage looked up; "
+                               "run with sparse_rows=False" % tuple(self.dense.shape))
 
     def merge(self):                 # captured in the update stage's graph, ahead of the fused AdamW
         sorted_all, perm = self.ids_all.sort(stable=True)
@@ -494,8 +508,14 @@ class GraphedDataParallelStep:
             _copy_batch(self.static_batch, batch)
         self.g_fwd.replay()
         prev = None          # collectives of the previous stage: waited for (and its update replayed) after the next stage is enqueued
+        self._calls = getattr(self, "_calls", 0) + 1
+        check = _SPARSE_CHECK > 0 and self._calls % _SPARSE_CHECK == 0
         for j, g in enumerate(self.g_bwd):
             g.replay()
+            if check:
+                for sp in self.sparse:
+                    if sp.stage == j:
+                        sp.verify()
             works = []
             if self.world > 1:
                 b = self.buckets[j]

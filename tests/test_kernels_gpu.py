@@ -941,7 +941,7 @@ def test_step_advance_is_seed_advance_plus_optim_state_advance():
 
 
 @pytest.mark.parametrize("B,T,S,H,V,dups", [(32, 128, 228, 768, 30522, 0.0), (8, 64, 64, 768, 50, 0.0), (3, 40, 57, 1024, 1000, 0.9), (2, 30, 30, 1280, 7, 0.0),
-                                            (12, 128, 128, 768, 2000, 0.8), (2, 60, 60, 768, 500, 0.4)])
+                                            (12, 128, 128, 768, 2000, 0.8), (2, 60, 60, 768, 500, 0.3)])
 def test_rows_scatter_add_with_an_index_array_is_deterministic_and_atomic_free(B, T, S, H, V, dups):
     """mmf_rows_scatter_add with an index array (the word-embedding gradient, embeddings.py:329-345 backward): one owner workgroup per distinct id adds that
     id's rows in row order and writes the output row once — against float64 torch, bit-identical from run to run and in row order (a float32 running sum in

@@ -30,41 +30,26 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------ */
 int mmf_amd_abi_version(void);
 /* Integer tuning knobs for on-hardware sweeps (0 = built-in heuristic).  Not part of the reference's interface. */
-enum { MMF_TUN_SPLITK_FORCE = 0,   /* split count for weight-gradient GEMMs */
-       MMF_TUN_LN_BWD_GRID = 1,    /* workgroups of mmf_layernorm_bwd (<= MMF_LN_BWD_MAX_GRID) */
-       MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 */
-       MMF_TUN_LN_OLD = 3,         /* 1: LayerNorm with the one-wave-per-row, 8-byte-per-lane kernels even when H % 256 == 0; 2: half-wave backward with one row in flight;
-                                      3: two rows in flight at H = 1024 too (A/B measurements) */
-       MMF_TUN_ATTN_BWD_TWO_PASS = 4,   /* 1: head_dim-64 attention backward as the separate dQ and dK/dV kernels (A/B measurements) */
-       MMF_TUN_GEMM_WIDE_KS = 5,   /* wide-tile wave layout: 2 the two ping-pong groups split every K-step (fewer LDS fragment reads), 0 / 1 never (the default since
-                                      round 4: faster in isolation at long K, slower inside the step), 3 the round-3 rule (256x96, K >= 1536) */
+enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 (tests, A/B) */
+       MMF_TUN_ALT_FORMS = 3,      /* cross-check hooks (tests compare kernel forms that serve different shapes in production): bit 0 LayerNorm with the one-wave-per-row
+                                      kernels even when H % 256 == 0; bit 1 head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head; bit 2
+                                      attention backward as the separate dQ and dK/dV kernels where the one-pass kernel would run (and no keep-bit table); bit 3
+                                      LayerNorm backward with one row in flight per half-wave */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
-       MMF_TUN_ATTN_FWD_OLD = 7,   /* 1: head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head (the round-2 form; A/B) */
        MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
-                                      kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B, tools/nt_site_ab.sh) */
-       MMF_TUN_GELU_WIDE = 9,      /* tile of the forward GEMMs with the GELU epilogue (act 1): 0 the 128-row kernel (two workgroups per CU hide the erf / exp
-                                      of one behind the other's K-loop: 60.5 vs 70.7 us when last measured, before the non-temporal stores), 1 / 2 / 3 force a wide tile (A/B) */
+                                      kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B) */
        MMF_TUN_WGRAD_WIDE = 10,    /* grouped weight-gradient launch: 0 the 256x128 wide tile when every problem is a whole number of such tiles and the launch fills
-                                      most of a round of the 256 CUs, 1 never (the 128x128 tiles, two workgroups per CU), 2 whenever the shapes allow (A/B) */
-       MMF_TUN_ADAM_GRID = 11,     /* > 0: cap on the workgroups of one mmf_adamw_multi launch (they stride over the 4096-element chunks): the form that runs beside
-                                      a GEMM launch; 0: one workgroup per chunk */
-       MMF_TUN_EPI_SC1 = 12,       /* GEMM epilogue write-through (`sc1`) stores, mask like MMF_TUN_EPI_NT's (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C): the lines
-                                      leave the XCD's L2 as they are written instead of at the end-of-kernel release (A/B) */
-       MMF_TUN_SKINNY_OFF = 13,    /* 1: never the skinny split-K path (mmf_gemm_skinny_splits returns 1; A/B) */
+                                      most of a round of the 256 CUs, 1 never (the 128x128 tiles, two workgroups per CU), 2 whenever the shapes allow (tests, A/B) */
        MMF_TUN_SC1_SITE = 14,      /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored write-through (`sc1`, not `nt`): the line is dropped from
                                       the writing XCD's L2 like a streaming store but allocates in the Infinity Cache, where the next kernel finds it (an `nt` store
                                       bypasses it: tools/cold_operand_probe.py, profiles/r04_store_policy.txt).  0: the measured default (MMF_SITE_SC1_DEFAULT: the FFN
                                       up-projection's GELU output and the FFN-down dgrad's du, the two A operands of the K = 3072 GEMMs); 1: no site at all (A/B) */
-       MMF_TUN_ACT2_TILE = 15,     /* 1: the act-2 (times saved gelu') dgrad of the FFN takes the cost model's tile (256x128) instead of 256x96, the tile that measured
-                                      0.22 - 0.32 ms per step faster INSIDE the step (round 4; A/B) */
-       MMF_TUN_ATTN_KEEP_BITS_OFF = 16,   /* 1: mmf_attention_keep_bits_words returns 0 — the attention backward hashes its dropout decisions again instead of reading
-                                             the forward's keep-bit table (A/B: tools/step_ab.py 16:1 16:0) */
-       MMF_TUN_SCATTER_ATOMIC = 17,   /* 1: mmf_rows_scatter_add with an index array always takes the fp32-atomic kernel (the round-1 form; A/B and the fallback beyond
-                                          16384 rows) instead of the deterministic owner-wave kernel */
+       MMF_TUN_SCATTER_ATOMIC = 17,   /* 1: mmf_rows_scatter_add with an index array always takes the fp32-atomic kernel (the reference the deterministic owner kernel
+                                          is tested against; by itself the library takes atomics beyond 16384 rows and for ids on more than 64 rows) */
        MMF_TUN_GEMM_PERSIST = 18,  /* NT-form GEMMs on the persistent kernel (gemm_persist.h: one workgroup per CU walks several tiles, the epilogue of a tile runs
                                       under the K-loop of the next): 0 where the measured rule says so (several tiles per workgroup, short K-loops), -1 never, 1 / 2 / 3 always, on the
                                       256x96 / 192x192 / 256x128 tile, 256 + mask: exactly the calls tagged MMF_GEMM_SITE(s) with bit s of mask set (A/B) */
-       MMF_TUN_COUNT = 19 };
+       MMF_TUN_COUNT = 19 };       /* (seven knobs; the other slots were measurement switches of rounds 1 - 5 whose losing branches are gone) */
 /* Call-site tag of a GEMM (bits 20..23 of mmf_gemm_desc::debug_flags; 0 = untagged).  It selects nothing by itself: it only names the call for
  * MMF_TUN_NT_SITE_KEEP.  The encoder layer's calls: */
 #define MMF_GEMM_SITE(s) (((s) & 15) << 20)

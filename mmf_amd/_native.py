@@ -97,9 +97,6 @@ class AttnBwdDesc(C.Structure):
 
 
 _lib = None
-# kernel-development switches (see mmf_gemm_desc.debug_flags); all zero in production
-_GEMM_DEBUG = ((int(os.environ.get("MMF_AMD_GEMM_DBG", "0")) << 4) | (int(os.environ.get("MMF_AMD_GEMM_4WAVE", "0")) << 8)
-               | (int(os.environ.get("MMF_AMD_GEMM_NO96", "0")) << 9))
 
 
 def lib():
@@ -122,26 +119,10 @@ def lib():
     if L.mmf_amd_abi_version() != 1:
         raise NativeLibraryError("ABI version mismatch: library %d, binding 1" % L.mmf_amd_abi_version())
     _lib = L
-    if os.environ.get("MMF_AMD_GEMM_WIDE"):      # A/B switch for measurements: -1 never a wide tile, 1..3 force one (see MMF_TUN_GEMM_WIDE)
-        L.mmf_amd_set_tunable(2, int(os.environ["MMF_AMD_GEMM_WIDE"]))
-    if os.environ.get("MMF_AMD_EPI_NT"):         # A/B switch: mask + 1 of the GEMM outputs stored non-temporally (see MMF_TUN_EPI_NT)
-        L.mmf_amd_set_tunable(6, int(os.environ["MMF_AMD_EPI_NT"]))
-    if os.environ.get("MMF_AMD_NT_SITE_KEEP"):   # A/B switch: bit s = the tagged GEMM call site s keeps its bf16 output temporal (see MMF_TUN_NT_SITE_KEEP)
-        L.mmf_amd_set_tunable(8, int(os.environ["MMF_AMD_NT_SITE_KEEP"], 0))
-    if os.environ.get("MMF_AMD_GELU_WIDE"):      # A/B switch: wide tile 1..3 for the GELU up-projection (see MMF_TUN_GELU_WIDE)
-        L.mmf_amd_set_tunable(9, int(os.environ["MMF_AMD_GELU_WIDE"]))
-    if os.environ.get("MMF_AMD_GEMM_WIDE_KS"):
-        L.mmf_amd_set_tunable(5, int(os.environ["MMF_AMD_GEMM_WIDE_KS"]))
-    if os.environ.get("MMF_AMD_ATTN_FWD_OLD"):
-        L.mmf_amd_set_tunable(7, int(os.environ["MMF_AMD_ATTN_FWD_OLD"]))
-    if os.environ.get("MMF_AMD_LN_OLD"):
-        L.mmf_amd_set_tunable(3, int(os.environ["MMF_AMD_LN_OLD"]))
     if os.environ.get("MMF_AMD_TUN"):            # generic A/B switch: "id:value,id:value" (include/mmf_amd.h MMF_TUN_*)
         for kv in os.environ["MMF_AMD_TUN"].split(","):
             k, v = kv.split(":")
             L.mmf_amd_set_tunable(int(k), int(v, 0))
-    if os.environ.get("MMF_AMD_ATTN_BWD_TWO_PASS"):
-        L.mmf_amd_set_tunable(4, int(os.environ["MMF_AMD_ATTN_BWD_TWO_PASS"]))
     return L
 
 
@@ -196,7 +177,7 @@ def _gemm_desc(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=Fal
                rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
                grp=(0, 0, 0), debug_flags=0, rowsum_out=None, d=None):
     d = GemmDesc() if d is None else d
-    d.debug_flags = int(debug_flags) | _GEMM_DEBUG
+    d.debug_flags = int(debug_flags)
     d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
@@ -627,10 +608,8 @@ def tanh_bwd(dy, y, dx):
     _check(lib().mmf_tanh_bwd_bf16(_p(dy), _p(y), _p(dx), C.c_int64(dy.numel()), _stream()), "mmf_tanh_bwd_bf16")
 
 
-TUN_SPLITK_FORCE, TUN_LN_BWD_GRID, TUN_GEMM_WIDE, TUN_LN_OLD, TUN_ATTN_BWD_TWO_PASS = 0, 1, 2, 3, 4
-TUN_WGRAD_WIDE = 10
-TUN_ADAM_GRID = 11
-TUN_SKINNY_OFF = 13
+# include/mmf_amd.h MMF_TUN_*: the measurement knobs that are left (MMF_AMD_TUN="id:value,..." sets them at load time)
+TUN_GEMM_WIDE, TUN_ALT_FORMS, TUN_EPI_NT, TUN_NT_SITE_KEEP, TUN_WGRAD_WIDE, TUN_SC1_SITE, TUN_SCATTER_ATOMIC, TUN_GEMM_PERSIST = 2, 3, 6, 8, 10, 14, 17, 18
 
 
 def set_tunable(which, value):

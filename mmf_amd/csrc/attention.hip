@@ -1073,7 +1073,7 @@ int set_lds(K kern, int bytes) {
 extern "C" int64_t mmf_attention_keep_bits_words(int B, int heads, int Sq, int Sk, int head_dim) {
     const int hd = head_dim ? head_dim : 64;
     if (B <= 0 || heads <= 0 || !keep_bits_shape(hd, Sq, Sk)) return 0;
-    if (mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS) || mmf_amd_get_tunable(MMF_TUN_ATTN_KEEP_BITS_OFF)) return 0;      // (the two-kernel backward hashes)
+    if (mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 4) return 0;      // (the two-kernel backward hashes)
     return (int64_t)B * heads * ((Sq + 31) / 32) * ((Sk + 31) / 32) * 32;
 }
 
@@ -1109,7 +1109,7 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         return 0;
     }
     if (a.m_qs) {      // per-query mask [B, Sq, Sk] (head_dim 64): the same two kernel forms, mask read per (query, key) from global memory
-        if (nkt > 4 && a.Sq > 128 && !mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD)) {
+        if (nkt > 4 && a.Sq > 128 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 2)) {
             const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
             if (int rc = set_lds(attn_fwd8_kernel<8, MASK_QUERY>, lds)) return rc;
             hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_QUERY>), dim3(a.B * a.heads, (a.Sq + 255) / 256), dim3(512), lds, s, a);
@@ -1119,8 +1119,8 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         return 0;
     }
     // head_dim 64 with more than 128 queries: the one-round form (one 8-wave workgroup per (batch, head), two per CU; attn_fwd8_kernel).
-    // MMF_TUN_ATTN_FWD_OLD = 1 keeps the two-workgroups-per-head form (A/B measurements, bit-equality test).
-    if (a.hd == 64 && nkt > 4 && a.Sq > 128 && !mmf_amd_get_tunable(MMF_TUN_ATTN_FWD_OLD)) {
+    // MMF_TUN_ALT_FORMS bit 1 keeps the two-workgroups-per-head form (A/B measurements, bit-equality test).
+    if (a.hd == 64 && nkt > 4 && a.Sq > 128 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 2)) {
         const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
         const dim3 grid8(a.B * a.heads, (a.Sq + 255) / 256);
         if (cz) {
@@ -1156,7 +1156,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;
     const bool cz = a.cfrom < a.Sk;
-    if (a.hd == 64 && nkt <= 8 && nqt <= 8 && (a.m_qs || !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS))) {
+    if (a.hd == 64 && nkt <= 8 && nqt <= 8 && (a.m_qs || !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 4))) {
         const int lds = 3 * 256 * 128 + 16 * 2048 + 2 * 256 * 4;
         if (a.m_qs) {      // per-query mask: the one-pass kernel only
             if (int rc = set_lds(attn_bwd_fused_kernel<64, 8, MASK_QUERY>, lds)) return rc;
@@ -1171,7 +1171,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         MMF_CHECK_LAUNCH();
         return 0;
     }
-    if (a.hd == 128 && nkt <= 4 && nqt <= 4 && !mmf_amd_get_tunable(MMF_TUN_ATTN_BWD_TWO_PASS)) {
+    if (a.hd == 128 && nkt <= 4 && nqt <= 4 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 4)) {
         // head_dim 128 (ViLBERT's visual stream and co-attention), up to 128 queries / keys: the one-pass kernel with four waves per (batch, head)
         const int lds = 3 * 128 * 256 + 8 * 2048 + 2 * 128 * 4;
         if (int rc = set_lds(attn_bwd_fused_kernel<128, 4, MASK_KEY>, lds)) return rc;

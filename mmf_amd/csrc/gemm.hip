@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_grouped_kernel(GroupArgs g, 
     bid -= g.start[gi];
     int tile_m, tile_n;
     wide_super_row(bid, P.tiles_m, P.tiles_n, tile_m, tile_n);
-    wide_tile<BM_, BN_, WGM, WGN, 3, false, 1, 0, AKM, BKM, RS>(reinterpret_cast<const bf16*>(P.A), reinterpret_cast<const bf16*>(P.B), P.M, P.N, P.K, P.lda,
+    wide_tile<BM_, BN_, WGM, WGN, 3, false, 0, AKM, BKM, RS>(reinterpret_cast<const bf16*>(P.A), reinterpret_cast<const bf16*>(P.B), P.M, P.N, P.K, P.lda,
                                                                P.ldb, tile_m, tile_n, P.epi, pr, smem);
 }
 
@@ -431,14 +431,14 @@ int launch_wide_grouped(const GroupArgs& g, hipStream_t s) {
 }
 
 // ---- wide tiles (gemm_wide.h): one workgroup per CU ---------------------------------------------------------------------
-template <int BM_, int BN_, int WGM, int WGN, int NS, int KS = 1>
+template <int BM_, int BN_, int WGM, int WGN, int NS>
 int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int tm = (d->M + BM_ - 1) / BM_, tn = d->N / BN_;
     constexpr int lds_bytes = NS * (BM_ + BN_) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (a0 != hipSuccess || a1 != hipSuccess) { mmf_amd_set_error(hipGetErrorString(a0 != hipSuccess ? a0 : a1)); return 2; }
         attr_set = true;
     }
@@ -449,8 +449,8 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     const int abl = (d->debug_flags >> 4) & 7;
 #define MMF_WIDE_ABL_CASE(V)                                                                                                          \
     if (abl == V) {                                                                                                                   \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS, V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS, V>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe()); \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, V>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe()); \
         MMF_CHECK_LAUNCH();                                                                                                           \
         return 0;                                                                                                                     \
     }
@@ -458,9 +458,9 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
 #undef MMF_WIDE_ABL_CASE
 #endif
     if (d->M % BM_)
-        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true, KS>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, true>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
     else
-        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false, KS>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
+        hipLaunchKernelGGL((gemm_wide_kernel<BM_, BN_, WGM, WGN, NS, false>), dim3(tm * tn), dim3(512), lds_bytes, s, A, B, d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e, next_probe());
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -491,7 +491,7 @@ int launch_persist_e(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     // profiles/r06_persist_experiments.txt): QKV forward 7.49 (nt) / 7.46 (sc1) / 7.35 (plain) ms per step; the one-burst kernels of gemm_wide.h lose
     // with plain stores (7.66 against 7.48).  The saved gelu' keeps its non-temporal stores (read a whole backward pass later).
     EpiArgs e2 = e;
-    if (mmf_amd_get_tunable(MMF_TUN_EPI_NT) == 0 && mmf_amd_get_tunable(MMF_TUN_SC1_SITE) == 0 && mmf_amd_get_tunable(MMF_TUN_EPI_SC1) == 0) { e2.nt &= ~1; e2.sc1 &= ~1; }
+    if (mmf_amd_get_tunable(MMF_TUN_EPI_NT) == 0 && mmf_amd_get_tunable(MMF_TUN_SC1_SITE) == 0) { e2.nt &= ~1; e2.sc1 &= ~1; }
     hipLaunchKernelGGL((gemm_persist_kernel<BM_, BN_, WGM, WGN, EPI>), dim3(grid), dim3(512), lds_bytes, s, reinterpret_cast<const bf16*>(d->A),
                        reinterpret_cast<const bf16*>(d->B), d->M, d->N, d->K, d->lda, d->ldb, tm, tn, e2);
     MMF_CHECK_LAUNCH();
@@ -573,14 +573,11 @@ static int wide_choice(const mmf_gemm_desc* d) {
     if (force >= 1 && force <= 3) return (d->N % BNs[force]) == 0 ? force : 0;
     // Measured INSIDE the step (round 4, tools/step_ab.py, profiles/r04_in_step_choices.txt): the FFN-down dgrad (N = 3072, K = 768, times the saved gelu')
     // on the 256 x 96 tile, 928 tiles in 3.6 rounds, instead of the 256 x 128 tile the isolated measurements and the cost model pick (44.5 us isolated,
-    // 54 - 60 us in the step): 7.63 against 7.89, 7.53 against 7.85 and 7.64 against 7.86 ms per step on three boxes.  MMF_TUN_ACT2_TILE = 1: the model's choice (A/B).
-    if (d->act == 2 && (d->N % 96) == 0 && d->N >= 2304 && d->K <= 1024 && mmf_amd_get_tunable(MMF_TUN_ACT2_TILE) != 1) return 1;
+    // 54 - 60 us in the step): 7.63 against 7.89, 7.53 against 7.85 and 7.64 against 7.86 ms per step on three boxes. 
+    if (d->act == 2 && (d->N % 96) == 0 && d->N >= 2304 && d->K <= 1024) return 1;
     // One workgroup per CU cannot hide a heavy epilogue behind a co-resident workgroup's K loop: the GELU up-projection (two
     // bf16 outputs, erf + exp per element) measured 70.7 us with wide tiles against 60.5 us inside the training step.
-    if (d->act == 1) {      // MMF_TUN_GELU_WIDE re-opens the question on a later tree (A/B): 1 / 2 / 3 = that wide tile for the GELU GEMMs
-        const int g = mmf_amd_get_tunable(MMF_TUN_GELU_WIDE);
-        return (g >= 1 && g <= 3 && (d->N % BNs[g]) == 0) ? g : 0;
-    }
+    if (d->act == 1) return 0;
     double best = tile_cost(d->M, d->N, d->K, 128, 128, 2);
     if ((d->N % 96) == 0) { const double c = tile_cost(d->M, d->N, d->K, 128, 96, 2); if (c < best) best = c; }
     int pick = 0;
@@ -602,17 +599,9 @@ int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
                 case 3: return launch_persist<256, 128, 4, 2>(d, e, s);
                 default: break;
             }
-            // K-split wave layout (gemm_wide.h, KS = 2).  In isolation (tools/gemm_ab.py, profiles/r03_gemm_ab_ks.txt) it wins 3 - 5 % on the 256 x 96
-            // tile once the K-loop is long (K = 2304 / 3072: 31.4 -> 30.2, 40.3 -> 38.1, 40.7 -> 39.4 us) and loses the extra LDS pass of its epilogue
-            // at K = 768 and on the square tiles.  INSIDE the step it loses: round 4's same-process A/B of the whole graphed step (tools/step_ab.py,
-            // profiles/r04_in_step_choices.txt) measures 7.95 against 8.28 ms and 7.68 against 7.79 ms (two boxes) without it, so the default is now
-            // "never".  MMF_TUN_GEMM_WIDE_KS: 0 / 1 never, 2 always, 3 the round-3 rule (256 x 96 with K >= 1536) (A/B measurements).
-            const int ks_t = mmf_amd_get_tunable(MMF_TUN_GEMM_WIDE_KS);
             const int wc = wide_choice(d);
-            // (Only the 256 x 96 tile is instantiated with KS = 2: the square tiles lost with it and would spill registers.)
-            const bool ks2 = wc == 1 && (ks_t == 2 || (ks_t == 3 && d->K >= 1536));
             switch (wc) {
-                case 1: return ks2 ? launch_wide<256, 96, 4, 1, 3, 2>(d, e, s) : launch_wide<256, 96, 4, 2, 3>(d, e, s);
+                case 1: return launch_wide<256, 96, 4, 2, 3>(d, e, s);
                 case 2: return launch_wide<192, 192, 2, 4, 3>(d, e, s);
                 case 3: return launch_wide<256, 128, 4, 2, 3>(d, e, s);
                 default: break;
@@ -667,7 +656,7 @@ static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     // MMF_TUN_EPI_NT: 0 = the default mask below, else (value - 1) is the mask (1 = no non-temporal stores at all)
     const int ntt = mmf_amd_get_tunable(MMF_TUN_EPI_NT);
     e.nt = ntt > 0 ? ntt - 1 : MMF_EPI_NT_DEFAULT;
-    e.sc1 = mmf_amd_get_tunable(MMF_TUN_EPI_SC1) & 7;
+    e.sc1 = 0;
     // call-site exception (MMF_TUN_NT_SITE_KEEP, default 0 = none): the tagged call's bf16 output is read by the very next kernel
     const int site = (d->debug_flags >> 20) & 15;
     if (site != 0 && ((mmf_amd_get_tunable(MMF_TUN_NT_SITE_KEEP) >> site) & 1)) e.nt &= ~1;
@@ -758,7 +747,6 @@ extern "C" int mmf_gemm_splitk_splits(int M, int N, int K) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int nk_all = (K + BK - 1) / BK;
     if (tiles >= 512 || nk_all < 16 || (N % 4) != 0) return 1;
-    if (const int f = mmf_amd_get_tunable(MMF_TUN_SPLITK_FORCE)) return f < 1 ? 1 : (f > nk_all / 2 ? nk_all / 2 : f);
     // Two workgroups are resident per CU (512 slots).  Cost in k-tile units: rounds x k-tiles per workgroup, plus ~1.5
     // k-tiles per split for writing and re-reading one more fp32 slab (fitted to tools/micro_sweep.py on MI355X:
     // qkv 2304x768 -> 4, out 768x768 -> 8, ffn 3072x768 -> 3).
@@ -773,7 +761,7 @@ extern "C" int mmf_gemm_splitk_splits(int M, int N, int K) {
 // K-slices of the skinny path (splitk_epilogue_kernel): 0 / 1 = not a skinny problem.  Row operand A with at most 64 rows, at least 24
 // K-steps; slices of >= 2 K-steps, about 128 workgroups in all.  Workspace: splits * M * round_up(N, 8) floats (mmf_gemm_desc::splitk_ws).
 extern "C" int mmf_gemm_skinny_splits(int M, int N, int K, int a_kmajor) {
-    if (a_kmajor || M > 64 || mmf_amd_get_tunable(MMF_TUN_SKINNY_OFF)) return 1;
+    if (a_kmajor || M > 64) return 1;
     const int tiles = (N + BN - 1) / BN, nk = (K + BK - 1) / BK;
     // (a short reduction gains nothing that the second launch does not cost again: 15 -> 10 us on the device for K = 768, one more kernel to
     // enqueue in a host-bound decoding loop; the path is for the LONG reductions — 49 K-steps through 6 workgroups for the classifier's

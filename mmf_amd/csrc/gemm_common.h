@@ -33,7 +33,7 @@ struct EpiArgs {
     int rowsum_col;     // >= 0: also write per-row sums of A (bias-gradient partials) behind the split-K slabs; -1: off
     float* rowsum_direct;  // no split-K: the row sums go straight here ([M] fp32) instead of behind the slabs
     int nt;             // non-temporal stores: bit 0 the bf16 output C, bit 1 the saved gelu' (U), bit 2 fp32 outputs (MMF_TUN_EPI_NT)
-    int sc1;            // write-through stores, same bits (MMF_TUN_EPI_SC1)
+    int sc1;            // write-through stores, same bits (the per-site rule: MMF_TUN_SC1_SITE)
 };
 
 // Timeline probe (development aid; off unless mmf_gemm_set_probe was called).  One record of 8 u64 per workgroup:
@@ -209,7 +209,7 @@ DEVI f32x8 load_bf8(const bf16* p) {
 // input further away (attention forward 28 -> 39 us behind a non-temporally stored Q|K|V), so which outputs get it is a per-output
 // choice (EpiArgs::nt, MMF_TUN_EPI_NT).
 // A 16-byte store in one of the cache policies: 0 plain, 1 non-temporal (`nt`), 2 write-through (`sc1`: the line leaves the XCD's L2 as it is
-// written, so the end-of-kernel release has nothing of it left to write back; MMF_TUN_EPI_SC1), 3 both.
+// written, so the end-of-kernel release has nothing of it left to write back), 3 both.
 DEVI void store16_policy(void* p, u32x4 v, int policy) {
     if (policy == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
     else if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");

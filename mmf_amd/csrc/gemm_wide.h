@@ -31,33 +31,28 @@ namespace gemm {
 template <int N> DEVI void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BM x BN tile, WGM x WGN wave grid, NS ring stages.
-//   KS = 1: WGM * WGN == 8, every wave multiplies both 32-deep halves of a 64-deep K-step over its (BM / WGM) x (BN / WGN) tile.
-//   KS = 2: WGM * WGN == 4, the wave grid covers the tile ONCE per ping-pong group and group g multiplies only half g of every
-//           K-step: same MFMA count per wave and K-step, wave tiles twice as large, so the fragments a wave pulls from LDS per
-//           K-step drop from 2 (NFM + NFN) to NFM' + NFN' ds_read_b128 (256 x 96: 14 -> 10, 192 x 192: 18 -> 12).  The K-loop of
-//           the KS = 1 form is bound by the LDS port, not by the matrix pipe (profiles/r02_wide_gemm_ablation.txt: MFMA alone
-//           0.41 us per step, MFMA + fragment reads 0.58, everything 0.68: a LOAD interval — 4 waves x 14 reads + the DMA writes
-//           landing in the same LDS — is longer than the COMP interval it is meant to hide behind).  The two K-halves are summed
-//           in the epilogue's LDS stage (group 1 adds in place before the row-wise pass).
+//   WGM * WGN == 8: every wave multiplies both 32-deep halves of a 64-deep K-step over its (BM / WGM) x (BN / WGN) tile.  (Rounds 3 - 5 also had
+//   a K-split layout - four wave positions, the two ping-pong groups multiplying one K-half each, 14 -> 10 fragment reads per step on 256 x 96: 3 - 5 %
+//   faster in isolation at long K, 0.1 - 0.3 ms per step slower inside the step on every box: profiles/r03_gemm_ab_ks.txt, r04_in_step_choices.txt.
+//   Removed in round 6.)
 // AKM / BKM: the operand is k-major (A(m,k) = A[k * lda + m]): the weight-gradient form dW = dY^T X, both operands token-major with the
 //   reduction running over their rows.  Its LDS image is the 128-row kernel's ([64 k-rows][256 B] per 128 tile rows, bytes rotated per
 //   k-row, read with ds_read_b64_tr_b16: gemm_common.h), one 16 KiB sub-image per 128 tile rows; a DMA piece is 32 k-rows of one
 //   sub-image, so pieces, ring slots and the whole schedule are those of the row-major form.
 // RS: the bias gradient rides on the launch (EpiArgs::rowsum_direct): the tile_n == 0 workgroups multiply every A fragment once more
 //   against an all-ones operand (see gemm_tile in gemm.hip).
-template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int KS, int ABL, bool AKM, bool BKM, bool RS>
+template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int ABL, bool AKM, bool BKM, bool RS>
 DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb, int tile_m, int tile_n,
                     const EpiArgs& epi, const Probe& pr, unsigned char* smem) {
     // ABL (ablation builds only, -DMMF_WIDE_ABLATE): bit 0 no DMA issue in the loop, bit 1 no MFMA, bit 2 no fragment reads, bit 3 no epilogue
     constexpr int dbg = ABL;
-    static_assert(KS == 1 || KS == 2, "K split across the two ping-pong groups");
-    static_assert(WGM * WGN * KS == 8, "eight waves");
-    constexpr int KK = 2 / KS;                   // 32-deep sub-steps a wave multiplies per 64-deep K-step
+    static_assert(WGM * WGN == 8, "eight waves");
+    constexpr int KK = 2;                        // 32-deep sub-steps a wave multiplies per 64-deep K-step
     static_assert(NS == 3, "the schedule below is written for a three-stage ring");
     static_assert(BM_ % 64 == 0 && BN_ % 32 == 0, "tile shape");
     static_assert(!AKM || (BM_ % 128 == 0 && !RAGGED_M), "k-major A: whole 128-row sub-images");
     static_assert(!BKM || BN_ % 128 == 0, "k-major B: whole 128-row sub-images");
-    static_assert(!RS || (AKM && KS == 1), "row sums ride on the weight-gradient form");
+    static_assert(!RS || AKM, "row sums ride on the weight-gradient form");
     constexpr int WTM = BM_ / WGM, WTN = BN_ / WGN, NFM = WTM / 16, NFN = WTN / 16;
     constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int PA = BM_ / 64;                 // LDS-DMA wave-instructions per wave for the A image (64 rows each, all 8 waves)
@@ -68,7 +63,7 @@ DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
-    const int gpos = KS == 2 ? (wave & 3) : wave;   // position in the wave grid (KS = 2: the grid repeats per group, group = K-half)
+    const int gpos = wave;                       // position in the wave grid
     const int wm = gpos / WGN, wn = gpos % WGN;
     const bool probing = pr.buf != nullptr;
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
@@ -144,7 +139,7 @@ DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
     const int frow = lane & 15, fswz = lane & 7;
     const int a_off = (wm * WTM + frow) * 128, b_off = A_BYTES + (wn * WTN + frow) * 128;
     const int c0_ = (((lane >> 4)) ^ fswz) << 4, c1_ = ((4 + (lane >> 4)) ^ fswz) << 4;
-    const int c0 = (KS == 2 && grp == 1) ? c1_ : c0_, c1 = c1_;     // KS = 2: the wave's only sub-step is K-half `grp`
+    const int c0 = c0_, c1 = c1_;
     // k-major image (read_frag<true> of gemm_common.h, addresses hoisted): lane (g = l >> 4, p = l & 15) reads 8 bytes at k-row
     // 32 kk + 8 g + (p >> 2) (+ 4 for the second half) of its sub-image, byte column ((col * 2 + rot) & 255), col = the fragment's
     // first tile row + 4 (p & 3), rot = 32 ((p >> 2) + 4 (g & 1)); sub-step kk adds 32 k-rows = 8192 bytes.
@@ -152,7 +147,7 @@ DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
     if constexpr (AKM || BKM) {
         const int g = lane >> 4, p = lane & 15;
         const int rot = 32 * ((p >> 2) + 4 * (g & 1)), krow = (8 * g + (p >> 2)) * 256;
-        const int kk0 = (KS == 2 && grp == 1) ? 8192 : 0;
+        const int kk0 = 0;
         if constexpr (AKM) {
 #pragma unroll
             for (int f = 0; f < NFM; ++f) {
@@ -349,7 +344,7 @@ DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
     const uint32_t dkey = drop_key(epi.drop);
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-        if (wm / WPP == p && (KS == 1 || grp == 0)) {
+        if (wm / WPP == p) {
             const int lr0 = (wm % WPP) * WTM;
 #pragma unroll
             for (int i = 0; i < NFM; ++i)
@@ -360,21 +355,6 @@ DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
                 }
         }
         __syncthreads();
-        if (KS == 2) {          // second K-half: added in place (each (wm, wn) region has exactly one writer per phase)
-            if (wm / WPP == p && grp == 1) {
-                const int lr0 = (wm % WPP) * WTM;
-#pragma unroll
-                for (int i = 0; i < NFM; ++i)
-#pragma unroll
-                    for (int j = 0; j < NFN; ++j) {
-                        const int row = lr0 + i * 16 + (lane & 15), col = wn * WTN + j * 16 + (lane >> 4) * 4;
-                        float4* pc = reinterpret_cast<float4*>(cs + row * CLD + col);
-                        const float4 v = *pc;
-                        *pc = make_float4(v.x + acc[i][j][0], v.y + acc[i][j][1], v.z + acc[i][j][2], v.w + acc[i][j][3]);
-                    }
-            }
-            __syncthreads();
-        }
         if (probing && p == 0) pt[3] = __builtin_amdgcn_s_memrealtime();
         if (fast) {
 #pragma unroll
@@ -424,13 +404,13 @@ DEVI void wide_super_row(int bid, int tiles_m, int tiles_n, int& tile_m, int& ti
     tile_m = sr * 4 + (rem - tile_n * h);
 }
 
-template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int KS = 1, int ABL = 0, bool AKM = false, bool BKM = false, bool RS = false>
+template <int BM_, int BN_, int WGM, int WGN, int NS, bool RAGGED_M, int ABL = 0, bool AKM = false, bool BKM = false, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
                                                             int lda, int ldb, int tiles_m, int tiles_n, EpiArgs epi, Probe pr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile_m, tile_n;
     wide_super_row(wide_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tile_m, tile_n);
-    wide_tile<BM_, BN_, WGM, WGN, NS, RAGGED_M, KS, ABL, AKM, BKM, RS>(A, B, M, N, K, lda, ldb, tile_m, tile_n, epi, pr, smem);
+    wide_tile<BM_, BN_, WGM, WGN, NS, RAGGED_M, ABL, AKM, BKM, RS>(A, B, M, N, K, lda, ldb, tile_m, tile_n, epi, pr, smem);
 }
 
 }  // namespace gemm

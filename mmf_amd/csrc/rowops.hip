@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // partials layout: [gridDim.x][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias
 // ------------------------------------------------------------------------------------------------
 constexpr int LNB_GRID = 128;       // default workgroups (16 waves each); one partial row per workgroup
-constexpr int LNB_MAX_GRID = 512;   // the workspace is sized for this many (MMF_TUN_LN_BWD_GRID may raise the grid)
+constexpr int LNB_MAX_GRID = 512;   // the workspace is sized for this many (the largest grid the launches use)
 constexpr int LNB_WAVES = 16;      // waves per workgroup for H <= 768; H = 1024 (four column chunks per lane) runs 8 waves so that
                                    // its register budget doubles and nothing spills
 template <int NCH> struct LnbWaves { static constexpr int value = (NCH >= 5) ? 4 : (NCH >= 4) ? 8 : LNB_WAVES; };   // 5..8 chunks (H <= 2048): 4 waves
@@ -1334,7 +1334,7 @@ struct AdamLaunch {
     mmf_adamw_multi_desc d;
     int cstart[MMF_MT_MAX + 1];
 };
-// (`total` chunks over gridDim.x workgroups: one chunk each by default; MMF_TUN_ADAM_GRID caps the grid and the workgroups stride over
+// (`total` chunks over gridDim.x workgroups: one chunk each by default; a capped grid would stride over
 // the chunk list — the form that runs beside a GEMM launch on the CUs it leaves idle.)
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamLaunch a, float bc1_in, float bc2_in, int total) {
     const mmf_adamw_multi_desc& d = a.d;
@@ -1501,7 +1501,7 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 
 extern "C" {
 
-static bool ln_h_path(int H) { return (H % 256) == 0 && H <= 1024 && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 1; }
+static bool ln_h_path(int H) { return (H % 256) == 0 && H <= 1024 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 1); }
 static int layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int H, float eps,
                               DropoutCfg dc, void* stream) {
     MMF_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null operand");
@@ -1546,11 +1546,11 @@ int mmf_layernorm_bwd_ws_floats(int H) { return LNB_MAX_GRID * 3 * H; }
 static int lnb_h_grid(int rows) {
     int grid = (rows + 15) / 16;
     if (grid > LNB_MAX_GRID) grid = LNB_MAX_GRID;
-    const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
+    const int tg = 0;
     if (tg > 0 && tg < grid) grid = tg;
     return grid;
 }
-static bool lnb_h_path(int H, bool dbias) { return (H % 256) == 0 && H <= 1024 && !(H == 1024 && dbias) && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 1; }
+static bool lnb_h_path(int H, bool dbias) { return (H % 256) == 0 && H <= 1024 && !(H == 1024 && dbias) && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 1); }
 
 int mmf_layernorm_bwd_deferrable(int rows, int H) { return rows > 0 && lnb_h_path(H, false) ? 1 : 0; }
 
@@ -1579,14 +1579,14 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* mean, 
     MMF_CHECK_ARG(drop_thr16 == 0 || dlin, "layernorm_bwd: dropout needs dlin");
     hipStream_t s = (hipStream_t)stream;
     DropoutCfg dc{drop_key, drop_thr16, drop_scale, drop_seed};
-    const int tg = mmf_amd_get_tunable(MMF_TUN_LN_BWD_GRID);
+    const int tg = 0;
     if (lnb_h_path(H, dbias != nullptr)) {     // half a wave per row, 16-byte accesses
         const int grid = lnb_h_grid(rows);
         const bf16* dyp = (const bf16*)dy; const bf16* xp = (const bf16*)x; bf16* dxp = (bf16*)dx; bf16* dlp = (bf16*)dlin;
-        // two rows of a half-wave in flight whenever it owns more than one (MMF_TUN_LN_OLD = 2: one at a time, the round-3 form; A/B) — except at H = 1024, where
+        // two rows of a half-wave in flight whenever it owns more than one (MMF_TUN_ALT_FORMS bit 3: one at a time, the schedule of the input-dropout form; its bit-equality test) — except at H = 1024, where
         // the two-row form needs all 256 registers = ONE wave per SIMD and loses to the one-row form at two (isolated, backward + dropout + reduce: 14.1 vs 13.0 us
         // at 3232 rows, 36.5 vs 28.7 at 14592: profiles/r05_experiments.txt section 14)
-        const bool two = rows > 8 * grid && mmf_amd_get_tunable(MMF_TUN_LN_OLD) != 2 && (H < 1024 || mmf_amd_get_tunable(MMF_TUN_LN_OLD) == 3);      // (3: two rows at H = 1024 too, A/B)
+        const bool two = rows > 8 * grid && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 8) && H < 1024;
 #define MMF_LNB_H(NC)                                                                                                              \
         /* (input dropout: one row in flight per half-wave — with two the H = 768 form needs all 256 registers and a single wave per SIMD) */ \
         if (din.thr16) hipLaunchKernelGGL((ln_bwd_h_kernel<NC, false, 1, true>), dim3(grid), dim3(256), 0, s, dyp, xp, mean, rstd, gamma, dxp, dlp, dc, partials, rows, din); \
@@ -2041,7 +2041,7 @@ int mmf_adamw_multi(const mmf_adamw_multi_desc* d, void* stream) {
     int blocks = 0;
     for (int i = 0; i < d->n; ++i) { a.cstart[i] = blocks; blocks += (int)((d->numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK); }
     for (int i = d->n; i <= MMF_MT_MAX; ++i) a.cstart[i] = blocks;
-    const int cap = mmf_amd_get_tunable(MMF_TUN_ADAM_GRID);
+    const int cap = 0;
     const int grid = (cap > 0 && cap < blocks) ? cap : blocks;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, bc1, bc2, blocks);
     MMF_CHECK_LAUNCH();

@@ -106,11 +106,11 @@ def make_drop(p, training):
 # ---------------------------------------------------------------------------------------------
 # bf16 shadows of fp32 master parameters
 # ---------------------------------------------------------------------------------------------
-# Transposed weight twins for the input-gradient GEMMs (MMF_AMD_DGRAD_NT=0 switches them off).  dX = dY W reads W k-major; with
+# Transposed weight twins for the input-gradient GEMMs (on; `DGRAD_NT` below).  dX = dY W reads W k-major; with
 # a W^T twin both operands are row operands and the launch can use the forward-form kernels.  On the 128x128 kernel that bought
 # nothing inside the step (round 1: 11.62 vs 11.53-11.62 ms), but it makes the narrow-output dgrads eligible for the 256x96 wide
 # tile, which does pay (see _twin_pays).  Cost: one bf16 transpose per twin and optimizer step (mmf_transpose_bf16_multi).
-DGRAD_NT = os.environ.get("MMF_AMD_DGRAD_NT", "1") == "1"
+DGRAD_NT = True      # (a module attribute, not an environment switch: tests/test_dgrad_nt_gpu.py flips it to compare with the k-major form)
 
 
 def _twin_pays(out_width):
@@ -151,7 +151,7 @@ class ShadowCache:
 
     def transposed(self, w16):
         """W^T [in, out] (bf16) of the weight shadow `w16` [out, in], or None when `w16` is not a whole tracked shadow (or
-        its dimensions are not multiples of 64, or MMF_AMD_DGRAD_NT=0).  Built on first use, re-built when the shadow's
+        its dimensions are not multiples of 64, or DGRAD_NT is off).  Built on first use, re-built when the shadow's
         signature changed (a re-cast after `load_state_dict` / a torch optimizer), and kept current by
         `refresh_transposed()` when the fused optimizer updates parameters and shadows in place."""
         if NATIVE:
@@ -290,8 +290,8 @@ def _grad_bf16(g, cols):
 # ---------------------------------------------------------------------------------------------
 # shared forward/backward pieces
 # ---------------------------------------------------------------------------------------------
-_FUSED_DB = os.environ.get("MMF_AMD_NO_FUSED_DB", "0") != "1"   # A/B switch for measurements
-_FEATS_CAST = os.environ.get("MMF_AMD_FEATS_CAST", "1") == "1"  # A/B switch: region features cast to bf16 once (see VisioLinguisticEmbeddingsFn)
+_FUSED_DB = True     # the bias gradient rides on the weight-gradient GEMM (tests switch it off to compare)
+_FEATS_CAST = True   # region features cast to bf16 once (see VisioLinguisticEmbeddingsFn)
 
 
 _WGRAD_DEFER_MIN_ROWS = 64      # token rows below which a weight gradient is not worth queueing (the heads: a handful of rows, their own skinny paths)
@@ -777,7 +777,7 @@ class _WgradDefer:
         self.queues = {}      # (wide-tile eligible, stream) -> list of (problem, tensors kept alive)
         self.seen = set()     # weights (their bf16 shadows) that already have a queued gradient in this deferral block
         self.streams = {}     # stream handle -> torch stream object of the queues above (a mid-backward flush orders itself behind them)
-        self.enabled = os.environ.get("MMF_AMD_WGRAD_DEFER", "1") != "0"       # (A/B switch)
+        self.enabled = True
 
     @contextlib.contextmanager
     def __call__(self):
@@ -847,78 +847,6 @@ class _WgradDefer:
 wgrad_defer = _WgradDefer()
 
 
-class _WgradOverlap:
-    """Opt-in: inside `with wgrad_overlap(stream):` every layer's grouped weight-gradient launch goes to `stream` instead of
-    the current one, so that it runs beside the dgrad chain of the layers below (the weight gradients are consumed only by the
-    optimizer); leaving the block makes the current stream wait for it.  Only for callers that own the whole backward
-    (GraphedTrainStep): autograd itself assumes gradients are ready on the stream backward ran on."""
-
-    def __init__(self):
-        self.stream = None
-
-    @contextlib.contextmanager
-    def __call__(self, stream):
-        old, self.stream = self.stream, stream
-        if stream is not None:
-            _ops_native.push_mode(1)      # the hook lives in the Python autograd node: route the layer operator there
-        try:
-            yield
-        finally:
-            self.stream = old
-            if stream is not None:
-                _ops_native.pop_mode(1)
-                torch.cuda.current_stream().wait_stream(stream)
-
-    def launch(self, problems, tensors):
-        side = self.stream
-        if side is None:
-            nat.gemm_grouped(problems)
-            return
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            nat.gemm_grouped(problems)
-        for t in tensors:          # operands were allocated on the launching stream: keep their memory until `side` is done
-            t.record_stream(side)
-
-
-wgrad_overlap = _WgradOverlap()
-
-
-class _ParamUpdateHook:
-    """Optimizer-in-backward: inside `with param_update(fn):` every TransformerLayerFn.backward hands the layer's weight and bias
-    parameters with their finished gradients to `fn(params, grads)` right after the grouped weight-gradient launch, instead of
-    leaving them for an optimizer step at the end of the backward pass.  The fused AdamW is HBM-bound while the input-gradient
-    GEMMs of the layers below are MFMA / LDS-bound, so the update of layer L runs beside the backward of layers < L on a second
-    stream (`AdamW.update_in_backward`, a parallel branch of the captured hipGraph).  LayerNorm parameters are not handed over:
-    under `ln_defer` their gradients are finished by the multi-tensor reduction at the end of the step."""
-
-    def __init__(self):
-        self.fn = None
-        self.beside = None
-        self.beside_wgrad = False
-
-    @contextlib.contextmanager
-    def __call__(self, fn, beside=None, beside_wgrad=False):
-        """`beside` (optional): a context-manager factory the layer's backward wraps around its attention-backward launch — the optimizer
-        uses it to run the update of the layer ABOVE (whose gradients are complete) on a second stream exactly beside that kernel
-        (`AdamW.beside_attention`): the one kernel of a layer's backward that leaves HBM and half the CUs idle (one 8-wave workgroup per
-        (batch, head) = 384 workgroups on 256 CUs, two rounds) and keeps no operand panels in L2 for the update stream to evict."""
-        old, self.fn = self.fn, fn
-        old_b, self.beside = self.beside, beside
-        old_w, self.beside_wgrad = self.beside_wgrad, beside_wgrad     # wrap the grouped weight-gradient launch instead of the attention backward
-        if fn is not None:
-            _ops_native.push_mode(1)      # the hook lives in the Python autograd node: route the layer operator there
-        try:
-            yield
-        finally:
-            self.fn, self.beside, self.beside_wgrad = old, old_b, old_w
-            if fn is not None:
-                _ops_native.pop_mode(1)
-
-
-param_update = _ParamUpdateHook()
-
-
 class TransformerLayerFn(torch.autograd.Function):
     """BertLayerJit.forward (hf_layers.py:255-292) as ONE autograd node: the attention sub-layer (AttentionBlockFn) followed by
     the feed-forward sub-layer (FeedForwardFn), same kernels and same saved tensors.  What the fusion buys is in backward:
@@ -945,7 +873,6 @@ class TransformerLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, qkv, ctxt, lse, y1, mean1, rstd1, a_out, u, hh, y2, mean2, rstd2, wqkv16, wo16, w1_16, w2_16,
                               g1.detach(), g2.detach(), mask_add, o32, kb)
         ctx.meta = (B, S, H, I, heads, drop_attn, drop_hid1, drop_hid2, tail)
-        ctx.update_params = (wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2)      # leaves: for `param_update` (optimizer in backward)
         return out.view(B, S, H)
 
     @staticmethod
@@ -967,20 +894,15 @@ class TransformerLayerFn(torch.autograd.Function):
         dqkv = torch.empty(M, 3 * H, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, S, dtype=F32, device=dev)
         scale = 1.0 / math.sqrt(H // heads)
-        with (param_update.beside() if (param_update.beside is not None and not param_update.beside_wgrad) else contextlib.nullcontext()):
-            nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
-                              dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
+        nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale,
+                          dctx, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], delta, drop_attn, head_dim=H // heads, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
         dx = _dgrad(dqkv, 3 * H, wqkv16, M, 3 * H, H, dx_resid=dres1, site=nat.SITE_QKV_DGRAD) if ctx.needs_input_grad[0] else None
         # the four weight gradients, one launch
         p_1, dw1, db1 = _wgrad_problem(du, I, a_out, M, I, H, True)
         p_2, dw2, db2 = _wgrad_problem(dlin2, H, hh, M, H, I, True)
         p_q, dwqkv, dbqkv = _wgrad_problem(dqkv, 3 * H, x2, M, 3 * H, H, True)
         p_o, dwo, dbo = _wgrad_problem(dlin1, H, ctxt, M, H, H, True)
-        with (param_update.beside() if (param_update.beside is not None and param_update.beside_wgrad) else contextlib.nullcontext()):
-            wgrad_overlap.launch([p_1, p_2, p_q, p_o], (du, a_out, dlin2, hh, dqkv, x2, dlin1, ctxt, dw1, db1, dw2, db2, dwqkv, dbqkv, dwo, dbo))
-        if param_update.fn is not None and wgrad_overlap.stream is None:
-            param_update.fn(ctx.update_params, (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
-                                                dwo, dbo, dw1, db1, dw2, db2))
+        nat.gemm_grouped([p_1, p_2, p_q, p_o])
         return ((dx.view(B, S, H) if dx is not None else None),
                 dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, dbe1,
                 dw1, db1, dw2, db2, dg2, dbe2) + (None,) * 13

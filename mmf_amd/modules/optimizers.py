@@ -43,11 +43,6 @@ class AdamW(torch.optim.Optimizer):
         self.external_grads = None  # id(parameter) -> tensor to read its gradient from instead of `.grad` (fp32 or bf16, contiguous, same
                                     # element count): the data-parallel step points this at its wire buffers, so the summed bf16
                                     # gradients are consumed where the all-reduce left them (no unpack / convert pass)
-        self._pending = None        # (params, grads) of a layer whose update waits for the next attention backward (beside_attention)
-        self.pin_to_attention = False
-        self._early = None          # ids of the parameters already updated inside this step's backward (update_in_backward)
-        self._early_stream = None
-        self._group_of = None
 
     @torch.no_grad()
     def ensure_state(self, params=None):
@@ -76,111 +71,6 @@ class AdamW(torch.optim.Optimizer):
         self._clip = (norm_sq, float(max_norm))
         return norm_sq.sqrt()[0] * self.grad_scale
 
-    # ---- optimizer in backward ---------------------------------------------------------------------------------------
-    # The update is HBM-bound (30 bytes per parameter), the backward GEMMs are MFMA / LDS-bound: run on a second stream, the
-    # update of an encoder layer hides beside the backward of the layers below it.  Legal whenever nothing needs ALL gradients
-    # before the first update: no gradient clipping (`clip_gradients: false` in the reference's VQA2 config,
-    # mmf/configs/defaults.yaml:101) and no cross-rank reduction (one rank).  Same kernel, same arithmetic, same result
-    # (tests/test_model_parity_gpu.py::test_optimizer_in_backward_equals_end_of_step_update).  OPT-IN (GraphedTrainStep(overlap_update=
-    # True) / MMF_AMD_ADAM_OVERLAP=1): at the VisualBERT VQA2 shape it measured SLOWER (8.53 vs 8.25 ms, same box) — the streamed
-    # 213 MB per layer push the GEMM operand panels out of L2.
-    @torch.no_grad()
-    def begin_step(self, stream):
-        """Open a step whose layer updates arrive through `update_in_backward` (functional.param_update): advances the device-side
-        step count / schedule factor now; `step()` then closes it (updates what is left, joins `stream`)."""
-        if self._clip is not None:
-            raise RuntimeError("optimizer-in-backward cannot be combined with gradient clipping (the clip factor needs every gradient)")
-        if self.capturable:
-            if self._dev_state is None:
-                self._dev_state = torch.zeros(2, dtype=torch.float32, device=self.param_groups[0]["params"][0].device)
-            nat.optim_state_advance(self._dev_state, *self._schedule)
-        self._early, self._early_stream = set(), stream
-        if self._group_of is None:
-            self._group_of = {id(p): g for g in self.param_groups for p in g["params"]}
-
-    # Round 3: pinned form.  Free-running beside the backward (above) the update loses: its 213 MB per layer evict the GEMMs' operand
-    # panels from L2.  With `pin_to_attention` the update of layer L is held back until the ATTENTION backward of layer L - 1 is
-    # launched and runs only beside that kernel (fork before it, join after it): attention backward is one 8-wave workgroup per
-    # (batch, head) — 384 workgroups in two rounds on 256 CUs, the second half-empty — latency-bound, with HBM idle outside its
-    # staging burst and nothing in L2 worth keeping.  Layer 0's update (nothing below it) joins the end-of-step update.
-    @torch.no_grad()
-    def update_in_backward(self, params, grads):
-        if self._early is None:
-            return
-        if self.pin_to_attention:
-            if self._pending is not None:          # (no attention backward came in between: do not lose the previous layer's update)
-                self._launch_update(*self._pending)
-            self._pending = (params, grads)
-            return
-        self._launch_update(params, grads)
-
-    def beside_attention(self):
-        """Context manager for `functional.param_update(..., beside=...)`: wraps ONE kernel launch on the current stream."""
-        opt = self
-
-        after = os.environ.get("MMF_AMD_ADAM_ORDER", "before") == "after"     # enqueue the update behind the wrapped kernel (still parallel to it)
-
-        class _Beside:
-            def __enter__(self_):
-                self_.ran = False
-                self_.pend = None
-                if opt._early is not None and opt._pending is not None:
-                    pend, opt._pending = opt._pending, None
-                    if after:
-                        self_.pend = pend
-                        self_.ev = torch.cuda.current_stream().record_event()      # the fork point: everything before the wrapped kernel
-                    else:
-                        opt._launch_update(*pend)           # fork: side stream waits for everything enqueued so far on the main stream
-                    self_.ran = True
-
-            def __exit__(self_, *exc):
-                if self_.ran:
-                    if self_.pend is not None:
-                        opt._launch_update(*self_.pend, fork_event=self_.ev)
-                    torch.cuda.current_stream().wait_stream(opt._early_stream)      # join behind the wrapped kernel
-        return _Beside()
-
-    @torch.no_grad()
-    def _launch_update(self, params, grads, fork_event=None):
-        if self._early is None:
-            return
-        main, side = torch.cuda.current_stream(), self._early_stream
-        by_group = {}
-        for p, g in zip(params, grads):
-            grp = self._group_of.get(id(p))
-            if grp is None or g is None or not p.requires_grad:
-                continue
-            if id(p) in self._early:
-                raise RuntimeError("optimizer-in-backward: a parameter received a second gradient in one step (shared weights); "
-                                   "use the end-of-step update")
-            st = self.state[p]
-            if len(st) == 0:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            st["step"] = int(st.get("step", 0)) + 1
-            self._early.add(id(p))
-            by_group.setdefault((id(grp), st["step"]), (grp, st["step"], []))[2].append(
-                (p, g if g.is_contiguous() else g.contiguous(), st["exp_avg"], st["exp_avg_sq"], Fn.shadows.slot(p), grp["lr"],
-                 grp["weight_decay"]))
-        if not by_group:
-            return
-        if fork_event is not None:
-            side.wait_event(fork_event)
-        else:
-            side.wait_stream(main)              # the gradients were produced on the launching stream
-        side_grid = int(os.environ.get("MMF_AMD_ADAM_SIDE_GRID", "0"))      # workgroup cap of the in-backward launches only (they stride over the chunks)
-        with torch.cuda.stream(side):
-            if side_grid:
-                nat.set_tunable(nat.TUN_ADAM_GRID, side_grid)
-            for grp, step, items in by_group.values():
-                b1, b2 = grp["betas"]
-                nat.adamw_multi(items, b1, b2, grp["eps"], step, grp["correct_bias"], 1 if self.torch_mode else 0, self.grad_scale,
-                                None, 0.0, self._dev_state if self.capturable else None)
-            if side_grid:
-                nat.set_tunable(nat.TUN_ADAM_GRID, 0)
-            Fn.shadows.refresh_transposed(only=list(params))
-
     @torch.no_grad()
     def advance(self, seed=None):
         """Advance the device-side step count / schedule factor now — and, in the SAME one-thread launch, the dropout seed word of a captured step
@@ -207,17 +97,12 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if self._pending is not None and self._early is not None:      # the lowest layer's update: nothing left to hide it behind
-            pend, self._pending = self._pending, None
-            self._launch_update(*pend)
-        early, self._early = self._early, None
-        early_params = None if early is None else [p for g in self.param_groups for p in g["params"] if id(p) in early]
         dev_state = None
         if self.capturable:
             if self._dev_state is None:
                 dev = self.param_groups[0]["params"][0].device
                 self._dev_state = torch.zeros(2, dtype=torch.float32, device=dev)
-            if early is None and advance:      # (begin_step already advanced the counters of a step opened for in-backward updates)
+            if advance:
                 nat.optim_state_advance(self._dev_state, *self._schedule)
             dev_state = self._dev_state
         # Learning rate and weight decay travel per tensor, so parameter groups that share betas / eps / correct_bias (the two BERT groups of
@@ -229,7 +114,7 @@ class AdamW(torch.optim.Optimizer):
                 if only is not None and id(p) not in only:
                     continue
                 grad = self._grad_of(p)
-                if grad is None or (early is not None and id(p) in early):
+                if grad is None:
                     continue
                 if grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
@@ -251,10 +136,7 @@ class AdamW(torch.optim.Optimizer):
         if only is not None:
             Fn.shadows.refresh_transposed(only=[p for g_ in self.param_groups for p in g_["params"] if id(p) in only])
         else:
-            Fn.shadows.refresh_transposed(skip=early_params)     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
-        if early is not None:
-            torch.cuda.current_stream().wait_stream(self._early_stream)      # join the in-backward updates
-            self._early_stream = None
+            Fn.shadows.refresh_transposed()     # W^T twins of the shadows the update just rewrote (dgrad GEMM operands)
         return loss
 
     # ---- checkpoints ---------------------------------------------------------------------------------------------------

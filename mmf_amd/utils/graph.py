@@ -76,26 +76,11 @@ class GraphedTrainStep:
     parameter is updated and no step is counted before the first replay; the optimizer's moments are allocated up front
     (`ensure_state`) so that the captured update contains no zero-fill."""
 
-    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None, overlap_wgrad=None, overlap_update=None):
-        """`overlap_wgrad`: run every layer's grouped weight-gradient GEMM on a second stream (a parallel branch of the graph)
-        beside the dgrad chain of the layers below; default from MMF_AMD_WGRAD_OVERLAP (off).
-        `overlap_update`: optimizer in backward — each encoder layer's AdamW update (HBM-bound) is launched on a second stream as
-        soon as the layer's weight gradients exist and runs beside the backward of the layers below (MFMA-bound); default from
-        MMF_AMD_ADAM_OVERLAP (OFF: measured slower at the VisualBERT VQA2 shape, 8.53 against 8.25 ms per step on the same box —
-        the streaming update evicts the GEMMs' operand panels from L2 and costs them more than the 0.33 ms it hides; kept, with its
-        bit-equality test, for shapes whose backward leaves the chip idle).  Same arithmetic as the end-of-step update; not
-        combinable with gradient clipping."""
+    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None):
+        # (Rounds 2 - 3 could also put the grouped weight gradients or each layer's AdamW update on a second stream beside the backward of the layers
+        #  below; both measured slower on every box - the streamed 213 MB per layer evict the GEMMs' operand panels from L2, 8.53 against 8.25 ms -
+        #  and were removed in round 6: profiles/r04_experiments.txt.)
         self.model = model
-        if overlap_wgrad is None:
-            overlap_wgrad = os.environ.get("MMF_AMD_WGRAD_OVERLAP", "0") == "1"
-        if overlap_update is None:
-            overlap_update = os.environ.get("MMF_AMD_ADAM_OVERLAP", "0")
-            overlap_update = {"0": False, "1": True, "2": "attention", "3": "wgrad"}.get(overlap_update, False)
-        self.pin_update = overlap_update in ("attention", "wgrad")    # each layer's update runs only beside ONE kernel of the layer below: its attention backward,
-        self.pin_wgrad = overlap_update == "wgrad"                    # or its grouped weight-gradient launch (216 tiles of the wide kernel: 40 CUs idle for ~100 us)
-        self.side_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
-        self.update_stream = (torch.cuda.Stream(device=next(model.parameters()).device)
-                              if (overlap_update and optimizer is not None and not overlap_wgrad and hasattr(optimizer, "begin_step")) else None)
         self.optimizer = optimizer
         if optimizer is not None and not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs an optimizer whose step reads its counters from device memory (capturable=True)")
@@ -123,23 +108,11 @@ class GraphedTrainStep:
                 self.out, self.loss = self._eager()
 
     def _eager(self, update=True):
-        # The opt-in hooks (weight gradients / optimizer on a second stream) live in the PYTHON autograd node of the encoder layer: the
-        # forward has to build that node, so the operator is routed to its Python twin for the whole pass, not only for the backward
-        # (with the native operator library the backward otherwise runs the C++ node and the hooks never fire).
-        hooks = self.side_stream is not None or (self.update_stream is not None and update)
-        if hooks:
-            from mmf_amd import _ops_native
-            _ops_native.push_mode(1)
-        try:
-            return self._eager_body(update)
-        finally:
-            if hooks:
-                _ops_native.pop_mode(1)
+        return self._eager_body(update)
 
     def _eager_body(self, update):
-        early = self.update_stream is not None and update
         # the dropout seed word and the optimizer's step count / schedule factor advance in ONE one-thread launch at the head of the step
-        head_advance = self.optimizer is not None and update and not early and hasattr(self.optimizer, "advance")
+        head_advance = self.optimizer is not None and update and hasattr(self.optimizer, "advance")
         if head_advance:
             self.optimizer.advance(self.seed)
         else:
@@ -150,12 +123,7 @@ class GraphedTrainStep:
         # created on; if an earlier eager step created them on the legacy default stream, running them inside the
         # capture drags that stream into it and hipStreamEndCapture crashes.  Capturing the gradients directly keeps
         # every captured node on the capture stream.
-        if early:
-            self.optimizer.pin_to_attention = self.pin_update
-            self.optimizer.begin_step(self.update_stream)
-        with Fn.wgrad_overlap(self.side_stream), Fn.ln_defer(), Fn.wgrad_defer(), Fn.param_update(
-                self.optimizer.update_in_backward if early else None, self.optimizer.beside_attention if (early and self.pin_update) else None,
-                beside_wgrad=self.pin_wgrad):
+        with Fn.ln_defer(), Fn.wgrad_defer():
             # (the seed of the backward pass is a tensor made once, ahead of the capture: `grad_outputs=None` fills a new ones tensor per step)
             if getattr(self, "_one", None) is None or self._one.dtype != loss.dtype:
                 self._one = torch.ones_like(loss)
@@ -163,7 +131,6 @@ class GraphedTrainStep:
         for p, g in zip(self.params, grads):
             p.grad = g
         if self.optimizer is not None and update:
-            # (closes a step opened by begin_step: the remaining parameters, then joins the update stream)
             self.optimizer.step(**({"advance": False} if head_advance else {}))
         return out, loss
 

@@ -1,5 +1,4 @@
-"""Transposed weight twins for the input-gradient GEMMs (GPU; an opt-in experiment, MMF_AMD_DGRAD_NT=1, off by default because
-the in-step A/B showed no gain): the multi-tensor transpose kernel, the NT form of dX = dY W
+"""Transposed weight twins for the input-gradient GEMMs (GPU; the default since round 4, `functional.DGRAD_NT`): the multi-tensor transpose kernel, the NT form of dX = dY W
 against the k-major form and fp32 torch, and the bookkeeping that keeps W^T current — re-built after a re-cast, refreshed by
 the fused optimizer's step."""
 import pytest

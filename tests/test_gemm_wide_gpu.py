@@ -27,52 +27,10 @@ def test_wide_forward_bias_matches_torch_and_the_128_row_kernel(cfg, M, K, force
     A = rnd(M, K, seed=1); B = rnd(N, K, seed=2, scale=0.05); bias = torch.randn(N, device=DEV)
     C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV); C0 = torch.empty_like(C)
     force_wide(cfg)
-    nat().set_tunable(5, 1)          # MMF_TUN_GEMM_WIDE_KS = 1: the layout whose K order equals the 128-row kernel's
-    try:
-        nat().gemm(A, B, C, M, N, K, K, K, N, bias=bias)
-    finally:
-        nat().set_tunable(5, 0)
+    nat().gemm(A, B, C, M, N, K, K, K, N, bias=bias)
     nat().gemm(A, B, C0, M, N, K, K, K, N, bias=bias, debug_flags=NO_WIDE | NO_KSPLIT)
     close(C, A.float() @ B.float().t() + bias, 1e-2, 2e-2, "wide tile %s forward" % (CONFIGS[cfg],))
     assert torch.equal(C, C0)
-
-
-@pytest.mark.parametrize("M,K", [(7296, 3072), (3200, 2304), (1500, 768), (300, 1536)])
-def test_wide_256x96_k_split_layout_matches_torch_and_the_unsplit_layout(M, K, force_wide):
-    """KS = 2 (round 3): the two ping-pong groups of the 256 x 96 tile multiply the two 32-deep halves of every K-step and the halves
-    are summed in the epilogue's LDS stage: against fp32 torch, and against the unsplit layout up to the fp32 summation order (one
-    bf16 rounding of the output), with every epilogue the fast path serves (bias + dropout + residual, act 2 + aux) and the generic one."""
-    N = 768
-    A = rnd(M, K, seed=11); B = rnd(N, K, seed=12, scale=0.05); bias = torch.randn(N, device=DEV)
-    R = rnd(M, N, seed=13); aux = rnd(M, N, seed=14)
-    force_wide(1)
-    for kw, ref in ((dict(bias=bias), lambda r: r + bias), (dict(bias=bias, resid=R, ldr=N), lambda r: r + bias + R.float()),
-                    (dict(act=2, aux=aux), lambda r: r * aux.float()),
-                    (dict(bias=bias, act=1, U=torch.empty(M, N, dtype=torch.bfloat16, device=DEV)), lambda r: torch.nn.functional.gelu(r + bias))):
-        outs = {}
-        for ks in (1, 2):
-            nat().set_tunable(5, ks)
-            try:
-                C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-                nat().gemm(A, B, C, M, N, K, K, K, N, **kw)
-                outs[ks] = C
-            finally:
-                nat().set_tunable(5, 0)
-        want = ref(A.float() @ B.float().t())
-        close(outs[2], want, 1e-2, 2e-2 * float(want.abs().max()), "K-split layout vs torch %s" % sorted(kw))
-        close(outs[2], outs[1], 1e-2, 1e-2 * float(want.abs().max()), "K-split vs unsplit layout %s" % sorted(kw))
-    drop = nat().drop_cfg(0.1, 4242)
-    outs = {}
-    for ks in (1, 2):         # the same dropout mask under both layouts (hash of the element index)
-        nat().set_tunable(5, ks)
-        try:
-            C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-            nat().gemm(A, B, C, M, N, K, K, K, N, bias=bias, resid=R, ldr=N, drop=drop)
-            outs[ks] = C
-        finally:
-            nat().set_tunable(5, 0)
-    assert torch.equal((outs[1] == R), (outs[2] == R)) or float(((outs[1] == R) != (outs[2] == R)).float().mean()) < 1e-3
-    close(outs[2], outs[1], 1e-2, 4e-2, "K-split vs unsplit layout under dropout")
 
 
 @pytest.mark.parametrize("cfg", [1, 2, 3])

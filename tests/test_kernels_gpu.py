@@ -334,7 +334,7 @@ def test_attention_forward_backward(B, heads, S):
 def test_attention_one_round_forward_is_bit_identical_to_the_two_workgroup_form(B, heads, S, tail, p):
     """Round 3: head_dim 64 with more than 128 queries runs as ONE 8-wave workgroup per (batch, head) that computes the scores twice
     (row maxima, then exponentials) instead of holding them in 128 registers — two workgroups per CU, one round.  Same arithmetic in
-    the same order as the two-workgroups-per-head kernel (MMF_TUN_ATTN_FWD_OLD = 1): context (bf16 and fp32 copy) and log-sum-exp
+    the same order as the two-workgroups-per-head kernel (MMF_TUN_ALT_FORMS bit 1): context (bf16 and fp32 copy) and log-sum-exp
     bit for bit, with ragged masks, dropout and the prefix-LM tail."""
     H = heads * 64
     qkv = rnd(B * S, 3 * H, seed=21)
@@ -344,7 +344,7 @@ def test_attention_one_round_forward_is_bit_identical_to_the_two_workgroup_form(
     drop = nat().drop_cfg(p, 777) if p > 0 else nat().NO_DROP
     outs = {}
     for old in (1, 0):
-        nat().set_tunable(7, old)
+        nat().set_tunable(nat().TUN_ALT_FORMS, 2 * old)
         try:
             ctx = torch.full((B * S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
             c32 = torch.full((B * S, H), float("nan"), dtype=torch.float32, device=DEV)
@@ -353,7 +353,7 @@ def test_attention_one_round_forward_is_bit_identical_to_the_two_workgroup_form(
                                 causal_tail=tail)
             outs[old] = (ctx, c32, lse)
         finally:
-            nat().set_tunable(7, 0)
+            nat().set_tunable(nat().TUN_ALT_FORMS, 0)
     for a, b_ in zip(outs[0], outs[1]):
         assert torch.isfinite(a.float()).all()
         assert torch.equal(a, b_)
@@ -541,7 +541,7 @@ def test_attention_dropout_consistent_between_forward_and_backward():
                                                   (2, 2, 182, 182, 12, 0.1), (1, 1, 32, 32, 5, 0.0)])
 def test_attention_one_pass_backward_agrees_with_the_two_kernel_backward(B, heads, Sq, Sk, tail, p):
     """head_dim 64: the fused backward (one workgroup per (batch, head), dS transposed through LDS, dQ accumulated in LDS) against
-    the separate dQ and dK/dV kernels (MMF_TUN_ATTN_BWD_TWO_PASS): same dropout decisions, same masks (key mask, prefix-LM tail),
+    the separate dQ and dK/dV kernels (MMF_TUN_ALT_FORMS bit 2): same dropout decisions, same masks (key mask, prefix-LM tail),
     same gradients up to bf16 rounding of differently ordered sums; rectangular (cross-attention) shapes included."""
     H = heads * 64
     q = rnd(B * Sq, H, scale=1.0); kv = rnd(B * Sk, 2 * H, scale=1.0)
@@ -557,14 +557,14 @@ def test_attention_one_pass_backward_agrees_with_the_two_kernel_backward(B, head
     outs = {}
     try:
         for two_pass in (1, 0):
-            nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, two_pass)
+            nat().set_tunable(nat().TUN_ALT_FORMS, 4 * int(two_pass))
             for exact in (True, False):
                 dq = torch.full_like(q, 7.0); dkv = torch.full_like(kv, 7.0); delta = torch.empty(B, heads, Sq, device=DEV)
                 nat().attention_bwd(q, k, v, H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, 0.125, dctx, dq, dkv[:, :H], dkv[:, H:],
                                     delta, drop, ctx_f32=o32 if exact else None, causal_tail=tail)
                 outs[(two_pass, exact)] = (dq.float(), dkv.float())
     finally:
-        nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, 0)
+        nat().set_tunable(nat().TUN_ALT_FORMS, 0)
     for exact in (True, False):
         for name, a_, b_ in (("dq", outs[(0, exact)][0], outs[(1, exact)][0]), ("dk|dv", outs[(0, exact)][1], outs[(1, exact)][1])):
             assert torch.isfinite(a_).all()
@@ -690,7 +690,7 @@ def test_layernorm_forward_backward(rows, H):
 
 @pytest.mark.parametrize("H", [768, 1024])
 def test_layernorm_half_wave_kernels_agree_with_the_one_wave_per_row_kernels(H):
-    """H % 256 == 0 runs the half-wave-per-row, 16-byte kernels; MMF_TUN_LN_OLD selects the one-wave-per-row form.  Same maths:
+    """H % 256 == 0 runs the half-wave-per-row, 16-byte kernels; MMF_TUN_ALT_FORMS bit 0 selects the one-wave-per-row form.  Same maths:
     outputs equal up to fp32 summation order (bf16 outputs almost always identical), dropout masks identical."""
     rows = 3000
     x = rnd(rows, H, scale=2.0, seed=1); gamma = rnd(H, dtype=torch.float32, seed=2) + 1.0; beta = rnd(H, dtype=torch.float32, seed=3)
@@ -698,7 +698,7 @@ def test_layernorm_half_wave_kernels_agree_with_the_one_wave_per_row_kernels(H):
     drop = nat().drop_cfg(0.1, 77)
     res = []
     for old in (0, 1):
-        nat().set_tunable(nat().TUN_LN_OLD, old)
+        nat().set_tunable(nat().TUN_ALT_FORMS, old)
         try:
             y = torch.empty_like(x); mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
             nat().layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, H, 1e-12)
@@ -708,7 +708,7 @@ def test_layernorm_half_wave_kernels_agree_with_the_one_wave_per_row_kernels(H):
             nat().layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, dg, db, None, 0, ws, rows, H)
             res.append((y, mean, rstd, dx, dlin, dg, db))
         finally:
-            nat().set_tunable(nat().TUN_LN_OLD, 0)
+            nat().set_tunable(nat().TUN_ALT_FORMS, 0)
     for a, b, name in zip(res[0], res[1], ("y", "mean", "rstd", "dx", "dlin", "dgamma", "dbeta")):
         close(a, b, 1e-2 if a.dtype == torch.bfloat16 else 1e-5, 1e-2 if a.dtype == torch.bfloat16 else 1e-4 * float(b.abs().max()), name)
     assert torch.equal(res[0][4] == 0, res[1][4] == 0)      # same dropout mask
@@ -908,12 +908,12 @@ def test_layernorm_with_fused_dropout_is_bit_identical_to_two_launches(rows, H):
     ws = torch.empty(nat().layernorm_bwd_ws_floats(H), device=DEV)
     dx0 = torch.empty_like(x); dg0 = torch.empty(H, device=DEV); db0 = torch.empty(H, device=DEV)
     # (the fused form keeps ONE row in flight per half-wave — with two, the extra hash registers would cost the H = 768 kernel its second wave per SIMD —
-    # so the two-launch reference runs the same row schedule: MMF_TUN_LN_OLD = 2)
-    nat().set_tunable(nat().TUN_LN_OLD, 2)
+    # so the two-launch reference runs the same row schedule: MMF_TUN_ALT_FORMS bit 3)
+    nat().set_tunable(nat().TUN_ALT_FORMS, 8)
     try:
         nat().layernorm_bwd(d2, x, mean0, rstd0, gamma, dx0, None, nat().NO_DROP, dg0, db0, None, 0, ws, rows, H)
     finally:
-        nat().set_tunable(nat().TUN_LN_OLD, 0)
+        nat().set_tunable(nat().TUN_ALT_FORMS, 0)
     dxn = torch.empty_like(x); dgn = torch.empty(H, device=DEV); dbn = torch.empty(H, device=DEV)
     nat().layernorm_bwd(d2, x, mean0, rstd0, gamma, dxn, None, nat().NO_DROP, dgn, dbn, None, 0, ws, rows, H)      # the default (two-row) schedule
     close(dxn, dx0, 1e-2, 1e-3, "two-row vs one-row schedule dx"); close(dgn, dg0, 1e-5, 1e-3, "dgamma"); close(dbn, db0, 1e-5, 1e-3, "dbeta")
@@ -976,12 +976,12 @@ def test_rows_scatter_add_with_an_index_array_is_deterministic_and_atomic_free(B
         for r in torch.nonzero(flat == bucket).view(-1).tolist():
             acc = acc + rows[r]
         assert torch.equal(outs[0][bucket], base[bucket] + acc), bucket
-    nat().set_tunable(17, 1)                                   # MMF_TUN_SCATTER_ATOMIC: the fp32-atomic kernel
+    nat().set_tunable(nat().TUN_SCATTER_ATOMIC, 1)             # MMF_TUN_SCATTER_ATOMIC: the fp32-atomic kernel
     try:
         old = base.clone()
         nat().rows_scatter_add(d, H, B, T, S, ids, T, 0, 0, old, H, 0, 0)
     finally:
-        nat().set_tunable(17, 0)
+        nat().set_tunable(nat().TUN_SCATTER_ATOMIC, 0)
     close(outs[0], old, 1e-5, 1e-4 * math.sqrt(B * T), "owner-wave vs atomics")
 
 

@@ -363,42 +363,3 @@ def test_training_step_is_bit_reproducible_from_run_to_run():
     assert float(ma["model.bert.embeddings.word_embeddings.weight"].abs().sum()) > 0
 
 
-@pytest.mark.parametrize("mode", [True, "attention"])
-def test_optimizer_in_backward_equals_end_of_step_update(mode):
-    """`GraphedTrainStep(overlap_update="attention")` (round 3): the update of layer L runs on a second stream exactly beside the attention
-    backward of layer L - 1 (fork before that kernel, join behind it); `GraphedTrainStep(overlap_update=True)`: each encoder layer's AdamW update is launched on a second stream as soon as the layer's
-    weight gradients exist (a parallel branch of the hipGraph beside the backward of the layers below).  Same kernel, same
-    arithmetic: after 3 replays every parameter, moment, bf16 shadow and W^T twin equals the end-of-step update's BIT FOR BIT."""
-    from mmf_amd import functional as Fn
-    from mmf_amd.modules.optimizers import AdamW
-    from mmf_amd.utils.graph import GraphedTrainStep
-    z, case, cfg, sd, sample = load_case("small64")
-    batch = SampleList(sample_to(sample, "cuda"))
-    res = []
-    for overlap in (mode, False):
-        m = build_visual_bert(cfg, sd)
-        m.eval()
-        o = AdamW(m.get_optimizer_parameters(__import__("mmf_amd.utils.configuration", fromlist=["Config"]).Config(
-            model="visual_bert", optimizer=dict(params=dict(lr=1e-3)), model_config=dict(visual_bert=m.config))), lr=1e-3, capturable=True)
-        g = GraphedTrainStep(m, batch, warmup=1, optimizer=o, overlap_update=overlap)
-        assert (g.update_stream is not None) == bool(overlap)
-        losses = [float(g()) for _ in range(3)]
-        torch.cuda.synchronize()
-        att = m.model.bert.encoder.layer[1].attention.self
-        w16, b32 = att.packed_qkv()
-        twin = Fn.shadows.transposed(w16)
-        res.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()},
-                    {n: o.state[p]["exp_avg_sq"].clone() for n, p in m.named_parameters() if p in o.state and len(o.state[p])},
-                    w16.clone(), b32.clone(), None if twin is None else twin.clone(), float(o._dev_state[0])))
-        del g
-    (la, pa, va, wa, ba, ta, sa), (lb, pb, vb, wb, bb, tb, sb) = res
-    assert la == lb and sa == sb == 3.0
-    for n in pa:
-        assert torch.equal(pa[n], pb[n]), n
-    for n in va:
-        assert torch.equal(va[n], vb[n]), n
-    assert torch.equal(wa, wb) and torch.equal(ba, bb)
-    assert (ta is None) == (tb is None) and (ta is None or torch.equal(ta, tb))
-    # and the parameters did move
-    assert not torch.equal(pa["model.bert.encoder.layer.0.intermediate.dense.weight"].cpu(),
-                           sd["bert.encoder.layer.0.intermediate.dense.weight"])

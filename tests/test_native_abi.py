@@ -86,13 +86,14 @@ def test_library_is_not_older_than_its_sources():
 
 
 def test_tunables_round_trip_and_the_site_tags_stay_clear_of_the_other_flag_bits(built_lib):
-    """MMF_TUN_NT_SITE_KEEP (the per-call-site exception to the non-temporal epilogue stores) and MMF_TUN_GELU_WIDE default to 0 = the measured
-    round-3 behaviour; the site tag occupies bits 20..23 of mmf_gemm_desc::debug_flags, which no other switch reads."""
+    """MMF_TUN_NT_SITE_KEEP (the per-call-site exception to the non-temporal epilogue stores) and every other knob default to 0 = the measured
+    behaviour; seven knobs are left (round 6 removed the measurement switches whose losing branches are gone); the site tag occupies bits 20..23 of mmf_gemm_desc::debug_flags, which no other switch reads."""
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(_native.HEADER_PATH).read()
     count = int(re.search(r"MMF_TUN_COUNT = (\d+)", header).group(1))
     keep = int(re.search(r"MMF_TUN_NT_SITE_KEEP = (\d+)", header).group(1))
     assert 0 <= keep < count
+    assert len(re.findall(r"MMF_TUN_[A-Z_0-9]+ = \d+", header)) - 1 <= 8          # (MMF_TUN_COUNT itself is not a knob)
     for t in range(count):
         assert built_lib.mmf_amd_get_tunable(t) == 0, t                  # every knob defaults to the built-in behaviour
     try:

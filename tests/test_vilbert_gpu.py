@@ -61,7 +61,7 @@ def test_cross_attention_forward_backward(B, heads, Sq, Sk, d):
 def test_attention_d128_one_pass_backward_agrees_with_the_two_kernel_backward(B, heads, Sq, Sk, p):
     """Round 5: head_dim 128 with up to 128 queries / keys (the visual stream: 101 regions; co-attention: 128 tokens x 101 regions) runs the ONE-PASS
     backward too — four waves per (batch, head), every probability recomputed, dropped out and turned into dS once — against the separate dQ and
-    dK/dV kernels it replaces (MMF_TUN_ATTN_BWD_TWO_PASS): same dropout decisions, same masks, gradients equal up to bf16 rounding of differently
+    dK/dV kernels it replaces (MMF_TUN_ALT_FORMS bit 2): same dropout decisions, same masks, gradients equal up to bf16 rounding of differently
     ordered sums, no systematic difference; with and without the fp32 copy of O."""
     d = 128
     H = heads * d
@@ -78,14 +78,14 @@ def test_attention_d128_one_pass_backward_agrees_with_the_two_kernel_backward(B,
     outs = {}
     try:
         for two_pass in (1, 0):
-            nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, two_pass)
+            nat().set_tunable(nat().TUN_ALT_FORMS, 4 * int(two_pass))
             for exact in (True, False):
                 dq = torch.full_like(q, 7.0); dkv = torch.full_like(kv, 7.0); delta = torch.empty(B, heads, Sq, device=DEV)
                 nat().attention_bwd(q, k, v, H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, scale, dctx, dq, dkv[:, :H], dkv[:, H:],
                                     delta, drop, head_dim=d, ctx_f32=o32 if exact else None)
                 outs[(two_pass, exact)] = (dq.float(), dkv.float())
     finally:
-        nat().set_tunable(nat().TUN_ATTN_BWD_TWO_PASS, 0)
+        nat().set_tunable(nat().TUN_ALT_FORMS, 0)
     for exact in (True, False):
         for name, a_, b_ in (("dq", outs[(0, exact)][0], outs[(1, exact)][0]), ("dk|dv", outs[(0, exact)][1], outs[(1, exact)][1])):
             assert torch.isfinite(a_).all()

@@ -15,7 +15,7 @@ dqkv = torch.empty_like(qkv); delta = torch.empty(B, heads, S, device=dev)
 drop = nat.drop_cfg(0.1 if "nodrop" not in sys.argv else 0.0, 1234)
 c32 = torch.empty(B * S, H, device=dev) if "noctx32" not in sys.argv else None
 if "oldfwd" in sys.argv:
-    nat.set_tunable(7, 1)
+    nat.set_tunable(nat.TUN_ALT_FORMS, 2)
 sc = 1 / math.sqrt(64)
 def fwd(): nat.attention_fwd(qkv, qkv[:, H:], qkv[:, 2*H:], 3*H, 3*H, 3*H, mask, ctx, H, lse, B, heads, S, S, sc, drop, ctx_f32=c32)
 def bwd(): nat.attention_bwd(qkv, qkv[:, H:], qkv[:, 2*H:], 3*H, 3*H, 3*H, mask, ctx, H, lse, B, heads, S, S, sc, dctx, dqkv, dqkv[:, H:], dqkv[:, 2*H:], delta, drop, ctx_f32=c32)

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--two-pass", action="store_true", help="backward as the separate dQ and dK/dV kernels")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, int(args.two_pass))
+    nat.set_tunable(nat.TUN_ALT_FORMS, 4 * int(args.two_pass))
     B, A, S, D = args.B, 12, args.S, 64
     H = A * D
     g = torch.Generator(device=dev).manual_seed(0)

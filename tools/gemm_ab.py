@@ -3,7 +3,7 @@ correctness check of every variant against an fp32 torch product of the same bf1
 
     python tools/gemm_ab.py [--tun ID:V1,V2,...] [--rounds R] [--iters I] [shape-name-filter ...]
 
-Default: tunable MMF_TUN_GEMM_WIDE_KS (5) in {1, 2}.  Every (shape, variant) is timed `rounds` times, `iters` launches each, the
+Default: tunable MMF_TUN_GEMM_PERSIST (18) in {-1, 0}: the one-tile kernels against the persistent kernel where the rule takes it.  Every (shape, variant) is timed `rounds` times, `iters` launches each, the
 variants interleaved inside a round (cdna_hip_programming.md section 5.4 rule 24); the table prints median / min per variant."""
 import os
 import statistics
@@ -57,7 +57,7 @@ def make(name, N, K, kind, dev="cuda"):
 
 def main():
     args = sys.argv[1:]
-    tun, vals, rounds, iters, filt, fixed = 5, [1, 2], 7, 20, [], []
+    tun, vals, rounds, iters, filt, fixed = 18, [-1, 0], 7, 20, [], []
     i = 0
     while i < len(args):
         if args[i] == "--tun":

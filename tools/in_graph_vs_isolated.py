@@ -2,7 +2,7 @@
 the same gpurun call.  Inputs (written by `tools/make_profiles.sh TAG` + the two extra commands named in profiles/README.md):
 
     gpurun_out/profiles_TAG/graph/g_kernel_trace.csv     rocprofv3 --kernel-trace -- python tools/graph_gaps.py run
-    gpurun_out/profiles_TAG/gemm_isolated.log            python tools/gemm_ab.py --tun 0:0 --rounds 5
+    gpurun_out/profiles_TAG/gemm_isolated.log            python tools/gemm_ab.py --tun 18:0 --rounds 5
 
     python tools/in_graph_vs_isolated.py TAG > profiles/TAG_in_graph_vs_isolated.txt"""
 import csv
@@ -33,7 +33,7 @@ n = min(len(r) for r in reps)
 seq = [(short(reps[0][i][2]), statistics.median((r[i][1] - r[i][0]) / 1e3 for r in reps)) for i in range(n)]
 per = statistics.median((r[-1][1] - r[0][0]) / 1e3 for r in reps)
 print("# The replayed hipGraph of the training step, kernel by kernel (median over 9 replays), for one encoder layer forward and backward, beside the")
-print("# SAME kernels timed in isolation on warm operands in the same gpurun call (tools/gemm_ab.py --tun 0:0).  Replay period %.1f us, %d kernels." % (per, n))
+print("# SAME kernels timed in isolation on warm operands in the same gpurun call (tools/gemm_ab.py --tun 18:0).  Replay period %.1f us, %d kernels." % (per, n))
 iso = {}
 for l in open(base + "gemm_isolated.log"):
     m = re.match(r"(\w+)\s+N=\s*(\d+) K=\s*(\d+) \| v=0 (\S+ \S+)\s+med\s+([\d.]+) us", l)

@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 # the replayed hipGraph of the step kernel by kernel, the layer GEMMs in isolation on the same box, and the default bench line
 # (tools/graph_gaps.py report, tools/in_graph_vs_isolated.py and tools/collect_profiles.py turn these into profiles/$tag_*)
 (cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $OLDPWD/$out/graph -o g -- python $OLDPWD/tools/graph_gaps.py run) > $out/graph.log 2>&1
-python tools/gemm_ab.py --tun 0:0 --rounds 5 > $out/gemm_isolated.log 2>&1
+python tools/gemm_ab.py --tun 18:0 --rounds 5 > $out/gemm_isolated.log 2>&1
 python bench.py > $out/bench_line.json 2> $out/bench.err
 grep -h metric $out/trace.log | cut -c1-300
 ls $out/*

@@ -41,21 +41,14 @@ def ln_sweep():
     ws = torch.empty(nat.layernorm_bwd_ws_floats(H), device=dev)
     y = torch.empty_like(x)
     for old in (0, 2, 1):      # 0: half-wave kernels, two rows in flight; 2: the same, one row in flight; 1: the one-wave-per-row kernels
-        nat.set_tunable(nat.TUN_LN_OLD, old)
+        nat.set_tunable(nat.TUN_ALT_FORMS, {0: 0, 2: 8, 1: 1}[old])
         tf = timeit(lambda: nat.layernorm_fwd(x, gamma, gamma, y, mean, rstd, rows, H, 1e-12))
         t0 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat.NO_DROP, dg, db, None, False, ws, rows, H))
         t1 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, None, False, ws, rows, H))
         t2 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, dbias, False, ws, rows, H))
         print("%s kernels: fwd %5.1f us (%.2f TB/s)  bwd plain %5.1f  bwd+dropout %5.1f (%.2f TB/s incl. reduce)  +dbias %5.1f" % (
             {0: "half-wave-per-row", 2: "half-wave, 1 row  ", 1: "one-wave-per-row "}[old], tf, 4.0 * rows * H / tf / 1e6, t0, t1, 8.0 * rows * H / t1 / 1e6, t2), flush=True)
-    nat.set_tunable(nat.TUN_LN_OLD, 1)
-    for grid in (128, 192, 256, 384, 512):
-        nat.set_tunable(nat.TUN_LN_BWD_GRID, grid)
-        t0 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, nat.NO_DROP, dg, db, None, False, ws, rows, H))
-        t1 = timeit(lambda: nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, nat.drop_cfg(0.1, 5), dg, db, dbias, False, ws, rows, H))
-        print("ln_bwd grid %3d: plain %6.1f us   dropout+dbias %6.1f us (incl. reduce kernel)" % (grid, t0, t1), flush=True)
-    nat.set_tunable(nat.TUN_LN_BWD_GRID, 0)
-    nat.set_tunable(nat.TUN_LN_OLD, 0)
+    nat.set_tunable(nat.TUN_ALT_FORMS, 0)
 
 
 def attn_sweep():
@@ -74,9 +67,9 @@ def attn_sweep():
             bwd = lambda: nat.attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, A, S, S, 0.125, dctx, dqkv[:, :H],
                                             dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta, drop=drop, ctx_f32=o32)
             t_f = timeit(fwd)
-            nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, 0); t_1 = timeit(bwd)
-            nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, 1); t_2 = timeit(bwd)
-            nat.set_tunable(nat.TUN_ATTN_BWD_TWO_PASS, 0)
+            nat.set_tunable(nat.TUN_ALT_FORMS, 0); t_1 = timeit(bwd)
+            nat.set_tunable(nat.TUN_ALT_FORMS, 4); t_2 = timeit(bwd)
+            nat.set_tunable(nat.TUN_ALT_FORMS, 0)
             print("attention B=32 S=228 dropout %.1f fp32-ctx %-5s: fwd %6.1f us   bwd one-pass %6.1f us   bwd two-kernel %6.1f us"
                   % (p, o32 is not None, t_f, t_1, t_2), flush=True)
             if p:      # the forward hands its dropout decisions to the one-pass backward as a bit table (mmf_attn_desc.keep_bits)
@@ -85,23 +78,6 @@ def attn_sweep():
                 t_bk = timeit(lambda: nat.attention_bwd(q, k, v, 3 * H, 3 * H, 3 * H, mask, ctx, H, lse, B, A, S, S, 0.125, dctx, dqkv[:, :H],
                                                         dqkv[:, H:2 * H], dqkv[:, 2 * H:], delta, drop=drop, ctx_f32=o32, keep_bits=kb))
                 print("          ... with the keep-bit table      : fwd %6.1f us   bwd one-pass %6.1f us" % (t_fk, t_bk), flush=True)
-
-
-def wgrad_sweep():
-    Mtok = 7296
-    dev = "cuda"
-    for name, m, n in (("qkv", 2304, 768), ("out", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)):
-        A = torch.randn(Mtok, m, device=dev).bfloat16(); B = torch.randn(Mtok, n, device=dev).bfloat16()
-        C = torch.empty(m, n, device=dev, dtype=torch.float32)
-        fl = 2.0 * m * n * Mtok
-        for form, flag in (("k64", 0),):
-            line = []
-            for sp in (0, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14):
-                nat.set_tunable(nat.TUN_SPLITK_FORCE, sp)
-                us = timeit(lambda: nat.gemm(A, B, C, m, n, Mtok, m, n, n, a_kmajor=True, b_kmajor=True, debug_flags=flag))
-                line.append("%d:%.0f(%.0f)" % (sp, us, fl / us / 1e6))
-            print("wgrad %-4s %s  sp:us(TF) " % (name, form) + " ".join(line), flush=True)
-    nat.set_tunable(nat.TUN_SPLITK_FORCE, 0)
 
 
 ABLATIONS = (("default", 0), ("no-dma", 1 << 4), ("no-mfma", 2 << 4), ("no-epilogue", 8 << 4), ("dma-only", (2 | 8) << 4),
@@ -142,11 +118,9 @@ def gemm_variants(variants=(("default", 0), ("ksplit", 4096), ("no-ksplit", 8192
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ln", "wgrad"]
+    which = sys.argv[1:] or ["ln"]
     if "ln" in which:
         ln_sweep()
-    if "wgrad" in which:
-        wgrad_sweep()
     if "gemm" in which:
         gemm_variants()
     if "ablate" in which:

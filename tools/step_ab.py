@@ -55,12 +55,7 @@ def main():
     for s in settings:
         items = [x.split(":") for x in s.split(",")]
         kw = {}
-        if any(a == "ow" for a, _ in items):       # "ow:1": the grouped weight-gradient launches on a second stream (GraphedTrainStep overlap_wgrad)
-            kw["overlap_wgrad"] = True
-        if any(a == "ou" for a, _ in items):       # "ou:1|attention|wgrad": optimizer in backward (overlap_update)
-            v = [b for a, b in items if a == "ou"][0]
-            kw["overlap_update"] = True if v == "1" else v
-        kv = [(int(a), int(b)) for a, b in items if a not in ("ow", "ou")]
+        kv = [(int(a), int(b)) for a, b in items]
         for k, v in kv:
             nat.set_tunable(k, v)
         opt = registry.get_optimizer_class("adam_w")(model.get_optimizer_parameters(full), lr=5e-5, eps=1e-8, capturable=True)

@@ -468,7 +468,10 @@ def main():
         return GraphedDataParallelStep(model, batch, cuts, optimizer, warmup=2, sparse_rows=sparse_rows)
 
     def eager_step(optimizer=None):
-        model.zero_grad(set_to_none=True)
+        if optimizer is not None:
+            optimizer.zero_grad()                  # (the reference's loop: mmf/trainers/core/training_loop.py:209)
+        else:
+            model.zero_grad(set_to_none=True)
         out = model(batch)
         loss = sum(v.sum() for v in out["losses"].values())
         loss.backward()

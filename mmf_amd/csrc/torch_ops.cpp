@@ -227,7 +227,7 @@ public:
     }
 
     // W^T [in, out] (bf16) of the weight shadow w16 [out, in] when it is a whole tracked shadow with dims % 64 == 0
-    bool twins_on = [] { const char* e = std::getenv("MMF_AMD_DGRAD_NT"); return !(e && e[0] == '0'); }();   // (A/B switch, see functional.DGRAD_NT)
+    bool twins_on = true;      // (tests/test_dgrad_nt_gpu.py flips it through _shadow_set_twins: functional.DGRAD_NT)
     Tensor transposed(const Tensor& w16) {
         if (!twins_on || !w16.defined() || w16.dim() != 2) return Tensor();
         auto k = by_ptr_.find(w16.data_ptr());
@@ -1038,6 +1038,40 @@ std::tuple<int64_t, std::vector<Tensor>> svc_drop_next() {
     const uint32_t k = g_keys.next(seed);
     return {(int64_t)k, seed.defined() ? std::vector<Tensor>{seed} : std::vector<Tensor>{}};
 }
+// The fused AdamW launches of one optimizer step (mmf/modules/optimizers.py:8-17, transformers.AdamW): the descriptor of every launch is filled
+// here instead of field by field through ctypes (0.4 ms of host time per step for the 200 tensors of VisualBERT, plus one operator call per
+// parameter for its shadow slot), so MMF's own eager loop (training_loop.py:199-231) stays ahead of the GPU.  Mirrors (bf16 weight shadow or
+// packed fp32 bias slice) are looked up per parameter, with the version check of Shadows::slot.
+void svc_adamw_step(at::TensorList p, at::TensorList g, at::TensorList m, at::TensorList v, at::ArrayRef<double> lr, at::ArrayRef<double> wd,
+                    double beta1, double beta2, double eps, int64_t step, bool correct_bias, int64_t mode, double grad_scale,
+                    const c10::optional<Tensor>& norm_sq, double max_norm, const c10::optional<Tensor>& dev_state) {
+    const size_t n = p.size();
+    TORCH_CHECK(g.size() == n && m.size() == n && v.size() == n && lr.size() == n && wd.size() == n, "mmf_amd: adamw_step takes lists of one length");
+    for (size_t i0 = 0; i0 < n; i0 += MMF_MT_MAX) {
+        mmf_adamw_multi_desc d;
+        std::memset(&d, 0, sizeof(d));
+        d.n = (int)std::min<size_t>(MMF_MT_MAX, n - i0);
+        for (int i = 0; i < d.n; ++i) {
+            const Tensor &pp = p[i0 + i], &gg = g[i0 + i];
+            TORCH_CHECK(pp.scalar_type() == at::kFloat && pp.is_contiguous() && m[i0 + i].is_contiguous() && v[i0 + i].is_contiguous(),
+                        "mmf_amd: adamw_step wants contiguous fp32 parameters and moments");
+            TORCH_CHECK((gg.scalar_type() == at::kFloat || gg.scalar_type() == at::kBFloat16) && gg.is_contiguous() && gg.numel() == pp.numel(),
+                        "mmf_amd: adamw_step: gradients must be contiguous fp32 or bf16 with the parameter's element count");
+            if (gg.scalar_type() == at::kBFloat16) d.g_bf16_mask |= (uint64_t)1 << i;
+            d.p[i] = pp.data_ptr(); d.g[i] = gg.data_ptr(); d.m[i] = m[i0 + i].data_ptr(); d.v[i] = v[i0 + i].data_ptr();
+            const Tensor mirror = g_shadows.slot(pp);
+            if (mirror.defined()) (mirror.scalar_type() == at::kBFloat16 ? d.p16[i] : d.p32[i]) = mirror.data_ptr();
+            d.numel[i] = pp.numel(); d.lr[i] = (float)lr[i0 + i]; d.wd[i] = (float)wd[i0 + i];
+        }
+        d.beta1 = (float)beta1; d.beta2 = (float)beta2; d.eps = (float)eps;
+        d.step = (int)step; d.correct_bias = correct_bias ? 1 : 0; d.mode = (int)mode;
+        d.grad_scale = (float)grad_scale;
+        d.norm_sq = (norm_sq.has_value() && norm_sq->defined()) ? norm_sq->data_ptr<float>() : nullptr;
+        d.max_norm = (float)max_norm;
+        d.dev_state = (dev_state.has_value() && dev_state->defined()) ? dev_state->data_ptr<float>() : nullptr;
+        MMF_RC(mmf_adamw_multi(&d, sp()), "mmf_adamw_multi");
+    }
+}
 bool svc_ln_defer_set(bool on) { const bool old = g_ln_defer; g_ln_defer = on; return old; }
 void svc_ln_defer_flush() { ln_flush(); }
 int64_t svc_set_py_mode(int64_t mode) { const int64_t old = g_py_mode; g_py_mode = mode; return old; }
@@ -1084,6 +1118,8 @@ TORCH_LIBRARY(mmf_amd, m) {
     m.def("_shadow_slot(Tensor p) -> Tensor[]");
     m.def("_shadow_transposed(Tensor w16) -> Tensor[]");
     m.def("_shadow_clear() -> ()");
+    m.def("_adamw_step(Tensor[] p, Tensor[] g, Tensor[] m, Tensor[] v, float[] lr, float[] wd, float beta1, float beta2, float eps, int step, "
+          "bool correct_bias, int mode, float grad_scale, Tensor? norm_sq, float max_norm, Tensor? dev_state) -> ()");
     m.def("_shadow_set_twins(bool on) -> bool");
     m.def("_shadow_refresh_transposed(Tensor[] only, bool has_only, Tensor[] skip, bool has_skip) -> ()");
     m.def("_drop_graph_mode(Tensor? seed) -> ()");
@@ -1112,6 +1148,7 @@ TORCH_LIBRARY_IMPL(mmf_amd, CompositeImplicitAutograd, m) {
     m.impl("_shadow_slot", svc_shadow_slot);
     m.impl("_shadow_transposed", svc_shadow_transposed);
     m.impl("_shadow_clear", svc_shadow_clear);
+    m.impl("_adamw_step", svc_adamw_step);
     m.impl("_shadow_set_twins", svc_shadow_set_twins);
     m.impl("_shadow_refresh_transposed", svc_shadow_refresh_transposed);
     m.impl("_drop_graph_mode", svc_drop_graph_mode);

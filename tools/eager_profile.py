@@ -35,7 +35,7 @@ def main():
 
     def step(acc=True):
         t = [time.perf_counter()]
-        model.zero_grad(set_to_none=True); t.append(time.perf_counter())
+        opt.zero_grad(); t.append(time.perf_counter())
         out = model(batch); t.append(time.perf_counter())
         loss = sum(v.sum() for v in out["losses"].values()); t.append(time.perf_counter())
         loss.backward(); t.append(time.perf_counter())

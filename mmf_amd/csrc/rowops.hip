@@ -602,54 +602,49 @@ __global__ __launch_bounds__(256) void scatter_add_direct_kernel(const bf16* __r
     }
 }
 
-// The same without atomics, deterministic (round 5): one workgroup per source row r = (b, i).  It stages the index array in LDS, counts the rows that share
-// its bucket (ballot + popcount, a quarter of the array per wave) and leaves unless r is the FIRST row of the bucket ("owner"); the owner goes on through
-// the rows behind it, adds every row of the same bucket in increasing row order and writes out[bucket] once.  No two workgroups write the same output
-// row, the order of the additions is fixed: the word-embedding gradient (the one atomically accumulated tensor of the VisualBERT step) is bit-reproducible,
-// and 4096 rows x 768 columns take ~12 us instead of 46 us of fp32 atomics.  O(rows^2 / 64) index comparisons in total (262144 wave steps at 4096 rows):
-// used up to SCATTER_UNIQUE_MAX rows, the atomic form beyond.
+// The same without atomics on the hot path, deterministic (round 5): one workgroup per source row r = (b, i).  Its waves count the EARLIER rows that share
+// its bucket (ballot + popcount over [0, r), a quarter each); the first row of a bucket ("owner") goes on through the rows behind it, adds the rows of the
+// bucket in increasing row order and adds the sum to out[bucket] once.  The order of the additions is fixed: the word-embedding gradient (the one
+// atomically accumulated tensor of the VisualBERT step) is bit-reproducible, and 4096 rows x 768 columns take ~12 us instead of 46 us of fp32 atomics.
+// O(rows^2 / 64) index comparisons in total (262144 wave steps at 4096 rows): used up to SCATTER_UNIQUE_MAX rows, the atomic form beyond.
 // Round 6 - bounded runs: an owner walks its run serially (four rows per dependent step), so ONE id on a quarter of the rows made the launch 270 us
-// against 162 us of atomics (M4C's previous-prediction gather: ~1000 of 1536 rows carry index 0; MLM batches with a frequent token).  Every workgroup
-// now knows its bucket's multiplicity: a bucket with more than SCATTER_RUN_MAX rows is added with fp32 atomics by ALL of its rows in parallel (the order
-// inside such a bucket is then the hardware's; every other bucket stays bit-reproducible).
+// against 162 us of atomics (M4C's previous-prediction gather: ~1000 of 1536 rows carry index 0; MLM batches with a frequent token).  The owner now
+// stops after SCATTER_RUN_MAX rows of its bucket; every later row of the bucket (it knows: it counted SCATTER_RUN_MAX earlier ones) adds itself with
+// fp32 atomics, in parallel.  An owner that stopped at the limit adds its sum atomically as well (tail rows may be writing); one that walked its whole
+// bucket writes it plainly: buckets of fewer than SCATTER_RUN_MAX rows stay bit-reproducible and atomic-free.
 constexpr int SCATTER_UNIQUE_MAX = 16384;
 constexpr int SCATTER_RUN_MAX = 64;
 __global__ __launch_bounds__(256) void scatter_add_unique_kernel(const bf16* __restrict__ x, int ld, int nb, int rpb, int bstride,
                                                                   const int64_t* __restrict__ idx, int idx_ld, float* __restrict__ out, int H, int skip,
                                                                   int nbuckets) {
-    extern __shared__ int sb[];      // the bucket of every source row (rows are numbered b * rpb + i), staged once per workgroup
+    extern __shared__ int sb[];      // the bucket of every source row behind r (rows are numbered b * rpb + i): staged once per owner workgroup — scanned from
+                                     // global memory the dependent steps of a wave cost a cache round trip each (48 us per launch, no better than the atomics)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nb * rpb;
     const int r = blockIdx.x;                 // one WORKGROUP per source row: its four waves share the scan and take a quarter of the columns each
     const int bk = [&]() { const int qb = r / rpb; const int64_t v = idx[(size_t)qb * idx_ld + (r - qb * rpb)]; return (v < 0 || v > 0x7ffffffe) ? -2 : (int)v; }();
     if (bk == skip) return;
     if (bk < 0 || (nbuckets > 0 && bk >= nbuckets)) { if (threadIdx.x == 0) flag_index_error(); return; }
-    __shared__ int cnt[2];                    // rows of this bucket before r / behind r
-    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
-    for (int q = threadIdx.x; q < total; q += 256) {
-        const int qb = q / rpb;
-        const int64_t v = idx[(size_t)qb * idx_ld + (q - qb * rpb)];
-        sb[q] = (v < 0 || v > 0x7ffffffe) ? -2 : (int)v;
-    }
+    // earlier rows with this bucket (every wave checks the rows [0, r) a quarter each; the count is shared through LDS and saturates at SCATTER_RUN_MAX)
+    __shared__ int n_before_s;
+    if (threadIdx.x == 0) n_before_s = 0;
     __syncthreads();
     {
-        int before = 0, behind = 0;
-        for (int q0 = wave * 64; q0 < total; q0 += 256) {
+        int mine = 0;
+        for (int q0 = wave * 64; q0 < r; q0 += 256) {
             const int q = q0 + lane;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(q < total && sb[q] == bk);
-            const int rel = r - q0;           // rows q0 .. q0 + 63 against r
-            const unsigned long long lo = rel <= 0 ? 0ull : (rel >= 64 ? ~0ull : ((1ull << rel) - 1ull));          // rows before r
-            const unsigned long long hi = rel < 0 ? ~0ull : (rel >= 63 ? 0ull : ~((2ull << rel) - 1ull));           // rows behind r
-            before += __builtin_popcountll(m & lo);
-            behind += __builtin_popcountll(m & hi);
+            bool hit = false;
+            if (q < r) { const int qb = q / rpb; hit = idx[(size_t)qb * idx_ld + (q - qb * rpb)] == (int64_t)bk; }
+            mine += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+            if (mine >= SCATTER_RUN_MAX) break;
         }
-        if (lane == 0) { atomicAdd(&cnt[0], before); atomicAdd(&cnt[1], behind); }
+        if (lane == 0 && mine) atomicAdd(&n_before_s, mine);
     }
     __syncthreads();
-    const int n_before = cnt[0], n_behind = cnt[1];
+    const int n_before = n_before_s;
     const int wq = H >> 2;                    // columns per wave (a multiple of 4)
     const int b = r / rpb, i = r - b * rpb;
-    if (n_before + 1 + n_behind > SCATTER_RUN_MAX) {       // a long run: all of its rows add themselves, in parallel
+    if (n_before >= SCATTER_RUN_MAX) {        // the tail of a long run: this row adds itself
         for (int c0 = 0; c0 < wq; c0 += 256) {
             const int col = wave * wq + c0 + 4 * lane;
             if (c0 + 4 * lane < wq) {
@@ -662,24 +657,31 @@ __global__ __launch_bounds__(256) void scatter_add_unique_kernel(const bf16* __r
         return;
     }
     if (n_before) return;                     // an earlier row owns the bucket
-    // owner: every wave adds its quarter of the columns of this row and of every later row of the bucket, in row order
+    // owner: stage the buckets of the rows behind this one, then every wave adds its quarter of the columns of this row and of the next (up to)
+    // SCATTER_RUN_MAX - 1 rows of the bucket, in row order
     const int rest = total - (r + 1);
-    const int* sbr = sb + r + 1;
+    for (int q = threadIdx.x; q < rest; q += 256) {
+        const int qq = r + 1 + q, qb = qq / rpb;
+        const int64_t v = idx[(size_t)qb * idx_ld + (qq - qb * rpb)];
+        sb[q] = (v < 0 || v > 0x7ffffffe) ? -2 : (int)v;
+    }
+    __syncthreads();
     for (int c0 = 0; c0 < wq; c0 += 256) {
         const int col = wave * wq + c0 + 4 * lane;
         const bool on = c0 + 4 * lane < wq;
         f32x4 acc = on ? load4(x + ((size_t)b * bstride + i) * ld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int q0 = 0; q0 < rest; q0 += 64) {
+        int taken = 1;                        // rows of the bucket added so far (this one included)
+        for (int q0 = 0; q0 < rest && taken < SCATTER_RUN_MAX; q0 += 64) {
             const int q = q0 + lane;
-            unsigned long long m = __builtin_amdgcn_ballot_w64(q < rest && sbr[q] == bk);
+            unsigned long long m = __builtin_amdgcn_ballot_w64(q < rest && sb[q] == bk);
             constexpr int RF = 4;
-            while (m) {      // up to four rows of the run in flight, added in row order (more in flight measured no faster)
+            while (m && taken < SCATTER_RUN_MAX) {      // up to four rows of the run in flight, added in row order (more in flight measured no faster)
                 const bf16* src[RF];
                 int n = 0;
 #pragma unroll
                 for (int u = 0; u < RF; ++u) {
                     src[u] = x;
-                    if (m) {
+                    if (m && taken + u < SCATTER_RUN_MAX) {
                         const int j = __builtin_ctzll(m);
                         m &= m - 1;
                         const int qq = r + 1 + q0 + j, qb = qq / rpb, qi = qq - qb * rpb;
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(256) void scatter_add_unique_kernel(const bf16* __r
                         n = u + 1;
                     }
                 }
+                taken += n;
                 f32x4 v[RF];
 #pragma unroll
                 for (int u = 0; u < RF; ++u) v[u] = (u < n && on) ? load4(src[u] + col) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -697,8 +700,13 @@ __global__ __launch_bounds__(256) void scatter_add_unique_kernel(const bf16* __r
         }
         if (on) {
             float* o = out + (size_t)bk * H + col;
-            const f32x4 old = load4(o);
-            *reinterpret_cast<float4*>(o) = make_float4(old[0] + acc[0], old[1] + acc[1], old[2] + acc[2], old[3] + acc[3]);
+            if (taken < SCATTER_RUN_MAX) {      // the whole bucket was walked: nobody else writes this row
+                const f32x4 old = load4(o);
+                *reinterpret_cast<float4*>(o) = make_float4(old[0] + acc[0], old[1] + acc[1], old[2] + acc[2], old[3] + acc[3]);
+            } else {                            // a longer run: its tail rows add themselves concurrently
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(o + j, acc[j]);
+            }
         }
     }
 }

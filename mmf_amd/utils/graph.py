@@ -215,11 +215,11 @@ class GraphedDataParallelStep:
     """The training step of ONE data-parallel rank as a short chain of hipGraphs with the gradient all-reduces between them
     (collective C1 of SURVEY.md section 2.3; the reference wraps the model in DistributedDataParallel, mmf/trainers/core/device.py:104-110):
 
-        F (forward + loss) | B_0 | B_1 | O_0 | B_2 | O_1 | ... | B_n | O_(n-1) | O_n      (B_j: backward stage, cut at the outputs of `cuts`;
-                             `-> all-reduce of stage 0's gradients on the             O_j: AdamW of the parameters of stage j)
-                                 communicator's stream, while B_1 replays, ...
+        [F B_0] | [B_1] | [O_0 B_2] | [O_1 B_3] | ... | [O_(n-2) O_(n-1)]         (F: forward + loss; B_j: backward stage j, cut at the outputs of
+           `-> all-reduce of stage 0's gradients on the communicator's stream,      `cuts`; O_j: AdamW of the parameters of stage j; [..]: ONE hipGraph)
+               while [B_1] replays; [O_0 B_2] waits for it, ...
 
-    so the host enqueues ~2n + 4 operations per step instead of ~450 kernels (the eager N > 1 step is host-bound: bench.py's
+    so the host enqueues n + 1 graph launches and the collectives per step instead of ~450 kernels (the eager N > 1 step is host-bound: bench.py's
     "eager" leg) and the collectives themselves stay outside the graphs (RCCL launched eagerly between replays — nothing
     depends on collective-in-graph support).  `cuts` are modules whose output tensor splits the network (e.g. three encoder
     layers): the forward hands the next module a detached copy, which makes each segment its own autograd graph; stage j of
@@ -293,30 +293,47 @@ class GraphedDataParallelStep:
             self._layout(fp32_ids, dev)
             # capture_error_mode="thread_local": the communicator's watchdog thread polls events while we capture
             pool = torch.cuda.graph_pool_handle()
-            self.g_fwd = torch.cuda.CUDAGraph()
-            self.g_bwd = [torch.cuda.CUDAGraph() for _ in self.stage_params]
-            self.g_opt = [torch.cuda.CUDAGraph() for _ in self.stage_params]
+            # Round 6: FIVE graph launches per step for four stages instead of nine.  The forward rides with backward stage 0 (no collective lies
+            # between them), the update of stage j - 2 rides at the head of backward stage j (that is where it sat in stream order already: behind
+            # stage j - 1, whose replay covers all-reduce j - 2), the last two updates share the tail graph:
+            #     [F B_0] ar_0^ [B_1] ar_1^ (ar_0) [O_0 B_2] ar_2^ (ar_1) [O_1 B_3] ar_3^ (ar_2, ar_3) [O_2 O_3]
+            # A graph launch costs ~12 us of host time and leaves a ~40 us hole on the GPU: the chain at N = 1 ran 0.44 ms behind the single graph.
+            n = len(self.stage_params)
+            self.g_bwd = [torch.cuda.CUDAGraph() for _ in range(n)]       # graph k holds backward stage k (k = 0: the forward too; k >= 2: update k - 2 first)
+            self.g_tail = torch.cuda.CUDAGraph()                          # updates n - 2 and n - 1
+
+            def stage_ids(j):
+                return {id(p) for p in self.buckets[j]["p16"]} | {id(p) for p in self.buckets[j]["p32"]} | {id(sp.p) for sp in self.sparse if sp.stage == j}
+
+            first_update = [True]
+
+            def update(j):       # captured: the ranks' touched rows -> the summed dense gradient, then the fused AdamW of stage j's parameters
+                ids = stage_ids(j)
+                if not ids and j > 0:
+                    return           # (a stage without parameters of its own: nothing to update)
+                optimizer.external_grads = self._wire_views()
+                for sp in self.sparse:
+                    if sp.stage == j:
+                        sp.merge()
+                optimizer.step(only=ids, advance=first_update[0])      # only the first update of a step advances the step count / schedule
+                first_update[0] = False
+
             with Fn.dropout_keys.graph_mode(self.seed):
-                with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):
-                    self.out, self.loss = self._forward()
                 carry = None
                 self._keep = []
                 for j, g in enumerate(self.g_bwd):
                     with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                        if j == 0:
+                            self.out, self.loss = self._forward()
+                        if j >= 2:
+                            update(j - 2)
                         grads, carry = self._stage_grads(j, carry, self.stage_params[j])
                         self._pack(j, grads)
                     self._keep.append((grads, carry))
-                optimizer.external_grads = self._wire_views()
-                for j, g in enumerate(self.g_opt):       # one update graph per stage; only the first advances the step count / schedule
-                    ids = {id(p) for p in self.buckets[j]["p16"]} | {id(p) for p in self.buckets[j]["p32"]} | {id(sp.p) for sp in self.sparse if sp.stage == j}
-                    if not ids and j > 0:
-                        self.g_opt[j] = None                 # (a stage without parameters of its own: nothing to update)
-                        continue
-                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                        for sp in self.sparse:
-                            if sp.stage == j:
-                                sp.merge()                   # the ranks' touched rows -> the summed dense gradient the update reads
-                        optimizer.step(only=ids, advance=(j == 0))
+                with torch.cuda.graph(self.g_tail, pool=pool, capture_error_mode="thread_local"):
+                    if n >= 2:
+                        update(n - 2)
+                    update(n - 1)
         finally:
             for h in handles:
                 h.remove()
@@ -473,11 +490,13 @@ class GraphedDataParallelStep:
     def __call__(self, batch=None):
         if batch is not None:
             _copy_batch(self.static_batch, batch)
-        self.g_fwd.replay()
-        prev = None          # collectives of the previous stage: waited for (and its update replayed) after the next stage is enqueued
         self._calls = getattr(self, "_calls", 0) + 1
         check = _SPARSE_CHECK > 0 and self._calls % _SPARSE_CHECK == 0
+        pending = []         # pending[j]: the collectives of backward stage j
         for j, g in enumerate(self.g_bwd):
+            if j >= 2:       # graph j opens with the update of stage j - 2: its gradients must have been summed
+                for w in pending[j - 2]:
+                    w.wait()
             g.replay()
             if check:
                 for sp in self.sparse:
@@ -492,14 +511,9 @@ class GraphedDataParallelStep:
                 for sp in self.sparse:
                     if sp.stage == j:
                         works += sp.exchange()
-            if prev is not None:
-                for w in prev:
-                    w.wait()
-                if self.g_opt[j - 1] is not None:
-                    self.g_opt[j - 1].replay()
-            prev = works
-        for w in prev:
-            w.wait()
-        if self.g_opt[-1] is not None:
-            self.g_opt[-1].replay()
+            pending.append(works)
+        for ws in pending[-2:]:
+            for w in ws:
+                w.wait()
+        self.g_tail.replay()
         return self.loss

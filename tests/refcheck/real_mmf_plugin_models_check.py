@@ -80,11 +80,11 @@ def configs():
     mc["model_data_dir"] = DATA
     mc["modal_encoder"]["params"]["model_data_dir"] = DATA          # ${model_config.mmbt.model_data_dir}
     out["mmbt"] = ("hateful_memes", mc)
-    out["uniter"] = ("vqa2", model_yaml("uniter", "mmf/configs/models/uniter/defaults.yaml"))
+    out["uniter"] = ("vqa2", model_yaml("uniter", "mmf/configs/models/uniter/defaults.yaml", "projects/uniter/configs/vqa2/defaults.yaml"))      # (the project file holds `losses`: with the bare defaults the reference itself has no loss for vqa2)
     mc = model_yaml("m4c", "mmf/configs/models/m4c/defaults.yaml", "projects/m4c/configs/textvqa/defaults.yaml")
     mc["model_data_dir"] = DATA                                       # ${env.data_dir}
     out["m4c"] = ("textvqa", mc)
-    mc = model_yaml("mmf_transformer", "mmf/configs/models/mmf_transformer/defaults.yaml", "projects/hateful_memes/configs/mmf_transformer/defaults.yaml")
+    mc = model_yaml("mmf_transformer", "mmf/configs/models/mmf_transformer/defaults.yaml", "projects/mmf_transformer/configs/hateful_memes/defaults.yaml")      # (what projects/hateful_memes/configs/mmf_transformer/defaults.yaml includes)
     for h in mc["heads"]:
         if isinstance(h.get("num_labels"), str):
             h["num_labels"] = mc["num_labels"]                         # ${model_config.mmf_transformer.num_labels}
@@ -168,6 +168,65 @@ def shapes_of(model):
     return {k: list(v.shape) for k, v in model.state_dict().items() if not k.endswith(SKIP)}
 
 
+def real_sample(name, B=2):
+    """A batch of the REAL `mmf.common.sample.SampleList` holding what the model's dataset hands it (shapes of the BASELINE configurations)."""
+    import torch
+    sample_mod = refshim.ref_import("mmf.common.sample")
+    g = torch.Generator().manual_seed(7)
+    sl = sample_mod.SampleList()
+
+    def text(T=128):
+        ids = torch.randint(1000, 28000, (B, T), generator=g)      # (UNITER's VQA2 project uses bert-base-cased: 28996 ids)
+        ids[:, 0] = 101
+        sl.add_field("input_ids", ids)
+        sl.add_field("input_mask", torch.ones(B, T, dtype=torch.long))
+        sl.add_field("segment_ids", torch.zeros(B, T, dtype=torch.long))
+
+    if name == "vilbert":
+        text()
+        sl.add_field("image_feature_0", torch.rand(B, 100, 2048, generator=g))
+        sl.add_field("image_info_0", {"max_features": torch.full((B,), 100, dtype=torch.long), "bbox": torch.rand(B, 100, 5, generator=g)})
+        sl.add_field("targets", torch.zeros(B, 3129))
+        sl.dataset_name, sl.dataset_type = "vqa2", "train"
+    elif name == "mmbt":
+        text()
+        sl.add_field("image_feature_0", torch.rand(B, 100, 2048, generator=g))
+        sl.add_field("targets", torch.randint(0, 2, (B,), generator=g))
+        sl.dataset_name, sl.dataset_type = "hateful_memes", "train"
+    elif name == "uniter":
+        text()
+        xy = torch.rand(B, 100, 4, generator=g) * 0.45
+        box = torch.stack([xy[..., 0], xy[..., 1], xy[..., 0] + xy[..., 2] + 0.05, xy[..., 1] + xy[..., 3] + 0.05], dim=-1)
+        sl.add_field("image_feature_0", torch.rand(B, 100, 2048, generator=g))
+        sl.add_field("image_info_0", {"max_features": torch.full((B,), 100, dtype=torch.long), "bbox": box,
+                                      "image_width": torch.full((B,), 640), "image_height": torch.full((B,), 480)})
+        sl.add_field("targets", torch.zeros(B, 3129))
+        sl.dataset_name, sl.dataset_type = "vqa2", "train"
+    elif name == "mmf_transformer":
+        text()
+        sl.add_field("image", torch.rand(B, 100, 2048, generator=g))
+        sl.add_field("image_mask", torch.ones(B, 100, dtype=torch.long))
+        sl.add_field("targets", torch.randint(0, 2, (B,), generator=g))
+        sl.dataset_name, sl.dataset_type = "hateful_memes", "train"
+    elif name == "m4c":
+        sl.add_field("text", torch.randint(1000, 30000, (B, 20), generator=g))
+        sl.add_field("text_len", torch.randint(5, 21, (B,), generator=g))
+        sl.add_field("image_feature_0", torch.rand(B, 100, 2048, generator=g))
+        sl.add_field("obj_bbox_coordinates", torch.rand(B, 100, 4, generator=g))
+        sl.add_field("image_info_0", {"max_features": torch.full((B,), 100, dtype=torch.long)})
+        sl.add_field("context_feature_0", torch.randn(B, 50, 300, generator=g))
+        sl.add_field("context_feature_1", torch.rand(B, 50, 604, generator=g))
+        sl.add_field("image_feature_1", torch.rand(B, 100, 2048, generator=g))
+        sl.add_field("ocr_bbox_coordinates", torch.rand(B, 50, 4, generator=g))
+        sl.add_field("context_info_0", {"max_features": torch.randint(5, 51, (B,), generator=g)})
+        sl.add_field("order_vectors", torch.zeros(B, 50, 50))
+        sl.add_field("train_prev_inds", torch.randint(0, 5050, (B, 12), generator=g))
+        sl.add_field("targets", (torch.rand(B, 12, 5050, generator=g) > 0.999).float())
+        sl.add_field("train_loss_mask", (torch.rand(B, 12, generator=g) > 0.3).float())
+        sl.dataset_name, sl.dataset_type = "textvqa", "train"
+    return sl
+
+
 def main():
     environment()
     registry = refshim.ref_import("mmf.common.registry").registry
@@ -217,6 +276,24 @@ def main():
         r["eval_propagates"] = not m._inner[0].training
         m.train()
         r["train_propagates"] = bool(m._inner[0].training)
+        # the adapter's forward + backward under the REAL BaseModel.__call__ with the REAL SampleList (round 6; round 5 did this for VisualBERT only).
+        # Every kernel launch is its extent / dtype checker on this CPU-only box (tests/native_stub.py): plumbing, not numbers.
+        try:
+            from tests import native_stub
+            sl = real_sample(name)
+            with native_stub.installed() as calls:
+                res = m(sl)
+                losses = res["losses"]
+                loss = sum(v.sum() for v in losses.values())
+                loss.backward()
+            r["call_scores_shape"] = list(res["scores"].shape) if "scores" in res else None
+            r["call_loss_keys"] = sorted(losses.keys())
+            r["call_launched"] = sorted({c[0] for c in calls})[:60]
+            r["call_grads"] = sum(1 for p_ in m.parameters() if p_.grad is not None)
+            r["call_params"] = sum(1 for p_ in m.parameters() if p_.requires_grad)
+        except Exception as e:
+            import traceback
+            r["call_error"] = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc()[-1200:])
         out[name] = r
         del m
     print("RESULT " + json.dumps(out))

@@ -86,3 +86,20 @@ def test_the_other_adapters_build_through_the_real_build_model(models_result, na
     assert r["eval_propagates"] and r["train_propagates"]
     if name != "uniter":          # (UNITER defers its losses to the per-task heads: uniter.py:640-660)
         assert r["losses_type"] == "mmf.modules.losses.Losses"
+
+
+@pytest.mark.parametrize("name,scores,loss_key,min_grads", [
+    ("vilbert", [2, 3129], "train/vqa2/logit_bce", 500), ("mmbt", [2, 2], "train/hateful_memes/cross_entropy", 209),
+    ("uniter", [2, 3129], "train/vqa2/logit_bce", 216), ("m4c", [2, 12, 5050], "train/textvqa/m4c_decoding_bce_with_mask", 151),
+    ("mmf_transformer", [2, 2], "train/hateful_memes/cross_entropy", 212)])
+def test_the_other_adapters_forward_and_backward_under_the_real_basemodel_call(models_result, name, scores, loss_key, min_grads):
+    """Round 6 ("the other five are constructed and key-checked, never called"): each adapter's `forward` under the REAL
+    `BaseModel.__call__` (mmf/models/base_model.py:305-337) with a REAL `mmf.common.sample.SampleList` of its BASELINE shapes, built from its real
+    YAMLs: MMF's own `Losses` (UNITER: its per-task `MMFLoss`, mmf/models/uniter.py:333-343) key the loss as the reference does, and the backward
+    reaches the trainable parameters (the poolers the reference computes and drops, mmf/models/vilbert.py:1322, stay without gradient).  Kernel
+    launches are extent / dtype checkers on this CPU-only box (tests/native_stub.py): plumbing, not numbers - those are the `-m gpu` tests' job."""
+    r = models_result[name]
+    assert "call_error" not in r, r.get("call_error")
+    assert r["call_scores_shape"] == scores and r["call_loss_keys"] == [loss_key]
+    assert r["call_grads"] >= min_grads and r["call_grads"] >= 0.95 * r["call_params"]
+    assert {"gemm", "attention_fwd", "attention_bwd", "layernorm_fwd"} <= set(r["call_launched"]) or len(r["call_launched"]) == 60

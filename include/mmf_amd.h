@@ -34,7 +34,9 @@ enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 
        MMF_TUN_ALT_FORMS = 3,      /* cross-check hooks (tests compare kernel forms that serve different shapes in production): bit 0 LayerNorm with the one-wave-per-row
                                       kernels even when H % 256 == 0; bit 1 head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head; bit 2
                                       attention backward as the separate dQ and dK/dV kernels where the one-pass kernel would run (and no keep-bit table); bit 3
-                                      LayerNorm backward with one row in flight per half-wave */
+                                      LayerNorm backward with one row in flight per half-wave; bit 4 the operator library draws the attention-dropout decisions of a graphed
+                                      step outside the attention kernels, one step ahead beside the AdamW launches (mmf_attention_draw_keep_bits; same decisions
+                                      bit for bit, measured +0.11 ms per step: opt-in); bits 4 + 5 the same at the step's own head beside the embedding stage */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
        MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
                                       kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B) */
@@ -204,8 +206,31 @@ typedef struct mmf_attn_desc {
                               profiles/r05_experiments.txt).  Same decisions, bit for bit.  mmf_attention_keep_bits_words(...) 32-bit words, 0 = this
                               shape's kernels do not take a table (pass NULL).  Word ((bh * nqt + qt) * nkt + kt) * 32 + j, bit x = keep(query 32 qt + x,
                               key 32 kt + j); nqt = ceil(Sq / 32), nkt = ceil(Sk / 32). */
+    const uint32_t* keep_lanes; /* optional, NULL = off (forward only).  The decisions were drawn AHEAD of this call by mmf_attention_draw_keep_bits with the same
+                              (drop_key, drop_seed, drop_thr16, shape): the forward reads them in its own lane order — a 16-bit field per key tile, one 16-byte
+                              load per lane — instead of hashing (8 of the forward's 31 us at the VQA2 shape), and does not write `keep_bits` (the same
+                              launch drew that table too; hand it to the backward as before).  Same decisions, same outputs, bit for bit.
+                              mmf_attention_keep_lanes_words(...) 32-bit words, 16-byte aligned. */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
+/* The probability-dropout decisions of up to any number of attention sites in ONE launch, ahead of the kernels that use them (they
+ * depend on (key, seed word, element index) only, never on the scores — hf_layers.py:196-200 draws them with nn.Dropout after the softmax).  Writes, per
+ * site, the key-major table `keep_bits` (what the forward would have written) and the lane-major `keep_lanes` the forward then reads.  A training step
+ * issues it once at its head on a side stream (a parallel branch of the step's hipGraph beside the embedding stage). */
+#define MMF_ATTN_DRAW_MAX 48
+typedef struct mmf_attn_draw_site {
+    uint32_t drop_key, drop_thr16;
+    const uint32_t* drop_seed;
+    int B, heads, Sq, Sk, head_dim;
+    uint32_t* keep_bits;    /* [mmf_attention_keep_bits_words] */
+    uint32_t* keep_lanes;   /* [mmf_attention_keep_lanes_words], 16-byte aligned */
+} mmf_attn_draw_site;
+/* seed_offset is added to every site's seed word before it enters the key: 0 = the decisions a forward launched NOW would draw; 1 = those of the next
+ * step of a graphed loop, whose head (mmf_step_advance) adds one to the word — a step can draw its successor's decisions on a side stream beside its own
+ * HBM-bound AdamW launches (MMF_TUN_ALT_FORMS bit 4). */
+int mmf_attention_draw_keep_bits(const mmf_attn_draw_site* sites, int n, uint32_t seed_offset, void* stream);
+/* Words of keep_lanes for this shape (0 where mmf_attention_keep_bits_words' shape rule gives 0): B * heads * ceil(Sq / 32) * 64 lanes * 4. */
+int64_t mmf_attention_keep_lanes_words(int B, int heads, int Sq, int Sk, int head_dim);
 /* Words of mmf_attn_desc.keep_bits for this shape, 0 when its backward is the two-kernel form, which hashes (head_dim 64 beyond 256 queries or keys, head_dim 128
  * beyond 128). */
 int64_t mmf_attention_keep_bits_words(int B, int heads, int Sq, int Sk, int head_dim);

@@ -50,7 +50,18 @@ class AttnDesc(C.Structure):
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("head_dim", C.c_int), ("ctx_f32", C.c_void_p), ("causal_tail", C.c_int),
         ("q_batch_rows", C.c_int), ("kv_batch_rows", C.c_int), ("mask_batch_stride", C.c_int), ("mask_query_stride", C.c_int),
-        ("keep_bits", C.c_void_p),
+        ("keep_bits", C.c_void_p), ("keep_lanes", C.c_void_p),
+    ]
+
+
+ATTN_DRAW_MAX = 48
+
+
+class AttnDrawSite(C.Structure):
+    _fields_ = [
+        ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_seed", C.c_void_p),
+        ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int), ("head_dim", C.c_int),
+        ("keep_bits", C.c_void_p), ("keep_lanes", C.c_void_p),
     ]
 
 
@@ -304,11 +315,32 @@ def attention_keep_bits_words(B, heads, Sq, Sk, head_dim=64):
     return int(f(int(B), int(heads), int(Sq), int(Sk), int(head_dim)))
 
 
+def attention_keep_lanes_words(B, heads, Sq, Sk, head_dim=64):
+    """int32 words of the lane-major table `attention_draw_keep_bits` writes for the forward (`keep_lanes=`), 0 where `attention_keep_bits_words` is 0."""
+    f = lib().mmf_attention_keep_lanes_words
+    f.restype = C.c_int64
+    return int(f(int(B), int(heads), int(Sq), int(Sk), int(head_dim)))
+
+
+def attention_draw_keep_bits(sites, seed_offset=0):
+    """The attention-dropout decisions of several attention calls in ONE launch, ahead of the kernels that use them.  `sites`: an iterable of
+    (drop, B, heads, Sq, Sk, head_dim, keep_bits, keep_lanes) with `drop` as `drop_cfg` returns it and the two int32 tables sized by
+    `attention_keep_bits_words` / `attention_keep_lanes_words`.  `seed_offset` is added to the seed word (1 = the next step's decisions)."""
+    sites = list(sites)
+    arr = (AttnDrawSite * max(1, len(sites)))()
+    for d, (drop, B, heads, Sq, Sk, hd, kb, kl) in zip(arr, sites):
+        _req(kb, torch.int32, "keep_bits"); _req(kl, torch.int32, "keep_lanes")
+        d.drop_key, d.drop_thr16, _, d.drop_seed = _drop4(drop)
+        d.B, d.heads, d.Sq, d.Sk, d.head_dim = int(B), int(heads), int(Sq), int(Sk), int(hd)
+        d.keep_bits, d.keep_lanes = _p(kb), _p(kl)
+    _check(lib().mmf_attention_draw_keep_bits(arr, len(sites), C.c_uint32(int(seed_offset)), _stream()), "mmf_attention_draw_keep_bits")
+
+
 def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim=64, ctx_f32=None,
-               causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None):
+               causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None, keep_lanes=None):
     d = AttnDesc()
-    _req(keep_bits, torch.int32, "keep_bits")
-    d.keep_bits = _p(keep_bits)
+    _req(keep_bits, torch.int32, "keep_bits"); _req(keep_lanes, torch.int32, "keep_lanes")
+    d.keep_bits, d.keep_lanes = _p(keep_bits), _p(keep_lanes)
     # a 3-D mask [B, Sq, Sk] is a materialised additive mask per (query, key) pair (mmf_attn_desc.mask_query_stride); 2-D: the key mask [B, Sk]
     d.mask_query_stride = int(mask.stride(1)) if (mask is not None and mask.dim() == 3) else 0
     if d.mask_query_stride and not mask_batch_stride:
@@ -333,12 +365,13 @@ def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, sc
 
 
 def attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=NO_DROP, head_dim=64, ctx_f32=None,
-                  causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None):
+                  causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None, keep_lanes=None):
     """`q_batch_rows` / `kv_batch_rows` / `mask_batch_stride` (forward only): q, k / v and the mask may live inside longer
     per-sample buffers (a K|V cache); 0 = the dense defaults Sq / Sk / Sk.  `keep_bits`: int32 [attention_keep_bits_words(...)], the forward
-    writes its dropout decisions there for `attention_bwd(..., keep_bits=)` (which then does not hash them again)."""
+    writes its dropout decisions there for `attention_bwd(..., keep_bits=)` (which then does not hash them again).  `keep_lanes`: the decisions
+    were drawn ahead by `attention_draw_keep_bits` (same drop, same shape): the forward reads them and writes no table."""
     d = _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop, head_dim, ctx_f32, causal_tail,
-                   q_batch_rows, kv_batch_rows, mask_batch_stride, keep_bits)
+                   q_batch_rows, kv_batch_rows, mask_batch_stride, keep_bits, keep_lanes)
     _check(lib().mmf_attention_fwd(C.byref(d), _stream()), "mmf_attention_fwd")
 
 

@@ -204,6 +204,7 @@ struct AttnArgs {
     float scale;
     DropoutCfg drop;
     uint32_t* keep;          // optional dropout keep-bit table (mmf_attn_desc.keep_bits): written by the forward kernels, read by attn_bwd_fused_kernel
+    const uint32_t* keep_lanes;   // optional (mmf_attn_desc.keep_lanes): the decisions drawn ahead of the forward by attn_keep_draw_kernel, in the forward's own lane order
     // backward only
     const bf16* dctx; bf16* dq; bf16* dk; bf16* dv; float* delta;
 };
@@ -282,10 +283,60 @@ DEVI void drop_tile(f32x16& acc, uint32_t dkey, uint32_t tilebase, int h, int la
     if (lane < 32) keep[lane] = (uint32_t)kw;
 }
 
+// The same decisions WITHOUT the multiplication: what attn_keep_draw_kernel runs ahead of the step (mmf_attention_draw_keep_bits).  Returns this lane's
+// 16 decisions of the tile (bit 4c + i = register 4c + i of the S^T tile, i.e. query x against key 8c + 4h + i) and writes the key-major table words
+// exactly as drop_tile does.
+DEVI uint32_t draw_tile(uint32_t dkey, uint32_t tilebase, int h, int lane, uint32_t thr16, uint32_t* keep) {
+    int kw = 0;
+    uint32_t own = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t idx4 = tilebase + 8 * c + 4 * h;
+        const uint32_t h0 = drop_hash(dkey, idx4 >> 1), h1 = drop_hash(dkey, (idx4 >> 1) + 1);
+        const uint32_t half[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+        unsigned long long m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool on = half[i] >= thr16;
+            m[i] = __builtin_amdgcn_ballot_w64(on);
+            own |= on ? (1u << (4 * c + i)) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kw = mmf_writelane((int)(uint32_t)m[i], 8 * c + i, kw);
+            kw = mmf_writelane((int)(uint32_t)(m[i] >> 32), 8 * c + 4 + i, kw);
+        }
+    }
+    if (lane < 32) keep[lane] = (uint32_t)kw;
+    return own;
+}
+
+// Forward side of the pre-drawn decisions (mmf_attn_desc.keep_lanes): a lane holds the 16 decisions of each of its (up to 8) key tiles as 16-bit
+// fields of ONE 16-byte word, fetched with the Q fragments; a probability costs a bit-field extract, an AND and the multiply the hashing path also
+// ends in (same factor — 0 or scale — hence the same bits out).
+DEVI uint32_t lane_bits(const u32x4& kl, int t) {
+    uint32_t w = kl[0];
+    if (t >= 2) w = kl[1];
+    if (t >= 4) w = kl[2];
+    if (t >= 6) w = kl[3];
+    return (t & 1) ? (w >> 16) : (w & 0xffffu);
+}
+DEVI void drop_tile_drawn(f32x16& acc, uint32_t bits, float scale) {
+    const uint32_t sb = __float_as_uint(scale);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t m = (uint32_t)((int)(bits << (31 - r)) >> 31);      // v_bfe_i32: all ones where the element is kept
+        acc[r] *= __uint_as_float(sb & m);
+    }
+}
+DEVI u32x4 load_keep_lanes(const uint32_t* keep_lanes, int bh, int Sq, int q0, int lane) {
+    return *reinterpret_cast<const u32x4*>(keep_lanes + (((size_t)bh * ((Sq + 31) >> 5) + (q0 >> 5)) * 64 + lane) * 4);
+}
+
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int NKT, int D, int MM>
+template <int NKT, int D, int MM, bool DRAWN = false>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs a) {
     constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
     constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
@@ -318,6 +369,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = frag_global(qptr, s, lane);
+    u32x4 kl = {};
+    if constexpr (DRAWN) { if (q0 < a.Sq) kl = load_keep_lanes(a.keep_lanes, bh, a.Sq, q0, lane); }
     PROBE_AT(1);
     stage_wait();
     PROBE_AT(2);
@@ -373,6 +426,10 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
 
     PROBE_AT(4);
     // dropout on the probabilities (hf_layers.py:201), index ((bh*Sq + q)*SKP + key)
+    if constexpr (DRAWN) {
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) drop_tile_drawn(sc[t], lane_bits(kl, t), a.drop.scale);
+    } else
     if (a.drop.thr16) {
         const uint32_t rowbase = ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)(q0 + x)) * (uint32_t)a.skp;
         const uint32_t dkey = drop_key(a.drop);
@@ -438,7 +495,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
 // on a CU: B * heads = 384 workgroups are ONE round of the 512 slots instead of 768 workgroups on 512 slots (1.5 rounds, the second
 // half-empty; profiles/r02_attention_timeline.txt), with four waves per SIMD to overlap one wave's softmax VALU with another's MFMAs.
 // Same arithmetic in the same order as attn_fwd_kernel (scores, maxima, exponentials, row sums, P V accumulation): bit-identical outputs.
-template <int NKT, int MM>
+template <int NKT, int MM, bool DRAWN = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
     constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
     constexpr int D = 64, HD = 64, NS = 4, NDT = 2, ROWB = 128, SKP = NKT * 32;
@@ -466,6 +523,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = frag_global(qptr, s, lane);
+    u32x4 kl = {};
+    if constexpr (DRAWN) { if (q0 < a.Sq) kl = load_keep_lanes(a.keep_lanes, bh, a.Sq, q0, lane); }
     stage_wait();
     const bool active = q0 < a.Sq;          // (idle waves run along to the barrier ahead of the epilogue)
 
@@ -523,7 +582,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
                     sum += p;
                 }
             }
-            if (a.drop.thr16)
+            if constexpr (DRAWN) drop_tile_drawn(acc, lane_bits(kl, t), a.drop.scale);
+            else if (a.drop.thr16)
                 drop_tile(acc, dkey, rowbase + 32 * t, h, lane, a.drop,
                           (a.keep && t < NKT_RT) ? a.keep + (((size_t)bh * ((a.Sq + 31) >> 5) + (q0 >> 5)) * NKT_RT + t) * 32 : nullptr);
 #pragma unroll
@@ -549,6 +609,49 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
             store_tile_rows_f32(o, inv, mine, a.ctx32 + ((size_t)b * a.Sq + q0) * a.ldo + head * HD, a.ldo, a.Sq - q0, lane);
         }
     }
+}
+
+// =================================================================================================
+// dropout decisions drawn ahead of the forward (mmf_attention_draw_keep_bits)
+// =================================================================================================
+// The keep decisions of the probability dropout are a pure function of (site key, step seed word, element index) — never of the scores — so ONE launch
+// can draw them for every attention site of a training step before the first encoder layer runs (on a side stream beside the embedding stage, where the
+// chip is idle: a branch of the step's hipGraph), and both attention kernels then READ them: the forward from `keep_lanes` (its own lane order), the
+// one-pass backward from `keep_bits` (one word per key lane, as before).  One wave = one (site, batch * head, 32-query tile), all its key tiles.
+constexpr int DRAW_MAX = MMF_ATTN_DRAW_MAX;
+struct DrawSite {
+    uint32_t key, thr16;
+    const uint32_t* seed;
+    uint32_t* keep;
+    uint32_t* lanes;
+    int Sq, skp, nqt, nkt;
+    int first;          // first wave of this site in the launch
+};
+struct DrawArgs {
+    int n, total;
+    uint32_t seed_off;  // added to the seed word: 1 draws the decisions of the NEXT step (whose head advances the word by one) beside this step's AdamW
+    DrawSite s[DRAW_MAX];
+};
+__global__ __launch_bounds__(256) void attn_keep_draw_kernel(DrawArgs a) {
+    const int lane = threadIdx.x & 63, x = lane & 31, h = lane >> 5;
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= a.total) return;
+    int si = 0;
+    while (si + 1 < a.n && g >= a.s[si + 1].first) ++si;
+    const DrawSite& st = a.s[si];
+    const int local = g - st.first, bh = local / st.nqt, qt = local - bh * st.nqt;
+    const uint32_t dkey = st.seed ? st.key + (st.seed[0] + a.seed_off) * 0x9E3779B1u : st.key;       // == drop_key() once the word has advanced by seed_off
+    const uint32_t rowbase = ((uint32_t)bh * (uint32_t)st.Sq + (uint32_t)(32 * qt + x)) * (uint32_t)st.skp;
+    uint32_t* keep = st.keep + ((size_t)bh * st.nqt + qt) * st.nkt * 32;
+    u32x4 w = {};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t < st.nkt) {
+            const uint32_t bits = draw_tile(dkey, rowbase + 32 * t, h, lane, st.thr16, keep + 32 * t);
+            w[t >> 1] |= bits << (16 * (t & 1));
+        }
+    }
+    *reinterpret_cast<u32x4*>(st.lanes + (((size_t)bh * st.nqt + qt) * 64 + lane) * 4) = w;
 }
 
 // =================================================================================================
@@ -1056,6 +1159,10 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
     a.keep = d->keep_bits;
+    a.keep_lanes = d->keep_lanes;
+    MMF_CHECK_ARG(!a.keep_lanes || (d->drop_thr16 != 0 && keep_bits_shape(hd, d->Sq, d->Sk) && d->q_batch_rows == 0 && d->kv_batch_rows == 0 &&
+                                    (reinterpret_cast<uintptr_t>(a.keep_lanes) & 15) == 0),
+                  "attention: keep_lanes (decisions drawn by mmf_attention_draw_keep_bits) is taken for the shapes that take keep_bits, with dropout on, 16-byte aligned");
     MMF_CHECK_ARG(!a.keep || (d->drop_thr16 != 0 && keep_bits_shape(hd, d->Sq, d->Sk) && d->q_batch_rows == 0 && d->kv_batch_rows == 0),
                   "attention: keep_bits is taken where the backward is the one-pass kernel (head_dim 64: <= 256 positions, 128: <= 128), with dropout on (mmf_attention_keep_bits_words)");
     return 0;
@@ -1077,6 +1184,40 @@ extern "C" int64_t mmf_attention_keep_bits_words(int B, int heads, int Sq, int S
     return (int64_t)B * heads * ((Sq + 31) / 32) * ((Sk + 31) / 32) * 32;
 }
 
+extern "C" int64_t mmf_attention_keep_lanes_words(int B, int heads, int Sq, int Sk, int head_dim) {
+    const int hd = head_dim ? head_dim : 64;
+    if (B <= 0 || heads <= 0 || !keep_bits_shape(hd, Sq, Sk)) return 0;
+    return (int64_t)B * heads * ((Sq + 31) / 32) * 64 * 4;
+}
+
+extern "C" int mmf_attention_draw_keep_bits(const mmf_attn_draw_site* sites, int n, uint32_t seed_offset, void* stream) {
+    MMF_CHECK_ARG(n >= 0 && (n == 0 || sites), "attention_draw_keep_bits: null sites");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int base = 0; base < n; base += DRAW_MAX) {
+        DrawArgs a;
+        a.n = n - base < DRAW_MAX ? n - base : DRAW_MAX;
+        a.seed_off = seed_offset;
+        int total = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const mmf_attn_draw_site& d = sites[base + i];
+            const int hd = d.head_dim ? d.head_dim : 64;
+            MMF_CHECK_ARG(d.B > 0 && d.heads > 0 && (hd == 64 || hd == 128) && keep_bits_shape(hd, d.Sq, d.Sk) && d.Sq > 0 && d.Sk > 0,
+                          "attention_draw_keep_bits: a site must be a shape that takes keep_bits (mmf_attention_keep_bits_words != 0)");
+            MMF_CHECK_ARG(d.drop_thr16 != 0 && d.keep_bits && d.keep_lanes && (reinterpret_cast<uintptr_t>(d.keep_lanes) & 15) == 0,
+                          "attention_draw_keep_bits: dropout off, or a null / misaligned table");
+            DrawSite& t = a.s[i];
+            t.key = d.drop_key; t.thr16 = d.drop_thr16; t.seed = d.drop_seed; t.keep = d.keep_bits; t.lanes = d.keep_lanes;
+            t.Sq = d.Sq; t.skp = (d.Sk + 31) / 32 * 32; t.nqt = (d.Sq + 31) / 32; t.nkt = t.skp / 32; t.first = total;
+            total += d.B * d.heads * t.nqt;
+        }
+        a.total = total;
+        if (total == 0) continue;
+        hipLaunchKernelGGL(attn_keep_draw_kernel, dim3((total + 3) / 4), dim3(256), 0, s, a);
+        MMF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     AttnArgs a;
     if (int rc = fill_args(d, a)) return rc;
@@ -1084,12 +1225,26 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nkt = a.skp / 32;
     const dim3 grid(a.B * a.heads, (a.Sq + 127) / 128);
-#define LAUNCH_FWD(N, DD, CZ)                                                                    \
+#define LAUNCH_FWD_(N, DD, CZ, DR)                                                               \
     {                                                                                            \
         int lds = 2 * N * 32 * (2 * DD) + N * 32 * 4;                                            \
         if (DD == 64 && lds < 4 * 12288) lds = 4 * 12288;   /* the epilogue's row images */      \
-        if (int rc = set_lds(attn_fwd_kernel<N, DD, CZ>, lds)) return rc;                        \
-        hipLaunchKernelGGL((attn_fwd_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);            \
+        if (int rc = set_lds(attn_fwd_kernel<N, DD, CZ, DR>, lds)) return rc;                    \
+        hipLaunchKernelGGL((attn_fwd_kernel<N, DD, CZ, DR>), grid, dim3(256), lds, s, a);        \
+    }
+    /* (decisions drawn ahead, mmf_attn_desc.keep_lanes: shapes with <= 8 key tiles only, checked in fill_args) */
+#define LAUNCH_FWD(N, DD, CZ) { if (a.keep_lanes) LAUNCH_FWD_(N, DD, CZ, true) else LAUNCH_FWD_(N, DD, CZ, false) }
+#define LAUNCH_FWD8(MMODE)                                                                       \
+    {                                                                                            \
+        const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;                                           \
+        const dim3 grid8(a.B * a.heads, (a.Sq + 255) / 256);                                     \
+        if (a.keep_lanes) {                                                                      \
+            if (int rc = set_lds(attn_fwd8_kernel<8, MMODE, true>, lds)) return rc;              \
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, MMODE, true>), grid8, dim3(512), lds, s, a); \
+        } else {                                                                                 \
+            if (int rc = set_lds(attn_fwd8_kernel<8, MMODE>, lds)) return rc;                    \
+            hipLaunchKernelGGL((attn_fwd8_kernel<8, MMODE>), grid8, dim3(512), lds, s, a);       \
+        }                                                                                        \
     }
     const bool cz = a.cfrom < a.Sk;
     if (a.hd == 64 && nkt > 8) {
@@ -1109,11 +1264,8 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         return 0;
     }
     if (a.m_qs) {      // per-query mask [B, Sq, Sk] (head_dim 64): the same two kernel forms, mask read per (query, key) from global memory
-        if (nkt > 4 && a.Sq > 128 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 2)) {
-            const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
-            if (int rc = set_lds(attn_fwd8_kernel<8, MASK_QUERY>, lds)) return rc;
-            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_QUERY>), dim3(a.B * a.heads, (a.Sq + 255) / 256), dim3(512), lds, s, a);
-        } else if (nkt <= 4) LAUNCH_FWD(4, 64, MASK_QUERY)
+        if (nkt > 4 && a.Sq > 128 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 2)) LAUNCH_FWD8(MASK_QUERY)
+        else if (nkt <= 4) LAUNCH_FWD(4, 64, MASK_QUERY)
         else LAUNCH_FWD(8, 64, MASK_QUERY)
         MMF_CHECK_LAUNCH();
         return 0;
@@ -1121,22 +1273,16 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
     // head_dim 64 with more than 128 queries: the one-round form (one 8-wave workgroup per (batch, head), two per CU; attn_fwd8_kernel).
     // MMF_TUN_ALT_FORMS bit 1 keeps the two-workgroups-per-head form (A/B measurements, bit-equality test).
     if (a.hd == 64 && nkt > 4 && a.Sq > 128 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 2)) {
-        const int lds = 2 * 8 * 32 * 128 + 8 * 32 * 4;
-        const dim3 grid8(a.B * a.heads, (a.Sq + 255) / 256);
-        if (cz) {
-            if (int rc = set_lds(attn_fwd8_kernel<8, MASK_TAIL>, lds)) return rc;
-            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_TAIL>), grid8, dim3(512), lds, s, a);
-        } else {
-            if (int rc = set_lds(attn_fwd8_kernel<8, MASK_KEY>, lds)) return rc;
-            hipLaunchKernelGGL((attn_fwd8_kernel<8, MASK_KEY>), grid8, dim3(512), lds, s, a);
-        }
+        if (cz) LAUNCH_FWD8(MASK_TAIL) else LAUNCH_FWD8(MASK_KEY)
         MMF_CHECK_LAUNCH();
         return 0;
     }
-    if (a.hd == 128) { if (nkt <= 4) LAUNCH_FWD(4, 128, MASK_KEY) else LAUNCH_FWD(8, 128, MASK_KEY) }
+    if (a.hd == 128) { if (nkt <= 4) LAUNCH_FWD(4, 128, MASK_KEY) else LAUNCH_FWD_(8, 128, MASK_KEY, false) }
     else if (nkt <= 4) { if (cz) LAUNCH_FWD(4, 64, MASK_TAIL) else LAUNCH_FWD(4, 64, MASK_KEY) }
     else { if (cz) LAUNCH_FWD(8, 64, MASK_TAIL) else LAUNCH_FWD(8, 64, MASK_KEY) }
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD_
+#undef LAUNCH_FWD8
     MMF_CHECK_LAUNCH();
     return 0;
 }

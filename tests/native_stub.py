@@ -72,7 +72,10 @@ def _gemm_grouped(problems):
 
 
 def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, drop=N.NO_DROP, head_dim=64, ctx_f32=None,
-                   causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None):
+                   causal_tail=0, q_batch_rows=0, kv_batch_rows=0, mask_batch_stride=0, keep_bits=None, keep_lanes=None):
+    if keep_lanes is not None:     # decisions drawn ahead (mmf_attn_desc.keep_lanes): the shapes that take keep_bits, dropout on
+        assert keep_lanes.dtype == torch.int32 and drop[1] and max(Sq, Sk) <= (256 if head_dim == 64 else 128)
+        assert keep_lanes.numel() == B * heads * ((Sq + 31) // 32) * 256
     assert head_dim in (64, 128) and 0 <= causal_tail <= Sk and (causal_tail == 0 or (Sq == Sk and head_dim == 64))
     if keep_bits is not None:      # the dropout keep-bit table (mmf_attn_desc.keep_bits): only where the kernels take one, only with dropout on
         assert keep_bits.dtype == torch.int32 and drop[1] and max(Sq, Sk) <= (256 if head_dim == 64 else 128)

@@ -427,6 +427,73 @@ def test_attention_keep_bit_table_cross_attention_and_head_dim_128(Sq, Sk, d):
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("Sq,Sk,d,mode", [(228, 228, 64, "key"), (256, 256, 64, "tail"), (200, 200, 64, "query"), (160, 160, 64, "key"), (128, 128, 64, "key"),
+                                          (100, 100, 64, "tail"), (40, 40, 64, "query"), (7, 7, 64, "key"), (128, 101, 128, "key"), (36, 20, 128, "key"),
+                                          (200, 64, 64, "key"), (100, 228, 64, "key")])
+def test_attention_dropout_decisions_drawn_ahead_of_the_forward(Sq, Sk, d, mode):
+    """mmf_attention_draw_keep_bits: the decisions depend on (key, seed word, element index) only, so ONE launch draws them for several attention calls
+    ahead of the kernels.  The key-major table equals what the forward writes while hashing, bit for bit; a forward that reads
+    `keep_lanes` returns the same context / log-sum-exp bits as the hashing forward, for every kernel form (8-wave and 4-wave head_dim 64, head_dim 128,
+    cross attention, causal tail, per-query mask), with a device seed word as a replayed graph uses it."""
+    B, heads = 3, 4
+    H = heads * d
+    q = rnd(B * Sq, H, scale=0.5, seed=Sq); kv = rnd(B * Sk, 2 * H, scale=0.5, seed=Sk + 1)
+    keym = torch.zeros(B, Sk, device=DEV); keym[:, Sk - 3:] = -10000.0
+    tail = min(12, Sk - 1) if mode == "tail" else 0
+    mask = keym
+    if mode == "query":
+        mask = (keym[:, None, :] + torch.where(torch.rand(B, Sq, Sk, device=DEV) < 0.1, -10000.0, 0.0)).contiguous()
+    seed = torch.tensor([12345], dtype=torch.int32, device=DEV)
+    drops = [nat().drop_cfg(0.1, 424242 + i, seed) for i in range(3)]
+    wb, wl = nat().attention_keep_bits_words(B, heads, Sq, Sk, d), nat().attention_keep_lanes_words(B, heads, Sq, Sk, d)
+    assert wb > 0 and wl == B * heads * ((Sq + 31) // 32) * 256
+    scale = 1.0 / math.sqrt(d)
+
+    def fwd(drop, kb, kl):
+        ctx = torch.empty(B * Sq, H, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, heads, Sq, device=DEV); o32 = torch.empty(B * Sq, H, device=DEV)
+        nat().attention_fwd(q, kv, kv[:, H:], H, 2 * H, 2 * H, mask, ctx, H, lse, B, heads, Sq, Sk, scale, drop, head_dim=d, ctx_f32=o32, causal_tail=tail,
+                            keep_bits=kb, keep_lanes=kl)
+        return ctx, lse, o32
+
+    # three sites in one launch (different keys), tables pre-filled with garbage
+    tabs = [(torch.full((wb,), 0x5A5A5A5A, dtype=torch.int32, device=DEV), torch.full((wl,), -1, dtype=torch.int32, device=DEV)) for _ in drops]
+    nat().attention_draw_keep_bits([(dr, B, heads, Sq, Sk, d, kb, kl) for dr, (kb, kl) in zip(drops, tabs)])
+    for dr, (kb, kl) in zip(drops, tabs):
+        kb_ref = torch.full((wb,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+        ref = fwd(dr, kb_ref, None)
+        assert torch.equal(kb, kb_ref)
+        kb_before = kb.clone()
+        got = fwd(dr, kb, kl)
+        assert torch.equal(kb, kb_before)       # (the reading forward writes no table)
+        for a_, b_ in zip(ref, got):
+            assert torch.equal(a_, b_)
+    assert not torch.equal(tabs[0][0], tabs[1][0])
+    # a new seed word: new decisions, still equal to the hashing forward's
+    old0 = tabs[0][0].clone()
+    seed.add_(1)
+    nat().attention_draw_keep_bits([(drops[0], B, heads, Sq, Sk, d) + tabs[0]])
+    assert not torch.equal(tabs[0][0], old0)
+    ref = fwd(drops[0], None, None); got = fwd(drops[0], None, tabs[0][1])
+    for a_, b_ in zip(ref, got):
+        assert torch.equal(a_, b_)
+    # seed_offset = 1: the decisions of the step AFTER the next advance of the word (what a step draws beside its AdamW launches for its successor)
+    nat().attention_draw_keep_bits([(drops[1], B, heads, Sq, Sk, d) + tabs[1]], seed_offset=1)
+    seed.add_(1)
+    nat().attention_draw_keep_bits([(drops[1], B, heads, Sq, Sk, d) + tabs[2]])
+    assert torch.equal(tabs[1][0], tabs[2][0]) and torch.equal(tabs[1][1], tabs[2][1])
+
+
+def test_attention_draw_refuses_shapes_without_tables():
+    drop = nat().drop_cfg(0.1, 1, torch.zeros(1, dtype=torch.int32, device=DEV))
+    t = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    assert nat().attention_keep_lanes_words(2, 2, 300, 300, 64) == 0
+    with pytest.raises(nat().NativeLibraryError):
+        nat().attention_draw_keep_bits([(drop, 2, 2, 300, 300, 64, t, t)])
+    with pytest.raises(nat().NativeLibraryError):      # dropout off: nothing to draw
+        nat().attention_draw_keep_bits([(nat().NO_DROP, 2, 2, 64, 64, 64, t, t)])
+    nat().attention_draw_keep_bits([])
+
+
 def test_attention_keep_bit_table_is_the_counter_hash():
     """Every bit of the table against a host restatement of the dropout RNG (mmf_amd/csrc/common.h: mix24 of (pair index + key), the 16-bit half of the
     element's parity against thr16; element index ((b * heads + head) * Sq + q) * Sk_pad + key): a wrong or stale word cannot hide behind statistics."""
@@ -1158,7 +1225,7 @@ def test_adamw_reads_bf16_wire_buffers_and_updates_subsets():
         assert p.grad is None
         assert torch.equal(p.detach(), q.detach())
     assert all(oa.state[p]["step"] == 2 for p in a)
-    with pytest.raises(nat().NativeLibraryError):
+    with pytest.raises((nat().NativeLibraryError, RuntimeError)):      # (the C ABI's error through ctypes, or the operator library's own check: torch_ops.cpp _adamw_step)
         oa.external_grads = {id(a[0]): g16[0].half()}
         oa.step()
 

@@ -707,6 +707,9 @@ int mmf_ptr_scores_f32(const float* q, const float* k, const float* mask_add, fl
  * text side); mmf_reduce_batch_bf16 is the backward (the sum over the broadcast index, fp32 accumulation).  n % 8 == 0. */
 int mmf_expand_batch_bf16(const void* x, void* out, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream);
 int mmf_reduce_batch_bf16(const void* g, void* dx, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream);
+/* The same on fp32 activations (mmf_amd.fp32_training() / fp32_inference(): `in_batch_pairs` / `fast_mode` in the reference's default arithmetic); n % 4 == 0. */
+int mmf_expand_batch_f32(const float* x, float* out, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream);
+int mmf_reduce_batch_f32(const float* g, float* dx, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream);
 
 /* ViLBERT's masked-region NCE loss (`visual_target: 2`, mmf/models/vilbert.py:1158-1227): pred fp32 [M, N] = the image-prediction head's output
  * for all M = B * R regions, target fp32 [M, N] the region features, neg int64 [M, K] flat indices (into the M regions) of each region's K

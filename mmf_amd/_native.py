@@ -820,11 +820,20 @@ def dropout_f32(x, y, drop):
 
 
 def expand_batch(x, out, Bs, reps, n, mode):
+    """bf16 or fp32 activations (both tensors of one dtype): the library's bf16 / f32 entry."""
+    if x.dtype == torch.float32:
+        _req(x, torch.float32, "x"); _req(out, torch.float32, "out")
+        _check(lib().mmf_expand_batch_f32(_p(x), _p(out), C.c_int64(Bs), C.c_int64(reps), C.c_int64(n), mode, _stream()), "mmf_expand_batch_f32")
+        return
     _req(x, torch.bfloat16, "x"); _req(out, torch.bfloat16, "out")
     _check(lib().mmf_expand_batch_bf16(_p(x), _p(out), C.c_int64(Bs), C.c_int64(reps), C.c_int64(n), mode, _stream()), "mmf_expand_batch_bf16")
 
 
 def reduce_batch(g, dx, Bs, reps, n, mode):
+    if g.dtype == torch.float32:
+        _req(g, torch.float32, "g"); _req(dx, torch.float32, "dx")
+        _check(lib().mmf_reduce_batch_f32(_p(g), _p(dx), C.c_int64(Bs), C.c_int64(reps), C.c_int64(n), mode, _stream()), "mmf_reduce_batch_f32")
+        return
     _req(g, torch.bfloat16, "g"); _req(dx, torch.bfloat16, "dx")
     _check(lib().mmf_reduce_batch_bf16(_p(g), _p(dx), C.c_int64(Bs), C.c_int64(reps), C.c_int64(n), mode, _stream()), "mmf_reduce_batch_bf16")
 

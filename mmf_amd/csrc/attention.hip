@@ -661,8 +661,9 @@ __global__ __launch_bounds__(256) void attn_keep_draw_kernel(DrawArgs a) {
 //   dQ = dS K * scale ; dK = dS^T Q * scale
 // =================================================================================================
 // dQ kernel: same decomposition as the forward (wave = 32 query rows, all keys).
-template <int NKT, int D, bool CZ>
+template <int NKT, int D, int MM>      // MM: MASK_KEY / MASK_TAIL / MASK_QUERY (bool-compatible: false = key mask, true = causal tail)
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
     constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SKP = NKT * 32;
@@ -681,10 +682,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     const bf16* vbase = a.v + (size_t)b * a.Sk * a.ldv + head * HD;
     stage_rows<D>(kbase, a.ldk, a.Sk, SKP, lds_k, tid);
     stage_rows<D>(vbase, a.ldv, a.Sk, SKP, lds_v, tid);
-    for (int i = tid; i < SKP; i += 256)   // additive mask in the log2 domain
-        lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    if constexpr (!MQ) {
+        for (int i = tid; i < SKP; i += 256)   // additive mask in the log2 domain
+            lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.Sk + i] * 1.4426950408889634f : 0.f) : -INFINITY;
+    }
     // per-query operands straight from global memory, fetched while the K / V DMA is still in flight
     const int qrow = min(q0 + x, a.Sq - 1);
+    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)qrow * a.m_qs : nullptr;      // this lane's row of a per-query mask
+    const bool mvec = MQ && ((a.m_qs | a.m_bs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
     const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
     const bf16* doptr = a.dctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
     bf16x8 qf[NS], dof[NS];
@@ -749,8 +754,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
         // dS^T[key][q] (scaled by `scale` for the dQ product)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
-            float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            float mkv[4];
+            if constexpr (MQ) query_mask4(mkv, mrow, 32 * t + 8 * c + 4 * h, a.Sk, mvec);
+            else {
+                const float4 mk = *reinterpret_cast<const float4*>(lds_mask + 32 * t + 8 * c + 4 * h);
+                mkv[0] = mk.x; mkv[1] = mk.y; mkv[2] = mk.z; mkv[3] = mk.w;
+            }
             if constexpr (CZ) tail_mask(mkv, 32 * t + 8 * c + 4 * h, q0 + x, a.cfrom, a.Sk);
             f32x4 ds = {1.f, 1.f, 1.f, 1.f};
             if (a.drop.thr16) ds = drop_scale4(drop_key(a.drop), rowbase + 32 * t + 8 * c + 4 * h, a.drop.thr16, a.drop.scale);
@@ -784,8 +793,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
 }
 
 // dK/dV kernel: wave = 32 key rows, loops over all query tiles.
-template <int NQT, int D, bool CZ>
+template <int NQT, int D, int MM>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr bool CZ = MM == MASK_TAIL, MQ = MM == MASK_QUERY;
     constexpr int HD = D, NS = D / 16, NDT = D / 32, ROWB = 2 * D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SQP = NQT * 32;
@@ -819,7 +829,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
     bf16x8 kf[NS], vf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
-    const float mk = kvalid ? (a.mask ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    const float mk = kvalid ? ((a.mask && !MQ) ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
+    const float* mcol = MQ ? a.mask + (size_t)b * a.m_bs + krow : nullptr;       // this lane's key column of a per-query mask
     PROBE_AT(1);
     stage_wait();
     PROBE_AT(2);
@@ -855,6 +866,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
                     dsc = drop_scale1(drop_key(a.drop), ((uint32_t)bh * (uint32_t)a.Sq + (uint32_t)q) * (uint32_t)SKP + (uint32_t)(k0 + x),
                                       a.drop.thr16, a.drop.scale);
                 float mkq = mk;
+                if constexpr (MQ) { if (kvalid) mkq = mcol[(size_t)min(q, a.Sq - 1) * a.m_qs] * 1.4426950408889634f; }      // (padded query rows carry lse = +inf: p = 0)
                 if constexpr (CZ) {   // causal tail (see tail_mask): this lane's key against query q
                     if (kvalid && k0 + x >= a.cfrom) mkq = (q >= a.cfrom && k0 + x <= q) ? 0.f : -10000.f * 1.4426950408889634f;
                 }
@@ -1151,7 +1163,6 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.m_qs = d->mask_query_stride;
     MMF_CHECK_ARG(a.m_qs == 0 || (d->mask && a.m_qs >= d->Sk), "attention: mask_query_stride must cover a mask row (>= Sk)");
     MMF_CHECK_ARG(a.m_qs == 0 || (hd == 64 && d->causal_tail == 0), "attention: a per-query mask is built for head_dim 64 (and replaces the causal tail)");
-    MMF_CHECK_ARG(a.m_qs == 0 || (d->Sk <= 256 && d->Sq <= 256), "attention: a per-query mask is built for Sq, Sk <= 256 (the one-pass backward reads it)");
     a.m_bs = d->mask_batch_stride > 0 ? d->mask_batch_stride : (a.m_qs ? d->Sq * a.m_qs : d->Sk);
     MMF_CHECK_ARG(a.q_bs >= d->Sq && a.kv_bs >= d->Sk && a.m_bs >= d->Sk, "attention: batch strides must cover the sequence");
     MMF_CHECK_ARG(a.m_qs == 0 || a.m_bs >= (d->Sq - 1) * a.m_qs + d->Sk, "attention: mask_batch_stride must cover the per-query mask of a sample");
@@ -1257,7 +1268,8 @@ extern "C" int mmf_attention_fwd(const mmf_attn_desc* d, void* stream) {
         if (int rc = set_lds(attn_fwd8_kernel<N, MMODE>, lds)) return rc;                        \
         hipLaunchKernelGGL((attn_fwd8_kernel<N, MMODE>), gridL, dim3(512), lds, s, a);           \
     }
-        if (nkt <= 12) { if (cz) LAUNCH_FWD_LONG(12, MASK_TAIL) else LAUNCH_FWD_LONG(12, MASK_KEY) }
+        if (a.m_qs) { if (nkt <= 12) LAUNCH_FWD_LONG(12, MASK_QUERY) else LAUNCH_FWD_LONG(16, MASK_QUERY) }
+        else if (nkt <= 12) { if (cz) LAUNCH_FWD_LONG(12, MASK_TAIL) else LAUNCH_FWD_LONG(12, MASK_KEY) }
         else { if (cz) LAUNCH_FWD_LONG(16, MASK_TAIL) else LAUNCH_FWD_LONG(16, MASK_KEY) }
 #undef LAUNCH_FWD_LONG
         MMF_CHECK_LAUNCH();
@@ -1302,7 +1314,7 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     const int nkt = a.skp / 32;
     const int nqt = (a.Sq + 31) / 32;
     const bool cz = a.cfrom < a.Sk;
-    if (a.hd == 64 && nkt <= 8 && nqt <= 8 && (a.m_qs || !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 4))) {
+    if (a.hd == 64 && nkt <= 8 && nqt <= 8 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 4)) {
         const int lds = 3 * 256 * 128 + 16 * 2048 + 2 * 256 * 4;
         if (a.m_qs) {      // per-query mask: the one-pass kernel only
             if (int rc = set_lds(attn_bwd_fused_kernel<64, 8, MASK_QUERY>, lds)) return rc;
@@ -1333,7 +1345,8 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         if (int rc = set_lds(attn_bwd_dq_kernel<N, DD, CZ>, lds)) return rc;                     \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);         \
     }
-        if (a.hd == 128) { if (nkt <= 4) LAUNCH_DQ(4, 128, false) else LAUNCH_DQ(8, 128, false) }
+        if (a.m_qs) LAUNCH_DQ(16, 64, MASK_QUERY)      // a per-query mask where the one-pass kernel does not run (beyond 256 positions): one 16-tile form
+        else if (a.hd == 128) { if (nkt <= 4) LAUNCH_DQ(4, 128, false) else LAUNCH_DQ(8, 128, false) }
         else if (nkt <= 4) { if (cz) LAUNCH_DQ(4, 64, true) else LAUNCH_DQ(4, 64, false) }
         else if (nkt <= 8) { if (cz) LAUNCH_DQ(8, 64, true) else LAUNCH_DQ(8, 64, false) }
         else { if (cz) LAUNCH_DQ(16, 64, true) else LAUNCH_DQ(16, 64, false) }      // 257 .. 512 keys: K, V whole in LDS (128 KB), one workgroup per CU
@@ -1348,7 +1361,8 @@ extern "C" int mmf_attention_bwd(const mmf_attn_bwd_desc* d, void* stream) {
         if (int rc = set_lds(attn_bwd_dkv_kernel<N, DD, CZ>, lds)) return rc;                    \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, DD, CZ>), grid, dim3(256), lds, s, a);        \
     }
-        if (a.hd == 128) { if (nqt <= 4) LAUNCH_DKV(4, 128, false) else LAUNCH_DKV(8, 128, false) }
+        if (a.m_qs) LAUNCH_DKV(16, 64, MASK_QUERY)
+        else if (a.hd == 128) { if (nqt <= 4) LAUNCH_DKV(4, 128, false) else LAUNCH_DKV(8, 128, false) }
         else if (nqt <= 4) { if (cz) LAUNCH_DKV(4, 64, true) else LAUNCH_DKV(4, 64, false) }
         else if (nqt <= 8) { if (cz) LAUNCH_DKV(8, 64, true) else LAUNCH_DKV(8, 64, false) }
         else { if (cz) LAUNCH_DKV(16, 64, true) else LAUNCH_DKV(16, 64, false) }    // 257 .. 512 queries: Q, dO whole in LDS

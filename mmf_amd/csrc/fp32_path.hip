@@ -434,6 +434,128 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
     }
 }
 
+// More keys than one LDS image holds (head_dim 64: 257 .. 512 keys, head_dim 128: 129 .. 256 — what the bf16 kernels run, BERT's
+// max_position_embeddings): K / V are staged in blocks of 16 * MAXT keys and the score tiles are computed TWICE instead of being held in
+// registers — pass 1 finds each query's row maximum over all blocks (K blocks only), pass 2 recomputes a block's scores, exponentiates against
+// that maximum, accumulates the row sum and P.V.  The softmax stays the reference's exact two-pass form (max, then sum of exp(x - max)); same
+// operand layouts, masks, dropout indices and output as attn_f32_fwd_kernel.
+template <int D, int MAXT>
+__global__ __launch_bounds__(512) void attn_f32_fwd_long_kernel(const AttnF32 a) {
+    constexpr int RS = D + 4, NM = D / 16, KB = 16 * MAXT;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ float att_smem[];
+    float* Ks = att_smem;
+    float* Vs = Ks + KB * RS;
+    float* Ms = Vs + KB * RS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int q0 = blockIdx.x * 128 + wave * 16;
+    const bool active = q0 < a.Sq;                // (idle waves run along to the barriers)
+    const int nblk = (a.Sk + KB - 1) / KB;
+    const int qme = q0 + j;
+    const int qcl = min(qme, a.Sq - 1);
+    f32x4 qv[NM];
+    {
+        const float* qp = a.q + ((size_t)b * a.Sq + qcl) * a.ldq + h * D + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) qv[m] = *reinterpret_cast<const f32x4*>(qp + 16 * m);
+    }
+    auto stage = [&](int kb, bool with_v) {
+        constexpr int QPR = D / 4;
+        const int key0 = kb * KB, nt = min(MAXT, (a.Sk - key0 + 15) >> 4);
+        for (int idx = threadIdx.x; idx < nt * 16 * QPR; idx += 512) {
+            const int lk = idx / QPR, qd = idx - lk * QPR;
+            const int kr = min(key0 + lk, a.Sk - 1);
+            *reinterpret_cast<f32x4*>(Ks + lk * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D + 4 * qd);
+            if (with_v) *reinterpret_cast<f32x4*>(Vs + lk * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.v + ((size_t)b * a.Sk + kr) * a.ldv + h * D + 4 * qd);
+        }
+        for (int lk = threadIdx.x; lk < nt * 16; lk += 512)
+            Ms[lk] = key0 + lk < a.Sk ? ((a.mask && !a.mqs) ? a.mask[(size_t)b * a.Sk + key0 + lk] * LOG2E : 0.f) : -INFINITY;
+        return nt;
+    };
+    const float sl2 = a.scale * LOG2E;
+    // x[r] = masked, scaled score (log2 units) of (query q0 + j, key key0 + 16 t + 4 g + r)
+    auto scores = [&](int key0, int t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* kr = Ks + (16 * t + j) * RS + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const f32x4 kq = *reinterpret_cast<const f32x4*>(kr + 16 * m);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[c], qv[m][c], acc, 0, 0, 0);
+        }
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + 16 * t + 4 * g);
+        f32x4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 16 * t + 4 * g + r;
+            float madd = mk[r];
+            if (a.mqs) madd = query_mask(a, b, qcl, key);
+            if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
+            x[r] = acc[r] * sl2 + madd;
+        }
+        return x;
+    };
+    float mx = -INFINITY;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int nt = stage(kb, false);
+        __syncthreads();
+        if (active) {
+#pragma unroll 2
+            for (int t = 0; t < nt; ++t) {
+                const f32x4 x = scores(kb * KB, t);
+                mx = fmaxf(fmaxf(mx, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+            }
+        }
+        __syncthreads();
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    f32x4 oc[NM];
+#pragma unroll
+    for (int eb = 0; eb < NM; ++eb) oc[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int nt = stage(kb, true);
+        __syncthreads();
+        if (active) {
+#pragma unroll 2
+            for (int t = 0; t < nt; ++t) {
+                f32x4 pr = scores(kb * KB, t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(pr[r] - mx);
+                    sum += p;
+                    pr[r] = a.drop.thr16 ? p * attn_drop(a, dkey, bh, qcl, min(kb * KB + 16 * t + 4 * g + r, a.Sk - 1)) : p;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* vr = Vs + (16 * t + 4 * g + c) * RS + j;
+#pragma unroll
+                    for (int eb = 0; eb < NM; ++eb) oc[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[c], vr[16 * eb], oc[eb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (a.lse && g == 0 && qme < a.Sq) a.lse[(size_t)bh * a.Sq + qme] = mx + __builtin_amdgcn_logf(sum);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float inv = 1.0f / __shfl(sum, 4 * g + r, 64);
+        const int qr = q0 + 4 * g + r;
+        if (qr < a.Sq) {
+            float* op = a.out + ((size_t)b * a.Sq + qr) * a.ldo + h * D + j;
+#pragma unroll
+            for (int eb = 0; eb < NM; ++eb) op[16 * eb] = oc[eb][r] * inv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // attention backward, fp32 (fp32 training: the reference's default arithmetic, training_loop.py:199-211), two launches built like the
 // forward.  With P = softmax(S), Pd = dropout(P), O = Pd V:   dPd = dO V^T,  delta = rowsum(dO o O),  dS = P o (dropmask o dPd - delta),
@@ -458,19 +580,23 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
     const int j = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
     const int q0 = blockIdx.x * 128 + wave * 16;
-    const int nt = (a.Sk + 15) >> 4;
-    {
+    // keys in blocks of 16 * MAXT (one block = one LDS image; more than one beyond 256 / 128 keys: same arithmetic, dQ accumulates across blocks)
+    constexpr int KB = 16 * MAXT;
+    const int nblk = (a.Sk + KB - 1) / KB;
+    auto stage = [&](int kb) {
         constexpr int QPR = D / 4;
-        const int quads = nt * 16 * QPR;
-        for (int idx = threadIdx.x; idx < quads; idx += 512) {
-            const int key = idx / QPR, qd = idx - key * QPR;
-            const int kr = min(key, a.Sk - 1);
-            *reinterpret_cast<f32x4*>(Ks + key * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D + 4 * qd);
-            *reinterpret_cast<f32x4*>(Vs + key * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.v + ((size_t)b * a.Sk + kr) * a.ldv + h * D + 4 * qd);
+        const int key0 = kb * KB, nt = min(MAXT, (a.Sk - key0 + 15) >> 4);
+        for (int idx = threadIdx.x; idx < nt * 16 * QPR; idx += 512) {
+            const int lk = idx / QPR, qd = idx - lk * QPR;
+            const int kr = min(key0 + lk, a.Sk - 1);
+            *reinterpret_cast<f32x4*>(Ks + lk * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.k + ((size_t)b * a.Sk + kr) * a.ldk + h * D + 4 * qd);
+            *reinterpret_cast<f32x4*>(Vs + lk * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.v + ((size_t)b * a.Sk + kr) * a.ldv + h * D + 4 * qd);
         }
-        for (int key = threadIdx.x; key < nt * 16; key += 512)
-            Ms[key] = key < a.Sk ? ((a.mask && !a.mqs) ? a.mask[(size_t)b * a.Sk + key] * LOG2E : 0.f) : -INFINITY;
-    }
+        for (int lk = threadIdx.x; lk < nt * 16; lk += 512)
+            Ms[lk] = key0 + lk < a.Sk ? ((a.mask && !a.mqs) ? a.mask[(size_t)b * a.Sk + key0 + lk] * LOG2E : 0.f) : -INFINITY;
+        return nt;
+    };
+    int nt = stage(0);
     const int qme = min(q0 + j, a.Sq - 1);
     f32x4 qv[NM], dov[NM];
     float dl = 0.f;
@@ -491,8 +617,9 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);                 // delta of query q0 + j
     __syncthreads();
-    if (q0 >= a.Sq) return;
-    if (g == 0 && q0 + j < a.Sq) a.delta[(size_t)bh * a.Sq + q0 + j] = dl;
+    const bool active = q0 < a.Sq;
+    if (!active && nblk == 1) return;           // (one block: no barrier below; more: idle waves run along to the barriers)
+    if (active && g == 0 && q0 + j < a.Sq) a.delta[(size_t)bh * a.Sq + q0 + j] = dl;
     const float lse = a.lse[(size_t)bh * a.Sq + qme];
     const float sl2 = a.scale * LOG2E;
     const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
@@ -500,6 +627,10 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
     f32x4 dq[NM];
 #pragma unroll
     for (int eb = 0; eb < NM; ++eb) dq[eb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < nblk; ++kb) {
+    if (kb) { __syncthreads(); nt = stage(kb); __syncthreads(); }
+    const int key0 = kb * KB;
+    if (active)
 #pragma unroll 2
     for (int t = 0; t < nt; ++t) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -519,7 +650,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
         f32x4 ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = 16 * t + 4 * g + r;
+            const int key = key0 + 16 * t + 4 * g + r;
             float madd = mk[r];
             if (a.mqs) madd = query_mask(a, b, qme, key);
             if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
@@ -534,6 +665,8 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
             for (int eb = 0; eb < NM; ++eb) dq[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[c], kc[16 * eb], dq[eb], 0, 0, 0);
         }
     }
+  }
+    if (!active) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qr = q0 + 4 * g + r;
@@ -558,21 +691,25 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
     const int j = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
     const int k0 = blockIdx.x * 128 + wave * 16;
-    const int nq = (a.Sq + 15) >> 4;
-    {
+    // queries in blocks of 16 * MAXT (one block = one LDS image; more than one beyond 256 / 128 queries: dK / dV accumulate across blocks)
+    constexpr int QB = 16 * MAXT;
+    const int nblk = (a.Sq + QB - 1) / QB;
+    auto stage = [&](int qb) {
         constexpr int QPR = D / 4;
-        const int quads = nq * 16 * QPR;
-        for (int idx = threadIdx.x; idx < quads; idx += 512) {
-            const int q = idx / QPR, qd = idx - q * QPR;
-            const int qr = min(q, a.Sq - 1);
-            *reinterpret_cast<f32x4*>(Qs + q * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.Sq + qr) * a.ldq + h * D + 4 * qd);
-            *reinterpret_cast<f32x4*>(Os + q * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.d_o + ((size_t)b * a.Sq + qr) * a.ldo + h * D + 4 * qd);
+        const int qs0 = qb * QB, nq_ = min(MAXT, (a.Sq - qs0 + 15) >> 4);
+        for (int idx = threadIdx.x; idx < nq_ * 16 * QPR; idx += 512) {
+            const int lq = idx / QPR, qd = idx - lq * QPR;
+            const int qr = min(qs0 + lq, a.Sq - 1);
+            *reinterpret_cast<f32x4*>(Qs + lq * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.Sq + qr) * a.ldq + h * D + 4 * qd);
+            *reinterpret_cast<f32x4*>(Os + lq * RS + 4 * qd) = *reinterpret_cast<const f32x4*>(a.d_o + ((size_t)b * a.Sq + qr) * a.ldo + h * D + 4 * qd);
         }
-        for (int q = threadIdx.x; q < nq * 16; q += 512) {
-            Ls[q] = q < a.Sq ? a.lse[(size_t)bh * a.Sq + q] : INFINITY;
-            Ds[q] = q < a.Sq ? a.delta[(size_t)bh * a.Sq + q] : 0.f;
+        for (int lq = threadIdx.x; lq < nq_ * 16; lq += 512) {
+            Ls[lq] = qs0 + lq < a.Sq ? a.lse[(size_t)bh * a.Sq + qs0 + lq] : INFINITY;
+            Ds[lq] = qs0 + lq < a.Sq ? a.delta[(size_t)bh * a.Sq + qs0 + lq] : 0.f;
         }
-    }
+        return nq_;
+    };
+    int nq = stage(0);
     const int kme = k0 + j;                        // this lane's key
     const int kcl = min(kme, a.Sk - 1);
     f32x4 kv[NM], vv[NM];
@@ -583,7 +720,8 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
         for (int m = 0; m < NM; ++m) { kv[m] = *reinterpret_cast<const f32x4*>(kp + 16 * m); vv[m] = *reinterpret_cast<const f32x4*>(vp + 16 * m); }
     }
     __syncthreads();
-    if (k0 >= a.Sk) return;
+    const bool active = k0 < a.Sk;
+    if (!active && nblk == 1) return;
     const float sl2 = a.scale * LOG2E;
     const float mkey = kme < a.Sk ? ((a.mask && !a.mqs) ? a.mask[(size_t)b * a.Sk + kme] * LOG2E : 0.f) : -INFINITY;
     const bool tail = kme >= a.cfrom && kme < a.Sk;
@@ -592,6 +730,10 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
     f32x4 dk[NM], dv[NM];
 #pragma unroll
     for (int eb = 0; eb < NM; ++eb) { dk[eb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[eb] = dk[eb]; }
+  for (int qb = 0; qb < nblk; ++qb) {
+    if (qb) { __syncthreads(); nq = stage(qb); __syncthreads(); }
+    const int qs0 = qb * QB;
+    if (active)
 #pragma unroll 2
     for (int u = 0; u < nq; ++u) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -612,7 +754,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
         f32x4 pd, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int q = 16 * u + 4 * g + r;
+            const int q = qs0 + 16 * u + 4 * g + r;
             float madd = mkey;
             if (a.mqs) madd = query_mask(a, b, min(q, a.Sq - 1), kme);       // (padded query rows carry lse = +inf: p = 0 whatever is read for them)
             if (tail) madd = (q >= a.cfrom && kme <= q) ? 0.f : -10000.f * LOG2E;
@@ -632,6 +774,8 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
             }
         }
     }
+  }
+    if (!active) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int kr = k0 + 4 * g + r;
@@ -874,6 +1018,14 @@ static int launch_attn_f32(const AttnF32& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_fwd_kernel<D, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         once = true;
     }
+    if (a.Sk > 16 * MAXT) {     // more keys than one LDS image: the blocked two-pass form
+        static bool once_long = false;
+        if (!once_long) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_fwd_long_kernel<D, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            once_long = true;
+        }
+        hipLaunchKernelGGL((attn_f32_fwd_long_kernel<D, MAXT>), dim3((a.Sq + 127) / 128, a.B * a.heads), dim3(512), lds, s, a);
+    } else
     hipLaunchKernelGGL((attn_f32_fwd_kernel<D, MAXT>), dim3((a.Sq + 127) / 128, a.B * a.heads), dim3(512), lds, s, a);
     MMF_CHECK_LAUNCH();
     return 0;
@@ -884,7 +1036,7 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
     MMF_CHECK_ARG(d->B > 0 && d->heads > 0 && d->Sq > 0 && d->Sk > 0, "attention_f32_fwd: empty problem");
     const int hd = d->head_dim ? d->head_dim : 64;
     MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_fwd: head_dim must be 64 or 128");
-    MMF_CHECK_ARG(d->Sk <= (hd == 64 ? 256 : 128), "attention_f32_fwd: Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
+    MMF_CHECK_ARG(d->Sk <= (hd == 64 ? 512 : 256) && d->Sq <= (hd == 64 ? 512 : 256), "attention_f32_fwd: Sq, Sk <= 512 (head_dim 64) / 256 (head_dim 128), like the bf16 kernels");
     MMF_CHECK_ARG(d->mask_query_stride == 0 || (d->mask && d->mask_query_stride >= d->Sk && d->causal_tail == 0),
                   "attention_f32_fwd: mask_query_stride must cover a mask row (>= Sk) and replaces the causal tail");
     MMF_CHECK_ARG(!d->ctx_f32 && d->q_batch_rows == 0 && d->kv_batch_rows == 0 && (d->mask_batch_stride == 0 || d->mask_query_stride != 0),
@@ -934,8 +1086,8 @@ extern "C" int mmf_attention_f32_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     MMF_CHECK_ARG(f->B > 0 && f->heads > 0 && f->Sq > 0 && f->Sk > 0, "attention_f32_bwd: empty problem");
     const int hd = f->head_dim ? f->head_dim : 64;
     MMF_CHECK_ARG(hd == 64 || hd == 128, "attention_f32_bwd: head_dim must be 64 or 128");
-    const int smax = hd == 64 ? 256 : 128;
-    MMF_CHECK_ARG(f->Sk <= smax && f->Sq <= smax, "attention_f32_bwd: Sq, Sk <= 256 (head_dim 64) / 128 (head_dim 128)");
+    const int smax = hd == 64 ? 512 : 256;
+    MMF_CHECK_ARG(f->Sk <= smax && f->Sq <= smax, "attention_f32_bwd: Sq, Sk <= 512 (head_dim 64) / 256 (head_dim 128), like the bf16 kernels");
     MMF_CHECK_ARG(f->mask_query_stride == 0 || (f->mask && f->mask_query_stride >= f->Sk && f->causal_tail == 0),
                   "attention_f32_bwd: mask_query_stride must cover a mask row (>= Sk) and replaces the causal tail");
     MMF_CHECK_ARG(!f->ctx_f32 && f->q_batch_rows == 0 && f->kv_batch_rows == 0 && (f->mask_batch_stride == 0 || f->mask_query_stride != 0),

@@ -224,6 +224,25 @@ __global__ __launch_bounds__(256) void expand_batch_kernel(const bf16* __restric
     const long src = mode == 0 ? sample % Bs : sample / reps;
     reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(x)[src * n8 + c];
 }
+// fp32 activations (mmf_amd.fp32_training() / fp32_inference(): the reference's default arithmetic): 16-byte chunks of four floats
+__global__ __launch_bounds__(256) void expand_batch_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long Bs, long reps, long n4, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= reps * Bs * n4) return;
+    const long sample = i / n4, c = i - sample * n4;
+    const long src = mode == 0 ? sample % Bs : sample / reps;
+    reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(x)[src * n4 + c];
+}
+__global__ __launch_bounds__(256) void reduce_batch_f32_kernel(const float* __restrict__ g, float* __restrict__ dx, long Bs, long reps, long n4, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Bs * n4) return;
+    const long s = i / n4, c = i - s * n4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long r = 0; r < reps; ++r) {       // fixed order: the sum torch.expand's backward forms, reproducible
+        const long sample = mode == 0 ? r * Bs + s : s * reps + r;
+        acc += reinterpret_cast<const f32x4*>(g)[sample * n4 + c];
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = acc;
+}
 __global__ __launch_bounds__(256) void reduce_batch_kernel(const bf16* __restrict__ g, bf16* __restrict__ dx, long Bs, long reps, long n8, int mode) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;            // over Bs * n8 chunks
     if (i >= Bs * n8) return;
@@ -336,6 +355,20 @@ int mmf_expand_batch_bf16(const void* x, void* out, int64_t Bs, int64_t reps, in
     const long total = reps * Bs * (n / 8);
     hipLaunchKernelGGL(expand_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, (long)Bs,
                        (long)reps, (long)(n / 8), mode);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_expand_batch_f32(const float* x, float* out, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream) {
+    MMF_CHECK_ARG(x && out && Bs > 0 && reps > 0 && n > 0 && (n % 4) == 0 && (mode == 0 || mode == 1), "expand_batch_f32: bad operand (n % 4 == 0, mode 0 / 1)");
+    const long total = reps * Bs * (n / 4);
+    hipLaunchKernelGGL(expand_batch_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)Bs, (long)reps, (long)(n / 4), mode);
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+int mmf_reduce_batch_f32(const float* g, float* dx, int64_t Bs, int64_t reps, int64_t n, int mode, void* stream) {
+    MMF_CHECK_ARG(g && dx && Bs > 0 && reps > 0 && n > 0 && (n % 4) == 0 && (mode == 0 || mode == 1), "reduce_batch_f32: bad operand (n % 4 == 0, mode 0 / 1)");
+    const long total = Bs * (n / 4);
+    hipLaunchKernelGGL(reduce_batch_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, dx, (long)Bs, (long)reps, (long)(n / 4), mode);
     MMF_CHECK_LAUNCH();
     return 0;
 }

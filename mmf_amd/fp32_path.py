@@ -181,8 +181,8 @@ def visio_linguistic_embeddings(input_ids, token_type_ids, feats, vtype, word, p
 def _check_head(hd, Sk):
     if hd not in (64, 128):
         raise NotImplementedError("fp32 path: the attention kernel is built for head_dim 64 and 128, got %d" % hd)
-    if Sk > (256 if hd == 64 else 128):
-        raise NotImplementedError("fp32 path: %d keys exceed what one workgroup stages (256 at head_dim 64, 128 at head_dim 128)" % Sk)
+    if Sk > (512 if hd == 64 else 256):      # (beyond 256 / 128 keys the kernels stage K / V in blocks; the cap is the bf16 kernels' own)
+        raise NotImplementedError("fp32 path: %d positions exceed what the attention kernels take (512 at head_dim 64, 256 at head_dim 128)" % Sk)
 
 
 def _attn_mask(mask_add, B, S):
@@ -428,6 +428,15 @@ def _eltwise(op, a, b=None):
     out = torch.empty_like(a2)
     nat.eltwise_f32(op, a2, None if b is None else _rows(b), out)
     return out.view(a.shape)
+
+
+def expand_batch(x, reps, mode):
+    """ViLBERT's `in_batch_pairs` / `fast_mode` batch expansion (vilbert.py:678-725), forward only: [Bs, L, H] -> [reps * Bs, L, H]."""
+    Bs, L, H = x.shape
+    x2 = _rows(x)
+    out = torch.empty(reps * Bs * L, H, dtype=F32, device=x2.device)
+    nat.expand_batch(x2, out, Bs, reps, L * H, mode)
+    return out.view(reps * Bs, L, H)
 
 
 def eltwise_mul(a, b):

@@ -551,6 +551,32 @@ class EltwiseFn(torch.autograd.Function):
         return None, da.view(g.shape), db.view(g.shape)
 
 
+class ExpandBatchFn(torch.autograd.Function):
+    """ViLBERT's `in_batch_pairs` / `fast_mode` batch expansion (mmf/models/vilbert.py:678-725) on fp32 activations [Bs, L, H] -> [reps * Bs, L, H]
+    (mode 0: `unsqueeze(0).expand`, mode 1: `unsqueeze(1).expand`); backward = the sum over the broadcast index in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x, reps, mode):
+        Bs, L, H = x.shape
+        x2 = _rows(x)
+        out = torch.empty(reps * Bs * L, H, dtype=F32, device=x2.device)
+        nat.expand_batch(x2, out, Bs, reps, L * H, mode)
+        ctx.meta = (Bs, L, H, reps, mode)
+        return out.view(reps * Bs, L, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        Bs, L, H, reps, mode = ctx.meta
+        g2 = _grad2(g, H)
+        dx = torch.empty(Bs * L, H, dtype=F32, device=g2.device)
+        nat.reduce_batch(g2, dx, Bs, reps, L * H, mode)
+        return dx.view(Bs, L, H), None, None
+
+
+def expand_batch(x, reps, mode):
+    return ExpandBatchFn.apply(x, reps, mode)
+
+
 # ---- MMBT (mmf/models/mmbt.py) and the MMF Transformer backend (mmf/models/transformers/backends/huggingface.py) ------------------------------
 class MMBTEmbeddingsFn(torch.autograd.Function):
     """ModalEmbeddings.forward (mmbt.py:84-129) + the text BertEmbeddings (hf_layers.py:108-135), modal block first (mmbt.py:225): one fp32

@@ -55,13 +55,13 @@ class ModalEmbeddings(nn.Module):
 
 
 class MMBTModel(nn.Module):
-    """mmbt.py:132-324 (encoder mode)."""
+    """mmbt.py:132-324.  `config.is_decoder`: the padding mask times a causal mask over the modal + text positions (:260-272), handed to the
+    attention kernels as a materialised per-(query, key) mask (mmf_attn_desc.mask_query_stride); `encoder_hidden_states` are accepted and
+    unused, as in the reference (its BertLayerJit.forward never calls the `crossattention` block it builds, hf_layers.py:268-292)."""
 
     def __init__(self, config, transformer, encoder):
         super().__init__()
-        self.is_decoder = getattr(config, "is_decoder", False)
-        if self.is_decoder:
-            raise NotImplementedError("MMBT as a decoder (mmbt.py:244-266) is not built")
+        self.is_decoder = bool(getattr(config, "is_decoder", False))
         self.num_hidden_layers = config.num_hidden_layers
         self.transformer = transformer
         self.modal_encoder = ModalEmbeddings(config, encoder, transformer.embeddings)
@@ -115,6 +115,13 @@ class MMBTModel(nn.Module):
             am = torch.ones(B, S, dtype=torch.int64, device=dev)                            # :228-229
         else:
             am = torch.cat([torch.ones(B, L, dtype=torch.int64, device=dev), attention_mask.long()], dim=1)  # :232-238
+        if self.is_decoder:                                                                 # :260-272, then (1 - m) * -10000 (:283)
+            seq_ids = torch.arange(S, device=dev)
+            causal = seq_ids[None, :] <= seq_ids[:, None]                                   # [query, key]: key <= query
+            ext = (causal[None, :, :] & (am[:, None, :] != 0)).to(torch.float32)
+            encoder_outputs = self.transformer.encoder(hidden, ((1.0 - ext) * -10000.0).view(B, 1, S, S))
+            sequence_output = encoder_outputs[0]
+            return sequence_output, self.transformer.pooler(sequence_output), encoder_outputs[1:]
         mask_add = torch.empty(B, S, dtype=torch.float32, device=dev)
         Fn.nat.make_additive_mask(am.contiguous(), mask_add)                                # (1 - m) * -10000, :283
         encoder_outputs = self.transformer.encoder(hidden, mask_add.view(B, 1, 1, S))

@@ -338,20 +338,20 @@ class BertEncoder(nn.Module):
                 for idx in range(v_start, v_end):
                     image_embedding = self.v_layer[idx](image_embedding, image_attention_mask, txt_embedding, txt_attention_mask2)[0]
             if count == 0 and (self.in_batch_pairs or self.fast_mode):
-                if F32P.active() or F32T.active():
-                    raise NotImplementedError("fp32 path: in_batch_pairs / fast_mode are built on the bf16 path only")
+                # (the same broadcast on whichever arithmetic is active: bf16 activations, or the fp32 kernels of mmf_amd.fp32_training() / fp32_inference())
+                expand = F32T.expand_batch if F32T.active() else (F32P.expand_batch if F32P.active() else Fn.ExpandBatchFn.apply)
                 if self.in_batch_pairs:          # new batch size = batch_size ^ 2 (:678-710): pair (i, j) = text i with image j
                     B = txt_embedding.shape[0]
-                    image_embedding = Fn.ExpandBatchFn.apply(image_embedding, B, 0)
+                    image_embedding = expand(image_embedding, B, 0)
                     image_attention_mask = image_attention_mask.unsqueeze(0).expand(B, B, -1).reshape(B * B, -1).contiguous()
-                    txt_embedding = Fn.ExpandBatchFn.apply(txt_embedding, B, 1)
+                    txt_embedding = expand(txt_embedding, B, 1)
                     txt_attention_mask = txt_attention_mask.unsqueeze(1).expand(B, B, -1).reshape(B * B, -1).contiguous()
                 if self.fast_mode:               # one text against N images (:712-723)
                     N = image_embedding.shape[0]
                     if txt_embedding.shape[0] != N:
                         if txt_embedding.shape[0] != 1:
                             raise ValueError("fast_mode expands a text batch of 1 to the image batch (got %d texts, %d images)" % (txt_embedding.shape[0], N))
-                        txt_embedding = Fn.ExpandBatchFn.apply(txt_embedding, N, 0)
+                        txt_embedding = expand(txt_embedding, N, 0)
                         txt_attention_mask = txt_attention_mask.expand(N, -1).contiguous()
             if self.with_coattention:
                 image_embedding, txt_embedding, _ = self.c_layer[count](image_embedding, image_attention_mask, txt_embedding,

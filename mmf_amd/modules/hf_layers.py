@@ -248,6 +248,9 @@ class BertLayerJit(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.attention = BertAttentionJit(config)
+        self.is_decoder = bool(getattr(config, "is_decoder", False))
+        if self.is_decoder:      # hf_layers.py:268-271: built, never called by forward (:273-292) — parameters a decoder-mode checkpoint carries
+            self.crossattention = BertAttentionJit(config)
         self.intermediate = BertIntermediate(config)
         self.output = BertOutput(config)
 

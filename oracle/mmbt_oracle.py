@@ -48,6 +48,14 @@ def parameter_shapes(cfg):
         s[p + "attention.output.dense.bias"] = (H,)
         s[p + "attention.output.LayerNorm.weight"] = (H,)
         s[p + "attention.output.LayerNorm.bias"] = (H,)
+        if cfg.get("is_decoder", False):      # BertLayerJit builds a second attention block in decoder mode and never calls it (hf_layers.py:268-292)
+            for n in ("query", "key", "value"):
+                s[p + "crossattention.self.%s.weight" % n] = (H, H)
+                s[p + "crossattention.self.%s.bias" % n] = (H,)
+            s[p + "crossattention.output.dense.weight"] = (H, H)
+            s[p + "crossattention.output.dense.bias"] = (H,)
+            s[p + "crossattention.output.LayerNorm.weight"] = (H,)
+            s[p + "crossattention.output.LayerNorm.bias"] = (H,)
         s[p + "intermediate.dense.weight"] = (I, H)
         s[p + "intermediate.dense.bias"] = (I,)
         s[p + "output.dense.weight"] = (H, I)
@@ -112,7 +120,7 @@ def text_embeddings(sd, cfg, input_ids, token_type_ids, dropout_p=0.0):
 
 def mmbt_model(sd, cfg, input_modal, input_ids, start_tokens, end_tokens, attention_mask, token_type_ids,
                modal_token_type_ids, train=False):
-    """MMBTModel.forward, mmbt.py:176-318 (encoder, not decoder)."""
+    """MMBTModel.forward, mmbt.py:176-318; `cfg["is_decoder"]`: the causal mask of :260-272 on top of the padding mask."""
     hd = cfg["hidden_dropout_prob"] if train else 0.0
     ad = cfg["attention_probs_dropout_prob"] if train else 0.0
     modal = modal_embeddings(sd, cfg, input_modal, start_tokens, end_tokens, modal_token_type_ids, hd)  # :203-209
@@ -124,7 +132,13 @@ def mmbt_model(sd, cfg, input_modal, input_ids, start_tokens, end_tokens, attent
         attention_mask = torch.ones(hidden.shape[:-1], device=hidden.device)
     else:
         attention_mask = torch.cat([torch.ones(modal.shape[:-1], dtype=torch.long, device=hidden.device), attention_mask], dim=1)  # :232-238
-    ext = attention_mask[:, None, None, :].to(hidden.dtype)  # :268-270
+    if cfg.get("is_decoder", False):  # :260-272: key <= query, times the padding mask, [B, 1, S, S]
+        S = hidden.shape[1]
+        seq_ids = torch.arange(S, device=hidden.device)
+        causal = seq_ids[None, None, :].repeat(hidden.shape[0], S, 1) <= seq_ids[None, :, None]
+        ext = (causal[:, None, :, :] * attention_mask[:, None, None, :]).to(hidden.dtype)
+    else:
+        ext = attention_mask[:, None, None, :].to(hidden.dtype)  # :268-270
     ext = (1.0 - ext) * -10000.0  # :283
     vb = _vb_view(sd)
     for i in range(cfg["num_hidden_layers"]):  # :300-305

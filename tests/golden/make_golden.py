@@ -130,6 +130,10 @@ def main(align=False):
 MMBT_CASES = {
     "mmbt_small64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
                          max_position_embeddings=40, modal_hidden_size=72, num_labels=2, B=4, T=12, N=7, seed=21),
+    # MMBT as a decoder (mmbt.py:244-266: the padding mask times a causal mask over the modal + text positions; BertLayerJit then also owns an
+    # unused `crossattention` block, hf_layers.py:268-271)
+    "mmbt_decoder64": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=211,
+                           max_position_embeddings=40, modal_hidden_size=72, num_labels=2, B=4, T=12, N=7, seed=23, is_decoder=True),
 }
 
 
@@ -147,7 +151,7 @@ def make_mmbt():
         bcfg = BertConfig(hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
                           num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
                           vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"], type_vocab_size=2,
-                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12)
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12, is_decoder=bool(c.get("is_decoder", False)))
         mcfg = M.MMBTConfig(bcfg, num_labels=c["num_labels"], modal_hidden_size=c["modal_hidden_size"])
 
         class Holder(nn.Module):

@@ -47,6 +47,8 @@ def load_mmbt_case(name="mmbt_small64"):
         hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, modal_hidden_size=case["modal_hidden_size"],
         num_labels=case["num_labels"], use_modal_start_token=True, use_modal_end_token=True, num_segments=2,
         initializer_range=0.02)
+    if case.get("is_decoder", False):
+        cfg["is_decoder"] = True
     sample = {
         "input_ids": torch.from_numpy(z["in_input_ids"]), "input_mask": torch.from_numpy(z["in_input_mask"]),
         "segment_ids": torch.from_numpy(z["in_segment_ids"]), "image_feature_0": torch.from_numpy(z["in_image_feature_0"]),

@@ -68,7 +68,7 @@ def mmbt_model_config(cfg, **over):
             max_position_embeddings=cfg["max_position_embeddings"], type_vocab_size=cfg.get("type_vocab_size", 2),
             hidden_dropout_prob=cfg.get("hidden_dropout_prob", 0.1),
             attention_probs_dropout_prob=cfg.get("attention_probs_dropout_prob", 0.1), layer_norm_eps=cfg["layer_norm_eps"],
-            output_attentions=False, output_hidden_states=False)),
+            output_attentions=False, output_hidden_states=False, is_decoder=bool(cfg.get("is_decoder", False)))),
         losses=[dict(type="cross_entropy")])
     d.update(over)
     return Config(d)

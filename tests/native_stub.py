@@ -319,15 +319,16 @@ def _visual_masks(input_mask, image_dim, B, T, R, image_mask, attention_mask, vt
 
 
 def _expand_batch(x, out, Bs, reps, n, mode):
-    assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and mode in (0, 1)
+    assert x.dtype in (torch.bfloat16, torch.float32) and out.dtype == x.dtype and mode in (0, 1)
+    assert n % (8 if x.dtype == torch.bfloat16 else 4) == 0
     assert _room(x) >= Bs * n and _room(out) >= reps * Bs * n, "expand_batch: %d x %d x %d does not fit" % (reps, Bs, n)
-    calls.append(("expand_batch", Bs, reps, n, mode))
+    calls.append(("expand_batch" if x.dtype == torch.bfloat16 else "expand_batch_f32", Bs, reps, n, mode))
 
 
 def _reduce_batch(g, dx, Bs, reps, n, mode):
-    assert g.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and mode in (0, 1)
+    assert g.dtype in (torch.bfloat16, torch.float32) and dx.dtype == g.dtype and mode in (0, 1)
     assert _room(g) >= reps * Bs * n and _room(dx) >= Bs * n
-    calls.append(("reduce_batch", Bs, reps, n, mode))
+    calls.append(("reduce_batch" if g.dtype == torch.bfloat16 else "reduce_batch_f32", Bs, reps, n, mode))
 
 
 _CHECKED = {"expand_batch": _expand_batch, "reduce_batch": _reduce_batch, "visual_masks": _visual_masks, "mse_fwd": _mse_fwd, "mse_bwd": _mse_bwd, "wra_fwd": _wra_fwd, "wra_bwd": _wra_bwd, "soft_target_kl_fwd": _soft_kl_fwd, "soft_target_kl_bwd": _soft_kl_bwd, "vocab_cross_entropy_fwd": _vocab_ce_fwd, "vocab_cross_entropy_bwd": _vocab_ce_bwd, "gemm_f32": _gemm_f32, "attention_f32_fwd": _attention_f32_fwd, "attention_f32_bwd": _attention_f32_bwd, "layernorm_f32_fwd": _layernorm_f32_fwd,

@@ -124,9 +124,12 @@ def test_gemm_f32_rejects_what_it_does_not_compute():
 
 
 @pytest.mark.parametrize("B,heads,Sq,Sk,hd", [(2, 2, 24, 24, 64), (3, 2, 100, 100, 64), (2, 12, 228, 228, 64), (1, 1, 256, 256, 64), (2, 3, 40, 150, 64),
-                                              (2, 2, 1, 33, 64), (2, 8, 101, 101, 128), (2, 8, 101, 128, 128), (3, 2, 128, 37, 128), (1, 1, 1, 128, 128)])
+                                              (2, 2, 1, 33, 64), (2, 8, 101, 101, 128), (2, 8, 101, 128, 128), (3, 2, 128, 37, 128), (1, 1, 1, 128, 128),
+                                              (2, 3, 356, 356, 64), (1, 2, 512, 512, 64), (2, 2, 40, 300, 64), (2, 2, 300, 257, 64), (2, 2, 200, 200, 128),
+                                              (1, 2, 256, 129, 128), (2, 1, 3, 500, 64)])
 def test_attention_f32_matches_float64(B, heads, Sq, Sk, hd):
-    """head_dim 64 (Sk <= 256) and 128 (Sk <= 128: ViLBERT's image stream 8 x 128 and both co-attention directions)."""
+    """head_dim 64 and 128 (ViLBERT's image stream 8 x 128 and both co-attention directions); beyond 256 / 128 keys the blocked two-pass form
+    (attn_f32_fwd_long_kernel), up to the 512 / 256 positions the bf16 kernels run."""
     H = heads * hd
     scale = 1.0 / hd ** 0.5
     q, k, v = _rand(B * Sq, H, seed=1), _rand(B * Sk, H, seed=2), _rand(B * Sk, H, seed=3)
@@ -151,7 +154,7 @@ def test_attention_f32_matches_float64(B, heads, Sq, Sk, hd):
         torch.testing.assert_close(out2.cpu().double(), ref2, rtol=KERNEL_TOL, atol=KERNEL_TOL)
 
 
-@pytest.mark.parametrize("S,tail,hd", [(70, 12, 64), (228, 12, 64), (40, 40, 64), (128, 5, 128)])
+@pytest.mark.parametrize("S,tail,hd", [(70, 12, 64), (228, 12, 64), (40, 40, 64), (128, 5, 128), (300, 12, 64), (400, 200, 64)])
 def test_attention_f32_prefix_lm_tail(S, tail, hd):
     """M4C's prefix-LM mask (m4c.py:424-440) without the [B,1,L,L] tensor: the last `tail` keys are visible only to the tail's own
     queries, causally, whatever the key mask says; every other pair uses the key mask."""

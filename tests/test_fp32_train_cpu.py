@@ -51,13 +51,20 @@ def test_nlvr2_step_builds_an_fp32_graph():
     assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in model.parameters())     # the pooler is in use here
 
 
-def test_operators_without_an_fp32_backward_refuse():
-    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_pairs")          # `in_batch_pairs`: the batch expansion is on the bf16 path only
+def test_in_batch_pairs_builds_an_fp32_graph():
+    """ViLBERT's `in_batch_pairs` batch expansion (vilbert.py:678-710), refused in fp32 until round 5: the dry run issues the fp32 expansion kernels and
+    no bf16 one."""
+    z, case, cfg, sd, sample = G.load_vilbert_case("vilbert_pairs")
     model = MU.build_vilbert(cfg, sd, device="cpu")
     model.eval()
-    with native_stub.installed(), pytest.raises(NotImplementedError, match="fp32"):
+    with native_stub.installed() as calls:
         with mmf_amd.fp32_training():
-            model(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+            out = model(SampleList({k: v for k, v in sample.items() if k != "targets"}))
+        out["scores"].sum().backward()
+        names = [c[0] for c in calls]
+    B = sample["input_ids"].shape[0]
+    assert out["scores"].shape[0] == B * B and out["scores"].dtype == torch.float32
+    assert names.count("expand_batch_f32") == 2 and names.count("reduce_batch_f32") == 2 and "expand_batch" not in names and not (set(names) & BF16_KERNELS)
 
 
 def _fp32_step(model, sample, train=True):

@@ -724,8 +724,8 @@ def test_attention_length_caps_are_reported():
     with pytest.raises(NativeLibraryError, match="head_dim 128 is built for Sq, Sk <= 256"):
         nat().attention_fwd(q2, q2[:, 128:], q2[:, 256:], 384, 384, 384, None, torch.empty(300, 128, dtype=torch.bfloat16, device=DEV), 128,
                             torch.empty(1, 1, 300, device=DEV), 1, 1, 300, 300, 0.1, head_dim=128)
-    with pytest.raises(NativeLibraryError, match="per-query mask is built for Sq, Sk <= 256"):
-        nat().attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, torch.zeros(1, 300, 300, device=DEV), ctx, H, lse, 1, 1, 300, 300, 0.125)
+    # (a per-query mask runs at every length the key mask does since round 6: test_attention_per_query_mask_against_reference)
+    nat().attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, torch.zeros(1, 300, 300, device=DEV), ctx, H, lse, 1, 1, 300, 300, 0.125)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -794,10 +794,11 @@ def _attn_run(qkv, mask, B, heads, S, drop, tail=0):
     return ctx, c32, lse, dqkv
 
 
-@pytest.mark.parametrize("B,heads,S", [(2, 3, 228), (2, 2, 100), (1, 2, 182), (1, 1, 33), (1, 2, 256)])
+@pytest.mark.parametrize("B,heads,S", [(2, 3, 228), (2, 2, 100), (1, 2, 182), (1, 1, 33), (1, 2, 256), (2, 2, 300), (1, 2, 384), (1, 1, 512)])
 def test_attention_per_query_mask_against_reference(B, heads, S):
     """A materialised additive mask per (query, key) pair, [B, S, S] — `attention_scores + attention_mask` with a [B, 1, S, S] mask
-    (mmf/modules/hf_layers.py:187-190) — read by the forward kernels (both forms) and the one-pass backward: against fp32 torch."""
+    (mmf/modules/hf_layers.py:187-190) — read by the forward kernels (every form) and the backward (one-pass up to 256 positions, the dQ and dK / dV
+    kernels beyond: BERT's 512 max_position_embeddings): against fp32 torch."""
     H = heads * 64
     qkv = rnd(B * S, 3 * H, scale=1.0, seed=31)
     g = torch.Generator(device="cpu").manual_seed(S)
@@ -820,7 +821,7 @@ def test_attention_per_query_mask_against_reference(B, heads, S):
         close(split_heads(got_.contiguous(), B, S, heads), ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name)
 
 
-@pytest.mark.parametrize("B,heads,S,tail", [(2, 3, 228, 0), (2, 2, 96, 0), (2, 2, 182, 12), (1, 2, 64, 7)])
+@pytest.mark.parametrize("B,heads,S,tail", [(2, 3, 228, 0), (2, 2, 96, 0), (2, 2, 182, 12), (1, 2, 64, 7), (2, 2, 300, 0), (1, 2, 420, 30)])
 def test_attention_per_query_mask_is_bit_identical_to_the_structured_forms(B, heads, S, tail):
     """The same mask handed over as the key mask [B, S] (+ M4C's causal tail, mmf/models/m4c.py:424-440) and materialised as [B, S, S]: context,
     its fp32 copy, log-sum-exp and dQ | dK | dV are bit-identical, dropout included (same decisions: they depend on the element index only)."""
@@ -842,6 +843,26 @@ def test_attention_per_query_mask_is_bit_identical_to_the_structured_forms(B, he
     for name, x, y in zip(("ctx", "ctx32", "lse", "dqkv"), a, b_):
         assert torch.isfinite(x.float()).all(), name
         assert torch.equal(x, y), name
+
+
+@pytest.mark.parametrize("B,heads,S", [(2, 2, 228), (1, 2, 100)])
+def test_attention_per_query_mask_two_kernel_backward_matches_the_one_pass_kernel(B, heads, S):
+    """The dQ and dK / dV kernels read a per-query mask too (what runs beyond 256 positions); forced at a one-pass shape (MMF_TUN_ALT_FORMS bit 2)
+    their gradients equal the one-pass kernel's up to the bf16 rounding of differently ordered sums."""
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, scale=1.0, seed=51)
+    g = torch.Generator(device="cpu").manual_seed(S)
+    mask3 = ((torch.rand(B, S, S, generator=g) < 0.3).float() * -10000.0).to(DEV)
+    drop = nat().drop_cfg(0.1, 99)
+    outs = []
+    try:
+        for two in (False, True):
+            nat().set_tunable(nat().TUN_ALT_FORMS, 4 * int(two))
+            outs.append(_attn_run(qkv, mask3, B, heads, S, drop))
+    finally:
+        nat().set_tunable(nat().TUN_ALT_FORMS, 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    close(outs[1][3], outs[0][3], 2e-2, 2e-2 * float(outs[0][3].abs().max()), "dqkv")
 
 
 def test_attention_per_query_mask_is_refused_where_it_is_not_built():

@@ -211,6 +211,10 @@ typedef struct mmf_attn_desc {
                               load per lane — instead of hashing (8 of the forward's 31 us at the VQA2 shape), and does not write `keep_bits` (the same
                               launch drew that table too; hand it to the backward as before).  Same decisions, same outputs, bit for bit.
                               mmf_attention_keep_lanes_words(...) 32-bit words, 16-byte aligned. */
+    int mask_head_stride;  /* 0: one mask for all heads.  n > 0 (with mask_query_stride): `mask` holds one [Sq, Sk] mask per (sample, head) — what
+                              BertSelfAttentionJit.forward accepts as a [B, heads, S, S] attention_mask (the `+` of mmf/modules/hf_layers.py:187-190
+                              broadcasts whatever it is given) — entry (b, head, q, key) at mask[b * mask_batch_stride + head * n + q * mask_query_stride
+                              + key]; mask_batch_stride then defaults to heads * n.  Forward and backward, bf16 and fp32 kernels. */
 } mmf_attn_desc;
 int mmf_attention_fwd(const mmf_attn_desc* d, void* stream);
 /* The probability-dropout decisions of up to any number of attention sites in ONE launch, ahead of the kernels that use them (they

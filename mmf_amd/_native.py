@@ -50,7 +50,7 @@ class AttnDesc(C.Structure):
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("head_dim", C.c_int), ("ctx_f32", C.c_void_p), ("causal_tail", C.c_int),
         ("q_batch_rows", C.c_int), ("kv_batch_rows", C.c_int), ("mask_batch_stride", C.c_int), ("mask_query_stride", C.c_int),
-        ("keep_bits", C.c_void_p), ("keep_lanes", C.c_void_p),
+        ("keep_bits", C.c_void_p), ("keep_lanes", C.c_void_p), ("mask_head_stride", C.c_int),
     ]
 
 
@@ -341,12 +341,20 @@ def _attn_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, sc
     d = AttnDesc()
     _req(keep_bits, torch.int32, "keep_bits"); _req(keep_lanes, torch.int32, "keep_lanes")
     d.keep_bits, d.keep_lanes = _p(keep_bits), _p(keep_lanes)
-    # a 3-D mask [B, Sq, Sk] is a materialised additive mask per (query, key) pair (mmf_attn_desc.mask_query_stride); 2-D: the key mask [B, Sk]
-    d.mask_query_stride = int(mask.stride(1)) if (mask is not None and mask.dim() == 3) else 0
-    if d.mask_query_stride and not mask_batch_stride:
+    # a 3-D mask [B, Sq, Sk] is a materialised additive mask per (query, key) pair (mmf_attn_desc.mask_query_stride); 4-D [B, heads, Sq, Sk]: one such
+    # mask per head (mmf_attn_desc.mask_head_stride); 2-D: the key mask [B, Sk]
+    d.mask_query_stride, d.mask_head_stride = 0, 0
+    if mask is not None and mask.dim() == 4:
+        if tuple(mask.shape) != (B, heads, Sq, Sk) or mask.stride(3) != 1:
+            raise NativeLibraryError("a per-head attention mask must be [B, heads, Sq, Sk] with contiguous rows, got %s" % (tuple(mask.shape),))
+        d.mask_query_stride, d.mask_head_stride = int(mask.stride(2)), int(mask.stride(1))
+        mask_batch_stride = int(mask.stride(0)) if (B > 1 and mask.stride(0) != heads * mask.stride(1)) else 0       # (0 = the dense default; a custom value is forward only)
+    elif mask is not None and mask.dim() == 3:
+        d.mask_query_stride = int(mask.stride(1))
+    if d.mask_query_stride and not d.mask_head_stride and not mask_batch_stride:
         if tuple(mask.shape) != (B, Sq, Sk) or mask.stride(2) != 1:
             raise NativeLibraryError("a per-query attention mask must be [B, Sq, Sk] with contiguous rows, got %s" % (tuple(mask.shape),))
-        mask_batch_stride = int(mask.stride(0)) if mask.stride(0) != Sq * mask.stride(1) else 0
+        mask_batch_stride = int(mask.stride(0)) if (B > 1 and mask.stride(0) != Sq * mask.stride(1)) else 0       # (the stride of a size-1 batch dimension is arbitrary)
     d.causal_tail = int(causal_tail)
     d.q_batch_rows, d.kv_batch_rows, d.mask_batch_stride = int(q_batch_rows), int(kv_batch_rows), int(mask_batch_stride)
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):
@@ -773,6 +781,10 @@ def _attn_f32_desc(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, B, heads, Sq, Sk, sca
             raise NativeLibraryError("a per-query attention mask must be [B, Sq, Sk] with contiguous rows, got %s" % (tuple(mask.shape),))
         d.mask_query_stride = int(mask.stride(1))
         d.mask_batch_stride = int(mask.stride(0))
+    elif mask is not None and mask.dim() == 4:      # one [Sq, Sk] mask per head (mmf_attn_desc.mask_head_stride)
+        if tuple(mask.shape) != (B, heads, Sq, Sk) or mask.stride(3) != 1:
+            raise NativeLibraryError("a per-head attention mask must be [B, heads, Sq, Sk] with contiguous rows, got %s" % (tuple(mask.shape),))
+        d.mask_query_stride, d.mask_head_stride, d.mask_batch_stride = int(mask.stride(2)), int(mask.stride(1)), int(mask.stride(0))
     return d
 
 

@@ -201,6 +201,7 @@ struct AttnArgs {
     int cfrom;           // first key of the causal tail (== Sk when there is none), see mmf_attn_desc.causal_tail
     int q_bs, kv_bs, m_bs;   // rows between consecutive batches of q / of k, v / mask entries per batch (defaults Sq, Sk, Sk)
     int m_qs;                // per-query mask (mmf_attn_desc.mask_query_stride): mask entries between consecutive query rows; 0 = one mask row per batch
+    int m_hs;                // per-head mask (mmf_attn_desc.mask_head_stride): mask entries between consecutive heads of a sample; 0 = one mask for all heads
     float scale;
     DropoutCfg drop;
     uint32_t* keep;          // optional dropout keep-bit table (mmf_attn_desc.keep_bits): written by the forward kernels, read by attn_bwd_fused_kernel
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_fwd_kernel(AttnArgs
     }
     // Q fragments (B operand: column = query row), fetched while the K / V DMA is still in flight
     const int qrow = min(q0 + x, a.Sq - 1);
-    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)qrow * a.m_qs : nullptr;      // this lane's row of the per-query mask
-    const bool mvec = MQ && ((a.m_qs | a.m_bs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
+    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)head * a.m_hs + (size_t)qrow * a.m_qs : nullptr;      // this lane's row of the per-query mask
+    const bool mvec = MQ && ((a.m_qs | a.m_bs | a.m_hs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
     const bf16* qptr = a.q + ((size_t)b * a.q_bs + qrow) * a.ldq + head * HD;
     bf16x8 qf[NS];
 #pragma unroll
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs a) {
             lds_mask[i] = (i < a.Sk) ? (a.mask ? a.mask[(size_t)b * a.m_bs + i] * 1.4426950408889634f : 0.f) : -INFINITY;
     }
     const int qrow = min(q0 + x, a.Sq - 1);
-    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)qrow * a.m_qs : nullptr;
-    const bool mvec = MQ && ((a.m_qs | a.m_bs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
+    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)head * a.m_hs + (size_t)qrow * a.m_qs : nullptr;
+    const bool mvec = MQ && ((a.m_qs | a.m_bs | a.m_hs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
     const bf16* qptr = a.q + ((size_t)b * a.q_bs + qrow) * a.ldq + head * HD;
     bf16x8 qf[NS];
 #pragma unroll
@@ -688,8 +689,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dq_kernel(AttnA
     }
     // per-query operands straight from global memory, fetched while the K / V DMA is still in flight
     const int qrow = min(q0 + x, a.Sq - 1);
-    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)qrow * a.m_qs : nullptr;      // this lane's row of a per-query mask
-    const bool mvec = MQ && ((a.m_qs | a.m_bs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
+    const float* mrow = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)head * a.m_hs + (size_t)qrow * a.m_qs : nullptr;      // this lane's row of a per-query mask
+    const bool mvec = MQ && ((a.m_qs | a.m_bs | a.m_hs) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0;
     const bf16* qptr = a.q + ((size_t)b * a.Sq + qrow) * a.ldq + head * HD;
     const bf16* doptr = a.dctx + ((size_t)b * a.Sq + qrow) * a.ldo + head * HD;
     bf16x8 qf[NS], dof[NS];
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
 #pragma unroll
     for (int s = 0; s < NS; ++s) { kf[s] = frag_global(kptr, s, lane); vf[s] = frag_global(vptr, s, lane); }
     const float mk = kvalid ? ((a.mask && !MQ) ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
-    const float* mcol = MQ ? a.mask + (size_t)b * a.m_bs + krow : nullptr;       // this lane's key column of a per-query mask
+    const float* mcol = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)head * a.m_hs + krow : nullptr;       // this lane's key column of a per-query mask
     PROBE_AT(1);
     stage_wait();
     PROBE_AT(2);
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_fused_kernel(AttnArgs a) 
     for (int s = 0; s < NS; ++s) vf[s] = frag_global(vptr, s, lane);
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses VALU arbitration otherwise (MI355X_MICROARCH.md)
     const float mk = kvalid ? ((a.mask && !MQ) ? a.mask[(size_t)b * a.Sk + krow] * 1.4426950408889634f : 0.f) : -INFINITY;
-    const float* mcol = MQ ? a.mask + (size_t)b * a.m_bs + krow : nullptr;      // per-query mask: this lane's key column, one entry per query row
+    const float* mcol = MQ ? a.mask + (size_t)b * a.m_bs + (size_t)head * a.m_hs + krow : nullptr;      // per-query mask: this lane's key column, one entry per query row
     // delta[q] = sum_d dO[q][d] O[q][d] (two threads per query row, a contiguous half of the head slice each; from the fp32
     // copy of O when the forward kept one) and the log-sum-exp in the log2 domain; padded rows: lse = +inf -> p = 0
     {
@@ -1163,9 +1164,13 @@ int fill_args(const mmf_attn_desc* d, AttnArgs& a) {
     a.m_qs = d->mask_query_stride;
     MMF_CHECK_ARG(a.m_qs == 0 || (d->mask && a.m_qs >= d->Sk), "attention: mask_query_stride must cover a mask row (>= Sk)");
     MMF_CHECK_ARG(a.m_qs == 0 || (hd == 64 && d->causal_tail == 0), "attention: a per-query mask is built for head_dim 64 (and replaces the causal tail)");
-    a.m_bs = d->mask_batch_stride > 0 ? d->mask_batch_stride : (a.m_qs ? d->Sq * a.m_qs : d->Sk);
+    a.m_hs = d->mask_head_stride;
+    MMF_CHECK_ARG(a.m_hs == 0 || (a.m_qs != 0 && a.m_hs >= (d->Sq - 1) * a.m_qs + d->Sk),
+                  "attention: mask_head_stride goes with a per-query mask (mask_query_stride) and must cover one head's [Sq, Sk] mask");
+    a.m_bs = d->mask_batch_stride > 0 ? d->mask_batch_stride : (a.m_hs ? d->heads * a.m_hs : (a.m_qs ? d->Sq * a.m_qs : d->Sk));
     MMF_CHECK_ARG(a.q_bs >= d->Sq && a.kv_bs >= d->Sk && a.m_bs >= d->Sk, "attention: batch strides must cover the sequence");
-    MMF_CHECK_ARG(a.m_qs == 0 || a.m_bs >= (d->Sq - 1) * a.m_qs + d->Sk, "attention: mask_batch_stride must cover the per-query mask of a sample");
+    MMF_CHECK_ARG(a.m_qs == 0 || a.m_bs >= (a.m_hs ? (d->heads - 1) * a.m_hs : 0) + (d->Sq - 1) * a.m_qs + d->Sk,
+                  "attention: mask_batch_stride must cover the per-query mask of a sample");
     a.scale = d->scale;
     a.drop.key = d->drop_key; a.drop.thr16 = d->drop_thr16; a.drop.scale = d->drop_scale; a.drop.seed = d->drop_seed;
     a.dctx = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;

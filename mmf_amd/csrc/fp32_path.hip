@@ -294,6 +294,7 @@ struct AttnF32 {
     int B, heads, Sq, Sk;
     float scale;
     int cfrom;     // first key of the causal tail (== Sk: none)
+    int mhs;       // per-head mask (mmf_attn_desc.mask_head_stride): mask entries between the heads of a sample, 0 = one mask for all heads
     int mqs, mbs;  // per-query mask (mmf_attn_desc.mask_query_stride / mask_batch_stride): mask entries between query rows (0: the key mask [B, Sk]) / samples
     float* lse;    // [B, heads, Sq]: row maximum + log2(row sum) of the scaled scores in log2 units (training: saved for the backward)
     DropoutCfg drop;   // attention-probability dropout, element index ((b heads + head) Sq + q) Sk + key
@@ -303,8 +304,8 @@ struct AttnF32 {
 
 // additive mask of (query q, key) in log2 units for the per-query form (what BertSelfAttentionJit.forward accepts as a [B, 1, S, S] mask,
 // hf_layers.py:187-190); q is clamped by the caller, keys past Sk are padding
-DEVI float query_mask(const AttnF32& a, int b, int q, int key) {
-    return key < a.Sk ? a.mask[(size_t)b * a.mbs + (size_t)q * a.mqs + key] * 1.4426950408889634f : -INFINITY;
+DEVI float query_mask(const AttnF32& a, int b, int h, int q, int key) {
+    return key < a.Sk ? a.mask[(size_t)b * a.mbs + (size_t)h * a.mhs + (size_t)q * a.mqs + key] * 1.4426950408889634f : -INFINITY;
 }
 // keep-scale of the probability of (query q, key) under attention dropout (1 when dropout is off)
 DEVI float attn_drop(const AttnF32& a, uint32_t dkey, int bh, int q, int key) {
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_kernel(const AttnF32 a) {
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * t + 4 * g + r;
                 float madd = mk[r];
-                if (a.mqs) madd = query_mask(a, b, min(qme, a.Sq - 1), key);
+                if (a.mqs) madd = query_mask(a, b, h, min(qme, a.Sq - 1), key);
                 if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
                 const float x = acc[r] * sl2 + madd;
                 sc[t][r] = x;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(512) void attn_f32_fwd_long_kernel(const AttnF32 a)
         for (int r = 0; r < 4; ++r) {
             const int key = key0 + 16 * t + 4 * g + r;
             float madd = mk[r];
-            if (a.mqs) madd = query_mask(a, b, qcl, key);
+            if (a.mqs) madd = query_mask(a, b, h, qcl, key);
             if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
             x[r] = acc[r] * sl2 + madd;
         }
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dq_kernel(const AttnF32 a) {
         for (int r = 0; r < 4; ++r) {
             const int key = key0 + 16 * t + 4 * g + r;
             float madd = mk[r];
-            if (a.mqs) madd = query_mask(a, b, qme, key);
+            if (a.mqs) madd = query_mask(a, b, h, qme, key);
             if (key >= a.cfrom && key < a.Sk) madd = (qme >= a.cfrom && key <= qme) ? 0.f : -10000.f * LOG2E;
             const float p = __builtin_amdgcn_exp2f(s[r] * sl2 + madd - lse);
             const float m = a.drop.thr16 ? attn_drop(a, dkey, bh, qme, min(key, a.Sk - 1)) : 1.f;
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(512) void attn_f32_bwd_dkv_kernel(const AttnF32 a) 
         for (int r = 0; r < 4; ++r) {
             const int q = qs0 + 16 * u + 4 * g + r;
             float madd = mkey;
-            if (a.mqs) madd = query_mask(a, b, min(q, a.Sq - 1), kme);       // (padded query rows carry lse = +inf: p = 0 whatever is read for them)
+            if (a.mqs) madd = query_mask(a, b, h, min(q, a.Sq - 1), kme);       // (padded query rows carry lse = +inf: p = 0 whatever is read for them)
             if (tail) madd = (q >= a.cfrom && kme <= q) ? 0.f : -10000.f * LOG2E;
             const float p = __builtin_amdgcn_exp2f(s[r] * sl2 + madd - ls[r]);
             const float m = a.drop.thr16 ? attn_drop(a, dkey, bh, min(q, a.Sq - 1), kcl) : 1.f;
@@ -1054,8 +1055,10 @@ extern "C" int mmf_attention_f32_fwd(const mmf_attn_desc* d, void* stream) {
     a.mask = d->mask; a.B = d->B; a.heads = d->heads; a.Sq = d->Sq; a.Sk = d->Sk; a.scale = d->scale;
     a.cfrom = d->Sk - d->causal_tail;
     a.mqs = d->mask_query_stride;
-    a.mbs = d->mask_batch_stride > 0 ? d->mask_batch_stride : d->Sq * d->mask_query_stride;
-    MMF_CHECK_ARG(a.mqs == 0 || a.mbs >= (d->Sq - 1) * a.mqs + d->Sk, "attention_f32_fwd: mask_batch_stride must cover the per-query mask of a sample");
+    a.mhs = d->mask_head_stride;
+    MMF_CHECK_ARG(a.mhs == 0 || (a.mqs != 0 && a.mhs >= (d->Sq - 1) * a.mqs + d->Sk), "attention_f32_fwd: mask_head_stride goes with a per-query mask and must cover one head's [Sq, Sk] mask");
+    a.mbs = d->mask_batch_stride > 0 ? d->mask_batch_stride : (a.mhs ? d->heads * a.mhs : d->Sq * d->mask_query_stride);
+    MMF_CHECK_ARG(a.mqs == 0 || a.mbs >= (a.mhs ? (d->heads - 1) * a.mhs : 0) + (d->Sq - 1) * a.mqs + d->Sk, "attention_f32_fwd: mask_batch_stride must cover the per-query mask of a sample");
     a.lse = d->lse;
     a.drop = DropoutCfg{d->drop_key, d->drop_thr16, d->drop_scale, d->drop_seed};
     a.o = nullptr; a.d_o = nullptr; a.dq = a.dk = a.dv = a.delta = nullptr;
@@ -1104,8 +1107,10 @@ extern "C" int mmf_attention_f32_bwd(const mmf_attn_bwd_desc* d, void* stream) {
     a.ldq = f->ldq; a.ldk = f->ldk; a.ldv = f->ldv; a.ldo = f->ldo;
     a.mask = f->mask; a.B = f->B; a.heads = f->heads; a.Sq = f->Sq; a.Sk = f->Sk; a.scale = f->scale;
     a.mqs = f->mask_query_stride;
-    a.mbs = f->mask_batch_stride > 0 ? f->mask_batch_stride : f->Sq * f->mask_query_stride;
-    MMF_CHECK_ARG(a.mqs == 0 || a.mbs >= (f->Sq - 1) * a.mqs + f->Sk, "attention_f32_bwd: mask_batch_stride must cover the per-query mask of a sample");
+    a.mhs = f->mask_head_stride;
+    MMF_CHECK_ARG(a.mhs == 0 || (a.mqs != 0 && a.mhs >= (f->Sq - 1) * a.mqs + f->Sk), "attention_f32_bwd: mask_head_stride goes with a per-query mask and must cover one head's [Sq, Sk] mask");
+    a.mbs = f->mask_batch_stride > 0 ? f->mask_batch_stride : (a.mhs ? f->heads * a.mhs : f->Sq * f->mask_query_stride);
+    MMF_CHECK_ARG(a.mqs == 0 || a.mbs >= (a.mhs ? (f->heads - 1) * a.mhs : 0) + (f->Sq - 1) * a.mqs + f->Sk, "attention_f32_bwd: mask_batch_stride must cover the per-query mask of a sample");
     a.cfrom = f->Sk - f->causal_tail;
     a.lse = f->lse;
     a.drop = DropoutCfg{f->drop_key, f->drop_thr16, f->drop_scale, f->drop_seed};

@@ -609,7 +609,12 @@ void attn_desc(mmf_attn_desc& d, const Tensor& qkv, int64_t H, const Tensor& mas
     d.ldq = d.ldk = d.ldv = (int)(3 * H);
     if (mask.defined()) {
         req(mask, at::kFloat, "attention mask"); d.mask = mask.data_ptr<float>();
-        if (mask.dim() == 3) {      // materialised additive mask per (query, key) pair, [B, S, S] (mmf_attn_desc.mask_query_stride)
+        if (mask.dim() == 4) {      // one [S, S] mask per (sample, head), [B, heads, S, S] (mmf_attn_desc.mask_head_stride)
+            TORCH_CHECK(mask.size(0) == B && mask.size(1) == heads && mask.size(2) == S && mask.size(3) == S && mask.is_contiguous(),
+                        "mmf_amd: a per-head attention mask must be a contiguous [B, heads, S, S] tensor");
+            d.mask_query_stride = (int)S;
+            d.mask_head_stride = (int)(S * S);
+        } else if (mask.dim() == 3) {      // materialised additive mask per (query, key) pair, [B, S, S] (mmf_attn_desc.mask_query_stride)
             TORCH_CHECK(mask.size(0) == B && mask.size(1) == S && mask.size(2) == S && mask.is_contiguous(), "mmf_amd: a per-query attention mask must be a contiguous [B, S, S] tensor");
             d.mask_query_stride = (int)S;
         } else {

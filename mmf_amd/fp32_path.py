@@ -191,7 +191,11 @@ def _attn_mask(mask_add, B, S):
     if mask_add is None:
         return None
     m = mask_add.float()
-    return (m.reshape(B, S) if m.numel() == B * S else m.reshape(B, S, S)).contiguous()
+    if m.numel() == B * S:
+        return m.reshape(B, S).contiguous()
+    if m.numel() == B * S * S:
+        return m.reshape(B, S, S).contiguous()
+    return m.reshape(B, -1, S, S).contiguous()      # one [S, S] mask per head, [B, heads, S, S] (mmf_attn_desc.mask_head_stride)
 
 
 def transformer_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, mask_add, heads, eps1, eps2,

@@ -98,8 +98,10 @@ def additive_key_mask(attention_mask, batch, seq):
         return Fn.PrefixLMMask(additive_key_mask(attention_mask.key_mask, batch, seq), attention_mask.causal_tail)
     m = attention_mask
     if m.dim() == 4:
-        if m.shape[1] != 1:
-            raise NotImplementedError("a per-head attention mask [B, heads, S, S] is not read by the fused kernel (one mask per sample: [B,1,1,S] or [B,1,S,S])")
+        if m.shape[1] != 1:         # one [S, S] mask per head (mmf_attn_desc.mask_head_stride): handed on as it is, [B, heads, S, S]
+            if m.shape[0] != batch or tuple(m.shape[2:]) != (seq, seq):
+                raise ValueError("attention_mask of shape %s does not match hidden states [%d, %d, ...]" % (tuple(m.shape), batch, seq))
+            return m.float().contiguous()
         if m.shape[2] != 1:
             # A materialised additive mask per (query, key) pair, as `attention_scores + attention_mask` takes it (hf_layers.py:187-190;
             # MMT.forward builds one, m4c.py:424-440): the kernels read it from global memory (mmf_attn_desc.mask_query_stride).  For M4C's
@@ -271,9 +273,9 @@ class BertLayerJit(nn.Module):
         if attention_mask is not None:
             m = attention_mask
             if m.dim() == 4:
-                if m.shape[1] != 1:
-                    raise NotImplementedError("a per-head attention mask [B, heads, S, S] is not read by the fused kernel")
-                if m.shape[2] != 1:       # a materialised additive mask per (query, key) pair (see additive_key_mask)
+                if m.shape[1] != 1:       # one [S, S] mask per head, [B, heads, S, S] (mmf_attn_desc.mask_head_stride)
+                    m = m.reshape(B, -1, S, S)
+                elif m.shape[2] != 1:     # a materialised additive mask per (query, key) pair (see additive_key_mask)
                     m = m.reshape(B, S, S)
                 else:
                     m = m.reshape(B, S)

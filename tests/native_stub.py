@@ -88,10 +88,13 @@ def _attention_fwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk
     if mask is not None and mask.dim() == 3:       # a materialised per-query mask (mmf_attn_desc.mask_query_stride): head_dim 64, no causal tail beside it
         assert mask.dtype == torch.float32 and tuple(mask.shape) == (B, Sq, Sk) and mask.stride(2) == 1
         assert head_dim == 64 and causal_tail == 0 and not mask_batch_stride
+    elif mask is not None and mask.dim() == 4:     # one [Sq, Sk] mask per head (mmf_attn_desc.mask_head_stride)
+        assert mask.dtype == torch.float32 and tuple(mask.shape) == (B, heads, Sq, Sk) and mask.stride(3) == 1 and head_dim == 64 and causal_tail == 0
     elif mask is not None:
         assert mask.dtype == torch.float32 and mask.numel() >= (B - 1) * mb + Sk
     assert lse.numel() >= B * heads * Sq
-    calls.append(("attention_fwd", B, heads, Sq, Sk, causal_tail) + (("per-query mask",) if (mask is not None and mask.dim() == 3) else ()))
+    calls.append(("attention_fwd", B, heads, Sq, Sk, causal_tail) + (("per-query mask",) if (mask is not None and mask.dim() == 3) else ()) +
+                 (("per-head mask",) if (mask is not None and mask.dim() == 4) else ()))
 
 
 def _attention_bwd(q, k, v, ldq, ldk, ldv, mask, ctx, ldo, lse, B, heads, Sq, Sk, scale, dctx, dq, dk, dv, delta, drop=N.NO_DROP,

@@ -378,7 +378,7 @@ def test_a_layer_applied_twice_is_not_queued_twice(monkeypatch):
 
 def test_encoder_hands_a_materialised_per_query_mask_to_the_attention_kernels():
     """A [B, 1, S, S] additive attention mask (hf_layers.py:187-190 adds any broadcastable mask to the scores; m4c.py:424-440 builds one) reaches the
-    attention launches as a [B, S, S] tensor (mmf_attn_desc.mask_query_stride), forward and backward; a per-head mask is refused."""
+    attention launches as a [B, S, S] tensor (mmf_attn_desc.mask_query_stride), forward and backward; a [B, heads, S, S] mask goes on as one mask per head (mmf_attn_desc.mask_head_stride)."""
     from transformers import BertConfig
     from mmf_amd.modules.hf_layers import BertEncoderJit
     B, S, H = 2, 40, 128
@@ -392,5 +392,10 @@ def test_encoder_hands_a_materialised_per_query_mask_to_the_attention_kernels():
         del calls[:]
         out = enc(x, torch.zeros(B, 1, 1, S))[0]
         assert [c[-1] for c in calls if c[0] == "attention_fwd"] == [0, 0]          # the key-mask form: (…, causal_tail = 0), no per-query marker
-        with pytest.raises(NotImplementedError):
-            enc(x, torch.zeros(B, 2, S, S))
+        del calls[:]
+        out = enc(x, torch.zeros(B, 2, S, S))[0]
+        out.float().sum().backward()
+        att = [c for c in calls if c[0] in ("attention_fwd", "attention_bwd")]
+        assert len(att) == 4 and all(c[-1] == "per-head mask" for c in att), att
+        with pytest.raises((ValueError, RuntimeError)):
+            enc(x, torch.zeros(B, 2, S, S + 1))

@@ -427,6 +427,19 @@ def test_attention_f32_per_query_mask_matches_float64_autograd(B, heads, S, hd):
     nat.attention_f32_bwd(qc, kc, vc, H, H, H, mc, out, H, lse, B, heads, S, S, scale, doc, dq, dk, dv, delta, head_dim=hd)
     for name, got, want in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
         torch.testing.assert_close(got.cpu().double(), want, rtol=2 * KERNEL_TOL, atol=2 * KERNEL_TOL, msg=lambda m, n=name: n + ": " + m)
+    # one mask per head, [B, heads, S, S] (mmf_attn_desc.mask_head_stride)
+    vis4 = (torch.rand(B, heads, S, S) > 0.3).float()
+    vis4[:, :, torch.arange(S), torch.arange(S)] = 1
+    m4 = (1.0 - vis4) * -10000.0
+    qd2, kd2, vd2 = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref4 = _ref_attention(qd2, kd2, vd2, m4.double(), scale, B, heads, S, S, hd)
+    ref4.backward(do.double())
+    m4c = m4.cuda().contiguous()
+    nat.attention_f32_fwd(qc, kc, vc, H, H, H, m4c, out, H, B, heads, S, S, scale, head_dim=hd, lse=lse)
+    torch.testing.assert_close(out.cpu().double(), ref4.detach(), rtol=KERNEL_TOL, atol=KERNEL_TOL)
+    nat.attention_f32_bwd(qc, kc, vc, H, H, H, m4c, out, H, lse, B, heads, S, S, scale, doc, dq, dk, dv, delta, head_dim=hd)
+    for name, got, want in (("dq", dq, qd2.grad), ("dk", dk, kd2.grad), ("dv", dv, vd2.grad)):
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2 * KERNEL_TOL, atol=2 * KERNEL_TOL, msg=lambda m, n=name: "per-head " + n + ": " + m)
     # the same mask as a key mask (all queries alike) gives the key-mask kernels' result
     key_only = m3[:, :1, :].expand(B, S, S).contiguous().cuda()
     o1 = torch.empty_like(out); o2 = torch.empty_like(out)

@@ -865,6 +865,35 @@ def test_attention_per_query_mask_two_kernel_backward_matches_the_one_pass_kerne
     close(outs[1][3], outs[0][3], 2e-2, 2e-2 * float(outs[0][3].abs().max()), "dqkv")
 
 
+@pytest.mark.parametrize("B,heads,S", [(2, 3, 228), (2, 2, 100), (1, 2, 300), (1, 4, 33)])
+def test_attention_per_head_mask_against_reference(B, heads, S):
+    """One additive [S, S] mask per (sample, head), [B, heads, S, S] — what `attention_scores + attention_mask` (mmf/modules/hf_layers.py:187-190)
+    does with a mask that is not broadcast over the heads — read through mmf_attn_desc.mask_head_stride by every forward and backward form: against
+    fp32 torch; and a mask repeated over the heads gives the bits of the [B, S, S] form."""
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, scale=1.0, seed=61)
+    g = torch.Generator(device="cpu").manual_seed(S + heads)
+    vis = torch.rand(B, heads, S, S, generator=g) > 0.3
+    vis[:, :, torch.arange(S), torch.arange(S)] = True
+    mask4 = (((~vis).float() * -10000.0) + torch.rand(B, heads, S, S, generator=g) * 2.0 - 1.0).to(DEV).contiguous()
+    ctx, c32, lse, dqkv = _attn_run(qkv, mask4, B, heads, S, nat().NO_DROP)
+    qf = split_heads(qkv[:, :H].contiguous(), B, S, heads).requires_grad_(True)
+    kf = split_heads(qkv[:, H:2 * H].contiguous(), B, S, heads).requires_grad_(True)
+    vf = split_heads(qkv[:, 2 * H:].contiguous(), B, S, heads).requires_grad_(True)
+    s_ = torch.matmul(qf, kf.transpose(-1, -2)) * 0.125 + mask4
+    o_ref = torch.matmul(torch.softmax(s_, dim=-1), vf)
+    close(split_heads(ctx, B, S, heads), o_ref, 2e-2, 2e-2, "ctx")
+    close(lse, torch.logsumexp(s_, dim=-1), 1e-4, 2e-3, "lse")
+    o_ref.backward(split_heads(rnd(B * S, H, seed=77), B, S, heads))
+    for name, got_, ref_ in (("dq", dqkv[:, :H], qf.grad), ("dk", dqkv[:, H:2 * H], kf.grad), ("dv", dqkv[:, 2 * H:], vf.grad)):
+        close(split_heads(got_.contiguous(), B, S, heads), ref_, 3e-2, 3e-2 * float(ref_.abs().max()), name)
+    drop = nat().drop_cfg(0.1, 777)
+    a = _attn_run(qkv, mask4[:, 0].contiguous(), B, heads, S, drop)
+    b_ = _attn_run(qkv, mask4[:, :1].expand(B, heads, S, S).contiguous(), B, heads, S, drop)
+    for name, x, y in zip(("ctx", "ctx32", "lse", "dqkv"), a, b_):
+        assert torch.equal(x, y), name
+
+
 def test_attention_per_query_mask_is_refused_where_it_is_not_built():
     from mmf_amd._native import NativeLibraryError
     B, heads, S, H = 1, 1, 64, 128

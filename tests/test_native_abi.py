@@ -129,3 +129,36 @@ def test_python_site_tags_and_descriptor_mirror_match_the_header():
             c_fields.append(part.replace("*", " ").split()[-1])
     assert c_fields == [f[0] for f in _native.AttnDesc._fields_], (c_fields, [f[0] for f in _native.AttnDesc._fields_])
     assert int(re.search(r"#define MMF_MT_MAX (\d+)", header).group(1)) == _native.MT_MAX
+
+
+def test_every_ctypes_mirror_has_the_size_and_field_offsets_the_c_compiler_gives_the_header_struct(tmp_path):
+    """The ctypes structures of mmf_amd/_native.py are hand-written mirrors of include/mmf_amd.h: a field added to one side only (round 6 did that to
+    mmf_attn_draw_site for one commit) shifts every later field silently.  gcc compiles the header and prints sizeof / offsetof of every field of
+    every mirrored struct; the mirrors must agree."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"mmf_gemm_desc": _native.GemmDesc, "mmf_attn_desc": _native.AttnDesc, "mmf_attn_draw_site": _native.AttnDrawSite,
+             "mmf_attn_bwd_desc": _native.AttnBwdDesc, "mmf_adamw_multi_desc": _native.AdamWMultiDesc, "mmf_wra_desc": _native.WraDesc,
+             "mmf_ln_reduce_list": _native.LnReduceList, "mmf_tensor_list": _native.TensorList, "mmf_transpose_list": _native.TransposeList,
+             "mmf_offset_list": _native.OffsetList}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "mmf_amd.h"', 'int main(void) {']
+    for cname, mirror in pairs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f in mirror._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, f[0]))
+        lines.append('printf("\\n");')
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.dirname(_native.HEADER_PATH), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line in out:
+        parts = line.split()
+        mirror = pairs[parts[0]]
+        want = [int(x) for x in parts[1:]]
+        got = [C.sizeof(mirror)] + [getattr(mirror, f[0]).offset for f in mirror._fields_]
+        assert got == want, (parts[0], got, want)

@@ -270,23 +270,19 @@ def mmbt_embeddings(feats, input_ids, start_tok, end_tok, text_type_ids, modal_t
     dev = word.device
     y = torch.empty(B * S, H, dtype=F32, device=dev)
     wd, pd, td = _w(word), _w(pos), _w(typ)
-    if isinstance(modal_type, torch.Tensor):
-        mt = modal_type.detach().reshape(1).to(device=dev, dtype=torch.int64)
-    else:
-        mt = torch.full((1,), int(modal_type), dtype=torch.int64, device=dev)
-    mtype = mt.reshape(1, 1).expand(B, 1).contiguous()
+    from mmf_amd.functional import mmbt_modal_types
+    mt_st, mt_en, coladd, rowtab, rowidx, _, _ = mmbt_modal_types(modal_type, B, L, N, s0, dev, pd, td)
     if start_tok is not None:
-        nat.embed_text_f32_fwd(start_tok.reshape(B, 1).contiguous(), mtype, wd, pd, td, y, B, 1, S, H, 0, 0)
+        nat.embed_text_f32_fwd(start_tok.reshape(B, 1).contiguous(), mt_st, wd, pd, td, y, B, 1, S, H, 0, 0)
     if end_tok is not None:
-        nat.embed_text_f32_fwd(end_tok.reshape(B, 1).contiguous(), mtype, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
+        nat.embed_text_f32_fwd(end_tok.reshape(B, 1).contiguous(), mt_en, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
     nat.embed_text_f32_fwd(input_ids.contiguous(), text_type_ids.contiguous(), wd, pd, td, y, B, T, S, H, L, 0)
     f2 = feats.reshape(B * N, D)
     f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
     if D % 4:
         raise ValueError("fp32 path: modal feature width (%d) must be a multiple of 4" % D)
-    posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
-    nat.gemm_f32(f2, _w(proj_w), y, B * N, H, D, D, D, H, bias=_w(proj_b), coladd=td.index_select(0, mt).reshape(H), rowtab=pd,
-                 rowidx=posidx, rowtab_ld=H, grp=(N, S - N, s0))
+    nat.gemm_f32(f2, _w(proj_w), y, B * N, H, D, D, D, H, bias=_w(proj_b), coladd=coladd, rowtab=rowtab,
+                 rowidx=rowidx, rowtab_ld=H, grp=(N, S - N, s0))
     out = torch.empty(B * S, H, dtype=F32, device=dev)
     nat.layernorm_f32_fwd(y, _w(ln_w), _w(ln_b), out, B * S, H, eps)
     return out.view(B, S, H)

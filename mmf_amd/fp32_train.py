@@ -595,38 +595,39 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
         dev = word.device
         y = torch.empty(B * S, H, dtype=F32, device=dev)
         wd, pd, td = _w(word), _w(pos), _w(typ)
-        if isinstance(modal_type, torch.Tensor):
-            mt = modal_type.detach().reshape(1).to(device=dev, dtype=torch.int64)
-        else:
-            mt = torch.full((1,), int(modal_type), dtype=torch.int64, device=dev)
-        mtype = mt.reshape(1, 1).expand(B, 1).contiguous()
+        from mmf_amd.functional import mmbt_modal_types
+        mt_st, mt_en, coladd, rowtab, rowidx, mtype_rows, feat_types = mmbt_modal_types(modal_type, B, L, N, s0, dev, pd, td)
         ids = input_ids.contiguous(); tt = text_type_ids.contiguous()
         st = None if start_tok is None else start_tok.reshape(B, 1).contiguous()
         en = None if end_tok is None else end_tok.reshape(B, 1).contiguous()
         if st is not None:
-            nat.embed_text_f32_fwd(st, mtype, wd, pd, td, y, B, 1, S, H, 0, 0)
+            nat.embed_text_f32_fwd(st, mt_st, wd, pd, td, y, B, 1, S, H, 0, 0)
         if en is not None:
-            nat.embed_text_f32_fwd(en, mtype, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
+            nat.embed_text_f32_fwd(en, mt_en, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
         nat.embed_text_f32_fwd(ids, tt, wd, pd, td, y, B, T, S, H, L, 0)
         if D % 4:
             raise ValueError("fp32 path: modal feature width (%d) must be a multiple of 4" % D)
         f2 = feats.reshape(B * N, D)
         f2 = (f2 if f2.dtype == F32 else f2.float()).contiguous()
         posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
-        nat.gemm_f32(f2, _w(proj_w), y, B * N, H, D, D, D, H, bias=_w(proj_b), coladd=td.index_select(0, mt).reshape(H), rowtab=pd, rowidx=posidx,
+        nat.gemm_f32(f2, _w(proj_w), y, B * N, H, D, D, D, H, bias=_w(proj_b), coladd=coladd, rowtab=rowtab, rowidx=rowidx,
                      rowtab_ld=H, grp=(N, S - N, s0))
+        # the type ids of the start token rows, the end token rows and the N feature rows of every sample (one id repeated, or a caller's own)
+        if feat_types is None:
+            feat_types = mtype_rows[:, s0:s0 + N].reshape(-1).contiguous()
+        mt = torch.stack([mt_st.reshape(-1), mt_en.reshape(-1)]).contiguous()
         out, mean, rstd = _ln_fwd(y, ln_w, ln_b, eps)
         if drop[1]:
             o2 = torch.empty_like(out)
             nat.dropout_f32(out, o2, drop)
             out = o2
-        ctx.save_for_backward(ids, tt, st, en, mt, f2, posidx, y, mean, rstd, ln_w.detach())
+        ctx.save_for_backward(ids, tt, st, en, mt, f2, posidx, y, mean, rstd, ln_w.detach(), feat_types)
         ctx.meta = (B, N, T, H, s0, L, S, drop, pad_idx, word.shape[0], pos.shape[0], typ.shape[0])
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, g):
-        ids, tt, st, en, mt, f2, posidx, y, mean, rstd, ln_w = ctx.saved_tensors
+        ids, tt, st, en, mt, f2, posidx, y, mean, rstd, ln_w, feat_types = ctx.saved_tensors
         B, N, T, H, s0, L, S, drop, pad_idx, V, NP, NT = ctx.meta
         dev = y.device
         dy, dln_w, dln_b = _ln_bwd(_drop_bwd(_grad2(g, H), drop), y, mean, rstd, ln_w)
@@ -635,12 +636,11 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
 
         def rows(idx, tab, n, off, sk=-1):         # rows off .. off + n - 1 of every sample's block scattered into `tab` by idx [B * n]
             nat.scatter_add_rows_f32(dy, H, B * n, H, idx, tab, H, grp=(n, S, off), skip=sk)
-        mtb = mt.expand(B).contiguous()
-        for tok, off in ((st, 0), (en, s0 + N)):
+        for tok, off, mtb in ((st, 0, mt[0]), (en, s0 + N, mt[1])):
             if tok is not None:
                 rows(tok.reshape(-1), dword, 1, off, skip)
                 rows(torch.full((B,), off, dtype=torch.int64, device=dev), dpos, 1, off)
-                rows(mtb, dtyp, 1, off)
+                rows(mtb.contiguous(), dtyp, 1, off)
         rows(ids.reshape(-1), dword, T, L, skip)
         rows(torch.arange(T, device=dev).repeat(B), dpos, T, L)
         rows(tt.reshape(-1), dtyp, T, L)
@@ -649,7 +649,7 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
         nat.copy_rows(dy.view(torch.bfloat16)[s0:], S, dmod.view(torch.bfloat16), N, B, N, 2 * H)
         dpw, dpb = _wgrad(dmod, f2), _colsum(dmod)
         nat.scatter_add_rows_f32(dmod, H, B * N, H, posidx, dpos, H)
-        nat.scatter_add_rows_f32(dpb.view(1, H), H, 1, H, mt, dtyp, H)
+        nat.scatter_add_rows_f32(dmod, H, B * N, H, feat_types, dtyp, H)       # every feature row into the type row of its position
         return None, None, None, None, None, None, dword, dpos, dtyp, dln_w, dln_b, dpw, dpb, None, None, None
 
 

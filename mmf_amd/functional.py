@@ -1165,6 +1165,27 @@ class LinearTanhFn(torch.autograd.Function):
         return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None
 
 
+def mmbt_modal_types(modal_type, B, L, N, s0, dev, pd, td):
+    """The token-type ids of MMBT's modal block (ModalEmbeddings.forward, mmbt.py:117-127) in the forms the fused embedding stage takes them.
+    `modal_type`: a Python int or a one-element device tensor — ONE type for the whole block, what MMBTBase derives from the batch's segment ids
+    (mmbt.py:385-410): its row rides in the projection GEMM's epilogue as a column vector — or a [B, L] tensor of per-position ids (a caller's
+    own `modal_token_type_ids`): each projected feature's position row and type row are then summed into one per-row table for the same epilogue.
+    Returns (start-token types [B, 1], end-token types [B, 1], coladd, rowtab, rowidx, types of all L modal rows [B, L], feature types [B * N] or None)."""
+    H = td.shape[1]
+    posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
+    if isinstance(modal_type, torch.Tensor) and modal_type.numel() > 1:
+        ids = modal_type.detach().to(device=dev, dtype=torch.int64).reshape(B, L).contiguous()
+        feat = ids[:, s0:s0 + N].reshape(-1).contiguous()
+        rowtab = pd.index_select(0, posidx).add_(td.index_select(0, feat)).contiguous()
+        return (ids[:, :1].contiguous(), ids[:, L - 1:].contiguous(), None, rowtab, torch.arange(B * N, device=dev, dtype=torch.int64), ids, feat)
+    if isinstance(modal_type, torch.Tensor):      # (a one-element device tensor stays on the device: no host read-back, capturable)
+        mt = modal_type.detach().reshape(1).to(device=dev, dtype=torch.int64)
+    else:
+        mt = torch.full((1,), int(modal_type), dtype=torch.int64, device=dev)
+    mtype = mt.reshape(1, 1).expand(B, 1).contiguous()
+    return mtype, mtype, td.index_select(0, mt).reshape(H), pd, posidx, mt.reshape(1, 1).expand(B, L).contiguous(), None
+
+
 class MMBTEmbeddingsFn(torch.autograd.Function):
     """ModalEmbeddings.forward (mmbt.py:84-129) and BertEmbeddingsJit.forward for the text (hf_layers.py:108-135),
     concatenated modal-first (mmbt.py:225), in one buffer: [start token | N projected features | end token | T text].
@@ -1183,26 +1204,19 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
         dev = word.device
         y = torch.empty(B * S, H, dtype=BF16, device=dev)
         wd, pd, td = word.detach(), pos.detach(), typ.detach()
-        # `modal_type`: a Python int or a one-element device tensor (MMBT derives it from the batch's segment ids, mmbt.py:385-410;
-        # keeping it on the device keeps the step free of host read-backs, i.e. capturable in a hipGraph)
-        if isinstance(modal_type, torch.Tensor):
-            mt = modal_type.detach().reshape(1).to(device=dev, dtype=torch.int64)
-        else:
-            mt = torch.full((1,), int(modal_type), dtype=torch.int64, device=dev)
-        mtype = mt.reshape(1, 1).expand(B, 1).contiguous()
+        mt_st, mt_en, coladd, rowtab, rowidx, mtype_rows, _ = mmbt_modal_types(modal_type, B, L, N, s0, dev, pd, td)
         ids = input_ids.contiguous()
         seg = text_type_ids.contiguous()
         st = start_tok.reshape(B, 1).contiguous() if start_tok is not None else None
         en = end_tok.reshape(B, 1).contiguous() if end_tok is not None else None
         if st is not None:
-            nat.embed_text_fwd(st, mtype, wd, pd, td, y, B, 1, S, H, 0, 0)
+            nat.embed_text_fwd(st, mt_st, wd, pd, td, y, B, 1, S, H, 0, 0)
         if en is not None:
-            nat.embed_text_fwd(en, mtype, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
+            nat.embed_text_fwd(en, mt_en, wd, pd, td, y, B, 1, S, H, s0 + N, s0 + N)
         nat.embed_text_fwd(ids, seg, wd, pd, td, y, B, T, S, H, L, 0)
         f2 = _feature_rows(feats, B * N, D)
-        posidx = (torch.arange(N, device=dev, dtype=torch.int64) + s0).repeat(B)
-        nat.gemm(f2, proj_w16, y, B * N, H, D, D, D, H, bias=proj_b.detach(), coladd=td.index_select(0, mt).reshape(H), rowtab=pd,
-                 rowidx=posidx, rowtab_ld=H, grp=(N, S - N, s0))
+        nat.gemm(f2, proj_w16, y, B * N, H, D, D, D, H, bias=proj_b.detach(), coladd=coladd, rowtab=rowtab,
+                 rowidx=rowidx, rowtab_ld=H, grp=(N, S - N, s0))
         out = torch.empty(B * S, H, dtype=BF16, device=dev)
         mean = torch.empty(B * S, dtype=F32, device=dev)
         rstd = torch.empty(B * S, dtype=F32, device=dev)
@@ -1211,7 +1225,7 @@ class MMBTEmbeddingsFn(torch.autograd.Function):
             out2 = torch.empty_like(out)
             nat.dropout(out, out2, drop)
             out = out2
-        ctx.save_for_backward(ids, seg, st, en, f2, y, mean, rstd, ln_w.detach(), proj_w16, mt.reshape(1, 1).expand(B, L).contiguous())
+        ctx.save_for_backward(ids, seg, st, en, f2, y, mean, rstd, ln_w.detach(), proj_w16, mtype_rows)
         ctx.meta = (B, N, T, S, L, s0, H, drop, word.shape[0], pos.shape[0], typ.shape[0])
         ctx.pad_idx = -1 if pad_idx is None else int(pad_idx)
         return out.view(B, S, H)

@@ -84,11 +84,11 @@ class MMBTModel(nn.Module):
         elif isinstance(modal_token_type_ids, int) or (isinstance(modal_token_type_ids, torch.Tensor)
                                                        and modal_token_type_ids.numel() == 1):
             modal_type = modal_token_type_ids          # (a one-element device tensor stays on the device)
-        else:
-            lo, hi = int(modal_token_type_ids.min()), int(modal_token_type_ids.max())
-            if lo != hi:
-                raise NotImplementedError("per-position modal_token_type_ids: the fused modal block adds ONE type row")
-            modal_type = lo
+        else:                                          # per-position ids [B, L] (:117-127 looks every one up): functional.mmbt_modal_types
+            if tuple(modal_token_type_ids.shape) != (B, L):
+                raise ValueError("modal_token_type_ids must be [batch, %d] (start token, %d modal rows, end token), got %s"
+                                 % (L, N, tuple(modal_token_type_ids.shape)))
+            modal_type = modal_token_type_ids
         emb, me = self.transformer.embeddings, self.modal_encoder
         if F32T.active():        # mmf_amd.fp32_training(): fp32 forward + backward
             hidden = F32T.mmbt_embeddings(

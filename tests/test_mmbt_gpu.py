@@ -2,6 +2,8 @@
 text-embedding kernel, cross-entropy) against plain PyTorch fp32, and the registered `mmbt` model against the
 fixture recorded from the real reference (tests/golden/mmbt_small64.npz) and the CPU oracle.
 Tolerance: BASELINE.json north_star, 5e-2 for the bf16 path."""
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -151,6 +153,50 @@ def test_mmbt_all_gradients_match_oracle_without_modal_tokens():
         errs[k] = rel_err(p.grad, v.grad)
     bad = {k: round(e, 4) for k, e in errs.items() if e > TOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("fp32", [False, True])
+def test_mmbt_per_position_modal_token_type_ids_match_oracle(fp32):
+    """A caller's own `modal_token_type_ids` [B, L] (ModalEmbeddings.forward looks every position up, mmbt.py:117-127; MMBTBase only ever builds a
+    constant block): start token, every projected feature and the end token carry their own type row, forward and backward (the token-type table
+    collects each row's gradient) — against the pinned oracle, on the bf16 kernels and under mmf_amd.fp32_training()."""
+    import mmf_amd
+    z, case, cfg, sd, sample = load_mmbt_case()
+    sample = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items()}
+    B = sample["input_ids"].shape[0]
+    L = sample["image_feature_0"].shape[1] + 2
+    g = torch.Generator().manual_seed(5)
+    sample["modal_token_type_ids"] = torch.randint(0, 2, (B, L), generator=g)
+    model = build_mmbt(cfg, sd, O.SHARED)
+    model.eval()
+    tol = 1e-3 if fp32 else TOL
+    with (mmf_amd.fp32_training() if fp32 else contextlib.nullcontext()):
+        out = model(SampleList(sample_to(sample, "cuda")))
+        (key, loss), = out["losses"].items()
+        loss.sum().backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.mmbt_forward(sdr, cfg, {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items()})
+    assert float((out["scores"].detach().float().cpu() - ref["scores"].detach()).abs().max()) <= tol
+    ref_loss = O.cross_entropy(ref["scores"], sample["targets"])
+    assert abs(loss.item() - ref_loss.item()) <= tol * abs(ref_loss.item())
+    ref_loss.backward()
+    # a constant block gives another answer: the per-position ids are really used
+    const = O.mmbt_forward(sd, cfg, {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items() if k != "modal_token_type_ids"})
+    assert float((const["scores"] - ref["scores"].detach()).abs().max()) > 10 * tol * 0 + 1e-4
+    params = dict(model.named_parameters())
+    bad = {}
+    for k, v in sdr.items():
+        p = params["model." + k]
+        assert p.grad is not None and v.grad is not None, k
+        if k.endswith("self.key.bias"):
+            continue
+        e = rel_err(p.grad, v.grad)
+        if e > tol:
+            bad[k] = round(e, 5)
+    assert not bad, bad
+    with pytest.raises(ValueError):
+        sample["modal_token_type_ids"] = torch.zeros(B, L + 1, dtype=torch.long)
+        model(SampleList(sample_to(sample, "cuda")))
 
 
 def test_mmbt_training_step_is_seed_reproducible_and_updates():

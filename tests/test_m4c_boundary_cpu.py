@@ -73,7 +73,9 @@ def test_prefix_lm_mask_is_handed_to_the_attention_op_unmaterialised():
     # a materialised [B, 1, S, S] mask (what MMT.forward builds, m4c.py:424-440) is accepted as it is: the kernels read it per (query, key) pair
     m3 = additive_key_mask(torch.zeros(2, 1, 10, 10), 2, 10)
     assert tuple(m3.shape) == (2, 10, 10) and m3.dtype == torch.float32 and m3.is_contiguous()
-    with pytest.raises(NotImplementedError):        # one mask per sample, not per head
-        additive_key_mask(torch.zeros(2, 4, 10, 10), 2, 10)
+    m4 = additive_key_mask(torch.zeros(2, 4, 10, 10), 2, 10)      # one mask per head (mmf_attn_desc.mask_head_stride, round 6): handed on as it is
+    assert tuple(m4.shape) == (2, 4, 10, 10) and m4.dtype == torch.float32 and m4.is_contiguous()
+    with pytest.raises(ValueError):
+        additive_key_mask(torch.zeros(2, 4, 10, 11), 2, 10)
     with pytest.raises(ValueError):
         additive_key_mask(torch.zeros(2, 1, 9, 10), 2, 10)

@@ -34,9 +34,7 @@ enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 
        MMF_TUN_ALT_FORMS = 3,      /* cross-check hooks (tests compare kernel forms that serve different shapes in production): bit 0 LayerNorm with the one-wave-per-row
                                       kernels even when H % 256 == 0; bit 1 head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head; bit 2
                                       attention backward as the separate dQ and dK/dV kernels where the one-pass kernel would run (and no keep-bit table); bit 3
-                                      LayerNorm backward with one row in flight per half-wave; bit 4 the operator library draws the attention-dropout decisions of a graphed
-                                      step outside the attention kernels, one step ahead beside the AdamW launches (mmf_attention_draw_keep_bits; same decisions
-                                      bit for bit, measured +0.11 ms per step: opt-in); bits 4 + 5 the same at the step's own head beside the embedding stage */
+                                      LayerNorm backward with one row in flight per half-wave */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
        MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
                                       kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B) */
@@ -230,8 +228,10 @@ typedef struct mmf_attn_draw_site {
     uint32_t* keep_lanes;   /* [mmf_attention_keep_lanes_words], 16-byte aligned */
 } mmf_attn_draw_site;
 /* seed_offset is added to every site's seed word before it enters the key: 0 = the decisions a forward launched NOW would draw; 1 = those of the next
- * step of a graphed loop, whose head (mmf_step_advance) adds one to the word — a step can draw its successor's decisions on a side stream beside its own
- * HBM-bound AdamW launches (MMF_TUN_ALT_FORMS bit 4). */
+ * step of a graphed loop, whose head (mmf_step_advance) adds one to the word (a step drawing its successor's decisions beside its own HBM-bound AdamW
+ * launches).  Round 6 measured both placements inside the VisualBERT step (a side branch of the hipGraph beside the embedding stage, or beside AdamW):
+ * the forwards gain 57 us, the 89 us draw hides nowhere and the branch costs the replay idle time: +0.11 ms per step, so the training steps of this
+ * package keep hashing in the kernels (profiles/r06_experiments.txt section 1; the step-level plumbing of that experiment: commit 8ce4125). */
 int mmf_attention_draw_keep_bits(const mmf_attn_draw_site* sites, int n, uint32_t seed_offset, void* stream);
 /* Words of keep_lanes for this shape (0 where mmf_attention_keep_bits_words' shape rule gives 0): B * heads * ceil(Sq / 32) * 64 lanes * 4. */
 int64_t mmf_attention_keep_lanes_words(int B, int heads, int Sq, int Sk, int head_dim);

@@ -35,7 +35,6 @@
 #include <ATen/ATen.h>
 #include <ATen/core/Generator.h>
 #include <c10/hip/HIPStream.h>
-#include <hip/hip_runtime_api.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
 
@@ -156,177 +155,6 @@ Drop drop_unpack(const c10::IValue& v, const Tensor& seed) {
     d.seed = seed;
     return d;
 }
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// attention-dropout decisions drawn ahead of a graphed step (mmf_attention_draw_keep_bits)
-// ---------------------------------------------------------------------------------------------------------------------------------
-// hf_layers.py:196-200 applies nn.Dropout to the attention probabilities; here the keep decisions are a hash of (site key, step seed word, element
-// index) and never depend on the scores, so the decisions of EVERY attention site of a step can be drawn by one launch outside the attention kernels,
-// which then read them instead of hashing.  Built, bit-identical (tests), measured, and NOT the default: the forward drops from
-// 29.8 to 25.1 us per layer, but the launch itself is ~90 us of full-chip VALU for VisualBERT's 12 layers, and nowhere in the step does it hide:
-//   * `tail` (MMF_TUN_ALT_FORMS bit 4): a step draws the decisions of its SUCCESSOR (seed word + 1) on a side stream beside its own HBM-bound AdamW
-//     launches — a parallel branch at the tail of the captured hipGraph.  AdamW slows by 47 us beside it and the branch costs the replay idle time at its
-//     fork and join (330 us under rocprofv3): step +0.11 ms (profiles/r06_experiments.txt section 1).
-//   * `begin` as a head draw (bits 4 + 5; also what warm-up passes and a first step use): beside the embedding stage, whose short kernels slow down
-//     by what the forwards gain: step +0.11 ms.
-//   * `prime`: an eager draw for seed word + 1 right before a step with a tail is captured, so that the first replay finds its tables.
-// The plan is learned, never declared: in graph mode (`_drop_graph_mode`, where the site keys are a fixed sequence restarted at every step head) each
-// attention forward registers (key, threshold, shape) in call order; the list of the last complete pass is what gets drawn, and a forward takes its
-// tables only when its own registration equals the planned entry — any mismatch (another model, another batch shape, dropout off) falls back to the
-// in-kernel draw with the same key, i.e. the same decisions.  Eager mode outside graph mode never draws ahead (its keys follow torch's Philox offset).
-// Contract of the tail form: between a tail draw and the forward that uses it the seed word changes by exactly the +1 of the step head
-// (GraphedTrainStep / GraphedDataParallelStep own the word; `prime` again after writing it by hand).
-struct DrawPlan {
-    struct E {
-        uint32_t key, thr16;
-        int B, heads, Sq, Sk, hd;
-        int64_t kb_off = 0, kl_off = 0, kb_words = 0, kl_words = 0;
-        bool same(const E& o) const { return key == o.key && thr16 == o.thr16 && B == o.B && heads == o.heads && Sq == o.Sq && Sk == o.Sk && hd == o.hd; }
-    };
-    std::vector<E> plan, learn;
-    Tensor buf, seed;
-    const void* mode_seed = nullptr;   // seed word of the graph mode that registered `learn`
-    std::vector<Tensor> retired;       // tables a captured graph still writes (a replay must never write into memory handed to somebody else)
-    bool drawn = false;                // the tables hold the decisions of the pass in progress
-    bool ahead = false;                // the tables hold the decisions of the NEXT pass (tail / prime), to be claimed by its `begin`
-    bool pass_open = false;            // a pass has registered into `learn` since the last `finalize`
-    bool buf_captured = false, buf_claimed = false;
-    int64_t n_sites = 0, n_taken = 0, n_head = 0, n_tail = 0;   // tests / records: `_attn_draw_stats`
-    std::vector<hipStream_t> joined;   // streams that already wait for the draw in flight
-    hipEvent_t fork = nullptr, done = nullptr;
-    optional<c10::hip::HIPStream> side;
-
-    // a buffer some captured graph writes must outlive that graph: its owner keeps it (`_attn_draw_buffer`, what GraphedTrainStep does) or it is parked here
-    void drop_buf() {
-        if (buf.defined() && buf_captured && !buf_claimed) retired.push_back(buf);
-        buf = Tensor(); buf_captured = buf_claimed = false;
-    }
-    static bool capturing(hipStream_t s) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
-    }
-    static bool off() { return (mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 16) == 0; }      // (opt-in: measured slower inside the graphed step, see above)
-    static bool no_tail() { return (mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 32) != 0; }
-    bool in_flight = false;            // a side-stream draw whose event some consumer stream has yet to wait for
-    void join_current() {
-        if (!in_flight) return;
-        hipStream_t cur = c10::hip::getCurrentHIPStream().stream();
-        for (hipStream_t s : joined) if (s == cur) return;
-        TORCH_CHECK(hipStreamWaitEvent(cur, done, 0) == hipSuccess, "mmf_amd: hipStreamWaitEvent failed");
-        joined.push_back(cur);
-    }
-    // the list of the last complete pass becomes the plan
-    void finalize(const Tensor& like) {
-        if (!pass_open) return;
-        pass_open = false;
-        bool changed = learn.size() != plan.size();
-        for (size_t i = 0; !changed && i < learn.size(); ++i) changed = !learn[i].same(plan[i]);
-        if (changed) {
-            plan = learn;
-            ahead = drawn = false;
-            int64_t words = 0;
-            for (E& e : plan) {
-                e.kb_words = mmf_attention_keep_bits_words(e.B, e.heads, e.Sq, e.Sk, e.hd);
-                e.kl_words = mmf_attention_keep_lanes_words(e.B, e.heads, e.Sq, e.Sk, e.hd);
-                e.kl_off = words; words += (e.kl_words + 3) / 4 * 4;
-                e.kb_off = words; words += (e.kb_words + 3) / 4 * 4;
-            }
-            drop_buf();
-            if (words > 0) buf = at::empty({words}, like.options().dtype(at::kInt));
-        }
-        learn.clear();
-    }
-    bool drawable() const {
-        if (plan.empty() || !buf.defined() || off()) return false;
-        for (const E& e : plan) if (e.kb_words == 0 || e.kl_words == 0) return false;     // (a knob changed the shape rule under the plan: hash in the kernels)
-        return true;
-    }
-    // one launch for the whole plan, on `stream` (the current one, or the side stream after a fork)
-    void launch(const Tensor& seed_t, uint32_t seed_off, bool on_side) {
-        seed = seed_t;
-        c10::hip::HIPStream cur = c10::hip::getCurrentHIPStream();
-        if (capturing(cur.stream())) buf_captured = true;
-        std::vector<mmf_attn_draw_site> sites(plan.size());
-        uint32_t* base = reinterpret_cast<uint32_t*>(buf.data_ptr<int32_t>());
-        for (size_t i = 0; i < plan.size(); ++i) {
-            const E& e = plan[i];
-            mmf_attn_draw_site& d = sites[i];
-            d.drop_key = e.key; d.drop_thr16 = e.thr16; d.drop_seed = reinterpret_cast<const uint32_t*>(seed.data_ptr());
-            d.B = e.B; d.heads = e.heads; d.Sq = e.Sq; d.Sk = e.Sk; d.head_dim = e.hd;
-            d.keep_bits = base + e.kb_off; d.keep_lanes = base + e.kl_off;
-        }
-        if (!on_side) {
-            MMF_RC(mmf_attention_draw_keep_bits(sites.data(), (int)sites.size(), seed_off, reinterpret_cast<void*>(cur.stream())), "mmf_attention_draw_keep_bits");
-            return;
-        }
-        if (!side.has_value() || side->device_index() != cur.device_index()) side = c10::hip::getStreamFromPool(false, cur.device_index());
-        if (!fork) {
-            TORCH_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess,
-                        "mmf_amd: hipEventCreate failed");
-        }
-        TORCH_CHECK(hipEventRecord(fork, cur.stream()) == hipSuccess && hipStreamWaitEvent(side->stream(), fork, 0) == hipSuccess, "mmf_amd: stream fork failed");
-        MMF_RC(mmf_attention_draw_keep_bits(sites.data(), (int)sites.size(), seed_off, reinterpret_cast<void*>(side->stream())), "mmf_attention_draw_keep_bits");
-        TORCH_CHECK(hipEventRecord(done, side->stream()) == hipSuccess, "mmf_amd: hipEventRecord failed");
-        joined.clear();
-        in_flight = true;
-    }
-    // head of a pass (right after the seed word advanced)
-    void begin(const Tensor& seed_t) {
-        join_current();                // (a tail draw nobody joined: never leave a branch of a capture open)
-        in_flight = false;
-        drawn = false;
-        n_sites = n_taken = 0;
-        if (!g_keys.graph_seed.defined()) { learn.clear(); pass_open = false; ahead = false; return; }
-        g_keys.counter = 0;            // the site keys of a step are the same fixed sequence in every warm-up pass, the capture and hence every replay
-        finalize(seed_t);
-        pass_open = true;
-        if (!drawable()) { ahead = false; return; }
-        if (ahead && seed.defined() && seed.data_ptr() == seed_t.data_ptr()) {      // drawn by the previous pass's tail (or primed): nothing to launch
-            ahead = false;
-        } else {
-            ahead = false;
-            launch(seed_t, 0, true);
-            ++n_head;
-        }
-        drawn = true;
-        n_sites = (int64_t)plan.size();
-    }
-    // after the backward of a pass, ahead of its optimizer step: the NEXT pass's decisions on a side stream (`tail_join` after the optimizer step)
-    void tail(const Tensor& seed_t) {
-        if (!g_keys.graph_seed.defined() || off() || no_tail()) return;
-        finalize(seed_t);
-        if (!drawable()) return;
-        drawn = false;                 // (the tables stop describing the pass that just ended)
-        launch(seed_t, 1, true);
-        ahead = true;
-        ++n_tail;
-    }
-    // eager, ahead of capturing a step that has a tail: the tables of the first replay
-    void prime(const Tensor& seed_t) {
-        if (off() || no_tail()) return;
-        finalize(seed_t);
-        if (!drawable()) return;
-        drawn = false;
-        launch(seed_t, 1, false);
-        ahead = true;
-    }
-    // the tables of this attention call, when the pass's draw covers it (else undefined tensors: the forward hashes and writes its own keep_bits)
-    bool take(const Drop& drop, int64_t B, int64_t heads, int64_t Sq, int64_t Sk, int64_t hd, Tensor& kb, Tensor& kl) {
-        if (!g_keys.graph_seed.defined() || !drop.on()) return false;
-        E e;
-        e.key = drop.key; e.thr16 = drop.thr16; e.B = (int)B; e.heads = (int)heads; e.Sq = (int)Sq; e.Sk = (int)Sk; e.hd = (int)hd;
-        if (mmf_attention_keep_bits_words(e.B, e.heads, e.Sq, e.Sk, e.hd) == 0) return false;
-        const size_t idx = learn.size();
-        learn.push_back(e);
-        if (!drawn || idx >= plan.size() || !plan[idx].same(e) || !drop.seed.defined() || drop.seed.data_ptr() != seed.data_ptr()) return false;
-        join_current();
-        ++n_taken;
-        kb = buf.narrow(0, plan[idx].kb_off, plan[idx].kb_words);
-        kl = buf.narrow(0, plan[idx].kl_off, plan[idx].kl_words);
-        return true;
-    }
-};
-DrawPlan g_draw;
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // bf16 shadows of fp32 master parameters (+ transposed twins for the input-gradient GEMMs)
@@ -652,15 +480,14 @@ struct TransformerLayerFn : public torch::autograd::Function<TransformerLayerFn>
         Tensor ctxt = empty_bf16({M, H}, x2), lse = empty_f32({B, heads, S}, x2);
         Tensor o32 = need_bwd ? empty_f32({M, H}, x2) : Tensor();
         // the forward's dropout decisions as a bit table for the backward, where this shape's kernels take one (mmf_attn_desc.keep_bits)
-        Tensor kb, kl;       // (drawn ahead of the step where the step's plan covers this call: DrawPlan)
-        if (need_bwd && drop_attn.on() && !g_draw.take(drop_attn, B, heads, S, S, H / heads, kb, kl)) {
+        Tensor kb;
+        if (need_bwd && drop_attn.on()) {
             const int64_t words = mmf_attention_keep_bits_words((int)B, (int)heads, (int)S, (int)S, (int)(H / heads));
             if (words > 0) kb = at::empty({words}, x2.options().dtype(at::kInt));
         }
         mmf_attn_desc ad;
         attn_desc(ad, qkv, H, mask, ctxt, lse, o32, B, heads, S, drop_attn, tail);
         ad.keep_bits = kb.defined() ? reinterpret_cast<uint32_t*>(kb.data_ptr<int32_t>()) : nullptr;
-        ad.keep_lanes = kl.defined() ? reinterpret_cast<const uint32_t*>(kl.data_ptr<int32_t>()) : nullptr;
         MMF_RC(mmf_attention_fwd(&ad, sp()), "mmf_attention_fwd");
         Ddrln a = ddrln_fwd(ctxt, x2, wo16, bo, g1, be1, eps1, drop_hid1, MMF_SITE_ATTN_OUT_FWD);
         // feed-forward
@@ -1210,37 +1037,7 @@ bool svc_shadow_set_twins(bool on) { const bool old = g_shadows.twins_on; g_shad
 void svc_shadow_refresh_transposed(at::TensorList only, bool has_only, at::TensorList skip, bool has_skip) {
     g_shadows.refresh_transposed(only.vec(), has_only, skip.vec(), has_skip);
 }
-void svc_drop_graph_mode(const optional<Tensor>& seed) {
-    g_keys.graph_seed = seed.has_value() ? *seed : Tensor();
-    g_keys.counter = 0;
-    // what the last pass registered (and drew ahead) stays valid across the warm-up / capture contexts of ONE graphed step (same seed word) and is
-    // forgotten when another step object (another seed word) enters graph mode
-    if (seed.has_value()) {
-        if (seed->data_ptr() != g_draw.mode_seed) {
-            g_draw.learn.clear(); g_draw.plan.clear(); g_draw.pass_open = false; g_draw.ahead = g_draw.drawn = false;
-            g_draw.drop_buf();       // every step object gets its own tables (its captured graph writes them at every replay)
-        }
-        g_draw.mode_seed = seed->data_ptr();
-    }
-}
-void svc_attn_draw_begin(const Tensor& seed) { g_draw.begin(seed); }
-void svc_attn_draw_join() { g_draw.join_current(); }
-void svc_attn_draw_tail(const Tensor& seed) { g_draw.tail(seed); }
-std::vector<Tensor> svc_attn_draw_buffer() {
-    if (!g_draw.buf.defined()) return {};
-    g_draw.buf_claimed = true;
-    return {g_draw.buf};
-}
-void svc_attn_draw_prime(const Tensor& seed) { g_draw.prime(seed); }
-std::vector<int64_t> svc_attn_draw_stats() { return {g_draw.n_sites, g_draw.n_taken, g_draw.n_head, g_draw.n_tail}; }
-std::vector<Tensor> svc_attn_draw_take(int64_t key, int64_t thr16, const optional<Tensor>& seed, int64_t B, int64_t heads, int64_t Sq, int64_t Sk, int64_t hd) {
-    Drop d;
-    d.key = (uint32_t)key; d.thr16 = (uint32_t)thr16;
-    if (seed.has_value()) d.seed = *seed;
-    Tensor kb, kl;
-    if (!g_draw.take(d, B, heads, Sq, Sk, hd, kb, kl)) return {};
-    return {kb, kl};
-}
+void svc_drop_graph_mode(const optional<Tensor>& seed) { g_keys.graph_seed = seed.has_value() ? *seed : Tensor(); g_keys.counter = 0; }
 std::tuple<int64_t, std::vector<Tensor>> svc_drop_next() {
     Tensor seed;
     const uint32_t k = g_keys.next(seed);
@@ -1332,13 +1129,6 @@ TORCH_LIBRARY(mmf_amd, m) {
     m.def("_shadow_refresh_transposed(Tensor[] only, bool has_only, Tensor[] skip, bool has_skip) -> ()");
     m.def("_drop_graph_mode(Tensor? seed) -> ()");
     m.def("_drop_next() -> (int, Tensor[])");
-    m.def("_attn_draw_begin(Tensor seed) -> ()");
-    m.def("_attn_draw_join() -> ()");
-    m.def("_attn_draw_stats() -> int[]");
-    m.def("_attn_draw_tail(Tensor seed) -> ()");
-    m.def("_attn_draw_buffer() -> Tensor[]");
-    m.def("_attn_draw_prime(Tensor seed) -> ()");
-    m.def("_attn_draw_take(int key, int thr16, Tensor? seed, int B, int heads, int Sq, int Sk, int head_dim) -> Tensor[]");
     m.def("_ln_defer_set(bool on) -> bool");
     m.def("_ln_defer_flush() -> ()");
     m.def("_set_py_mode(int mode) -> int");
@@ -1368,13 +1158,6 @@ TORCH_LIBRARY_IMPL(mmf_amd, CompositeImplicitAutograd, m) {
     m.impl("_shadow_refresh_transposed", svc_shadow_refresh_transposed);
     m.impl("_drop_graph_mode", svc_drop_graph_mode);
     m.impl("_drop_next", svc_drop_next);
-    m.impl("_attn_draw_begin", svc_attn_draw_begin);
-    m.impl("_attn_draw_join", svc_attn_draw_join);
-    m.impl("_attn_draw_stats", svc_attn_draw_stats);
-    m.impl("_attn_draw_tail", svc_attn_draw_tail);
-    m.impl("_attn_draw_buffer", svc_attn_draw_buffer);
-    m.impl("_attn_draw_prime", svc_attn_draw_prime);
-    m.impl("_attn_draw_take", svc_attn_draw_take);
     m.impl("_ln_defer_set", svc_ln_defer_set);
     m.impl("_ln_defer_flush", svc_ln_defer_flush);
     m.impl("_set_py_mode", svc_set_py_mode);

@@ -404,51 +404,9 @@ def _keep_bits(B, heads, Sq, Sk, head_dim, drop, dev, need):
     one-pass kernel — head_dim 64 up to 256 positions, head_dim 128 up to 128: every model of the path at BASELINE's shapes — else None (both directions
     hash)."""
     if not (need and drop[1]):
-        return None, None
-    if NATIVE and len(drop) > 3 and drop[3] is not None:
-        # graph mode: the decisions of this call may have been drawn at the head of the step (torch_ops.cpp DrawPlan, mmf_attention_draw_keep_bits);
-        # the forward then reads them in its own lane order (`keep_lanes`) and the backward takes `keep_bits` as before
-        drawn = torch.ops.mmf_amd._attn_draw_take(drop[0], drop[1], drop[3], B, heads, Sq, Sk, head_dim)
-        if drawn:
-            return drawn[0], drawn[1]
+        return None
     words = nat.attention_keep_bits_words(B, heads, Sq, Sk, head_dim)
-    return (torch.empty(words, dtype=torch.int32, device=dev) if words else None), None
-
-
-def attn_draw_begin(seed):
-    """Head of a graphed training step, right after the seed word advanced: draw the attention-dropout decisions of every attention call the previous
-    pass registered, in ONE launch on a side stream (the reference draws them with nn.Dropout after the softmax, hf_layers.py:196-200).
-    `attn_draw_join` after the forward makes the current stream wait for that launch if no attention call did (nothing may stay unjoined in a capture)."""
-    if NATIVE:
-        torch.ops.mmf_amd._attn_draw_begin(seed)
-
-
-def attn_draw_join():
-    if NATIVE:
-        torch.ops.mmf_amd._attn_draw_join()
-
-
-def attn_draw_tail(seed):
-    """After the backward of a graphed step, ahead of its optimizer step: the NEXT step's decisions (seed word + 1) on a side stream beside the HBM-bound
-    AdamW launches (`attn_draw_join` after the optimizer step).  The production form of the draw: at the head of the step it costs what it saves."""
-    if NATIVE:
-        torch.ops.mmf_amd._attn_draw_tail(seed)
-
-
-def attn_draw_prime(seed):
-    """Eager, right before a step with a tail draw is captured: the tables its first replay reads.  Returns the table buffer, which the owner of the
-    captured graph must keep alive (every replay writes it)."""
-    if not NATIVE:
-        return None
-    torch.ops.mmf_amd._attn_draw_prime(seed)
-    return attn_draw_buffer()
-
-
-def attn_draw_buffer():
-    if not NATIVE:
-        return None
-    buf = torch.ops.mmf_amd._attn_draw_buffer()
-    return buf[0] if buf else None
+    return torch.empty(words, dtype=torch.int32, device=dev) if words else None
 
 
 class PrefixLMMask:
@@ -479,9 +437,9 @@ def _attn_fwd(x2, wqkv16, bqkv, mask_add, B, S, heads, drop, need_bwd=True, tail
     lse = torch.empty(B, heads, S, dtype=F32, device=dev)
     scale = 1.0 / math.sqrt(H // heads)
     o32 = _o32(M, H, dev, need_bwd)
-    kb, kl = _keep_bits(B, heads, S, S, H // heads, drop, dev, need_bwd)
+    kb = _keep_bits(B, heads, S, S, H // heads, drop, dev, need_bwd)
     nat.attention_fwd(qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H, 3 * H, mask_add, ctxt, H, lse, B, heads, S, S, scale, drop,
-                      head_dim=H // heads, ctx_f32=o32, causal_tail=tail, keep_bits=kb, keep_lanes=kl)
+                      head_dim=H // heads, ctx_f32=o32, causal_tail=tail, keep_bits=kb)
     return qkv, ctxt, lse, o32, kb
 
 
@@ -1686,13 +1644,13 @@ class BiAttentionFn(torch.autograd.Function):
         lse1 = torch.empty(B, heads, T, dtype=F32, device=dev)
         need = any(ctx.needs_input_grad)
         o1, o2 = _o32(B * T, BH, dev, need), _o32(B * R, BH, dev, need)
-        (kb1, kl1), (kb2, kl2) = _keep_bits(B, heads, T, R, hd, drop1, dev, need), _keep_bits(B, heads, R, T, hd, drop2, dev, need)
+        kb1, kb2 = _keep_bits(B, heads, T, R, hd, drop1, dev, need), _keep_bits(B, heads, R, T, hd, drop2, dev, need)
         nat.attention_fwd(qkv2, qkv1[:, BH:], qkv1[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, img_mask_add, ctx1, BH, lse1, B, heads, T, R,
-                          scale, drop1, head_dim=hd, ctx_f32=o1, keep_bits=kb1, keep_lanes=kl1)
+                          scale, drop1, head_dim=hd, ctx_f32=o1, keep_bits=kb1)
         ctx2 = torch.empty(B * R, BH, dtype=BF16, device=dev)
         lse2 = torch.empty(B, heads, R, dtype=F32, device=dev)
         nat.attention_fwd(qkv1, qkv2[:, BH:], qkv2[:, 2 * BH:], 3 * BH, 3 * BH, 3 * BH, txt_mask_add, ctx2, BH, lse2, B, heads, R, T,
-                          scale, drop2, head_dim=hd, ctx_f32=o2, keep_bits=kb2, keep_lanes=kl2)
+                          scale, drop2, head_dim=hd, ctx_f32=o2, keep_bits=kb2)
         ctx.save_for_backward(i2, t2, qkv1, qkv2, ctx1, ctx2, lse1, lse2, w1_16, w2_16, img_mask_add, txt_mask_add, o1, o2, kb1, kb2)
         ctx.meta = (B, R, T, VH, H, BH, heads, drop1, drop2)
         return ctx1.view(B, T, BH), ctx2.view(B, R, BH)

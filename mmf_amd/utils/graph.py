@@ -104,11 +104,8 @@ class GraphedTrainStep:
         if optimizer is None:
             Fn.shadows.clear()   # so the weight-shadow casts are part of the captured step
         with Fn.dropout_keys.graph_mode(self.seed):
-            # the first replay's attention-dropout decisions (every later replay finds those its predecessor drew beside its AdamW launches)
-            self._draw_tables = Fn.attn_draw_prime(self.seed) if optimizer is not None else None
             with torch.cuda.graph(self.graph):
                 self.out, self.loss = self._eager()
-            self._draw_tables = Fn.attn_draw_buffer()      # (kept alive with the graph that writes it)
 
     def _eager(self, update=True):
         return self._eager_body(update)
@@ -120,9 +117,7 @@ class GraphedTrainStep:
             self.optimizer.advance(self.seed)
         else:
             Fn.nat.seed_advance(self.seed)
-        Fn.attn_draw_begin(self.seed)      # the step's attention-dropout decisions: one launch on a side stream, beside the embedding stage
         out = self.model(self.static_batch)
-        Fn.attn_draw_join()
         loss = self.loss_of(out)
         # torch.autograd.grad instead of loss.backward(): AccumulateGrad nodes are bound to the stream they were first
         # created on; if an earlier eager step created them on the legacy default stream, running them inside the
@@ -136,9 +131,7 @@ class GraphedTrainStep:
         for p, g in zip(self.params, grads):
             p.grad = g
         if self.optimizer is not None and update:
-            Fn.attn_draw_tail(self.seed)       # the next step's attention-dropout decisions: a side branch beside the HBM-bound AdamW launches
             self.optimizer.step(**({"advance": False} if head_advance else {}))
-            Fn.attn_draw_join()
         return out, loss
 
     def __call__(self, batch=None):
@@ -363,13 +356,11 @@ class GraphedDataParallelStep:
     def _forward(self):
         self._ids = {}
         Fn.nat.seed_advance(self.seed)
-        Fn.attn_draw_begin(self.seed)
         self._bounds, self._hooking = [], True
         try:
             out = self.model(self.static_batch)
         finally:
             self._hooking = False
-        Fn.attn_draw_join()
         if len(self._bounds) != len(self.cuts):
             raise RuntimeError("GraphedDataParallelStep: %d of the %d cut modules ran in the forward" % (len(self._bounds), len(self.cuts)))
         self._loss_t = self.loss_of(out)

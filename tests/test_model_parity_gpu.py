@@ -361,46 +361,3 @@ def test_training_step_is_bit_reproducible_from_run_to_run():
     for n in ma:
         assert torch.equal(ma[n], mb[n]), n
     assert float(ma["model.bert.embeddings.word_embeddings.weight"].abs().sum()) > 0
-
-
-
-
-def test_attention_dropout_drawn_at_the_head_of_the_step_changes_no_bit():
-    """the graphed step draws the attention-dropout decisions of all its layers in ONE launch outside the attention kernels
-    (torch_ops.cpp DrawPlan -> mmf_attention_draw_keep_bits, opt-in: MMF_TUN_ALT_FORMS bit 4) and the attention kernels read them: a step draws its
-    successor's decisions beside its own AdamW launches, or its own at its head (bits 4 + 5).  Same keys, same seed words, same decisions: three updates
-    end with the same losses, parameters and moments, bit for bit, as the default step whose forward kernels hash; and the plan really covered every layer
-    of the captured step.  (Measured slower than hashing inside the step — profiles/r06_experiments.txt — hence opt-in.)"""
-    from mmf_amd import _native as nat
-    from mmf_amd.modules.optimizers import AdamW
-    from mmf_amd.utils.configuration import Config
-    from mmf_amd.utils.graph import GraphedTrainStep
-    z, case, cfg, sd, sample = load_case("small64")
-    batch = SampleList(sample_to(dict(sample), "cuda"))
-    res = []
-    try:
-        for ahead, knob in ((True, 16), (True, 48), (False, 0)):     # drawn one step ahead beside AdamW / at the step's own head / hashed in the kernels (default)
-            nat.set_tunable(nat.TUN_ALT_FORMS, knob)
-            m = build_visual_bert(cfg, sd)
-            m.train()
-            o = AdamW(m.get_optimizer_parameters(Config(model="visual_bert", optimizer=dict(params=dict(lr=1e-3)), model_config=dict(visual_bert=m.config))),
-                      lr=1e-3, capturable=True)
-            g = GraphedTrainStep(m, batch, warmup=2, optimizer=o)
-            stats = list(torch.ops.mmf_amd._attn_draw_stats())
-            layers = len(m.model.bert.encoder.layer)
-            assert stats[:2] == ([layers, layers] if ahead else [0, 0]), stats
-            losses = [float(g()) for _ in range(3)]
-            torch.cuda.synchronize()
-            res.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()},
-                        {n: o.state[p]["exp_avg"].clone() for n, p in m.named_parameters() if p in o.state and len(o.state[p])}))
-            del g
-    finally:
-        nat.set_tunable(nat.TUN_ALT_FORMS, 0)
-    la, pa, ma = res[0]
-    assert len(set(la)) == 3
-    for lb, pb, mb in res[1:]:
-        assert la == lb
-        for n in pa:
-            assert torch.equal(pa[n], pb[n]), n
-        for n in ma:
-            assert torch.equal(ma[n], mb[n]), n

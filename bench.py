@@ -588,6 +588,24 @@ def main():
                   "value": round(args.batch * args.steps / dtp, 2), "unit": "samples/s",
                   "note": "same graph, padded batch: 228 positions per sample are computed whatever the mask (as in the reference); the word-embedding "
                           "gradient skips [PAD] rows"}
+        # ... and what the path does about it when asked: the text columns NO sample of the batch uses are cut before the step (results unchanged:
+        # tests/test_text_padding_{cpu,gpu}.py), one captured step per length bucket (mmf_amd/utils/graph.py BucketedTrainStep).  Lengths ~ U{8..24} ->
+        # 24 + 100 positions per sample instead of 228.
+        try:
+            from mmf_amd.common.prefetch import trim_text_padding
+            from mmf_amd.utils.graph import BucketedTrainStep
+            tb = trim_text_padding(pb, 8)
+            bucketed = BucketedTrainStep(model, optimizer=opt, warmup=2, trim=0)
+            bucketed(tb)
+            dtt, _ = timed(lambda: bucketed(tb))
+            padded["trimmed"] = {"positions_per_sample": int(tb["input_ids"].shape[1]) + 100, "ms_per_step": round(dtt / args.steps * 1e3, 3),
+                                 "value": round(args.batch * args.steps / dtt, 2), "unit": "samples/s",
+                                 "note": "trim_text_padding(multiple=8) + BucketedTrainStep: same scores, loss and gradients as the untrimmed batch; "
+                                         "the trim itself runs on the host batch ahead of the copy (DevicePrefetcher(trim_text_padding=8)) and is not in "
+                                         "the timed region; never the headline (the headline batch is full length)"}
+            del bucketed, tb
+        except Exception as e:      # the secondary run must not take the headline down
+            padded["trimmed"] = {"error": "%s: %s" % (type(e).__name__, e)}
         del pb
     fwd_bwd_only = None
     if use_graph and opt is not None:

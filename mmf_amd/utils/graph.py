@@ -76,7 +76,7 @@ class GraphedTrainStep:
     parameter is updated and no step is counted before the first replay; the optimizer's moments are allocated up front
     (`ensure_state`) so that the captured update contains no zero-fill."""
 
-    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None):
+    def __init__(self, model, batch, warmup=3, loss_of=None, optimizer=None, seed=None):
         # (Rounds 2 - 3 could also put the grouped weight gradients or each layer's AdamW update on a second stream beside the backward of the layers
         #  below; both measured slower on every box - the streamed 213 MB per layer evict the GEMMs' operand panels from L2, 8.53 against 8.25 ms -
         #  and were removed in round 6: profiles/r04_experiments.txt.)
@@ -89,7 +89,7 @@ class GraphedTrainStep:
         self.static_batch = _clone_batch(batch)
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = next(model.parameters()).device
-        self.seed = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seed = torch.zeros(1, dtype=torch.int32, device=dev) if seed is None else seed      # (shared between the steps of a BucketedTrainStep)
         if optimizer is not None:
             optimizer.ensure_state(self.params)
         side = torch.cuda.Stream(device=dev)
@@ -128,17 +128,68 @@ class GraphedTrainStep:
             if getattr(self, "_one", None) is None or self._one.dtype != loss.dtype:
                 self._one = torch.ones_like(loss)
             grads = torch.autograd.grad(loss, self.params, grad_outputs=self._one, allow_unused=True)
+        self.grads = grads
         for p, g in zip(self.params, grads):
             p.grad = g
         if self.optimizer is not None and update:
             self.optimizer.step(**({"advance": False} if head_advance else {}))
         return out, loss
 
+    def bind_gradients(self):
+        """Point every `p.grad` at THIS step's captured gradient tensors (after another step captured or replayed over the same parameters)."""
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+
     def __call__(self, batch=None):
         if batch is not None:
             _copy_batch(self.static_batch, batch)
         self.graph.replay()
         return self.loss
+
+
+def _batch_signature(batch):
+    sig = []
+    for k in batch.fields():
+        v = batch[k]
+        if isinstance(v, torch.Tensor):
+            sig.append((k, tuple(v.shape), str(v.dtype)))
+        elif isinstance(v, SampleList):
+            sig.append((k, _batch_signature(v)))
+    return tuple(sig)
+
+
+class BucketedTrainStep:
+    """The graphed training step for batches whose TEXT LENGTH varies: one `GraphedTrainStep` per batch shape, captured the first time the shape is
+    seen (a few eager warm-up passes without update, then the capture), replayed afterwards.  With `trim=m` (> 0) the step first cuts the text
+    columns no sample of the batch uses, rounded up to a multiple of m (`mmf_amd.common.prefetch.trim_text_padding`: results are those of the
+    untrimmed batch) — for a batch already in HBM that reads the mask back (one synchronisation per step); feed it from
+    `DevicePrefetcher(trim_text_padding=m)` with `trim=0` here and nothing waits.  All buckets share the model, the optimizer (its moments, step count
+    and schedule words live in device memory the captured updates read), the weight shadows and the dropout seed word; each owns its activations
+    (a private pool of ~ 70 MB per sample position block: 2.2 GB at 228 positions, B = 32 — 288 GB of HBM hold every bucket of a 128-token model)."""
+
+    def __init__(self, model, optimizer=None, warmup=2, loss_of=None, trim=8, max_buckets=32):
+        self.model, self.optimizer, self.warmup, self.loss_of = model, optimizer, warmup, loss_of
+        self.trim, self.max_buckets = int(trim or 0), max_buckets
+        self.steps = {}
+        self.seed = torch.zeros(1, dtype=torch.int32, device=next(model.parameters()).device)
+        self._bound = None
+
+    def __call__(self, batch):
+        if self.trim > 0:
+            from mmf_amd.common.prefetch import trim_text_padding
+            batch = trim_text_padding(batch, self.trim)
+        key = _batch_signature(batch)
+        step = self.steps.get(key)
+        if step is None:
+            if len(self.steps) >= self.max_buckets:
+                raise RuntimeError("BucketedTrainStep: more than %d batch shapes; raise `trim` (coarser buckets) or max_buckets" % self.max_buckets)
+            step = self.steps[key] = GraphedTrainStep(self.model, batch, warmup=self.warmup, loss_of=self.loss_of, optimizer=self.optimizer, seed=self.seed)
+            self._bound = step          # (the capture left p.grad on its own tensors)
+        loss = step(batch)
+        if self._bound is not step:
+            step.bind_gradients()
+            self._bound = step
+        return loss
 
 
 _SPARSE_CHECK = int(os.environ.get("MMF_AMD_SPARSE_CHECK", "0") or 0)      # k > 0: every k-th step verifies the touched-row contract (a host read-back)

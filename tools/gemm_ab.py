@@ -1,7 +1,7 @@
 """Same-process, interleaved A/B of GEMM kernel variants on the VisualBERT VQA2 layer shapes WITH their real epilogues, plus a
 correctness check of every variant against an fp32 torch product of the same bf16 operands.
 
-    python tools/gemm_ab.py [--tun ID:V1,V2,...] [--rounds R] [--iters I] [shape-name-filter ...]
+    python tools/gemm_ab.py [--tun ID:V1,V2,...] [--set ID:V] [--M rows] [--rounds R] [--iters I] [shape-name-filter ...]
 
 Default: tunable MMF_TUN_GEMM_PERSIST (18) in {-1, 0}: the one-tile kernels against the persistent kernel where the rule takes it.  Every (shape, variant) is timed `rounds` times, `iters` launches each, the
 variants interleaved inside a round (cdna_hip_programming.md section 5.4 rule 24); the table prints median / min per variant."""
@@ -68,6 +68,9 @@ def main():
             rounds = int(args[i + 1]); i += 2
         elif args[i] == "--iters":
             iters = int(args[i + 1]); i += 2
+        elif args[i] == "--M":            # token rows (default 7296 = 32 x 228; a trimmed batch of 24 + 100 positions: 3968)
+            global M
+            M = int(args[i + 1]); i += 2
         else:
             filt.append(args[i]); i += 1
     L = nat.lib()

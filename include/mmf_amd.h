@@ -30,11 +30,12 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------ */
 int mmf_amd_abi_version(void);
 /* Integer tuning knobs for on-hardware sweeps (0 = built-in heuristic).  Not part of the reference's interface. */
-enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 force 256x96 / 192x192 / 256x128 (tests, A/B) */
+enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 / 2 / 3 / 4 force 256x96 / 192x192 / 256x128 / 128x96 (tests, A/B) */
        MMF_TUN_ALT_FORMS = 3,      /* cross-check hooks (tests compare kernel forms that serve different shapes in production): bit 0 LayerNorm with the one-wave-per-row
                                       kernels even when H % 256 == 0; bit 1 head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head; bit 2
                                       attention backward as the separate dQ and dK/dV kernels where the one-pass kernel would run (and no keep-bit table); bit 3
-                                      LayerNorm backward with one row in flight per half-wave */
+                                      LayerNorm backward with one row in flight per half-wave; bit 4 the 256-row wide GEMM tiles also where few token rows would take
+                                      the 128x96 tile (A/B of that rule) */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
        MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
                                       kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B) */

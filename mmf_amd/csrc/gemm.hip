@@ -444,7 +444,7 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     }
     const bf16* A = reinterpret_cast<const bf16*>(d->A);
     const bf16* B = reinterpret_cast<const bf16*>(d->B);
-    g_last_kernel = BM_ == 192 ? "gemm_wide_kernel 192x192" : (BN_ == 96 ? "gemm_wide_kernel 256x96" : "gemm_wide_kernel 256x128");
+    g_last_kernel = BM_ == 192 ? "gemm_wide_kernel 192x192" : (BM_ == 128 ? "gemm_wide_kernel 128x96" : (BN_ == 96 ? "gemm_wide_kernel 256x96" : "gemm_wide_kernel 256x128"));
 #ifdef MMF_WIDE_ABLATE
     const int abl = (d->debug_flags >> 4) & 7;
 #define MMF_WIDE_ABL_CASE(V)                                                                                                          \
@@ -569,8 +569,8 @@ static double tile_cost(long M, long N, long K, int bm, int bn, int slots) {
 static int wide_choice(const mmf_gemm_desc* d) {
     const int force = mmf_amd_get_tunable(MMF_TUN_GEMM_WIDE);
     if (force < 0 || (d->debug_flags & 131072) || d->M < 512 || (d->K % 64) != 0 || d->K < 128) return 0;
-    static const int BMs[4] = {0, 256, 192, 256}, BNs[4] = {0, 96, 192, 128};
-    if (force >= 1 && force <= 3) return (d->N % BNs[force]) == 0 ? force : 0;
+    static const int BMs[5] = {0, 256, 192, 256, 128}, BNs[5] = {0, 96, 192, 128, 96};
+    if (force >= 1 && force <= 4) return (d->N % BNs[force]) == 0 ? force : 0;
     // Measured INSIDE the step (round 4, tools/step_ab.py, profiles/r04_in_step_choices.txt): the FFN-down dgrad (N = 3072, K = 768, times the saved gelu')
     // on the 256 x 96 tile, 928 tiles in 3.6 rounds, instead of the 256 x 128 tile the isolated measurements and the cost model pick (44.5 us isolated,
     // 54 - 60 us in the step): 7.63 against 7.89, 7.53 against 7.85 and 7.64 against 7.86 ms per step on three boxes. 
@@ -578,6 +578,14 @@ static int wide_choice(const mmf_gemm_desc* d) {
     // One workgroup per CU cannot hide a heavy epilogue behind a co-resident workgroup's K loop: the GELU up-projection (two
     // bf16 outputs, erf + exp per element) measured 70.7 us with wide tiles against 60.5 us inside the training step.
     if (d->act == 1) return 0;
+    // Few token rows (a batch whose text padding was trimmed, mmf_amd/common/prefetch.py: 32 x 124 = 3968 rows): the 256-row tiles of an N = 768 site
+    // fill half the chip (16 x 8 = 128 tiles).  The same ping-pong kernel on a 128 x 96 tile puts a workgroup on (nearly) every CU: out-proj 14.8 ->
+    // 11.7 us, FFN-down 34.9 -> 29.2, FFN-up dgrad 30.8 -> 25.8, QKV dgrad 23.9 -> 20.2 at M = 3968 (tools/gemm_ab.py --M 3968 --tun 2:0,1,4); it
+    // loses as soon as its tiles need a second round (M = 5248: 41 x 8 tiles, 52.6 against 35.9 us) and on the wide outputs (N >= 2304).
+    if ((d->N % 96) == 0 && d->N <= 1024 && d->act != 1 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 16)) {
+        const long t128 = (long)((d->M + 127) / 128) * (d->N / 96), t256 = (long)((d->M + 255) / 256) * (d->N / 96);
+        if (t128 <= 256 && t256 <= 160) return 4;
+    }
     double best = tile_cost(d->M, d->N, d->K, 128, 128, 2);
     if ((d->N % 96) == 0) { const double c = tile_cost(d->M, d->N, d->K, 128, 96, 2); if (c < best) best = c; }
     int pick = 0;
@@ -604,6 +612,7 @@ int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
                 case 1: return launch_wide<256, 96, 4, 2, 3>(d, e, s);
                 case 2: return launch_wide<192, 192, 2, 4, 3>(d, e, s);
                 case 3: return launch_wide<256, 128, 4, 2, 3>(d, e, s);
+                case 4: return launch_wide<128, 96, 4, 2, 3>(d, e, s);
                 default: break;
             }
         }

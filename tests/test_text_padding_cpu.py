@@ -79,3 +79,70 @@ def test_prefetcher_trims_on_the_host():
     assert out[0]["input_ids"].shape == (3, 8) and out[1]["input_ids"].shape == (3, 24)
     out = list(DevicePrefetcher([SampleList(s)], device="cpu"))
     assert out[0]["input_ids"].shape == (3, 24)
+
+
+def _padded(sample, lengths, total, vocab):
+    g = torch.Generator().manual_seed(11)
+    B = sample["input_ids"].shape[0]
+    lens = torch.tensor(lengths[:B])
+    mask = (torch.arange(total)[None, :] < lens[:, None]).long()
+    s = dict(sample)
+    s["input_ids"] = torch.randint(1, vocab, (B, total), generator=g) * mask
+    s["input_mask"], s["segment_ids"] = mask, torch.zeros_like(mask)
+    return s
+
+
+def _loss_and_grads(fn, sd, cfg, batch):
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = fn(sdr, cfg, batch, train=False)
+    loss = sum(v.sum() for v in out["losses"].values())
+    loss.backward()
+    return out["scores"].detach(), float(loss), {k: v.grad for k, v in sdr.items()}
+
+
+def _same(res0, res1):
+    (s0, l0, g0), (s1, l1, g1) = res0, res1
+    assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-6)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    n = 0
+    for k in g0:
+        if g0[k] is None or float(g0[k].abs().max()) == 0.0:
+            assert g1[k] is None or float(g1[k].abs().max()) == 0.0, k
+            continue
+        if k.endswith(("key.bias", "key1.bias", "key2.bias")):      # identically zero in exact arithmetic (softmax shift invariance)
+            continue
+        e = float((g0[k] - g1[k]).double().norm() / g0[k].double().norm())
+        assert e <= 1e-5, (k, e)
+        n += 1
+    return n
+
+
+def test_vilbert_oracle_does_not_change():
+    """Two streams + co-attention (mmf/models/vilbert.py:1092-1198): the text mask reaches the text stream's self-attention and the image -> text
+    co-attention as an additive -10000; the pooled text output is position 0."""
+    from oracle import vilbert_oracle as OV
+    from tests.golden_utils import load_vilbert_case
+    z, case, cfg, sd, sample = load_vilbert_case("vilbert_small")
+    s = _padded(sample, (5, 3, 7), 24, cfg["vocab_size"])
+    t = trim_text_padding(SampleList(s), 8)
+    assert t["input_ids"].shape == (3, 8)
+
+    def fn(sdr, cfg_, batch, train=False):
+        out = OV.vilbert_forward(sdr, cfg_, batch, train=train)
+        return {"scores": out["scores"], "losses": {"l": O.logit_bce(out["scores"], batch["targets"])}}
+    assert _same(_loss_and_grads(fn, sd, cfg, s), _loss_and_grads(fn, sd, cfg, dict(t))) > 60
+
+
+def test_mmbt_oracle_does_not_change():
+    """MMBT (mmf/models/mmbt.py:244-272): [start] features [end] text; the text sits at the END of the joint sequence, its position ids are arange(T)."""
+    from oracle import mmbt_oracle as OM
+    from tests.golden_utils import load_mmbt_case
+    z, case, cfg, sd, sample = load_mmbt_case("mmbt_small64")
+    s = _padded(sample, (5, 3, 7, 8), 24, cfg["vocab_size"])
+    t = trim_text_padding(SampleList(s), 8)
+    assert t["input_ids"].shape == (4, 8)
+
+    def fn(sdr, cfg_, batch, train=False):
+        out = OM.mmbt_forward(sdr, cfg_, batch, train=train)
+        return {"scores": out["scores"], "losses": {"l": OM.cross_entropy(out["scores"], batch["targets"])}}
+    assert _same(_loss_and_grads(fn, sd, cfg, s), _loss_and_grads(fn, sd, cfg, dict(t))) > 30

@@ -102,3 +102,36 @@ def test_bucketed_graphed_step_trains_like_the_eager_step_on_untrimmed_batches()
     # p.grad follows the bucket that ran last
     last = [g for g in step.steps.values() if int(g.static_batch["input_ids"].shape[1]) == 8][0]
     assert all(p.grad is g for p, g in zip(last.params, last.grads))
+
+
+@pytest.mark.parametrize("which", ["vilbert", "mmbt"])
+def test_trimmed_batch_on_the_two_stream_and_the_mmbt_models(which):
+    """The same identity on the HIP path for ViLBERT (text mask in the text stream and in the image -> text co-attention) and MMBT (text at the END of the
+    joint sequence); oracle side: tests/test_text_padding_cpu.py."""
+    from tests.golden_utils import load_mmbt_case, load_vilbert_case
+    from tests.model_utils import build_mmbt, build_vilbert
+    from tests.test_text_padding_cpu import _padded
+    if which == "vilbert":
+        z, case, cfg, sd, sample = load_vilbert_case("vilbert_small")
+        model = build_vilbert(cfg, sd)
+        s = _padded(sample, (5, 3, 7), 24, cfg["vocab_size"])
+    else:
+        z, case, cfg, sd, sample = load_mmbt_case("mmbt_small64")
+        from oracle import mmbt_oracle as OM
+        model = build_mmbt(cfg, sd, OM.SHARED)
+        s = _padded(sample, (5, 3, 7, 8), 24, cfg["vocab_size"])
+    model.eval()
+    t = trim_text_padding(SampleList(s), 8)
+    assert t["input_ids"].shape[1] == 8
+    s0, l0, g0 = run(model, s)
+    s1, l1, g1 = run(model, t)
+    assert float((s0 - s1).abs().max()) <= 4e-3 * max(1.0, float(s0.abs().max()))
+    assert abs(l0 - l1) <= 4e-3 * abs(l0)
+    assert set(g0) == set(g1)
+    for n in g0:
+        if n.endswith(("key.bias", "key1.bias", "key2.bias")) or "position_embeddings" in n:
+            continue
+        if float(g0[n].abs().max()) == 0.0:
+            assert float(g1[n].abs().max()) == 0.0, n
+            continue
+        assert rel(g1[n], g0[n]) <= 2e-2, (n, rel(g1[n], g0[n]))

@@ -126,16 +126,25 @@ def measure_config(name, steps, warmup, no_graph=False):
             launch = "eager (hipGraph capture failed: %s)" % type(e).__name__
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    t0 = time.perf_counter()
-    evs[0].record()
-    for i in range(steps):
-        last = step()
-        evs[i + 1].record()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    gc.collect()
+    stall_note = None
+    for attempt in range(2):
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(steps):
+            last = step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        # A host-side stall inside the loop (seen once in ~20 runs on this pool: 150 ms in one of 8 steps of the 4.5 ms MMBT graph, the HIP events of the
+        # same loop unaffected) says nothing about the step: the loop is repeated ONCE and the line says so.
+        if attempt == 0 and dt / steps * 1e3 > 1.5 * per[len(per) // 2] + 0.5:
+            stall_note = "first timed loop: %.3f ms per step wall against %.3f ms event median (host stall); repeated once" % (dt / steps * 1e3, per[len(per) // 2])
+            continue
+        break
     gem = {k: v for k, v in by.items() if k.startswith("gemm") and "(ragged / small)" not in k}
     dom = max(gem, key=lambda k: gem[k]["ms"])
     tot_ms = sum(v["ms"] for k, v in by.items() if k.startswith("gemm")); tot_fl = sum(v["work"] for k, v in by.items() if k.startswith("gemm"))
@@ -147,7 +156,8 @@ def measure_config(name, steps, warmup, no_graph=False):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": configs[OTHER_CONFIGS[name]], "shape": label, "global_batch": B, "parallelism": "dp1", "launch": launch,
                    "loss": round(float(last.item() if hasattr(last, "item") else last), 4), "params": sum(p.numel() for p in model.parameters()),
-                   "note": "a parity-test configuration of BASELINE.json, not its headline; one GPU's share of the multi-GPU configs"},
+                   "note": "a parity-test configuration of BASELINE.json, not its headline; one GPU's share of the multi-GPU configs"
+                           + ("; " + stall_note if stall_note else "")},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(by[dom]["work"] / by[dom]["ms"] / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(by[dom]["work"] / by[dom]["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                      "avg_launch_ms": round(by[dom]["ms"] / by[dom]["launches"], 4), "launches_per_step": by[dom]["launches"],
@@ -173,6 +183,8 @@ def other_configs_block(names=("vilbert", "mmbt", "uniter", "m4c"), steps=8, war
                          "samples_per_s": ln["value"], "steps": steps, "warmup": warmup, "dominant_gemm_family": ln["roofline"]["kernel"],
                          "dominant_frac_of_mfma_peak": ln["roofline"]["frac"], "all_gemm_tflops": ln["roofline"]["all_gemm"]["tflops"],
                          "step_frac_of_mfma_peak": ln["roofline"]["step_frac_of_mfma_peak"], "wall_s": round(time.perf_counter() - t0, 1)}
+            if "repeated once" in ln["config"]["note"]:
+                out[name]["note"] = ln["config"]["note"].split("; ", 1)[1]
         except Exception as e:
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         gc.collect()

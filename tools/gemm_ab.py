@@ -68,6 +68,9 @@ def main():
             rounds = int(args[i + 1]); i += 2
         elif args[i] == "--iters":
             iters = int(args[i + 1]); i += 2
+        elif args[i] == "--shapes":       # "name:N:K:kind,..." instead of the VisualBERT layer table (kinds: bias, bias_drop_resid, gelu, gelup, resid, plain)
+            global SHAPES
+            SHAPES = [(a, int(b), int(c), d) for a, b, c, d in (x.split(":") for x in args[i + 1].split(","))]; i += 2
         elif args[i] == "--M":            # token rows (default 7296 = 32 x 228; a trimmed batch of 24 + 100 positions: 3968)
             global M
             M = int(args[i + 1]); i += 2

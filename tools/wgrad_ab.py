@@ -1,7 +1,7 @@
 """Same-process interleaved A/B of the grouped weight-gradient launch of a VisualBERT layer (dW1, dW2, dWqkv, dWo + their bias
 gradients, M = 7296 tokens): 128 x 128 tiles, two workgroups per CU (MMF_TUN_WGRAD_WIDE = 1) against the 256 x 128 wide tile (0).
 
-    python tools/wgrad_ab.py [rounds] [iters]"""
+    python tools/wgrad_ab.py [rounds] [iters] [tokens]"""
 import os
 import statistics
 import sys
@@ -15,7 +15,7 @@ from mmf_amd import _native as nat
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    T, H, I = 7296, 768, 3072
+    T, H, I = (int(sys.argv[3]) if len(sys.argv) > 3 else 7296), 768, 3072      # (T = 6144: the 96 K-steps per CU a stream-K schedule would leave)
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(1)
     mk = lambda r, c: (torch.randn(r, c, device=dev, generator=g) * 0.5).bfloat16()

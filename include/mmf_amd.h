@@ -30,7 +30,7 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------ */
 int mmf_amd_abi_version(void);
 /* Integer tuning knobs for on-hardware sweeps (0 = built-in heuristic).  Not part of the reference's interface. */
-enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 .. 5 force 256x96 / 192x192 / 256x128 / 128x96 / 128x128 (tests, A/B) */
+enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 never a wide tile, 1 .. 6 force 256x96 / 192x192 / 256x128 / 128x96 / 128x128 / 192x96 (tests, A/B) */
        MMF_TUN_ALT_FORMS = 3,      /* cross-check hooks (tests compare kernel forms that serve different shapes in production): bit 0 LayerNorm with the one-wave-per-row
                                       kernels even when H % 256 == 0; bit 1 head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head; bit 2
                                       attention backward as the separate dQ and dK/dV kernels where the one-pass kernel would run (and no keep-bit table); bit 3

@@ -444,7 +444,7 @@ int launch_wide(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
     }
     const bf16* A = reinterpret_cast<const bf16*>(d->A);
     const bf16* B = reinterpret_cast<const bf16*>(d->B);
-    g_last_kernel = BM_ == 192 ? "gemm_wide_kernel 192x192" : (BM_ == 128 ? (BN_ == 96 ? "gemm_wide_kernel 128x96" : "gemm_wide_kernel 128x128") : (BN_ == 96 ? "gemm_wide_kernel 256x96" : "gemm_wide_kernel 256x128"));
+    g_last_kernel = BM_ == 192 ? (BN_ == 96 ? "gemm_wide_kernel 192x96" : "gemm_wide_kernel 192x192") : (BM_ == 128 ? (BN_ == 96 ? "gemm_wide_kernel 128x96" : "gemm_wide_kernel 128x128") : (BN_ == 96 ? "gemm_wide_kernel 256x96" : "gemm_wide_kernel 256x128"));
 #ifdef MMF_WIDE_ABLATE
     const int abl = (d->debug_flags >> 4) & 7;
 #define MMF_WIDE_ABL_CASE(V)                                                                                                          \
@@ -569,8 +569,8 @@ static double tile_cost(long M, long N, long K, int bm, int bn, int slots) {
 static int wide_choice(const mmf_gemm_desc* d) {
     const int force = mmf_amd_get_tunable(MMF_TUN_GEMM_WIDE);
     if (force < 0 || (d->debug_flags & 131072) || d->M < 512 || (d->K % 64) != 0 || d->K < 128) return 0;
-    static const int BMs[6] = {0, 256, 192, 256, 128, 128}, BNs[6] = {0, 96, 192, 128, 96, 128};
-    if (force >= 1 && force <= 5) return (d->N % BNs[force]) == 0 ? force : 0;
+    static const int BMs[7] = {0, 256, 192, 256, 128, 128, 192}, BNs[7] = {0, 96, 192, 128, 96, 128, 96};
+    if (force >= 1 && force <= 6) return (d->N % BNs[force]) == 0 ? force : 0;
     // Measured INSIDE the step (round 4, tools/step_ab.py, profiles/r04_in_step_choices.txt): the FFN-down dgrad (N = 3072, K = 768, times the saved gelu')
     // on the 256 x 96 tile, 928 tiles in 3.6 rounds, instead of the 256 x 128 tile the isolated measurements and the cost model pick (44.5 us isolated,
     // 54 - 60 us in the step): 7.63 against 7.89, 7.53 against 7.85 and 7.64 against 7.86 ms per step on three boxes. 
@@ -585,6 +585,10 @@ static int wide_choice(const mmf_gemm_desc* d) {
     if ((d->N % 96) == 0 && d->N <= 1024 && d->act != 1 && !(mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 16)) {
         const long t128 = (long)((d->M + 127) / 128) * (d->N / 96), t256 = (long)((d->M + 255) / 256) * (d->N / 96);
         if (t128 <= 256 && t256 <= 160) return 4;
+        // between the buckets (4224 .. 6144 rows: a 128-row tiling needs a second round) the 192 x 96 tile still fits one round and beats 256 x 96 by 9 - 10 % at every
+        // site (M = 4224 / 5248 / 6144: FFN-down 35.1 -> 31.9 / 36.4 -> 33.0 / 39.4 -> 35.2 us, tools/gemm_ab.py --M .. --tun 2:1,6); 7296 rows: 38 x 8 tiles, a second round.
+        const long t192 = (long)((d->M + 191) / 192) * (d->N / 96);
+        if (t192 <= 256 && d->M >= 1024) return 6;
     }
     // ... and on a 128 x 128 tile where N is a multiple of 128 only (ViLBERT's 1024-wide visual stream and connection layers at 3200 / 4096 rows: 104 / 128
     // tiles of 256 x 128 on 256 CUs): out-proj 19.0 -> 14.5 us, FFN-down 18.6 -> 14.1, dgrads 15.8 -> 12.6 and 40.3 -> 33.5 (K = 4096) at M = 3200.
@@ -620,6 +624,7 @@ int launch(const mmf_gemm_desc* d, const EpiArgs& e, hipStream_t s) {
                 case 3: return launch_wide<256, 128, 4, 2, 3>(d, e, s);
                 case 4: return launch_wide<128, 96, 4, 2, 3>(d, e, s);
                 case 5: return launch_wide<128, 128, 4, 2, 3>(d, e, s);
+                case 6: return launch_wide<192, 96, 4, 2, 3>(d, e, s);
                 default: break;
             }
         }

@@ -9,7 +9,7 @@ from tests.test_kernels_gpu import DEV, close, nat, rnd
 pytestmark = pytest.mark.gpu
 NO_WIDE = 1 << 17          # debug_flags: never a wide tile
 NO_KSPLIT = 1 << 13        # keep the 128-row kernel on the plain K order
-CONFIGS = {1: (256, 96), 2: (192, 192), 3: (256, 128), 4: (128, 96), 5: (128, 128)}
+CONFIGS = {1: (256, 96), 2: (192, 192), 3: (256, 128), 4: (128, 96), 5: (128, 128), 6: (192, 96)}
 
 
 @pytest.fixture
@@ -20,10 +20,10 @@ def force_wide():
     nat().set_tunable(nat().TUN_GEMM_WIDE, 0)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,K", [(7296, 768), (1500, 768), (512, 128), (3200, 3072), (2000, 192), (3968, 2304)])
 def test_wide_forward_bias_matches_torch_and_the_128_row_kernel(cfg, M, K, force_wide):
-    N = {1: 768, 2: 2304, 3: 3072, 4: 768, 5: 1024}[cfg] if M > 2000 else {1: 192, 2: 384, 3: 512, 4: 192, 5: 256}[cfg]
+    N = {1: 768, 2: 2304, 3: 3072, 4: 768, 5: 1024, 6: 768}[cfg] if M > 2000 else {1: 192, 2: 384, 3: 512, 4: 192, 5: 256, 6: 192}[cfg]
     A = rnd(M, K, seed=1); B = rnd(N, K, seed=2, scale=0.05); bias = torch.randn(N, device=DEV)
     C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV); C0 = torch.empty_like(C)
     force_wide(cfg)
@@ -33,10 +33,10 @@ def test_wide_forward_bias_matches_torch_and_the_128_row_kernel(cfg, M, K, force
     assert torch.equal(C, C0)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
 def test_wide_epilogues(cfg, force_wide):
     M, K = 1500, 768
-    N = {1: 768, 2: 768, 3: 1024, 4: 768, 5: 1024}[cfg]
+    N = {1: 768, 2: 768, 3: 1024, 4: 768, 5: 1024, 6: 768}[cfg]
     A = rnd(M, K, seed=3); B = rnd(N, K, seed=4, scale=0.05); bias = torch.randn(N, device=DEV)
     force_wide(cfg)
     cases = (dict(act=1, U=torch.empty(M, N, dtype=torch.bfloat16, device=DEV)),
@@ -75,7 +75,7 @@ def test_few_token_rows_take_the_128_row_wide_tile(force_wide):
     """A trimmed batch (32 x 124 = 3968 token rows): the N = 768 sites run on the 128 x 96 ping-pong tile (248 workgroups instead of 128), the wide
     outputs and the full-length batch keep their tiles."""
     for M, N, K, kernel in ((3968, 768, 3072, "gemm_wide_kernel 128x96"), (3968, 768, 768, "gemm_wide_kernel 128x96"),
-                            (7296, 768, 3072, "gemm_wide_kernel 256x96"), (5248, 768, 768, "gemm_wide_kernel 256x96"),
+                            (7296, 768, 3072, "gemm_wide_kernel 256x96"), (5248, 768, 768, "gemm_wide_kernel 192x96"), (6144, 768, 3072, "gemm_wide_kernel 192x96"),
                             (3200, 1024, 1024, "gemm_wide_kernel 128x128"), (4096, 1024, 4096, "gemm_wide_kernel 128x128"),
                             (14592, 1024, 1024, "gemm_persist_kernel 256x128")):
         A = rnd(M, K, seed=8); B = rnd(N, K, seed=9, scale=0.05)
@@ -87,7 +87,7 @@ def test_few_token_rows_take_the_128_row_wide_tile(force_wide):
         assert torch.equal(C, C0)
 
 
-@pytest.mark.parametrize("cfg,N", [(1, 768), (2, 2304), (3, 3072), (4, 768), (5, 1024)])
+@pytest.mark.parametrize("cfg,N", [(1, 768), (2, 2304), (3, 3072), (4, 768), (5, 1024), (6, 768)])
 def test_wide_repeated_launches_are_stable(cfg, N, force_wide):
     """Race screen: the ring's RAW / WAR ordering must not depend on timing — 30 launches on operands that other work evicts
     in between, identical results."""

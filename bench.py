@@ -177,7 +177,22 @@ def other_configs_block(names=("vilbert", "mmbt", "uniter", "m4c"), steps=8, war
     for name in names:
         t0 = time.perf_counter()
         try:
-            ln = measure_config(name, steps, warmup)
+            # Each configuration in a FRESH process (`python bench.py --config NAME`): measured behind the headline's models and graphs in this process
+            # the same replayed step is 3 - 10 % slower (M4C 5.33 against 4.83 ms, MMBT 4.72 against 4.25, ViLBERT 12.04 against 11.7 on one box: what
+            # the caching allocator hands a late-comer is scattered over the leftovers of five earlier models).  In-process only if the child fails.
+            ln = None
+            if os.environ.get("MMF_AMD_BENCH_INPROC_CONFIGS") != "1":
+                try:
+                    import subprocess
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", str(warmup)],
+                                       capture_output=True, text=True, timeout=300)
+                    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    if r.returncode == 0 and lines:
+                        ln = json.loads(lines[-1])
+                except Exception:
+                    ln = None
+            if ln is None:
+                ln = measure_config(name, steps, warmup)
             out[name] = {"workload": ln["config"]["workload"], "shape": ln["config"]["shape"], "global_batch": ln["config"]["global_batch"],
                          "launch": ln["config"]["launch"], "ms_per_step": ln["ms_per_step"], "ms_per_step_event_median": ln["ms_per_step_event_median"],
                          "samples_per_s": ln["value"], "steps": steps, "warmup": warmup, "dominant_gemm_family": ln["roofline"]["kernel"],

@@ -35,7 +35,7 @@ enum { MMF_TUN_GEMM_WIDE = 2,      /* forward-form GEMM tile: 0 model picks, -1 
                                       kernels even when H % 256 == 0; bit 1 head_dim-64 attention forward with > 128 queries as two 4-wave workgroups per head; bit 2
                                       attention backward as the separate dQ and dK/dV kernels where the one-pass kernel would run (and no keep-bit table); bit 3
                                       LayerNorm backward with one row in flight per half-wave; bit 4 the 256-row wide GEMM tiles also where few token rows would take
-                                      the 128x96 tile (A/B of that rule) */
+                                      the 128x96 tile (A/B of that rule); bit 5 mmf_gemm_bf16_grouped_ln never lets the LayerNorm ride (A/B) */
        MMF_TUN_EPI_NT = 6,         /* GEMM epilogue non-temporal stores: 0 default, else value - 1 = mask (bit 0 bf16 C, bit 1 saved gelu', bit 2 fp32 C) */
        MMF_TUN_NT_SITE_KEEP = 8,   /* bit s set: the bf16 output of GEMM calls tagged MMF_GEMM_SITE(s) is stored TEMPORALLY (stays in L2 / the Infinity Cache for the
                                       kernel that consumes it next) although MMF_TUN_EPI_NT stores outputs non-temporally; 0 (default): no exception (A/B) */
@@ -136,6 +136,20 @@ int mmf_gemm_skinny_splits(int M, int N, int K, int a_kmajor);
  * (dW = dY^T X of the Linear layers at hf_layers.py:169-180 and of HF BertSelfOutput / BertIntermediate / BertOutput,
  * call sites hf_layers.py:248,289,290; mmf/trainers/core/training_loop.py:211). */
 int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream);
+/* The grouped launch above together with ONE deferred LayerNorm backward that does not depend on it (the training step's order: a layer's four weight
+ * gradients, then the first LayerNorm backward of the layer below; reference: autograd of HF BertOutput.LayerNorm, mmf/modules/hf_layers.py:290, beside the
+ * weight gradients of nn.Linear at :169-180,248,289-290).  `ln` is mmf_layernorm_bwd's argument list with dgamma = dbeta = dbias = NULL (column-sum partials
+ * only: finish with mmf_layernorm_bwd_reduce_multi).  Where the weight gradients run one 256 x 128 tile per CU and leave CUs idle (216 tiles on 256 CUs for a
+ * BERT-base layer at 7296 tokens) and the LayerNorm is 768 wide with two rows per half-wave, the LayerNorm runs on those CUs inside the SAME launch; otherwise
+ * the two launches follow each other.  Results are bit-identical either way.  MMF_TUN_ALT_FORMS bit 5: never ride (A/B). */
+typedef struct mmf_ln_bwd_desc {
+    const void* dy; const void* x; const float* mean; const float* rstd; const float* gamma;
+    void* dx; void* dlin;                       /* bf16 [rows, H]; dlin (dropout backward of the preceding Linear) may be NULL when drop_thr16 == 0 */
+    uint32_t drop_key, drop_thr16; float drop_scale; const uint32_t* drop_seed;
+    float* partials;                            /* mmf_layernorm_bwd_ws_floats(H) floats */
+    int rows, H;
+} mmf_ln_bwd_desc;
+int mmf_gemm_bf16_grouped_ln(const mmf_gemm_desc* descs, int count, const mmf_ln_bwd_desc* ln, void* stream);
 /* Development aid (profiling, not a reference operation): while `buf` (device memory, (1 + capacity_records) * 64 bytes,
  * zeroed) is set, every workgroup of every GEMM launch appends one 64-byte timeline record of s_memrealtime (100 MHz) stamps
  * {launch << 32 | block, HW_ID | XCC_ID << 32, entry, first stage landed, K loop done, tile staged, stores drained, tile};

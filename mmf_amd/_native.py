@@ -254,6 +254,33 @@ def gemm_grouped(problems):
     _check(lib().mmf_gemm_bf16_grouped(arr, n, _stream()), "mmf_gemm_bf16_grouped")
 
 
+class LnBwdDesc(C.Structure):
+    """include/mmf_amd.h mmf_ln_bwd_desc"""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("dx", C.c_void_p),
+                ("dlin", C.c_void_p), ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
+                ("partials", C.c_void_p), ("rows", C.c_int), ("H", C.c_int)]
+
+
+def gemm_grouped_ln(problems, dy, x, mean, rstd, gamma, dx, dlin, drop, partials, rows, H):
+    """`gemm_grouped(problems)` and the deferred LayerNorm backward `layernorm_bwd(dy, x, ..., None, None, None, 0, partials, rows, H)` that does not depend on
+    it, in ONE launch where the tiles leave CUs idle (mmf_gemm_bf16_grouped_ln); otherwise one after the other.  Same bits either way."""
+    n = len(problems)
+    if not 1 <= n <= GEMM_GROUP_MAX:
+        raise NativeLibraryError("gemm_grouped_ln takes 1..%d problems, got %d" % (GEMM_GROUP_MAX, n))
+    arr = (GemmDesc * n)()
+    for i, kw in enumerate(problems):
+        _gemm_desc(d=arr[i], **kw)
+    for t, nm in ((dy, "dy"), (x, "x"), (dx, "dx"), (dlin, "dlin")):
+        _req(t, torch.bfloat16, nm)
+    for t, nm in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (partials, "partials")):
+        _req(t, torch.float32, nm)
+    k, t, sc, sd = _drop4(drop)
+    ptr = lambda v: None if v is None else v.data_ptr()
+    d = LnBwdDesc(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dlin), k, t, sc, None if len(drop) == 3 or drop[3] is None else drop[3].data_ptr(),
+                  ptr(partials), int(rows), int(H))
+    _check(lib().mmf_gemm_bf16_grouped_ln(arr, n, C.byref(d), _stream()), "mmf_gemm_bf16_grouped_ln")
+
+
 # call-site tags of the encoder layer's GEMMs (include/mmf_amd.h MMF_SITE_*, MMF_GEMM_SITE): they name a call for the per-site store policy
 SITE_QKV_FWD, SITE_ATTN_OUT_FWD, SITE_FFN_UP_FWD, SITE_FFN_DOWN_FWD, SITE_FFN_DOWN_DGRAD, SITE_FFN_UP_DGRAD, SITE_ATTN_OUT_DGRAD, SITE_QKV_DGRAD = range(1, 9)
 

@@ -27,6 +27,7 @@
 #include "gemm_common.h"
 #include "gemm_wide.h"
 #include "gemm_persist.h"
+#include "ln_bwd_dev.h"
 
 using namespace gemm;
 
@@ -314,6 +315,42 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_grouped_kernel(GroupArgs g, 
                                                                P.ldb, tile_m, tile_n, P.epi, pr, smem);
 }
 
+// The grouped weight gradients with a LayerNorm-backward RIDER (round 6): a VisualBERT layer's 216 tiles run one per CU (147 KB of LDS each) and leave 40 of the 256 CUs
+// idle for the whole launch; the kernel that follows in the step — the first LayerNorm backward of the layer BELOW, HBM-bound, 45 MB — depends on nothing
+// the tiles compute.  Workgroups g.total .. g.total + nrider - 1 of this launch are that LayerNorm backward: a rider workgroup is two independent 256-thread
+// halves, each walking the blocks (blk = 2 * rider + half + 2 * nrider * k) of the SAME block decomposition ln_bwd_h_kernel uses (lnk::ln_bwd_h_block: same
+// rows per half-wave, same partials layout, bit-identical results); both halves run the same number of iterations so that the workgroup-wide barriers match.
+// Riders carry the highest block indices: they are dispatched after the tiles, onto the CUs still free (a tile's LDS leaves no room for one beside it).
+struct LnRider {
+    const bf16* dy; const bf16* x; const float* mean; const float* rstd; const float* gamma;
+    bf16* dx; bf16* dlin; DropoutCfg drop; float* partials; int rows, nblk, nrider;
+};
+template <int BM_, int BN_, int WGM, int WGN, bool AKM, bool BKM, bool RS>
+__global__ __launch_bounds__(512) void gemm_wide_grouped_ln_kernel(GroupArgs g, LnRider r, Probe pr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= g.total) {
+        const int rid = (int)blockIdx.x - g.total, half = (int)threadIdx.x >> 8;
+        float* red = reinterpret_cast<float*>(smem) + half * LN_BWD_RED_FLOATS(3);
+        const int per = 2 * r.nrider, iters = (r.nblk + per - 1) / per;
+        for (int k = 0; k < iters; ++k) {
+            const int blk = 2 * rid + half + k * per;
+            lnk::ln_bwd_h_block<3, false, 2, false>(r.dy, r.x, r.mean, r.rstd, r.gamma, r.dx, r.dlin, r.drop, r.partials, r.rows, DropoutCfg{0u, 0u, 1.f, nullptr},
+                                                    (int)threadIdx.x & 255, blk, r.nblk, blk < r.nblk, red);
+        }
+        return;
+    }
+    int bid = wide_xcd_remap(blockIdx.x, g.total);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXG; ++i) gi += (i < g.count && bid >= g.start[i]) ? 1 : 0;
+    const GroupProblem& P = g.p[gi];
+    bid -= g.start[gi];
+    int tile_m, tile_n;
+    wide_super_row(bid, P.tiles_m, P.tiles_n, tile_m, tile_n);
+    wide_tile<BM_, BN_, WGM, WGN, 3, false, 0, AKM, BKM, RS>(reinterpret_cast<const bf16*>(P.A), reinterpret_cast<const bf16*>(P.B), P.M, P.N, P.K, P.lda,
+                                                               P.ldb, tile_m, tile_n, P.epi, pr, smem);
+}
+
 // C[m][n] = beta * C[m][n] + sum_s slab[s][m][n]   (N % 4 == 0).  Behind the `splits` slabs the workspace holds
 // [splits][M] row-sum partials (bias gradient); the threads past the last float4 group sum those into rowsum[m].
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long n, int N, int M,
@@ -426,6 +463,22 @@ int launch_wide_grouped(const GroupArgs& g, hipStream_t s) {
     }
     g_last_kernel = "gemm_wide_grouped_kernel 256x128";
     hipLaunchKernelGGL((gemm_wide_grouped_kernel<BM_, BN_, WGM, WGN, AKM, BKM, RS>), dim3(g.total), dim3(512), lds_bytes, s, g, next_probe());
+    MMF_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool RS>
+int launch_wide_grouped_ln(const GroupArgs& g, const LnRider& r, hipStream_t s) {
+    constexpr int lds_bytes = 3 * (256 + 128) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_grouped_ln_kernel<256, 128, 4, 2, true, true, RS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (ae != hipSuccess) { mmf_amd_set_error(hipGetErrorString(ae)); return 2; }
+        attr_set = true;
+    }
+    g_last_kernel = "gemm_wide_grouped_ln_kernel 256x128";
+    hipLaunchKernelGGL((gemm_wide_grouped_ln_kernel<256, 128, 4, 2, true, true, RS>), dim3(g.total + r.nrider), dim3(512), lds_bytes, s, g, r, next_probe());
     MMF_CHECK_LAUNCH();
     return 0;
 }
@@ -796,7 +849,7 @@ extern "C" int mmf_gemm_skinny_splits(int M, int N, int K, int a_kmajor) {
 
 // Several GEMMs of ONE operand layout in one grid (see gemm_bf16_grouped_kernel).  Every problem runs without split-K and with its
 // own epilogue; `rowsum_out` is honoured (written directly).  debug_flags, splitk_ws are ignored.
-extern "C" int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream) {
+static int grouped_impl(const mmf_gemm_desc* descs, int count, const LnRider* rider, bool* rode, void* stream) {
     MMF_CHECK_ARG(descs && count >= 1 && count <= MAXG, "mmf_gemm_bf16_grouped: 1 .. 8 problems");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     GroupArgs g;
@@ -843,6 +896,12 @@ extern "C" int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void
             }
             for (int i = count; i <= MAXG; ++i) g.start[i] = t;
             g.total = t;
+            if (rider && t + 8 <= 256) {      // CUs left over by the tiles: the LayerNorm backward rides on them (gemm_wide_grouped_ln_kernel)
+                LnRider r = *rider;
+                r.nrider = 256 - t < (r.nblk + 1) / 2 ? 256 - t : (r.nblk + 1) / 2;
+                if (rode) *rode = true;
+                return rowsum ? launch_wide_grouped_ln<true>(g, r, s) : launch_wide_grouped_ln<false>(g, r, s);
+            }
             return rowsum ? launch_wide_grouped<256, 128, 4, 2, true, true, true>(g, s) : launch_wide_grouped<256, 128, 4, 2, true, true, false>(g, s);
         }
     }
@@ -856,6 +915,31 @@ extern "C" int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void
             mmf_amd_set_error("mmf_gemm_bf16_grouped: unsupported operand layout combination");
             return 1;
     }
+}
+
+extern "C" int mmf_gemm_bf16_grouped(const mmf_gemm_desc* descs, int count, void* stream) { return grouped_impl(descs, count, nullptr, nullptr, stream); }
+
+extern "C" __attribute__((visibility("hidden"))) int mmf_lnb_rider_blocks(int rows, int H);       // rowops.hip (library-internal)
+// The grouped launch above AND one deferred LayerNorm backward that does not depend on it (mmf_layernorm_bwd with dgamma = dbeta = dbias = NULL: column-sum
+// partials only).  Where the problems run on the wide tile and leave CUs idle (a VisualBERT layer's weight gradients: 216 tiles on 256 CUs) and the LayerNorm is
+// the H = 768 two-row form, it rides on the idle CUs of the SAME launch (gemm_wide_grouped_ln_kernel); otherwise the two are launched one after the other.
+// Same results either way, bit for bit.
+extern "C" int mmf_gemm_bf16_grouped_ln(const mmf_gemm_desc* descs, int count, const mmf_ln_bwd_desc* ln, void* stream) {
+    MMF_CHECK_ARG(ln && ln->dy && ln->x && ln->mean && ln->rstd && ln->gamma && ln->dx && ln->partials && ln->rows > 0, "mmf_gemm_bf16_grouped_ln: null LayerNorm operand");
+    MMF_CHECK_ARG(ln->drop_thr16 == 0 || ln->dlin, "mmf_gemm_bf16_grouped_ln: dropout needs dlin");
+    LnRider r;
+    const int nblk = mmf_lnb_rider_blocks(ln->rows, ln->H);
+    if (nblk > 0) {
+        r.dy = reinterpret_cast<const bf16*>(ln->dy); r.x = reinterpret_cast<const bf16*>(ln->x); r.mean = ln->mean; r.rstd = ln->rstd; r.gamma = ln->gamma;
+        r.dx = reinterpret_cast<bf16*>(ln->dx); r.dlin = reinterpret_cast<bf16*>(ln->dlin);
+        r.drop = DropoutCfg{ln->drop_key, ln->drop_thr16, ln->drop_scale, ln->drop_seed};
+        r.partials = ln->partials; r.rows = ln->rows; r.nblk = nblk; r.nrider = 0;
+    }
+    bool rode = false;
+    if (int rc = grouped_impl(descs, count, nblk > 0 ? &r : nullptr, &rode, stream)) return rc;
+    if (rode) return 0;
+    return mmf_layernorm_bwd(ln->dy, ln->x, ln->mean, ln->rstd, ln->gamma, ln->dx, ln->dlin, ln->drop_key, ln->drop_thr16, ln->drop_scale, ln->drop_seed,
+                             nullptr, nullptr, nullptr, 0, ln->partials, ln->rows, ln->H, stream);
 }
 
 // Development aid: while a probe buffer is set, every workgroup of every GEMM launch appends one 64-byte timeline record (see Probe).

@@ -43,6 +43,7 @@
 #include <cstring>
 #include <mutex>
 #include <optional>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -367,8 +368,26 @@ LinBwd linear_bwd(const Tensor& dy, int64_t ldy, const Tensor& x, const Tensor& 
 // ---- LayerNorm backward with deferred parameter-gradient reductions ---------------------------------------------------------------
 struct LnPending { Tensor ws; int rows, H; Tensor dgamma, dbeta; };
 bool g_ln_defer = false;
+bool g_wgrad_hold = true;             // A/B switch of the held weight gradients (_wgrad_hold_set)
 std::vector<LnPending> g_ln_pending;
+// A fused layer's grouped weight gradients held back until the NEXT LayerNorm backward of the same stream (inside a deferral block only: the caller owns the
+// whole backward and reads parameter gradients after `_ln_defer_flush`): that LayerNorm — the first kernel of the layer below, independent of the weight
+// gradients — rides on the CUs the gradient tiles leave idle (mmf_gemm_bf16_grouped_ln).  Anything else that ends the wait launches the group plainly.
+struct WgradHeld { mmf_gemm_desc g[4]; std::vector<Tensor> keep; void* stream; };
+std::vector<WgradHeld> g_wgrad_held;
+int64_t g_wgrad_joint = 0;                 // joint launches so far (tests read it through _wgrad_joint_launches)
+std::set<const void*> g_wgrad_seen;       // weights with a gradient produced in this deferral block (a layer applied twice is never held: autograd sums at once)
+void wgrad_release(void* stream, bool all) {
+    for (size_t i = 0; i < g_wgrad_held.size();) {
+        if (all || g_wgrad_held[i].stream == stream) {
+            MMF_RC(mmf_gemm_bf16_grouped(g_wgrad_held[i].g, 4, all ? sp() : stream), "mmf_gemm_bf16_grouped");
+            g_wgrad_held.erase(g_wgrad_held.begin() + i);
+        } else ++i;
+    }
+}
 void ln_flush() {
+    wgrad_release(nullptr, true);
+    g_wgrad_seen.clear();
     mmf_ln_reduce_list l;
     l.n = 0;
     auto go = [&]() { if (l.n) { MMF_RC(mmf_layernorm_bwd_reduce_multi(&l, sp()), "mmf_layernorm_bwd_reduce_multi"); l.n = 0; } };
@@ -390,9 +409,22 @@ LnBwd ln_bwd(const Tensor& dy, const Tensor& y, const Tensor& mean, const Tensor
     if (want_dbias) r.dbias = empty_f32({N}, y);
     Tensor ws = empty_f32({(int64_t)mmf_layernorm_bwd_ws_floats((int)N)}, y);
     const bool defer = g_ln_defer && !want_dbias && mmf_layernorm_bwd_deferrable((int)M, (int)N);
-    MMF_RC(mmf_layernorm_bwd(dy.data_ptr(), y.data_ptr(), PF(mean), PF(rstd), PF(gamma), r.dx.data_ptr(), P(dlin), drop.key, drop.thr16, drop.scale,
-                             drop.seed_ptr(), defer ? nullptr : r.dgamma.data_ptr<float>(), defer ? nullptr : r.dbeta.data_ptr<float>(),
-                             defer ? nullptr : (float*)P(r.dbias), 0, ws.data_ptr<float>(), (int)M, (int)N, sp()), "mmf_layernorm_bwd");
+    WgradHeld* held = nullptr;
+    for (auto& h : g_wgrad_held) if (h.stream == sp()) held = &h;
+    if (held && defer) {
+        mmf_ln_bwd_desc ld;
+        ld.dy = dy.data_ptr(); ld.x = y.data_ptr(); ld.mean = PF(mean); ld.rstd = PF(rstd); ld.gamma = PF(gamma); ld.dx = r.dx.data_ptr(); ld.dlin = P(dlin);
+        ld.drop_key = drop.key; ld.drop_thr16 = drop.thr16; ld.drop_scale = drop.scale; ld.drop_seed = drop.seed_ptr(); ld.partials = ws.data_ptr<float>();
+        ld.rows = (int)M; ld.H = (int)N;
+        MMF_RC(mmf_gemm_bf16_grouped_ln(held->g, 4, &ld, sp()), "mmf_gemm_bf16_grouped_ln");
+        ++g_wgrad_joint;
+        g_wgrad_held.erase(g_wgrad_held.begin() + (held - g_wgrad_held.data()));
+    } else {
+        if (held) wgrad_release(sp(), false);
+        MMF_RC(mmf_layernorm_bwd(dy.data_ptr(), y.data_ptr(), PF(mean), PF(rstd), PF(gamma), r.dx.data_ptr(), P(dlin), drop.key, drop.thr16, drop.scale,
+                                 drop.seed_ptr(), defer ? nullptr : r.dgamma.data_ptr<float>(), defer ? nullptr : r.dbeta.data_ptr<float>(),
+                                 defer ? nullptr : (float*)P(r.dbias), 0, ws.data_ptr<float>(), (int)M, (int)N, sp()), "mmf_layernorm_bwd");
+    }
     if (defer) g_ln_pending.push_back(LnPending{ws, (int)M, (int)N, r.dgamma, r.dbeta});
     r.dlin = dlin.defined() ? dlin : r.dx;
     return r;
@@ -533,7 +565,18 @@ struct TransformerLayerFn : public torch::autograd::Function<TransformerLayerFn>
         g[1] = Gemm(l2.dlin, hh, dw2, H, I, M, H, I, I).kmajor(true, true).rowsum(db2).d;
         g[2] = Gemm(dqkv, x2, dwqkv, 3 * H, H, M, 3 * H, H, H).kmajor(true, true).rowsum(dbqkv).d;
         g[3] = Gemm(l1.dlin, ctxt, dwo, H, H, M, H, H, H).kmajor(true, true).rowsum(dbo).d;
-        MMF_RC(mmf_gemm_bf16_grouped(g, 4, sp()), "mmf_gemm_bf16_grouped");
+        // inside a deferral block the launch waits for the next LayerNorm backward of this stream (WgradHeld); a layer applied twice launches at once
+        if (g_ln_defer && g_wgrad_hold && g_wgrad_seen.insert(wqkv16.data_ptr()).second) {
+            wgrad_release(sp(), false);
+            WgradHeld h;
+            std::memcpy(h.g, g, sizeof(g));
+            h.keep = {du, a_out, dw1, db1, l2.dlin, hh, dw2, db2, dqkv, x2, dwqkv, dbqkv, l1.dlin, ctxt, dwo, dbo};
+            h.stream = sp();
+            g_wgrad_held.push_back(std::move(h));
+        } else {
+            wgrad_release(sp(), false);
+            MMF_RC(mmf_gemm_bf16_grouped(g, 4, sp()), "mmf_gemm_bf16_grouped");
+        }
         variable_list out(31);
         if (dx.defined()) out[0] = dx.view({B, S, H});
         out[1] = dwqkv.narrow(0, 0, H); out[2] = dbqkv.narrow(0, 0, H); out[3] = dwqkv.narrow(0, H, H); out[4] = dbqkv.narrow(0, H, H);
@@ -1079,6 +1122,8 @@ void svc_adamw_step(at::TensorList p, at::TensorList g, at::TensorList m, at::Te
 }
 bool svc_ln_defer_set(bool on) { const bool old = g_ln_defer; g_ln_defer = on; return old; }
 void svc_ln_defer_flush() { ln_flush(); }
+int64_t svc_wgrad_joint_launches() { return g_wgrad_joint; }
+bool svc_wgrad_hold_set(bool on) { const bool old = g_wgrad_hold; g_wgrad_hold = on; return old; }
 int64_t svc_set_py_mode(int64_t mode) { const int64_t old = g_py_mode; g_py_mode = mode; return old; }
 
 }  // namespace
@@ -1131,6 +1176,8 @@ TORCH_LIBRARY(mmf_amd, m) {
     m.def("_drop_next() -> (int, Tensor[])");
     m.def("_ln_defer_set(bool on) -> bool");
     m.def("_ln_defer_flush() -> ()");
+    m.def("_wgrad_hold_set(bool on) -> bool");
+    m.def("_wgrad_joint_launches() -> int");
     m.def("_set_py_mode(int mode) -> int");
 }
 
@@ -1160,5 +1207,7 @@ TORCH_LIBRARY_IMPL(mmf_amd, CompositeImplicitAutograd, m) {
     m.impl("_drop_next", svc_drop_next);
     m.impl("_ln_defer_set", svc_ln_defer_set);
     m.impl("_ln_defer_flush", svc_ln_defer_flush);
+    m.impl("_wgrad_hold_set", svc_wgrad_hold_set);
+    m.impl("_wgrad_joint_launches", svc_wgrad_joint_launches);
     m.impl("_set_py_mode", svc_set_py_mode);
 }

@@ -147,6 +147,47 @@ def test_gemm_grouped_layer_weight_gradients(T):
             close(db, dy.float().sum(0), 1e-5, 1e-3 * math.sqrt(T) / 8, "grouped bias gradient")
 
 
+@pytest.mark.parametrize("T,H,p,rides", [(7296, 768, 0.1, True), (3648, 768, 0.0, True), (8704, 768, 0.1, True), (456, 768, 0.1, False), (4096, 1024, 0.1, False)])
+def test_layernorm_backward_rides_the_grouped_weight_gradients_bit_for_bit(T, H, p, rides):
+    """mmf_gemm_bf16_grouped_ln: a layer's four weight gradients and the deferred LayerNorm backward of the layer below in ONE launch (the LayerNorm on the CUs
+    the 216 gradient tiles leave idle) against the two launches one after the other: every output the same bits — dW, db, dx, the dropout-masked dlin, the
+    column-sum partials.  Shapes that do not ride (token count not 64-aligned: no wide tiles; H = 1024: not the rider's form) take the two launches inside
+    the entry point.  8704 rows: more than the LayerNorm's 512 blocks hold two rows each, so its row loop runs twice."""
+    I = 4 * H
+    du = rnd(T, I, seed=1); a_out = rnd(T, H, seed=2); dlin2 = rnd(T, H, seed=3); hh = rnd(T, I, seed=4)
+    dqkv = rnd(T, 3 * H, seed=5); x = rnd(T, H, seed=6); dlin1 = rnd(T, H, seed=7); ctxt = rnd(T, H, seed=8)
+    specs = [(du, a_out, I, H), (dlin2, hh, H, I), (dqkv, x, 3 * H, H), (dlin1, ctxt, H, H)]
+    dy = rnd(T, H, seed=9); y = rnd(T, H, seed=10)
+    mean = rnd(T, dtype=torch.float32, seed=11); rstd = rnd(T, dtype=torch.float32, seed=12).abs() + 0.5; gamma = rnd(H, dtype=torch.float32, seed=13)
+    drop = nat().drop_cfg(p, 4242, torch.tensor([7], dtype=torch.int32, device=DEV)) if p else nat().NO_DROP
+    res = []
+    for ride in (False, True):
+        probs = []
+        for a, b, N, K in specs:
+            probs.append(dict(A=a, B=b, C_out=torch.full((N, K), float("nan"), device=DEV), M=N, N=K, K=T, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True,
+                              rowsum_out=torch.full((N,), float("nan"), device=DEV)))
+        dx = torch.full((T, H), float("nan"), dtype=torch.bfloat16, device=DEV); dlin = torch.full_like(dx, float("nan")) if p else None
+        ws = torch.zeros(nat().layernorm_bwd_ws_floats(H), device=DEV)
+        if ride:
+            nat().gemm_grouped_ln(probs, dy, y, mean, rstd, gamma, dx, dlin, drop, ws, T, H)
+            assert ("grouped_ln" in nat().gemm_last_kernel()) == rides
+        else:
+            nat().gemm_grouped(probs)
+            nat().layernorm_bwd(dy, y, mean, rstd, gamma, dx, dlin, drop, None, None, None, 0, ws, T, H)
+        torch.cuda.synchronize()
+        res.append([q["C_out"] for q in probs] + [q["rowsum_out"] for q in probs] + [dx, ws] + ([dlin] if p else []))
+    for a, b in zip(*res):
+        assert not bool(torch.isnan(a.float()).any())
+        assert torch.equal(a, b)
+    # the partials reduce to the parameter gradients of the plain (non-deferred) backward
+    dg = torch.empty(H, device=DEV); db = torch.empty(H, device=DEV)
+    nat().layernorm_bwd_reduce_multi([(res[1][9], T, H, dg, db)])
+    dg0 = torch.empty(H, device=DEV); db0 = torch.empty(H, device=DEV); dx0 = torch.empty_like(res[1][8]); dl0 = torch.empty_like(dx0) if p else None
+    nat().layernorm_bwd(dy, y, mean, rstd, gamma, dx0, dl0, drop, dg0, db0, None, 0, torch.zeros_like(res[1][9]), T, H)
+    assert torch.equal(dx0, res[1][8])
+    close(dg, dg0, 1e-4, 1e-2, "dgamma from the rider's partials"); close(db, db0, 1e-4, 1e-2, "dbeta from the rider's partials")
+
+
 def test_gemm_grouped_forward_problems_keep_their_epilogues():
     """Grouping is layout-generic: two forward GEMMs of different shapes, each with its own bias / residual, in one launch;
     results are bit-identical to the separate launches (same tiles, same K order)."""

@@ -361,3 +361,42 @@ def test_training_step_is_bit_reproducible_from_run_to_run():
     for n in ma:
         assert torch.equal(ma[n], mb[n]), n
     assert float(ma["model.bert.embeddings.word_embeddings.weight"].abs().sum()) > 0
+
+
+def test_held_weight_gradients_with_the_layernorm_rider_change_no_bit_of_the_step():
+    """Inside the captured step a layer's grouped weight gradients wait for the first LayerNorm backward of the layer below, which then rides on the CUs the
+    gradient tiles leave idle (torch_ops.cpp WgradHeld, mmf_gemm_bf16_grouped_ln).  Three updates of a 3-layer, 768-wide model at 3648 token rows (B = 16) with
+    the hold on and off (`_wgrad_hold_set`): same losses, same bits in every parameter and first moment — and the held form really launches the rider."""
+    from mmf_amd.modules.optimizers import AdamW
+    from mmf_amd.utils.configuration import Config
+    from mmf_amd.utils.graph import GraphedTrainStep
+    cfg = dict(O.DEFAULT_CONFIG)
+    cfg["num_hidden_layers"] = 3
+    sd = O.init_state_dict(cfg, seed=3)
+    batch = SampleList(sample_to(O.synthetic_batch(cfg, 16, seed=4), "cuda"))
+    res = []
+    for hold in (False, True):
+        old = torch.ops.mmf_amd._wgrad_hold_set(hold)
+        try:
+            m = build_visual_bert(cfg, sd)
+            m.train()
+            o = AdamW(m.get_optimizer_parameters(Config(model="visual_bert", optimizer=dict(params=dict(lr=1e-3)), model_config=dict(visual_bert=m.config))),
+                      lr=1e-3, capturable=True)
+            joint0 = torch.ops.mmf_amd._wgrad_joint_launches()
+            g = GraphedTrainStep(m, batch, warmup=1, optimizer=o)
+            # two of the three layers have a layer below: warm-up pass + capture pass = 4 joint launches with the hold, none without
+            assert torch.ops.mmf_amd._wgrad_joint_launches() - joint0 == (4 if hold else 0)
+            losses = [float(g()) for _ in range(3)]
+            torch.cuda.synchronize()
+            res.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()},
+                        {n: o.state[p]["exp_avg"].clone() for n, p in m.named_parameters() if p in o.state and len(o.state[p])}))
+            del g
+        finally:
+            torch.ops.mmf_amd._wgrad_hold_set(old)
+    (la, pa, ma), (lb, pb, mb) = res
+    assert la == lb
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
+    for n in ma:
+        assert torch.equal(ma[n], mb[n]), n
+    assert float(ma["model.bert.encoder.layer.0.attention.self.query.weight"].abs().sum()) > 0

@@ -143,7 +143,7 @@ def test_every_ctypes_mirror_has_the_size_and_field_offsets_the_c_compiler_gives
     pairs = {"mmf_gemm_desc": _native.GemmDesc, "mmf_attn_desc": _native.AttnDesc, "mmf_attn_draw_site": _native.AttnDrawSite,
              "mmf_attn_bwd_desc": _native.AttnBwdDesc, "mmf_adamw_multi_desc": _native.AdamWMultiDesc, "mmf_wra_desc": _native.WraDesc,
              "mmf_ln_reduce_list": _native.LnReduceList, "mmf_tensor_list": _native.TensorList, "mmf_transpose_list": _native.TransposeList,
-             "mmf_offset_list": _native.OffsetList}
+             "mmf_offset_list": _native.OffsetList, "mmf_ln_bwd_desc": _native.LnBwdDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "mmf_amd.h"', 'int main(void) {']
     for cname, mirror in pairs.items():
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

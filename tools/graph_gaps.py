@@ -23,6 +23,10 @@ def run():
     from mmf_amd.utils.configuration import Config
     from mmf_amd.utils.graph import GraphedTrainStep
     dev = torch.device("cuda", 0)
+    for kv in os.environ.get("GRAPH_GAPS_TUN", "").split(","):      # "id:value,..." (include/mmf_amd.h MMF_TUN_*): A/B traces of one tunable
+        if kv:
+            from mmf_amd import _native as nat
+            nat.set_tunable(int(kv.split(":")[0]), int(kv.split(":")[1]))
     model = build(dev, 0)
     model.train()
     batch = synthetic_batch(32, 0, dev)

@@ -1440,7 +1440,8 @@ int mmf_layernorm_bwd_deferrable(int rows, int H) { return rows > 0 && lnb_h_pat
 // (library-internal, gemm.hip: the LayerNorm rider of the grouped weight-gradient launch) number of 256-thread blocks of the deferred backward of `rows` rows
 // when it is the H = 768 two-rows-in-flight half-wave form — the form the rider implements — else 0
 __attribute__((visibility("hidden"))) int mmf_lnb_rider_blocks(int rows, int H) {
-    if (H != 768 || rows <= 0 || !lnb_h_path(H, false) || (mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & (8 | 32))) return 0;
+    // (few token rows - MMBT at B = 8, 1824 rows - make the tiles' K-loops short and the joint launch measured 0.3 % slower than the two: 2048 rows and up ride)
+    if (H != 768 || rows < 2048 || !lnb_h_path(H, false) || (mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & (8 | 32))) return 0;
     const int grid = lnb_h_grid(rows);
     return rows > 8 * grid ? grid : 0;
 }

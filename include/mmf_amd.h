@@ -123,19 +123,9 @@ typedef struct mmf_gemm_desc {
                                  of nn.Linear, hf_layers.py:169-180) computed by the same launch with one extra MFMA per A
                                  fragment against a ones operand; with split-K it travels through the workspace (behind the
                                  slabs) and is summed by the slab reduction, else it is written directly */
-    /* LayerNorm of the output rows INSIDE the launch (dense -> dropout -> + residual -> LayerNorm of HF BertSelfOutput / BertOutput, mmf/modules/hf_layers.py:248,290,
-     * as one kernel): set all of ln_gamma, ln_beta [N], ln_out (bf16 [M, N]), ln_mean, ln_rstd ([M] fp32), ln_eps and ln_sync where mmf_gemm_ln_fusable(d) says 1 (else the
-     * call is refused).  C still receives the pre-LayerNorm rows (saved for the backward).  The tiles of a row panel meet at a counter in ln_sync; each then
-     * normalises its share of the panel's rows with the row code of mmf_layernorm_fwd (same bits).  ln_sync: MMF_GEMM_LN_SYNC_WORDS zeroed uint32, never reset by the
-     * caller, one buffer per stream that may run such launches concurrently. */
-    const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps; uint32_t* ln_sync;
     int debug_flags;          /* 0 in production.  bit 8: 4-wave workgroups, bit 9: never use 128x96 tiles, bit 12 / 13: force / forbid the K-split wave layout, bits 4-7: ablation switches, bit 17: never a wide (one workgroup per CU) tile; (bit 18 is the Python binding's: no skinny-path workspace) */
 } mmf_gemm_desc;
 int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream);
-/* 1 when mmf_gemm_bf16(d) would run as ONE round of one-tile-per-CU workgroups whose tiles cover whole output rows of a 768- or 1024-wide bf16 output (the forward
- * GEMMs ahead of the encoder's LayerNorms at 7296 token rows and below): the shape that can carry the LayerNorm (ln_* fields; they are ignored by this query). */
-#define MMF_GEMM_LN_SYNC_WORDS 2048
-int mmf_gemm_ln_fusable(const mmf_gemm_desc* d);
 /* Skinny problems (a row-major A of at most 64 rows and a long reduction: the classification heads of visual_bert.py:349-404 and their input
  * gradients): number of K-slices mmf_gemm_bf16 spreads over the chip when `splitk_ws` holds splits * M * round_up(N, 8) floats — ANY epilogue,
  * it runs on the slab sums in a second kernel.  Returns 1 when the problem is not skinny (no workspace needed). */

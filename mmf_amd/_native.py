@@ -36,9 +36,7 @@ class GemmDesc(C.Structure):
         ("resid", C.c_void_p), ("ldr", C.c_int),
         ("drop_key", C.c_uint32), ("drop_thr16", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", C.c_void_p),
         ("grp_in", C.c_int), ("grp_pad", C.c_int), ("grp_off", C.c_int),
-        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("rowsum_out", C.c_void_p),
-        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float),
-        ("ln_sync", C.c_void_p), ("debug_flags", C.c_int),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("rowsum_out", C.c_void_p), ("debug_flags", C.c_int),
     ]
 
 
@@ -188,7 +186,7 @@ def _drop4(drop):
 # --------------------------------------------------------------------------------------------
 def _gemm_desc(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
                rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
-               grp=(0, 0, 0), debug_flags=0, rowsum_out=None, d=None, ln=None):
+               grp=(0, 0, 0), debug_flags=0, rowsum_out=None, d=None):
     d = GemmDesc() if d is None else d
     d.debug_flags = int(debug_flags)
     d.A, d.B, d.C = _p(A), _p(B), _p(C_out)
@@ -217,23 +215,15 @@ def _gemm_desc(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=Fal
     if rowsum_out is not None:
         _req(rowsum_out, torch.float32, "rowsum_out")
         d.rowsum_out = _p(rowsum_out)
-    if ln is not None:      # (gamma, beta, out, mean, rstd, eps, sync): the LayerNorm of the output rows inside the launch (mmf_gemm_desc.ln_*)
-        gamma, beta_, out, mean, rstd, eps, sync = ln
-        _req(gamma, torch.float32, "ln gamma"); _req(beta_, torch.float32, "ln beta"); _req(out, torch.bfloat16, "ln out")
-        _req(mean, torch.float32, "ln mean"); _req(rstd, torch.float32, "ln rstd"); _req(sync, torch.int32, "ln sync")
-        if sync.numel() < GEMM_LN_SYNC_WORDS:
-            raise NativeLibraryError("ln sync buffer must hold %d int32 words" % GEMM_LN_SYNC_WORDS)
-        d.ln_gamma, d.ln_beta, d.ln_out, d.ln_mean, d.ln_rstd, d.ln_eps, d.ln_sync = _p(gamma), _p(beta_), _p(out), _p(mean), _p(rstd), float(eps), _p(sync)
     return d
 
 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, beta=0.0, bias=None, coladd=None,
          rowtab=None, rowidx=None, rowtab_ld=0, act=0, U=None, aux=None, resid=None, ldr=0, drop=NO_DROP,
-         grp=(0, 0, 0), debug_flags=0, rowsum_out=None, ln=None):
-    """`rowsum_out` (fp32 [M], weight-gradient form): also returns sum_k A[k][m], the bias gradient (with or without split-K).
-    `ln` = (gamma, beta, out, mean, rstd, eps, sync): LayerNorm of the output rows inside the launch, where `gemm_ln_fusable` says so."""
+         grp=(0, 0, 0), debug_flags=0, rowsum_out=None):
+    """`rowsum_out` (fp32 [M], weight-gradient form): also returns sum_k A[k][m], the bias gradient (with or without split-K)."""
     d = _gemm_desc(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, beta, bias, coladd, rowtab, rowidx, rowtab_ld, act, U,
-                   aux, resid, ldr, drop, grp, debug_flags, rowsum_out, ln=ln)
+                   aux, resid, ldr, drop, grp, debug_flags, rowsum_out)
     if d.out_f32 and a_kmajor and b_kmajor and bias is None and resid is None and act == 0:
         sp = lib().mmf_gemm_splitk_splits(M, N, K)
         if sp > 1:
@@ -249,14 +239,6 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, be
 
 GEMM_GROUP_MAX = 8
 GEMM_NO_SKINNY = 1 << 18     # mmf_gemm_desc.debug_flags: never the skinny split-K path (M <= 64, K >= 1536), whatever workspace is offered
-
-
-GEMM_LN_SYNC_WORDS = 2048      # include/mmf_amd.h MMF_GEMM_LN_SYNC_WORDS
-
-
-def gemm_ln_fusable(A, B, C_out, M, N, K, lda, ldb, ldc, **kw):
-    """True where `gemm(..., ln=...)` runs the LayerNorm of its output rows inside the launch (mmf_gemm_ln_fusable)."""
-    return bool(lib().mmf_gemm_ln_fusable(C.byref(_gemm_desc(A, B, C_out, M, N, K, lda, ldb, ldc, **kw))))
 
 
 def gemm_grouped(problems):

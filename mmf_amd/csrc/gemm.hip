@@ -731,7 +731,6 @@ static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     const int ntt = mmf_amd_get_tunable(MMF_TUN_EPI_NT);
     e.nt = ntt > 0 ? ntt - 1 : MMF_EPI_NT_DEFAULT;
     e.sc1 = 0;
-    e.ln.gamma = e.ln.beta = nullptr; e.ln.out = nullptr; e.ln.mean = e.ln.rstd = nullptr; e.ln.eps = 0.f; e.ln.sync = nullptr;
     // call-site exception (MMF_TUN_NT_SITE_KEEP, default 0 = none): the tagged call's bf16 output is read by the very next kernel
     const int site = (d->debug_flags >> 20) & 15;
     if (site != 0 && ((mmf_amd_get_tunable(MMF_TUN_NT_SITE_KEEP) >> site) & 1)) e.nt &= ~1;
@@ -742,39 +741,10 @@ static int check_and_fill(const mmf_gemm_desc* d, EpiArgs& e) {
     return 0;
 }
 
-// The launch that can carry the LayerNorm of its output rows (gemm_wide.h ln_panel_phase): row-major bf16 operands, a bf16 output whose rows are 768 or 1024 contiguous
-// columns, no split, and the dispatcher's pick a one-tile-per-workgroup kernel on 96- or 128-column tiles whose tiles all fit ONE round of the 256 CUs.
-static bool ln_fusable(const mmf_gemm_desc* d, const EpiArgs& e) {
-    if (d->a_kmajor || d->b_kmajor || d->a_f32 || d->b_f32 || d->out_f32 || d->ldc != d->N || (d->N != 768 && d->N != 1024) || d->grp_in != 0 || d->rowsum_out ||
-        (d->debug_flags & (0xF0 | 8 | 256 | 131072)) || (mmf_amd_get_tunable(MMF_TUN_ALT_FORMS) & 64))
-        return false;
-    if (mmf_gemm_skinny_splits(d->M, d->N, d->K, 0) > 1 || persist_choice(d, e) != 0) return false;
-    static const int BMs[7] = {0, 256, 192, 256, 128, 128, 192}, BNs[7] = {0, 96, 192, 128, 96, 128, 96};
-    const int wc = wide_choice(d);
-    if (wc == 0 || wc == 2) return false;
-    const long tiles_n = d->N / BNs[wc], tiles = (long)((d->M + BMs[wc] - 1) / BMs[wc]) * tiles_n;
-    return tiles_n <= 14 && tiles <= 256 && (d->M + BMs[wc] - 1) / BMs[wc] * 16 <= MMF_GEMM_LN_SYNC_WORDS;
-}
-
-extern "C" int mmf_gemm_ln_fusable(const mmf_gemm_desc* d) {
-    EpiArgs e;
-    mmf_gemm_desc q = *d;
-    q.ln_gamma = q.ln_beta = nullptr; q.ln_out = nullptr; q.ln_mean = q.ln_rstd = nullptr; q.ln_sync = nullptr;
-    if (check_and_fill(&q, e)) return 0;
-    return ln_fusable(&q, e) ? 1 : 0;
-}
-
 extern "C" int mmf_gemm_bf16(const mmf_gemm_desc* d, void* stream) {
     EpiArgs e;
     if (int rc = check_and_fill(d, e)) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d->ln_out) {
-        MMF_CHECK_ARG(d->ln_gamma && d->ln_beta && d->ln_mean && d->ln_rstd && d->ln_sync, "mmf_gemm_bf16: the fused LayerNorm needs gamma, beta, mean, rstd and the sync words");
-        MMF_CHECK_ARG(ln_fusable(d, e), "mmf_gemm_bf16: this launch cannot carry the LayerNorm (ask mmf_gemm_ln_fusable first)");
-        e.ln.gamma = d->ln_gamma; e.ln.beta = d->ln_beta; e.ln.out = reinterpret_cast<bf16*>(d->ln_out); e.ln.mean = d->ln_mean; e.ln.rstd = d->ln_rstd;
-        e.ln.eps = d->ln_eps; e.ln.sync = d->ln_sync;
-        e.nt &= ~1; e.sc1 |= 1;       // write-through: the rows must be visible to the panel's other tiles (other XCDs) before the ticket is taken
-    }
     if (g_probe.buf) { g_note[0] = (d->a_kmajor ? 1 : 0) | (d->b_kmajor ? 2 : 0); g_note[1] = d->M; g_note[2] = d->N; g_note[3] = d->K; }
     // Split-K: a weight-gradient GEMM has few output tiles (768x768 -> 36) and a long reduction (K = tokens).
     // With a workspace, the K range is spread over `splits` workgroups per tile; each writes an fp32 partial slab

@@ -34,8 +34,6 @@ struct EpiArgs {
     float* rowsum_direct;  // no split-K: the row sums go straight here ([M] fp32) instead of behind the slabs
     int nt;             // non-temporal stores: bit 0 the bf16 output C, bit 1 the saved gelu' (U), bit 2 fp32 outputs (MMF_TUN_EPI_NT)
     int sc1;            // write-through stores, same bits (the per-site rule: MMF_TUN_SC1_SITE)
-    // LayerNorm of the output rows behind the epilogue (one-round wide tiles only: gemm_wide.h ln_panel_phase); out == nullptr: off
-    struct { const float* gamma; const float* beta; bf16* out; float* mean; float* rstd; float eps; unsigned* sync; } ln;
 };
 
 // Timeline probe (development aid; off unless mmf_gemm_set_probe was called).  One record of 8 u64 per workgroup:

@@ -24,7 +24,6 @@
 //        its last LOAD.
 // The accumulators go through LDS (fp32, one wave-row group per pass) to the same row-wise fused epilogue as the 128-row kernel.
 #pragma once
-#include "ln_bwd_dev.h"
 #include "gemm_common.h"
 
 namespace gemm {
@@ -392,72 +391,6 @@ DEVI void wide_tile(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
     }
 }
 
-// ---- LayerNorm of the output rows behind the epilogue (round 6) -------------------------------------------------------------------------------------------
-// dense -> dropout -> + residual -> LayerNorm (HF BertSelfOutput / BertOutput) as ONE launch: the N = 768 GEMM's tiles_n column tiles of a 256-row panel each hold
-// a 96-column strip of every row, a row's statistics need all of them.  Every tile stores its strip of the pre-LayerNorm rows (C: the backward needs them anyway),
-// makes it visible device-wide and takes a ticket at the panel's counter; the panel's LAST arriver publishes the epoch; every tile that sees it normalises ITS share of
-// the panel's rows (BM / tiles_n rows; half a wave per row, lnk::ln_fwd_row: the code and the bits of ln_fwd_h_kernel) reading the rows back from L2.  Nothing waits
-// without a bound: a tile whose wait runs out (its siblings not resident: another stream holds the CUs) leaves, and the last arriver, which never waits, normalises
-// every share nobody claimed.  Counters only grow (ticket / tiles_n = the launch's epoch; launches of one stream are serial), so no launch resets anything:
-//   sync[panel * 16 + 0] tickets, + 1 published epoch, + 2 + s claim word of share s (epoch of the last launch that took it).
-// Saves the LayerNorm's launch (7.3 us inside the replayed graph for 22 MB) at the price of a fence, an atomic and ~1 us of L2-resident row work per tile.
-template <int BM_, int NC>
-DEVI void ln_panel_phase(const EpiArgs& epi, const int tile_m, const int tile_n, const int tiles_n, unsigned char* smem) {
-    const int tid = threadIdx.x;
-    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's strip stores have reached L2
-    __syncthreads();
-    unsigned long long st1 = 0, st2 = 0, st3 = 0;
-    volatile int* sh = reinterpret_cast<volatile int*>(smem);
-    unsigned* sy = epi.ln.sync + tile_m * 16;
-    if (tid == 0) {
-        st1 = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // ONE write-back of this XCD's L2 per tile (every wave fencing for itself cost 76 us per launch)
-        st2 = __builtin_amdgcn_s_memrealtime();
-        const unsigned t = __hip_atomic_fetch_add(sy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st3 = __builtin_amdgcn_s_memrealtime();
-        const unsigned e = t / (unsigned)tiles_n;
-        const bool last = t - e * (unsigned)tiles_n == (unsigned)tiles_n - 1u;
-        int ok = 1;
-        if (last) __hip_atomic_store(sy + 1, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-            while (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != e + 1u) {
-                __builtin_amdgcn_s_sleep(2);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000ull) { ok = 0; break; }      // 30 us: the siblings are not on the chip
-            }
-        }
-        sh[0] = (int)e; sh[1] = last ? 1 : 0; sh[2] = ok;
-        if (tile_n == 3) { sy[10] = (unsigned)(st1 - st0); sy[11] = (unsigned)(st2 - st1); sy[12] = (unsigned)(st3 - st2); sy[13] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st3); }
-    }
-    __syncthreads();
-    const unsigned e = (unsigned)sh[0];
-    const bool last = sh[1] != 0;
-    if (!sh[2]) return;
-    const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
-    // (no acquire fence: the siblings' strips are read with device-coherent loads, ln_fwd_row<NC, true>)
-    const unsigned long long st5 = __builtin_amdgcn_s_memrealtime();
-    constexpr int H = NC * 256;
-    const int share = (BM_ + tiles_n - 1) / tiles_n;
-    const int m_end = min(epi.M, (tile_m + 1) * BM_);
-    const DropoutCfg nodrop{0u, 0u, 1.f, nullptr};
-    for (int k = 0; k < (last ? tiles_n : 1); ++k) {
-        const int s = tile_n + k < tiles_n ? tile_n + k : tile_n + k - tiles_n;      // the own share first
-        __syncthreads();
-        if (tid == 0) sh[3] = atomicCAS(sy + 2 + s, e, e + 1u) == e ? 1 : 0;
-        __syncthreads();
-        if (!sh[3]) continue;
-        for (int r = tid >> 5; r < share; r += 16) {
-            const int row = tile_m * BM_ + s * share + r;
-            if (row < m_end && r + s * share < BM_)
-                lnk::ln_fwd_row<NC, true>(reinterpret_cast<const bf16*>(epi.C), epi.ln.gamma, epi.ln.beta, epi.ln.out, epi.ln.mean, epi.ln.rstd, row, epi.ln.eps, nodrop, tid & 31);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0 && tile_n == 3) { sy[14] = (unsigned)(st5 - st4); sy[15] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st5); }
-}
-
 // tile order: XCD-aware contiguous runs, 4-row super-rows (column-major inside) so an XCD's resident tiles share panels
 DEVI int wide_xcd_remap(int bid, int ntile) {
     const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, j = bid >> 3;
@@ -478,12 +411,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16* __restric
     int tile_m, tile_n;
     wide_super_row(wide_xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tile_m, tile_n);
     wide_tile<BM_, BN_, WGM, WGN, NS, RAGGED_M, ABL, AKM, BKM, RS>(A, B, M, N, K, lda, ldb, tile_m, tile_n, epi, pr, smem);
-    if constexpr (!AKM && !BKM && !RS && ABL == 0 && (BN_ == 96 || BN_ == 128)) {
-        if (epi.ln.out) {
-            if (N == 768) ln_panel_phase<BM_, 3>(epi, tile_m, tile_n, tiles_n, smem);
-            else ln_panel_phase<BM_, 4>(epi, tile_m, tile_n, tiles_n, smem);
-        }
-    }
 }
 
 }  // namespace gemm

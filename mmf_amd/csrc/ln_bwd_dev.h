@@ -1,4 +1,4 @@
-// mmf_amd :: the half-wave-per-row LayerNorm forward (one row: ln_fwd_row) and backward as device functions; the backward: the body of ln_bwd_h_kernel (rowops.hip) and of the LayerNorm RIDER of the grouped
+// mmf_amd :: the half-wave-per-row LayerNorm backward as a device function: the body of ln_bwd_h_kernel (rowops.hip) and of the LayerNorm RIDER of the grouped
 // weight-gradient launch (gemm.hip: gemm_wide_grouped_ln_kernel runs the next layer's first LayerNorm backward on the CUs its 216 tiles leave idle).
 #pragma once
 #include "common.h"
@@ -8,19 +8,6 @@ namespace lnk {
 typedef float f32x8r __attribute__((ext_vector_type(8)));
 DEVI f32x8r load8(const bf16* p) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-    f32x8r r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
-    return r;
-}
-// the same 8 values through loads that are coherent across the device (two 8-byte relaxed atomic loads, `sc1`): rows another XCD's tile has just written,
-// read without invalidating this XCD's L2 first (gemm_wide.h ln_panel_phase: the wholesale invalidate of an acquire fence cost 15 us per launch)
-DEVI f32x8r load8_coherent(const bf16* p) {
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-    unsigned long long w[2];
-    w[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    w[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bf16x8 v = __builtin_bit_cast(bf16x8, w);
     f32x8r r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
@@ -40,50 +27,6 @@ DEVI float half_sum(float v) {      // sum over the 32 lanes of this half-wave
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-
-// Forward of ONE row by half a wave (lane hl = 0..31 owns columns hl * 8 + 256 * c .. + 7): the body of ln_fwd_h_kernel (rowops.hip) and of the LayerNorm phase of the
-// one-round wide GEMM (gemm_wide.h ln_panel_phase) - one code, same bits.
-template <int NC, bool COHERENT = false>
-DEVI void ln_fwd_row(const bf16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ y, float* __restrict__ mean,
-                     float* __restrict__ rstd, const int row, const float eps, const DropoutCfg drop, const int hl) {
-    constexpr int H = NC * 256;
-    const bf16* xr = x + (size_t)row * H + hl * 8;
-    f32x8r v[NC];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        v[c] = COHERENT ? load8_coherent(xr + 256 * c) : load8(xr + 256 * c);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[c][i];
-    }
-    const float mu = half_sum(s) * (1.f / (float)H);
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mu; q += d * d; }
-    const float rs = rsqrtf(half_sum(q) * (1.f / (float)H) + eps);
-    bf16* yr = y + (size_t)row * H + hl * 8;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const f32x8r g = load8(gamma + hl * 8 + 256 * c), b = load8(beta + hl * 8 + 256 * c);
-        f32x8r o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * g[i] + b[i];
-        if (drop.thr16) {      // nn.Dropout on the LayerNorm output (embeddings.py:345), element index row * H + col like mmf_dropout_bf16: the value is
-                               // rounded to bf16 first, as the two-launch form stores it between its kernels
-            const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
-            const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale), s1 = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { o[i] = (float)(bf16)o[i] * s0[i]; o[i + 4] = (float)(bf16)o[i + 4] * s1[i]; }
-        }
-        store8(yr + 256 * c, o);
-    }
-    if (hl == 0) {
-        if (mean) mean[row] = mu;
-        if (rstd) rstd[row] = rs;
-    }
 }
 
 #define LN_BWD_RED_FLOATS(NC) (8 * ((NC) * 256 / 8 + 1) * 8)

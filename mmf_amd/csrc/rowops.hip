@@ -205,9 +205,46 @@ template <int NC>   // NC = H / 256
 __global__ __launch_bounds__(256) void ln_fwd_h_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps, DropoutCfg drop) {
+    constexpr int H = NC * 256;
+    const int hl = threadIdx.x & 31;
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (row >= rows) return;
-    lnk::ln_fwd_row<NC>(x, gamma, beta, y, mean, rstd, row, eps, drop, (int)threadIdx.x & 31);
+    const bf16* xr = x + (size_t)row * H + hl * 8;
+    f32x8r v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        v[c] = load8(xr + 256 * c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[c][i];
+    }
+    const float mu = half_sum(s) * (1.f / (float)H);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mu; q += d * d; }
+    const float rs = rsqrtf(half_sum(q) * (1.f / (float)H) + eps);
+    bf16* yr = y + (size_t)row * H + hl * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x8r g = load8(gamma + hl * 8 + 256 * c), b = load8(beta + hl * 8 + 256 * c);
+        f32x8r o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * g[i] + b[i];
+        if (drop.thr16) {      // nn.Dropout on the LayerNorm output (embeddings.py:345), element index row * H + col like mmf_dropout_bf16: the value is
+                               // rounded to bf16 first, as the two-launch form stores it between its kernels
+            const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
+            const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale), s1 = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i] = (float)(bf16)o[i] * s0[i]; o[i + 4] = (float)(bf16)o[i + 4] * s1[i]; }
+        }
+        store8(yr + 256 * c, o);
+    }
+    if (hl == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
 }
 
 // Backward: see ln_bwd_dev.h (ln_bwd_h_block): one 256-thread workgroup per block of 8 half-waves.

@@ -446,14 +446,6 @@ LnBwd ln_bwd_din(const Tensor& dy, const Tensor& y, const Tensor& mean, const Te
     return r;
 }
 
-// the counters of the LayerNorm phase inside a GEMM launch (mmf_gemm_desc.ln_sync): one zeroed buffer per stream, made at its first use and never reset
-bool g_ln_in_gemm = true;
-uint32_t* ln_sync_words() {
-    static std::unordered_map<void*, Tensor> bufs;
-    Tensor& t = bufs[sp()];
-    if (!t.defined()) t = at::zeros({MMF_GEMM_LN_SYNC_WORDS}, at::TensorOptions().dtype(at::kInt).device(c10::Device(c10::kCUDA, c10::hip::current_device())));
-    return reinterpret_cast<uint32_t*>(t.data_ptr<int32_t>());
-}
 // dense -> dropout -> (+ residual) -> LayerNorm   (HF BertSelfOutput / BertOutput)
 struct Ddrln { Tensor out, y, mean, rstd; };
 Ddrln ddrln_fwd(const Tensor& h2, const Tensor& resid2, const Tensor& w16, const Tensor& bias, const Tensor& gamma, const Tensor& beta, double eps,
@@ -461,17 +453,9 @@ Ddrln ddrln_fwd(const Tensor& h2, const Tensor& resid2, const Tensor& w16, const
     const int64_t M = h2.size(0), K = h2.size(1), N = w16.size(0);
     Ddrln r;
     r.y = empty_bf16({M, N}, h2);
+    Gemm(h2, w16, r.y, M, N, K, K, K, N).bias(bias).resid(resid2, N).drop(drop).site(site).run();
     r.out = empty_bf16({M, N}, h2); r.mean = empty_f32({M}, h2); r.rstd = empty_f32({M}, h2);
     req(gamma, at::kFloat, "LayerNorm.weight"); req(beta, at::kFloat, "LayerNorm.bias");
-    Gemm gm(h2, w16, r.y, M, N, K, K, K, N);
-    gm.bias(bias).resid(resid2, N).drop(drop).site(site);
-    if (g_ln_in_gemm && mmf_gemm_ln_fusable(&gm.d)) {      // the LayerNorm inside the GEMM launch (mmf_gemm_desc.ln_*): same bits, one launch fewer
-        gm.d.ln_gamma = PF(gamma); gm.d.ln_beta = PF(beta); gm.d.ln_out = r.out.data_ptr(); gm.d.ln_mean = r.mean.data_ptr<float>(); gm.d.ln_rstd = r.rstd.data_ptr<float>();
-        gm.d.ln_eps = (float)eps; gm.d.ln_sync = ln_sync_words();
-        gm.run();
-        return r;
-    }
-    gm.run();
     MMF_RC(mmf_layernorm_fwd(r.y.data_ptr(), PF(gamma), PF(beta), r.out.data_ptr(), r.mean.data_ptr<float>(), r.rstd.data_ptr<float>(), (int)M, (int)N,
                              (float)eps, sp()), "mmf_layernorm_fwd");
     return r;

@@ -60,6 +60,8 @@ OTHER_FAMILIES = [("attn_fwd8_kernel", "attention fwd | attn_fwd8_kernel"), ("at
 def variant(name):
     """The label bench.py's KernelProbe gives the launches of this kernel ("gemm <form> | <kernel family and tile>[ ksplit]
     [ (ragged / small)]"), so that profiles/pmc_traffic.json can be looked up with the bench line's dominant-kernel label."""
+    if "gemm_wide_grouped_ln_kernel" in name:
+        return "gemm TN grouped wgrad + LayerNorm bwd rider | gemm_wide_grouped_ln_kernel 256x128"
     if "gemm_wide_grouped_kernel" in name:
         return "gemm TN grouped wgrad | gemm_wide_grouped_kernel 256x128"
     if "gemm_bf16_grouped_kernel" in name:

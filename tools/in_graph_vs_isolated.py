@@ -46,6 +46,8 @@ print("\n## forward, layer 5                              in graph    isolated (
 for nm, k in zip(names_f, seq[i0:i0 + 7]):
     print("%-48s %7.1f us   %s   %s" % (nm, k[1], ("%7.1f us" % iso[nm]) if nm in iso else "      -   ", k[0]))
 names_b = ["layernorm bwd", "ffn2_dgrad", "ffn1_dgrad", "layernorm bwd", "out_dgrad", "attention bwd", "qkv_dgrad", "grouped weight gradients (4 GEMMs)"]
+if any("grouped_ln" in k[0] for k in seq):      # the first LayerNorm backward of a layer rides on the weight-gradient launch of the layer above (gemm_wide_grouped_ln_kernel)
+    names_b = ["weight gradients of the layer above + layernorm bwd"] + names_b[1:7] + ["weight gradients + layernorm bwd of the layer below"]
 idx = [i for i, k in enumerate(seq) if "attn_bwd_fused" in k[0]]
 i0 = idx[5] - 5
 print("\n## backward, one layer                           in graph    isolated (warm)   kernel")

@@ -35,6 +35,7 @@
 #include <ATen/ATen.h>
 #include <ATen/core/Generator.h>
 #include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
 
@@ -380,6 +381,14 @@ std::set<const void*> g_wgrad_seen;       // weights with a gradient produced in
 void wgrad_release(void* stream, bool all) {
     for (size_t i = 0; i < g_wgrad_held.size();) {
         if (all || g_wgrad_held[i].stream == stream) {
+            if (all && g_wgrad_held[i].stream != sp()) {
+                // another stream's group (ViLBERT's visual stream) ends the block on the caller's stream, after the autograd engine has joined the streams: its
+                // buffers belong to that stream's pool of the caching allocator, which must not hand them out again while this launch is pending
+                hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(reinterpret_cast<hipStream_t>(sp()), &st);
+                if (st == hipStreamCaptureStatusNone)
+                    for (auto& t : g_wgrad_held[i].keep) t.record_stream(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+            }
             MMF_RC(mmf_gemm_bf16_grouped(g_wgrad_held[i].g, 4, all ? sp() : stream), "mmf_gemm_bf16_grouped");
             g_wgrad_held.erase(g_wgrad_held.begin() + i);
         } else ++i;

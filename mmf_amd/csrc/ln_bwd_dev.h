@@ -13,6 +13,23 @@ DEVI f32x8r load8(const bf16* p) {
     for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
     return r;
 }
+// streaming forms (the LayerNorm rider of the weight-gradient launch: its rows pass the L2 the gradient tiles share their operand panels in)
+DEVI f32x8r load8_nt(const bf16* p) {
+    typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+    const u32x4r w = __builtin_nontemporal_load(reinterpret_cast<const u32x4r*>(p));
+    const bf16x8 v = __builtin_bit_cast(bf16x8, w);
+    f32x8r r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+    return r;
+}
+DEVI void store8_nt(bf16* p, f32x8r v) {
+    typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4r, t), reinterpret_cast<u32x4r*>(p));
+}
 DEVI f32x8r load8(const float* p) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     return f32x8r{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -34,7 +51,7 @@ DEVI float half_sum(float v) {      // sum over the 32 lanes of this half-wave
 // Backward: a workgroup of 4 waves = 8 half-waves; half-wave h owns rows blockIdx * 8 + h + 8 * gridDim * i (two rows each at the
 // VQA2 shape: 456 workgroups, two co-resident per CU so that one streams while the other reduces); all loads of a row are issued before anything is reduced.  Column-sum partials (dgamma, dbeta, optionally dbias) are combined across the
 // workgroup's 32 half-waves in LDS and written once per workgroup: partials[blk][q][H], q < NQ.
-template <int NC, bool DBIAS, int NR, bool DIN = false>      // DIN: dropout backward applied to dy as it is loaded (its own instantiation: the register budget of the hot form decides its occupancy)
+template <int NC, bool DBIAS, int NR, bool DIN = false, int STREAM = 0>      // STREAM: bit 0 non-temporal loads of dy / x (the rider, gemm.hip), bit 1 non-temporal stores of dx / dlin (measured: no gain).  DIN: dropout backward applied to dy as it is loaded (its own instantiation: the register budget of the hot form decides its occupancy)
 DEVI void ln_bwd_h_block(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                          const float* __restrict__ gamma, bf16* __restrict__ dx, bf16* __restrict__ dlin, DropoutCfg drop, float* __restrict__ partials,
                          int rows, DropoutCfg din, const int tid, const int blk, const int nblk, const bool active, float* __restrict__ red_) {
@@ -63,7 +80,10 @@ DEVI void ln_bwd_h_block(const bf16* __restrict__ dy, const bf16* __restrict__ x
             const int rowc = row < rows ? row : row0;          // (a missing second row re-reads the first; its results are dropped)
             const size_t off = (size_t)rowc * H + hl * 8;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { xv[r][c] = load8(x + off + 256 * c); dv[r][c] = load8(dy + off + 256 * c); }
+            for (int c = 0; c < NC; ++c) {
+                if constexpr (STREAM & 1) { xv[r][c] = load8_nt(x + off + 256 * c); dv[r][c] = load8_nt(dy + off + 256 * c); }
+                else { xv[r][c] = load8(x + off + 256 * c); dv[r][c] = load8(dy + off + 256 * c); }
+            }
             mu[r] = mean[rowc]; rs[r] = rstd[rowc];
         }
         if (DIN && din.thr16) {      // the LayerNorm's OUTPUT went through nn.Dropout in the forward (embeddings.py:345): dy = dropout_backward(incoming), element
@@ -109,14 +129,14 @@ DEVI void ln_bwd_h_block(const bf16* __restrict__ dy, const bf16* __restrict__ x
                     ag[c][i] += dv[r][c][i] * xv[r][c][i];
                     ab[c][i] += dv[r][c][i];
                 }
-                store8(dx + off + 256 * c, d);
+                if constexpr (STREAM & 2) store8_nt(dx + off + 256 * c, d); else store8(dx + off + 256 * c, d);
                 if (dlin) {
                     const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)(hl * 8 + 256 * c);
                     const f32x4 s0 = drop_scale4(drop_key(drop), idx, drop.thr16, drop.scale);
                     const f32x4 s1_ = drop_scale4(drop_key(drop), idx + 4, drop.thr16, drop.scale);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { d[i] *= s0[i]; d[i + 4] *= s1_[i]; }
-                    store8(dlin + off + 256 * c, d);
+                    if constexpr (STREAM & 2) store8_nt(dlin + off + 256 * c, d); else store8(dlin + off + 256 * c, d);
                 }
                 if (DBIAS) {     // the bias gradient uses the same rounding the weight-gradient GEMM will see
 #pragma unroll

@@ -2,7 +2,7 @@
 one workgroup per CU, 147 KB of LDS each) and the NEXT layer's first LayerNorm backward (independent of them, HBM-bound, 45 MB) launched on two HIP
 streams at once — the LayerNorm's small workgroups can only land on the 40 CUs the tiles leave free — against the two launched back to back.
 
-    python tools/rider_probe.py [rounds] [iters]"""
+    python tools/rider_probe.py [rounds] [iters] [layernorm rows]"""
 import os
 import statistics
 import sys
@@ -17,6 +17,7 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     T, H, I = 7296, 768, 3072
+    TL = int(sys.argv[3]) if len(sys.argv) > 3 else T       # rows of the LayerNorm (a multiple of T: how much streaming work the 40 idle CUs absorb before they outlast the tiles)
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(1)
     mk = lambda r, c: (torch.randn(r, c, device=dev, generator=g) * 0.5).bfloat16()
@@ -25,20 +26,20 @@ def main():
     for dy, x, N, K in specs:
         dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
         probs.append(dict(A=dy, B=x, C_out=dw, M=N, N=K, K=T, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True, rowsum_out=db))
-    dy, x = mk(T, H), mk(T, H)
-    mean = torch.zeros(T, device=dev); rstd = torch.ones(T, device=dev); gamma = torch.ones(H, device=dev)
+    dy, x = mk(TL, H), mk(TL, H)
+    mean = torch.zeros(TL, device=dev); rstd = torch.ones(TL, device=dev); gamma = torch.ones(H, device=dev)
     dx = torch.empty_like(x); dlin = torch.empty_like(x)
     ws = torch.zeros(nat.layernorm_bwd_ws_floats(H), device=dev)
     drop = nat.drop_cfg(0.1, 77, None)
 
     def ln():
-        nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, None, None, None, 0, ws, T, H)
+        nat.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dlin, drop, None, None, None, 0, ws, TL, H)
 
     def wg():
         nat.gemm_grouped(probs)
 
     def rider():
-        nat.gemm_grouped_ln(probs, dy, x, mean, rstd, gamma, dx, dlin, drop, ws, T, H)
+        nat.gemm_grouped_ln(probs, dy, x, mean, rstd, gamma, dx, dlin, drop, ws, TL, H)
 
     # same bits: the two launches one after the other against the one launch with the rider
     both = lambda: (wg(), ln())
